@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py — Jaccard edges/s (headline) and GF-ICF cells/s on MI355X.
+
+A "step" is one pass of the Jaccard hot path over one batch of synthetic input that is
+already resident in HBM: the column-major int32 kNN index block of this rank's cells
+(what `uwot:::find_nn(...)$idx[,-1]` hands to the reference, R/clustCells.R:63-65)
+  -> ingest (transpose / validate into the row-major table)
+  -> [N > 1: RCCL all-gather of the table rows over xGMI]
+  -> edge kernel -> this rank's rows of the reference's (N*k) x 3 double matrix.
+
+Workload (config.workload): the north-star point of BASELINE.json — 100 000 cells x k = 30
+per GPU ("windowed" synthetic kNN with realistic overlap, ids relabelled by a random
+permutation).  Weak scaling: every rank owns 100 000 cells, the data set has
+100 000 x n_gpus cells and every rank's edge kernel gathers from the full table.
+
+Launch: `python bench.py` (1 GPU) or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CELLS_PER_GPU = 100_000
+K = 30
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md "HBM3E peak BW")
+JACCARD_BYTES_PER_EDGE = 28      # 4 B index entry read once + 24 B reference output row
+GFICF_BYTES_PER_NNZ = 24         # 4 (count pass rowidx) + 12 (scale pass rowidx+x) + 8 (write x)  
+GFICF_G, GFICF_N = 23_000, 54_000  # BASELINE config 3 shape (Tabula-Muris-sized synthetic stand-in)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cells-per-gpu", type=int, default=CELLS_PER_GPU)
+    ap.add_argument("--k", type=int, default=K)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gficf", action="store_true")
+    ap.add_argument("--check", action="store_true", help="verify one step against the oracle (rank 0, N=1)")
+    return ap.parse_args()
+
+
+def time_kernel_ms(torch, fn, iters):
+    """Average duration of `fn`'s launches with HIP events on torch's current stream
+    (gficf_amd binds its context to that stream before every launch)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def synth_counts_device(torch, G, N, seed=7, median_frac=0.07, sigma=0.5, zipf_s=0.9):
+    """Device-side generator of the BASELINE-shaped synthetic CSC count matrix (same recipe as
+    gficf_amd.synth.counts_csc, torch RNG instead of splitmix64 so that ~1e8 draws take seconds)."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    n_draw = torch.clamp(torch.round(median_frac * G * torch.exp(sigma * torch.randn(N, generator=g, device="cuda", dtype=torch.float64))), 1, G).long()
+    pop = 1.0 / torch.arange(1, G + 1, device="cuda", dtype=torch.float64).pow(zipf_s)
+    cdf = torch.cumsum(pop, 0)
+    cdf = cdf / cdf[-1]
+    cell_of = torch.repeat_interleave(torch.arange(N, device="cuda"), n_draw)
+    gene = torch.searchsorted(cdf, torch.rand(cell_of.numel(), generator=g, device="cuda", dtype=torch.float64)).clamp_(max=G - 1)
+    key = torch.unique(cell_of * G + gene)          # sorted by (cell, gene), de-duplicated
+    del cell_of, gene
+    col = torch.div(key, G, rounding_mode="floor")
+    rowidx = (key - col * G).to(torch.int32)
+    colptr = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
+    colptr[1:] = torch.cumsum(torch.bincount(col, minlength=N), 0)
+    x = 1.0 + torch.floor(-torch.log2(1.0 - torch.rand(key.numel(), generator=g, device="cuda", dtype=torch.float64)))
+    return colptr, rowidx, x
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import gficf_amd
+    from gficf_amd import synth
+    from gficf_amd.dist import JaccardShard, shard_bounds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (gficf_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    k = args.k
+    N_total = args.cells_per_gpu * world
+    ops = gficf_amd.HipOps(local_rank)
+
+    # ---- synthetic input, resident in HBM before the timed region
+    mat = synth.knn_windowed(N_total, k)                       # N_total x k, 1-based ids (same on every rank)
+    b, e = shard_bounds(N_total, world, rank)
+    idx_local = torch.from_numpy(np.ascontiguousarray(mat[b:e].T)).to(dev)   # (k, n_local) == column-major block
+    shard = JaccardShard(ops, N_total, k, device=dev, with_u=False)
+
+    def step():
+        shard.step(idx_local)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.sync()                                                  # surfaces deferred validation errors
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    edges_per_step = N_total * k
+    value = edges_per_step * args.steps / dt
+
+    # ---- roofline of the dominant kernel (k_jaccard_edges), HIP events on the launch stream
+    n_local = e - b
+    t_edges_ms = time_kernel_ms(torch, lambda: ops.jaccard_edges(shard.table, N_total, k, b, e, shard.out, None), max(args.steps, 20))
+    t_ingest_ms = time_kernel_ms(torch, lambda: ops.jaccard_ingest(idx_local, n_local, k, N_total, shard.table[rank * shard.rpr:(rank + 1) * shard.rpr]), max(args.steps, 20))
+    achieved = JACCARD_BYTES_PER_EDGE * n_local * k / (t_edges_ms * 1e-3) / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            pj = json.load(open(prof))
+            ent = pj.get(f"jaccard_edges_N{N_total}_k{k}")
+            if ent:
+                traffic = ent["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_jaccard_edges", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel_ms": round(t_edges_ms, 5), "ingest_kernel_ms": round(t_ingest_ms, 5),
+                "algorithmic_bytes_per_launch": JACCARD_BYTES_PER_EDGE * n_local * k}
+
+    out = {
+        "metric": "jaccard_edges_per_sec", "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int32 ids -> f64 edge rows", "data": "synthetic",
+        "config": {"workload": f"north-star point: {args.cells_per_gpu} cells x k={k} per GPU, windowed kNN (W=100) with permuted ids; "
+                               f"N_total={N_total}; step = ingest + {'RCCL all-gather + ' if world > 1 else ''}edge kernel, device-resident",
+                   "cells_total": N_total, "k": k, "edges_per_step": edges_per_step,
+                   "partition": f"cell blocks x{world}" + (", 1 all-gather of int32 table rows" if world > 1 else "")},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1:
+        if args.check or True:
+            # one step against the oracle on a bounded sample of source cells (checker only)
+            import oracle
+
+            rm = shard.out.cpu().numpy().T
+            want, _ = oracle.jaccard(mat, nthreads=os.cpu_count() or 1) if N_total <= 200_000 else (None, None)
+            out["checked_vs_oracle"] = bool(want is not None and np.array_equal(rm, want))
+        if not args.no_cpu_baseline:
+            import oracle
+
+            cores = os.cpu_count() or 1
+            mf = np.asfortranarray(mat.astype(np.float64))
+            rmh = np.empty((3, N_total * k))
+            uh = np.empty(N_total * k, dtype=np.int32)
+            L = oracle.lib()
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                L.oracle_jaccard_f64(mf.ctypes.data, N_total, k, rmh.ctypes.data, uh.ctypes.data, cores)
+                ts.append(time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            L.oracle_jaccard_f64(mf.ctypes.data, N_total, k, rmh.ctypes.data, uh.ctypes.data, 2)
+            t_nt2 = time.perf_counter() - t1
+            cpu_v = edges_per_step / statistics.median(ts)
+            out["cpu_baseline"] = {"value": cpu_v, "unit": "edges/s", "cores": cores, "kind": "port",
+                                   "sample": f"the full workload ({N_total} cells x k={k}, same input), median of 3 passes of the oracle's "
+                                             "faithful restatement of the RcppParallel worker (g++ -O2, dynamic chunks over std::thread)",
+                                   "nt2_value": edges_per_step / t_nt2, "nt2_note": "clustcells() default nt = 2 (reference R/clustCells.R:46)",
+                                   "gpu_over_cpu": value / cpu_v}
+        if not args.no_gficf:
+            G, Nc = GFICF_G, GFICF_N
+            colptr, rowidx, x = synth_counts_device(torch, G, Nc)
+            nnz = int(rowidx.numel())
+            ws = ops.csc_workspace(G, Nc, nnz)
+            run = lambda: ops.gficf_csc(G, Nc, colptr, rowidx, x, 0.05, 1.0, None, ws)
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            reps = 10
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                run()
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - t1) / reps
+            ops.sync()
+            t_scale = time_kernel_ms(torch, lambda: ops.csc_scale(G, Nc, colptr, rowidx, x, ws["remap"], ws["w"], ws["out_colptr"], ws["out_rowidx"], ws["out_x"]), 10)
+            t_count = time_kernel_ms(torch, lambda: ops.csc_count(G, Nc, colptr, rowidx, x, ws["nt"]), 10)
+            gf = {"metric": "gficf_cells_per_sec", "value": Nc / tg, "unit": "cells/s", "ms_per_pass": tg * 1e3,
+                  "config": {"workload": f"BASELINE config 3 shape: {G} genes x {Nc} cells synthetic UMI CSC (nnz={nnz}), "
+                                         "gene filter 5 % + GF + ICF + L2, device-resident, compacted output"},
+                  "nnz": nnz, "kept_nnz": int(ws["out_colptr"][Nc]), "kept_genes": int(ws["gkept"][0]), "dtype": "f64",
+                  "roofline": {"bound": "hbm", "kernel": "whole pass (count + colptr + scale)",
+                               "achieved": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                               "scale_kernel_ms": round(t_scale, 4), "count_kernel_ms": round(t_count, 4)}}
+            out["gficf"] = gf
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,20 @@
+"""gficf_amd — MI355X (gfx950) GF-ICF normalisation and Phenograph kNN -> Jaccard edge build.
+
+Drop-in for one hot path of the dibbelab/gficf R package: ``gficf()`` (sparse GF / ICF /
+L2 scaling of a CSC genes x cells matrix) and the Jaccard step of ``clustcells()``
+(``rcpp_parallel_jaccard_coef``).  All compute runs in hand-written HIP kernels behind the C
+ABI of ``libgficf_hip.so`` (include/gficf_hip.h); there is no CPU fallback.
+"""
+from ._lib import GficfError, LIB_PATH  # noqa: F401
+from .api import (  # noqa: F401
+    Context,
+    HipOps,
+    default_context,
+    device_count,
+    gficf,
+    gficf_with_weights,
+    jaccard_edges,
+    rcpp_parallel_jaccard_coef,
+)
+
+__version__ = "0.1.0"

@@ -1,0 +1,85 @@
+"""ctypes binding of libgficf_hip.so (the C ABI declared in include/gficf_hip.h).
+
+The library is built in-tree by ``gficf_amd.build.build_extension()`` (hipcc, gfx950) and
+lives next to this file.  There is no CPU fallback: if the library is missing or no GPU
+is visible, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgficf_hip.so")
+
+GFICF_OK = 0
+STATUS_NAMES = {
+    0: "GFICF_OK", 1: "GFICF_ERR_INVALID_ARG", 2: "GFICF_ERR_BAD_ID", 3: "GFICF_ERR_BAD_CSC",
+    4: "GFICF_ERR_NO_DEVICE", 5: "GFICF_ERR_HIP", 6: "GFICF_ERR_UNSUPPORTED", 7: "GFICF_ERR_CAPACITY",
+}
+JACCARD_MAX_K = 256
+
+
+class GficfError(RuntimeError):
+    """A libgficf_hip call returned a non-zero gficf_status."""
+
+    def __init__(self, code: int, message: str):
+        self.code = code
+        self.status = STATUS_NAMES.get(code, str(code))
+        super().__init__(f"{self.status}: {message}")
+
+
+_i64, _int, _dbl, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol include/gficf_hip.h declares
+SIGNATURES = {
+    "gficf_hip_abi_version": (_int, []),
+    "gficf_device_count": (_int, [ctypes.POINTER(_int)]),
+    "gficf_ctx_create": (_int, [_int, _vp, ctypes.POINTER(_vp)]),
+    "gficf_ctx_destroy": (None, [_vp]),
+    "gficf_ctx_set_stream": (_int, [_vp, _vp]),
+    "gficf_ctx_sync": (_int, [_vp]),
+    "gficf_last_error": (ctypes.c_char_p, []),
+    "gficf_jaccard_host": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _int]),
+    "gficf_jaccard_kpad": (_int, [_int]),
+    "gficf_jaccard_ingest_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _i64, _vp]),
+    "gficf_jaccard_edges_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gficf_jaccard_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _vp, _vp]),
+    "gficf_normalize_csc_host_plan": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _dbl, _dbl, _vp,
+                                             ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "gficf_normalize_csc_host_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_csc_count_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "gficf_csc_genes_device": (_int, [_vp, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_csc_colptr_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_csc_scale_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_csc_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libgficf_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C gficf_amd/csrc` (hipcc, --offload-arch=gfx950). gficf_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI and this table diverge
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return (load().gficf_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != GFICF_OK:
+        raise GficfError(rc, last_error())

@@ -1,0 +1,318 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Two layers over the C ABI (include/gficf_hip.h):
+
+* reference-shaped functions on host data, same names / argument meaning / error
+  behaviour as the R package, so that parity tests read like the reference's own calls:
+    - ``rcpp_parallel_jaccard_coef(mat, printOutput)``   reference R/RcppExports.R:16-18
+    - ``jaccard_edges(neigh, verbose)``                  reference R/clustCells.R:63-68
+    - ``gficf(M, cell_proportion_max, cell_proportion_min, storeRaw, normalize, verbose)``
+                                                         reference R/gficf.R:17-33
+    - ``gficf_with_weights(M, w)``                       reference R/cellClassifier.R:50-53
+* ``HipOps``: the device-resident pipeline stages on torch CUDA tensors (torch is only
+  the owner of device memory / streams here), used by the bench and the multi-GPU path.
+
+All compute happens in libgficf_hip.so; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import GficfError, check
+
+
+# ---------------------------------------------------------------------------- context
+class Context:
+    """One libgficf_hip context (device + stream + workspace)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = ctypes.c_void_p()
+        check(_lib.load().gficf_ctx_create(int(device), ctypes.c_void_p(stream or 0), ctypes.byref(self._h)))
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("context is closed")
+        return self._h
+
+    def set_stream(self, stream: int | None):
+        check(_lib.load().gficf_ctx_set_stream(self.handle, ctypes.c_void_p(stream or 0)))
+
+    def sync(self):
+        """Wait for the stream; raises GficfError for deferred input-validation failures."""
+        check(_lib.load().gficf_ctx_sync(self.handle))
+
+    def close(self):
+        if self._h:
+            _lib.load().gficf_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    rc = _lib.load().gficf_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ------------------------------------------------------------- Jaccard, reference-shaped
+def rcpp_parallel_jaccard_coef(mat, printOutput: bool = False, ctx: Context | None = None) -> np.ndarray:
+    """Drop-in for the reference's ``rcpp_parallel_jaccard_coef(mat, printOutput)``.
+
+    ``mat``: N x k matrix of 1-based neighbour ids (integer or float64, as R hands it over:
+    reference R/clustCells.R:63-65).  Returns the (N*k) x 3 float64 matrix (Fortran order,
+    like an R matrix) whose row i*k+j is (i+1, mat[i,j], u/(2k-u)) or zeros when the two
+    neighbour sets do not intersect (reference src/rcpp_parallel_jaccard_coeff.cpp:48-52,67).
+    """
+    mat = np.asarray(mat)
+    if mat.ndim != 2:
+        raise ValueError("mat must be a 2-d matrix")
+    N, k = mat.shape
+    if np.issubdtype(mat.dtype, np.integer):
+        m = np.asfortranarray(mat, dtype=np.int32)
+        is_f64 = 0
+    else:
+        m = np.asfortranarray(mat, dtype=np.float64)
+        is_f64 = 1
+    E = N * k
+    rm = np.zeros((3, E), dtype=np.float64)  # C-order (3, E) == column-major (E, 3)
+    ctx = ctx or default_context()
+    check(_lib.load().gficf_jaccard_host(ctx.handle, _np_ptr(m), is_f64, N, k, max(N, 1), _np_ptr(rm),
+                                         1 if printOutput else 0))
+    return rm.T
+
+
+def jaccard_edges(neigh, verbose: bool = False, ctx: Context | None = None):
+    """The Jaccard call-site of ``clustcells()`` (reference R/clustCells.R:63-68).
+
+    ``neigh``: N x (k+1) kNN index matrix whose first column is the cell itself
+    (``uwot:::find_nn(..., include_self = TRUE)$idx``).  Drops column 1, builds the Jaccard
+    edges and keeps the rows with weight > 0, in order.  Returns a dict with float64
+    arrays ``from``, ``to``, ``weight`` (the columns of the reference's data.frame).
+    """
+    neigh = np.asarray(neigh)
+    rel = rcpp_parallel_jaccard_coef(neigh[:, 1:], verbose, ctx=ctx)   # :63, :65
+    rel = rel[rel[:, 2] > 0, :]                                        # :66
+    return {"from": rel[:, 0].copy(), "to": rel[:, 1].copy(), "weight": rel[:, 2].copy()}  # :67-68
+
+
+# -------------------------------------------------------------- GF-ICF, reference-shaped
+def _csc_parts(M):
+    import scipy.sparse as sp
+
+    if not sp.isspmatrix_csc(M):
+        M = sp.csc_matrix(M)
+    if not M.has_sorted_indices:
+        M = M.copy()
+        M.sort_indices()
+    colptr = np.ascontiguousarray(M.indptr)
+    if colptr.dtype not in (np.int32, np.int64):
+        colptr = colptr.astype(np.int64)
+    rowidx = np.ascontiguousarray(M.indices, dtype=np.int32)
+    x = np.ascontiguousarray(M.data, dtype=np.float64)
+    return M, colptr, rowidx, x
+
+
+def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx):
+    import scipy.sparse as sp
+
+    M, colptr, rowidx, x = _csc_parts(M)
+    G, N = M.shape
+    L = _lib.load()
+    ctx = ctx or default_context()
+    gk, nk = ctypes.c_int64(0), ctypes.c_int64(0)
+    if w_in is not None:
+        w_in = np.ascontiguousarray(w_in, dtype=np.float64)
+        if w_in.shape != (G,):
+            raise ValueError("w must have one weight per gene (row) of M")
+    is64 = 1 if colptr.dtype == np.int64 else 0
+    check(L.gficf_normalize_csc_host_plan(ctx.handle, G, N, _np_ptr(colptr), is64, _np_ptr(rowidx), _np_ptr(x),
+                                          float(prop_min), float(prop_max), _np_ptr(w_in),
+                                          ctypes.byref(gk), ctypes.byref(nk)))
+    keep = np.zeros(G, dtype=np.uint8)
+    nt = np.zeros(G, dtype=np.int64)
+    w = np.zeros(G, dtype=np.float64)
+    ocp = np.zeros(N + 1, dtype=colptr.dtype)
+    ori = np.zeros(nk.value, dtype=np.int32)
+    ox = np.zeros(nk.value, dtype=np.float64)
+    check(L.gficf_normalize_csc_host_finish(ctx.handle, _np_ptr(keep), _np_ptr(nt), _np_ptr(w), _np_ptr(ocp),
+                                            _np_ptr(ori), _np_ptr(ox)))
+    keep = keep.astype(bool)
+    out = sp.csc_matrix((ox, ori, ocp), shape=(gk.value, N))
+    return M, keep, nt, w, out
+
+
+def gficf(M, cell_proportion_max: float = 1, cell_proportion_min: float = 0.05, storeRaw: bool = True,
+          normalize: bool = True, verbose: bool = True, ctx: Context | None = None) -> dict:
+    """Drop-in for the reference's ``gficf()`` (reference R/gficf.R:17-33).
+
+    ``M``: genes x cells sparse count matrix (scipy CSC — the dgCMatrix analogue).
+    Returns the "gficf object" as a dict: ``gficf`` (CSC over the kept genes), ``rawCounts``
+    (when ``storeRaw``), ``w`` (ICF weight per kept gene), ``param``; plus ``genes`` (indices
+    of the kept genes in M, standing in for R's rownames) and ``nt``.
+
+    ``normalize=TRUE`` in the reference rescales counts with edgeR TMM/CPM
+    (R/gficf.R:43-47) before GF; that is a per-cell scale which cancels in x/colSums(x),
+    so ``gficf`` is unaffected; ``rawCounts`` here always holds the unscaled filtered counts.
+    """
+    if verbose and normalize:
+        warnings.warn("normalize=True: the edgeR CPM/TMM rescale (reference R/gficf.R:43-47) is a per-cell scale "
+                      "that cancels in the GF step; rawCounts holds unscaled counts", stacklevel=2)
+    M, keep, nt, w, out = _normalize_csc_host(M, cell_proportion_min, cell_proportion_max, None, ctx)
+    data = {"gficf": out}
+    if storeRaw:
+        data["rawCounts"] = M[np.flatnonzero(keep), :]
+    data["w"] = w[keep]
+    data["genes"] = np.flatnonzero(keep)
+    data["nt"] = nt[keep]
+    data["param"] = {"cell_proportion_max": cell_proportion_max, "cell_proportion_min": cell_proportion_min,
+                     "normalized": normalize}
+    return data
+
+
+def gficf_with_weights(M, w, ctx: Context | None = None):
+    """GF -> ICF (weights supplied) -> L2 for new cells (reference R/cellClassifier.R:50-53).
+
+    ``w``: one ICF weight per gene (row) of ``M`` (the R code matches by gene name,
+    R/gficf.R:69-78; that name handling stays with the caller).  As in the reference call
+    ``normCounts(..., max = 2, min = 0)``, genes absent from every new cell are dropped.
+    Returns (gficf CSC over kept genes, kept gene indices).
+    """
+    _, keep, _, _, out = _normalize_csc_host(M, 0.0, 2.0, w, ctx)
+    return out, np.flatnonzero(keep)
+
+
+# ----------------------------------------------------------- device-resident stage ops
+def _tptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("expected a CUDA (HIP) tensor")
+    if not t.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class HipOps:
+    """Pipeline stages of the hot path on device-resident torch tensors.
+
+    Work is enqueued on torch's current stream of the context's device; nothing
+    synchronises except :meth:`sync`.
+    """
+
+    def __init__(self, device: int = 0):
+        import torch
+
+        self.torch = torch
+        self.device = int(device)
+        self.ctx = Context(self.device)
+        self.L = _lib.load()
+
+    def _bind(self):
+        self.ctx.set_stream(self.torch.cuda.current_stream(self.device).cuda_stream)
+        return self.ctx.handle
+
+    def sync(self):
+        self._bind()
+        self.ctx.sync()
+
+    # -- Jaccard
+    @staticmethod
+    def kpad(k: int) -> int:
+        kp = _lib.load().gficf_jaccard_kpad(int(k))
+        if kp < 0:
+            raise GficfError(6, f"k = {k} outside [0, {_lib.JACCARD_MAX_K}]")
+        return kp
+
+    def jaccard_ingest(self, idx_cm, n_rows: int, k: int, N_total: int, table_rows):
+        """idx_cm: (k, ld) int32/float64 tensor == column-major n_rows x k.  table_rows: (n_rows, kpad) int32."""
+        tc = self.torch
+        is_f64 = 1 if idx_cm.dtype == tc.float64 else 0
+        if not is_f64 and idx_cm.dtype != tc.int32:
+            raise ValueError("idx must be int32 or float64")
+        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else n_rows
+        check(self.L.gficf_jaccard_ingest_device(self._bind(), _tptr(idx_cm), is_f64, n_rows, k, ld, N_total,
+                                                 _tptr(table_rows)))
+
+    def jaccard_edges(self, table, N: int, k: int, cell_begin: int, cell_end: int, out3, u=None):
+        """table: (N, kpad) int32.  out3: (3, (cell_end-cell_begin)*k) float64 — src, dst, weight rows."""
+        n = (cell_end - cell_begin) * k
+        if out3.shape != (3, n) or out3.dtype != self.torch.float64:
+            raise ValueError(f"out3 must be float64 of shape (3, {n})")
+        base = out3.data_ptr()
+        check(self.L.gficf_jaccard_edges_device(self._bind(), _tptr(table), N, k, cell_begin, cell_end,
+                                                ctypes.c_void_p(base), ctypes.c_void_p(base + 8 * n),
+                                                ctypes.c_void_p(base + 16 * n), _tptr(u)))
+
+    def jaccard(self, idx_cm, N: int, k: int, table_ws, rmat3, u=None):
+        """Single-GPU ingest + edges.  rmat3: (3, N*k) float64 == the (N*k) x 3 R matrix."""
+        tc = self.torch
+        is_f64 = 1 if idx_cm.dtype == tc.float64 else 0
+        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else N
+        check(self.L.gficf_jaccard_device(self._bind(), _tptr(idx_cm), is_f64, N, k, ld, _tptr(table_ws),
+                                          _tptr(rmat3), _tptr(u)))
+
+    # -- GF-ICF
+    def csc_count(self, G, n_cells, colptr, rowidx, x, nt):
+        check(self.L.gficf_csc_count_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),
+                                            int(rowidx.numel()), _tptr(nt)))
+
+    def csc_genes(self, G, N_total, nt, prop_min, prop_max, w_in, keep, remap, w, gkept):
+        check(self.L.gficf_csc_genes_device(self._bind(), G, N_total, _tptr(nt), float(prop_min), float(prop_max),
+                                            _tptr(w_in), _tptr(keep), _tptr(remap), _tptr(w), _tptr(gkept)))
+
+    def csc_colptr(self, G, n_cells, colptr, rowidx, keep, gkept, out_colptr):
+        check(self.L.gficf_csc_colptr_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(keep),
+                                             _tptr(gkept), _tptr(out_colptr)))
+
+    def csc_scale(self, G, n_cells, colptr, rowidx, x, remap, w, out_colptr, out_rowidx, out_x):
+        check(self.L.gficf_csc_scale_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),
+                                            int(rowidx.numel()), _tptr(remap), _tptr(w), _tptr(out_colptr),
+                                            _tptr(out_rowidx), _tptr(out_x)))
+
+    def csc_workspace(self, G: int, n_cells: int, nnz: int) -> dict:
+        """Pre-allocated outputs / scratch of the GF-ICF pipeline (keeps allocation out of timed loops)."""
+        tc, dev = self.torch, f"cuda:{self.device}"
+        return dict(
+            nt=tc.zeros(max(G, 1), dtype=tc.int64, device=dev),
+            keep=tc.zeros(max(G, 1), dtype=tc.uint8, device=dev),
+            remap=tc.zeros(max(G, 1), dtype=tc.int32, device=dev),
+            w=tc.zeros(max(G, 1), dtype=tc.float64, device=dev),
+            gkept=tc.zeros(1, dtype=tc.int64, device=dev),
+            out_colptr=tc.zeros(n_cells + 1, dtype=tc.int64, device=dev),
+            out_rowidx=tc.zeros(max(nnz, 1), dtype=tc.int32, device=dev),
+            out_x=tc.zeros(max(nnz, 1), dtype=tc.float64, device=dev),
+        )
+
+    def gficf_csc(self, G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None, ws=None) -> dict:
+        """Single-GPU GF-ICF on a device-resident CSC matrix (colptr int64).  Returns the workspace dict;
+        ``out_colptr[N]`` is the kept nnz, ``gkept[0]`` the number of kept genes."""
+        ws = ws or self.csc_workspace(G, N, int(rowidx.numel()))
+        check(self.L.gficf_csc_device(self._bind(), G, N, _tptr(colptr), _tptr(rowidx), _tptr(x), int(rowidx.numel()),
+                                      float(prop_min), float(prop_max), _tptr(w_in), _tptr(ws["nt"]),
+                                      _tptr(ws["keep"]), _tptr(ws["remap"]), _tptr(ws["w"]), _tptr(ws["gkept"]),
+                                      _tptr(ws["out_colptr"]), _tptr(ws["out_rowidx"]), _tptr(ws["out_x"])))
+        return ws

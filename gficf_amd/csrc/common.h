@@ -1,0 +1,62 @@
+// common.h — context, error plumbing and small device helpers shared by the HIP sources.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "gficf_hip.h"
+
+// Deferred device-side validation flags (OR-ed into gficf_ctx::d_status by kernels).
+constexpr uint32_t GFICF_ST_BAD_ID = 1u;    // kNN id outside [1, N] or not an integer
+constexpr uint32_t GFICF_ST_BAD_CSC = 2u;   // rowidx outside [0, G) / colptr not monotone
+
+struct gficf_host_plan;  // gficf_csc.hip
+
+struct gficf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cus = 256;
+  uint32_t* d_status = nullptr;   // device status word
+  uint32_t* h_status = nullptr;   // pinned host mirror
+  void* d_ws = nullptr;           // scan partials (fixed size, allocated at create)
+  size_t ws_bytes = 0;
+  gficf_host_plan* plan = nullptr;
+};
+
+// releases the host-form GF-ICF plan held by the context, if any (gficf_csc.hip)
+void gficf_host_plan_free(gficf_ctx* ctx);
+
+// thread-local last error message
+void gficf_set_error(const char* fmt, ...);
+
+#define GFICF_FAIL(code, ...)        \
+  do {                               \
+    gficf_set_error(__VA_ARGS__);    \
+    return (code);                   \
+  } while (0)
+
+#define GFICF_HIP_CHECK(expr)                                                              \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      gficf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,     \
+                      __LINE__);                                                           \
+      return GFICF_ERR_HIP;                                                                \
+    }                                                                                      \
+  } while (0)
+
+// Binds the calling thread to the context's device.
+#define GFICF_CTX_ENTER(ctx)                                         \
+  do {                                                               \
+    if (!(ctx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ctx is NULL");    \
+    GFICF_HIP_CHECK(hipSetDevice((ctx)->device));                    \
+  } while (0)
+
+__host__ __device__ static inline int64_t gficf_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// In-place exclusive scan of n int64 values on the context's stream (scan.hip).
+// Uses ctx->d_ws for block partials.
+int gficf_exclusive_scan_i64(gficf_ctx* ctx, int64_t* d_data, int64_t n);

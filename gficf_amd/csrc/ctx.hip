@@ -1,0 +1,188 @@
+// ctx.hip — library context, error strings, and the int64 exclusive scan helper.
+#include <cstring>
+
+#include "common.h"
+
+static thread_local char g_err[768] = "";
+
+void gficf_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+int gficf_hip_abi_version(void) { return GFICF_HIP_ABI_VERSION; }
+
+const char* gficf_last_error(void) { return g_err; }
+
+int gficf_device_count(int* count) {
+  if (!count) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    gficf_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return GFICF_ERR_NO_DEVICE;
+  }
+  *count = n;
+  return GFICF_OK;
+}
+
+int gficf_ctx_create(int device, void* stream, gficf_ctx** out) {
+  if (!out) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    GFICF_FAIL(GFICF_ERR_NO_DEVICE, "no HIP device visible (libgficf_hip needs an AMD GPU; there is no CPU fallback)");
+  if (device < 0 || device >= n)
+    GFICF_FAIL(GFICF_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, n);
+  GFICF_HIP_CHECK(hipSetDevice(device));
+  gficf_ctx* c = new gficf_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+  c->ws_bytes = 1u << 20;
+  hipError_t e = hipMalloc((void**)&c->d_status, sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(c->d_status, 0, sizeof(uint32_t));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_status, sizeof(uint32_t), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipMalloc(&c->d_ws, c->ws_bytes);
+  if (e != hipSuccess) {
+    gficf_set_error("context allocation failed: %s", hipGetErrorString(e));
+    gficf_ctx_destroy(c);
+    return GFICF_ERR_HIP;
+  }
+  *c->h_status = 0;
+  *out = c;
+  return GFICF_OK;
+}
+
+void gficf_ctx_destroy(gficf_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  gficf_host_plan_free(ctx);
+  if (ctx->d_status) (void)hipFree(ctx->d_status);
+  if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+  if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+  delete ctx;
+}
+
+int gficf_ctx_set_stream(gficf_ctx* ctx, void* stream) {
+  if (!ctx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ctx is NULL");
+  ctx->stream = (hipStream_t)stream;
+  return GFICF_OK;
+}
+
+int gficf_ctx_sync(gficf_ctx* ctx) {
+  GFICF_CTX_ENTER(ctx);
+  GFICF_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  GFICF_HIP_CHECK(hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream));
+  GFICF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  uint32_t st = *ctx->h_status;
+  if (st & GFICF_ST_BAD_ID)
+    GFICF_FAIL(GFICF_ERR_BAD_ID, "kNN index matrix holds an id outside [1, N] or a non-integer value");
+  if (st & GFICF_ST_BAD_CSC)
+    GFICF_FAIL(GFICF_ERR_BAD_CSC, "CSC matrix malformed: row index outside [0, G) or colptr not monotone");
+  return GFICF_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ exclusive scan (int64)
+namespace {
+
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ inline int64_t wave_inclusive_scan(int64_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int64_t t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// Block-wide exclusive scan of one value per thread; returns the exclusive prefix and the
+// block total through *total.  SCAN_THREADS threads.
+__device__ inline int64_t block_exclusive_scan(int64_t v, int64_t* total) {
+  __shared__ int64_t s_wave[SCAN_THREADS / 64];
+  __shared__ int64_t s_total;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t inc = wave_inclusive_scan(v, lane);
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    int64_t w = lane < SCAN_THREADS / 64 ? s_wave[lane] : 0;
+    int64_t winc = wave_inclusive_scan(w, lane);
+    if (lane < SCAN_THREADS / 64) s_wave[lane] = winc - w;
+    if (lane == SCAN_THREADS / 64 - 1) s_total = winc;
+  }
+  __syncthreads();
+  int64_t r = inc - v + s_wave[wave];
+  *total = s_total;
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const int64_t* __restrict__ d, int64_t n,
+                                                              int64_t* __restrict__ partial) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int64_t s = 0;
+#pragma unroll
+  for (int t = 0; t < SCAN_ITEMS; ++t)
+    if (base + t < n) s += d[base + t];
+  int64_t total;
+  (void)block_exclusive_scan(s, &total);
+  if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_partials(int64_t* __restrict__ partial, int64_t nb) {
+  int64_t carry = 0;
+  for (int64_t b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
+    int64_t idx = b0 + threadIdx.x;
+    int64_t v = idx < nb ? partial[idx] : 0;
+    int64_t total;
+    int64_t ex = block_exclusive_scan(v, &total);
+    if (idx < nb) partial[idx] = carry + ex;
+    carry += total;
+  }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(int64_t* __restrict__ d, int64_t n,
+                                                             const int64_t* __restrict__ partial) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int64_t v[SCAN_ITEMS];
+  int64_t s = 0;
+#pragma unroll
+  for (int t = 0; t < SCAN_ITEMS; ++t) {
+    v[t] = base + t < n ? d[base + t] : 0;
+    s += v[t];
+  }
+  int64_t total;
+  int64_t ex = block_exclusive_scan(s, &total) + partial[blockIdx.x];
+#pragma unroll
+  for (int t = 0; t < SCAN_ITEMS; ++t) {
+    if (base + t < n) d[base + t] = ex;
+    ex += v[t];
+  }
+}
+
+}  // namespace
+
+int gficf_exclusive_scan_i64(gficf_ctx* ctx, int64_t* d_data, int64_t n) {
+  if (n <= 0) return GFICF_OK;
+  const int64_t nb = gficf_ceil_div(n, SCAN_TILE);
+  if ((size_t)nb * sizeof(int64_t) > ctx->ws_bytes)
+    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "scan of %lld elements exceeds the workspace", (long long)n);
+  int64_t* partial = (int64_t*)ctx->d_ws;
+  hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_data, n, partial);
+  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, partial, nb);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_data, n, partial);
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
+}

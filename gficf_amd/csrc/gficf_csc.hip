@@ -1,0 +1,473 @@
+// gficf_csc.hip — GF-ICF normalisation of a CSC genes x cells matrix for gfx950 (MI355X).
+//
+// Replaces the R-level chain of gficf() (reference R/gficf.R:17-33, normalize = FALSE):
+//   R/gficf.R:40-41   gene filter by cell frequency        -> k_gene_count + k_gene_table
+//   R/gficf.R:59      GF:  x / S_c (per-cell L1)            \
+//   R/gficf.R:88-89   ICF weights log((N+1)/(nt_g+1))        | k_gene_table (weights)
+//   R/gficf.R:79      x * w_g                                | k_scale_cells (per cell)
+//   R/gficf.R:100-103 per-cell L2, Inf -> 0                 /
+// HBM-bound sparse scaling in f64, no MFMA.  The only global dependency is the per-gene
+// cell count nt_g, so the matrix is read twice: once to count (pass A), once to scale
+// (pass B); the row subset of R/gficf.R:41 is a stream compaction fused into pass B whose
+// output offsets come from a per-cell kept-count pass + scan.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ pass A: nt_g counts
+// nt_g = #{cells c : x[g,c] != 0}  (explicitly stored zeros do not count, as in
+// rowSums(M != 0)).  Per-workgroup histogram in LDS (G counters), flushed with one global
+// atomic per touched gene; falls back to global atomics when G does not fit LDS.
+constexpr int CNT_THREADS = 1024;
+constexpr int CNT_LDS_MAX_G = 36 * 1024;   // 144 KiB of uint32 counters
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __restrict__ rowidx,
+                                                            const double* __restrict__ x, int64_t nnz, int64_t G,
+                                                            unsigned long long* __restrict__ nt,
+                                                            uint32_t* __restrict__ status) {
+  extern __shared__ uint32_t s_hist[];
+  if (USE_LDS) {
+    for (int64_t g = threadIdx.x; g < G; g += CNT_THREADS) s_hist[g] = 0;
+    __syncthreads();
+  }
+  bool bad = false;
+  // each workgroup sweeps a contiguous slab (keeps one cell's distinct genes in one wave-instruction)
+  const int64_t per_block = gficf_ceil_div(gficf_ceil_div(nnz, (int64_t)gridDim.x), CNT_THREADS) * CNT_THREADS;
+  const int64_t p0 = (int64_t)blockIdx.x * per_block;
+  const int64_t p1 = p0 + per_block < nnz ? p0 + per_block : nnz;
+  for (int64_t p = p0 + threadIdx.x; p < p1; p += CNT_THREADS) {
+    const int32_t g = rowidx[p];
+    const double v = x[p];
+    if (g < 0 || g >= G) { bad = true; continue; }
+    if (v != 0.0) {
+      if (USE_LDS) atomicAdd(&s_hist[g], 1u);
+      else atomicAdd(&nt[g], 1ull);
+    }
+  }
+  if (bad) atomicOr(status, GFICF_ST_BAD_CSC);
+  if (USE_LDS) {
+    __syncthreads();
+    for (int64_t g = threadIdx.x; g < G; g += CNT_THREADS) {
+      const uint32_t c = s_hist[g];
+      if (c) atomicAdd(&nt[g], (unsigned long long)c);
+    }
+  }
+}
+
+// --------------------------------------------------- gene table: keep / remap / weights
+// One workgroup.  keep_g = nt_g > N*min && nt_g <= N*max (double compare, R/gficf.R:41);
+// remap = exclusive scan of keep (new row id of a kept gene); w_g = log((N+1)/(nt_g+1))
+// (R/gficf.R:89) or the supplied weight.
+constexpr int GT_THREADS = 1024;
+
+__global__ __launch_bounds__(GT_THREADS) void k_gene_table(int64_t G, int64_t N_total, const int64_t* __restrict__ nt,
+                                                           double prop_min, double prop_max,
+                                                           const double* __restrict__ w_in, uint8_t* __restrict__ keep,
+                                                           int32_t* __restrict__ remap, double* __restrict__ w,
+                                                           int64_t* __restrict__ gkept) {
+  __shared__ int32_t s_part[GT_THREADS];
+  const int tid = threadIdx.x;
+  const int64_t per = gficf_ceil_div(G, GT_THREADS);
+  const int64_t g0 = (int64_t)tid * per, g1 = g0 + per < G ? g0 + per : G;
+  const double lo = (double)N_total * prop_min, hi = (double)N_total * prop_max;
+  int32_t cnt = 0;
+  for (int64_t g = g0; g < g1; ++g) {
+    const double c = (double)nt[g];
+    cnt += (c > lo && c <= hi) ? 1 : 0;
+  }
+  s_part[tid] = cnt;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over the 1024 partials
+  for (int d = 1; d < GT_THREADS; d <<= 1) {
+    int32_t t = tid >= d ? s_part[tid - d] : 0;
+    __syncthreads();
+    s_part[tid] += t;
+    __syncthreads();
+  }
+  int32_t r = s_part[tid] - cnt;
+  for (int64_t g = g0; g < g1; ++g) {
+    const double c = (double)nt[g];
+    const bool kp = c > lo && c <= hi;
+    keep[g] = kp ? 1 : 0;
+    remap[g] = kp ? r : -1;
+    r += kp ? 1 : 0;
+    double wv = 0.0;
+    if (kp) wv = w_in ? w_in[g] : log(((double)N_total + 1.0) / (c + 1.0));
+    w[g] = wv;
+  }
+  if (tid == GT_THREADS - 1) *gkept = (int64_t)s_part[tid];
+}
+
+// ------------------------------------------------------- pass B0: kept entries per cell
+// One wave per cell; out[c] = #{entries of cell c whose gene is kept}; out[n_cells] = 0,
+// turned into the new colptr by an exclusive scan.  When no gene is dropped the count is
+// the old column length and rowidx is not read at all.
+constexpr int CC_THREADS = 256;
+
+__global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64_t n_cells,
+                                                                const int64_t* __restrict__ colptr,
+                                                                const int32_t* __restrict__ rowidx,
+                                                                const uint8_t* __restrict__ keep,
+                                                                const int64_t* __restrict__ gkept,
+                                                                int64_t* __restrict__ out, uint32_t* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * CC_THREADS + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * CC_THREADS) >> 6;
+  const bool all_kept = (*gkept == G);
+  if (wave == 0 && lane == 0) out[n_cells] = 0;
+  for (int64_t c = wave; c < n_cells; c += nwaves) {
+    const int64_t p0 = colptr[c], p1 = colptr[c + 1];
+    if (p1 < p0) { if (lane == 0) { atomicOr(status, GFICF_ST_BAD_CSC); out[c] = 0; } continue; }
+    int64_t cnt;
+    if (all_kept) {
+      cnt = p1 - p0;
+    } else {
+      int n = 0;
+      for (int64_t p = p0 + lane; p < p1; p += 64) {
+        const int32_t g = rowidx[p];
+        n += (g >= 0 && g < G) ? keep[g] : 0;
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
+      cnt = n;
+    }
+    if (lane == 0) out[c] = cnt;
+  }
+}
+
+// ---------------------------------------------------------------- pass B: scale a cell
+// One workgroup of SC_WAVES waves per cell.  Wave w owns a contiguous run of the cell's
+// entries, so kept entries keep their order and every wave's output run is contiguous.
+//   sweep 1: S_c = sum of kept x (R/gficf.R:59), kept count per wave
+//   sweep 2: v = (x / S_c) * w_g (R/gficf.R:59,79); q_c = sum v^2 (R/gficf.R:100)
+//   sweep 3: out = (1/sqrt(q_c), Inf -> 0) * v (R/gficf.R:100-103), compacted + renumbered
+// Sweeps 2 and 3 re-read the cell's entries from L2 (a cell is a few tens of KB).
+constexpr int SC_WAVES = 4;
+constexpr int SC_THREADS = SC_WAVES * 64;
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+__global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n_cells,
+                                                            const int64_t* __restrict__ colptr,
+                                                            const int32_t* __restrict__ rowidx,
+                                                            const double* __restrict__ x,
+                                                            const int32_t* __restrict__ remap,
+                                                            const double* __restrict__ w,
+                                                            const int64_t* __restrict__ out_colptr,
+                                                            int32_t* __restrict__ out_rowidx,
+                                                            double* __restrict__ out_x) {
+  __shared__ double s_sum[SC_WAVES];
+  __shared__ int32_t s_cnt[SC_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  for (int64_t c = blockIdx.x; c < n_cells; c += gridDim.x) {
+    const int64_t p0 = colptr[c], p1 = colptr[c + 1];
+    const int64_t len = p1 - p0;
+    if (len <= 0) continue;                         // uniform over the workgroup
+    const int64_t seg = gficf_ceil_div(gficf_ceil_div(len, SC_WAVES), 64) * 64;
+    const int64_t a0 = p0 + (int64_t)wave * seg < p1 ? p0 + (int64_t)wave * seg : p1;
+    const int64_t a1 = a0 + seg < p1 ? a0 + seg : p1;
+    // sweep 1
+    double S = 0.0;
+    int kept = 0;
+    for (int64_t p = a0 + lane; p < a1; p += 64) {
+      const int32_t g = rowidx[p];
+      const bool kp = (g >= 0 && g < G) && remap[g] >= 0;
+      if (kp) { S += x[p]; ++kept; }
+    }
+    S = wave_sum(S);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d);
+    if (lane == 0) { s_sum[wave] = S; s_cnt[wave] = kept; }
+    __syncthreads();
+    double Sc = 0.0;
+    int64_t opos = out_colptr[c];
+#pragma unroll
+    for (int t = 0; t < SC_WAVES; ++t) {
+      Sc += s_sum[t];
+      if (t < wave) opos += s_cnt[t];
+    }
+    __syncthreads();
+    // sweep 2
+    double q = 0.0;
+    if (Sc != 0.0) {
+      for (int64_t p = a0 + lane; p < a1; p += 64) {
+        const int32_t g = rowidx[p];
+        const bool kp = (g >= 0 && g < G) && remap[g] >= 0;
+        if (kp) { const double v = (x[p] / Sc) * w[g]; q += v * v; }
+      }
+    }
+    q = wave_sum(q);
+    if (lane == 0) s_sum[wave] = q;
+    __syncthreads();
+    double qc = 0.0;
+#pragma unroll
+    for (int t = 0; t < SC_WAVES; ++t) qc += s_sum[t];
+    __syncthreads();
+    double nv = 1.0 / sqrt(qc);
+    if (isinf(nv)) nv = 0.0;                        // R/gficf.R:101
+    // sweep 3
+    for (int64_t pb = a0; pb < a1; pb += 64) {
+      const int64_t p = pb + lane;
+      bool kp = false;
+      int32_t r = -1;
+      double v = 0.0;
+      if (p < a1) {
+        const int32_t g = rowidx[p];
+        if (g >= 0 && g < G) r = remap[g];
+        kp = r >= 0;
+        if (kp && Sc != 0.0) v = nv * ((x[p] / Sc) * w[g]);
+      }
+      const unsigned long long m = __ballot(kp);
+      if (kp) {
+        const int64_t dst = opos + __popcll(m & lt_mask);
+        out_rowidx[dst] = r;
+        out_x[dst] = v;
+      }
+      opos += __popcll(m);
+    }
+  }
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int gficf_csc_count_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
+                           const int32_t* d_rowidx, const double* d_x, int64_t nnz, int64_t* d_nt) {
+  GFICF_CTX_ENTER(ctx);
+  (void)d_colptr;
+  if (G < 0 || n_cells < 0 || nnz < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
+  if (G > 0x7FFFFFFFll) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "G = %lld exceeds int32 row indices", (long long)G);
+  if (nnz == 0 || G == 0) return GFICF_OK;
+  if (!d_rowidx || !d_x || !d_nt) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  int64_t blocks = gficf_ceil_div(nnz, (int64_t)CNT_THREADS * 16);
+  if (blocks > ctx->num_cus) blocks = ctx->num_cus;
+  if (G <= CNT_LDS_MAX_G) {
+    const size_t lds = (size_t)G * sizeof(uint32_t);
+    static bool attr_set[64] = {};
+    if (!attr_set[ctx->device & 63]) {
+      GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_gene_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CNT_LDS_MAX_G * (int)sizeof(uint32_t)));
+      attr_set[ctx->device & 63] = true;
+    }
+    hipLaunchKernelGGL(k_gene_count<true>, dim3((unsigned)blocks), dim3(CNT_THREADS), lds, ctx->stream, d_rowidx, d_x,
+                       nnz, G, (unsigned long long*)d_nt, ctx->d_status);
+  } else {
+    blocks = gficf_ceil_div(nnz, (int64_t)CNT_THREADS * 16);
+    if (blocks > (int64_t)ctx->num_cus * 2) blocks = (int64_t)ctx->num_cus * 2;
+    hipLaunchKernelGGL(k_gene_count<false>, dim3((unsigned)blocks), dim3(CNT_THREADS), 0, ctx->stream, d_rowidx, d_x,
+                       nnz, G, (unsigned long long*)d_nt, ctx->d_status);
+  }
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
+}
+
+int gficf_csc_genes_device(gficf_ctx* ctx, int64_t G, int64_t N_total, const int64_t* d_nt, double prop_min,
+                           double prop_max, const double* d_w_in, uint8_t* d_keep, int32_t* d_remap, double* d_w,
+                           int64_t* d_gkept) {
+  GFICF_CTX_ENTER(ctx);
+  if (G < 0 || N_total < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
+  if (G > 0x7FFFFFFFll) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "G = %lld exceeds int32 row indices", (long long)G);
+  if (!d_gkept || (G > 0 && (!d_nt || !d_keep || !d_remap || !d_w))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  hipLaunchKernelGGL(k_gene_table, dim3(1), dim3(GT_THREADS), 0, ctx->stream, G, N_total, d_nt, prop_min, prop_max,
+                     d_w_in, d_keep, d_remap, d_w, d_gkept);
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
+}
+
+int gficf_csc_colptr_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
+                            const int32_t* d_rowidx, const uint8_t* d_keep, const int64_t* d_gkept,
+                            int64_t* d_out_colptr) {
+  GFICF_CTX_ENTER(ctx);
+  if (G < 0 || n_cells < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
+  if (!d_colptr || !d_out_colptr || !d_gkept || !d_keep) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  int64_t blocks = gficf_ceil_div(n_cells > 0 ? n_cells : 1, CC_THREADS / 64);
+  if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+  hipLaunchKernelGGL(k_cell_kept_count, dim3((unsigned)blocks), dim3(CC_THREADS), 0, ctx->stream, G, n_cells, d_colptr,
+                     d_rowidx, d_keep, d_gkept, d_out_colptr, ctx->d_status);
+  GFICF_HIP_CHECK(hipGetLastError());
+  return gficf_exclusive_scan_i64(ctx, d_out_colptr, n_cells + 1);
+}
+
+int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
+                           const int32_t* d_rowidx, const double* d_x, int64_t nnz, const int32_t* d_remap,
+                           const double* d_w, const int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
+  GFICF_CTX_ENTER(ctx);
+  if (G < 0 || n_cells < 0 || nnz < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
+  if (n_cells == 0 || nnz == 0) return GFICF_OK;
+  if (!d_colptr || !d_rowidx || !d_x || !d_remap || !d_w || !d_out_colptr || !d_out_rowidx || !d_out_x)
+    GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  int64_t blocks = n_cells;
+  if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+  hipLaunchKernelGGL(k_scale_cells, dim3((unsigned)blocks), dim3(SC_THREADS), 0, ctx->stream, G, n_cells, d_colptr,
+                     d_rowidx, d_x, d_remap, d_w, d_out_colptr, d_out_rowidx, d_out_x);
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
+}
+
+int gficf_csc_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colptr, const int32_t* d_rowidx,
+                     const double* d_x, int64_t nnz, double prop_min, double prop_max, const double* d_w_in,
+                     int64_t* d_nt, uint8_t* d_keep, int32_t* d_remap, double* d_w, int64_t* d_gkept,
+                     int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
+  GFICF_CTX_ENTER(ctx);
+  if (G < 0 || N < 0 || nnz < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
+  if (G > 0) {
+    if (!d_nt) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+    GFICF_HIP_CHECK(hipMemsetAsync(d_nt, 0, sizeof(int64_t) * (size_t)G, ctx->stream));
+  }
+  int rc = gficf_csc_count_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_nt);
+  if (rc) return rc;
+  rc = gficf_csc_genes_device(ctx, G, N, d_nt, prop_min, prop_max, d_w_in, d_keep, d_remap, d_w, d_gkept);
+  if (rc) return rc;
+  rc = gficf_csc_colptr_device(ctx, G, N, d_colptr, d_rowidx, d_keep, d_gkept, d_out_colptr);
+  if (rc) return rc;
+  return gficf_csc_scale_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_remap, d_w, d_out_colptr, d_out_rowidx,
+                                d_out_x);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------- host form (R glue)
+struct gficf_host_plan {
+  int64_t G = 0, N = 0, nnz = 0, nnz_kept = 0, g_kept = 0;
+  int colptr_is_i64 = 0;
+  int64_t* d_colptr = nullptr;
+  int32_t* d_rowidx = nullptr;
+  double* d_x = nullptr;
+  double* d_w_in = nullptr;
+  int64_t* d_nt = nullptr;
+  uint8_t* d_keep = nullptr;
+  int32_t* d_remap = nullptr;
+  double* d_w = nullptr;
+  int64_t* d_gkept = nullptr;
+  int64_t* d_out_colptr = nullptr;
+};
+
+void gficf_host_plan_free(gficf_ctx* ctx) {
+  gficf_host_plan* p = ctx->plan;
+  if (!p) return;
+  void* ptrs[] = {p->d_colptr, p->d_rowidx, p->d_x, p->d_w_in, p->d_nt, p->d_keep, p->d_remap, p->d_w, p->d_gkept, p->d_out_colptr};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  delete p;
+  ctx->plan = nullptr;
+}
+
+#define PLAN_HIP(expr)                                                                              \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      gficf_set_error("%s failed: %s", #expr, hipGetErrorString(_e));                               \
+      (void)hipStreamSynchronize(ctx->stream);                                                      \
+      gficf_host_plan_free(ctx);                                                                    \
+      return GFICF_ERR_HIP;                                                                         \
+    }                                                                                               \
+  } while (0)
+
+extern "C" {
+
+int gficf_normalize_csc_host_plan(gficf_ctx* ctx, int64_t G, int64_t N, const void* colptr, int colptr_is_i64,
+                                  const int32_t* rowidx, const double* x, double prop_min, double prop_max,
+                                  const double* w_in, int64_t* G_kept, int64_t* nnz_kept) {
+  GFICF_CTX_ENTER(ctx);
+  if (G < 0 || N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative dimension");
+  if (!colptr || !G_kept || !nnz_kept) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
+  gficf_host_plan_free(ctx);
+  std::vector<int64_t> cp((size_t)N + 1);
+  for (int64_t c = 0; c <= N; ++c)
+    cp[(size_t)c] = colptr_is_i64 ? ((const int64_t*)colptr)[c] : (int64_t)((const int32_t*)colptr)[c];
+  if (cp[0] != 0) GFICF_FAIL(GFICF_ERR_BAD_CSC, "colptr[0] = %lld, expected 0", (long long)cp[0]);
+  for (int64_t c = 0; c < N; ++c)
+    if (cp[(size_t)c + 1] < cp[(size_t)c]) GFICF_FAIL(GFICF_ERR_BAD_CSC, "colptr not monotone at cell %lld", (long long)c);
+  const int64_t nnz = cp[(size_t)N];
+  if (nnz > 0 && (!rowidx || !x)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
+  gficf_host_plan* p = new gficf_host_plan();
+  ctx->plan = p;
+  p->G = G; p->N = N; p->nnz = nnz; p->colptr_is_i64 = colptr_is_i64;
+  const size_t gsz = (size_t)(G > 0 ? G : 1), nsz = (size_t)(nnz > 0 ? nnz : 1);
+  PLAN_HIP(hipMalloc((void**)&p->d_colptr, sizeof(int64_t) * ((size_t)N + 1)));
+  PLAN_HIP(hipMalloc((void**)&p->d_rowidx, sizeof(int32_t) * nsz));
+  PLAN_HIP(hipMalloc((void**)&p->d_x, sizeof(double) * nsz));
+  PLAN_HIP(hipMalloc((void**)&p->d_nt, sizeof(int64_t) * gsz));
+  PLAN_HIP(hipMalloc((void**)&p->d_keep, gsz));
+  PLAN_HIP(hipMalloc((void**)&p->d_remap, sizeof(int32_t) * gsz));
+  PLAN_HIP(hipMalloc((void**)&p->d_w, sizeof(double) * gsz));
+  PLAN_HIP(hipMalloc((void**)&p->d_gkept, sizeof(int64_t)));
+  PLAN_HIP(hipMalloc((void**)&p->d_out_colptr, sizeof(int64_t) * ((size_t)N + 1)));
+  PLAN_HIP(hipMemcpyAsync(p->d_colptr, cp.data(), sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice, ctx->stream));
+  if (nnz > 0) {
+    PLAN_HIP(hipMemcpyAsync(p->d_rowidx, rowidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+    PLAN_HIP(hipMemcpyAsync(p->d_x, x, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (w_in && G > 0) {
+    PLAN_HIP(hipMalloc((void**)&p->d_w_in, sizeof(double) * gsz));
+    PLAN_HIP(hipMemcpyAsync(p->d_w_in, w_in, sizeof(double) * (size_t)G, hipMemcpyHostToDevice, ctx->stream));
+  }
+  PLAN_HIP(hipMemsetAsync(p->d_nt, 0, sizeof(int64_t) * gsz, ctx->stream));
+  int rc = gficf_csc_count_device(ctx, G, N, p->d_colptr, p->d_rowidx, p->d_x, nnz, p->d_nt);
+  if (!rc) rc = gficf_csc_genes_device(ctx, G, N, p->d_nt, prop_min, prop_max, p->d_w_in, p->d_keep, p->d_remap, p->d_w, p->d_gkept);
+  if (!rc) rc = gficf_csc_colptr_device(ctx, G, N, p->d_colptr, p->d_rowidx, p->d_keep, p->d_gkept, p->d_out_colptr);
+  int64_t hk[2] = {0, 0};
+  if (!rc) {
+    PLAN_HIP(hipMemcpyAsync(&hk[0], p->d_gkept, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PLAN_HIP(hipMemcpyAsync(&hk[1], p->d_out_colptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    rc = gficf_ctx_sync(ctx);
+  } else {
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  if (rc) { gficf_host_plan_free(ctx); return rc; }
+  p->g_kept = hk[0];
+  p->nnz_kept = hk[1];
+  *G_kept = hk[0];
+  *nnz_kept = hk[1];
+  return GFICF_OK;
+}
+
+int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, double* w, void* out_colptr,
+                                    int32_t* out_rowidx, double* out_x) {
+  GFICF_CTX_ENTER(ctx);
+  gficf_host_plan* p = ctx->plan;
+  if (!p) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "gficf_normalize_csc_host_finish without a plan");
+  if (!out_colptr || (p->nnz_kept > 0 && (!out_rowidx || !out_x))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
+  int32_t* d_ori = nullptr;
+  double* d_ox = nullptr;
+  const size_t ksz = (size_t)(p->nnz_kept > 0 ? p->nnz_kept : 1);
+  PLAN_HIP(hipMalloc((void**)&d_ori, sizeof(int32_t) * ksz));
+  hipError_t e2 = hipMalloc((void**)&d_ox, sizeof(double) * ksz);
+  if (e2 != hipSuccess) { (void)hipFree(d_ori); PLAN_HIP(e2); }
+  int rc = gficf_csc_scale_device(ctx, p->G, p->N, p->d_colptr, p->d_rowidx, p->d_x, p->nnz, p->d_remap, p->d_w,
+                                  p->d_out_colptr, d_ori, d_ox);
+  std::vector<int64_t> cp((size_t)p->N + 1);
+  hipError_t e = hipSuccess;
+  if (!rc) {
+    e = hipMemcpyAsync(cp.data(), p->d_out_colptr, sizeof(int64_t) * cp.size(), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && p->nnz_kept > 0) e = hipMemcpyAsync(out_rowidx, d_ori, sizeof(int32_t) * (size_t)p->nnz_kept, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && p->nnz_kept > 0) e = hipMemcpyAsync(out_x, d_ox, sizeof(double) * (size_t)p->nnz_kept, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && keep && p->G > 0) e = hipMemcpyAsync(keep, p->d_keep, (size_t)p->G, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && nt && p->G > 0) e = hipMemcpyAsync(nt, p->d_nt, sizeof(int64_t) * (size_t)p->G, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && w && p->G > 0) e = hipMemcpyAsync(w, p->d_w, sizeof(double) * (size_t)p->G, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) rc = gficf_ctx_sync(ctx);
+  }
+  if (e != hipSuccess || rc) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_ori);
+  (void)hipFree(d_ox);
+  if (e != hipSuccess) { gficf_set_error("HIP failure in gficf_normalize_csc_host_finish: %s", hipGetErrorString(e)); rc = GFICF_ERR_HIP; }
+  if (!rc) {
+    if (p->colptr_is_i64) std::memcpy(out_colptr, cp.data(), sizeof(int64_t) * cp.size());
+    else for (size_t c = 0; c < cp.size(); ++c) ((int32_t*)out_colptr)[c] = (int32_t)cp[c];
+  }
+  gficf_host_plan_free(ctx);
+  return rc;
+}
+
+}  // extern "C"

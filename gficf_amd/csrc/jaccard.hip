@@ -1,0 +1,422 @@
+// jaccard.hip — Phenograph kNN -> Jaccard edge build for gfx950 (MI355X).
+//
+// Replaces the reference hot loop JCoefficient::operator()
+// (reference src/rcpp_parallel_jaccard_coeff.cpp:24-55): for every cell i and neighbour
+// slot j,  u = |multiset(row i) ∩ multiset(row idx[i,j])|  and the edge row
+// (i+1, idx[i,j], u/(2k-u)), zero when u == 0.
+//
+// This is integer set work bounded by memory, not a contraction: no MFMA.  Design:
+//   * ingest  : the R matrix (column-major, int32 or double) is transposed once into a
+//               row-major int32 table with rows padded to KPAD in {16,32,64,128,256}
+//               entries, so that one neighbour row is one (or a few) contiguous 64..1024 B
+//               reads.  Ids are validated here; bit 31 of a row's first entry flags a
+//               row that holds duplicate ids (never the case for real kNN output).
+//   * edges   : one wave64 per cell.  Row i is staged in LDS as a 2-slot-bucket hash set
+//               (one ds_read_b64 per probe, no probing loop); 64/KPAD neighbour rows are
+//               gathered per wave-instruction, every lane probes the set with its element,
+//               and the per-edge intersection count is the popcount of the wave ballot.
+//               Weights come from a per-block LDS table W[u] = u/(2k-u) computed in IEEE
+//               double, so they are bit-identical to the reference's division.
+//   * rows with duplicate ids (multiset semantics), hash overflow: exact slow path in the
+//               same kernel (all-pairs with occurrence ranks).
+#include "common.h"
+
+namespace {
+
+constexpr uint32_t ROW_DUP_FLAG = 0x80000000u;
+constexpr uint32_t ID_MASK = 0x7FFFFFFFu;
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+
+__host__ __device__ inline int kpad_for(int k) {
+  return k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : k <= 128 ? 128 : 256;
+}
+
+// ------------------------------------------------------------------------------ ingest
+template <typename T>
+__device__ inline uint32_t decode_id(T raw, int64_t N, bool& ok);
+template <>
+__device__ inline uint32_t decode_id<int32_t>(int32_t raw, int64_t N, bool& ok) {
+  ok = raw >= 1 && (int64_t)raw <= N;
+  return ok ? (uint32_t)raw : 0u;
+}
+template <>
+__device__ inline uint32_t decode_id<double>(double raw, int64_t N, bool& ok) {
+  // reference: int k = mat(i,j) - 1  (:28) — only integer-valued ids are meaningful.
+  ok = raw >= 1.0 && raw <= (double)N && raw == trunc(raw);
+  return ok ? (uint32_t)raw : 0u;
+}
+
+constexpr int INGEST_ROWS = 64;
+
+// Tile transpose: 64 cells x KPAD slots per step.  Reads are coalesced along cells
+// (column-major input), writes are one contiguous 64*KPAD*4 B run of the table.
+template <typename T, int KPAD>
+__global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
+                                                int64_t N_total, uint32_t* __restrict__ table,
+                                                uint32_t* __restrict__ status) {
+  __shared__ uint32_t tile[INGEST_ROWS][KPAD + 1];
+  __shared__ uint32_t dup[INGEST_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int64_t row0 = (int64_t)blockIdx.x * INGEST_ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * INGEST_ROWS) {
+    const int64_t r = row0 + lane;
+    bool bad = false;
+    for (int j = wave; j < KPAD; j += 4) {
+      uint32_t v = 0;
+      if (j < k && r < n_rows) {
+        bool ok;
+        v = decode_id<T>(idx[(int64_t)j * ld + r], N_total, ok);
+        bad |= !ok;
+      }
+      tile[lane][j] = v;
+    }
+    if (tid < INGEST_ROWS) dup[tid] = 0;
+    if (bad) atomicOr(status, GFICF_ST_BAD_ID);
+    __syncthreads();
+    // duplicate ids inside a row (multiset case): thread (row = lane, part = wave)
+    bool d = false;
+    for (int j = wave; j < k; j += 4) {
+      const uint32_t a = tile[lane][j];
+      if (a != 0)
+        for (int j2 = 0; j2 < j; ++j2) d |= (tile[lane][j2] == a);
+    }
+    if (d) dup[lane] = 1;
+    __syncthreads();
+    const int64_t rows_here = (n_rows - row0) < INGEST_ROWS ? (n_rows - row0) : INGEST_ROWS;
+    const int n_out = (int)rows_here * KPAD;
+    for (int e = tid; e < n_out; e += 256) {
+      const int rr = e / KPAD, j = e % KPAD;
+      uint32_t v = tile[rr][j];
+      if (j == 0 && dup[rr]) v |= ROW_DUP_FLAG;
+      table[row0 * KPAD + e] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------- edges
+template <int KPAD>
+struct JCfg {
+  static constexpr int G = KPAD >= 64 ? 1 : 64 / KPAD;        // neighbour rows per wave-instruction
+  static constexpr int EPL = KPAD >= 64 ? KPAD / 64 : 1;      // row elements per lane
+  static constexpr int TPQ = KPAD >= 64 ? 64 : KPAD / G;      // loop steps per element register
+  static constexpr int NB = 8 * KPAD;                         // 2-slot buckets in the hash set
+  static constexpr int WAVES = KPAD <= 128 ? 4 : 2;           // waves per workgroup
+  static constexpr int U = TPQ >= 8 ? 8 : TPQ;                // gathers in flight per wave
+  static constexpr int LOG2NB = KPAD == 16 ? 7 : KPAD == 32 ? 8 : KPAD == 64 ? 9 : KPAD == 128 ? 10 : 11;
+};
+
+template <int KPAD>
+__device__ inline uint32_t bucket_of(uint32_t id) {
+  return (id * 0x9E3779B1u) >> (32 - JCfg<KPAD>::LOG2NB);
+}
+
+// v_writelane_b32: drop a wave-uniform value into one lane of a VGPR (clang exposes no
+// builtin for it; bind the LLVM intrinsic by name).
+extern "C" __device__ int gficf_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+__device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+struct EdgeOut {
+  double* src;
+  double* dst;
+  double* w;
+  int32_t* u;
+};
+
+__device__ inline void store_edge(const EdgeOut& o, int64_t r, int64_t cell, uint32_t dst, int u,
+                                  const double* lut) {
+  const bool pos = u > 0;
+  o.src[r] = pos ? (double)(cell + 1) : 0.0;   // reference :49
+  o.dst[r] = pos ? (double)dst : 0.0;          // reference :50
+  o.w[r] = pos ? lut[u] : 0.0;                 // reference :51
+  if (o.u) o.u[r] = u;
+}
+
+// Exact multiset path for one cell: rows with duplicate ids or a hash set that overflowed.
+// u = sum over distinct values of min(multiplicity in A, multiplicity in B), evaluated as
+// "element e of B counts iff its occurrence rank within B is below the value's multiplicity in A".
+template <int KPAD>
+__device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64_t i, int k, int64_t out_base,
+                                       uint32_t* sA, uint32_t* sB, int lane, const EdgeOut& o,
+                                       const double* lut) {
+  for (int e = lane; e < KPAD; e += 64) sA[e] = table[i * KPAD + e] & ID_MASK;
+  wave_lds_fence();
+  for (int s = 0; s < k; ++s) {
+    const uint32_t dst = sA[s];
+    int u = 0;
+    if (dst != 0) {
+      for (int e = lane; e < KPAD; e += 64) sB[e] = table[(int64_t)(dst - 1) * KPAD + e] & ID_MASK;
+      wave_lds_fence();
+      int cnt = 0;
+      for (int e = lane; e < k; e += 64) {
+        const uint32_t b = sB[e];
+        if (b != 0) {
+          int rank = 0, ca = 0;
+          for (int t = 0; t < k; ++t) {
+            ca += (sA[t] == b);
+            rank += (t < e && sB[t] == b);
+          }
+          cnt += (rank < ca);
+        }
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+      u = cnt;
+      wave_lds_fence();
+    }
+    if (lane == 0) store_edge(o, out_base + s, i, dst, u, lut);
+  }
+}
+
+template <int KPAD>
+__global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
+    const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
+  using C = JCfg<KPAD>;
+  __shared__ uint2 s_hash[C::WAVES][C::NB];
+  __shared__ uint32_t s_rows[C::WAVES][2][KPAD];
+  __shared__ double s_lut[GFICF_JACCARD_MAX_K + 1];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // W[u] = u / (2.0*k - u): same IEEE-754 double division as reference :51
+  for (int u = tid; u <= k; u += C::WAVES * 64) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);
+  for (int b = lane; b < C::NB; b += 64) s_hash[wave][b] = make_uint2(EMPTY, EMPTY);
+  __syncthreads();
+
+  uint32_t* const hslots = reinterpret_cast<uint32_t*>(&s_hash[wave][0]);
+  const int e0 = KPAD >= 64 ? lane : (lane & (KPAD - 1));   // this lane's element within a row
+  const int grp = KPAD >= 64 ? 0 : lane / KPAD;             // which of the G rows of a step
+  const int64_t nwaves = (int64_t)gridDim.x * C::WAVES;
+
+  for (int64_t i = cell_begin + (int64_t)blockIdx.x * C::WAVES + wave; i < cell_end; i += nwaves) {
+    const int64_t out_base = (i - cell_begin) * (int64_t)k;
+    // ---- stage row i
+    uint32_t a[C::EPL];
+    uint32_t flags = 0;
+#pragma unroll
+    for (int q = 0; q < C::EPL; ++q) {
+      const uint32_t raw = table[i * KPAD + q * 64 + e0];
+      flags |= raw;
+      a[q] = raw & ID_MASK;
+    }
+    bool slow = __ballot((flags & ROW_DUP_FLAG) != 0) != 0ull;
+    uint32_t ov0 = EMPTY, ov1 = EMPTY;
+    int myslot[C::EPL];
+#pragma unroll
+    for (int q = 0; q < C::EPL; ++q) myslot[q] = -1;
+    if (!slow) {
+      bool over = false;
+      uint32_t ovkey = 0;
+#pragma unroll
+      for (int q = 0; q < C::EPL; ++q) {
+        if (lane < KPAD && a[q] != 0) {      // group 0 inserts (groups hold replicas when KPAD < 64)
+          const uint32_t bk = bucket_of<KPAD>(a[q]);
+          uint32_t old = atomicCAS(&hslots[2 * bk], EMPTY, a[q]);
+          if (old == EMPTY) {
+            myslot[q] = 2 * bk;
+          } else {
+            old = atomicCAS(&hslots[2 * bk + 1], EMPTY, a[q]);
+            if (old == EMPTY) myslot[q] = 2 * bk + 1;
+            else { slow |= over; over = true; ovkey = a[q]; }   // a lane with two overflows -> slow
+          }
+        }
+      }
+      wave_lds_fence();
+      unsigned long long om = __ballot(over);
+      const int nov = __popcll(om);
+      slow = (__ballot(slow) != 0ull) || nov > 2;
+      if (nov >= 1) { ov0 = __shfl(ovkey, __ffsll((long long)om) - 1); om &= om - 1; }
+      if (nov >= 2) { ov1 = __shfl(ovkey, __ffsll((long long)om) - 1); }
+    }
+
+    int myu[C::EPL];
+#pragma unroll
+    for (int q = 0; q < C::EPL; ++q) myu[q] = 0;
+
+    if (!slow) {
+      uint32_t dupflags = 0;
+#pragma unroll
+      for (int q = 0; q < C::EPL; ++q) {        // q: which register of row i holds the slot's id
+        for (int t0 = 0; t0 < C::TPQ && (q * 64 + t0 * C::G) < k; t0 += C::U) {
+          uint32_t bv[C::U][C::EPL];
+          // issue the gathers of U steps (U*G neighbour rows) before consuming any
+#pragma unroll
+          for (int uu = 0; uu < C::U; ++uu) {
+            const int srcl = (t0 + uu) * C::G + grp;            // lane of a[q] holding this slot's id
+            const int slot = q * 64 + srcl;
+            const uint32_t dst = __shfl(a[q], srcl);
+            const bool live = slot < k && dst != 0;
+#pragma unroll
+            for (int qq = 0; qq < C::EPL; ++qq) {
+              uint32_t raw = 0;
+              if (live) raw = table[(int64_t)(dst - 1) * KPAD + qq * 64 + e0];
+              dupflags |= raw;
+              bv[uu][qq] = raw & ID_MASK;
+            }
+          }
+#pragma unroll
+          for (int uu = 0; uu < C::U; ++uu) {
+            unsigned long long m = 0;
+            int cnt_big = 0;
+#pragma unroll
+            for (int qq = 0; qq < C::EPL; ++qq) {
+              const uint32_t b = bv[uu][qq];
+              const uint2 h = s_hash[wave][bucket_of<KPAD>(b)];
+              const unsigned long long mm = __ballot(h.x == b) | __ballot(h.y == b) | __ballot(b == ov0) | __ballot(b == ov1);
+              if (C::EPL == 1) m = mm; else cnt_big += __popcll(mm);
+            }
+            if (C::EPL == 1) {
+#pragma unroll
+              for (int gg = 0; gg < C::G; ++gg) {
+                const unsigned long long gm = KPAD >= 64 ? m : ((m >> (gg * (KPAD & 63))) & ((1ull << (KPAD & 63)) - 1ull));
+                myu[0] = gficf_writelane(__popcll(gm), (t0 + uu) * C::G + gg, myu[0]);
+              }
+            } else {
+              myu[q] = gficf_writelane(cnt_big, t0 + uu, myu[q]);
+            }
+          }
+        }
+      }
+      // a neighbour row with duplicate ids: redo this cell exactly
+      slow = __ballot((dupflags & ROW_DUP_FLAG) != 0) != 0ull;
+      if (!slow) {
+#pragma unroll
+        for (int q = 0; q < C::EPL; ++q) {
+          const int slot = q * 64 + lane;
+          if (lane < KPAD && slot < k) store_edge(o, out_base + slot, i, a[q], myu[q], s_lut);
+        }
+      }
+    }
+    // ---- clear this cell's keys from the set
+#pragma unroll
+    for (int q = 0; q < C::EPL; ++q)
+      if (myslot[q] >= 0) hslots[myslot[q]] = EMPTY;
+    wave_lds_fence();
+    if (slow) slow_cell<KPAD>(table, i, k, out_base, s_rows[wave][0], s_rows[wave][1], lane, o, s_lut);
+  }
+}
+
+template <typename T>
+int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t ld, int64_t N_total,
+                  uint32_t* table) {
+  const int kpad = kpad_for(k);
+  const int64_t tiles = gficf_ceil_div(n_rows, INGEST_ROWS);
+  const unsigned grid = (unsigned)(tiles < (int64_t)ctx->num_cus * 8 ? tiles : (int64_t)ctx->num_cus * 8);
+#define LAUNCH_INGEST(KP)                                                                                   \
+  hipLaunchKernelGGL((k_ingest<T, KP>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
+                     table, ctx->d_status)
+  switch (kpad) {
+    case 16: LAUNCH_INGEST(16); break;
+    case 32: LAUNCH_INGEST(32); break;
+    case 64: LAUNCH_INGEST(64); break;
+    case 128: LAUNCH_INGEST(128); break;
+    default: LAUNCH_INGEST(256); break;
+  }
+#undef LAUNCH_INGEST
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
+}
+
+template <int KPAD>
+int launch_edges(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+  using C = JCfg<KPAD>;
+  const int64_t blocks_needed = gficf_ceil_div(ce - cb, C::WAVES);
+  const int64_t cap = (int64_t)ctx->num_cus * 8;
+  const unsigned grid = (unsigned)(blocks_needed < cap ? blocks_needed : cap);
+  hipLaunchKernelGGL((k_jaccard_edges<KPAD>), dim3(grid), dim3(C::WAVES * 64), 0, ctx->stream, table, N, k, cb, ce, o);
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
+}
+
+int check_nk(int64_t N, int k) {
+  if (N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N = %lld is negative", (long long)N);
+  if (k < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "k = %d is negative", k);
+  if (k > GFICF_JACCARD_MAX_K)
+    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d exceeds GFICF_JACCARD_MAX_K = %d", k, GFICF_JACCARD_MAX_K);
+  if (N > 0x7FFFFFFFll) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "N = %lld exceeds int32 ids", (long long)N);
+  return GFICF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gficf_jaccard_kpad(int k) { return (k < 0 || k > GFICF_JACCARD_MAX_K) ? -1 : kpad_for(k); }
+
+int gficf_jaccard_ingest_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int64_t n_rows, int k,
+                                int64_t ld, int64_t N_total, int32_t* d_table_rows) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = check_nk(N_total, k);
+  if (rc) return rc;
+  if (n_rows < 0 || n_rows > N_total) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "n_rows = %lld outside [0, N_total]", (long long)n_rows);
+  if (n_rows == 0 || k == 0) return GFICF_OK;
+  if (!d_idx || !d_table_rows) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (ld < n_rows) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < n_rows = %lld", (long long)ld, (long long)n_rows);
+  if (idx_is_f64) return launch_ingest<double>(ctx, (const double*)d_idx, n_rows, k, ld, N_total, (uint32_t*)d_table_rows);
+  return launch_ingest<int32_t>(ctx, (const int32_t*)d_idx, n_rows, k, ld, N_total, (uint32_t*)d_table_rows);
+}
+
+int gficf_jaccard_edges_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k, int64_t cell_begin,
+                               int64_t cell_end, double* d_src, double* d_dst, double* d_w, int32_t* d_u) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = check_nk(N, k);
+  if (rc) return rc;
+  if (cell_begin < 0 || cell_end < cell_begin || cell_end > N)
+    GFICF_FAIL(GFICF_ERR_INVALID_ARG, "cell range [%lld, %lld) outside [0, %lld]", (long long)cell_begin, (long long)cell_end, (long long)N);
+  if (cell_end == cell_begin || k == 0) return GFICF_OK;
+  if (!d_table || !d_src || !d_dst || !d_w) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  EdgeOut o{d_src, d_dst, d_w, d_u};
+  const uint32_t* t = (const uint32_t*)d_table;
+  switch (kpad_for(k)) {
+    case 16: return launch_edges<16>(ctx, t, N, k, cell_begin, cell_end, o);
+    case 32: return launch_edges<32>(ctx, t, N, k, cell_begin, cell_end, o);
+    case 64: return launch_edges<64>(ctx, t, N, k, cell_begin, cell_end, o);
+    case 128: return launch_edges<128>(ctx, t, N, k, cell_begin, cell_end, o);
+    default: return launch_edges<256>(ctx, t, N, k, cell_begin, cell_end, o);
+  }
+}
+
+int gficf_jaccard_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int64_t N, int k, int64_t ld,
+                         int32_t* d_table_ws, double* d_rmat, int32_t* d_u) {
+  int rc = gficf_jaccard_ingest_device(ctx, d_idx, idx_is_f64, N, k, ld, N, d_table_ws);
+  if (rc) return rc;
+  const int64_t E = N * (int64_t)k;
+  return gficf_jaccard_edges_device(ctx, d_table_ws, N, k, 0, N, d_rmat, d_rmat + E, d_rmat + 2 * E, d_u);
+}
+
+int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld,
+                       double* rmat, int print_output) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = check_nk(N, k);
+  if (rc) return rc;
+  if (print_output) printf("Running Parallell Jaccard Coefficient Estimation...\n");  // reference :63
+  const int64_t E = N * (int64_t)k;
+  if (E > 0) {
+    if (!idx || !rmat) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
+    if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
+    const size_t esz = idx_is_f64 ? sizeof(double) : sizeof(int32_t);
+    const int kpad = kpad_for(k);
+    void* d_idx = nullptr;
+    int32_t* d_table = nullptr;
+    double* d_rmat = nullptr;
+    hipError_t e = hipMalloc(&d_idx, esz * (size_t)ld * (size_t)k);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_table, sizeof(int32_t) * (size_t)N * (size_t)kpad);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_rmat, sizeof(double) * 3 * (size_t)E);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, esz * (size_t)ld * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
+    rc = GFICF_OK;
+    if (e == hipSuccess) {
+      rc = gficf_jaccard_device(ctx, d_idx, idx_is_f64, N, k, ld, d_table, d_rmat, nullptr);
+      if (rc == GFICF_OK) e = hipMemcpyAsync(rmat, d_rmat, sizeof(double) * 3 * (size_t)E, hipMemcpyDeviceToHost, ctx->stream);
+      if (rc == GFICF_OK && e == hipSuccess) rc = gficf_ctx_sync(ctx);
+      else (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (d_idx) (void)hipFree(d_idx);
+    if (d_table) (void)hipFree(d_table);
+    if (d_rmat) (void)hipFree(d_rmat);
+    if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_jaccard_host: %s", hipGetErrorString(e));
+    if (rc) return rc;
+  }
+  if (print_output) printf("Done!!\n");  // reference :77
+  return GFICF_OK;
+}
+
+}  // extern "C"

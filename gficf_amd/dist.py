@@ -1,0 +1,105 @@
+"""Multi-GPU form of the hot path: one process per GPU, cells sharded by contiguous block.
+
+New design (the reference is single-process):
+
+* Jaccard — the edges of cell i need row i and the k rows it names, which may live on any
+  rank, so there is exactly one exchange step: every rank transposes its own block of the
+  kNN matrix into table rows, then ONE all-gather (RCCL over xGMI) replicates the
+  int32 table, then every rank builds the edges of its own cell block.  No other
+  collective touches the data path; outputs stay sharded (each rank owns rows
+  [b*k, e*k) of the reference's edge matrix).
+* GF-ICF — cells (columns) are independent except for the per-gene cell counts nt_g, so
+  there is exactly one all-reduce(sum) of G int64 counters between the counting pass and
+  the scaling pass.
+
+``ops`` is the object that runs the stage kernels (``gficf_amd.api.HipOps`` in the product
+path).  It is a parameter only so that the collective / sharding logic can be exercised on
+CPU with the gloo backend and a test double; there is no fallback here.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def rows_per_rank(n: int, world: int) -> int:
+    return (n + world - 1) // world
+
+
+def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous, equal-pitch cell blocks: rank r owns [r*rpr, min(n, (r+1)*rpr))."""
+    rpr = rows_per_rank(n, world)
+    b = min(n, rank * rpr)
+    return b, min(n, b + rpr)
+
+
+def _all_gather_rows(table, local_view, group):
+    """All-gather equal-sized row blocks into ``table`` (``local_view`` aliases this rank's block)."""
+    try:
+        dist.all_gather_into_tensor(table, local_view, group=group)
+    except (RuntimeError, NotImplementedError):
+        # backend without a flat all-gather (older gloo): gather into per-rank views
+        world = dist.get_world_size(group)
+        chunks = list(table.view(world, -1).unbind(0))
+        dist.all_gather(chunks, local_view.reshape(-1).clone(), group=group)
+
+
+class JaccardShard:
+    """Per-rank state of the sharded Jaccard build (buffers allocated once, reused per step)."""
+
+    def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False):
+        self.ops, self.N, self.k, self.group = ops, int(N_total), int(k), group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.kpad = ops.kpad(k)
+        self.rpr = rows_per_rank(self.N, self.world)
+        self.b, self.e = shard_bounds(self.N, self.world, self.rank)
+        self.n_local = self.e - self.b
+        # full table, padded to world*rpr rows so that every rank contributes an equal block
+        self.table = torch.zeros((self.world * self.rpr, self.kpad), dtype=torch.int32, device=device)
+        self.out = torch.zeros((3, self.n_local * self.k), dtype=torch.float64, device=device)
+        self.u = torch.zeros(self.n_local * self.k, dtype=torch.int32, device=device) if with_u else None
+
+    def step(self, idx_local_cm):
+        """idx_local_cm: (k, n_local) tensor == column-major n_local x k block of the kNN matrix
+        (global 1-based ids).  Returns this rank's (3, n_local*k) slice of the edge matrix."""
+        my_rows = self.table[self.rank * self.rpr:(self.rank + 1) * self.rpr]
+        if self.n_local > 0:
+            self.ops.jaccard_ingest(idx_local_cm, self.n_local, self.k, self.N, my_rows)
+        if self.world > 1:
+            _all_gather_rows(self.table.view(-1), my_rows.reshape(-1), self.group)
+        if self.n_local > 0:
+            self.ops.jaccard_edges(self.table, self.N, self.k, self.b, self.e, self.out, self.u)
+        return self.out
+
+
+class GficfShard:
+    """Per-rank state of the sharded GF-ICF normalisation (local CSC block of cells)."""
+
+    def __init__(self, ops, G: int, N_total: int, n_local: int, nnz_local: int, group=None, device=None):
+        self.ops, self.G, self.N, self.n_local, self.group = ops, int(G), int(N_total), int(n_local), group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        dev = device
+        self.ws = dict(
+            nt=torch.zeros(max(G, 1), dtype=torch.int64, device=dev),
+            keep=torch.zeros(max(G, 1), dtype=torch.uint8, device=dev),
+            remap=torch.zeros(max(G, 1), dtype=torch.int32, device=dev),
+            w=torch.zeros(max(G, 1), dtype=torch.float64, device=dev),
+            gkept=torch.zeros(1, dtype=torch.int64, device=dev),
+            out_colptr=torch.zeros(n_local + 1, dtype=torch.int64, device=dev),
+            out_rowidx=torch.zeros(max(nnz_local, 1), dtype=torch.int32, device=dev),
+            out_x=torch.zeros(max(nnz_local, 1), dtype=torch.float64, device=dev),
+        )
+
+    def step(self, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None):
+        """colptr (int64, n_local+1, starting at 0), rowidx, x: this rank's block of cells."""
+        ws, ops = self.ws, self.ops
+        ws["nt"].zero_()
+        ops.csc_count(self.G, self.n_local, colptr, rowidx, x, ws["nt"])
+        if self.world > 1:
+            dist.all_reduce(ws["nt"], op=dist.ReduceOp.SUM, group=self.group)
+        ops.csc_genes(self.G, self.N, ws["nt"], prop_min, prop_max, w_in, ws["keep"], ws["remap"], ws["w"], ws["gkept"])
+        ops.csc_colptr(self.G, self.n_local, colptr, rowidx, ws["keep"], ws["gkept"], ws["out_colptr"])
+        ops.csc_scale(self.G, self.n_local, colptr, rowidx, x, ws["remap"], ws["w"], ws["out_colptr"],
+                      ws["out_rowidx"], ws["out_x"])
+        return ws

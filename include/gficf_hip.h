@@ -1,0 +1,179 @@
+/* gficf_hip.h — C ABI of libgficf_hip.so: MI355X (gfx950) GF-ICF normalisation and
+ * Phenograph kNN -> Jaccard edge build.
+ *
+ * This is the drop-in boundary for ONE hot path of the dibbelab/gficf R package.  Plain
+ * pointers and sizes only; no R, Rcpp or torch types.  Every entry point cites the
+ * reference interface it replaces (paths relative to the reference repository).  The R
+ * `.Call` glue a maintainer would add on top of it is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns a gficf_status (0 = OK); gficf_last_error() gives the
+ *     message for the calling thread's last failure.  Nothing here aborts or throws.
+ *   - "host" entry points take caller-owned host buffers and do H2D / compute / D2H
+ *     themselves (this is what the R glue binds).  "device" entry points take caller-
+ *     owned device buffers (HBM-resident) and only enqueue work on the context's stream;
+ *     call gficf_ctx_sync() to wait and to collect deferred input-validation errors.
+ *   - ids in kNN matrices are 1-based, as R hands them over.
+ *   - matrices are column-major (R layout) unless stated otherwise.
+ */
+#ifndef GFICF_HIP_H
+#define GFICF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFICF_HIP_ABI_VERSION 1
+
+typedef enum gficf_status {
+  GFICF_OK = 0,
+  GFICF_ERR_INVALID_ARG = 1,   /* NULL pointer, negative size, k out of range ...          */
+  GFICF_ERR_BAD_ID = 2,        /* a kNN id outside [1, N] or not an integer (the reference
+                                  has undefined behaviour there:
+                                  src/rcpp_parallel_jaccard_coeff.cpp:28,34)               */
+  GFICF_ERR_BAD_CSC = 3,       /* rowidx outside [0, G), colptr not monotone               */
+  GFICF_ERR_NO_DEVICE = 4,     /* no HIP device / device index out of range                */
+  GFICF_ERR_HIP = 5,           /* a HIP runtime call failed; message has hipGetErrorString */
+  GFICF_ERR_UNSUPPORTED = 6,   /* k > GFICF_JACCARD_MAX_K, table too large for the kernel  */
+  GFICF_ERR_CAPACITY = 7       /* caller-provided output buffer too small                  */
+} gficf_status;
+
+#define GFICF_JACCARD_MAX_K 256
+
+typedef struct gficf_ctx gficf_ctx;  /* one per (thread, device): stream, workspace, status */
+
+/* ------------------------------------------------------------------ library / context */
+int gficf_hip_abi_version(void);
+/* Number of HIP devices (does not create a context on any of them). */
+int gficf_device_count(int* count);
+/* device: HIP device ordinal.  stream: a hipStream_t owned by the caller, or NULL for the
+ * device's default (null) stream.  Work of every *_device call is enqueued there. */
+int gficf_ctx_create(int device, void* stream, gficf_ctx** out);
+void gficf_ctx_destroy(gficf_ctx* ctx);
+/* Rebind the stream later work is enqueued on (e.g. torch's current stream). */
+int gficf_ctx_set_stream(gficf_ctx* ctx, void* stream);
+/* Wait for the stream, then report (and clear) deferred device-side validation errors
+ * (GFICF_ERR_BAD_ID / GFICF_ERR_BAD_CSC) of the *_device calls enqueued since last sync. */
+int gficf_ctx_sync(gficf_ctx* ctx);
+const char* gficf_last_error(void);
+
+/* ----------------------------------------------------------------------------- Jaccard
+ * Replaces  SEXP _gficf_rcpp_parallel_jaccard_coef(SEXP mat, SEXP printOutput)
+ *           (src/RcppExports.cpp:61-70, registered :89) ->
+ *           rcpp_parallel_jaccard_coef()  (src/rcpp_parallel_jaccard_coeff.cpp:59-80) ->
+ *           JCoefficient::operator()      (src/rcpp_parallel_jaccard_coeff.cpp:24-55).
+ *
+ * For every cell i in [0,N) and slot j in [0,k):  kk = idx(i,j);
+ *   u = | multiset(row i) ∩ multiset(row kk) |          (std::set_intersection semantics)
+ *   u > 0 : rmat row i*k+j = (i+1, kk, u / (2.0*k - u));   u == 0 : the row stays 0.
+ */
+
+/* Host form.  idx: N x k column-major with leading dimension ld (>= N), int32
+ * (idx_is_f64 == 0; what uwot returns) or double (idx_is_f64 != 0; what Rcpp coerces to,
+ * src/RcppExports.cpp:65).  rmat: caller-allocated (N*k) x 3 column-major doubles
+ * (src/rcpp_parallel_jaccard_coeff.cpp:67), fully overwritten.
+ * print_output mirrors the reference's printOutput banners (:61-64, :75-78) on stdout. */
+int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k,
+                       int64_t ld, double* rmat, int print_output);
+
+/* Device-resident pipeline, split where a multi-GPU caller needs the seam:
+ *   1. ingest : column-major ids of a block of cells -> row-major padded int32 table rows
+ *   2. (multi-GPU only) the caller all-gathers the table rows of all blocks (RCCL)
+ *   3. edges  : table + a block of cells -> that block's rows of rmat
+ */
+
+/* Row pitch (int32 elements) of the table for a given k: 16, 32, 64, 128 or 256. */
+int gficf_jaccard_kpad(int k);
+
+/* d_idx: n_rows x k column-major (ld >= n_rows) device matrix holding the neighbour ids
+ * of cells [row0, row0+n_rows) of an N_total-cell data set.  Writes d_table_rows
+ * (n_rows x kpad int32, row-major; caller passes the address of the block's first row).
+ * Ids are validated against [1, N_total]; failures are reported by gficf_ctx_sync(). */
+int gficf_jaccard_ingest_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64,
+                                int64_t n_rows, int k, int64_t ld, int64_t N_total,
+                                int32_t* d_table_rows);
+
+/* d_table: the FULL N x kpad table.  Computes edges of cells [cell_begin, cell_end).
+ * d_src/d_dst/d_w: three arrays of (cell_end-cell_begin)*k doubles — the block's slice of
+ * the three columns of rmat (pass rmat + cell_begin*k, rmat + E + cell_begin*k,
+ * rmat + 2E + cell_begin*k to land directly in the reference layout).
+ * d_u: optional (may be NULL) int32 intersection counts, same indexing. */
+int gficf_jaccard_edges_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k,
+                               int64_t cell_begin, int64_t cell_end, double* d_src,
+                               double* d_dst, double* d_w, int32_t* d_u);
+
+/* Single-GPU convenience: ingest + edges, d_rmat in the reference layout ((N*k) x 3
+ * column-major).  d_table_ws: caller-provided workspace of N*kpad int32 (kept by the
+ * caller so that no allocation happens per call), d_u optional. */
+int gficf_jaccard_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int64_t N, int k,
+                         int64_t ld, int32_t* d_table_ws, double* d_rmat, int32_t* d_u);
+
+/* ------------------------------------------------------------------------------ GF-ICF
+ * Replaces the R-level chain of gficf()  (R/gficf.R:17-33, normalize = FALSE):
+ *   normCounts filter R/gficf.R:40-41, tf R/gficf.R:59, getIdfW("classic") R/gficf.R:88-89,
+ *   idf R/gficf.R:79, l.norm("l2") R/gficf.R:100-103 (applied per cell, R/gficf.R:25);
+ * and, with w_in != NULL, the same chain as used by embedNewCells() R/cellClassifier.R:50-53.
+ * The reference has no native entry for this path; this is the new one.
+ *
+ * Input: CSC genes x cells (dgCMatrix slots): colptr = @p (N+1 entries, int32 when
+ * colptr_is_i64 == 0, else int64), rowidx = @i (0-based int32, sorted within a column),
+ * x = @x (double).  Genes are kept iff  nt_g > N*prop_min  &&  nt_g <= N*prop_max  where
+ * nt_g = #{cells with a non-zero entry}.  Output value of a stored kept entry:
+ *     ((x / S_c) * w_g) * (1 / sqrt(sum_g' ((x'/S_c) * w_g')^2)),  S_c = sum of kept x of cell c,
+ *     w_g = log((N+1)/(nt_g+1))   (or w_in[g]).
+ * Cells with S_c == 0 get 0.0 in every stored kept entry (R would produce NaN).
+ */
+
+/* Host form, two calls so that the caller (R glue) can allocate exactly-sized outputs:
+ *   plan   : uploads the matrix, counts, filters; returns G_kept and nnz_kept.
+ *   finish : writes keep[G] (0/1), nt[G] (raw count of every gene, dropped ones included),
+ *            w[G] (0 for dropped genes), out_colptr[N+1]
+ *            (same integer width as the input colptr), out_rowidx[nnz_kept] (renumbered
+ *            over kept genes), out_x[nnz_kept]; releases the plan.  Any of keep/nt/w may
+ *            be NULL.
+ * w_in: NULL, or G weights indexed by original gene (ICF weights supplied). */
+int gficf_normalize_csc_host_plan(gficf_ctx* ctx, int64_t G, int64_t N, const void* colptr,
+                                  int colptr_is_i64, const int32_t* rowidx, const double* x,
+                                  double prop_min, double prop_max, const double* w_in,
+                                  int64_t* G_kept, int64_t* nnz_kept);
+int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, double* w,
+                                    void* out_colptr, int32_t* out_rowidx, double* out_x);
+
+/* Device-resident pipeline (all pointers are device memory; colptr is int64 here), split
+ * where a multi-GPU caller needs the seam (cells sharded by column block):
+ *   1. count   : d_nt[g] += #{local cells with non-zero entry of gene g}   (d_nt zeroed by caller)
+ *   2. (multi-GPU only) caller all-reduces d_nt (sum) over ranks
+ *   3. genes   : d_nt, N_total -> d_keep[G] (uint8), d_remap[G] (new row id or -1), d_w[G],
+ *                d_gkept[1] (int64)
+ *   4. colptr  : per-cell kept counts + exclusive scan -> d_out_colptr[n_cells+1] (int64)
+ *   5. scale   : writes d_out_rowidx / d_out_x (capacity >= kept nnz; nnz always suffices)
+ */
+int gficf_csc_count_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
+                           const int32_t* d_rowidx, const double* d_x, int64_t nnz,
+                           int64_t* d_nt);
+int gficf_csc_genes_device(gficf_ctx* ctx, int64_t G, int64_t N_total, const int64_t* d_nt,
+                           double prop_min, double prop_max, const double* d_w_in,
+                           uint8_t* d_keep, int32_t* d_remap, double* d_w, int64_t* d_gkept);
+int gficf_csc_colptr_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
+                            const int32_t* d_rowidx, const uint8_t* d_keep,
+                            const int64_t* d_gkept, int64_t* d_out_colptr);
+int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
+                           const int32_t* d_rowidx, const double* d_x, int64_t nnz,
+                           const int32_t* d_remap, const double* d_w,
+                           const int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x);
+
+/* Single-GPU convenience: steps 1,3,4,5 back to back on the context's stream.  Output
+ * buffers need capacity nnz (upper bound); *d_out_colptr[n_cells] holds the kept nnz. */
+int gficf_csc_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colptr,
+                     const int32_t* d_rowidx, const double* d_x, int64_t nnz, double prop_min,
+                     double prop_max, const double* d_w_in, int64_t* d_nt, uint8_t* d_keep,
+                     int32_t* d_remap, double* d_w, int64_t* d_gkept, int64_t* d_out_colptr,
+                     int32_t* d_out_rowidx, double* d_out_x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFICF_HIP_H */

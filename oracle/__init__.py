@@ -1,0 +1,110 @@
+"""CPU oracle for the GF-ICF / Jaccard hot path — TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this package, and only as the checker / timed CPU baseline.  The product package
+``gficf_amd`` never imports it.
+
+PARITY UNPINNED: the reference (dibbelab/gficf) has no tests or golden vectors for this
+path, R is absent from this image and the reference's Jaccard translation unit needs
+Rcpp / RcppParallel headers that are absent too, so neither restatement could be checked
+against the reference itself.  See ``jaccard_oracle.cpp`` / ``gficf_oracle.cpp`` headers.
+
+Two independent writings of the same algorithm live here:
+  * ``liboracle.so``  — C++ (``jaccard_oracle.cpp``, ``gficf_oracle.cpp``), built by
+    ``make -C oracle``; this is also the timed CPU baseline.
+  * ``oracle_np``     — numpy/scipy, used to cross-check the C++ one.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with g++ (make -C oracle)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_LIB_PATH)
+        for s in ("jaccard_oracle.cpp", "gficf_oracle.cpp")
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        i64, i32, dbl = ctypes.c_int64, ctypes.c_int, ctypes.c_double
+        vp = ctypes.c_void_p
+        L.oracle_jaccard_f64.restype = i32
+        L.oracle_jaccard_f64.argtypes = [vp, i64, i32, vp, vp, i32]
+        L.oracle_jaccard_i32.restype = i32
+        L.oracle_jaccard_i32.argtypes = [vp, i64, i32, vp, vp, i32]
+        L.oracle_gficf_csc.restype = i32
+        L.oracle_gficf_csc.argtypes = [i64, i64, vp, vp, vp, dbl, dbl, vp] + [vp] * 8
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def jaccard(mat: np.ndarray, nthreads: int = 1):
+    """Reference-layout Jaccard: ``mat`` is N x k (ids 1-based; int32 or float64).
+
+    Returns (rmat, u): rmat is the (N*k) x 3 float64 matrix of
+    rcpp_parallel_jaccard_coef (reference src/rcpp_parallel_jaccard_coeff.cpp:59-80),
+    u the N*k int32 intersection counts in edge order i*k+j.
+    """
+    N, k = mat.shape
+    E = N * k
+    rm = np.empty((3, E), dtype=np.float64)  # column-major (E x 3) == C-order (3 x E)
+    u = np.empty(E, dtype=np.int32)
+    if mat.dtype == np.int32:
+        m = np.asfortranarray(mat)
+        rc = lib().oracle_jaccard_i32(_p(m), N, k, _p(rm), _p(u), nthreads)
+    else:
+        m = np.asfortranarray(mat, dtype=np.float64)
+        rc = lib().oracle_jaccard_f64(_p(m), N, k, _p(rm), _p(u), nthreads)
+    if rc != 0:
+        raise ValueError(f"oracle_jaccard: invalid input (rc={rc})")
+    return rm.T, u  # view: (E x 3), Fortran-ordered like the R matrix
+
+
+def gficf_csc(G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None):
+    """GF-ICF on a CSC genes x cells matrix (reference R/gficf.R:17-33, normalize=FALSE).
+
+    Returns dict(keep, nt, w, colptr, rowidx, x, G_kept).
+    """
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+    rowidx = np.ascontiguousarray(rowidx, dtype=np.int32)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    nnz = int(colptr[N])
+    keep = np.zeros(G, dtype=np.uint8)
+    nt = np.zeros(G, dtype=np.int64)
+    w = np.zeros(G, dtype=np.float64)
+    ocp = np.zeros(N + 1, dtype=np.int64)
+    ori = np.zeros(max(nnz, 1), dtype=np.int32)
+    ox = np.zeros(max(nnz, 1), dtype=np.float64)
+    gk = ctypes.c_int64(0)
+    nk = ctypes.c_int64(0)
+    if w_in is not None:
+        w_in = np.ascontiguousarray(w_in, dtype=np.float64)
+    rc = lib().oracle_gficf_csc(
+        G, N, _p(colptr), _p(rowidx), _p(x), float(prop_min), float(prop_max), _p(w_in),
+        _p(keep), _p(nt), _p(w), _p(ocp), _p(ori), _p(ox),
+        ctypes.cast(ctypes.byref(gk), ctypes.c_void_p), ctypes.cast(ctypes.byref(nk), ctypes.c_void_p))
+    if rc != 0:
+        raise ValueError(f"oracle_gficf_csc: malformed CSC (rc={rc})")
+    n = nk.value
+    return dict(keep=keep.astype(bool), nt=nt, w=w, colptr=ocp, rowidx=ori[:n].copy(),
+                x=ox[:n].copy(), G_kept=gk.value)

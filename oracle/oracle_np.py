@@ -1,0 +1,133 @@
+"""Independent numpy/scipy restatement of the hot path — TEST INFRASTRUCTURE ONLY.
+
+Second writing of the same reference lines as ``jaccard_oracle.cpp`` / ``gficf_oracle.cpp``,
+deliberately through a different formulation (multiset keys + broadcasting for Jaccard;
+scipy.sparse matrix algebra for GF-ICF) so that the two can cross-check each other.
+PARITY UNPINNED for the same reason as the C++ oracle (no runnable reference here).
+
+Citations relative to /root/reference.
+"""
+from __future__ import annotations
+
+from collections import Counter
+
+import numpy as np
+import scipy.sparse as sp
+
+
+# --------------------------------------------------------------------------- Jaccard
+def jaccard_counts_py(mat: np.ndarray) -> np.ndarray:
+    """Pure-Python multiset intersection counts (small cases only).
+
+    u[i*k+j] = |sorted(row i) ∩ sorted(row mat[i,j])| with std::set_intersection
+    semantics (src/rcpp_parallel_jaccard_coeff.cpp:38-46): every value counts
+    min(multiplicity in row i, multiplicity in the neighbour row) times.
+    """
+    N, k = mat.shape
+    rows = [Counter(int(v) for v in mat[i]) for i in range(N)]
+    u = np.zeros(N * k, dtype=np.int32)
+    for i in range(N):
+        for j in range(k):
+            kk = int(mat[i, j] - 1)                       # :28
+            u[i * k + j] = sum((rows[i] & rows[kk]).values())
+    return u
+
+
+def jaccard_counts_np(mat: np.ndarray, block: int = 512) -> np.ndarray:
+    """Vectorised multiset intersection counts.
+
+    Each row element gets the key (value, occurrence-rank-within-row); keys are distinct
+    within a row and |A ∩ B|_multiset == number of equal keys, so the count is a plain
+    broadcast equality sum.
+    """
+    mat = np.asarray(mat)
+    N, k = mat.shape
+    ids = mat.astype(np.int64)
+    order = np.argsort(ids, axis=1, kind="stable")
+    srt = np.take_along_axis(ids, order, axis=1)
+    same = np.zeros((N, k), dtype=np.int64)
+    for t in range(1, k):
+        same[:, t] = np.where(srt[:, t] == srt[:, t - 1], same[:, t - 1] + 1, 0)
+    keys = srt * (k + 1) + same                      # N x k, sorted, distinct per row
+    u = np.empty((N, k), dtype=np.int32)
+    dst = ids - 1
+    for b0 in range(0, N, block):
+        b1 = min(N, b0 + block)
+        A = keys[b0:b1]                               # B x k
+        Bn = keys[dst[b0:b1]]                         # B x k(slot) x k
+        eq = A[:, None, :, None] == Bn[:, :, None, :]  # B x slot x k x k
+        u[b0:b1] = eq.sum(axis=(2, 3))
+    return u.reshape(-1)
+
+
+def jaccard_rmat(mat: np.ndarray, u: np.ndarray | None = None) -> np.ndarray:
+    """(N*k) x 3 output of rcpp_parallel_jaccard_coef (:48-52, :67): rows with u == 0
+    stay zero; others are (i+1, kk+1, u/(2.0*k-u))."""
+    mat = np.asarray(mat)
+    N, k = mat.shape
+    if u is None:
+        u = jaccard_counts_np(mat)
+    E = N * k
+    rm = np.zeros((E, 3), dtype=np.float64, order="F")
+    src = np.repeat(np.arange(1, N + 1, dtype=np.float64), k)
+    dst = np.trunc(mat.astype(np.float64) - 1.0).reshape(-1) + 1.0
+    ud = u.astype(np.float64)
+    pos = u > 0
+    rm[pos, 0] = src[pos]
+    rm[pos, 1] = dst[pos]
+    rm[pos, 2] = ud[pos] / (2.0 * k - ud[pos])
+    return rm
+
+
+# ---------------------------------------------------------------------------- GF-ICF
+def gficf_np(M: sp.csc_matrix, prop_min: float = 0.05, prop_max: float = 1.0, w_in=None):
+    """gficf(M, normalize=FALSE) on a scipy CSC genes x cells matrix (R/gficf.R:17-33).
+
+    Returns dict(keep, nt, w (per ORIGINAL gene, 0 where dropped), gficf (CSC over kept
+    genes)).  Written with sparse-matrix algebra, the way the R code is.
+    """
+    M = sp.csc_matrix(M, dtype=np.float64, copy=True)
+    M.sort_indices()
+    G, N = M.shape
+    # R/gficf.R:40-41
+    ix = np.asarray((M != 0).sum(axis=1)).ravel().astype(np.int64)
+    keep = (ix.astype(np.float64) > N * prop_min) & (ix.astype(np.float64) <= N * prop_max)
+    Mk = sp.csc_matrix(M[np.flatnonzero(keep), :])
+    Mk.sort_indices()
+    # R/gficf.R:59   t(t(M) / colSums(M))  — sequential storage-order sums
+    cnt = np.diff(Mk.indptr)
+    S = np.zeros(N, dtype=np.float64)
+    for c in range(N):
+        s = 0.0
+        for v in Mk.data[Mk.indptr[c]:Mk.indptr[c + 1]]:
+            s += v
+        S[c] = s
+    Srep = np.repeat(S, cnt)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tf = np.where(Srep != 0.0, Mk.data / Srep, 0.0)   # defined-zero for S == 0 (see C++ header)
+    TF = sp.csc_matrix((tf, Mk.indices, Mk.indptr), shape=Mk.shape)
+    # R/gficf.R:88-89
+    ntk = np.bincount(TF.indices[TF.data != 0], minlength=Mk.shape[0]).astype(np.int64)
+    if w_in is None:
+        wk = np.log((N + 1.0) / (ntk + 1.0))
+    else:
+        wk = np.asarray(w_in, dtype=np.float64)[keep]
+    # R/gficf.R:79
+    v = TF.data * wk[TF.indices]
+    # R/gficf.R:100-103
+    ss = np.zeros(N, dtype=np.float64)
+    for c in range(N):
+        s = 0.0
+        for t in v[TF.indptr[c]:TF.indptr[c + 1]]:
+            s += t * t
+        ss[c] = s
+    with np.errstate(divide="ignore"):
+        nv = 1.0 / np.sqrt(ss)
+    nv[np.isinf(nv)] = 0.0
+    out = np.repeat(nv, cnt) * v
+    nt = np.zeros(G, dtype=np.int64)
+    w = np.zeros(G, dtype=np.float64)
+    nt[keep] = ntk
+    w[keep] = wk
+    return dict(keep=keep, nt=nt, w=w,
+                gficf=sp.csc_matrix((out, TF.indices, TF.indptr), shape=Mk.shape))

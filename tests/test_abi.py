@@ -1,0 +1,70 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gficf_hip.h declares
+(no compute calls — there is no GPU here), and fails loudly without a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gficf_amd
+from gficf_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "gficf_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gficf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    L = _lib.load()
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in gficf_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_abi_version_and_kpad():
+    L = _lib.load()
+    assert L.gficf_hip_abi_version() == 1
+    assert [L.gficf_jaccard_kpad(k) for k in (0, 1, 15, 16, 17, 30, 32, 33, 50, 64, 65, 128, 129, 256)] == \
+        [16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 128, 128, 256, 256]
+    assert L.gficf_jaccard_kpad(257) == -1 and L.gficf_jaccard_kpad(-1) == -1
+
+
+def test_status_enum_matches_header():
+    src = open(os.path.join(ROOT, "include", "gficf_hip.h")).read()
+    for code, name in _lib.STATUS_NAMES.items():
+        assert re.search(rf"\b{name}\s*=\s*{code}\b", src), name
+
+
+@pytest.mark.skipif(gficf_amd.device_count() > 0, reason="GPU present")
+def test_no_gpu_fails_loudly_no_fallback():
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        gficf_amd.Context(0)
+    assert ei.value.status == "GFICF_ERR_NO_DEVICE"
+    with pytest.raises(gficf_amd.GficfError):
+        gficf_amd.rcpp_parallel_jaccard_coef(np.array([[2], [1]], dtype=np.int32), False)
+
+
+def test_null_ctx_is_rejected_not_crashing():
+    L = _lib.load()
+    rc = L.gficf_ctx_sync(None)
+    assert rc == 1 and b"ctx" in L.gficf_last_error()
+    rc = L.gficf_jaccard_host(None, None, 0, 10, 3, 10, None, 0)
+    assert rc == 1
+
+
+def test_product_package_never_imports_oracle():
+    pkg = os.path.join(ROOT, "gficf_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
+                assert "liboracle" not in txt, f

@@ -1,0 +1,192 @@
+"""GPU parity: the HIP GF-ICF path (through the C ABI) against the CPU oracle.
+Bar: keep mask, nt, structure (colptr / renumbered rowidx) exact; values and weights
+within 1e-6 (absolute and relative) as BASELINE.json states — f64 throughout, observed
+differences are ~1e-16 (summation order only)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import gficf_amd
+import oracle
+from gficf_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def check_against_oracle(res, ref, N):
+    keep = ref["keep"]
+    assert np.array_equal(res["genes"], np.flatnonzero(keep))
+    assert np.array_equal(res["nt"], ref["nt"][keep])
+    g = res["gficf"]
+    assert g.shape == (int(keep.sum()), N)
+    assert np.array_equal(g.indptr, ref["colptr"])
+    assert np.array_equal(g.indices, ref["rowidx"])
+    assert np.allclose(g.data, ref["x"], rtol=TOL, atol=TOL)
+    assert np.allclose(res["w"], ref["w"][keep], rtol=TOL, atol=TOL)
+    # much tighter in practice
+    assert np.abs(g.data - ref["x"]).max(initial=0.0) < 1e-12
+
+
+def test_known_answers(golden_dir):
+    with open(os.path.join(golden_dir, "known_answers.json")) as f:
+        known = json.load(f)["gficf"]
+    for nm in ("basic", "filter", "w_zero_cell"):
+        c = known[nm]
+        M = sp.csc_matrix(np.array(c["M"], dtype=float))
+        res = gficf_amd.gficf(M, cell_proportion_max=c["max"], cell_proportion_min=c["min"], normalize=False, verbose=False)
+        assert np.allclose(res["gficf"].toarray(), np.array(c["dense"]), rtol=0, atol=1e-14), nm
+        if "w" in c:
+            assert np.allclose(res["w"], np.array(c["w"]), rtol=0, atol=1e-15)
+        if "keep" in c:
+            assert res["genes"].tolist() == [i for i, kp in enumerate(c["keep"]) if kp]
+
+
+@pytest.mark.parametrize("G,N,mn,mx,seed", [(600, 400, 0.05, 1.0, 7), (300, 500, 0.0, 1.0, 8), (500, 300, 0.02, 0.6, 9),
+                                            (5000, 3000, 0.05, 1.0, 7), (20000, 2000, 0.05, 1.0, 3),
+                                            (40000, 500, 0.01, 1.0, 4), (1, 50, 0.0, 1.0, 5), (50, 1, 0.0, 1.0, 6)])
+def test_matches_oracle(G, N, mn, mx, seed):
+    cp, ri, x = synth.counts_csc(G, N, seed=seed)
+    M = sp.csc_matrix((x, ri, cp), shape=(G, N))
+    res = gficf_amd.gficf(M, cell_proportion_max=mx, cell_proportion_min=mn, normalize=False, verbose=False)
+    ref = oracle.gficf_csc(G, N, cp, ri, x, mn, mx)
+    check_against_oracle(res, ref, N)
+    assert res["param"] == {"cell_proportion_max": mx, "cell_proportion_min": mn, "normalized": False}
+    assert (res["rawCounts"] != M[res["genes"], :]).nnz == 0
+
+
+def test_golden_fixtures(golden_dir):
+    z = np.load(os.path.join(golden_dir, "gficf_cases.npz"))
+    for nm in ("g600_n400", "g300_n500_nofilter", "g500_n300_max"):
+        G, N, seed = (int(v) for v in z[nm + "_meta"])
+        mn, mx = z[nm + "_prop"]
+        cp, ri, x = synth.counts_csc(G, N, seed=seed)
+        res = gficf_amd.gficf(sp.csc_matrix((x, ri, cp), shape=(G, N)), mx, mn, normalize=False, verbose=False)
+        assert np.array_equal(res["genes"], np.flatnonzero(z[nm + "_keep"]))
+        assert np.array_equal(res["gficf"].indptr, z[nm + "_colptr"])
+        assert np.array_equal(res["gficf"].indices, z[nm + "_rowidx"])
+        assert np.allclose(res["gficf"].data, z[nm + "_x"], rtol=TOL, atol=TOL)
+
+
+def test_int32_and_int64_colptr_agree():
+    cp, ri, x = synth.counts_csc(800, 600, seed=2)
+    M32 = sp.csc_matrix((x, ri, cp.astype(np.int32)), shape=(800, 600))
+    M64 = sp.csc_matrix((x, ri, cp.astype(np.int64)), shape=(800, 600))
+    M64.indptr = M64.indptr.astype(np.int64)
+    a = gficf_amd.gficf(M32, normalize=False, verbose=False)["gficf"]
+    b = gficf_amd.gficf(M64, normalize=False, verbose=False)["gficf"]
+    assert np.array_equal(a.data, b.data) and np.array_equal(a.indices, b.indices)
+
+
+def test_supplied_weights_second_caller():
+    # embedNewCells(): reference R/cellClassifier.R:50-53 — ICF weights supplied, not recomputed
+    G, N = 700, 300
+    cp, ri, x = synth.counts_csc(G, N, seed=12)
+    w_in = 0.25 + synth.rand_unit(13, np.arange(G))
+    out, genes = gficf_amd.gficf_with_weights(sp.csc_matrix((x, ri, cp), shape=(G, N)), w_in)
+    ref = oracle.gficf_csc(G, N, cp, ri, x, 0.0, 2.0, w_in=w_in)
+    assert np.array_equal(genes, np.flatnonzero(ref["keep"]))
+    assert np.array_equal(out.indices, ref["rowidx"]) and np.array_equal(out.indptr, ref["colptr"])
+    assert np.allclose(out.data, ref["x"], rtol=TOL, atol=TOL)
+
+
+def test_empty_cells_explicit_zeros_and_empty_matrix():
+    colptr = np.array([0, 2, 2, 4, 4], dtype=np.int32)
+    rowidx = np.array([0, 1, 0, 1], dtype=np.int32)
+    x = np.array([1.0, 3.0, 0.0, 2.0])
+    M = sp.csc_matrix((x, rowidx, colptr), shape=(2, 4))
+    res = gficf_amd.gficf(M, 1, 0.0, normalize=False, verbose=False)
+    ref = oracle.gficf_csc(2, 4, colptr, rowidx, x, 0.0, 1.0)
+    check_against_oracle(res, ref, 4)
+    # nothing stored at all
+    E = sp.csc_matrix((5, 3))
+    r = gficf_amd.gficf(E, normalize=False, verbose=False)
+    assert r["gficf"].shape == (0, 3) and r["gficf"].nnz == 0
+
+
+def test_all_genes_filtered_out():
+    cp, ri, x = synth.counts_csc(300, 200, seed=3)
+    res = gficf_amd.gficf(sp.csc_matrix((x, ri, cp), shape=(300, 200)), 1, 1.0, normalize=False, verbose=False)
+    assert res["gficf"].shape == (0, 200) and res["gficf"].nnz == 0
+
+
+def test_malformed_csc_rejected():
+    ctx = gficf_amd.default_context()
+    from gficf_amd import api
+
+    cp = np.array([0, 2, 1], dtype=np.int64)
+    bad = sp.csc_matrix((3, 2))
+    bad.indptr, bad.indices, bad.data = cp, np.array([0, 1], dtype=np.int32), np.array([1.0, 2.0])
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        api._normalize_csc_host(bad, 0.0, 1.0, None, ctx)
+    assert ei.value.status == "GFICF_ERR_BAD_CSC"
+    bad2 = sp.csc_matrix((3, 2))
+    bad2.indptr, bad2.indices, bad2.data = np.array([0, 1, 2], dtype=np.int64), np.array([0, 7], dtype=np.int32), np.array([1.0, 2.0])
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        api._normalize_csc_host(bad2, 0.0, 1.0, None, ctx)
+    assert ei.value.status == "GFICF_ERR_BAD_CSC"
+
+
+def test_device_pipeline_and_cell_block_seam():
+    """Device-resident stages; two column blocks + summed counts == the single-shot result
+    (the multi-GPU seam exercised on one GPU)."""
+    import torch
+
+    ops = gficf_amd.HipOps(0)
+    G, N = 3000, 2500
+    cp, ri, x = synth.counts_csc(G, N, seed=17)
+    ref = oracle.gficf_csc(G, N, cp, ri, x, 0.05, 1.0)
+    d = lambda a: torch.from_numpy(a).cuda()
+    ws = ops.gficf_csc(G, N, d(cp), d(ri), d(x), 0.05, 1.0)
+    ops.sync()
+    nk = int(ws["out_colptr"][N])
+    assert int(ws["gkept"][0]) == ref["G_kept"] and nk == len(ref["x"])
+    assert np.array_equal(ws["out_colptr"].cpu().numpy(), ref["colptr"])
+    assert np.array_equal(ws["out_rowidx"][:nk].cpu().numpy(), ref["rowidx"])
+    assert np.allclose(ws["out_x"][:nk].cpu().numpy(), ref["x"], rtol=TOL, atol=TOL)
+    assert np.array_equal(ws["keep"].cpu().numpy().astype(bool), ref["keep"])
+    # two blocks of cells
+    cut = 1100
+    blocks = []
+    nt = torch.zeros(G, dtype=torch.int64, device="cuda")
+    for b, e in ((0, cut), (cut, N)):
+        lcp = d((cp[b:e + 1] - cp[b]).astype(np.int64))
+        lri, lx = d(ri[cp[b]:cp[e]]), d(x[cp[b]:cp[e]])
+        blocks.append((e - b, lcp, lri, lx))
+        ops.csc_count(G, e - b, lcp, lri, lx, nt)
+    xs, rs = [], []
+    for n, lcp, lri, lx in blocks:
+        w2 = ops.csc_workspace(G, n, int(lri.numel()))
+        ops.csc_genes(G, N, nt, 0.05, 1.0, None, w2["keep"], w2["remap"], w2["w"], w2["gkept"])
+        ops.csc_colptr(G, n, lcp, lri, w2["keep"], w2["gkept"], w2["out_colptr"])
+        ops.csc_scale(G, n, lcp, lri, lx, w2["remap"], w2["w"], w2["out_colptr"], w2["out_rowidx"], w2["out_x"])
+        ops.sync()
+        m = int(w2["out_colptr"][n])
+        xs.append(w2["out_x"][:m].cpu().numpy())
+        rs.append(w2["out_rowidx"][:m].cpu().numpy())
+    assert np.array_equal(np.concatenate(rs), ref["rowidx"])
+    assert np.allclose(np.concatenate(xs), ref["x"], rtol=TOL, atol=TOL)
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 shape (10 k cells x 20 k genes): size-independent properties + oracle."""
+    G, N = 20000, 10000
+    cp, ri, x = synth.counts_csc(G, N)
+    M = sp.csc_matrix((x, ri, cp), shape=(G, N))
+    res = gficf_amd.gficf(M, normalize=False, verbose=False)
+    g = res["gficf"]
+    # every non-empty cell has unit L2 norm; values in [0, 1]
+    nrm = np.sqrt(np.asarray(g.multiply(g).sum(axis=0)).ravel())
+    nonempty = np.diff(g.indptr) > 0
+    assert np.allclose(nrm[nonempty], 1.0, rtol=1e-12)
+    assert g.data.min() >= 0.0 and g.data.max() <= 1.0 + 1e-12
+    # idempotence of the per-cell scale: scaling the counts of a cell by a constant changes nothing
+    M2 = M.copy()
+    M2.data = M2.data * np.repeat(1.0 + (np.arange(N) % 7), np.diff(M2.indptr))
+    g2 = gficf_amd.gficf(M2, normalize=False, verbose=False)["gficf"]
+    assert np.allclose(g2.data, g.data, rtol=1e-12, atol=1e-15) and np.array_equal(g2.indices, g.indices)
+    ref = oracle.gficf_csc(G, N, cp, ri, x, 0.05, 1.0)
+    check_against_oracle(res, ref, N)

@@ -1,0 +1,244 @@
+"""GPU parity: the HIP Jaccard path (through the C ABI) against the CPU oracle.
+Bar: intersection counts, edge list and zero rows bit-exact; weights bit-exact."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gficf_amd
+import oracle
+from gficf_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return gficf_amd.HipOps(0)
+
+
+def device_jaccard(ops, mat, with_u=True):
+    """Device-resident pipeline: column-major idx on the GPU -> (E x 3) matrix + counts."""
+    import torch
+
+    N, k = mat.shape
+    idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()        # (k, N) == column-major N x k
+    table = torch.empty((N, ops.kpad(k)), dtype=torch.int32, device="cuda")
+    rmat = torch.full((3, N * k), -7.0, dtype=torch.float64, device="cuda")   # poison: must be fully overwritten
+    u = torch.full((N * k,), -7, dtype=torch.int32, device="cuda") if with_u else None
+    ops.jaccard(idx, N, k, table, rmat, u)
+    ops.sync()
+    return rmat.cpu().numpy().T, (u.cpu().numpy() if with_u else None)
+
+
+def test_known_answers(golden_dir):
+    with open(os.path.join(golden_dir, "known_answers.json")) as f:
+        known = json.load(f)
+    for case in known["jaccard"]:
+        mat = np.array(case["mat"], dtype=np.int32)
+        k = mat.shape[1]
+        want_u = np.array(case["u"], dtype=np.int32).reshape(-1)
+        got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
+        want, _ = oracle.jaccard(mat)
+        assert np.array_equal(got, want), case["name"]
+        pos = want_u > 0
+        assert np.array_equal(got[:, 2], np.where(pos, want_u / (2.0 * k - want_u), 0.0)), case["name"]
+
+
+@pytest.mark.parametrize("N,k", [(64, 5), (1000, 15), (1000, 16), (1000, 17), (1000, 30), (999, 32), (700, 33),
+                                 (1200, 50), (500, 64), (400, 65), (300, 100), (300, 128), (300, 129), (600, 200),
+                                 (520, 256), (3000, 15), (10000, 30)])
+def test_host_api_matches_oracle(N, k):
+    mat = synth.knn_windowed(N, k, W=max(100, k), seed=N + k, perm_seed=7)
+    got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
+    want, _ = oracle.jaccard(mat, nthreads=8)
+    assert got.shape == (N * k, 3) and got.dtype == np.float64
+    assert np.array_equal(got, want)
+
+
+def test_double_input_matches_int_input():
+    mat = synth.knn_windowed(2000, 30, seed=5)
+    a = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
+    b = gficf_amd.rcpp_parallel_jaccard_coef(mat.astype(np.float64), False)     # what Rcpp coerces to
+    c = gficf_amd.rcpp_parallel_jaccard_coef(np.asfortranarray(mat), False)
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_golden_fixtures(golden_dir, ops):
+    z = np.load(os.path.join(golden_dir, "jaccard_cases.npz"))
+    for nm in z["names"]:
+        N, k, seed = (int(v) for v in z[nm + "_meta"])
+        mat = synth.knn_windowed(N, k, seed=seed, perm_seed=seed + 100)
+        rm, u = device_jaccard(ops, mat)
+        assert np.array_equal(u.astype(np.uint8), z[nm + "_u"]), nm
+        assert sha(np.asfortranarray(rm)) == bytes(z[nm + "_sha"]).decode(), nm
+    for nm in ("uniform", "dupheavy"):
+        rm, u = device_jaccard(ops, z[nm + "_mat"])
+        assert np.array_equal(u.astype(np.uint8), z[nm + "_u"]), nm
+        assert sha(np.asfortranarray(rm)) == bytes(z[nm + "_sha"]).decode(), nm
+
+
+def test_uniform_random_mostly_empty_intersections(ops):
+    mat = synth.knn_uniform(20000, 30)
+    rm, u = device_jaccard(ops, mat)
+    want, wu = oracle.jaccard(mat, nthreads=8)
+    assert np.array_equal(u, wu) and np.array_equal(rm, want)
+    assert (u == 0).mean() > 0.9
+    assert not rm[u == 0].any()           # zero rows stay zero
+
+
+@pytest.mark.parametrize("k,mod", [(12, 40), (30, 50), (40, 45), (100, 130)])
+def test_duplicate_and_self_ids_multiset_semantics(ops, k, mod):
+    # ids drawn from a small range: rows hold duplicates and their own id (std::set_intersection multiset counts)
+    N = 600
+    r = synth.rand_u64(k, np.arange(N * k)).reshape(N, k)
+    mat = (r % np.uint64(mod)).astype(np.int32) + 1
+    rm, u = device_jaccard(ops, mat)
+    want, wu = oracle.jaccard(mat, nthreads=8)
+    assert np.array_equal(u, wu)
+    assert np.array_equal(rm, want)
+
+
+def test_mixed_duplicate_rows_only_some_cells(ops):
+    # mostly clean rows, a few rows with duplicates: exercises the per-row duplicate flag on
+    # both the source row and a gathered neighbour row
+    mat = synth.knn_windowed(5000, 30, seed=21)
+    mat[17, 3] = mat[17, 4]
+    mat[4000, 0] = mat[4000, 29]
+    mat[123, :] = mat[123, 0]
+    rm, u = device_jaccard(ops, mat)
+    want, wu = oracle.jaccard(mat, nthreads=8)
+    assert np.array_equal(u, wu) and np.array_equal(rm, want)
+
+
+def test_hash_collision_heavy_rows(ops):
+    # ids congruent modulo a large power of two: stresses the LDS hash set's overflow path
+    N, k = 1 << 16, 30
+    base = synth.knn_windowed(64, k, W=31, seed=2)                 # ids 1..64
+    mat = ((base.astype(np.int64) - 1) * 1024 + 1).astype(np.int32)   # ids 1, 1025, 2049, ...
+    full = synth.knn_windowed(N, k, seed=3)
+    rows = (np.arange(64) * 1024)
+    full[rows] = mat
+    rm, u = device_jaccard(ops, full)
+    want, wu = oracle.jaccard(full, nthreads=8)
+    assert np.array_equal(u, wu) and np.array_equal(rm, want)
+
+
+def test_out_of_range_ids_are_rejected():
+    mat = synth.knn_windowed(1000, 15, seed=1)
+    for bad in (0, 1001, -3):
+        m = mat.copy()
+        m[500, 7] = bad
+        with pytest.raises(gficf_amd.GficfError) as ei:
+            gficf_amd.rcpp_parallel_jaccard_coef(m, False)
+        assert ei.value.status == "GFICF_ERR_BAD_ID"
+    m = mat.astype(np.float64)
+    m[3, 3] = 2.5
+    with pytest.raises(gficf_amd.GficfError):
+        gficf_amd.rcpp_parallel_jaccard_coef(m, False)
+    m[3, 3] = np.nan
+    with pytest.raises(gficf_amd.GficfError):
+        gficf_amd.rcpp_parallel_jaccard_coef(m, False)
+    # the context stays usable afterwards
+    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(mat, False), oracle.jaccard(mat)[0])
+
+
+def test_unsupported_k_and_empty_inputs():
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        gficf_amd.rcpp_parallel_jaccard_coef(np.ones((300, 257), dtype=np.int32), False)
+    assert ei.value.status == "GFICF_ERR_UNSUPPORTED"
+    assert gficf_amd.rcpp_parallel_jaccard_coef(np.zeros((0, 5), dtype=np.int32), False).shape == (0, 3)
+    assert gficf_amd.rcpp_parallel_jaccard_coef(np.zeros((7, 0), dtype=np.int32), False).shape == (0, 3)
+
+
+def test_print_output_banners(capfd):
+    mat = synth.knn_windowed(200, 5, seed=1)
+    gficf_amd.rcpp_parallel_jaccard_coef(mat, True)
+    out = capfd.readouterr().out
+    assert "Running Parallell Jaccard Coefficient Estimation..." in out and "Done!!" in out
+
+
+def test_clustcells_call_site_filter():
+    # reference R/clustCells.R:63-68: drop the self column, keep weight > 0 rows in order
+    mat = synth.knn_uniform(3000, 15)
+    neigh = np.concatenate([np.arange(1, 3001, dtype=np.int32)[:, None], mat], axis=1)
+    rel = gficf_amd.jaccard_edges(neigh)
+    want, _ = oracle.jaccard(mat, nthreads=4)
+    want = want[want[:, 2] > 0]
+    assert np.array_equal(rel["from"], want[:, 0]) and np.array_equal(rel["to"], want[:, 1])
+    assert np.array_equal(rel["weight"], want[:, 2])
+
+
+def test_cell_block_seam_matches_full(ops):
+    """The multi-GPU seam on one GPU: two ingests into table blocks + per-block edges == one shot."""
+    import torch
+
+    N, k = 5001, 30
+    mat = synth.knn_windowed(N, k, seed=8)
+    full, fu = device_jaccard(ops, mat)
+    kp = ops.kpad(k)
+    table = torch.zeros((N, kp), dtype=torch.int32, device="cuda")
+    cut = 2600
+    outs = []
+    for b, e in ((0, cut), (cut, N)):
+        blk = torch.from_numpy(np.ascontiguousarray(mat[b:e].T)).cuda()
+        ops.jaccard_ingest(blk, e - b, k, N, table[b:e])
+    for b, e in ((0, cut), (cut, N)):
+        out = torch.empty((3, (e - b) * k), dtype=torch.float64, device="cuda")
+        ops.jaccard_edges(table, N, k, b, e, out)
+        outs.append(out)
+    ops.sync()
+    got = torch.cat(outs, dim=1).cpu().numpy().T
+    assert np.array_equal(got, full)
+
+
+def test_full_size_north_star_point_bit_exact(ops):
+    """100 k cells x k = 30 (the north-star point): whole edge matrix bit-exact vs the oracle."""
+    mat = synth.knn_windowed(100000, 30)
+    rm, u = device_jaccard(ops, mat)
+    want, wu = oracle.jaccard(mat, nthreads=os.cpu_count() or 8)
+    assert np.array_equal(u, wu)
+    assert np.array_equal(rm, want)
+
+
+def test_full_size_properties_1M_cells(ops):
+    """BASELINE config 5 scale on one GPU (1 M cells x k = 30): size-independent properties."""
+    import torch
+
+    N, k = 1_000_000, 30
+    mat = synth.knn_windowed(N, k, seed=11)
+    rm, u = device_jaccard(ops, mat)
+    E = N * k
+    src, dst, w = rm[:, 0], rm[:, 1], rm[:, 2]
+    pos = u > 0
+    # edge list: src = cell id, dst = the input id, zero rows exactly where u == 0
+    assert np.array_equal(src, np.where(pos, np.repeat(np.arange(1, N + 1, dtype=np.float64), k), 0.0))
+    assert np.array_equal(dst, np.where(pos, mat.reshape(-1).astype(np.float64), 0.0))
+    assert np.array_equal(w, np.where(pos, u / (2.0 * k - u), 0.0))
+    assert u.min() >= 0 and u.max() <= k
+    # symmetry: whenever j is in row i and i is in row j, u(i->j) == u(j->i)
+    ii = np.repeat(np.arange(N, dtype=np.int64), k)
+    jj = mat.reshape(-1).astype(np.int64) - 1
+    key_f = ii * N + jj
+    key_b = jj * N + ii
+    order = np.argsort(key_f)
+    pos_b = np.searchsorted(key_f[order], key_b)
+    pos_b = np.minimum(pos_b, E - 1)
+    mutual = key_f[order][pos_b] == key_b
+    assert mutual.mean() > 0.1
+    assert np.array_equal(u[mutual], u[order][pos_b][mutual])
+    # a 20 k-cell sample of source cells against the oracle's counting rule (numpy restatement)
+    sample = np.arange(0, N, 50)[:2000]
+    rows = mat[sample]
+    nb = mat[rows.reshape(-1) - 1].reshape(len(sample), k, k)
+    cnt = (rows[:, None, :, None] == nb[:, :, None, :]).sum(axis=(2, 3)).astype(np.int32)
+    assert np.array_equal(cnt.reshape(-1), u.reshape(N, k)[sample].reshape(-1))

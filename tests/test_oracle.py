@@ -1,0 +1,188 @@
+"""CPU: the oracle against hand-derived known answers, its independent numpy restatement,
+and the committed golden fixtures.  (The reference has no tests / golden vectors and cannot
+run here: the oracle is 'parity unpinned' — see oracle/__init__.py.)"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from hypothesis import given, settings, strategies as st
+
+import oracle
+from gficf_amd import synth
+from oracle import oracle_np
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def known(golden_dir):
+    with open(os.path.join(golden_dir, "known_answers.json")) as f:
+        return json.load(f)
+
+
+def test_jaccard_known_answers(known):
+    for case in known["jaccard"]:
+        mat = np.array(case["mat"], dtype=np.int32)
+        want_u = np.array(case["u"], dtype=np.int32).reshape(-1)
+        N, k = mat.shape
+        rm, u = oracle.jaccard(mat)
+        assert np.array_equal(u, want_u), case["name"]
+        assert np.array_equal(oracle_np.jaccard_counts_py(mat), want_u), case["name"]
+        assert np.array_equal(oracle_np.jaccard_counts_np(mat), want_u), case["name"]
+        # rows: (i+1, dst, u/(2k-u)) or zeros   (reference :48-52)
+        for r in range(N * k):
+            i, j = divmod(r, k)
+            if want_u[r] == 0:
+                assert tuple(rm[r]) == (0.0, 0.0, 0.0)
+            else:
+                assert tuple(rm[r]) == (i + 1.0, float(mat[i, j]), want_u[r] / (2.0 * k - want_u[r]))
+
+
+def test_jaccard_toy_literals():
+    mat = np.array([[2, 3, 4], [1, 3, 5], [1, 2, 4], [3, 5, 1], [4, 1, 2]], dtype=np.float64)
+    rm, _ = oracle.jaccard(mat)
+    assert rm.shape == (15, 3)
+    assert rm[0].tolist() == [1.0, 2.0, 0.2]
+    assert rm[1].tolist() == [1.0, 3.0, 0.5]
+    assert rm[13].tolist() == [5.0, 1.0, 0.5]
+
+
+def test_jaccard_int_and_double_inputs_agree():
+    mat = synth.knn_windowed(500, 10, seed=3)
+    a, ua = oracle.jaccard(mat)
+    b, ub = oracle.jaccard(mat.astype(np.float64))
+    assert np.array_equal(a, b) and np.array_equal(ua, ub)
+
+
+def test_jaccard_rejects_out_of_range_ids():
+    mat = np.array([[2, 3], [1, 3], [1, 4]], dtype=np.int32)   # 4 > N = 3
+    with pytest.raises(ValueError):
+        oracle.jaccard(mat)
+    with pytest.raises(ValueError):
+        oracle.jaccard(np.array([[0, 1], [1, 2]], dtype=np.int32))
+
+
+def test_jaccard_threads_do_not_change_results():
+    mat = synth.knn_windowed(3000, 15, seed=5)
+    a, ua = oracle.jaccard(mat, nthreads=1)
+    b, ub = oracle.jaccard(mat, nthreads=8)
+    assert np.array_equal(a, b) and np.array_equal(ua, ub)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(2, 40), st.integers(1, 12), st.integers(0, 2**31 - 1))
+def test_jaccard_cxx_vs_numpy_random_multisets(N, k, seed):
+    r = synth.rand_u64(seed, np.arange(N * k)).reshape(N, k)
+    mat = (r % np.uint64(N)).astype(np.int32) + 1       # duplicates and self ids allowed
+    rm, u = oracle.jaccard(mat)
+    assert np.array_equal(u, oracle_np.jaccard_counts_py(mat))
+    assert np.array_equal(u, oracle_np.jaccard_counts_np(mat))
+    assert np.array_equal(rm, oracle_np.jaccard_rmat(mat, u))
+
+
+def test_jaccard_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "jaccard_cases.npz"))
+    for nm in z["names"]:
+        N, k, seed = (int(v) for v in z[nm + "_meta"])
+        mat = synth.knn_windowed(N, k, seed=seed, perm_seed=seed + 100)
+        rm, u = oracle.jaccard(mat, nthreads=4)
+        assert np.array_equal(u.astype(np.uint8), z[nm + "_u"]), nm
+        assert sha(np.asfortranarray(rm)) == bytes(z[nm + "_sha"]).decode(), nm
+    for nm in ("uniform", "dupheavy"):
+        rm, u = oracle.jaccard(z[nm + "_mat"], nthreads=2)
+        assert np.array_equal(u.astype(np.uint8), z[nm + "_u"]), nm
+        assert sha(np.asfortranarray(rm)) == bytes(z[nm + "_sha"]).decode(), nm
+
+
+def test_synthetic_knn_statistics():
+    # ~97 % of edges have u > 0 and the mean weight is ~0.06 at k = 30
+    mat = synth.knn_windowed(20000, 30)
+    assert all(len(set(r)) == 30 for r in mat[:200])
+    assert (mat != np.arange(1, 20001)[:, None]).all()
+    rm, u = oracle.jaccard(mat, nthreads=8)
+    assert 0.95 < (u > 0).mean() < 0.99
+    assert 0.05 < rm[u > 0, 2].mean() < 0.07
+
+
+# --------------------------------------------------------------------------- GF-ICF
+def _dense(res, N):
+    return sp.csc_matrix((res["x"], res["rowidx"], res["colptr"]), shape=(res["G_kept"], N)).toarray()
+
+
+def test_gficf_known_answers(known):
+    g = known["gficf"]["basic"]
+    M = sp.csc_matrix(np.array(g["M"], dtype=float))
+    r = oracle.gficf_csc(4, 3, M.indptr, M.indices, M.data, g["min"], g["max"])
+    assert r["nt"].tolist() == g["nt"]
+    assert np.allclose(r["w"], g["w"], rtol=0, atol=1e-15)
+    assert np.allclose(_dense(r, 3), np.array(g["dense"]), rtol=0, atol=1e-15)
+    r2 = oracle_np.gficf_np(M, g["min"], g["max"])
+    assert np.allclose(r2["gficf"].toarray(), np.array(g["dense"]), rtol=0, atol=1e-15)
+
+    f = known["gficf"]["filter"]
+    r = oracle.gficf_csc(4, 3, M.indptr, M.indices, M.data, f["min"], f["max"])
+    assert r["keep"].astype(int).tolist() == f["keep"]
+    assert np.allclose(_dense(r, 3), np.array(f["dense"]), rtol=0, atol=1e-15)
+
+    z = known["gficf"]["w_zero_cell"]
+    Mz = sp.csc_matrix(np.array(z["M"], dtype=float))
+    r = oracle.gficf_csc(2, 2, Mz.indptr, Mz.indices, Mz.data, z["min"], z["max"])
+    assert np.allclose(_dense(r, 2), np.array(z["dense"]), rtol=0, atol=1e-15)
+
+
+def test_gficf_cxx_vs_numpy():
+    for G, N, mn, mx, seed in [(400, 300, 0.05, 1.0, 1), (250, 350, 0.0, 1.0, 2), (300, 200, 0.1, 0.5, 3)]:
+        cp, ri, x = synth.counts_csc(G, N, seed=seed)
+        r = oracle.gficf_csc(G, N, cp, ri, x, mn, mx)
+        r2 = oracle_np.gficf_np(sp.csc_matrix((x, ri, cp), shape=(G, N)), mn, mx)
+        assert np.array_equal(r["keep"], r2["keep"])
+        assert np.array_equal(r["nt"], r2["nt"])
+        assert np.allclose(r["w"], r2["w"], rtol=1e-15, atol=0)
+        assert np.array_equal(r["rowidx"], r2["gficf"].indices)
+        assert np.array_equal(r["colptr"], r2["gficf"].indptr)
+        assert np.allclose(r["x"], r2["gficf"].data, rtol=1e-13, atol=1e-16)
+
+
+def test_gficf_supplied_weights_and_properties():
+    G, N = 300, 200
+    cp, ri, x = synth.counts_csc(G, N, seed=4)
+    w_in = 0.5 + synth.rand_unit(5, np.arange(G))
+    r = oracle.gficf_csc(G, N, cp, ri, x, 0.0, 2.0, w_in=w_in)
+    r2 = oracle_np.gficf_np(sp.csc_matrix((x, ri, cp), shape=(G, N)), 0.0, 2.0, w_in=w_in)
+    assert np.allclose(r["x"], r2["gficf"].data, rtol=1e-13, atol=1e-16)
+    assert np.array_equal(r["w"][r["keep"]], w_in[r["keep"]])
+    # every non-empty cell has unit L2 norm
+    D = _dense(r, N)
+    assert np.allclose(np.sqrt((D ** 2).sum(axis=0)), 1.0, rtol=1e-12)
+
+
+def test_gficf_empty_cell_and_explicit_zero():
+    # cell 1 empty; cell 2 holds an explicit zero (does not count in nt, R/gficf.R:40)
+    colptr = np.array([0, 2, 2, 4], dtype=np.int64)
+    rowidx = np.array([0, 1, 0, 1], dtype=np.int32)
+    x = np.array([1.0, 3.0, 0.0, 2.0])
+    r = oracle.gficf_csc(2, 3, colptr, rowidx, x, 0.0, 1.0)
+    assert r["nt"].tolist() == [1, 2]
+    assert r["colptr"].tolist() == [0, 2, 2, 4]
+    D = _dense(r, 3)
+    assert np.all(D[:, 1] == 0) and D[0, 2] == 0.0 and D[1, 2] == 1.0
+
+
+def test_gficf_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "gficf_cases.npz"))
+    for nm in ("g600_n400", "g300_n500_nofilter", "g500_n300_max"):
+        G, N, seed = (int(v) for v in z[nm + "_meta"])
+        mn, mx = z[nm + "_prop"]
+        cp, ri, x = synth.counts_csc(G, N, seed=seed)
+        r = oracle.gficf_csc(G, N, cp, ri, x, mn, mx)
+        assert np.array_equal(r["keep"], z[nm + "_keep"])
+        assert np.array_equal(r["nt"], z[nm + "_nt"])
+        assert np.array_equal(r["colptr"], z[nm + "_colptr"])
+        assert np.array_equal(r["rowidx"], z[nm + "_rowidx"])
+        assert np.allclose(r["x"], z[nm + "_x"], rtol=1e-14, atol=0)
+        assert np.allclose(r["w"], z[nm + "_w"], rtol=1e-14, atol=0)
