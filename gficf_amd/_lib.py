@@ -67,6 +67,14 @@ def load() -> ctypes.CDLL:
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C gficf_amd/csrc` (hipcc, --offload-arch=gfx950). gficf_amd has no CPU fallback.")
+        # Load order matters in a Python process that also uses torch: torch ships its own copy of
+        # the HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  If /opt/rocm's copy
+        # is mapped first, torch later maps a second runtime and then finds no GPU; if torch's is
+        # mapped first, our NEEDED libamdhip64.so.7 resolves to it and both share one runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the ABI and this table diverge

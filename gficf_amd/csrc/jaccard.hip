@@ -19,6 +19,8 @@
 //               double, so they are bit-identical to the reference's division.
 //   * rows with duplicate ids (multiset semantics), hash overflow: exact slow path in the
 //               same kernel (all-pairs with occurrence ranks).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -101,13 +103,16 @@ struct JCfg {
   static constexpr int TPQ = KPAD >= 64 ? 64 : KPAD / G;      // loop steps per element register
   static constexpr int NB = 8 * KPAD;                         // 2-slot buckets in the hash set
   static constexpr int WAVES = KPAD <= 128 ? 4 : 2;           // waves per workgroup
-  static constexpr int U = TPQ >= 8 ? 8 : TPQ;                // gathers in flight per wave
+  static constexpr int U = TPQ >= 16 ? 16 / EPL : TPQ;        // steps whose gathers are in flight together
   static constexpr int LOG2NB = KPAD == 16 ? 7 : KPAD == 32 ? 8 : KPAD == 64 ? 9 : KPAD == 128 ? 10 : 11;
 };
 
-template <int KPAD>
+// Bucket of an id.  BIG == false: ids < 2^24 (full-rate 24-bit multiply).
+template <int KPAD, bool BIG>
 __device__ inline uint32_t bucket_of(uint32_t id) {
-  return (id * 0x9E3779B1u) >> (32 - JCfg<KPAD>::LOG2NB);
+  if (BIG) return (id * 0x9E3779B1u) >> (32 - JCfg<KPAD>::LOG2NB);
+  // (HIP declares __umul24 as returning int: cast before the shift, or it is arithmetic)
+  return (uint32_t)__umul24(id, 0x9E3779u) >> (32 - JCfg<KPAD>::LOG2NB);
 }
 
 // v_writelane_b32: drop a wave-uniform value into one lane of a VGPR (clang exposes no
@@ -123,22 +128,24 @@ struct EdgeOut {
   int32_t* u;
 };
 
-__device__ inline void store_edge(const EdgeOut& o, int64_t r, int64_t cell, uint32_t dst, int u,
+__device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint32_t dst, int u,
                                   const double* lut) {
   const bool pos = u > 0;
-  o.src[r] = pos ? (double)(cell + 1) : 0.0;   // reference :49
+  o.src[r] = pos ? (double)(uint32_t)(cell + 1) : 0.0;   // reference :49 (cell + 1 <= 2^31)
   o.dst[r] = pos ? (double)dst : 0.0;          // reference :50
   o.w[r] = pos ? lut[u] : 0.0;                 // reference :51
   if (o.u) o.u[r] = u;
 }
 
-// Exact multiset path for one cell: rows with duplicate ids or a hash set that overflowed.
+// Exact multiset path for one cell whose own row or one of whose neighbour rows holds
+// duplicate ids (never the case for real kNN output).
 // u = sum over distinct values of min(multiplicity in A, multiplicity in B), evaluated as
 // "element e of B counts iff its occurrence rank within B is below the value's multiplicity in A".
 template <int KPAD>
 __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64_t i, int k, int64_t out_base,
-                                       uint32_t* sA, uint32_t* sB, int lane, const EdgeOut& o,
-                                       const double* lut) {
+                                       uint32_t* sA, uint32_t* sB, int lane, double* o_src, double* o_dst,
+                                       double* o_w, int32_t* o_u, const double* lut) {
+  const EdgeOut o{o_src, o_dst, o_w, o_u};
   for (int e = lane; e < KPAD; e += 64) sA[e] = table[i * KPAD + e] & ID_MASK;
   wave_lds_fence();
   for (int s = 0; s < k; ++s) {
@@ -168,12 +175,19 @@ __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64
   }
 }
 
-template <int KPAD>
+// One wave per cell, cells strided over all waves of the grid.  Per cell:
+//   insert row i into the wave's LDS hash set (keys that find both slots of their bucket
+//   taken go to a small per-wave overflow list) -> gather the neighbour rows, U steps of G
+//   rows in flight -> probe (one ds_read_b64 per element) -> popcount of the match ballot.
+// The loads of the next cell's own row and the stores of the previous cell's edges are
+// issued while the gathers are in flight.
+template <int KPAD, bool BIG>
 __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
   using C = JCfg<KPAD>;
+  using off_t = typename std::conditional<BIG, uint64_t, uint32_t>::type;
   __shared__ uint2 s_hash[C::WAVES][C::NB];
-  __shared__ uint32_t s_rows[C::WAVES][2][KPAD];
+  __shared__ uint32_t s_rows[C::WAVES][2][KPAD];     // overflow list [0]; slow path rows [0],[1]
   __shared__ double s_lut[GFICF_JACCARD_MAX_K + 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -183,74 +197,113 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
   __syncthreads();
 
   uint32_t* const hslots = reinterpret_cast<uint32_t*>(&s_hash[wave][0]);
+  uint32_t* const ovlist = s_rows[wave][0];
+  const char* const tbytes = reinterpret_cast<const char*>(table);
   const int e0 = KPAD >= 64 ? lane : (lane & (KPAD - 1));   // this lane's element within a row
   const int grp = KPAD >= 64 ? 0 : lane / KPAD;             // which of the G rows of a step
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const int64_t nwaves = (int64_t)gridDim.x * C::WAVES;
+  constexpr uint32_t ROWB = KPAD * 4;
 
-  for (int64_t i = cell_begin + (int64_t)blockIdx.x * C::WAVES + wave; i < cell_end; i += nwaves) {
+  int64_t i = cell_begin + (int64_t)blockIdx.x * C::WAVES + wave;
+  uint32_t araw[C::EPL];
+  if (i < cell_end) {
+#pragma unroll
+    for (int q = 0; q < C::EPL; ++q) araw[q] = table[i * KPAD + q * 64 + e0];
+  }
+  // edges of the previous cell, stored while the current cell's gathers are in flight
+  bool have_prev = false;
+  int64_t prev_i = 0;
+  uint32_t prev_a[C::EPL];
+  int prev_u[C::EPL];
+
+  for (; i < cell_end; i += nwaves) {
     const int64_t out_base = (i - cell_begin) * (int64_t)k;
-    // ---- stage row i
     uint32_t a[C::EPL];
     uint32_t flags = 0;
 #pragma unroll
     for (int q = 0; q < C::EPL; ++q) {
-      const uint32_t raw = table[i * KPAD + q * 64 + e0];
-      flags |= raw;
-      a[q] = raw & ID_MASK;
+      flags |= araw[q];
+      a[q] = araw[q] & ID_MASK;
     }
     bool slow = __ballot((flags & ROW_DUP_FLAG) != 0) != 0ull;
-    uint32_t ov0 = EMPTY, ov1 = EMPTY;
     int myslot[C::EPL];
+    int nov = 0;
 #pragma unroll
     for (int q = 0; q < C::EPL; ++q) myslot[q] = -1;
     if (!slow) {
-      bool over = false;
-      uint32_t ovkey = 0;
 #pragma unroll
       for (int q = 0; q < C::EPL; ++q) {
-        if (lane < KPAD && a[q] != 0) {      // group 0 inserts (groups hold replicas when KPAD < 64)
-          const uint32_t bk = bucket_of<KPAD>(a[q]);
+        bool over = false;
+        if (lane < KPAD && a[q] != 0) {      // group 0 inserts (the other groups hold replicas when KPAD < 64)
+          const uint32_t bk = bucket_of<KPAD, BIG>(a[q]);
           uint32_t old = atomicCAS(&hslots[2 * bk], EMPTY, a[q]);
           if (old == EMPTY) {
             myslot[q] = 2 * bk;
           } else {
             old = atomicCAS(&hslots[2 * bk + 1], EMPTY, a[q]);
             if (old == EMPTY) myslot[q] = 2 * bk + 1;
-            else { slow |= over; over = true; ovkey = a[q]; }   // a lane with two overflows -> slow
+            else over = true;
           }
+        }
+        const unsigned long long om = __ballot(over);
+        if (om) {
+          if (over) ovlist[nov + __popcll(om & lt_mask)] = a[q];
+          nov += __popcll(om);
         }
       }
       wave_lds_fence();
-      unsigned long long om = __ballot(over);
-      const int nov = __popcll(om);
-      slow = (__ballot(slow) != 0ull) || nov > 2;
-      if (nov >= 1) { ov0 = __shfl(ovkey, __ffsll((long long)om) - 1); om &= om - 1; }
-      if (nov >= 2) { ov1 = __shfl(ovkey, __ffsll((long long)om) - 1); }
     }
 
     int myu[C::EPL];
 #pragma unroll
     for (int q = 0; q < C::EPL; ++q) myu[q] = 0;
+    const int64_t i_next = i + nwaves;
+    bool next_issued = false;
 
+    // next cell's own row: issued ahead of the gathers so that it has landed by the next iteration
+    if (i_next < cell_end) {
+#pragma unroll
+      for (int qq = 0; qq < C::EPL; ++qq) araw[qq] = table[i_next * KPAD + qq * 64 + e0];
+    }
     if (!slow) {
       uint32_t dupflags = 0;
 #pragma unroll
       for (int q = 0; q < C::EPL; ++q) {        // q: which register of row i holds the slot's id
         for (int t0 = 0; t0 < C::TPQ && (q * 64 + t0 * C::G) < k; t0 += C::U) {
           uint32_t bv[C::U][C::EPL];
+          unsigned long long livem = 0;          // bit (uu*G + gg): that row exists (id != 0)
           // issue the gathers of U steps (U*G neighbour rows) before consuming any
 #pragma unroll
           for (int uu = 0; uu < C::U; ++uu) {
-            const int srcl = (t0 + uu) * C::G + grp;            // lane of a[q] holding this slot's id
-            const int slot = q * 64 + srcl;
-            const uint32_t dst = __shfl(a[q], srcl);
-            const bool live = slot < k && dst != 0;
+            uint32_t dsel = 0;
+#pragma unroll
+            for (int gg = 0; gg < C::G; ++gg) {
+              uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)a[q], (t0 + uu) * C::G + gg);   // uniform
+              if (d != 0) livem |= 1ull << (uu * C::G + gg);
+              d = d != 0 ? d : 1u;
+              dsel = (gg == 0 || grp == gg) ? d : dsel;
+            }
+            const off_t rowoff = (off_t)(dsel - 1) * ROWB + (off_t)(e0 * 4);
 #pragma unroll
             for (int qq = 0; qq < C::EPL; ++qq) {
-              uint32_t raw = 0;
-              if (live) raw = table[(int64_t)(dst - 1) * KPAD + qq * 64 + e0];
+              const uint32_t raw = *reinterpret_cast<const uint32_t*>(tbytes + rowoff + qq * 256);
               dupflags |= raw;
               bv[uu][qq] = raw & ID_MASK;
+            }
+          }
+          if (!next_issued) {
+            // the previous cell's edges ride behind the gathers (younger in vmcnt order, so the
+            // wait for the gathers does not wait for them)
+            next_issued = true;
+            if (have_prev) {
+              const int64_t pb = (prev_i - cell_begin) * (int64_t)k;
+#pragma unroll
+              for (int qq = 0; qq < C::EPL; ++qq) {
+                const int slot = qq * 64 + lane;
+                if (lane < KPAD && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
+              }
+              have_prev = false;
             }
           }
 #pragma unroll
@@ -260,30 +313,37 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
 #pragma unroll
             for (int qq = 0; qq < C::EPL; ++qq) {
               const uint32_t b = bv[uu][qq];
-              const uint2 h = s_hash[wave][bucket_of<KPAD>(b)];
-              const unsigned long long mm = __ballot(h.x == b) | __ballot(h.y == b) | __ballot(b == ov0) | __ballot(b == ov1);
+              const uint2 h = s_hash[wave][bucket_of<KPAD, BIG>(b)];
+              unsigned long long mm = __ballot(h.x == b) | __ballot(h.y == b);
+              for (int t = 0; t < nov; ++t) mm |= __ballot(b == ovlist[t]);
               if (C::EPL == 1) m = mm; else cnt_big += __popcll(mm);
             }
             if (C::EPL == 1) {
 #pragma unroll
               for (int gg = 0; gg < C::G; ++gg) {
                 const unsigned long long gm = KPAD >= 64 ? m : ((m >> (gg * (KPAD & 63))) & ((1ull << (KPAD & 63)) - 1ull));
-                myu[0] = gficf_writelane(__popcll(gm), (t0 + uu) * C::G + gg, myu[0]);
+                const int cnt = ((livem >> (uu * C::G + gg)) & 1ull) ? __popcll(gm) : 0;
+                myu[0] = gficf_writelane(cnt, (t0 + uu) * C::G + gg, myu[0]);
               }
             } else {
-              myu[q] = gficf_writelane(cnt_big, t0 + uu, myu[q]);
+              const int cnt = ((livem >> uu) & 1ull) ? cnt_big : 0;
+              myu[q] = gficf_writelane(cnt, t0 + uu, myu[q]);
             }
           }
         }
       }
       // a neighbour row with duplicate ids: redo this cell exactly
       slow = __ballot((dupflags & ROW_DUP_FLAG) != 0) != 0ull;
-      if (!slow) {
+    }
+    if (!next_issued) {    // own row with duplicates: the gather loop was skipped
+      if (have_prev) {
+        const int64_t pb = (prev_i - cell_begin) * (int64_t)k;
 #pragma unroll
-        for (int q = 0; q < C::EPL; ++q) {
-          const int slot = q * 64 + lane;
-          if (lane < KPAD && slot < k) store_edge(o, out_base + slot, i, a[q], myu[q], s_lut);
+        for (int qq = 0; qq < C::EPL; ++qq) {
+          const int slot = qq * 64 + lane;
+          if (lane < KPAD && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
         }
+        have_prev = false;
       }
     }
     // ---- clear this cell's keys from the set
@@ -291,7 +351,22 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
     for (int q = 0; q < C::EPL; ++q)
       if (myslot[q] >= 0) hslots[myslot[q]] = EMPTY;
     wave_lds_fence();
-    if (slow) slow_cell<KPAD>(table, i, k, out_base, s_rows[wave][0], s_rows[wave][1], lane, o, s_lut);
+    if (slow) {
+      slow_cell<KPAD>(table, i, k, out_base, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w, o.u, s_lut);
+    } else {
+      have_prev = true;
+      prev_i = i;
+#pragma unroll
+      for (int q = 0; q < C::EPL; ++q) { prev_a[q] = a[q]; prev_u[q] = myu[q]; }
+    }
+  }
+  if (have_prev) {
+    const int64_t pb = (prev_i - cell_begin) * (int64_t)k;
+#pragma unroll
+    for (int qq = 0; qq < C::EPL; ++qq) {
+      const int slot = qq * 64 + lane;
+      if (lane < KPAD && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
+    }
   }
 }
 
@@ -316,15 +391,30 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
   return GFICF_OK;
 }
 
-template <int KPAD>
-int launch_edges(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+template <int KPAD, bool BIG>
+int launch_edges_t(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
   using C = JCfg<KPAD>;
+  // grid = what is resident at once (occupancy x CUs); waves stride over the cells
+  static int blocks_per_cu = 0;
+  if (blocks_per_cu == 0) {
+    int nb = 0;
+    GFICF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_jaccard_edges<KPAD, BIG>, C::WAVES * 64, 0));
+    blocks_per_cu = nb > 0 ? nb : 1;
+  }
   const int64_t blocks_needed = gficf_ceil_div(ce - cb, C::WAVES);
-  const int64_t cap = (int64_t)ctx->num_cus * 8;
+  const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
   const unsigned grid = (unsigned)(blocks_needed < cap ? blocks_needed : cap);
-  hipLaunchKernelGGL((k_jaccard_edges<KPAD>), dim3(grid), dim3(C::WAVES * 64), 0, ctx->stream, table, N, k, cb, ce, o);
+  hipLaunchKernelGGL((k_jaccard_edges<KPAD, BIG>), dim3(grid), dim3(C::WAVES * 64), 0, ctx->stream, table, N, k, cb, ce, o);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
+}
+
+template <int KPAD>
+int launch_edges(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+  // 32-bit byte offsets and the 24-bit hash multiply need table < 4 GiB and ids < 2^24
+  const bool big = N >= (1ll << 24) || N * (int64_t)KPAD * 4 >= (1ll << 32);
+  return big ? launch_edges_t<KPAD, true>(ctx, table, N, k, cb, ce, o)
+             : launch_edges_t<KPAD, false>(ctx, table, N, k, cb, ce, o);
 }
 
 int check_nk(int64_t N, int k) {
@@ -388,7 +478,7 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
   GFICF_CTX_ENTER(ctx);
   int rc = check_nk(N, k);
   if (rc) return rc;
-  if (print_output) printf("Running Parallell Jaccard Coefficient Estimation...\n");  // reference :63
+  if (print_output) { printf("Running Parallell Jaccard Coefficient Estimation...\n"); fflush(stdout); }  // reference :63
   const int64_t E = N * (int64_t)k;
   if (E > 0) {
     if (!idx || !rmat) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
@@ -415,7 +505,7 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
     if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_jaccard_host: %s", hipGetErrorString(e));
     if (rc) return rc;
   }
-  if (print_output) printf("Done!!\n");  // reference :77
+  if (print_output) { printf("Done!!\n"); fflush(stdout); }  // reference :77
   return GFICF_OK;
 }
 
