@@ -12,9 +12,9 @@
 //               reads.  Ids are validated here; bit 31 of a row's first entry flags a
 //               row that holds duplicate ids (never the case for real kNN output).
 //   * edges   : one wave64 per cell.  Row i is staged in LDS as a 2-slot-bucket hash set
-//               (one ds_read_b64 per probe, no probing loop); 64/KPAD neighbour rows are
-//               gathered per wave-instruction, every lane probes the set with its element,
-//               and the per-edge intersection count is the popcount of the wave ballot.
+//               (one ds_read_b64 per probe, no probing loop); 256/KPAD neighbour rows are
+//               gathered per wave-instruction (16 B per lane), every lane probes the set with
+//               its ids, and the per-edge intersection count is a DPP sum over the row's lanes.
 //               Weights come from a per-block LDS table W[u] = u/(2k-u) computed in IEEE
 //               double, so they are bit-identical to the reference's division.
 //   * rows with duplicate ids (multiset semantics), hash overflow: exact slow path in the
@@ -98,12 +98,13 @@ __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64
 // ------------------------------------------------------------------------------- edges
 template <int KPAD>
 struct JCfg {
-  static constexpr int G = KPAD >= 64 ? 1 : 64 / KPAD;        // neighbour rows per wave-instruction
-  static constexpr int EPL = KPAD >= 64 ? KPAD / 64 : 1;      // row elements per lane
-  static constexpr int TPQ = KPAD >= 64 ? 64 : KPAD / G;      // loop steps per element register
+  static constexpr int LPR = KPAD / 4;                        // lanes per neighbour row (16 B per lane)
+  static constexpr int RPS = 64 / LPR;                        // neighbour rows per wave-instruction ("step")
+  static constexpr int EPL = KPAD > 64 ? KPAD / 64 : 1;       // registers holding row i (slot s -> reg s/64, lane s%64)
+  static constexpr int SPQ = (KPAD < 64 ? KPAD : 64) / RPS;   // steps per register of row i
   static constexpr int NB = 8 * KPAD;                         // 2-slot buckets in the hash set
   static constexpr int WAVES = KPAD <= 128 ? 4 : 2;           // waves per workgroup
-  static constexpr int U = TPQ >= 16 ? 16 / EPL : TPQ;        // steps whose gathers are in flight together
+  static constexpr int U = SPQ < 4 ? SPQ : 4;                 // steps whose gathers are in flight together
   static constexpr int LOG2NB = KPAD == 16 ? 7 : KPAD == 32 ? 8 : KPAD == 64 ? 9 : KPAD == 128 ? 10 : 11;
 };
 
@@ -175,12 +176,29 @@ __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64
   }
 }
 
+// Sum over the LPR consecutive lanes that share one neighbour row; every lane of the group
+// gets the sum.  DPP inside a 16-lane row, shuffles above.
+template <int LPR>
+__device__ inline int group_sum(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);                  // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);                  // quad_perm [2,3,0,1]
+  if (LPR >= 8) x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);   // row_half_mirror
+  if (LPR >= 16) x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);  // row_mirror
+  if (LPR >= 32) x += __shfl_xor(x, 16);
+  if (LPR >= 64) x += __shfl_xor(x, 32);
+  return x;
+}
+
 // One wave per cell, cells strided over all waves of the grid.  Per cell:
-//   insert row i into the wave's LDS hash set (keys that find both slots of their bucket
-//   taken go to a small per-wave overflow list) -> gather the neighbour rows, U steps of G
-//   rows in flight -> probe (one ds_read_b64 per element) -> popcount of the match ballot.
-// The loads of the next cell's own row and the stores of the previous cell's edges are
-// issued while the gathers are in flight.
+//   * row i (one id per lane) is inserted into the wave's LDS hash set; keys that find both
+//     slots of their bucket taken go to a small per-wave overflow list;
+//   * "steps": each lane loads 16 B (4 ids) of a neighbour row, so KPAD/4 lanes cover one row
+//     and a wave-instruction gathers RPS = 256/KPAD rows; U steps are in flight together;
+//   * every lane probes the set with its 4 ids (one ds_read_b64 per id), the per-row
+//     intersection count is a DPP sum over the row's lanes;
+//   * counts are permuted back to one-slot-per-lane and stored as three coalesced runs.
+// The load of the next cell's own row is issued ahead of the gathers and the stores of the
+// previous cell's edges behind them, so neither sits on the wait for the gathers.
 template <int KPAD, bool BIG>
 __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
@@ -199,17 +217,20 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
   uint32_t* const hslots = reinterpret_cast<uint32_t*>(&s_hash[wave][0]);
   uint32_t* const ovlist = s_rows[wave][0];
   const char* const tbytes = reinterpret_cast<const char*>(table);
-  const int e0 = KPAD >= 64 ? lane : (lane & (KPAD - 1));   // this lane's element within a row
-  const int grp = KPAD >= 64 ? 0 : lane / KPAD;             // which of the G rows of a step
+  const bool arow_lane = KPAD >= 64 || lane < KPAD;         // lanes that hold an id of row i
+  const int grow = lane / C::LPR;                           // which of the RPS rows of a step this lane reads
+  const uint32_t gcol = (uint32_t)(lane % C::LPR) * 16u;    // byte offset of this lane's 4 ids inside a row
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const int64_t nwaves = (int64_t)gridDim.x * C::WAVES;
   constexpr uint32_t ROWB = KPAD * 4;
 
   int64_t i = cell_begin + (int64_t)blockIdx.x * C::WAVES + wave;
   uint32_t araw[C::EPL];
-  if (i < cell_end) {
 #pragma unroll
-    for (int q = 0; q < C::EPL; ++q) araw[q] = table[i * KPAD + q * 64 + e0];
+  for (int q = 0; q < C::EPL; ++q) araw[q] = 0;
+  if (i < cell_end && arow_lane) {
+#pragma unroll
+    for (int q = 0; q < C::EPL; ++q) araw[q] = table[i * KPAD + q * 64 + lane];
   }
   // edges of the previous cell, stored while the current cell's gathers are in flight
   bool have_prev = false;
@@ -218,15 +239,23 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
   int prev_u[C::EPL];
 
   for (; i < cell_end; i += nwaves) {
-    const int64_t out_base = (i - cell_begin) * (int64_t)k;
-    uint32_t a[C::EPL];
+    uint32_t a[C::EPL], asafe[C::EPL];
     uint32_t flags = 0;
 #pragma unroll
     for (int q = 0; q < C::EPL; ++q) {
       flags |= araw[q];
       a[q] = araw[q] & ID_MASK;
+      // a slot without a usable id (padding, rejected id) gathers the cell's own row instead; its
+      // count is discarded at the store
+      asafe[q] = a[q] != 0 ? a[q] : (uint32_t)(i + 1);
     }
     bool slow = __ballot((flags & ROW_DUP_FLAG) != 0) != 0ull;
+    // next cell's own row: ahead of the gathers, so that it has landed by the next iteration
+    const int64_t i_next = i + nwaves;
+    if (i_next < cell_end && arow_lane) {
+#pragma unroll
+      for (int q = 0; q < C::EPL; ++q) araw[q] = table[i_next * KPAD + q * 64 + lane];
+    }
     int myslot[C::EPL];
     int nov = 0;
 #pragma unroll
@@ -235,7 +264,7 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
 #pragma unroll
       for (int q = 0; q < C::EPL; ++q) {
         bool over = false;
-        if (lane < KPAD && a[q] != 0) {      // group 0 inserts (the other groups hold replicas when KPAD < 64)
+        if (a[q] != 0) {
           const uint32_t bk = bucket_of<KPAD, BIG>(a[q]);
           uint32_t old = atomicCAS(&hslots[2 * bk], EMPTY, a[q]);
           if (old == EMPTY) {
@@ -258,93 +287,79 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
     int myu[C::EPL];
 #pragma unroll
     for (int q = 0; q < C::EPL; ++q) myu[q] = 0;
-    const int64_t i_next = i + nwaves;
-    bool next_issued = false;
+    bool prev_stored = false;
 
-    // next cell's own row: issued ahead of the gathers so that it has landed by the next iteration
-    if (i_next < cell_end) {
-#pragma unroll
-      for (int qq = 0; qq < C::EPL; ++qq) araw[qq] = table[i_next * KPAD + qq * 64 + e0];
-    }
     if (!slow) {
       uint32_t dupflags = 0;
 #pragma unroll
-      for (int q = 0; q < C::EPL; ++q) {        // q: which register of row i holds the slot's id
-        for (int t0 = 0; t0 < C::TPQ && (q * 64 + t0 * C::G) < k; t0 += C::U) {
-          uint32_t bv[C::U][C::EPL];
-          unsigned long long livem = 0;          // bit (uu*G + gg): that row exists (id != 0)
-          // issue the gathers of U steps (U*G neighbour rows) before consuming any
+      for (int q = 0; q < C::EPL; ++q) {        // q: which register of row i holds the slots of these steps
+        for (int t0 = 0; t0 < C::SPQ && (q * 64 + t0 * C::RPS) < k; t0 += C::U) {
+          uint4 bv[C::U];
+          // issue the gathers of U steps (U*RPS neighbour rows) before consuming any
 #pragma unroll
           for (int uu = 0; uu < C::U; ++uu) {
-            uint32_t dsel = 0;
-#pragma unroll
-            for (int gg = 0; gg < C::G; ++gg) {
-              uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)a[q], (t0 + uu) * C::G + gg);   // uniform
-              if (d != 0) livem |= 1ull << (uu * C::G + gg);
-              d = d != 0 ? d : 1u;
-              dsel = (gg == 0 || grp == gg) ? d : dsel;
-            }
-            const off_t rowoff = (off_t)(dsel - 1) * ROWB + (off_t)(e0 * 4);
-#pragma unroll
-            for (int qq = 0; qq < C::EPL; ++qq) {
-              const uint32_t raw = *reinterpret_cast<const uint32_t*>(tbytes + rowoff + qq * 256);
-              dupflags |= raw;
-              bv[uu][qq] = raw & ID_MASK;
-            }
+            const uint32_t dst = (uint32_t)__shfl((int)asafe[q], (t0 + uu) * C::RPS + grow);
+            const off_t off = (off_t)(dst - 1) * ROWB + gcol;
+            bv[uu] = *reinterpret_cast<const uint4*>(tbytes + off);
           }
-          if (!next_issued) {
+          if (!prev_stored) {
             // the previous cell's edges ride behind the gathers (younger in vmcnt order, so the
             // wait for the gathers does not wait for them)
-            next_issued = true;
+            prev_stored = true;
             if (have_prev) {
               const int64_t pb = (prev_i - cell_begin) * (int64_t)k;
 #pragma unroll
               for (int qq = 0; qq < C::EPL; ++qq) {
                 const int slot = qq * 64 + lane;
-                if (lane < KPAD && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
+                if (arow_lane && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
               }
               have_prev = false;
             }
           }
+          int cnt[C::U];
 #pragma unroll
           for (int uu = 0; uu < C::U; ++uu) {
-            unsigned long long m = 0;
-            int cnt_big = 0;
+            dupflags |= bv[uu].x;
+            bv[uu].x &= ID_MASK;             // only a row's first id can carry the duplicate flag
+            const uint2 h0 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].x)];
+            const uint2 h1 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].y)];
+            const uint2 h2 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].z)];
+            const uint2 h3 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].w)];
+            int c = 0;
+            c += (h0.x == bv[uu].x) | (h0.y == bv[uu].x);
+            c += (h1.x == bv[uu].y) | (h1.y == bv[uu].y);
+            c += (h2.x == bv[uu].z) | (h2.y == bv[uu].z);
+            c += (h3.x == bv[uu].w) | (h3.y == bv[uu].w);
+            cnt[uu] = c;
+          }
+          if (nov) {                          // wave-uniform, rare: ids that overflowed the set
+            for (int t = 0; t < nov; ++t) {
+              const uint32_t ov = ovlist[t];
 #pragma unroll
-            for (int qq = 0; qq < C::EPL; ++qq) {
-              const uint32_t b = bv[uu][qq];
-              const uint2 h = s_hash[wave][bucket_of<KPAD, BIG>(b)];
-              unsigned long long mm = __ballot(h.x == b) | __ballot(h.y == b);
-              for (int t = 0; t < nov; ++t) mm |= __ballot(b == ovlist[t]);
-              if (C::EPL == 1) m = mm; else cnt_big += __popcll(mm);
+              for (int uu = 0; uu < C::U; ++uu)
+                cnt[uu] += (bv[uu].x == ov) + (bv[uu].y == ov) + (bv[uu].z == ov) + (bv[uu].w == ov);
             }
-            if (C::EPL == 1) {
+          }
 #pragma unroll
-              for (int gg = 0; gg < C::G; ++gg) {
-                const unsigned long long gm = KPAD >= 64 ? m : ((m >> (gg * (KPAD & 63))) & ((1ull << (KPAD & 63)) - 1ull));
-                const int cnt = ((livem >> (uu * C::G + gg)) & 1ull) ? __popcll(gm) : 0;
-                myu[0] = gficf_writelane(cnt, (t0 + uu) * C::G + gg, myu[0]);
-              }
-            } else {
-              const int cnt = ((livem >> uu) & 1ull) ? cnt_big : 0;
-              myu[q] = gficf_writelane(cnt, t0 + uu, myu[q]);
-            }
+          for (int uu = 0; uu < C::U; ++uu) {
+            const int rowcnt = group_sum<C::LPR>(cnt[uu]);
+            // slot s = (t0+uu)*RPS + r lives in lane s of myu[q]; its count sits in lanes r*LPR..
+            const int v = __shfl(rowcnt, (lane % C::RPS) * C::LPR);
+            myu[q] = (lane / C::RPS == t0 + uu) ? v : myu[q];
           }
         }
       }
       // a neighbour row with duplicate ids: redo this cell exactly
       slow = __ballot((dupflags & ROW_DUP_FLAG) != 0) != 0ull;
     }
-    if (!next_issued) {    // own row with duplicates: the gather loop was skipped
-      if (have_prev) {
-        const int64_t pb = (prev_i - cell_begin) * (int64_t)k;
+    if (!prev_stored && have_prev) {    // own row with duplicates: the gather loop was skipped
+      const int64_t pb = (prev_i - cell_begin) * (int64_t)k;
 #pragma unroll
-        for (int qq = 0; qq < C::EPL; ++qq) {
-          const int slot = qq * 64 + lane;
-          if (lane < KPAD && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
-        }
-        have_prev = false;
+      for (int qq = 0; qq < C::EPL; ++qq) {
+        const int slot = qq * 64 + lane;
+        if (arow_lane && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
       }
+      have_prev = false;
     }
     // ---- clear this cell's keys from the set
 #pragma unroll
@@ -352,12 +367,16 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
       if (myslot[q] >= 0) hslots[myslot[q]] = EMPTY;
     wave_lds_fence();
     if (slow) {
-      slow_cell<KPAD>(table, i, k, out_base, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w, o.u, s_lut);
+      slow_cell<KPAD>(table, i, k, (i - cell_begin) * (int64_t)k, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w,
+                      o.u, s_lut);
     } else {
       have_prev = true;
       prev_i = i;
 #pragma unroll
-      for (int q = 0; q < C::EPL; ++q) { prev_a[q] = a[q]; prev_u[q] = myu[q]; }
+      for (int q = 0; q < C::EPL; ++q) {
+        prev_a[q] = a[q];
+        prev_u[q] = a[q] != 0 ? myu[q] : 0;      // rejected id: zero row
+      }
     }
   }
   if (have_prev) {
@@ -365,7 +384,7 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
 #pragma unroll
     for (int qq = 0; qq < C::EPL; ++qq) {
       const int slot = qq * 64 + lane;
-      if (lane < KPAD && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
+      if (arow_lane && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
     }
   }
 }
