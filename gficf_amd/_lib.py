@@ -10,7 +10,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgficf_hip.so")
+LIB_PATH = os.environ.get("GFICF_HIP_LIB") or os.path.join(_HERE, "libgficf_hip.so")
 
 GFICF_OK = 0
 STATUS_NAMES = {

@@ -19,6 +19,7 @@
 //               double, so they are bit-identical to the reference's division.
 //   * rows with duplicate ids (multiset semantics), hash overflow: exact slow path in the
 //               same kernel (all-pairs with occurrence ranks).
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -95,6 +96,55 @@ __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64
   }
 }
 
+// Register variant for KPAD <= 64: one thread per cell.  The k loads of a thread are independent
+// (all in flight at once) and each is a coalesced 256 B run per wave; duplicate detection is an
+// all-pairs compare in registers; the tile goes through LDS once so that the table is written as
+// contiguous 16 B-per-lane runs.
+constexpr int INGEST2_ROWS = 64;
+
+template <typename T, int KPAD>
+__global__ __launch_bounds__(INGEST2_ROWS) void k_ingest_reg(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
+                                                             int64_t N_total, uint32_t* __restrict__ table,
+                                                             uint32_t* __restrict__ status) {
+  __shared__ uint32_t tile[INGEST2_ROWS][KPAD + 1];
+  const int tid = threadIdx.x;
+  for (int64_t row0 = (int64_t)blockIdx.x * INGEST2_ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * INGEST2_ROWS) {
+    const int64_t r = row0 + tid;
+    uint32_t v[KPAD];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < KPAD; ++j) {
+      v[j] = 0;
+      if (j < k && r < n_rows) {
+        bool ok;
+        v[j] = decode_id<T>(idx[(int64_t)j * ld + r], N_total, ok);
+        bad |= !ok;
+      }
+    }
+    if (bad) atomicOr(status, GFICF_ST_BAD_ID);
+    bool dup = false;
+#pragma unroll
+    for (int j = 1; j < KPAD; ++j) {
+      bool dj = false;
+#pragma unroll
+      for (int j2 = 0; j2 < j; ++j2) dj |= (v[j] == v[j2]);
+      dup |= dj && v[j] != 0;
+    }
+    if (dup) v[0] |= ROW_DUP_FLAG;
+#pragma unroll
+    for (int j = 0; j < KPAD; ++j) tile[tid][j] = v[j];
+    __syncthreads();
+    const int64_t rows_here = (n_rows - row0) < INGEST2_ROWS ? (n_rows - row0) : INGEST2_ROWS;
+    const int n_out4 = (int)rows_here * (KPAD / 4);
+    uint4* const out4 = reinterpret_cast<uint4*>(table + row0 * KPAD);
+    for (int e = tid; e < n_out4; e += INGEST2_ROWS) {
+      const int rr = e / (KPAD / 4), jj = (e % (KPAD / 4)) * 4;
+      out4[e] = make_uint4(tile[rr][jj], tile[rr][jj + 1], tile[rr][jj + 2], tile[rr][jj + 3]);
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------- edges
 template <int KPAD>
 struct JCfg {
@@ -131,6 +181,9 @@ struct EdgeOut {
 
 __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint32_t dst, int u,
                                   const double* lut) {
+#ifdef GFICF_LAB_NOSTORE   // timing-only lab build: (almost) no output traffic
+  if (u != 12345) return;
+#endif
   const bool pos = u > 0;
   o.src[r] = pos ? (double)(uint32_t)(cell + 1) : 0.0;   // reference :49 (cell + 1 <= 2^31)
   o.dst[r] = pos ? (double)dst : 0.0;          // reference :50
@@ -299,7 +352,11 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
 #pragma unroll
           for (int uu = 0; uu < C::U; ++uu) {
             const uint32_t dst = (uint32_t)__shfl((int)asafe[q], (t0 + uu) * C::RPS + grow);
+#ifdef GFICF_LAB_NOGATHER   // timing-only lab build: every gather hits the cell's own row
+            const off_t off = (off_t)i * ROWB + gcol + (off_t)(dst & 0u);
+#else
             const off_t off = (off_t)(dst - 1) * ROWB + gcol;
+#endif
             bv[uu] = *reinterpret_cast<const uint4*>(tbytes + off);
           }
           if (!prev_stored) {
@@ -321,10 +378,19 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
           for (int uu = 0; uu < C::U; ++uu) {
             dupflags |= bv[uu].x;
             bv[uu].x &= ID_MASK;             // only a row's first id can carry the duplicate flag
+#if defined(GFICF_LAB_NOPROBE)     // timing-only lab build: no LDS probes at all
+            const uint2 h0 = make_uint2(bv[uu].y, 1u), h1 = make_uint2(bv[uu].z, 2u), h2 = make_uint2(bv[uu].w, 3u), h3 = make_uint2(bv[uu].x, 4u);
+#elif defined(GFICF_LAB_LINPROBE)  // timing-only lab build: conflict-free probe addresses
+            const uint2 h0 = s_hash[wave][(lane + (bv[uu].x & 0u)) & (C::NB - 1)];
+            const uint2 h1 = s_hash[wave][(lane + 64 + (bv[uu].y & 0u)) & (C::NB - 1)];
+            const uint2 h2 = s_hash[wave][(lane + 128 + (bv[uu].z & 0u)) & (C::NB - 1)];
+            const uint2 h3 = s_hash[wave][(lane + 192 + (bv[uu].w & 0u)) & (C::NB - 1)];
+#else
             const uint2 h0 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].x)];
             const uint2 h1 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].y)];
             const uint2 h2 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].z)];
             const uint2 h3 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].w)];
+#endif
             int c = 0;
             c += (h0.x == bv[uu].x) | (h0.y == bv[uu].x);
             c += (h1.x == bv[uu].y) | (h1.y == bv[uu].y);
@@ -393,19 +459,26 @@ template <typename T>
 int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t ld, int64_t N_total,
                   uint32_t* table) {
   const int kpad = kpad_for(k);
+  const int64_t cap = (int64_t)ctx->num_cus * 8;
+  const int64_t tiles2 = gficf_ceil_div(n_rows, INGEST2_ROWS);
+  const unsigned grid2 = (unsigned)(tiles2 < cap ? tiles2 : cap);
   const int64_t tiles = gficf_ceil_div(n_rows, INGEST_ROWS);
-  const unsigned grid = (unsigned)(tiles < (int64_t)ctx->num_cus * 8 ? tiles : (int64_t)ctx->num_cus * 8);
+  const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+#define LAUNCH_INGEST_REG(KP)                                                                                          \
+  hipLaunchKernelGGL((k_ingest_reg<T, KP>), dim3(grid2), dim3(INGEST2_ROWS), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
+                     table, ctx->d_status)
 #define LAUNCH_INGEST(KP)                                                                                   \
   hipLaunchKernelGGL((k_ingest<T, KP>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
                      table, ctx->d_status)
   switch (kpad) {
-    case 16: LAUNCH_INGEST(16); break;
-    case 32: LAUNCH_INGEST(32); break;
-    case 64: LAUNCH_INGEST(64); break;
+    case 16: LAUNCH_INGEST_REG(16); break;
+    case 32: LAUNCH_INGEST_REG(32); break;
+    case 64: LAUNCH_INGEST_REG(64); break;
     case 128: LAUNCH_INGEST(128); break;
     default: LAUNCH_INGEST(256); break;
   }
 #undef LAUNCH_INGEST
+#undef LAUNCH_INGEST_REG
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -419,6 +492,10 @@ int launch_edges_t(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
     int nb = 0;
     GFICF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_jaccard_edges<KPAD, BIG>, C::WAVES * 64, 0));
     blocks_per_cu = nb > 0 ? nb : 1;
+    if (const char* e = getenv("GFICF_JACCARD_BLOCKS_PER_CU")) {   // tuning knob
+      const int v = atoi(e);
+      if (v > 0) blocks_per_cu = v;
+    }
   }
   const int64_t blocks_needed = gficf_ceil_div(ce - cb, C::WAVES);
   const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
