@@ -280,17 +280,18 @@ class HipOps:
         check(self.L.gficf_csc_count_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),
                                             int(rowidx.numel()), _tptr(nt)))
 
-    def csc_genes(self, G, N_total, nt, prop_min, prop_max, w_in, keep, remap, w, gkept):
+    def csc_genes(self, G, N_total, nt, prop_min, prop_max, w_in, keep, genes, w, gkept):
+        """genes: (G, 2) float64 tensor used as raw storage for the 16-byte gficf_gene_entry records."""
         check(self.L.gficf_csc_genes_device(self._bind(), G, N_total, _tptr(nt), float(prop_min), float(prop_max),
-                                            _tptr(w_in), _tptr(keep), _tptr(remap), _tptr(w), _tptr(gkept)))
+                                            _tptr(w_in), _tptr(keep), _tptr(genes), _tptr(w), _tptr(gkept)))
 
     def csc_colptr(self, G, n_cells, colptr, rowidx, keep, gkept, out_colptr):
         check(self.L.gficf_csc_colptr_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(keep),
                                              _tptr(gkept), _tptr(out_colptr)))
 
-    def csc_scale(self, G, n_cells, colptr, rowidx, x, remap, w, out_colptr, out_rowidx, out_x):
+    def csc_scale(self, G, n_cells, colptr, rowidx, x, genes, out_colptr, out_rowidx, out_x):
         check(self.L.gficf_csc_scale_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),
-                                            int(rowidx.numel()), _tptr(remap), _tptr(w), _tptr(out_colptr),
+                                            int(rowidx.numel()), _tptr(genes), _tptr(out_colptr),
                                             _tptr(out_rowidx), _tptr(out_x)))
 
     def csc_workspace(self, G: int, n_cells: int, nnz: int) -> dict:
@@ -299,7 +300,7 @@ class HipOps:
         return dict(
             nt=tc.zeros(max(G, 1), dtype=tc.int64, device=dev),
             keep=tc.zeros(max(G, 1), dtype=tc.uint8, device=dev),
-            remap=tc.zeros(max(G, 1), dtype=tc.int32, device=dev),
+            genes=tc.zeros((max(G, 1), 2), dtype=tc.float64, device=dev),   # gficf_gene_entry[G]
             w=tc.zeros(max(G, 1), dtype=tc.float64, device=dev),
             gkept=tc.zeros(1, dtype=tc.int64, device=dev),
             out_colptr=tc.zeros(n_cells + 1, dtype=tc.int64, device=dev),
@@ -313,6 +314,6 @@ class HipOps:
         ws = ws or self.csc_workspace(G, N, int(rowidx.numel()))
         check(self.L.gficf_csc_device(self._bind(), G, N, _tptr(colptr), _tptr(rowidx), _tptr(x), int(rowidx.numel()),
                                       float(prop_min), float(prop_max), _tptr(w_in), _tptr(ws["nt"]),
-                                      _tptr(ws["keep"]), _tptr(ws["remap"]), _tptr(ws["w"]), _tptr(ws["gkept"]),
+                                      _tptr(ws["keep"]), _tptr(ws["genes"]), _tptr(ws["w"]), _tptr(ws["gkept"]),
                                       _tptr(ws["out_colptr"]), _tptr(ws["out_rowidx"]), _tptr(ws["out_x"])))
         return ws

@@ -22,10 +22,21 @@ namespace {
 // nt_g = #{cells c : x[g,c] != 0}  (explicitly stored zeros do not count, as in
 // rowSums(M != 0)).  Per-workgroup histogram in LDS (G counters), flushed with one global
 // atomic per touched gene; falls back to global atomics when G does not fit LDS.
+// Each workgroup sweeps one contiguous slab; a thread takes 4 consecutive entries per load
+// (16 B of rowidx, 2 x 16 B of x) and keeps two such groups in flight.
 constexpr int CNT_THREADS = 1024;
 constexpr int CNT_LDS_MAX_G = 36 * 1024;   // 144 KiB of uint32 counters
 
 template <bool USE_LDS>
+__device__ inline void count_one(int32_t g, double v, int64_t G, uint32_t* hist, unsigned long long* nt, bool& bad) {
+  if (g < 0 || g >= G) { bad = true; return; }
+  if (v != 0.0) {
+    if (USE_LDS) atomicAdd(&hist[g], 1u);
+    else atomicAdd(&nt[g], 1ull);
+  }
+}
+
+template <bool USE_LDS, bool VEC>
 __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __restrict__ rowidx,
                                                             const double* __restrict__ x, int64_t nnz, int64_t G,
                                                             unsigned long long* __restrict__ nt,
@@ -36,19 +47,29 @@ __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __res
     __syncthreads();
   }
   bool bad = false;
-  // each workgroup sweeps a contiguous slab (keeps one cell's distinct genes in one wave-instruction)
-  const int64_t per_block = gficf_ceil_div(gficf_ceil_div(nnz, (int64_t)gridDim.x), CNT_THREADS) * CNT_THREADS;
+  constexpr int64_t CHUNK = (int64_t)CNT_THREADS * 8;
+  const int64_t per_block = gficf_ceil_div(gficf_ceil_div(nnz, (int64_t)gridDim.x), CHUNK) * CHUNK;
   const int64_t p0 = (int64_t)blockIdx.x * per_block;
   const int64_t p1 = p0 + per_block < nnz ? p0 + per_block : nnz;
-  for (int64_t p = p0 + threadIdx.x; p < p1; p += CNT_THREADS) {
-    const int32_t g = rowidx[p];
-    const double v = x[p];
-    if (g < 0 || g >= G) { bad = true; continue; }
-    if (v != 0.0) {
-      if (USE_LDS) atomicAdd(&s_hist[g], 1u);
-      else atomicAdd(&nt[g], 1ull);
+  int64_t p = p0;
+  if (VEC) {
+    for (; p + CHUNK <= p1; p += CHUNK) {
+      const int64_t q = p + (int64_t)threadIdx.x * 4;
+      const int4 ga = *reinterpret_cast<const int4*>(rowidx + q);
+      const int4 gb = *reinterpret_cast<const int4*>(rowidx + q + CHUNK / 2);
+      const double2 xa0 = *reinterpret_cast<const double2*>(x + q), xa1 = *reinterpret_cast<const double2*>(x + q + 2);
+      const double2 xb0 = *reinterpret_cast<const double2*>(x + q + CHUNK / 2), xb1 = *reinterpret_cast<const double2*>(x + q + CHUNK / 2 + 2);
+      count_one<USE_LDS>(ga.x, xa0.x, G, s_hist, nt, bad);
+      count_one<USE_LDS>(ga.y, xa0.y, G, s_hist, nt, bad);
+      count_one<USE_LDS>(ga.z, xa1.x, G, s_hist, nt, bad);
+      count_one<USE_LDS>(ga.w, xa1.y, G, s_hist, nt, bad);
+      count_one<USE_LDS>(gb.x, xb0.x, G, s_hist, nt, bad);
+      count_one<USE_LDS>(gb.y, xb0.y, G, s_hist, nt, bad);
+      count_one<USE_LDS>(gb.z, xb1.x, G, s_hist, nt, bad);
+      count_one<USE_LDS>(gb.w, xb1.y, G, s_hist, nt, bad);
     }
   }
+  for (p += threadIdx.x; p < p1; p += CNT_THREADS) count_one<USE_LDS>(rowidx[p], x[p], G, s_hist, nt, bad);
   if (bad) atomicOr(status, GFICF_ST_BAD_CSC);
   if (USE_LDS) {
     __syncthreads();
@@ -60,53 +81,78 @@ __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __res
 }
 
 // --------------------------------------------------- gene table: keep / remap / weights
-// One workgroup.  keep_g = nt_g > N*min && nt_g <= N*max (double compare, R/gficf.R:41);
-// remap = exclusive scan of keep (new row id of a kept gene); w_g = log((N+1)/(nt_g+1))
-// (R/gficf.R:89) or the supplied weight.
+// keep_g = nt_g > N*min && nt_g <= N*max (double compare, R/gficf.R:41); remap = exclusive
+// scan of keep (new row id of a kept gene); w_g = log((N+1)/(nt_g+1)) (R/gficf.R:89) or the
+// supplied weight.  One workgroup per 1024 genes; a workgroup obtains the number of kept
+// genes in front of its tile by counting over nt[0 .. tile) itself (G is a few 10^4, the
+// counters sit in L2), so there is no cross-workgroup dependency.
 constexpr int GT_THREADS = 1024;
+
+__device__ inline int block_sum_i32(int v, int* s_red) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  int t = 0;
+#pragma unroll
+  for (int w = 0; w < GT_THREADS / 64; ++w) t += s_red[w];
+  __syncthreads();
+  return t;
+}
 
 __global__ __launch_bounds__(GT_THREADS) void k_gene_table(int64_t G, int64_t N_total, const int64_t* __restrict__ nt,
                                                            double prop_min, double prop_max,
                                                            const double* __restrict__ w_in, uint8_t* __restrict__ keep,
-                                                           int32_t* __restrict__ remap, double* __restrict__ w,
+                                                           gficf_gene_entry* __restrict__ genes, double* __restrict__ w,
                                                            int64_t* __restrict__ gkept) {
-  __shared__ int32_t s_part[GT_THREADS];
-  const int tid = threadIdx.x;
-  const int64_t per = gficf_ceil_div(G, GT_THREADS);
-  const int64_t g0 = (int64_t)tid * per, g1 = g0 + per < G ? g0 + per : G;
+  __shared__ int s_red[GT_THREADS / 64];
+  __shared__ int s_wave_excl[GT_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const double lo = (double)N_total * prop_min, hi = (double)N_total * prop_max;
-  int32_t cnt = 0;
-  for (int64_t g = g0; g < g1; ++g) {
+  const int64_t tile0 = (int64_t)blockIdx.x * GT_THREADS;
+  // kept genes in front of this tile
+  int before = 0;
+  for (int64_t g = tid; g < tile0; g += GT_THREADS) {
     const double c = (double)nt[g];
-    cnt += (c > lo && c <= hi) ? 1 : 0;
+    before += (c > lo && c <= hi) ? 1 : 0;
   }
-  s_part[tid] = cnt;
+  before = block_sum_i32(before, s_red);
+  const int64_t g = tile0 + tid;
+  double c = 0.0;
+  bool kp = false;
+  if (g < G) {
+    c = (double)nt[g];
+    kp = c > lo && c <= hi;
+  }
+  const unsigned long long m = __ballot(kp);
+  if (lane == 0) s_red[wave] = __popcll(m);
   __syncthreads();
-  // Hillis-Steele inclusive scan over the 1024 partials
-  for (int d = 1; d < GT_THREADS; d <<= 1) {
-    int32_t t = tid >= d ? s_part[tid - d] : 0;
-    __syncthreads();
-    s_part[tid] += t;
-    __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int wv = 0; wv < GT_THREADS / 64; ++wv) { s_wave_excl[wv] = run; run += s_red[wv]; }
+    if (tile0 + GT_THREADS >= G) *gkept = (int64_t)before + run;     // last tile publishes the total
   }
-  int32_t r = s_part[tid] - cnt;
-  for (int64_t g = g0; g < g1; ++g) {
-    const double c = (double)nt[g];
-    const bool kp = c > lo && c <= hi;
-    keep[g] = kp ? 1 : 0;
-    remap[g] = kp ? r : -1;
-    r += kp ? 1 : 0;
+  __syncthreads();
+  if (g < G) {
+    const int r = before + s_wave_excl[wave] + __popcll(m & ((1ull << lane) - 1ull));
     double wv = 0.0;
     if (kp) wv = w_in ? w_in[g] : log(((double)N_total + 1.0) / (c + 1.0));
+    keep[g] = kp ? 1 : 0;
     w[g] = wv;
+    gficf_gene_entry e;
+    e.w = wv;
+    e.remap = kp ? r : -1;
+    e.reserved = 0;
+    genes[g] = e;
   }
-  if (tid == GT_THREADS - 1) *gkept = (int64_t)s_part[tid];
 }
 
 // ------------------------------------------------------- pass B0: kept entries per cell
 // One wave per cell; out[c] = #{entries of cell c whose gene is kept}; out[n_cells] = 0,
-// turned into the new colptr by an exclusive scan.  When no gene is dropped the count is
-// the old column length and rowidx is not read at all.
+// turned into the new colptr by an exclusive scan.  The keep mask is staged as a bitmask in
+// LDS (G bits).  When no gene is dropped the count is the old column length and rowidx is
+// not read at all.
 constexpr int CC_THREADS = 256;
 
 __global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64_t n_cells,
@@ -115,11 +161,33 @@ __global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64
                                                                 const uint8_t* __restrict__ keep,
                                                                 const int64_t* __restrict__ gkept,
                                                                 int64_t* __restrict__ out, uint32_t* __restrict__ status) {
+  extern __shared__ uint32_t s_bits[];      // ceil(G/32) words
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * CC_THREADS + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * CC_THREADS) >> 6;
   const bool all_kept = (*gkept == G);
   if (wave == 0 && lane == 0) out[n_cells] = 0;
+  if (!all_kept) {
+    const int64_t words = (G + 31) / 32;
+    const bool aligned4 = ((uintptr_t)keep & 3u) == 0;
+    for (int64_t wd = threadIdx.x; wd < words; wd += CC_THREADS) {
+      uint32_t bits = 0;
+      const int64_t g0 = wd * 32;
+      if (aligned4 && g0 + 32 <= G) {            // 32 keep bytes (0/1) -> one word
+        const uint32_t* k4 = reinterpret_cast<const uint32_t*>(keep + g0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const uint32_t v = k4[t];
+          bits |= ((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * t);
+        }
+      } else {
+        for (int b = 0; b < 32; ++b)
+          if (g0 + b < G && keep[g0 + b]) bits |= 1u << b;
+      }
+      s_bits[wd] = bits;
+    }
+    __syncthreads();
+  }
   for (int64_t c = wave; c < n_cells; c += nwaves) {
     const int64_t p0 = colptr[c], p1 = colptr[c + 1];
     if (p1 < p0) { if (lane == 0) { atomicOr(status, GFICF_ST_BAD_CSC); out[c] = 0; } continue; }
@@ -130,7 +198,7 @@ __global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64
       int n = 0;
       for (int64_t p = p0 + lane; p < p1; p += 64) {
         const int32_t g = rowidx[p];
-        n += (g >= 0 && g < G) ? keep[g] : 0;
+        if (g >= 0 && g < G) n += (s_bits[g >> 5] >> (g & 31)) & 1u;
       }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
@@ -143,12 +211,15 @@ __global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64
 // ---------------------------------------------------------------- pass B: scale a cell
 // One workgroup of SC_WAVES waves per cell.  Wave w owns a contiguous run of the cell's
 // entries, so kept entries keep their order and every wave's output run is contiguous.
-//   sweep 1: S_c = sum of kept x (R/gficf.R:59), kept count per wave
-//   sweep 2: v = (x / S_c) * w_g (R/gficf.R:59,79); q_c = sum v^2 (R/gficf.R:100)
-//   sweep 3: out = (1/sqrt(q_c), Inf -> 0) * v (R/gficf.R:100-103), compacted + renumbered
-// Sweeps 2 and 3 re-read the cell's entries from L2 (a cell is a few tens of KB).
+// A cell of up to SC_WAVES*64*SC_CH entries is read from HBM exactly once: every thread keeps
+// its entries (x, weight, new row id) in registers across the two workgroup reductions
+//   S_c = sum of kept x                      (R/gficf.R:59)
+//   q_c = sum ((x / S_c) * w_g)^2            (R/gficf.R:59,79,100)
+// and then writes  (1/sqrt(q_c), Inf -> 0) * ((x / S_c) * w_g)   (R/gficf.R:100-103) compacted
+// and renumbered.  Longer cells take three sweeps (the re-reads hit L2).
 constexpr int SC_WAVES = 4;
 constexpr int SC_THREADS = SC_WAVES * 64;
+constexpr int SC_CH = 8;
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -160,8 +231,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
                                                             const int64_t* __restrict__ colptr,
                                                             const int32_t* __restrict__ rowidx,
                                                             const double* __restrict__ x,
-                                                            const int32_t* __restrict__ remap,
-                                                            const double* __restrict__ w,
+                                                            const gficf_gene_entry* __restrict__ genes,
                                                             const int64_t* __restrict__ out_colptr,
                                                             int32_t* __restrict__ out_rowidx,
                                                             double* __restrict__ out_x) {
@@ -169,6 +239,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
   __shared__ int32_t s_cnt[SC_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int4* const gtab = reinterpret_cast<const int4*>(genes);
   for (int64_t c = blockIdx.x; c < n_cells; c += gridDim.x) {
     const int64_t p0 = colptr[c], p1 = colptr[c + 1];
     const int64_t len = p1 - p0;
@@ -176,13 +247,36 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
     const int64_t seg = gficf_ceil_div(gficf_ceil_div(len, SC_WAVES), 64) * 64;
     const int64_t a0 = p0 + (int64_t)wave * seg < p1 ? p0 + (int64_t)wave * seg : p1;
     const int64_t a1 = a0 + seg < p1 ? a0 + seg : p1;
-    // sweep 1
+    const bool cached = seg <= 64 * SC_CH;          // uniform over the workgroup
     double S = 0.0;
     int kept = 0;
-    for (int64_t p = a0 + lane; p < a1; p += 64) {
-      const int32_t g = rowidx[p];
-      const bool kp = (g >= 0 && g < G) && remap[g] >= 0;
-      if (kp) { S += x[p]; ++kept; }
+    double xv[SC_CH], wv[SC_CH];
+    int32_t rv[SC_CH];
+    if (cached) {
+      int32_t gv[SC_CH];
+#pragma unroll
+      for (int m = 0; m < SC_CH; ++m) {
+        const int64_t p = a0 + m * 64 + lane;
+        gv[m] = -1;
+        xv[m] = 0.0;
+        if (p < a1) { gv[m] = rowidx[p]; xv[m] = x[p]; }
+      }
+#pragma unroll
+      for (int m = 0; m < SC_CH; ++m) {
+        rv[m] = -1;
+        wv[m] = 0.0;
+        if (gv[m] >= 0 && gv[m] < G) {
+          const int4 e = gtab[gv[m]];
+          rv[m] = e.z;
+          wv[m] = __hiloint2double(e.y, e.x);
+        }
+        if (rv[m] >= 0) { S += xv[m]; ++kept; }
+      }
+    } else {
+      for (int64_t p = a0 + lane; p < a1; p += 64) {
+        const int32_t g = rowidx[p];
+        if (g >= 0 && g < G && gtab[g].z >= 0) { S += x[p]; ++kept; }
+      }
     }
     S = wave_sum(S);
 #pragma unroll
@@ -197,13 +291,22 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
       if (t < wave) opos += s_cnt[t];
     }
     __syncthreads();
-    // sweep 2
     double q = 0.0;
-    if (Sc != 0.0) {
+    if (cached) {
+#pragma unroll
+      for (int m = 0; m < SC_CH; ++m) {
+        double v = 0.0;
+        if (rv[m] >= 0 && Sc != 0.0) v = (xv[m] / Sc) * wv[m];
+        xv[m] = v;
+        q += v * v;
+      }
+    } else if (Sc != 0.0) {
       for (int64_t p = a0 + lane; p < a1; p += 64) {
         const int32_t g = rowidx[p];
-        const bool kp = (g >= 0 && g < G) && remap[g] >= 0;
-        if (kp) { const double v = (x[p] / Sc) * w[g]; q += v * v; }
+        if (g >= 0 && g < G) {
+          const int4 e = gtab[g];
+          if (e.z >= 0) { const double v = (x[p] / Sc) * __hiloint2double(e.y, e.x); q += v * v; }
+        }
       }
     }
     q = wave_sum(q);
@@ -215,25 +318,43 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
     __syncthreads();
     double nv = 1.0 / sqrt(qc);
     if (isinf(nv)) nv = 0.0;                        // R/gficf.R:101
-    // sweep 3
-    for (int64_t pb = a0; pb < a1; pb += 64) {
-      const int64_t p = pb + lane;
-      bool kp = false;
-      int32_t r = -1;
-      double v = 0.0;
-      if (p < a1) {
-        const int32_t g = rowidx[p];
-        if (g >= 0 && g < G) r = remap[g];
-        kp = r >= 0;
-        if (kp && Sc != 0.0) v = nv * ((x[p] / Sc) * w[g]);
+    if (cached) {
+#pragma unroll
+      for (int m = 0; m < SC_CH; ++m) {
+        if (a0 + m * 64 < a1) {                     // uniform over the wave
+          const bool kp = rv[m] >= 0;
+          const unsigned long long mk = __ballot(kp);
+          if (kp) {
+            const int64_t dst = opos + __popcll(mk & lt_mask);
+            out_rowidx[dst] = rv[m];
+            out_x[dst] = nv * xv[m];
+          }
+          opos += __popcll(mk);
+        }
       }
-      const unsigned long long m = __ballot(kp);
-      if (kp) {
-        const int64_t dst = opos + __popcll(m & lt_mask);
-        out_rowidx[dst] = r;
-        out_x[dst] = v;
+    } else {
+      for (int64_t pb = a0; pb < a1; pb += 64) {
+        const int64_t p = pb + lane;
+        bool kp = false;
+        int32_t r = -1;
+        double v = 0.0;
+        if (p < a1) {
+          const int32_t g = rowidx[p];
+          if (g >= 0 && g < G) {
+            const int4 e = gtab[g];
+            r = e.z;
+            kp = r >= 0;
+            if (kp && Sc != 0.0) v = nv * ((x[p] / Sc) * __hiloint2double(e.y, e.x));
+          }
+        }
+        const unsigned long long mk = __ballot(kp);
+        if (kp) {
+          const int64_t dst = opos + __popcll(mk & lt_mask);
+          out_rowidx[dst] = r;
+          out_x[dst] = v;
+        }
+        opos += __popcll(mk);
       }
-      opos += __popcll(m);
     }
   }
 }
@@ -252,35 +373,41 @@ int gficf_csc_count_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
   if (nnz == 0 || G == 0) return GFICF_OK;
   if (!d_rowidx || !d_x || !d_nt) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   int64_t blocks = gficf_ceil_div(nnz, (int64_t)CNT_THREADS * 16);
-  if (blocks > ctx->num_cus) blocks = ctx->num_cus;
+  // 16 B vector loads need 16 B-aligned bases (slab starts are multiples of 8192 entries)
+  const bool vec = (((uintptr_t)d_rowidx | (uintptr_t)d_x) & 15u) == 0;
   if (G <= CNT_LDS_MAX_G) {
+    // LDS histogram: G counters per workgroup; as many workgroups per CU as LDS allows
     const size_t lds = (size_t)G * sizeof(uint32_t);
+    int per_cu = (int)((160 * 1024) / (lds + 256));
+    per_cu = per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu;
+    if (blocks > (int64_t)ctx->num_cus * per_cu) blocks = (int64_t)ctx->num_cus * per_cu;
     static bool attr_set[64] = {};
     if (!attr_set[ctx->device & 63]) {
-      GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_gene_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CNT_LDS_MAX_G * (int)sizeof(uint32_t)));
+      GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_gene_count<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CNT_LDS_MAX_G * (int)sizeof(uint32_t)));
+      GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_gene_count<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CNT_LDS_MAX_G * (int)sizeof(uint32_t)));
       attr_set[ctx->device & 63] = true;
     }
-    hipLaunchKernelGGL(k_gene_count<true>, dim3((unsigned)blocks), dim3(CNT_THREADS), lds, ctx->stream, d_rowidx, d_x,
-                       nnz, G, (unsigned long long*)d_nt, ctx->d_status);
+    if (vec) hipLaunchKernelGGL((k_gene_count<true, true>), dim3((unsigned)blocks), dim3(CNT_THREADS), lds, ctx->stream, d_rowidx, d_x, nnz, G, (unsigned long long*)d_nt, ctx->d_status);
+    else hipLaunchKernelGGL((k_gene_count<true, false>), dim3((unsigned)blocks), dim3(CNT_THREADS), lds, ctx->stream, d_rowidx, d_x, nnz, G, (unsigned long long*)d_nt, ctx->d_status);
   } else {
-    blocks = gficf_ceil_div(nnz, (int64_t)CNT_THREADS * 16);
     if (blocks > (int64_t)ctx->num_cus * 2) blocks = (int64_t)ctx->num_cus * 2;
-    hipLaunchKernelGGL(k_gene_count<false>, dim3((unsigned)blocks), dim3(CNT_THREADS), 0, ctx->stream, d_rowidx, d_x,
-                       nnz, G, (unsigned long long*)d_nt, ctx->d_status);
+    if (vec) hipLaunchKernelGGL((k_gene_count<false, true>), dim3((unsigned)blocks), dim3(CNT_THREADS), 0, ctx->stream, d_rowidx, d_x, nnz, G, (unsigned long long*)d_nt, ctx->d_status);
+    else hipLaunchKernelGGL((k_gene_count<false, false>), dim3((unsigned)blocks), dim3(CNT_THREADS), 0, ctx->stream, d_rowidx, d_x, nnz, G, (unsigned long long*)d_nt, ctx->d_status);
   }
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
 
 int gficf_csc_genes_device(gficf_ctx* ctx, int64_t G, int64_t N_total, const int64_t* d_nt, double prop_min,
-                           double prop_max, const double* d_w_in, uint8_t* d_keep, int32_t* d_remap, double* d_w,
+                           double prop_max, const double* d_w_in, uint8_t* d_keep, gficf_gene_entry* d_genes, double* d_w,
                            int64_t* d_gkept) {
   GFICF_CTX_ENTER(ctx);
   if (G < 0 || N_total < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (G > 0x7FFFFFFFll) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "G = %lld exceeds int32 row indices", (long long)G);
-  if (!d_gkept || (G > 0 && (!d_nt || !d_keep || !d_remap || !d_w))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
-  hipLaunchKernelGGL(k_gene_table, dim3(1), dim3(GT_THREADS), 0, ctx->stream, G, N_total, d_nt, prop_min, prop_max,
-                     d_w_in, d_keep, d_remap, d_w, d_gkept);
+  if (!d_gkept || (G > 0 && (!d_nt || !d_keep || !d_genes || !d_w))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  const int64_t tiles = G > 0 ? gficf_ceil_div(G, GT_THREADS) : 1;
+  hipLaunchKernelGGL(k_gene_table, dim3((unsigned)tiles), dim3(GT_THREADS), 0, ctx->stream, G, N_total, d_nt, prop_min, prop_max,
+                     d_w_in, d_keep, d_genes, d_w, d_gkept);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -293,31 +420,33 @@ int gficf_csc_colptr_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const in
   if (!d_colptr || !d_out_colptr || !d_gkept || !d_keep) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   int64_t blocks = gficf_ceil_div(n_cells > 0 ? n_cells : 1, CC_THREADS / 64);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
-  hipLaunchKernelGGL(k_cell_kept_count, dim3((unsigned)blocks), dim3(CC_THREADS), 0, ctx->stream, G, n_cells, d_colptr,
+  const size_t lds = (size_t)((G + 31) / 32) * sizeof(uint32_t);     // G <= 2^31 -> at most 256 MiB: checked below
+  if (lds > 64 * 1024) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "G = %lld too large for the LDS keep bitmask", (long long)G);
+  hipLaunchKernelGGL(k_cell_kept_count, dim3((unsigned)blocks), dim3(CC_THREADS), lds, ctx->stream, G, n_cells, d_colptr,
                      d_rowidx, d_keep, d_gkept, d_out_colptr, ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
   return gficf_exclusive_scan_i64(ctx, d_out_colptr, n_cells + 1);
 }
 
 int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
-                           const int32_t* d_rowidx, const double* d_x, int64_t nnz, const int32_t* d_remap,
-                           const double* d_w, const int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
+                           const int32_t* d_rowidx, const double* d_x, int64_t nnz, const gficf_gene_entry* d_genes,
+                           const int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
   GFICF_CTX_ENTER(ctx);
   if (G < 0 || n_cells < 0 || nnz < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (n_cells == 0 || nnz == 0) return GFICF_OK;
-  if (!d_colptr || !d_rowidx || !d_x || !d_remap || !d_w || !d_out_colptr || !d_out_rowidx || !d_out_x)
+  if (!d_colptr || !d_rowidx || !d_x || !d_genes || !d_out_colptr || !d_out_rowidx || !d_out_x)
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   int64_t blocks = n_cells;
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
   hipLaunchKernelGGL(k_scale_cells, dim3((unsigned)blocks), dim3(SC_THREADS), 0, ctx->stream, G, n_cells, d_colptr,
-                     d_rowidx, d_x, d_remap, d_w, d_out_colptr, d_out_rowidx, d_out_x);
+                     d_rowidx, d_x, d_genes, d_out_colptr, d_out_rowidx, d_out_x);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
 
 int gficf_csc_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colptr, const int32_t* d_rowidx,
                      const double* d_x, int64_t nnz, double prop_min, double prop_max, const double* d_w_in,
-                     int64_t* d_nt, uint8_t* d_keep, int32_t* d_remap, double* d_w, int64_t* d_gkept,
+                     int64_t* d_nt, uint8_t* d_keep, gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept,
                      int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
   GFICF_CTX_ENTER(ctx);
   if (G < 0 || N < 0 || nnz < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
@@ -327,12 +456,11 @@ int gficf_csc_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colp
   }
   int rc = gficf_csc_count_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_nt);
   if (rc) return rc;
-  rc = gficf_csc_genes_device(ctx, G, N, d_nt, prop_min, prop_max, d_w_in, d_keep, d_remap, d_w, d_gkept);
+  rc = gficf_csc_genes_device(ctx, G, N, d_nt, prop_min, prop_max, d_w_in, d_keep, d_genes, d_w, d_gkept);
   if (rc) return rc;
   rc = gficf_csc_colptr_device(ctx, G, N, d_colptr, d_rowidx, d_keep, d_gkept, d_out_colptr);
   if (rc) return rc;
-  return gficf_csc_scale_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_remap, d_w, d_out_colptr, d_out_rowidx,
-                                d_out_x);
+  return gficf_csc_scale_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_genes, d_out_colptr, d_out_rowidx, d_out_x);
 }
 
 }  // extern "C"
@@ -347,7 +475,7 @@ struct gficf_host_plan {
   double* d_w_in = nullptr;
   int64_t* d_nt = nullptr;
   uint8_t* d_keep = nullptr;
-  int32_t* d_remap = nullptr;
+  gficf_gene_entry* d_genes = nullptr;
   double* d_w = nullptr;
   int64_t* d_gkept = nullptr;
   int64_t* d_out_colptr = nullptr;
@@ -356,7 +484,7 @@ struct gficf_host_plan {
 void gficf_host_plan_free(gficf_ctx* ctx) {
   gficf_host_plan* p = ctx->plan;
   if (!p) return;
-  void* ptrs[] = {p->d_colptr, p->d_rowidx, p->d_x, p->d_w_in, p->d_nt, p->d_keep, p->d_remap, p->d_w, p->d_gkept, p->d_out_colptr};
+  void* ptrs[] = {p->d_colptr, p->d_rowidx, p->d_x, p->d_w_in, p->d_nt, p->d_keep, p->d_genes, p->d_w, p->d_gkept, p->d_out_colptr};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
@@ -400,7 +528,7 @@ int gficf_normalize_csc_host_plan(gficf_ctx* ctx, int64_t G, int64_t N, const vo
   PLAN_HIP(hipMalloc((void**)&p->d_x, sizeof(double) * nsz));
   PLAN_HIP(hipMalloc((void**)&p->d_nt, sizeof(int64_t) * gsz));
   PLAN_HIP(hipMalloc((void**)&p->d_keep, gsz));
-  PLAN_HIP(hipMalloc((void**)&p->d_remap, sizeof(int32_t) * gsz));
+  PLAN_HIP(hipMalloc((void**)&p->d_genes, sizeof(gficf_gene_entry) * gsz));
   PLAN_HIP(hipMalloc((void**)&p->d_w, sizeof(double) * gsz));
   PLAN_HIP(hipMalloc((void**)&p->d_gkept, sizeof(int64_t)));
   PLAN_HIP(hipMalloc((void**)&p->d_out_colptr, sizeof(int64_t) * ((size_t)N + 1)));
@@ -415,7 +543,7 @@ int gficf_normalize_csc_host_plan(gficf_ctx* ctx, int64_t G, int64_t N, const vo
   }
   PLAN_HIP(hipMemsetAsync(p->d_nt, 0, sizeof(int64_t) * gsz, ctx->stream));
   int rc = gficf_csc_count_device(ctx, G, N, p->d_colptr, p->d_rowidx, p->d_x, nnz, p->d_nt);
-  if (!rc) rc = gficf_csc_genes_device(ctx, G, N, p->d_nt, prop_min, prop_max, p->d_w_in, p->d_keep, p->d_remap, p->d_w, p->d_gkept);
+  if (!rc) rc = gficf_csc_genes_device(ctx, G, N, p->d_nt, prop_min, prop_max, p->d_w_in, p->d_keep, p->d_genes, p->d_w, p->d_gkept);
   if (!rc) rc = gficf_csc_colptr_device(ctx, G, N, p->d_colptr, p->d_rowidx, p->d_keep, p->d_gkept, p->d_out_colptr);
   int64_t hk[2] = {0, 0};
   if (!rc) {
@@ -445,7 +573,7 @@ int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, 
   PLAN_HIP(hipMalloc((void**)&d_ori, sizeof(int32_t) * ksz));
   hipError_t e2 = hipMalloc((void**)&d_ox, sizeof(double) * ksz);
   if (e2 != hipSuccess) { (void)hipFree(d_ori); PLAN_HIP(e2); }
-  int rc = gficf_csc_scale_device(ctx, p->G, p->N, p->d_colptr, p->d_rowidx, p->d_x, p->nnz, p->d_remap, p->d_w,
+  int rc = gficf_csc_scale_device(ctx, p->G, p->N, p->d_colptr, p->d_rowidx, p->d_x, p->nnz, p->d_genes,
                                   p->d_out_colptr, d_ori, d_ox);
   std::vector<int64_t> cp((size_t)p->N + 1);
   hipError_t e = hipSuccess;

@@ -160,9 +160,9 @@ def test_device_pipeline_and_cell_block_seam():
     xs, rs = [], []
     for n, lcp, lri, lx in blocks:
         w2 = ops.csc_workspace(G, n, int(lri.numel()))
-        ops.csc_genes(G, N, nt, 0.05, 1.0, None, w2["keep"], w2["remap"], w2["w"], w2["gkept"])
+        ops.csc_genes(G, N, nt, 0.05, 1.0, None, w2["keep"], w2["genes"], w2["w"], w2["gkept"])
         ops.csc_colptr(G, n, lcp, lri, w2["keep"], w2["gkept"], w2["out_colptr"])
-        ops.csc_scale(G, n, lcp, lri, lx, w2["remap"], w2["w"], w2["out_colptr"], w2["out_rowidx"], w2["out_x"])
+        ops.csc_scale(G, n, lcp, lri, lx, w2["genes"], w2["out_colptr"], w2["out_rowidx"], w2["out_x"])
         ops.sync()
         m = int(w2["out_colptr"][n])
         xs.append(w2["out_x"][:m].cpu().numpy())
