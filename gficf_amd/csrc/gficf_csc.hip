@@ -196,7 +196,16 @@ __global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64
       cnt = p1 - p0;
     } else {
       int n = 0;
-      for (int64_t p = p0 + lane; p < p1; p += 64) {
+      int64_t p = p0 + lane;
+      for (; p + 7 * 64 < p1; p += 8 * 64) {        // 8 independent loads in flight per lane
+        int32_t g[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) g[t] = rowidx[p + t * 64];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (g[t] >= 0 && g[t] < G) n += (s_bits[g[t] >> 5] >> (g[t] & 31)) & 1u;
+      }
+      for (; p < p1; p += 64) {
         const int32_t g = rowidx[p];
         if (g >= 0 && g < G) n += (s_bits[g >> 5] >> (g & 31)) & 1u;
       }
@@ -261,15 +270,16 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
         xv[m] = 0.0;
         if (p < a1) { gv[m] = rowidx[p]; xv[m] = x[p]; }
       }
+      // all gene-record gathers are issued before any is consumed (ids outside [0, G) re-read
+      // record 0 and are masked afterwards)
+      int4 ge[SC_CH];
+#pragma unroll
+      for (int m = 0; m < SC_CH; ++m) ge[m] = gtab[(gv[m] >= 0 && gv[m] < G) ? gv[m] : 0];
 #pragma unroll
       for (int m = 0; m < SC_CH; ++m) {
-        rv[m] = -1;
-        wv[m] = 0.0;
-        if (gv[m] >= 0 && gv[m] < G) {
-          const int4 e = gtab[gv[m]];
-          rv[m] = e.z;
-          wv[m] = __hiloint2double(e.y, e.x);
-        }
+        const bool valid = gv[m] >= 0 && gv[m] < G;
+        rv[m] = valid ? ge[m].z : -1;
+        wv[m] = __hiloint2double(ge[m].y, ge[m].x);
         if (rv[m] >= 0) { S += xv[m]; ++kept; }
       }
     } else {
