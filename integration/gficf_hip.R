@@ -1,0 +1,25 @@
+# gficf_hip.R — R side of the drop-in (replaces the bodies of tf/getIdfW/idf/l.norm in gficf();
+# reference R/gficf.R:17-33).  Signature, defaults and the returned list fields are unchanged.
+gficf = function(M, cell_proportion_max = 1, cell_proportion_min = 0.05, storeRaw = TRUE, normalize = TRUE, verbose = TRUE)
+{
+  data = list()
+  M = methods::as(M, "CsparseMatrix")
+  r = .Call(`_gficf_gficf_csc`, M@i, M@p, M@x, M@Dim, NULL, cell_proportion_min, cell_proportion_max)
+  keep = as.logical(r[[4]])
+  data$gficf = Matrix::sparseMatrix(i = r[[1]], p = r[[2]], x = r[[3]], index1 = FALSE,
+                                    dims = c(sum(keep), ncol(M)), dimnames = list(rownames(M)[keep], colnames(M)))
+  if (storeRaw) {
+    raw = M[keep, ]
+    # the edgeR branch (reference R/gficf.R:43-47) only rescales what is stored here: a per-cell scale
+    # cancels in x/colSums(x), so $gficf is the same with or without it
+    if (normalize) raw = Matrix::Matrix(edgeR::cpm(edgeR::calcNormFactors(edgeR::DGEList(counts = raw))), sparse = TRUE)
+    data$rawCounts = raw
+  }
+  data$w = stats::setNames(r[[6]][keep], rownames(M)[keep])
+  data$param <- list(cell_proportion_max = cell_proportion_max, cell_proportion_min = cell_proportion_min, normalized = normalize)
+  return(data)
+}
+
+# embedNewCells() keeps its name matching (reference R/gficf.R:69-78) in R and calls
+#   .Call(`_gficf_gficf_csc`, x@i, x@p, x@x, x@Dim, as.numeric(data$w[rownames(x)]), 0, 2)
+# in place of tf() / idf() / l.norm() (reference R/cellClassifier.R:50-53).

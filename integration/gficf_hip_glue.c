@@ -1,0 +1,92 @@
+/* gficf_hip_glue.c — R `.Call` glue over libgficf_hip.so (C ABI: include/gficf_hip.h).
+ *
+ * NOT compiled in this repository's CI: R and <Rinternals.h> are absent from the build image.
+ * A maintainer of the gficf R package drops this file into src/, removes
+ * src/rcpp_parallel_jaccard_coeff.cpp, deletes the `_gficf_rcpp_parallel_jaccard_coef` wrapper and
+ * its CallEntries row from the generated src/RcppExports.cpp (reference :59-70, :89) and adds
+ *   PKG_CPPFLAGS += -I$(GFICF_HIP_HOME)/include
+ *   PKG_LIBS     += -L$(GFICF_HIP_HOME)/gficf_amd -lgficf_hip -Wl,-rpath,$(GFICF_HIP_HOME)/gficf_amd
+ * to src/Makevars (reference src/Makevars:5-12).  Plain C, no Rcpp dependency.
+ *
+ * Symbols
+ *   _gficf_rcpp_parallel_jaccard_coef(mat, printOutput)  — SAME name/arity as the reference entry
+ *       (src/RcppExports.cpp:61): R/RcppExports.R:16-18 and clustcells() (R/clustCells.R:65) stay as is.
+ *   _gficf_gficf_csc(i, p, x, dim, w, min, max)          — NEW entry for the GF-ICF chain of
+ *       R/gficf.R:38-105 (the reference has no native entry on that path).
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+#include <stdint.h>
+
+#include "gficf_hip.h"
+
+static gficf_ctx* g_ctx = NULL;
+
+static gficf_ctx* ctx_get(void) {
+  if (!g_ctx) {
+    int dev = 0;
+    const char* e = getenv("GFICF_HIP_DEVICE");
+    if (e) dev = atoi(e);
+    if (gficf_ctx_create(dev, NULL, &g_ctx) != GFICF_OK) Rf_error("gficf_hip: %s", gficf_last_error());
+  }
+  return g_ctx;
+}
+
+/* replaces src/RcppExports.cpp:61-70 + src/rcpp_parallel_jaccard_coeff.cpp:59-80 */
+SEXP _gficf_rcpp_parallel_jaccard_coef(SEXP matSEXP, SEXP printOutputSEXP) {
+  if (!Rf_isMatrix(matSEXP) || !(TYPEOF(matSEXP) == INTSXP || TYPEOF(matSEXP) == REALSXP))
+    Rf_error("mat must be an integer or numeric matrix");
+  SEXP dim = Rf_getAttrib(matSEXP, R_DimSymbol);
+  const int64_t N = INTEGER(dim)[0];
+  const int k = INTEGER(dim)[1];
+  const int is_f64 = TYPEOF(matSEXP) == REALSXP;          /* uwot returns INTSXP; no coercion copy needed */
+  const void* idx = is_f64 ? (const void*)REAL(matSEXP) : (const void*)INTEGER(matSEXP);
+  SEXP rmat = PROTECT(Rf_allocMatrix(REALSXP, (int)(N * k), 3));   /* reference :67 */
+  int rc = gficf_jaccard_host(ctx_get(), idx, is_f64, N, k, N, REAL(rmat), Rf_asLogical(printOutputSEXP));
+  if (rc != GFICF_OK) {
+    UNPROTECT(1);
+    Rf_error("gficf_hip: %s", gficf_last_error());         /* BEGIN_RCPP/END_RCPP equivalent */
+  }
+  UNPROTECT(1);
+  return rmat;
+}
+
+/* list(i, p, x, keep, nt, w) for gficf() / embedNewCells(); w = NULL -> compute ICF weights */
+SEXP _gficf_gficf_csc(SEXP iS, SEXP pS, SEXP xS, SEXP dimS, SEXP wS, SEXP minS, SEXP maxS) {
+  const int64_t G = INTEGER(dimS)[0], N = INTEGER(dimS)[1];
+  const double* w_in = Rf_isNull(wS) ? NULL : REAL(wS);
+  int64_t gk = 0, nk = 0;
+  if (gficf_normalize_csc_host_plan(ctx_get(), G, N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(minS),
+                                    Rf_asReal(maxS), w_in, &gk, &nk) != GFICF_OK)
+    Rf_error("gficf_hip: %s", gficf_last_error());
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 6));
+  SEXP oi = PROTECT(Rf_allocVector(INTSXP, nk)), op = PROTECT(Rf_allocVector(INTSXP, N + 1));
+  SEXP ox = PROTECT(Rf_allocVector(REALSXP, nk)), keep = PROTECT(Rf_allocVector(RAWSXP, G));
+  SEXP w = PROTECT(Rf_allocVector(REALSXP, G));
+  int64_t* nt = (int64_t*)R_alloc((size_t)G, sizeof(int64_t));
+  if (gficf_normalize_csc_host_finish(ctx_get(), RAW(keep), nt, REAL(w), INTEGER(op), INTEGER(oi), REAL(ox)) != GFICF_OK) {
+    UNPROTECT(6);
+    Rf_error("gficf_hip: %s", gficf_last_error());
+  }
+  SEXP ntS = PROTECT(Rf_allocVector(REALSXP, G));
+  for (int64_t g = 0; g < G; ++g) REAL(ntS)[g] = (double)nt[g];
+  SET_VECTOR_ELT(out, 0, oi); SET_VECTOR_ELT(out, 1, op); SET_VECTOR_ELT(out, 2, ox);
+  SET_VECTOR_ELT(out, 3, keep); SET_VECTOR_ELT(out, 4, ntS); SET_VECTOR_ELT(out, 5, w);
+  UNPROTECT(7);
+  return out;
+}
+
+static const R_CallMethodDef HipCallEntries[] = {
+    {"_gficf_rcpp_parallel_jaccard_coef", (DL_FUNC)&_gficf_rcpp_parallel_jaccard_coef, 2},
+    {"_gficf_gficf_csc", (DL_FUNC)&_gficf_gficf_csc, 7},
+    {NULL, NULL, 0}};
+
+/* Called from the package's R_init_gficf (reference src/RcppExports.cpp:94-97) next to the Rcpp entries:
+ *   R_registerRoutines(dll, NULL, HipCallEntries, NULL, NULL);                                     */
+void gficf_hip_register(DllInfo* dll) { R_registerRoutines(dll, NULL, HipCallEntries, NULL, NULL); }
+
+void R_unload_gficf(DllInfo* dll) {
+  (void)dll;
+  if (g_ctx) { gficf_ctx_destroy(g_ctx); g_ctx = NULL; }
+}

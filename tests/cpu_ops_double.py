@@ -1,0 +1,77 @@
+"""CPU test double for the stage-kernel object (`gficf_amd.api.HipOps`) — tests only.
+
+It lets the sharding / collective logic of gficf_amd.dist run on CPU tensors under the gloo
+backend.  Arithmetic comes from the oracle and numpy; nothing here is part of the product.
+"""
+import numpy as np
+import torch
+
+import oracle
+
+
+class CpuOpsDouble:
+    @staticmethod
+    def kpad(k):
+        return 16 if k <= 16 else 32 if k <= 32 else 64 if k <= 64 else 128 if k <= 128 else 256
+
+    def sync(self):
+        pass
+
+    # ---- Jaccard
+    def jaccard_ingest(self, idx_cm, n_rows, k, N_total, table_rows):
+        rows = idx_cm.numpy().reshape(k, -1)[:, :n_rows].T          # n_rows x k
+        assert rows.min() >= 1 and rows.max() <= N_total
+        table_rows[:n_rows, :k] = torch.from_numpy(np.ascontiguousarray(rows.astype(np.int32)))
+        table_rows[:n_rows, k:] = 0
+
+    def jaccard_edges(self, table, N, k, cell_begin, cell_end, out3, u=None):
+        mat = table.numpy()[:N, :k]
+        rm, uu = oracle.jaccard(np.ascontiguousarray(mat), nthreads=2)
+        sl = slice(cell_begin * k, cell_end * k)
+        out3.copy_(torch.from_numpy(np.ascontiguousarray(rm[sl].T)))
+        if u is not None:
+            u.copy_(torch.from_numpy(uu[sl]))
+
+    # ---- GF-ICF
+    def csc_count(self, G, n_cells, colptr, rowidx, x, nt):
+        ri, xv = rowidx.numpy(), x.numpy()
+        nt += torch.from_numpy(np.bincount(ri[xv != 0], minlength=G).astype(np.int64))
+
+    def csc_genes(self, G, N_total, nt, prop_min, prop_max, w_in, keep, genes, w, gkept):
+        c = nt.numpy().astype(np.float64)
+        kp = (c > N_total * prop_min) & (c <= N_total * prop_max)
+        wv = np.where(kp, np.log((N_total + 1.0) / (c + 1.0)) if w_in is None else w_in.numpy(), 0.0)
+        remap = np.where(kp, np.cumsum(kp) - 1, -1).astype(np.int32)
+        keep.copy_(torch.from_numpy(kp.astype(np.uint8)))
+        w.copy_(torch.from_numpy(wv))
+        g = genes.numpy()
+        g[:G, 0] = wv
+        g[:G, 1] = remap.astype(np.float64)      # the double only needs to round-trip inside this double
+        gkept[0] = int(kp.sum())
+
+    def csc_colptr(self, G, n_cells, colptr, rowidx, keep, gkept, out_colptr):
+        cp, ri, kp = colptr.numpy(), rowidx.numpy(), keep.numpy().astype(bool)
+        cnt = np.add.reduceat(kp[ri].astype(np.int64), cp[:-1]) if len(ri) else np.zeros(n_cells, np.int64)
+        cnt[np.diff(cp) == 0] = 0
+        out_colptr.copy_(torch.from_numpy(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)))
+
+    def csc_scale(self, G, n_cells, colptr, rowidx, x, genes, out_colptr, out_rowidx, out_x):
+        cp, ri, xv = colptr.numpy(), rowidx.numpy(), x.numpy()
+        g = genes.numpy()
+        wv, remap = g[:G, 0], g[:G, 1].astype(np.int64)
+        ocp = out_colptr.numpy()
+        ori, ox = out_rowidx.numpy(), out_x.numpy()
+        for c in range(n_cells):
+            sl = slice(cp[c], cp[c + 1])
+            kp = remap[ri[sl]] >= 0
+            xs, gs = xv[sl][kp], ri[sl][kp]
+            S = 0.0
+            for v in xs:
+                S += v
+            v = (xs / S) * wv[gs] if S != 0 else np.zeros_like(xs)
+            q = 0.0
+            for t in v:
+                q += t * t
+            nv = 1.0 / np.sqrt(q) if q > 0 else 0.0
+            ori[ocp[c]:ocp[c + 1]] = remap[gs]
+            ox[ocp[c]:ocp[c + 1]] = nv * v

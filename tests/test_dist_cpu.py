@@ -1,0 +1,109 @@
+"""CPU, world_size 2, gloo: the N > 1 path of gficf_amd.dist (cell-block sharding, the
+all-gather of kNN table rows, the all-reduce of per-gene counts, output placement) with a CPU
+test double standing in for the HIP stage kernels."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, k, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpu_ops_double import CpuOpsDouble
+        from gficf_amd import synth
+        from gficf_amd.dist import GficfShard, JaccardShard, shard_bounds
+
+        ops = CpuOpsDouble()
+        # ---- Jaccard: every rank holds only its block of the kNN matrix
+        mat = synth.knn_windowed(N, k, seed=3)
+        b, e = shard_bounds(N, world, rank)
+        idx_local = torch.from_numpy(np.ascontiguousarray(mat[b:e].T))
+        sh = JaccardShard(ops, N, k, with_u=True)
+        assert (sh.b, sh.e) == (b, e)
+        out = sh.step(idx_local)
+        out2 = sh.step(idx_local).clone()            # buffers are reused across steps
+        assert torch.equal(out, out2)
+        np.save(os.path.join(outdir, f"jac_{rank}.npy"), out.numpy())
+        np.save(os.path.join(outdir, f"u_{rank}.npy"), sh.u.numpy())
+        # the gathered table must be identical on all ranks
+        tabs = [torch.zeros_like(sh.table) for _ in range(world)]
+        dist.all_gather(tabs, sh.table)
+        assert all(torch.equal(tabs[0], t) for t in tabs)
+        # ---- GF-ICF: every rank holds a block of cells (columns)
+        G, Nc = 300, 101
+        cp, ri, x = synth.counts_csc(G, Nc, seed=5)
+        cb, ce = shard_bounds(Nc, world, rank)
+        lcp = torch.from_numpy((cp[cb:ce + 1] - cp[cb]).astype(np.int64))
+        lri = torch.from_numpy(ri[cp[cb]:cp[ce]].copy())
+        lx = torch.from_numpy(x[cp[cb]:cp[ce]].copy())
+        gs = GficfShard(ops, G, Nc, ce - cb, int(lri.numel()))
+        ws = gs.step(lcp, lri, lx, 0.05, 1.0)
+        n = int(ws["out_colptr"][ce - cb])
+        np.savez(os.path.join(outdir, f"gf_{rank}.npz"), colptr=ws["out_colptr"].numpy(), rowidx=ws["out_rowidx"][:n].numpy(),
+                 x=ws["out_x"][:n].numpy(), keep=ws["keep"].numpy(), nt=ws["nt"].numpy(), w=ws["w"].numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,k", [(1001, 15), (640, 30)])
+def test_sharded_path_world2_gloo(tmp_path, N, k):
+    import oracle
+    from gficf_amd import synth
+    from gficf_amd.dist import shard_bounds
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), N, k, str(tmp_path)), nprocs=world, join=True)
+    mat = synth.knn_windowed(N, k, seed=3)
+    want, wu = oracle.jaccard(mat, nthreads=2)
+    got = np.concatenate([np.load(tmp_path / f"jac_{r}.npy") for r in range(world)], axis=1).T
+    gu = np.concatenate([np.load(tmp_path / f"u_{r}.npy") for r in range(world)])
+    assert np.array_equal(gu, wu)
+    assert np.array_equal(got, want)
+    # GF-ICF: concatenated blocks == single-shot oracle
+    G, Nc = 300, 101
+    cp, ri, x = synth.counts_csc(G, Nc, seed=5)
+    ref = oracle.gficf_csc(G, Nc, cp, ri, x, 0.05, 1.0)
+    parts = [np.load(tmp_path / f"gf_{r}.npz") for r in range(world)]
+    assert all(np.array_equal(p["keep"].astype(bool), ref["keep"]) for p in parts)
+    assert all(np.array_equal(p["nt"][ref["keep"]], ref["nt"][ref["keep"]]) for p in parts)
+    assert np.array_equal(np.concatenate([p["rowidx"] for p in parts]), ref["rowidx"])
+    assert np.allclose(np.concatenate([p["x"] for p in parts]), ref["x"], rtol=1e-12, atol=1e-15)
+    offs = 0
+    for r, p in enumerate(parts):
+        cb, ce = shard_bounds(Nc, world, r)
+        assert np.array_equal(p["colptr"] + offs, ref["colptr"][cb:ce + 1])
+        offs += p["colptr"][-1]
+
+
+def test_shard_bounds_cover_and_are_equal_pitch():
+    from gficf_amd.dist import rows_per_rank, shard_bounds
+
+    for n in (0, 1, 7, 100, 1001, 100000):
+        for world in (1, 2, 3, 8):
+            rpr = rows_per_rank(n, world)
+            blocks = [shard_bounds(n, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            for r, (b, e) in enumerate(blocks):
+                assert b == min(n, r * rpr) and 0 <= e - b <= rpr
+                if r:
+                    assert b == blocks[r - 1][1]
