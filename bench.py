@@ -148,16 +148,16 @@ def main():
     t_edges_ms = time_kernel_ms(torch, lambda: ops.jaccard_edges(shard.table, N_total, k, b, e, shard.out, None), max(args.steps, 20))
     t_ingest_ms = time_kernel_ms(torch, lambda: ops.jaccard_ingest(idx_local, n_local, k, N_total, shard.table[rank * shard.rpr:(rank + 1) * shard.rpr]), max(args.steps, 20))
     achieved = JACCARD_BYTES_PER_EDGE * n_local * k / (t_edges_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch from the committed PMC passes (tools/pmc.sh + tools/make_traffic.py; FETCH_SIZE
+    # correction documented there); null when no pass was taken for this workload
+    pmc = {}
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(prof):
         try:
-            pj = json.load(open(prof))
-            ent = pj.get(f"jaccard_edges_N{N_total}_k{k}")
-            if ent:
-                traffic = ent["hbm_bytes_per_launch"]
+            pmc = json.load(open(prof))
         except Exception:
-            traffic = None
+            pmc = {}
+    traffic = pmc.get(f"jaccard_edges_N{N_total}_k{k}", {}).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "k_jaccard_edges", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel_ms": round(t_edges_ms, 5), "ingest_kernel_ms": round(t_ingest_ms, 5),
@@ -228,8 +228,25 @@ def main():
                   "nnz": nnz, "kept_nnz": int(ws["out_colptr"][Nc]), "kept_genes": int(ws["gkept"][0]), "dtype": "f64",
                   "roofline": {"bound": "hbm", "kernel": "whole pass (count + colptr + scale)",
                                "achieved": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                               "scale_kernel_ms": round(t_scale, 4), "count_kernel_ms": round(t_count, 4)}}
+                               "frac": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_PEAK_GBS, 4),
+                               "traffic": (sum(pmc[kk]["hbm_bytes_per_launch"] for kk in ("gene_count", "cell_kept_count", "scale_cells"))
+                                           if all(kk in pmc for kk in ("gene_count", "cell_kept_count", "scale_cells")) and nnz == 59809258 else None),
+                               "scale_kernel_ms": round(t_scale, 4), "count_kernel_ms": round(t_count, 4),
+                               "algorithmic_bytes_per_pass": GFICF_BYTES_PER_NNZ * nnz}}
+            if not args.no_cpu_baseline:
+                import oracle
+
+                hcp, hri, hx = colptr.cpu().numpy(), rowidx.cpu().numpy(), x.cpu().numpy()
+                t1 = time.perf_counter()
+                ref = oracle.gficf_csc(G, Nc, hcp, hri, hx, 0.05, 1.0)
+                tc = time.perf_counter() - t1
+                kn = int(ws["out_colptr"][Nc])
+                gf["cpu_baseline"] = {"value": Nc / tc, "unit": "cells/s", "cores": 1, "kind": "port",
+                                      "sample": "the full matrix, one pass of the oracle's single-threaded restatement of R/gficf.R "
+                                                "(the reference path is single-threaded R on the Matrix package and cannot run here)",
+                                      "gpu_over_cpu": (Nc / tg) / (Nc / tc)}
+                gf["checked_vs_oracle"] = bool(kn == len(ref["x"]) and np.array_equal(ws["out_rowidx"][:kn].cpu().numpy(), ref["rowidx"])
+                                               and np.allclose(ws["out_x"][:kn].cpu().numpy(), ref["x"], rtol=1e-6, atol=1e-6))
             out["gficf"] = gf
 
     if rank == 0:
