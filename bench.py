@@ -220,7 +220,7 @@ def main():
             torch.cuda.synchronize()
             tg = (time.perf_counter() - t1) / reps
             ops.sync()
-            t_scale = time_kernel_ms(torch, lambda: ops.csc_scale(G, Nc, colptr, rowidx, x, ws["genes"], ws["out_colptr"], ws["out_rowidx"], ws["out_x"]), 10)
+            t_scale = time_kernel_ms(torch, lambda: ops.csc_scale(G, Nc, colptr, rowidx, x, ws["genes"], ws["gkept"], ws["out_colptr"], ws["out_rowidx"], ws["out_x"]), 10)
             t_count = time_kernel_ms(torch, lambda: ops.csc_count(G, Nc, colptr, rowidx, x, ws["nt"]), 10)
             gf = {"metric": "gficf_cells_per_sec", "value": Nc / tg, "unit": "cells/s", "ms_per_pass": tg * 1e3,
                   "config": {"workload": f"BASELINE config 3 shape: {G} genes x {Nc} cells synthetic UMI CSC (nnz={nnz}), "

@@ -48,10 +48,11 @@ SIGNATURES = {
     "gficf_normalize_csc_host_plan": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _dbl, _dbl, _vp,
                                              ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "gficf_normalize_csc_host_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_csc_genes_bytes": (ctypes.c_size_t, [_i64]),
     "gficf_csc_count_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "gficf_csc_genes_device": (_int, [_vp, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp]),
     "gficf_csc_colptr_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "gficf_csc_scale_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "gficf_csc_scale_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_csc_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
 }

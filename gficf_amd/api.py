@@ -206,6 +206,11 @@ def gficf_with_weights(M, w, ctx: Context | None = None):
 
 
 # ----------------------------------------------------------- device-resident stage ops
+def genes_words(G: int) -> int:
+    """float64 elements of the opaque per-gene table buffer (gficf_csc_genes_bytes)."""
+    return int(_lib.load().gficf_csc_genes_bytes(int(G)) + 7) // 8
+
+
 def _tptr(t):
     if t is None:
         return None
@@ -281,7 +286,7 @@ class HipOps:
                                             int(rowidx.numel()), _tptr(nt)))
 
     def csc_genes(self, G, N_total, nt, prop_min, prop_max, w_in, keep, genes, w, gkept):
-        """genes: (G, 2) float64 tensor used as raw storage for the 16-byte gficf_gene_entry records."""
+        """genes: float64 tensor of genes_words(G) elements, raw storage for the per-gene tables."""
         check(self.L.gficf_csc_genes_device(self._bind(), G, N_total, _tptr(nt), float(prop_min), float(prop_max),
                                             _tptr(w_in), _tptr(keep), _tptr(genes), _tptr(w), _tptr(gkept)))
 
@@ -289,9 +294,9 @@ class HipOps:
         check(self.L.gficf_csc_colptr_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(keep),
                                              _tptr(gkept), _tptr(out_colptr)))
 
-    def csc_scale(self, G, n_cells, colptr, rowidx, x, genes, out_colptr, out_rowidx, out_x):
+    def csc_scale(self, G, n_cells, colptr, rowidx, x, genes, gkept, out_colptr, out_rowidx, out_x):
         check(self.L.gficf_csc_scale_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),
-                                            int(rowidx.numel()), _tptr(genes), _tptr(out_colptr),
+                                            int(rowidx.numel()), _tptr(genes), _tptr(gkept), _tptr(out_colptr),
                                             _tptr(out_rowidx), _tptr(out_x)))
 
     def csc_workspace(self, G: int, n_cells: int, nnz: int) -> dict:
@@ -300,7 +305,7 @@ class HipOps:
         return dict(
             nt=tc.zeros(max(G, 1), dtype=tc.int64, device=dev),
             keep=tc.zeros(max(G, 1), dtype=tc.uint8, device=dev),
-            genes=tc.zeros((max(G, 1), 2), dtype=tc.float64, device=dev),   # gficf_gene_entry[G]
+            genes=tc.zeros(genes_words(G), dtype=tc.float64, device=dev),   # opaque per-gene tables
             w=tc.zeros(max(G, 1), dtype=tc.float64, device=dev),
             gkept=tc.zeros(1, dtype=tc.int64, device=dev),
             out_colptr=tc.zeros(n_cells + 1, dtype=tc.int64, device=dev),

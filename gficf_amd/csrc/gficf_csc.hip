@@ -11,6 +11,7 @@
 // (pass B); the row subset of R/gficf.R:41 is a stream compaction fused into pass B whose
 // output offsets come from a per-cell kept-count pass + scan.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -80,6 +81,13 @@ __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __res
   }
 }
 
+// Layout of the opaque per-gene buffer: G records {w, remap} | G doubles (weights of kept genes,
+// indexed by new row id) | G uint16 (new row id, 0xFFFF = dropped).
+__host__ __device__ inline double* genes_wkept(gficf_gene_entry* genes, int64_t G) { return reinterpret_cast<double*>(genes + G); }
+__host__ __device__ inline const double* genes_wkept(const gficf_gene_entry* genes, int64_t G) { return reinterpret_cast<const double*>(genes + G); }
+__host__ __device__ inline uint16_t* genes_remap16(gficf_gene_entry* genes, int64_t G) { return reinterpret_cast<uint16_t*>(genes_wkept(genes, G) + G); }
+__host__ __device__ inline const uint16_t* genes_remap16(const gficf_gene_entry* genes, int64_t G) { return reinterpret_cast<const uint16_t*>(genes_wkept(genes, G) + G); }
+
 // --------------------------------------------------- gene table: keep / remap / weights
 // keep_g = nt_g > N*min && nt_g <= N*max (double compare, R/gficf.R:41); remap = exclusive
 // scan of keep (new row id of a kept gene); w_g = log((N+1)/(nt_g+1)) (R/gficf.R:89) or the
@@ -145,6 +153,9 @@ __global__ __launch_bounds__(GT_THREADS) void k_gene_table(int64_t G, int64_t N_
     e.remap = kp ? r : -1;
     e.reserved = 0;
     genes[g] = e;
+    // compact tables for the LDS-resident scaling variant
+    if (kp) genes_wkept(genes, G)[r] = wv;
+    genes_remap16(genes, G)[g] = (kp && r < 0xFFFF) ? (uint16_t)r : (uint16_t)0xFFFF;
   }
 }
 
@@ -217,6 +228,15 @@ __global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64
   }
 }
 
+constexpr size_t SL_LDS_BYTES = 156 * 1024;
+
+__host__ __device__ inline size_t sl_lds_need(int64_t G, int64_t gkept) {
+  return (((size_t)G * 2 + 15) & ~(size_t)15) + (size_t)gkept * 8;
+}
+__host__ __device__ inline bool sl_fits(int64_t G, int64_t gkept) {
+  return gkept < 0xFFFF && sl_lds_need(G, gkept) <= SL_LDS_BYTES;
+}
+
 // ---------------------------------------------------------------- pass B: scale a cell
 // One workgroup of SC_WAVES waves per cell.  Wave w owns a contiguous run of the cell's
 // entries, so kept entries keep their order and every wave's output run is contiguous.
@@ -241,10 +261,12 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
                                                             const int32_t* __restrict__ rowidx,
                                                             const double* __restrict__ x,
                                                             const gficf_gene_entry* __restrict__ genes,
+                                                            const int64_t* __restrict__ gkept_p,
                                                             const int64_t* __restrict__ out_colptr,
                                                             int32_t* __restrict__ out_rowidx,
                                                             double* __restrict__ out_x) {
   __shared__ double s_sum[SC_WAVES];
+  if (gkept_p && sl_fits(G, *gkept_p)) return;    // the LDS-resident variant handles this input
   __shared__ int32_t s_cnt[SC_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -369,6 +391,169 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
   }
 }
 
+// ------------------------------------------------ pass B, LDS-resident gene tables
+// When the 16-bit row ids of all genes (2 G bytes) and the weights of the kept genes (8 G_kept
+// bytes) fit the CU's LDS, one persistent workgroup per CU stages both once and then every wave
+// scales whole cells on its own: no barriers after the staging, and the per-entry lookups are LDS
+// reads instead of L2 requests (the global-gather variant above issues one L2 request per
+// entry).  A lane keeps x and the new row id of its entries in registers (3 VGPRs per entry), the
+// weight is read from LDS when it is needed.  Same arithmetic and order of operations.
+constexpr int SL_THREADS = 1024;
+constexpr int SL_CH = 24;                         // chunks of 64 entries a wave keeps in registers
+constexpr int SL_LB = 8;                          // chunks per batch on the long-cell path
+__global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64_t n_cells,
+                                                                const int64_t* __restrict__ colptr,
+                                                                const int32_t* __restrict__ rowidx,
+                                                                const double* __restrict__ x,
+                                                                const gficf_gene_entry* __restrict__ genes,
+                                                                const int64_t* __restrict__ gkept_p,
+                                                                const int64_t* __restrict__ out_colptr,
+                                                                int32_t* __restrict__ out_rowidx,
+                                                                double* __restrict__ out_x) {
+  extern __shared__ unsigned char s_raw[];
+  const int64_t gkept = *gkept_p;
+  if (!sl_fits(G, gkept)) return;                 // the global-gather variant handles this input
+  uint16_t* const s_remap = reinterpret_cast<uint16_t*>(s_raw);
+  double* const s_w = reinterpret_cast<double*>(s_raw + (((size_t)G * 2 + 15) & ~(size_t)15));
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(genes_remap16(genes, G));
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_remap);
+    for (int64_t t = threadIdx.x; t < (G + 1) / 2; t += SL_THREADS) dst[t] = src[t];
+    const double* wk = genes_wkept(genes, G);
+    for (int64_t t = threadIdx.x; t < gkept; t += SL_THREADS) s_w[t] = wk[t];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int64_t wave0 = ((int64_t)blockIdx.x * SL_THREADS + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * SL_THREADS) >> 6;
+  for (int64_t c = wave0; c < n_cells; c += nwaves) {
+    const int64_t p0 = colptr[c], p1 = colptr[c + 1];
+    const int64_t len = p1 - p0;
+    if (len <= 0) continue;                       // uniform over the wave
+    int64_t opos = out_colptr[c];
+    if (len <= 64 * SL_CH) {
+      const int n_it = (int)((len + 63) >> 6);
+      double xv[SL_CH];
+      int32_t rv[SL_CH];
+      // entries: all loads of the cell are issued before any is consumed
+#pragma unroll
+      for (int m = 0; m < SL_CH; ++m) {
+        rv[m] = -1;
+        xv[m] = 0.0;
+        if (m < n_it) {
+          const int64_t p = p0 + m * 64 + lane;
+          if (p < p1) { rv[m] = __builtin_nontemporal_load(rowidx + p); xv[m] = __builtin_nontemporal_load(x + p); }
+        }
+      }
+      double S = 0.0;
+#pragma unroll
+      for (int m = 0; m < SL_CH; ++m) {
+        if (m < n_it) {
+          const uint32_t g = (uint32_t)rv[m];
+          const uint32_t r = g < (uint32_t)G ? (uint32_t)s_remap[g] : 0xFFFFu;
+          rv[m] = r == 0xFFFFu ? -1 : (int32_t)r;
+          if (rv[m] >= 0) S += xv[m];
+        }
+      }
+      const double Sc = wave_sum(S);
+      double q = 0.0;
+#pragma unroll
+      for (int m = 0; m < SL_CH; ++m) {
+        if (m < n_it) {
+          double v = 0.0;
+          if (rv[m] >= 0 && Sc != 0.0) v = (xv[m] / Sc) * s_w[rv[m]];
+          xv[m] = v;
+          q += v * v;
+        }
+      }
+      const double qc = wave_sum(q);
+      double nv = 1.0 / sqrt(qc);
+      if (isinf(nv)) nv = 0.0;                    // R/gficf.R:101
+#pragma unroll
+      for (int m = 0; m < SL_CH; ++m) {
+        if (m < n_it) {
+          const bool kp = rv[m] >= 0;
+          const unsigned long long mk = __ballot(kp);
+          if (kp) {
+            const int64_t dst = opos + __popcll(mk & lt_mask);
+            __builtin_nontemporal_store(rv[m], out_rowidx + dst);
+            __builtin_nontemporal_store(nv * xv[m], out_x + dst);
+          }
+          opos += __popcll(mk);
+        }
+      }
+    } else {
+      // long cell: three sweeps in batches of SL_LB chunks; the 2nd and 3rd sweep re-read it from L2
+      double S = 0.0;
+      for (int64_t base = p0; base < p1; base += 64 * SL_LB) {
+        int32_t gz[SL_LB];
+        double xb[SL_LB];
+#pragma unroll
+        for (int m = 0; m < SL_LB; ++m) {
+          const int64_t p = base + m * 64 + lane;
+          gz[m] = -1; xb[m] = 0.0;
+          if (p < p1) { gz[m] = rowidx[p]; xb[m] = x[p]; }
+        }
+#pragma unroll
+        for (int m = 0; m < SL_LB; ++m) {
+          const uint32_t g = (uint32_t)gz[m];
+          if (g < (uint32_t)G && s_remap[g] != 0xFFFFu) S += xb[m];
+        }
+      }
+      const double Sc = wave_sum(S);
+      double q = 0.0;
+      if (Sc != 0.0) {
+        for (int64_t base = p0; base < p1; base += 64 * SL_LB) {
+          int32_t gz[SL_LB];
+          double xb[SL_LB];
+#pragma unroll
+          for (int m = 0; m < SL_LB; ++m) {
+            const int64_t p = base + m * 64 + lane;
+            gz[m] = -1; xb[m] = 0.0;
+            if (p < p1) { gz[m] = rowidx[p]; xb[m] = x[p]; }
+          }
+#pragma unroll
+          for (int m = 0; m < SL_LB; ++m) {
+            const uint32_t g = (uint32_t)gz[m];
+            const uint32_t r = g < (uint32_t)G ? (uint32_t)s_remap[g] : 0xFFFFu;
+            if (r != 0xFFFFu) { const double v = (xb[m] / Sc) * s_w[r]; q += v * v; }
+          }
+        }
+      }
+      const double qc = wave_sum(q);
+      double nv = 1.0 / sqrt(qc);
+      if (isinf(nv)) nv = 0.0;                    // R/gficf.R:101
+      for (int64_t base = p0; base < p1; base += 64 * SL_LB) {
+        int32_t gz[SL_LB];
+        double xb[SL_LB];
+#pragma unroll
+        for (int m = 0; m < SL_LB; ++m) {
+          const int64_t p = base + m * 64 + lane;
+          gz[m] = -1; xb[m] = 0.0;
+          if (p < p1) { gz[m] = rowidx[p]; xb[m] = x[p]; }
+        }
+#pragma unroll
+        for (int m = 0; m < SL_LB; ++m) {
+          if (base + m * 64 < p1) {               // uniform over the wave
+            const uint32_t g = (uint32_t)gz[m];
+            const uint32_t r = g < (uint32_t)G ? (uint32_t)s_remap[g] : 0xFFFFu;
+            const bool kp = r != 0xFFFFu;
+            const unsigned long long mk = __ballot(kp);
+            if (kp) {
+              const int64_t dst = opos + __popcll(mk & lt_mask);
+              const double v = Sc != 0.0 ? nv * ((xb[m] / Sc) * s_w[r]) : 0.0;
+              __builtin_nontemporal_store((int32_t)r, out_rowidx + dst);
+              __builtin_nontemporal_store(v, out_x + dst);
+            }
+            opos += __popcll(mk);
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ----------------------------------------------------------------------------- C ABI
@@ -440,18 +625,38 @@ int gficf_csc_colptr_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const in
 
 int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
                            const int32_t* d_rowidx, const double* d_x, int64_t nnz, const gficf_gene_entry* d_genes,
-                           const int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
+                           const int64_t* d_gkept, const int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
   GFICF_CTX_ENTER(ctx);
   if (G < 0 || n_cells < 0 || nnz < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (n_cells == 0 || nnz == 0) return GFICF_OK;
-  if (!d_colptr || !d_rowidx || !d_x || !d_genes || !d_out_colptr || !d_out_rowidx || !d_out_x)
+  if (!d_colptr || !d_rowidx || !d_x || !d_genes || !d_gkept || !d_out_colptr || !d_out_rowidx || !d_out_x)
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  // Two variants, selected on the device by the number of kept genes (unknown to the host without a
+  // sync): each kernel returns at once when the input is the other one's.
+  static const bool force_global = getenv("GFICF_SCALE_FORCE_GLOBAL") != nullptr;   // test hook
+  const bool try_lds = sl_fits(G, 0) && !force_global;     // else not even the row ids fit LDS
+  if (try_lds) {
+    static bool attr_set[64] = {};
+    if (!attr_set[ctx->device & 63]) {
+      GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_scale_cells_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SL_LDS_BYTES));
+      attr_set[ctx->device & 63] = true;
+    }
+    int64_t blocks = gficf_ceil_div(n_cells, SL_THREADS / 64);
+    if (blocks > ctx->num_cus) blocks = ctx->num_cus;
+    hipLaunchKernelGGL(k_scale_cells_lds, dim3((unsigned)blocks), dim3(SL_THREADS), SL_LDS_BYTES, ctx->stream, G, n_cells,
+                       d_colptr, d_rowidx, d_x, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x);
+  }
   int64_t blocks = n_cells;
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
   hipLaunchKernelGGL(k_scale_cells, dim3((unsigned)blocks), dim3(SC_THREADS), 0, ctx->stream, G, n_cells, d_colptr,
-                     d_rowidx, d_x, d_genes, d_out_colptr, d_out_rowidx, d_out_x);
+                     d_rowidx, d_x, d_genes, try_lds ? d_gkept : (const int64_t*)nullptr, d_out_colptr, d_out_rowidx, d_out_x);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
+}
+
+size_t gficf_csc_genes_bytes(int64_t G) {
+  const size_t g = (size_t)(G > 0 ? G : 1);
+  return g * sizeof(gficf_gene_entry) + g * sizeof(double) + ((g * sizeof(uint16_t) + 63) & ~(size_t)63) + 64;
 }
 
 int gficf_csc_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colptr, const int32_t* d_rowidx,
@@ -470,7 +675,7 @@ int gficf_csc_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colp
   if (rc) return rc;
   rc = gficf_csc_colptr_device(ctx, G, N, d_colptr, d_rowidx, d_keep, d_gkept, d_out_colptr);
   if (rc) return rc;
-  return gficf_csc_scale_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_genes, d_out_colptr, d_out_rowidx, d_out_x);
+  return gficf_csc_scale_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x);
 }
 
 }  // extern "C"
@@ -538,7 +743,7 @@ int gficf_normalize_csc_host_plan(gficf_ctx* ctx, int64_t G, int64_t N, const vo
   PLAN_HIP(hipMalloc((void**)&p->d_x, sizeof(double) * nsz));
   PLAN_HIP(hipMalloc((void**)&p->d_nt, sizeof(int64_t) * gsz));
   PLAN_HIP(hipMalloc((void**)&p->d_keep, gsz));
-  PLAN_HIP(hipMalloc((void**)&p->d_genes, sizeof(gficf_gene_entry) * gsz));
+  PLAN_HIP(hipMalloc((void**)&p->d_genes, gficf_csc_genes_bytes(G)));
   PLAN_HIP(hipMalloc((void**)&p->d_w, sizeof(double) * gsz));
   PLAN_HIP(hipMalloc((void**)&p->d_gkept, sizeof(int64_t)));
   PLAN_HIP(hipMalloc((void**)&p->d_out_colptr, sizeof(int64_t) * ((size_t)N + 1)));
@@ -583,7 +788,7 @@ int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, 
   PLAN_HIP(hipMalloc((void**)&d_ori, sizeof(int32_t) * ksz));
   hipError_t e2 = hipMalloc((void**)&d_ox, sizeof(double) * ksz);
   if (e2 != hipSuccess) { (void)hipFree(d_ori); PLAN_HIP(e2); }
-  int rc = gficf_csc_scale_device(ctx, p->G, p->N, p->d_colptr, p->d_rowidx, p->d_x, p->nnz, p->d_genes,
+  int rc = gficf_csc_scale_device(ctx, p->G, p->N, p->d_colptr, p->d_rowidx, p->d_x, p->nnz, p->d_genes, p->d_gkept,
                                   p->d_out_colptr, d_ori, d_ox);
   std::vector<int64_t> cp((size_t)p->N + 1);
   hipError_t e = hipSuccess;

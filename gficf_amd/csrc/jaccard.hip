@@ -508,7 +508,8 @@ int launch_edges_t(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
 template <int KPAD>
 int launch_edges(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
   // 32-bit byte offsets and the 24-bit hash multiply need table < 4 GiB and ids < 2^24
-  const bool big = N >= (1ll << 24) || N * (int64_t)KPAD * 4 >= (1ll << 32);
+  static const bool force_big = getenv("GFICF_JACCARD_FORCE_BIG") != nullptr;   // test hook for the 64-bit variant
+  const bool big = force_big || N >= (1ll << 24) || N * (int64_t)KPAD * 4 >= (1ll << 32);
   return big ? launch_edges_t<KPAD, true>(ctx, table, N, k, cb, ce, o)
              : launch_edges_t<KPAD, false>(ctx, table, N, k, cb, ce, o);
 }

@@ -22,6 +22,12 @@ import torch
 import torch.distributed as dist
 
 
+def genes_words(G: int) -> int:
+    from .api import genes_words as _gw
+
+    return _gw(G)
+
+
 def rows_per_rank(n: int, world: int) -> int:
     return (n + world - 1) // world
 
@@ -83,7 +89,7 @@ class GficfShard:
         self.ws = dict(
             nt=torch.zeros(max(G, 1), dtype=torch.int64, device=dev),
             keep=torch.zeros(max(G, 1), dtype=torch.uint8, device=dev),
-            genes=torch.zeros((max(G, 1), 2), dtype=torch.float64, device=dev),   # gficf_gene_entry[G]
+            genes=torch.zeros(genes_words(G), dtype=torch.float64, device=dev),   # opaque per-gene tables
             w=torch.zeros(max(G, 1), dtype=torch.float64, device=dev),
             gkept=torch.zeros(1, dtype=torch.int64, device=dev),
             out_colptr=torch.zeros(n_local + 1, dtype=torch.int64, device=dev),
@@ -100,6 +106,6 @@ class GficfShard:
             dist.all_reduce(ws["nt"], op=dist.ReduceOp.SUM, group=self.group)
         ops.csc_genes(self.G, self.N, ws["nt"], prop_min, prop_max, w_in, ws["keep"], ws["genes"], ws["w"], ws["gkept"])
         ops.csc_colptr(self.G, self.n_local, colptr, rowidx, ws["keep"], ws["gkept"], ws["out_colptr"])
-        ops.csc_scale(self.G, self.n_local, colptr, rowidx, x, ws["genes"], ws["out_colptr"], ws["out_rowidx"],
-                      ws["out_x"])
+        ops.csc_scale(self.G, self.n_local, colptr, rowidx, x, ws["genes"], ws["gkept"], ws["out_colptr"],
+                      ws["out_rowidx"], ws["out_x"])
         return ws

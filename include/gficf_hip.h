@@ -146,8 +146,8 @@ int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, 
  * where a multi-GPU caller needs the seam (cells sharded by column block):
  *   1. count   : d_nt[g] += #{local cells with non-zero entry of gene g}   (d_nt zeroed by caller)
  *   2. (multi-GPU only) caller all-reduces d_nt (sum) over ranks
- *   3. genes   : d_nt, N_total -> d_keep[G] (uint8), d_w[G], d_genes[G] (the per-gene record the
- *                scaling pass gathers: weight + new row id, 16 B), d_gkept[1] (int64)
+ *   3. genes   : d_nt, N_total -> d_keep[G] (uint8), d_w[G], d_genes (the per-gene tables the
+ *                scaling pass looks up: gficf_csc_genes_bytes(G) bytes, opaque), d_gkept[1] (int64)
  *   4. colptr  : per-cell kept counts + exclusive scan -> d_out_colptr[n_cells+1] (int64)
  *   5. scale   : writes d_out_rowidx / d_out_x (capacity >= kept nnz; nnz always suffices)
  */
@@ -156,6 +156,11 @@ typedef struct gficf_gene_entry {
   int32_t remap;    /* row id among the kept genes, or -1 when dropped */
   int32_t reserved;
 } gficf_gene_entry;
+
+/* Size in bytes of the d_genes buffer for G genes: G 16-byte records {w, remap}, followed by the
+ * compact tables the LDS-resident variant of the scaling pass stages (weights of the kept genes,
+ * 16-bit new row ids). */
+size_t gficf_csc_genes_bytes(int64_t G);
 
 int gficf_csc_count_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
                            const int32_t* d_rowidx, const double* d_x, int64_t nnz,
@@ -168,8 +173,8 @@ int gficf_csc_colptr_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const in
                             const int64_t* d_gkept, int64_t* d_out_colptr);
 int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
                            const int32_t* d_rowidx, const double* d_x, int64_t nnz,
-                           const gficf_gene_entry* d_genes, const int64_t* d_out_colptr,
-                           int32_t* d_out_rowidx, double* d_out_x);
+                           const gficf_gene_entry* d_genes, const int64_t* d_gkept,
+                           const int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x);
 
 /* Single-GPU convenience: steps 1,3,4,5 back to back on the context's stream.  Output
  * buffers need capacity nnz (upper bound); *d_out_colptr[n_cells] holds the kept nnz. */

@@ -44,9 +44,9 @@ class CpuOpsDouble:
         remap = np.where(kp, np.cumsum(kp) - 1, -1).astype(np.int32)
         keep.copy_(torch.from_numpy(kp.astype(np.uint8)))
         w.copy_(torch.from_numpy(wv))
-        g = genes.numpy()
-        g[:G, 0] = wv
-        g[:G, 1] = remap.astype(np.float64)      # the double only needs to round-trip inside this double
+        g = genes.numpy()[:2 * G].reshape(G, 2)
+        g[:, 0] = wv
+        g[:, 1] = remap.astype(np.float64)      # the double only needs to round-trip inside this double
         gkept[0] = int(kp.sum())
 
     def csc_colptr(self, G, n_cells, colptr, rowidx, keep, gkept, out_colptr):
@@ -55,10 +55,10 @@ class CpuOpsDouble:
         cnt[np.diff(cp) == 0] = 0
         out_colptr.copy_(torch.from_numpy(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)))
 
-    def csc_scale(self, G, n_cells, colptr, rowidx, x, genes, out_colptr, out_rowidx, out_x):
+    def csc_scale(self, G, n_cells, colptr, rowidx, x, genes, gkept, out_colptr, out_rowidx, out_x):
         cp, ri, xv = colptr.numpy(), rowidx.numpy(), x.numpy()
-        g = genes.numpy()
-        wv, remap = g[:G, 0], g[:G, 1].astype(np.int64)
+        g = genes.numpy()[:2 * G].reshape(G, 2)
+        wv, remap = g[:, 0], g[:, 1].astype(np.int64)
         ocp = out_colptr.numpy()
         ori, ox = out_rowidx.numpy(), out_x.numpy()
         for c in range(n_cells):

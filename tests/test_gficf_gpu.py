@@ -162,7 +162,7 @@ def test_device_pipeline_and_cell_block_seam():
         w2 = ops.csc_workspace(G, n, int(lri.numel()))
         ops.csc_genes(G, N, nt, 0.05, 1.0, None, w2["keep"], w2["genes"], w2["w"], w2["gkept"])
         ops.csc_colptr(G, n, lcp, lri, w2["keep"], w2["gkept"], w2["out_colptr"])
-        ops.csc_scale(G, n, lcp, lri, lx, w2["genes"], w2["out_colptr"], w2["out_rowidx"], w2["out_x"])
+        ops.csc_scale(G, n, lcp, lri, lx, w2["genes"], w2["gkept"], w2["out_colptr"], w2["out_rowidx"], w2["out_x"])
         ops.sync()
         m = int(w2["out_colptr"][n])
         xs.append(w2["out_x"][:m].cpu().numpy())
@@ -188,5 +188,36 @@ def test_full_size_properties_config2():
     M2.data = M2.data * np.repeat(1.0 + (np.arange(N) % 7), np.diff(M2.indptr))
     g2 = gficf_amd.gficf(M2, normalize=False, verbose=False)["gficf"]
     assert np.allclose(g2.data, g.data, rtol=1e-12, atol=1e-15) and np.array_equal(g2.indices, g.indices)
+    ref = oracle.gficf_csc(G, N, cp, ri, x, 0.05, 1.0)
+    check_against_oracle(res, ref, N)
+
+
+def test_global_gather_variant_matches():
+    """The scaling pass has two variants (gene tables staged in LDS when they fit, per-entry L2
+    gathers otherwise).  Force the second through its test hook in a fresh process."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, scipy.sparse as sp, gficf_amd, oracle\n"
+        "from gficf_amd import synth\n"
+        "for G, N, mn in ((5000, 3000, 0.05), (20000, 1500, 0.0), (800, 600, 0.1)):\n"
+        "    cp, ri, x = synth.counts_csc(G, N, seed=G)\n"
+        "    res = gficf_amd.gficf(sp.csc_matrix((x, ri, cp), shape=(G, N)), 1, mn, normalize=False, verbose=False)\n"
+        "    ref = oracle.gficf_csc(G, N, cp, ri, x, mn, 1.0)\n"
+        "    assert np.array_equal(res['gficf'].indices, ref['rowidx']) and np.array_equal(res['gficf'].indptr, ref['colptr'])\n"
+        "    assert np.allclose(res['gficf'].data, ref['x'], rtol=1e-6, atol=1e-6) and np.abs(res['gficf'].data - ref['x']).max() < 1e-12\n"
+        "print('ok')\n")
+    env = dict(os.environ, GFICF_SCALE_FORCE_GLOBAL="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_long_cells_take_the_batched_path():
+    # dense-ish matrix: cells with > 1536 entries exercise the three-sweep path of both variants
+    G, N = 6000, 300
+    cp, ri, x = synth.counts_csc(G, N, median_frac=0.5, sigma=0.3, seed=23)
+    assert np.diff(cp).max() > 1600
+    res = gficf_amd.gficf(sp.csc_matrix((x, ri, cp), shape=(G, N)), 1, 0.05, normalize=False, verbose=False)
     ref = oracle.gficf_csc(G, N, cp, ri, x, 0.05, 1.0)
     check_against_oracle(res, ref, N)

@@ -242,3 +242,21 @@ def test_full_size_properties_1M_cells(ops):
     nb = mat[rows.reshape(-1) - 1].reshape(len(sample), k, k)
     cnt = (rows[:, None, :, None] == nb[:, :, None, :]).sum(axis=(2, 3)).astype(np.int32)
     assert np.array_equal(cnt.reshape(-1), u.reshape(N, k)[sample].reshape(-1))
+
+
+def test_wide_offset_variant_matches(tmp_path):
+    """The 64-bit-offset / 32-bit-hash kernel variant (used for N >= 2^24 or tables >= 4 GiB), forced
+    through its test hook in a fresh process, gives the same bits."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, gficf_amd, oracle\n"
+        "from gficf_amd import synth\n"
+        "for N, k in ((5000, 30), (3000, 50), (2000, 15), (700, 100)):\n"
+        "    mat = synth.knn_windowed(N, k, W=max(100, k), seed=N)\n"
+        "    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(mat, False), oracle.jaccard(mat, nthreads=4)[0])\n"
+        "print('ok')\n")
+    env = dict(os.environ, GFICF_JACCARD_FORCE_BIG="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
