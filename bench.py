@@ -204,6 +204,28 @@ def main():
                                              "faithful restatement of the RcppParallel worker (g++ -O2, dynamic chunks over std::thread)",
                                    "nt2_value": edges_per_step / t_nt2, "nt2_note": "clustcells() default nt = 2 (reference R/clustCells.R:46)",
                                    "gpu_over_cpu": value / cpu_v}
+        # end-to-end through the host C ABI (what the R glue calls): H2D + ingest + edges + D2H of the
+        # 24 B/edge reference matrix, device buffers allocated per call.  PCIe-inclusive: reported, never `value`.
+        try:
+            import ctypes
+
+            from gficf_amd import _lib
+
+            L = _lib.load()
+            hm = np.asfortranarray(mat)
+            hr = np.empty((3, edges_per_step), dtype=np.float64)
+            hctx = gficf_amd.default_context(local_rank)
+            call = lambda: L.gficf_jaccard_host(hctx.handle, hm.ctypes.data_as(ctypes.c_void_p), 0, N_total, k, N_total,
+                                                hr.ctypes.data_as(ctypes.c_void_p), 0)
+            call()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                rc = call()
+            th = (time.perf_counter() - t1) / 3
+            out["host_abi"] = {"edges_per_sec": edges_per_step / th, "ms_per_call": th * 1e3, "rc": rc,
+                               "note": "gficf_jaccard_host: pageable host buffers, hipMalloc/hipFree per call, PCIe both ways"}
+        except Exception as ex:  # pragma: no cover
+            out["host_abi"] = {"error": str(ex)}
         if not args.no_gficf:
             G, Nc = GFICF_G, GFICF_N
             colptr, rowidx, x = synth_counts_device(torch, G, Nc)

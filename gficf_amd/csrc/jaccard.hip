@@ -185,10 +185,11 @@ __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint
   if (u != 12345) return;
 #endif
   const bool pos = u > 0;
-  o.src[r] = pos ? (double)(uint32_t)(cell + 1) : 0.0;   // reference :49 (cell + 1 <= 2^31)
-  o.dst[r] = pos ? (double)dst : 0.0;          // reference :50
-  o.w[r] = pos ? lut[u] : 0.0;                 // reference :51
-  if (o.u) o.u[r] = u;
+  // written once, never re-read by this kernel: non-temporal, so the table rows keep the L2
+  __builtin_nontemporal_store(pos ? (double)(uint32_t)(cell + 1) : 0.0, o.src + r);   // reference :49 (cell + 1 <= 2^31)
+  __builtin_nontemporal_store(pos ? (double)dst : 0.0, o.dst + r);                    // reference :50
+  __builtin_nontemporal_store(pos ? lut[u] : 0.0, o.w + r);                           // reference :51
+  if (o.u) __builtin_nontemporal_store(u, o.u + r);
 }
 
 // Exact multiset path for one cell whose own row or one of whose neighbour rows holds

@@ -221,3 +221,10 @@ def test_long_cells_take_the_batched_path():
     res = gficf_amd.gficf(sp.csc_matrix((x, ri, cp), shape=(G, N)), 1, 0.05, normalize=False, verbose=False)
     ref = oracle.gficf_csc(G, N, cp, ri, x, 0.05, 1.0)
     check_against_oracle(res, ref, N)
+
+
+def test_degenerate_shapes():
+    r = gficf_amd.gficf(sp.csc_matrix((0, 3)), normalize=False, verbose=False)
+    assert r["gficf"].shape == (0, 3) and r["w"].size == 0
+    r = gficf_amd.gficf(sp.csc_matrix((5, 0)), normalize=False, verbose=False)
+    assert r["gficf"].shape == (0, 0) and r["gficf"].nnz == 0
