@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gficf", action="store_true")
-    ap.add_argument("--check", action="store_true", help="verify one step against the oracle (rank 0, N=1)")
+    ap.add_argument("--no-pipeline", action="store_true", help="ingest/all-gather on the same stream as the edge kernel")
     return ap.parse_args()
 
 
@@ -116,7 +116,7 @@ def main():
     mat = synth.knn_windowed(N_total, k)                       # N_total x k, 1-based ids (same on every rank)
     b, e = shard_bounds(N_total, world, rank)
     idx_local = torch.from_numpy(np.ascontiguousarray(mat[b:e].T)).to(dev)   # (k, n_local) == column-major block
-    shard = JaccardShard(ops, N_total, k, device=dev, with_u=False)
+    shard = JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=not args.no_pipeline)
 
     def step():
         shard.step(idx_local)
@@ -135,7 +135,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    ops.sync()                                                  # surfaces deferred validation errors
+    shard.sync()                                                # surfaces deferred validation errors
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -168,14 +168,16 @@ def main():
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32 ids -> f64 edge rows", "data": "synthetic",
         "config": {"workload": f"north-star point: {args.cells_per_gpu} cells x k={k} per GPU, windowed kNN (W=100) with permuted ids; "
-                               f"N_total={N_total}; step = ingest + {'RCCL all-gather + ' if world > 1 else ''}edge kernel, device-resident",
+                               f"N_total={N_total}; step = ingest + {'RCCL all-gather + ' if world > 1 else ''}edge kernel, device-resident"
+                               + ("" if args.no_pipeline else "; steps software-pipelined over two tables (ingest"
+                                  + ("/all-gather" if world > 1 else "") + " of step s+1 on a second stream under the edge kernel of step s)"),
                    "cells_total": N_total, "k": k, "edges_per_step": edges_per_step,
                    "partition": f"cell blocks x{world}" + (", 1 all-gather of int32 table rows" if world > 1 else "")},
         "roofline": roofline,
     }
 
     if rank == 0 and world == 1:
-        if args.check or True:
+        if True:
             # one step against the oracle on a bounded sample of source cells (checker only)
             import oracle
 

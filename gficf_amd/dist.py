@@ -51,9 +51,17 @@ def _all_gather_rows(table, local_view, group):
 
 
 class JaccardShard:
-    """Per-rank state of the sharded Jaccard build (buffers allocated once, reused per step)."""
+    """Per-rank state of the sharded Jaccard build (buffers allocated once, reused per step).
 
-    def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False):
+    ``pipeline=True`` (GPU only): steps are software-pipelined over two tables — the ingest (and,
+    for N > 1, the all-gather) of a step runs on a second stream, so it overlaps the edge kernel of
+    the step before it, which still reads the other table.  Every step does the same work and
+    yields the same bits; only the stream placement changes.  The input block handed to
+    :meth:`step` must already be valid on the device when the call is made.
+    """
+
+    def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False,
+                 pipeline: bool = False):
         self.ops, self.N, self.k, self.group = ops, int(N_total), int(k), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -61,22 +69,56 @@ class JaccardShard:
         self.rpr = rows_per_rank(self.N, self.world)
         self.b, self.e = shard_bounds(self.N, self.world, self.rank)
         self.n_local = self.e - self.b
-        # full table, padded to world*rpr rows so that every rank contributes an equal block
-        self.table = torch.zeros((self.world * self.rpr, self.kpad), dtype=torch.int32, device=device)
+        self.pipeline = bool(pipeline) and device is not None and torch.device(device).type == "cuda"
+        # full table(s), padded to world*rpr rows so that every rank contributes an equal block
+        self.tables = [torch.zeros((self.world * self.rpr, self.kpad), dtype=torch.int32, device=device)
+                       for _ in range(2 if self.pipeline else 1)]
+        self.table = self.tables[0]
         self.out = torch.zeros((3, self.n_local * self.k), dtype=torch.float64, device=device)
         self.u = torch.zeros(self.n_local * self.k, dtype=torch.int32, device=device) if with_u else None
+        self.t = 0
+        if self.pipeline:
+            self.side = torch.cuda.Stream(device=device)
+            self.ev_table_ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_table_free = [torch.cuda.Event(), torch.cuda.Event()]
 
-    def step(self, idx_local_cm):
-        """idx_local_cm: (k, n_local) tensor == column-major n_local x k block of the kNN matrix
-        (global 1-based ids).  Returns this rank's (3, n_local*k) slice of the edge matrix."""
-        my_rows = self.table[self.rank * self.rpr:(self.rank + 1) * self.rpr]
+    def _fill_table(self, table, idx_local_cm):
+        my_rows = table[self.rank * self.rpr:(self.rank + 1) * self.rpr]
         if self.n_local > 0:
             self.ops.jaccard_ingest(idx_local_cm, self.n_local, self.k, self.N, my_rows)
         if self.world > 1:
-            _all_gather_rows(self.table.view(-1), my_rows.reshape(-1), self.group)
+            _all_gather_rows(table.view(-1), my_rows.reshape(-1), self.group)
+
+    def step(self, idx_local_cm):
+        """idx_local_cm: (k, n_local) tensor == column-major n_local x k block of the kNN matrix
+        (global 1-based ids).  Returns this rank's (3, n_local*k) slice of the edge matrix (valid in
+        stream order on the caller's current stream)."""
+        if not self.pipeline:
+            self._fill_table(self.table, idx_local_cm)
+            if self.n_local > 0:
+                self.ops.jaccard_edges(self.table, self.N, self.k, self.b, self.e, self.out, self.u)
+            return self.out
+        p = self.t & 1
+        table = self.tables[p]
+        main = torch.cuda.current_stream(table.device)
+        if self.t >= 2:
+            self.side.wait_event(self.ev_table_free[p])      # edges of step t-2 have finished reading it
+        with torch.cuda.stream(self.side):
+            self._fill_table(table, idx_local_cm)
+            self.ev_table_ready[p].record(self.side)
+        main.wait_event(self.ev_table_ready[p])
         if self.n_local > 0:
-            self.ops.jaccard_edges(self.table, self.N, self.k, self.b, self.e, self.out, self.u)
+            self.ops.jaccard_edges(table, self.N, self.k, self.b, self.e, self.out, self.u)
+        self.ev_table_free[p].record(main)
+        self.table = table
+        self.t += 1
         return self.out
+
+    def sync(self):
+        """Wait for both streams and surface deferred input-validation errors."""
+        if self.pipeline:
+            self.side.synchronize()
+        self.ops.sync()
 
 
 class GficfShard:
