@@ -113,10 +113,24 @@ def jaccard_edges(neigh, verbose: bool = False, ctx: Context | None = None):
     edges and keeps the rows with weight > 0, in order.  Returns a dict with float64
     arrays ``from``, ``to``, ``weight`` (the columns of the reference's data.frame).
     """
-    neigh = np.asarray(neigh)
-    rel = rcpp_parallel_jaccard_coef(neigh[:, 1:], verbose, ctx=ctx)   # :63, :65
-    rel = rel[rel[:, 2] > 0, :]                                        # :66
-    return {"from": rel[:, 0].copy(), "to": rel[:, 1].copy(), "weight": rel[:, 2].copy()}  # :67-68
+    neigh = np.asarray(neigh)[:, 1:]                                   # :63
+    if verbose:
+        print("Running Parallell Jaccard Coefficient Estimation...")
+    N, k = neigh.shape
+    if np.issubdtype(neigh.dtype, np.integer):
+        m, is_f64 = np.asfortranarray(neigh, dtype=np.int32), 0
+    else:
+        m, is_f64 = np.asfortranarray(neigh, dtype=np.float64), 1
+    ctx = ctx or default_context()
+    L = _lib.load()
+    n = ctypes.c_int64(0)
+    # :65 and the weight > 0 filter of :66 in one device pass; only the kept edges cross PCIe
+    check(L.gficf_jaccard_filtered_host_plan(ctx.handle, _np_ptr(m), is_f64, N, k, max(N, 1), ctypes.byref(n)))
+    out = {key: np.empty(n.value, dtype=np.float64) for key in ("from", "to", "weight")}                  # :67-68
+    check(L.gficf_jaccard_filtered_host_finish(ctx.handle, _np_ptr(out["from"]), _np_ptr(out["to"]), _np_ptr(out["weight"])))
+    if verbose:
+        print("Done!!")
+    return out
 
 
 # -------------------------------------------------------------- GF-ICF, reference-shaped
@@ -271,6 +285,15 @@ class HipOps:
         check(self.L.gficf_jaccard_edges_device(self._bind(), _tptr(table), N, k, cell_begin, cell_end,
                                                 ctypes.c_void_p(base), ctypes.c_void_p(base + 8 * n),
                                                 ctypes.c_void_p(base + 16 * n), _tptr(u)))
+
+    def jaccard_edges_filtered(self, table, N: int, k: int, cell_begin: int, cell_end: int, u_ws, cell_ptr, out3):
+        """Edges with u > 0 only, in order (reference R/clustCells.R:66).  u_ws: int16 workspace of n*k;
+        cell_ptr: int64 (n+1); out3: (3, n*k) float64 capacity — rows from / to / weight, first cell_ptr[n] valid."""
+        n = (cell_end - cell_begin) * k
+        base = out3.data_ptr()
+        check(self.L.gficf_jaccard_edges_filtered_device(self._bind(), _tptr(table), N, k, cell_begin, cell_end,
+                                                         _tptr(u_ws), _tptr(cell_ptr), ctypes.c_void_p(base),
+                                                         ctypes.c_void_p(base + 8 * n), ctypes.c_void_p(base + 16 * n)))
 
     def jaccard(self, idx_cm, N: int, k: int, table_ws, rmat3, u=None):
         """Single-GPU ingest + edges.  rmat3: (3, N*k) float64 == the (N*k) x 3 R matrix."""

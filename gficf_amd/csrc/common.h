@@ -14,6 +14,7 @@ constexpr uint32_t GFICF_ST_BAD_ID = 1u;    // kNN id outside [1, N] or not an i
 constexpr uint32_t GFICF_ST_BAD_CSC = 2u;   // rowidx outside [0, G) / colptr not monotone
 
 struct gficf_host_plan;  // gficf_csc.hip
+struct gficf_edge_plan;  // jaccard.hip
 
 struct gficf_ctx {
   int device = 0;
@@ -24,10 +25,13 @@ struct gficf_ctx {
   void* d_ws = nullptr;           // scan partials (fixed size, allocated at create)
   size_t ws_bytes = 0;
   gficf_host_plan* plan = nullptr;
+  gficf_edge_plan* edge_plan = nullptr;
 };
 
 // releases the host-form GF-ICF plan held by the context, if any (gficf_csc.hip)
 void gficf_host_plan_free(gficf_ctx* ctx);
+// same for the host-form filtered edge build (jaccard.hip)
+extern "C" void gficf_edge_plan_free(gficf_ctx* ctx);
 
 // thread-local last error message
 void gficf_set_error(const char* fmt, ...);

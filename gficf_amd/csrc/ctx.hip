@@ -64,6 +64,7 @@ void gficf_ctx_destroy(gficf_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   gficf_host_plan_free(ctx);
+  gficf_edge_plan_free(ctx);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->d_ws) (void)hipFree(ctx->d_ws);

@@ -173,10 +173,11 @@ extern "C" __device__ int gficf_writelane(int value, int lane, int old) __asm("l
 __device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 struct EdgeOut {
-  double* src;
+  double* src;      // the three columns of the reference's edge matrix (all NULL: counts only)
   double* dst;
   double* w;
-  int32_t* u;
+  int32_t* u;       // optional intersection counts
+  uint16_t* u16;    // optional intersection counts, compact (input of the edge filter)
 };
 
 __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint32_t dst, int u,
@@ -186,10 +187,13 @@ __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint
 #endif
   const bool pos = u > 0;
   // written once, never re-read by this kernel: non-temporal, so the table rows keep the L2
-  __builtin_nontemporal_store(pos ? (double)(uint32_t)(cell + 1) : 0.0, o.src + r);   // reference :49 (cell + 1 <= 2^31)
-  __builtin_nontemporal_store(pos ? (double)dst : 0.0, o.dst + r);                    // reference :50
-  __builtin_nontemporal_store(pos ? lut[u] : 0.0, o.w + r);                           // reference :51
+  if (o.src) {
+    __builtin_nontemporal_store(pos ? (double)(uint32_t)(cell + 1) : 0.0, o.src + r);   // reference :49 (cell + 1 <= 2^31)
+    __builtin_nontemporal_store(pos ? (double)dst : 0.0, o.dst + r);                    // reference :50
+    __builtin_nontemporal_store(pos ? lut[u] : 0.0, o.w + r);                           // reference :51
+  }
   if (o.u) __builtin_nontemporal_store(u, o.u + r);
+  if (o.u16) o.u16[r] = (uint16_t)u;
 }
 
 // Exact multiset path for one cell whose own row or one of whose neighbour rows holds
@@ -199,8 +203,8 @@ __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint
 template <int KPAD>
 __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64_t i, int k, int64_t out_base,
                                        uint32_t* sA, uint32_t* sB, int lane, double* o_src, double* o_dst,
-                                       double* o_w, int32_t* o_u, const double* lut) {
-  const EdgeOut o{o_src, o_dst, o_w, o_u};
+                                       double* o_w, int32_t* o_u, uint16_t* o_u16, const double* lut) {
+  const EdgeOut o{o_src, o_dst, o_w, o_u, o_u16};
   for (int e = lane; e < KPAD; e += 64) sA[e] = table[i * KPAD + e] & ID_MASK;
   wave_lds_fence();
   for (int s = 0; s < k; ++s) {
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
     wave_lds_fence();
     if (slow) {
       slow_cell<KPAD>(table, i, k, (i - cell_begin) * (int64_t)k, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w,
-                      o.u, s_lut);
+                      o.u, o.u16, s_lut);
     } else {
       have_prev = true;
       prev_i = i;
@@ -452,6 +456,53 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
     for (int qq = 0; qq < C::EPL; ++qq) {
       const int slot = qq * 64 + lane;
       if (arow_lane && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ edge filter (N1)
+// The caller's next line, relations[relations[,3] > 0, ] (reference R/clustCells.R:66), on the
+// device: per-cell count of edges with u > 0 -> exclusive scan -> ordered compacted write.
+__global__ __launch_bounds__(256) void k_edge_kept_count(const uint16_t* __restrict__ u16, int64_t n_cells, int k,
+                                                         int64_t* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c == 0) out[n_cells] = 0;
+  if (c >= n_cells) return;
+  int n = 0;
+  for (int s = 0; s < k; ++s) n += u16[c * k + s] != 0;
+  out[c] = n;
+}
+
+template <int KPAD>
+__global__ __launch_bounds__(256) void k_edge_write(const uint32_t* __restrict__ table, const uint16_t* __restrict__ u16,
+                                                    int k, int64_t cell_begin, int64_t n_cells,
+                                                    const int64_t* __restrict__ ptr, double* __restrict__ from,
+                                                    double* __restrict__ to, double* __restrict__ weight) {
+  __shared__ double s_lut[GFICF_JACCARD_MAX_K + 1];
+  for (int u = threadIdx.x; u <= k; u += 256) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);   // reference :51
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t c = w0; c < n_cells; c += nw) {
+    int64_t pos = ptr[c];
+    for (int s0 = 0; s0 < k; s0 += 64) {
+      const int s = s0 + lane;
+      int u = 0;
+      uint32_t dst = 0;
+      if (s < k) {
+        u = u16[c * k + s];
+        dst = table[(cell_begin + c) * KPAD + s] & ID_MASK;
+      }
+      const bool kp = u > 0;
+      const unsigned long long m = __ballot(kp);
+      if (kp) {
+        const int64_t d = pos + __popcll(m & lt_mask);
+        from[d] = (double)(uint32_t)(cell_begin + c + 1);
+        to[d] = (double)dst;
+        weight[d] = s_lut[u];
+      }
+      pos += __popcll(m);
     }
   }
 }
@@ -555,7 +606,7 @@ int gficf_jaccard_edges_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "cell range [%lld, %lld) outside [0, %lld]", (long long)cell_begin, (long long)cell_end, (long long)N);
   if (cell_end == cell_begin || k == 0) return GFICF_OK;
   if (!d_table || !d_src || !d_dst || !d_w) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
-  EdgeOut o{d_src, d_dst, d_w, d_u};
+  EdgeOut o{d_src, d_dst, d_w, d_u, nullptr};
   const uint32_t* t = (const uint32_t*)d_table;
   switch (kpad_for(k)) {
     case 16: return launch_edges<16>(ctx, t, N, k, cell_begin, cell_end, o);
@@ -607,6 +658,142 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
     if (rc) return rc;
   }
   if (print_output) { printf("Done!!\n"); fflush(stdout); }  // reference :77
+  return GFICF_OK;
+}
+
+int gficf_jaccard_edges_filtered_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k, int64_t cell_begin,
+                                        int64_t cell_end, uint16_t* d_u_ws, int64_t* d_cell_ptr, double* d_from,
+                                        double* d_to, double* d_weight) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = check_nk(N, k);
+  if (rc) return rc;
+  if (cell_begin < 0 || cell_end < cell_begin || cell_end > N)
+    GFICF_FAIL(GFICF_ERR_INVALID_ARG, "cell range [%lld, %lld) outside [0, %lld]", (long long)cell_begin, (long long)cell_end, (long long)N);
+  if (!d_cell_ptr) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  const int64_t n_cells = cell_end - cell_begin;
+  if (n_cells == 0 || k == 0) {
+    GFICF_HIP_CHECK(hipMemsetAsync(d_cell_ptr, 0, sizeof(int64_t) * (size_t)(n_cells + 1), ctx->stream));
+    return GFICF_OK;
+  }
+  if (!d_table || !d_u_ws || !d_from || !d_to || !d_weight) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  // 1. intersection counts only (no 24 B/edge matrix)
+  EdgeOut o{nullptr, nullptr, nullptr, nullptr, d_u_ws};
+  const uint32_t* t = (const uint32_t*)d_table;
+  switch (kpad_for(k)) {
+    case 16: rc = launch_edges<16>(ctx, t, N, k, cell_begin, cell_end, o); break;
+    case 32: rc = launch_edges<32>(ctx, t, N, k, cell_begin, cell_end, o); break;
+    case 64: rc = launch_edges<64>(ctx, t, N, k, cell_begin, cell_end, o); break;
+    case 128: rc = launch_edges<128>(ctx, t, N, k, cell_begin, cell_end, o); break;
+    default: rc = launch_edges<256>(ctx, t, N, k, cell_begin, cell_end, o); break;
+  }
+  if (rc) return rc;
+  // 2. kept edges per cell -> offsets
+  hipLaunchKernelGGL(k_edge_kept_count, dim3((unsigned)gficf_ceil_div(n_cells, 256)), dim3(256), 0, ctx->stream, d_u_ws,
+                     n_cells, k, d_cell_ptr);
+  GFICF_HIP_CHECK(hipGetLastError());
+  rc = gficf_exclusive_scan_i64(ctx, d_cell_ptr, n_cells + 1);
+  if (rc) return rc;
+  // 3. ordered compacted write
+  int64_t blocks = gficf_ceil_div(n_cells, 4);
+  if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+#define LAUNCH_EW(KP)                                                                                               \
+  hipLaunchKernelGGL((k_edge_write<KP>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, t, d_u_ws, k, cell_begin, \
+                     n_cells, d_cell_ptr, d_from, d_to, d_weight)
+  switch (kpad_for(k)) {
+    case 16: LAUNCH_EW(16); break;
+    case 32: LAUNCH_EW(32); break;
+    case 64: LAUNCH_EW(64); break;
+    case 128: LAUNCH_EW(128); break;
+    default: LAUNCH_EW(256); break;
+  }
+#undef LAUNCH_EW
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
+}
+
+// host form of the filtered build: plan runs everything and returns the edge count, finish copies out
+struct gficf_edge_plan {
+  int64_t n_edges = 0;
+  double* d_from = nullptr;
+  double* d_to = nullptr;
+  double* d_weight = nullptr;
+};
+
+static void edge_plan_free(gficf_ctx* ctx) {
+  gficf_edge_plan* p = ctx->edge_plan;
+  if (!p) return;
+  if (p->d_from) (void)hipFree(p->d_from);
+  if (p->d_to) (void)hipFree(p->d_to);
+  if (p->d_weight) (void)hipFree(p->d_weight);
+  delete p;
+  ctx->edge_plan = nullptr;
+}
+
+void gficf_edge_plan_free(gficf_ctx* ctx) { edge_plan_free(ctx); }
+
+int gficf_jaccard_filtered_host_plan(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld,
+                                     int64_t* n_edges) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = check_nk(N, k);
+  if (rc) return rc;
+  if (!n_edges) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "n_edges is NULL");
+  edge_plan_free(ctx);
+  *n_edges = 0;
+  const int64_t E = N * (int64_t)k;
+  gficf_edge_plan* p = new gficf_edge_plan();
+  ctx->edge_plan = p;
+  if (E == 0) return GFICF_OK;
+  if (!idx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
+  if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
+  const size_t esz = idx_is_f64 ? sizeof(double) : sizeof(int32_t);
+  const int kpad = kpad_for(k);
+  void* d_idx = nullptr;
+  int32_t* d_table = nullptr;
+  uint16_t* d_u = nullptr;
+  int64_t* d_ptr = nullptr;
+  hipError_t e = hipMalloc(&d_idx, esz * (size_t)ld * (size_t)k);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_table, sizeof(int32_t) * (size_t)N * (size_t)kpad);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_u, sizeof(uint16_t) * (size_t)E);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_ptr, sizeof(int64_t) * (size_t)(N + 1));
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_from, sizeof(double) * (size_t)E);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_to, sizeof(double) * (size_t)E);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->d_weight, sizeof(double) * (size_t)E);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, esz * (size_t)ld * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
+  rc = GFICF_OK;
+  int64_t total = 0;
+  if (e == hipSuccess) {
+    rc = gficf_jaccard_ingest_device(ctx, d_idx, idx_is_f64, N, k, ld, N, d_table);
+    if (!rc) rc = gficf_jaccard_edges_filtered_device(ctx, d_table, N, k, 0, N, d_u, d_ptr, p->d_from, p->d_to, p->d_weight);
+    if (!rc) e = hipMemcpyAsync(&total, d_ptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
+    else (void)hipStreamSynchronize(ctx->stream);
+  }
+  if (d_idx) (void)hipFree(d_idx);
+  if (d_table) (void)hipFree(d_table);
+  if (d_u) (void)hipFree(d_u);
+  if (d_ptr) (void)hipFree(d_ptr);
+  if (e != hipSuccess) { gficf_set_error("HIP failure in gficf_jaccard_filtered_host_plan: %s", hipGetErrorString(e)); rc = GFICF_ERR_HIP; }
+  if (rc) { edge_plan_free(ctx); return rc; }
+  p->n_edges = total;
+  *n_edges = total;
+  return GFICF_OK;
+}
+
+int gficf_jaccard_filtered_host_finish(gficf_ctx* ctx, double* from, double* to, double* weight) {
+  GFICF_CTX_ENTER(ctx);
+  gficf_edge_plan* p = ctx->edge_plan;
+  if (!p) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "gficf_jaccard_filtered_host_finish without a plan");
+  hipError_t e = hipSuccess;
+  if (p->n_edges > 0) {
+    if (!from || !to || !weight) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
+    const size_t b = sizeof(double) * (size_t)p->n_edges;
+    e = hipMemcpyAsync(from, p->d_from, b, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(to, p->d_to, b, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(weight, p->d_weight, b, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  edge_plan_free(ctx);
+  if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_jaccard_filtered_host_finish: %s", hipGetErrorString(e));
   return GFICF_OK;
 }
 

@@ -111,6 +111,21 @@ int gficf_jaccard_edges_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N
 int gficf_jaccard_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int64_t N, int k,
                          int64_t ld, int32_t* d_table_ws, double* d_rmat, int32_t* d_u);
 
+/* Edge filter of clustcells() fused on the device ("next" row N1): the caller's next line,
+ *   relations <- relations[relations[,3] > 0, ]            (R/clustCells.R:66)
+ * Only the edges with u > 0 are written, in the reference's row order (cell-major, slot order).
+ * d_u_ws: workspace of (cell_end-cell_begin)*k uint16.  d_cell_ptr[n_cells+1]: offsets of every
+ * source cell's edges in the output (d_cell_ptr[n_cells] = number of edges written).
+ * d_from/d_to/d_weight: capacity (cell_end-cell_begin)*k doubles each. */
+int gficf_jaccard_edges_filtered_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k,
+                                        int64_t cell_begin, int64_t cell_end, uint16_t* d_u_ws,
+                                        int64_t* d_cell_ptr, double* d_from, double* d_to,
+                                        double* d_weight);
+/* Host form (two calls so that the caller can allocate exactly n_edges rows): R/clustCells.R:65-66. */
+int gficf_jaccard_filtered_host_plan(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k,
+                                     int64_t ld, int64_t* n_edges);
+int gficf_jaccard_filtered_host_finish(gficf_ctx* ctx, double* from, double* to, double* weight);
+
 /* ------------------------------------------------------------------------------ GF-ICF
  * Replaces the R-level chain of gficf()  (R/gficf.R:17-33, normalize = FALSE):
  *   normCounts filter R/gficf.R:40-41, tf R/gficf.R:59, getIdfW("classic") R/gficf.R:88-89,

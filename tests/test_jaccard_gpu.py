@@ -282,3 +282,35 @@ def test_pipelined_steps_give_the_same_bits(ops):
     torch.cuda.synchronize()
     for i, g in got:
         assert np.array_equal(g.cpu().numpy().T, want[i])
+
+
+@pytest.mark.parametrize("gen,N,k", [("win", 5000, 30), ("uni", 20000, 15), ("win", 700, 100), ("uni", 3000, 50)])
+def test_device_edge_filter_matches_reference_filter(ops, gen, N, k):
+    """N1: edges with weight > 0 only, in order == relations[relations[,3] > 0, ] (R/clustCells.R:66)."""
+    import torch
+
+    mat = synth.knn_windowed(N, k, W=max(100, k), seed=9) if gen == "win" else synth.knn_uniform(N, k, seed=9)
+    want, _ = oracle.jaccard(mat, nthreads=8)
+    want = want[want[:, 2] > 0]
+    idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
+    table = torch.empty((N, ops.kpad(k)), dtype=torch.int32, device="cuda")
+    ops.jaccard_ingest(idx, N, k, N, table)
+    # two cell blocks, concatenated, must equal the single filter
+    parts = []
+    for b, e in ((0, N // 3), (N // 3, N)):
+        n = (e - b) * k
+        u_ws = torch.empty(n, dtype=torch.int16, device="cuda")
+        ptr = torch.empty(e - b + 1, dtype=torch.int64, device="cuda")
+        out3 = torch.full((3, n), -1.0, dtype=torch.float64, device="cuda")
+        ops.jaccard_edges_filtered(table, N, k, b, e, u_ws, ptr, out3)
+        ops.sync()
+        m = int(ptr[-1])
+        parts.append(out3[:, :m].cpu().numpy().T)
+        cnt = np.diff(ptr.cpu().numpy())
+        assert cnt.min() >= 0 and cnt.max() <= k
+    got = np.concatenate(parts, axis=0)
+    assert np.array_equal(got, want)
+    # host form through the clustcells() call-site mirror
+    neigh = np.concatenate([np.arange(1, N + 1, dtype=np.int32)[:, None], mat], axis=1)
+    rel = gficf_amd.jaccard_edges(neigh)
+    assert np.array_equal(rel["from"], want[:, 0]) and np.array_equal(rel["to"], want[:, 1]) and np.array_equal(rel["weight"], want[:, 2])
