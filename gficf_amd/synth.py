@@ -80,18 +80,29 @@ def knn_uniform(N: int, k: int, seed: int = 44, dtype=np.int32) -> np.ndarray:
     if N - 1 < k:
         raise ValueError("need N-1 >= k")
     cells = np.arange(N, dtype=np.int64)
+    if (N - 1) <= 4 * k and N * (N - 1) <= 64_000_000:
+        # dense case: rank random keys of all N-1 offsets, keep the first k
+        keys = rand_u64(seed, cells[:, None], np.arange(N - 1, dtype=np.int64)[None, :])
+        off = 1 + np.argsort(keys, axis=1, kind="stable")[:, :k].astype(np.int64)
+        return (((cells[:, None] + off) % N) + 1).astype(dtype)
     off = np.empty((N, k), dtype=np.int64)
     for t in range(k):
         off[:, t] = 1 + (rand_u64(seed, cells, t) % np.uint64(N - 1)).astype(np.int64)
+    # redraw only the entries that repeat an earlier entry of their row (terminates quickly for any k < N-1)
     rnd = 1
     while True:
-        s = np.sort(off, axis=1)
-        bad = np.flatnonzero((s[:, 1:] == s[:, :-1]).any(axis=1))
-        if bad.size == 0:
+        order = np.argsort(off, axis=1, kind="stable")
+        srt = np.take_along_axis(off, order, axis=1)
+        dup_sorted = np.zeros_like(srt, dtype=bool)
+        dup_sorted[:, 1:] = srt[:, 1:] == srt[:, :-1]
+        if not dup_sorted.any():
             break
-        for t in range(k):
-            off[bad, t] = 1 + (rand_u64(seed + 1000 * rnd, cells[bad], t) % np.uint64(N - 1)).astype(np.int64)
+        rows, pos = np.nonzero(dup_sorted)
+        cols = order[rows, pos]
+        off[rows, cols] = 1 + (rand_u64(seed + 1000 * rnd, rows * k + cols, rnd) % np.uint64(N - 1)).astype(np.int64)
         rnd += 1
+        if rnd > 10_000:
+            raise RuntimeError("knn_uniform did not converge")
     return (((cells[:, None] + off) % N) + 1).astype(dtype)
 
 

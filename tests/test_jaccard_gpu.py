@@ -314,3 +314,23 @@ def test_device_edge_filter_matches_reference_filter(ops, gen, N, k):
     neigh = np.concatenate([np.arange(1, N + 1, dtype=np.int32)[:, None], mat], axis=1)
     rel = gficf_amd.jaccard_edges(neigh)
     assert np.array_equal(rel["from"], want[:, 0]) and np.array_equal(rel["to"], want[:, 1]) and np.array_equal(rel["weight"], want[:, 2])
+
+
+def test_randomised_shapes_against_oracle(ops):
+    """Fuzz: random N, k in [1, 256], windowed / uniform / duplicate-heavy ids, int32 and float64 input."""
+    rng = np.random.default_rng(20261003)
+    for case in range(40):
+        k = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 30, 31, 32, 33, 50, 63, 64, 65, 100, 128, 129, 200, 255, 256]))
+        N = int(rng.integers(max(k + 2, 4), 3000))
+        mode = case % 3
+        if mode == 0 and N > 2 * k + 2:
+            mat = synth.knn_windowed(N, k, W=max(100, k), seed=case)
+        elif mode == 1:
+            mat = synth.knn_uniform(N, k, seed=case)
+        else:
+            mat = (synth.rand_u64(case, np.arange(N * k)).reshape(N, k) % np.uint64(min(N, 3 * k))).astype(np.int32) + 1
+        if case % 4 == 0:
+            mat = mat.astype(np.float64)
+        got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
+        want, _ = oracle.jaccard(mat, nthreads=8)
+        assert np.array_equal(got, want), (case, N, k, mode)
