@@ -182,9 +182,6 @@ struct EdgeOut {
 
 __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint32_t dst, int u,
                                   const double* lut) {
-#ifdef GFICF_LAB_NOSTORE   // timing-only lab build: (almost) no output traffic
-  if (u != 12345) return;
-#endif
   const bool pos = u > 0;
   // written once, never re-read by this kernel: non-temporal, so the table rows keep the L2
   if (o.src) {
@@ -357,11 +354,7 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
 #pragma unroll
           for (int uu = 0; uu < C::U; ++uu) {
             const uint32_t dst = (uint32_t)__shfl((int)asafe[q], (t0 + uu) * C::RPS + grow);
-#ifdef GFICF_LAB_NOGATHER   // timing-only lab build: every gather hits the cell's own row
-            const off_t off = (off_t)i * ROWB + gcol + (off_t)(dst & 0u);
-#else
             const off_t off = (off_t)(dst - 1) * ROWB + gcol;
-#endif
             bv[uu] = *reinterpret_cast<const uint4*>(tbytes + off);
           }
           if (!prev_stored) {
@@ -383,19 +376,10 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
           for (int uu = 0; uu < C::U; ++uu) {
             dupflags |= bv[uu].x;
             bv[uu].x &= ID_MASK;             // only a row's first id can carry the duplicate flag
-#if defined(GFICF_LAB_NOPROBE)     // timing-only lab build: no LDS probes at all
-            const uint2 h0 = make_uint2(bv[uu].y, 1u), h1 = make_uint2(bv[uu].z, 2u), h2 = make_uint2(bv[uu].w, 3u), h3 = make_uint2(bv[uu].x, 4u);
-#elif defined(GFICF_LAB_LINPROBE)  // timing-only lab build: conflict-free probe addresses
-            const uint2 h0 = s_hash[wave][(lane + (bv[uu].x & 0u)) & (C::NB - 1)];
-            const uint2 h1 = s_hash[wave][(lane + 64 + (bv[uu].y & 0u)) & (C::NB - 1)];
-            const uint2 h2 = s_hash[wave][(lane + 128 + (bv[uu].z & 0u)) & (C::NB - 1)];
-            const uint2 h3 = s_hash[wave][(lane + 192 + (bv[uu].w & 0u)) & (C::NB - 1)];
-#else
             const uint2 h0 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].x)];
             const uint2 h1 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].y)];
             const uint2 h2 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].z)];
             const uint2 h3 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].w)];
-#endif
             int c = 0;
             c += (h0.x == bv[uu].x) | (h0.y == bv[uu].x);
             c += (h1.x == bv[uu].y) | (h1.y == bv[uu].y);
