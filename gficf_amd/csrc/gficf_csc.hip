@@ -48,7 +48,9 @@ __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __res
     __syncthreads();
   }
   bool bad = false;
-  constexpr int64_t CHUNK = (int64_t)CNT_THREADS * 8;
+  constexpr int GROUPS = 4;                                  // 16 B rowidx + 32 B x per group, all in flight
+  constexpr int64_t STRIDE = (int64_t)CNT_THREADS * 4;       // entries per group sweep of the workgroup
+  constexpr int64_t CHUNK = STRIDE * GROUPS;
   const int64_t per_block = gficf_ceil_div(gficf_ceil_div(nnz, (int64_t)gridDim.x), CHUNK) * CHUNK;
   const int64_t p0 = (int64_t)blockIdx.x * per_block;
   const int64_t p1 = p0 + per_block < nnz ? p0 + per_block : nnz;
@@ -56,18 +58,23 @@ __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __res
   if (VEC) {
     for (; p + CHUNK <= p1; p += CHUNK) {
       const int64_t q = p + (int64_t)threadIdx.x * 4;
-      const int4 ga = *reinterpret_cast<const int4*>(rowidx + q);
-      const int4 gb = *reinterpret_cast<const int4*>(rowidx + q + CHUNK / 2);
-      const double2 xa0 = *reinterpret_cast<const double2*>(x + q), xa1 = *reinterpret_cast<const double2*>(x + q + 2);
-      const double2 xb0 = *reinterpret_cast<const double2*>(x + q + CHUNK / 2), xb1 = *reinterpret_cast<const double2*>(x + q + CHUNK / 2 + 2);
-      count_one<USE_LDS>(ga.x, xa0.x, G, s_hist, nt, bad);
-      count_one<USE_LDS>(ga.y, xa0.y, G, s_hist, nt, bad);
-      count_one<USE_LDS>(ga.z, xa1.x, G, s_hist, nt, bad);
-      count_one<USE_LDS>(ga.w, xa1.y, G, s_hist, nt, bad);
-      count_one<USE_LDS>(gb.x, xb0.x, G, s_hist, nt, bad);
-      count_one<USE_LDS>(gb.y, xb0.y, G, s_hist, nt, bad);
-      count_one<USE_LDS>(gb.z, xb1.x, G, s_hist, nt, bad);
-      count_one<USE_LDS>(gb.w, xb1.y, G, s_hist, nt, bad);
+      typedef int v4i __attribute__((ext_vector_type(4)));
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      v4i g[GROUPS];
+      v2d xa[GROUPS], xb[GROUPS];
+#pragma unroll
+      for (int t = 0; t < GROUPS; ++t) {                     // streamed once: non-temporal
+        g[t] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(rowidx + q + t * STRIDE));
+        xa[t] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(x + q + t * STRIDE));
+        xb[t] = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(x + q + t * STRIDE + 2));
+      }
+#pragma unroll
+      for (int t = 0; t < GROUPS; ++t) {
+        count_one<USE_LDS>(g[t].x, xa[t].x, G, s_hist, nt, bad);
+        count_one<USE_LDS>(g[t].y, xa[t].y, G, s_hist, nt, bad);
+        count_one<USE_LDS>(g[t].z, xb[t].x, G, s_hist, nt, bad);
+        count_one<USE_LDS>(g[t].w, xb[t].y, G, s_hist, nt, bad);
+      }
     }
   }
   for (p += threadIdx.x; p < p1; p += CNT_THREADS) count_one<USE_LDS>(rowidx[p], x[p], G, s_hist, nt, bad);
