@@ -253,8 +253,8 @@ def main():
                   "roofline": {"bound": "hbm", "kernel": "whole pass (count + colptr + scale)",
                                "achieved": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_PEAK_GBS, 4),
-                               "traffic": (sum(pmc[kk]["hbm_bytes_per_launch"] for kk in ("gene_count", "cell_kept_count", "scale_cells"))
-                                           if all(kk in pmc for kk in ("gene_count", "cell_kept_count", "scale_cells")) and nnz == 59809258 else None),
+                               "traffic": (sum(pmc[kk]["hbm_bytes_per_launch"] for kk in ("gene_count", "gene_table", "cell_kept_count", "scale_cells", "scale_cells_lds") if kk in pmc)
+                                           if all(kk in pmc for kk in ("gene_count", "cell_kept_count")) and nnz == 59809258 else None),
                                "scale_kernel_ms": round(t_scale, 4), "count_kernel_ms": round(t_count, 4),
                                "algorithmic_bytes_per_pass": GFICF_BYTES_PER_NNZ * nnz}}
             if not args.no_cpu_baseline:
