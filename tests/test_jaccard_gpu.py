@@ -334,3 +334,46 @@ def test_randomised_shapes_against_oracle(ops):
         got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
         want, _ = oracle.jaccard(mat, nthreads=8)
         assert np.array_equal(got, want), (case, N, k, mode)
+
+
+def test_rccl_single_rank_collectives_and_bench_launch_path():
+    """RCCL path smoke on the 1-GPU box: a 1-rank NCCL group accepts the in-place flat all-gather of
+    table rows and the int64 all-reduce that the N > 1 path issues (gficf_amd/dist.py), and bench.py
+    runs under torch.distributed.run."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, numpy as np, torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "import gficf_amd, oracle\n"
+        "from gficf_amd import synth\n"
+        "from gficf_amd.dist import JaccardShard, GficfShard, _all_gather_rows\n"
+        "ops = gficf_amd.HipOps(0)\n"
+        "N, k = 4000, 30\n"
+        "mat = synth.knn_windowed(N, k, seed=2)\n"
+        "sh = JaccardShard(ops, N, k, device='cuda', pipeline=True)\n"
+        "idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()\n"
+        "for _ in range(3): out = sh.step(idx)\n"
+        "t = sh.table; mine = t[0:sh.rpr]\n"
+        "_all_gather_rows(t.view(-1), mine.reshape(-1), None)\n"
+        "sh.sync(); torch.cuda.synchronize()\n"
+        "assert np.array_equal(out.cpu().numpy().T, oracle.jaccard(mat, nthreads=4)[0])\n"
+        "cp, ri, x = synth.counts_csc(900, 500, seed=3)\n"
+        "d = lambda a: torch.from_numpy(a).cuda()\n"
+        "gs = GficfShard(ops, 900, 500, 500, len(ri), device='cuda')\n"
+        "ws = gs.step(d(cp), d(ri), d(x), 0.05, 1.0)\n"
+        "dist.all_reduce(ws['nt'], op=dist.ReduceOp.SUM)\n"
+        "ops.sync(); ref = oracle.gficf_csc(900, 500, cp, ri, x, 0.05, 1.0)\n"
+        "n = int(ws['out_colptr'][500]); assert np.allclose(ws['out_x'][:n].cpu().numpy(), ref['x'], rtol=1e-6, atol=1e-6)\n"
+        "dist.barrier(); dist.destroy_process_group(); print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29534", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-gficf"], env=env, capture_output=True, text=True, timeout=280, cwd=root)
+    assert r.returncode == 0 and '"metric": "jaccard_edges_per_sec"' in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
