@@ -228,3 +228,55 @@ def test_degenerate_shapes():
     assert r["gficf"].shape == (0, 3) and r["w"].size == 0
     r = gficf_amd.gficf(sp.csc_matrix((5, 0)), normalize=False, verbose=False)
     assert r["gficf"].shape == (0, 0) and r["gficf"].nnz == 0
+
+
+def test_config4_shape_properties_device_resident():
+    """BASELINE config 4 shape (100 k cells x 30 k genes, ~1.5e8 stored entries), device-resident:
+    size-independent properties (no host oracle at this size)."""
+    import torch
+
+    sys_path = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import sys
+    sys.path.insert(0, sys_path)
+    import bench
+
+    ops = gficf_amd.HipOps(0)
+    G, N = 30000, 100000
+    colptr, rowidx, x = bench.synth_counts_device(torch, G, N, seed=11)
+    ws = ops.gficf_csc(G, N, colptr, rowidx, x, 0.05, 1.0)
+    ops.sync()
+    nk = int(ws["out_colptr"][N])
+    gk = int(ws["gkept"][0])
+    ocp, ori, ox = ws["out_colptr"], ws["out_rowidx"][:nk], ws["out_x"][:nk]
+    keep = ws["keep"].bool()
+    assert gk == int(keep.sum()) and 0 < gk < G
+    # structure: the kept entries of every cell, renumbered, in order
+    kept_entry = keep[rowidx.long()]
+    assert nk == int(kept_entry.sum())
+    remap = torch.cumsum(keep.long(), 0) - 1
+    assert torch.equal(ori.long(), remap[rowidx.long()[kept_entry]])
+    cnt = torch.zeros(N, dtype=torch.int64, device="cuda")
+    col_of = torch.repeat_interleave(torch.arange(N, device="cuda"), colptr[1:] - colptr[:-1])
+    cnt.index_add_(0, col_of, kept_entry.long())
+    assert torch.equal(ocp[1:] - ocp[:-1], cnt)
+    # nt = cells with a non-zero entry per gene; w = log((N+1)/(nt+1))
+    nt = torch.bincount(rowidx.long()[x != 0], minlength=G)
+    assert torch.equal(ws["nt"], nt)
+    w_ref = torch.log((N + 1.0) / (nt.double() + 1.0))
+    assert torch.allclose(ws["w"][keep], w_ref[keep], rtol=1e-12, atol=0)
+    # values: every non-empty cell has unit L2 norm, values in [0, 1]
+    ocol = torch.repeat_interleave(torch.arange(N, device="cuda"), cnt)
+    sq = torch.zeros(N, dtype=torch.float64, device="cuda").index_add_(0, ocol, ox * ox)
+    nonempty = cnt > 0
+    has_w = torch.zeros(N, dtype=torch.float64, device="cuda").index_add_(0, ocol, (ws["w"][keep][ori.long()] > 0).double()) > 0
+    assert torch.allclose(sq[nonempty & has_w], torch.ones_like(sq[nonempty & has_w]), rtol=1e-12, atol=0)
+    assert float(ox.min()) >= 0.0 and float(ox.max()) <= 1.0 + 1e-12
+    # and the closed form on a sample of cells
+    for c in (0, 1, N // 2, N - 1):
+        sl = slice(int(colptr[c]), int(colptr[c + 1]))
+        kp = kept_entry[sl]
+        xs, gsel = x[sl][kp], rowidx[sl][kp].long()
+        v = (xs / xs.sum()) * ws["w"][gsel]
+        ref = v / torch.sqrt((v * v).sum())
+        got = ox[int(ocp[c]):int(ocp[c + 1])]
+        assert torch.allclose(got, ref, rtol=1e-10, atol=1e-14)

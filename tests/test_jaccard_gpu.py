@@ -377,3 +377,11 @@ def test_rccl_single_rank_collectives_and_bench_launch_path():
                         "--master-port", "29534", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
                         "--no-cpu-baseline", "--no-gficf"], env=env, capture_output=True, text=True, timeout=280, cwd=root)
     assert r.returncode == 0 and '"metric": "jaccard_edges_per_sec"' in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_config4_shape_100k_cells_k50_bit_exact(ops):
+    """BASELINE config 4 shape (100 k cells, k = 50): whole edge matrix bit-exact vs the oracle."""
+    mat = synth.knn_windowed(100000, 50, seed=4)
+    rm, u = device_jaccard(ops, mat)
+    want, wu = oracle.jaccard(mat, nthreads=os.cpu_count() or 8)
+    assert np.array_equal(u, wu) and np.array_equal(rm, want)
