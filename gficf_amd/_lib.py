@@ -43,6 +43,9 @@ SIGNATURES = {
     "gficf_jaccard_host": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _int]),
     "gficf_jaccard_kpad": (_int, [_int]),
     "gficf_jaccard_ingest_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _i64, _vp]),
+    "gficf_jaccard_packed_words": (_int, [_i64, _int]),
+    "gficf_jaccard_pack_rows_device": (_int, [_vp, _vp, _i64, _int, _i64, _vp]),
+    "gficf_jaccard_unpack_rows_device": (_int, [_vp, _vp, _i64, _int, _i64, _vp]),
     "gficf_jaccard_edges_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _vp, _vp]),
     "gficf_jaccard_edges_filtered_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

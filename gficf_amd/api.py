@@ -276,6 +276,17 @@ class HipOps:
         check(self.L.gficf_jaccard_ingest_device(self._bind(), _tptr(idx_cm), is_f64, n_rows, k, ld, N_total,
                                                  _tptr(table_rows)))
 
+    @staticmethod
+    def packed_words(N_total: int, k: int) -> int:
+        return int(_lib.load().gficf_jaccard_packed_words(int(N_total), int(k)))
+
+    def jaccard_pack_rows(self, table_rows, n_rows: int, k: int, N_total: int, packed):
+        """table_rows (n_rows, kpad) int32 -> packed (n_rows, packed_words) int32 (transport form)."""
+        check(self.L.gficf_jaccard_pack_rows_device(self._bind(), _tptr(table_rows), n_rows, k, N_total, _tptr(packed)))
+
+    def jaccard_unpack_rows(self, packed, n_rows: int, k: int, N_total: int, table_rows):
+        check(self.L.gficf_jaccard_unpack_rows_device(self._bind(), _tptr(packed), n_rows, k, N_total, _tptr(table_rows)))
+
     def jaccard_edges(self, table, N: int, k: int, cell_begin: int, cell_end: int, out3, u=None):
         """table: (N, kpad) int32.  out3: (3, (cell_end-cell_begin)*k) float64 — src, dst, weight rows."""
         n = (cell_end - cell_begin) * k

@@ -491,6 +491,76 @@ __global__ __launch_bounds__(256) void k_edge_write(const uint32_t* __restrict__
   }
 }
 
+// ------------------------------------------------- packed table rows (multi-GPU transport)
+// The all-gather of table rows is what bounds the N > 1 path (xGMI), so rows travel bit-packed:
+// k ids of ceil(log2(N+1)) bits each + 1 bit for the row's duplicate flag, rounded up to whole
+// 32-bit words (k = 30, N = 800 k: 76 B instead of the 128 B row pitch).  One thread per row.
+__host__ __device__ inline int id_bits(int64_t N) {
+  int b = 1;
+  while (b < 31 && ((int64_t)1 << b) <= N) ++b;
+  return b;
+}
+__host__ __device__ inline int packed_words(int64_t N, int k) { return (k * id_bits(N) + 1 + 31) / 32; }
+
+// 64 rows per workgroup, staged through LDS so that both the table read and the packed write are
+// contiguous runs; every thread assembles whole 32-bit output words.
+constexpr int PACK_ROWS = 64;
+
+__global__ __launch_bounds__(256) void k_pack_rows(const uint32_t* __restrict__ table, int64_t n_rows, int k, int kpad,
+                                                   int bits, int wpr, uint32_t* __restrict__ packed) {
+  extern __shared__ uint32_t s_tb[];                        // PACK_ROWS * kpad words
+  const int fl = k * bits;                                  // bit position of the duplicate flag
+  for (int64_t row0 = (int64_t)blockIdx.x * PACK_ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * PACK_ROWS) {
+    const int rows_here = (int)((n_rows - row0) < PACK_ROWS ? (n_rows - row0) : PACK_ROWS);
+    for (int e = threadIdx.x; e < rows_here * kpad; e += 256) s_tb[e] = table[row0 * kpad + e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows_here * wpr; e += 256) {
+      const int rr = e / wpr, w = e % wpr;
+      const uint32_t* row = s_tb + rr * kpad;
+      const int lo = 32 * w, hi = lo + 32;
+      uint32_t v = 0;
+      for (int j = lo / bits; j < k && j * bits < hi; ++j) {
+        const uint32_t id = row[j] & ID_MASK;
+        const int pos = j * bits - lo;
+        v |= pos >= 0 ? id << pos : id >> (-pos);
+      }
+      if (fl >= lo && fl < hi) v |= (row[0] >> 31) << (fl - lo);
+      packed[row0 * wpr + e] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// 64 rows per workgroup: the packed words are staged in LDS with coalesced loads, every thread then
+// extracts ids for consecutive slots, so the table is written as contiguous runs.
+constexpr int UNPACK_ROWS = 64;
+
+__global__ __launch_bounds__(256) void k_unpack_rows(const uint32_t* __restrict__ packed, int64_t n_rows, int k, int kpad,
+                                                     int bits, int wpr, uint32_t* __restrict__ table) {
+  extern __shared__ uint32_t s_pk[];                        // UNPACK_ROWS * wpr words
+  const uint32_t mask = (uint32_t)(((unsigned long long)1 << bits) - 1ull);
+  const int fl_w = (k * bits) >> 5, fl_b = (k * bits) & 31; // position of the duplicate flag
+  for (int64_t row0 = (int64_t)blockIdx.x * UNPACK_ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * UNPACK_ROWS) {
+    const int rows_here = (int)((n_rows - row0) < UNPACK_ROWS ? (n_rows - row0) : UNPACK_ROWS);
+    for (int e = threadIdx.x; e < rows_here * wpr; e += 256) s_pk[e] = packed[row0 * wpr + e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows_here * kpad; e += 256) {
+      const int rr = e / kpad, j = e % kpad;
+      uint32_t id = 0;
+      if (j < k) {
+        const uint32_t* in = s_pk + rr * wpr;
+        const int off = j * bits, w = off >> 5, sh = off & 31;
+        unsigned long long v = in[w];
+        if (w + 1 < wpr) v |= (unsigned long long)in[w + 1] << 32;
+        id = (uint32_t)(v >> sh) & mask;
+        if (j == 0) id |= ((in[fl_w] >> fl_b) & 1u) << 31;
+      }
+      table[row0 * kpad + e] = id;
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T>
 int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t ld, int64_t N_total,
                   uint32_t* table) {
@@ -642,6 +712,44 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
     if (rc) return rc;
   }
   if (print_output) { printf("Done!!\n"); fflush(stdout); }  // reference :77
+  return GFICF_OK;
+}
+
+int gficf_jaccard_packed_words(int64_t N_total, int k) {
+  if (N_total < 0 || N_total > 0x7FFFFFFFll || k < 0 || k > GFICF_JACCARD_MAX_K) return -1;
+  return packed_words(N_total, k);
+}
+
+int gficf_jaccard_pack_rows_device(gficf_ctx* ctx, const int32_t* d_table_rows, int64_t n_rows, int k, int64_t N_total,
+                                   uint32_t* d_packed) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = check_nk(N_total, k);
+  if (rc) return rc;
+  if (n_rows < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative n_rows");
+  if (n_rows == 0 || k == 0) return GFICF_OK;
+  if (!d_table_rows || !d_packed) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  int64_t blocks = gficf_ceil_div(n_rows, PACK_ROWS);
+  if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(256), (size_t)PACK_ROWS * kpad_for(k) * sizeof(uint32_t), ctx->stream,
+                     (const uint32_t*)d_table_rows, n_rows, k, kpad_for(k), id_bits(N_total), packed_words(N_total, k), d_packed);
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
+}
+
+int gficf_jaccard_unpack_rows_device(gficf_ctx* ctx, const uint32_t* d_packed, int64_t n_rows, int k, int64_t N_total,
+                                     int32_t* d_table_rows) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = check_nk(N_total, k);
+  if (rc) return rc;
+  if (n_rows < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative n_rows");
+  if (n_rows == 0 || k == 0) return GFICF_OK;
+  if (!d_table_rows || !d_packed) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  const int wpr = packed_words(N_total, k);
+  int64_t blocks = gficf_ceil_div(n_rows, UNPACK_ROWS);
+  if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+  hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)blocks), dim3(256), (size_t)UNPACK_ROWS * wpr * sizeof(uint32_t), ctx->stream,
+                     d_packed, n_rows, k, kpad_for(k), id_bits(N_total), wpr, (uint32_t*)d_table_rows);
+  GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
 

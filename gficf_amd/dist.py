@@ -61,7 +61,7 @@ class JaccardShard:
     """
 
     def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False,
-                 pipeline: bool = False):
+                 pipeline: bool = False, packed_transport: bool = True):
         self.ops, self.N, self.k, self.group = ops, int(N_total), int(k), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -77,6 +77,11 @@ class JaccardShard:
         self.out = torch.zeros((3, self.n_local * self.k), dtype=torch.float64, device=device)
         self.u = torch.zeros(self.n_local * self.k, dtype=torch.int32, device=device) if with_u else None
         self.t = 0
+        # N > 1: rows travel bit-packed (ceil(log2(N+1)) bits per id) and are unpacked after the all-gather
+        self.packed = None
+        if self.world > 1 and packed_transport:
+            self.pw = ops.packed_words(self.N, self.k)
+            self.packed = torch.zeros((self.world * self.rpr, self.pw), dtype=torch.int32, device=device)
         if self.pipeline:
             self.side = torch.cuda.Stream(device=device)
             self.ev_table_ready = [torch.cuda.Event(), torch.cuda.Event()]
@@ -86,7 +91,19 @@ class JaccardShard:
         my_rows = table[self.rank * self.rpr:(self.rank + 1) * self.rpr]
         if self.n_local > 0:
             self.ops.jaccard_ingest(idx_local_cm, self.n_local, self.k, self.N, my_rows)
-        if self.world > 1:
+        if self.world > 1 and self.packed is not None:
+            mine = self.packed[self.rank * self.rpr:(self.rank + 1) * self.rpr]
+            if self.n_local > 0:
+                self.ops.jaccard_pack_rows(my_rows, self.n_local, self.k, self.N, mine)
+            _all_gather_rows(self.packed.view(-1), mine.reshape(-1), self.group)
+            # every other rank's block (the own block is already in place, unpacked)
+            for r in range(self.world):
+                if r != self.rank:
+                    b, e = shard_bounds(self.N, self.world, r)
+                    if e > b:
+                        self.ops.jaccard_unpack_rows(self.packed[r * self.rpr:r * self.rpr + (e - b)], e - b, self.k, self.N,
+                                                     table[r * self.rpr:r * self.rpr + (e - b)])
+        elif self.world > 1:
             _all_gather_rows(table.view(-1), my_rows.reshape(-1), self.group)
 
     def step(self, idx_local_cm):

@@ -96,6 +96,16 @@ int gficf_jaccard_ingest_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f6
                                 int64_t n_rows, int k, int64_t ld, int64_t N_total,
                                 int32_t* d_table_rows);
 
+/* Transport form of table rows for step 2 (the all-gather is what bounds the N > 1 path): k ids of
+ * ceil(log2(N_total+1)) bits each + the row's duplicate flag, bit-packed into
+ * gficf_jaccard_packed_words(N_total, k) 32-bit words per row (76 B instead of 128 B at k = 30,
+ * N_total = 800 k).  pack: table rows -> packed rows; unpack: the inverse (pads zeroed). */
+int gficf_jaccard_packed_words(int64_t N_total, int k);
+int gficf_jaccard_pack_rows_device(gficf_ctx* ctx, const int32_t* d_table_rows, int64_t n_rows, int k,
+                                   int64_t N_total, uint32_t* d_packed);
+int gficf_jaccard_unpack_rows_device(gficf_ctx* ctx, const uint32_t* d_packed, int64_t n_rows, int k,
+                                     int64_t N_total, int32_t* d_table_rows);
+
 /* d_table: the FULL N x kpad table.  Computes edges of cells [cell_begin, cell_end).
  * d_src/d_dst/d_w: three arrays of (cell_end-cell_begin)*k doubles — the block's slice of
  * the three columns of rmat (pass rmat + cell_begin*k, rmat + E + cell_begin*k,

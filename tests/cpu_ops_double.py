@@ -24,6 +24,39 @@ class CpuOpsDouble:
         table_rows[:n_rows, :k] = torch.from_numpy(np.ascontiguousarray(rows.astype(np.int32)))
         table_rows[:n_rows, k:] = 0
 
+    @staticmethod
+    def _bits(N):
+        b = 1
+        while b < 31 and (1 << b) <= N:
+            b += 1
+        return b
+
+    def packed_words(self, N_total, k):
+        return (k * self._bits(N_total) + 1 + 31) // 32
+
+    def jaccard_pack_rows(self, table_rows, n_rows, k, N_total, packed):
+        bits, out = self._bits(N_total), packed.numpy().view(np.uint32)
+        rows = table_rows.numpy().view(np.uint32)
+        for r in range(n_rows):
+            acc = 0
+            for j in range(k):
+                acc |= int(rows[r, j] & 0x7FFFFFFF) << (j * bits)
+            acc |= int(rows[r, 0] >> 31) << (k * bits)
+            for w in range(out.shape[1]):
+                out[r, w] = (acc >> (32 * w)) & 0xFFFFFFFF
+
+    def jaccard_unpack_rows(self, packed, n_rows, k, N_total, table_rows):
+        bits, src = self._bits(N_total), packed.numpy().view(np.uint32)
+        rows = table_rows.numpy().view(np.uint32)
+        for r in range(n_rows):
+            acc = 0
+            for w in range(src.shape[1]):
+                acc |= int(src[r, w]) << (32 * w)
+            rows[r, :] = 0
+            for j in range(k):
+                rows[r, j] = (acc >> (j * bits)) & ((1 << bits) - 1)
+            rows[r, 0] |= ((acc >> (k * bits)) & 1) << 31
+
     def jaccard_edges(self, table, N, k, cell_begin, cell_end, out3, u=None):
         mat = table.numpy()[:N, :k]
         rm, uu = oracle.jaccard(np.ascontiguousarray(mat), nthreads=2)

@@ -385,3 +385,34 @@ def test_config4_shape_100k_cells_k50_bit_exact(ops):
     rm, u = device_jaccard(ops, mat)
     want, wu = oracle.jaccard(mat, nthreads=os.cpu_count() or 8)
     assert np.array_equal(u, wu) and np.array_equal(rm, want)
+
+
+@pytest.mark.parametrize("N,k", [(5000, 30), (70000, 15), (3000, 50), (900, 100), (200000, 30)])
+def test_packed_transport_rows_roundtrip(ops, N, k):
+    """Transport form of table rows (bit-packed ids + duplicate flag): pack -> unpack is the identity,
+    and a table rebuilt block-wise from packed rows yields the same edges."""
+    import torch
+
+    mat = synth.knn_windowed(N, k, W=max(100, k), seed=13)
+    mat[7, 1] = mat[7, 0]                       # a row with duplicate ids: its flag must survive
+    mat[N - 1, :] = mat[N - 1, 0]
+    idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
+    kp, pw = ops.kpad(k), ops.packed_words(N, k)
+    bits = int(np.ceil(np.log2(N + 1)))
+    assert pw == (k * bits + 1 + 31) // 32 and pw * 4 <= kp * 4
+    table = torch.empty((N, kp), dtype=torch.int32, device="cuda")
+    ops.jaccard_ingest(idx, N, k, N, table)
+    packed = torch.empty((N, pw), dtype=torch.int32, device="cuda")
+    ops.jaccard_pack_rows(table, N, k, N, packed)
+    back = torch.full((N, kp), -1, dtype=torch.int32, device="cuda")
+    cut = N // 3
+    ops.jaccard_unpack_rows(packed[:cut], cut, k, N, back[:cut])
+    ops.jaccard_unpack_rows(packed[cut:], N - cut, k, N, back[cut:])
+    ops.sync()
+    assert torch.equal(back, table)
+    assert int(table[7, 0]) < 0 and int(table[N - 1, 0]) < 0      # duplicate flags set and preserved
+    if N <= 70000:
+        out = torch.empty((3, N * k), dtype=torch.float64, device="cuda")
+        ops.jaccard_edges(back, N, k, 0, N, out)
+        ops.sync()
+        assert np.array_equal(out.cpu().numpy().T, oracle.jaccard(mat, nthreads=8)[0])
