@@ -24,6 +24,11 @@ struct gficf_ctx {
   uint32_t* h_status = nullptr;   // pinned host mirror
   void* d_ws = nullptr;           // scan partials (fixed size, allocated at create)
   size_t ws_bytes = 0;
+  // Conditional re-execution (gficf_csc_device): kernels launched while cur_gate is set return at once
+  // unless *cur_gate != 0; the scaling pass raises *cur_zero when it meets an explicitly stored zero.
+  uint32_t* d_flags = nullptr;
+  const uint32_t* cur_gate = nullptr;
+  uint32_t* cur_zero = nullptr;
   gficf_host_plan* plan = nullptr;
   gficf_edge_plan* edge_plan = nullptr;
 };
@@ -58,6 +63,10 @@ void gficf_set_error(const char* fmt, ...);
     if (!(ctx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ctx is NULL");    \
     GFICF_HIP_CHECK(hipSetDevice((ctx)->device));                    \
   } while (0)
+
+// first statement of a gated kernel
+#define GFICF_GATE(gate) \
+  if ((gate) != nullptr && *(gate) == 0u) return
 
 __host__ __device__ static inline int64_t gficf_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

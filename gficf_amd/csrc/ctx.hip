@@ -50,6 +50,8 @@ int gficf_ctx_create(int device, void* stream, gficf_ctx** out) {
   if (e == hipSuccess) e = hipMemset(c->d_status, 0, sizeof(uint32_t));
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_status, sizeof(uint32_t), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(&c->d_ws, c->ws_bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, 4 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemset(c->d_flags, 0, 4 * sizeof(uint32_t));
   if (e != hipSuccess) {
     gficf_set_error("context allocation failed: %s", hipGetErrorString(e));
     gficf_ctx_destroy(c);
@@ -68,6 +70,7 @@ void gficf_ctx_destroy(gficf_ctx* ctx) {
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+  if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   delete ctx;
 }
 
@@ -131,7 +134,8 @@ __device__ inline int64_t block_exclusive_scan(int64_t v, int64_t* total) {
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const int64_t* __restrict__ d, int64_t n,
-                                                              int64_t* __restrict__ partial) {
+                                                              int64_t* __restrict__ partial, const uint32_t* gate) {
+  GFICF_GATE(gate);
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   int64_t s = 0;
 #pragma unroll
@@ -142,7 +146,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const int64_t* __r
   if (threadIdx.x == 0) partial[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_partials(int64_t* __restrict__ partial, int64_t nb) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_partials(int64_t* __restrict__ partial, int64_t nb, const uint32_t* gate) {
+  GFICF_GATE(gate);
   int64_t carry = 0;
   for (int64_t b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
     int64_t idx = b0 + threadIdx.x;
@@ -155,7 +160,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_partials(int64_t* __restr
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(int64_t* __restrict__ d, int64_t n,
-                                                             const int64_t* __restrict__ partial) {
+                                                             const int64_t* __restrict__ partial, const uint32_t* gate) {
+  GFICF_GATE(gate);
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   int64_t v[SCAN_ITEMS];
   int64_t s = 0;
@@ -181,9 +187,9 @@ int gficf_exclusive_scan_i64(gficf_ctx* ctx, int64_t* d_data, int64_t n) {
   if ((size_t)nb * sizeof(int64_t) > ctx->ws_bytes)
     GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "scan of %lld elements exceeds the workspace", (long long)n);
   int64_t* partial = (int64_t*)ctx->d_ws;
-  hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_data, n, partial);
-  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, partial, nb);
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_data, n, partial);
+  hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_data, n, partial, ctx->cur_gate);
+  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, partial, nb, ctx->cur_gate);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_data, n, partial, ctx->cur_gate);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }

@@ -280,3 +280,28 @@ def test_config4_shape_properties_device_resident():
         ref = v / torch.sqrt((v * v).sum())
         got = ox[int(ocp[c]):int(ocp[c + 1])]
         assert torch.allclose(got, ref, rtol=1e-10, atol=1e-14)
+
+
+@pytest.mark.parametrize("n_zero", [0, 1, 500])
+def test_device_path_with_explicit_zeros_redoes_exactly(n_zero):
+    """gficf_csc_device counts stored entries first (no x read) and re-runs with the exact count when
+    the scaling pass meets an explicitly stored zero: results must match R's rowSums(M != 0) rule."""
+    import torch
+
+    ops = gficf_amd.HipOps(0)
+    G, N = 4000, 2500
+    cp, ri, x = synth.counts_csc(G, N, seed=31)
+    x = x.copy()
+    if n_zero:
+        pos = (synth.rand_u64(5, np.arange(n_zero)) % np.uint64(len(x))).astype(np.int64)
+        x[pos] = 0.0
+    ref = oracle.gficf_csc(G, N, cp, ri, x, 0.05, 1.0)
+    d = lambda a: torch.from_numpy(a).cuda()
+    for rep in range(2):                        # twice: the flag is reset per call
+        ws = ops.gficf_csc(G, N, d(cp), d(ri), d(x), 0.05, 1.0)
+        ops.sync()
+        nk = int(ws["out_colptr"][N])
+        assert np.array_equal(ws["keep"].cpu().numpy().astype(bool), ref["keep"])
+        assert np.array_equal(ws["nt"].cpu().numpy()[ref["keep"]], ref["nt"][ref["keep"]])
+        assert nk == len(ref["x"]) and np.array_equal(ws["out_rowidx"][:nk].cpu().numpy(), ref["rowidx"])
+        assert np.allclose(ws["out_x"][:nk].cpu().numpy(), ref["x"], rtol=TOL, atol=TOL)
