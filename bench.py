@@ -206,6 +206,23 @@ def main():
                                              "faithful restatement of the RcppParallel worker (g++ -O2, dynamic chunks over std::thread)",
                                    "nt2_value": edges_per_step / t_nt2, "nt2_note": "clustcells() default nt = 2 (reference R/clustCells.R:46)",
                                    "gpu_over_cpu": value / cpu_v}
+        # stress row: uniformly random neighbour ids — u ~ 0, no overlap to exploit, same traffic
+        try:
+            umat = synth.knn_uniform(N_total, k)
+            uidx = torch.from_numpy(np.ascontiguousarray(umat.T)).to(dev)
+            ush = JaccardShard(ops, N_total, k, device=dev, pipeline=not args.no_pipeline)
+            for _ in range(3):
+                ush.step(uidx)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                ush.step(uidx)
+            torch.cuda.synchronize()
+            out["stress_uniform_ids"] = {"edges_per_sec": edges_per_step * 20 / (time.perf_counter() - t1),
+                                         "nonzero_edge_fraction": float((ush.out[2] > 0).double().mean().item())}
+            del ush, uidx, umat
+        except Exception as ex:  # pragma: no cover
+            out["stress_uniform_ids"] = {"error": str(ex)}
         # end-to-end through the host C ABI (what the R glue calls): H2D + ingest + edges + D2H of the
         # 24 B/edge reference matrix, device buffers allocated per call.  PCIe-inclusive: reported, never `value`.
         try:
