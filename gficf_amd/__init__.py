@@ -8,6 +8,7 @@ ABI of ``libgficf_hip.so`` (include/gficf_hip.h); there is no CPU fallback.
 from ._lib import GficfError, LIB_PATH  # noqa: F401
 from .api import (  # noqa: F401
     Context,
+    cluster_signatures,
     HipOps,
     default_context,
     device_count,

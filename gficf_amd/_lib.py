@@ -59,6 +59,8 @@ SIGNATURES = {
     "gficf_csc_genes_device": (_int, [_vp, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp]),
     "gficf_csc_colptr_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_csc_scale_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_cluster_signatures_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _vp]),
+    "gficf_cluster_signatures_host": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _vp, _int, _vp]),
     "gficf_csc_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
 }

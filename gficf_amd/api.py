@@ -219,6 +219,32 @@ def gficf_with_weights(M, w, ctx: Context | None = None):
     return out, np.flatnonzero(keep)
 
 
+def cluster_signatures(gficf_mat, cluster, ctx: Context | None = None):
+    """``data$cluster.gene.rnk`` of ``clustcells()`` (reference R/clustCells.R:121-123).
+
+    ``gficf_mat``: the GF-ICF matrix (genes x cells, scipy CSC); ``cluster``: one label per cell.
+    Returns (G x C float64 matrix whose column j is the gene-wise sum over the cells of the j-th label,
+    labels in order of first appearance — ``base::unique`` order —, and that label list).
+    """
+    M, colptr, rowidx, x = _csc_parts(gficf_mat)
+    G, N = M.shape
+    lab = np.asarray(cluster)
+    if lab.shape != (N,):
+        raise ValueError("cluster must hold one label per cell")
+    uniq, first, inv = np.unique(lab, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")                 # first-appearance order (R/clustCells.R:122)
+    rank = np.empty_like(order)
+    rank[order] = np.arange(len(order))
+    ids = np.ascontiguousarray(rank[inv], dtype=np.int32)
+    C = len(uniq)
+    out = np.zeros((C, G), dtype=np.float64)                  # C-order (C, G) == column-major G x C
+    ctx = ctx or default_context()
+    is64 = 1 if colptr.dtype == np.int64 else 0
+    check(_lib.load().gficf_cluster_signatures_host(ctx.handle, G, N, _np_ptr(colptr), is64, _np_ptr(rowidx), _np_ptr(x),
+                                                    _np_ptr(ids), C, _np_ptr(out)))
+    return out.T, uniq[order]
+
+
 # ----------------------------------------------------------- device-resident stage ops
 def genes_words(G: int) -> int:
     """float64 elements of the opaque per-gene table buffer (gficf_csc_genes_bytes)."""
@@ -332,6 +358,11 @@ class HipOps:
         check(self.L.gficf_csc_scale_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),
                                             int(rowidx.numel()), _tptr(genes), _tptr(gkept), _tptr(out_colptr),
                                             _tptr(out_rowidx), _tptr(out_x)))
+
+    def cluster_signatures(self, G, n_cells, colptr, rowidx, x, cluster, C, out):
+        """out: (C, G) float64 == column-major G x C; cluster: int32 ids in [0, C)."""
+        check(self.L.gficf_cluster_signatures_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),
+                                                     _tptr(cluster), int(C), _tptr(out)))
 
     def csc_workspace(self, G: int, n_cells: int, nnz: int) -> dict:
         """Pre-allocated outputs / scratch of the GF-ICF pipeline (keeps allocation out of timed loops)."""

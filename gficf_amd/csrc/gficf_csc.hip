@@ -586,6 +586,29 @@ __global__ __launch_bounds__(256) void k_zero_i64(int64_t* __restrict__ p, int64
   if (i < n) p[i] = 0;
 }
 
+// ------------------------------------------------------- cluster signatures (next row N3)
+// data$cluster.gene.rnk = sapply(unique(cluster), function(x) rowSums(gficf[, cluster %in% x]))
+// (reference R/clustCells.R:121-123): out[g, c] = sum over the cells of cluster c of gficf[g, cell].
+// One wave per cell; f64 atomic adds into the dense G x C result (column-major).  The order of the
+// additions is not fixed, so the last bits can differ from run to run (well inside 1e-6).
+__global__ __launch_bounds__(256) void k_cluster_signatures(int64_t G, int64_t n_cells, const int64_t* __restrict__ colptr,
+                                                            const int32_t* __restrict__ rowidx, const double* __restrict__ x,
+                                                            const int32_t* __restrict__ cluster, int32_t C,
+                                                            double* __restrict__ out, uint32_t* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t c = w0; c < n_cells; c += nw) {
+    const int32_t cl = cluster[c];
+    if (cl < 0 || cl >= C) { if (lane == 0) atomicOr(status, GFICF_ST_BAD_CSC); continue; }
+    double* const col = out + (int64_t)cl * G;
+    const int64_t p0 = colptr[c], p1 = colptr[c + 1];
+    for (int64_t p = p0 + lane; p < p1; p += 64) {
+      const int32_t g = rowidx[p];
+      if (g >= 0 && g < G) atomicAdd(col + g, x[p]);
+    }
+  }
+}
+
 }  // namespace
 
 // ----------------------------------------------------------------------------- C ABI
@@ -705,6 +728,61 @@ int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
                      ctx->cur_gate, ctx->cur_zero);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
+}
+
+int gficf_cluster_signatures_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
+                                    const int32_t* d_rowidx, const double* d_x, const int32_t* d_cluster, int32_t C,
+                                    double* d_out) {
+  GFICF_CTX_ENTER(ctx);
+  if (G < 0 || n_cells < 0 || C < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
+  if (G == 0 || C == 0) return GFICF_OK;
+  if (!d_out) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  GFICF_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)G * (size_t)C, ctx->stream));
+  if (n_cells == 0) return GFICF_OK;
+  if (!d_colptr || !d_rowidx || !d_x || !d_cluster) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  int64_t blocks = gficf_ceil_div(n_cells, 4);
+  if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+  hipLaunchKernelGGL(k_cluster_signatures, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, G, n_cells, d_colptr, d_rowidx,
+                     d_x, d_cluster, C, d_out, ctx->d_status);
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
+}
+
+int gficf_cluster_signatures_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* colptr, int colptr_is_i64,
+                                  const int32_t* rowidx, const double* x, const int32_t* cluster, int32_t C, double* out) {
+  GFICF_CTX_ENTER(ctx);
+  if (G < 0 || N < 0 || C < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
+  if (G == 0 || C == 0) return GFICF_OK;
+  if (!colptr || !out || (N > 0 && !cluster)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
+  std::vector<int64_t> cp((size_t)N + 1);
+  for (int64_t c = 0; c <= N; ++c)
+    cp[(size_t)c] = colptr_is_i64 ? ((const int64_t*)colptr)[c] : (int64_t)((const int32_t*)colptr)[c];
+  for (int64_t c = 0; c < N; ++c)
+    if (cp[(size_t)c + 1] < cp[(size_t)c] || cp[0] != 0) GFICF_FAIL(GFICF_ERR_BAD_CSC, "colptr not monotone at cell %lld", (long long)c);
+  const int64_t nnz = cp[(size_t)N];
+  if (nnz > 0 && (!rowidx || !x)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
+  int64_t* d_cp = nullptr; int32_t* d_ri = nullptr; double* d_x = nullptr; int32_t* d_cl = nullptr; double* d_out = nullptr;
+  const size_t nsz = (size_t)(nnz > 0 ? nnz : 1), csz = (size_t)(N > 0 ? N : 1);
+  hipError_t e = hipMalloc((void**)&d_cp, sizeof(int64_t) * ((size_t)N + 1));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_ri, sizeof(int32_t) * nsz);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_x, sizeof(double) * nsz);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_cl, sizeof(int32_t) * csz);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_out, sizeof(double) * (size_t)G * (size_t)C);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_cp, cp.data(), sizeof(int64_t) * cp.size(), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_ri, rowidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && N > 0) e = hipMemcpyAsync(d_cl, cluster, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, ctx->stream);
+  int rc = GFICF_OK;
+  if (e == hipSuccess) {
+    rc = gficf_cluster_signatures_device(ctx, G, N, d_cp, d_ri, d_x, d_cl, C, d_out);
+    if (!rc) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)G * (size_t)C, hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
+    else (void)hipStreamSynchronize(ctx->stream);
+  }
+  void* ptrs[] = {d_cp, d_ri, d_x, d_cl, d_out};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_cluster_signatures_host: %s", hipGetErrorString(e));
+  return rc;
 }
 
 size_t gficf_csc_genes_bytes(int64_t G) {

@@ -209,6 +209,18 @@ int gficf_csc_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colp
                      gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept, int64_t* d_out_colptr,
                      int32_t* d_out_rowidx, double* d_out_x);
 
+/* ------------------------------------------------------------------- cluster signatures
+ * "Next" row N3: data$cluster.gene.rnk of clustcells() (R/clustCells.R:121-123):
+ *   out[g, c] = sum over the cells of cluster c of gficf[g, cell]        (G x C doubles, column-major).
+ * cluster[cell] in [0, C): the caller numbers the labels in order of first appearance, as
+ * base::unique() does (R/clustCells.R:122).  f64 atomic adds: summation order is not fixed. */
+int gficf_cluster_signatures_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
+                                    const int32_t* d_rowidx, const double* d_x,
+                                    const int32_t* d_cluster, int32_t C, double* d_out);
+int gficf_cluster_signatures_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* colptr,
+                                  int colptr_is_i64, const int32_t* rowidx, const double* x,
+                                  const int32_t* cluster, int32_t C, double* out);
+
 #ifdef __cplusplus
 }
 #endif

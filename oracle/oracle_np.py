@@ -131,3 +131,14 @@ def gficf_np(M: sp.csc_matrix, prop_min: float = 0.05, prop_max: float = 1.0, w_
     w[keep] = wk
     return dict(keep=keep, nt=nt, w=w,
                 gficf=sp.csc_matrix((out, TF.indices, TF.indptr), shape=Mk.shape))
+
+
+# ---------------------------------------------------------------- cluster signatures
+def cluster_signatures_np(gficf_mat: sp.csc_matrix, cluster):
+    """R/clustCells.R:121-123: sapply(unique(cluster), function(x) rowSums(gficf[, cluster %in% x]))."""
+    lab = np.asarray(cluster)
+    _, first = np.unique(lab, return_index=True)
+    labels = lab[np.sort(first)]                       # base::unique keeps first-appearance order
+    M = sp.csc_matrix(gficf_mat)
+    cols = [np.asarray(M[:, np.flatnonzero(lab == u)].sum(axis=1)).ravel() for u in labels]
+    return np.stack(cols, axis=1) if cols else np.zeros((M.shape[0], 0)), labels

@@ -305,3 +305,20 @@ def test_device_path_with_explicit_zeros_redoes_exactly(n_zero):
         assert np.array_equal(ws["nt"].cpu().numpy()[ref["keep"]], ref["nt"][ref["keep"]])
         assert nk == len(ref["x"]) and np.array_equal(ws["out_rowidx"][:nk].cpu().numpy(), ref["rowidx"])
         assert np.allclose(ws["out_x"][:nk].cpu().numpy(), ref["x"], rtol=TOL, atol=TOL)
+
+
+def test_cluster_signatures_next_row_n3():
+    """N3: data$cluster.gene.rnk (R/clustCells.R:121-123) on the GF-ICF matrix; labels in first-appearance order."""
+    from oracle import oracle_np
+
+    G, N = 3000, 2000
+    cp, ri, x = synth.counts_csc(G, N, seed=41)
+    res = gficf_amd.gficf(sp.csc_matrix((x, ri, cp), shape=(G, N)), normalize=False, verbose=False)
+    lab = np.array([f"c{v}" for v in (synth.rand_u64(3, np.arange(N)) % np.uint64(7)).astype(int)])
+    got, labels = gficf_amd.cluster_signatures(res["gficf"], lab)
+    want, wl = oracle_np.cluster_signatures_np(res["gficf"], lab)
+    assert list(labels) == list(wl) and got.shape == want.shape == (res["gficf"].shape[0], 7)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-6) and np.abs(got - want).max() < 1e-10
+    # an empty matrix / a single cluster
+    got1, l1 = gficf_amd.cluster_signatures(res["gficf"], np.zeros(N, dtype=int))
+    assert got1.shape[1] == 1 and np.allclose(got1[:, 0], np.asarray(res["gficf"].sum(axis=1)).ravel(), rtol=1e-10)
