@@ -169,8 +169,9 @@ def main():
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": f"north-star point: {args.cells_per_gpu} cells x k={k} per GPU, windowed kNN (W=100) with permuted ids; "
                                f"N_total={N_total}; step = ingest + {'RCCL all-gather + ' if world > 1 else ''}edge kernel, device-resident"
-                               + ("" if args.no_pipeline else "; steps software-pipelined over two tables (ingest"
-                                  + ("/all-gather" if world > 1 else "") + " of step s+1 on a second stream under the edge kernel of step s)"),
+                               + ("" if args.no_pipeline else "; steps software-pipelined over two tables and two output buffers (ingest"
+                                  + ("/pack/all-gather/unpack" if world > 1 else "") + " of step s+1 on a side stream under the edge kernel of step s; "
+                                  "edge kernels of consecutive steps on alternating streams)"),
                    "cells_total": N_total, "k": k, "edges_per_step": edges_per_step,
                    "partition": f"cell blocks x{world}" + (", 1 all-gather of int32 table rows" if world > 1 else "")},
         "roofline": roofline,

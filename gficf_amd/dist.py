@@ -53,11 +53,14 @@ def _all_gather_rows(table, local_view, group):
 class JaccardShard:
     """Per-rank state of the sharded Jaccard build (buffers allocated once, reused per step).
 
-    ``pipeline=True`` (GPU only): steps are software-pipelined over two tables — the ingest (and,
-    for N > 1, the all-gather) of a step runs on a second stream, so it overlaps the edge kernel of
-    the step before it, which still reads the other table.  Every step does the same work and
-    yields the same bits; only the stream placement changes.  The input block handed to
-    :meth:`step` must already be valid on the device when the call is made.
+    ``pipeline=True`` (GPU only): steps are software-pipelined over two tables and two output
+    buffers.  The ingest (and, for N > 1, pack + all-gather + unpack) of a step runs on a side stream,
+    so it overlaps the edge kernel of the step before it, which still reads the other table; the edge
+    kernels of consecutive steps run on two alternating streams, so the tail of one overlaps the ramp
+    of the next.  Every step does the same work and yields the same bits; only stream placement
+    changes.  Contract in this mode: the input block handed to :meth:`step` must already be valid on
+    the device; the returned buffer is one of two and is overwritten by the step after next; call
+    :meth:`wait` to make the caller's current stream wait for the latest step before reading it.
     """
 
     def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False,
@@ -70,12 +73,12 @@ class JaccardShard:
         self.b, self.e = shard_bounds(self.N, self.world, self.rank)
         self.n_local = self.e - self.b
         self.pipeline = bool(pipeline) and device is not None and torch.device(device).type == "cuda"
+        nbuf = 2 if self.pipeline else 1
         # full table(s), padded to world*rpr rows so that every rank contributes an equal block
-        self.tables = [torch.zeros((self.world * self.rpr, self.kpad), dtype=torch.int32, device=device)
-                       for _ in range(2 if self.pipeline else 1)]
-        self.table = self.tables[0]
-        self.out = torch.zeros((3, self.n_local * self.k), dtype=torch.float64, device=device)
-        self.u = torch.zeros(self.n_local * self.k, dtype=torch.int32, device=device) if with_u else None
+        self.tables = [torch.zeros((self.world * self.rpr, self.kpad), dtype=torch.int32, device=device) for _ in range(nbuf)]
+        self.outs = [torch.zeros((3, self.n_local * self.k), dtype=torch.float64, device=device) for _ in range(nbuf)]
+        self.us = [torch.zeros(self.n_local * self.k, dtype=torch.int32, device=device) if with_u else None for _ in range(nbuf)]
+        self.table, self.out, self.u = self.tables[0], self.outs[0], self.us[0]
         self.t = 0
         # N > 1: rows travel bit-packed (ceil(log2(N+1)) bits per id) and are unpacked after the all-gather
         self.packed = None
@@ -84,8 +87,10 @@ class JaccardShard:
             self.packed = torch.zeros((self.world * self.rpr, self.pw), dtype=torch.int32, device=device)
         if self.pipeline:
             self.side = torch.cuda.Stream(device=device)
+            self.edge_streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
             self.ev_table_ready = [torch.cuda.Event(), torch.cuda.Event()]
-            self.ev_table_free = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_edges_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.last_done = None
 
     def _fill_table(self, table, idx_local_cm):
         my_rows = table[self.rank * self.rpr:(self.rank + 1) * self.rpr]
@@ -117,24 +122,33 @@ class JaccardShard:
             return self.out
         p = self.t & 1
         table = self.tables[p]
-        main = torch.cuda.current_stream(table.device)
         if self.t >= 2:
-            self.side.wait_event(self.ev_table_free[p])      # edges of step t-2 have finished reading it
+            self.side.wait_event(self.ev_edges_done[p])      # edges of step t-2 have finished reading this table
         with torch.cuda.stream(self.side):
             self._fill_table(table, idx_local_cm)
             self.ev_table_ready[p].record(self.side)
-        main.wait_event(self.ev_table_ready[p])
-        if self.n_local > 0:
-            self.ops.jaccard_edges(table, self.N, self.k, self.b, self.e, self.out, self.u)
-        self.ev_table_free[p].record(main)
-        self.table = table
+        es = self.edge_streams[p]                            # in order behind step t-2, which wrote the same buffers
+        es.wait_event(self.ev_table_ready[p])
+        with torch.cuda.stream(es):
+            if self.n_local > 0:
+                self.ops.jaccard_edges(table, self.N, self.k, self.b, self.e, self.outs[p], self.us[p])
+            self.ev_edges_done[p].record(es)
+        self.table, self.out, self.u = table, self.outs[p], self.us[p]
+        self.last_done = self.ev_edges_done[p]
         self.t += 1
         return self.out
 
+    def wait(self):
+        """Make the caller's current stream wait for the latest step (pipelined mode; no-op otherwise)."""
+        if self.pipeline and self.last_done is not None:
+            torch.cuda.current_stream(self.out.device).wait_event(self.last_done)
+
     def sync(self):
-        """Wait for both streams and surface deferred input-validation errors."""
+        """Wait for all streams and surface deferred input-validation errors."""
         if self.pipeline:
             self.side.synchronize()
+            for es in self.edge_streams:
+                es.synchronize()
         self.ops.sync()
 
 

@@ -277,7 +277,8 @@ def test_pipelined_steps_give_the_same_bits(ops):
     for rep in range(3):
         for i in range(3):
             out = sh.step(idx[i])
-            got.append((i, out.clone()))          # clone is stream-ordered after the edge kernel
+            sh.wait()                             # current stream waits for this step's edge kernel
+            got.append((i, out.clone()))
     sh.sync()
     torch.cuda.synchronize()
     for i, g in got:
