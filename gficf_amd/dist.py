@@ -64,8 +64,10 @@ class JaccardShard:
     """
 
     def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False,
-                 pipeline: bool = False, packed_transport: bool = True):
+                 pipeline: bool = False, packed_transport: bool = True, time_edges: bool = False):
         self.ops, self.N, self.k, self.group = ops, int(N_total), int(k), group
+        self.time_edges = bool(time_edges)      # HIP events around every edge-kernel launch, on its launch stream
+        self.edge_events = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.kpad = ops.kpad(k)
@@ -117,8 +119,14 @@ class JaccardShard:
         stream order on the caller's current stream)."""
         if not self.pipeline:
             self._fill_table(self.table, idx_local_cm)
+            if self.time_edges:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             if self.n_local > 0:
                 self.ops.jaccard_edges(self.table, self.N, self.k, self.b, self.e, self.out, self.u)
+            if self.time_edges:
+                e1.record()
+                self.edge_events.append((e0, e1))
             return self.out
         p = self.t & 1
         table = self.tables[p]
@@ -130,13 +138,24 @@ class JaccardShard:
         es = self.edge_streams[p]                            # in order behind step t-2, which wrote the same buffers
         es.wait_event(self.ev_table_ready[p])
         with torch.cuda.stream(es):
+            if self.time_edges:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(es)
             if self.n_local > 0:
                 self.ops.jaccard_edges(table, self.N, self.k, self.b, self.e, self.outs[p], self.us[p])
+            if self.time_edges:
+                e1.record(es)
+                self.edge_events.append((e0, e1))
             self.ev_edges_done[p].record(es)
         self.table, self.out, self.u = table, self.outs[p], self.us[p]
         self.last_done = self.ev_edges_done[p]
         self.t += 1
         return self.out
+
+    def edge_kernel_ms(self, last: int | None = None) -> float:
+        """Mean duration of the (last ``last``) timed edge-kernel launches; call after a device sync."""
+        ev = self.edge_events if last is None else self.edge_events[-last:]
+        return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
 
     def wait(self):
         """Make the caller's current stream wait for the latest step (pipelined mode; no-op otherwise)."""
