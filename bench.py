@@ -254,7 +254,7 @@ def main():
                 rc = call()
             th = (time.perf_counter() - t1) / 3
             out["host_abi"] = {"edges_per_sec": edges_per_step / th, "ms_per_call": th * 1e3, "rc": rc,
-                               "note": "gficf_jaccard_host: pageable host buffers, hipMalloc/hipFree per call, PCIe both ways"}
+                               "note": "gficf_jaccard_host: pageable host buffers, device scratch from the context pool, PCIe both ways"}
         except Exception as ex:  # pragma: no cover
             out["host_abi"] = {"error": str(ex)}
         if not args.no_gficf:

@@ -31,7 +31,13 @@ struct gficf_ctx {
   uint32_t* cur_zero = nullptr;
   gficf_host_plan* plan = nullptr;
   gficf_edge_plan* edge_plan = nullptr;
+  // grow-only device scratch of the host entry points (kept between calls, released at destroy)
+  void* pool[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t pool_bytes[4] = {0, 0, 0, 0};
 };
+
+// Device scratch slot of at least `bytes` bytes (reallocated only when it has to grow).
+hipError_t gficf_pool_get(gficf_ctx* ctx, int slot, size_t bytes, void** out);
 
 // releases the host-form GF-ICF plan held by the context, if any (gficf_csc.hip)
 void gficf_host_plan_free(gficf_ctx* ctx);

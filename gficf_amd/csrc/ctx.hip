@@ -12,6 +12,22 @@ void gficf_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+hipError_t gficf_pool_get(gficf_ctx* ctx, int slot, size_t bytes, void** out) {
+  if (bytes > ctx->pool_bytes[slot]) {
+    if (ctx->pool[slot]) {
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipFree(ctx->pool[slot]);
+      ctx->pool[slot] = nullptr;
+      ctx->pool_bytes[slot] = 0;
+    }
+    hipError_t e = hipMalloc(&ctx->pool[slot], bytes);
+    if (e != hipSuccess) return e;
+    ctx->pool_bytes[slot] = bytes;
+  }
+  *out = ctx->pool[slot];
+  return hipSuccess;
+}
+
 extern "C" {
 
 int gficf_hip_abi_version(void) { return GFICF_HIP_ABI_VERSION; }
@@ -71,6 +87,8 @@ void gficf_ctx_destroy(gficf_ctx* ctx) {
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->d_ws) (void)hipFree(ctx->d_ws);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+  for (void* q : ctx->pool)
+    if (q) (void)hipFree(q);
   delete ctx;
 }
 

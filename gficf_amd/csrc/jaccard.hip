@@ -694,9 +694,10 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
     void* d_idx = nullptr;
     int32_t* d_table = nullptr;
     double* d_rmat = nullptr;
-    hipError_t e = hipMalloc(&d_idx, esz * (size_t)ld * (size_t)k);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_table, sizeof(int32_t) * (size_t)N * (size_t)kpad);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_rmat, sizeof(double) * 3 * (size_t)E);
+    // device scratch comes from the context's grow-only pool: no hipMalloc/hipFree per call
+    hipError_t e = gficf_pool_get(ctx, 0, esz * (size_t)ld * (size_t)k, &d_idx);
+    if (e == hipSuccess) e = gficf_pool_get(ctx, 1, sizeof(int32_t) * (size_t)N * (size_t)kpad, (void**)&d_table);
+    if (e == hipSuccess) e = gficf_pool_get(ctx, 2, sizeof(double) * 3 * (size_t)E, (void**)&d_rmat);
     if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, esz * (size_t)ld * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
     rc = GFICF_OK;
     if (e == hipSuccess) {
@@ -705,9 +706,6 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
       if (rc == GFICF_OK && e == hipSuccess) rc = gficf_ctx_sync(ctx);
       else (void)hipStreamSynchronize(ctx->stream);
     }
-    if (d_idx) (void)hipFree(d_idx);
-    if (d_table) (void)hipFree(d_table);
-    if (d_rmat) (void)hipFree(d_rmat);
     if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_jaccard_host: %s", hipGetErrorString(e));
     if (rc) return rc;
   }
