@@ -597,10 +597,11 @@ int launch_edges_t(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
   if (blocks_per_cu == 0) {
     int nb = 0;
     GFICF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_jaccard_edges<KPAD, BIG>, C::WAVES * 64, 0));
-    // 4 workgroups per CU already saturate the L2-miss path that bounds this kernel (measured: 3..16
-    // per CU run at the same speed); not taking every wave slot leaves room for the next batch's
-    // ingest / all-gather kernels to run underneath on a second stream
-    blocks_per_cu = nb > 4 ? 4 : nb > 0 ? nb : 1;
+    // 3 workgroups per CU already saturate the L2-miss path that bounds this kernel (measured: 3..16
+    // per CU run at the same speed, 2 is 20 % slower); not taking every wave slot leaves room for the
+    // neighbouring step's edge kernel and the next batch's ingest / all-gather kernels, which the
+    // pipelined caller runs concurrently on other streams (measured best there: 3)
+    blocks_per_cu = nb > 3 ? 3 : nb > 0 ? nb : 1;
     if (const char* e = getenv("GFICF_JACCARD_BLOCKS_PER_CU")) {   // tuning knob
       const int v = atoi(e);
       if (v > 0) blocks_per_cu = v;

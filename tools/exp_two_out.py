@@ -9,21 +9,22 @@ ops = gficf_amd.HipOps(0)
 mat = synth.knn_windowed(N, k)
 idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
 kp = ops.kpad(k)
-tables = [torch.zeros((N, kp), dtype=torch.int32, device="cuda") for _ in range(2)]
-outs = [torch.zeros((3, N * k), dtype=torch.float64, device="cuda") for _ in range(2)]
-side = torch.cuda.Stream(); mains = [torch.cuda.Stream(), torch.cuda.Stream()]
-ready = [torch.cuda.Event(), torch.cuda.Event()]; free = [torch.cuda.Event(), torch.cuda.Event()]
-def run(K, two_main):
+NB = 3
+tables = [torch.zeros((N, kp), dtype=torch.int32, device="cuda") for _ in range(NB)]
+outs = [torch.zeros((3, N * k), dtype=torch.float64, device="cuda") for _ in range(NB)]
+side = torch.cuda.Stream(); mains = [torch.cuda.Stream() for _ in range(NB)]
+ready = [torch.cuda.Event() for _ in range(NB)]; free = [torch.cuda.Event() for _ in range(NB)]
+def run(K, nm):
     for t in range(K):
-        p = t & 1
-        if t >= 2: side.wait_event(free[p])
+        p = t % nm
+        if t >= nm: side.wait_event(free[p])
         with torch.cuda.stream(side):
             ops.jaccard_ingest(idx, N, k, N, tables[p]); ready[p].record(side)
-        m = mains[p] if two_main else mains[0]
+        m = mains[p]
         m.wait_event(ready[p])
         with torch.cuda.stream(m):
-            ops.jaccard_edges(tables[p], N, k, 0, N, outs[p] if two_main else outs[0]); free[p].record(m)
-for two in (False, True, False, True):
-    run(10, two); torch.cuda.synchronize()
-    t0 = time.perf_counter(); run(200, two); torch.cuda.synchronize()
-    print("two_main=%s: %.2f us/step" % (two, (time.perf_counter() - t0) / 200 * 1e6))
+            ops.jaccard_edges(tables[p], N, k, 0, N, outs[p]); free[p].record(m)
+for nm in (1, 2, 3, 2, 3):
+    run(12, nm); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(300, nm); torch.cuda.synchronize()
+    print("streams=%d: %.2f us/step" % (nm, (time.perf_counter() - t0) / 300 * 1e6))
