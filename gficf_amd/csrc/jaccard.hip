@@ -158,12 +158,33 @@ struct JCfg {
   static constexpr int LOG2NB = KPAD == 16 ? 7 : KPAD == 32 ? 8 : KPAD == 64 ? 9 : KPAD == 128 ? 10 : 11;
 };
 
-// Bucket of an id.  BIG == false: ids < 2^24 (full-rate 24-bit multiply).
+// Byte offset of an id's bucket inside a wave's hash set: bits [3, 3+LOG2NB) of id*K, i.e. a
+// multiplicative hash of the id's low 3+LOG2NB bits.  BIG == false: ids < 2^24, full-rate 24-bit
+// multiply (bound to the intrinsic by name: written as a plain product the masked multiply is
+// canonicalised to the quarter-rate v_mul_lo_u32).
+extern "C" __device__ uint32_t gficf_mul_u24(uint32_t a, uint32_t b) __asm("llvm.amdgcn.mul.u24.i32");
+
 template <int KPAD, bool BIG>
-__device__ inline uint32_t bucket_of(uint32_t id) {
-  if (BIG) return (id * 0x9E3779B1u) >> (32 - JCfg<KPAD>::LOG2NB);
-  // (HIP declares __umul24 as returning int: cast before the shift, or it is arithmetic)
-  return (uint32_t)__umul24(id, 0x9E3779u) >> (32 - JCfg<KPAD>::LOG2NB);
+__device__ inline uint32_t bucket_off(uint32_t id) {
+  constexpr uint32_t HMASK = (uint32_t)(JCfg<KPAD>::NB - 1) << 3;
+  return (BIG ? id * 0x9E3779B1u : gficf_mul_u24(id, 0x9E3779u)) & HMASK;
+}
+
+// LDS accessed at an integer byte address (base | offset folds into one v_and_or_b32 per probe).
+typedef uint32_t gficf_v2u __attribute__((ext_vector_type(2)));
+__device__ inline uint32_t lds_address(const void* p) {
+  return (uint32_t)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+__device__ inline uint2 lds_read_b64(uint32_t addr) {
+  const gficf_v2u v = *(__attribute__((address_space(3))) const gficf_v2u*)(size_t)addr;
+  return make_uint2(v.x, v.y);
+}
+
+// c + (this lane's bit of the 64-bit lane mask m): one v_addc with the mask as carry-in.
+__device__ inline int add_lane_bit(int c, unsigned long long m) {
+  int r;
+  asm("v_addc_co_u32_e64 %0, vcc, %1, 0, %2" : "=v"(r) : "v"(c), "s"(m) : "vcc");
+  return r;
 }
 
 // v_writelane_b32: drop a wave-uniform value into one lane of a VGPR (clang exposes no
@@ -259,17 +280,23 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
   using C = JCfg<KPAD>;
   using off_t = typename std::conditional<BIG, uint64_t, uint32_t>::type;
-  __shared__ uint2 s_hash[C::WAVES][C::NB];
-  __shared__ uint32_t s_rows[C::WAVES][2][KPAD];     // overflow list [0]; slow path rows [0],[1]
-  __shared__ double s_lut[GFICF_JACCARD_MAX_K + 1];
+  // LDS (dynamic, laid out here so that a wave's hash set starts at a multiple of its size and a probe
+  // address is (hash & mask) | wave_base):  hash sets | overflow list / slow-path rows | weight table
+  extern __shared__ unsigned char smem[];
+  constexpr uint32_t HBYTES = C::NB * 8;                      // bytes of one wave's hash set
+  uint32_t(*const s_rows)[2][KPAD] = reinterpret_cast<uint32_t(*)[2][KPAD]>(smem + C::WAVES * HBYTES);
+  double* const s_lut = reinterpret_cast<double*>(smem + C::WAVES * HBYTES + C::WAVES * 2 * KPAD * 4);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned char* const hbase = smem + wave * HBYTES;          // this wave's hash set
   // W[u] = u / (2.0*k - u): same IEEE-754 double division as reference :51
   for (int u = tid; u <= k; u += C::WAVES * 64) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);
-  for (int b = lane; b < C::NB; b += 64) s_hash[wave][b] = make_uint2(EMPTY, EMPTY);
+  for (int b = lane; b < C::NB; b += 64) reinterpret_cast<uint2*>(hbase)[b] = make_uint2(EMPTY, EMPTY);
   __syncthreads();
 
-  uint32_t* const hslots = reinterpret_cast<uint32_t*>(&s_hash[wave][0]);
+  // LDS byte address of this wave's hash set (a multiple of HBYTES: dynamic LDS starts at 0 here,
+  // there is no static LDS in this kernel), OR-ed with a bucket offset per probe
+  const uint32_t wave_off = lds_address(smem) + (uint32_t)wave * HBYTES;
   uint32_t* const ovlist = s_rows[wave][0];
   const char* const tbytes = reinterpret_cast<const char*>(table);
   const bool arow_lane = KPAD >= 64 || lane < KPAD;         // lanes that hold an id of row i
@@ -320,13 +347,13 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
       for (int q = 0; q < C::EPL; ++q) {
         bool over = false;
         if (a[q] != 0) {
-          const uint32_t bk = bucket_of<KPAD, BIG>(a[q]);
-          uint32_t old = atomicCAS(&hslots[2 * bk], EMPTY, a[q]);
+          const uint32_t bo = bucket_off<KPAD, BIG>(a[q]) + (uint32_t)wave * HBYTES;   // byte offset of the bucket in smem
+          uint32_t old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo), EMPTY, a[q]);
           if (old == EMPTY) {
-            myslot[q] = 2 * bk;
+            myslot[q] = (int)bo;
           } else {
-            old = atomicCAS(&hslots[2 * bk + 1], EMPTY, a[q]);
-            if (old == EMPTY) myslot[q] = 2 * bk + 1;
+            old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo + 4), EMPTY, a[q]);
+            if (old == EMPTY) myslot[q] = (int)bo + 4;
             else over = true;
           }
         }
@@ -376,15 +403,15 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
           for (int uu = 0; uu < C::U; ++uu) {
             dupflags |= bv[uu].x;
             bv[uu].x &= ID_MASK;             // only a row's first id can carry the duplicate flag
-            const uint2 h0 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].x)];
-            const uint2 h1 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].y)];
-            const uint2 h2 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].z)];
-            const uint2 h3 = s_hash[wave][bucket_of<KPAD, BIG>(bv[uu].w)];
+            const uint2 h0 = lds_read_b64(bucket_off<KPAD, BIG>(bv[uu].x) | wave_off);
+            const uint2 h1 = lds_read_b64(bucket_off<KPAD, BIG>(bv[uu].y) | wave_off);
+            const uint2 h2 = lds_read_b64(bucket_off<KPAD, BIG>(bv[uu].z) | wave_off);
+            const uint2 h3 = lds_read_b64(bucket_off<KPAD, BIG>(bv[uu].w) | wave_off);
             int c = 0;
-            c += (h0.x == bv[uu].x) | (h0.y == bv[uu].x);
-            c += (h1.x == bv[uu].y) | (h1.y == bv[uu].y);
-            c += (h2.x == bv[uu].z) | (h2.y == bv[uu].z);
-            c += (h3.x == bv[uu].w) | (h3.y == bv[uu].w);
+            c = add_lane_bit(c, __ballot(h0.x == bv[uu].x) | __ballot(h0.y == bv[uu].x));
+            c = add_lane_bit(c, __ballot(h1.x == bv[uu].y) | __ballot(h1.y == bv[uu].y));
+            c = add_lane_bit(c, __ballot(h2.x == bv[uu].z) | __ballot(h2.y == bv[uu].z));
+            c = add_lane_bit(c, __ballot(h3.x == bv[uu].w) | __ballot(h3.y == bv[uu].w));
             cnt[uu] = c;
           }
           if (nov) {                          // wave-uniform, rare: ids that overflowed the set
@@ -419,7 +446,7 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
     // ---- clear this cell's keys from the set
 #pragma unroll
     for (int q = 0; q < C::EPL; ++q)
-      if (myslot[q] >= 0) hslots[myslot[q]] = EMPTY;
+      if (myslot[q] >= 0) *reinterpret_cast<uint32_t*>(smem + myslot[q]) = EMPTY;
     wave_lds_fence();
     if (slow) {
       slow_cell<KPAD>(table, i, k, (i - cell_begin) * (int64_t)k, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w,
@@ -589,6 +616,12 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
   return GFICF_OK;
 }
 
+template <int KPAD>
+constexpr size_t edges_lds_bytes() {
+  using C = JCfg<KPAD>;
+  return (size_t)C::WAVES * C::NB * 8 + (size_t)C::WAVES * 2 * KPAD * 4 + (GFICF_JACCARD_MAX_K + 1) * sizeof(double);
+}
+
 template <int KPAD, bool BIG>
 int launch_edges_t(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
   using C = JCfg<KPAD>;
@@ -596,7 +629,7 @@ int launch_edges_t(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
   static int blocks_per_cu = 0;
   if (blocks_per_cu == 0) {
     int nb = 0;
-    GFICF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_jaccard_edges<KPAD, BIG>, C::WAVES * 64, 0));
+    GFICF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_jaccard_edges<KPAD, BIG>, C::WAVES * 64, edges_lds_bytes<KPAD>()));
     // 3 workgroups per CU already saturate the L2-miss path that bounds this kernel (measured: 3..16
     // per CU run at the same speed, 2 is 20 % slower); not taking every wave slot leaves room for the
     // neighbouring step's edge kernel and the next batch's ingest / all-gather kernels, which the
@@ -610,7 +643,8 @@ int launch_edges_t(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
   const int64_t blocks_needed = gficf_ceil_div(ce - cb, C::WAVES);
   const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
   const unsigned grid = (unsigned)(blocks_needed < cap ? blocks_needed : cap);
-  hipLaunchKernelGGL((k_jaccard_edges<KPAD, BIG>), dim3(grid), dim3(C::WAVES * 64), 0, ctx->stream, table, N, k, cb, ce, o);
+  hipLaunchKernelGGL((k_jaccard_edges<KPAD, BIG>), dim3(grid), dim3(C::WAVES * 64), edges_lds_bytes<KPAD>(), ctx->stream, table,
+                     N, k, cb, ce, o);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
