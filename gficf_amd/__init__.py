@@ -2,13 +2,15 @@
 
 Drop-in for one hot path of the dibbelab/gficf R package: ``gficf()`` (sparse GF / ICF /
 L2 scaling of a CSC genes x cells matrix) and the Jaccard step of ``clustcells()``
-(``rcpp_parallel_jaccard_coef``).  All compute runs in hand-written HIP kernels behind the C
+(``rcpp_parallel_jaccard_coef``), plus the exact neighbour search in front of it (``find_nn``).  All compute runs in hand-written HIP kernels behind the C
 ABI of ``libgficf_hip.so`` (include/gficf_hip.h); there is no CPU fallback.
 """
 from ._lib import GficfError, LIB_PATH  # noqa: F401
 from .api import (  # noqa: F401
     Context,
     cluster_signatures,
+    clustcells_graph,
+    find_nn,
     HipOps,
     default_context,
     device_count,

@@ -18,6 +18,8 @@ STATUS_NAMES = {
     4: "GFICF_ERR_NO_DEVICE", 5: "GFICF_ERR_HIP", 6: "GFICF_ERR_UNSUPPORTED", 7: "GFICF_ERR_CAPACITY",
 }
 JACCARD_MAX_K = 256
+KNN_MAX_K = 128
+KNN_METRICS = {"manhattan": 0, "euclidean": 1, "cosine": 2}
 
 
 class GficfError(RuntimeError):
@@ -61,6 +63,11 @@ SIGNATURES = {
     "gficf_csc_scale_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_cluster_signatures_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _vp]),
     "gficf_cluster_signatures_host": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _vp, _int, _vp]),
+    "gficf_knn_dpad": (_int, [_int]),
+    "gficf_knn_prepare_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _int, _vp]),
+    "gficf_knn_workspace_bytes": (ctypes.c_size_t, [_vp, _i64, _i64, _int]),
+    "gficf_knn_search_device": (_int, [_vp, _vp, _i64, _int, _int, _int, _i64, _i64, _vp, ctypes.c_size_t, _vp, _vp, _i64]),
+    "gficf_knn_host": (_int, [_vp, _vp, _i64, _int, _i64, _int, _int, _vp, _vp]),
     "gficf_csc_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
 }

@@ -245,6 +245,48 @@ def cluster_signatures(gficf_mat, cluster, ctx: Context | None = None):
     return out.T, uniq[order]
 
 
+# ------------------------------------------------------------------ kNN, reference-shaped
+def find_nn(X, k: int, include_self: bool = True, metric: str = "manhattan", ctx: Context | None = None) -> dict:
+    """The neighbour search in front of the Jaccard build, shaped like the reference's call
+    ``uwot:::find_nn(X, k, include_self = T, method = "annoy", metric = dist.method)``
+    (reference R/clustCells.R:57,60) — but EXACT: all N distances per row in f32, the ``k`` smallest
+    (distance, index) pairs, ties broken by the smaller index.
+
+    ``X``: N x d matrix (cells x PCA components).  Returns ``{"idx": N x k int32 (1-based), "dist":
+    N x k float64}``; with ``include_self`` column 0 is the row itself (or an identical point with a
+    smaller index); without it the row's own id is removed from every list (k+1 are searched).
+    """
+    if metric not in _lib.KNN_METRICS:
+        raise ValueError(f"metric must be one of {sorted(_lib.KNN_METRICS)}")
+    X = np.asfortranarray(X, dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError("X must be a 2-d matrix")
+    N, d = X.shape
+    kk = int(k) if include_self else int(k) + 1
+    idx = np.zeros((kk, N), dtype=np.int32)          # C-order (kk, N) == column-major N x kk
+    dist = np.zeros((kk, N), dtype=np.float64)
+    ctx = ctx or default_context()
+    check(_lib.load().gficf_knn_host(ctx.handle, _np_ptr(X), N, d, max(N, 1), kk, _lib.KNN_METRICS[metric],
+                                     _np_ptr(idx), _np_ptr(dist)))
+    idx, dist = idx.T, dist.T
+    if not include_self:
+        own = np.arange(1, N + 1, dtype=np.int32)[:, None]
+        is_self = idx == own
+        drop = np.where(is_self.any(axis=1), is_self.argmax(axis=1), kk - 1)   # self absent (duplicates): drop the last
+        keep = np.ones_like(idx, dtype=bool)
+        keep[np.arange(N), drop] = False
+        idx, dist = idx[keep].reshape(N, kk - 1), dist[keep].reshape(N, kk - 1)
+    return {"idx": np.ascontiguousarray(idx), "dist": np.ascontiguousarray(dist)}
+
+
+def clustcells_graph(X, k: int = 15, dist_method: str = "manhattan", verbose: bool = False, ctx: Context | None = None) -> dict:
+    """The graph-building lines of ``clustcells()`` (reference R/clustCells.R:57-68) as one call:
+    ``neigh = find_nn(X, k+1, include_self=T)$idx; neigh[,-1]; rcpp_parallel_jaccard_coef;
+    relations[relations[,3] > 0, ]``.  Returns the ``from`` / ``to`` / ``weight`` columns."""
+    neigh = find_nn(X, k + 1, True, dist_method, ctx)["idx"]
+    return jaccard_edges(neigh, verbose, ctx)
+
+
 # ----------------------------------------------------------- device-resident stage ops
 def genes_words(G: int) -> int:
     """float64 elements of the opaque per-gene table buffer (gficf_csc_genes_bytes)."""
@@ -339,6 +381,35 @@ class HipOps:
         ld = idx_cm.shape[1] if idx_cm.dim() == 2 else N
         check(self.L.gficf_jaccard_device(self._bind(), _tptr(idx_cm), is_f64, N, k, ld, _tptr(table_ws),
                                           _tptr(rmat3), _tptr(u)))
+
+    # -- exact kNN (next row N2)
+    @staticmethod
+    def knn_dpad(d: int) -> int:
+        dp = _lib.load().gficf_knn_dpad(int(d))
+        if dp < 0:
+            raise GficfError(6, f"d = {d} outside [0, 128]")
+        return dp
+
+    def knn_prepare(self, X_cm, n_rows: int, d: int, metric: str, point_rows):
+        """X_cm: (d, ld) float64/float32 tensor == column-major n_rows x d block of the R matrix.
+        point_rows: (n_rows, dpad) float32."""
+        tc = self.torch
+        is_f64 = 1 if X_cm.dtype == tc.float64 else 0
+        if not is_f64 and X_cm.dtype != tc.float32:
+            raise ValueError("X must be float64 or float32")
+        ld = X_cm.shape[1] if X_cm.dim() == 2 else n_rows
+        check(self.L.gficf_knn_prepare_device(self._bind(), _tptr(X_cm), is_f64, n_rows, d, ld, _lib.KNN_METRICS[metric],
+                                              _tptr(point_rows)))
+
+    def knn_workspace_bytes(self, n_queries: int, N: int, k: int) -> int:
+        return int(self.L.gficf_knn_workspace_bytes(self.ctx.handle, n_queries, N, k))
+
+    def knn_search(self, points, N: int, d: int, k: int, metric: str, q_begin: int, q_end: int, ws, idx_cm, dist_cm=None):
+        """points: (N, dpad) float32.  idx_cm: (k, ld) int32 == column-major (q_end-q_begin) x k, 1-based ids;
+        dist_cm: same shape float32 or None.  ws: uint8 scratch of knn_workspace_bytes()."""
+        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else q_end - q_begin
+        check(self.L.gficf_knn_search_device(self._bind(), _tptr(points), N, d, k, _lib.KNN_METRICS[metric], q_begin, q_end,
+                                             _tptr(ws), int(ws.numel()), _tptr(idx_cm), _tptr(dist_cm), ld))
 
     # -- GF-ICF
     def csc_count(self, G, n_cells, colptr, rowidx, x, nt):

@@ -212,7 +212,10 @@ __global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64
     }
     __syncthreads();
   }
-  for (int64_t c = wave; c < n_cells; c += nwaves) {
+  // Cells are swept from the last to the first: pass A has just streamed rowidx front to back, so its
+  // tail is what the 256 MiB Infinity Cache still holds; reading backwards re-uses it before it ages out.
+  for (int64_t cr = wave; cr < n_cells; cr += nwaves) {
+    const int64_t c = n_cells - 1 - cr;
     const int64_t p0 = colptr[c], p1 = colptr[c + 1];
     if (p1 < p0) { if (lane == 0) { atomicOr(status, GFICF_ST_BAD_CSC); out[c] = 0; } continue; }
     int64_t cnt;

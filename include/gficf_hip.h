@@ -221,6 +221,47 @@ int gficf_cluster_signatures_host(gficf_ctx* ctx, int64_t G, int64_t N, const vo
                                   int colptr_is_i64, const int32_t* rowidx, const double* x,
                                   const int32_t* cluster, int32_t C, double* out);
 
+/* ------------------------------------------------------------------- exact kNN search
+ * "Next" row N2: the caller's step in front of the Jaccard build,
+ *   neigh = uwot:::find_nn(data$pca$cells, k = k+1, include_self = T, method = "annoy",
+ *                          metric = dist.method)$idx                    (R/clustCells.R:57,60)
+ * uwot / Annoy are third-party and approximate; this is an EXACT search in f32 (Annoy's own
+ * precision): for every query the k smallest (distance, index) pairs over ALL N points, the
+ * query itself included (include_self = T), ties broken by the smaller index.  Distances:
+ * manhattan = sum |a-b| (the reference's default, R/clustCells.R:46), euclidean = sqrt(sum (a-b)^2),
+ * cosine = 1 - cos (rows L2-normalised first); all accumulated in dimension order.
+ */
+typedef enum gficf_knn_metric {
+  GFICF_KNN_MANHATTAN = 0,
+  GFICF_KNN_EUCLIDEAN = 1,
+  GFICF_KNN_COSINE = 2
+} gficf_knn_metric;
+
+#define GFICF_KNN_MAX_K 128
+
+/* Row pitch (floats) of the point table for d dimensions (d rounded up to 4), -1 if d > 128. */
+int gficf_knn_dpad(int d);
+
+/* Device pipeline, split where a multi-GPU caller needs the seam (queries shard by cell block):
+ *   1. prepare : a block of rows of the R matrix (n_rows x d column-major, f64 or f32, ld >= n_rows)
+ *                -> row-major f32 point rows (n_rows x dpad, zero padded; cosine: normalised)
+ *   2. (multi-GPU only) the caller all-gathers the point rows of all blocks
+ *   3. search  : queries [q_begin, q_end) against all N points -> d_idx (1-based ids, (q_end-q_begin) x k
+ *                column-major with leading dimension ld_out: column 0 is the nearest — the query
+ *                itself unless an identical point has a smaller index), d_dist optional, same layout.
+ *                d_idx + ld_out (k-1 columns) is exactly what gficf_jaccard_ingest_device reads.
+ * d_ws: scratch of gficf_knn_workspace_bytes(ctx, q_end-q_begin, N, k) bytes. */
+int gficf_knn_prepare_device(gficf_ctx* ctx, const void* d_X, int x_is_f64, int64_t n_rows, int d,
+                             int64_t ld, int metric, float* d_point_rows);
+size_t gficf_knn_workspace_bytes(gficf_ctx* ctx, int64_t n_queries, int64_t N, int k);
+int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, int d, int k, int metric,
+                            int64_t q_begin, int64_t q_end, void* d_ws, size_t ws_bytes,
+                            int32_t* d_idx, float* d_dist, int64_t ld_out);
+/* Host form: X = N x d column-major doubles (an R numeric matrix); idx: N x k column-major int32
+ * (1-based), dist: N x k column-major doubles or NULL. */
+int gficf_knn_host(gficf_ctx* ctx, const double* X, int64_t N, int d, int64_t ld, int k, int metric,
+                   int32_t* idx, double* dist);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,7 @@ def build(force: bool = False) -> str:
     """Compile liboracle.so with g++ (make -C oracle)."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, s)) > os.path.getmtime(_LIB_PATH)
-        for s in ("jaccard_oracle.cpp", "gficf_oracle.cpp")
+        for s in ("jaccard_oracle.cpp", "gficf_oracle.cpp", "knn_oracle.cpp")
     ):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"] + (["-B"] if force else []))
     return _LIB_PATH
@@ -50,6 +50,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_jaccard_i32.argtypes = [vp, i64, i32, vp, vp, i32]
         L.oracle_gficf_csc.restype = i32
         L.oracle_gficf_csc.argtypes = [i64, i64, vp, vp, vp, dbl, dbl, vp] + [vp] * 8
+        L.oracle_knn.restype = i32
+        L.oracle_knn.argtypes = [vp, i64, i32, i64, i32, i32, vp, vp, i32]
         _lib = L
     return _lib
 
@@ -108,3 +110,20 @@ def gficf_csc(G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None):
     n = nk.value
     return dict(keep=keep.astype(bool), nt=nt, w=w, colptr=ocp, rowidx=ori[:n].copy(),
                 x=ox[:n].copy(), G_kept=gk.value)
+
+
+KNN_METRICS = {"manhattan": 0, "euclidean": 1, "cosine": 2}
+
+
+def knn(X: np.ndarray, k: int, metric: str = "manhattan", nthreads: int = 1):
+    """Exact kNN in f32 (the contract the approximate ``uwot:::find_nn(..., method="annoy")`` call of
+    reference R/clustCells.R:57,60 aims at): X is N x d, returns (idx N x k int32 1-based, dist N x k
+    float64), the k smallest (distance, index) pairs per row, the row itself included."""
+    X = np.asfortranarray(X, dtype=np.float64)
+    N, d = X.shape
+    idx = np.zeros((k, N), dtype=np.int32)     # C-order (k, N) == column-major N x k
+    dist = np.zeros((k, N), dtype=np.float64)
+    rc = lib().oracle_knn(_p(X), N, d, max(N, 1), int(k), KNN_METRICS[metric], _p(idx), _p(dist), int(nthreads))
+    if rc != 0:
+        raise ValueError(f"oracle_knn: rc={rc}")
+    return idx.T, dist.T

@@ -142,3 +142,31 @@ def cluster_signatures_np(gficf_mat: sp.csc_matrix, cluster):
     M = sp.csc_matrix(gficf_mat)
     cols = [np.asarray(M[:, np.flatnonzero(lab == u)].sum(axis=1)).ravel() for u in labels]
     return np.stack(cols, axis=1) if cols else np.zeros((M.shape[0], 0)), labels
+
+
+# ------------------------------------------------------------------------------- kNN
+def knn_np(X: np.ndarray, k: int, metric: str = "manhattan"):
+    """Exact kNN in float64 (different arithmetic from ``knn_oracle.cpp``, which works in f32 like the
+    HIP kernel): the k smallest (distance, index) pairs per row, the row itself included — the
+    contract the approximate ``uwot:::find_nn(..., method="annoy", metric=...)`` call of
+    R/clustCells.R:57,60 aims at.  Returns (idx N x k, 1-based; dist N x k)."""
+    X = np.asarray(X, dtype=np.float64)
+    N = X.shape[0]
+    idx = np.zeros((N, k), dtype=np.int32)
+    dist = np.zeros((N, k), dtype=np.float64)
+    if metric == "cosine":
+        nrm = np.sqrt((X * X).sum(axis=1, keepdims=True))
+        Xn = np.divide(X, nrm, out=np.zeros_like(X), where=nrm > 0)
+    for i in range(N):
+        if metric == "manhattan":
+            dv = np.abs(X - X[i]).sum(axis=1)
+        elif metric == "euclidean":
+            dv = np.sqrt(((X - X[i]) ** 2).sum(axis=1))
+        elif metric == "cosine":
+            dv = 1.0 - Xn @ Xn[i]
+        else:
+            raise ValueError(metric)
+        order = np.lexsort((np.arange(N), dv))[:k]
+        idx[i] = order + 1
+        dist[i] = dv[order]
+    return idx, dist

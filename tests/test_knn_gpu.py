@@ -1,0 +1,140 @@
+"""GPU parity of the exact kNN search ("next" row N2, the step in front of the Jaccard build:
+reference R/clustCells.R:57,60) against the CPU oracle.  Bar: index matrix bit-exact (the oracle
+evaluates the same f32 chain, ties broken by index), distances equal as f32; against the float64
+numpy restatement distances within 1e-5 relative."""
+import numpy as np
+import pytest
+
+import gficf_amd
+import oracle
+from oracle import oracle_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return gficf_amd.HipOps(0)
+
+
+def blobs(N, d, seed, centers=12):
+    """Clustered points (like cells in PCA space): Gaussian blobs with unequal spreads."""
+    rng = np.random.default_rng(seed)
+    c = rng.normal(scale=6.0, size=(centers, d))
+    lab = rng.integers(0, centers, size=N)
+    return c[lab] + rng.normal(size=(N, d)) * rng.uniform(0.5, 2.0, size=(centers, 1))[lab]
+
+
+@pytest.mark.parametrize("metric", ["manhattan", "euclidean", "cosine"])
+@pytest.mark.parametrize("N,d,k", [(300, 2, 5), (1000, 50, 16), (2500, 50, 31), (2000, 7, 31), (1500, 64, 51),
+                                   (700, 128, 33), (900, 20, 100), (130, 3, 128), (129, 50, 1), (4000, 50, 31)])
+def test_host_api_matches_oracle(metric, N, d, k):
+    X = blobs(N, d, seed=N + d + k)
+    got = gficf_amd.find_nn(X, k, True, metric)
+    widx, wdist = oracle.knn(X, k, metric, nthreads=8)
+    assert got["idx"].shape == (N, k) and got["idx"].dtype == np.int32
+    assert np.array_equal(got["idx"], widx)
+    assert np.array_equal(got["dist"].astype(np.float32), wdist.astype(np.float32))
+    # the row itself comes first (distinct points)
+    if metric != "cosine":
+        assert np.array_equal(got["idx"][:, 0], np.arange(1, N + 1))
+        assert np.all(got["dist"][:, 0] == 0.0)
+
+
+@pytest.mark.parametrize("metric", ["manhattan", "euclidean", "cosine"])
+def test_against_float64_restatement(metric):
+    X = blobs(600, 30, seed=5)
+    got = gficf_amd.find_nn(X, 20, True, metric)
+    nidx, ndist = oracle_np.knn_np(X, 20, metric)
+    assert np.allclose(got["dist"], ndist, rtol=1e-5, atol=1e-5)
+    # ids agree wherever the float64 distances are not within rounding of the next one
+    agree = got["idx"] == nidx
+    assert agree.mean() > 0.995
+
+
+def test_duplicates_and_ties_break_by_index():
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 4, size=(40, 3)).astype(np.float64)       # a small grid: many exact ties and duplicates
+    X = np.concatenate([base, base, base[:17]])
+    for metric in ("manhattan", "euclidean"):
+        got = gficf_amd.find_nn(X, 12, True, metric)
+        widx, wdist = oracle.knn(X, 12, metric)
+        assert np.array_equal(got["idx"], widx)
+        assert np.array_equal(got["dist"], wdist)
+        # a duplicated point's nearest is the copy with the smallest index, at distance 0
+        assert np.all(got["dist"][:, 0] == 0.0)
+        assert np.all(got["idx"][40:80, 0] <= np.arange(1, 41))
+
+
+def test_include_self_false_drops_own_id():
+    X = blobs(500, 10, seed=9)
+    a = gficf_amd.find_nn(X, 11, True, "manhattan")
+    b = gficf_amd.find_nn(X, 10, False, "manhattan")
+    assert np.array_equal(a["idx"][:, 1:], b["idx"]) and np.array_equal(a["dist"][:, 1:], b["dist"])
+
+
+def test_argument_errors():
+    X = blobs(50, 4, seed=1)
+    with pytest.raises(gficf_amd.GficfError):
+        gficf_amd.find_nn(X, 51, True, "manhattan")            # more neighbours than points
+    with pytest.raises(gficf_amd.GficfError):
+        gficf_amd.find_nn(blobs(50, 129, seed=1), 5, True, "manhattan")
+    with pytest.raises(ValueError):
+        gficf_amd.find_nn(X, 5, True, "hamming")
+
+
+def test_device_query_blocks_and_split_seams(ops, monkeypatch):
+    """Queries in two blocks (the multi-GPU seam) and a forced 5-way candidate split give the same bits."""
+    import torch
+
+    N, d, k = 3000, 50, 31
+    X = blobs(N, d, seed=11)
+    widx, _ = oracle.knn(X, k, "manhattan", nthreads=8)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()                     # (d, N) == column-major N x d
+    pts = torch.zeros((N, ops.knn_dpad(d)), dtype=torch.float32, device="cuda")
+    # prepare in two row blocks, as two ranks would before their all-gather
+    h = 1700
+    ops.knn_prepare(Xd[:, :h].contiguous(), h, d, "manhattan", pts[:h])
+    ops.knn_prepare(Xd[:, h:].contiguous(), N - h, d, "manhattan", pts[h:])
+    for split in (None, "5"):
+        if split:
+            monkeypatch.setenv("GFICF_KNN_SPLIT", split)
+        out = []
+        for b, e in ((0, 1300), (1300, N)):
+            ws = torch.zeros(ops.knn_workspace_bytes(e - b, N, k), dtype=torch.uint8, device="cuda")
+            idx = torch.full((k, e - b), -7, dtype=torch.int32, device="cuda")
+            dist = torch.full((k, e - b), -7.0, dtype=torch.float32, device="cuda")
+            ops.knn_search(pts, N, d, k, "manhattan", b, e, ws, idx, dist)
+            ops.sync()
+            out.append(idx.cpu().numpy().T)
+        assert np.array_equal(np.concatenate(out), widx)
+
+
+def test_knn_feeds_jaccard_on_device(ops):
+    """find_nn -> neigh[,-1] -> Jaccard without leaving the device: the index matrix the search writes
+    (column-major, 1-based) is what the ingest reads, skipping the self column."""
+    import torch
+
+    N, d, k = 2000, 20, 15
+    X = blobs(N, d, seed=21)
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()
+    pts = torch.zeros((N, ops.knn_dpad(d)), dtype=torch.float32, device="cuda")
+    ops.knn_prepare(Xd, N, d, "manhattan", pts)
+    ws = torch.zeros(ops.knn_workspace_bytes(N, N, k + 1), dtype=torch.uint8, device="cuda")
+    idx = torch.zeros((k + 1, N), dtype=torch.int32, device="cuda")
+    ops.knn_search(pts, N, d, k + 1, "manhattan", 0, N, ws, idx, None)
+    table = torch.empty((N, ops.kpad(k)), dtype=torch.int32, device="cuda")
+    rmat = torch.zeros((3, N * k), dtype=torch.float64, device="cuda")
+    ops.jaccard(idx[1:], N, k, table, rmat, None)                               # neigh[,-1]  (R/clustCells.R:63)
+    ops.sync()
+    widx, _ = oracle.knn(X, k + 1, "manhattan", nthreads=8)
+    want, _ = oracle.jaccard(np.ascontiguousarray(widx[:, 1:]), nthreads=8)
+    assert np.array_equal(rmat.cpu().numpy().T, want)
+    # and the one-call host form of the same lines
+    edges = gficf_amd.clustcells_graph(X, k, "manhattan")
+    keep = want[:, 2] > 0
+    assert np.array_equal(edges["from"], want[keep, 0]) and np.array_equal(edges["to"], want[keep, 1])
+    assert np.array_equal(edges["weight"], want[keep, 2])

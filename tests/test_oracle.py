@@ -186,3 +186,27 @@ def test_gficf_golden(golden_dir):
         assert np.array_equal(r["rowidx"], z[nm + "_rowidx"])
         assert np.allclose(r["x"], z[nm + "_x"], rtol=1e-14, atol=0)
         assert np.allclose(r["w"], z[nm + "_w"], rtol=1e-14, atol=0)
+
+
+# ------------------------------------------------------------------------------- kNN (N2)
+@pytest.mark.parametrize("metric", ["manhattan", "euclidean", "cosine"])
+def test_knn_oracle_cpp_vs_float64_restatement(metric):
+    """The f32 C++ brute force against the float64 numpy restatement: same neighbours except where
+    two float64 distances are within f32 rounding of each other; distances within 1e-5."""
+    rng = np.random.default_rng(12)
+    X = rng.normal(size=(400, 24)) * rng.uniform(0.3, 3.0, size=(1, 24))
+    idx, dist = oracle.knn(X, 15, metric, nthreads=4)
+    nidx, ndist = oracle_np.knn_np(X, 15, metric)
+    assert np.allclose(dist, ndist, rtol=1e-5, atol=1e-5)
+    assert (idx == nidx).mean() > 0.995
+    assert np.array_equal(idx[:, 0], np.arange(1, 401)) or metric == "cosine"
+
+
+def test_knn_oracle_known_answer_and_ties():
+    # 1-d points 0, 1, 3, 6 and a duplicate of 1: distances are exact small integers
+    X = np.array([[0.0], [1.0], [3.0], [6.0], [1.0]])
+    idx, dist = oracle.knn(X, 3, "manhattan")
+    assert idx.tolist() == [[1, 2, 5], [2, 5, 1], [3, 2, 5], [4, 3, 2], [2, 5, 1]]
+    assert dist.tolist() == [[0, 1, 1], [0, 0, 1], [0, 2, 2], [0, 3, 5], [0, 0, 1]]
+    idx2, dist2 = oracle.knn(X, 3, "euclidean")
+    assert idx2.tolist() == idx.tolist() and dist2.tolist() == dist.tolist()
