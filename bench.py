@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md "
 JACCARD_BYTES_PER_EDGE = 28      # 4 B index entry read once + 24 B reference output row
 GFICF_BYTES_PER_NNZ = 24         # 4 (count pass rowidx) + 12 (scale pass rowidx+x) + 8 (write x)  
 GFICF_G, GFICF_N = 23_000, 54_000  # BASELINE config 3 shape (Tabula-Muris-sized synthetic stand-in)
+KNN_N, KNN_D, KNN_K = 100_000, 50, 31  # north-star point: 100 k cells, 50 PCA components, k = 30 + the cell itself
 
 
 def parse():
@@ -48,6 +49,7 @@ def parse():
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gficf", action="store_true")
+    ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="ingest/all-gather on the same stream as the edge kernel")
     return ap.parse_args()
 
@@ -85,6 +87,57 @@ def synth_counts_device(torch, G, N, seed=7, median_frac=0.07, sigma=0.5, zipf_s
     colptr[1:] = torch.cumsum(torch.bincount(col, minlength=N), 0)
     x = 1.0 + torch.floor(-torch.log2(1.0 - torch.rand(key.numel(), generator=g, device="cuda", dtype=torch.float64)))
     return colptr, rowidx, x
+
+
+def bench_knn(torch, ops, args):
+    """The exact kNN search in front of the Jaccard build ("next" row N2; reference call-site R/clustCells.R:57,60):
+    100 k cells x 50 PCA components, k+1 = 31 (k = 30 plus the cell itself), manhattan — the reference's default."""
+    N, d, k, metric = KNN_N, KNN_D, KNN_K, "manhattan"
+    rng = np.random.default_rng(11)
+    centers = rng.normal(scale=6.0, size=(40, d))
+    lab = rng.integers(0, 40, size=N)
+    Xh = centers[lab] + rng.normal(size=(N, d)) * rng.uniform(0.5, 2.0, size=(40, 1))[lab]
+    X = torch.from_numpy(np.ascontiguousarray(Xh.T)).cuda()            # (d, N) == column-major N x d, as R holds it
+    pts = torch.zeros((N, ops.knn_dpad(d)), dtype=torch.float32, device="cuda")
+    ws = torch.zeros(ops.knn_workspace_bytes(N, N, k), dtype=torch.uint8, device="cuda")
+    idx = torch.zeros((k, N), dtype=torch.int32, device="cuda")
+
+    def run():
+        ops.knn_prepare(X, N, d, metric, pts)
+        ops.knn_search(pts, N, d, k, metric, 0, N, ws, idx, None)
+
+    run()
+    torch.cuda.synchronize()
+    reps = 3
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t1) / reps
+    # VALU-bound, not a contraction: |a-b| accumulation costs 1.5 lane-instructions per element on gfx950
+    # (one packed subtract per pair + one add with |.| per element); peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+    lane_ops = 1.5 * N * N * d
+    peak = 256 * 4 * 16 * 2.4e9
+    res = {"metric": "knn_cells_per_sec", "value": N / t, "unit": "cells/s", "ms_per_pass": t * 1e3, "dtype": "f32",
+           "config": {"workload": f"exact kNN, {N} cells x {d} components (Gaussian blobs), {k} nearest incl. self, {metric}, device-resident"},
+           "pair_distances_per_sec": N * N / t,
+           "roofline": {"bound": "valu", "achieved": round(lane_ops / t / 1e12, 2), "peak": round(peak / 1e12, 2), "unit": "T lane-instr/s",
+                        "frac": round(lane_ops / t / peak, 4), "traffic": None,
+                        "note": "1.5 VALU lane-instructions per (pair, dimension) is the minimum for f32 |a-b| accumulation on gfx950"}}
+    if not args.no_cpu_baseline:
+        import oracle
+
+        cores = os.cpu_count() or 1
+        nq = 2048                                                      # bounded sample: the first 2048 queries against all N points
+        t1 = time.perf_counter()
+        widx, _ = oracle.knn(Xh, k, metric, nthreads=cores, queries=(0, nq))
+        tc = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": nq / tc, "unit": "cells/s", "cores": cores, "kind": "port",
+                               "sample": f"the first {nq} queries against all {N} points, oracle brute force (f32, g++ -O2, {cores} threads); "
+                                         "the reference's own search is Annoy (approximate, third-party) and cannot run here",
+                               "gpu_over_cpu": (N / t) / (nq / tc)}
+        res["checked_vs_oracle"] = bool(np.array_equal(idx[:, :nq].cpu().numpy().T, widx[:nq]))
+    return res
 
 
 def main():
@@ -301,6 +354,8 @@ def main():
                 gf["checked_vs_oracle"] = bool(kn == len(ref["x"]) and np.array_equal(ws["out_rowidx"][:kn].cpu().numpy(), ref["rowidx"])
                                                and np.allclose(ws["out_x"][:kn].cpu().numpy(), ref["x"], rtol=1e-6, atol=1e-6))
             out["gficf"] = gf
+        if not args.no_knn:
+            out["knn"] = bench_knn(torch, ops, args)
 
     if world > 1 and not args.no_gficf:
         # GF-ICF, cell-sharded: every rank owns a 54 k-cell block of a (54 k x n_gpus)-cell matrix; the only

@@ -218,6 +218,10 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[r][s] = knn_f2{0.0f, 0.0f};
 
+  float tau[8];                 // current k-th best distance of this thread's 8 query rows
+#pragma unroll
+  for (int r = 0; r < 8; ++r) tau[r] = INFINITY;
+
   float4 pre[2];
   if (G > 0) { load_chunk(0, pre); store_chunk(0, pre); }
   __syncthreads();
@@ -242,8 +246,6 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
       for (int r = 0; r < 8; ++r) {
         const int row = (r < 4 ? 0 : 64) + ty * 4 + (r & 3);
         volatile u64* const list = sKey + row * KL;
-        const uint32_t tau_hi = (uint32_t)(list[kk - 1] >> 32);
-        const float tau = tau_hi == 0xFFFFFFFFu ? INFINITY : sortable_f32(tau_hi);     // list not full yet: everything enters
         float dv[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -255,8 +257,11 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
         for (int s = 0; s < 4; ++s) acc[r][s] = knn_f2{0.0f, 0.0f};
         const float mn = fminf(fminf(fminf(dv[0], dv[1]), fminf(dv[2], dv[3])), fminf(fminf(dv[4], dv[5]), fminf(dv[6], dv[7])));
         // common case after the first tiles: nothing in the whole wave beats its query's k-th best
-        if (__ballot(mn <= tau && q0 + row < q_end) == 0) continue;
-        knn_row_insert<KL>(list, kk, dv, tau, q0 + row < q_end, j0, tid);
+        if (__ballot(mn <= tau[r] && q0 + row < q_end) == 0) continue;
+        knn_row_insert<KL>(list, kk, dv, tau[r], q0 + row < q_end, j0, tid);
+        // this wave is the only writer of its rows' lists, so the register copy of the k-th best stays exact
+        const uint32_t tau_hi = (uint32_t)(list[kk - 1] >> 32);
+        tau[r] = tau_hi == 0xFFFFFFFFu ? INFINITY : sortable_f32(tau_hi);     // list not full yet: everything enters
       }
     }
     if (g + 1 < G) store_chunk((int)((g + 1) & 1), pre);

@@ -8,6 +8,10 @@ New design (the reference is single-process):
   int32 table, then every rank builds the edges of its own cell block.  No other
   collective touches the data path; outputs stay sharded (each rank owns rows
   [b*k, e*k) of the reference's edge matrix).
+* kNN (the step in front, "next" row N2) — queries shard by the same cell blocks; every rank prepares
+  its own block of point rows (f32, row-major), ONE all-gather replicates the points (N x dpad x 4 B:
+  20 MB at 100 k x 50), then every rank searches its own queries against all points.  The index
+  block it writes is exactly the input block of the sharded Jaccard build, already in place.
 * GF-ICF — cells (columns) are independent except for the per-gene cell counts nt_g, so
   there is exactly one all-reduce(sum) of G int64 counters between the counting pass and
   the scaling pass.
@@ -201,3 +205,38 @@ class GficfShard:
         ops.csc_scale(self.G, self.n_local, colptr, rowidx, x, ws["genes"], ws["gkept"], ws["out_colptr"],
                       ws["out_rowidx"], ws["out_x"])
         return ws
+
+
+class KnnShard:
+    """Per-rank state of the sharded exact kNN search (reference call-site R/clustCells.R:57,60).
+
+    ``step(X_local_cm)`` takes this rank's block of the cells x components matrix ((d, n_local) tensor ==
+    column-major n_local x d) and returns the (k, n_local) int32 index block (1-based global ids, column 0 =
+    the cell itself) — ``idx[1:]`` is what :meth:`JaccardShard.step` takes (``neigh[,-1]``, R/clustCells.R:63).
+    """
+
+    def __init__(self, ops, N_total: int, d: int, k: int, metric: str = "manhattan", group=None, device=None,
+                 with_dist: bool = False):
+        self.ops, self.N, self.d, self.k, self.metric, self.group = ops, int(N_total), int(d), int(k), metric, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rpr = rows_per_rank(self.N, self.world)
+        self.b, self.e = shard_bounds(self.N, self.world, self.rank)
+        self.n_local = self.e - self.b
+        self.dpad = ops.knn_dpad(self.d)
+        # all points, padded to world*rpr rows so that every rank contributes an equal block
+        self.points = torch.zeros((self.world * self.rpr, self.dpad), dtype=torch.float32, device=device)
+        self.idx = torch.zeros((self.k, max(self.n_local, 1)), dtype=torch.int32, device=device)
+        self.dist = torch.zeros((self.k, max(self.n_local, 1)), dtype=torch.float32, device=device) if with_dist else None
+        self.ws = torch.zeros(max(ops.knn_workspace_bytes(self.n_local, self.N, self.k), 16), dtype=torch.uint8, device=device)
+
+    def step(self, X_local_cm):
+        mine = self.points[self.rank * self.rpr:(self.rank + 1) * self.rpr]
+        if self.n_local > 0:
+            self.ops.knn_prepare(X_local_cm, self.n_local, self.d, self.metric, mine)
+        if self.world > 1:
+            _all_gather_rows(self.points.view(-1), mine.reshape(-1), self.group)
+        if self.n_local > 0:
+            # blocks are equal-pitch and only the last can be short, so rows [0, N) of the table are the N points
+            self.ops.knn_search(self.points, self.N, self.d, self.k, self.metric, self.b, self.e, self.ws, self.idx, self.dist)
+        return self.idx

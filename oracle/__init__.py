@@ -52,6 +52,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_gficf_csc.argtypes = [i64, i64, vp, vp, vp, dbl, dbl, vp] + [vp] * 8
         L.oracle_knn.restype = i32
         L.oracle_knn.argtypes = [vp, i64, i32, i64, i32, i32, vp, vp, i32]
+        L.oracle_knn_block.restype = i32
+        L.oracle_knn_block.argtypes = [vp, i64, i32, i64, i32, i32, i64, i64, vp, vp, i32]
         _lib = L
     return _lib
 
@@ -115,15 +117,17 @@ def gficf_csc(G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None):
 KNN_METRICS = {"manhattan": 0, "euclidean": 1, "cosine": 2}
 
 
-def knn(X: np.ndarray, k: int, metric: str = "manhattan", nthreads: int = 1):
+def knn(X: np.ndarray, k: int, metric: str = "manhattan", nthreads: int = 1, queries: tuple | None = None):
     """Exact kNN in f32 (the contract the approximate ``uwot:::find_nn(..., method="annoy")`` call of
     reference R/clustCells.R:57,60 aims at): X is N x d, returns (idx N x k int32 1-based, dist N x k
-    float64), the k smallest (distance, index) pairs per row, the row itself included."""
+    float64), the k smallest (distance, index) pairs per row, the row itself included.  ``queries=(b, e)``
+    restricts the search to rows [b, e) (the other rows of the result stay zero)."""
     X = np.asfortranarray(X, dtype=np.float64)
     N, d = X.shape
     idx = np.zeros((k, N), dtype=np.int32)     # C-order (k, N) == column-major N x k
     dist = np.zeros((k, N), dtype=np.float64)
-    rc = lib().oracle_knn(_p(X), N, d, max(N, 1), int(k), KNN_METRICS[metric], _p(idx), _p(dist), int(nthreads))
+    qb, qe = queries if queries is not None else (0, N)
+    rc = lib().oracle_knn_block(_p(X), N, d, max(N, 1), int(k), KNN_METRICS[metric], int(qb), int(qe), _p(idx), _p(dist), int(nthreads))
     if rc != 0:
         raise ValueError(f"oracle_knn: rc={rc}")
     return idx.T, dist.T

@@ -98,10 +98,12 @@ KNN_TARGET static void prepare_rows(const double* X, int64_t N, int d, int64_t l
   }
 }
 
-extern "C" int oracle_knn(const double* X, int64_t N, int d, int64_t ld, int k, int metric, int32_t* idx, double* dist,
-                          int nthreads) {
-  if (N < 0 || d <= 0 || k < 0 || k > N || ld < N || metric < 0 || metric > 2) return 1;
-  if (N == 0 || k == 0) return 0;
+// Queries [q_begin, q_end) only (a bounded sample of the same workload for the timed CPU baseline); idx / dist
+// keep the full N x k column-major shape, rows outside the range are left untouched.
+extern "C" int oracle_knn_block(const double* X, int64_t N, int d, int64_t ld, int k, int metric, int64_t q_begin, int64_t q_end,
+                                int32_t* idx, double* dist, int nthreads) {
+  if (N < 0 || d <= 0 || k < 0 || k > N || ld < N || metric < 0 || metric > 2 || q_begin < 0 || q_end < q_begin || q_end > N) return 1;
+  if (N == 0 || k == 0 || q_end == q_begin) return 0;
 #if defined(__x86_64__)
   if (!__builtin_cpu_supports("fma")) return 2;
 #endif
@@ -109,9 +111,9 @@ extern "C" int oracle_knn(const double* X, int64_t N, int d, int64_t ld, int k, 
   prepare_rows(X, N, d, ld, metric, P.data());
   if (nthreads < 1) nthreads = 1;
   std::vector<std::thread> th;
-  const int64_t per = (N + nthreads - 1) / nthreads;
+  const int64_t per = (q_end - q_begin + nthreads - 1) / nthreads;
   for (int w = 0; w < nthreads; ++w) {
-    const int64_t q0 = std::min<int64_t>(N, w * per), q1 = std::min<int64_t>(N, q0 + per);
+    const int64_t q0 = std::min<int64_t>(q_end, q_begin + w * per), q1 = std::min<int64_t>(q_end, q0 + per);
     if (q0 >= q1) continue;
     th.emplace_back([=, &P]() {
       const float* p = P.data();
@@ -122,4 +124,9 @@ extern "C" int oracle_knn(const double* X, int64_t N, int d, int64_t ld, int k, 
   }
   for (auto& t : th) t.join();
   return 0;
+}
+
+extern "C" int oracle_knn(const double* X, int64_t N, int d, int64_t ld, int k, int metric, int32_t* idx, double* dist,
+                          int nthreads) {
+  return oracle_knn_block(X, N, d, ld, k, metric, 0, N, idx, dist, nthreads);
 }

@@ -108,3 +108,34 @@ class CpuOpsDouble:
             nv = 1.0 / np.sqrt(q) if q > 0 else 0.0
             ori[ocp[c]:ocp[c + 1]] = remap[gs]
             ox[ocp[c]:ocp[c + 1]] = nv * v
+
+    # ---- exact kNN (N2)
+    @staticmethod
+    def knn_dpad(d):
+        return (d + 3) & ~3
+
+    def knn_workspace_bytes(self, n_queries, N, k):
+        return 16
+
+    def knn_prepare(self, X_cm, n_rows, d, metric, point_rows):
+        X = X_cm.numpy().reshape(d, -1)[:, :n_rows].T.astype(np.float32)
+        if metric == "cosine":
+            nrm = np.sqrt((X.astype(np.float64) ** 2).sum(axis=1, keepdims=True)).astype(np.float32)
+            X = np.divide(X, nrm, out=np.zeros_like(X), where=nrm > 0)
+        point_rows[:n_rows, :d] = torch.from_numpy(np.ascontiguousarray(X))
+        point_rows[:n_rows, d:] = 0
+
+    def knn_search(self, points, N, d, k, metric, q_begin, q_end, ws, idx_cm, dist_cm=None):
+        # points are already prepared (normalised for cosine): a dot product / L1 / L2 brute force in float64
+        P = points.numpy()[:N, :d].astype(np.float64)
+        for q in range(q_begin, q_end):
+            if metric == "manhattan":
+                dv = np.abs(P - P[q]).sum(axis=1)
+            elif metric == "euclidean":
+                dv = np.sqrt(((P - P[q]) ** 2).sum(axis=1))
+            else:
+                dv = 1.0 - P @ P[q]
+            order = np.lexsort((np.arange(N), dv))[:k]
+            idx_cm[:, q - q_begin] = torch.from_numpy((order + 1).astype(np.int32))
+            if dist_cm is not None:
+                dist_cm[:, q - q_begin] = torch.from_numpy(dv[order].astype(np.float32))

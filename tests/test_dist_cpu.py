@@ -49,6 +49,20 @@ def _worker(rank, world, port, N, k, outdir):
         tabs = [torch.zeros_like(sh.table) for _ in range(world)]
         dist.all_gather(tabs, sh.table)
         assert all(torch.equal(tabs[0], t) for t in tabs)
+        # ---- kNN in front of it: points sharded by the same cell blocks, the index block feeds the Jaccard shard
+        from gficf_amd.dist import KnnShard
+
+        rng = np.random.default_rng(17)
+        X = rng.normal(size=(N, 6)) * 3.0
+        ks = KnnShard(ops, N, 6, 9, "manhattan")
+        assert (ks.b, ks.e) == (b, e)
+        kidx = ks.step(torch.from_numpy(np.ascontiguousarray(X[b:e].T)))
+        np.save(os.path.join(outdir, f"knn_{rank}.npy"), kidx.numpy())
+        pts = [torch.zeros_like(ks.points) for _ in range(world)]
+        dist.all_gather(pts, ks.points)
+        assert all(torch.equal(pts[0], t) for t in pts)
+        sh2 = JaccardShard(ops, N, 8)
+        np.save(os.path.join(outdir, f"kjac_{rank}.npy"), sh2.step(kidx[1:].contiguous()).numpy())
         # ---- GF-ICF: every rank holds a block of cells (columns)
         G, Nc = 300, 101
         cp, ri, x = synth.counts_csc(G, Nc, seed=5)
@@ -79,6 +93,16 @@ def test_sharded_path_world2_gloo(tmp_path, N, k):
     gu = np.concatenate([np.load(tmp_path / f"u_{r}.npy") for r in range(world)])
     assert np.array_equal(gu, wu)
     assert np.array_equal(got, want)
+    # kNN blocks == the float64 restatement on the whole matrix; chained Jaccard == oracle on those ids
+    from oracle import oracle_np
+
+    X = np.random.default_rng(17).normal(size=(N, 6)) * 3.0
+    nidx, _ = oracle_np.knn_np(X.astype(np.float32), 9, "manhattan")
+    kgot = np.concatenate([np.load(tmp_path / f"knn_{r}.npy") for r in range(world)], axis=1).T
+    assert np.array_equal(kgot, nidx)
+    kwant, _ = oracle.jaccard(np.ascontiguousarray(nidx[:, 1:]), nthreads=2)
+    kj = np.concatenate([np.load(tmp_path / f"kjac_{r}.npy") for r in range(world)], axis=1).T
+    assert np.array_equal(kj, kwant)
     # GF-ICF: concatenated blocks == single-shot oracle
     G, Nc = 300, 101
     cp, ri, x = synth.counts_csc(G, Nc, seed=5)

@@ -1,6 +1,6 @@
 """GPU, two processes on one device, gloo: the complete N > 1 path with the real HIP kernels — ingest,
 bit-packed transport rows, all-gather, unpack, pipelined edges on alternating streams; sharded GF-ICF
-with the all-reduce of gene counts.  (RCCL itself needs one GPU per rank; its call pattern is covered
+with the all-reduce of gene counts; the sharded exact kNN search chained into a sharded Jaccard build.  (RCCL itself needs one GPU per rank; its call pattern is covered
 by test_rccl_single_rank_collectives_and_bench_launch_path.)"""
 import os
 import socket
@@ -52,6 +52,19 @@ def _worker(rank, world, port, outdir):
         torch.cuda.synchronize()
         for n, (i, r) in enumerate(res):
             np.save(os.path.join(outdir, f"j_{rank}_{n}.npy"), r.cpu().numpy())
+        # exact kNN sharded by the same cell blocks, its index block chained into a sharded Jaccard build
+        from gficf_amd.dist import KnnShard
+
+        Nk, dk, kk = 5003, 50, 16
+        X = np.random.default_rng(23).normal(size=(Nk, dk)) * np.linspace(0.5, 3.0, dk)
+        kb, ke = shard_bounds(Nk, world, rank)
+        ks = KnnShard(ops, Nk, dk, kk, "manhattan", device="cuda")
+        kidx = ks.step(torch.from_numpy(np.ascontiguousarray(X[kb:ke].T)).cuda())
+        sh2 = JaccardShard(ops, Nk, kk - 1, device="cuda")
+        kj = sh2.step(kidx[1:].contiguous())
+        ops.sync()
+        np.save(os.path.join(outdir, f"knn_{rank}.npy"), kidx.cpu().numpy())
+        np.save(os.path.join(outdir, f"kjac_{rank}.npy"), kj.cpu().numpy())
         # GF-ICF
         G, Nc = 1200, 901
         cp, ri, x = synth.counts_csc(G, Nc, seed=5)
@@ -80,6 +93,13 @@ def test_two_ranks_one_gpu_full_sharded_path(tmp_path):
     for n in range(6):
         got = np.concatenate([np.load(tmp_path / f"j_{r}_{n}.npy") for r in range(world)], axis=1).T
         assert np.array_equal(got, want[n % 3]), n
+    Nk, dk, kk = 5003, 50, 16
+    X = np.random.default_rng(23).normal(size=(Nk, dk)) * np.linspace(0.5, 3.0, dk)
+    widx, _ = oracle.knn(X, kk, "manhattan", nthreads=8)
+    kgot = np.concatenate([np.load(tmp_path / f"knn_{r}.npy") for r in range(world)], axis=1).T
+    assert np.array_equal(kgot, widx)
+    kwant, _ = oracle.jaccard(np.ascontiguousarray(widx[:, 1:]), nthreads=8)
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"kjac_{r}.npy") for r in range(world)], axis=1).T, kwant)
     G, Nc = 1200, 901
     cp, ri, x = synth.counts_csc(G, Nc, seed=5)
     ref = oracle.gficf_csc(G, Nc, cp, ri, x, 0.05, 1.0)
