@@ -24,6 +24,7 @@
 // writes the 1-based index matrix column-major — the layout the Jaccard ingest reads.
 #include <cfloat>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -83,8 +84,13 @@ typedef unsigned long long u64;
 // — an insertion shift with one LDS read and one LDS write per entry, no serial walk, no lock (one wave,
 // program order).  Out of line: it runs rarely once the lists have warmed up and must not cost the
 // distance loop its registers.
+typedef __attribute__((address_space(3))) volatile u64 knn_lds_u64;
+
 template <int KL>
-__device__ __noinline__ void knn_row_insert(volatile u64* list, int kk, const float (&dv)[8], float tau, bool live, int64_t j0, int tid) {
+__device__ __noinline__ float knn_row_insert(uint32_t list_addr, int kk, float d0, float d1, float d2, float d3, float d4, float d5,
+                                             float d6, float d7, float tau, bool live, uint32_t j0, int tid) {
+  knn_lds_u64* const list = (knn_lds_u64*)(size_t)list_addr;      // LDS byte address of the row's list
+  const float dv[8] = {d0, d1, d2, d3, d4, d5, d6, d7};
   const int tx = tid & 15;
   uint32_t pass = 0;
   if (live) {
@@ -104,7 +110,7 @@ __device__ __noinline__ void knn_row_insert(volatile u64* list, int kk, const fl
 #pragma unroll
       for (int t = 1; t < 8; ++t) h = s == t ? dv[t] : h;
       khi = f32_sortable(h);
-      klo = (uint32_t)(j0 + (s < 4 ? 0 : 64) + tx * 4 + (s & 3));
+      klo = j0 + (uint32_t)((s < 4 ? 0 : 64) + tx * 4 + (s & 3));
     }
     const int src = ((tid & 48) | (leader & 15)) << 2;
     khi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)khi);
@@ -126,6 +132,9 @@ __device__ __noinline__ void knn_row_insert(volatile u64* list, int kk, const fl
       }
     }
   }
+  // this wave is the only writer of its rows' lists, so the caller's register copy of the k-th best stays exact
+  const uint32_t tau_hi = (uint32_t)(list[kk - 1] >> 32);
+  return tau_hi == 0xFFFFFFFFu ? INFINITY : sortable_f32(tau_hi);     // list not full yet: everything enters
 }
 
 // One dimension of the 8 x 8 register block.  Accumulators are float pairs (two neighbouring candidates), so
@@ -135,12 +144,20 @@ __device__ __noinline__ void knn_row_insert(volatile u64* list, int kk, const fl
 // the two adds and pay for it with two v_and to clear the sign bits.
 typedef float knn_f2 __attribute__((ext_vector_type(2)));
 
+struct KnnOperands {            // one dimension's slice of the tiles: 8 query values, 8 candidate values
+  float4 a0, a1, b0, b1;
+};
+__device__ inline void knn_read(KnnOperands& o, const float* __restrict__ pa, const float* __restrict__ pb) {
+  o.a0 = *reinterpret_cast<const float4*>(pa);
+  o.a1 = *reinterpret_cast<const float4*>(pa + 64);
+  o.b0 = *reinterpret_cast<const float4*>(pb);
+  o.b1 = *reinterpret_cast<const float4*>(pb + 64);
+}
+
 template <int METRIC>
-__device__ inline void knn_dim(knn_f2 (&acc)[8][4], const float* __restrict__ pa, const float* __restrict__ pb) {
-  const float4 a0 = *reinterpret_cast<const float4*>(pa), a1 = *reinterpret_cast<const float4*>(pa + 64);
-  const float4 b0 = *reinterpret_cast<const float4*>(pb), b1 = *reinterpret_cast<const float4*>(pb + 64);
-  const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-  const knn_f2 b[4] = {{b0.x, b0.y}, {b0.z, b0.w}, {b1.x, b1.y}, {b1.z, b1.w}};
+__device__ inline void knn_dim(knn_f2 (&acc)[8][4], const KnnOperands& o) {
+  const float a[8] = {o.a0.x, o.a0.y, o.a0.z, o.a0.w, o.a1.x, o.a1.y, o.a1.z, o.a1.w};
+  const knn_f2 b[4] = {{o.b0.x, o.b0.y}, {o.b0.z, o.b0.w}, {o.b1.x, o.b1.y}, {o.b1.z, o.b1.w}};
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const knn_f2 ar = {a[r], a[r]};
@@ -167,10 +184,12 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
   float* const sA = reinterpret_cast<float*>(smem);                          // [dpad][TQ]
   float* const sB = sA + (size_t)dpad * KNN_TQ;                              // [2][DK][TC]
   u64* const sKey = reinterpret_cast<u64*>(sB + 2 * KNN_DK * KNN_TC);        // [TQ][KL]
+  const uint32_t key_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)sKey;   // LDS byte address
 
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int qt = blockIdx.x / S, sp = blockIdx.x % S;
   const int64_t q0 = q_begin + (int64_t)qt * KNN_TQ;
+  const int nq_live = q_end - q0 < KNN_TQ ? (int)(q_end - q0) : KNN_TQ;      // rows of the tile that are real queries
   const int64_t n_ct = gficf_ceil_div(N, KNN_TC);
   const int64_t ct0 = n_ct * sp / S, ct1 = n_ct * (sp + 1) / S;
   const int nq4 = dpad >> 2;                         // float4 per point row
@@ -189,9 +208,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
 
   // chunk g of the flattened (candidate tile, dim chunk) sequence: 2 float4 per thread
   const int64_t G = (ct1 - ct0) * nch;
-  auto load_chunk = [&](int64_t g, float4 (&v)[2]) {
-    const int64_t ct = ct0 + g / nch;
-    const int c = (int)(g % nch);
+  auto load_chunk = [&](int64_t ct, int c, float4 (&v)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int f = tid + i * KNN_THREADS;
@@ -223,46 +240,80 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
   for (int r = 0; r < 8; ++r) tau[r] = INFINITY;
 
   float4 pre[2];
-  if (G > 0) { load_chunk(0, pre); store_chunk(0, pre); }
+  if (G > 0) { load_chunk(ct0, 0, pre); store_chunk(0, pre); }
   __syncthreads();
 
+  // (ct, c): candidate tile and dim chunk of step g; (nct, nc): those of step g + 1 (no divisions in the loop)
+  int64_t ct = ct0, nct = ct0;
+  int c = 0, nc = 0;
   for (int64_t g = 0; g < G; ++g) {
-    const int c = (int)(g % nch);
-    if (g + 1 < G) load_chunk(g + 1, pre);
+    ct = nct; c = nc;
+    if (++nc == nch) { nc = 0; ++nct; }
+    if (g + 1 < G) load_chunk(nct, nc, pre);
     const float* const pa = sA + (size_t)(c * KNN_DK) * KNN_TQ + ty * 4;
     const float* const pb = sB + (size_t)(g & 1) * KNN_DK * KNN_TC + tx * 4;
     const int nd = d - c * KNN_DK < KNN_DK ? d - c * KNN_DK : KNN_DK;
     if (nd == KNN_DK) {
-#pragma unroll 4
-      for (int t = 0; t < KNN_DK; ++t) knn_dim<METRIC>(acc, pa + t * KNN_TQ, pb + t * KNN_TC);
+      // operands of the next dimension are read from LDS while the current one is being accumulated
+      KnnOperands oa, ob;
+      knn_read(oa, pa, pb);
+#pragma unroll 2
+      for (int t = 0; t < KNN_DK; t += 2) {
+        knn_read(ob, pa + (t + 1) * KNN_TQ, pb + (t + 1) * KNN_TC);
+        knn_dim<METRIC>(acc, oa);
+        if (t + 2 < KNN_DK) knn_read(oa, pa + (t + 2) * KNN_TQ, pb + (t + 2) * KNN_TC);
+        knn_dim<METRIC>(acc, ob);
+      }
     } else {
-      for (int t = 0; t < nd; ++t) knn_dim<METRIC>(acc, pa + t * KNN_TQ, pb + t * KNN_TC);
+      // short last chunk, two dims per round (the point rows are zero padded to a multiple of 4 dims, and a
+      // zero dim adds exactly 0 to every metric's accumulator)
+      KnnOperands oa, ob;
+#pragma unroll 1
+      for (int t = 0; t < nd; t += 2) {
+        knn_read(oa, pa + t * KNN_TQ, pb + t * KNN_TC);
+        knn_read(ob, pa + (t + 1) * KNN_TQ, pb + (t + 1) * KNN_TC);
+        knn_dim<METRIC>(acc, oa);
+        knn_dim<METRIC>(acc, ob);
+      }
     }
     if (c == nch - 1) {
       // the tile's 8 x 8 distances of this thread against the current k-th best of their queries
-      const int64_t j0 = (ct0 + g / nch) * KNN_TC;
-      const bool ragged = j0 + KNN_TC > N;           // last tile: candidates beyond N must not enter
+      const int64_t j0 = ct * KNN_TC;
+      // Only the data set's last candidate tile can hold fewer than TC points; it gets its own copy of the
+      // code below (RAG), so that all the other tiles do not pay for the masking.
+      auto epilogue = [&](auto rag_tag) {
+        constexpr bool RAG = decltype(rag_tag)::value;
+        const int nvalid = (int)(N - j0);                      // RAG only: candidates at columns >= nvalid do not exist
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int row = (r < 4 ? 0 : 64) + ty * 4 + (r & 3);
-        volatile u64* const list = sKey + row * KL;
-        float dv[8];
+        for (int r = 0; r < 8; ++r) {
+          const int row = (r < 4 ? 0 : 64) + ty * 4 + (r & 3);
+          const bool live = row < nq_live;
+          // common case after the first tiles: nothing in the whole wave beats its query's k-th best
+          bool any = false;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const float av = (s & 1) ? acc[r][s >> 1].y : acc[r][s >> 1].x;
-          dv[s] = METRIC == GFICF_KNN_COSINE ? 1.0f - av : av;
-          if (ragged && j0 + (s < 4 ? 0 : 64) + tx * 4 + (s & 3) >= N) dv[s] = NAN;      // never <= tau, ignored by fminf
+          for (int s = 0; s < 8; ++s) {
+            const float av = (s & 1) ? acc[r][s >> 1].y : acc[r][s >> 1].x;
+            bool ok = (METRIC == GFICF_KNN_COSINE ? 1.0f - av : av) <= tau[r];
+            if (RAG) ok = ok && (s < 4 ? 0 : 64) + tx * 4 + (s & 3) < nvalid;
+            any |= ok;
+          }
+          if (__ballot(any && live) != 0) {
+            float dv[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+              const float av = (s & 1) ? acc[r][s >> 1].y : acc[r][s >> 1].x;
+              dv[s] = METRIC == GFICF_KNN_COSINE ? 1.0f - av : av;
+              if (RAG && (s < 4 ? 0 : 64) + tx * 4 + (s & 3) >= nvalid) dv[s] = NAN;       // never <= tau
+            }
+            tau[r] = knn_row_insert<KL>(key_addr + (uint32_t)(row * KL * 8), kk, dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6],
+                                        dv[7], tau[r], live, (uint32_t)j0, tid);
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[r][s] = knn_f2{0.0f, 0.0f};
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[r][s] = knn_f2{0.0f, 0.0f};
-        const float mn = fminf(fminf(fminf(dv[0], dv[1]), fminf(dv[2], dv[3])), fminf(fminf(dv[4], dv[5]), fminf(dv[6], dv[7])));
-        // common case after the first tiles: nothing in the whole wave beats its query's k-th best
-        if (__ballot(mn <= tau[r] && q0 + row < q_end) == 0) continue;
-        knn_row_insert<KL>(list, kk, dv, tau[r], q0 + row < q_end, j0, tid);
-        // this wave is the only writer of its rows' lists, so the register copy of the k-th best stays exact
-        const uint32_t tau_hi = (uint32_t)(list[kk - 1] >> 32);
-        tau[r] = tau_hi == 0xFFFFFFFFu ? INFINITY : sortable_f32(tau_hi);     // list not full yet: everything enters
-      }
+      };
+      if (j0 + KNN_TC > N) epilogue(std::true_type{});
+      else epilogue(std::false_type{});
     }
     if (g + 1 < G) store_chunk((int)((g + 1) & 1), pre);
     __syncthreads();

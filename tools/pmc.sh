@@ -13,7 +13,7 @@ for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_A
             "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum TCC_EA0_WRREQ_64B_sum" \
             "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum" ; do
   P=$((P+1))
-  (cd /tmp && timeout 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/p$P -o pmc -- python3 $GRAFT_REPO_ROOT/tools/prof_driver.py > $GRAFT_REPO_ROOT/$OUT/p$P.log 2>&1) || echo "pass $P failed: $(tail -2 $OUT/p$P.log)"
+  (cd /tmp && timeout 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/p$P -o pmc -- python3 $GRAFT_REPO_ROOT/tools/${PROF_DRIVER:-prof_driver.py} > $GRAFT_REPO_ROOT/$OUT/p$P.log 2>&1) || echo "pass $P failed: $(tail -2 $OUT/p$P.log)"
 done
 python - <<PY
 import csv, glob, collections, re
