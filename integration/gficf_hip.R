@@ -23,3 +23,17 @@ gficf = function(M, cell_proportion_max = 1, cell_proportion_min = 0.05, storeRa
 # embedNewCells() keeps its name matching (reference R/gficf.R:69-78) in R and calls
 #   .Call(`_gficf_gficf_csc`, x@i, x@p, x@x, x@Dim, as.numeric(data$w[rownames(x)]), 0, 2)
 # in place of tf() / idf() / l.norm() (reference R/cellClassifier.R:50-53).
+
+# Optional ("next" row N2): exact neighbour search for clustcells().  Replaces the two lines
+#   neigh = uwot:::find_nn(data$pca$cells, k = k+1, include_self = T, n_threads = nt, verbose = verbose,
+#                          method = "annoy", metric = dist.method)$idx          (reference R/clustCells.R:57,60)
+# with
+#   neigh = find_nn_hip(data$pca$cells, k = k+1, metric = dist.method)$idx
+# Same result shape (idx: N x (k+1) integer matrix, 1-based, first column the cell itself; dist).  Exact, not
+# approximate: ties broken by the smaller index; f32 arithmetic like Annoy's.
+find_nn_hip = function(X, k, metric = "manhattan")
+{
+  m = match(metric, c("manhattan", "euclidean", "cosine")) - 1L
+  if (is.na(m)) stop("metric must be manhattan, euclidean or cosine")
+  .Call(`_gficf_find_nn`, as.matrix(X) + 0, as.integer(k), m)
+}

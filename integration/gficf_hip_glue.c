@@ -13,6 +13,8 @@
  *       (src/RcppExports.cpp:61): R/RcppExports.R:16-18 and clustcells() (R/clustCells.R:65) stay as is.
  *   _gficf_gficf_csc(i, p, x, dim, w, min, max)          — NEW entry for the GF-ICF chain of
  *       R/gficf.R:38-105 (the reference has no native entry on that path).
+ *   _gficf_find_nn(X, k, metric)                         — NEW, optional: exact kNN in place of the
+ *       uwot:::find_nn(..., method = "annoy") call of clustcells() (R/clustCells.R:57,60).
  */
 #include <R.h>
 #include <Rinternals.h>
@@ -77,9 +79,32 @@ SEXP _gficf_gficf_csc(SEXP iS, SEXP pS, SEXP xS, SEXP dimS, SEXP wS, SEXP minS, 
   return out;
 }
 
+/* Optional: exact neighbour search in place of the approximate uwot:::find_nn(..., method = "annoy") call of
+ * clustcells() (reference R/clustCells.R:57,60).  X: numeric N x d matrix; returns list(idx = N x k integer
+ * matrix (1-based, column 1 = the cell itself), dist = N x k numeric) like uwot's result.
+ * metric: 0 manhattan, 1 euclidean, 2 cosine. */
+SEXP _gficf_find_nn(SEXP XS, SEXP kS, SEXP metricS) {
+  if (!Rf_isMatrix(XS) || TYPEOF(XS) != REALSXP) Rf_error("X must be a numeric matrix");
+  SEXP dim = Rf_getAttrib(XS, R_DimSymbol);
+  const int64_t N = INTEGER(dim)[0];
+  const int d = INTEGER(dim)[1], k = Rf_asInteger(kS);
+  SEXP idx = PROTECT(Rf_allocMatrix(INTSXP, (int)N, k)), dist = PROTECT(Rf_allocMatrix(REALSXP, (int)N, k));
+  if (gficf_knn_host(ctx_get(), REAL(XS), N, d, N, k, Rf_asInteger(metricS), INTEGER(idx), REAL(dist)) != GFICF_OK) {
+    UNPROTECT(2);
+    Rf_error("gficf_hip: %s", gficf_last_error());
+  }
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 2)), nm = PROTECT(Rf_allocVector(STRSXP, 2));
+  SET_VECTOR_ELT(out, 0, idx); SET_VECTOR_ELT(out, 1, dist);
+  SET_STRING_ELT(nm, 0, Rf_mkChar("idx")); SET_STRING_ELT(nm, 1, Rf_mkChar("dist"));
+  Rf_setAttrib(out, R_NamesSymbol, nm);
+  UNPROTECT(4);
+  return out;
+}
+
 static const R_CallMethodDef HipCallEntries[] = {
     {"_gficf_rcpp_parallel_jaccard_coef", (DL_FUNC)&_gficf_rcpp_parallel_jaccard_coef, 2},
     {"_gficf_gficf_csc", (DL_FUNC)&_gficf_gficf_csc, 7},
+    {"_gficf_find_nn", (DL_FUNC)&_gficf_find_nn, 3},
     {NULL, NULL, 0}};
 
 /* Called from the package's R_init_gficf (reference src/RcppExports.cpp:94-97) next to the Rcpp entries:
