@@ -13,9 +13,9 @@
 // |x|^2+|y|^2-2xy would change the rounding and with it the order of near-ties).
 //
 // Layout: points row-major f32 [N][dpad] (dpad = d rounded up to 4, zero padded; cosine: rows
-// L2-normalised by the prepare kernel).  One workgroup = a tile of 128 queries x a slice of the
+// L2-normalised by the prepare kernel).  One workgroup = a tile of 64 queries x a slice of the
 // candidates: the query tile stays in LDS ([dim][query]), candidate tiles of 128 points stream
-// through a double-buffered LDS chunk of 16 dims; every thread accumulates an 8 x 8 block of
+// through a double-buffered LDS chunk of 16 dims; every thread accumulates a 4 x 8 block of
 // distances in registers.  Per query a sorted list of the k best 64-bit keys
 // (sortable(distance) << 32 | index) lives in LDS; a thread inserts a candidate only when it beats
 // the list's last key (rare after the first tiles).  A query's row of the tile belongs to the 16 lanes
@@ -31,7 +31,6 @@
 
 namespace {
 
-constexpr int KNN_TQ = 128;        // queries per workgroup
 constexpr int KNN_TC = 128;        // candidates per tile
 constexpr int KNN_DK = 16;         // dims per LDS chunk of the candidate tile
 constexpr int KNN_THREADS = 256;
@@ -144,22 +143,24 @@ __device__ __noinline__ float knn_row_insert(uint32_t list_addr, int kk, float d
 // the two adds and pay for it with two v_and to clear the sign bits.
 typedef float knn_f2 __attribute__((ext_vector_type(2)));
 
-struct KnnOperands {            // one dimension's slice of the tiles: 8 query values, 8 candidate values
+// RQ = query rows per thread: 8 (tile of 128 queries: rows ty*4.. and 64+ty*4..) or 4 (tile of 64 queries).
+struct KnnOperands {            // one dimension's slice of the tiles: RQ query values, 8 candidate values
   float4 a0, a1, b0, b1;
 };
+template <int RQ>
 __device__ inline void knn_read(KnnOperands& o, const float* __restrict__ pa, const float* __restrict__ pb) {
   o.a0 = *reinterpret_cast<const float4*>(pa);
-  o.a1 = *reinterpret_cast<const float4*>(pa + 64);
+  if (RQ == 8) o.a1 = *reinterpret_cast<const float4*>(pa + 64);
   o.b0 = *reinterpret_cast<const float4*>(pb);
   o.b1 = *reinterpret_cast<const float4*>(pb + 64);
 }
 
-template <int METRIC>
-__device__ inline void knn_dim(knn_f2 (&acc)[8][4], const KnnOperands& o) {
+template <int METRIC, int RQ>
+__device__ inline void knn_dim(knn_f2 (&acc)[RQ][4], const KnnOperands& o) {
   const float a[8] = {o.a0.x, o.a0.y, o.a0.z, o.a0.w, o.a1.x, o.a1.y, o.a1.z, o.a1.w};
   const knn_f2 b[4] = {{o.b0.x, o.b0.y}, {o.b0.z, o.b0.w}, {o.b1.x, o.b1.y}, {o.b1.z, o.b1.w}};
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
+  for (int r = 0; r < RQ; ++r) {
     const knn_f2 ar = {a[r], a[r]};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -177,33 +178,34 @@ __device__ inline void knn_dim(knn_f2 (&acc)[8][4], const KnnOperands& o) {
   }
 }
 
-template <int METRIC, int KL>
+template <int METRIC, int KL, int RQ>
 __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __restrict__ X, int64_t N, int d, int dpad, int kk,
                                                            int64_t q_begin, int64_t q_end, int S, u64* __restrict__ part) {
+  constexpr int TQ = 16 * RQ;                                                // queries per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const sA = reinterpret_cast<float*>(smem);                          // [dpad][TQ]
-  float* const sB = sA + (size_t)dpad * KNN_TQ;                              // [2][DK][TC]
+  float* const sB = sA + (size_t)dpad * TQ;                              // [2][DK][TC]
   u64* const sKey = reinterpret_cast<u64*>(sB + 2 * KNN_DK * KNN_TC);        // [TQ][KL]
   const uint32_t key_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)sKey;   // LDS byte address
 
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int qt = blockIdx.x / S, sp = blockIdx.x % S;
-  const int64_t q0 = q_begin + (int64_t)qt * KNN_TQ;
-  const int nq_live = q_end - q0 < KNN_TQ ? (int)(q_end - q0) : KNN_TQ;      // rows of the tile that are real queries
+  const int64_t q0 = q_begin + (int64_t)qt * TQ;
+  const int nq_live = q_end - q0 < TQ ? (int)(q_end - q0) : TQ;      // rows of the tile that are real queries
   const int64_t n_ct = gficf_ceil_div(N, KNN_TC);
   const int64_t ct0 = n_ct * sp / S, ct1 = n_ct * (sp + 1) / S;
   const int nq4 = dpad >> 2;                         // float4 per point row
   const int nch = (d + KNN_DK - 1) / KNN_DK;         // chunks per candidate tile (padded dims are skipped)
   const float4* const X4 = reinterpret_cast<const float4*>(X);
 
-  for (int e = tid; e < KNN_TQ * KL; e += KNN_THREADS) sKey[e] = ~0ull;
+  for (int e = tid; e < TQ * KL; e += KNN_THREADS) sKey[e] = ~0ull;
   // query tile -> sA[dim][query]; consecutive lanes take consecutive queries (conflict-free LDS writes)
-  for (int f = tid; f < KNN_TQ * nq4; f += KNN_THREADS) {
-    const int row = f & (KNN_TQ - 1), quad = f >> 7;
+  for (int f = tid; f < TQ * nq4; f += KNN_THREADS) {
+    const int row = f & (TQ - 1), quad = f / TQ;
     const int64_t q = q0 + row;
     const float4 v = q < N ? X4[q * nq4 + quad] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float* o = sA + (size_t)(quad * 4) * KNN_TQ + row;
-    o[0] = v.x; o[KNN_TQ] = v.y; o[2 * KNN_TQ] = v.z; o[3 * KNN_TQ] = v.w;
+    float* o = sA + (size_t)(quad * 4) * TQ + row;
+    o[0] = v.x; o[TQ] = v.y; o[2 * TQ] = v.z; o[3 * TQ] = v.w;
   }
 
   // chunk g of the flattened (candidate tile, dim chunk) sequence: 2 float4 per thread
@@ -229,15 +231,15 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
     }
   };
 
-  knn_f2 acc[8][4];
+  knn_f2 acc[RQ][4];
 #pragma unroll
-  for (int r = 0; r < 8; ++r)
+  for (int r = 0; r < RQ; ++r)
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc[r][s] = knn_f2{0.0f, 0.0f};
 
-  float tau[8];                 // current k-th best distance of this thread's 8 query rows
+  float tau[RQ];                // current k-th best distance of this thread's query rows
 #pragma unroll
-  for (int r = 0; r < 8; ++r) tau[r] = INFINITY;
+  for (int r = 0; r < RQ; ++r) tau[r] = INFINITY;
 
   float4 pre[2];
   if (G > 0) { load_chunk(ct0, 0, pre); store_chunk(0, pre); }
@@ -250,19 +252,19 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
     ct = nct; c = nc;
     if (++nc == nch) { nc = 0; ++nct; }
     if (g + 1 < G) load_chunk(nct, nc, pre);
-    const float* const pa = sA + (size_t)(c * KNN_DK) * KNN_TQ + ty * 4;
+    const float* const pa = sA + (size_t)(c * KNN_DK) * TQ + ty * 4;
     const float* const pb = sB + (size_t)(g & 1) * KNN_DK * KNN_TC + tx * 4;
     const int nd = d - c * KNN_DK < KNN_DK ? d - c * KNN_DK : KNN_DK;
     if (nd == KNN_DK) {
       // operands of the next dimension are read from LDS while the current one is being accumulated
       KnnOperands oa, ob;
-      knn_read(oa, pa, pb);
+      knn_read<RQ>(oa, pa, pb);
 #pragma unroll 2
       for (int t = 0; t < KNN_DK; t += 2) {
-        knn_read(ob, pa + (t + 1) * KNN_TQ, pb + (t + 1) * KNN_TC);
-        knn_dim<METRIC>(acc, oa);
-        if (t + 2 < KNN_DK) knn_read(oa, pa + (t + 2) * KNN_TQ, pb + (t + 2) * KNN_TC);
-        knn_dim<METRIC>(acc, ob);
+        knn_read<RQ>(ob, pa + (t + 1) * TQ, pb + (t + 1) * KNN_TC);
+        knn_dim<METRIC, RQ>(acc, oa);
+        if (t + 2 < KNN_DK) knn_read<RQ>(oa, pa + (t + 2) * TQ, pb + (t + 2) * KNN_TC);
+        knn_dim<METRIC, RQ>(acc, ob);
       }
     } else {
       // short last chunk, two dims per round (the point rows are zero padded to a multiple of 4 dims, and a
@@ -270,10 +272,10 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
       KnnOperands oa, ob;
 #pragma unroll 1
       for (int t = 0; t < nd; t += 2) {
-        knn_read(oa, pa + t * KNN_TQ, pb + t * KNN_TC);
-        knn_read(ob, pa + (t + 1) * KNN_TQ, pb + (t + 1) * KNN_TC);
-        knn_dim<METRIC>(acc, oa);
-        knn_dim<METRIC>(acc, ob);
+        knn_read<RQ>(oa, pa + t * TQ, pb + t * KNN_TC);
+        knn_read<RQ>(ob, pa + (t + 1) * TQ, pb + (t + 1) * KNN_TC);
+        knn_dim<METRIC, RQ>(acc, oa);
+        knn_dim<METRIC, RQ>(acc, ob);
       }
     }
     if (c == nch - 1) {
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
         constexpr bool RAG = decltype(rag_tag)::value;
         const int nvalid = (int)(N - j0);                      // RAG only: candidates at columns >= nvalid do not exist
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < RQ; ++r) {
           const int row = (r < 4 ? 0 : 64) + ty * 4 + (r & 3);
           const bool live = row < nq_live;
           // common case after the first tiles: nothing in the whole wave beats its query's k-th best
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
   }
 
   // partial lists of this candidate slice
-  for (int e = tid; e < KNN_TQ * kk; e += KNN_THREADS) {
+  for (int e = tid; e < TQ * kk; e += KNN_THREADS) {
     const int row = e / kk, t = e % kk;
     const int64_t q = q0 + row;
     if (q < q_end) part[((q - q_begin) * S + sp) * kk + t] = sKey[row * KL + t];
@@ -360,8 +362,17 @@ __global__ __launch_bounds__(256) void k_knn_merge(const u64* __restrict__ part,
   }
 }
 
-int knn_split(const gficf_ctx* ctx, int64_t n_q, int64_t N) {
-  const int64_t n_qt = gficf_ceil_div(n_q > 0 ? n_q : 1, KNN_TQ), n_ct = gficf_ceil_div(N > 0 ? N : 1, KNN_TC);
+// Query rows per thread: 4 (64-query tiles) by default.  Measured at 100 k x 50, 31 nearest, manhattan: 64-query tiles
+// 27.7 ms, 128-query tiles 33.1 ms — the smaller tile halves the candidate splits' insertions and the per-tile
+// epilogue weighs less; LDS operand traffic per VALU instruction is higher but the LDS pipe has the room.
+// GFICF_KNN_RQ=8 selects the 128-query tile for lists of at most 32 entries (tuning knob).
+inline int knn_rq(int k) {
+  static const int forced = getenv("GFICF_KNN_RQ") ? atoi(getenv("GFICF_KNN_RQ")) : 0;
+  return (k <= 32 && forced == 8) ? 8 : 4;
+}
+
+int knn_split(const gficf_ctx* ctx, int64_t n_q, int64_t N, int k) {
+  const int64_t n_qt = gficf_ceil_div(n_q > 0 ? n_q : 1, 16 * knn_rq(k)), n_ct = gficf_ceil_div(N > 0 ? N : 1, KNN_TC);
   // enough work items for ~8 per CU, but every candidate slice at least 8 tiles long
   int64_t S = gficf_ceil_div((int64_t)ctx->num_cus * 8, n_qt);
   if (S > n_ct / 8) S = n_ct / 8;
@@ -385,26 +396,27 @@ int knn_check(int64_t N, int d, int k, int metric) {
   return GFICF_OK;
 }
 
-template <int METRIC, int KL>
+template <int METRIC, int KL, int RQ>
 int knn_launch(gficf_ctx* ctx, const float* X, int64_t N, int d, int kk, int64_t qb, int64_t qe, int S, u64* part) {
   const int dpad = knn_dpad(d);
-  const size_t lds = (size_t)dpad * KNN_TQ * 4 + 2 * KNN_DK * KNN_TC * 4 + (size_t)KNN_TQ * KL * 8;
+  constexpr int TQ = 16 * RQ;
+  const size_t lds = (size_t)dpad * TQ * 4 + 2 * KNN_DK * KNN_TC * 4 + (size_t)TQ * KL * 8;
   static bool attr_set[64] = {};
   if (!attr_set[ctx->device & 63]) {
-    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_knn_tiles<METRIC, KL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_knn_tiles<METRIC, KL, RQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[ctx->device & 63] = true;
   }
-  const int64_t blocks = gficf_ceil_div(qe - qb, KNN_TQ) * S;
-  hipLaunchKernelGGL((k_knn_tiles<METRIC, KL>), dim3((unsigned)blocks), dim3(KNN_THREADS), lds, ctx->stream, X, N, d, dpad, kk, qb, qe, S, part);
+  const int64_t blocks = gficf_ceil_div(qe - qb, TQ) * S;
+  hipLaunchKernelGGL((k_knn_tiles<METRIC, KL, RQ>), dim3((unsigned)blocks), dim3(KNN_THREADS), lds, ctx->stream, X, N, d, dpad, kk, qb, qe, S, part);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
 
 template <int METRIC>
 int knn_launch_k(gficf_ctx* ctx, const float* X, int64_t N, int d, int kk, int64_t qb, int64_t qe, int S, u64* part) {
-  if (kk <= 32) return knn_launch<METRIC, 32>(ctx, X, N, d, kk, qb, qe, S, part);
-  if (kk <= 64) return knn_launch<METRIC, 64>(ctx, X, N, d, kk, qb, qe, S, part);
-  return knn_launch<METRIC, 128>(ctx, X, N, d, kk, qb, qe, S, part);
+  if (kk <= 32) return knn_rq(kk) == 8 ? knn_launch<METRIC, 32, 8>(ctx, X, N, d, kk, qb, qe, S, part) : knn_launch<METRIC, 32, 4>(ctx, X, N, d, kk, qb, qe, S, part);
+  if (kk <= 64) return knn_launch<METRIC, 64, 4>(ctx, X, N, d, kk, qb, qe, S, part);
+  return knn_launch<METRIC, 128, 4>(ctx, X, N, d, kk, qb, qe, S, part);
 }
 
 }  // namespace
@@ -432,7 +444,7 @@ int gficf_knn_prepare_device(gficf_ctx* ctx, const void* d_X, int x_is_f64, int6
 
 size_t gficf_knn_workspace_bytes(gficf_ctx* ctx, int64_t n_queries, int64_t N, int k) {
   if (!ctx || n_queries <= 0 || N <= 0 || k <= 0) return 16;
-  return (size_t)n_queries * (size_t)knn_split(ctx, n_queries, N) * (size_t)k * sizeof(u64) + 16;
+  return (size_t)n_queries * (size_t)knn_split(ctx, n_queries, N, k) * (size_t)k * sizeof(u64) + 16;
 }
 
 int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, int d, int k, int metric, int64_t q_begin,
@@ -448,7 +460,7 @@ int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, in
   if (!d_points || !d_ws || !d_idx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   if (ld_out < n_q) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld_out = %lld < number of queries %lld", (long long)ld_out, (long long)n_q);
   if (ws_bytes < gficf_knn_workspace_bytes(ctx, n_q, N, k)) GFICF_FAIL(GFICF_ERR_CAPACITY, "kNN workspace too small");
-  const int S = knn_split(ctx, n_q, N);
+  const int S = knn_split(ctx, n_q, N, k);
   u64* part = (u64*)d_ws;
   switch (metric) {
     case GFICF_KNN_MANHATTAN: rc = knn_launch_k<GFICF_KNN_MANHATTAN>(ctx, d_points, N, d, k, q_begin, q_end, S, part); break;

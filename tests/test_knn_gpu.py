@@ -69,6 +69,39 @@ def test_duplicates_and_ties_break_by_index():
         assert np.all(got["idx"][40:80, 0] <= np.arange(1, 41))
 
 
+@pytest.mark.parametrize("N,d,k", [(5, 1, 5), (64, 1, 64), (100, 3, 100), (127, 50, 33), (200, 5, 64), (257, 2, 65)])
+def test_small_and_degenerate_shapes(N, d, k):
+    # fewer points than one tile, one dimension, every point a neighbour (k = N), list lengths at the 32 / 64 seams
+    X = blobs(N, d, seed=N * 7 + k, centers=3)
+    for metric in ("manhattan", "euclidean", "cosine"):
+        got = gficf_amd.find_nn(X, k, True, metric)
+        widx, wdist = oracle.knn(X, k, metric)
+        assert np.array_equal(got["idx"], widx), metric
+        assert np.array_equal(got["dist"].astype(np.float32), wdist.astype(np.float32)), metric
+    if k == N:
+        assert all(sorted(r) == list(range(1, N + 1)) for r in gficf_amd.find_nn(X, k)["idx"].tolist())
+
+
+def test_float32_input_and_zero_rows_cosine(ops):
+    import torch
+
+    N, d, k = 900, 12, 10
+    X = blobs(N, d, seed=4).astype(np.float32)
+    X[17] = 0.0                                                     # a zero vector: cosine distance 1 to everything
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda()         # f32 column-major block
+    pts = torch.zeros((N, ops.knn_dpad(d)), dtype=torch.float32, device="cuda")
+    ops.knn_prepare(Xd, N, d, "cosine", pts)
+    ws = torch.zeros(ops.knn_workspace_bytes(N, N, k), dtype=torch.uint8, device="cuda")
+    idx = torch.zeros((k, N), dtype=torch.int32, device="cuda")
+    dist = torch.zeros((k, N), dtype=torch.float32, device="cuda")
+    ops.knn_search(pts, N, d, k, "cosine", 0, N, ws, idx, dist)
+    ops.sync()
+    widx, wdist = oracle.knn(X.astype(np.float64), k, "cosine", nthreads=4)
+    assert np.array_equal(idx.cpu().numpy().T, widx)
+    assert np.array_equal(dist.cpu().numpy().T, wdist.astype(np.float32))
+    assert np.all(dist.cpu().numpy().T[17] == 1.0)
+
+
 def test_include_self_false_drops_own_id():
     X = blobs(500, 10, seed=9)
     a = gficf_amd.find_nn(X, 11, True, "manhattan")
