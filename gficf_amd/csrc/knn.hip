@@ -9,8 +9,9 @@
 //
 // Metrics: manhattan (the reference's default, R/clustCells.R:46), euclidean, cosine (1 - cos).
 // Manhattan is |a-b| accumulation — VALU work, not a contraction, so no MFMA; euclidean and cosine
-// share the same register-tiled kernel with an fma chain in dimension order (an MFMA formulation
-// |x|^2+|y|^2-2xy would change the rounding and with it the order of near-ties).
+// share the same register-tiled kernel with a packed-fma chain in dimension order (an MFMA formulation
+// |x|^2+|y|^2-2xy would change the rounding and with it the order of near-ties, and in f32 the matrix
+// cores peak at the same 157 TFLOP/s as v_pk_fma_f32).
 //
 // Layout: points row-major f32 [N][dpad] (dpad = d rounded up to 4, zero padded; cosine: rows
 // L2-normalised by the prepare kernel).  One workgroup = a tile of 64 queries x a slice of the
