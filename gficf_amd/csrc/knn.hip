@@ -209,28 +209,28 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
     o[0] = v.x; o[TQ] = v.y; o[2 * TQ] = v.z; o[3 * TQ] = v.w;
   }
 
-  // chunk g of the flattened (candidate tile, dim chunk) sequence: 2 float4 per thread
+  // Staging of the candidate tiles: step g of the flattened (candidate tile, dim chunk) sequence moves
+  // 128 points x 16 dims = 512 float4, two per thread (point row_l, float4 columns quad0 and quad0 + 2 of the
+  // chunk).  The source pointer advances by a constant per step; consecutive lanes take consecutive points, so
+  // the transposing LDS writes are conflict-free.
   const int64_t G = (ct1 - ct0) * nch;
-  auto load_chunk = [&](int64_t ct, int c, float4 (&v)[2]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int f = tid + i * KNN_THREADS;
-      const int row = f & (KNN_TC - 1), quad = f >> 7;
-      const int64_t j = ct * KNN_TC + row;
-      const int q4 = c * (KNN_DK / 4) + quad;
-      v[i] = (j < N && q4 < nq4) ? X4[j * nq4 + q4] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+  const int row_l = tid & (KNN_TC - 1), quad0 = tid >> 7;
+  const float4* pn = X4 + (ct0 * KNN_TC + row_l) * nq4 + quad0;             // chunk of the NEXT load
+  const int64_t tile_step = (int64_t)KNN_TC * nq4 - (int64_t)(nch - 1) * (KNN_DK / 4);
+  float* const st0 = sB + (size_t)(quad0 * 4) * KNN_TC + row_l;             // LDS destination inside a buffer
+  auto load_chunk = [&](int c, int nvalid, float4 (&v)[2]) {
+    const bool rowok = row_l < nvalid;
+    const int q4 = c * (KNN_DK / 4) + quad0;
+    v[0] = (rowok && q4 < nq4) ? pn[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[1] = (rowok && q4 + 2 < nq4) ? pn[2] : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto store_chunk = [&](int buf, const float4 (&v)[2]) {
-    float* const base = sB + (size_t)buf * KNN_DK * KNN_TC;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int f = tid + i * KNN_THREADS;
-      const int row = f & (KNN_TC - 1), quad = f >> 7;
-      float* o = base + (size_t)(quad * 4) * KNN_TC + row;
-      o[0] = v[i].x; o[KNN_TC] = v[i].y; o[2 * KNN_TC] = v[i].z; o[3 * KNN_TC] = v[i].w;
-    }
+    float* o = st0 + (size_t)buf * KNN_DK * KNN_TC;
+    o[0] = v[0].x; o[KNN_TC] = v[0].y; o[2 * KNN_TC] = v[0].z; o[3 * KNN_TC] = v[0].w;
+    o += 8 * KNN_TC;
+    o[0] = v[1].x; o[KNN_TC] = v[1].y; o[2 * KNN_TC] = v[1].z; o[3 * KNN_TC] = v[1].w;
   };
+  auto tile_valid = [&](int64_t t) { return N - t * KNN_TC < KNN_TC ? (int)(N - t * KNN_TC) : KNN_TC; };
 
   knn_f2 acc[RQ][4];
 #pragma unroll
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
   for (int r = 0; r < RQ; ++r) tau[r] = INFINITY;
 
   float4 pre[2];
-  if (G > 0) { load_chunk(ct0, 0, pre); store_chunk(0, pre); }
+  if (G > 0) { load_chunk(0, tile_valid(ct0), pre); store_chunk(0, pre); }
   __syncthreads();
 
   // (ct, c): candidate tile and dim chunk of step g; (nct, nc): those of step g + 1 (no divisions in the loop)
@@ -251,31 +251,24 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
   int c = 0, nc = 0;
   for (int64_t g = 0; g < G; ++g) {
     ct = nct; c = nc;
-    if (++nc == nch) { nc = 0; ++nct; }
-    if (g + 1 < G) load_chunk(nct, nc, pre);
+    if (++nc == nch) { nc = 0; ++nct; pn += tile_step; } else { pn += KNN_DK / 4; }
+    if (g + 1 < G) load_chunk(nc, tile_valid(nct), pre);
     const float* const pa = sA + (size_t)(c * KNN_DK) * TQ + ty * 4;
     const float* const pb = sB + (size_t)(g & 1) * KNN_DK * KNN_TC + tx * 4;
     const int nd = d - c * KNN_DK < KNN_DK ? d - c * KNN_DK : KNN_DK;
-    if (nd == KNN_DK) {
-      // operands of the next dimension are read from LDS while the current one is being accumulated
+    {
+      // Two dims per round (the point rows are zero padded to a multiple of 4 dims, and a zero dim adds exactly 0 to
+      // every metric's accumulator, so an odd d costs one padded dim).  The operands of the next dim are read from
+      // LDS while the current one is accumulated.  One rolled loop for full and short chunks alike: the
+      // accumulators never change registers.
+      const int np = (nd + 1) >> 1;
       KnnOperands oa, ob;
       knn_read<RQ>(oa, pa, pb);
-#pragma unroll 2
-      for (int t = 0; t < KNN_DK; t += 2) {
-        knn_read<RQ>(ob, pa + (t + 1) * TQ, pb + (t + 1) * KNN_TC);
+#pragma unroll 1       // measured: unroll 2 duplicates the body with a remainder copy and runs 45 % slower
+      for (int t = 0; t < np; ++t) {
+        knn_read<RQ>(ob, pa + (2 * t + 1) * TQ, pb + (2 * t + 1) * KNN_TC);
         knn_dim<METRIC, RQ>(acc, oa);
-        if (t + 2 < KNN_DK) knn_read<RQ>(oa, pa + (t + 2) * TQ, pb + (t + 2) * KNN_TC);
-        knn_dim<METRIC, RQ>(acc, ob);
-      }
-    } else {
-      // short last chunk, two dims per round (the point rows are zero padded to a multiple of 4 dims, and a
-      // zero dim adds exactly 0 to every metric's accumulator)
-      KnnOperands oa, ob;
-#pragma unroll 1
-      for (int t = 0; t < nd; t += 2) {
-        knn_read<RQ>(oa, pa + t * TQ, pb + t * KNN_TC);
-        knn_read<RQ>(ob, pa + (t + 1) * TQ, pb + (t + 1) * KNN_TC);
-        knn_dim<METRIC, RQ>(acc, oa);
+        if (t + 1 < np) knn_read<RQ>(oa, pa + (2 * t + 2) * TQ, pb + (2 * t + 2) * KNN_TC);
         knn_dim<METRIC, RQ>(acc, ob);
       }
     }
