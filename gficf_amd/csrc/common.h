@@ -22,7 +22,8 @@ struct gficf_ctx {
   int num_cus = 256;
   uint32_t* d_status = nullptr;   // device status word
   uint32_t* h_status = nullptr;   // pinned host mirror
-  void* d_ws = nullptr;           // scan partials (fixed size, allocated at create)
+  void* d_ws = nullptr;           // scan ticket + tile descriptors (fixed size, allocated and zeroed at create)
+  uint32_t scan_epoch = 0;        // tag of the current scan launch's descriptors (22 bits, never 0)
   size_t ws_bytes = 0;
   // Conditional re-execution (gficf_csc_device): kernels launched while cur_gate is set return at once
   // unless *cur_gate != 0; the scaling pass raises *cur_zero when it meets an explicitly stored zero.
@@ -77,5 +78,5 @@ void gficf_set_error(const char* fmt, ...);
 __host__ __device__ static inline int64_t gficf_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // In-place exclusive scan of n int64 values on the context's stream (scan.hip).
-// Uses ctx->d_ws for block partials.
+// One launch (decoupled look-back); uses ctx->d_ws.  Sums must stay below 2^40.
 int gficf_exclusive_scan_i64(gficf_ctx* ctx, int64_t* d_data, int64_t n);

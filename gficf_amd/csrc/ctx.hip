@@ -66,6 +66,7 @@ int gficf_ctx_create(int device, void* stream, gficf_ctx** out) {
   if (e == hipSuccess) e = hipMemset(c->d_status, 0, sizeof(uint32_t));
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_status, sizeof(uint32_t), hipHostMallocDefault);
   if (e == hipSuccess) e = hipMalloc(&c->d_ws, c->ws_bytes);
+  if (e == hipSuccess) e = hipMemset(c->d_ws, 0, c->ws_bytes);     // scan ticket + descriptors (epoch 0 = never written)
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_flags, 4 * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMemset(c->d_flags, 0, 4 * sizeof(uint32_t));
   if (e != hipSuccess) {
@@ -151,36 +152,29 @@ __device__ inline int64_t block_exclusive_scan(int64_t v, int64_t* total) {
   return r;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const int64_t* __restrict__ d, int64_t n,
-                                                              int64_t* __restrict__ partial, const uint32_t* gate) {
-  GFICF_GATE(gate);
-  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
-  int64_t s = 0;
-#pragma unroll
-  for (int t = 0; t < SCAN_ITEMS; ++t)
-    if (base + t < n) s += d[base + t];
-  int64_t total;
-  (void)block_exclusive_scan(s, &total);
-  if (threadIdx.x == 0) partial[blockIdx.x] = total;
+// Single-pass scan with decoupled look-back over tiles of SCAN_TILE elements.  Tiles are claimed by ticket
+// (ws[0]), so a tile's predecessors always belong to running workgroups; ws[1 + t] is tile t's descriptor
+//   bits 63..42 epoch | 41..40 status (1 = aggregate, 2 = inclusive prefix) | 39..0 value,
+// one 8-byte granule written by ONE write-through store and polled with agent-scope loads (the data is the flag,
+// valid across XCDs).  The epoch (host counter, never 0) tells this launch's descriptors from older ones, so
+// nothing has to be zeroed between launches; the workgroup that draws the last ticket resets the ticket word.
+constexpr int SCAN_VALUE_BITS = 40;
+
+__device__ inline unsigned long long scan_desc(uint32_t epoch, uint32_t status, int64_t value) {
+  return ((unsigned long long)epoch << 42) | ((unsigned long long)status << SCAN_VALUE_BITS) |
+         ((unsigned long long)value & ((1ull << SCAN_VALUE_BITS) - 1ull));
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_partials(int64_t* __restrict__ partial, int64_t nb, const uint32_t* gate) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(int64_t* __restrict__ d, int64_t n, unsigned long long* ws,
+                                                                uint32_t epoch, uint32_t* __restrict__ status,
+                                                                const uint32_t* gate) {
   GFICF_GATE(gate);
-  int64_t carry = 0;
-  for (int64_t b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
-    int64_t idx = b0 + threadIdx.x;
-    int64_t v = idx < nb ? partial[idx] : 0;
-    int64_t total;
-    int64_t ex = block_exclusive_scan(v, &total);
-    if (idx < nb) partial[idx] = carry + ex;
-    carry += total;
-  }
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(int64_t* __restrict__ d, int64_t n,
-                                                             const int64_t* __restrict__ partial, const uint32_t* gate) {
-  GFICF_GATE(gate);
-  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  __shared__ unsigned long long s_tile;
+  __shared__ int64_t s_prefix;
+  if (threadIdx.x == 0) s_tile = atomicAdd(&ws[0], 1ull);
+  __syncthreads();
+  const int64_t tile = (int64_t)s_tile;
+  const int64_t base = tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   int64_t v[SCAN_ITEMS];
   int64_t s = 0;
 #pragma unroll
@@ -189,7 +183,28 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(int64_t* __restrict
     s += v[t];
   }
   int64_t total;
-  int64_t ex = block_exclusive_scan(s, &total) + partial[blockIdx.x];
+  int64_t ex = block_exclusive_scan(s, &total);
+  if (threadIdx.x == 0) {
+    unsigned long long* const desc = ws + 1;
+    if (total < 0 || (total >> SCAN_VALUE_BITS) != 0) atomicOr(status, GFICF_ST_BAD_CSC);    // counts out of range
+    int64_t run = 0;
+    if (tile > 0) {
+      __hip_atomic_store(desc + tile, scan_desc(epoch, 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int64_t t = tile - 1;; --t) {
+        unsigned long long x;
+        do {
+          x = __hip_atomic_load(desc + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((uint32_t)(x >> 42) != epoch || ((x >> SCAN_VALUE_BITS) & 3ull) == 0ull);
+        run += (int64_t)(x & ((1ull << SCAN_VALUE_BITS) - 1ull));
+        if (((x >> SCAN_VALUE_BITS) & 3ull) == 2ull) break;
+      }
+    }
+    __hip_atomic_store(desc + tile, scan_desc(epoch, 2u, run + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tile == (int64_t)gridDim.x - 1) __hip_atomic_store(ws, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket is out
+    s_prefix = run;
+  }
+  __syncthreads();
+  ex += s_prefix;
 #pragma unroll
   for (int t = 0; t < SCAN_ITEMS; ++t) {
     if (base + t < n) d[base + t] = ex;
@@ -202,12 +217,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(int64_t* __restrict
 int gficf_exclusive_scan_i64(gficf_ctx* ctx, int64_t* d_data, int64_t n) {
   if (n <= 0) return GFICF_OK;
   const int64_t nb = gficf_ceil_div(n, SCAN_TILE);
-  if ((size_t)nb * sizeof(int64_t) > ctx->ws_bytes)
+  if ((size_t)(nb + 1) * sizeof(unsigned long long) > ctx->ws_bytes)
     GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "scan of %lld elements exceeds the workspace", (long long)n);
-  int64_t* partial = (int64_t*)ctx->d_ws;
-  hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_data, n, partial, ctx->cur_gate);
-  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, partial, nb, ctx->cur_gate);
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_data, n, partial, ctx->cur_gate);
+  if (++ctx->scan_epoch >= (1u << 22)) {            // epoch wrap: start over from clean descriptors
+    GFICF_HIP_CHECK(hipMemsetAsync(ctx->d_ws, 0, ctx->ws_bytes, ctx->stream));
+    ctx->scan_epoch = 1;
+  }
+  hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_data, n, (unsigned long long*)ctx->d_ws,
+                     ctx->scan_epoch, ctx->d_status, ctx->cur_gate);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }

@@ -26,6 +26,7 @@ namespace {
 // Each workgroup sweeps one contiguous slab; a thread takes 4 consecutive entries per load
 // (16 B of rowidx, 2 x 16 B of x) and keeps two such groups in flight.
 constexpr int CNT_THREADS = 1024;
+constexpr int GATED_BLOCKS = 32;            // grid cap of launches that normally return at once (see launch_count)
 constexpr int CNT_LDS_MAX_G = 36 * 1024;   // 144 KiB of uint32 counters
 
 template <bool USE_LDS>
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __res
     __syncthreads();
   }
   bool bad = false;
-  constexpr int GROUPS = 4;                                  // 16 B rowidx + 32 B x per group, all in flight
+  constexpr int GROUPS = 4;                                  // 16 B rowidx + 32 B x per group, all in flight (12 groups without x: no faster)
   constexpr int64_t STRIDE = (int64_t)CNT_THREADS * 4;       // entries per group sweep of the workgroup
   constexpr int64_t CHUNK = STRIDE * GROUPS;
   const int64_t per_block = gficf_ceil_div(gficf_ceil_div(nnz, (int64_t)gridDim.x), CHUNK) * CHUNK;
@@ -232,9 +233,13 @@ __global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64
         for (int t = 0; t < 8; ++t)
           if (g[t] >= 0 && g[t] < G) n += (s_bits[g[t] >> 5] >> (g[t] & 31)) & 1u;
       }
-      for (; p < p1; p += 64) {
-        const int32_t g = rowidx[p];
-        if (g >= 0 && g < G) n += (s_bits[g >> 5] >> (g & 31)) & 1u;
+      if (p < p1) {                                 // tail of up to 8 x 64 entries: all loads in flight as well
+        int32_t g[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) g[t] = p + t * 64 < p1 ? rowidx[p + t * 64] : -1;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (g[t] >= 0 && g[t] < G) n += (s_bits[g[t] >> 5] >> (g[t] & 31)) & 1u;
       }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
@@ -641,6 +646,9 @@ static int launch_count(gficf_ctx* ctx, int64_t G, const int32_t* d_rowidx, cons
   } else if (blocks > (int64_t)ctx->num_cus * 2) {
     blocks = (int64_t)ctx->num_cus * 2;
   }
+  // A gated launch (the exact re-run behind the explicit-zero flag, gficf_csc_device) returns at once in the common
+  // case, and an empty launch costs by its number of workgroups: give it a small grid (all kernels stride).
+  if (ctx->cur_gate && blocks > GATED_BLOCKS) blocks = GATED_BLOCKS;
 #define LAUNCH_CNT(L, V, X)                                                                                          \
   hipLaunchKernelGGL((k_gene_count<L, V, X>), dim3((unsigned)blocks), dim3(CNT_THREADS), lds, ctx->stream, d_rowidx, d_x, \
                      nnz, G, (unsigned long long*)d_nt, ctx->d_status, ctx->cur_gate)
@@ -693,6 +701,7 @@ int gficf_csc_colptr_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const in
   if (!d_colptr || !d_out_colptr || !d_gkept || !d_keep) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   int64_t blocks = gficf_ceil_div(n_cells > 0 ? n_cells : 1, CC_THREADS / 64);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+  if (ctx->cur_gate && blocks > GATED_BLOCKS) blocks = GATED_BLOCKS;
   const size_t lds = (size_t)((G + 31) / 32) * sizeof(uint32_t);     // G <= 2^31 -> at most 256 MiB: checked below
   if (lds > 64 * 1024) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "G = %lld too large for the LDS keep bitmask", (long long)G);
   hipLaunchKernelGGL(k_cell_kept_count, dim3((unsigned)blocks), dim3(CC_THREADS), lds, ctx->stream, G, n_cells, d_colptr,
@@ -721,11 +730,13 @@ int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
     }
     int64_t blocks = gficf_ceil_div(n_cells, SL_THREADS / 64);
     if (blocks > ctx->num_cus) blocks = ctx->num_cus;
+    if (ctx->cur_gate && blocks > GATED_BLOCKS) blocks = GATED_BLOCKS;
     hipLaunchKernelGGL(k_scale_cells_lds, dim3((unsigned)blocks), dim3(SL_THREADS), SL_LDS_BYTES, ctx->stream, G, n_cells,
                        d_colptr, d_rowidx, d_x, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x, ctx->cur_gate, ctx->cur_zero);
   }
   int64_t blocks = n_cells;
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+  if (ctx->cur_gate && blocks > GATED_BLOCKS) blocks = GATED_BLOCKS;
   hipLaunchKernelGGL(k_scale_cells, dim3((unsigned)blocks), dim3(SC_THREADS), 0, ctx->stream, G, n_cells, d_colptr,
                      d_rowidx, d_x, d_genes, try_lds ? d_gkept : (const int64_t*)nullptr, d_out_colptr, d_out_rowidx, d_out_x,
                      ctx->cur_gate, ctx->cur_zero);
