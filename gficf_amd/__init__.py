@@ -16,6 +16,7 @@ from .api import (  # noqa: F401
     device_count,
     gficf,
     gficf_with_weights,
+    jaccard_adjacency,
     jaccard_edges,
     rcpp_parallel_jaccard_coef,
 )

@@ -16,6 +16,7 @@ GFICF_OK = 0
 STATUS_NAMES = {
     0: "GFICF_OK", 1: "GFICF_ERR_INVALID_ARG", 2: "GFICF_ERR_BAD_ID", 3: "GFICF_ERR_BAD_CSC",
     4: "GFICF_ERR_NO_DEVICE", 5: "GFICF_ERR_HIP", 6: "GFICF_ERR_UNSUPPORTED", 7: "GFICF_ERR_CAPACITY",
+    8: "GFICF_ERR_BAD_VALUE",
 }
 JACCARD_MAX_K = 256
 KNN_MAX_K = 128
@@ -53,6 +54,10 @@ SIGNATURES = {
     "gficf_jaccard_edges_filtered_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_filtered_host_plan": (_int, [_vp, _vp, _int, _i64, _int, _i64, ctypes.POINTER(_i64)]),
     "gficf_jaccard_filtered_host_finish": (_int, [_vp, _vp, _vp, _vp]),
+    "gficf_adjacency_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
+    "gficf_adjacency_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, _vp, _vp]),
+    "gficf_adjacency_host_plan": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
+    "gficf_adjacency_host_finish": (_int, [_vp, _vp, _int, _vp, _vp]),
     "gficf_normalize_csc_host_plan": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _dbl, _dbl, _vp,
                                              ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "gficf_normalize_csc_host_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -133,6 +133,30 @@ def jaccard_edges(neigh, verbose: bool = False, ctx: Context | None = None):
     return out
 
 
+def jaccard_adjacency(edges: dict, N: int, ctx: Context | None = None):
+    """The kept edges as the symmetric weighted adjacency matrix of the undirected graph —
+    ``igraph::as_adjacency_matrix(igraph::graph.data.frame(relations, directed = FALSE), attr = "weight", sparse = T)``
+    (reference R/clustCells.R:69,80,86), the input of the modularity optimiser.  ``edges``: the dict of
+    :func:`jaccard_edges` (``from`` / ``to`` / ``weight``); ``N``: number of cells.  Returns a scipy CSC matrix
+    (N x N, sorted indices): A[i,j] = A[j,i] = sum of the weights of the edges between i and j."""
+    import scipy.sparse as sp
+
+    f = np.ascontiguousarray(edges["from"], dtype=np.float64)
+    t = np.ascontiguousarray(edges["to"], dtype=np.float64)
+    w = np.ascontiguousarray(edges["weight"], dtype=np.float64)
+    if not (f.shape == t.shape == w.shape and f.ndim == 1):
+        raise ValueError("from / to / weight must be 1-d arrays of the same length")
+    ctx = ctx or default_context()
+    L = _lib.load()
+    nnz = ctypes.c_int64(0)
+    check(L.gficf_adjacency_host_plan(ctx.handle, int(N), len(f), _np_ptr(f), _np_ptr(t), _np_ptr(w), ctypes.byref(nnz)))
+    indptr = np.zeros(N + 1, dtype=np.int64)
+    indices = np.zeros(nnz.value, dtype=np.int32)
+    x = np.zeros(nnz.value, dtype=np.float64)
+    check(L.gficf_adjacency_host_finish(ctx.handle, _np_ptr(indptr), 1, _np_ptr(indices), _np_ptr(x)))
+    return sp.csc_matrix((x, indices, indptr), shape=(N, N))
+
+
 # -------------------------------------------------------------- GF-ICF, reference-shaped
 def _csc_parts(M):
     import scipy.sparse as sp
@@ -373,6 +397,17 @@ class HipOps:
         check(self.L.gficf_jaccard_edges_filtered_device(self._bind(), _tptr(table), N, k, cell_begin, cell_end,
                                                          _tptr(u_ws), _tptr(cell_ptr), ctypes.c_void_p(base),
                                                          ctypes.c_void_p(base + 8 * n), ctypes.c_void_p(base + 16 * n)))
+
+    def adjacency_workspace_bytes(self, N: int, edge_capacity: int) -> int:
+        return int(self.L.gficf_adjacency_workspace_bytes(int(N), int(edge_capacity)))
+
+    def adjacency(self, N: int, edge_capacity: int, n_edges_dev, out3, ws, indptr, indices, x):
+        """out3: the (3, edge_capacity) float64 buffer of jaccard_edges_filtered (rows from / to / weight);
+        n_edges_dev: int64 device scalar (a 1-element view, e.g. cell_ptr[n:n+1]) or None = all edge_capacity rows."""
+        base = out3.data_ptr()
+        check(self.L.gficf_adjacency_device(self._bind(), N, edge_capacity, _tptr(n_edges_dev), ctypes.c_void_p(base),
+                                            ctypes.c_void_p(base + 8 * edge_capacity), ctypes.c_void_p(base + 16 * edge_capacity),
+                                            _tptr(ws), int(ws.numel()), _tptr(indptr), _tptr(indices), _tptr(x)))
 
     def jaccard(self, idx_cm, N: int, k: int, table_ws, rmat3, u=None):
         """Single-GPU ingest + edges.  rmat3: (3, N*k) float64 == the (N*k) x 3 R matrix."""

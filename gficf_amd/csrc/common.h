@@ -12,9 +12,11 @@
 // Deferred device-side validation flags (OR-ed into gficf_ctx::d_status by kernels).
 constexpr uint32_t GFICF_ST_BAD_ID = 1u;    // kNN id outside [1, N] or not an integer
 constexpr uint32_t GFICF_ST_BAD_CSC = 2u;   // rowidx outside [0, G) / colptr not monotone
+constexpr uint32_t GFICF_ST_BAD_VALUE = 4u; // non-finite coordinate handed to the kNN search
 
 struct gficf_host_plan;  // gficf_csc.hip
 struct gficf_edge_plan;  // jaccard.hip
+struct gficf_adj_plan;   // adjacency.hip
 
 struct gficf_ctx {
   int device = 0;
@@ -32,6 +34,7 @@ struct gficf_ctx {
   uint32_t* cur_zero = nullptr;
   gficf_host_plan* plan = nullptr;
   gficf_edge_plan* edge_plan = nullptr;
+  gficf_adj_plan* adj_plan = nullptr;
   // grow-only device scratch of the host entry points (kept between calls, released at destroy)
   void* pool[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pool_bytes[4] = {0, 0, 0, 0};
@@ -44,6 +47,8 @@ hipError_t gficf_pool_get(gficf_ctx* ctx, int slot, size_t bytes, void** out);
 void gficf_host_plan_free(gficf_ctx* ctx);
 // same for the host-form filtered edge build (jaccard.hip)
 extern "C" void gficf_edge_plan_free(gficf_ctx* ctx);
+// same for the host-form adjacency build (adjacency.hip)
+void gficf_adj_plan_free(gficf_ctx* ctx);
 
 // thread-local last error message
 void gficf_set_error(const char* fmt, ...);

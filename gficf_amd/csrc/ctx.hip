@@ -84,6 +84,7 @@ void gficf_ctx_destroy(gficf_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   gficf_host_plan_free(ctx);
   gficf_edge_plan_free(ctx);
+  gficf_adj_plan_free(ctx);
   if (ctx->d_status) (void)hipFree(ctx->d_status);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->d_ws) (void)hipFree(ctx->d_ws);
@@ -107,6 +108,8 @@ int gficf_ctx_sync(gficf_ctx* ctx) {
   uint32_t st = *ctx->h_status;
   if (st & GFICF_ST_BAD_ID)
     GFICF_FAIL(GFICF_ERR_BAD_ID, "kNN index matrix holds an id outside [1, N] or a non-integer value");
+  if (st & GFICF_ST_BAD_VALUE)
+    GFICF_FAIL(GFICF_ERR_BAD_VALUE, "kNN point matrix holds a non-finite value");
   if (st & GFICF_ST_BAD_CSC)
     GFICF_FAIL(GFICF_ERR_BAD_CSC, "CSC matrix malformed: row index outside [0, G) or colptr not monotone");
   return GFICF_OK;

@@ -54,9 +54,10 @@ __device__ inline float sortable_f32(uint32_t s) {
 // cosine: the row is divided by its f32 L2 norm (fma chain in dimension order), zero rows stay zero.
 template <typename T>
 __global__ __launch_bounds__(256) void k_knn_prepare(const T* __restrict__ X, int64_t n_rows, int d, int dpad, int64_t ld,
-                                                     int metric, float* __restrict__ out) {
+                                                     int metric, float* __restrict__ out, uint32_t* __restrict__ status) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= n_rows) return;
+  bool bad = false;
   float inv = 1.0f;
   bool scale = false;
   if (metric == GFICF_KNN_COSINE) {
@@ -69,9 +70,11 @@ __global__ __launch_bounds__(256) void k_knn_prepare(const T* __restrict__ X, in
   float* o = out + r * dpad;
   for (int t = 0; t < dpad; ++t) {
     float v = t < d ? (float)X[(int64_t)t * ld + r] : 0.0f;
+    bad |= !(fabsf(v) <= FLT_MAX);              // NaN or +-Inf (also a double too large for f32)
     if (scale) v = v / inv;
     o[t] = v;
   }
+  if (bad) atomicOr(status, GFICF_ST_BAD_VALUE);
 }
 
 // ------------------------------------------------------------------------------ search
@@ -429,9 +432,9 @@ int gficf_knn_prepare_device(gficf_ctx* ctx, const void* d_X, int x_is_f64, int6
   if (ld < n_rows) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < n_rows = %lld", (long long)ld, (long long)n_rows);
   const unsigned blocks = (unsigned)gficf_ceil_div(n_rows, 256);
   if (x_is_f64)
-    hipLaunchKernelGGL(k_knn_prepare<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)d_X, n_rows, d, knn_dpad(d), ld, metric, d_point_rows);
+    hipLaunchKernelGGL(k_knn_prepare<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)d_X, n_rows, d, knn_dpad(d), ld, metric, d_point_rows, ctx->d_status);
   else
-    hipLaunchKernelGGL(k_knn_prepare<float>, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)d_X, n_rows, d, knn_dpad(d), ld, metric, d_point_rows);
+    hipLaunchKernelGGL(k_knn_prepare<float>, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)d_X, n_rows, d, knn_dpad(d), ld, metric, d_point_rows, ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }

@@ -38,7 +38,8 @@ typedef enum gficf_status {
   GFICF_ERR_NO_DEVICE = 4,     /* no HIP device / device index out of range                */
   GFICF_ERR_HIP = 5,           /* a HIP runtime call failed; message has hipGetErrorString */
   GFICF_ERR_UNSUPPORTED = 6,   /* k > GFICF_JACCARD_MAX_K, table too large for the kernel  */
-  GFICF_ERR_CAPACITY = 7       /* caller-provided output buffer too small                  */
+  GFICF_ERR_CAPACITY = 7,      /* caller-provided output buffer too small                  */
+  GFICF_ERR_BAD_VALUE = 8      /* a non-finite coordinate in the kNN point matrix          */
 } gficf_status;
 
 #define GFICF_JACCARD_MAX_K 256
@@ -135,6 +136,25 @@ int gficf_jaccard_edges_filtered_device(gficf_ctx* ctx, const int32_t* d_table, 
 int gficf_jaccard_filtered_host_plan(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k,
                                      int64_t ld, int64_t* n_edges);
 int gficf_jaccard_filtered_host_finish(gficf_ctx* ctx, double* from, double* to, double* weight);
+
+/* Second half of N1, the graph hand-off: the kept edges as the symmetric weighted adjacency matrix that
+ *   g <- igraph::graph.data.frame(relations, directed = FALSE)                       (R/clustCells.R:69)
+ *   igraph::as_adjacency_matrix(g, attr = "weight", sparse = T)                       (R/clustCells.R:80,86)
+ * hand to RunModularityClustering: A[i,j] = A[j,i] = sum of the weights of all edges between i and j (an i -> j and
+ * a j -> i edge are two edges: a mutual pair carries 2w; a self edge counts once), cells in cell order, indices
+ * sorted within a column, 0-based (dgCMatrix @p / @i / @x).
+ * d_from / d_to / d_weight: edge list with capacity edge_capacity (1-based ids as doubles, what the filtered build
+ * writes); d_n_edges: device count of valid edges (e.g. d_cell_ptr + n_cells of the filtered build) or NULL = all.
+ * d_indptr[N+1] (d_indptr[N] = nnz), d_indices / d_x: capacity 2 * edge_capacity.  d_ws: scratch of
+ * gficf_adjacency_workspace_bytes(N, edge_capacity) bytes. */
+size_t gficf_adjacency_workspace_bytes(int64_t N, int64_t edge_capacity);
+int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, const int64_t* d_n_edges,
+                           const double* d_from, const double* d_to, const double* d_weight, void* d_ws,
+                           size_t ws_bytes, int64_t* d_indptr, int32_t* d_indices, double* d_x);
+/* Host form, two calls so that the caller can allocate exactly nnz entries. */
+int gficf_adjacency_host_plan(gficf_ctx* ctx, int64_t N, int64_t n_edges, const double* from, const double* to,
+                              const double* weight, int64_t* nnz);
+int gficf_adjacency_host_finish(gficf_ctx* ctx, void* indptr, int indptr_is_i64, int32_t* indices, double* x);
 
 /* ------------------------------------------------------------------------------ GF-ICF
  * Replaces the R-level chain of gficf()  (R/gficf.R:17-33, normalize = FALSE):
@@ -244,7 +264,8 @@ int gficf_knn_dpad(int d);
 
 /* Device pipeline, split where a multi-GPU caller needs the seam (queries shard by cell block):
  *   1. prepare : a block of rows of the R matrix (n_rows x d column-major, f64 or f32, ld >= n_rows)
- *                -> row-major f32 point rows (n_rows x dpad, zero padded; cosine: normalised)
+ *                -> row-major f32 point rows (n_rows x dpad, zero padded; cosine: normalised);
+ *                non-finite coordinates are reported by gficf_ctx_sync() (GFICF_ERR_BAD_VALUE)
  *   2. (multi-GPU only) the caller all-gathers the point rows of all blocks
  *   3. search  : queries [q_begin, q_end) against all N points -> d_idx (1-based ids, (q_end-q_begin) x k
  *                column-major with leading dimension ld_out: column 0 is the nearest — the query

@@ -37,3 +37,13 @@ find_nn_hip = function(X, k, metric = "manhattan")
   if (is.na(m)) stop("metric must be manhattan, euclidean or cosine")
   .Call(`_gficf_find_nn`, as.matrix(X) + 0, as.integer(k), m)
 }
+
+# Optional (second half of N1): the adjacency matrix for RunModularityClustering ("louvian 2" / "louvian 3").  Replaces
+#   igraph::as_adjacency_matrix(g, attr = "weight", sparse = T)                       (reference R/clustCells.R:80,86)
+# with
+#   jaccard_adjacency_hip(relations, nrow(data$pca$cells))
+jaccard_adjacency_hip = function(relations, n)
+{
+  r = .Call(`_gficf_jaccard_adjacency`, as.numeric(relations$from), as.numeric(relations$to), as.numeric(relations$weight), n)
+  Matrix::sparseMatrix(i = r[[1]], p = r[[2]], x = r[[3]], index1 = FALSE, dims = c(n, n))
+}

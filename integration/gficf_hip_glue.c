@@ -101,10 +101,30 @@ SEXP _gficf_find_nn(SEXP XS, SEXP kS, SEXP metricS) {
   return out;
 }
 
+/* Optional: the symmetric weighted adjacency matrix of the undirected graph, in place of
+ *   igraph::as_adjacency_matrix(igraph::graph.data.frame(relations, directed = FALSE), attr = "weight", sparse = T)
+ * (reference R/clustCells.R:69,80,86).  Returns list(i, p, x) for Matrix::sparseMatrix(i=, p=, x=, index1 = FALSE). */
+SEXP _gficf_jaccard_adjacency(SEXP fromS, SEXP toS, SEXP weightS, SEXP nS) {
+  const int64_t E = XLENGTH(fromS), N = (int64_t)Rf_asReal(nS);
+  int64_t nnz = 0;
+  if (gficf_adjacency_host_plan(ctx_get(), N, E, REAL(fromS), REAL(toS), REAL(weightS), &nnz) != GFICF_OK)
+    Rf_error("gficf_hip: %s", gficf_last_error());
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 3));
+  SEXP oi = PROTECT(Rf_allocVector(INTSXP, nnz)), op = PROTECT(Rf_allocVector(INTSXP, N + 1)), ox = PROTECT(Rf_allocVector(REALSXP, nnz));
+  if (gficf_adjacency_host_finish(ctx_get(), INTEGER(op), 0, INTEGER(oi), REAL(ox)) != GFICF_OK) {
+    UNPROTECT(4);
+    Rf_error("gficf_hip: %s", gficf_last_error());
+  }
+  SET_VECTOR_ELT(out, 0, oi); SET_VECTOR_ELT(out, 1, op); SET_VECTOR_ELT(out, 2, ox);
+  UNPROTECT(4);
+  return out;
+}
+
 static const R_CallMethodDef HipCallEntries[] = {
     {"_gficf_rcpp_parallel_jaccard_coef", (DL_FUNC)&_gficf_rcpp_parallel_jaccard_coef, 2},
     {"_gficf_gficf_csc", (DL_FUNC)&_gficf_gficf_csc, 7},
     {"_gficf_find_nn", (DL_FUNC)&_gficf_find_nn, 3},
+    {"_gficf_jaccard_adjacency", (DL_FUNC)&_gficf_jaccard_adjacency, 4},
     {NULL, NULL, 0}};
 
 /* Called from the package's R_init_gficf (reference src/RcppExports.cpp:94-97) next to the Rcpp entries:

@@ -117,6 +117,13 @@ def test_argument_errors():
         gficf_amd.find_nn(blobs(50, 129, seed=1), 5, True, "manhattan")
     with pytest.raises(ValueError):
         gficf_amd.find_nn(X, 5, True, "hamming")
+    for poison in (np.nan, np.inf, 1e300):                          # not representable as a finite f32
+        Y = X.copy()
+        Y[7, 2] = poison
+        with pytest.raises(gficf_amd.GficfError) as ei:
+            gficf_amd.find_nn(Y, 5, True, "manhattan")
+        assert ei.value.status == "GFICF_ERR_BAD_VALUE"
+    assert gficf_amd.find_nn(X, 5, True, "manhattan")["idx"].shape == (50, 5)     # the context is usable afterwards
 
 
 def test_device_query_blocks_and_split_seams(ops, monkeypatch):
