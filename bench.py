@@ -137,6 +137,35 @@ def bench_knn(torch, ops, args):
                                          "the reference's own search is Annoy (approximate, third-party) and cannot run here",
                                "gpu_over_cpu": (N / t) / (nq / tc)}
         res["checked_vs_oracle"] = bool(np.array_equal(idx[:, :nq].cpu().numpy().T, widx[:nq]))
+    # the whole graph build of clustcells() on the device (R/clustCells.R:57-69,80): kNN -> neigh[,-1] -> Jaccard ->
+    # weight > 0 filter -> symmetric adjacency, no host round trip (the edge count stays on the device)
+    kj = k - 1
+    cap = N * kj
+    table = torch.empty((N, ops.kpad(kj)), dtype=torch.int32, device="cuda")
+    u_ws = torch.zeros(cap, dtype=torch.int16, device="cuda")
+    cell_ptr = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
+    out3 = torch.zeros((3, cap), dtype=torch.float64, device="cuda")
+    aws = torch.zeros(ops.adjacency_workspace_bytes(N, cap), dtype=torch.uint8, device="cuda")
+    indptr = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
+    indices = torch.zeros(2 * cap, dtype=torch.int32, device="cuda")
+    ax = torch.zeros(2 * cap, dtype=torch.float64, device="cuda")
+
+    def graph():
+        run()
+        ops.jaccard_ingest(idx[1:], N, kj, N, table)
+        ops.jaccard_edges_filtered(table, N, kj, 0, N, u_ws, cell_ptr, out3)
+        ops.adjacency(N, cap, cell_ptr[N:N + 1], out3, aws, indptr, indices, ax)
+
+    graph()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        graph()
+    torch.cuda.synchronize()
+    tgr = (time.perf_counter() - t1) / reps
+    res["graph_build"] = {"ms_total": tgr * 1e3, "ms_knn": t * 1e3, "ms_jaccard_filter_adjacency": (tgr - t) * 1e3,
+                          "kept_edges": int(cell_ptr[N]), "adjacency_nnz": int(indptr[N]),
+                          "note": "kNN -> Jaccard -> weight > 0 filter -> symmetric adjacency (CSC), device-resident, one stream"}
     return res
 
 
