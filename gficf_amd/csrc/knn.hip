@@ -25,8 +25,11 @@
 // writes the 1-based index matrix column-major — the layout the Jaccard ingest reads.
 #include <cfloat>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
 
@@ -91,7 +94,8 @@ typedef __attribute__((address_space(3))) volatile u64 knn_lds_u64;
 
 template <int KL>
 __device__ __noinline__ float knn_row_insert(uint32_t list_addr, int kk, float d0, float d1, float d2, float d3, float d4, float d5,
-                                             float d6, float d7, float tau, bool live, uint32_t j0, int tid) {
+                                             float d6, float d7, float tau, bool live, uint32_t j0, int tid,
+                                             const int32_t* __restrict__ perm) {
   knn_lds_u64* const list = (knn_lds_u64*)(size_t)list_addr;      // LDS byte address of the row's list
   const float dv[8] = {d0, d1, d2, d3, d4, d5, d6, d7};
   const int tx = tid & 15;
@@ -114,6 +118,7 @@ __device__ __noinline__ float knn_row_insert(uint32_t list_addr, int kk, float d
       for (int t = 1; t < 8; ++t) h = s == t ? dv[t] : h;
       khi = f32_sortable(h);
       klo = j0 + (uint32_t)((s < 4 ? 0 : 64) + tx * 4 + (s & 3));
+      if (perm) klo = (uint32_t)perm[klo];              // pruned search: the key carries the point's original id
     }
     const int src = ((tid & 48) | (leader & 15)) << 2;
     khi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)khi);
@@ -182,50 +187,80 @@ __device__ inline void knn_dim(knn_f2 (&acc)[RQ][4], const KnnOperands& o) {
   }
 }
 
-template <int METRIC, int KL, int RQ>
-__global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __restrict__ X, int64_t N, int d, int dpad, int kk,
-                                                           int64_t q_begin, int64_t q_end, int S, u64* __restrict__ part) {
-  constexpr int TQ = 16 * RQ;                                                // queries per workgroup
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* const sA = reinterpret_cast<float*>(smem);                          // [dpad][TQ]
-  float* const sB = sA + (size_t)dpad * TQ;                              // [2][DK][TC]
-  u64* const sKey = reinterpret_cast<u64*>(sB + 2 * KNN_DK * KNN_TC);        // [TQ][KL]
-  const uint32_t key_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)sKey;   // LDS byte address
+// Arguments of the tile kernel.  Queries and candidates are separate row-major arrays (the plain search passes
+// Q = X + q_begin rows; the pruned search passes its two reordered copies).
+struct KnnTileArgs {
+  const float* Q;          // n_q query rows
+  int64_t n_q;
+  const float* X;          // N candidate rows
+  int64_t N;
+  int d, dpad, kk, S;
+  u64* part;               // [n_q][S][kk] partial lists
+  const int32_t* perm_x;   // PRUNE: original 0-based id of candidate row j (the keys carry original ids)
+  const float* lb;         // PRUNE: [n_qt][n_ct] lower bound of the distance between query tile and candidate tile
+  int32_t* visited;        // optional (GFICF_KNN_STATS lab knob): tiles processed per workgroup
+  const uint32_t* gate;    // optional: run only if *gate == gate_want (the pruned / plain choice is made on the device)
+  uint32_t gate_want;
+};
 
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+// One workgroup = one tile of TQ = 16 * RQ queries x a sequence of candidate tiles.
+//   PRUNE == false: the candidate tiles of slice sp of S, in order.
+//   PRUNE == true : S = 1; the candidate tiles in the order of their lower bound lb[qt][*], best first, and the
+//     sequence ends at the first tile whose bound exceeds the largest k-th best distance of the tile's queries —
+//     no point of that tile or of any later one can enter a list (the bound is a triangle-inequality bound
+//     with slack for f32 rounding, built by k_knn_lb).  The next tile is chosen by every wave for itself from
+//     the same LDS data (bounds, visited marks and the waves' k-th best maxima published one tile earlier,
+//     double-buffered), so the waves agree without an extra barrier.
+template <int METRIC, int KL, int RQ, bool PRUNE>
+__global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const KnnTileArgs A) {
+  constexpr int TQ = 16 * RQ;                                                // queries per workgroup
+  if (A.gate != nullptr && *A.gate != A.gate_want) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int d = A.d, dpad = A.dpad, kk = A.kk, S = A.S;
+  const int64_t N = A.N;
+  float* const sA = reinterpret_cast<float*>(smem);                          // [dpad][TQ]
+  float* const sB = sA + (size_t)dpad * TQ;                                  // [2][DK][TC]
+  u64* const sKey = reinterpret_cast<u64*>(sB + 2 * KNN_DK * KNN_TC);        // [TQ][KL]
+  float* const sLb = reinterpret_cast<float*>(sKey + TQ * KL);               // PRUNE: [n_ct] bounds, +inf once visited
+  const uint32_t key_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)sKey;   // LDS byte address
+  __shared__ float s_wtau[2][KNN_THREADS / 64];                              // PRUNE: per-wave max of the k-th best, by tile parity
+
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, lane = tid & 63, wave = tid >> 6;
   const int qt = blockIdx.x / S, sp = blockIdx.x % S;
-  const int64_t q0 = q_begin + (int64_t)qt * TQ;
-  const int nq_live = q_end - q0 < TQ ? (int)(q_end - q0) : TQ;      // rows of the tile that are real queries
+  const int64_t q0 = (int64_t)qt * TQ;
+  const int nq_live = A.n_q - q0 < TQ ? (int)(A.n_q - q0) : TQ;              // rows of the tile that are real queries
   const int64_t n_ct = gficf_ceil_div(N, KNN_TC);
-  const int64_t ct0 = n_ct * sp / S, ct1 = n_ct * (sp + 1) / S;
+  const int64_t ct0 = PRUNE ? 0 : n_ct * sp / S, ct1 = PRUNE ? n_ct : n_ct * (sp + 1) / S;
   const int nq4 = dpad >> 2;                         // float4 per point row
   const int nch = (d + KNN_DK - 1) / KNN_DK;         // chunks per candidate tile (padded dims are skipped)
-  const float4* const X4 = reinterpret_cast<const float4*>(X);
+  const float4* const X4 = reinterpret_cast<const float4*>(A.X);
+  const float4* const Q4 = reinterpret_cast<const float4*>(A.Q);
 
   for (int e = tid; e < TQ * KL; e += KNN_THREADS) sKey[e] = ~0ull;
   // query tile -> sA[dim][query]; consecutive lanes take consecutive queries (conflict-free LDS writes)
   for (int f = tid; f < TQ * nq4; f += KNN_THREADS) {
     const int row = f & (TQ - 1), quad = f / TQ;
     const int64_t q = q0 + row;
-    const float4 v = q < N ? X4[q * nq4 + quad] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 v = q < A.n_q ? Q4[q * nq4 + quad] : make_float4(0.f, 0.f, 0.f, 0.f);
     float* o = sA + (size_t)(quad * 4) * TQ + row;
     o[0] = v.x; o[TQ] = v.y; o[2 * TQ] = v.z; o[3 * TQ] = v.w;
   }
+  if (PRUNE) {
+    for (int64_t e = tid; e < n_ct; e += KNN_THREADS) sLb[e] = A.lb[(int64_t)qt * n_ct + e];
+    if (tid < 2 * (KNN_THREADS / 64)) s_wtau[tid / (KNN_THREADS / 64)][tid % (KNN_THREADS / 64)] = INFINITY;
+  }
 
-  // Staging of the candidate tiles: step g of the flattened (candidate tile, dim chunk) sequence moves
-  // 128 points x 16 dims = 512 float4, two per thread (point row_l, float4 columns quad0 and quad0 + 2 of the
-  // chunk).  The source pointer advances by a constant per step; consecutive lanes take consecutive points, so
-  // the transposing LDS writes are conflict-free.
-  const int64_t G = (ct1 - ct0) * nch;
+  // Staging of a candidate tile's dim chunk: 128 points x 16 dims = 512 float4, two per thread (point row_l,
+  // float4 columns quad0 and quad0 + 2 of the chunk); consecutive lanes take consecutive points, so the
+  // transposing LDS writes are conflict-free.
   const int row_l = tid & (KNN_TC - 1), quad0 = tid >> 7;
-  const float4* pn = X4 + (ct0 * KNN_TC + row_l) * nq4 + quad0;             // chunk of the NEXT load
-  const int64_t tile_step = (int64_t)KNN_TC * nq4 - (int64_t)(nch - 1) * (KNN_DK / 4);
   float* const st0 = sB + (size_t)(quad0 * 4) * KNN_TC + row_l;             // LDS destination inside a buffer
-  auto load_chunk = [&](int c, int nvalid, float4 (&v)[2]) {
-    const bool rowok = row_l < nvalid;
+  auto load_chunk = [&](int64_t ct, int c, float4 (&v)[2]) {
+    const int64_t j = ct * KNN_TC + row_l;
     const int q4 = c * (KNN_DK / 4) + quad0;
-    v[0] = (rowok && q4 < nq4) ? pn[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-    v[1] = (rowok && q4 + 2 < nq4) ? pn[2] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* src = X4 + j * nq4 + q4;
+    v[0] = (j < N && q4 < nq4) ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[1] = (j < N && q4 + 2 < nq4) ? src[2] : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto store_chunk = [&](int buf, const float4 (&v)[2]) {
     float* o = st0 + (size_t)buf * KNN_DK * KNN_TC;
@@ -233,7 +268,27 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
     o += 8 * KNN_TC;
     o[0] = v[1].x; o[KNN_TC] = v[1].y; o[2 * KNN_TC] = v[1].z; o[3 * KNN_TC] = v[1].w;
   };
-  auto tile_valid = [&](int64_t t) { return N - t * KNN_TC < KNN_TC ? (int)(N - t * KNN_TC) : KNN_TC; };
+  // PRUNE: the unvisited tile with the smallest bound, or -1 when that bound is beyond every query's k-th best.
+  // `skip` is the tile in work (its visited mark may not be visible to every wave yet); `par` selects the
+  // published k-th best maxima of the tile before it.
+  auto select_tile = [&](int64_t skip, int par) -> int64_t {
+    float best = INFINITY;
+    int bi = -1;
+    for (int e = lane; e < (int)n_ct; e += 64) {
+      const float v = sLb[e];
+      if (e != (int)skip && v < best) { best = v; bi = e; }      // ascending e: the lowest index wins a tie
+    }
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+      const float ov = __shfl_xor(best, w);
+      const int oi = __shfl_xor(bi, w);
+      if (ov < best || (ov == best && oi >= 0 && (bi < 0 || oi < bi))) { best = ov; bi = oi; }
+    }
+    float tmax = s_wtau[par][0];
+#pragma unroll
+    for (int w = 1; w < KNN_THREADS / 64; ++w) tmax = fmaxf(tmax, s_wtau[par][w]);
+    return (bi >= 0 && best <= tmax) ? (int64_t)bi : -1;
+  };
 
   knn_f2 acc[RQ][4];
 #pragma unroll
@@ -245,92 +300,120 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const float* __res
 #pragma unroll
   for (int r = 0; r < RQ; ++r) tau[r] = INFINITY;
 
+  __syncthreads();              // sLb / s_wtau / sA are in place
+  int64_t cur = PRUNE ? select_tile(-1, 0) : (ct0 < ct1 ? ct0 : -1);
   float4 pre[2];
-  if (G > 0) { load_chunk(0, tile_valid(ct0), pre); store_chunk(0, pre); }
+  if (cur >= 0) { load_chunk(cur, 0, pre); store_chunk(0, pre); }
   __syncthreads();
 
-  // (ct, c): candidate tile and dim chunk of step g; (nct, nc): those of step g + 1 (no divisions in the loop)
-  int64_t ct = ct0, nct = ct0;
-  int c = 0, nc = 0;
-  for (int64_t g = 0; g < G; ++g) {
-    ct = nct; c = nc;
-    if (++nc == nch) { nc = 0; ++nct; pn += tile_step; } else { pn += KNN_DK / 4; }
-    if (g + 1 < G) load_chunk(nc, tile_valid(nct), pre);
-    const float* const pa = sA + (size_t)(c * KNN_DK) * TQ + ty * 4;
-    const float* const pb = sB + (size_t)(g & 1) * KNN_DK * KNN_TC + tx * 4;
-    const int nd = d - c * KNN_DK < KNN_DK ? d - c * KNN_DK : KNN_DK;
-    {
-      // Two dims per round (the point rows are zero padded to a multiple of 4 dims, and a zero dim adds exactly 0 to
-      // every metric's accumulator, so an odd d costs one padded dim).  The operands of the next dim are read from
-      // LDS while the current one is accumulated.  One rolled loop for full and short chunks alike: the
-      // accumulators never change registers.
-      const int np = (nd + 1) >> 1;
-      KnnOperands oa, ob;
-      knn_read<RQ>(oa, pa, pb);
-#pragma unroll 1       // measured: unroll 2 duplicates the body with a remainder copy and runs 45 % slower
-      for (int t = 0; t < np; ++t) {
-        knn_read<RQ>(ob, pa + (2 * t + 1) * TQ, pb + (2 * t + 1) * KNN_TC);
-        knn_dim<METRIC, RQ>(acc, oa);
-        if (t + 1 < np) knn_read<RQ>(oa, pa + (2 * t + 2) * TQ, pb + (2 * t + 2) * KNN_TC);
-        knn_dim<METRIC, RQ>(acc, ob);
+  int buf = 0, tile_no = 0;
+  while (cur >= 0) {
+    if (PRUNE && tid == 0) sLb[cur] = INFINITY;              // visited; read by select_tile only after a later barrier
+    int64_t nxt = -1;
+    for (int c = 0; c < nch; ++c) {
+      bool have_next;
+      if (c + 1 < nch) {
+        load_chunk(cur, c + 1, pre);
+        have_next = true;
+      } else {
+        nxt = PRUNE ? select_tile(cur, (tile_no + 1) & 1) : (cur + 1 < ct1 ? cur + 1 : -1);
+        have_next = nxt >= 0;
+        if (have_next) load_chunk(nxt, 0, pre);
       }
-    }
-    if (c == nch - 1) {
-      // the tile's 8 x 8 distances of this thread against the current k-th best of their queries
-      const int64_t j0 = ct * KNN_TC;
-      // Only the data set's last candidate tile can hold fewer than TC points; it gets its own copy of the
-      // code below (RAG), so that all the other tiles do not pay for the masking.
-      auto epilogue = [&](auto rag_tag) {
-        constexpr bool RAG = decltype(rag_tag)::value;
-        const int nvalid = (int)(N - j0);                      // RAG only: candidates at columns >= nvalid do not exist
+      const float* const pa = sA + (size_t)(c * KNN_DK) * TQ + ty * 4;
+      const float* const pb = sB + (size_t)buf * KNN_DK * KNN_TC + tx * 4;
+      const int nd = d - c * KNN_DK < KNN_DK ? d - c * KNN_DK : KNN_DK;
+      {
+        // Two dims per round (the point rows are zero padded to a multiple of 4 dims, and a zero dim adds exactly 0
+        // to every metric's accumulator, so an odd d costs one padded dim).  The operands of the next dim are read
+        // from LDS while the current one is accumulated.  One rolled loop for full and short chunks alike: the
+        // accumulators never change registers.
+        const int np = (nd + 1) >> 1;
+        KnnOperands oa, ob;
+        knn_read<RQ>(oa, pa, pb);
+#pragma unroll 1       // measured: unroll 2 duplicates the body with a remainder copy and runs 45 % slower
+        for (int t = 0; t < np; ++t) {
+          knn_read<RQ>(ob, pa + (2 * t + 1) * TQ, pb + (2 * t + 1) * KNN_TC);
+          knn_dim<METRIC, RQ>(acc, oa);
+          if (t + 1 < np) knn_read<RQ>(oa, pa + (2 * t + 2) * TQ, pb + (2 * t + 2) * KNN_TC);
+          knn_dim<METRIC, RQ>(acc, ob);
+        }
+      }
+      if (c == nch - 1) {
+        // the tile's distances of this thread against the current k-th best of their queries
+        const int64_t j0 = cur * KNN_TC;
+        // Only the data set's last candidate tile can hold fewer than TC points; it gets its own copy of the
+        // code below (RAG), so that all the other tiles do not pay for the masking.
+        auto epilogue = [&](auto rag_tag) {
+          constexpr bool RAG = decltype(rag_tag)::value;
+          const int nvalid = (int)(N - j0);                    // RAG only: candidates at columns >= nvalid do not exist
 #pragma unroll
-        for (int r = 0; r < RQ; ++r) {
-          const int row = (r < 4 ? 0 : 64) + ty * 4 + (r & 3);
-          const bool live = row < nq_live;
-          // common case after the first tiles: nothing in the whole wave beats its query's k-th best
-          bool any = false;
-#pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const float av = (s & 1) ? acc[r][s >> 1].y : acc[r][s >> 1].x;
-            bool ok = (METRIC == GFICF_KNN_COSINE ? 1.0f - av : av) <= tau[r];
-            if (RAG) ok = ok && (s < 4 ? 0 : 64) + tx * 4 + (s & 3) < nvalid;
-            any |= ok;
-          }
-          if (__ballot(any && live) != 0) {
-            float dv[8];
+          for (int r = 0; r < RQ; ++r) {
+            const int row = (r < 4 ? 0 : 64) + ty * 4 + (r & 3);
+            const bool live = row < nq_live;
+            // common case after the first tiles: nothing in the whole wave beats its query's k-th best
+            bool any = false;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
               const float av = (s & 1) ? acc[r][s >> 1].y : acc[r][s >> 1].x;
-              dv[s] = METRIC == GFICF_KNN_COSINE ? 1.0f - av : av;
-              if (RAG && (s < 4 ? 0 : 64) + tx * 4 + (s & 3) >= nvalid) dv[s] = NAN;       // never <= tau
+              bool ok = (METRIC == GFICF_KNN_COSINE ? 1.0f - av : av) <= tau[r];
+              if (RAG) ok = ok && (s < 4 ? 0 : 64) + tx * 4 + (s & 3) < nvalid;
+              any |= ok;
             }
-            tau[r] = knn_row_insert<KL>(key_addr + (uint32_t)(row * KL * 8), kk, dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6],
-                                        dv[7], tau[r], live, (uint32_t)j0, tid);
-          }
+            if (__ballot(any && live) != 0) {
+              float dv[8];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc[r][s] = knn_f2{0.0f, 0.0f};
+              for (int s = 0; s < 8; ++s) {
+                const float av = (s & 1) ? acc[r][s >> 1].y : acc[r][s >> 1].x;
+                dv[s] = METRIC == GFICF_KNN_COSINE ? 1.0f - av : av;
+                if (RAG && (s < 4 ? 0 : 64) + tx * 4 + (s & 3) >= nvalid) dv[s] = NAN;       // never <= tau
+              }
+              tau[r] = knn_row_insert<KL>(key_addr + (uint32_t)(row * KL * 8), kk, dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6],
+                                          dv[7], tau[r], live, (uint32_t)j0, tid, PRUNE ? A.perm_x : (const int32_t*)nullptr);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[r][s] = knn_f2{0.0f, 0.0f};
+          }
+        };
+        if (j0 + KNN_TC > N) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+        if (PRUNE) {
+          // this wave's largest k-th best (rows without a query do not count; an unfilled list is +inf)
+          float tm = 0.0f;
+#pragma unroll
+          for (int r = 0; r < RQ; ++r)
+            if ((r < 4 ? 0 : 64) + ty * 4 + (r & 3) < nq_live) tm = fmaxf(tm, tau[r]);
+          tm = fmaxf(tm, __shfl_xor(tm, 16));
+          tm = fmaxf(tm, __shfl_xor(tm, 32));
+          if (lane == 0) s_wtau[tile_no & 1][wave] = tm;
         }
-      };
-      if (j0 + KNN_TC > N) epilogue(std::true_type{});
-      else epilogue(std::false_type{});
+      }
+      if (have_next) store_chunk(buf ^ 1, pre);
+      __syncthreads();
+      buf ^= 1;
     }
-    if (g + 1 < G) store_chunk((int)((g + 1) & 1), pre);
-    __syncthreads();
+    cur = nxt;
+    ++tile_no;
   }
 
+  if (A.visited && tid == 0) A.visited[blockIdx.x] = tile_no;
   // partial lists of this candidate slice
   for (int e = tid; e < TQ * kk; e += KNN_THREADS) {
     const int row = e / kk, t = e % kk;
     const int64_t q = q0 + row;
-    if (q < q_end) part[((q - q_begin) * S + sp) * kk + t] = sKey[row * KL + t];
+    if (q < A.n_q) A.part[(q * S + sp) * kk + t] = sKey[row * KL + t];
   }
 }
 
 // k best of the S partial lists of a query (each ascending) -> 1-based ids / distances, column-major.
+// perm_q (pruned search): the query's position in the caller's block.
 __global__ __launch_bounds__(256) void k_knn_merge(const u64* __restrict__ part, int64_t n_q, int S, int kk, int metric,
-                                                   int32_t* __restrict__ idx, float* __restrict__ dist, int64_t ld_out) {
+                                                   const int32_t* __restrict__ perm_q, int32_t* __restrict__ idx,
+                                                   float* __restrict__ dist, int64_t ld_out, const uint32_t* gate, uint32_t gate_want) {
+  if (gate != nullptr && *gate != gate_want) return;
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (q >= n_q) return;
+  const int64_t oq = perm_q ? (int64_t)perm_q[q] : q;
   int pos[KNN_MAX_SPLIT];
 #pragma unroll
   for (int s = 0; s < KNN_MAX_SPLIT; ++s) pos[s] = 0;
@@ -354,22 +437,127 @@ __global__ __launch_bounds__(256) void k_knn_merge(const u64* __restrict__ part,
       dv = sortable_f32((uint32_t)(best >> 32));
       if (metric == GFICF_KNN_EUCLIDEAN) dv = sqrtf(dv);
     }
-    idx[(int64_t)t * ld_out + q] = id;
-    if (dist) dist[(int64_t)t * ld_out + q] = dv;
+    idx[(int64_t)t * ld_out + oq] = id;
+    if (dist) dist[(int64_t)t * ld_out + oq] = dv;
   }
 }
 
-// Query rows per thread: 4 (64-query tiles) by default.  Measured at 100 k x 50, 31 nearest, manhattan: 64-query tiles
-// 27.7 ms, 128-query tiles 33.1 ms — the smaller tile halves the candidate splits' insertions and the per-tile
-// epilogue weighs less; LDS operand traffic per VALU instruction is higher but the LDS pipe has the room.
-// GFICF_KNN_RQ=8 selects the 128-query tile for lists of at most 32 entries (tuning knob).
-inline int knn_rq(int k) {
-  static const int forced = getenv("GFICF_KNN_RQ") ? atoi(getenv("GFICF_KNN_RQ")) : 0;
-  return (k <= 32 && forced == 8) ? 8 : 4;
+// ------------------------------------------------------------------ pruned search: preparation
+// The exact search skips whole candidate tiles that provably cannot contribute: with a centre c_t and radius r_t
+// per candidate tile (r_t = largest distance of a tile point to c_t), every point x of the tile is at least
+//   min over the query tile's points q of dist(q, c_t)  -  r_t
+// away from every query of the tile (triangle inequality: manhattan and euclidean directly; cosine through the
+// euclidean distance e of the unit vectors, 1 - cos = e^2 / 2).  For the bound to bite, the points are reordered so
+// that a tile holds neighbours: every point is assigned to its nearest of ~N/128 pivots (the tile kernel itself
+// with the pivots as candidates and k = 1) and the points are sorted by pivot.
+constexpr int KNN_RQ = 4;
+constexpr int KNN_TQ = 16 * KNN_RQ;
+constexpr float KNN_LB_SLACK = 1e-4f;      // relative slack on the bound: f32 rounding of 128-dim sums is ~1e-5
+
+__global__ __launch_bounds__(256) void k_knn_gather_rows(const float* __restrict__ src, const int32_t* __restrict__ rows, int64_t n,
+                                                         int nq4, int64_t stride_or_zero, float* __restrict__ dst) {
+  // dst row r = src row rows[r] (rows == nullptr: src row r * stride_or_zero — evenly spaced pivots)
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * nq4) return;
+  const int64_t r = e / nq4;
+  const int q4 = (int)(e % nq4);
+  const int64_t sr = rows ? (int64_t)rows[r] : r * stride_or_zero;
+  reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[sr * nq4 + q4];
 }
 
-int knn_split(const gficf_ctx* ctx, int64_t n_q, int64_t N, int k) {
-  const int64_t n_qt = gficf_ceil_div(n_q > 0 ? n_q : 1, 16 * knn_rq(k)), n_ct = gficf_ceil_div(N > 0 ? N : 1, KNN_TC);
+__global__ __launch_bounds__(256) void k_knn_iota(int32_t* __restrict__ v, int64_t n) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) v[e] = (int32_t)e;
+}
+
+// sort key of a point: (coarse pivot of its fine pivot) << 13 | fine pivot   (ids 1-based, at most 4096 fine pivots)
+__global__ __launch_bounds__(256) void k_knn_sort_keys(const int32_t* __restrict__ pivot_of, const int32_t* __restrict__ coarse_of,
+                                                       int64_t n, int32_t* __restrict__ keys) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) {
+    const int32_t f = pivot_of[e];
+    keys[e] = (coarse_of[f - 1] << 13) | f;
+  }
+}
+
+// distance used by the bounds: the metric itself for manhattan, the euclidean distance otherwise
+template <int METRIC>
+__device__ inline float knn_bound_dist(const float* __restrict__ a, const float* __restrict__ b, int d) {
+  float acc = 0.0f;
+  for (int t = 0; t < d; ++t) {
+    const float df = a[t] - b[t];
+    acc = METRIC == GFICF_KNN_MANHATTAN ? acc + fabsf(df) : fmaf(df, df, acc);
+  }
+  return METRIC == GFICF_KNN_MANHATTAN ? acc : sqrtf(acc);
+}
+
+// one workgroup of 128 threads per candidate tile: centre = mean of the tile's points, radius = largest distance to it
+template <int METRIC>
+__global__ __launch_bounds__(KNN_TC) void k_knn_tile_stats(const float* __restrict__ X, int64_t N, int d, int dpad,
+                                                           float* __restrict__ centers, float* __restrict__ radius) {
+  __shared__ float s_c[KNN_MAX_D];
+  __shared__ float s_r[KNN_TC / 64];
+  const int64_t t = blockIdx.x, j0 = t * KNN_TC;
+  const int n = N - j0 < KNN_TC ? (int)(N - j0) : KNN_TC;
+  for (int dim = threadIdx.x; dim < dpad; dim += KNN_TC) {
+    float sum = 0.0f;
+    for (int p = 0; p < n; ++p) sum += X[(j0 + p) * dpad + dim];
+    const float c = sum / (float)n;
+    s_c[dim] = c;
+    centers[t * dpad + dim] = c;
+  }
+  __syncthreads();
+  float r = 0.0f;
+  if ((int)threadIdx.x < n) r = knn_bound_dist<METRIC>(X + (j0 + threadIdx.x) * dpad, s_c, d);
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) r = fmaxf(r, __shfl_xor(r, w));
+  if ((threadIdx.x & 63) == 0) s_r[threadIdx.x >> 6] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) radius[t] = fmaxf(s_r[0], s_r[1]);
+}
+
+// one workgroup per query tile: lb[qt][ct] = the bound above, in the domain of the keys (manhattan: distance,
+// euclidean: squared distance, cosine: 1 - cos), lowered by the slack; never negative.
+template <int METRIC>
+__global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, int64_t n_q, int d, int dpad,
+                                                const float* __restrict__ centers, const float* __restrict__ radius, int64_t n_ct,
+                                                float* __restrict__ lb, unsigned long long* __restrict__ n_zero) {
+  extern __shared__ float s_q[];                     // [KNN_TQ][dpad + 1]
+  const int64_t qt = blockIdx.x, q0 = qt * KNN_TQ;
+  const int nq = n_q - q0 < KNN_TQ ? (int)(n_q - q0) : KNN_TQ;
+  const int pitch = dpad + 1;
+  for (int e = threadIdx.x; e < KNN_TQ * dpad; e += 256) {
+    const int row = e / dpad, dim = e % dpad;
+    s_q[row * pitch + dim] = row < nq ? Q[(q0 + row) * dpad + dim] : 0.0f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int nz = 0;
+  for (int64_t c = wave; c < n_ct; c += 4) {
+    float dq = lane < nq ? knn_bound_dist<METRIC>(s_q + lane * pitch, centers + c * dpad, d) : INFINITY;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) dq = fminf(dq, __shfl_xor(dq, w));
+    if (lane == 0) {
+      const float r = radius[c];
+      float b = dq - r - KNN_LB_SLACK * (dq + r);
+      b = b > 0.0f ? b : 0.0f;
+      if (METRIC == GFICF_KNN_EUCLIDEAN) b = b * b * (1.0f - KNN_LB_SLACK);
+      if (METRIC == GFICF_KNN_COSINE) b = fmaxf(0.5f * b * b * (1.0f - KNN_LB_SLACK) - 4e-6f, 0.0f);
+      lb[qt * n_ct + c] = b;
+      nz += b <= 0.0f ? 1 : 0;
+    }
+  }
+  if (lane == 0 && nz) atomicAdd(n_zero, (unsigned long long)nz);
+}
+
+// flag = 1 (plain search) when more than half of the (query tile, candidate tile) pairs have no positive bound: the
+// data has no cluster structure to prune by, and the plain form with its split candidate range runs faster
+__global__ void k_knn_choose(const unsigned long long* __restrict__ n_zero, unsigned long long n_pairs, uint32_t force, uint32_t* __restrict__ flag) {
+  *flag = force ? 0u : (2ull * *n_zero > n_pairs ? 1u : 0u);
+}
+
+int knn_split(const gficf_ctx* ctx, int64_t n_q, int64_t N) {
+  const int64_t n_qt = gficf_ceil_div(n_q > 0 ? n_q : 1, KNN_TQ), n_ct = gficf_ceil_div(N > 0 ? N : 1, KNN_TC);
   // enough work items for ~8 per CU, but every candidate slice at least 8 tiles long
   int64_t S = gficf_ceil_div((int64_t)ctx->num_cus * 8, n_qt);
   if (S > n_ct / 8) S = n_ct / 8;
@@ -380,6 +568,28 @@ int knn_split(const gficf_ctx* ctx, int64_t n_q, int64_t N, int k) {
     if (v >= 1 && v <= KNN_MAX_SPLIT) S = v;
   }
   return (int)S;
+}
+
+// The pruned search pays for its preparation (~1 ms at 100 k points) only on larger inputs; the bounds of a query
+// tile have to fit LDS.  GFICF_KNN_PRUNE=0 / 1 forces it off / on (test hook).
+constexpr int64_t KNN_PRUNE_MIN_N = 30000;
+constexpr int64_t KNN_PRUNE_MAX_TILES = 8192;
+bool knn_use_prune(int64_t N) {
+  const int64_t n_ct = gficf_ceil_div(N > 0 ? N : 1, KNN_TC);
+  if (n_ct < 2 || n_ct > KNN_PRUNE_MAX_TILES) return false;
+  if (const char* e = getenv("GFICF_KNN_PRUNE")) return atoi(e) != 0;
+  return N >= KNN_PRUNE_MIN_N;
+}
+// Two levels of pivots: C fine pivots (a cell of ~KNN_CELL points each) and C/16 coarse ones.  Points are ordered by
+// (coarse pivot of their fine pivot, fine pivot), so that cells that follow each other in memory are neighbours in
+// space and a 128-point tile that straddles two cells stays compact.
+inline int64_t knn_coarse(int64_t C) { return C / 16 > 2 ? C / 16 : 2; }
+
+int64_t knn_pivots(int64_t N) {
+  int64_t per = 512;
+  if (const char* e = getenv("GFICF_KNN_PIVOT_CELL")) per = atoi(e) > 0 ? atoi(e) : per;    // lab knob: points per pivot
+  int64_t c = gficf_ceil_div(N, per);
+  return c < 2 ? 2 : c > 4096 ? 4096 : c;
 }
 
 int knn_check(int64_t N, int d, int k, int metric) {
@@ -393,27 +603,87 @@ int knn_check(int64_t N, int d, int k, int metric) {
   return GFICF_OK;
 }
 
-template <int METRIC, int KL, int RQ>
-int knn_launch(gficf_ctx* ctx, const float* X, int64_t N, int d, int kk, int64_t qb, int64_t qe, int S, u64* part) {
-  const int dpad = knn_dpad(d);
-  constexpr int TQ = 16 * RQ;
-  const size_t lds = (size_t)dpad * TQ * 4 + 2 * KNN_DK * KNN_TC * 4 + (size_t)TQ * KL * 8;
+template <int METRIC, int KL, bool PRUNE>
+int knn_launch(gficf_ctx* ctx, const KnnTileArgs& a) {
+  const int64_t n_ct = gficf_ceil_div(a.N, KNN_TC);
+  const size_t lds = (size_t)a.dpad * KNN_TQ * 4 + 2 * KNN_DK * KNN_TC * 4 + (size_t)KNN_TQ * KL * 8 + (PRUNE ? (size_t)n_ct * 4 : 0);
   static bool attr_set[64] = {};
   if (!attr_set[ctx->device & 63]) {
-    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_knn_tiles<METRIC, KL, RQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_knn_tiles<METRIC, KL, KNN_RQ, PRUNE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_set[ctx->device & 63] = true;
   }
-  const int64_t blocks = gficf_ceil_div(qe - qb, TQ) * S;
-  hipLaunchKernelGGL((k_knn_tiles<METRIC, KL, RQ>), dim3((unsigned)blocks), dim3(KNN_THREADS), lds, ctx->stream, X, N, d, dpad, kk, qb, qe, S, part);
+  const int64_t blocks = gficf_ceil_div(a.n_q, KNN_TQ) * a.S;
+  hipLaunchKernelGGL((k_knn_tiles<METRIC, KL, KNN_RQ, PRUNE>), dim3((unsigned)blocks), dim3(KNN_THREADS), lds, ctx->stream, a);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
 
-template <int METRIC>
-int knn_launch_k(gficf_ctx* ctx, const float* X, int64_t N, int d, int kk, int64_t qb, int64_t qe, int S, u64* part) {
-  if (kk <= 32) return knn_rq(kk) == 8 ? knn_launch<METRIC, 32, 8>(ctx, X, N, d, kk, qb, qe, S, part) : knn_launch<METRIC, 32, 4>(ctx, X, N, d, kk, qb, qe, S, part);
-  if (kk <= 64) return knn_launch<METRIC, 64, 4>(ctx, X, N, d, kk, qb, qe, S, part);
-  return knn_launch<METRIC, 128, 4>(ctx, X, N, d, kk, qb, qe, S, part);
+template <int METRIC, bool PRUNE>
+int knn_launch_k(gficf_ctx* ctx, const KnnTileArgs& a) {
+  if (a.kk <= 32) return knn_launch<METRIC, 32, PRUNE>(ctx, a);
+  if (a.kk <= 64) return knn_launch<METRIC, 64, PRUNE>(ctx, a);
+  return knn_launch<METRIC, 128, PRUNE>(ctx, a);
+}
+
+template <bool PRUNE>
+int knn_launch_m(gficf_ctx* ctx, int metric, const KnnTileArgs& a) {
+  switch (metric) {
+    case GFICF_KNN_MANHATTAN: return knn_launch_k<GFICF_KNN_MANHATTAN, PRUNE>(ctx, a);
+    case GFICF_KNN_EUCLIDEAN: return knn_launch_k<GFICF_KNN_EUCLIDEAN, PRUNE>(ctx, a);
+    default: return knn_launch_k<GFICF_KNN_COSINE, PRUNE>(ctx, a);
+  }
+}
+
+inline size_t knn_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+size_t knn_sort_temp_bytes(int64_t n) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u, 32u,
+                                  (hipStream_t) nullptr);
+  return tmp;
+}
+
+// workspace of the pruned search, carved in this order
+struct KnnPruneWs {
+  float *pivots, *coarse, *xp, *qp, *centers, *radius, *lb;
+  u64* apart;                       // assignment: N lists of one key (also used for the pivots' own assignment)
+  int32_t *pivot_of, *coarse_of, *keys, *key_tmp, *iota, *perm_x, *perm_q;
+  float* adist;                     // unused distance output of the assignment merge (not written)
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
+  u64* part;
+  u64* part_plain;                  // the plain search's partial lists (taken when the data does not prune)
+  unsigned long long* n_zero;       // [0] zero-bound pairs, [1] (as uint32) the choice flag
+  size_t total;
+};
+
+KnnPruneWs knn_prune_ws(char* base, int64_t n_q, int64_t N, int dpad, int k) {
+  KnnPruneWs w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += knn_align(bytes); return (void*)p; };
+  const int64_t C = knn_pivots(N), n_ct = gficf_ceil_div(N, KNN_TC), n_qt = gficf_ceil_div(n_q, KNN_TQ);
+  w.pivots = (float*)take((size_t)C * dpad * 4);
+  w.coarse = (float*)take((size_t)knn_coarse(C) * dpad * 4);
+  w.coarse_of = (int32_t*)take((size_t)C * 4);
+  w.keys = (int32_t*)take((size_t)N * 4);
+  w.xp = (float*)take((size_t)N * dpad * 4);
+  w.qp = (float*)take((size_t)n_q * dpad * 4);
+  w.centers = (float*)take((size_t)n_ct * dpad * 4);
+  w.radius = (float*)take((size_t)n_ct * 4);
+  w.lb = (float*)take((size_t)n_qt * n_ct * 4);
+  w.apart = (u64*)take((size_t)N * 8);
+  w.pivot_of = (int32_t*)take((size_t)N * 4);
+  w.key_tmp = (int32_t*)take((size_t)N * 4);
+  w.iota = (int32_t*)take((size_t)N * 4);
+  w.perm_x = (int32_t*)take((size_t)N * 4);
+  w.perm_q = (int32_t*)take((size_t)n_q * 4);
+  w.sort_tmp_bytes = knn_sort_temp_bytes(N);
+  w.sort_tmp = take(w.sort_tmp_bytes);
+  w.part = (u64*)take((size_t)n_q * (size_t)k * 8);
+  w.part_plain = (u64*)take((size_t)n_q * (size_t)KNN_MAX_SPLIT * (size_t)k * 8);
+  w.n_zero = (unsigned long long*)take(16);
+  w.total = off + 256;
+  return w;
 }
 
 }  // namespace
@@ -440,8 +710,13 @@ int gficf_knn_prepare_device(gficf_ctx* ctx, const void* d_X, int x_is_f64, int6
 }
 
 size_t gficf_knn_workspace_bytes(gficf_ctx* ctx, int64_t n_queries, int64_t N, int k) {
-  if (!ctx || n_queries <= 0 || N <= 0 || k <= 0) return 16;
-  return (size_t)n_queries * (size_t)knn_split(ctx, n_queries, N, k) * (size_t)k * sizeof(u64) + 16;
+  if (!ctx || n_queries <= 0 || N <= 0 || k <= 0) return 256;
+  // the larger of the two forms, so that the size does not depend on the tuning knobs
+  const size_t plain = (size_t)n_queries * (size_t)KNN_MAX_SPLIT * (size_t)k * sizeof(u64) + 256;
+  const size_t small = (size_t)n_queries * (size_t)knn_split(ctx, n_queries, N) * (size_t)k * sizeof(u64) + 256;
+  const size_t pruned = gficf_ceil_div(N, KNN_TC) <= KNN_PRUNE_MAX_TILES ? knn_prune_ws(nullptr, n_queries, N, knn_dpad(KNN_MAX_D), k).total : 0;
+  (void)plain;
+  return small > pruned ? small : pruned;
 }
 
 int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, int d, int k, int metric, int64_t q_begin,
@@ -457,15 +732,99 @@ int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, in
   if (!d_points || !d_ws || !d_idx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   if (ld_out < n_q) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld_out = %lld < number of queries %lld", (long long)ld_out, (long long)n_q);
   if (ws_bytes < gficf_knn_workspace_bytes(ctx, n_q, N, k)) GFICF_FAIL(GFICF_ERR_CAPACITY, "kNN workspace too small");
-  const int S = knn_split(ctx, n_q, N, k);
-  u64* part = (u64*)d_ws;
+  const int dpad = knn_dpad(d);
+  const unsigned mblocks = (unsigned)gficf_ceil_div(n_q, 256);
+  KnnTileArgs a{};
+  a.d = d; a.dpad = dpad; a.kk = k;
+
+  if (!knn_use_prune(N)) {
+    // plain search: every query tile against every candidate tile, the candidate range split S ways
+    a.Q = d_points + q_begin * dpad; a.n_q = n_q; a.X = d_points; a.N = N;
+    a.S = knn_split(ctx, n_q, N);
+    a.part = (u64*)d_ws;
+    rc = knn_launch_m<false>(ctx, metric, a);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_knn_merge, dim3(mblocks), dim3(256), 0, ctx->stream, a.part, n_q, a.S, k, metric, (const int32_t*)nullptr, d_idx, d_dist, ld_out, (const uint32_t*)nullptr, 0u);
+    GFICF_HIP_CHECK(hipGetLastError());
+    return GFICF_OK;
+  }
+
+  // pruned search (see "pruned search: preparation" above)
+  const KnnPruneWs w = knn_prune_ws((char*)d_ws, n_q, N, dpad, k);
+  const int nq4 = dpad >> 2;
+  const int64_t C = knn_pivots(N), n_ct = gficf_ceil_div(N, KNN_TC), n_qt = gficf_ceil_div(n_q, KNN_TQ);
+  auto blocks_for = [](int64_t n) { return dim3((unsigned)gficf_ceil_div(n, 256)); };
+  // 1. pivots = C evenly spaced points; every point's nearest pivot (the tile kernel, k = 1)
+  hipLaunchKernelGGL(k_knn_gather_rows, blocks_for(C * nq4), dim3(256), 0, ctx->stream, d_points, (const int32_t*)nullptr, C, nq4, N / C, w.pivots);
+  KnnTileArgs as{};
+  as.Q = d_points; as.n_q = N; as.X = w.pivots; as.N = C; as.d = d; as.dpad = dpad; as.kk = 1; as.S = 1; as.part = w.apart;
+  rc = knn_launch_m<false>(ctx, metric, as);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_knn_merge, blocks_for(N), dim3(256), 0, ctx->stream, w.apart, N, 1, 1, metric, (const int32_t*)nullptr, w.pivot_of, (float*)nullptr, N, (const uint32_t*)nullptr, 0u);
+  // the fine pivots' own nearest coarse pivot (coarse pivots = every (C / Cc)-th fine pivot)
+  const int64_t Cc = knn_coarse(C);
+  hipLaunchKernelGGL(k_knn_gather_rows, blocks_for(Cc * nq4), dim3(256), 0, ctx->stream, w.pivots, (const int32_t*)nullptr, Cc, nq4, C / Cc, w.coarse);
+  KnnTileArgs ac{};
+  ac.Q = w.pivots; ac.n_q = C; ac.X = w.coarse; ac.N = Cc; ac.d = d; ac.dpad = dpad; ac.kk = 1; ac.S = 1; ac.part = w.apart;
+  rc = knn_launch_m<false>(ctx, metric, ac);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_knn_merge, blocks_for(C), dim3(256), 0, ctx->stream, w.apart, C, 1, 1, metric, (const int32_t*)nullptr, w.coarse_of, (float*)nullptr, C, (const uint32_t*)nullptr, 0u);
+  // 2. candidates sorted by (coarse, fine) pivot (stable: ties keep index order); the queries of this block likewise
+  hipLaunchKernelGGL(k_knn_sort_keys, blocks_for(N), dim3(256), 0, ctx->stream, w.pivot_of, w.coarse_of, N, w.keys);
+  hipLaunchKernelGGL(k_knn_iota, blocks_for(N), dim3(256), 0, ctx->stream, w.iota, N);
+  size_t tb = w.sort_tmp_bytes;
+  GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys, w.key_tmp, w.iota, w.perm_x, (size_t)N, 0u, 26u, ctx->stream));
+  tb = w.sort_tmp_bytes;
+  GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys + q_begin, w.key_tmp, w.iota, w.perm_q, (size_t)n_q, 0u, 26u, ctx->stream));
+  hipLaunchKernelGGL(k_knn_gather_rows, blocks_for(N * nq4), dim3(256), 0, ctx->stream, d_points, w.perm_x, N, nq4, (int64_t)0, w.xp);
+  hipLaunchKernelGGL(k_knn_gather_rows, blocks_for(n_q * nq4), dim3(256), 0, ctx->stream, d_points + q_begin * dpad, w.perm_q, n_q, nq4, (int64_t)0, w.qp);
+  // 3. centre and radius of every candidate tile; bound of every (query tile, candidate tile) pair
+  GFICF_HIP_CHECK(hipMemsetAsync(w.n_zero, 0, 16, ctx->stream));
+  const size_t lds_lb = (size_t)KNN_TQ * (dpad + 1) * sizeof(float);
   switch (metric) {
-    case GFICF_KNN_MANHATTAN: rc = knn_launch_k<GFICF_KNN_MANHATTAN>(ctx, d_points, N, d, k, q_begin, q_end, S, part); break;
-    case GFICF_KNN_EUCLIDEAN: rc = knn_launch_k<GFICF_KNN_EUCLIDEAN>(ctx, d_points, N, d, k, q_begin, q_end, S, part); break;
-    default: rc = knn_launch_k<GFICF_KNN_COSINE>(ctx, d_points, N, d, k, q_begin, q_end, S, part); break;
+    case GFICF_KNN_MANHATTAN:
+      hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_MANHATTAN>, dim3((unsigned)n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, N, d, dpad, w.centers, w.radius);
+      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_MANHATTAN>, dim3((unsigned)n_qt), dim3(256), lds_lb, ctx->stream, w.qp, n_q, d, dpad, w.centers, w.radius, n_ct, w.lb, w.n_zero);
+      break;
+    case GFICF_KNN_EUCLIDEAN:
+      hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_EUCLIDEAN>, dim3((unsigned)n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, N, d, dpad, w.centers, w.radius);
+      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_EUCLIDEAN>, dim3((unsigned)n_qt), dim3(256), lds_lb, ctx->stream, w.qp, n_q, d, dpad, w.centers, w.radius, n_ct, w.lb, w.n_zero);
+      break;
+    default:
+      hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_COSINE>, dim3((unsigned)n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, N, d, dpad, w.centers, w.radius);
+      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_COSINE>, dim3((unsigned)n_qt), dim3(256), lds_lb, ctx->stream, w.qp, n_q, d, dpad, w.centers, w.radius, n_ct, w.lb, w.n_zero);
+      break;
+  }
+  GFICF_HIP_CHECK(hipGetLastError());
+  // 4. the search over the reordered copies, tiles in best-first order with early exit; 5. back to the caller's order
+  // ... unless the bounds say there is nothing to prune: then the plain search runs instead (chosen on the device,
+  // both forms are enqueued and the one not chosen returns at once)
+  uint32_t* const flag = (uint32_t*)(w.n_zero + 1);
+  const char* fe = getenv("GFICF_KNN_PRUNE");
+  hipLaunchKernelGGL(k_knn_choose, dim3(1), dim3(1), 0, ctx->stream, w.n_zero, (unsigned long long)(n_qt * n_ct), (uint32_t)(fe && atoi(fe) != 0), flag);
+  KnnTileArgs ap{};
+  ap.Q = d_points + q_begin * dpad; ap.n_q = n_q; ap.X = d_points; ap.N = N; ap.d = d; ap.dpad = dpad; ap.kk = k;
+  ap.S = knn_split(ctx, n_q, N); ap.part = w.part_plain; ap.gate = flag; ap.gate_want = 1u;
+  rc = knn_launch_m<false>(ctx, metric, ap);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_knn_merge, dim3(mblocks), dim3(256), 0, ctx->stream, w.part_plain, n_q, ap.S, k, metric, (const int32_t*)nullptr, d_idx, d_dist, ld_out, (const uint32_t*)flag, 1u);
+  a.Q = w.qp; a.n_q = n_q; a.X = w.xp; a.N = N; a.S = 1; a.part = w.part; a.perm_x = w.perm_x; a.lb = w.lb; a.gate = flag; a.gate_want = 0u;
+  int32_t* d_vis = nullptr;
+  if (getenv("GFICF_KNN_STATS")) {                 // lab knob: mean number of candidate tiles a query tile had to visit
+    GFICF_HIP_CHECK(hipMalloc((void**)&d_vis, sizeof(int32_t) * (size_t)n_qt));
+    a.visited = d_vis;
+  }
+  rc = knn_launch_m<true>(ctx, metric, a);
+  if (d_vis) {
+    std::vector<int32_t> hv((size_t)n_qt);
+    (void)hipMemcpy(hv.data(), d_vis, sizeof(int32_t) * (size_t)n_qt, hipMemcpyDeviceToHost);
+    (void)hipFree(d_vis);
+    double sum = 0; int mx = 0;
+    for (int v : hv) { sum += v; mx = v > mx ? v : mx; }
+    fprintf(stderr, "[gficf knn] pruned search: %lld query tiles, %lld candidate tiles, visited mean %.1f max %d\n", (long long)n_qt, (long long)n_ct, sum / (double)n_qt, mx);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(k_knn_merge, dim3((unsigned)gficf_ceil_div(n_q, 256)), dim3(256), 0, ctx->stream, part, n_q, S, k, metric, d_idx, d_dist, ld_out);
+  hipLaunchKernelGGL(k_knn_merge, dim3(mblocks), dim3(256), 0, ctx->stream, w.part, n_q, 1, k, metric, (const int32_t*)w.perm_q, d_idx, d_dist, ld_out, (const uint32_t*)flag, 0u);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }

@@ -45,6 +45,33 @@ def test_host_api_matches_oracle(metric, N, d, k):
 
 
 @pytest.mark.parametrize("metric", ["manhattan", "euclidean", "cosine"])
+@pytest.mark.parametrize("N,d,k", [(300, 2, 5), (1000, 50, 16), (2500, 50, 31), (2000, 7, 31), (1500, 64, 51), (700, 128, 33),
+                                   (900, 20, 100), (257, 3, 65), (4000, 50, 31), (9000, 10, 31)])
+def test_pruned_search_gives_the_same_bits(metric, N, d, k, monkeypatch):
+    """The pruned form (reordered points, tile bounds, best-first order with early exit; taken by default from 20 k
+    points) forced on small inputs: the answer must not change by a bit."""
+    monkeypatch.setenv("GFICF_KNN_PRUNE", "1")
+    X = blobs(N, d, seed=N + d + k)
+    got = gficf_amd.find_nn(X, k, True, metric)
+    widx, wdist = oracle.knn(X, k, metric, nthreads=8)
+    assert np.array_equal(got["idx"], widx)
+    assert np.array_equal(got["dist"].astype(np.float32), wdist.astype(np.float32))
+
+
+def test_pruned_search_on_unclustered_and_degenerate_data(monkeypatch):
+    monkeypatch.setenv("GFICF_KNN_PRUNE", "1")
+    rng = np.random.default_rng(8)
+    cases = {"uniform": rng.uniform(size=(3000, 6)), "all equal": np.ones((600, 4)), "two points repeated": np.repeat(np.array([[0.0, 0.0], [5.0, 1.0]]), 400, axis=0),
+             "line": np.linspace(0, 1, 2000)[:, None] * np.ones((1, 3))}
+    for name, X in cases.items():
+        for metric in ("manhattan", "euclidean"):
+            got = gficf_amd.find_nn(X, 17, True, metric)
+            widx, wdist = oracle.knn(X, 17, metric, nthreads=8)
+            assert np.array_equal(got["idx"], widx), (name, metric)
+            assert np.array_equal(got["dist"].astype(np.float32), wdist.astype(np.float32)), (name, metric)
+
+
+@pytest.mark.parametrize("metric", ["manhattan", "euclidean", "cosine"])
 def test_against_float64_restatement(metric):
     X = blobs(600, 30, seed=5)
     got = gficf_amd.find_nn(X, 20, True, metric)
@@ -139,8 +166,11 @@ def test_device_query_blocks_and_split_seams(ops, monkeypatch):
     h = 1700
     ops.knn_prepare(Xd[:, :h].contiguous(), h, d, "manhattan", pts[:h])
     ops.knn_prepare(Xd[:, h:].contiguous(), N - h, d, "manhattan", pts[h:])
-    for split in (None, "5"):
-        if split:
+    for split in (None, "5", "prune"):
+        if split == "prune":
+            monkeypatch.delenv("GFICF_KNN_SPLIT")
+            monkeypatch.setenv("GFICF_KNN_PRUNE", "1")
+        elif split:
             monkeypatch.setenv("GFICF_KNN_SPLIT", split)
         out = []
         for b, e in ((0, 1300), (1300, N)):

@@ -19,7 +19,12 @@ if len(sys.argv) > 4:
     cases = [(int(a[i]), int(a[i + 1]), int(a[i + 2]), a[i + 3]) for i in range(0, len(a) - 3, 4)]
 for N, d, k, metric in cases:
     rng = np.random.default_rng(1)
-    X = torch.from_numpy(rng.normal(size=(d, N))).cuda()
+    if os.environ.get("KNN_DATA", "normal") == "blobs":        # clustered, like cells in PCA space (bench.py's recipe)
+        centers = rng.normal(scale=6.0, size=(40, d))
+        lab = rng.integers(0, 40, size=N)
+        X = torch.from_numpy(np.ascontiguousarray((centers[lab] + rng.normal(size=(N, d)) * rng.uniform(0.5, 2.0, size=(40, 1))[lab]).T)).cuda()
+    else:
+        X = torch.from_numpy(rng.normal(size=(d, N))).cuda()
     pts = torch.zeros((N, ops.knn_dpad(d)), dtype=torch.float32, device="cuda")
     ws = torch.zeros(ops.knn_workspace_bytes(N, N, k), dtype=torch.uint8, device="cuda")
     idx = torch.zeros((k, N), dtype=torch.int32, device="cuda")
