@@ -198,6 +198,8 @@ struct KnnTileArgs {
   u64* part;               // [n_q][S][kk] partial lists
   const int32_t* perm_x;   // PRUNE: original 0-based id of candidate row j (the keys carry original ids)
   const float* lb;         // PRUNE: [n_qt][n_ct] lower bound of the distance between query tile and candidate tile
+  const int32_t* tile_n;   // PRUNE: points in candidate tile t (cells are padded to whole tiles: a prefix of the tile is real)
+  const int32_t* qtile_n;  // PRUNE: queries in query tile qt
   int32_t* visited;        // optional (GFICF_KNN_STATS lab knob): tiles processed per workgroup
   const uint32_t* gate;    // optional: run only if *gate == gate_want (the pruned / plain choice is made on the device)
   uint32_t gate_want;
@@ -228,7 +230,8 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const KnnTileArgs 
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4, lane = tid & 63, wave = tid >> 6;
   const int qt = blockIdx.x / S, sp = blockIdx.x % S;
   const int64_t q0 = (int64_t)qt * TQ;
-  const int nq_live = A.n_q - q0 < TQ ? (int)(A.n_q - q0) : TQ;              // rows of the tile that are real queries
+  const int nq_live = (PRUNE && A.qtile_n) ? A.qtile_n[qt] : (A.n_q - q0 < TQ ? (int)(A.n_q - q0) : TQ);   // rows that are real queries
+  if (nq_live <= 0) return;                          // padding tile (uniform over the workgroup, before any barrier)
   const int64_t n_ct = gficf_ceil_div(N, KNN_TC);
   const int64_t ct0 = PRUNE ? 0 : n_ct * sp / S, ct1 = PRUNE ? n_ct : n_ct * (sp + 1) / S;
   const int nq4 = dpad >> 2;                         // float4 per point row
@@ -344,9 +347,9 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const KnnTileArgs 
         const int64_t j0 = cur * KNN_TC;
         // Only the data set's last candidate tile can hold fewer than TC points; it gets its own copy of the
         // code below (RAG), so that all the other tiles do not pay for the masking.
+        const int nvalid = (PRUNE && A.tile_n) ? A.tile_n[cur] : (N - j0 < KNN_TC ? (int)(N - j0) : KNN_TC);
         auto epilogue = [&](auto rag_tag) {
-          constexpr bool RAG = decltype(rag_tag)::value;
-          const int nvalid = (int)(N - j0);                    // RAG only: candidates at columns >= nvalid do not exist
+          constexpr bool RAG = decltype(rag_tag)::value;      // RAG: candidates at columns >= nvalid do not exist
 #pragma unroll
           for (int r = 0; r < RQ; ++r) {
             const int row = (r < 4 ? 0 : 64) + ty * 4 + (r & 3);
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const KnnTileArgs 
             for (int s = 0; s < 4; ++s) acc[r][s] = knn_f2{0.0f, 0.0f};
           }
         };
-        if (j0 + KNN_TC > N) epilogue(std::true_type{});
+        if (nvalid < KNN_TC) epilogue(std::true_type{});
         else epilogue(std::false_type{});
         if (PRUNE) {
           // this wave's largest k-th best (rows without a query do not count; an unfilled list is +inf)
@@ -414,6 +417,7 @@ __global__ __launch_bounds__(256) void k_knn_merge(const u64* __restrict__ part,
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (q >= n_q) return;
   const int64_t oq = perm_q ? (int64_t)perm_q[q] : q;
+  if (oq < 0) return;                                // padding row of the reordered query block
   int pos[KNN_MAX_SPLIT];
 #pragma unroll
   for (int s = 0; s < KNN_MAX_SPLIT; ++s) pos[s] = 0;
@@ -493,12 +497,13 @@ __device__ inline float knn_bound_dist(const float* __restrict__ a, const float*
 
 // one workgroup of 128 threads per candidate tile: centre = mean of the tile's points, radius = largest distance to it
 template <int METRIC>
-__global__ __launch_bounds__(KNN_TC) void k_knn_tile_stats(const float* __restrict__ X, int64_t N, int d, int dpad,
+__global__ __launch_bounds__(KNN_TC) void k_knn_tile_stats(const float* __restrict__ X, const int32_t* __restrict__ tile_n, int d, int dpad,
                                                            float* __restrict__ centers, float* __restrict__ radius) {
   __shared__ float s_c[KNN_MAX_D];
   __shared__ float s_r[KNN_TC / 64];
   const int64_t t = blockIdx.x, j0 = t * KNN_TC;
-  const int n = N - j0 < KNN_TC ? (int)(N - j0) : KNN_TC;
+  const int n = tile_n[t];
+  if (n <= 0) { if (threadIdx.x == 0) radius[t] = -1.0f; return; }      // padding tile: marked empty
   for (int dim = threadIdx.x; dim < dpad; dim += KNN_TC) {
     float sum = 0.0f;
     for (int p = 0; p < n; ++p) sum += X[(j0 + p) * dpad + dim];
@@ -519,12 +524,13 @@ __global__ __launch_bounds__(KNN_TC) void k_knn_tile_stats(const float* __restri
 // one workgroup per query tile: lb[qt][ct] = the bound above, in the domain of the keys (manhattan: distance,
 // euclidean: squared distance, cosine: 1 - cos), lowered by the slack; never negative.
 template <int METRIC>
-__global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, int64_t n_q, int d, int dpad,
+__global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, const int32_t* __restrict__ qtile_n, int d, int dpad,
                                                 const float* __restrict__ centers, const float* __restrict__ radius, int64_t n_ct,
-                                                float* __restrict__ lb, unsigned long long* __restrict__ n_zero) {
+                                                float* __restrict__ lb, unsigned long long* __restrict__ counters) {
   extern __shared__ float s_q[];                     // [KNN_TQ][dpad + 1]
   const int64_t qt = blockIdx.x, q0 = qt * KNN_TQ;
-  const int nq = n_q - q0 < KNN_TQ ? (int)(n_q - q0) : KNN_TQ;
+  const int nq = qtile_n[qt];
+  if (nq <= 0) return;                               // padding tile: its workgroup of the search exits at once
   const int pitch = dpad + 1;
   for (int e = threadIdx.x; e < KNN_TQ * dpad; e += 256) {
     const int row = e / dpad, dim = e % dpad;
@@ -532,8 +538,12 @@ __global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, int
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int nz = 0;
+  int nz = 0, np = 0;
   for (int64_t c = wave; c < n_ct; c += 4) {
+    if (radius[c] < 0.0f) {                          // empty candidate tile: never visited
+      if (lane == 0) lb[qt * n_ct + c] = INFINITY;
+      continue;
+    }
     float dq = lane < nq ? knn_bound_dist<METRIC>(s_q + lane * pitch, centers + c * dpad, d) : INFINITY;
 #pragma unroll
     for (int w = 32; w >= 1; w >>= 1) dq = fminf(dq, __shfl_xor(dq, w));
@@ -545,15 +555,81 @@ __global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, int
       if (METRIC == GFICF_KNN_COSINE) b = fmaxf(0.5f * b * b * (1.0f - KNN_LB_SLACK) - 4e-6f, 0.0f);
       lb[qt * n_ct + c] = b;
       nz += b <= 0.0f ? 1 : 0;
+      ++np;
     }
   }
-  if (lane == 0 && nz) atomicAdd(n_zero, (unsigned long long)nz);
+  if (lane == 0) { atomicAdd(counters, (unsigned long long)nz); atomicAdd(counters + 1, (unsigned long long)np); }
 }
 
 // flag = 1 (plain search) when more than half of the (query tile, candidate tile) pairs have no positive bound: the
 // data has no cluster structure to prune by, and the plain form with its split candidate range runs faster
-__global__ void k_knn_choose(const unsigned long long* __restrict__ n_zero, unsigned long long n_pairs, uint32_t force, uint32_t* __restrict__ flag) {
-  *flag = force ? 0u : (2ull * *n_zero > n_pairs ? 1u : 0u);
+__global__ void k_knn_choose(const unsigned long long* __restrict__ counters, uint32_t force, uint32_t* __restrict__ flag) {
+  *flag = force ? 0u : (2ull * counters[0] > counters[1] ? 1u : 0u);
+}
+
+// ---- cells padded to whole tiles
+// The points are sorted by cell key; every cell is moved to a position that is a multiple of the tile size T, so that
+// no tile holds points of two cells (a straddling tile spans both and its radius makes it unprunable for everybody
+// near either cell).  Rows in between are padding: zero coordinates, id -1, never a candidate, never a query.
+__global__ __launch_bounds__(256) void k_knn_cell_heads(const int32_t* __restrict__ keys, int64_t n, int64_t* __restrict__ flags) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p > n) return;
+  flags[p] = (p < n && (p == 0 || keys[p] != keys[p - 1])) ? 1 : 0;
+}
+// rank[] = exclusive scan of the head flags (rank[n] = number of cells); cstart[c] = first sorted position of cell c
+__global__ __launch_bounds__(256) void k_knn_cell_starts(const int32_t* __restrict__ keys, const int64_t* __restrict__ rank, int64_t n,
+                                                         int32_t* __restrict__ cstart) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p > n) return;
+  if (p == n) { cstart[rank[n]] = (int32_t)n; return; }
+  if (p == 0 || keys[p] != keys[p - 1]) cstart[rank[p]] = (int32_t)p;
+}
+// one workgroup: pstart[c] = padded start of cell c (exclusive scan of the cells' sizes rounded up to T), pstart[n_cells] =
+// padded total; at most 4097 cells
+__global__ __launch_bounds__(1024) void k_knn_cell_offsets(const int32_t* __restrict__ cstart, const int64_t* __restrict__ n_cells_p, int T,
+                                                           int32_t* __restrict__ pstart) {
+  __shared__ int s_part[1024];
+  __shared__ int s_total;
+  const int n_cells = (int)*n_cells_p;
+  const int per = (n_cells + 1023) / 1024;
+  const int c0 = threadIdx.x * per;
+  int sum = 0;
+  for (int c = c0; c < c0 + per && c < n_cells; ++c) sum += (cstart[c + 1] - cstart[c] + T - 1) / T * T;
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < 1024; ++t) { const int v = s_part[t]; s_part[t] = run; run += v; }
+    s_total = run;
+  }
+  __syncthreads();
+  int run = s_part[threadIdx.x];
+  for (int c = c0; c < c0 + per && c < n_cells; ++c) { pstart[c] = run; run += (cstart[c + 1] - cstart[c] + T - 1) / T * T; }
+  if (threadIdx.x == 0) pstart[n_cells] = s_total;
+}
+// padded position of every sorted point; copy of its row; its id
+__global__ __launch_bounds__(256) void k_knn_pad_scatter(const int32_t* __restrict__ keys, const int64_t* __restrict__ rank,
+                                                         const int32_t* __restrict__ cstart, const int32_t* __restrict__ pstart,
+                                                         const int32_t* __restrict__ perm, int64_t n, int nq4,
+                                                         const float* __restrict__ src, float* __restrict__ dst, int32_t* __restrict__ perm_pad) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * nq4) return;
+  const int64_t p = e / nq4;
+  const int q4 = (int)(e % nq4);
+  const bool head = p == 0 || keys[p] != keys[p - 1];
+  const int64_t c = rank[p] + (head ? 1 : 0) - 1;
+  const int64_t pp = (int64_t)pstart[c] + (p - cstart[c]);
+  const int32_t id = perm[p];
+  reinterpret_cast<float4*>(dst)[pp * nq4 + q4] = reinterpret_cast<const float4*>(src)[(int64_t)id * nq4 + q4];
+  if (q4 == 0) perm_pad[pp] = id;
+}
+// real rows per tile (they are a prefix of the tile)
+__global__ __launch_bounds__(256) void k_knn_tile_counts(const int32_t* __restrict__ perm_pad, int64_t n_tiles, int T, int32_t* __restrict__ tile_n) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_tiles) return;
+  int n = 0;
+  for (int r = 0; r < T; ++r) n += perm_pad[t * T + r] >= 0 ? 1 : 0;
+  tile_n[t] = n;
 }
 
 int knn_split(const gficf_ctx* ctx, int64_t n_q, int64_t N) {
@@ -586,7 +662,7 @@ bool knn_use_prune(int64_t N) {
 inline int64_t knn_coarse(int64_t C) { return C / 16 > 2 ? C / 16 : 2; }
 
 int64_t knn_pivots(int64_t N) {
-  int64_t per = 512;
+  int64_t per = 256;
   if (const char* e = getenv("GFICF_KNN_PIVOT_CELL")) per = atoi(e) > 0 ? atoi(e) : per;    // lab knob: points per pivot
   int64_t c = gficf_ceil_div(N, per);
   return c < 2 ? 2 : c > 4096 ? 4096 : c;
@@ -643,17 +719,19 @@ size_t knn_sort_temp_bytes(int64_t n) {
   return tmp;
 }
 
-// workspace of the pruned search, carved in this order
+// workspace of the pruned search, carved in this order.  Rows / tiles are counted with the padding of the cell-aligned
+// layout at its worst (every cell adds less than one tile).
 struct KnnPruneWs {
+  int64_t C, xrows, qrows, n_ct, n_qt;      // pivots; padded candidate / query rows; candidate / query tiles (upper bounds)
   float *pivots, *coarse, *xp, *qp, *centers, *radius, *lb;
   u64* apart;                       // assignment: N lists of one key (also used for the pivots' own assignment)
-  int32_t *pivot_of, *coarse_of, *keys, *key_tmp, *iota, *perm_x, *perm_q;
-  float* adist;                     // unused distance output of the assignment merge (not written)
+  int32_t *pivot_of, *coarse_of, *keys, *key_tmp, *iota, *perm_sorted, *perm_x, *perm_q, *cstart, *pstart, *tile_n, *qtile_n;
+  int64_t* rank;
   void* sort_tmp;
   size_t sort_tmp_bytes;
   u64* part;
   u64* part_plain;                  // the plain search's partial lists (taken when the data does not prune)
-  unsigned long long* n_zero;       // [0] zero-bound pairs, [1] (as uint32) the choice flag
+  unsigned long long* counters;     // [0] zero-bound pairs, [1] pairs, [2] (as uint32) the choice flag
   size_t total;
 };
 
@@ -661,27 +739,38 @@ KnnPruneWs knn_prune_ws(char* base, int64_t n_q, int64_t N, int dpad, int k) {
   KnnPruneWs w{};
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += knn_align(bytes); return (void*)p; };
-  const int64_t C = knn_pivots(N), n_ct = gficf_ceil_div(N, KNN_TC), n_qt = gficf_ceil_div(n_q, KNN_TQ);
+  const int64_t C = knn_pivots(N);
+  w.C = C;
+  w.n_ct = gficf_ceil_div(N, KNN_TC) + (C < N ? C : N);
+  w.n_qt = gficf_ceil_div(n_q, KNN_TQ) + (C < n_q ? C : n_q);
+  w.xrows = w.n_ct * KNN_TC;
+  w.qrows = w.n_qt * KNN_TQ;
   w.pivots = (float*)take((size_t)C * dpad * 4);
   w.coarse = (float*)take((size_t)knn_coarse(C) * dpad * 4);
   w.coarse_of = (int32_t*)take((size_t)C * 4);
   w.keys = (int32_t*)take((size_t)N * 4);
-  w.xp = (float*)take((size_t)N * dpad * 4);
-  w.qp = (float*)take((size_t)n_q * dpad * 4);
-  w.centers = (float*)take((size_t)n_ct * dpad * 4);
-  w.radius = (float*)take((size_t)n_ct * 4);
-  w.lb = (float*)take((size_t)n_qt * n_ct * 4);
+  w.xp = (float*)take((size_t)w.xrows * dpad * 4);
+  w.qp = (float*)take((size_t)w.qrows * dpad * 4);
+  w.centers = (float*)take((size_t)w.n_ct * dpad * 4);
+  w.radius = (float*)take((size_t)w.n_ct * 4);
+  w.lb = (float*)take((size_t)w.n_qt * w.n_ct * 4);
   w.apart = (u64*)take((size_t)N * 8);
   w.pivot_of = (int32_t*)take((size_t)N * 4);
   w.key_tmp = (int32_t*)take((size_t)N * 4);
   w.iota = (int32_t*)take((size_t)N * 4);
-  w.perm_x = (int32_t*)take((size_t)N * 4);
-  w.perm_q = (int32_t*)take((size_t)n_q * 4);
+  w.perm_sorted = (int32_t*)take((size_t)N * 4);
+  w.perm_x = (int32_t*)take((size_t)w.xrows * 4);
+  w.perm_q = (int32_t*)take((size_t)w.qrows * 4);
+  w.cstart = (int32_t*)take((size_t)(C + 2) * 4);
+  w.pstart = (int32_t*)take((size_t)(C + 2) * 4);
+  w.tile_n = (int32_t*)take((size_t)w.n_ct * 4);
+  w.qtile_n = (int32_t*)take((size_t)w.n_qt * 4);
+  w.rank = (int64_t*)take((size_t)(N + 1) * 8);
   w.sort_tmp_bytes = knn_sort_temp_bytes(N);
   w.sort_tmp = take(w.sort_tmp_bytes);
-  w.part = (u64*)take((size_t)n_q * (size_t)k * 8);
+  w.part = (u64*)take((size_t)w.qrows * (size_t)k * 8);
   w.part_plain = (u64*)take((size_t)n_q * (size_t)KNN_MAX_SPLIT * (size_t)k * 8);
-  w.n_zero = (unsigned long long*)take(16);
+  w.counters = (unsigned long long*)take(32);
   w.total = off + 256;
   return w;
 }
@@ -752,7 +841,7 @@ int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, in
   // pruned search (see "pruned search: preparation" above)
   const KnnPruneWs w = knn_prune_ws((char*)d_ws, n_q, N, dpad, k);
   const int nq4 = dpad >> 2;
-  const int64_t C = knn_pivots(N), n_ct = gficf_ceil_div(N, KNN_TC), n_qt = gficf_ceil_div(n_q, KNN_TQ);
+  const int64_t C = w.C;
   auto blocks_for = [](int64_t n) { return dim3((unsigned)gficf_ceil_div(n, 256)); };
   // 1. pivots = C evenly spaced points; every point's nearest pivot (the tile kernel, k = 1)
   hipLaunchKernelGGL(k_knn_gather_rows, blocks_for(C * nq4), dim3(256), 0, ctx->stream, d_points, (const int32_t*)nullptr, C, nq4, N / C, w.pivots);
@@ -769,46 +858,65 @@ int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, in
   rc = knn_launch_m<false>(ctx, metric, ac);
   if (rc) return rc;
   hipLaunchKernelGGL(k_knn_merge, blocks_for(C), dim3(256), 0, ctx->stream, w.apart, C, 1, 1, metric, (const int32_t*)nullptr, w.coarse_of, (float*)nullptr, C, (const uint32_t*)nullptr, 0u);
-  // 2. candidates sorted by (coarse, fine) pivot (stable: ties keep index order); the queries of this block likewise
+  // 2. candidates sorted by (coarse, fine) pivot (stable: ties keep index order) and laid out cell by cell, every cell
+  //    starting on a tile boundary; the queries of this block likewise, with the query tile size
   hipLaunchKernelGGL(k_knn_sort_keys, blocks_for(N), dim3(256), 0, ctx->stream, w.pivot_of, w.coarse_of, N, w.keys);
   hipLaunchKernelGGL(k_knn_iota, blocks_for(N), dim3(256), 0, ctx->stream, w.iota, N);
-  size_t tb = w.sort_tmp_bytes;
-  GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys, w.key_tmp, w.iota, w.perm_x, (size_t)N, 0u, 26u, ctx->stream));
-  tb = w.sort_tmp_bytes;
-  GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys + q_begin, w.key_tmp, w.iota, w.perm_q, (size_t)n_q, 0u, 26u, ctx->stream));
-  hipLaunchKernelGGL(k_knn_gather_rows, blocks_for(N * nq4), dim3(256), 0, ctx->stream, d_points, w.perm_x, N, nq4, (int64_t)0, w.xp);
-  hipLaunchKernelGGL(k_knn_gather_rows, blocks_for(n_q * nq4), dim3(256), 0, ctx->stream, d_points + q_begin * dpad, w.perm_q, n_q, nq4, (int64_t)0, w.qp);
+  GFICF_HIP_CHECK(hipMemsetAsync(w.xp, 0, sizeof(float) * (size_t)w.xrows * dpad, ctx->stream));
+  GFICF_HIP_CHECK(hipMemsetAsync(w.qp, 0, sizeof(float) * (size_t)w.qrows * dpad, ctx->stream));
+  GFICF_HIP_CHECK(hipMemsetAsync(w.perm_x, 0xFF, sizeof(int32_t) * (size_t)w.xrows, ctx->stream));
+  GFICF_HIP_CHECK(hipMemsetAsync(w.perm_q, 0xFF, sizeof(int32_t) * (size_t)w.qrows, ctx->stream));
+  auto layout = [&](const int32_t* keys_in, int64_t n, int T, const float* src, float* dst, int32_t* perm_pad, int64_t n_tiles, int32_t* tile_n) -> int {
+    size_t tb = w.sort_tmp_bytes;
+    GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, keys_in, w.key_tmp, w.iota, w.perm_sorted, (size_t)n, 0u, 26u, ctx->stream));
+    hipLaunchKernelGGL(k_knn_cell_heads, blocks_for(n + 1), dim3(256), 0, ctx->stream, w.key_tmp, n, w.rank);
+    int r = gficf_exclusive_scan_i64(ctx, w.rank, n + 1);
+    if (r) return r;
+    hipLaunchKernelGGL(k_knn_cell_starts, blocks_for(n + 1), dim3(256), 0, ctx->stream, w.key_tmp, w.rank, n, w.cstart);
+    hipLaunchKernelGGL(k_knn_cell_offsets, dim3(1), dim3(1024), 0, ctx->stream, w.cstart, w.rank + n, T, w.pstart);
+    hipLaunchKernelGGL(k_knn_pad_scatter, blocks_for(n * nq4), dim3(256), 0, ctx->stream, w.key_tmp, w.rank, w.cstart, w.pstart, w.perm_sorted, n, nq4,
+                       src, dst, perm_pad);
+    hipLaunchKernelGGL(k_knn_tile_counts, blocks_for(n_tiles), dim3(256), 0, ctx->stream, perm_pad, n_tiles, T, tile_n);
+    GFICF_HIP_CHECK(hipGetLastError());
+    return GFICF_OK;
+  };
+  rc = layout(w.keys, N, KNN_TC, d_points, w.xp, w.perm_x, w.n_ct, w.tile_n);
+  if (rc) return rc;
+  rc = layout(w.keys + q_begin, n_q, KNN_TQ, d_points + q_begin * dpad, w.qp, w.perm_q, w.n_qt, w.qtile_n);
+  if (rc) return rc;
   // 3. centre and radius of every candidate tile; bound of every (query tile, candidate tile) pair
-  GFICF_HIP_CHECK(hipMemsetAsync(w.n_zero, 0, 16, ctx->stream));
+  GFICF_HIP_CHECK(hipMemsetAsync(w.counters, 0, 32, ctx->stream));
   const size_t lds_lb = (size_t)KNN_TQ * (dpad + 1) * sizeof(float);
   switch (metric) {
     case GFICF_KNN_MANHATTAN:
-      hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_MANHATTAN>, dim3((unsigned)n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, N, d, dpad, w.centers, w.radius);
-      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_MANHATTAN>, dim3((unsigned)n_qt), dim3(256), lds_lb, ctx->stream, w.qp, n_q, d, dpad, w.centers, w.radius, n_ct, w.lb, w.n_zero);
+      hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_MANHATTAN>, dim3((unsigned)w.n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, w.tile_n, d, dpad, w.centers, w.radius);
+      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_MANHATTAN>, dim3((unsigned)w.n_qt), dim3(256), lds_lb, ctx->stream, w.qp, w.qtile_n, d, dpad, w.centers, w.radius, w.n_ct, w.lb, w.counters);
       break;
     case GFICF_KNN_EUCLIDEAN:
-      hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_EUCLIDEAN>, dim3((unsigned)n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, N, d, dpad, w.centers, w.radius);
-      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_EUCLIDEAN>, dim3((unsigned)n_qt), dim3(256), lds_lb, ctx->stream, w.qp, n_q, d, dpad, w.centers, w.radius, n_ct, w.lb, w.n_zero);
+      hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_EUCLIDEAN>, dim3((unsigned)w.n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, w.tile_n, d, dpad, w.centers, w.radius);
+      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_EUCLIDEAN>, dim3((unsigned)w.n_qt), dim3(256), lds_lb, ctx->stream, w.qp, w.qtile_n, d, dpad, w.centers, w.radius, w.n_ct, w.lb, w.counters);
       break;
     default:
-      hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_COSINE>, dim3((unsigned)n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, N, d, dpad, w.centers, w.radius);
-      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_COSINE>, dim3((unsigned)n_qt), dim3(256), lds_lb, ctx->stream, w.qp, n_q, d, dpad, w.centers, w.radius, n_ct, w.lb, w.n_zero);
+      hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_COSINE>, dim3((unsigned)w.n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, w.tile_n, d, dpad, w.centers, w.radius);
+      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_COSINE>, dim3((unsigned)w.n_qt), dim3(256), lds_lb, ctx->stream, w.qp, w.qtile_n, d, dpad, w.centers, w.radius, w.n_ct, w.lb, w.counters);
       break;
   }
   GFICF_HIP_CHECK(hipGetLastError());
   // 4. the search over the reordered copies, tiles in best-first order with early exit; 5. back to the caller's order
   // ... unless the bounds say there is nothing to prune: then the plain search runs instead (chosen on the device,
   // both forms are enqueued and the one not chosen returns at once)
-  uint32_t* const flag = (uint32_t*)(w.n_zero + 1);
+  uint32_t* const flag = (uint32_t*)(w.counters + 2);
   const char* fe = getenv("GFICF_KNN_PRUNE");
-  hipLaunchKernelGGL(k_knn_choose, dim3(1), dim3(1), 0, ctx->stream, w.n_zero, (unsigned long long)(n_qt * n_ct), (uint32_t)(fe && atoi(fe) != 0), flag);
+  hipLaunchKernelGGL(k_knn_choose, dim3(1), dim3(1), 0, ctx->stream, w.counters, (uint32_t)(fe && atoi(fe) != 0), flag);
   KnnTileArgs ap{};
   ap.Q = d_points + q_begin * dpad; ap.n_q = n_q; ap.X = d_points; ap.N = N; ap.d = d; ap.dpad = dpad; ap.kk = k;
   ap.S = knn_split(ctx, n_q, N); ap.part = w.part_plain; ap.gate = flag; ap.gate_want = 1u;
   rc = knn_launch_m<false>(ctx, metric, ap);
   if (rc) return rc;
   hipLaunchKernelGGL(k_knn_merge, dim3(mblocks), dim3(256), 0, ctx->stream, w.part_plain, n_q, ap.S, k, metric, (const int32_t*)nullptr, d_idx, d_dist, ld_out, (const uint32_t*)flag, 1u);
-  a.Q = w.qp; a.n_q = n_q; a.X = w.xp; a.N = N; a.S = 1; a.part = w.part; a.perm_x = w.perm_x; a.lb = w.lb; a.gate = flag; a.gate_want = 0u;
+  a.Q = w.qp; a.n_q = w.qrows; a.X = w.xp; a.N = w.xrows; a.S = 1; a.part = w.part; a.perm_x = w.perm_x; a.lb = w.lb;
+  a.tile_n = w.tile_n; a.qtile_n = w.qtile_n; a.gate = flag; a.gate_want = 0u;
+  const int64_t n_qt = w.n_qt, n_ct = w.n_ct;
   int32_t* d_vis = nullptr;
   if (getenv("GFICF_KNN_STATS")) {                 // lab knob: mean number of candidate tiles a query tile had to visit
     GFICF_HIP_CHECK(hipMalloc((void**)&d_vis, sizeof(int32_t) * (size_t)n_qt));
@@ -824,7 +932,7 @@ int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, in
     fprintf(stderr, "[gficf knn] pruned search: %lld query tiles, %lld candidate tiles, visited mean %.1f max %d\n", (long long)n_qt, (long long)n_ct, sum / (double)n_qt, mx);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(k_knn_merge, dim3(mblocks), dim3(256), 0, ctx->stream, w.part, n_q, 1, k, metric, (const int32_t*)w.perm_q, d_idx, d_dist, ld_out, (const uint32_t*)flag, 0u);
+  hipLaunchKernelGGL(k_knn_merge, blocks_for(w.qrows), dim3(256), 0, ctx->stream, w.part, w.qrows, 1, k, metric, (const int32_t*)w.perm_q, d_idx, d_dist, ld_out, (const uint32_t*)flag, 0u);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
