@@ -20,9 +20,15 @@
 // distances in registers.  Per query a sorted list of the k best 64-bit keys
 // (sortable(distance) << 32 | index) lives in LDS; a thread inserts a candidate only when it beats
 // the list's last key (rare after the first tiles).  A query's row of the tile belongs to the 16 lanes
-// of one wave, which take turns (wave-uniform loop, one elected lane per row and round): no locks.  The candidate range
-// is split S ways to fill the chip; a merge kernel picks the k best of the S partial lists and
+// of one wave, which take turns (wave-uniform loop, one elected lane per row and round): no locks.  A merge kernel
 // writes the 1-based index matrix column-major — the layout the Jaccard ingest reads.
+//
+// Two forms of the same kernel, same bits:
+//   plain  : every query tile against every candidate tile, the candidate range split S ways to fill the chip;
+//   pruned : (default from 30 k points) the points are reordered so that a tile holds neighbours, every
+//            (query tile, candidate tile) pair gets a triangle-inequality lower bound, and a query tile visits the
+//            candidate tiles best bound first until the bound passes its queries' k-th best — see "pruned search:
+//            preparation" below.  When the bounds show no cluster structure, a device flag routes to the plain form.
 #include <cfloat>
 #include <cstdlib>
 #include <cstring>
@@ -152,7 +158,8 @@ __device__ __noinline__ float knn_row_insert(uint32_t list_addr, int kk, float d
 // the two adds and pay for it with two v_and to clear the sign bits.
 typedef float knn_f2 __attribute__((ext_vector_type(2)));
 
-// RQ = query rows per thread: 8 (tile of 128 queries: rows ty*4.. and 64+ty*4..) or 4 (tile of 64 queries).
+// RQ = query rows per thread: 4 (tile of 64 queries; measured faster than 8 = 128 queries, which the code still supports:
+// 100 k x 50, 31 nearest, manhattan: 27.7 against 33.1 ms — fewer insertions per slice, lighter epilogue).
 struct KnnOperands {            // one dimension's slice of the tiles: RQ query values, 8 candidate values
   float4 a0, a1, b0, b1;
 };
