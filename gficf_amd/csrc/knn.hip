@@ -194,6 +194,24 @@ __device__ inline void knn_dim(knn_f2 (&acc)[RQ][4], const KnnOperands& o) {
   }
 }
 
+// Lists of up to 64 entries live in registers: lane t of the row's 16-lane group holds entries EPL*t .. EPL*t+EPL-1
+// (EPL = KL / 16).  An insertion is the same shift as in the LDS form, but the entry in front of a lane's first one
+// comes from the lane below through one DPP row shift (the group's lane 0 reads 0, i.e. "nothing in front"), so a
+// round is ~25 VALU instructions and no LDS round trip.  Every lane of the group calls it with the group's key.
+template <int EPL>
+__device__ __forceinline__ void knn_reg_insert(u64 (&lst)[EPL], u64 key) {
+  const u64 last = lst[EPL - 1];
+  const uint32_t plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)last, 0x111, 0xf, 0xf, true);          // row_shr:1, zero fill
+  const uint32_t phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(last >> 32), 0x111, 0xf, 0xf, true);
+  u64 prev = ((u64)phi << 32) | (u64)plo;
+#pragma unroll
+  for (int h = 0; h < EPL; ++h) {
+    const u64 cur = lst[h];
+    lst[h] = cur <= key ? cur : (prev <= key ? key : prev);
+    prev = cur;
+  }
+}
+
 // Arguments of the tile kernel.  Queries and candidates are separate row-major arrays (the plain search passes
 // Q = X + q_begin rows; the pruned search passes its two reordered copies).
 struct KnnTileArgs {
@@ -229,8 +247,10 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const KnnTileArgs 
   const int64_t N = A.N;
   float* const sA = reinterpret_cast<float*>(smem);                          // [dpad][TQ]
   float* const sB = sA + (size_t)dpad * TQ;                                  // [2][DK][TC]
-  u64* const sKey = reinterpret_cast<u64*>(sB + 2 * KNN_DK * KNN_TC);        // [TQ][KL]
-  float* const sLb = reinterpret_cast<float*>(sKey + TQ * KL);               // PRUNE: [n_ct] bounds, +inf once visited
+  constexpr bool REGL = KL <= 64;                                            // lists in registers (else in LDS)
+  constexpr int EPL = KL / 16;                                               // list entries per lane of a row's 16-lane group
+  u64* const sKey = reinterpret_cast<u64*>(sB + 2 * KNN_DK * KNN_TC);        // !REGL: [TQ][KL]
+  float* const sLb = reinterpret_cast<float*>(sKey + (REGL ? 0 : TQ * KL));  // PRUNE: [n_ct] bounds, +inf once visited
   const uint32_t key_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)(unsigned char*)sKey;   // LDS byte address
   __shared__ float s_wtau[2][KNN_THREADS / 64];                              // PRUNE: per-wave max of the k-th best, by tile parity
 
@@ -246,7 +266,13 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const KnnTileArgs 
   const float4* const X4 = reinterpret_cast<const float4*>(A.X);
   const float4* const Q4 = reinterpret_cast<const float4*>(A.Q);
 
-  for (int e = tid; e < TQ * KL; e += KNN_THREADS) sKey[e] = ~0ull;
+  if (!REGL)
+    for (int e = tid; e < TQ * KL; e += KNN_THREADS) sKey[e] = ~0ull;
+  u64 lst[RQ][REGL ? EPL : 1];                       // REGL: this lane's entries of its rows' lists
+#pragma unroll
+  for (int r = 0; r < RQ; ++r)
+#pragma unroll
+    for (int h = 0; h < (REGL ? EPL : 1); ++h) lst[r][h] = ~0ull;
   // query tile -> sA[dim][query]; consecutive lanes take consecutive queries (conflict-free LDS writes)
   for (int f = tid; f < TQ * nq4; f += KNN_THREADS) {
     const int row = f & (TQ - 1), quad = f / TQ;
@@ -378,8 +404,46 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const KnnTileArgs 
                 dv[s] = METRIC == GFICF_KNN_COSINE ? 1.0f - av : av;
                 if (RAG && (s < 4 ? 0 : 64) + tx * 4 + (s & 3) >= nvalid) dv[s] = NAN;       // never <= tau
               }
-              tau[r] = knn_row_insert<KL>(key_addr + (uint32_t)(row * KL * 8), kk, dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6],
-                                          dv[7], tau[r], live, (uint32_t)j0, tid, PRUNE ? A.perm_x : (const int32_t*)nullptr);
+              if (REGL) {
+                // Insertions (rare once the lists have warmed up).  The 16 lanes of a 16-lane group share this row
+                // (= this list).  The wave loops (uniformly) while any lane holds a candidate; per round the lowest
+                // such lane of each group hands one key to its group, whose lanes shift it into their registers.
+                uint32_t pass = 0;
+                if (live) {
+#pragma unroll
+                  for (int s = 0; s < 8; ++s) pass |= (dv[s] <= tau[r]) ? 1u << s : 0u;
+                }
+                for (;;) {
+                  const u64 m = __ballot(pass != 0);
+                  if (m == 0) break;
+                  const uint32_t gm = (uint32_t)(m >> (tid & 48)) & 0xFFFFu;
+                  const int leader = __ffs(gm) - 1;             // -1: this group has no candidate this round
+                  uint32_t khi = 0, klo = 0;
+                  if (pass != 0 && tx == leader) {
+                    const int s = __ffs(pass) - 1;
+                    pass &= pass - 1;
+                    float h = dv[0];
+#pragma unroll
+                    for (int t = 1; t < 8; ++t) h = s == t ? dv[t] : h;
+                    khi = f32_sortable(h);
+                    klo = (uint32_t)j0 + (uint32_t)((s < 4 ? 0 : 64) + tx * 4 + (s & 3));
+                    if (PRUNE) klo = (uint32_t)A.perm_x[klo];   // the key carries the point's original id
+                  }
+                  const int src = ((tid & 48) | (leader & 15)) << 2;
+                  khi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)khi);
+                  klo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)klo);
+                  if (leader >= 0) knn_reg_insert<REGL ? EPL : 1>(lst[r], ((u64)khi << 32) | (u64)klo);
+                }
+                // the row's k-th best: entry kk - 1 sits in lane (kk - 1) / EPL of the group
+                uint32_t th = (uint32_t)(lst[r][0] >> 32);
+#pragma unroll
+                for (int h = 1; h < (REGL ? EPL : 1); ++h) th = ((kk - 1) % EPL) == h ? (uint32_t)(lst[r][h] >> 32) : th;
+                th = (uint32_t)__shfl((int)th, (kk - 1) / EPL, 16);
+                tau[r] = th == 0xFFFFFFFFu ? INFINITY : sortable_f32(th);      // list not full yet: everything enters
+              } else {
+                tau[r] = knn_row_insert<KL>(key_addr + (uint32_t)(row * KL * 8), kk, dv[0], dv[1], dv[2], dv[3], dv[4], dv[5], dv[6],
+                                            dv[7], tau[r], live, (uint32_t)j0, tid, PRUNE ? A.perm_x : (const int32_t*)nullptr);
+              }
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[r][s] = knn_f2{0.0f, 0.0f};
@@ -408,10 +472,22 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const KnnTileArgs 
 
   if (A.visited && tid == 0) A.visited[blockIdx.x] = tile_no;
   // partial lists of this candidate slice
-  for (int e = tid; e < TQ * kk; e += KNN_THREADS) {
-    const int row = e / kk, t = e % kk;
-    const int64_t q = q0 + row;
-    if (q < A.n_q) A.part[(q * S + sp) * kk + t] = sKey[row * KL + t];
+  if (REGL) {
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) {
+      const int64_t q = q0 + (r < 4 ? 0 : 64) + ty * 4 + (r & 3);
+#pragma unroll
+      for (int h = 0; h < (REGL ? EPL : 1); ++h) {
+        const int e = EPL * tx + h;
+        if (q < A.n_q && e < kk) A.part[(q * S + sp) * kk + e] = lst[r][h];
+      }
+    }
+  } else {
+    for (int e = tid; e < TQ * kk; e += KNN_THREADS) {
+      const int row = e / kk, t = e % kk;
+      const int64_t q = q0 + row;
+      if (q < A.n_q) A.part[(q * S + sp) * kk + t] = sKey[row * KL + t];
+    }
   }
 }
 
@@ -530,11 +606,16 @@ __global__ __launch_bounds__(KNN_TC) void k_knn_tile_stats(const float* __restri
 
 // one workgroup per query tile: lb[qt][ct] = the bound above, in the domain of the keys (manhattan: distance,
 // euclidean: squared distance, cosine: 1 - cos), lowered by the slack; never negative.
+// It also counts the pairs that are certain to be pruned, for the choice between the two forms of the search: any
+// candidate tile with at least kk points bounds every query's k-th best from above by max_q dist(q, centre) + radius
+// (all its points are that close); U = the smallest such bound over the tiles; a pair with lb > U is never visited.
 template <int METRIC>
 __global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, const int32_t* __restrict__ qtile_n, int d, int dpad,
-                                                const float* __restrict__ centers, const float* __restrict__ radius, int64_t n_ct,
-                                                float* __restrict__ lb, unsigned long long* __restrict__ counters) {
+                                                const float* __restrict__ centers, const float* __restrict__ radius,
+                                                const int32_t* __restrict__ tile_n, int kk, int64_t n_ct, float* __restrict__ lb,
+                                                unsigned long long* __restrict__ counters) {
   extern __shared__ float s_q[];                     // [KNN_TQ][dpad + 1]
+  __shared__ float s_u[4];
   const int64_t qt = blockIdx.x, q0 = qt * KNN_TQ;
   const int nq = qtile_n[qt];
   if (nq <= 0) return;                               // padding tile: its workgroup of the search exits at once
@@ -545,33 +626,46 @@ __global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, con
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int nz = 0, np = 0;
+  float u = INFINITY;                                // upper bound of the queries' k-th best (key domain), this wave's tiles
+  auto to_key = [](float e, float slack_sign) {     // distance of the bound's metric -> key domain, pushed by the slack
+    if (METRIC == GFICF_KNN_MANHATTAN) return e;
+    if (METRIC == GFICF_KNN_EUCLIDEAN) return e * e * (1.0f + slack_sign * KNN_LB_SLACK);
+    return 0.5f * e * e * (1.0f + slack_sign * KNN_LB_SLACK) + slack_sign * 4e-6f;
+  };
   for (int64_t c = wave; c < n_ct; c += 4) {
     if (radius[c] < 0.0f) {                          // empty candidate tile: never visited
       if (lane == 0) lb[qt * n_ct + c] = INFINITY;
       continue;
     }
-    float dq = lane < nq ? knn_bound_dist<METRIC>(s_q + lane * pitch, centers + c * dpad, d) : INFINITY;
+    const float dq = lane < nq ? knn_bound_dist<METRIC>(s_q + lane * pitch, centers + c * dpad, d) : INFINITY;
+    float dmin = dq, dmax = lane < nq ? dq : 0.0f;
 #pragma unroll
-    for (int w = 32; w >= 1; w >>= 1) dq = fminf(dq, __shfl_xor(dq, w));
+    for (int w = 32; w >= 1; w >>= 1) { dmin = fminf(dmin, __shfl_xor(dmin, w)); dmax = fmaxf(dmax, __shfl_xor(dmax, w)); }
     if (lane == 0) {
       const float r = radius[c];
-      float b = dq - r - KNN_LB_SLACK * (dq + r);
-      b = b > 0.0f ? b : 0.0f;
-      if (METRIC == GFICF_KNN_EUCLIDEAN) b = b * b * (1.0f - KNN_LB_SLACK);
-      if (METRIC == GFICF_KNN_COSINE) b = fmaxf(0.5f * b * b * (1.0f - KNN_LB_SLACK) - 4e-6f, 0.0f);
-      lb[qt * n_ct + c] = b;
-      nz += b <= 0.0f ? 1 : 0;
-      ++np;
+      float b = dmin - r - KNN_LB_SLACK * (dmin + r);
+      b = b > 0.0f ? to_key(b, -1.0f) : 0.0f;
+      lb[qt * n_ct + c] = b > 0.0f ? b : 0.0f;
+      if (tile_n[c] >= kk) u = fminf(u, to_key((dmax + r) * (1.0f + KNN_LB_SLACK), 1.0f));
     }
   }
-  if (lane == 0) { atomicAdd(counters, (unsigned long long)nz); atomicAdd(counters + 1, (unsigned long long)np); }
+  if (lane == 0) s_u[wave] = u;
+  __syncthreads();
+  const float U = fminf(fminf(s_u[0], s_u[1]), fminf(s_u[2], s_u[3]));
+  int npr = 0, np = 0;                               // pairs certain to be pruned / all pairs with a real candidate tile
+  for (int64_t c = threadIdx.x; c < n_ct; c += 256) {
+    const float b = lb[qt * n_ct + c];               // written above by this workgroup (same wave's lane 0 or another wave: after the barrier)
+    if (b < INFINITY) { ++np; npr += b > U ? 1 : 0; }
+  }
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) { npr += __shfl_xor(npr, w); np += __shfl_xor(np, w); }
+  if (lane == 0) { atomicAdd(counters, (unsigned long long)npr); atomicAdd(counters + 1, (unsigned long long)np); }
 }
 
-// flag = 1 (plain search) when more than half of the (query tile, candidate tile) pairs have no positive bound: the
-// data has no cluster structure to prune by, and the plain form with its split candidate range runs faster
+// flag = 1 (plain search) when fewer than half of the (query tile, candidate tile) pairs are certain to be pruned: the
+// data has too little cluster structure, and the plain form with its split candidate range runs faster
 __global__ void k_knn_choose(const unsigned long long* __restrict__ counters, uint32_t force, uint32_t* __restrict__ flag) {
-  *flag = force ? 0u : (2ull * counters[0] > counters[1] ? 1u : 0u);
+  *flag = force ? 0u : (2ull * counters[0] < counters[1] ? 1u : 0u);
 }
 
 // ---- cells padded to whole tiles
@@ -689,7 +783,7 @@ int knn_check(int64_t N, int d, int k, int metric) {
 template <int METRIC, int KL, bool PRUNE>
 int knn_launch(gficf_ctx* ctx, const KnnTileArgs& a) {
   const int64_t n_ct = gficf_ceil_div(a.N, KNN_TC);
-  const size_t lds = (size_t)a.dpad * KNN_TQ * 4 + 2 * KNN_DK * KNN_TC * 4 + (size_t)KNN_TQ * KL * 8 + (PRUNE ? (size_t)n_ct * 4 : 0);
+  const size_t lds = (size_t)a.dpad * KNN_TQ * 4 + 2 * KNN_DK * KNN_TC * 4 + (KL > 64 ? (size_t)KNN_TQ * KL * 8 : 0) + (PRUNE ? (size_t)n_ct * 4 : 0);
   static bool attr_set[64] = {};
   if (!attr_set[ctx->device & 63]) {
     GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_knn_tiles<METRIC, KL, KNN_RQ, PRUNE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
@@ -897,15 +991,15 @@ int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, in
   switch (metric) {
     case GFICF_KNN_MANHATTAN:
       hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_MANHATTAN>, dim3((unsigned)w.n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, w.tile_n, d, dpad, w.centers, w.radius);
-      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_MANHATTAN>, dim3((unsigned)w.n_qt), dim3(256), lds_lb, ctx->stream, w.qp, w.qtile_n, d, dpad, w.centers, w.radius, w.n_ct, w.lb, w.counters);
+      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_MANHATTAN>, dim3((unsigned)w.n_qt), dim3(256), lds_lb, ctx->stream, w.qp, w.qtile_n, d, dpad, w.centers, w.radius, w.tile_n, k, w.n_ct, w.lb, w.counters);
       break;
     case GFICF_KNN_EUCLIDEAN:
       hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_EUCLIDEAN>, dim3((unsigned)w.n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, w.tile_n, d, dpad, w.centers, w.radius);
-      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_EUCLIDEAN>, dim3((unsigned)w.n_qt), dim3(256), lds_lb, ctx->stream, w.qp, w.qtile_n, d, dpad, w.centers, w.radius, w.n_ct, w.lb, w.counters);
+      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_EUCLIDEAN>, dim3((unsigned)w.n_qt), dim3(256), lds_lb, ctx->stream, w.qp, w.qtile_n, d, dpad, w.centers, w.radius, w.tile_n, k, w.n_ct, w.lb, w.counters);
       break;
     default:
       hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_COSINE>, dim3((unsigned)w.n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, w.tile_n, d, dpad, w.centers, w.radius);
-      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_COSINE>, dim3((unsigned)w.n_qt), dim3(256), lds_lb, ctx->stream, w.qp, w.qtile_n, d, dpad, w.centers, w.radius, w.n_ct, w.lb, w.counters);
+      hipLaunchKernelGGL(k_knn_lb<GFICF_KNN_COSINE>, dim3((unsigned)w.n_qt), dim3(256), lds_lb, ctx->stream, w.qp, w.qtile_n, d, dpad, w.centers, w.radius, w.tile_n, k, w.n_ct, w.lb, w.counters);
       break;
   }
   GFICF_HIP_CHECK(hipGetLastError());
