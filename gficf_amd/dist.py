@@ -43,6 +43,25 @@ def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
     return b, min(n, b + rpr)
 
 
+def shard_bounds_by_nnz(colptr, world: int) -> list[tuple[int, int]]:
+    """Contiguous cell (column) blocks of a CSC matrix balanced by stored entries rather than by cell count
+    (the GF-ICF passes stream nnz, so that is what a rank's time follows).  ``colptr``: the
+    N+1 column pointers (any integer array-like).  Returns ``world`` (begin, end) pairs covering [0, N); block r
+    ends at the first cell boundary at or after r+1 equal shares of the entries."""
+    import numpy as np
+
+    cp = np.asarray(colptr, dtype=np.int64)
+    n = len(cp) - 1
+    nnz = int(cp[-1] - cp[0]) if n > 0 else 0
+    cuts = [0]
+    for r in range(1, world):
+        target = cp[0] + (nnz * r + world - 1) // world
+        c = int(np.searchsorted(cp, target, side="left"))
+        cuts.append(min(max(c, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
 def _all_gather_rows(table, local_view, group):
     """All-gather equal-sized row blocks into ``table`` (``local_view`` aliases this rank's block)."""
     try:

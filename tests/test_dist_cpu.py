@@ -131,3 +131,21 @@ def test_shard_bounds_cover_and_are_equal_pitch():
                 assert b == min(n, r * rpr) and 0 <= e - b <= rpr
                 if r:
                     assert b == blocks[r - 1][1]
+
+
+def test_nnz_balanced_column_blocks():
+    from gficf_amd import synth
+    from gficf_amd.dist import shard_bounds_by_nnz
+
+    cp, _, _ = synth.counts_csc(400, 1000, seed=3)
+    for world in (1, 2, 3, 8):
+        blocks = shard_bounds_by_nnz(cp, world)
+        assert blocks[0][0] == 0 and blocks[-1][1] == 1000 and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+        share = [cp[e] - cp[b] for b, e in blocks]
+        assert sum(share) == cp[-1]
+        # no block is further from the ideal share than the largest cell
+        assert max(abs(s - cp[-1] / world) for s in share) <= np.diff(cp).max() * 2
+    # degenerate inputs: empty matrix, more ranks than cells, all entries in one cell
+    assert shard_bounds_by_nnz([0], 4) == [(0, 0)] * 4
+    assert shard_bounds_by_nnz([0, 5], 3)[-1][1] == 1 and sum(e - b for b, e in shard_bounds_by_nnz([0, 5], 3)) == 1
+    assert sum(e - b for b, e in shard_bounds_by_nnz([0, 0, 0, 9, 9], 2)) == 4
