@@ -614,47 +614,58 @@ __global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, con
                                                 const float* __restrict__ centers, const float* __restrict__ radius,
                                                 const int32_t* __restrict__ tile_n, int kk, int64_t n_ct, float* __restrict__ lb,
                                                 unsigned long long* __restrict__ counters) {
-  extern __shared__ float s_q[];                     // [KNN_TQ][dpad + 1]
+  extern __shared__ float s_q[];                     // [KNN_TQ][dpad + 1] queries, then [dpad] their centre
+  __shared__ float s_red[4];
   __shared__ float s_u[4];
   const int64_t qt = blockIdx.x, q0 = qt * KNN_TQ;
   const int nq = qtile_n[qt];
   if (nq <= 0) return;                               // padding tile: its workgroup of the search exits at once
   const int pitch = dpad + 1;
+  float* const s_c = s_q + KNN_TQ * pitch;
   for (int e = threadIdx.x; e < KNN_TQ * dpad; e += 256) {
     const int row = e / dpad, dim = e % dpad;
     s_q[row * pitch + dim] = row < nq ? Q[(q0 + row) * dpad + dim] : 0.0f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float u = INFINITY;                                // upper bound of the queries' k-th best (key domain), this wave's tiles
+  // the query tile's own centre and radius
+  for (int dim = threadIdx.x; dim < dpad; dim += 256) {
+    float sum = 0.0f;
+    for (int r = 0; r < nq; ++r) sum += s_q[r * pitch + dim];
+    s_c[dim] = sum / (float)nq;
+  }
+  __syncthreads();
+  float rq = (int)threadIdx.x < nq ? knn_bound_dist<METRIC>(s_q + threadIdx.x * pitch, s_c, d) : 0.0f;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) rq = fmaxf(rq, __shfl_xor(rq, w));
+  if (lane == 0) s_red[wave] = rq;
+  __syncthreads();
+  rq = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   auto to_key = [](float e, float slack_sign) {     // distance of the bound's metric -> key domain, pushed by the slack
     if (METRIC == GFICF_KNN_MANHATTAN) return e;
     if (METRIC == GFICF_KNN_EUCLIDEAN) return e * e * (1.0f + slack_sign * KNN_LB_SLACK);
     return 0.5f * e * e * (1.0f + slack_sign * KNN_LB_SLACK) + slack_sign * 4e-6f;
   };
-  for (int64_t c = wave; c < n_ct; c += 4) {
-    if (radius[c] < 0.0f) {                          // empty candidate tile: never visited
-      if (lane == 0) lb[qt * n_ct + c] = INFINITY;
-      continue;
-    }
-    const float dq = lane < nq ? knn_bound_dist<METRIC>(s_q + lane * pitch, centers + c * dpad, d) : INFINITY;
-    float dmin = dq, dmax = lane < nq ? dq : 0.0f;
-#pragma unroll
-    for (int w = 32; w >= 1; w >>= 1) { dmin = fminf(dmin, __shfl_xor(dmin, w)); dmax = fmaxf(dmax, __shfl_xor(dmax, w)); }
-    if (lane == 0) {
-      const float r = radius[c];
-      float b = dmin - r - KNN_LB_SLACK * (dmin + r);
-      b = b > 0.0f ? to_key(b, -1.0f) : 0.0f;
-      lb[qt * n_ct + c] = b > 0.0f ? b : 0.0f;
-      if (tile_n[c] >= kk) u = fminf(u, to_key((dmax + r) * (1.0f + KNN_LB_SLACK), 1.0f));
-    }
+  // one thread per candidate tile: centre-to-centre distance; every query is within rq of the query centre and every
+  // point of the tile within its radius of the tile centre, so  dist(q, x) >= dcc - rq - r  and  <= dcc + rq + r
+  float u = INFINITY;                                // upper bound of the queries' k-th best (key domain)
+  for (int64_t c = threadIdx.x; c < n_ct; c += 256) {
+    const float r = radius[c];
+    if (r < 0.0f) { lb[qt * n_ct + c] = INFINITY; continue; }      // empty candidate tile: never visited
+    const float dcc = knn_bound_dist<METRIC>(s_c, centers + c * dpad, d);
+    float b = dcc - rq - r - KNN_LB_SLACK * (dcc + rq + r);
+    b = b > 0.0f ? to_key(b, -1.0f) : 0.0f;
+    lb[qt * n_ct + c] = b > 0.0f ? b : 0.0f;
+    if (tile_n[c] >= kk) u = fminf(u, to_key((dcc + rq + r) * (1.0f + KNN_LB_SLACK), 1.0f));
   }
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) u = fminf(u, __shfl_xor(u, w));
   if (lane == 0) s_u[wave] = u;
   __syncthreads();
   const float U = fminf(fminf(s_u[0], s_u[1]), fminf(s_u[2], s_u[3]));
   int npr = 0, np = 0;                               // pairs certain to be pruned / all pairs with a real candidate tile
   for (int64_t c = threadIdx.x; c < n_ct; c += 256) {
-    const float b = lb[qt * n_ct + c];               // written above by this workgroup (same wave's lane 0 or another wave: after the barrier)
+    const float b = lb[qt * n_ct + c];               // this thread's own stores
     if (b < INFINITY) { ++np; npr += b > U ? 1 : 0; }
   }
 #pragma unroll
@@ -987,7 +998,7 @@ int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, in
   if (rc) return rc;
   // 3. centre and radius of every candidate tile; bound of every (query tile, candidate tile) pair
   GFICF_HIP_CHECK(hipMemsetAsync(w.counters, 0, 32, ctx->stream));
-  const size_t lds_lb = (size_t)KNN_TQ * (dpad + 1) * sizeof(float);
+  const size_t lds_lb = ((size_t)KNN_TQ * (dpad + 1) + dpad) * sizeof(float);
   switch (metric) {
     case GFICF_KNN_MANHATTAN:
       hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_MANHATTAN>, dim3((unsigned)w.n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, w.tile_n, d, dpad, w.centers, w.radius);
