@@ -58,6 +58,20 @@ def test_pruned_search_gives_the_same_bits(metric, N, d, k, monkeypatch):
     assert np.array_equal(got["dist"].astype(np.float32), wdist.astype(np.float32))
 
 
+@pytest.mark.parametrize("metric,k", [("manhattan", 31), ("euclidean", 16), ("cosine", 51)])
+def test_default_path_at_size_clustered_and_not(metric, k):
+    """60 k points: the pruned form is the default here (and falls back to the plain one on the device when the data
+    has nothing to prune).  Blocks of queries against the oracle, clustered and unclustered data."""
+    N, d = 60000, 30
+    rng = np.random.default_rng(5)
+    for name, X in (("blobs", blobs(N, d, seed=77, centers=25)), ("normal", rng.normal(size=(N, d)))):
+        got = gficf_amd.find_nn(X, k, True, metric)
+        for qb, qe in ((0, 700), (31000, 31500), (N - 300, N)):
+            widx, wdist = oracle.knn(X, k, metric, nthreads=16, queries=(qb, qe))
+            assert np.array_equal(got["idx"][qb:qe], widx[qb:qe]), (name, qb)
+            assert np.array_equal(got["dist"][qb:qe].astype(np.float32), wdist[qb:qe].astype(np.float32)), (name, qb)
+
+
 def test_pruned_search_on_unclustered_and_degenerate_data(monkeypatch):
     monkeypatch.setenv("GFICF_KNN_PRUNE", "1")
     rng = np.random.default_rng(8)
