@@ -225,7 +225,6 @@ struct KnnTileArgs {
   const float* lb;         // PRUNE: [n_qt][n_ct] lower bound of the distance between query tile and candidate tile
   const int32_t* tile_n;   // PRUNE: points in candidate tile t (cells are padded to whole tiles: a prefix of the tile is real)
   const int32_t* qtile_n;  // PRUNE: queries in query tile qt
-  int32_t* visited;        // optional (GFICF_KNN_STATS lab knob): tiles processed per workgroup
   const uint32_t* gate;    // optional: run only if *gate == gate_want (the pruned / plain choice is made on the device)
   uint32_t gate_want;
 };
@@ -470,7 +469,6 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const KnnTileArgs 
     ++tile_no;
   }
 
-  if (A.visited && tid == 0) A.visited[blockIdx.x] = tile_no;
   // partial lists of this candidate slice
   if (REGL) {
 #pragma unroll
@@ -1028,21 +1026,7 @@ int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, in
   hipLaunchKernelGGL(k_knn_merge, dim3(mblocks), dim3(256), 0, ctx->stream, w.part_plain, n_q, ap.S, k, metric, (const int32_t*)nullptr, d_idx, d_dist, ld_out, (const uint32_t*)flag, 1u);
   a.Q = w.qp; a.n_q = w.qrows; a.X = w.xp; a.N = w.xrows; a.S = 1; a.part = w.part; a.perm_x = w.perm_x; a.lb = w.lb;
   a.tile_n = w.tile_n; a.qtile_n = w.qtile_n; a.gate = flag; a.gate_want = 0u;
-  const int64_t n_qt = w.n_qt, n_ct = w.n_ct;
-  int32_t* d_vis = nullptr;
-  if (getenv("GFICF_KNN_STATS")) {                 // lab knob: mean number of candidate tiles a query tile had to visit
-    GFICF_HIP_CHECK(hipMalloc((void**)&d_vis, sizeof(int32_t) * (size_t)n_qt));
-    a.visited = d_vis;
-  }
   rc = knn_launch_m<true>(ctx, metric, a);
-  if (d_vis) {
-    std::vector<int32_t> hv((size_t)n_qt);
-    (void)hipMemcpy(hv.data(), d_vis, sizeof(int32_t) * (size_t)n_qt, hipMemcpyDeviceToHost);
-    (void)hipFree(d_vis);
-    double sum = 0; int mx = 0;
-    for (int v : hv) { sum += v; mx = v > mx ? v : mx; }
-    fprintf(stderr, "[gficf knn] pruned search: %lld query tiles, %lld candidate tiles, visited mean %.1f max %d\n", (long long)n_qt, (long long)n_ct, sum / (double)n_qt, mx);
-  }
   if (rc) return rc;
   hipLaunchKernelGGL(k_knn_merge, blocks_for(w.qrows), dim3(256), 0, ctx->stream, w.part, w.qrows, 1, k, metric, (const int32_t*)w.perm_q, d_idx, d_dist, ld_out, (const uint32_t*)flag, 0u);
   GFICF_HIP_CHECK(hipGetLastError());

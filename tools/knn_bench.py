@@ -20,7 +20,7 @@ if len(sys.argv) > 4:
 for N, d, k, metric in cases:
     rng = np.random.default_rng(1)
     if os.environ.get("KNN_DATA", "normal") == "blobs":        # clustered, like cells in PCA space (bench.py's recipe)
-        centers = rng.normal(scale=6.0, size=(40, d))
+        centers = rng.normal(scale=float(os.environ.get("KNN_CENTER_SCALE", "6.0")), size=(40, d))
         lab = rng.integers(0, 40, size=N)
         X = torch.from_numpy(np.ascontiguousarray((centers[lab] + rng.normal(size=(N, d)) * rng.uniform(0.5, 2.0, size=(40, 1))[lab]).T)).cuda()
     else:
