@@ -17,6 +17,7 @@ from .api import (  # noqa: F401
     gficf,
     gficf_with_weights,
     jaccard_adjacency,
+    jaccard_coeff,
     jaccard_edges,
     rcpp_parallel_jaccard_coef,
 )

@@ -44,6 +44,7 @@ SIGNATURES = {
     "gficf_ctx_sync": (_int, [_vp]),
     "gficf_last_error": (ctypes.c_char_p, []),
     "gficf_jaccard_host": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _int]),
+    "gficf_jaccard_coeff_host": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _int]),
     "gficf_jaccard_kpad": (_int, [_int]),
     "gficf_jaccard_ingest_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _i64, _vp]),
     "gficf_jaccard_packed_words": (_int, [_i64, _int]),

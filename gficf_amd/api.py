@@ -5,6 +5,7 @@ Two layers over the C ABI (include/gficf_hip.h):
 * reference-shaped functions on host data, same names / argument meaning / error
   behaviour as the R package, so that parity tests read like the reference's own calls:
     - ``rcpp_parallel_jaccard_coef(mat, printOutput)``   reference R/RcppExports.R:16-18
+    - ``jaccard_coeff(idx, printOutput)``                reference R/RcppExports.R:8-10 (the serial entry)
     - ``jaccard_edges(neigh, verbose)``                  reference R/clustCells.R:63-68
     - ``gficf(M, cell_proportion_max, cell_proportion_min, storeRaw, normalize, verbose)``
                                                          reference R/gficf.R:17-33
@@ -103,6 +104,25 @@ def rcpp_parallel_jaccard_coef(mat, printOutput: bool = False, ctx: Context | No
     check(_lib.load().gficf_jaccard_host(ctx.handle, _np_ptr(m), is_f64, N, k, max(N, 1), _np_ptr(rm),
                                          1 if printOutput else 0))
     return rm.T
+
+
+def jaccard_coeff(idx, printOutput: bool = False, ctx: Context | None = None) -> np.ndarray:
+    """Drop-in for the reference's serial ``jaccard_coeff(idx, printOutput)`` (reference R/RcppExports.R:8-10,
+    src/jaccard_coeff.cpp:19-44): the same edges as :func:`rcpp_parallel_jaccard_coef`, but the rows with u > 0 follow
+    one another from the top of the (N*k) x 3 matrix (the rest is zero) and the intersection is of the rows as sets
+    (``Rcpp::intersect``; only rows that hold an id twice can tell)."""
+    idx = np.asarray(idx)
+    if idx.ndim != 2:
+        raise ValueError("idx must be a 2-d matrix")
+    N, k = idx.shape
+    if np.issubdtype(idx.dtype, np.integer):
+        m, is_f64 = np.asfortranarray(idx, dtype=np.int32), 0
+    else:
+        m, is_f64 = np.asfortranarray(idx, dtype=np.float64), 1
+    w = np.zeros((3, N * k), dtype=np.float64)      # C-order (3, E) == column-major (E, 3)
+    ctx = ctx or default_context()
+    check(_lib.load().gficf_jaccard_coeff_host(ctx.handle, _np_ptr(m), is_f64, N, k, max(N, 1), _np_ptr(w), 1 if printOutput else 0))
+    return w.T
 
 
 def jaccard_edges(neigh, verbose: bool = False, ctx: Context | None = None):

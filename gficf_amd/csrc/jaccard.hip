@@ -20,6 +20,7 @@
 //   * rows with duplicate ids (multiset semantics), hash overflow: exact slow path in the
 //               same kernel (all-pairs with occurrence ranks).
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "common.h"
@@ -199,6 +200,8 @@ struct EdgeOut {
   double* w;
   int32_t* u;       // optional intersection counts
   uint16_t* u16;    // optional intersection counts, compact (input of the edge filter)
+  int set_mode;     // rows with duplicate ids: 0 = multiset intersection (std::set_intersection of the parallel entry),
+                    // 1 = set intersection (Rcpp::intersect of the serial jaccard_coeff entry)
 };
 
 __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint32_t dst, int u,
@@ -221,8 +224,8 @@ __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint
 template <int KPAD>
 __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64_t i, int k, int64_t out_base,
                                        uint32_t* sA, uint32_t* sB, int lane, double* o_src, double* o_dst,
-                                       double* o_w, int32_t* o_u, uint16_t* o_u16, const double* lut) {
-  const EdgeOut o{o_src, o_dst, o_w, o_u, o_u16};
+                                       double* o_w, int32_t* o_u, uint16_t* o_u16, int set_mode, const double* lut) {
+  const EdgeOut o{o_src, o_dst, o_w, o_u, o_u16, set_mode};
   for (int e = lane; e < KPAD; e += 64) sA[e] = table[i * KPAD + e] & ID_MASK;
   wave_lds_fence();
   for (int s = 0; s < k; ++s) {
@@ -240,7 +243,7 @@ __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64
             ca += (sA[t] == b);
             rank += (t < e && sB[t] == b);
           }
-          cnt += (rank < ca);
+          cnt += set_mode ? (rank == 0 && ca > 0) : (rank < ca);      // first occurrence of a shared value / min multiplicity
         }
       }
 #pragma unroll
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
     wave_lds_fence();
     if (slow) {
       slow_cell<KPAD>(table, i, k, (i - cell_begin) * (int64_t)k, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w,
-                      o.u, o.u16, s_lut);
+                      o.u, o.u16, o.set_mode, s_lut);
     } else {
       have_prev = true;
       prev_i = i;
@@ -695,7 +698,7 @@ int gficf_jaccard_edges_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "cell range [%lld, %lld) outside [0, %lld]", (long long)cell_begin, (long long)cell_end, (long long)N);
   if (cell_end == cell_begin || k == 0) return GFICF_OK;
   if (!d_table || !d_src || !d_dst || !d_w) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
-  EdgeOut o{d_src, d_dst, d_w, d_u, nullptr};
+  EdgeOut o{d_src, d_dst, d_w, d_u, nullptr, 0};
   const uint32_t* t = (const uint32_t*)d_table;
   switch (kpad_for(k)) {
     case 16: return launch_edges<16>(ctx, t, N, k, cell_begin, cell_end, o);
@@ -786,9 +789,8 @@ int gficf_jaccard_unpack_rows_device(gficf_ctx* ctx, const uint32_t* d_packed, i
   return GFICF_OK;
 }
 
-int gficf_jaccard_edges_filtered_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k, int64_t cell_begin,
-                                        int64_t cell_end, uint16_t* d_u_ws, int64_t* d_cell_ptr, double* d_from,
-                                        double* d_to, double* d_weight) {
+static int edges_filtered(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k, int64_t cell_begin, int64_t cell_end,
+                          uint16_t* d_u_ws, int64_t* d_cell_ptr, double* d_from, double* d_to, double* d_weight, int set_mode) {
   GFICF_CTX_ENTER(ctx);
   int rc = check_nk(N, k);
   if (rc) return rc;
@@ -802,7 +804,7 @@ int gficf_jaccard_edges_filtered_device(gficf_ctx* ctx, const int32_t* d_table, 
   }
   if (!d_table || !d_u_ws || !d_from || !d_to || !d_weight) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   // 1. intersection counts only (no 24 B/edge matrix)
-  EdgeOut o{nullptr, nullptr, nullptr, nullptr, d_u_ws};
+  EdgeOut o{nullptr, nullptr, nullptr, nullptr, d_u_ws, set_mode};
   const uint32_t* t = (const uint32_t*)d_table;
   switch (kpad_for(k)) {
     case 16: rc = launch_edges<16>(ctx, t, N, k, cell_begin, cell_end, o); break;
@@ -834,6 +836,12 @@ int gficf_jaccard_edges_filtered_device(gficf_ctx* ctx, const int32_t* d_table, 
 #undef LAUNCH_EW
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
+}
+
+int gficf_jaccard_edges_filtered_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k, int64_t cell_begin,
+                                        int64_t cell_end, uint16_t* d_u_ws, int64_t* d_cell_ptr, double* d_from,
+                                        double* d_to, double* d_weight) {
+  return edges_filtered(ctx, d_table, N, k, cell_begin, cell_end, d_u_ws, d_cell_ptr, d_from, d_to, d_weight, 0);
 }
 
 // host form of the filtered build: plan runs everything and returns the edge count, finish copies out
@@ -902,6 +910,49 @@ int gficf_jaccard_filtered_host_plan(gficf_ctx* ctx, const void* idx, int idx_is
   p->n_edges = total;
   *n_edges = total;
   return GFICF_OK;
+}
+
+/* The package's second Jaccard entry, the serial jaccard_coeff(idx, printOutput) (reference src/jaccard_coeff.cpp:19-44,
+ * .Call symbol _gficf_jaccard_coeff, src/RcppExports.cpp:36): same edges, but (a) the intersection is Rcpp::intersect,
+ * i.e. of the two rows as SETS (it differs from the parallel entry only for rows with duplicate ids), and (b) the rows
+ * with u > 0 are written one after the other from the top of the (N*k) x 3 matrix (`r++`, :36-41), the rest stays 0. */
+int gficf_jaccard_coeff_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, double* weights,
+                             int print_output) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = check_nk(N, k);
+  if (rc) return rc;
+  if (print_output) { printf("Running Jaccard Coefficient Estimation...\n"); fflush(stdout); }  // reference :25
+  const int64_t E = N * (int64_t)k;
+  if (E == 0) return GFICF_OK;
+  if (!idx || !weights) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
+  if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
+  const size_t esz = idx_is_f64 ? sizeof(double) : sizeof(int32_t);
+  const int kpad = kpad_for(k);
+  void *d_idx = nullptr, *d_table = nullptr, *d_out = nullptr, *d_aux = nullptr;
+  hipError_t e = gficf_pool_get(ctx, 0, esz * (size_t)ld * (size_t)k, &d_idx);
+  if (e == hipSuccess) e = gficf_pool_get(ctx, 1, sizeof(int32_t) * (size_t)N * (size_t)kpad, &d_table);
+  if (e == hipSuccess) e = gficf_pool_get(ctx, 2, sizeof(double) * 3 * (size_t)E, &d_out);
+  if (e == hipSuccess) e = gficf_pool_get(ctx, 3, sizeof(uint16_t) * (size_t)E + 64 + sizeof(int64_t) * (size_t)(N + 1), &d_aux);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, esz * (size_t)ld * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
+  int64_t total = 0;
+  if (e == hipSuccess) {
+    double* d_from = (double*)d_out;
+    int64_t* d_ptr = (int64_t*)d_aux;
+    uint16_t* d_u = (uint16_t*)(d_ptr + N + 1);
+    rc = gficf_jaccard_ingest_device(ctx, d_idx, idx_is_f64, N, k, ld, N, (int32_t*)d_table);
+    if (!rc) rc = edges_filtered(ctx, (const int32_t*)d_table, N, k, 0, N, d_u, d_ptr, d_from, d_from + E, d_from + 2 * E, 1);
+    if (!rc) e = hipMemcpyAsync(&total, d_ptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
+    else (void)hipStreamSynchronize(ctx->stream);
+    if (!rc && e == hipSuccess) {
+      std::memset(weights, 0, sizeof(double) * 3 * (size_t)E);                                  // NumericMatrix weights(nrow*ncol, 3), :21
+      for (int c = 0; c < 3 && e == hipSuccess && total > 0; ++c)
+        e = hipMemcpyAsync(weights + (size_t)c * (size_t)E, d_from + (size_t)c * (size_t)E, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream);
+      (void)hipStreamSynchronize(ctx->stream);
+    }
+  }
+  if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_jaccard_coeff_host: %s", hipGetErrorString(e));
+  return rc;
 }
 
 int gficf_jaccard_filtered_host_finish(gficf_ctx* ctx, double* from, double* to, double* weight) {

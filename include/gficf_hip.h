@@ -80,6 +80,15 @@ const char* gficf_last_error(void);
 int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k,
                        int64_t ld, double* rmat, int print_output);
 
+/* The package's second Jaccard entry:  SEXP _gficf_jaccard_coeff(SEXP idx, SEXP printOutput)
+ *   (src/RcppExports.cpp:36-45, registered :87) -> jaccard_coeff() (src/jaccard_coeff.cpp:19-44), the serial form
+ *   (not called by clustcells(), but exported).  Same edges and weights u / (2k - u); two differences:
+ *   the intersection is Rcpp::intersect (:33), i.e. of the two rows as sets — it only differs from the parallel entry
+ *   for rows that hold an id twice —, and rows with u > 0 are written one after the other from the top of the
+ *   (N*k) x 3 matrix (`r++`, :36-41), the rows below stay zero.  weights: caller-allocated (N*k) x 3 column-major. */
+int gficf_jaccard_coeff_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k,
+                             int64_t ld, double* weights, int print_output);
+
 /* Device-resident pipeline, split where a multi-GPU caller needs the seam:
  *   1. ingest : column-major ids of a block of cells -> row-major padded int32 table rows
  *   2. (multi-GPU only) the caller all-gathers the table rows of all blocks (RCCL)

@@ -11,6 +11,8 @@
  * Symbols
  *   _gficf_rcpp_parallel_jaccard_coef(mat, printOutput)  — SAME name/arity as the reference entry
  *       (src/RcppExports.cpp:61): R/RcppExports.R:16-18 and clustcells() (R/clustCells.R:65) stay as is.
+ *   _gficf_jaccard_coeff(idx, printOutput)               — SAME name/arity as the reference's serial entry
+ *       (src/RcppExports.cpp:36): set intersection, rows with u > 0 packed from the top.
  *   _gficf_gficf_csc(i, p, x, dim, w, min, max)          — NEW entry for the GF-ICF chain of
  *       R/gficf.R:38-105 (the reference has no native entry on that path).
  *   _gficf_find_nn(X, k, metric)                         — NEW, optional: exact kNN in place of the
@@ -52,6 +54,24 @@ SEXP _gficf_rcpp_parallel_jaccard_coef(SEXP matSEXP, SEXP printOutputSEXP) {
   }
   UNPROTECT(1);
   return rmat;
+}
+
+/* replaces src/RcppExports.cpp:36-45 + src/jaccard_coeff.cpp:19-44 (the serial entry; same name and arity) */
+SEXP _gficf_jaccard_coeff(SEXP idxSEXP, SEXP printOutputSEXP) {
+  if (!Rf_isMatrix(idxSEXP) || !(TYPEOF(idxSEXP) == INTSXP || TYPEOF(idxSEXP) == REALSXP))
+    Rf_error("idx must be an integer or numeric matrix");
+  SEXP dim = Rf_getAttrib(idxSEXP, R_DimSymbol);
+  const int64_t N = INTEGER(dim)[0];
+  const int k = INTEGER(dim)[1];
+  const int is_f64 = TYPEOF(idxSEXP) == REALSXP;
+  const void* idx = is_f64 ? (const void*)REAL(idxSEXP) : (const void*)INTEGER(idxSEXP);
+  SEXP weights = PROTECT(Rf_allocMatrix(REALSXP, (int)(N * k), 3));
+  if (gficf_jaccard_coeff_host(ctx_get(), idx, is_f64, N, k, N, REAL(weights), Rf_asLogical(printOutputSEXP)) != GFICF_OK) {
+    UNPROTECT(1);
+    Rf_error("gficf_hip: %s", gficf_last_error());
+  }
+  UNPROTECT(1);
+  return weights;
 }
 
 /* list(i, p, x, keep, nt, w) for gficf() / embedNewCells(); w = NULL -> compute ICF weights */
@@ -122,6 +142,7 @@ SEXP _gficf_jaccard_adjacency(SEXP fromS, SEXP toS, SEXP weightS, SEXP nS) {
 
 static const R_CallMethodDef HipCallEntries[] = {
     {"_gficf_rcpp_parallel_jaccard_coef", (DL_FUNC)&_gficf_rcpp_parallel_jaccard_coef, 2},
+    {"_gficf_jaccard_coeff", (DL_FUNC)&_gficf_jaccard_coeff, 2},
     {"_gficf_gficf_csc", (DL_FUNC)&_gficf_gficf_csc, 7},
     {"_gficf_find_nn", (DL_FUNC)&_gficf_find_nn, 3},
     {"_gficf_jaccard_adjacency", (DL_FUNC)&_gficf_jaccard_adjacency, 4},

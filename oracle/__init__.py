@@ -48,6 +48,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_jaccard_f64.argtypes = [vp, i64, i32, vp, vp, i32]
         L.oracle_jaccard_i32.restype = i32
         L.oracle_jaccard_i32.argtypes = [vp, i64, i32, vp, vp, i32]
+        L.oracle_jaccard_coeff_f64.restype = i32
+        L.oracle_jaccard_coeff_f64.argtypes = [vp, i64, i32, vp]
         L.oracle_gficf_csc.restype = i32
         L.oracle_gficf_csc.argtypes = [i64, i64, vp, vp, vp, dbl, dbl, vp] + [vp] * 8
         L.oracle_knn.restype = i32
@@ -82,6 +84,18 @@ def jaccard(mat: np.ndarray, nthreads: int = 1):
     if rc != 0:
         raise ValueError(f"oracle_jaccard: invalid input (rc={rc})")
     return rm.T, u  # view: (E x 3), Fortran-ordered like the R matrix
+
+
+def jaccard_coeff(mat: np.ndarray) -> np.ndarray:
+    """The serial entry ``jaccard_coeff(idx, printOutput)`` (reference src/jaccard_coeff.cpp:19-44): set intersection,
+    rows with u > 0 packed from the top of the (N*k) x 3 matrix."""
+    N, k = mat.shape
+    m = np.asfortranarray(mat, dtype=np.float64)
+    w = np.empty((3, N * k), dtype=np.float64)
+    rc = lib().oracle_jaccard_coeff_f64(_p(m), N, k, _p(w))
+    if rc != 0:
+        raise ValueError(f"oracle_jaccard_coeff: invalid input (rc={rc})")
+    return w.T
 
 
 def gficf_csc(G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None):

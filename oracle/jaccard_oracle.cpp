@@ -14,6 +14,7 @@
 // What it restates (all citations relative to /root/reference):
 //   src/rcpp_parallel_jaccard_coeff.cpp:24-55   JCoefficient::operator()  — the hot loop
 //   src/rcpp_parallel_jaccard_coeff.cpp:59-80   rcpp_parallel_jaccard_coef — driver
+//   src/jaccard_coeff.cpp:19-44                 jaccard_coeff — the serial entry (set intersection, packed rows)
 //
 // Per edge (i, j) the reference
 //   :28     kk = (int)(mat(i,j) - 1)                      (double -> int truncation)
@@ -118,6 +119,43 @@ int oracle_jaccard_f64(const double* mat, int64_t N, int k, double* rmat, int32_
     });
   }
   for (auto& th : pool) th.join();
+  return 0;
+}
+
+// The package's serial entry jaccard_coeff(idx, printOutput) (reference src/jaccard_coeff.cpp:19-44):
+//   :29-30  for every i, j:  k = idx(i,j) - 1
+//   :31-33  u = intersect(idx(i,_), idx(k,_)).size()   — Rcpp sugar intersect: the rows as SETS (unique common values)
+//   :34-39  if (u > 0) { weights(r,0) = i+1; weights(r,1) = k+1; weights(r,2) = u/(2.0*ncol - u); r++; }
+// so the rows with u > 0 are packed from the top of the zero-initialised (N*k) x 3 matrix (:21), in (i, j) order.
+int oracle_jaccard_coeff_f64(const double* mat, int64_t N, int k, double* weights) {
+  if (N < 0 || k < 0) return -2;
+  const int64_t E = N * (int64_t)k;
+  for (int64_t p = 0; p < E; ++p) {
+    double v = mat[p];
+    if (!(v >= 1.0) || !(v < (double)N + 1.0)) return -1;
+  }
+  std::memset(weights, 0, sizeof(double) * 3 * (size_t)E);
+  std::vector<double> a(k), b(k), common;
+  int64_t r = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    for (int j = 0; j < k; ++j) {
+      const int kk = (int)(mat[(int64_t)j * N + i] - 1);
+      for (int t = 0; t < k; ++t) a[t] = mat[(int64_t)t * N + i];
+      for (int t = 0; t < k; ++t) b[t] = mat[(int64_t)t * N + kk];
+      std::sort(a.begin(), a.end());
+      std::sort(b.begin(), b.end());
+      const size_t na = std::unique(a.begin(), a.end()) - a.begin(), nb = std::unique(b.begin(), b.end()) - b.begin();
+      common.clear();
+      std::set_intersection(a.begin(), a.begin() + na, b.begin(), b.begin() + nb, std::back_inserter(common));
+      const int u = (int)common.size();
+      if (u > 0) {
+        weights[r] = (double)(i + 1);
+        weights[E + r] = (double)(kk + 1);
+        weights[2 * E + r] = u / (2.0 * k - u);
+        ++r;
+      }
+    }
+  }
   return 0;
 }
 

@@ -144,6 +144,22 @@ def cluster_signatures_np(gficf_mat: sp.csc_matrix, cluster):
     return np.stack(cols, axis=1) if cols else np.zeros((M.shape[0], 0)), labels
 
 
+def jaccard_coeff_np(mat: np.ndarray) -> np.ndarray:
+    """The serial entry (src/jaccard_coeff.cpp:19-44) through numpy set algebra: u = |unique(row i) ∩ unique(row kk)|
+    (``Rcpp::intersect``, :33), rows with u > 0 packed from the top (:34-39)."""
+    N, k = mat.shape
+    out = np.zeros((N * k, 3))
+    r = 0
+    for i in range(N):
+        for j in range(k):
+            kk = int(mat[i, j]) - 1
+            u = len(np.intersect1d(mat[i], mat[kk]))
+            if u > 0:
+                out[r] = (i + 1, kk + 1, u / (2.0 * k - u))
+                r += 1
+    return out
+
+
 # ------------------------------------------------------------------------------- kNN
 def knn_np(X: np.ndarray, k: int, metric: str = "manhattan"):
     """Exact kNN in float64 (different arithmetic from ``knn_oracle.cpp``, which works in f32 like the

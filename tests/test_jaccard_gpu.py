@@ -417,3 +417,29 @@ def test_packed_transport_rows_roundtrip(ops, N, k):
         ops.jaccard_edges(back, N, k, 0, N, out)
         ops.sync()
         assert np.array_equal(out.cpu().numpy().T, oracle.jaccard(mat, nthreads=8)[0])
+
+
+@pytest.mark.parametrize("N,k", [(64, 5), (1000, 15), (3000, 30), (700, 33), (300, 100)])
+def test_serial_entry_jaccard_coeff_matches_oracle(N, k):
+    """The package's serial entry (reference src/jaccard_coeff.cpp:19-44): set intersection (Rcpp::intersect), rows
+    with u > 0 packed from the top.  Bit-exact, including rows that hold an id several times and int32 / double input."""
+    mat = synth.knn_windowed(N, k, W=max(100, k), seed=N + k)
+    mat[3, : min(3, k)] = mat[3, 0]                              # duplicates: here set and multiset counts differ
+    mat[int(mat[3, 0]) - 1, : min(2, k)] = mat[3, 0]
+    mat[N - 1, :] = 7
+    for m in (mat, mat.astype(np.float64)):
+        got = gficf_amd.jaccard_coeff(m, False)
+        assert got.shape == (N * k, 3)
+        assert np.array_equal(got, oracle.jaccard_coeff(mat))
+    # the parallel entry counts the same rows as multisets: different weights on the duplicate rows, same elsewhere
+    par = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
+    kept = par[par[:, 2] > 0]
+    assert len(kept) == int((got[:, 2] > 0).sum())
+    assert not np.array_equal(kept[:, 2], got[:len(kept), 2])
+
+
+def test_serial_entry_empty_and_error_paths():
+    assert gficf_amd.jaccard_coeff(np.zeros((0, 4), dtype=np.int32)).shape == (0, 3)
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        gficf_amd.jaccard_coeff(np.array([[2, 9], [1, 1]], dtype=np.int32))
+    assert ei.value.status == "GFICF_ERR_BAD_ID"

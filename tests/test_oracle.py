@@ -210,3 +210,32 @@ def test_knn_oracle_known_answer_and_ties():
     assert dist.tolist() == [[0, 1, 1], [0, 0, 1], [0, 2, 2], [0, 3, 5], [0, 0, 1]]
     idx2, dist2 = oracle.knn(X, 3, "euclidean")
     assert idx2.tolist() == idx.tolist() and dist2.tolist() == dist.tolist()
+
+
+# ------------------------------------------------------------- the serial entry jaccard_coeff
+def test_serial_jaccard_coeff_oracle_cpp_vs_numpy_and_vs_parallel_entry():
+    """src/jaccard_coeff.cpp:19-44: set intersection, rows with u > 0 packed from the top.  C++ vs numpy set algebra;
+    on rows without duplicate ids it holds the parallel entry's non-zero rows, in order."""
+    mat = synth.knn_windowed(400, 9, seed=21)
+    ser = oracle.jaccard_coeff(mat)
+    assert np.array_equal(ser, oracle_np.jaccard_coeff_np(mat))
+    full, _ = oracle.jaccard(mat)
+    kept = full[full[:, 2] > 0]
+    assert np.array_equal(ser[:len(kept)], kept) and not ser[len(kept):].any()
+    # a row that holds an id three times: multiset (parallel entry) and set (serial entry) counts differ
+    mat[3, :3] = mat[3, 0]
+    mat[int(mat[3, 0]) - 1, :2] = mat[3, 0]
+    ser = oracle.jaccard_coeff(mat)
+    assert np.array_equal(ser, oracle_np.jaccard_coeff_np(mat))
+    full, _ = oracle.jaccard(mat)
+    kept = full[full[:, 2] > 0]
+    assert not np.array_equal(ser[:len(kept), 2], kept[:, 2])
+
+
+def test_serial_jaccard_coeff_known_answer():
+    # 3 cells, k = 2: row 1 = {2,3}, row 2 = {1,3}, row 3 = {3,3} (an id twice: a set of one element)
+    mat = np.array([[2, 3], [1, 3], [3, 3]], dtype=np.int32)
+    got = oracle.jaccard_coeff(mat)
+    # edges in (i, j) order with u: (1,2): {2,3}∩{1,3} = 1; (1,3): {2,3}∩{3} = 1; (2,1): 1; (2,3): {1,3}∩{3} = 1; (3,3): 1; (3,3): 1
+    want = np.array([[1, 2, 1 / 3], [1, 3, 1 / 3], [2, 1, 1 / 3], [2, 3, 1 / 3], [3, 3, 1 / 3], [3, 3, 1 / 3]])
+    assert np.allclose(got, want) and np.array_equal(got[:, :2], want[:, :2])
