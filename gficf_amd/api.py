@@ -194,13 +194,29 @@ def _csc_parts(M):
     return M, colptr, rowidx, x
 
 
-def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx):
+ICF_TYPES = {"classic": 0, "prob": 1, "smooth": 2}      # getIdfW(type = ...), reference R/gficf.R:89-91
+NORMS = {"l2": 0, "l1": 1}                               # l.norm(norm = ...), reference R/gficf.R:100
+
+
+def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx, icf_type="classic", norm="l2"):
     import scipy.sparse as sp
 
+    if icf_type not in ICF_TYPES or norm not in NORMS:
+        raise ValueError("icf_type must be classic / prob / smooth and norm l2 / l1")
     M, colptr, rowidx, x = _csc_parts(M)
     G, N = M.shape
     L = _lib.load()
     ctx = ctx or default_context()
+    check(L.gficf_ctx_set_gficf_options(ctx.handle, ICF_TYPES[icf_type], NORMS[norm]))
+    try:
+        return _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_max, w_in)
+    finally:
+        L.gficf_ctx_set_gficf_options(ctx.handle, 0, 0)
+
+
+def _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_max, w_in):
+    import scipy.sparse as sp
+
     gk, nk = ctypes.c_int64(0), ctypes.c_int64(0)
     if w_in is not None:
         w_in = np.ascontiguousarray(w_in, dtype=np.float64)
@@ -224,7 +240,8 @@ def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx):
 
 
 def gficf(M, cell_proportion_max: float = 1, cell_proportion_min: float = 0.05, storeRaw: bool = True,
-          normalize: bool = True, verbose: bool = True, ctx: Context | None = None) -> dict:
+          normalize: bool = True, verbose: bool = True, ctx: Context | None = None, *, icf_type: str = "classic",
+          norm: str = "l2") -> dict:
     """Drop-in for the reference's ``gficf()`` (reference R/gficf.R:17-33).
 
     ``M``: genes x cells sparse count matrix (scipy CSC — the dgCMatrix analogue).
@@ -235,11 +252,15 @@ def gficf(M, cell_proportion_max: float = 1, cell_proportion_min: float = 0.05, 
     ``normalize=TRUE`` in the reference rescales counts with edgeR TMM/CPM
     (R/gficf.R:43-47) before GF; that is a per-cell scale which cancels in x/colSums(x),
     so ``gficf`` is unaffected; ``rawCounts`` here always holds the unscaled filtered counts.
+
+    ``icf_type`` / ``norm`` (keyword only, not arguments of the reference's ``gficf()``, which always runs
+    "classic" / "l2") select the other branches of its helpers ``getIdfW(type = ...)`` (R/gficf.R:89-91) and
+    ``l.norm(norm = ...)`` (R/gficf.R:100).
     """
     if verbose and normalize:
         warnings.warn("normalize=True: the edgeR CPM/TMM rescale (reference R/gficf.R:43-47) is a per-cell scale "
                       "that cancels in the GF step; rawCounts holds unscaled counts", stacklevel=2)
-    M, keep, nt, w, out = _normalize_csc_host(M, cell_proportion_min, cell_proportion_max, None, ctx)
+    M, keep, nt, w, out = _normalize_csc_host(M, cell_proportion_min, cell_proportion_max, None, ctx, icf_type, norm)
     data = {"gficf": out}
     if storeRaw:
         data["rawCounts"] = M[np.flatnonzero(keep), :]

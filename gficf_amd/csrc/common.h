@@ -32,6 +32,10 @@ struct gficf_ctx {
   uint32_t* d_flags = nullptr;
   const uint32_t* cur_gate = nullptr;
   uint32_t* cur_zero = nullptr;
+  // options of the GF-ICF chain that the reference's internal helpers take (gficf() itself always uses the defaults):
+  // getIdfW(type = classic / prob / smooth) R/gficf.R:89-91, l.norm(norm = l2 / l1) R/gficf.R:100
+  int icf_type = 0;
+  int norm_l1 = 0;
   gficf_host_plan* plan = nullptr;
   gficf_edge_plan* edge_plan = nullptr;
   gficf_adj_plan* adj_plan = nullptr;

@@ -100,6 +100,14 @@ int gficf_ctx_set_stream(gficf_ctx* ctx, void* stream) {
   return GFICF_OK;
 }
 
+int gficf_ctx_set_gficf_options(gficf_ctx* ctx, int icf_type, int norm) {
+  if (!ctx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ctx is NULL");
+  if (icf_type < 0 || icf_type > 2 || norm < 0 || norm > 1) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "icf_type must be 0..2 and norm 0..1");
+  ctx->icf_type = icf_type;
+  ctx->norm_l1 = norm;
+  return GFICF_OK;
+}
+
 int gficf_ctx_sync(gficf_ctx* ctx) {
   GFICF_CTX_ENTER(ctx);
   GFICF_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

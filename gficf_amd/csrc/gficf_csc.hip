@@ -124,7 +124,7 @@ __global__ __launch_bounds__(GT_THREADS) void k_gene_table(int64_t G, int64_t N_
                                                            double prop_min, double prop_max,
                                                            const double* __restrict__ w_in, uint8_t* __restrict__ keep,
                                                            gficf_gene_entry* __restrict__ genes, double* __restrict__ w,
-                                                           int64_t* __restrict__ gkept, const uint32_t* gate) {
+                                                           int64_t* __restrict__ gkept, int icf_type, const uint32_t* gate) {
   GFICF_GATE(gate);
   __shared__ int s_red[GT_THREADS / 64];
   __shared__ int s_wave_excl[GT_THREADS / 64];
@@ -157,7 +157,12 @@ __global__ __launch_bounds__(GT_THREADS) void k_gene_table(int64_t G, int64_t N_
   if (g < G) {
     const int r = before + s_wave_excl[wave] + __popcll(m & ((1ull << lane) - 1ull));
     double wv = 0.0;
-    if (kp) wv = w_in ? w_in[g] : log(((double)N_total + 1.0) / (c + 1.0));
+    if (kp) {
+      if (w_in) wv = w_in[g];
+      else if (icf_type == 1) wv = log(((double)N_total - c) / c);               // "prob"    R/gficf.R:90
+      else if (icf_type == 2) wv = log(1.0 + (double)N_total / c);               // "smooth"  R/gficf.R:91
+      else wv = log(((double)N_total + 1.0) / (c + 1.0));                        // "classic" R/gficf.R:89
+    }
     keep[g] = kp ? 1 : 0;
     w[g] = wv;
     gficf_gene_entry e;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
                                                             const int64_t* __restrict__ gkept_p,
                                                             const int64_t* __restrict__ out_colptr,
                                                             int32_t* __restrict__ out_rowidx,
-                                                            double* __restrict__ out_x, const uint32_t* gate,
+                                                            double* __restrict__ out_x, int norm_l1, const uint32_t* gate,
                                                             uint32_t* zero_flag) {
   GFICF_GATE(gate);
   __shared__ double s_sum[SC_WAVES];
@@ -357,14 +362,14 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
         double v = 0.0;
         if (rv[m] >= 0 && Sc != 0.0) v = (xv[m] / Sc) * wv[m];
         xv[m] = v;
-        q += v * v;
+        q += norm_l1 ? v : v * v;
       }
     } else if (Sc != 0.0) {
       for (int64_t p = a0 + lane; p < a1; p += 64) {
         const int32_t g = rowidx[p];
         if (g >= 0 && g < G) {
           const int4 e = gtab[g];
-          if (e.z >= 0) { const double v = (x[p] / Sc) * __hiloint2double(e.y, e.x); q += v * v; }
+          if (e.z >= 0) { const double v = (x[p] / Sc) * __hiloint2double(e.y, e.x); q += norm_l1 ? v : v * v; }
         }
       }
     }
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
 #pragma unroll
     for (int t = 0; t < SC_WAVES; ++t) qc += s_sum[t];
     __syncthreads();
-    double nv = 1.0 / sqrt(qc);
+    double nv = 1.0 / (norm_l1 ? qc : sqrt(qc));      // l.norm: l1 = 1/rowSums(m), l2 = 1/sqrt(rowSums(m^2))  R/gficf.R:100
     if (isinf(nv)) nv = 0.0;                        // R/gficf.R:101
     if (cached) {
 #pragma unroll
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
                                                                 const int64_t* __restrict__ gkept_p,
                                                                 const int64_t* __restrict__ out_colptr,
                                                                 int32_t* __restrict__ out_rowidx,
-                                                                double* __restrict__ out_x, const uint32_t* gate,
+                                                                double* __restrict__ out_x, int norm_l1, const uint32_t* gate,
                                                                 uint32_t* zero_flag) {
   GFICF_GATE(gate);
   extern __shared__ unsigned char s_raw[];
@@ -496,11 +501,11 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
           double v = 0.0;
           if (rv[m] >= 0 && Sc != 0.0) v = (xv[m] / Sc) * s_w[rv[m]];
           xv[m] = v;
-          q += v * v;
+          q += norm_l1 ? v : v * v;
         }
       }
       const double qc = wave_sum(q);
-      double nv = 1.0 / sqrt(qc);
+      double nv = 1.0 / (norm_l1 ? qc : sqrt(qc));
       if (isinf(nv)) nv = 0.0;                    // R/gficf.R:101
 #pragma unroll
       for (int m = 0; m < SL_CH; ++m) {
@@ -550,12 +555,12 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
           for (int m = 0; m < SL_LB; ++m) {
             const uint32_t g = (uint32_t)gz[m];
             const uint32_t r = g < (uint32_t)G ? (uint32_t)s_remap[g] : 0xFFFFu;
-            if (r != 0xFFFFu) { const double v = (xb[m] / Sc) * s_w[r]; q += v * v; }
+            if (r != 0xFFFFu) { const double v = (xb[m] / Sc) * s_w[r]; q += norm_l1 ? v : v * v; }
           }
         }
       }
       const double qc = wave_sum(q);
-      double nv = 1.0 / sqrt(qc);
+      double nv = 1.0 / (norm_l1 ? qc : sqrt(qc));
       if (isinf(nv)) nv = 0.0;                    // R/gficf.R:101
       for (int64_t base = p0; base < p1; base += 64 * SL_LB) {
         int32_t gz[SL_LB];
@@ -688,7 +693,7 @@ int gficf_csc_genes_device(gficf_ctx* ctx, int64_t G, int64_t N_total, const int
   if (!d_gkept || (G > 0 && (!d_nt || !d_keep || !d_genes || !d_w))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   const int64_t tiles = G > 0 ? gficf_ceil_div(G, GT_THREADS) : 1;
   hipLaunchKernelGGL(k_gene_table, dim3((unsigned)tiles), dim3(GT_THREADS), 0, ctx->stream, G, N_total, d_nt, prop_min, prop_max,
-                     d_w_in, d_keep, d_genes, d_w, d_gkept, ctx->cur_gate);
+                     d_w_in, d_keep, d_genes, d_w, d_gkept, ctx->icf_type, ctx->cur_gate);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -732,14 +737,14 @@ int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
     if (blocks > ctx->num_cus) blocks = ctx->num_cus;
     if (ctx->cur_gate && blocks > GATED_BLOCKS) blocks = GATED_BLOCKS;
     hipLaunchKernelGGL(k_scale_cells_lds, dim3((unsigned)blocks), dim3(SL_THREADS), SL_LDS_BYTES, ctx->stream, G, n_cells,
-                       d_colptr, d_rowidx, d_x, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x, ctx->cur_gate, ctx->cur_zero);
+                       d_colptr, d_rowidx, d_x, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x, ctx->norm_l1, ctx->cur_gate, ctx->cur_zero);
   }
   int64_t blocks = n_cells;
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
   if (ctx->cur_gate && blocks > GATED_BLOCKS) blocks = GATED_BLOCKS;
   hipLaunchKernelGGL(k_scale_cells, dim3((unsigned)blocks), dim3(SC_THREADS), 0, ctx->stream, G, n_cells, d_colptr,
                      d_rowidx, d_x, d_genes, try_lds ? d_gkept : (const int64_t*)nullptr, d_out_colptr, d_out_rowidx, d_out_x,
-                     ctx->cur_gate, ctx->cur_zero);
+                     ctx->norm_l1, ctx->cur_gate, ctx->cur_zero);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }

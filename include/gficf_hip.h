@@ -181,6 +181,13 @@ int gficf_adjacency_host_finish(gficf_ctx* ctx, void* indptr, int indptr_is_i64,
  * Cells with S_c == 0 get 0.0 in every stored kept entry (R would produce NaN).
  */
 
+/* Options of the reference's internal helpers (gficf() itself always runs with the defaults 0, 0):
+ *   icf_type: getIdfW(type = ...) R/gficf.R:89-91 — 0 "classic" log((N+1)/(nt+1)), 1 "prob" log((N-nt)/nt),
+ *             2 "smooth" log(1 + N/nt);
+ *   norm    : l.norm(norm = ...) R/gficf.R:100 — 0 "l2" 1/sqrt(sum v^2), 1 "l1" 1/sum v  (Inf -> 0 in both).
+ * They apply to every later GF-ICF call on this context. */
+int gficf_ctx_set_gficf_options(gficf_ctx* ctx, int icf_type, int norm);
+
 /* Host form, two calls so that the caller (R glue) can allocate exactly-sized outputs:
  *   plan   : uploads the matrix, counts, filters; returns G_kept and nnz_kept.
  *   finish : writes keep[G] (0/1), nt[G] (raw count of every gene, dropped ones included),

@@ -52,6 +52,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_jaccard_coeff_f64.argtypes = [vp, i64, i32, vp]
         L.oracle_gficf_csc.restype = i32
         L.oracle_gficf_csc.argtypes = [i64, i64, vp, vp, vp, dbl, dbl, vp] + [vp] * 8
+        L.oracle_gficf_csc_ex.restype = i32
+        L.oracle_gficf_csc_ex.argtypes = [i64, i64, vp, vp, vp, dbl, dbl, vp, i32, i32] + [vp] * 8
         L.oracle_knn.restype = i32
         L.oracle_knn.argtypes = [vp, i64, i32, i64, i32, i32, vp, vp, i32]
         L.oracle_knn_block.restype = i32
@@ -98,7 +100,7 @@ def jaccard_coeff(mat: np.ndarray) -> np.ndarray:
     return w.T
 
 
-def gficf_csc(G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None):
+def gficf_csc(G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None, icf_type="classic", norm="l2"):
     """GF-ICF on a CSC genes x cells matrix (reference R/gficf.R:17-33, normalize=FALSE).
 
     Returns dict(keep, nt, w, colptr, rowidx, x, G_kept).
@@ -117,8 +119,9 @@ def gficf_csc(G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None):
     nk = ctypes.c_int64(0)
     if w_in is not None:
         w_in = np.ascontiguousarray(w_in, dtype=np.float64)
-    rc = lib().oracle_gficf_csc(
+    rc = lib().oracle_gficf_csc_ex(
         G, N, _p(colptr), _p(rowidx), _p(x), float(prop_min), float(prop_max), _p(w_in),
+        {"classic": 0, "prob": 1, "smooth": 2}[icf_type], {"l2": 0, "l1": 1}[norm],
         _p(keep), _p(nt), _p(w), _p(ocp), _p(ori), _p(ox),
         ctypes.cast(ctypes.byref(gk), ctypes.c_void_p), ctypes.cast(ctypes.byref(nk), ctypes.c_void_p))
     if rc != 0:

@@ -45,10 +45,12 @@ extern "C" {
 //   out_colptr[N+1], out_rowidx[<=nnz] (renumbered over kept genes), out_x[<=nnz],
 //   *G_kept, *nnz_kept.
 // Returns 0 on success, -1 on malformed structure.
-int oracle_gficf_csc(int64_t G, int64_t N, const int64_t* colptr, const int32_t* rowidx,
-                     const double* x, double prop_min, double prop_max, const double* w_in,
-                     uint8_t* keep, int64_t* nt, double* w, int64_t* out_colptr,
-                     int32_t* out_rowidx, double* out_x, int64_t* G_kept, int64_t* nnz_kept) {
+// icf_type: getIdfW(type) R/gficf.R:89-91 (0 classic, 1 prob, 2 smooth); norm_l1: l.norm(norm = "l1") R/gficf.R:100.
+// gficf() itself always runs (0, 0).
+int oracle_gficf_csc_ex(int64_t G, int64_t N, const int64_t* colptr, const int32_t* rowidx,
+                        const double* x, double prop_min, double prop_max, const double* w_in, int icf_type, int norm_l1,
+                        uint8_t* keep, int64_t* nt, double* w, int64_t* out_colptr,
+                        int32_t* out_rowidx, double* out_x, int64_t* G_kept, int64_t* nnz_kept) {
   if (G < 0 || N < 0 || colptr[0] != 0) return -1;
   const int64_t nnz = colptr[N];
   for (int64_t p = 0; p < nnz; ++p)
@@ -98,7 +100,11 @@ int oracle_gficf_csc(int64_t G, int64_t N, const int64_t* colptr, const int32_t*
     if (!keep[g]) continue;
     int32_t r = remap[g];
     nt[g] = ntk[r];
-    wk[r] = w_in ? w_in[g] : std::log(((double)N + 1.0) / ((double)ntk[r] + 1.0));
+    const double c = (double)ntk[r];
+    if (w_in) wk[r] = w_in[g];
+    else if (icf_type == 1) wk[r] = std::log(((double)N - c) / c);            // "prob"    R/gficf.R:90
+    else if (icf_type == 2) wk[r] = std::log(1.0 + (double)N / c);            // "smooth"  R/gficf.R:91
+    else wk[r] = std::log(((double)N + 1.0) / (c + 1.0));                     // "classic" R/gficf.R:89
     w[g] = wk[r];
   }
 
@@ -107,13 +113,21 @@ int oracle_gficf_csc(int64_t G, int64_t N, const int64_t* colptr, const int32_t*
     double ss = 0.0;
     for (int64_t t = out_colptr[c]; t < out_colptr[c + 1]; ++t) {
       out_x[t] = out_x[t] * wk[out_rowidx[t]];
-      ss += out_x[t] * out_x[t];
+      ss += norm_l1 ? out_x[t] : out_x[t] * out_x[t];
     }
-    double nv = 1.0 / std::sqrt(ss);
+    double nv = 1.0 / (norm_l1 ? ss : std::sqrt(ss));   // l1: 1/rowSums(m), l2: 1/sqrt(rowSums(m^2))  R/gficf.R:100
     if (std::isinf(nv)) nv = 0.0;                  // R/gficf.R:101
     for (int64_t t = out_colptr[c]; t < out_colptr[c + 1]; ++t) out_x[t] = nv * out_x[t];
   }
   return 0;
+}
+
+int oracle_gficf_csc(int64_t G, int64_t N, const int64_t* colptr, const int32_t* rowidx,
+                     const double* x, double prop_min, double prop_max, const double* w_in,
+                     uint8_t* keep, int64_t* nt, double* w, int64_t* out_colptr,
+                     int32_t* out_rowidx, double* out_x, int64_t* G_kept, int64_t* nnz_kept) {
+  return oracle_gficf_csc_ex(G, N, colptr, rowidx, x, prop_min, prop_max, w_in, 0, 0, keep, nt, w, out_colptr, out_rowidx, out_x,
+                             G_kept, nnz_kept);
 }
 
 }  // extern "C"

@@ -80,7 +80,7 @@ def jaccard_rmat(mat: np.ndarray, u: np.ndarray | None = None) -> np.ndarray:
 
 
 # ---------------------------------------------------------------------------- GF-ICF
-def gficf_np(M: sp.csc_matrix, prop_min: float = 0.05, prop_max: float = 1.0, w_in=None):
+def gficf_np(M: sp.csc_matrix, prop_min: float = 0.05, prop_max: float = 1.0, w_in=None, icf_type: str = "classic", norm: str = "l2"):
     """gficf(M, normalize=FALSE) on a scipy CSC genes x cells matrix (R/gficf.R:17-33).
 
     Returns dict(keep, nt, w (per ORIGINAL gene, 0 where dropped), gficf (CSC over kept
@@ -109,7 +109,10 @@ def gficf_np(M: sp.csc_matrix, prop_min: float = 0.05, prop_max: float = 1.0, w_
     # R/gficf.R:88-89
     ntk = np.bincount(TF.indices[TF.data != 0], minlength=Mk.shape[0]).astype(np.int64)
     if w_in is None:
-        wk = np.log((N + 1.0) / (ntk + 1.0))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            wk = {"classic": lambda: np.log((N + 1.0) / (ntk + 1.0)),          # R/gficf.R:89
+                  "prob": lambda: np.log((N - ntk) / ntk),                      # R/gficf.R:90
+                  "smooth": lambda: np.log(1.0 + N / ntk)}[icf_type]()          # R/gficf.R:91
     else:
         wk = np.asarray(w_in, dtype=np.float64)[keep]
     # R/gficf.R:79
@@ -119,10 +122,10 @@ def gficf_np(M: sp.csc_matrix, prop_min: float = 0.05, prop_max: float = 1.0, w_
     for c in range(N):
         s = 0.0
         for t in v[TF.indptr[c]:TF.indptr[c + 1]]:
-            s += t * t
+            s += t if norm == "l1" else t * t
         ss[c] = s
     with np.errstate(divide="ignore"):
-        nv = 1.0 / np.sqrt(ss)
+        nv = 1.0 / (ss if norm == "l1" else np.sqrt(ss))      # R/gficf.R:100
     nv[np.isinf(nv)] = 0.0
     out = np.repeat(nv, cnt) * v
     nt = np.zeros(G, dtype=np.int64)

@@ -322,3 +322,25 @@ def test_cluster_signatures_next_row_n3():
     # an empty matrix / a single cluster
     got1, l1 = gficf_amd.cluster_signatures(res["gficf"], np.zeros(N, dtype=int))
     assert got1.shape[1] == 1 and np.allclose(got1[:, 0], np.asarray(res["gficf"].sum(axis=1)).ravel(), rtol=1e-10)
+
+
+@pytest.mark.parametrize("icf_type", ["classic", "prob", "smooth"])
+@pytest.mark.parametrize("norm", ["l2", "l1"])
+def test_helper_branches_icf_type_and_norm(icf_type, norm):
+    """getIdfW(type = prob / smooth) and l.norm(norm = "l1") (reference R/gficf.R:89-91,100; gficf() itself never takes
+    them): structure exact, values and weights within 1e-6 of the oracle; the context falls back to the defaults."""
+    G, N = 1800, 900
+    cp, ri, x = synth.counts_csc(G, N, seed=31)
+    M = sp.csc_matrix((x, ri, cp), shape=(G, N))
+    res = gficf_amd.gficf(M, normalize=False, verbose=False, icf_type=icf_type, norm=norm)
+    ref = oracle.gficf_csc(G, N, cp, ri, x, 0.05, 1.0, None, icf_type, norm)
+    assert np.array_equal(res["genes"], np.flatnonzero(ref["keep"]))
+    assert np.array_equal(res["gficf"].indices, ref["rowidx"]) and np.array_equal(res["gficf"].indptr, ref["colptr"])
+    assert np.allclose(res["gficf"].data, ref["x"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(res["w"], ref["w"][ref["keep"]], rtol=1e-6, atol=1e-6)
+    # options do not leak into the next call
+    d = gficf_amd.gficf(M, normalize=False, verbose=False)
+    ref0 = oracle.gficf_csc(G, N, cp, ri, x, 0.05, 1.0)
+    assert np.allclose(d["gficf"].data, ref0["x"], rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError):
+        gficf_amd.gficf(M, normalize=False, verbose=False, icf_type="bm25")

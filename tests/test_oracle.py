@@ -239,3 +239,24 @@ def test_serial_jaccard_coeff_known_answer():
     # edges in (i, j) order with u: (1,2): {2,3}∩{1,3} = 1; (1,3): {2,3}∩{3} = 1; (2,1): 1; (2,3): {1,3}∩{3} = 1; (3,3): 1; (3,3): 1
     want = np.array([[1, 2, 1 / 3], [1, 3, 1 / 3], [2, 1, 1 / 3], [2, 3, 1 / 3], [3, 3, 1 / 3], [3, 3, 1 / 3]])
     assert np.allclose(got, want) and np.array_equal(got[:, :2], want[:, :2])
+
+
+@pytest.mark.parametrize("icf_type", ["classic", "prob", "smooth"])
+@pytest.mark.parametrize("norm", ["l2", "l1"])
+def test_gficf_oracle_helper_branches_cpp_vs_numpy(icf_type, norm):
+    """The other branches of the reference's helpers getIdfW(type) (R/gficf.R:89-91) and l.norm(norm) (R/gficf.R:100),
+    which gficf() itself never takes: the two restatements agree, and one closed-form value is checked by hand."""
+    cp, ri, x = synth.counts_csc(250, 180, seed=6)
+    M = sp.csc_matrix((x, ri, cp), shape=(250, 180))
+    a = oracle.gficf_csc(250, 180, cp, ri, x, 0.05, 1.0, None, icf_type, norm)
+    b = oracle_np.gficf_np(M, 0.05, 1.0, None, icf_type, norm)
+    assert np.array_equal(a["keep"], b["keep"]) and np.array_equal(a["rowidx"], b["gficf"].indices)
+    assert np.allclose(a["x"], b["gficf"].data, rtol=1e-12, atol=1e-15)
+    assert np.allclose(a["w"], b["w"], rtol=1e-14)
+    # hand check on the 4 x 3 example of the golden known answers: nt = [2, 2, 3, 1], N = 3
+    Mk = np.array([[1, 0, 3], [1, 2, 0], [2, 2, 1], [0, 4, 0]], dtype=np.float64)
+    r = oracle_np.gficf_np(sp.csc_matrix(Mk), 0.0, 1.0, None, icf_type, norm)
+    want_w = {"classic": np.log(4 / np.array([3, 3, 4, 2.0])), "prob": np.log((3 - np.array([2, 2, 3, 1.0])) / np.array([2, 2, 3, 1.0])),
+              "smooth": np.log(1 + 3 / np.array([2, 2, 3, 1.0]))}[icf_type]
+    with np.errstate(divide="ignore"):
+        assert np.allclose(r["w"], want_w, equal_nan=True)
