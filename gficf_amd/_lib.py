@@ -20,7 +20,7 @@ STATUS_NAMES = {
 }
 JACCARD_MAX_K = 256
 KNN_MAX_K = 128
-KNN_METRICS = {"manhattan": 0, "euclidean": 1, "cosine": 2}
+KNN_METRICS = {"manhattan": 0, "euclidean": 1, "cosine": 2, "correlation": 3}
 
 
 class GficfError(RuntimeError):

@@ -7,7 +7,8 @@
 // smallest (distance, index) pairs are kept, ties broken by the smaller index — so the result is
 // unique and checkable bit for bit against a CPU brute force.
 //
-// Metrics: manhattan (the reference's default, R/clustCells.R:46), euclidean, cosine (1 - cos).
+// Metrics: manhattan (the reference's default, R/clustCells.R:46), euclidean, cosine (1 - cos), correlation (cosine of
+// the mean-centred rows).
 // Manhattan is |a-b| accumulation — VALU work, not a contraction, so no MFMA; euclidean and cosine
 // share the same register-tiled kernel with a packed-fma chain in dimension order (an MFMA formulation
 // |x|^2+|y|^2-2xy would change the rounding and with it the order of near-ties, and in f32 the matrix
@@ -69,9 +70,15 @@ __global__ __launch_bounds__(256) void k_knn_prepare(const T* __restrict__ X, in
   bool bad = false;
   float inv = 1.0f;
   bool scale = false;
-  if (metric == GFICF_KNN_COSINE) {
+  float mean = 0.0f;
+  if (metric == GFICF_KNN_CORRELATION) {         // Pearson: centre the row first (f32 sum in dimension order / d)
+    float sm = 0.0f;
+    for (int t = 0; t < d; ++t) sm = sm + (float)X[(int64_t)t * ld + r];
+    mean = sm / (float)d;
+  }
+  if (metric == GFICF_KNN_COSINE || metric == GFICF_KNN_CORRELATION) {
     float s = 0.0f;
-    for (int t = 0; t < d; ++t) { const float v = (float)X[(int64_t)t * ld + r]; s = fmaf(v, v, s); }
+    for (int t = 0; t < d; ++t) { const float v = (float)X[(int64_t)t * ld + r] - mean; s = fmaf(v, v, s); }
     const float nrm = sqrtf(s);
     scale = nrm > 0.0f;
     inv = nrm;
@@ -80,6 +87,7 @@ __global__ __launch_bounds__(256) void k_knn_prepare(const T* __restrict__ X, in
   for (int t = 0; t < dpad; ++t) {
     float v = t < d ? (float)X[(int64_t)t * ld + r] : 0.0f;
     bad |= !(fabsf(v) <= FLT_MAX);              // NaN or +-Inf (also a double too large for f32)
+    if (t < d) v = v - mean;
     if (scale) v = v / inv;
     o[t] = v;
   }
@@ -784,7 +792,7 @@ int knn_check(int64_t N, int d, int k, int metric) {
   if (d > KNN_MAX_D) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "d = %d exceeds %d dimensions", d, KNN_MAX_D);
   if (k > GFICF_KNN_MAX_K) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d exceeds GFICF_KNN_MAX_K = %d", k, GFICF_KNN_MAX_K);
   if (k > N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "k = %d neighbours asked of N = %lld points", k, (long long)N);
-  if (metric != GFICF_KNN_MANHATTAN && metric != GFICF_KNN_EUCLIDEAN && metric != GFICF_KNN_COSINE)
+  if (metric != GFICF_KNN_MANHATTAN && metric != GFICF_KNN_EUCLIDEAN && metric != GFICF_KNN_COSINE && metric != GFICF_KNN_CORRELATION)
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "unknown metric %d", metric);
   return GFICF_OK;
 }
@@ -931,6 +939,7 @@ int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, in
   if (!d_points || !d_ws || !d_idx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   if (ld_out < n_q) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld_out = %lld < number of queries %lld", (long long)ld_out, (long long)n_q);
   if (ws_bytes < gficf_knn_workspace_bytes(ctx, n_q, N, k)) GFICF_FAIL(GFICF_ERR_CAPACITY, "kNN workspace too small");
+  if (metric == GFICF_KNN_CORRELATION) metric = GFICF_KNN_COSINE;      // the prepared rows are centred: same search
   const int dpad = knn_dpad(d);
   const unsigned mblocks = (unsigned)gficf_ceil_div(n_q, 256);
   KnnTileArgs a{};

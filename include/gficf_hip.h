@@ -265,12 +265,14 @@ int gficf_cluster_signatures_host(gficf_ctx* ctx, int64_t G, int64_t N, const vo
  * precision): for every query the k smallest (distance, index) pairs over ALL N points, the
  * query itself included (include_self = T), ties broken by the smaller index.  Distances:
  * manhattan = sum |a-b| (the reference's default, R/clustCells.R:46), euclidean = sqrt(sum (a-b)^2),
- * cosine = 1 - cos (rows L2-normalised first); all accumulated in dimension order.
+ * cosine = 1 - cos (rows L2-normalised first), correlation = cosine of the mean-centred rows (uwot's "correlation");
+ * all accumulated in dimension order.
  */
 typedef enum gficf_knn_metric {
   GFICF_KNN_MANHATTAN = 0,
   GFICF_KNN_EUCLIDEAN = 1,
-  GFICF_KNN_COSINE = 2
+  GFICF_KNN_COSINE = 2,
+  GFICF_KNN_CORRELATION = 3    /* 1 - Pearson correlation = cosine distance of the rows with their mean removed */
 } gficf_knn_metric;
 
 #define GFICF_KNN_MAX_K 128

@@ -33,8 +33,8 @@ gficf = function(M, cell_proportion_max = 1, cell_proportion_min = 0.05, storeRa
 # approximate: ties broken by the smaller index; f32 arithmetic like Annoy's.
 find_nn_hip = function(X, k, metric = "manhattan")
 {
-  m = match(metric, c("manhattan", "euclidean", "cosine")) - 1L
-  if (is.na(m)) stop("metric must be manhattan, euclidean or cosine")
+  m = match(metric, c("manhattan", "euclidean", "cosine", "correlation")) - 1L
+  if (is.na(m)) stop("metric must be manhattan, euclidean, cosine or correlation")
   .Call(`_gficf_find_nn`, as.matrix(X) + 0, as.integer(k), m)
 }
 

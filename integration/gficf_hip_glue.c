@@ -102,7 +102,7 @@ SEXP _gficf_gficf_csc(SEXP iS, SEXP pS, SEXP xS, SEXP dimS, SEXP wS, SEXP minS, 
 /* Optional: exact neighbour search in place of the approximate uwot:::find_nn(..., method = "annoy") call of
  * clustcells() (reference R/clustCells.R:57,60).  X: numeric N x d matrix; returns list(idx = N x k integer
  * matrix (1-based, column 1 = the cell itself), dist = N x k numeric) like uwot's result.
- * metric: 0 manhattan, 1 euclidean, 2 cosine. */
+ * metric: 0 manhattan, 1 euclidean, 2 cosine, 3 correlation. */
 SEXP _gficf_find_nn(SEXP XS, SEXP kS, SEXP metricS) {
   if (!Rf_isMatrix(XS) || TYPEOF(XS) != REALSXP) Rf_error("X must be a numeric matrix");
   SEXP dim = Rf_getAttrib(XS, R_DimSymbol);

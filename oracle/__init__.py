@@ -131,7 +131,7 @@ def gficf_csc(G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None, i
                 x=ox[:n].copy(), G_kept=gk.value)
 
 
-KNN_METRICS = {"manhattan": 0, "euclidean": 1, "cosine": 2}
+KNN_METRICS = {"manhattan": 0, "euclidean": 1, "cosine": 2, "correlation": 3}
 
 
 def knn(X: np.ndarray, k: int, metric: str = "manhattan", nthreads: int = 1, queries: tuple | None = None):

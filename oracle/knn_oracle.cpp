@@ -15,6 +15,7 @@
 //   manhattan  acc = acc + |a - b|                      (Annoy Manhattan::distance)
 //   euclidean  df = a - b; acc = fma(df, df, acc); sqrt at the end   (Annoy Euclidean, sqrt in get_nns)
 //   cosine     rows divided by their f32 L2 norm first; acc = fma(a, b, acc); dist = 1 - acc
+//   correlation  the same on rows with their f32 mean removed first (uwot "correlation" = Annoy angular on centred rows)
 //              (uwot converts Annoy's angular distance sqrt(2(1-cos)) to 1 - cos)
 #include <algorithm>
 #include <cmath>
@@ -82,16 +83,21 @@ KNN_TARGET void query_block(const float* P, int64_t N, int d, int64_t q0, int64_
 // 1 euclidean, 2 cosine.  Returns 0, 1 for invalid arguments, 2 for a host without fma.
 KNN_TARGET static void prepare_rows(const double* X, int64_t N, int d, int64_t ld, int metric, float* P) {
   for (int64_t r = 0; r < N; ++r) {
-    float nrm = 0.0f;
+    float nrm = 0.0f, mean = 0.0f;
     bool scale = false;
-    if (metric == 2) {
+    if (metric == 3) {                               // correlation: centre the row (f32 sum in dimension order / d)
+      float sm = 0.0f;
+      for (int t = 0; t < d; ++t) sm = sm + (float)X[(int64_t)t * ld + r];
+      mean = sm / (float)d;
+    }
+    if (metric >= 2) {
       float s = 0.0f;
-      for (int t = 0; t < d; ++t) { const float v = (float)X[(int64_t)t * ld + r]; s = __builtin_fmaf(v, v, s); }
+      for (int t = 0; t < d; ++t) { const float v = (float)X[(int64_t)t * ld + r] - mean; s = __builtin_fmaf(v, v, s); }
       nrm = std::sqrt(s);
       scale = nrm > 0.0f;
     }
     for (int t = 0; t < d; ++t) {
-      float v = (float)X[(int64_t)t * ld + r];
+      float v = (float)X[(int64_t)t * ld + r] - mean;
       if (scale) v = v / nrm;
       P[(size_t)r * d + t] = v;
     }
@@ -102,7 +108,7 @@ KNN_TARGET static void prepare_rows(const double* X, int64_t N, int d, int64_t l
 // keep the full N x k column-major shape, rows outside the range are left untouched.
 extern "C" int oracle_knn_block(const double* X, int64_t N, int d, int64_t ld, int k, int metric, int64_t q_begin, int64_t q_end,
                                 int32_t* idx, double* dist, int nthreads) {
-  if (N < 0 || d <= 0 || k < 0 || k > N || ld < N || metric < 0 || metric > 2 || q_begin < 0 || q_end < q_begin || q_end > N) return 1;
+  if (N < 0 || d <= 0 || k < 0 || k > N || ld < N || metric < 0 || metric > 3 || q_begin < 0 || q_end < q_begin || q_end > N) return 1;
   if (N == 0 || k == 0 || q_end == q_begin) return 0;
 #if defined(__x86_64__)
   if (!__builtin_cpu_supports("fma")) return 2;
@@ -119,7 +125,7 @@ extern "C" int oracle_knn_block(const double* X, int64_t N, int d, int64_t ld, i
       const float* p = P.data();
       if (metric == 0) query_block<0>(p, N, d, q0, q1, k, idx, dist, N);
       else if (metric == 1) query_block<1>(p, N, d, q0, q1, k, idx, dist, N);
-      else query_block<2>(p, N, d, q0, q1, k, idx, dist, N);
+      else query_block<2>(p, N, d, q0, q1, k, idx, dist, N);      // cosine, and correlation on the centred rows
     });
   }
   for (auto& t : th) t.join();

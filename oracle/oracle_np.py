@@ -173,7 +173,9 @@ def knn_np(X: np.ndarray, k: int, metric: str = "manhattan"):
     N = X.shape[0]
     idx = np.zeros((N, k), dtype=np.int32)
     dist = np.zeros((N, k), dtype=np.float64)
-    if metric == "cosine":
+    if metric == "correlation":
+        X = X - X.mean(axis=1, keepdims=True)
+    if metric in ("cosine", "correlation"):
         nrm = np.sqrt((X * X).sum(axis=1, keepdims=True))
         Xn = np.divide(X, nrm, out=np.zeros_like(X), where=nrm > 0)
     for i in range(N):
@@ -181,7 +183,7 @@ def knn_np(X: np.ndarray, k: int, metric: str = "manhattan"):
             dv = np.abs(X - X[i]).sum(axis=1)
         elif metric == "euclidean":
             dv = np.sqrt(((X - X[i]) ** 2).sum(axis=1))
-        elif metric == "cosine":
+        elif metric in ("cosine", "correlation"):
             dv = 1.0 - Xn @ Xn[i]
         else:
             raise ValueError(metric)

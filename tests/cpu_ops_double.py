@@ -119,7 +119,9 @@ class CpuOpsDouble:
 
     def knn_prepare(self, X_cm, n_rows, d, metric, point_rows):
         X = X_cm.numpy().reshape(d, -1)[:, :n_rows].T.astype(np.float32)
-        if metric == "cosine":
+        if metric == "correlation":
+            X = X - X.mean(axis=1, keepdims=True)
+        if metric in ("cosine", "correlation"):
             nrm = np.sqrt((X.astype(np.float64) ** 2).sum(axis=1, keepdims=True)).astype(np.float32)
             X = np.divide(X, nrm, out=np.zeros_like(X), where=nrm > 0)
         point_rows[:n_rows, :d] = torch.from_numpy(np.ascontiguousarray(X))

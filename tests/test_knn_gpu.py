@@ -143,6 +143,20 @@ def test_float32_input_and_zero_rows_cosine(ops):
     assert np.all(dist.cpu().numpy().T[17] == 1.0)
 
 
+@pytest.mark.parametrize("N,d,k", [(1200, 50, 16), (3000, 9, 31)])
+def test_correlation_metric(N, d, k, monkeypatch):
+    """uwot's "correlation": cosine distance of the rows with their mean removed — plain and pruned form."""
+    X = blobs(N, d, seed=N + k) + 5.0                               # an offset that the centring has to remove
+    widx, wdist = oracle.knn(X, k, "correlation", nthreads=8)
+    nidx, ndist = oracle_np.knn_np(X, k, "correlation")
+    assert np.allclose(wdist, ndist, rtol=1e-4, atol=2e-6) and (widx == nidx).mean() > 0.99
+    for prune in ("0", "1"):
+        monkeypatch.setenv("GFICF_KNN_PRUNE", prune)
+        got = gficf_amd.find_nn(X, k, True, "correlation")
+        assert np.array_equal(got["idx"], widx)
+        assert np.array_equal(got["dist"].astype(np.float32), wdist.astype(np.float32))
+
+
 def test_include_self_false_drops_own_id():
     X = blobs(500, 10, seed=9)
     a = gficf_amd.find_nn(X, 11, True, "manhattan")
