@@ -381,6 +381,21 @@ def main():
                                            if all(kk in pmc for kk in ("gene_count", "cell_kept_count")) and nnz == 59809258 else None),
                                "scale_kernel_ms": round(t_scale, 4), "count_kernel_ms": round(t_count, 4),
                                "algorithmic_bytes_per_pass": GFICF_BYTES_PER_NNZ * nnz}}
+            # next row N3: t(gficf), the PCA input (R/dimensinalityReduction.R:33), on the matrix just produced
+            gk, kn = int(ws["gkept"][0]), int(ws["out_colptr"][Nc])
+            tws = torch.zeros(ops.csc_transpose_workspace_bytes(gk, Nc), dtype=torch.uint8, device=dev)
+            t_ptr = torch.zeros(gk + 1, dtype=torch.int64, device=dev)
+            t_idx = torch.zeros(kn, dtype=torch.int32, device=dev)
+            t_val = torch.zeros(kn, dtype=torch.float64, device=dev)
+            run_t = lambda: ops.csc_transpose(gk, Nc, ws["out_colptr"], ws["out_rowidx"][:kn], ws["out_x"][:kn], t_ptr, t_idx, t_val, tws)
+            t_tr = time_kernel_ms(torch, run_t, 10)
+            order = torch.sort(ws["out_rowidx"][:kn].long(), stable=True)[1]
+            cell = torch.repeat_interleave(torch.arange(Nc, device=dev, dtype=torch.int32), ws["out_colptr"][1:] - ws["out_colptr"][:-1])
+            gf["transpose"] = {"ms": round(t_tr, 4), "entries": kn, "cells_per_sec": Nc / (t_tr * 1e-3),
+                               "algorithmic_GBps": round(28 * kn / t_tr / 1e6, 1),
+                               "note": "t(gficf): kept genes x cells CSC -> cells x genes CSC, 28 B/entry (4 count + 12 read + 12 written)",
+                               "checked_vs_stable_sort": bool(torch.equal(t_idx, cell[order]) and torch.equal(t_val, ws["out_x"][:kn][order]))}
+            del order, cell, tws, t_idx, t_val
             if not args.no_cpu_baseline:
                 import oracle
 

@@ -70,6 +70,9 @@ SIGNATURES = {
     "gficf_csc_scale_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_cluster_signatures_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _vp]),
     "gficf_cluster_signatures_host": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _vp, _int, _vp]),
+    "gficf_csc_transpose_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
+    "gficf_csc_transpose_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, ctypes.c_size_t]),
+    "gficf_csc_transpose_host": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "gficf_knn_dpad": (_int, [_int]),
     "gficf_knn_prepare_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _int, _vp]),
     "gficf_knn_workspace_bytes": (ctypes.c_size_t, [_vp, _i64, _i64, _int]),

@@ -310,6 +310,26 @@ def cluster_signatures(gficf_mat, cluster, ctx: Context | None = None):
     return out.T, uniq[order]
 
 
+def transpose_gficf(gficf_mat, ctx: Context | None = None):
+    """``data$pca$cells = t(data$gficf)`` (reference R/dimensinalityReduction.R:33, :100): the genes x cells CSC
+    matrix as a cells x genes CSC matrix (cell indices ascending within every gene, every stored entry kept)."""
+    import scipy.sparse as sp
+
+    M, colptr, rowidx, x = _csc_parts(gficf_mat)
+    G, N = M.shape
+    nnz = len(rowidx)
+    out_ptr = np.zeros(G + 1, dtype=np.int64)
+    out_idx = np.zeros(max(nnz, 1), dtype=np.int32)
+    out_x = np.zeros(max(nnz, 1), dtype=np.float64)
+    ctx = ctx or default_context()
+    is64 = 1 if colptr.dtype == np.int64 else 0
+    check(_lib.load().gficf_csc_transpose_host(ctx.handle, G, N, _np_ptr(colptr), is64, _np_ptr(rowidx), _np_ptr(x),
+                                               _np_ptr(out_ptr), _np_ptr(out_idx), _np_ptr(out_x)))
+    T = sp.csc_matrix((out_x[:nnz], out_idx[:nnz], out_ptr), shape=(N, G))
+    T.has_sorted_indices = True
+    return T
+
+
 # ------------------------------------------------------------------ kNN, reference-shaped
 def find_nn(X, k: int, include_self: bool = True, metric: str = "manhattan", ctx: Context | None = None) -> dict:
     """The neighbour search in front of the Jaccard build, shaped like the reference's call
@@ -510,6 +530,16 @@ class HipOps:
         """out: (C, G) float64 == column-major G x C; cluster: int32 ids in [0, C)."""
         check(self.L.gficf_cluster_signatures_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),
                                                      _tptr(cluster), int(C), _tptr(out)))
+
+    def csc_transpose_workspace_bytes(self, G: int, n_cells: int) -> int:
+        return int(self.L.gficf_csc_transpose_workspace_bytes(int(G), int(n_cells)))
+
+    def csc_transpose(self, G, n_cells, colptr, rowidx, x, out_ptr, out_idx, out_x, ws):
+        """t(gficf): out_ptr int64[G + 1], out_idx int32[nnz] (cells, ascending within a gene), out_x float64[nnz];
+        ws: a uint8 tensor of csc_transpose_workspace_bytes(G, n_cells) bytes."""
+        check(self.L.gficf_csc_transpose_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),
+                                                int(rowidx.numel()), _tptr(out_ptr), _tptr(out_idx), _tptr(out_x),
+                                                _tptr(ws), int(ws.numel() * ws.element_size())))
 
     def csc_workspace(self, G: int, n_cells: int, nnz: int) -> dict:
         """Pre-allocated outputs / scratch of the GF-ICF pipeline (keeps allocation out of timed loops)."""

@@ -257,6 +257,23 @@ int gficf_cluster_signatures_host(gficf_ctx* ctx, int64_t G, int64_t N, const vo
                                   int colptr_is_i64, const int32_t* rowidx, const double* x,
                                   const int32_t* cluster, int32_t C, double* out);
 
+/* ------------------------------------------------------------------- transpose of the GF-ICF matrix
+ * "Next" row N3, second half: data$pca$cells = t(data$gficf) (R/dimensinalityReduction.R:33, :100;
+ * Matrix::t, third-party) — the genes x cells CSC matrix as cells x genes CSC (= its CSR form):
+ *   out_ptr[G + 1], out_idx[nnz] (cell of every entry, ascending within a gene, 0-based), out_x[nnz].
+ * Every stored entry is kept (explicit zeros too), as Matrix::t does.  A stable counting sort by
+ * gene; d_ws: gficf_csc_transpose_workspace_bytes(G, n_cells) bytes of device scratch.  A row index
+ * outside [0, G) or a bad colptr is reported by gficf_ctx_sync() (GFICF_ERR_BAD_CSC); the columns
+ * must not name a gene twice (a dgCMatrix never does). */
+size_t gficf_csc_transpose_workspace_bytes(int64_t G, int64_t n_cells);
+int gficf_csc_transpose_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
+                               const int32_t* d_rowidx, const double* d_x, int64_t nnz,
+                               int64_t* d_out_ptr, int32_t* d_out_idx, double* d_out_x, void* d_ws,
+                               size_t ws_bytes);
+int gficf_csc_transpose_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* colptr,
+                             int colptr_is_i64, const int32_t* rowidx, const double* x,
+                             int64_t* out_ptr, int32_t* out_idx, double* out_x);
+
 /* ------------------------------------------------------------------- exact kNN search
  * "Next" row N2: the caller's step in front of the Jaccard build,
  *   neigh = uwot:::find_nn(data$pca$cells, k = k+1, include_self = T, method = "annoy",

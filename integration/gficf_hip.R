@@ -47,3 +47,27 @@ jaccard_adjacency_hip = function(relations, n)
   r = .Call(`_gficf_jaccard_adjacency`, as.numeric(relations$from), as.numeric(relations$to), as.numeric(relations$weight), n)
   Matrix::sparseMatrix(i = r[[1]], p = r[[2]], x = r[[3]], index1 = FALSE, dims = c(n, n))
 }
+
+# Optional (N3): cluster signatures.  Replaces
+#   u = base::unique(cluster.map)
+#   data$cluster.gene.rnk = base::sapply(u, function(x,y=data$gficf,z=cluster.map) Matrix::rowSums(y[,z%in%x]))
+#                                                                               (reference R/clustCells.R:121-123)
+# with
+#   data$cluster.gene.rnk = cluster_signatures_hip(data$gficf, cluster.map)
+cluster_signatures_hip = function(M, cluster.map)
+{
+  u = base::unique(cluster.map)
+  r = .Call(`_gficf_cluster_signatures`, M@i, M@p, M@x, M@Dim, match(cluster.map, u) - 1L, length(u))
+  rownames(r) = rownames(M)
+  r
+}
+
+# Optional (N3): the PCA input.  Replaces
+#   data$pca$cells = t(data$gficf)                                   (reference R/dimensinalityReduction.R:33, :100)
+# with
+#   data$pca$cells = transpose_hip(data$gficf)
+transpose_hip = function(M)
+{
+  r = .Call(`_gficf_transpose_csc`, M@i, M@p, M@x, M@Dim)
+  Matrix::sparseMatrix(i = r[[1]], p = r[[2]], x = r[[3]], index1 = FALSE, dims = rev(M@Dim), dimnames = rev(M@Dimnames))
+}

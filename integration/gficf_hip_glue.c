@@ -17,6 +17,9 @@
  *       R/gficf.R:38-105 (the reference has no native entry on that path).
  *   _gficf_find_nn(X, k, metric)                         — NEW, optional: exact kNN in place of the
  *       uwot:::find_nn(..., method = "annoy") call of clustcells() (R/clustCells.R:57,60).
+ *   _gficf_jaccard_adjacency(from, to, weight, n)        — NEW, optional: igraph::as_adjacency_matrix (R/clustCells.R:80,86).
+ *   _gficf_cluster_signatures(i, p, x, dim, cluster, C)  — NEW, optional: data$cluster.gene.rnk (R/clustCells.R:121-123).
+ *   _gficf_transpose_csc(i, p, x, dim)                   — NEW, optional: t(data$gficf) (R/dimensinalityReduction.R:33,100).
  */
 #include <R.h>
 #include <Rinternals.h>
@@ -140,12 +143,47 @@ SEXP _gficf_jaccard_adjacency(SEXP fromS, SEXP toS, SEXP weightS, SEXP nS) {
   return out;
 }
 
+/* Optional: data$cluster.gene.rnk = sapply(unique(cluster), function(x) rowSums(gficf[, cluster %in% x]))
+ * (reference R/clustCells.R:121-123).  cluster: integer ids 0..C-1 numbered in base::unique order by the R stub.
+ * Returns the G x C numeric matrix. */
+SEXP _gficf_cluster_signatures(SEXP iS, SEXP pS, SEXP xS, SEXP dimS, SEXP clS, SEXP CS) {
+  const int64_t G = INTEGER(dimS)[0], N = INTEGER(dimS)[1];
+  const int C = Rf_asInteger(CS);
+  SEXP out = PROTECT(Rf_allocMatrix(REALSXP, (int)G, C));
+  if (gficf_cluster_signatures_host(ctx_get(), G, N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), INTEGER(clS), C, REAL(out)) != GFICF_OK) {
+    UNPROTECT(1);
+    Rf_error("gficf_hip: %s", gficf_last_error());
+  }
+  UNPROTECT(1);
+  return out;
+}
+
+/* Optional: data$pca$cells = t(data$gficf) (reference R/dimensinalityReduction.R:33, :100).
+ * Returns list(i, p, x) of the cells x genes dgCMatrix. */
+SEXP _gficf_transpose_csc(SEXP iS, SEXP pS, SEXP xS, SEXP dimS) {
+  const int64_t G = INTEGER(dimS)[0], N = INTEGER(dimS)[1];
+  const int64_t nnz = INTEGER(pS)[N];
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 3));
+  SEXP oi = PROTECT(Rf_allocVector(INTSXP, nnz)), op = PROTECT(Rf_allocVector(INTSXP, G + 1)), ox = PROTECT(Rf_allocVector(REALSXP, nnz));
+  int64_t* ptr = (int64_t*)R_alloc((size_t)G + 1, sizeof(int64_t));
+  if (gficf_csc_transpose_host(ctx_get(), G, N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), ptr, INTEGER(oi), REAL(ox)) != GFICF_OK) {
+    UNPROTECT(4);
+    Rf_error("gficf_hip: %s", gficf_last_error());
+  }
+  for (int64_t g = 0; g <= G; ++g) INTEGER(op)[g] = (int)ptr[g];
+  SET_VECTOR_ELT(out, 0, oi); SET_VECTOR_ELT(out, 1, op); SET_VECTOR_ELT(out, 2, ox);
+  UNPROTECT(4);
+  return out;
+}
+
 static const R_CallMethodDef HipCallEntries[] = {
     {"_gficf_rcpp_parallel_jaccard_coef", (DL_FUNC)&_gficf_rcpp_parallel_jaccard_coef, 2},
     {"_gficf_jaccard_coeff", (DL_FUNC)&_gficf_jaccard_coeff, 2},
     {"_gficf_gficf_csc", (DL_FUNC)&_gficf_gficf_csc, 7},
     {"_gficf_find_nn", (DL_FUNC)&_gficf_find_nn, 3},
     {"_gficf_jaccard_adjacency", (DL_FUNC)&_gficf_jaccard_adjacency, 4},
+    {"_gficf_cluster_signatures", (DL_FUNC)&_gficf_cluster_signatures, 6},
+    {"_gficf_transpose_csc", (DL_FUNC)&_gficf_transpose_csc, 4},
     {NULL, NULL, 0}};
 
 /* Called from the package's R_init_gficf (reference src/RcppExports.cpp:94-97) next to the Rcpp entries:

@@ -147,6 +147,17 @@ def cluster_signatures_np(gficf_mat: sp.csc_matrix, cluster):
     return np.stack(cols, axis=1) if cols else np.zeros((M.shape[0], 0)), labels
 
 
+def transpose_np(G, N, colptr, rowidx, x):
+    """t(data$gficf) (R/dimensinalityReduction.R:33, :100; Matrix::t): the CSC arrays of the cells x genes matrix.
+    A stable sort of the stored entries by gene keeps the cells ascending within every gene; explicit zeros stay."""
+    colptr = np.asarray(colptr, dtype=np.int64)
+    rowidx = np.asarray(rowidx)
+    cell = np.repeat(np.arange(N, dtype=np.int32), np.diff(colptr))
+    order = np.argsort(rowidx, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(rowidx, minlength=G))]).astype(np.int64)
+    return ptr, cell[order], np.asarray(x, dtype=np.float64)[order]
+
+
 def jaccard_coeff_np(mat: np.ndarray) -> np.ndarray:
     """The serial entry (src/jaccard_coeff.cpp:19-44) through numpy set algebra: u = |unique(row i) ∩ unique(row kk)|
     (``Rcpp::intersect``, :33), rows with u > 0 packed from the top (:34-39)."""

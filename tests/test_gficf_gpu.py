@@ -324,6 +324,63 @@ def test_cluster_signatures_next_row_n3():
     assert got1.shape[1] == 1 and np.allclose(got1[:, 0], np.asarray(res["gficf"].sum(axis=1)).ravel(), rtol=1e-10)
 
 
+@pytest.mark.parametrize("G,N,seed", [(3000, 2000, 41), (500, 7, 3), (40000, 300, 5), (1200, 5000, 9)])
+def test_transpose_next_row_n3(G, N, seed):
+    """N3: data$pca$cells = t(data$gficf) (R/dimensinalityReduction.R:33,100): exact structure and values, cells ascending
+    within every gene; G = 40 000 takes two gene ranges of the LDS counters."""
+    from oracle import oracle_np
+
+    cp, ri, x = synth.counts_csc(G, N, seed=seed)
+    x = x.copy()
+    x[::17] = 0.0                                                     # explicit zeros are entries like any other
+    M = sp.csc_matrix((x, ri, cp), shape=(G, N))
+    T = gficf_amd.transpose_gficf(M)
+    ptr, idx, val = oracle_np.transpose_np(G, N, cp, ri, x)
+    assert T.shape == (N, G)
+    assert np.array_equal(T.indptr, ptr) and np.array_equal(T.indices, idx) and np.array_equal(T.data, val)
+    S = M.T.tocsc()                                                   # scipy's own transpose as a second opinion
+    S.sort_indices()
+    assert np.array_equal(S.indptr, ptr) and np.array_equal(S.indices, idx) and np.array_equal(S.data, val)
+
+
+def test_transpose_device_resident_and_edge_cases():
+    import torch
+
+    ops = gficf_amd.HipOps(0)
+    dev = "cuda:0"
+    from oracle import oracle_np
+
+    G, N = 2500, 1500
+    cp, ri, x = synth.counts_csc(G, N, seed=77)
+    res = ops.gficf_csc(G, N, torch.from_numpy(cp.astype(np.int64)).to(dev), torch.from_numpy(ri).to(dev), torch.from_numpy(x).to(dev))
+    ops.sync()
+    gk, nk = int(res["gkept"][0]), int(res["out_colptr"][N])
+    ws = torch.zeros(ops.csc_transpose_workspace_bytes(gk, N), dtype=torch.uint8, device=dev)
+    ptr = torch.zeros(gk + 1, dtype=torch.int64, device=dev)
+    idx = torch.zeros(nk, dtype=torch.int32, device=dev)
+    val = torch.zeros(nk, dtype=torch.float64, device=dev)
+    for _ in range(2):                                                # the scratch is reusable as it is
+        ops.csc_transpose(gk, N, res["out_colptr"], res["out_rowidx"][:nk], res["out_x"][:nk], ptr, idx, val, ws)
+        ops.sync()
+        wp, wi, wv = oracle_np.transpose_np(gk, N, res["out_colptr"].cpu().numpy(), res["out_rowidx"][:nk].cpu().numpy(),
+                                            res["out_x"][:nk].cpu().numpy())
+        assert np.array_equal(ptr.cpu().numpy(), wp) and np.array_equal(idx.cpu().numpy(), wi)
+        assert np.array_equal(val.cpu().numpy(), wv)
+    # empty matrices
+    E = gficf_amd.transpose_gficf(sp.csc_matrix((5, 4)))
+    assert E.shape == (4, 5) and E.nnz == 0
+    E = gficf_amd.transpose_gficf(sp.csc_matrix((0, 4)))
+    assert E.shape == (4, 0)
+    # a row index outside [0, G) is reported, not followed
+    bad = ri.copy(); bad[5] = G + 3
+    with pytest.raises(gficf_amd.GficfError):
+        out_p, out_i, out_x = np.zeros(G + 1, np.int64), np.zeros(len(ri), np.int32), np.zeros(len(ri))
+        from gficf_amd import _lib
+        from gficf_amd.api import _np_ptr, check, default_context
+        check(_lib.load().gficf_csc_transpose_host(default_context().handle, G, N, _np_ptr(cp.astype(np.int64)), 1, _np_ptr(bad),
+                                                   _np_ptr(x), _np_ptr(out_p), _np_ptr(out_i), _np_ptr(out_x)))
+
+
 @pytest.mark.parametrize("icf_type", ["classic", "prob", "smooth"])
 @pytest.mark.parametrize("norm", ["l2", "l1"])
 def test_helper_branches_icf_type_and_norm(icf_type, norm):

@@ -260,3 +260,26 @@ def test_gficf_oracle_helper_branches_cpp_vs_numpy(icf_type, norm):
               "smooth": np.log(1 + 3 / np.array([2, 2, 3, 1.0]))}[icf_type]
     with np.errstate(divide="ignore"):
         assert np.allclose(r["w"], want_w, equal_nan=True)
+
+
+def test_transpose_restatement_matches_scipy():
+    """t(data$gficf) (R/dimensinalityReduction.R:33): the numpy restatement against scipy's transpose, explicit zeros kept."""
+    import scipy.sparse as sp
+
+    from gficf_amd import synth
+    from oracle import oracle_np
+
+    G, N = 700, 450
+    cp, ri, x = synth.counts_csc(G, N, seed=12)
+    x = x.copy()
+    x[::9] = 0.0
+    ptr, idx, val = oracle_np.transpose_np(G, N, cp, ri, x)
+    S = sp.csc_matrix((x, ri, cp), shape=(G, N)).T.tocsc()
+    S.sort_indices()
+    assert np.array_equal(S.indptr, ptr) and np.array_equal(S.indices, idx) and np.array_equal(S.data, val)
+    assert len(val) == len(x)                                       # nothing dropped
+    # known answer: the 4 x 3 matrix of SURVEY.md 8c
+    M = sp.csc_matrix(np.array([[1, 0, 3], [1, 2, 0], [2, 2, 1], [0, 4, 0]], dtype=float))
+    ptr, idx, val = oracle_np.transpose_np(4, 3, M.indptr, M.indices, M.data)
+    assert ptr.tolist() == [0, 2, 4, 7, 8] and idx.tolist() == [0, 2, 0, 1, 0, 1, 2, 1]
+    assert val.tolist() == [1, 3, 1, 2, 2, 2, 1, 4]
