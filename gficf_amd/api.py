@@ -310,6 +310,54 @@ def cluster_signatures(gficf_mat, cluster, ctx: Context | None = None):
     return out.T, uniq[order]
 
 
+def run_modularity_clustering(SNN, modularity: int = 1, resolution: float = 0.8, algorithm: int = 1, n_start: int = 10,
+                              n_iter: int = 10, random_seed: int = 0, print_output: bool = False, ctx: Context | None = None):
+    """``RunModularityClustering(SNN, modularity, resolution, algorithm, n.start, n.iter, random.seed, print.output)``
+    (reference R/clustCells.R:145-149 -> src/RModularityOptimizer.cpp:25) on the symmetric weighted adjacency matrix of
+    the Jaccard graph (``jaccard_adjacency``).  RELAXED CONTRACT (see include/gficf_hip.h): a deterministic parallel
+    Louvain on the reference's objective — standard modularity with a resolution parameter, diagonal ignored — instead
+    of its sequential, seeded one; ``n_start`` and ``random_seed`` therefore have nothing to act on and are accepted for
+    signature compatibility only.  ``modularity`` must be 1 and ``algorithm`` 1 (Louvain) or 2 (treated as 1).
+
+    Returns the cluster of every vertex (int32, 0-based like the reference's return value, clusters numbered by
+    decreasing size); ``.modularity`` and ``.n_clusters`` are attached as attributes of the returned array subclass.
+    """
+    import scipy.sparse as sp
+
+    if modularity != 1:
+        raise ValueError("only the standard modularity function (1) is provided")
+    if algorithm not in (1, 2):
+        raise ValueError("algorithm must be 1 (Louvain) or 2 (Louvain with multilevel refinement, run as 1)")
+    if n_start < 1 or n_iter < 1:
+        raise ValueError("n_start and n_iter must be at least 1")
+    A = sp.csc_matrix(SNN)
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("SNN must be square")
+    if not A.has_sorted_indices:
+        A = A.copy()
+        A.sort_indices()
+    N = A.shape[0]
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+    x = np.ascontiguousarray(A.data, dtype=np.float64)
+    labels = np.zeros(max(N, 1), dtype=np.int32)
+    nc, q = ctypes.c_int64(0), ctypes.c_double(0.0)
+    ctx = ctx or default_context()
+    check(_lib.load().gficf_louvain_host(ctx.handle, N, _np_ptr(indptr), 1, _np_ptr(indices), _np_ptr(x), float(resolution), int(n_iter),
+                                         _np_ptr(labels), ctypes.byref(nc), ctypes.byref(q)))
+    out = labels[:N].view(ClusterLabels)
+    out.modularity, out.n_clusters = q.value, nc.value
+    if print_output:
+        print(f"Number of nodes: {N}\nModularity: {q.value:.4f}\nNumber of communities: {nc.value}")
+    return out
+
+
+class ClusterLabels(np.ndarray):
+    """int32 labels with the modularity and cluster count of the run attached."""
+    modularity = float("nan")
+    n_clusters = 0
+
+
 def transpose_gficf(gficf_mat, ctx: Context | None = None):
     """``data$pca$cells = t(data$gficf)`` (reference R/dimensinalityReduction.R:33, :100): the genes x cells CSC
     matrix as a cells x genes CSC matrix (cell indices ascending within every gene, every stored entry kept)."""
@@ -530,6 +578,18 @@ class HipOps:
         """out: (C, G) float64 == column-major G x C; cluster: int32 ids in [0, C)."""
         check(self.L.gficf_cluster_signatures_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),
                                                      _tptr(cluster), int(C), _tptr(out)))
+
+    def louvain_workspace_bytes(self, N: int, nnz: int) -> int:
+        return int(self.L.gficf_louvain_workspace_bytes(int(N), int(nnz)))
+
+    def louvain(self, N, indptr, indices, x, resolution, n_iter, labels, ws):
+        """Community detection on a device-resident symmetric adjacency matrix (indptr int64, indices int32, x float64).
+        Returns (n_clusters, modularity); labels: int32[N]."""
+        nc, q = ctypes.c_int64(0), ctypes.c_double(0.0)
+        check(self.L.gficf_louvain_device(self._bind(), int(N), _tptr(indptr), _tptr(indices), _tptr(x), int(indices.numel()),
+                                          float(resolution), int(n_iter), _tptr(labels), ctypes.byref(nc), ctypes.byref(q),
+                                          _tptr(ws), int(ws.numel() * ws.element_size())))
+        return nc.value, q.value
 
     def csc_transpose_workspace_bytes(self, G: int, n_cells: int) -> int:
         return int(self.L.gficf_csc_transpose_workspace_bytes(int(G), int(n_cells)))

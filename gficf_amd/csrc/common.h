@@ -12,7 +12,8 @@
 // Deferred device-side validation flags (OR-ed into gficf_ctx::d_status by kernels).
 constexpr uint32_t GFICF_ST_BAD_ID = 1u;    // kNN id outside [1, N] or not an integer
 constexpr uint32_t GFICF_ST_BAD_CSC = 2u;   // rowidx outside [0, G) / colptr not monotone
-constexpr uint32_t GFICF_ST_BAD_VALUE = 4u; // non-finite coordinate handed to the kNN search
+constexpr uint32_t GFICF_ST_BAD_VALUE = 4u; // non-finite coordinate handed to the kNN search / bad edge weight
+constexpr uint32_t GFICF_ST_TOO_DENSE = 8u; // Louvain: a vertex touches more communities than its table holds
 
 struct gficf_host_plan;  // gficf_csc.hip
 struct gficf_edge_plan;  // jaccard.hip

@@ -117,9 +117,11 @@ int gficf_ctx_sync(gficf_ctx* ctx) {
   if (st & GFICF_ST_BAD_ID)
     GFICF_FAIL(GFICF_ERR_BAD_ID, "kNN index matrix holds an id outside [1, N] or a non-integer value");
   if (st & GFICF_ST_BAD_VALUE)
-    GFICF_FAIL(GFICF_ERR_BAD_VALUE, "kNN point matrix holds a non-finite value");
+    GFICF_FAIL(GFICF_ERR_BAD_VALUE, "a non-finite kNN coordinate, or an edge weight that is negative / not finite");
   if (st & GFICF_ST_BAD_CSC)
     GFICF_FAIL(GFICF_ERR_BAD_CSC, "CSC matrix malformed: row index outside [0, G) or colptr not monotone");
+  if (st & GFICF_ST_TOO_DENSE)
+    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "Louvain: a vertex is adjacent to more communities than the 8192-slot table holds");
   return GFICF_OK;
 }
 

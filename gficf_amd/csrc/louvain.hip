@@ -1,0 +1,674 @@
+// louvain.hip — community detection on the Jaccard graph ("next" row N4 of the scope table).
+//
+// What clustcells() runs on the adjacency matrix of the kNN -> Jaccard graph:
+//   RunModularityClustering(igraph::as_adjacency_matrix(g, attr = "weight", sparse = T), 1, resolution, 1 | 2, n.start,
+//                           n.iter, seed, verbose)                                         (reference R/clustCells.R:80,86)
+// -> RunModularityClusteringCpp (src/RModularityOptimizer.cpp:25-181) -> VOSClusteringTechnique::runLouvainAlgorithm
+// (src/ModularityOptimizer.cpp:594-612): local moving (:484-592), network reduction, recursion; quality function
+// calcQualityFunction (:461-482) = standard modularity with a resolution parameter,
+//   Q = (1 / 2W) * [ sum_ij A_ij delta(c_i, c_j)  -  resolution * sum_c K_c^2 / 2W ],   K_c = sum of the degrees in c,
+// over the strict lower triangle of the matrix (the driver skips the diagonal, src/RModularityOptimizer.cpp:73-75).
+//
+// RELAXED PARITY CONTRACT.  The reference is a sequential, seed-exact algorithm: vertices move one at
+// a time in the order of a java.util.Random permutation.  A device form cannot follow that order and stay parallel, so
+// this is NOT label-for-label parity: the contract is the same objective (the Q above, same resolution semantics, same
+// diagonal handling, clusters numbered by decreasing size as Clustering::orderClustersByNNodes :132-158 does), a
+// modularity within a stated tolerance of the reference's own result on the same graph (tests/test_louvain_gpu.py
+// compares against a build of the reference's ModularityOptimizer.cpp, oracle/_ref/), and bit-reproducible output.
+//
+// Device algorithm (deterministic parallel Louvain):
+//   * weights in 2^-32 fixed point (u64): every sum — a vertex's weight towards a community, the community totals —
+//     is an integer sum, so atomics commute and the result does not depend on scheduling;
+//   * local moving, synchronous within a sub-round: every vertex reads the same snapshot (labels, community totals and
+//     sizes), accumulates its edge weight per neighbouring community in an LDS hash table (one wave per vertex up to 128
+//     neighbours, one workgroup with an 8192-slot table beyond), takes the community with the best gain
+//       gain(v -> c) = w(v, c) - k_v * K_c(without v) * resolution / 2W         (reference :540, ties: smaller id :541)
+//     if that beats staying; two singletons never swap (only the larger id moves).  The vertices are split into S
+//     hash classes that move one after the other (S grows as the graph gets small, where simultaneous moves hurt most);
+//     totals are applied between sub-rounds.  An iteration that lowers Q is undone and ends the level;
+//   * reduction: communities renumbered by a scan, every inter-community edge keyed (c_u << 32 | c_v), one rocPRIM
+//     radix sort, equal keys summed (integers again), CSR rebuilt; repeat until nothing merges;
+//   * n_iter > 1 restarts from the finest graph with the labels found so far, as the reference's iterations do.
+// Not reproduced: random starts (there is no randomness to restart), the move of a vertex into an empty cluster when
+// every gain is negative (:546-550), algorithm 3 (SLM).
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr double LV_SCALE = 4294967296.0;      // 2^32
+constexpr int LV_SMALL_DEG = 128;              // up to here: one wave per vertex, 256-slot table
+constexpr int LV_SMALL_SLOTS = 256;
+constexpr int LV_BIG_SLOTS = 8192;             // one workgroup per vertex: 32 KB keys + 64 KB sums
+constexpr int LV_MAX_ITERS = 64;
+
+struct LvGraph {
+  int64_t n, m;
+  const int64_t* ptr;
+  const int32_t* nbr;
+  const u64* wt;
+  const u64* kv;
+};
+
+__device__ __host__ static inline uint32_t lv_hash(uint32_t v) {
+  v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+  return v;
+}
+
+// ---- level 0: fixed-point weights, validation
+__global__ __launch_bounds__(256) void k_lv_fix(int64_t N, int64_t nnz, const int32_t* __restrict__ nbr, const double* __restrict__ x,
+                                                u64* __restrict__ wt, uint32_t* __restrict__ status) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= nnz) return;
+  const double v = x[e];
+  const int32_t u = nbr[e];
+  bool ok = u >= 0 && u < N && v >= 0.0 && v <= 1048576.0;      // NaN fails the comparisons
+  if (!ok) atomicOr(status, u >= 0 && u < N ? GFICF_ST_BAD_VALUE : GFICF_ST_BAD_CSC);
+  wt[e] = ok ? (u64)llrint(v * LV_SCALE) : 0ull;
+}
+
+__global__ __launch_bounds__(256) void k_lv_vertex_weight(LvGraph g, u64* __restrict__ kv, u64* __restrict__ two_w,
+                                                         uint32_t* __restrict__ status) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  u64 s = 0;
+  if (v < g.n) {
+    int64_t lo = g.ptr[v], hi = g.ptr[v + 1];
+    if (lo < 0 || hi < lo || hi > g.m) { atomicOr(status, GFICF_ST_BAD_CSC); lo = hi = 0; }
+    for (int64_t e = lo; e < hi; ++e) {
+      const int32_t u = g.nbr[e];
+      if (u != v && u >= 0 && u < g.n) s += g.wt[e];
+    }
+    kv[v] = s;
+  }
+  // block sum -> one atomic
+  __shared__ u64 s_sum[4];
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(two_w, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+}
+
+// labels given (init == nullptr: singletons) -> community totals and sizes
+__global__ __launch_bounds__(256) void k_lv_init(int64_t n, const int32_t* __restrict__ init, const u64* __restrict__ kv,
+                                                 int32_t* __restrict__ comm, u64* __restrict__ K, int32_t* __restrict__ size) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= n) return;
+  if (!init) {
+    comm[v] = (int32_t)v; K[v] = kv[v]; size[v] = 1;
+  } else {
+    const int32_t c = init[v];
+    comm[v] = c;
+    atomicAdd(&K[c], kv[v]);
+    atomicAdd(&size[c], 1);
+  }
+}
+
+// ---- local moving
+struct LvMove {
+  double r;            // resolution / 2W (in fixed-point units of 2W)
+  int s, S;            // this sub-round's hash class
+};
+
+__device__ static inline bool lv_better(double g, int32_t c, double bg, int32_t bc) { return g > bg || (g == bg && c < bc); }
+
+// One wave per vertex (degree <= LV_SMALL_DEG).
+__global__ __launch_bounds__(256) void k_lv_move_small(LvGraph g, LvMove mv, const int32_t* __restrict__ comm, const u64* __restrict__ K,
+                                                       const int32_t* __restrict__ size, int32_t* __restrict__ next,
+                                                       unsigned* __restrict__ moved) {
+  __shared__ int32_t s_key[4][LV_SMALL_SLOTS];
+  __shared__ u64 s_val[4][LV_SMALL_SLOTS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + wave;
+  int64_t lo = 0, hi = 0;
+  bool active = v < g.n;
+  if (active) {
+    lo = g.ptr[v]; hi = g.ptr[v + 1];
+    active = hi - lo <= LV_SMALL_DEG && (mv.S == 1 || (int)(lv_hash((uint32_t)v) % (uint32_t)mv.S) == mv.s);
+  }
+  int32_t* key = s_key[wave];
+  u64* val = s_val[wave];
+  for (int t = lane; t < LV_SMALL_SLOTS; t += 64) { key[t] = -1; val[t] = 0ull; }
+  __syncthreads();
+  if (active) {
+    for (int64_t e = lo + lane; e < hi; e += 64) {
+      const int32_t u = g.nbr[e];
+      if (u == v) continue;
+      const int32_t c = comm[u];
+      uint32_t h = lv_hash((uint32_t)c) & (LV_SMALL_SLOTS - 1);
+      for (;;) {
+        const int32_t old = atomicCAS(&key[h], -1, c);
+        if (old == -1 || old == c) { atomicAdd(&val[h], g.wt[e]); break; }
+        h = (h + 1) & (LV_SMALL_SLOTS - 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  const int32_t cv = comm[v];
+  const double kvd = (double)g.kv[v];
+  double bg = -INFINITY, stay_w = 0.0;
+  int32_t bc = INT32_MAX;
+  for (int t = lane; t < LV_SMALL_SLOTS; t += 64) {
+    const int32_t c = key[t];
+    if (c < 0) continue;
+    const double w = (double)val[t];
+    if (c == cv) { stay_w = w; continue; }
+    const double gain = w - kvd * (double)K[c] * mv.r;
+    if (lv_better(gain, c, bg, bc)) { bg = gain; bc = c; }
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    const double og = __shfl_xor(bg, d), ow = __shfl_xor(stay_w, d);
+    const int32_t oc = __shfl_xor(bc, d);
+    if (lv_better(og, oc, bg, bc)) { bg = og; bc = oc; }
+    stay_w = fmax(stay_w, ow);
+  }
+  if (lane == 0) {
+    const double g_stay = stay_w - kvd * (double)(K[cv] - g.kv[v]) * mv.r;
+    bool move = bc != INT32_MAX && bg > g_stay;
+    if (move && size[cv] == 1 && size[bc] == 1 && bc > cv) move = false;      // two singletons never swap
+    next[v] = move ? bc : cv;
+    if (move) atomicAdd(moved, 1u);
+  }
+}
+
+// One workgroup per listed vertex (degree > LV_SMALL_DEG).
+__global__ __launch_bounds__(256) void k_lv_move_big(LvGraph g, LvMove mv, const int32_t* __restrict__ big, const int32_t* __restrict__ comm,
+                                                     const u64* __restrict__ K, const int32_t* __restrict__ size,
+                                                     int32_t* __restrict__ next, unsigned* __restrict__ moved,
+                                                     uint32_t* __restrict__ status) {
+  extern __shared__ unsigned char s_raw[];
+  u64* val = (u64*)s_raw;
+  int32_t* key = (int32_t*)(val + LV_BIG_SLOTS);
+  __shared__ double s_g[256], s_w[4];
+  __shared__ int32_t s_c[256];
+  const int tid = threadIdx.x;
+  const int64_t v = big[blockIdx.x];
+  if (mv.S != 1 && (int)(lv_hash((uint32_t)v) % (uint32_t)mv.S) != mv.s) return;     // uniform per workgroup
+  for (int t = tid; t < LV_BIG_SLOTS; t += 256) { key[t] = -1; val[t] = 0ull; }
+  __syncthreads();
+  const int64_t lo = g.ptr[v], hi = g.ptr[v + 1];
+  for (int64_t e = lo + tid; e < hi; e += 256) {
+    const int32_t u = g.nbr[e];
+    if (u == v) continue;
+    const int32_t c = comm[u];
+    uint32_t h = lv_hash((uint32_t)c) & (LV_BIG_SLOTS - 1);
+    int probes = 0;
+    for (;;) {
+      const int32_t old = atomicCAS(&key[h], -1, c);
+      if (old == -1 || old == c) { atomicAdd(&val[h], g.wt[e]); break; }
+      h = (h + 1) & (LV_BIG_SLOTS - 1);
+      if (++probes >= LV_BIG_SLOTS) { atomicOr(status, GFICF_ST_TOO_DENSE); break; }   // more communities than slots
+    }
+  }
+  __syncthreads();
+  const int32_t cv = comm[v];
+  const double kvd = (double)g.kv[v];
+  double bg = -INFINITY, stay_w = 0.0;
+  int32_t bc = INT32_MAX;
+  for (int t = tid; t < LV_BIG_SLOTS; t += 256) {
+    const int32_t c = key[t];
+    if (c < 0) continue;
+    const double w = (double)val[t];
+    if (c == cv) { stay_w = w; continue; }
+    const double gain = w - kvd * (double)K[c] * mv.r;
+    if (lv_better(gain, c, bg, bc)) { bg = gain; bc = c; }
+  }
+  for (int d = 32; d > 0; d >>= 1) stay_w = fmax(stay_w, __shfl_xor(stay_w, d));
+  if ((tid & 63) == 0) s_w[tid >> 6] = stay_w;
+  s_g[tid] = bg; s_c[tid] = bc;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (tid < d && lv_better(s_g[tid + d], s_c[tid + d], s_g[tid], s_c[tid])) { s_g[tid] = s_g[tid + d]; s_c[tid] = s_c[tid + d]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    bg = s_g[0]; bc = s_c[0];
+    stay_w = fmax(fmax(s_w[0], s_w[1]), fmax(s_w[2], s_w[3]));
+    const double g_stay = stay_w - kvd * (double)(K[cv] - g.kv[v]) * mv.r;
+    bool move = bc != INT32_MAX && bg > g_stay;
+    if (move && size[cv] == 1 && size[bc] == 1 && bc > cv) move = false;
+    next[v] = move ? bc : cv;
+    if (move) atomicAdd(moved, 1u);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_lv_list_big(LvGraph g, int32_t* __restrict__ big, unsigned* __restrict__ n_big) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v < g.n && g.ptr[v + 1] - g.ptr[v] > LV_SMALL_DEG) big[atomicAdd(n_big, 1u)] = (int32_t)v;
+}
+
+// applies the sub-round's moves to the labels, totals and sizes
+__global__ __launch_bounds__(256) void k_lv_apply(int64_t n, LvMove mv, const u64* __restrict__ kv, int32_t* __restrict__ comm,
+                                                  const int32_t* __restrict__ next, u64* __restrict__ K, int32_t* __restrict__ size) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= n) return;
+  if (mv.S != 1 && (int)(lv_hash((uint32_t)v) % (uint32_t)mv.S) != mv.s) return;
+  const int32_t a = comm[v], b = next[v];
+  if (a == b) return;
+  const u64 k = kv[v];
+  atomicAdd(&K[a], 0ull - k);
+  atomicAdd(&K[b], k);
+  atomicSub(&size[a], 1);
+  atomicAdd(&size[b], 1);
+  comm[v] = b;
+}
+
+// ---- quality: internal weight (integer) and sum of squared totals (fixed summation order)
+__global__ __launch_bounds__(256) void k_lv_internal(LvGraph g, const int32_t* __restrict__ comm, u64* __restrict__ in_w) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + wave;
+  u64 s = 0;
+  if (v < g.n) {
+    const int32_t cv = comm[v];
+    for (int64_t e = g.ptr[v] + lane; e < g.ptr[v + 1]; e += 64) {
+      const int32_t u = g.nbr[e];
+      if (u != v && comm[u] == cv) s += g.wt[e];
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+  if (lane == 0 && s) atomicAdd(in_w, s);
+}
+
+__global__ __launch_bounds__(1024) void k_lv_sumsq(int64_t n, const u64* __restrict__ K, double* __restrict__ out) {
+  __shared__ double s_p[1024];
+  double s = 0.0;
+  for (int64_t c = threadIdx.x; c < n; c += 1024) { const double k = (double)K[c]; s += k * k; }
+  s_p[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 512; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) s_p[threadIdx.x] += s_p[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = s_p[0];
+}
+
+// ---- reduction of the graph
+__global__ __launch_bounds__(256) void k_lv_used(int64_t n, const int32_t* __restrict__ size, int64_t* __restrict__ flag) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c <= n) flag[c] = c < n && size[c] > 0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_lv_coarse_weights(int64_t n, const int32_t* __restrict__ size, const int64_t* __restrict__ newid,
+                                                           const u64* __restrict__ K, u64* __restrict__ kv2) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c < n && size[c] > 0) kv2[newid[c]] = K[c];
+}
+
+__global__ __launch_bounds__(256) void k_lv_relabel(int64_t n, int32_t* __restrict__ lab, const int32_t* __restrict__ comm,
+                                                    const int64_t* __restrict__ newid) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v < n) lab[v] = (int32_t)newid[comm[lab ? lab[v] : v]];
+}
+
+__global__ __launch_bounds__(256) void k_lv_relabel_first(int64_t n, int32_t* __restrict__ lab, const int32_t* __restrict__ comm,
+                                                          const int64_t* __restrict__ newid) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v < n) lab[v] = (int32_t)newid[comm[v]];
+}
+
+// none = n2 << 32: the key of an entry that stays inside a community; it sorts behind every kept key
+__global__ __launch_bounds__(256) void k_lv_emit(LvGraph g, const int32_t* __restrict__ comm, const int64_t* __restrict__ newid, u64 none,
+                                                 u64* __restrict__ keys, u64* __restrict__ vals) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + wave;
+  if (v >= g.n) return;
+  const u64 cv = (u64)newid[comm[v]];
+  for (int64_t e = g.ptr[v] + lane; e < g.ptr[v + 1]; e += 64) {
+    const int32_t u = g.nbr[e];
+    u64 k = none;
+    if (u != v) {
+      const u64 cu = (u64)newid[comm[u]];
+      if (cu != cv) k = (cv << 32) | cu;
+    }
+    keys[e] = k;
+    vals[e] = g.wt[e];
+  }
+}
+
+// flag[e] = 1 where a new (row, col) starts; flag[m] = 0 (the scan turns it into the number of coarse entries)
+__global__ __launch_bounds__(256) void k_lv_heads(const u64* __restrict__ keys, int64_t m, u64 none, int64_t* __restrict__ flag) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e > m) return;
+  int64_t f = 0;
+  if (e < m) {
+    const u64 k = keys[e];
+    f = (k != none && (e == 0 || keys[e - 1] != k)) ? 1 : 0;
+  }
+  flag[e] = f;
+}
+
+// pos = exclusive scan of the head flags: entry e belongs to coarse entry pos[e + 1] - 1
+__global__ __launch_bounds__(256) void k_lv_reduce(const u64* __restrict__ keys, const u64* __restrict__ vals, int64_t m, u64 none,
+                                                   const int64_t* __restrict__ pos, int32_t* __restrict__ nbr2, u64* __restrict__ wt2,
+                                                   int64_t* __restrict__ row_cnt) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= m) return;
+  const u64 k = keys[e];
+  if (k == none) return;
+  const int64_t p = pos[e + 1] - 1;
+  atomicAdd(&wt2[p], vals[e]);
+  if (pos[e + 1] != pos[e]) {                   // a head
+    nbr2[p] = (int32_t)(k & 0xffffffffull);
+    atomicAdd((u64*)&row_cnt[k >> 32], 1ull);
+  }
+}
+
+// ---- final numbering: clusters by decreasing size, ties by id (Clustering::orderClustersByNNodes, reference :132-158)
+__global__ __launch_bounds__(256) void k_lv_count(int64_t n, const int32_t* __restrict__ lab, int32_t* __restrict__ cnt) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v < n) atomicAdd(&cnt[lab[v]], 1);
+}
+
+__global__ __launch_bounds__(256) void k_lv_size_keys(int64_t C, int64_t n, const int32_t* __restrict__ cnt, u64* __restrict__ keys,
+                                                      u64* __restrict__ ids) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c < C) { keys[c] = ((u64)(n - cnt[c]) << 32) | (u64)c; ids[c] = (u64)c; }
+}
+
+__global__ __launch_bounds__(256) void k_lv_rank(int64_t C, const u64* __restrict__ sorted_ids, int32_t* __restrict__ rank) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < C) rank[sorted_ids[p]] = (int32_t)p;
+}
+
+__global__ __launch_bounds__(256) void k_lv_final(int64_t n, const int32_t* __restrict__ lab, const int32_t* __restrict__ rank,
+                                                  int32_t* __restrict__ out) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v < n) out[v] = rank[lab[v]];
+}
+
+// ---- host side
+struct Bump {
+  char* base; size_t off, cap;
+  template <typename T> T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = (T*)(base + off);
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+static size_t lv_sort_tmp_bytes(int64_t m) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, (u64*)nullptr, (u64*)nullptr, (u64*)nullptr, (u64*)nullptr, (size_t)(m > 0 ? m : 1), 0u, 64u,
+                                  (hipStream_t) nullptr);
+  return tmp;
+}
+
+struct LvLevel {          // a coarse graph's arrays
+  int64_t* ptr; int32_t* nbr; u64* wt; u64* kv;
+};
+
+struct LvWs {
+  u64* wt0; u64* kv0;
+  LvLevel lvl[2];
+  int32_t *comm, *next, *snap_comm, *size, *snap_size, *big, *lab, *cnt, *rank;
+  u64 *K, *snap_K;
+  int64_t* flag;            // max(n, m) + 1 entries: scans
+  u64 *keys_a, *vals_a, *keys_b, *vals_b;
+  void* sort_tmp; size_t sort_tmp_bytes;
+  u64* scalars;             // [0] 2W, [1] internal weight, [2] moved (unsigned) | n_big, [3] sum of squares (double)
+};
+
+static size_t lv_carve(LvWs* w, void* base, int64_t N, int64_t nnz) {
+  Bump b{(char*)base, 0, 0};
+  const size_t n = (size_t)(N > 0 ? N : 1), m = (size_t)(nnz > 0 ? nnz : 1);
+  LvWs d;
+  d.wt0 = b.take<u64>(m); d.kv0 = b.take<u64>(n);
+  for (int i = 0; i < 2; ++i) {
+    d.lvl[i].ptr = b.take<int64_t>(n + 1); d.lvl[i].nbr = b.take<int32_t>(m); d.lvl[i].wt = b.take<u64>(m); d.lvl[i].kv = b.take<u64>(n);
+  }
+  d.comm = b.take<int32_t>(n); d.next = b.take<int32_t>(n); d.snap_comm = b.take<int32_t>(n);
+  d.size = b.take<int32_t>(n); d.snap_size = b.take<int32_t>(n); d.big = b.take<int32_t>(n);
+  d.lab = b.take<int32_t>(n); d.cnt = b.take<int32_t>(n); d.rank = b.take<int32_t>(n);
+  d.K = b.take<u64>(n); d.snap_K = b.take<u64>(n);
+  d.flag = b.take<int64_t>((n > m ? n : m) + 1);
+  d.keys_a = b.take<u64>(m > n ? m : n); d.vals_a = b.take<u64>(m > n ? m : n);
+  d.keys_b = b.take<u64>(m > n ? m : n); d.vals_b = b.take<u64>(m > n ? m : n);
+  d.sort_tmp_bytes = lv_sort_tmp_bytes((int64_t)(m > n ? m : n));
+  d.sort_tmp = b.take<char>(d.sort_tmp_bytes);
+  d.scalars = b.take<u64>(8);
+  if (w) *w = d;
+  return b.off + 256;
+}
+
+static inline unsigned lv_blocks(int64_t n, int per) { return (unsigned)gficf_ceil_div(n > 0 ? n : 1, per); }
+
+static int lv_sub_rounds(int64_t n) {
+  if (const char* e = getenv("GFICF_LOUVAIN_SUBROUNDS")) { const int s = atoi(e); if (s >= 1 && s <= 64) return s; }
+  return n > 50000 ? 2 : n > 4000 ? 4 : n > 400 ? 8 : 16;
+}
+
+struct LvQ { double q; u64 in_w; };
+
+// Q of the current labels on graph g (self = weight already folded into the vertices), deterministic.
+static int lv_quality(gficf_ctx* ctx, const LvGraph& g, const LvWs& w, u64 self_w, double two_w, double resolution, double* q_out, u64* in_out) {
+  GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 1, 0, sizeof(u64), ctx->stream));
+  hipLaunchKernelGGL(k_lv_internal, dim3(lv_blocks(g.n, 4)), dim3(256), 0, ctx->stream, g, w.comm, w.scalars + 1);
+  hipLaunchKernelGGL(k_lv_sumsq, dim3(1), dim3(1024), 0, ctx->stream, g.n, w.K, (double*)(w.scalars + 3));
+  u64 h[4];
+  GFICF_HIP_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  GFICF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  double sq;
+  memcpy(&sq, &h[3], sizeof(double));
+  *in_out = h[1];
+  *q_out = ((double)(h[1] + self_w)) / two_w - resolution * sq / (two_w * two_w);
+  return GFICF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz) {
+  if (N < 0 || nnz < 0) return 0;
+  return lv_carve(nullptr, nullptr, N, nnz);
+}
+
+int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, const int32_t* d_indices, const double* d_x, int64_t nnz,
+                         double resolution, int n_iter, int32_t* d_labels, int64_t* n_clusters, double* modularity, void* d_ws,
+                         size_t ws_bytes) {
+  GFICF_CTX_ENTER(ctx);
+  if (N < 0 || nnz < 0 || n_iter < 1 || !(resolution >= 0.0)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size, n_iter < 1 or a negative resolution");
+  if (n_clusters) *n_clusters = 0;
+  if (modularity) *modularity = 0.0;
+  if (N == 0) return GFICF_OK;
+  if (!d_indptr || !d_labels || !d_ws || (nnz > 0 && (!d_indices || !d_x))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (N > INT32_MAX) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "more than 2^31 - 1 vertices");
+  if (ws_bytes < gficf_louvain_workspace_bytes(N, nnz))
+    GFICF_FAIL(GFICF_ERR_INVALID_ARG, "workspace too small: %zu < %zu bytes", ws_bytes, gficf_louvain_workspace_bytes(N, nnz));
+  static bool attr_set = false;
+  if (!attr_set) {
+    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_lv_move_big, hipFuncAttributeMaxDynamicSharedMemorySize, LV_BIG_SLOTS * 12));
+    attr_set = true;
+  }
+  LvWs w;
+  lv_carve(&w, d_ws, N, nnz);
+  hipStream_t st = ctx->stream;
+
+  // level 0: fixed-point weights, vertex weights, 2W
+  GFICF_HIP_CHECK(hipMemsetAsync(w.scalars, 0, 8 * sizeof(u64), st));
+  if (nnz > 0) hipLaunchKernelGGL(k_lv_fix, dim3(lv_blocks(nnz, 256)), dim3(256), 0, st, N, nnz, d_indices, d_x, w.wt0, ctx->d_status);
+  LvGraph g0{N, nnz, d_indptr, d_indices, w.wt0, w.kv0};
+  hipLaunchKernelGGL(k_lv_vertex_weight, dim3(lv_blocks(N, 256)), dim3(256), 0, st, g0, w.kv0, w.scalars, ctx->d_status);
+  u64 two_w_fix = 0;
+  GFICF_HIP_CHECK(hipMemcpyAsync(&two_w_fix, w.scalars, sizeof(u64), hipMemcpyDeviceToHost, st));
+  int rc = gficf_ctx_sync(ctx);                    // also reports a malformed matrix before anything follows it
+  if (rc) return rc;
+  const double two_w = (double)two_w_fix;
+  if (two_w_fix == 0) {                            // no edges: every vertex is its own cluster, Q = 0
+    hipLaunchKernelGGL(k_lv_init, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, (const int32_t*)nullptr, w.kv0, d_labels, w.K, w.size);
+    GFICF_HIP_CHECK(hipStreamSynchronize(st));
+    if (n_clusters) *n_clusters = N;
+    return GFICF_OK;
+  }
+  const double r = resolution / two_w;
+  double q_final = 0.0;
+  bool have_labels = false;
+
+  for (int pass = 0; pass < n_iter; ++pass) {
+    LvGraph g = g0;
+    u64 self_w = 0;
+    bool any_move = false;
+    for (int level = 0;; ++level) {
+      // ---- start of a level: labels, totals, sizes
+      const bool seeded = level == 0 && have_labels;
+      if (seeded) {
+        GFICF_HIP_CHECK(hipMemsetAsync(w.K, 0, sizeof(u64) * (size_t)g.n, st));
+        GFICF_HIP_CHECK(hipMemsetAsync(w.size, 0, sizeof(int32_t) * (size_t)g.n, st));
+      }
+      hipLaunchKernelGGL(k_lv_init, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, seeded ? (const int32_t*)w.lab : (const int32_t*)nullptr,
+                         g.kv, w.comm, w.K, w.size);
+      GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 2, 0, sizeof(u64), st));
+      hipLaunchKernelGGL(k_lv_list_big, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g, w.big, ((unsigned*)(w.scalars + 2)) + 1);
+      unsigned h_cnt[2] = {0, 0};
+      GFICF_HIP_CHECK(hipMemcpyAsync(h_cnt, w.scalars + 2, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+      double q_prev; u64 in_w;
+      rc = lv_quality(ctx, g, w, self_w, two_w, resolution, &q_prev, &in_w);
+      if (rc) return rc;
+      const unsigned n_big = h_cnt[1];
+      const int S = lv_sub_rounds(g.n);
+
+      // ---- local moving
+      bool level_moved = false;
+      for (int iter = 0; iter < LV_MAX_ITERS; ++iter) {
+        GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_comm, w.comm, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+        GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_size, w.size, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+        GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_K, w.K, sizeof(u64) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+        GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 2, 0, sizeof(unsigned), st));
+        for (int s = 0; s < S; ++s) {
+          const LvMove mv{r, s, S};
+          hipLaunchKernelGGL(k_lv_move_small, dim3(lv_blocks(g.n, 4)), dim3(256), 0, st, g, mv, w.comm, w.K, w.size, w.next, (unsigned*)(w.scalars + 2));
+          if (n_big)
+            hipLaunchKernelGGL(k_lv_move_big, dim3(n_big), dim3(256), LV_BIG_SLOTS * 12, st, g, mv, w.big, w.comm, w.K, w.size, w.next,
+                               (unsigned*)(w.scalars + 2), ctx->d_status);
+          hipLaunchKernelGGL(k_lv_apply, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, mv, g.kv, w.comm, w.next, w.K, w.size);
+        }
+        unsigned moved = 0;
+        GFICF_HIP_CHECK(hipMemcpyAsync(&moved, w.scalars + 2, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        double q; u64 in_now;
+        rc = lv_quality(ctx, g, w, self_w, two_w, resolution, &q, &in_now);
+        if (rc) return rc;
+        if (moved == 0) break;
+        if (q < q_prev) {                          // simultaneous moves made it worse: undo the iteration, the level ends
+          GFICF_HIP_CHECK(hipMemcpyAsync(w.comm, w.snap_comm, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+          GFICF_HIP_CHECK(hipMemcpyAsync(w.size, w.snap_size, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+          GFICF_HIP_CHECK(hipMemcpyAsync(w.K, w.snap_K, sizeof(u64) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+          break;
+        }
+        level_moved = true;
+        in_w = in_now;
+        const bool small_gain = q - q_prev < 1e-7;
+        q_prev = q;
+        if (small_gain) break;
+      }
+      any_move |= level_moved;
+      q_final = q_prev;
+
+      // ---- renumber the communities, compose the labels of the original vertices
+      hipLaunchKernelGGL(k_lv_used, dim3(lv_blocks(g.n + 1, 256)), dim3(256), 0, st, g.n, w.size, w.flag);
+      rc = gficf_exclusive_scan_i64(ctx, w.flag, g.n + 1);
+      if (rc) return rc;
+      int64_t n2 = 0;
+      GFICF_HIP_CHECK(hipMemcpyAsync(&n2, w.flag + g.n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+      if (level == 0) hipLaunchKernelGGL(k_lv_relabel_first, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, w.lab, w.comm, w.flag);
+      else hipLaunchKernelGGL(k_lv_relabel, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, w.lab, w.comm, w.flag);
+      GFICF_HIP_CHECK(hipStreamSynchronize(st));
+      have_labels = true;
+      if (n2 == g.n || n2 <= 1 || (!level_moved && !(seeded && n2 < g.n))) {
+        if (n_clusters) *n_clusters = n2;
+        break;                                     // nothing merged: this pass is done
+      }
+
+      // ---- the reduced graph
+      LvLevel& nl = w.lvl[level & 1];
+      hipLaunchKernelGGL(k_lv_coarse_weights, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, w.size, w.flag, w.K, nl.kv);
+      int64_t m2 = 0;
+      if (g.m > 0) {
+        const u64 none = (u64)n2 << 32;
+        hipLaunchKernelGGL(k_lv_emit, dim3(lv_blocks(g.n, 4)), dim3(256), 0, st, g, w.comm, w.flag, none, w.keys_a, w.vals_a);
+        unsigned bits = 33;                        // the keys in use: (row < n2) << 32 | col, and none = n2 << 32
+        while (bits < 64 && ((int64_t)1 << (bits - 32)) <= n2) ++bits;
+        size_t tb = w.sort_tmp_bytes;
+        GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys_a, w.keys_b, w.vals_a, w.vals_b, (size_t)g.m, 0u, bits, st));
+        hipLaunchKernelGGL(k_lv_heads, dim3(lv_blocks(g.m + 1, 256)), dim3(256), 0, st, w.keys_b, g.m, none, w.flag);
+        rc = gficf_exclusive_scan_i64(ctx, w.flag, g.m + 1);
+        if (rc) return rc;
+        GFICF_HIP_CHECK(hipMemcpyAsync(&m2, w.flag + g.m, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        GFICF_HIP_CHECK(hipStreamSynchronize(st));
+        GFICF_HIP_CHECK(hipMemsetAsync(nl.wt, 0, sizeof(u64) * (size_t)(m2 > 0 ? m2 : 1), st));
+        GFICF_HIP_CHECK(hipMemsetAsync(nl.ptr, 0, sizeof(int64_t) * (size_t)(n2 + 1), st));
+        hipLaunchKernelGGL(k_lv_reduce, dim3(lv_blocks(g.m, 256)), dim3(256), 0, st, w.keys_b, w.vals_b, g.m, none, w.flag, nl.nbr, nl.wt, nl.ptr);
+        rc = gficf_exclusive_scan_i64(ctx, nl.ptr, n2 + 1);
+        if (rc) return rc;
+      } else {
+        GFICF_HIP_CHECK(hipMemsetAsync(nl.ptr, 0, sizeof(int64_t) * (size_t)(n2 + 1), st));
+      }
+      self_w += in_w;
+      g = LvGraph{n2, m2, nl.ptr, nl.nbr, nl.wt, nl.kv};
+    }
+    if (!any_move) break;
+  }
+
+  // ---- clusters by decreasing size
+  int64_t C = n_clusters ? *n_clusters : 0;
+  if (!n_clusters) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "n_clusters is NULL");
+  GFICF_HIP_CHECK(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * (size_t)C, st));
+  hipLaunchKernelGGL(k_lv_count, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, w.lab, w.cnt);
+  hipLaunchKernelGGL(k_lv_size_keys, dim3(lv_blocks(C, 256)), dim3(256), 0, st, C, N, w.cnt, w.keys_a, w.vals_a);
+  size_t tb = w.sort_tmp_bytes;
+  GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys_a, w.keys_b, w.vals_a, w.vals_b, (size_t)C, 0u, 64u, st));
+  hipLaunchKernelGGL(k_lv_rank, dim3(lv_blocks(C, 256)), dim3(256), 0, st, C, w.vals_b, w.rank);
+  hipLaunchKernelGGL(k_lv_final, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, w.lab, w.rank, d_labels);
+  GFICF_HIP_CHECK(hipGetLastError());
+  if (modularity) *modularity = q_final;
+  return gficf_ctx_sync(ctx);
+}
+
+int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr_is_i64, const int32_t* indices, const double* x,
+                       double resolution, int n_iter, int32_t* labels, int64_t* n_clusters, double* modularity) {
+  GFICF_CTX_ENTER(ctx);
+  if (N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
+  if (n_clusters) *n_clusters = 0;
+  if (modularity) *modularity = 0.0;
+  if (N == 0) return GFICF_OK;
+  if (!indptr || !labels || !n_clusters) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
+  int64_t* h_ptr = nullptr;
+  GFICF_HIP_CHECK(hipHostMalloc((void**)&h_ptr, sizeof(int64_t) * ((size_t)N + 1), hipHostMallocDefault));
+  for (int64_t c = 0; c <= N; ++c) h_ptr[c] = indptr_is_i64 ? ((const int64_t*)indptr)[c] : (int64_t)((const int32_t*)indptr)[c];
+  bool mono = h_ptr[0] == 0;
+  for (int64_t c = 0; c < N && mono; ++c) mono = h_ptr[c + 1] >= h_ptr[c];
+  const int64_t nnz = h_ptr[N];
+  if (!mono) { (void)hipHostFree(h_ptr); GFICF_FAIL(GFICF_ERR_BAD_CSC, "indptr does not start at 0 or is not monotone"); }
+  if (nnz > 0 && (!indices || !x)) { (void)hipHostFree(h_ptr); GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer"); }
+  const size_t nsz = (size_t)(nnz > 0 ? nnz : 1), wsb = gficf_louvain_workspace_bytes(N, nnz);
+  int64_t* d_ptr = nullptr; int32_t *d_idx = nullptr, *d_lab = nullptr; double* d_x = nullptr; void* d_ws = nullptr;
+  hipError_t e = hipMalloc((void**)&d_ptr, sizeof(int64_t) * ((size_t)N + 1));
+  if (e == hipSuccess) e = hipMalloc((void**)&d_idx, sizeof(int32_t) * nsz);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_x, sizeof(double) * nsz);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_lab, sizeof(int32_t) * (size_t)N);
+  if (e == hipSuccess) e = hipMalloc(&d_ws, wsb);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ptr, h_ptr, sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
+  int rc = GFICF_OK;
+  if (e == hipSuccess) {
+    rc = gficf_louvain_device(ctx, N, d_ptr, d_idx, d_x, nnz, resolution, n_iter, d_lab, n_clusters, modularity, d_ws, wsb);
+    if (!rc) e = hipMemcpyAsync(labels, d_lab, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
+    else (void)hipStreamSynchronize(ctx->stream);
+  }
+  void* ptrs[] = {d_ptr, d_idx, d_x, d_lab, d_ws};
+  for (void* q : ptrs) if (q) (void)hipFree(q);
+  (void)hipHostFree(h_ptr);
+  if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_louvain_host: %s", hipGetErrorString(e));
+  return rc;
+}
+
+}  // extern "C"

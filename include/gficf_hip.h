@@ -274,6 +274,29 @@ int gficf_csc_transpose_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* c
                              int colptr_is_i64, const int32_t* rowidx, const double* x,
                              int64_t* out_ptr, int32_t* out_idx, double* out_x);
 
+/* ------------------------------------------------------------------- community detection (Louvain)
+ * "Next" row N4: RunModularityClustering(adjacency, 1, resolution, 1, n.start, n.iter, seed, verbose)
+ * (R/clustCells.R:80,86 -> src/RModularityOptimizer.cpp:25-181 -> src/ModularityOptimizer.cpp:594-612) on the
+ * symmetric weighted adjacency matrix that gficf_adjacency_* produce (CSC == CSR; the diagonal is ignored, as the
+ * reference driver does).  RELAXED CONTRACT: the reference moves vertices one at a time in a seeded random order;
+ * this is a deterministic parallel Louvain on the same objective,
+ *   Q = (1/2W) * [ sum_ij A_ij delta(c_i, c_j) - resolution * sum_c K_c^2 / 2W ]   (calcQualityFunction, :461-482),
+ * whose modularity is tested to lie within a stated tolerance of the reference's own, not label-for-label parity.
+ * labels[v] in [0, *n_clusters), clusters numbered by decreasing size, ties by first vertex order
+ * (Clustering::orderClustersByNNodes, :132-158); *modularity = Q of the returned labels.  n_iter >= 1 is the
+ * reference's nIterations (a further pass restarts from the labels found so far and stops when nothing moves);
+ * there are no random starts.  The call synchronises the stream several times (an iterative algorithm).
+ * Edge weights must be finite and in [0, 2^20]; a vertex adjacent to more than 8192 communities at once is
+ * GFICF_ERR_UNSUPPORTED. */
+size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz);
+int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, const int32_t* d_indices,
+                         const double* d_x, int64_t nnz, double resolution, int n_iter,
+                         int32_t* d_labels, int64_t* n_clusters, double* modularity, void* d_ws,
+                         size_t ws_bytes);
+int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr_is_i64,
+                       const int32_t* indices, const double* x, double resolution, int n_iter,
+                       int32_t* labels, int64_t* n_clusters, double* modularity);
+
 /* ------------------------------------------------------------------- exact kNN search
  * "Next" row N2: the caller's step in front of the Jaccard build,
  *   neigh = uwot:::find_nn(data$pca$cells, k = k+1, include_self = T, method = "annoy",

@@ -37,6 +37,49 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+REFERENCE_ROOT = "/root/reference"
+_REF_LOUVAIN = os.path.join(_HERE, "_ref", "modularity_optimizer")
+
+
+def build_ref() -> str | None:
+    """oracle/_ref/modularity_optimizer: the reference's own src/ModularityOptimizer.cpp compiled with -DSTANDALONE
+    (``make -C oracle ref``).  Built only where /root/reference exists (the container); the GPU box uses the file that
+    travelled with the snapshot.  Returns the path, or None when there is neither a source tree nor a built file."""
+    src = os.path.join(REFERENCE_ROOT, "src", "ModularityOptimizer.cpp")
+    if os.path.exists(src):
+        subprocess.check_call(["make", "-C", _HERE, "ref", f"REFERENCE={REFERENCE_ROOT}"])
+    return _REF_LOUVAIN if os.path.exists(_REF_LOUVAIN) else None
+
+
+def modularity_reference(A, resolution: float = 0.8, algorithm: int = 1, n_start: int = 10, n_iter: int = 10, seed: int = 0):
+    """Runs the REFERENCE's modularity optimiser (oracle/_ref/modularity_optimizer, built from
+    /root/reference/src/ModularityOptimizer.cpp) on the symmetric adjacency matrix ``A`` exactly as
+    RunModularityClusteringCpp feeds it (src/RModularityOptimizer.cpp:66-84: strict lower triangle, node1 = column,
+    node2 = row).  Returns (labels int32[N] ordered by decreasing cluster size, modularity as printed, 4 decimals)."""
+    import re
+    import tempfile
+
+    import scipy.sparse as sp
+
+    exe = _REF_LOUVAIN if os.path.exists(_REF_LOUVAIN) else build_ref()
+    if exe is None:
+        raise FileNotFoundError("oracle/_ref/modularity_optimizer is not built and /root/reference is absent")
+    L = sp.tril(sp.csc_matrix(A), k=-1).tocoo()
+    N = A.shape[0]
+    if L.nnz == 0 or max(L.row.max(), L.col.max()) != N - 1:
+        raise ValueError("the reference sizes the network by its largest vertex id: the last vertex needs an edge")
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "edges.txt"), os.path.join(d, "clusters.txt")
+        with open(fin, "w") as f:
+            for c, r, v in zip(L.col.tolist(), L.row.tolist(), L.data.tolist()):
+                f.write(f"{c}\t{r}\t{v!r}\n")
+        out = subprocess.run([exe, fin, fout, "1", repr(float(resolution)), str(int(algorithm)), str(int(n_start)), str(int(n_iter)),
+                              str(int(seed)), "1"], check=True, capture_output=True, text=True).stdout
+        labels = np.loadtxt(fout, dtype=np.int64).astype(np.int32).reshape(-1)
+    m = re.findall(r"(?:^|\n)(?:Modularity|Maximum modularity in \d+ random starts): (-?[0-9.]+)", out)
+    return labels, float(m[-1]) if m else float("nan")        # the last line printed is the final value
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:

@@ -158,6 +158,23 @@ def transpose_np(G, N, colptr, rowidx, x):
     return ptr, cell[order], np.asarray(x, dtype=np.float64)[order]
 
 
+def modularity_np(A, labels, resolution: float = 1.0) -> float:
+    """VOSClusteringTechnique::calcQualityFunction (src/ModularityOptimizer.cpp:461-482) for modularityFunction = 1 on the
+    network RunModularityClusteringCpp builds (diagonal dropped, src/RModularityOptimizer.cpp:73-75; node weight = the
+    vertex's total edge weight, :185; resolution2 = resolution / 2W, :100):
+        Q = ( sum_{ij, c_i = c_j} A_ij  -  resolution * sum_c K_c^2 / 2W ) / 2W."""
+    A = sp.csr_matrix(A).astype(np.float64).copy()
+    A.setdiag(0.0)
+    A.eliminate_zeros()
+    lab = np.asarray(labels)
+    k = np.asarray(A.sum(axis=1)).ravel()
+    two_w = k.sum()
+    coo = A.tocoo()
+    inside = coo.data[lab[coo.row] == lab[coo.col]].sum()
+    K = np.bincount(lab, weights=k)
+    return float((inside - resolution * (K * K).sum() / two_w) / two_w)
+
+
 def jaccard_coeff_np(mat: np.ndarray) -> np.ndarray:
     """The serial entry (src/jaccard_coeff.cpp:19-44) through numpy set algebra: u = |unique(row i) ∩ unique(row kk)|
     (``Rcpp::intersect``, :33), rows with u > 0 packed from the top (:34-39)."""

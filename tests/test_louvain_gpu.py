@@ -1,0 +1,139 @@
+"""Scope row N4: community detection on the Jaccard graph — RunModularityClustering(adjacency, 1, resolution, 1, ...)
+(reference R/clustCells.R:80,86 -> src/RModularityOptimizer.cpp:25 -> src/ModularityOptimizer.cpp:594-612).
+
+RELAXED CONTRACT, stated here as include/gficf_hip.h states it: the reference is sequential and seed-exact, the device
+form is a deterministic parallel Louvain on the SAME objective.  What is tested:
+  * against the reference's own outputs (tests/golden/louvain_cases.npz, made by running a build of the reference's
+    src/ModularityOptimizer.cpp; and the same binary live, oracle/_ref/, when it is there): modularity not more than
+    Q_TOL below the reference's, the same partition where the structure is unambiguous (planted partitions);
+  * the modularity the call reports == the restated quality function (oracle_np.modularity_np, itself pinned to the
+    reference's print-out) of the labels it returns, to 1e-9;
+  * label conventions (0-based, clusters by decreasing size), bit-reproducibility, the resolution parameter, edge cases."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import gficf_amd
+import oracle
+from oracle import oracle_np
+
+pytestmark = pytest.mark.gpu
+
+Q_TOL = 0.005          # device modularity >= reference modularity - Q_TOL (observed: within 0.0013, often above)
+
+
+def golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "louvain_cases.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    for n in names:
+        N = len(z[n + "/indptr"]) - 1
+        A = sp.csc_matrix((z[n + "/data"], z[n + "/indices"], z[n + "/indptr"]), shape=(N, N))
+        yield n, A, z[n + "/params"], z[n + "/labels"], float(z[n + "/printed_q"][0])
+
+
+def same_partition(a, b):
+    pairs = np.unique(np.stack([a, b], axis=1), axis=0)
+    return len(pairs) == len(np.unique(a)) == len(np.unique(b))
+
+
+def check_labels(A, lab, res):
+    N = A.shape[0]
+    assert lab.shape == (N,) and lab.dtype == np.int32 and lab.min() == 0 and lab.max() == lab.n_clusters - 1
+    sizes = np.bincount(lab, minlength=lab.n_clusters)
+    assert (sizes > 0).all() and (np.diff(sizes) <= 0).all()                 # orderClustersByNNodes
+    assert abs(lab.modularity - oracle_np.modularity_np(A, lab, res)) < 1e-9
+
+
+def test_against_reference_outputs(golden_dir):
+    seen = 0
+    for name, A, (res, alg, n_start, n_iter, seed), ref_labels, printed in golden(golden_dir):
+        q_ref = oracle_np.modularity_np(A, ref_labels, res)
+        assert abs(q_ref - printed) < 6e-5                                    # the restatement vs the reference's print-out
+        lab = gficf_amd.run_modularity_clustering(A, 1, res, int(alg), int(n_start), int(n_iter), int(seed), False)
+        check_labels(A, lab, res)
+        assert lab.modularity >= q_ref - Q_TOL, (name, lab.modularity, q_ref)
+        if name.startswith("planted") or name == "knn_blobs":
+            assert same_partition(lab, ref_labels), name                     # unambiguous structure: the same clusters
+            assert np.array_equal(np.bincount(lab), np.bincount(ref_labels))
+        seen += 1
+    assert seen == 4
+
+
+def knn_graph(N, d, k, C, seed, spread=3.0):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(C, d))[rng.integers(0, C, N)] * spread + rng.normal(size=(N, d))
+    edges = gficf_amd.clustcells_graph(X, k, "manhattan")
+    return gficf_amd.jaccard_adjacency(edges, N)
+
+
+@pytest.mark.parametrize("N,d,k,C,res", [(6000, 15, 15, 12, 0.8), (20000, 20, 30, 1, 0.8), (8000, 10, 50, 1, 1.0), (12000, 8, 10, 3, 2.0)])
+def test_live_against_the_reference_binary(N, d, k, C, res):
+    """The full chain on the device (kNN -> Jaccard -> filter -> adjacency -> Louvain) against the reference's optimiser run
+    on the same adjacency matrix.  k = 50 and the structureless cases give vertices of degree > 128 (workgroup path)."""
+    if oracle.build_ref() is None:
+        pytest.skip("oracle/_ref/modularity_optimizer neither built nor buildable here")
+    A = knn_graph(N, d, k, C, seed=N + k)
+    lab = gficf_amd.run_modularity_clustering(A, 1, res, 1, 1, 10, 0, False)
+    check_labels(A, lab, res)
+    ref_labels, printed = oracle.modularity_reference(A, res, 1, 1, 10, 0)
+    q_ref = oracle_np.modularity_np(A, ref_labels, res)
+    assert abs(q_ref - printed) < 6e-5
+    assert lab.modularity >= q_ref - Q_TOL, (lab.modularity, q_ref)
+    assert 0.5 * (ref_labels.max() + 1) <= lab.n_clusters <= 2 * (ref_labels.max() + 1)
+    again = gficf_amd.run_modularity_clustering(A, 1, res, 1, 1, 10, 0, False)
+    assert np.array_equal(lab, again) and lab.modularity == again.modularity    # bit-reproducible
+
+
+def test_resolution_and_iterations():
+    A = knn_graph(5000, 10, 15, 1, seed=11)
+    coarse = gficf_amd.run_modularity_clustering(A, 1, 0.3, 1, 1, 10, 0, False)
+    fine = gficf_amd.run_modularity_clustering(A, 1, 3.0, 1, 1, 10, 0, False)
+    assert coarse.n_clusters < fine.n_clusters
+    one = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 1, 1, 0, False)
+    ten = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 1, 10, 0, False)
+    assert ten.modularity >= one.modularity - 1e-12                            # further passes never lose quality
+    for lab, res in ((coarse, 0.3), (fine, 3.0), (one, 1.0), (ten, 1.0)):
+        check_labels(A, lab, res)
+
+
+def test_device_resident_chain_and_edge_cases():
+    import torch
+
+    ops = gficf_amd.HipOps(0)
+    A = knn_graph(4000, 10, 15, 6, seed=5)
+    dev = "cuda:0"
+    ptr = torch.from_numpy(A.indptr.astype(np.int64)).to(dev)
+    idx = torch.from_numpy(A.indices.astype(np.int32)).to(dev)
+    x = torch.from_numpy(A.data).to(dev)
+    ws = torch.zeros(ops.louvain_workspace_bytes(A.shape[0], A.nnz), dtype=torch.uint8, device=dev)
+    lab = torch.zeros(A.shape[0], dtype=torch.int32, device=dev)
+    nc, q = ops.louvain(A.shape[0], ptr, idx, x, 0.8, 10, lab, ws)
+    host = gficf_amd.run_modularity_clustering(A, 1, 0.8, 1, 1, 10, 0, False)
+    assert nc == host.n_clusters and q == host.modularity and np.array_equal(lab.cpu().numpy(), host)
+    # the diagonal is ignored (src/RModularityOptimizer.cpp:73-75)
+    B = (A + sp.identity(A.shape[0], format="csc") * 0.5).tocsc()
+    B.sort_indices()
+    with_diag = gficf_amd.run_modularity_clustering(B, 1, 0.8, 1, 1, 10, 0, False)
+    assert np.array_equal(with_diag, host)
+    # no edges: every vertex alone; two components: two clusters
+    empty = gficf_amd.run_modularity_clustering(sp.csc_matrix((7, 7)), 1, 1.0, 1, 1, 1, 0, False)
+    assert empty.n_clusters == 7 and sorted(empty.tolist()) == list(range(7)) and empty.modularity == 0.0
+    tri = sp.csc_matrix(np.array([[0, 1, 1, 0, 0], [1, 0, 1, 0, 0], [1, 1, 0, 0, 0], [0, 0, 0, 0, 1], [0, 0, 0, 1, 0]], dtype=float))
+    two = gficf_amd.run_modularity_clustering(tri, 1, 1.0, 1, 1, 10, 0, False)
+    assert two.tolist() == [0, 0, 0, 1, 1] and abs(two.modularity - oracle_np.modularity_np(tri, two, 1.0)) < 1e-12
+    # bad input is reported, not followed
+    bad = A.copy()
+    bad.data[3] = np.nan
+    with pytest.raises(gficf_amd.GficfError):
+        gficf_amd.run_modularity_clustering(bad, 1, 0.8, 1, 1, 1, 0, False)
+    bad = A.copy()
+    bad.indices[5] = A.shape[0] + 9
+    bad.has_sorted_indices = True
+    with pytest.raises(gficf_amd.GficfError):
+        gficf_amd.run_modularity_clustering(bad, 1, 0.8, 1, 1, 1, 0, False)
+    with pytest.raises(ValueError):
+        gficf_amd.run_modularity_clustering(A, 2, 0.8)
+    with pytest.raises(ValueError):
+        gficf_amd.run_modularity_clustering(A, 1, 0.8, 3)

@@ -283,3 +283,34 @@ def test_transpose_restatement_matches_scipy():
     ptr, idx, val = oracle_np.transpose_np(4, 3, M.indptr, M.indices, M.data)
     assert ptr.tolist() == [0, 2, 4, 7, 8] and idx.tolist() == [0, 2, 0, 1, 0, 1, 2, 1]
     assert val.tolist() == [1, 3, 1, 2, 2, 2, 1, 4]
+
+
+def test_modularity_restatement_against_reference_outputs(golden_dir):
+    """calcQualityFunction (src/ModularityOptimizer.cpp:461-482) restated in numpy against the modularity the reference
+    itself printed for its own labels (tests/golden/louvain_cases.npz: outputs of a build of the reference's optimiser),
+    and against the binary run live when oracle/_ref holds it."""
+    import os
+
+    import scipy.sparse as sp
+
+    from oracle import oracle_np
+
+    z = np.load(os.path.join(golden_dir, "louvain_cases.npz"))
+    names = sorted({k.split("/")[0] for k in z.files})
+    assert len(names) == 4
+    for n in names:
+        N = len(z[n + "/indptr"]) - 1
+        A = sp.csc_matrix((z[n + "/data"], z[n + "/indices"], z[n + "/indptr"]), shape=(N, N))
+        assert (abs(A - A.T)).nnz == 0
+        res = float(z[n + "/params"][0])
+        labels = z[n + "/labels"]
+        assert abs(oracle_np.modularity_np(A, labels, res) - float(z[n + "/printed_q"][0])) < 6e-5
+        sizes = np.bincount(labels)
+        assert (np.diff(sizes) <= 0).all()                                  # orderClustersByNNodes
+    if oracle.build_ref() is not None:                                      # live: the same numbers again
+        n = "planted3"
+        N = len(z[n + "/indptr"]) - 1
+        A = sp.csc_matrix((z[n + "/data"], z[n + "/indices"], z[n + "/indptr"]), shape=(N, N))
+        res, alg, n_start, n_iter, seed = z[n + "/params"]
+        labels, q = oracle.modularity_reference(A, res, int(alg), int(n_start), int(n_iter), int(seed))
+        assert np.array_equal(labels, z[n + "/labels"]) and q == float(z[n + "/printed_q"][0])
