@@ -46,7 +46,8 @@ typedef unsigned long long u64;
 constexpr double LV_SCALE = 4294967296.0;      // 2^32
 constexpr int LV_SMALL_DEG = 128;              // up to here: one wave per vertex, 256-slot table
 constexpr int LV_SMALL_SLOTS = 256;
-constexpr int LV_BIG_SLOTS = 8192;             // one workgroup per vertex: 32 KB keys + 64 KB sums
+constexpr int LV_MID_DEG = 1024, LV_MID_SLOTS = 2048;   // one workgroup per vertex, 24 KB table
+constexpr int LV_BIG_SLOTS = 8192;             // beyond: 32 KB keys + 64 KB sums
 constexpr int LV_MAX_ITERS = 64;
 
 struct LvGraph {
@@ -95,18 +96,42 @@ __global__ __launch_bounds__(256) void k_lv_vertex_weight(LvGraph g, u64* __rest
   if (threadIdx.x == 0) atomicAdd(two_w, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
 }
 
-// labels given (init == nullptr: singletons) -> community totals and sizes
-__global__ __launch_bounds__(256) void k_lv_init(int64_t n, const int32_t* __restrict__ init, const u64* __restrict__ kv,
-                                                 int32_t* __restrict__ comm, u64* __restrict__ K, int32_t* __restrict__ size) {
+// singletons: every vertex its own community
+__global__ __launch_bounds__(256) void k_lv_init(int64_t n, const u64* __restrict__ kv, int32_t* __restrict__ comm, u64* __restrict__ K,
+                                                 int32_t* __restrict__ size) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v >= n) return;
-  if (!init) {
-    comm[v] = (int32_t)v; K[v] = kv[v]; size[v] = 1;
-  } else {
-    const int32_t c = init[v];
-    comm[v] = c;
-    atomicAdd(&K[c], kv[v]);
-    atomicAdd(&size[c], 1);
+  if (v < n) { comm[v] = (int32_t)v; K[v] = kv[v]; size[v] = 1; }
+}
+
+// Per-label totals (K, may be NULL) and member counts of given labels in [0, C).  With few labels every vertex would
+// hit the same few addresses: up to LV_ACC_BINS labels are binned in LDS first, one global atomic per label and block.
+constexpr int LV_ACC_BINS = 4096;
+__global__ __launch_bounds__(256) void k_lv_accum(int64_t n, int64_t C, const int32_t* __restrict__ lab, const u64* __restrict__ kv,
+                                                  int32_t* __restrict__ comm, u64* __restrict__ K, int32_t* __restrict__ size) {
+  __shared__ u64 s_k[LV_ACC_BINS];
+  __shared__ int32_t s_n[LV_ACC_BINS];
+  const bool binned = C <= LV_ACC_BINS;
+  if (binned) {
+    for (int t = threadIdx.x; t < C; t += 256) { s_k[t] = 0ull; s_n[t] = 0; }
+    __syncthreads();
+  }
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (int64_t)gridDim.x * 256) {
+    const int32_t c = lab[v];
+    if (comm) comm[v] = c;
+    if (binned) {
+      if (K) atomicAdd(&s_k[c], kv[v]);
+      atomicAdd(&s_n[c], 1);
+    } else {
+      if (K) atomicAdd(&K[c], kv[v]);
+      atomicAdd(&size[c], 1);
+    }
+  }
+  if (binned) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < C; t += 256) {
+      if (s_n[t]) atomicAdd(&size[t], s_n[t]);
+      if (K && s_k[t]) atomicAdd(&K[t], s_k[t]);
+    }
   }
 }
 
@@ -178,33 +203,34 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvGraph g, LvMove mv, con
   }
 }
 
-// One workgroup per listed vertex (degree > LV_SMALL_DEG).
+// One workgroup per listed vertex (degree > LV_SMALL_DEG): SLOTS = 2048 up to LV_MID_DEG neighbours, 8192 beyond.
+template <int SLOTS>
 __global__ __launch_bounds__(256) void k_lv_move_big(LvGraph g, LvMove mv, const int32_t* __restrict__ big, const int32_t* __restrict__ comm,
                                                      const u64* __restrict__ K, const int32_t* __restrict__ size,
                                                      int32_t* __restrict__ next, unsigned* __restrict__ moved,
                                                      uint32_t* __restrict__ status) {
   extern __shared__ unsigned char s_raw[];
   u64* val = (u64*)s_raw;
-  int32_t* key = (int32_t*)(val + LV_BIG_SLOTS);
+  int32_t* key = (int32_t*)(val + SLOTS);
   __shared__ double s_g[256], s_w[4];
   __shared__ int32_t s_c[256];
   const int tid = threadIdx.x;
   const int64_t v = big[blockIdx.x];
   if (mv.S != 1 && (int)(lv_hash((uint32_t)v) % (uint32_t)mv.S) != mv.s) return;     // uniform per workgroup
-  for (int t = tid; t < LV_BIG_SLOTS; t += 256) { key[t] = -1; val[t] = 0ull; }
+  for (int t = tid; t < SLOTS; t += 256) { key[t] = -1; val[t] = 0ull; }
   __syncthreads();
   const int64_t lo = g.ptr[v], hi = g.ptr[v + 1];
   for (int64_t e = lo + tid; e < hi; e += 256) {
     const int32_t u = g.nbr[e];
     if (u == v) continue;
     const int32_t c = comm[u];
-    uint32_t h = lv_hash((uint32_t)c) & (LV_BIG_SLOTS - 1);
+    uint32_t h = lv_hash((uint32_t)c) & (SLOTS - 1);
     int probes = 0;
     for (;;) {
       const int32_t old = atomicCAS(&key[h], -1, c);
       if (old == -1 || old == c) { atomicAdd(&val[h], g.wt[e]); break; }
-      h = (h + 1) & (LV_BIG_SLOTS - 1);
-      if (++probes >= LV_BIG_SLOTS) { atomicOr(status, GFICF_ST_TOO_DENSE); break; }   // more communities than slots
+      h = (h + 1) & (SLOTS - 1);
+      if (++probes >= SLOTS) { atomicOr(status, GFICF_ST_TOO_DENSE); break; }   // more communities than slots
     }
   }
   __syncthreads();
@@ -212,7 +238,7 @@ __global__ __launch_bounds__(256) void k_lv_move_big(LvGraph g, LvMove mv, const
   const double kvd = (double)g.kv[v];
   double bg = -INFINITY, stay_w = 0.0;
   int32_t bc = INT32_MAX;
-  for (int t = tid; t < LV_BIG_SLOTS; t += 256) {
+  for (int t = tid; t < SLOTS; t += 256) {
     const int32_t c = key[t];
     if (c < 0) continue;
     const double w = (double)val[t];
@@ -239,9 +265,13 @@ __global__ __launch_bounds__(256) void k_lv_move_big(LvGraph g, LvMove mv, const
   }
 }
 
-__global__ __launch_bounds__(256) void k_lv_list_big(LvGraph g, int32_t* __restrict__ big, unsigned* __restrict__ n_big) {
+// the vertices of the workgroup path: middle degrees from the front of the list, large ones from its end
+__global__ __launch_bounds__(256) void k_lv_list_big(LvGraph g, int32_t* __restrict__ big, unsigned* __restrict__ n_mid_large) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v < g.n && g.ptr[v + 1] - g.ptr[v] > LV_SMALL_DEG) big[atomicAdd(n_big, 1u)] = (int32_t)v;
+  if (v >= g.n) return;
+  const int64_t deg = g.ptr[v + 1] - g.ptr[v];
+  if (deg > LV_MID_DEG) big[g.n - 1 - atomicAdd(n_mid_large + 1, 1u)] = (int32_t)v;
+  else if (deg > LV_SMALL_DEG) big[atomicAdd(n_mid_large, 1u)] = (int32_t)v;
 }
 
 // applies the sub-round's moves to the labels, totals and sizes
@@ -262,10 +292,10 @@ __global__ __launch_bounds__(256) void k_lv_apply(int64_t n, LvMove mv, const u6
 
 // ---- quality: internal weight (integer) and sum of squared totals (fixed summation order)
 __global__ __launch_bounds__(256) void k_lv_internal(LvGraph g, const int32_t* __restrict__ comm, u64* __restrict__ in_w) {
+  __shared__ u64 s_sum[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t v = (int64_t)blockIdx.x * 4 + wave;
   u64 s = 0;
-  if (v < g.n) {
+  for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < g.n; v += (int64_t)gridDim.x * 4) {
     const int32_t cv = comm[v];
     for (int64_t e = g.ptr[v] + lane; e < g.ptr[v + 1]; e += 64) {
       const int32_t u = g.nbr[e];
@@ -273,7 +303,9 @@ __global__ __launch_bounds__(256) void k_lv_internal(LvGraph g, const int32_t* _
     }
   }
   for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
-  if (lane == 0 && s) atomicAdd(in_w, s);
+  if (lane == 0) s_sum[wave] = s;
+  __syncthreads();
+  if (threadIdx.x == 0 && (s_sum[0] | s_sum[1] | s_sum[2] | s_sum[3])) atomicAdd(in_w, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
 }
 
 __global__ __launch_bounds__(1024) void k_lv_sumsq(int64_t n, const u64* __restrict__ K, double* __restrict__ out) {
@@ -344,28 +376,35 @@ __global__ __launch_bounds__(256) void k_lv_heads(const u64* __restrict__ keys, 
   flag[e] = f;
 }
 
-// pos = exclusive scan of the head flags: entry e belongs to coarse entry pos[e + 1] - 1
+// pos = exclusive scan of the head flags: entry e belongs to coarse entry pos[e + 1] - 1.  A workgroup takes LV_RED_CHUNK
+// consecutive sorted entries, sums them per coarse entry in LDS (their positions span less than the chunk) and adds
+// each sum once: a graph reduced to a handful of communities would otherwise put millions of atomics on a few addresses.
+constexpr int LV_RED_CHUNK = 4096;
 __global__ __launch_bounds__(256) void k_lv_reduce(const u64* __restrict__ keys, const u64* __restrict__ vals, int64_t m, u64 none,
                                                    const int64_t* __restrict__ pos, int32_t* __restrict__ nbr2, u64* __restrict__ wt2,
                                                    int64_t* __restrict__ row_cnt) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= m) return;
-  const u64 k = keys[e];
-  if (k == none) return;
-  const int64_t p = pos[e + 1] - 1;
-  atomicAdd(&wt2[p], vals[e]);
-  if (pos[e + 1] != pos[e]) {                   // a head
-    nbr2[p] = (int32_t)(k & 0xffffffffull);
-    atomicAdd((u64*)&row_cnt[k >> 32], 1ull);
+  __shared__ u64 s_w[LV_RED_CHUNK];
+  const int64_t e0 = (int64_t)blockIdx.x * LV_RED_CHUNK, e1 = e0 + LV_RED_CHUNK < m ? e0 + LV_RED_CHUNK : m;
+  if (keys[e0] == none) return;                  // the dropped entries sort last: nothing kept in this chunk
+  for (int t = threadIdx.x; t < LV_RED_CHUNK; t += 256) s_w[t] = 0ull;
+  __syncthreads();
+  const int64_t p_lo = pos[e0 + 1] - 1;
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+    const u64 k = keys[e];
+    if (k == none) break;
+    const int64_t p = pos[e + 1] - 1;
+    atomicAdd(&s_w[p - p_lo], vals[e]);
+    if (pos[e + 1] != pos[e]) {                   // a head
+      nbr2[p] = (int32_t)(k & 0xffffffffull);
+      atomicAdd((u64*)&row_cnt[k >> 32], 1ull);
+    }
   }
+  __syncthreads();
+  for (int t = threadIdx.x; t < LV_RED_CHUNK; t += 256)
+    if (s_w[t]) atomicAdd(&wt2[p_lo + t], s_w[t]);
 }
 
 // ---- final numbering: clusters by decreasing size, ties by id (Clustering::orderClustersByNNodes, reference :132-158)
-__global__ __launch_bounds__(256) void k_lv_count(int64_t n, const int32_t* __restrict__ lab, int32_t* __restrict__ cnt) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v < n) atomicAdd(&cnt[lab[v]], 1);
-}
-
 __global__ __launch_bounds__(256) void k_lv_size_keys(int64_t C, int64_t n, const int32_t* __restrict__ cnt, u64* __restrict__ keys,
                                                       u64* __restrict__ ids) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -413,7 +452,7 @@ struct LvWs {
   int64_t* flag;            // max(n, m) + 1 entries: scans
   u64 *keys_a, *vals_a, *keys_b, *vals_b;
   void* sort_tmp; size_t sort_tmp_bytes;
-  u64* scalars;             // [0] 2W, [1] internal weight, [2] moved (unsigned) | n_big, [3] sum of squares (double)
+  u64* scalars;             // [0] 2W, [1] internal weight, [2] moved (unsigned), [3] sum of squares (double), [4] n_mid | n_large
 };
 
 static size_t lv_carve(LvWs* w, void* base, int64_t N, int64_t nnz) {
@@ -450,7 +489,7 @@ struct LvQ { double q; u64 in_w; };
 // Q of the current labels on graph g (self = weight already folded into the vertices), deterministic.
 static int lv_quality(gficf_ctx* ctx, const LvGraph& g, const LvWs& w, u64 self_w, double two_w, double resolution, double* q_out, u64* in_out) {
   GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 1, 0, sizeof(u64), ctx->stream));
-  hipLaunchKernelGGL(k_lv_internal, dim3(lv_blocks(g.n, 4)), dim3(256), 0, ctx->stream, g, w.comm, w.scalars + 1);
+  hipLaunchKernelGGL(k_lv_internal, dim3(lv_blocks(g.n, 4) < 2048u ? lv_blocks(g.n, 4) : 2048u), dim3(256), 0, ctx->stream, g, w.comm, w.scalars + 1);
   hipLaunchKernelGGL(k_lv_sumsq, dim3(1), dim3(1024), 0, ctx->stream, g.n, w.K, (double*)(w.scalars + 3));
   u64 h[4];
   GFICF_HIP_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -485,7 +524,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "workspace too small: %zu < %zu bytes", ws_bytes, gficf_louvain_workspace_bytes(N, nnz));
   static bool attr_set = false;
   if (!attr_set) {
-    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_lv_move_big, hipFuncAttributeMaxDynamicSharedMemorySize, LV_BIG_SLOTS * 12));
+    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_lv_move_big<LV_BIG_SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_BIG_SLOTS * 12));
     attr_set = true;
   }
   LvWs w;
@@ -503,7 +542,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   if (rc) return rc;
   const double two_w = (double)two_w_fix;
   if (two_w_fix == 0) {                            // no edges: every vertex is its own cluster, Q = 0
-    hipLaunchKernelGGL(k_lv_init, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, (const int32_t*)nullptr, w.kv0, d_labels, w.K, w.size);
+    hipLaunchKernelGGL(k_lv_init, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, w.kv0, d_labels, w.K, w.size);
     GFICF_HIP_CHECK(hipStreamSynchronize(st));
     if (n_clusters) *n_clusters = N;
     return GFICF_OK;
@@ -511,6 +550,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   const double r = resolution / two_w;
   double q_final = 0.0;
   bool have_labels = false;
+  int64_t n_labels = 0;                          // labels of the previous pass lie in [0, n_labels)
 
   for (int pass = 0; pass < n_iter; ++pass) {
     LvGraph g = g0;
@@ -522,17 +562,19 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
       if (seeded) {
         GFICF_HIP_CHECK(hipMemsetAsync(w.K, 0, sizeof(u64) * (size_t)g.n, st));
         GFICF_HIP_CHECK(hipMemsetAsync(w.size, 0, sizeof(int32_t) * (size_t)g.n, st));
+        hipLaunchKernelGGL(k_lv_accum, dim3(lv_blocks(g.n, 256) < 1024u ? lv_blocks(g.n, 256) : 1024u), dim3(256), 0, st, g.n, n_labels, w.lab, g.kv,
+                           w.comm, w.K, w.size);
+      } else {
+        hipLaunchKernelGGL(k_lv_init, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, g.kv, w.comm, w.K, w.size);
       }
-      hipLaunchKernelGGL(k_lv_init, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, seeded ? (const int32_t*)w.lab : (const int32_t*)nullptr,
-                         g.kv, w.comm, w.K, w.size);
-      GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 2, 0, sizeof(u64), st));
-      hipLaunchKernelGGL(k_lv_list_big, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g, w.big, ((unsigned*)(w.scalars + 2)) + 1);
-      unsigned h_cnt[2] = {0, 0};
-      GFICF_HIP_CHECK(hipMemcpyAsync(h_cnt, w.scalars + 2, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+      GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(u64), st));
+      hipLaunchKernelGGL(k_lv_list_big, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g, w.big, (unsigned*)(w.scalars + 4));
+      unsigned h_cnt[2] = {0, 0};                  // vertices of middle and of large degree
+      GFICF_HIP_CHECK(hipMemcpyAsync(h_cnt, w.scalars + 4, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
       double q_prev; u64 in_w;
       rc = lv_quality(ctx, g, w, self_w, two_w, resolution, &q_prev, &in_w);
       if (rc) return rc;
-      const unsigned n_big = h_cnt[1];
+      const unsigned n_mid = h_cnt[0], n_large = h_cnt[1];
       const int S = lv_sub_rounds(g.n);
 
       // ---- local moving
@@ -545,9 +587,12 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
         for (int s = 0; s < S; ++s) {
           const LvMove mv{r, s, S};
           hipLaunchKernelGGL(k_lv_move_small, dim3(lv_blocks(g.n, 4)), dim3(256), 0, st, g, mv, w.comm, w.K, w.size, w.next, (unsigned*)(w.scalars + 2));
-          if (n_big)
-            hipLaunchKernelGGL(k_lv_move_big, dim3(n_big), dim3(256), LV_BIG_SLOTS * 12, st, g, mv, w.big, w.comm, w.K, w.size, w.next,
+          if (n_mid)
+            hipLaunchKernelGGL(k_lv_move_big<LV_MID_SLOTS>, dim3(n_mid), dim3(256), LV_MID_SLOTS * 12, st, g, mv, w.big, w.comm, w.K, w.size, w.next,
                                (unsigned*)(w.scalars + 2), ctx->d_status);
+          if (n_large)
+            hipLaunchKernelGGL(k_lv_move_big<LV_BIG_SLOTS>, dim3(n_large), dim3(256), LV_BIG_SLOTS * 12, st, g, mv, w.big + (g.n - n_large), w.comm,
+                               w.K, w.size, w.next, (unsigned*)(w.scalars + 2), ctx->d_status);
           hipLaunchKernelGGL(k_lv_apply, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, mv, g.kv, w.comm, w.next, w.K, w.size);
         }
         unsigned moved = 0;
@@ -583,6 +628,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
       have_labels = true;
       if (n2 == g.n || n2 <= 1 || (!level_moved && !(seeded && n2 < g.n))) {
         if (n_clusters) *n_clusters = n2;
+        n_labels = n2;
         break;                                     // nothing merged: this pass is done
       }
 
@@ -604,7 +650,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
         GFICF_HIP_CHECK(hipStreamSynchronize(st));
         GFICF_HIP_CHECK(hipMemsetAsync(nl.wt, 0, sizeof(u64) * (size_t)(m2 > 0 ? m2 : 1), st));
         GFICF_HIP_CHECK(hipMemsetAsync(nl.ptr, 0, sizeof(int64_t) * (size_t)(n2 + 1), st));
-        hipLaunchKernelGGL(k_lv_reduce, dim3(lv_blocks(g.m, 256)), dim3(256), 0, st, w.keys_b, w.vals_b, g.m, none, w.flag, nl.nbr, nl.wt, nl.ptr);
+        hipLaunchKernelGGL(k_lv_reduce, dim3(lv_blocks(g.m, LV_RED_CHUNK)), dim3(256), 0, st, w.keys_b, w.vals_b, g.m, none, w.flag, nl.nbr, nl.wt, nl.ptr);
         rc = gficf_exclusive_scan_i64(ctx, nl.ptr, n2 + 1);
         if (rc) return rc;
       } else {
@@ -620,7 +666,8 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   int64_t C = n_clusters ? *n_clusters : 0;
   if (!n_clusters) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "n_clusters is NULL");
   GFICF_HIP_CHECK(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * (size_t)C, st));
-  hipLaunchKernelGGL(k_lv_count, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, w.lab, w.cnt);
+  hipLaunchKernelGGL(k_lv_accum, dim3(lv_blocks(N, 256) < 1024u ? lv_blocks(N, 256) : 1024u), dim3(256), 0, st, N, C, w.lab, (const u64*)nullptr,
+                     (int32_t*)nullptr, (u64*)nullptr, w.cnt);
   hipLaunchKernelGGL(k_lv_size_keys, dim3(lv_blocks(C, 256)), dim3(256), 0, st, C, N, w.cnt, w.keys_a, w.vals_a);
   size_t tb = w.sort_tmp_bytes;
   GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys_a, w.keys_b, w.vals_a, w.vals_b, (size_t)C, 0u, 64u, st));
