@@ -71,3 +71,17 @@ transpose_hip = function(M)
   r = .Call(`_gficf_transpose_csc`, M@i, M@p, M@x, M@Dim)
   Matrix::sparseMatrix(i = r[[1]], p = r[[2]], x = r[[3]], index1 = FALSE, dims = rev(M@Dim), dimnames = rev(M@Dimnames))
 }
+
+# Optional (N4): community detection.  Same arguments as the reference's RunModularityClustering (R/clustCells.R:145-149); in
+# clustcells() the calls at R/clustCells.R:80 and :86 become
+#   community <- RunModularityClusteringHip(igraph::as_adjacency_matrix(g, attr = "weight", sparse = T), 1, resolution, 1, n.start, n.iter, seed, verbose)
+# (or with jaccard_adjacency_hip(relations, n) as the matrix).  A deterministic parallel Louvain on the same modularity
+# (resolution as in the reference, diagonal ignored): labels are NOT those of the seeded sequential optimiser, the
+# modularity is (tested) within 0.005 of it.  n.start and random.seed are accepted and have no effect.
+RunModularityClusteringHip <- function(SNN = matrix(), modularity = 1, resolution = 0.8, algorithm = 1, n.start = 10, n.iter = 10,
+                                       random.seed = 0, print.output = TRUE, temp.file.location = NULL, edge.file.name = "")
+{
+  SNN = methods::as(SNN, "CsparseMatrix")
+  .Call(`_gficf_RunModularityClusteringHip`, SNN, as.integer(modularity), resolution, as.integer(algorithm), as.integer(n.start),
+        as.integer(n.iter), as.integer(random.seed), print.output, edge.file.name)
+}

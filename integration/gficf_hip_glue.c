@@ -20,6 +20,10 @@
  *   _gficf_jaccard_adjacency(from, to, weight, n)        — NEW, optional: igraph::as_adjacency_matrix (R/clustCells.R:80,86).
  *   _gficf_cluster_signatures(i, p, x, dim, cluster, C)  — NEW, optional: data$cluster.gene.rnk (R/clustCells.R:121-123).
  *   _gficf_transpose_csc(i, p, x, dim)                   — NEW, optional: t(data$gficf) (R/dimensinalityReduction.R:33,100).
+ *   _gficf_RunModularityClusteringHip(SNN, ...9 args)    — OPTIONAL, same arguments as the reference's
+ *       _gficf_RunModularityClusteringCpp (src/RcppExports.cpp:17): the deterministic parallel Louvain.  NOT registered
+ *       under the reference's name: its results differ from the seeded sequential optimiser (same objective, see
+ *       include/gficf_hip.h), so the switch is an explicit choice in R/clustCells.R:80,86, not a silent replacement.
  */
 #include <R.h>
 #include <Rinternals.h>
@@ -176,6 +180,39 @@ SEXP _gficf_transpose_csc(SEXP iS, SEXP pS, SEXP xS, SEXP dimS) {
   return out;
 }
 
+/* Optional: community detection on the adjacency matrix, argument list of RunModularityClusteringCpp
+ * (reference src/RModularityOptimizer.cpp:25-33).  SNN: a dgCMatrix (symmetric).  nRandomStarts and randomSeed have nothing to act
+ * on (the device algorithm is deterministic); an edge file is not read.  Returns the 0-based cluster of every vertex, clusters by
+ * decreasing size, as the reference does (:171-173). */
+SEXP _gficf_RunModularityClusteringHip(SEXP SNN, SEXP modularityFunctionS, SEXP resolutionS, SEXP algorithmS, SEXP nRandomStartsS,
+                                       SEXP nIterationsS, SEXP randomSeedS, SEXP printOutputS, SEXP edgefilenameS) {
+  (void)nRandomStartsS; (void)randomSeedS;
+  if (Rf_asInteger(modularityFunctionS) != 1) Rf_error("Modularity parameter must be equal to 1 on this path.");
+  const int algorithm = Rf_asInteger(algorithmS);
+  if (algorithm != 1 && algorithm != 2) Rf_error("Algorithm for modularity optimization must be 1 or 2 on this path");
+  if (Rf_asInteger(nIterationsS) < 1) Rf_error("Need at least one interation");
+  if (Rf_length(edgefilenameS) > 0 && CHAR(STRING_ELT(edgefilenameS, 0))[0] != 0) Rf_error("edge files are not read on this path");
+  SEXP iS = R_do_slot(SNN, Rf_install("i")), pS = R_do_slot(SNN, Rf_install("p")), xS = R_do_slot(SNN, Rf_install("x"));
+  SEXP dimS = R_do_slot(SNN, Rf_install("Dim"));
+  const int64_t N = INTEGER(dimS)[0];
+  if (INTEGER(dimS)[1] != N) Rf_error("SNN must be square");
+  SEXP out = PROTECT(Rf_allocVector(INTSXP, N));
+  int64_t n_clusters = 0;
+  double q = 0.0;
+  if (gficf_louvain_host(ctx_get(), N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(resolutionS), Rf_asInteger(nIterationsS),
+                         INTEGER(out), &n_clusters, &q) != GFICF_OK) {
+    UNPROTECT(1);
+    Rf_error("gficf_hip: %s", gficf_last_error());
+  }
+  if (Rf_asLogical(printOutputS)) {
+    Rprintf("Number of nodes: %d\n", (int)N);
+    Rprintf("Modularity: %.4f\n", q);
+    Rprintf("Number of communities: %d\n", (int)n_clusters);
+  }
+  UNPROTECT(1);
+  return out;
+}
+
 static const R_CallMethodDef HipCallEntries[] = {
     {"_gficf_rcpp_parallel_jaccard_coef", (DL_FUNC)&_gficf_rcpp_parallel_jaccard_coef, 2},
     {"_gficf_jaccard_coeff", (DL_FUNC)&_gficf_jaccard_coeff, 2},
@@ -184,6 +221,7 @@ static const R_CallMethodDef HipCallEntries[] = {
     {"_gficf_jaccard_adjacency", (DL_FUNC)&_gficf_jaccard_adjacency, 4},
     {"_gficf_cluster_signatures", (DL_FUNC)&_gficf_cluster_signatures, 6},
     {"_gficf_transpose_csc", (DL_FUNC)&_gficf_transpose_csc, 4},
+    {"_gficf_RunModularityClusteringHip", (DL_FUNC)&_gficf_RunModularityClusteringHip, 9},
     {NULL, NULL, 0}};
 
 /* Called from the package's R_init_gficf (reference src/RcppExports.cpp:94-97) next to the Rcpp entries:
