@@ -9,6 +9,7 @@ from ._lib import GficfError, LIB_PATH  # noqa: F401
 from .api import (  # noqa: F401
     Context,
     cluster_signatures,
+    clustcells,
     clustcells_graph,
     find_nn,
     HipOps,

@@ -420,6 +420,55 @@ def clustcells_graph(X, k: int = 15, dist_method: str = "manhattan", verbose: bo
     return jaccard_edges(neigh, verbose, ctx)
 
 
+COMMUNITY_ALGOS = ("louvian", "louvian 2", "louvian 3")
+
+
+def clustcells(data: dict, from_embedded: bool = False, k: int = 15, dist_method: str = "manhattan", nt: int = 2,
+               community_algo: str = "louvian", store_graph: bool = True, seed: int = 180582, verbose: bool = True,
+               resolution: float = 0.8, n_start: int = 10, n_iter: int = 10, ctx: Context | None = None) -> dict:
+    """``clustcells(data, from.embedded, k, dist.method, nt, community.algo, store.graph, seed, verbose, resolution,
+    n.start, n.iter)`` of the reference (R/clustCells.R:46-126) with every step on the device: neighbour search (:57,60,
+    exact instead of Annoy), ``neigh[,-1]`` + Jaccard edges + ``weight > 0`` (:63-68), adjacency matrix (:69,80),
+    community detection (:72-86, relaxed contract of ``run_modularity_clustering``), cluster signatures (:121-123).
+
+    ``data``: dict with ``"pca": {"cells": N x d}`` (or ``"embedded"``: N x >=2 array when ``from_embedded``) and
+    ``"gficf"`` (genes x cells CSC).  ``community_algo``: "louvian 2" / "louvian 3" (resolution, n_iter as given) or
+    "louvian" (the reference calls igraph::cluster_louvain there: plain modularity, i.e. resolution 1); the igraph /
+    leidenalg algorithms ("walktrap", "fastgreedy", "leiden") are third-party and not provided.  ``nt`` and ``seed`` are
+    accepted for signature compatibility (no CPU threads, nothing random).  Returns ``data`` updated with ``community``
+    (1-based like the reference), ``cluster`` (the labels as strings, ``data$embedded$cluster``), ``cluster.gene.rnk``
+    (+ its column labels ``cluster.labels``) and, with ``store_graph``, ``cell.graph`` (the edge columns) and
+    ``cell.adjacency``.
+    """
+    if community_algo not in COMMUNITY_ALGOS:
+        raise ValueError(f"community_algo must be one of {COMMUNITY_ALGOS} (igraph / leidenalg algorithms are not provided)")
+    if from_embedded:
+        if data.get("embedded") is None:
+            raise ValueError("First run runReduction to embed your cells")
+        X = np.asarray(data["embedded"])[:, :2]
+    else:
+        if data.get("pca") is None:
+            raise ValueError("First run runPCA or runLSA to reduce dimensionality")
+        X = np.asarray(data["pca"]["cells"])
+    N = X.shape[0]
+    edges = clustcells_graph(X, k, dist_method, verbose, ctx)
+    A = jaccard_adjacency(edges, N, ctx)
+    if community_algo == "louvian":
+        community = run_modularity_clustering(A, 1, 1.0, 1, 1, n_iter, seed, False, ctx)
+    else:
+        community = run_modularity_clustering(A, 1, resolution, 1 if community_algo == "louvian 2" else 2, n_start, n_iter, seed, verbose, ctx)
+    data["community"] = np.asarray(community, dtype=np.int32) + 1
+    data["modularity"] = community.modularity
+    data["cluster"] = data["community"].astype(str)
+    if store_graph:
+        data["cell.graph"], data["cell.adjacency"] = edges, A
+    if data.get("gficf") is not None:
+        data["cluster.gene.rnk"], data["cluster.labels"] = cluster_signatures(data["gficf"], data["cluster"], ctx)
+    if verbose:
+        print(f"Detected Clusters: {community.n_clusters}")
+    return data
+
+
 # ----------------------------------------------------------- device-resident stage ops
 def genes_words(G: int) -> int:
     """float64 elements of the opaque per-gene table buffer (gficf_csc_genes_bytes)."""

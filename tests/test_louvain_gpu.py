@@ -137,3 +137,29 @@ def test_device_resident_chain_and_edge_cases():
         gficf_amd.run_modularity_clustering(A, 2, 0.8)
     with pytest.raises(ValueError):
         gficf_amd.run_modularity_clustering(A, 1, 0.8, 3)
+
+
+def test_clustcells_end_to_end():
+    """clustcells() (R/clustCells.R:46-126) in one call: planted cell types come back as the clusters, the signatures are the
+    per-cluster gene sums of the GF-ICF matrix."""
+    from gficf_amd import synth
+
+    rng = np.random.default_rng(8)
+    N, C, d, G = 3000, 5, 12, 400
+    truth = rng.integers(0, C, N)
+    X = rng.normal(size=(C, d))[truth] * 6.0 + rng.normal(size=(N, d))
+    cp, ri, x = synth.counts_csc(G, N, seed=3)
+    M = sp.csc_matrix((x, ri, cp), shape=(G, N))
+    for algo in ("louvian", "louvian 2", "louvian 3"):
+        data = gficf_amd.clustcells({"pca": {"cells": X}, "gficf": M}, k=15, community_algo=algo, verbose=False)
+        assert same_partition(data["community"], truth) and data["community"].min() == 1
+        sig, labels = data["cluster.gene.rnk"], data["cluster.labels"]
+        assert sig.shape == (G, C) and sorted(labels) == sorted(str(c) for c in range(1, C + 1))
+        j = list(labels).index(data["cluster"][0])
+        want = np.asarray(M[:, data["cluster"] == data["cluster"][0]].sum(axis=1)).ravel()
+        assert np.allclose(sig[:, j], want, rtol=1e-9, atol=1e-9)
+        assert data["cell.adjacency"].shape == (N, N) and len(data["cell.graph"]["weight"]) > 0
+    with pytest.raises(ValueError):
+        gficf_amd.clustcells({"pca": {"cells": X}}, community_algo="walktrap")
+    with pytest.raises(ValueError):
+        gficf_amd.clustcells({"gficf": M})
