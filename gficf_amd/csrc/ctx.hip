@@ -121,7 +121,7 @@ int gficf_ctx_sync(gficf_ctx* ctx) {
   if (st & GFICF_ST_BAD_CSC)
     GFICF_FAIL(GFICF_ERR_BAD_CSC, "CSC matrix malformed: row index outside [0, G) or colptr not monotone");
   if (st & GFICF_ST_TOO_DENSE)
-    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "Louvain: a vertex is adjacent to more communities than the 8192-slot table holds");
+    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "Louvain: one hash class of a vertex's neighbouring communities overflowed the 8192-slot table");
   return GFICF_OK;
 }
 

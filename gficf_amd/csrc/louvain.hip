@@ -217,34 +217,42 @@ __global__ __launch_bounds__(256) void k_lv_move_big(LvGraph g, LvMove mv, const
   const int tid = threadIdx.x;
   const int64_t v = big[blockIdx.x];
   if (mv.S != 1 && (int)(lv_hash((uint32_t)v) % (uint32_t)mv.S) != mv.s) return;     // uniform per workgroup
-  for (int t = tid; t < SLOTS; t += 256) { key[t] = -1; val[t] = 0ull; }
-  __syncthreads();
   const int64_t lo = g.ptr[v], hi = g.ptr[v + 1];
-  for (int64_t e = lo + tid; e < hi; e += 256) {
-    const int32_t u = g.nbr[e];
-    if (u == v) continue;
-    const int32_t c = comm[u];
-    uint32_t h = lv_hash((uint32_t)c) & (SLOTS - 1);
-    int probes = 0;
-    for (;;) {
-      const int32_t old = atomicCAS(&key[h], -1, c);
-      if (old == -1 || old == c) { atomicAdd(&val[h], g.wt[e]); break; }
-      h = (h + 1) & (SLOTS - 1);
-      if (++probes >= SLOTS) { atomicOr(status, GFICF_ST_TOO_DENSE); break; }   // more communities than slots
-    }
-  }
-  __syncthreads();
   const int32_t cv = comm[v];
   const double kvd = (double)g.kv[v];
   double bg = -INFINITY, stay_w = 0.0;
   int32_t bc = INT32_MAX;
-  for (int t = tid; t < SLOTS; t += 256) {
-    const int32_t c = key[t];
-    if (c < 0) continue;
-    const double w = (double)val[t];
-    if (c == cv) { stay_w = w; continue; }
-    const double gain = w - kvd * (double)K[c] * mv.r;
-    if (lv_better(gain, c, bg, bc)) { bg = gain; bc = c; }
+  // A vertex with more neighbours than the table comfortably holds (every neighbour can be its own community) is done in
+  // P passes over its edges, pass p taking the communities of hash class p: about deg / P <= SLOTS / 2 of them at a time.
+  const uint32_t P = (uint32_t)((hi - lo + SLOTS / 2 - 1) / (SLOTS / 2));
+  for (uint32_t p = 0; p < (P ? P : 1u); ++p) {
+    for (int t = tid; t < SLOTS; t += 256) { key[t] = -1; val[t] = 0ull; }
+    __syncthreads();
+    for (int64_t e = lo + tid; e < hi; e += 256) {
+      const int32_t u = g.nbr[e];
+      if (u == v) continue;
+      const int32_t c = comm[u];
+      const uint32_t hc = lv_hash((uint32_t)c);
+      if (P > 1 && (hc >> 13) % P != p) continue;
+      uint32_t h = hc & (SLOTS - 1);
+      int probes = 0;
+      for (;;) {
+        const int32_t old = atomicCAS(&key[h], -1, c);
+        if (old == -1 || old == c) { atomicAdd(&val[h], g.wt[e]); break; }
+        h = (h + 1) & (SLOTS - 1);
+        if (++probes >= SLOTS) { atomicOr(status, GFICF_ST_TOO_DENSE); break; }   // a hash class that overflows the table
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < SLOTS; t += 256) {
+      const int32_t c = key[t];
+      if (c < 0) continue;
+      const double w = (double)val[t];
+      if (c == cv) { stay_w = w; continue; }
+      const double gain = w - kvd * (double)K[c] * mv.r;
+      if (lv_better(gain, c, bg, bc)) { bg = gain; bc = c; }
+    }
+    __syncthreads();
   }
   for (int d = 32; d > 0; d >>= 1) stay_w = fmax(stay_w, __shfl_xor(stay_w, d));
   if ((tid & 63) == 0) s_w[tid >> 6] = stay_w;

@@ -286,8 +286,8 @@ int gficf_csc_transpose_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* c
  * (Clustering::orderClustersByNNodes, :132-158); *modularity = Q of the returned labels.  n_iter >= 1 is the
  * reference's nIterations (a further pass restarts from the labels found so far and stops when nothing moves);
  * there are no random starts.  The call synchronises the stream several times (an iterative algorithm).
- * Edge weights must be finite and in [0, 2^20]; a vertex adjacent to more than 8192 communities at once is
- * GFICF_ERR_UNSUPPORTED. */
+ * Edge weights must be finite and in [0, 2^20].  GFICF_ERR_UNSUPPORTED only if one hash class of a vertex's neighbouring
+ * communities overflows the 8192-slot table (vertices of any degree are handled in several passes; not observed). */
 size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz);
 int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, const int32_t* d_indices,
                          const double* d_x, int64_t nnz, double resolution, int n_iter,

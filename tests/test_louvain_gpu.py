@@ -86,6 +86,29 @@ def test_live_against_the_reference_binary(N, d, k, C, res):
     assert np.array_equal(lab, again) and lab.modularity == again.modularity    # bit-reproducible
 
 
+def test_hub_vertices_beyond_the_table():
+    """Hubs with 3 000 and 30 000 neighbours, each neighbour its own community at the start: more than the 2048- and the
+    8192-slot table hold — the second takes several passes over its edges.  Checked against the reference binary."""
+    rng = np.random.default_rng(21)
+    N = 40000
+    rows, cols, vals = [], [], []
+    for hub, deg in ((0, 30000), (1, 3000)):
+        leaves = rng.choice(np.arange(2, N), deg, replace=False)
+        rows += [np.full(deg, hub)]; cols += [leaves]; vals += [rng.integers(1, 32, deg) / 64.0]
+    ring = np.arange(2, N)                                           # every leaf also sits on a ring: no isolated vertices
+    rows += [ring]; cols += [np.roll(ring, -1)]; vals += [np.full(N - 2, 0.5)]
+    W = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(N, N)).tocsc()
+    A = (W + W.T).tocsc()
+    A.sum_duplicates(); A.sort_indices()
+    lab = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 1, 10, 0, False)
+    check_labels(A, lab, 1.0)
+    again = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 1, 10, 0, False)
+    assert np.array_equal(lab, again)
+    if oracle.build_ref() is not None:
+        ref_labels, _ = oracle.modularity_reference(A, 1.0, 1, 1, 10, 0)
+        assert lab.modularity >= oracle_np.modularity_np(A, ref_labels, 1.0) - Q_TOL
+
+
 def test_resolution_and_iterations():
     A = knn_graph(5000, 10, 15, 1, seed=11)
     coarse = gficf_amd.run_modularity_clustering(A, 1, 0.3, 1, 1, 10, 0, False)
