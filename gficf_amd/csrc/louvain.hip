@@ -65,14 +65,19 @@ __device__ __host__ static inline uint32_t lv_hash(uint32_t v) {
 
 // ---- level 0: fixed-point weights, validation
 __global__ __launch_bounds__(256) void k_lv_fix(int64_t N, int64_t nnz, const int32_t* __restrict__ nbr, const double* __restrict__ x,
-                                                u64* __restrict__ wt, uint32_t* __restrict__ status) {
+                                                u64* __restrict__ wt, u64* __restrict__ max_wt, uint32_t* __restrict__ status) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= nnz) return;
-  const double v = x[e];
-  const int32_t u = nbr[e];
-  bool ok = u >= 0 && u < N && v >= 0.0 && v <= 1048576.0;      // NaN fails the comparisons
-  if (!ok) atomicOr(status, u >= 0 && u < N ? GFICF_ST_BAD_VALUE : GFICF_ST_BAD_CSC);
-  wt[e] = ok ? (u64)llrint(v * LV_SCALE) : 0ull;
+  u64 f = 0;
+  if (e < nnz) {
+    const double v = x[e];
+    const int32_t u = nbr[e];
+    const bool ok = u >= 0 && u < N && v >= 0.0 && v <= 1048576.0;      // NaN fails the comparisons
+    if (!ok) atomicOr(status, u >= 0 && u < N ? GFICF_ST_BAD_VALUE : GFICF_ST_BAD_CSC);
+    f = ok ? (u64)llrint(v * LV_SCALE) : 0ull;
+    wt[e] = f;
+  }
+  for (int d = 32; d > 0; d >>= 1) { const u64 o = __shfl_down(f, d); f = o > f ? o : f; }
+  if ((threadIdx.x & 63) == 0 && f) atomicMax(max_wt, f);       // the largest weight bounds every later sum (checked by the host)
 }
 
 __global__ __launch_bounds__(256) void k_lv_vertex_weight(LvGraph g, u64* __restrict__ kv, u64* __restrict__ two_w,
@@ -435,7 +440,7 @@ struct Bump {
   char* base; size_t off, cap;
   template <typename T> T* take(size_t count) {
     off = (off + 255) & ~(size_t)255;
-    T* p = (T*)(base + off);
+    T* p = base ? (T*)(base + off) : nullptr;     // base == NULL: sizing only
     off += count * sizeof(T);
     return p;
   }
@@ -460,7 +465,7 @@ struct LvWs {
   int64_t* flag;            // max(n, m) + 1 entries: scans
   u64 *keys_a, *vals_a, *keys_b, *vals_b;
   void* sort_tmp; size_t sort_tmp_bytes;
-  u64* scalars;             // [0] 2W, [1] internal weight, [2] moved (unsigned), [3] sum of squares (double), [4] n_mid | n_large
+  u64* scalars;             // [0] 2W, [1] internal weight, [2] moved (unsigned), [3] sum of squares (double), [4] n_mid | n_large, [5] largest weight
 };
 
 static size_t lv_carve(LvWs* w, void* base, int64_t N, int64_t nnz) {
@@ -523,7 +528,8 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
                          size_t ws_bytes) {
   GFICF_CTX_ENTER(ctx);
   if (N < 0 || nnz < 0 || n_iter < 1 || !(resolution >= 0.0)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size, n_iter < 1 or a negative resolution");
-  if (n_clusters) *n_clusters = 0;
+  if (!n_clusters) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "n_clusters is NULL");
+  *n_clusters = 0;
   if (modularity) *modularity = 0.0;
   if (N == 0) return GFICF_OK;
   if (!d_indptr || !d_labels || !d_ws || (nnz > 0 && (!d_indices || !d_x))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
@@ -541,18 +547,21 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
 
   // level 0: fixed-point weights, vertex weights, 2W
   GFICF_HIP_CHECK(hipMemsetAsync(w.scalars, 0, 8 * sizeof(u64), st));
-  if (nnz > 0) hipLaunchKernelGGL(k_lv_fix, dim3(lv_blocks(nnz, 256)), dim3(256), 0, st, N, nnz, d_indices, d_x, w.wt0, ctx->d_status);
+  if (nnz > 0) hipLaunchKernelGGL(k_lv_fix, dim3(lv_blocks(nnz, 256)), dim3(256), 0, st, N, nnz, d_indices, d_x, w.wt0, w.scalars + 5, ctx->d_status);
   LvGraph g0{N, nnz, d_indptr, d_indices, w.wt0, w.kv0};
   hipLaunchKernelGGL(k_lv_vertex_weight, dim3(lv_blocks(N, 256)), dim3(256), 0, st, g0, w.kv0, w.scalars, ctx->d_status);
-  u64 two_w_fix = 0;
-  GFICF_HIP_CHECK(hipMemcpyAsync(&two_w_fix, w.scalars, sizeof(u64), hipMemcpyDeviceToHost, st));
+  u64 h_sc[6] = {0, 0, 0, 0, 0, 0};
+  GFICF_HIP_CHECK(hipMemcpyAsync(h_sc, w.scalars, sizeof(h_sc), hipMemcpyDeviceToHost, st));
   int rc = gficf_ctx_sync(ctx);                    // also reports a malformed matrix before anything follows it
   if (rc) return rc;
+  const u64 two_w_fix = h_sc[0];
+  if ((double)h_sc[5] * (double)nnz >= 9.0e18)     // the u64 sums (2W, community totals) could wrap
+    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "edge weights too large for the 2^-32 fixed-point sums (largest weight x entries >= 2^31): scale the matrix");
   const double two_w = (double)two_w_fix;
   if (two_w_fix == 0) {                            // no edges: every vertex is its own cluster, Q = 0
     hipLaunchKernelGGL(k_lv_init, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, w.kv0, d_labels, w.K, w.size);
     GFICF_HIP_CHECK(hipStreamSynchronize(st));
-    if (n_clusters) *n_clusters = N;
+    *n_clusters = N;
     return GFICF_OK;
   }
   const double r = resolution / two_w;
@@ -635,7 +644,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
       GFICF_HIP_CHECK(hipStreamSynchronize(st));
       have_labels = true;
       if (n2 == g.n || n2 <= 1 || (!level_moved && !(seeded && n2 < g.n))) {
-        if (n_clusters) *n_clusters = n2;
+        *n_clusters = n2;
         n_labels = n2;
         break;                                     // nothing merged: this pass is done
       }
@@ -671,8 +680,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   }
 
   // ---- clusters by decreasing size
-  int64_t C = n_clusters ? *n_clusters : 0;
-  if (!n_clusters) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "n_clusters is NULL");
+  const int64_t C = *n_clusters;
   GFICF_HIP_CHECK(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * (size_t)C, st));
   hipLaunchKernelGGL(k_lv_accum, dim3(lv_blocks(N, 256) < 1024u ? lv_blocks(N, 256) : 1024u), dim3(256), 0, st, N, C, w.lab, (const u64*)nullptr,
                      (int32_t*)nullptr, (u64*)nullptr, w.cnt);
