@@ -317,7 +317,8 @@ def run_modularity_clustering(SNN, modularity: int = 1, resolution: float = 0.8,
     the Jaccard graph (``jaccard_adjacency``).  RELAXED CONTRACT (see include/gficf_hip.h): a deterministic parallel
     Louvain on the reference's objective — standard modularity with a resolution parameter, diagonal ignored — instead
     of its sequential, seeded one; ``n_start`` and ``random_seed`` therefore have nothing to act on and are accepted for
-    signature compatibility only.  ``modularity`` must be 1 and ``algorithm`` 1 (Louvain) or 2 (treated as 1).
+    signature compatibility only.  ``modularity`` must be 1 and ``algorithm`` 1 (Louvain) or 2 (Louvain with multilevel
+    refinement).
 
     Returns the cluster of every vertex (int32, 0-based like the reference's return value, clusters numbered by
     decreasing size); ``.modularity`` and ``.n_clusters`` are attached as attributes of the returned array subclass.
@@ -327,7 +328,7 @@ def run_modularity_clustering(SNN, modularity: int = 1, resolution: float = 0.8,
     if modularity != 1:
         raise ValueError("only the standard modularity function (1) is provided")
     if algorithm not in (1, 2):
-        raise ValueError("algorithm must be 1 (Louvain) or 2 (Louvain with multilevel refinement, run as 1)")
+        raise ValueError("algorithm must be 1 (Louvain) or 2 (Louvain with multilevel refinement)")
     if n_start < 1 or n_iter < 1:
         raise ValueError("n_start and n_iter must be at least 1")
     A = sp.csc_matrix(SNN)
@@ -343,8 +344,8 @@ def run_modularity_clustering(SNN, modularity: int = 1, resolution: float = 0.8,
     labels = np.zeros(max(N, 1), dtype=np.int32)
     nc, q = ctypes.c_int64(0), ctypes.c_double(0.0)
     ctx = ctx or default_context()
-    check(_lib.load().gficf_louvain_host(ctx.handle, N, _np_ptr(indptr), 1, _np_ptr(indices), _np_ptr(x), float(resolution), int(n_iter),
-                                         _np_ptr(labels), ctypes.byref(nc), ctypes.byref(q)))
+    check(_lib.load().gficf_louvain_host(ctx.handle, N, _np_ptr(indptr), 1, _np_ptr(indices), _np_ptr(x), float(resolution), int(algorithm),
+                                         int(n_iter), _np_ptr(labels), ctypes.byref(nc), ctypes.byref(q)))
     out = labels[:N].view(ClusterLabels)
     out.modularity, out.n_clusters = q.value, nc.value
     if print_output:
@@ -631,12 +632,12 @@ class HipOps:
     def louvain_workspace_bytes(self, N: int, nnz: int) -> int:
         return int(self.L.gficf_louvain_workspace_bytes(int(N), int(nnz)))
 
-    def louvain(self, N, indptr, indices, x, resolution, n_iter, labels, ws):
+    def louvain(self, N, indptr, indices, x, resolution, n_iter, labels, ws, algorithm: int = 1):
         """Community detection on a device-resident symmetric adjacency matrix (indptr int64, indices int32, x float64).
         Returns (n_clusters, modularity); labels: int32[N]."""
         nc, q = ctypes.c_int64(0), ctypes.c_double(0.0)
         check(self.L.gficf_louvain_device(self._bind(), int(N), _tptr(indptr), _tptr(indices), _tptr(x), int(indices.numel()),
-                                          float(resolution), int(n_iter), _tptr(labels), ctypes.byref(nc), ctypes.byref(q),
+                                          float(resolution), int(algorithm), int(n_iter), _tptr(labels), ctypes.byref(nc), ctypes.byref(q),
                                           _tptr(ws), int(ws.numel() * ws.element_size())))
         return nc.value, q.value
 

@@ -28,7 +28,10 @@
 //     totals are applied between sub-rounds.  An iteration that lowers Q is undone and ends the level;
 //   * reduction: communities renumbered by a scan, every inter-community edge keyed (c_u << 32 | c_v), one rocPRIM
 //     radix sort, equal keys summed (integers again), CSR rebuilt; repeat until nothing merges;
-//   * n_iter > 1 restarts from the finest graph with the labels found so far, as the reference's iterations do.
+//   * n_iter > 1 restarts from the finest graph with the labels found so far, as the reference's iterations do;
+//   * algorithm 2 (runLouvainAlgorithmWithMultilevelRefinement, :629-649): after the descent, back up through the levels
+//     with one more local moving on each, seeded with the labels found below it; a level's graph is rebuilt from the
+//     finest one through its saved vertex map (one sort) rather than kept.
 // Not reproduced: random starts (there is no randomness to restart), the move of a vertex into an empty cluster when
 // every gain is negative (:546-550), algorithm 3 (SLM).
 #include <cmath>
@@ -49,6 +52,7 @@ constexpr int LV_SMALL_SLOTS = 256;
 constexpr int LV_MID_DEG = 1024, LV_MID_SLOTS = 2048;   // one workgroup per vertex, 24 KB table
 constexpr int LV_BIG_SLOTS = 8192;             // beyond: 32 KB keys + 64 KB sums
 constexpr int LV_MAX_ITERS = 64;
+constexpr int LV_MAX_SAVED = 12;              // levels whose vertex map is kept for the refinement of algorithm 2
 
 struct LvGraph {
   int64_t n, m;
@@ -346,16 +350,23 @@ __global__ __launch_bounds__(256) void k_lv_coarse_weights(int64_t n, const int3
   if (c < n && size[c] > 0) kv2[newid[c]] = K[c];
 }
 
-__global__ __launch_bounds__(256) void k_lv_relabel(int64_t n, int32_t* __restrict__ lab, const int32_t* __restrict__ comm,
-                                                    const int64_t* __restrict__ newid) {
+// lab[v] = new id of the community of the level's vertex that original vertex v maps to (src == NULL: v itself)
+__global__ __launch_bounds__(256) void k_lv_relabel(int64_t n, const int32_t* src, const int32_t* __restrict__ comm,
+                                                    const int64_t* __restrict__ newid, int32_t* lab) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v < n) lab[v] = (int32_t)newid[comm[lab ? lab[v] : v]];
+  if (v < n) lab[v] = (int32_t)newid[comm[src ? src[v] : v]];        // src may be lab itself: one read, one write per thread
 }
 
-__global__ __launch_bounds__(256) void k_lv_relabel_first(int64_t n, int32_t* __restrict__ lab, const int32_t* __restrict__ comm,
-                                                          const int64_t* __restrict__ newid) {
+__global__ __launch_bounds__(256) void k_lv_iota(int64_t n, int64_t* __restrict__ out) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v < n) lab[v] = (int32_t)newid[comm[v]];
+  if (v < n) out[v] = v;
+}
+
+// seed[x] = the label of the original vertices that make up level vertex x (they all carry the same one)
+__global__ __launch_bounds__(256) void k_lv_seed(int64_t n, const int32_t* __restrict__ top, const int32_t* __restrict__ lab,
+                                                 int32_t* __restrict__ seed) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v < n) seed[top[v]] = lab[v];
 }
 
 // none = n2 << 32: the key of an entry that stays inside a community; it sorts behind every kept key
@@ -460,7 +471,7 @@ struct LvLevel {          // a coarse graph's arrays
 struct LvWs {
   u64* wt0; u64* kv0;
   LvLevel lvl[2];
-  int32_t *comm, *next, *snap_comm, *size, *snap_size, *big, *lab, *cnt, *rank;
+  int32_t *comm, *next, *snap_comm, *size, *snap_size, *big, *lab, *cnt, *rank, *tops;
   u64 *K, *snap_K;
   int64_t* flag;            // max(n, m) + 1 entries: scans
   u64 *keys_a, *vals_a, *keys_b, *vals_b;
@@ -479,6 +490,7 @@ static size_t lv_carve(LvWs* w, void* base, int64_t N, int64_t nnz) {
   d.comm = b.take<int32_t>(n); d.next = b.take<int32_t>(n); d.snap_comm = b.take<int32_t>(n);
   d.size = b.take<int32_t>(n); d.snap_size = b.take<int32_t>(n); d.big = b.take<int32_t>(n);
   d.lab = b.take<int32_t>(n); d.cnt = b.take<int32_t>(n); d.rank = b.take<int32_t>(n);
+  d.tops = b.take<int32_t>(n * LV_MAX_SAVED);
   d.K = b.take<u64>(n); d.snap_K = b.take<u64>(n);
   d.flag = b.take<int64_t>((n > m ? n : m) + 1);
   d.keys_a = b.take<u64>(m > n ? m : n); d.vals_a = b.take<u64>(m > n ? m : n);
@@ -524,10 +536,11 @@ size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz) {
 }
 
 int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, const int32_t* d_indices, const double* d_x, int64_t nnz,
-                         double resolution, int n_iter, int32_t* d_labels, int64_t* n_clusters, double* modularity, void* d_ws,
+                         double resolution, int algorithm, int n_iter, int32_t* d_labels, int64_t* n_clusters, double* modularity, void* d_ws,
                          size_t ws_bytes) {
   GFICF_CTX_ENTER(ctx);
   if (N < 0 || nnz < 0 || n_iter < 1 || !(resolution >= 0.0)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size, n_iter < 1 or a negative resolution");
+  if (algorithm != 1 && algorithm != 2) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "algorithm must be 1 (Louvain) or 2 (Louvain with multilevel refinement)");
   if (!n_clusters) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "n_clusters is NULL");
   *n_clusters = 0;
   if (modularity) *modularity = 0.0;
@@ -569,112 +582,174 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   bool have_labels = false;
   int64_t n_labels = 0;                          // labels of the previous pass lie in [0, n_labels)
 
+  // ---- the steps of one level (host side; every one ends synchronised or enqueues on the context's stream)
+  double q_prev = 0.0;                           // Q of the labels the level holds
+  u64 in_w = 0;                                  // their internal weight on the level's graph
+  unsigned n_mid = 0, n_large = 0;
+  const auto grid_cap = [](unsigned b) { return b < 1024u ? b : 1024u; };
+  // labels (seed == NULL: singletons), totals, sizes, the workgroup-path vertex lists, Q
+  const auto start_level = [&](const LvGraph& g, const int32_t* seed, int64_t seed_labels, u64 self_w) -> int {
+    if (seed) {
+      GFICF_HIP_CHECK(hipMemsetAsync(w.K, 0, sizeof(u64) * (size_t)g.n, st));
+      GFICF_HIP_CHECK(hipMemsetAsync(w.size, 0, sizeof(int32_t) * (size_t)g.n, st));
+      hipLaunchKernelGGL(k_lv_accum, dim3(grid_cap(lv_blocks(g.n, 256))), dim3(256), 0, st, g.n, seed_labels, seed, g.kv, w.comm, w.K, w.size);
+    } else {
+      hipLaunchKernelGGL(k_lv_init, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, g.kv, w.comm, w.K, w.size);
+    }
+    GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(u64), st));
+    hipLaunchKernelGGL(k_lv_list_big, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g, w.big, (unsigned*)(w.scalars + 4));
+    unsigned h_cnt[2] = {0, 0};                  // vertices of middle and of large degree
+    GFICF_HIP_CHECK(hipMemcpyAsync(h_cnt, w.scalars + 4, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+    const int rc2 = lv_quality(ctx, g, w, self_w, two_w, resolution, &q_prev, &in_w);
+    n_mid = h_cnt[0]; n_large = h_cnt[1];
+    return rc2;
+  };
+  const auto local_moving = [&](const LvGraph& g, u64 self_w, bool* level_moved) -> int {
+    const int S = lv_sub_rounds(g.n);
+    *level_moved = false;
+    for (int iter = 0; iter < LV_MAX_ITERS; ++iter) {
+      GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_comm, w.comm, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+      GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_size, w.size, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+      GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_K, w.K, sizeof(u64) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+      GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 2, 0, sizeof(unsigned), st));
+      for (int s = 0; s < S; ++s) {
+        const LvMove mv{r, s, S};
+        hipLaunchKernelGGL(k_lv_move_small, dim3(lv_blocks(g.n, 4)), dim3(256), 0, st, g, mv, w.comm, w.K, w.size, w.next, (unsigned*)(w.scalars + 2));
+        if (n_mid)
+          hipLaunchKernelGGL(k_lv_move_big<LV_MID_SLOTS>, dim3(n_mid), dim3(256), LV_MID_SLOTS * 12, st, g, mv, w.big, w.comm, w.K, w.size, w.next,
+                             (unsigned*)(w.scalars + 2), ctx->d_status);
+        if (n_large)
+          hipLaunchKernelGGL(k_lv_move_big<LV_BIG_SLOTS>, dim3(n_large), dim3(256), LV_BIG_SLOTS * 12, st, g, mv, w.big + (g.n - n_large), w.comm,
+                             w.K, w.size, w.next, (unsigned*)(w.scalars + 2), ctx->d_status);
+        hipLaunchKernelGGL(k_lv_apply, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, mv, g.kv, w.comm, w.next, w.K, w.size);
+      }
+      unsigned moved = 0;
+      GFICF_HIP_CHECK(hipMemcpyAsync(&moved, w.scalars + 2, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      double q; u64 in_now;
+      const int rc2 = lv_quality(ctx, g, w, self_w, two_w, resolution, &q, &in_now);
+      if (rc2) return rc2;
+      if (moved == 0) break;
+      if (q < q_prev) {                          // simultaneous moves made it worse: undo the iteration, the level ends
+        GFICF_HIP_CHECK(hipMemcpyAsync(w.comm, w.snap_comm, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+        GFICF_HIP_CHECK(hipMemcpyAsync(w.size, w.snap_size, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+        GFICF_HIP_CHECK(hipMemcpyAsync(w.K, w.snap_K, sizeof(u64) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
+        break;
+      }
+      *level_moved = true;
+      in_w = in_now;
+      const bool small_gain = q - q_prev < 1e-7;
+      q_prev = q;
+      if (small_gain) break;
+    }
+    return GFICF_OK;
+  };
+  // the communities in use numbered 0 .. n2-1 (w.flag = old id -> new id); lab[v] = new id of comm[src[v]] (src NULL: v)
+  const auto renumber = [&](const LvGraph& g, const int32_t* src, int64_t* n2) -> int {
+    hipLaunchKernelGGL(k_lv_used, dim3(lv_blocks(g.n + 1, 256)), dim3(256), 0, st, g.n, w.size, w.flag);
+    const int rc2 = gficf_exclusive_scan_i64(ctx, w.flag, g.n + 1);
+    if (rc2) return rc2;
+    GFICF_HIP_CHECK(hipMemcpyAsync(n2, w.flag + g.n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_lv_relabel, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, src, w.comm, w.flag, w.lab);
+    GFICF_HIP_CHECK(hipStreamSynchronize(st));
+    return GFICF_OK;
+  };
+  // g reduced by the labels newid[comm[.]] (n2 of them) into the arrays of nl; kv of the result is NOT set here
+  const auto reduce = [&](const LvGraph& g, const int32_t* comm, const int64_t* newid, int64_t n2, LvLevel& nl, LvGraph* out) -> int {
+    int64_t m2 = 0;
+    if (g.m > 0) {
+      const u64 none = (u64)n2 << 32;
+      hipLaunchKernelGGL(k_lv_emit, dim3(lv_blocks(g.n, 4)), dim3(256), 0, st, g, comm, newid, none, w.keys_a, w.vals_a);
+      unsigned bits = 33;                        // the keys in use: (row < n2) << 32 | col, and none = n2 << 32
+      while (bits < 64 && ((int64_t)1 << (bits - 32)) <= n2) ++bits;
+      size_t tb = w.sort_tmp_bytes;
+      GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys_a, w.keys_b, w.vals_a, w.vals_b, (size_t)g.m, 0u, bits, st));
+      hipLaunchKernelGGL(k_lv_heads, dim3(lv_blocks(g.m + 1, 256)), dim3(256), 0, st, w.keys_b, g.m, none, w.flag);
+      int rc2 = gficf_exclusive_scan_i64(ctx, w.flag, g.m + 1);
+      if (rc2) return rc2;
+      GFICF_HIP_CHECK(hipMemcpyAsync(&m2, w.flag + g.m, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+      GFICF_HIP_CHECK(hipStreamSynchronize(st));
+      GFICF_HIP_CHECK(hipMemsetAsync(nl.wt, 0, sizeof(u64) * (size_t)(m2 > 0 ? m2 : 1), st));
+      GFICF_HIP_CHECK(hipMemsetAsync(nl.ptr, 0, sizeof(int64_t) * (size_t)(n2 + 1), st));
+      hipLaunchKernelGGL(k_lv_reduce, dim3(lv_blocks(g.m, LV_RED_CHUNK)), dim3(256), 0, st, w.keys_b, w.vals_b, g.m, none, w.flag, nl.nbr, nl.wt, nl.ptr);
+      rc2 = gficf_exclusive_scan_i64(ctx, nl.ptr, n2 + 1);
+      if (rc2) return rc2;
+    } else {
+      GFICF_HIP_CHECK(hipMemsetAsync(nl.ptr, 0, sizeof(int64_t) * (size_t)(n2 + 1), st));
+    }
+    *out = LvGraph{n2, m2, nl.ptr, nl.nbr, nl.wt, nl.kv};
+    return GFICF_OK;
+  };
+
   for (int pass = 0; pass < n_iter; ++pass) {
     LvGraph g = g0;
     u64 self_w = 0;
     bool any_move = false;
+    int n_saved = 0;                             // levels 1 .. n_saved have their vertex map in w.tops
+    int64_t saved_n[LV_MAX_SAVED + 1];
     for (int level = 0;; ++level) {
-      // ---- start of a level: labels, totals, sizes
       const bool seeded = level == 0 && have_labels;
-      if (seeded) {
-        GFICF_HIP_CHECK(hipMemsetAsync(w.K, 0, sizeof(u64) * (size_t)g.n, st));
-        GFICF_HIP_CHECK(hipMemsetAsync(w.size, 0, sizeof(int32_t) * (size_t)g.n, st));
-        hipLaunchKernelGGL(k_lv_accum, dim3(lv_blocks(g.n, 256) < 1024u ? lv_blocks(g.n, 256) : 1024u), dim3(256), 0, st, g.n, n_labels, w.lab, g.kv,
-                           w.comm, w.K, w.size);
-      } else {
-        hipLaunchKernelGGL(k_lv_init, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, g.kv, w.comm, w.K, w.size);
-      }
-      GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(u64), st));
-      hipLaunchKernelGGL(k_lv_list_big, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g, w.big, (unsigned*)(w.scalars + 4));
-      unsigned h_cnt[2] = {0, 0};                  // vertices of middle and of large degree
-      GFICF_HIP_CHECK(hipMemcpyAsync(h_cnt, w.scalars + 4, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
-      double q_prev; u64 in_w;
-      rc = lv_quality(ctx, g, w, self_w, two_w, resolution, &q_prev, &in_w);
+      rc = start_level(g, seeded ? w.lab : nullptr, n_labels, self_w);
       if (rc) return rc;
-      const unsigned n_mid = h_cnt[0], n_large = h_cnt[1];
-      const int S = lv_sub_rounds(g.n);
-
-      // ---- local moving
       bool level_moved = false;
-      for (int iter = 0; iter < LV_MAX_ITERS; ++iter) {
-        GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_comm, w.comm, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-        GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_size, w.size, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-        GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_K, w.K, sizeof(u64) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-        GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 2, 0, sizeof(unsigned), st));
-        for (int s = 0; s < S; ++s) {
-          const LvMove mv{r, s, S};
-          hipLaunchKernelGGL(k_lv_move_small, dim3(lv_blocks(g.n, 4)), dim3(256), 0, st, g, mv, w.comm, w.K, w.size, w.next, (unsigned*)(w.scalars + 2));
-          if (n_mid)
-            hipLaunchKernelGGL(k_lv_move_big<LV_MID_SLOTS>, dim3(n_mid), dim3(256), LV_MID_SLOTS * 12, st, g, mv, w.big, w.comm, w.K, w.size, w.next,
-                               (unsigned*)(w.scalars + 2), ctx->d_status);
-          if (n_large)
-            hipLaunchKernelGGL(k_lv_move_big<LV_BIG_SLOTS>, dim3(n_large), dim3(256), LV_BIG_SLOTS * 12, st, g, mv, w.big + (g.n - n_large), w.comm,
-                               w.K, w.size, w.next, (unsigned*)(w.scalars + 2), ctx->d_status);
-          hipLaunchKernelGGL(k_lv_apply, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, mv, g.kv, w.comm, w.next, w.K, w.size);
-        }
-        unsigned moved = 0;
-        GFICF_HIP_CHECK(hipMemcpyAsync(&moved, w.scalars + 2, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        double q; u64 in_now;
-        rc = lv_quality(ctx, g, w, self_w, two_w, resolution, &q, &in_now);
-        if (rc) return rc;
-        if (moved == 0) break;
-        if (q < q_prev) {                          // simultaneous moves made it worse: undo the iteration, the level ends
-          GFICF_HIP_CHECK(hipMemcpyAsync(w.comm, w.snap_comm, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-          GFICF_HIP_CHECK(hipMemcpyAsync(w.size, w.snap_size, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-          GFICF_HIP_CHECK(hipMemcpyAsync(w.K, w.snap_K, sizeof(u64) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-          break;
-        }
-        level_moved = true;
-        in_w = in_now;
-        const bool small_gain = q - q_prev < 1e-7;
-        q_prev = q;
-        if (small_gain) break;
-      }
+      rc = local_moving(g, self_w, &level_moved);
+      if (rc) return rc;
       any_move |= level_moved;
       q_final = q_prev;
-
-      // ---- renumber the communities, compose the labels of the original vertices
-      hipLaunchKernelGGL(k_lv_used, dim3(lv_blocks(g.n + 1, 256)), dim3(256), 0, st, g.n, w.size, w.flag);
-      rc = gficf_exclusive_scan_i64(ctx, w.flag, g.n + 1);
-      if (rc) return rc;
       int64_t n2 = 0;
-      GFICF_HIP_CHECK(hipMemcpyAsync(&n2, w.flag + g.n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-      if (level == 0) hipLaunchKernelGGL(k_lv_relabel_first, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, w.lab, w.comm, w.flag);
-      else hipLaunchKernelGGL(k_lv_relabel, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, w.lab, w.comm, w.flag);
-      GFICF_HIP_CHECK(hipStreamSynchronize(st));
+      rc = renumber(g, level == 0 ? nullptr : w.lab, &n2);
+      if (rc) return rc;
       have_labels = true;
-      if (n2 == g.n || n2 <= 1 || (!level_moved && !(seeded && n2 < g.n))) {
-        *n_clusters = n2;
-        n_labels = n2;
-        break;                                     // nothing merged: this pass is done
-      }
-
+      *n_clusters = n_labels = n2;
+      if (n2 == g.n || n2 <= 1 || (!level_moved && !(seeded && n2 < g.n))) break;      // nothing merged: the descent is done
       // ---- the reduced graph
       LvLevel& nl = w.lvl[level & 1];
       hipLaunchKernelGGL(k_lv_coarse_weights, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, w.size, w.flag, w.K, nl.kv);
-      int64_t m2 = 0;
-      if (g.m > 0) {
-        const u64 none = (u64)n2 << 32;
-        hipLaunchKernelGGL(k_lv_emit, dim3(lv_blocks(g.n, 4)), dim3(256), 0, st, g, w.comm, w.flag, none, w.keys_a, w.vals_a);
-        unsigned bits = 33;                        // the keys in use: (row < n2) << 32 | col, and none = n2 << 32
-        while (bits < 64 && ((int64_t)1 << (bits - 32)) <= n2) ++bits;
-        size_t tb = w.sort_tmp_bytes;
-        GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys_a, w.keys_b, w.vals_a, w.vals_b, (size_t)g.m, 0u, bits, st));
-        hipLaunchKernelGGL(k_lv_heads, dim3(lv_blocks(g.m + 1, 256)), dim3(256), 0, st, w.keys_b, g.m, none, w.flag);
-        rc = gficf_exclusive_scan_i64(ctx, w.flag, g.m + 1);
-        if (rc) return rc;
-        GFICF_HIP_CHECK(hipMemcpyAsync(&m2, w.flag + g.m, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-        GFICF_HIP_CHECK(hipStreamSynchronize(st));
-        GFICF_HIP_CHECK(hipMemsetAsync(nl.wt, 0, sizeof(u64) * (size_t)(m2 > 0 ? m2 : 1), st));
-        GFICF_HIP_CHECK(hipMemsetAsync(nl.ptr, 0, sizeof(int64_t) * (size_t)(n2 + 1), st));
-        hipLaunchKernelGGL(k_lv_reduce, dim3(lv_blocks(g.m, LV_RED_CHUNK)), dim3(256), 0, st, w.keys_b, w.vals_b, g.m, none, w.flag, nl.nbr, nl.wt, nl.ptr);
-        rc = gficf_exclusive_scan_i64(ctx, nl.ptr, n2 + 1);
-        if (rc) return rc;
-      } else {
-        GFICF_HIP_CHECK(hipMemsetAsync(nl.ptr, 0, sizeof(int64_t) * (size_t)(n2 + 1), st));
-      }
+      LvGraph g2;
+      rc = reduce(g, w.comm, w.flag, n2, nl, &g2);
+      if (rc) return rc;
       self_w += in_w;
-      g = LvGraph{n2, m2, nl.ptr, nl.nbr, nl.wt, nl.kv};
+      g = g2;
+      if (algorithm == 2 && n_saved == level && level < LV_MAX_SAVED) {               // level + 1's vertices: lab as it is now
+        GFICF_HIP_CHECK(hipMemcpyAsync(w.tops + (size_t)level * (size_t)N, w.lab, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToDevice, st));
+        saved_n[++n_saved] = n2;
+      }
+    }
+
+    // ---- algorithm 2: back up through the levels, local moving on each with the labels found below it
+    // (runLouvainAlgorithmWithMultilevelRefinement, reference :629-649).  The graph of a level is rebuilt from the finest
+    // one by its saved vertex map (one sort) instead of being kept.
+    if (algorithm == 2 && any_move) {
+      for (int level = n_saved; level >= 0; --level) {
+        const int32_t* top = level ? w.tops + (size_t)(level - 1) * (size_t)N : nullptr;
+        LvGraph gl = g0;
+        u64 self_l = 0;
+        const int32_t* seed = w.lab;
+        if (level) {
+          const int64_t nl_n = saved_n[level];
+          LvLevel& nl = w.lvl[0];
+          hipLaunchKernelGGL(k_lv_iota, dim3(lv_blocks(nl_n, 256)), dim3(256), 0, st, nl_n, w.flag);
+          GFICF_HIP_CHECK(hipMemsetAsync(nl.kv, 0, sizeof(u64) * (size_t)nl_n, st));
+          GFICF_HIP_CHECK(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * (size_t)nl_n, st));
+          hipLaunchKernelGGL(k_lv_accum, dim3(grid_cap(lv_blocks(N, 256))), dim3(256), 0, st, N, nl_n, top, w.kv0, (int32_t*)nullptr, nl.kv, w.cnt);
+          GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 1, 0, sizeof(u64), st));
+          hipLaunchKernelGGL(k_lv_internal, dim3(lv_blocks(N, 4) < 2048u ? lv_blocks(N, 4) : 2048u), dim3(256), 0, st, g0, top, w.scalars + 1);
+          GFICF_HIP_CHECK(hipMemcpyAsync(&self_l, w.scalars + 1, sizeof(u64), hipMemcpyDeviceToHost, st));
+          hipLaunchKernelGGL(k_lv_seed, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, top, w.lab, w.rank);
+          rc = reduce(g0, top, w.flag, nl_n, nl, &gl);               // synchronises: self_l is there
+          if (rc) return rc;
+          seed = w.rank;
+        }
+        rc = start_level(gl, seed, n_labels, self_l);
+        if (rc) return rc;
+        bool level_moved = false;
+        rc = local_moving(gl, self_l, &level_moved);
+        if (rc) return rc;
+        q_final = q_prev;
+        int64_t n2 = 0;
+        rc = renumber(gl, top, &n2);
+        if (rc) return rc;
+        *n_clusters = n_labels = n2;
+      }
     }
     if (!any_move) break;
   }
@@ -695,7 +770,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
 }
 
 int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr_is_i64, const int32_t* indices, const double* x,
-                       double resolution, int n_iter, int32_t* labels, int64_t* n_clusters, double* modularity) {
+                       double resolution, int algorithm, int n_iter, int32_t* labels, int64_t* n_clusters, double* modularity) {
   GFICF_CTX_ENTER(ctx);
   if (N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (n_clusters) *n_clusters = 0;
@@ -722,7 +797,7 @@ int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr
   if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
   int rc = GFICF_OK;
   if (e == hipSuccess) {
-    rc = gficf_louvain_device(ctx, N, d_ptr, d_idx, d_x, nnz, resolution, n_iter, d_lab, n_clusters, modularity, d_ws, wsb);
+    rc = gficf_louvain_device(ctx, N, d_ptr, d_idx, d_x, nnz, resolution, algorithm, n_iter, d_lab, n_clusters, modularity, d_ws, wsb);
     if (!rc) e = hipMemcpyAsync(labels, d_lab, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, ctx->stream);
     if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
     else (void)hipStreamSynchronize(ctx->stream);

@@ -199,7 +199,7 @@ SEXP _gficf_RunModularityClusteringHip(SEXP SNN, SEXP modularityFunctionS, SEXP 
   SEXP out = PROTECT(Rf_allocVector(INTSXP, N));
   int64_t n_clusters = 0;
   double q = 0.0;
-  if (gficf_louvain_host(ctx_get(), N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(resolutionS), Rf_asInteger(nIterationsS),
+  if (gficf_louvain_host(ctx_get(), N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(resolutionS), algorithm, Rf_asInteger(nIterationsS),
                          INTEGER(out), &n_clusters, &q) != GFICF_OK) {
     UNPROTECT(1);
     Rf_error("gficf_hip: %s", gficf_last_error());

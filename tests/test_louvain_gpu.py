@@ -117,8 +117,16 @@ def test_resolution_and_iterations():
     one = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 1, 1, 0, False)
     ten = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 1, 10, 0, False)
     assert ten.modularity >= one.modularity - 1e-12                            # further passes never lose quality
-    for lab, res in ((coarse, 0.3), (fine, 3.0), (one, 1.0), (ten, 1.0)):
+    # algorithm 2 = the same descent plus one more local moving per level on the way back up: never worse in one pass
+    refined = gficf_amd.run_modularity_clustering(A, 1, 1.0, 2, 1, 1, 0, False)
+    assert refined.modularity >= one.modularity - 1e-12
+    for lab, res in ((coarse, 0.3), (fine, 3.0), (one, 1.0), (ten, 1.0), (refined, 1.0)):
         check_labels(A, lab, res)
+    if oracle.build_ref() is not None:                                         # against the reference's algorithm 2
+        ref_labels, _ = oracle.modularity_reference(A, 1.0, 2, 1, 10, 0)
+        ref10 = gficf_amd.run_modularity_clustering(A, 1, 1.0, 2, 1, 10, 0, False)
+        check_labels(A, ref10, 1.0)
+        assert ref10.modularity >= oracle_np.modularity_np(A, ref_labels, 1.0) - Q_TOL
 
 
 def test_device_resident_chain_and_edge_cases():
