@@ -32,8 +32,8 @@
 //   * algorithm 2 (runLouvainAlgorithmWithMultilevelRefinement, :629-649): after the descent, back up through the levels
 //     with one more local moving on each, seeded with the labels found below it; a level's graph is rebuilt from the
 //     finest one through its saved vertex map (one sort) rather than kept.
-// Not reproduced: random starts (there is no randomness to restart), the move of a vertex into an empty cluster when
-// every gain is negative (:546-550), algorithm 3 (SLM).
+//   * a vertex whose every option has a negative gain leaves for an unused cluster (:546-550): its own id, if free.
+// Not reproduced: random starts (there is no randomness to restart), algorithm 3 (SLM).
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -207,7 +207,11 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvGraph g, LvMove mv, con
     const double g_stay = stay_w - kvd * (double)(K[cv] - g.kv[v]) * mv.r;
     bool move = bc != INT32_MAX && bg > g_stay;
     if (move && size[cv] == 1 && size[bc] == 1 && bc > cv) move = false;      // two singletons never swap
-    next[v] = move ? bc : cv;
+    int32_t to = move ? bc : cv;
+    // every option loses: alone is better (the reference's move into an unused cluster, :546-550).  The unused cluster
+    // is the vertex's own id when nobody holds it — unique per vertex, so simultaneous escapes never meet.
+    if ((move ? bg : g_stay) < 0.0 && size[cv] > 1 && size[v] == 0) { to = (int32_t)v; move = true; }
+    next[v] = to;
     if (move) atomicAdd(moved, 1u);
   }
 }
@@ -277,7 +281,9 @@ __global__ __launch_bounds__(256) void k_lv_move_big(LvGraph g, LvMove mv, const
     const double g_stay = stay_w - kvd * (double)(K[cv] - g.kv[v]) * mv.r;
     bool move = bc != INT32_MAX && bg > g_stay;
     if (move && size[cv] == 1 && size[bc] == 1 && bc > cv) move = false;
-    next[v] = move ? bc : cv;
+    int32_t to = move ? bc : cv;
+    if ((move ? bg : g_stay) < 0.0 && size[cv] > 1 && size[v] == 0) { to = (int32_t)v; move = true; }     // see k_lv_move_small
+    next[v] = to;
     if (move) atomicAdd(moved, 1u);
   }
 }
