@@ -320,6 +320,8 @@ def run_modularity_clustering(SNN, modularity: int = 1, resolution: float = 0.8,
     signature compatibility only.  ``modularity`` must be 1 and ``algorithm`` 1 (Louvain) or 2 (Louvain with multilevel
     refinement).
 
+    ``SNN`` must be symmetric (the reference reads its strict lower triangle and mirrors it).
+
     Returns the cluster of every vertex (int32, 0-based like the reference's return value, clusters numbered by
     decreasing size); ``.modularity`` and ``.n_clusters`` are attached as attributes of the returned array subclass.
     """

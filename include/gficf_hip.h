@@ -287,7 +287,8 @@ int gficf_csc_transpose_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* c
  * reference's nIterations (a further pass restarts from the labels found so far and stops when nothing moves);
  * algorithm 1 = Louvain, 2 = Louvain with multilevel refinement (one more local moving on every level on the way back
  * up, :629-649); there are no random starts.  The call synchronises the stream several times (an iterative algorithm).
- * Edge weights must be finite and in [0, 2^20].  GFICF_ERR_UNSUPPORTED only if one hash class of a vertex's neighbouring
+ * The matrix must be symmetric (an undirected graph's adjacency matrix is; the reference reads only its strict lower
+ * triangle and mirrors it, which is the same thing then).  Edge weights must be finite and in [0, 2^20].  GFICF_ERR_UNSUPPORTED only if one hash class of a vertex's neighbouring
  * communities overflows the 8192-slot table (vertices of any degree are handled in several passes; not observed). */
 size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz);
 int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, const int32_t* d_indices,
