@@ -70,18 +70,24 @@ __device__ __host__ static inline uint32_t lv_hash(uint32_t v) {
 // ---- level 0: fixed-point weights, validation
 __global__ __launch_bounds__(256) void k_lv_fix(int64_t N, int64_t nnz, const int32_t* __restrict__ nbr, const double* __restrict__ x,
                                                 u64* __restrict__ wt, u64* __restrict__ max_wt, uint32_t* __restrict__ status) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  u64 f = 0;
-  if (e < nnz) {
+  __shared__ u64 s_max[4];
+  u64 mx = 0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256) {
     const double v = x[e];
     const int32_t u = nbr[e];
     const bool ok = u >= 0 && u < N && v >= 0.0 && v <= 1048576.0;      // NaN fails the comparisons
     if (!ok) atomicOr(status, u >= 0 && u < N ? GFICF_ST_BAD_VALUE : GFICF_ST_BAD_CSC);
-    f = ok ? (u64)llrint(v * LV_SCALE) : 0ull;
+    const u64 f = ok ? (u64)llrint(v * LV_SCALE) : 0ull;
     wt[e] = f;
+    mx = f > mx ? f : mx;
   }
-  for (int d = 32; d > 0; d >>= 1) { const u64 o = __shfl_down(f, d); f = o > f ? o : f; }
-  if ((threadIdx.x & 63) == 0 && f) atomicMax(max_wt, f);       // the largest weight bounds every later sum (checked by the host)
+  for (int d = 32; d > 0; d >>= 1) { const u64 o = __shfl_down(mx, d); mx = o > mx ? o : mx; }
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {                                        // the largest weight bounds every later sum (checked by the host)
+    for (int t = 1; t < 4; ++t) mx = s_max[t] > mx ? s_max[t] : mx;
+    if (mx) atomicMax(max_wt, mx);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_lv_vertex_weight(LvGraph g, u64* __restrict__ kv, u64* __restrict__ two_w,
@@ -150,6 +156,12 @@ struct LvMove {
   int s, S;            // this sub-round's hash class
 };
 
+__device__ static inline void lv_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ static inline bool lv_better(double g, int32_t c, double bg, int32_t bc) { return g > bg || (g == bg && c < bc); }
 
 // One wave per vertex (degree <= LV_SMALL_DEG).
@@ -168,9 +180,12 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvGraph g, LvMove mv, con
   }
   int32_t* key = s_key[wave];
   u64* val = s_val[wave];
+  // the table belongs to this wave alone and LDS serves a wave's operations in issue order: a wave-level fence (no
+  // workgroup barrier) is all that separates clearing, filling and reading it
+  if (!active) return;
   for (int t = lane; t < LV_SMALL_SLOTS; t += 64) { key[t] = -1; val[t] = 0ull; }
-  __syncthreads();
-  if (active) {
+  lv_wave_sync();
+  {
     for (int64_t e = lo + lane; e < hi; e += 64) {
       const int32_t u = g.nbr[e];
       if (u == v) continue;
@@ -183,8 +198,7 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvGraph g, LvMove mv, con
       }
     }
   }
-  __syncthreads();
-  if (!active) return;
+  lv_wave_sync();
   const int32_t cv = comm[v];
   const double kvd = (double)g.kv[v];
   double bg = -INFINITY, stay_w = 0.0;
@@ -566,7 +580,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
 
   // level 0: fixed-point weights, vertex weights, 2W
   GFICF_HIP_CHECK(hipMemsetAsync(w.scalars, 0, 8 * sizeof(u64), st));
-  if (nnz > 0) hipLaunchKernelGGL(k_lv_fix, dim3(lv_blocks(nnz, 256)), dim3(256), 0, st, N, nnz, d_indices, d_x, w.wt0, w.scalars + 5, ctx->d_status);
+  if (nnz > 0) hipLaunchKernelGGL(k_lv_fix, dim3(lv_blocks(nnz, 256) < 2048u ? lv_blocks(nnz, 256) : 2048u), dim3(256), 0, st, N, nnz, d_indices, d_x, w.wt0, w.scalars + 5, ctx->d_status);
   LvGraph g0{N, nnz, d_indptr, d_indices, w.wt0, w.kv0};
   hipLaunchKernelGGL(k_lv_vertex_weight, dim3(lv_blocks(N, 256)), dim3(256), 0, st, g0, w.kv0, w.scalars, ctx->d_status);
   u64 h_sc[6] = {0, 0, 0, 0, 0, 0};
