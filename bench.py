@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 CELLS_PER_GPU = 100_000
 K = 30
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md "HBM3E peak BW")
+HBM_COPY_GBS = 6300.0            # achievable streaming copy rate on the same part (MI355X_MICROARCH.md; SURVEY.md 8d asks for both)
 JACCARD_BYTES_PER_EDGE = 28      # 4 B index entry read once + 24 B reference output row
 GFICF_BYTES_PER_NNZ = 24         # 4 (count pass rowidx) + 12 (scale pass rowidx+x) + 8 (write x)  
 GFICF_G, GFICF_N = 23_000, 54_000  # BASELINE config 3 shape (Tabula-Muris-sized synthetic stand-in)
@@ -293,7 +294,7 @@ def main():
             pmc = {}
     traffic = pmc.get(f"jaccard_edges_N{N_total}_k{k}", {}).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "k_jaccard_edges", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_copy_rate": round(achieved / HBM_COPY_GBS, 4), "traffic": traffic,
                 "kernel_ms": round(t_edges_ms, 5), "kernel_ms_standalone": round(t_edges_alone_ms, 5),
                 "frac_standalone": round(JACCARD_BYTES_PER_EDGE * n_local * k / (t_edges_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "ingest_kernel_ms": round(t_ingest_ms, 5),
@@ -407,6 +408,7 @@ def main():
                   "roofline": {"bound": "hbm", "kernel": "whole pass (count + colptr + scale)",
                                "achieved": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_PEAK_GBS, 4),
+                               "frac_of_copy_rate": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_COPY_GBS, 4),
                                "traffic": (sum(pmc[kk]["hbm_bytes_per_launch"] for kk in ("gene_count", "gene_table", "cell_kept_count", "scale_cells", "scale_cells_lds") if kk in pmc)
                                            if all(kk in pmc for kk in ("gene_count", "cell_kept_count")) and nnz == 59809258 else None),
                                "scale_kernel_ms": round(t_scale, 4), "count_kernel_ms": round(t_count, 4),
