@@ -607,6 +607,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   u64 in_w = 0;                                  // their internal weight on the level's graph
   unsigned n_mid = 0, n_large = 0;
   const auto grid_cap = [](unsigned b) { return b < 1024u ? b : 1024u; };
+  const bool debug = getenv("GFICF_LOUVAIN_DEBUG") != nullptr;      // per-iteration trace on stderr
   // labels (seed == NULL: singletons), totals, sizes, the workgroup-path vertex lists, Q
   const auto start_level = [&](const LvGraph& g, const int32_t* seed, int64_t seed_labels, u64 self_w) -> int {
     if (seed) {
@@ -658,6 +659,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
       *level_moved = true;
       in_w = in_now;
       const bool small_gain = q - q_prev < 1e-7;
+      if (debug) fprintf(stderr, "[louvain]   n=%lld iter %d: moved %u, Q %.9f -> %.9f\n", (long long)g.n, iter, moved, q_prev, q);
       q_prev = q;
       if (small_gain) break;
     }
@@ -708,6 +710,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
     int64_t saved_n[LV_MAX_SAVED + 1];
     for (int level = 0;; ++level) {
       const bool seeded = level == 0 && have_labels;
+      if (debug) fprintf(stderr, "[louvain] pass %d level %d: n=%lld m=%lld\n", pass, level, (long long)g.n, (long long)g.m);
       rc = start_level(g, seeded ? w.lab : nullptr, n_labels, self_w);
       if (rc) return rc;
       bool level_moved = false;

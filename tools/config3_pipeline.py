@@ -1,0 +1,34 @@
+"""BASELINE config 3 shape end to end through the host mirror: gficf() on a 23 k genes x 54 k cells synthetic count matrix, then
+clustcells(k = 30) on a 50-component stand-in for the PCA space (PCA itself is third-party, RSpectra/irlba, and out of scope:
+the stand-in is clustered Gaussian data).  Prints the wall time of every call (host entries: PCIe both ways included)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import scipy.sparse as sp
+
+import gficf_amd
+from gficf_amd import synth
+
+G, N, k = 23000, 54000, 30
+t0 = time.perf_counter()
+cp, ri, x = synth.counts_csc(G, N, seed=7)
+M = sp.csc_matrix((x, ri, cp), shape=(G, N))
+rng = np.random.default_rng(1)
+C = 30
+pca = rng.normal(size=(C, 50))[rng.integers(0, C, N)] * 3.0 + rng.normal(size=(N, 50))
+print(f"synthetic input: {G} x {N}, nnz {M.nnz}, built in {time.perf_counter() - t0:.1f} s (host)")
+gficf_amd.gficf(M[:, :2000], normalize=False, verbose=False)                      # warm-up: context, library
+for rep in range(2):
+    t0 = time.perf_counter()
+    data = gficf_amd.gficf(M, normalize=False, verbose=False)
+    t1 = time.perf_counter()
+    data["pca"] = {"cells": pca}
+    data = gficf_amd.clustcells(data, k=k, community_algo="louvian 2", verbose=False)
+    t2 = time.perf_counter()
+    cells = gficf_amd.transpose_gficf(data["gficf"])
+    t3 = time.perf_counter()
+    print(f"run {rep}: gficf() {1e3 * (t1 - t0):.1f} ms ({data['gficf'].shape[0]} genes kept), clustcells(k={k}, louvian 2) {1e3 * (t2 - t1):.1f} ms "
+          f"({len(set(data['cluster']))} clusters, Q {data['modularity']:.4f}), t(gficf) {1e3 * (t3 - t2):.1f} ms")
