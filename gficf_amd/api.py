@@ -316,8 +316,9 @@ def run_modularity_clustering(SNN, modularity: int = 1, resolution: float = 0.8,
     (reference R/clustCells.R:145-149 -> src/RModularityOptimizer.cpp:25) on the symmetric weighted adjacency matrix of
     the Jaccard graph (``jaccard_adjacency``).  RELAXED CONTRACT (see include/gficf_hip.h): a deterministic parallel
     Louvain on the reference's objective — standard modularity with a resolution parameter, diagonal ignored — instead
-    of its sequential, seeded one; ``n_start`` and ``random_seed`` therefore have nothing to act on and are accepted for
-    signature compatibility only.  ``modularity`` must be 1 and ``algorithm`` 1 (Louvain) or 2 (Louvain with multilevel
+    of its sequential, seeded one.  ``n_start`` starts each begin from singletons and the best modularity is kept, as in the
+    reference; what a start varies is the seed (from ``random_seed`` and the start number) of the hash that splits the
+    vertices into sub-round classes — the result is a function of the arguments, never of scheduling.  ``modularity`` must be 1 and ``algorithm`` 1 (Louvain) or 2 (Louvain with multilevel
     refinement).
 
     ``SNN`` must be symmetric (the reference reads its strict lower triangle and mirrors it).
@@ -347,7 +348,7 @@ def run_modularity_clustering(SNN, modularity: int = 1, resolution: float = 0.8,
     nc, q = ctypes.c_int64(0), ctypes.c_double(0.0)
     ctx = ctx or default_context()
     check(_lib.load().gficf_louvain_host(ctx.handle, N, _np_ptr(indptr), 1, _np_ptr(indices), _np_ptr(x), float(resolution), int(algorithm),
-                                         int(n_iter), _np_ptr(labels), ctypes.byref(nc), ctypes.byref(q)))
+                                         int(n_start), int(n_iter), int(random_seed) & 0x7FFFFFFF, _np_ptr(labels), ctypes.byref(nc), ctypes.byref(q)))
     out = labels[:N].view(ClusterLabels)
     out.modularity, out.n_clusters = q.value, nc.value
     if print_output:
@@ -437,8 +438,8 @@ def clustcells(data: dict, from_embedded: bool = False, k: int = 15, dist_method
     ``data``: dict with ``"pca": {"cells": N x d}`` (or ``"embedded"``: N x >=2 array when ``from_embedded``) and
     ``"gficf"`` (genes x cells CSC).  ``community_algo``: "louvian 2" / "louvian 3" (resolution, n_iter as given) or
     "louvian" (the reference calls igraph::cluster_louvain there: plain modularity, i.e. resolution 1); the igraph /
-    leidenalg algorithms ("walktrap", "fastgreedy", "leiden") are third-party and not provided.  ``nt`` and ``seed`` are
-    accepted for signature compatibility (no CPU threads, nothing random).  Returns ``data`` updated with ``community``
+    leidenalg algorithms ("walktrap", "fastgreedy", "leiden") are third-party and not provided.  ``nt`` is accepted for
+    signature compatibility (no CPU threads); ``seed`` and ``n_start`` act as in ``run_modularity_clustering``.  Returns ``data`` updated with ``community``
     (1-based like the reference), ``cluster`` (the labels as strings, ``data$embedded$cluster``), ``cluster.gene.rnk``
     (+ its column labels ``cluster.labels``) and, with ``store_graph``, ``cell.graph`` (the edge columns) and
     ``cell.adjacency``.
@@ -457,7 +458,7 @@ def clustcells(data: dict, from_embedded: bool = False, k: int = 15, dist_method
     edges = clustcells_graph(X, k, dist_method, verbose, ctx)
     A = jaccard_adjacency(edges, N, ctx)
     if community_algo == "louvian":
-        community = run_modularity_clustering(A, 1, 1.0, 1, 1, n_iter, seed, False, ctx)
+        community = run_modularity_clustering(A, 1, 1.0, 1, 1, n_iter, 0, False, ctx)
     else:
         community = run_modularity_clustering(A, 1, resolution, 1 if community_algo == "louvian 2" else 2, n_start, n_iter, seed, verbose, ctx)
     data["community"] = np.asarray(community, dtype=np.int32) + 1
@@ -634,12 +635,13 @@ class HipOps:
     def louvain_workspace_bytes(self, N: int, nnz: int) -> int:
         return int(self.L.gficf_louvain_workspace_bytes(int(N), int(nnz)))
 
-    def louvain(self, N, indptr, indices, x, resolution, n_iter, labels, ws, algorithm: int = 1):
+    def louvain(self, N, indptr, indices, x, resolution, n_iter, labels, ws, algorithm: int = 1, n_start: int = 1, seed: int = 0):
         """Community detection on a device-resident symmetric adjacency matrix (indptr int64, indices int32, x float64).
         Returns (n_clusters, modularity); labels: int32[N]."""
         nc, q = ctypes.c_int64(0), ctypes.c_double(0.0)
         check(self.L.gficf_louvain_device(self._bind(), int(N), _tptr(indptr), _tptr(indices), _tptr(x), int(indices.numel()),
-                                          float(resolution), int(algorithm), int(n_iter), _tptr(labels), ctypes.byref(nc), ctypes.byref(q),
+                                          float(resolution), int(algorithm), int(n_start), int(n_iter), int(seed), _tptr(labels), ctypes.byref(nc),
+                                          ctypes.byref(q),
                                           _tptr(ws), int(ws.numel() * ws.element_size())))
         return nc.value, q.value
 

@@ -33,7 +33,9 @@
 //     with one more local moving on each, seeded with the labels found below it; a level's graph is rebuilt from the
 //     finest one through its saved vertex map (one sort) rather than kept.
 //   * a vertex whose every option has a negative gain leaves for an unused cluster (:546-550): its own id, if free.
-// Not reproduced: random starts (there is no randomness to restart), algorithm 3 (SLM).
+//   * n_start "random starts": each start varies the seed of the class hash (the only arbitrary choice there is); the best
+//     modularity wins, as in the reference.  Start 0 with seed 0 is the plain run.
+// Not reproduced: algorithm 3 (SLM), the alternative modularity function (2).
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(256) void k_lv_accum(int64_t n, int64_t C, const in
 struct LvMove {
   double r;            // resolution / 2W (in fixed-point units of 2W)
   int s, S;            // this sub-round's hash class
+  uint32_t seed;       // of the class hash: what a "random start" varies
 };
 
 __device__ static inline void lv_wave_sync() {
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvGraph g, LvMove mv, con
   bool active = v < g.n;
   if (active) {
     lo = g.ptr[v]; hi = g.ptr[v + 1];
-    active = hi - lo <= LV_SMALL_DEG && (mv.S == 1 || (int)(lv_hash((uint32_t)v) % (uint32_t)mv.S) == mv.s);
+    active = hi - lo <= LV_SMALL_DEG && (mv.S == 1 || (int)(lv_hash((uint32_t)v + mv.seed) % (uint32_t)mv.S) == mv.s);
   }
   int32_t* key = s_key[wave];
   u64* val = s_val[wave];
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256) void k_lv_move_big(LvGraph g, LvMove mv, const
   __shared__ int32_t s_c[256];
   const int tid = threadIdx.x;
   const int64_t v = big[blockIdx.x];
-  if (mv.S != 1 && (int)(lv_hash((uint32_t)v) % (uint32_t)mv.S) != mv.s) return;     // uniform per workgroup
+  if (mv.S != 1 && (int)(lv_hash((uint32_t)v + mv.seed) % (uint32_t)mv.S) != mv.s) return;     // uniform per workgroup
   const int64_t lo = g.ptr[v], hi = g.ptr[v + 1];
   const int32_t cv = comm[v];
   const double kvd = (double)g.kv[v];
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256) void k_lv_apply(int64_t n, LvMove mv, const u6
                                                   const int32_t* __restrict__ next, u64* __restrict__ K, int32_t* __restrict__ size) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (v >= n) return;
-  if (mv.S != 1 && (int)(lv_hash((uint32_t)v) % (uint32_t)mv.S) != mv.s) return;
+  if (mv.S != 1 && (int)(lv_hash((uint32_t)v + mv.seed) % (uint32_t)mv.S) != mv.s) return;
   const int32_t a = comm[v], b = next[v];
   if (a == b) return;
   const u64 k = kv[v];
@@ -491,7 +494,7 @@ struct LvLevel {          // a coarse graph's arrays
 struct LvWs {
   u64* wt0; u64* kv0;
   LvLevel lvl[2];
-  int32_t *comm, *next, *snap_comm, *size, *snap_size, *big, *lab, *cnt, *rank, *tops;
+  int32_t *comm, *next, *snap_comm, *size, *snap_size, *big, *lab, *cnt, *rank, *tops, *best;
   u64 *K, *snap_K;
   int64_t* flag;            // max(n, m) + 1 entries: scans
   u64 *keys_a, *vals_a, *keys_b, *vals_b;
@@ -511,6 +514,7 @@ static size_t lv_carve(LvWs* w, void* base, int64_t N, int64_t nnz) {
   d.size = b.take<int32_t>(n); d.snap_size = b.take<int32_t>(n); d.big = b.take<int32_t>(n);
   d.lab = b.take<int32_t>(n); d.cnt = b.take<int32_t>(n); d.rank = b.take<int32_t>(n);
   d.tops = b.take<int32_t>(n * LV_MAX_SAVED);
+  d.best = b.take<int32_t>(n);
   d.K = b.take<u64>(n); d.snap_K = b.take<u64>(n);
   d.flag = b.take<int64_t>((n > m ? n : m) + 1);
   d.keys_a = b.take<u64>(m > n ? m : n); d.vals_a = b.take<u64>(m > n ? m : n);
@@ -556,10 +560,11 @@ size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz) {
 }
 
 int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, const int32_t* d_indices, const double* d_x, int64_t nnz,
-                         double resolution, int algorithm, int n_iter, int32_t* d_labels, int64_t* n_clusters, double* modularity, void* d_ws,
+                         double resolution, int algorithm, int n_start, int n_iter, int seed, int32_t* d_labels, int64_t* n_clusters, double* modularity, void* d_ws,
                          size_t ws_bytes) {
   GFICF_CTX_ENTER(ctx);
-  if (N < 0 || nnz < 0 || n_iter < 1 || !(resolution >= 0.0)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size, n_iter < 1 or a negative resolution");
+  if (N < 0 || nnz < 0 || n_iter < 1 || n_start < 1 || !(resolution >= 0.0))
+    GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size, n_start < 1, n_iter < 1 or a negative resolution");
   if (algorithm != 1 && algorithm != 2) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "algorithm must be 1 (Louvain) or 2 (Louvain with multilevel refinement)");
   if (!n_clusters) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "n_clusters is NULL");
   *n_clusters = 0;
@@ -606,6 +611,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   double q_prev = 0.0;                           // Q of the labels the level holds
   u64 in_w = 0;                                  // their internal weight on the level's graph
   unsigned n_mid = 0, n_large = 0;
+  uint32_t start_seed = 0;                       // of the sub-round class hash (what a "random start" varies)
   const auto grid_cap = [](unsigned b) { return b < 1024u ? b : 1024u; };
   const bool debug = getenv("GFICF_LOUVAIN_DEBUG") != nullptr;      // per-iteration trace on stderr
   // labels (seed == NULL: singletons), totals, sizes, the workgroup-path vertex lists, Q
@@ -634,7 +640,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
       GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_K, w.K, sizeof(u64) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
       GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 2, 0, sizeof(unsigned), st));
       for (int s = 0; s < S; ++s) {
-        const LvMove mv{r, s, S};
+        const LvMove mv{r, s, S, start_seed};
         hipLaunchKernelGGL(k_lv_move_small, dim3(lv_blocks(g.n, 4)), dim3(256), 0, st, g, mv, w.comm, w.K, w.size, w.next, (unsigned*)(w.scalars + 2));
         if (n_mid)
           hipLaunchKernelGGL(k_lv_move_big<LV_MID_SLOTS>, dim3(n_mid), dim3(256), LV_MID_SLOTS * 12, st, g, mv, w.big, w.comm, w.K, w.size, w.next,
@@ -702,6 +708,15 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
     return GFICF_OK;
   };
 
+  // Random starts (reference src/RModularityOptimizer.cpp:108-142): every start begins from singletons, runs up to n_iter
+  // passes and is kept if its modularity beats the best so far.  Nothing here is random; what a start varies is the seed
+  // of the hash that splits the vertices into sub-round classes (start 0 with seed 0 is the plain deterministic run).
+  double q_best = -INFINITY;
+  int64_t n_best = 0;
+  for (int start = 0; start < n_start; ++start) {
+  start_seed = start == 0 && seed == 0 ? 0u : lv_hash((uint32_t)seed * 0x9E3779B1u + (uint32_t)start + 1u);
+  have_labels = false;
+  n_labels = 0;
   for (int pass = 0; pass < n_iter; ++pass) {
     LvGraph g = g0;
     u64 self_w = 0;
@@ -776,6 +791,16 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
     }
     if (!any_move) break;
   }
+  if (debug) fprintf(stderr, "[louvain] start %d: Q %.9f, %lld clusters\n", start, q_final, (long long)n_labels);
+  if (q_final > q_best) {                        // strictly better, as the reference keeps the first of equals (:128)
+    q_best = q_final;
+    n_best = n_labels;
+    if (n_start > 1) GFICF_HIP_CHECK(hipMemcpyAsync(w.best, w.lab, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToDevice, st));
+  }
+  }
+  if (n_start > 1) GFICF_HIP_CHECK(hipMemcpyAsync(w.lab, w.best, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToDevice, st));
+  q_final = q_best;
+  *n_clusters = n_best;
 
   // ---- clusters by decreasing size
   const int64_t C = *n_clusters;
@@ -793,7 +818,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
 }
 
 int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr_is_i64, const int32_t* indices, const double* x,
-                       double resolution, int algorithm, int n_iter, int32_t* labels, int64_t* n_clusters, double* modularity) {
+                       double resolution, int algorithm, int n_start, int n_iter, int seed, int32_t* labels, int64_t* n_clusters, double* modularity) {
   GFICF_CTX_ENTER(ctx);
   if (N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (n_clusters) *n_clusters = 0;
@@ -820,7 +845,7 @@ int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr
   if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
   int rc = GFICF_OK;
   if (e == hipSuccess) {
-    rc = gficf_louvain_device(ctx, N, d_ptr, d_idx, d_x, nnz, resolution, algorithm, n_iter, d_lab, n_clusters, modularity, d_ws, wsb);
+    rc = gficf_louvain_device(ctx, N, d_ptr, d_idx, d_x, nnz, resolution, algorithm, n_start, n_iter, seed, d_lab, n_clusters, modularity, d_ws, wsb);
     if (!rc) e = hipMemcpyAsync(labels, d_lab, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, ctx->stream);
     if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
     else (void)hipStreamSynchronize(ctx->stream);

@@ -286,18 +286,20 @@ int gficf_csc_transpose_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* c
  * (Clustering::orderClustersByNNodes, :132-158); *modularity = Q of the returned labels.  n_iter >= 1 is the
  * reference's nIterations (a further pass restarts from the labels found so far and stops when nothing moves);
  * algorithm 1 = Louvain, 2 = Louvain with multilevel refinement (one more local moving on every level on the way back
- * up, :629-649); there are no random starts.  The call synchronises the stream several times (an iterative algorithm).
+ * up, :629-649).  n_start >= 1 "random starts" (:108-142): every start begins from singletons and the best modularity is
+ * kept; nothing is random here — a start varies the seed of the hash that splits the vertices into sub-round classes,
+ * derived from (seed, start); start 0 with seed 0 is the plain run.  The call synchronises the stream several times (an iterative algorithm).
  * The matrix must be symmetric (an undirected graph's adjacency matrix is; the reference reads only its strict lower
  * triangle and mirrors it, which is the same thing then).  Edge weights must be finite and in [0, 2^20].  GFICF_ERR_UNSUPPORTED only if one hash class of a vertex's neighbouring
  * communities overflows the 8192-slot table (vertices of any degree are handled in several passes; not observed). */
 size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz);
 int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, const int32_t* d_indices,
-                         const double* d_x, int64_t nnz, double resolution, int algorithm, int n_iter,
-                         int32_t* d_labels, int64_t* n_clusters, double* modularity, void* d_ws,
+                         const double* d_x, int64_t nnz, double resolution, int algorithm, int n_start,
+                         int n_iter, int seed, int32_t* d_labels, int64_t* n_clusters, double* modularity, void* d_ws,
                          size_t ws_bytes);
 int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr_is_i64,
                        const int32_t* indices, const double* x, double resolution, int algorithm,
-                       int n_iter, int32_t* labels, int64_t* n_clusters, double* modularity);
+                       int n_start, int n_iter, int seed, int32_t* labels, int64_t* n_clusters, double* modularity);
 
 /* ------------------------------------------------------------------- exact kNN search
  * "Next" row N2: the caller's step in front of the Jaccard build,

@@ -181,15 +181,15 @@ SEXP _gficf_transpose_csc(SEXP iS, SEXP pS, SEXP xS, SEXP dimS) {
 }
 
 /* Optional: community detection on the adjacency matrix, argument list of RunModularityClusteringCpp
- * (reference src/RModularityOptimizer.cpp:25-33).  SNN: a dgCMatrix (symmetric).  nRandomStarts and randomSeed have nothing to act
- * on (the device algorithm is deterministic); an edge file is not read.  Returns the 0-based cluster of every vertex, clusters by
+ * (reference src/RModularityOptimizer.cpp:25-33).  SNN: a dgCMatrix (symmetric).  nRandomStarts starts are run and the best kept; randomSeed seeds the
+ * one arbitrary choice there is (see include/gficf_hip.h); an edge file is not read.  Returns the 0-based cluster of every vertex, clusters by
  * decreasing size, as the reference does (:171-173). */
 SEXP _gficf_RunModularityClusteringHip(SEXP SNN, SEXP modularityFunctionS, SEXP resolutionS, SEXP algorithmS, SEXP nRandomStartsS,
                                        SEXP nIterationsS, SEXP randomSeedS, SEXP printOutputS, SEXP edgefilenameS) {
-  (void)nRandomStartsS; (void)randomSeedS;
   if (Rf_asInteger(modularityFunctionS) != 1) Rf_error("Modularity parameter must be equal to 1 on this path.");
   const int algorithm = Rf_asInteger(algorithmS);
   if (algorithm != 1 && algorithm != 2) Rf_error("Algorithm for modularity optimization must be 1 or 2 on this path");
+  if (Rf_asInteger(nRandomStartsS) < 1) Rf_error("Have to have at least one start");
   if (Rf_asInteger(nIterationsS) < 1) Rf_error("Need at least one interation");
   if (Rf_length(edgefilenameS) > 0 && CHAR(STRING_ELT(edgefilenameS, 0))[0] != 0) Rf_error("edge files are not read on this path");
   SEXP iS = R_do_slot(SNN, Rf_install("i")), pS = R_do_slot(SNN, Rf_install("p")), xS = R_do_slot(SNN, Rf_install("x"));
@@ -199,8 +199,8 @@ SEXP _gficf_RunModularityClusteringHip(SEXP SNN, SEXP modularityFunctionS, SEXP 
   SEXP out = PROTECT(Rf_allocVector(INTSXP, N));
   int64_t n_clusters = 0;
   double q = 0.0;
-  if (gficf_louvain_host(ctx_get(), N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(resolutionS), algorithm, Rf_asInteger(nIterationsS),
-                         INTEGER(out), &n_clusters, &q) != GFICF_OK) {
+  if (gficf_louvain_host(ctx_get(), N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(resolutionS), algorithm, Rf_asInteger(nRandomStartsS),
+                         Rf_asInteger(nIterationsS), Rf_asInteger(randomSeedS) & 0x7FFFFFFF, INTEGER(out), &n_clusters, &q) != GFICF_OK) {
     UNPROTECT(1);
     Rf_error("gficf_hip: %s", gficf_last_error());
   }

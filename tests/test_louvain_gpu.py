@@ -117,6 +117,15 @@ def test_resolution_and_iterations():
     one = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 1, 1, 0, False)
     ten = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 1, 10, 0, False)
     assert ten.modularity >= one.modularity - 1e-12                            # further passes never lose quality
+    # random starts: the best of several is never worse than the first, equal arguments give equal results, the seed matters
+    s1 = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 1, 10, 0, False)
+    s5 = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 5, 10, 0, False)
+    s5b = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 5, 10, 0, False)
+    other = gficf_amd.run_modularity_clustering(A, 1, 1.0, 1, 1, 10, 1234, False)
+    assert np.array_equal(s1, ten) and s5.modularity >= s1.modularity and np.array_equal(s5, s5b)
+    assert not np.array_equal(other, s1)                                       # structureless data: another split, another optimum
+    for lab in (s5, other):
+        check_labels(A, lab, 1.0)
     # algorithm 2 = the same descent plus one more local moving per level on the way back up: never worse in one pass
     refined = gficf_amd.run_modularity_clustering(A, 1, 1.0, 2, 1, 1, 0, False)
     assert refined.modularity >= one.modularity - 1e-12
