@@ -85,7 +85,13 @@ __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __res
   if (bad) atomicOr(status, GFICF_ST_BAD_CSC);
   if (USE_LDS) {
     __syncthreads();
-    for (int64_t g = threadIdx.x; g < G; g += CNT_THREADS) {
+    // every workgroup starts its flush at another gene: all of them finish streaming at about the same time, and in
+    // step they would put gridDim.x atomics on the same address at once while the other L2 channels idle
+    const int64_t rot = (int64_t)blockIdx.x * (G / gridDim.x + 1);
+    for (int64_t t = threadIdx.x; t < G; t += CNT_THREADS) {
+      int64_t g = t + rot;
+      if (g >= G) g -= G;
+      if (g >= G) g %= G;
       const uint32_t c = s_hist[g];
       if (c) atomicAdd(&nt[g], (unsigned long long)c);
     }
