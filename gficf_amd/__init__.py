@@ -20,6 +20,7 @@ from .api import (  # noqa: F401
     jaccard_adjacency,
     jaccard_coeff,
     jaccard_edges,
+    phenograph,
     rcpp_parallel_jaccard_coef,
     run_modularity_clustering,
     transpose_gficf,

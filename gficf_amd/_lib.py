@@ -78,6 +78,8 @@ SIGNATURES = {
                                     ctypes.POINTER(_dbl), _vp, ctypes.c_size_t]),
     "gficf_louvain_host": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _dbl, _int, _int, _int, _int, _vp, ctypes.POINTER(_i64),
                                   ctypes.POINTER(_dbl)]),
+    "gficf_phenograph_host": (_int, [_vp, _vp, _i64, _int, _i64, _int, _int, _dbl, _int, _int, _int, _int, _vp, ctypes.POINTER(_i64),
+                                     ctypes.POINTER(_dbl), ctypes.POINTER(_i64)]),
     "gficf_knn_dpad": (_int, [_int]),
     "gficf_knn_prepare_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _int, _vp]),
     "gficf_knn_workspace_bytes": (ctypes.c_size_t, [_vp, _i64, _i64, _int]),

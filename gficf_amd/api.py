@@ -360,6 +360,7 @@ class ClusterLabels(np.ndarray):
     """int32 labels with the modularity and cluster count of the run attached."""
     modularity = float("nan")
     n_clusters = 0
+    n_edges = 0
 
 
 def transpose_gficf(gficf_mat, ctx: Context | None = None):
@@ -424,6 +425,29 @@ def clustcells_graph(X, k: int = 15, dist_method: str = "manhattan", verbose: bo
     return jaccard_edges(neigh, verbose, ctx)
 
 
+def phenograph(X, k: int = 15, dist_method: str = "manhattan", resolution: float = 0.8, algorithm: int = 1, n_start: int = 10,
+               n_iter: int = 10, random_seed: int = 0, ctx: Context | None = None):
+    """The graph build and the community detection of ``clustcells()`` (reference R/clustCells.R:57-86) chained on the
+    device in one call of the C ABI (``gficf_phenograph_host``): search, ``neigh[,-1]``, Jaccard edges, ``weight > 0``,
+    adjacency matrix, Louvain — one upload of ``X`` (N x d), one download of the labels.  Returns ``ClusterLabels``
+    (0-based, clusters by decreasing size) with ``.modularity``, ``.n_clusters`` and ``.n_edges`` attached."""
+    if dist_method not in _lib.KNN_METRICS:
+        raise ValueError(f"dist_method must be one of {sorted(_lib.KNN_METRICS)}")
+    X = np.asfortranarray(X, dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError("X must be a matrix")
+    N, d = X.shape
+    labels = np.zeros(max(N, 1), dtype=np.int32)
+    nc, q, ne = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_int64(0)
+    ctx = ctx or default_context()
+    check(_lib.load().gficf_phenograph_host(ctx.handle, _np_ptr(X), N, d, N, int(k), _lib.KNN_METRICS[dist_method], float(resolution),
+                                            int(algorithm), int(n_start), int(n_iter), int(random_seed) & 0x7FFFFFFF, _np_ptr(labels),
+                                            ctypes.byref(nc), ctypes.byref(q), ctypes.byref(ne)))
+    out = labels[:N].view(ClusterLabels)
+    out.modularity, out.n_clusters, out.n_edges = q.value, nc.value, ne.value
+    return out
+
+
 COMMUNITY_ALGOS = ("louvian", "louvian 2", "louvian 3")
 
 
@@ -455,12 +479,13 @@ def clustcells(data: dict, from_embedded: bool = False, k: int = 15, dist_method
             raise ValueError("First run runPCA or runLSA to reduce dimensionality")
         X = np.asarray(data["pca"]["cells"])
     N = X.shape[0]
-    edges = clustcells_graph(X, k, dist_method, verbose, ctx)
-    A = jaccard_adjacency(edges, N, ctx)
-    if community_algo == "louvian":
-        community = run_modularity_clustering(A, 1, 1.0, 1, 1, n_iter, 0, False, ctx)
-    else:
-        community = run_modularity_clustering(A, 1, resolution, 1 if community_algo == "louvian 2" else 2, n_start, n_iter, seed, verbose, ctx)
+    lv = (1.0, 1, 1, n_iter, 0) if community_algo == "louvian" else (resolution, 1 if community_algo == "louvian 2" else 2, n_start, n_iter, seed)
+    if store_graph:
+        edges = clustcells_graph(X, k, dist_method, verbose, ctx)
+        A = jaccard_adjacency(edges, N, ctx)
+        community = run_modularity_clustering(A, 1, lv[0], lv[1], lv[2], lv[3], lv[4], verbose and community_algo != "louvian", ctx)
+    else:                                                     # nothing but the labels comes back: the fused entry
+        community = phenograph(X, k, dist_method, lv[0], lv[1], lv[2], lv[3], lv[4], ctx)
     data["community"] = np.asarray(community, dtype=np.int32) + 1
     data["modularity"] = community.modularity
     data["cluster"] = data["community"].astype(str)

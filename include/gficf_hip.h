@@ -301,6 +301,16 @@ int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr
                        const int32_t* indices, const double* x, double resolution, int algorithm,
                        int n_start, int n_iter, int seed, int32_t* labels, int64_t* n_clusters, double* modularity);
 
+/* ------------------------------------------------------------------- clustcells() in one call
+ * The graph build and the community detection of clustcells() (R/clustCells.R:57-86) chained on the device — search
+ * (k + 1 nearest, the cell itself dropped), Jaccard edges, weight > 0 filter, adjacency matrix, Louvain — with one upload
+ * of the points and one download of the labels.  X: N x d column-major doubles (data$pca$cells); metric as in
+ * gficf_knn_host; resolution .. seed as in gficf_louvain_host.  labels: int32[N], 0-based, clusters by decreasing size;
+ * n_edges (optional): the number of edges kept by the filter.  Every stage keeps its own contract. */
+int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N, int d, int64_t ld, int k, int metric,
+                          double resolution, int algorithm, int n_start, int n_iter, int seed,
+                          int32_t* labels, int64_t* n_clusters, double* modularity, int64_t* n_edges);
+
 /* ------------------------------------------------------------------- exact kNN search
  * "Next" row N2: the caller's step in front of the Jaccard build,
  *   neigh = uwot:::find_nn(data$pca$cells, k = k+1, include_self = T, method = "annoy",

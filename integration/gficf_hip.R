@@ -86,3 +86,14 @@ RunModularityClusteringHip <- function(SNN = matrix(), modularity = 1, resolutio
   .Call(`_gficf_RunModularityClusteringHip`, SNN, as.integer(modularity), resolution, as.integer(algorithm), as.integer(n.start),
         as.integer(n.iter), as.integer(random.seed), print.output, edge.file.name)
 }
+
+# Optional: lines 57-86 of clustcells() in one call (search, neigh[,-1], Jaccard edges, weight > 0, adjacency matrix, Louvain)
+# with nothing crossing PCIe between the steps; for store.graph = FALSE, when only the communities are wanted:
+#   community = phenograph_hip(data$pca$cells, k, dist.method, resolution, 1, n.start, n.iter, seed) + 1
+phenograph_hip = function(X, k = 15, metric = "manhattan", resolution = 0.8, algorithm = 1, n.start = 10, n.iter = 10, seed = 0)
+{
+  m = match(metric, c("manhattan", "euclidean", "cosine", "correlation")) - 1L
+  if (is.na(m)) stop("metric must be manhattan, euclidean, cosine or correlation")
+  .Call(`_gficf_phenograph`, as.matrix(X) + 0, as.integer(k), m, resolution, as.integer(algorithm), as.integer(n.start),
+        as.integer(n.iter), as.integer(seed))
+}

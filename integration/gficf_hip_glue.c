@@ -24,6 +24,8 @@
  *       _gficf_RunModularityClusteringCpp (src/RcppExports.cpp:17): the deterministic parallel Louvain.  NOT registered
  *       under the reference's name: its results differ from the seeded sequential optimiser (same objective, see
  *       include/gficf_hip.h), so the switch is an explicit choice in R/clustCells.R:80,86, not a silent replacement.
+ *   _gficf_phenograph(X, k, metric, resolution, algorithm, n.start, n.iter, seed) — OPTIONAL: lines 57-86 of clustcells()
+ *       (search, Jaccard, filter, adjacency, Louvain) chained on the device in one call.
  */
 #include <R.h>
 #include <Rinternals.h>
@@ -213,6 +215,30 @@ SEXP _gficf_RunModularityClusteringHip(SEXP SNN, SEXP modularityFunctionS, SEXP 
   return out;
 }
 
+/* Optional: lines 57-86 of clustcells() in one call, nothing crossing PCIe between the steps.  X: numeric N x d matrix
+ * (data$pca$cells); metric as in _gficf_find_nn.  Returns the 0-based cluster of every cell (clusters by decreasing size),
+ * with attributes "modularity" and "n.edges". */
+SEXP _gficf_phenograph(SEXP XS, SEXP kS, SEXP metricS, SEXP resolutionS, SEXP algorithmS, SEXP nRandomStartsS, SEXP nIterationsS,
+                       SEXP randomSeedS) {
+  if (!Rf_isMatrix(XS) || TYPEOF(XS) != REALSXP) Rf_error("X must be a numeric matrix");
+  SEXP dim = Rf_getAttrib(XS, R_DimSymbol);
+  const int64_t N = INTEGER(dim)[0];
+  const int d = INTEGER(dim)[1];
+  SEXP out = PROTECT(Rf_allocVector(INTSXP, N));
+  int64_t n_clusters = 0, n_edges = 0;
+  double q = 0.0;
+  if (gficf_phenograph_host(ctx_get(), REAL(XS), N, d, N, Rf_asInteger(kS), Rf_asInteger(metricS), Rf_asReal(resolutionS),
+                            Rf_asInteger(algorithmS), Rf_asInteger(nRandomStartsS), Rf_asInteger(nIterationsS),
+                            Rf_asInteger(randomSeedS) & 0x7FFFFFFF, INTEGER(out), &n_clusters, &q, &n_edges) != GFICF_OK) {
+    UNPROTECT(1);
+    Rf_error("gficf_hip: %s", gficf_last_error());
+  }
+  Rf_setAttrib(out, Rf_install("modularity"), Rf_ScalarReal(q));
+  Rf_setAttrib(out, Rf_install("n.edges"), Rf_ScalarReal((double)n_edges));
+  UNPROTECT(1);
+  return out;
+}
+
 static const R_CallMethodDef HipCallEntries[] = {
     {"_gficf_rcpp_parallel_jaccard_coef", (DL_FUNC)&_gficf_rcpp_parallel_jaccard_coef, 2},
     {"_gficf_jaccard_coeff", (DL_FUNC)&_gficf_jaccard_coeff, 2},
@@ -222,6 +248,7 @@ static const R_CallMethodDef HipCallEntries[] = {
     {"_gficf_cluster_signatures", (DL_FUNC)&_gficf_cluster_signatures, 6},
     {"_gficf_transpose_csc", (DL_FUNC)&_gficf_transpose_csc, 4},
     {"_gficf_RunModularityClusteringHip", (DL_FUNC)&_gficf_RunModularityClusteringHip, 9},
+    {"_gficf_phenograph", (DL_FUNC)&_gficf_phenograph, 8},
     {NULL, NULL, 0}};
 
 /* Called from the package's R_init_gficf (reference src/RcppExports.cpp:94-97) next to the Rcpp entries:

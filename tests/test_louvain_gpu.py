@@ -199,6 +199,18 @@ def test_clustcells_end_to_end():
         want = np.asarray(M[:, data["cluster"] == data["cluster"][0]].sum(axis=1)).ravel()
         assert np.allclose(sig[:, j], want, rtol=1e-9, atol=1e-9)
         assert data["cell.adjacency"].shape == (N, N) and len(data["cell.graph"]["weight"]) > 0
+    # the fused entry (nothing crosses PCIe between the steps) gives the labels of the staged path
+    staged = gficf_amd.clustcells({"pca": {"cells": X}}, k=15, community_algo="louvian 2", verbose=False, n_start=2)
+    fused = gficf_amd.clustcells({"pca": {"cells": X}}, k=15, community_algo="louvian 2", verbose=False, n_start=2, store_graph=False)
+    assert np.array_equal(staged["community"], fused["community"]) and staged["modularity"] == fused["modularity"]
+    assert "cell.graph" not in fused
+    rngu = np.random.default_rng(4)
+    U = rngu.normal(size=(5000, 6))                                       # no structure: many near-ties on the way
+    lab = gficf_amd.phenograph(U, 20, "euclidean", 0.8, 1, 1, 10, 0)
+    A = gficf_amd.jaccard_adjacency(gficf_amd.clustcells_graph(U, 20, "euclidean"), 5000)
+    want = gficf_amd.run_modularity_clustering(A, 1, 0.8, 1, 1, 10, 0, False)
+    assert np.array_equal(lab, want) and lab.modularity == want.modularity
+    assert lab.n_edges == len(gficf_amd.clustcells_graph(U, 20, "euclidean")["weight"])
     with pytest.raises(ValueError):
         gficf_amd.clustcells({"pca": {"cells": X}}, community_algo="walktrap")
     with pytest.raises(ValueError):

@@ -30,5 +30,8 @@ for rep in range(2):
     t2 = time.perf_counter()
     cells = gficf_amd.transpose_gficf(data["gficf"])
     t3 = time.perf_counter()
+    fused = gficf_amd.phenograph(pca, k, "manhattan", 0.8, 1, 10, 10, 180582)
+    t4 = time.perf_counter()
     print(f"run {rep}: gficf() {1e3 * (t1 - t0):.1f} ms ({data['gficf'].shape[0]} genes kept), clustcells(k={k}, louvian 2) {1e3 * (t2 - t1):.1f} ms "
-          f"({len(set(data['cluster']))} clusters, Q {data['modularity']:.4f}), t(gficf) {1e3 * (t3 - t2):.1f} ms")
+          f"({len(set(data['cluster']))} clusters, Q {data['modularity']:.4f}), t(gficf) {1e3 * (t3 - t2):.1f} ms, "
+          f"phenograph() in one call {1e3 * (t4 - t3):.1f} ms ({fused.n_clusters} clusters)")
