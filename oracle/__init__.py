@@ -9,6 +9,10 @@ path, R is absent from this image and the reference's Jaccard translation unit n
 Rcpp / RcppParallel headers that are absent too, so neither restatement could be checked
 against the reference itself.  See ``jaccard_oracle.cpp`` / ``gficf_oracle.cpp`` headers.
 
+One part of the reference DOES build here and is used as the checker of scope row N4 (community detection) only:
+``src/ModularityOptimizer.cpp`` is plain C++ with its own ``main()`` under ``-DSTANDALONE``; ``build_ref()`` compiles it from
+where it lies into ``oracle/_ref/modularity_optimizer`` and ``modularity_reference()`` runs it (nothing of it is copied).
+
 Two independent writings of the same algorithm live here:
   * ``liboracle.so``  — C++ (``jaccard_oracle.cpp``, ``gficf_oracle.cpp``), built by
     ``make -C oracle``; this is also the timed CPU baseline.
