@@ -86,6 +86,20 @@ def test_live_against_the_reference_binary(N, d, k, C, res):
     assert np.array_equal(lab, again) and lab.modularity == again.modularity    # bit-reproducible
 
 
+def test_large_graph_200k_cells_against_the_reference():
+    """200 k cells, k = 30 (9 M adjacency entries): label conventions, reported Q, reproducibility, and — when the reference
+    binary is there — its modularity on the same matrix (a few seconds on one core)."""
+    A = knn_graph(200000, 20, 30, 40, seed=77, spread=2.0)
+    lab = gficf_amd.run_modularity_clustering(A, 1, 0.8, 1, 1, 10, 0, False)
+    check_labels(A, lab, 0.8)
+    again = gficf_amd.run_modularity_clustering(A, 1, 0.8, 1, 1, 10, 0, False)
+    assert np.array_equal(lab, again)
+    if oracle.build_ref() is not None:
+        ref_labels, printed = oracle.modularity_reference(A, 0.8, 1, 1, 10, 0)
+        q_ref = oracle_np.modularity_np(A, ref_labels, 0.8)
+        assert abs(q_ref - printed) < 6e-5 and lab.modularity >= q_ref - Q_TOL, (lab.modularity, q_ref)
+
+
 def test_hub_vertices_beyond_the_table():
     """Hubs with 3 000 and 30 000 neighbours, each neighbour its own community at the start: more than the 2048- and the
     8192-slot table hold — the second takes several passes over its edges.  Checked against the reference binary."""
