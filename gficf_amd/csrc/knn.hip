@@ -439,7 +439,24 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_tiles(const KnnTileArgs 
                   const int src = ((tid & 48) | (leader & 15)) << 2;
                   khi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)khi);
                   klo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)klo);
-                  if (leader >= 0) knn_reg_insert<REGL ? EPL : 1>(lst[r], ((u64)khi << 32) | (u64)klo);
+                  if (leader >= 0) {
+                    knn_reg_insert<REGL ? EPL : 1>(lst[r], ((u64)khi << 32) | (u64)klo);
+                    {
+                    // the list's k-th best may just have dropped: candidates it no longer admits need no round of their own
+                    // (near tiles — the pruned form's, the pivot assignment's — pass most of their candidates by the stale bound)
+                    uint32_t tn = (uint32_t)(lst[r][0] >> 32);
+#pragma unroll
+                    for (int h = 1; h < (REGL ? EPL : 1); ++h) tn = ((kk - 1) % EPL) == h ? (uint32_t)(lst[r][h] >> 32) : tn;
+                    tn = (uint32_t)__shfl((int)tn, (kk - 1) / EPL, 16);
+                    if (tn != 0xFFFFFFFFu && pass != 0) {
+                      const float tnew = sortable_f32(tn);
+                      uint32_t keep = 0;
+#pragma unroll
+                      for (int s = 0; s < 8; ++s) keep |= (dv[s] <= tnew) ? 1u << s : 0u;
+                      pass &= keep;
+                    }
+                    }
+                  }
                 }
                 // the row's k-th best: entry kk - 1 sits in lane (kk - 1) / EPL of the group
                 uint32_t th = (uint32_t)(lst[r][0] >> 32);
