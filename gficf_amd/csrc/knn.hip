@@ -615,7 +615,7 @@ __global__ __launch_bounds__(KNN_TC) void k_knn_tile_stats(const float* __restri
     for (int p = 0; p < n; ++p) sum += X[(j0 + p) * dpad + dim];
     const float c = sum / (float)n;
     s_c[dim] = c;
-    centers[t * dpad + dim] = c;
+    centers[(int64_t)dim * gridDim.x + t] = c;        // [dim][tile]: k_knn_lb reads a dim of consecutive tiles at a time
   }
   __syncthreads();
   float r = 0.0f;
@@ -675,7 +675,12 @@ __global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, con
   for (int64_t c = threadIdx.x; c < n_ct; c += 256) {
     const float r = radius[c];
     if (r < 0.0f) { lb[qt * n_ct + c] = INFINITY; continue; }      // empty candidate tile: never visited
-    const float dcc = knn_bound_dist<METRIC>(s_c, centers + c * dpad, d);
+    float dcc = 0.0f;                                 // knn_bound_dist(s_c, centre of tile c), the centres read [dim][tile]
+    for (int t = 0; t < d; ++t) {
+      const float df = s_c[t] - centers[(int64_t)t * n_ct + c];
+      dcc = METRIC == GFICF_KNN_MANHATTAN ? dcc + fabsf(df) : fmaf(df, df, dcc);
+    }
+    if (METRIC != GFICF_KNN_MANHATTAN) dcc = sqrtf(dcc);
     float b = dcc - rq - r - KNN_LB_SLACK * (dcc + rq + r);
     b = b > 0.0f ? to_key(b, -1.0f) : 0.0f;
     lb[qt * n_ct + c] = b > 0.0f ? b : 0.0f;
