@@ -68,3 +68,26 @@ def test_product_package_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M), f
                 assert "liboracle" not in txt, f
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r01_bench.json is the line bench.py printed on the GPU box: the keys the driver and the judge read are there,
+    the roofline and the CPU baseline objects included, and the numbers are self-consistent."""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench.json")
+    d = json.load(open(path))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and d["data"] == "synthetic"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 0.01
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    edges = d["config"]["edges_per_step"]
+    assert abs(d["value"] - edges / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["checked_vs_oracle"] is True and d["gficf"]["checked_vs_oracle"] is True and d["knn"]["checked_vs_oracle"] is True
