@@ -428,6 +428,19 @@ def main():
                                "note": "t(gficf): kept genes x cells CSC -> cells x genes CSC, 28 B/entry (4 count + 12 read + 12 written)",
                                "checked_vs_stable_sort": bool(torch.equal(t_idx, cell[order]) and torch.equal(t_val, ws["out_x"][:kn][order]))}
             del order, cell, tws, t_idx, t_val
+            # next row N3, first half: cluster signatures (R/clustCells.R:121-123) of the same matrix, 30 synthetic clusters
+            n_cl = 30
+            cl = (torch.arange(Nc, device=dev, dtype=torch.int64) * 2654435761 % n_cl).to(torch.int32)
+            sig = torch.zeros((n_cl, gk), dtype=torch.float64, device=dev)
+            run_s = lambda: (sig.zero_(), ops.cluster_signatures(gk, Nc, ws["out_colptr"], ws["out_rowidx"][:kn], ws["out_x"][:kn], cl, n_cl, sig))
+            t_sig = time_kernel_ms(torch, run_s, 10)
+            want = torch.zeros((n_cl, gk), dtype=torch.float64, device=dev)
+            cell_of = torch.repeat_interleave(torch.arange(Nc, device=dev), ws["out_colptr"][1:] - ws["out_colptr"][:-1])
+            want.index_put_((cl[cell_of].long(), ws["out_rowidx"][:kn].long()), ws["out_x"][:kn], accumulate=True)
+            gf["cluster_signatures"] = {"ms": round(t_sig, 4), "clusters": n_cl, "algorithmic_GBps": round(12 * kn / t_sig / 1e6, 1),
+                                        "note": "G x C sums of gficf[, cluster == c] (12 B/entry read; cells grouped by cluster, sums kept in LDS per workgroup)",
+                                        "checked_vs_torch": bool(torch.allclose(sig, want, rtol=1e-9, atol=1e-12))}
+            del cell_of, want, sig
             if not args.no_cpu_baseline:
                 import oracle
 

@@ -623,8 +623,88 @@ __global__ __launch_bounds__(256) void k_cluster_signatures(int64_t G, int64_t n
     const int64_t p0 = colptr[c], p1 = colptr[c + 1];
     for (int64_t p = p0 + lane; p < p1; p += 64) {
       const int32_t g = rowidx[p];
-      if (g >= 0 && g < G) atomicAdd(col + g, x[p]);
+      if (g >= 0 && g < G) unsafeAtomicAdd(col + g, x[p]);      // the hardware f64 add (atomicAdd compiles to a compare-and-swap loop)
     }
+  }
+}
+
+// The same sums with the additions kept on the CU: the cells are grouped by cluster first (counting sort of the cell ids),
+// a workgroup takes a slice of ONE cluster's cells and adds their entries into G doubles of LDS (ds_add_f64), then adds
+// its G partial sums to the result — a few hundred global atomics per gene instead of one per stored entry (the plain
+// kernel above sits at the L2's rate for contended f64 atomics, 43 G/s).  Needs G doubles of LDS: G <= SIG_MAX_G.
+constexpr int SIG_MAX_G = 18432;          // 144 KiB
+constexpr int SIG_BINS = 4096;            // clusters binned in LDS while grouping the cells
+
+__global__ __launch_bounds__(256) void k_sig_count(int64_t n_cells, const int32_t* __restrict__ cluster, int32_t C, int64_t* __restrict__ cnt,
+                                                   uint32_t* __restrict__ status) {
+  __shared__ uint32_t s_n[SIG_BINS];
+  const bool binned = C <= SIG_BINS;
+  if (binned) {
+    for (int t = threadIdx.x; t < C; t += 256) s_n[t] = 0u;
+    __syncthreads();
+  }
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n_cells; c += (int64_t)gridDim.x * 256) {
+    const int32_t cl = cluster[c];
+    if (cl < 0 || cl >= C) { atomicOr(status, GFICF_ST_BAD_CSC); continue; }
+    if (binned) atomicAdd(&s_n[cl], 1u);
+    else atomicAdd((unsigned long long*)&cnt[cl], 1ull);
+  }
+  if (binned) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < C; t += 256)
+      if (s_n[t]) atomicAdd((unsigned long long*)&cnt[t], (unsigned long long)s_n[t]);
+  }
+}
+
+// order[start[cl] ..] = the cells of cluster cl (in no particular order: only the order of the additions depends on it)
+__global__ __launch_bounds__(256) void k_sig_fill(int64_t n_cells, const int32_t* __restrict__ cluster, int32_t C, const int64_t* __restrict__ start,
+                                                  uint32_t* __restrict__ cursor, int32_t* __restrict__ order) {
+  __shared__ uint32_t s_n[SIG_BINS], s_base[SIG_BINS];
+  const bool binned = C <= SIG_BINS;
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int32_t cl = c < n_cells ? cluster[c] : -1;
+  const bool ok = cl >= 0 && cl < C;
+  if (!binned) {
+    if (ok) order[start[cl] + atomicAdd(&cursor[cl], 1u)] = (int32_t)c;
+    return;
+  }
+  for (int t = threadIdx.x; t < C; t += 256) s_n[t] = 0u;
+  __syncthreads();
+  uint32_t mine = 0;
+  if (ok) mine = atomicAdd(&s_n[cl], 1u);
+  __syncthreads();
+  for (int t = threadIdx.x; t < C; t += 256)
+    if (s_n[t]) s_base[t] = atomicAdd(&cursor[t], s_n[t]);
+  __syncthreads();
+  if (ok) order[start[cl] + s_base[cl] + mine] = (int32_t)c;
+}
+
+// grid (slices, C): workgroup (b, cl) sums slice b of cluster cl's cells
+__global__ __launch_bounds__(256) void k_sig_sum(int64_t G, const int64_t* __restrict__ colptr, const int32_t* __restrict__ rowidx,
+                                                 const double* __restrict__ x, const int64_t* __restrict__ start,
+                                                 const int32_t* __restrict__ order, double* __restrict__ out) {
+  extern __shared__ double s_acc[];
+  const int cl = blockIdx.y;
+  const int64_t lo0 = start[cl], n = start[cl + 1] - lo0;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = lo0 + (int64_t)blockIdx.x * per, hi = lo + per < lo0 + n ? lo + per : lo0 + n;
+  if (lo >= hi) return;                                   // uniform over the workgroup
+  for (int64_t g = threadIdx.x; g < G; g += 256) s_acc[g] = 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t t = lo + wave; t < hi; t += 4) {
+    const int64_t c = order[t];
+    const int64_t p0 = colptr[c], p1 = colptr[c + 1];
+    for (int64_t p = p0 + lane; p < p1; p += 64) {
+      const int32_t g = rowidx[p];
+      if (g >= 0 && g < G) unsafeAtomicAdd(&s_acc[g], x[p]);       // ds_add_f64
+    }
+  }
+  __syncthreads();
+  double* const col = out + (int64_t)cl * G;
+  for (int64_t g = threadIdx.x; g < G; g += 256) {
+    const double v = s_acc[g];
+    if (v != 0.0) unsafeAtomicAdd(col + g, v);
   }
 }
 
@@ -765,6 +845,36 @@ int gficf_cluster_signatures_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, 
   GFICF_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(double) * (size_t)G * (size_t)C, ctx->stream));
   if (n_cells == 0) return GFICF_OK;
   if (!d_colptr || !d_rowidx || !d_x || !d_cluster) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (G <= SIG_MAX_G && C <= 65535 && n_cells >= 1024) {
+    // grouped form: scratch = start[C + 1] | cursor[C] | order[n_cells] from the context's pool (stream-ordered like
+    // everything else the context enqueues)
+    const size_t off_cur = ((size_t)(C + 1) * 8 + 255) & ~(size_t)255, off_ord = (off_cur + (size_t)C * 4 + 255) & ~(size_t)255;
+    void* scratch = nullptr;
+    GFICF_HIP_CHECK(gficf_pool_get(ctx, 3, off_ord + (size_t)n_cells * 4, &scratch));
+    int64_t* const start = (int64_t*)scratch;
+    uint32_t* const cursor = (uint32_t*)((char*)scratch + off_cur);
+    int32_t* const order = (int32_t*)((char*)scratch + off_ord);
+    GFICF_HIP_CHECK(hipMemsetAsync(scratch, 0, off_ord, ctx->stream));
+    const unsigned cb = (unsigned)(gficf_ceil_div(n_cells, 256) < 512 ? gficf_ceil_div(n_cells, 256) : 512);
+    hipLaunchKernelGGL(k_sig_count, dim3(cb), dim3(256), 0, ctx->stream, n_cells, d_cluster, C, start, ctx->d_status);
+    const int rc = gficf_exclusive_scan_i64(ctx, start, (int64_t)C + 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sig_fill, dim3((unsigned)gficf_ceil_div(n_cells, 256)), dim3(256), 0, ctx->stream, n_cells, d_cluster, C, start, cursor,
+                       order);
+    static bool attr_set[64] = {};
+    if (!attr_set[ctx->device & 63]) {
+      GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_sig_sum, hipFuncAttributeMaxDynamicSharedMemorySize, SIG_MAX_G * (int)sizeof(double)));
+      attr_set[ctx->device & 63] = true;
+    }
+    // slices per cluster: enough workgroups to fill the chip a few times over, whatever the number of clusters
+    int64_t slices = gficf_ceil_div((int64_t)ctx->num_cus * 4, (int64_t)C);
+    if (slices < 1) slices = 1;
+    if (slices > 1024) slices = 1024;
+    hipLaunchKernelGGL(k_sig_sum, dim3((unsigned)slices, (unsigned)C), dim3(256), (size_t)G * sizeof(double), ctx->stream, G, d_colptr, d_rowidx, d_x,
+                       start, order, d_out);
+    GFICF_HIP_CHECK(hipGetLastError());
+    return GFICF_OK;
+  }
   int64_t blocks = gficf_ceil_div(n_cells, 4);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
   hipLaunchKernelGGL(k_cluster_signatures, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, G, n_cells, d_colptr, d_rowidx,

@@ -324,6 +324,23 @@ def test_cluster_signatures_next_row_n3():
     assert got1.shape[1] == 1 and np.allclose(got1[:, 0], np.asarray(res["gficf"].sum(axis=1)).ravel(), rtol=1e-10)
 
 
+@pytest.mark.parametrize("G,N,C", [(800, 500, 5), (20000, 3000, 11), (2500, 30000, 6000), (3000, 20000, 40)])
+def test_cluster_signatures_both_forms(G, N, C):
+    """The plain form (few cells, or more genes than LDS holds) and the grouped form (cells sorted by cluster, sums kept in LDS;
+    more clusters than the grouping bins at C = 6000) against scipy; labels that are not 0..C-1 strings."""
+    cp, ri, x = synth.counts_csc(G, N, seed=G + C, median_frac=0.02)
+    M = sp.csc_matrix((x * 0.25, ri, cp), shape=(G, N))
+    lab = np.array([f"t{v}" for v in (synth.rand_u64(5, np.arange(N)) % np.uint64(C)).astype(int)])
+    got, labels = gficf_amd.cluster_signatures(M, lab)
+    assert got.shape == (G, len(labels)) and len(labels) == len(set(lab))
+    onehot = sp.csr_matrix((np.ones(N), (np.arange(N), np.unique(lab, return_inverse=True)[1])), shape=(N, len(labels)))
+    want = np.asarray((M @ onehot).todense())
+    uniq = np.unique(lab)
+    col_of = {u: j for j, u in enumerate(uniq)}
+    want = want[:, [col_of[u] for u in labels]]
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("G,N,seed", [(3000, 2000, 41), (500, 7, 3), (40000, 300, 5), (1200, 5000, 9)])
 def test_transpose_next_row_n3(G, N, seed):
     """N3: data$pca$cells = t(data$gficf) (R/dimensinalityReduction.R:33,100): exact structure and values, cells ascending
