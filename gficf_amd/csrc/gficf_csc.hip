@@ -68,7 +68,7 @@ __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __res
       v2d xa[GROUPS], xb[GROUPS];
 #pragma unroll
       for (int t = 0; t < GROUPS; ++t) {                     // streamed once: non-temporal
-        g[t] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(rowidx + q + t * STRIDE));
+        g[t] = *reinterpret_cast<const v4i*>(rowidx + q + t * STRIDE);      // kept in the Infinity Cache for the kept-count pass
         xa[t] = HAS_X ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(x + q + t * STRIDE)) : v2d{1.0, 1.0};
         xb[t] = HAS_X ? __builtin_nontemporal_load(reinterpret_cast<const v2d*>(x + q + t * STRIDE + 2)) : v2d{1.0, 1.0};
       }
