@@ -77,7 +77,7 @@ transpose_hip = function(M)
 #   community <- RunModularityClusteringHip(igraph::as_adjacency_matrix(g, attr = "weight", sparse = T), 1, resolution, 1, n.start, n.iter, seed, verbose)
 # (or with jaccard_adjacency_hip(relations, n) as the matrix).  A deterministic parallel Louvain on the same modularity
 # (resolution as in the reference, diagonal ignored): labels are NOT those of the seeded sequential optimiser, the
-# modularity is (tested) within 0.005 of it.  n.start starts are run and the best kept; random.seed seeds the one arbitrary
+# modularity is (tested) within 0.01 of it — the spread the reference itself shows between seeds.  n.start starts are run and the best kept; random.seed seeds the one arbitrary
 # choice of the device algorithm (how the vertices are split into sub-rounds), so equal arguments give equal results.
 RunModularityClusteringHip <- function(SNN = matrix(), modularity = 1, resolution = 0.8, algorithm = 1, n.start = 10, n.iter = 10,
                                        random.seed = 0, print.output = TRUE, temp.file.location = NULL, edge.file.name = "")

@@ -21,7 +21,9 @@ from oracle import oracle_np
 
 pytestmark = pytest.mark.gpu
 
-Q_TOL = 0.005          # device modularity >= reference modularity - Q_TOL (observed: within 0.0013, often above)
+Q_TOL = 0.01           # device modularity >= reference modularity - Q_TOL.  Measured over a sweep of 72 kNN -> Jaccard graphs
+                       # (tools/louvain_sweep.py): device - reference(seed 0) in [-0.0065, +0.0345], mean +0.0004; the reference's
+                       # own results on the worst of them span 0.012 across 12 seeds, which is what sets the tolerance
 
 
 def golden(golden_dir):
