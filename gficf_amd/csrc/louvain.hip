@@ -574,10 +574,10 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   if (N > INT32_MAX) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "more than 2^31 - 1 vertices");
   if (ws_bytes < gficf_louvain_workspace_bytes(N, nnz))
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "workspace too small: %zu < %zu bytes", ws_bytes, gficf_louvain_workspace_bytes(N, nnz));
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};                 // per device: the attribute belongs to the device's copy of the kernel
+  if (!attr_set[ctx->device & 63]) {
     GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_lv_move_big<LV_BIG_SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_BIG_SLOTS * 12));
-    attr_set = true;
+    attr_set[ctx->device & 63] = true;
   }
   LvWs w;
   lv_carve(&w, d_ws, N, nnz);
