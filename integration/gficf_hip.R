@@ -97,3 +97,40 @@ phenograph_hip = function(X, k = 15, metric = "manhattan", resolution = 0.8, alg
   .Call(`_gficf_phenograph`, as.matrix(X) + 0, as.integer(k), m, resolution, as.integer(algorithm), as.integer(n.start),
         as.integer(n.iter), as.integer(seed))
 }
+
+# Optional: clustcells() with every step on the device.  Same arguments and the same fields set on `data` as the reference's
+# clustcells() (R/clustCells.R:46-126); only the Seurat-optimiser choices of community.algo are served ("louvian" is run
+# as plain Louvain, resolution 1: the reference calls igraph::cluster_louvain there), the igraph / leidenalg ones are not.
+#   store.graph = TRUE : find_nn_hip -> rcpp_parallel_jaccard_coef (the replaced entry) -> weight > 0 -> jaccard_adjacency_hip
+#                        -> RunModularityClusteringHip; data$cell.graph is built with igraph as before
+#   store.graph = FALSE: phenograph_hip, one call, nothing crossing PCIe between the steps
+clustcells_hip = function(data, from.embedded = F, k = 15, dist.method = "manhattan", nt = 2, community.algo = "louvian 2",
+                          store.graph = T, seed = 180582, verbose = TRUE, resolution = 0.8, n.start = 10, n.iter = 10)
+{
+  community.algo = base::match.arg(arg = community.algo, choices = c("louvian", "louvian 2", "louvian 3"), several.ok = F)
+  if (from.embedded) {
+    if (is.null(data$embedded)) {stop("First run runReduction to embed your cells")}
+    X = as.matrix(data$embedded[, c(1, 2)])
+  } else {
+    if (is.null(data$pca)) {stop("First run runPCA or runLSA to reduce dimensionality")}
+    X = as.matrix(data$pca$cells)
+  }
+  algorithm = if (community.algo == "louvian 3") 2L else 1L
+  if (community.algo == "louvian") {resolution = 1; n.start = 1; seed = 0}
+  if (store.graph) {
+    neigh = find_nn_hip(X, k + 1, dist.method)$idx[, -1]
+    relations = rcpp_parallel_jaccard_coef(neigh, verbose)
+    relations = as.data.frame(relations[relations[, 3] > 0, ])
+    colnames(relations) = c("from", "to", "weight")
+    adjacency = jaccard_adjacency_hip(relations, nrow(X))
+    community = RunModularityClusteringHip(adjacency, 1, resolution, algorithm, n.start, n.iter, seed, verbose) + 1
+    data$cell.graph = igraph::graph.data.frame(relations, directed = FALSE)
+  } else {
+    community = as.integer(phenograph_hip(X, k, dist.method, resolution, algorithm, n.start, n.iter, seed)) + 1L
+  }
+  data$community = community
+  data$embedded$cluster = as.character(community)
+  data$cluster.gene.rnk = cluster_signatures_hip(data$gficf, data$embedded$cluster)
+  tsmessage(paste("Detected Clusters:", length(unique(data$embedded$cluster))), verbose = verbose)
+  return(data)
+}
