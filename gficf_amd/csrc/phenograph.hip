@@ -11,15 +11,16 @@
 
 namespace {
 
-struct DevBufs {                 // everything this call allocates, released on every way out
-  void* p[16];
-  int n = 0;
-  hipError_t get(void** out, size_t bytes) {
-    hipError_t e = hipMalloc(out, bytes ? bytes : 1);
-    if (e == hipSuccess) p[n++] = *out;
-    return e;
+// One grow-only block of the context's pool carved into the call's buffers (no allocation once the pool has grown).
+struct Carver {
+  char* base = nullptr;
+  size_t off = 0;
+  template <typename T> T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
   }
-  ~DevBufs() { for (int i = 0; i < n; ++i) (void)hipFree(p[i]); }
 };
 
 }  // namespace
@@ -42,23 +43,31 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
   const int kk = k + 1;
   const int64_t cap = N * (int64_t)k;
   const size_t knn_ws = gficf_knn_workspace_bytes(ctx, N, N, kk), adj_ws = gficf_adjacency_workspace_bytes(N, cap);
-  DevBufs bufs;
-  void *d_X = nullptr, *d_P = nullptr, *d_kws = nullptr, *d_idx = nullptr, *d_table = nullptr, *d_u = nullptr, *d_cptr = nullptr, *d_e3 = nullptr;
-  void *d_aws = nullptr, *d_indptr = nullptr, *d_indices = nullptr, *d_ax = nullptr, *d_lab = nullptr, *d_lws = nullptr;
-  hipError_t e = bufs.get(&d_X, sizeof(double) * (size_t)ld * (size_t)d);
-  if (e == hipSuccess) e = bufs.get(&d_P, sizeof(float) * (size_t)N * (size_t)dpad);
-  if (e == hipSuccess) e = bufs.get(&d_kws, knn_ws);
-  if (e == hipSuccess) e = bufs.get(&d_idx, sizeof(int32_t) * (size_t)N * (size_t)kk);
-  if (e == hipSuccess) e = bufs.get(&d_table, sizeof(int32_t) * (size_t)N * (size_t)kpad);
-  if (e == hipSuccess) e = bufs.get(&d_u, sizeof(uint16_t) * (size_t)cap);
-  if (e == hipSuccess) e = bufs.get(&d_cptr, sizeof(int64_t) * ((size_t)N + 1));
-  if (e == hipSuccess) e = bufs.get(&d_e3, sizeof(double) * 3 * (size_t)cap);
-  if (e == hipSuccess) e = bufs.get(&d_aws, adj_ws);
-  if (e == hipSuccess) e = bufs.get(&d_indptr, sizeof(int64_t) * ((size_t)N + 1));
-  if (e == hipSuccess) e = bufs.get(&d_indices, sizeof(int32_t) * 2 * (size_t)cap);
-  if (e == hipSuccess) e = bufs.get(&d_ax, sizeof(double) * 2 * (size_t)cap);
-  if (e == hipSuccess) e = bufs.get(&d_lab, sizeof(int32_t) * (size_t)N);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_X, X, sizeof(double) * (size_t)ld * (size_t)d, hipMemcpyHostToDevice, ctx->stream);
+  void *d_X, *d_P, *d_kws, *d_idx, *d_table, *d_u, *d_cptr, *d_e3, *d_aws, *d_indptr, *d_indices, *d_ax, *d_lab;
+  Carver cv;
+  for (int pass = 0; pass < 2; ++pass) {               // pass 0 sizes the block, pass 1 hands the pointers out
+    cv.off = 0;
+    d_X = cv.take<double>((size_t)ld * (size_t)d);
+    d_P = cv.take<float>((size_t)N * (size_t)dpad);
+    d_kws = cv.take<char>(knn_ws);
+    d_idx = cv.take<int32_t>((size_t)N * (size_t)kk);
+    d_table = cv.take<int32_t>((size_t)N * (size_t)kpad);
+    d_u = cv.take<uint16_t>((size_t)cap);
+    d_cptr = cv.take<int64_t>((size_t)N + 1);
+    d_e3 = cv.take<double>(3 * (size_t)cap);
+    d_aws = cv.take<char>(adj_ws);
+    d_indptr = cv.take<int64_t>((size_t)N + 1);
+    d_indices = cv.take<int32_t>(2 * (size_t)cap);
+    d_ax = cv.take<double>(2 * (size_t)cap);
+    d_lab = cv.take<int32_t>((size_t)N);
+    if (pass == 0) {
+      void* blk = nullptr;
+      const hipError_t e0 = gficf_pool_get(ctx, 0, cv.off + 256, &blk);
+      if (e0 != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_phenograph_host: %s", hipGetErrorString(e0));
+      cv.base = (char*)blk;
+    }
+  }
+  hipError_t e = hipMemcpyAsync(d_X, X, sizeof(double) * (size_t)ld * (size_t)d, hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_phenograph_host: %s", hipGetErrorString(e));
 
   // neighbours (column 0 = the cell itself is dropped by starting at column 1), edges with weight > 0, adjacency matrix
@@ -83,7 +92,8 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
 
   // communities
   const size_t lws = gficf_louvain_workspace_bytes(N, h_cnt[1]);
-  e = bufs.get(&d_lws, lws);
+  void* d_lws = nullptr;
+  e = gficf_pool_get(ctx, 1, lws, &d_lws);
   if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_phenograph_host: %s", hipGetErrorString(e));
   rc = gficf_louvain_device(ctx, N, (const int64_t*)d_indptr, (const int32_t*)d_indices, (const double*)d_ax, h_cnt[1], resolution, algorithm,
                             n_start, n_iter, seed, (int32_t*)d_lab, n_clusters, modularity, d_lws, lws);
