@@ -43,6 +43,7 @@ SIGNATURES = {
     "gficf_ctx_set_stream": (_int, [_vp, _vp]),
     "gficf_ctx_sync": (_int, [_vp]),
     "gficf_ctx_set_gficf_options": (_int, [_vp, _int, _int]),
+    "gficf_ctx_set_louvain_options": (_int, [_vp, _int]),
     "gficf_last_error": (ctypes.c_char_p, []),
     "gficf_jaccard_host": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _int]),
     "gficf_jaccard_coeff_host": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _int]),

@@ -318,8 +318,8 @@ def run_modularity_clustering(SNN, modularity: int = 1, resolution: float = 0.8,
     Louvain on the reference's objective — standard modularity with a resolution parameter, diagonal ignored — instead
     of its sequential, seeded one.  ``n_start`` starts each begin from singletons and the best modularity is kept, as in the
     reference; what a start varies is the seed (from ``random_seed`` and the start number) of the hash that splits the
-    vertices into sub-round classes — the result is a function of the arguments, never of scheduling.  ``modularity`` must be 1 and ``algorithm`` 1 (Louvain) or 2 (Louvain with multilevel
-    refinement).
+    vertices into sub-round classes — the result is a function of the arguments, never of scheduling.  ``modularity`` 1 (standard) or 2 (alternative: unit node weights, resolution <= 1), ``algorithm`` 1 (Louvain) or 2
+    (Louvain with multilevel refinement).
 
     ``SNN`` must be symmetric (the reference reads its strict lower triangle and mirrors it).
 
@@ -328,8 +328,10 @@ def run_modularity_clustering(SNN, modularity: int = 1, resolution: float = 0.8,
     """
     import scipy.sparse as sp
 
-    if modularity != 1:
-        raise ValueError("only the standard modularity function (1) is provided")
+    if modularity not in (1, 2):
+        raise ValueError("Modularity parameter must be equal to 1 or 2.")
+    if modularity == 2 and resolution > 1.0:
+        raise ValueError("error: resolution<1 for alternative modularity")
     if algorithm not in (1, 2):
         raise ValueError("algorithm must be 1 (Louvain) or 2 (Louvain with multilevel refinement)")
     if n_start < 1 or n_iter < 1:
@@ -347,8 +349,13 @@ def run_modularity_clustering(SNN, modularity: int = 1, resolution: float = 0.8,
     labels = np.zeros(max(N, 1), dtype=np.int32)
     nc, q = ctypes.c_int64(0), ctypes.c_double(0.0)
     ctx = ctx or default_context()
-    check(_lib.load().gficf_louvain_host(ctx.handle, N, _np_ptr(indptr), 1, _np_ptr(indices), _np_ptr(x), float(resolution), int(algorithm),
-                                         int(n_start), int(n_iter), int(random_seed) & 0x7FFFFFFF, _np_ptr(labels), ctypes.byref(nc), ctypes.byref(q)))
+    L = _lib.load()
+    check(L.gficf_ctx_set_louvain_options(ctx.handle, int(modularity)))
+    try:
+        check(L.gficf_louvain_host(ctx.handle, N, _np_ptr(indptr), 1, _np_ptr(indices), _np_ptr(x), float(resolution), int(algorithm),
+                                   int(n_start), int(n_iter), int(random_seed) & 0x7FFFFFFF, _np_ptr(labels), ctypes.byref(nc), ctypes.byref(q)))
+    finally:
+        L.gficf_ctx_set_louvain_options(ctx.handle, 1)
     out = labels[:N].view(ClusterLabels)
     out.modularity, out.n_clusters = q.value, nc.value
     if print_output:

@@ -37,6 +37,9 @@ struct gficf_ctx {
   // getIdfW(type = classic / prob / smooth) R/gficf.R:89-91, l.norm(norm = l2 / l1) R/gficf.R:100
   int icf_type = 0;
   int norm_l1 = 0;
+  // RunModularityClustering(modularity = 1 standard / 2 alternative), reference src/RModularityOptimizer.cpp:36,100 (clustcells()
+  // always passes 1)
+  int lv_modularity_fn = 1;
   gficf_host_plan* plan = nullptr;
   gficf_edge_plan* edge_plan = nullptr;
   gficf_adj_plan* adj_plan = nullptr;

@@ -108,6 +108,13 @@ int gficf_ctx_set_gficf_options(gficf_ctx* ctx, int icf_type, int norm) {
   return GFICF_OK;
 }
 
+int gficf_ctx_set_louvain_options(gficf_ctx* ctx, int modularity_function) {
+  if (!ctx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ctx is NULL");
+  if (modularity_function != 1 && modularity_function != 2) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "Modularity parameter must be equal to 1 or 2.");
+  ctx->lv_modularity_fn = modularity_function;
+  return GFICF_OK;
+}
+
 int gficf_ctx_sync(gficf_ctx* ctx) {
   GFICF_CTX_ENTER(ctx);
   GFICF_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -35,7 +35,8 @@
 //   * a vertex whose every option has a negative gain leaves for an unused cluster (:546-550): its own id, if free.
 //   * n_start "random starts": each start varies the seed of the class hash (the only arbitrary choice there is); the best
 //     modularity wins, as in the reference.  Start 0 with seed 0 is the plain run.
-// Not reproduced: algorithm 3 (SLM), the alternative modularity function (2).
+//   * the alternative modularity function (2): unit node weights, the resolution as given — a context option.
+// Not reproduced: algorithm 3 (SLM).
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -111,6 +112,11 @@ __global__ __launch_bounds__(256) void k_lv_vertex_weight(LvGraph g, u64* __rest
   if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(two_w, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+}
+
+__global__ __launch_bounds__(256) void k_lv_fill_u64(int64_t n, u64 v, u64* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = v;
 }
 
 // singletons: every vertex its own community
@@ -536,7 +542,7 @@ static int lv_sub_rounds(int64_t n) {
 struct LvQ { double q; u64 in_w; };
 
 // Q of the current labels on graph g (self = weight already folded into the vertices), deterministic.
-static int lv_quality(gficf_ctx* ctx, const LvGraph& g, const LvWs& w, u64 self_w, double two_w, double resolution, double* q_out, u64* in_out) {
+static int lv_quality(gficf_ctx* ctx, const LvGraph& g, const LvWs& w, u64 self_w, double two_w, double q_coef, double* q_out, u64* in_out) {
   GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 1, 0, sizeof(u64), ctx->stream));
   hipLaunchKernelGGL(k_lv_internal, dim3(lv_blocks(g.n, 4) < 2048u ? lv_blocks(g.n, 4) : 2048u), dim3(256), 0, ctx->stream, g, w.comm, w.scalars + 1);
   hipLaunchKernelGGL(k_lv_sumsq, dim3(1), dim3(1024), 0, ctx->stream, g.n, w.K, (double*)(w.scalars + 3));
@@ -546,7 +552,7 @@ static int lv_quality(gficf_ctx* ctx, const LvGraph& g, const LvWs& w, u64 self_
   double sq;
   memcpy(&sq, &h[3], sizeof(double));
   *in_out = h[1];
-  *q_out = ((double)(h[1] + self_w)) / two_w - resolution * sq / (two_w * two_w);
+  *q_out = ((double)(h[1] + self_w)) / two_w - q_coef * sq;          // sq = sum of squared community totals (fixed point)
   return GFICF_OK;
 }
 
@@ -602,7 +608,13 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
     *n_clusters = N;
     return GFICF_OK;
   }
-  const double r = resolution / two_w;
+  // standard modularity: node weight = degree, gain coefficient resolution / 2W, Q's second term resolution * sum K^2 / (2W)^2;
+  // alternative (modularity function 2): node weight = 1 (2^32 in fixed point), coefficient = the resolution itself
+  const bool alt = ctx->lv_modularity_fn == 2;
+  if (alt && resolution > 1.0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "error: resolution<1 for alternative modularity");
+  if (alt) hipLaunchKernelGGL(k_lv_fill_u64, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, (u64)LV_SCALE, w.kv0);
+  const double r = alt ? resolution / LV_SCALE : resolution / two_w;
+  const double q_coef = alt ? resolution / (LV_SCALE * two_w) : resolution / (two_w * two_w);
   double q_final = 0.0;
   bool have_labels = false;
   int64_t n_labels = 0;                          // labels of the previous pass lie in [0, n_labels)
@@ -627,7 +639,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
     hipLaunchKernelGGL(k_lv_list_big, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g, w.big, (unsigned*)(w.scalars + 4));
     unsigned h_cnt[2] = {0, 0};                  // vertices of middle and of large degree
     GFICF_HIP_CHECK(hipMemcpyAsync(h_cnt, w.scalars + 4, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
-    const int rc2 = lv_quality(ctx, g, w, self_w, two_w, resolution, &q_prev, &in_w);
+    const int rc2 = lv_quality(ctx, g, w, self_w, two_w, q_coef, &q_prev, &in_w);
     n_mid = h_cnt[0]; n_large = h_cnt[1];
     return rc2;
   };
@@ -653,7 +665,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
       unsigned moved = 0;
       GFICF_HIP_CHECK(hipMemcpyAsync(&moved, w.scalars + 2, sizeof(unsigned), hipMemcpyDeviceToHost, st));
       double q; u64 in_now;
-      const int rc2 = lv_quality(ctx, g, w, self_w, two_w, resolution, &q, &in_now);
+      const int rc2 = lv_quality(ctx, g, w, self_w, two_w, q_coef, &q, &in_now);
       if (rc2) return rc2;
       if (moved == 0) break;
       if (q < q_prev) {                          // simultaneous moves made it worse: undo the iteration, the level ends

@@ -292,6 +292,11 @@ int gficf_csc_transpose_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* c
  * The matrix must be symmetric (an undirected graph's adjacency matrix is; the reference reads only its strict lower
  * triangle and mirrors it, which is the same thing then).  Edge weights must be finite and in [0, 2^20].  GFICF_ERR_UNSUPPORTED only if one hash class of a vertex's neighbouring
  * communities overflows the 8192-slot table (vertices of any degree are handled in several passes; not observed). */
+/* The optimiser's other quality function (RunModularityClustering(modularity = 2), src/RModularityOptimizer.cpp:36,100,
+ * src/ModularityOptimizer.cpp:799-805): every node weighs 1 instead of its degree and the resolution is not divided by 2W,
+ *   Q = (1/2W) * [ sum_ij A_ij delta(c_i, c_j) - resolution * sum_c n_c^2 ],   n_c = nodes in c;   resolution <= 1.
+ * clustcells() always passes 1, which is the default of a new context. */
+int gficf_ctx_set_louvain_options(gficf_ctx* ctx, int modularity_function);
 size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz);
 int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, const int32_t* d_indices,
                          const double* d_x, int64_t nnz, double resolution, int algorithm, int n_start,

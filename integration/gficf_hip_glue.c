@@ -188,7 +188,9 @@ SEXP _gficf_transpose_csc(SEXP iS, SEXP pS, SEXP xS, SEXP dimS) {
  * decreasing size, as the reference does (:171-173). */
 SEXP _gficf_RunModularityClusteringHip(SEXP SNN, SEXP modularityFunctionS, SEXP resolutionS, SEXP algorithmS, SEXP nRandomStartsS,
                                        SEXP nIterationsS, SEXP randomSeedS, SEXP printOutputS, SEXP edgefilenameS) {
-  if (Rf_asInteger(modularityFunctionS) != 1) Rf_error("Modularity parameter must be equal to 1 on this path.");
+  const int modularityFunction = Rf_asInteger(modularityFunctionS);
+  if (modularityFunction != 1 && modularityFunction != 2) Rf_error("Modularity parameter must be equal to 1 or 2.");
+  if (modularityFunction == 2 && Rf_asReal(resolutionS) > 1.0) Rf_error("error: resolution<1 for alternative modularity");
   const int algorithm = Rf_asInteger(algorithmS);
   if (algorithm != 1 && algorithm != 2) Rf_error("Algorithm for modularity optimization must be 1 or 2 on this path");
   if (Rf_asInteger(nRandomStartsS) < 1) Rf_error("Have to have at least one start");
@@ -201,8 +203,11 @@ SEXP _gficf_RunModularityClusteringHip(SEXP SNN, SEXP modularityFunctionS, SEXP 
   SEXP out = PROTECT(Rf_allocVector(INTSXP, N));
   int64_t n_clusters = 0;
   double q = 0.0;
-  if (gficf_louvain_host(ctx_get(), N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(resolutionS), algorithm, Rf_asInteger(nRandomStartsS),
-                         Rf_asInteger(nIterationsS), Rf_asInteger(randomSeedS) & 0x7FFFFFFF, INTEGER(out), &n_clusters, &q) != GFICF_OK) {
+  gficf_ctx_set_louvain_options(ctx_get(), modularityFunction);
+  const int lrc = gficf_louvain_host(ctx_get(), N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(resolutionS), algorithm, Rf_asInteger(nRandomStartsS),
+                                     Rf_asInteger(nIterationsS), Rf_asInteger(randomSeedS) & 0x7FFFFFFF, INTEGER(out), &n_clusters, &q);
+  gficf_ctx_set_louvain_options(ctx_get(), 1);
+  if (lrc != GFICF_OK) {
     UNPROTECT(1);
     Rf_error("gficf_hip: %s", gficf_last_error());
   }

@@ -55,7 +55,7 @@ def build_ref() -> str | None:
     return _REF_LOUVAIN if os.path.exists(_REF_LOUVAIN) else None
 
 
-def modularity_reference(A, resolution: float = 0.8, algorithm: int = 1, n_start: int = 10, n_iter: int = 10, seed: int = 0):
+def modularity_reference(A, resolution: float = 0.8, algorithm: int = 1, n_start: int = 10, n_iter: int = 10, seed: int = 0, function: int = 1):
     """Runs the REFERENCE's modularity optimiser (oracle/_ref/modularity_optimizer, built from
     /root/reference/src/ModularityOptimizer.cpp) on the symmetric adjacency matrix ``A`` exactly as
     RunModularityClusteringCpp feeds it (src/RModularityOptimizer.cpp:66-84: strict lower triangle, node1 = column,
@@ -82,7 +82,7 @@ def modularity_reference(A, resolution: float = 0.8, algorithm: int = 1, n_start
             with open(fin, "w") as f:
                 for c, r, v in zip(L.col.tolist(), L.row.tolist(), L.data.tolist()):
                     f.write(f"{c}\t{r}\t{v!r}\n")
-        out = subprocess.run([exe, fin, fout, "1", repr(float(resolution)), str(int(algorithm)), str(int(n_start)), str(int(n_iter)),
+        out = subprocess.run([exe, fin, fout, str(int(function)), repr(float(resolution)), str(int(algorithm)), str(int(n_start)), str(int(n_iter)),
                               str(int(seed)), "1"], check=True, capture_output=True, text=True).stdout
         labels = np.loadtxt(fout, dtype=np.int64).astype(np.int32).reshape(-1)
     m = re.findall(r"(?:^|\n)(?:Modularity|Maximum modularity in \d+ random starts): (-?[0-9.]+)", out)

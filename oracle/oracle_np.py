@@ -158,7 +158,7 @@ def transpose_np(G, N, colptr, rowidx, x):
     return ptr, cell[order], np.asarray(x, dtype=np.float64)[order]
 
 
-def modularity_np(A, labels, resolution: float = 1.0) -> float:
+def modularity_np(A, labels, resolution: float = 1.0, function: int = 1) -> float:
     """VOSClusteringTechnique::calcQualityFunction (src/ModularityOptimizer.cpp:461-482) for modularityFunction = 1 on the
     network RunModularityClusteringCpp builds (diagonal dropped, src/RModularityOptimizer.cpp:73-75; node weight = the
     vertex's total edge weight, :185; resolution2 = resolution / 2W, :100):
@@ -171,6 +171,9 @@ def modularity_np(A, labels, resolution: float = 1.0) -> float:
     two_w = k.sum()
     coo = A.tocoo()
     inside = coo.data[lab[coo.row] == lab[coo.col]].sum()
+    if function == 2:                                   # alternative: node weight 1, resolution as given (:799-805, :100)
+        n_c = np.bincount(lab).astype(np.float64)
+        return float((inside - resolution * (n_c * n_c).sum()) / two_w)
     K = np.bincount(lab, weights=k)
     return float((inside - resolution * (K * K).sum() / two_w) / two_w)
 

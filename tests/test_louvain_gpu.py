@@ -102,6 +102,26 @@ def test_large_graph_200k_cells_against_the_reference():
         assert abs(q_ref - printed) < 6e-5 and lab.modularity >= q_ref - Q_TOL, (lab.modularity, q_ref)
 
 
+@pytest.mark.parametrize("N,k,C,res", [(6000, 15, 10, 0.05), (8000, 20, 1, 0.02)])
+def test_alternative_modularity_function(N, k, C, res):
+    """RunModularityClustering(modularity = 2): unit node weights, the resolution taken as it is (reference
+    src/RModularityOptimizer.cpp:36,100; never chosen by clustcells()).  Against the reference binary run with the same function."""
+    A = knn_graph(N, 10, k, C, seed=N + k)
+    lab = gficf_amd.run_modularity_clustering(A, 2, res, 1, 1, 10, 0, False)
+    assert abs(lab.modularity - oracle_np.modularity_np(A, lab, res, 2)) < 1e-9
+    sizes = np.bincount(lab)
+    assert lab.min() == 0 and (sizes > 0).all() and (np.diff(sizes) <= 0).all()
+    std = gficf_amd.run_modularity_clustering(A, 1, 0.8, 1, 1, 10, 0, False)            # the context is back on the standard function
+    assert abs(std.modularity - oracle_np.modularity_np(A, std, 0.8)) < 1e-9
+    if oracle.build_ref() is not None:
+        ref_labels, printed = oracle.modularity_reference(A, res, 1, 1, 10, 0, function=2)
+        q_ref = oracle_np.modularity_np(A, ref_labels, res, 2)
+        assert abs(q_ref - printed) < 6e-5                                              # the restatement vs the reference's print-out
+        assert lab.modularity >= q_ref - Q_TOL, (lab.modularity, q_ref)
+    with pytest.raises(ValueError):
+        gficf_amd.run_modularity_clustering(A, 2, 1.5)
+
+
 def test_hub_vertices_beyond_the_table():
     """Hubs with 3 000 and 30 000 neighbours, each neighbour its own community at the start: more than the 2048- and the
     8192-slot table hold — the second takes several passes over its edges.  Checked against the reference binary."""
@@ -190,7 +210,7 @@ def test_device_resident_chain_and_edge_cases():
     with pytest.raises(gficf_amd.GficfError):
         gficf_amd.run_modularity_clustering(bad, 1, 0.8, 1, 1, 1, 0, False)
     with pytest.raises(ValueError):
-        gficf_amd.run_modularity_clustering(A, 2, 0.8)
+        gficf_amd.run_modularity_clustering(A, 3, 0.8)
     with pytest.raises(ValueError):
         gficf_amd.run_modularity_clustering(A, 1, 0.8, 3)
 
