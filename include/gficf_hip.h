@@ -1,5 +1,7 @@
 /* gficf_hip.h — C ABI of libgficf_hip.so: MI355X (gfx950) GF-ICF normalisation and
- * Phenograph kNN -> Jaccard edge build.
+ * Phenograph kNN -> Jaccard edge build, with the steps either side of them in clustcells()
+ * (neighbour search, edge filter, adjacency matrix, community detection, cluster signatures)
+ * and t(gficf).
  *
  * This is the drop-in boundary for ONE hot path of the dibbelab/gficf R package.  Plain
  * pointers and sizes only; no R, Rcpp or torch types.  Every entry point cites the
@@ -37,9 +39,11 @@ typedef enum gficf_status {
   GFICF_ERR_BAD_CSC = 3,       /* rowidx outside [0, G), colptr not monotone               */
   GFICF_ERR_NO_DEVICE = 4,     /* no HIP device / device index out of range                */
   GFICF_ERR_HIP = 5,           /* a HIP runtime call failed; message has hipGetErrorString */
-  GFICF_ERR_UNSUPPORTED = 6,   /* k > GFICF_JACCARD_MAX_K, table too large for the kernel  */
+  GFICF_ERR_UNSUPPORTED = 6,   /* k > GFICF_JACCARD_MAX_K, table too large for the kernel,
+                                  edge weights too large for the Louvain fixed point ...   */
   GFICF_ERR_CAPACITY = 7,      /* caller-provided output buffer too small                  */
-  GFICF_ERR_BAD_VALUE = 8      /* a non-finite coordinate in the kNN point matrix          */
+  GFICF_ERR_BAD_VALUE = 8      /* a non-finite coordinate in the kNN point matrix, a
+                                  negative / non-finite edge weight (Louvain)             */
 } gficf_status;
 
 #define GFICF_JACCARD_MAX_K 256
@@ -57,7 +61,8 @@ void gficf_ctx_destroy(gficf_ctx* ctx);
 /* Rebind the stream later work is enqueued on (e.g. torch's current stream). */
 int gficf_ctx_set_stream(gficf_ctx* ctx, void* stream);
 /* Wait for the stream, then report (and clear) deferred device-side validation errors
- * (GFICF_ERR_BAD_ID / GFICF_ERR_BAD_CSC) of the *_device calls enqueued since last sync. */
+ * (GFICF_ERR_BAD_ID / GFICF_ERR_BAD_CSC / GFICF_ERR_BAD_VALUE / GFICF_ERR_UNSUPPORTED) of the
+ * *_device calls enqueued since last sync. */
 int gficf_ctx_sync(gficf_ctx* ctx);
 const char* gficf_last_error(void);
 
