@@ -354,17 +354,22 @@ __global__ __launch_bounds__(256) void k_lv_internal(LvGraph g, const int32_t* _
   if (threadIdx.x == 0 && (s_sum[0] | s_sum[1] | s_sum[2] | s_sum[3])) atomicAdd(in_w, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
 }
 
-__global__ __launch_bounds__(1024) void k_lv_sumsq(int64_t n, const u64* __restrict__ K, double* __restrict__ out) {
-  __shared__ double s_p[1024];
+// Sum of the squared community totals, in a fixed order: LV_SQ_BLOCKS slices of the communities, a fixed tree inside each,
+// the slices added up by the host in slice order.
+constexpr int LV_SQ_BLOCKS = 64;
+__global__ __launch_bounds__(256) void k_lv_sumsq(int64_t n, const u64* __restrict__ K, double* __restrict__ part) {
+  __shared__ double s_p[256];
+  const int64_t per = (n + LV_SQ_BLOCKS - 1) / LV_SQ_BLOCKS;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
   double s = 0.0;
-  for (int64_t c = threadIdx.x; c < n; c += 1024) { const double k = (double)K[c]; s += k * k; }
+  for (int64_t c = lo + threadIdx.x; c < hi; c += 256) { const double k = (double)K[c]; s += k * k; }
   s_p[threadIdx.x] = s;
   __syncthreads();
-  for (int d = 512; d > 0; d >>= 1) {
+  for (int d = 128; d > 0; d >>= 1) {
     if ((int)threadIdx.x < d) s_p[threadIdx.x] += s_p[threadIdx.x + d];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *out = s_p[0];
+  if (threadIdx.x == 0) part[blockIdx.x] = s_p[0];
 }
 
 // ---- reduction of the graph
@@ -505,7 +510,8 @@ struct LvWs {
   int64_t* flag;            // max(n, m) + 1 entries: scans
   u64 *keys_a, *vals_a, *keys_b, *vals_b;
   void* sort_tmp; size_t sort_tmp_bytes;
-  u64* scalars;             // [0] 2W, [1] internal weight, [2] moved (unsigned), [3] sum of squares (double), [4] n_mid | n_large, [5] largest weight
+  double* sq_part;          // LV_SQ_BLOCKS partial sums of squared community totals
+  u64* scalars;             // [0] 2W, [1] internal weight, [2] moved (unsigned), [3] unused, [4] n_mid | n_large, [5] largest weight
 };
 
 static size_t lv_carve(LvWs* w, void* base, int64_t N, int64_t nnz) {
@@ -528,6 +534,7 @@ static size_t lv_carve(LvWs* w, void* base, int64_t N, int64_t nnz) {
   d.sort_tmp_bytes = lv_sort_tmp_bytes((int64_t)(m > n ? m : n));
   d.sort_tmp = b.take<char>(d.sort_tmp_bytes);
   d.scalars = b.take<u64>(8);
+  d.sq_part = b.take<double>(LV_SQ_BLOCKS);
   if (w) *w = d;
   return b.off + 256;
 }
@@ -545,12 +552,14 @@ struct LvQ { double q; u64 in_w; };
 static int lv_quality(gficf_ctx* ctx, const LvGraph& g, const LvWs& w, u64 self_w, double two_w, double q_coef, double* q_out, u64* in_out) {
   GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 1, 0, sizeof(u64), ctx->stream));
   hipLaunchKernelGGL(k_lv_internal, dim3(lv_blocks(g.n, 4) < 2048u ? lv_blocks(g.n, 4) : 2048u), dim3(256), 0, ctx->stream, g, w.comm, w.scalars + 1);
-  hipLaunchKernelGGL(k_lv_sumsq, dim3(1), dim3(1024), 0, ctx->stream, g.n, w.K, (double*)(w.scalars + 3));
+  hipLaunchKernelGGL(k_lv_sumsq, dim3(LV_SQ_BLOCKS), dim3(256), 0, ctx->stream, g.n, w.K, w.sq_part);
   u64 h[4];
+  double hp[LV_SQ_BLOCKS];
   GFICF_HIP_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  GFICF_HIP_CHECK(hipMemcpyAsync(hp, w.sq_part, sizeof(hp), hipMemcpyDeviceToHost, ctx->stream));
   GFICF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  double sq;
-  memcpy(&sq, &h[3], sizeof(double));
+  double sq = 0.0;
+  for (int i = 0; i < LV_SQ_BLOCKS; ++i) sq += hp[i];
   *in_out = h[1];
   *q_out = ((double)(h[1] + self_w)) / two_w - q_coef * sq;          // sq = sum of squared community totals (fixed point)
   return GFICF_OK;
