@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — Jaccard edges/s (headline) and GF-ICF cells/s on MI355X.
 
-A "step" is one pass of the Jaccard hot path over one batch of synthetic input that is
-already resident in HBM: the column-major int32 kNN index block of this rank's cells
-(what `uwot:::find_nn(...)$idx[,-1]` hands to the reference, R/clustCells.R:63-65)
+A "step" is one pass of the Jaccard hot path over one batch of synthetic input that is already resident in HBM: for
+every data set of the batch, the column-major int32 kNN index block of this rank's cells (what
+`uwot:::find_nn(...)$idx[,-1]` hands to the reference, R/clustCells.R:63-65)
   -> ingest (transpose / validate into the row-major table)
   -> [N > 1: RCCL all-gather of the table rows over xGMI]
-  -> edge kernel -> this rank's rows of the reference's (N*k) x 3 double matrix.
+  -> edge kernel -> this rank's rows of the reference's (N*k) x 3 double matrix,
+all on ONE stream, in order: every data set pays its own ingest + edge kernel (+ exchange), nothing of one data set
+overlaps another (no software pipelining in `value`; `--pipeline` keeps the overlapped mode as a separate figure).
 
-Workload (config.workload): the north-star point of BASELINE.json — 100 000 cells x k = 30
-per GPU ("windowed" synthetic kNN with realistic overlap, ids relabelled by a random
-permutation).  Weak scaling: every rank owns 100 000 cells, the data set has
-100 000 x n_gpus cells and every rank's edge kernel gathers from the full table.
+Workloads (`--config`, named in config.workload):
+  north_star (default; what BASELINE.json's metric is quoted on): 100 000 cells x k = 30 per GPU, weak scaling — every
+             rank owns 100 000 cells of a (100 000 x n_gpus)-cell data set; a batch of 8 independent data sets per step
+             (different seeds), so that K = 20 steps time >= 10 ms and no launch re-reads what the one before left in
+             the caches;
+  c4 / c5    BASELINE configs 4 / 5: ONE data set (100 000 x k = 50 / 1 000 000 x k = 30) split over the ranks by cell
+             block — strong scaling.
 
 Launch: `python bench.py` (1 GPU) or
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
@@ -33,6 +38,11 @@ sys.path.insert(0, ROOT)
 
 CELLS_PER_GPU = 100_000
 K = 30
+BATCH = 8                        # independent data sets per step (north_star)
+CONFIGS = {                      # strong-scaling configs of BASELINE.json: cells_total, k
+    "c4": (100_000, 50),
+    "c5": (1_000_000, 30),
+}
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md "HBM3E peak BW")
 HBM_COPY_GBS = 6300.0            # achievable streaming copy rate on the same part (MI355X_MICROARCH.md; SURVEY.md 8d asks for both)
 JACCARD_BYTES_PER_EDGE = 28      # 4 B index entry read once + 24 B reference output row
@@ -44,14 +54,17 @@ KNN_N, KNN_D, KNN_K = 100_000, 50, 31  # north-star point: 100 k cells, 50 PCA c
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--cells-per-gpu", type=int, default=CELLS_PER_GPU)
-    ap.add_argument("--k", type=int, default=K)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=["north_star", "c4", "c5"], default="north_star")
+    ap.add_argument("--cells-per-gpu", type=int, default=CELLS_PER_GPU, help="north_star only")
+    ap.add_argument("--k", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="independent data sets per step (default 8 for north_star, 1 for c4 / c5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gficf", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="ingest/all-gather on the same stream as the edge kernel")
+    ap.add_argument("--no-extras", action="store_true", help="headline line only (no stress / host ABI / GF-ICF / kNN sub-objects)")
+    ap.add_argument("--pipeline", action="store_true", help="also report the software-pipelined mode (steps overlapped on side streams)")
     return ap.parse_args()
 
 
@@ -69,12 +82,31 @@ def time_kernel_ms(torch, fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def synth_counts_device(torch, G, N, seed=7, median_frac=0.07, sigma=0.5, zipf_s=0.9):
+def synth_counts_device(torch, G, N, seed=7, median_frac=0.07, sigma=0.5, zipf_s=0.9, max_per_cell=None, chunk_cells=None):
     """Device-side generator of the BASELINE-shaped synthetic CSC count matrix (same recipe as
-    gficf_amd.synth.counts_csc, torch RNG instead of splitmix64 so that ~1e8 draws take seconds)."""
+    gficf_amd.synth.counts_csc, torch RNG instead of splitmix64 so that ~1e8 draws take seconds).
+    max_per_cell caps the draws of a cell (SURVEY.md §8d: 2 147 for config 5, so that nnz < 2^31);
+    chunk_cells generates the cells in blocks of that many (bounds the generator's temporaries at config 5's size)."""
+    if chunk_cells is not None and N > chunk_cells:
+        parts = [synth_counts_device(torch, G, min(chunk_cells, N - c0), seed + 1000003 * (i + 1), median_frac, sigma, zipf_s, max_per_cell)
+                 for i, c0 in enumerate(range(0, N, chunk_cells))]
+        colptr = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
+        off, c0 = 0, 0
+        for cp, ri, _ in parts:
+            n = cp.numel() - 1
+            colptr[c0 + 1:c0 + n + 1] = cp[1:] + off
+            off, c0 = off + int(ri.numel()), c0 + n
+        rows, xs = [p[1] for p in parts], [p[2] for p in parts]
+        del parts
+        rowidx = torch.cat(rows)
+        del rows
+        x = torch.cat(xs)
+        return colptr, rowidx, x
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
     n_draw = torch.clamp(torch.round(median_frac * G * torch.exp(sigma * torch.randn(N, generator=g, device="cuda", dtype=torch.float64))), 1, G).long()
+    if max_per_cell is not None:
+        n_draw = torch.clamp(n_draw, max=int(max_per_cell))
     pop = 1.0 / torch.arange(1, G + 1, device="cuda", dtype=torch.float64).pow(zipf_s)
     cdf = torch.cumsum(pop, 0)
     cdf = cdf / cdf[-1]
@@ -234,18 +266,33 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
-    k = args.k
-    N_total = args.cells_per_gpu * world
+    strong = args.config in CONFIGS
+    if strong:
+        N_total, k = CONFIGS[args.config]
+        k = args.k or k
+        batch = args.batch or 1
+    else:
+        k = args.k or K
+        N_total = args.cells_per_gpu * world
+        batch = args.batch or BATCH
     ops = gficf_amd.HipOps(local_rank)
 
-    # ---- synthetic input, resident in HBM before the timed region
-    mat = synth.knn_windowed(N_total, k)                       # N_total x k, 1-based ids (same on every rank)
+    # ---- synthetic input, resident in HBM before the timed region: `batch` independent data sets
     b, e = shard_bounds(N_total, world, rank)
-    idx_local = torch.from_numpy(np.ascontiguousarray(mat[b:e].T)).to(dev)   # (k, n_local) == column-major block
-    shard = JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=not args.no_pipeline)
+    n_local = e - b
+    mats, idx_local, shards = [], [], []
+    for d in range(batch):
+        m = synth.knn_windowed(N_total, k, seed=42 + 7 * d, perm_seed=43 + 7 * d)   # N_total x k, 1-based ids (same on every rank)
+        if d == 0:
+            mats.append(m)                                              # kept for the oracle check / CPU baseline
+        idx_local.append(torch.from_numpy(np.ascontiguousarray(m[b:e].T)).to(dev))   # (k, n_local) == column-major block
+        shards.append(JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=False))
+        del m
+    mat = mats[0]
 
     def step():
-        shard.step(idx_local)
+        for d in range(batch):
+            shards[d].step(idx_local[d])
 
     def fence():
         torch.cuda.synchronize()
@@ -256,34 +303,52 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         step()
+    ev1.record()
     fence()
     dt = time.perf_counter() - t0
-    shard.sync()                                                # surfaces deferred validation errors
+    region_ms = ev0.elapsed_time(ev1)                               # the same K steps by HIP events on the launch stream
+    for sh in shards:
+        sh.sync()                                                   # surfaces deferred validation errors
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    edges_per_step = N_total * k
+    edges_per_step = N_total * k * batch
     value = edges_per_step * args.steps / dt
 
-    # ---- roofline of the dominant kernel (k_jaccard_edges): HIP events around every launch of the timed region,
-    # recorded on the stream the kernel is launched on (two alternating streams in pipelined mode, where a
-    # launch overlaps its neighbours and the side-stream ingest, so its duration is longer than standalone)
-    n_local = e - b
-    # (a second run of the same K steps: the event pairs cost ~6 us per step when left in the timed region)
-    shard.time_edges = True
+    # ---- roofline of the dominant kernel (k_jaccard_edges): HIP events around every launch of a second run of the same
+    # K steps, recorded on the stream the kernel is launched on (the event pairs cost a few us per launch, so they stay out of
+    # the timed region); and the two kernels of a data set launched back to back alone
+    for sh in shards:
+        sh.time_edges = True
     for _ in range(args.steps):
         step()
     fence()
-    shard.time_edges = False
-    t_edges_ms = shard.edge_kernel_ms(last=args.steps)
-    t_edges_alone_ms = time_kernel_ms(torch, lambda: ops.jaccard_edges(shard.table, N_total, k, b, e, shard.out, None), max(args.steps, 20))
-    t_ingest_ms = time_kernel_ms(torch, lambda: ops.jaccard_ingest(idx_local, n_local, k, N_total, shard.table[rank * shard.rpr:(rank + 1) * shard.rpr]), max(args.steps, 20))
-    achieved = JACCARD_BYTES_PER_EDGE * n_local * k / (t_edges_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the committed PMC passes (tools/pmc.sh + tools/make_traffic.py; FETCH_SIZE
+    for sh in shards:
+        sh.time_edges = False
+    t_edges_ms = sum(sh.edge_kernel_ms(last=args.steps) for sh in shards) / batch
+    rot = {"i": 0}
+
+    def one_edges():
+        d = rot["i"] % batch
+        rot["i"] += 1
+        ops.jaccard_edges(shards[d].table, N_total, k, b, e, shards[d].out, None)
+
+    def one_ingest():
+        d = rot["i"] % batch
+        rot["i"] += 1
+        ops.jaccard_ingest(idx_local[d], n_local, k, N_total, shards[d].table[rank * shards[d].rpr:(rank + 1) * shards[d].rpr])
+
+    t_edges_b2b_ms = time_kernel_ms(torch, one_edges, max(args.steps * batch, 40))
+    t_ingest_ms = time_kernel_ms(torch, one_ingest, max(args.steps * batch, 40))
+    alg_bytes = JACCARD_BYTES_PER_EDGE * n_local * k
+    achieved = alg_bytes / (t_edges_ms * 1e-3) / 1e9
+    # HBM-side bytes per launch from the committed PMC passes (tools/pmc.sh + tools/make_traffic.py; FETCH_SIZE
     # correction documented there); null when no pass was taken for this workload
     pmc = {}
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -295,26 +360,57 @@ def main():
     traffic = pmc.get(f"jaccard_edges_N{N_total}_k{k}", {}).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "k_jaccard_edges", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_copy_rate": round(achieved / HBM_COPY_GBS, 4), "traffic": traffic,
-                "kernel_ms": round(t_edges_ms, 5), "kernel_ms_standalone": round(t_edges_alone_ms, 5),
-                "frac_standalone": round(JACCARD_BYTES_PER_EDGE * n_local * k / (t_edges_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernel_ms": round(t_edges_ms, 5), "kernel_ms_back_to_back": round(t_edges_b2b_ms, 5),
                 "ingest_kernel_ms": round(t_ingest_ms, 5),
-                "algorithmic_bytes_per_launch": JACCARD_BYTES_PER_EDGE * n_local * k}
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "row_bytes": 4 * ops.row_words(N_total, k),
+                "note": "kernel_ms: mean of HIP-event pairs around every k_jaccard_edges launch of a second run of the K steps "
+                        "(same stream, same order as the timed region); kernel_ms_back_to_back: the kernel alone, launched back to "
+                        "back over the batch's tables"}
 
+    wl = (f"BASELINE config {args.config[1]}: ONE data set of {N_total} cells x k={k} split over {world} GPU(s) by cell block (strong scaling)"
+          if strong else
+          f"north-star point: {args.cells_per_gpu} cells x k={k} per GPU; N_total={N_total}; {batch} independent data sets per step")
     out = {
         "metric": "jaccard_edges_per_sec", "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": f"north-star point: {args.cells_per_gpu} cells x k={k} per GPU, windowed kNN (W=100) with permuted ids; "
-                               f"N_total={N_total}; step = ingest + {'RCCL all-gather + ' if world > 1 else ''}edge kernel, device-resident"
-                               + ("" if args.no_pipeline else "; steps software-pipelined over two tables and two output buffers (ingest"
-                                  + ("/pack/all-gather/unpack" if world > 1 else "") + " of step s+1 on a side stream under the edge kernel of step s; "
-                                  "edge kernels of consecutive steps on alternating streams)"),
-                   "cells_total": N_total, "k": k, "edges_per_step": edges_per_step,
-                   "partition": f"cell blocks x{world}" + (", 1 all-gather of int32 table rows" if world > 1 else "")},
+        "config": {"workload": wl + f", windowed kNN (W=100) with permuted ids; per data set: ingest + {'RCCL all-gather + ' if world > 1 else ''}"
+                               "edge kernel, device-resident, one stream, in order (no overlap between data sets or steps)",
+                   "cells_total": N_total, "k": k, "data_sets_per_step": batch, "edges_per_step": edges_per_step,
+                   "partition": f"cell blocks x{world}" + (", 1 all-gather of table rows per data set" if world > 1 else "")},
+        "timed_region_ms": round(region_ms, 4),
+        "ms_per_data_set": dt / args.steps / batch * 1e3,
         "roofline": roofline,
     }
+    if world > 1:
+        sh0 = shards[0]
+        row_b = 4 * (sh0.pw if sh0.packed is not None else sh0.row_words)
+        out["exchange"] = {"bytes_received_per_rank_per_data_set": int((N_total - n_local) * row_b), "row_bytes_on_the_wire": row_b,
+                           "form": "all-gather of table rows" + (" (bit-packed)" if sh0.packed is not None else "")}
 
-    if rank == 0 and world == 1:
+    if args.pipeline:
+        # the overlapped mode (not `value`): ingest / exchange of data set d+1 on a side stream under the edge kernel of d
+        psh = JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=True)
+        for _ in range(3 * batch):
+            psh.step(idx_local[0])
+        fence()
+        t1 = time.perf_counter()
+        for i in range(args.steps * batch):
+            psh.step(idx_local[i % batch])
+        fence()
+        tp = time.perf_counter() - t1
+        if world > 1:
+            tmax = torch.tensor([tp], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            tp = float(tmax.item())
+        out["pipelined"] = {"edges_per_sec": edges_per_step * args.steps / tp, "ms_per_data_set": tp / (args.steps * batch) * 1e3,
+                            "note": "software-pipelined over two tables and two output buffers; a steady-state rate over many data sets, not a call"}
+        del psh
+
+    extras = not args.no_extras and not strong
+    shard = shards[0]
+    if rank == 0 and world == 1 and extras:
         if True:
             # one step against the oracle on a bounded sample of source cells (checker only)
             import oracle
@@ -338,31 +434,27 @@ def main():
             t1 = time.perf_counter()
             L.oracle_jaccard_f64(mf.ctypes.data, N_total, k, rmh.ctypes.data, uh.ctypes.data, 2)
             t_nt2 = time.perf_counter() - t1
-            cpu_v = edges_per_step / statistics.median(ts)
+            edges_ds = N_total * k                                      # one data set
+            cpu_v = edges_ds / statistics.median(ts)
             out["cpu_baseline"] = {"value": cpu_v, "unit": "edges/s", "cores": cores, "kind": "port",
                                    "sample": f"the full workload ({N_total} cells x k={k}, same input), median of 3 passes of the oracle's "
                                              "faithful restatement of the RcppParallel worker (g++ -O2, dynamic chunks over std::thread)",
-                                   "nt2_value": edges_per_step / t_nt2, "nt2_note": "clustcells() default nt = 2 (reference R/clustCells.R:46)",
+                                   "nt2_value": edges_ds / t_nt2, "nt2_note": "clustcells() default nt = 2 (reference R/clustCells.R:46)",
                                    "gpu_over_cpu": value / cpu_v}
         # stress row: uniformly random neighbour ids — u ~ 0, no overlap to exploit, same traffic
         try:
             umat = synth.knn_uniform(N_total, k)
             uidx = torch.from_numpy(np.ascontiguousarray(umat.T)).to(dev)
-            ush = JaccardShard(ops, N_total, k, device=dev, pipeline=not args.no_pipeline)
-            for _ in range(3):
-                ush.step(uidx)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(20):
-                ush.step(uidx)
-            torch.cuda.synchronize()
-            out["stress_uniform_ids"] = {"edges_per_sec": edges_per_step * 20 / (time.perf_counter() - t1),
+            ush = JaccardShard(ops, N_total, k, device=dev, pipeline=False)
+            t_u = time_kernel_ms(torch, lambda: ush.step(uidx), 40)
+            out["stress_uniform_ids"] = {"edges_per_sec": N_total * k / (t_u * 1e-3), "ms_per_data_set": t_u,
                                          "nonzero_edge_fraction": float((ush.out[2] > 0).double().mean().item())}
             del ush, uidx, umat
         except Exception as ex:  # pragma: no cover
             out["stress_uniform_ids"] = {"error": str(ex)}
-        # end-to-end through the host C ABI (what the R glue calls): H2D + ingest + edges + D2H of the
-        # 24 B/edge reference matrix, device buffers allocated per call.  PCIe-inclusive: reported, never `value`.
+        # end-to-end through the host C ABI (what the R glue calls): H2D + ingest + edges + D2H, device scratch from the
+        # context's pool.  PCIe-inclusive: reported, never `value`.  Two forms: the reference's 24 B/edge matrix, and the
+        # compact return (2 B/edge intersection counts; gficf_jaccard_expand_host rebuilds the matrix on the host)
         try:
             import ctypes
 
@@ -370,17 +462,29 @@ def main():
 
             L = _lib.load()
             hm = np.asfortranarray(mat)
-            hr = np.empty((3, edges_per_step), dtype=np.float64)
+            E1 = N_total * k
+            hr = np.empty((3, E1), dtype=np.float64)
+            hu = np.empty(E1, dtype=np.uint16)
             hctx = gficf_amd.default_context(local_rank)
-            call = lambda: L.gficf_jaccard_host(hctx.handle, hm.ctypes.data_as(ctypes.c_void_p), 0, N_total, k, N_total,
-                                                hr.ctypes.data_as(ctypes.c_void_p), 0)
-            call()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                rc = call()
-            th = (time.perf_counter() - t1) / 3
-            out["host_abi"] = {"edges_per_sec": edges_per_step / th, "ms_per_call": th * 1e3, "rc": rc,
-                               "note": "gficf_jaccard_host: pageable host buffers, device scratch from the context pool, PCIe both ways"}
+            vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+            def timed(call, reps=5):
+                call()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    rc = call()
+                return (time.perf_counter() - t1) / reps, rc
+
+            th, rc = timed(lambda: L.gficf_jaccard_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(hr), 0))
+            out["host_abi"] = {"edges_per_sec": E1 / th, "ms_per_call": th * 1e3, "rc": rc,
+                               "note": "gficf_jaccard_host: pageable host buffers, device scratch from the context pool, PCIe both ways (12 MB in, 72 MB out)"}
+            tc, rc = timed(lambda: L.gficf_jaccard_counts_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(hu)))
+            tx, rc2 = timed(lambda: L.gficf_jaccard_expand_host(vp(hm), 0, N_total, k, N_total, vp(hu), vp(hr), 0))
+            want_full = shard.out.cpu().numpy()
+            out["host_abi_counts"] = {"edges_per_sec": E1 / tc, "ms_per_call": tc * 1e3, "rc": rc, "expand_on_host_ms": tx * 1e3,
+                                      "expanded_equals_device_matrix": bool(rc2 == 0 and np.array_equal(hr, want_full)),
+                                      "note": "gficf_jaccard_counts_host: uint16 intersection counts only (12 MB in, 6 MB out); "
+                                              "expand_on_host_ms = gficf_jaccard_expand_host rebuilding the 72 MB reference matrix on the host cores"}
         except Exception as ex:  # pragma: no cover
             out["host_abi"] = {"error": str(ex)}
         if not args.no_gficf:
@@ -459,7 +563,7 @@ def main():
         if not args.no_knn:
             out["knn"] = bench_knn(torch, ops, args)
 
-    if world > 1 and not args.no_gficf:
+    if world > 1 and not args.no_gficf and not strong and not args.no_extras:
         # GF-ICF, cell-sharded: every rank owns a 54 k-cell block of a (54 k x n_gpus)-cell matrix; the only
         # exchange is the all-reduce(sum) of the G per-gene cell counts between the count and the scale pass
         from gficf_amd.dist import GficfShard

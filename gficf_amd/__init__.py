@@ -8,6 +8,7 @@ ABI of ``libgficf_hip.so`` (include/gficf_hip.h); there is no CPU fallback.
 from ._lib import GficfError, LIB_PATH  # noqa: F401
 from .api import (  # noqa: F401
     Context,
+    MultiContext,
     cluster_signatures,
     clustcells,
     clustcells_graph,
@@ -19,11 +20,13 @@ from .api import (  # noqa: F401
     gficf_with_weights,
     jaccard_adjacency,
     jaccard_coeff,
+    jaccard_counts,
     jaccard_edges,
+    jaccard_expand,
     phenograph,
     rcpp_parallel_jaccard_coef,
     run_modularity_clustering,
     transpose_gficf,
 )
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

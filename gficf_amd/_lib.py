@@ -16,7 +16,7 @@ GFICF_OK = 0
 STATUS_NAMES = {
     0: "GFICF_OK", 1: "GFICF_ERR_INVALID_ARG", 2: "GFICF_ERR_BAD_ID", 3: "GFICF_ERR_BAD_CSC",
     4: "GFICF_ERR_NO_DEVICE", 5: "GFICF_ERR_HIP", 6: "GFICF_ERR_UNSUPPORTED", 7: "GFICF_ERR_CAPACITY",
-    8: "GFICF_ERR_BAD_VALUE",
+    8: "GFICF_ERR_BAD_VALUE", 9: "GFICF_ERR_EXPLICIT_ZEROS",
 }
 JACCARD_MAX_K = 256
 KNN_MAX_K = 128
@@ -45,9 +45,24 @@ SIGNATURES = {
     "gficf_ctx_set_gficf_options": (_int, [_vp, _int, _int]),
     "gficf_ctx_set_louvain_options": (_int, [_vp, _int]),
     "gficf_last_error": (ctypes.c_char_p, []),
+    "gficf_ctx_set_print": (_int, [_vp, _vp]),
+    "gficf_ctx_trim": (_int, [_vp]),
+    "gficf_jaccard_counts_host": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp]),
+    "gficf_jaccard_expand_host": (_int, [_vp, _int, _i64, _int, _i64, _vp, _vp, _int]),
+    "gficf_multi_create": (_int, [_vp, _int, ctypes.POINTER(_vp)]),
+    "gficf_multi_destroy": (None, [_vp]),
+    "gficf_multi_device_count": (_int, [_vp]),
+    "gficf_multi_set_print": (_int, [_vp, _vp]),
+    "gficf_multi_cell_blocks": (_int, [_i64, _int, _vp]),
+    "gficf_multi_cell_blocks_by_nnz": (_int, [_i64, _vp, _int, _int, _vp]),
+    "gficf_jaccard_host_multi": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _int]),
+    "gficf_normalize_csc_host_multi_plan": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _dbl, _dbl, _vp,
+                                                   ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "gficf_normalize_csc_host_multi_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_host": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _int]),
     "gficf_jaccard_coeff_host": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _int]),
     "gficf_jaccard_kpad": (_int, [_int]),
+    "gficf_jaccard_row_words": (_int, [_i64, _int]),
     "gficf_jaccard_ingest_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _i64, _vp]),
     "gficf_jaccard_packed_words": (_int, [_i64, _int]),
     "gficf_jaccard_pack_rows_device": (_int, [_vp, _vp, _i64, _int, _i64, _vp]),
@@ -88,6 +103,8 @@ SIGNATURES = {
     "gficf_knn_host": (_int, [_vp, _vp, _i64, _int, _i64, _int, _int, _vp, _vp]),
     "gficf_csc_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
+    "gficf_csc_exact_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -79,30 +79,125 @@ def _np_ptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
+class MultiContext:
+    """Several GPUs of one node behind the host entry points, single process (``gficf_multi_*`` of the C ABI): cells
+    shard by contiguous block, one context and one stream per device.  ``devices``: HIP ordinals; the same ordinal may be
+    named more than once (one block each)."""
+
+    def __init__(self, devices):
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise ValueError("devices must name at least one GPU")
+        arr = (ctypes.c_int * len(devices))(*devices)
+        self._h = ctypes.c_void_p()
+        check(_lib.load().gficf_multi_create(arr, len(devices), ctypes.byref(self._h)))
+        self.devices = devices
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("multi context is closed")
+        return self._h
+
+    def close(self):
+        if self._h:
+            _lib.load().gficf_multi_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_multi_ctx: dict[tuple, MultiContext] = {}
+
+
+def env_devices():
+    """The device list of the environment variable GFICF_HIP_DEVICES ("0,1,2,3"), which is what the R glue reads; None when
+    it is unset or names a single device."""
+    import os
+
+    e = os.environ.get("GFICF_HIP_DEVICES", "").strip()
+    if not e:
+        return None
+    devs = [int(t) for t in e.replace(";", ",").split(",") if t.strip() != ""]
+    return devs if len(devs) > 1 else None
+
+
+def _multi(devices) -> MultiContext | None:
+    if devices is None:
+        devices = env_devices()
+    if devices is None:
+        return None
+    key = tuple(int(d) for d in devices)
+    if key not in _multi_ctx:
+        _multi_ctx[key] = MultiContext(key)
+    return _multi_ctx[key]
+
+
+def _knn_matrix(mat, name="mat"):
+    """The kNN index matrix as the C ABI takes it: Fortran-ordered int32 (integer input) or float64 (anything else, what
+    Rcpp coerces to).  Integer ids that do not fit int32 cannot be valid (N <= 2^31 - 1): rejected here, before the
+    narrowing cast could alias them onto valid ids."""
+    mat = np.asarray(mat)
+    if mat.ndim != 2:
+        raise ValueError(f"{name} must be a 2-d matrix")
+    if np.issubdtype(mat.dtype, np.integer):
+        if mat.dtype != np.int32 and mat.size and (int(mat.min()) < -2 ** 31 or int(mat.max()) > 2 ** 31 - 1):
+            raise GficfError(2, "kNN index matrix holds an id outside [1, N] or a non-integer value")
+        return np.asfortranarray(mat, dtype=np.int32), 0
+    return np.asfortranarray(mat, dtype=np.float64), 1
+
+
 # ------------------------------------------------------------- Jaccard, reference-shaped
-def rcpp_parallel_jaccard_coef(mat, printOutput: bool = False, ctx: Context | None = None) -> np.ndarray:
+def rcpp_parallel_jaccard_coef(mat, printOutput: bool = False, ctx: Context | None = None, devices=None) -> np.ndarray:
     """Drop-in for the reference's ``rcpp_parallel_jaccard_coef(mat, printOutput)``.
 
     ``mat``: N x k matrix of 1-based neighbour ids (integer or float64, as R hands it over:
     reference R/clustCells.R:63-65).  Returns the (N*k) x 3 float64 matrix (Fortran order,
     like an R matrix) whose row i*k+j is (i+1, mat[i,j], u/(2k-u)) or zeros when the two
     neighbour sets do not intersect (reference src/rcpp_parallel_jaccard_coeff.cpp:48-52,67).
+
+    ``devices`` (or the environment variable GFICF_HIP_DEVICES): a list of GPUs to shard the cells over, single process
+    (``gficf_jaccard_host_multi``); same result.
     """
-    mat = np.asarray(mat)
-    if mat.ndim != 2:
-        raise ValueError("mat must be a 2-d matrix")
-    N, k = mat.shape
-    if np.issubdtype(mat.dtype, np.integer):
-        m = np.asfortranarray(mat, dtype=np.int32)
-        is_f64 = 0
-    else:
-        m = np.asfortranarray(mat, dtype=np.float64)
-        is_f64 = 1
+    m, is_f64 = _knn_matrix(mat)
+    N, k = m.shape
     E = N * k
     rm = np.zeros((3, E), dtype=np.float64)  # C-order (3, E) == column-major (E, 3)
+    mc = _multi(devices) if ctx is None else None
+    if mc is not None:
+        check(_lib.load().gficf_jaccard_host_multi(mc.handle, _np_ptr(m), is_f64, N, k, max(N, 1), _np_ptr(rm),
+                                                   1 if printOutput else 0))
+        return rm.T
     ctx = ctx or default_context()
     check(_lib.load().gficf_jaccard_host(ctx.handle, _np_ptr(m), is_f64, N, k, max(N, 1), _np_ptr(rm),
                                          1 if printOutput else 0))
+    return rm.T
+
+
+def jaccard_counts(mat, ctx: Context | None = None) -> np.ndarray:
+    """The intersection counts u[i, j] = |row i ∩ row mat[i, j]| alone (uint16, N x k): the compact return of the C ABI
+    (``gficf_jaccard_counts_host``, 2 B per edge across PCIe instead of the reference's 24 B row)."""
+    m, is_f64 = _knn_matrix(mat)
+    N, k = m.shape
+    u = np.zeros((N, k), dtype=np.uint16)
+    ctx = ctx or default_context()
+    check(_lib.load().gficf_jaccard_counts_host(ctx.handle, _np_ptr(m), is_f64, N, k, max(N, 1), _np_ptr(u)))
+    return u
+
+
+def jaccard_expand(mat, u, n_threads: int = 0) -> np.ndarray:
+    """Counts -> the reference's (N*k) x 3 edge matrix, on the host (``gficf_jaccard_expand_host``; no device)."""
+    m, is_f64 = _knn_matrix(mat)
+    N, k = m.shape
+    u = np.ascontiguousarray(u, dtype=np.uint16)
+    if u.shape != (N, k):
+        raise ValueError("u must have the shape of mat")
+    rm = np.zeros((3, N * k), dtype=np.float64)
+    check(_lib.load().gficf_jaccard_expand_host(_np_ptr(m), is_f64, N, k, max(N, 1), _np_ptr(u), _np_ptr(rm), int(n_threads)))
     return rm.T
 
 
@@ -111,14 +206,8 @@ def jaccard_coeff(idx, printOutput: bool = False, ctx: Context | None = None) ->
     src/jaccard_coeff.cpp:19-44): the same edges as :func:`rcpp_parallel_jaccard_coef`, but the rows with u > 0 follow
     one another from the top of the (N*k) x 3 matrix (the rest is zero) and the intersection is of the rows as sets
     (``Rcpp::intersect``; only rows that hold an id twice can tell)."""
-    idx = np.asarray(idx)
-    if idx.ndim != 2:
-        raise ValueError("idx must be a 2-d matrix")
-    N, k = idx.shape
-    if np.issubdtype(idx.dtype, np.integer):
-        m, is_f64 = np.asfortranarray(idx, dtype=np.int32), 0
-    else:
-        m, is_f64 = np.asfortranarray(idx, dtype=np.float64), 1
+    m, is_f64 = _knn_matrix(idx, "idx")
+    N, k = m.shape
     w = np.zeros((3, N * k), dtype=np.float64)      # C-order (3, E) == column-major (E, 3)
     ctx = ctx or default_context()
     check(_lib.load().gficf_jaccard_coeff_host(ctx.handle, _np_ptr(m), is_f64, N, k, max(N, 1), _np_ptr(w), 1 if printOutput else 0))
@@ -136,11 +225,8 @@ def jaccard_edges(neigh, verbose: bool = False, ctx: Context | None = None):
     neigh = np.asarray(neigh)[:, 1:]                                   # :63
     if verbose:
         print("Running Parallell Jaccard Coefficient Estimation...")
-    N, k = neigh.shape
-    if np.issubdtype(neigh.dtype, np.integer):
-        m, is_f64 = np.asfortranarray(neigh, dtype=np.int32), 0
-    else:
-        m, is_f64 = np.asfortranarray(neigh, dtype=np.float64), 1
+    m, is_f64 = _knn_matrix(neigh, "neigh")
+    N, k = m.shape
     ctx = ctx or default_context()
     L = _lib.load()
     n = ctypes.c_int64(0)
@@ -198,7 +284,7 @@ ICF_TYPES = {"classic": 0, "prob": 1, "smooth": 2}      # getIdfW(type = ...), r
 NORMS = {"l2": 0, "l1": 1}                               # l.norm(norm = ...), reference R/gficf.R:100
 
 
-def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx, icf_type="classic", norm="l2"):
+def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx, icf_type="classic", norm="l2", devices=None):
     import scipy.sparse as sp
 
     if icf_type not in ICF_TYPES or norm not in NORMS:
@@ -206,6 +292,12 @@ def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx, icf_type="classic", no
     M, colptr, rowidx, x = _csc_parts(M)
     G, N = M.shape
     L = _lib.load()
+    mc = _multi(devices) if ctx is None else None
+    if mc is not None:
+        if icf_type != "classic" or norm != "l2":
+            raise ValueError("the multi-GPU entry runs gficf() as the reference calls it: icf_type classic, norm l2")
+        return _normalize_csc_host_run(L, mc, M, colptr, rowidx, x, G, N, prop_min, prop_max, w_in,
+                                       L.gficf_normalize_csc_host_multi_plan, L.gficf_normalize_csc_host_multi_finish)
     ctx = ctx or default_context()
     check(L.gficf_ctx_set_gficf_options(ctx.handle, ICF_TYPES[icf_type], NORMS[norm]))
     try:
@@ -214,26 +306,26 @@ def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx, icf_type="classic", no
         L.gficf_ctx_set_gficf_options(ctx.handle, 0, 0)
 
 
-def _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_max, w_in):
+def _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_max, w_in, plan=None, finish=None):
     import scipy.sparse as sp
 
+    plan = plan or L.gficf_normalize_csc_host_plan
+    finish = finish or L.gficf_normalize_csc_host_finish
     gk, nk = ctypes.c_int64(0), ctypes.c_int64(0)
     if w_in is not None:
         w_in = np.ascontiguousarray(w_in, dtype=np.float64)
         if w_in.shape != (G,):
             raise ValueError("w must have one weight per gene (row) of M")
     is64 = 1 if colptr.dtype == np.int64 else 0
-    check(L.gficf_normalize_csc_host_plan(ctx.handle, G, N, _np_ptr(colptr), is64, _np_ptr(rowidx), _np_ptr(x),
-                                          float(prop_min), float(prop_max), _np_ptr(w_in),
-                                          ctypes.byref(gk), ctypes.byref(nk)))
+    check(plan(ctx.handle, G, N, _np_ptr(colptr), is64, _np_ptr(rowidx), _np_ptr(x),
+               float(prop_min), float(prop_max), _np_ptr(w_in), ctypes.byref(gk), ctypes.byref(nk)))
     keep = np.zeros(G, dtype=np.uint8)
     nt = np.zeros(G, dtype=np.int64)
     w = np.zeros(G, dtype=np.float64)
     ocp = np.zeros(N + 1, dtype=colptr.dtype)
-    ori = np.zeros(nk.value, dtype=np.int32)
-    ox = np.zeros(nk.value, dtype=np.float64)
-    check(L.gficf_normalize_csc_host_finish(ctx.handle, _np_ptr(keep), _np_ptr(nt), _np_ptr(w), _np_ptr(ocp),
-                                            _np_ptr(ori), _np_ptr(ox)))
+    ori = np.empty(nk.value, dtype=np.int32)            # fully written by the finish call
+    ox = np.empty(nk.value, dtype=np.float64)
+    check(finish(ctx.handle, _np_ptr(keep), _np_ptr(nt), _np_ptr(w), _np_ptr(ocp), _np_ptr(ori), _np_ptr(ox)))
     keep = keep.astype(bool)
     out = sp.csc_matrix((ox, ori, ocp), shape=(gk.value, N))
     return M, keep, nt, w, out
@@ -241,7 +333,7 @@ def _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_m
 
 def gficf(M, cell_proportion_max: float = 1, cell_proportion_min: float = 0.05, storeRaw: bool = True,
           normalize: bool = True, verbose: bool = True, ctx: Context | None = None, *, icf_type: str = "classic",
-          norm: str = "l2") -> dict:
+          norm: str = "l2", devices=None) -> dict:
     """Drop-in for the reference's ``gficf()`` (reference R/gficf.R:17-33).
 
     ``M``: genes x cells sparse count matrix (scipy CSC — the dgCMatrix analogue).
@@ -255,12 +347,13 @@ def gficf(M, cell_proportion_max: float = 1, cell_proportion_min: float = 0.05, 
 
     ``icf_type`` / ``norm`` (keyword only, not arguments of the reference's ``gficf()``, which always runs
     "classic" / "l2") select the other branches of its helpers ``getIdfW(type = ...)`` (R/gficf.R:89-91) and
-    ``l.norm(norm = ...)`` (R/gficf.R:100).
+    ``l.norm(norm = ...)`` (R/gficf.R:100).  ``devices`` (or the environment variable GFICF_HIP_DEVICES): a list of GPUs
+    to shard the cells over, single process (``gficf_normalize_csc_host_multi_*``); same result.
     """
     if verbose and normalize:
         warnings.warn("normalize=True: the edgeR CPM/TMM rescale (reference R/gficf.R:43-47) is a per-cell scale "
                       "that cancels in the GF step; rawCounts holds unscaled counts", stacklevel=2)
-    M, keep, nt, w, out = _normalize_csc_host(M, cell_proportion_min, cell_proportion_max, None, ctx, icf_type, norm)
+    M, keep, nt, w, out = _normalize_csc_host(M, cell_proportion_min, cell_proportion_max, None, ctx, icf_type, norm, devices)
     data = {"gficf": out}
     if storeRaw:
         data["rawCounts"] = M[np.flatnonzero(keep), :]
@@ -552,8 +645,17 @@ class HipOps:
             raise GficfError(6, f"k = {k} outside [0, {_lib.JACCARD_MAX_K}]")
         return kp
 
+    @staticmethod
+    def row_words(N_total: int, k: int) -> int:
+        """Row pitch (int32 words) of the table of an N_total-cell data set: kpad(k), or half of it where the
+        library stores the rows compactly (fewer than 2^17 cells).  Tables are (N, row_words) int32."""
+        rw = _lib.load().gficf_jaccard_row_words(int(N_total), int(k))
+        if rw < 0:
+            raise GficfError(6, f"k = {k} outside [0, {_lib.JACCARD_MAX_K}] or N_total = {N_total} beyond int32 ids")
+        return rw
+
     def jaccard_ingest(self, idx_cm, n_rows: int, k: int, N_total: int, table_rows):
-        """idx_cm: (k, ld) int32/float64 tensor == column-major n_rows x k.  table_rows: (n_rows, kpad) int32."""
+        """idx_cm: (k, ld) int32/float64 tensor == column-major n_rows x k.  table_rows: (n_rows, row_words) int32."""
         tc = self.torch
         is_f64 = 1 if idx_cm.dtype == tc.float64 else 0
         if not is_f64 and idx_cm.dtype != tc.int32:
@@ -567,14 +669,14 @@ class HipOps:
         return int(_lib.load().gficf_jaccard_packed_words(int(N_total), int(k)))
 
     def jaccard_pack_rows(self, table_rows, n_rows: int, k: int, N_total: int, packed):
-        """table_rows (n_rows, kpad) int32 -> packed (n_rows, packed_words) int32 (transport form)."""
+        """table_rows (n_rows, row_words) int32 -> packed (n_rows, packed_words) int32 (transport form)."""
         check(self.L.gficf_jaccard_pack_rows_device(self._bind(), _tptr(table_rows), n_rows, k, N_total, _tptr(packed)))
 
     def jaccard_unpack_rows(self, packed, n_rows: int, k: int, N_total: int, table_rows):
         check(self.L.gficf_jaccard_unpack_rows_device(self._bind(), _tptr(packed), n_rows, k, N_total, _tptr(table_rows)))
 
     def jaccard_edges(self, table, N: int, k: int, cell_begin: int, cell_end: int, out3, u=None):
-        """table: (N, kpad) int32.  out3: (3, (cell_end-cell_begin)*k) float64 — src, dst, weight rows."""
+        """table: (N, row_words) int32.  out3: (3, (cell_end-cell_begin)*k) float64 — src, dst, weight rows."""
         n = (cell_end - cell_begin) * k
         if out3.shape != (3, n) or out3.dtype != self.torch.float64:
             raise ValueError(f"out3 must be float64 of shape (3, {n})")
@@ -701,11 +803,16 @@ class HipOps:
             out_x=tc.zeros(max(nnz, 1), dtype=tc.float64, device=dev),
         )
 
-    def gficf_csc(self, G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None, ws=None) -> dict:
+    def gficf_csc(self, G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None, ws=None, exact: bool = False) -> dict:
         """Single-GPU GF-ICF on a device-resident CSC matrix (colptr int64).  Returns the workspace dict;
-        ``out_colptr[N]`` is the kept nnz, ``gkept[0]`` the number of kept genes."""
+        ``out_colptr[N]`` is the kept nnz, ``gkept[0]`` the number of kept genes.
+
+        ``exact=False``: the count pass does not read ``x`` (stored entries are taken for non-zero cells); if the matrix
+        stores explicit zeros the next :meth:`sync` raises ``GFICF_ERR_EXPLICIT_ZEROS`` and the call is to be repeated
+        with ``exact=True`` (the count pass reads ``x``: ``rowSums(M != 0)``, reference R/gficf.R:40,88)."""
         ws = ws or self.csc_workspace(G, N, int(rowidx.numel()))
-        check(self.L.gficf_csc_device(self._bind(), G, N, _tptr(colptr), _tptr(rowidx), _tptr(x), int(rowidx.numel()),
+        fn = self.L.gficf_csc_exact_device if exact else self.L.gficf_csc_device
+        check(fn(self._bind(), G, N, _tptr(colptr), _tptr(rowidx), _tptr(x), int(rowidx.numel()),
                                       float(prop_min), float(prop_max), _tptr(w_in), _tptr(ws["nt"]),
                                       _tptr(ws["keep"]), _tptr(ws["genes"]), _tptr(ws["w"]), _tptr(ws["gkept"]),
                                       _tptr(ws["out_colptr"]), _tptr(ws["out_rowidx"]), _tptr(ws["out_x"])))

@@ -167,13 +167,8 @@ struct gficf_adj_plan {
   double* d_x = nullptr;
 };
 
-void gficf_adj_plan_free(gficf_ctx* ctx) {
-  gficf_adj_plan* p = ctx->adj_plan;
-  if (!p) return;
-  void* ptrs[] = {p->d_indptr, p->d_indices, p->d_x};
-  for (void* q : ptrs)
-    if (q) (void)hipFree(q);
-  delete p;
+void gficf_adj_plan_free(gficf_ctx* ctx) {        // the buffers are pieces of pool slot 6: nothing to release
+  delete ctx->adj_plan;
   ctx->adj_plan = nullptr;
 }
 
@@ -195,9 +190,10 @@ int gficf_adjacency_host_plan(gficf_ctx* ctx, int64_t N, int64_t n_edges, const 
   void *d_e = nullptr, *d_ws = nullptr;
   hipError_t e = gficf_pool_get(ctx, 0, 3 * eb, &d_e);
   if (e == hipSuccess) e = gficf_pool_get(ctx, 1, wsb, &d_ws);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_indptr, sizeof(int64_t) * (size_t)(N + 1));
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_indices, sizeof(int32_t) * cap);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_x, sizeof(double) * cap);
+  gficf_arena ar;
+  const size_t o_ip = ar.take(sizeof(int64_t) * (size_t)(N + 1)), o_ii = ar.take(sizeof(int32_t) * cap), o_xx = ar.take(sizeof(double) * cap);
+  if (e == hipSuccess) e = ar.bind(ctx, 6);
+  p->d_indptr = ar.at<int64_t>(o_ip); p->d_indices = ar.at<int32_t>(o_ii); p->d_x = ar.at<double>(o_xx);
   double* d_from = (double*)d_e;
   double* d_to = d_from + (n_edges > 0 ? n_edges : 1);
   double* d_w = d_to + (n_edges > 0 ? n_edges : 1);

@@ -14,6 +14,9 @@ constexpr uint32_t GFICF_ST_BAD_ID = 1u;    // kNN id outside [1, N] or not an i
 constexpr uint32_t GFICF_ST_BAD_CSC = 2u;   // rowidx outside [0, G) / colptr not monotone
 constexpr uint32_t GFICF_ST_BAD_VALUE = 4u; // non-finite coordinate handed to the kNN search / bad edge weight
 constexpr uint32_t GFICF_ST_TOO_DENSE = 8u; // Louvain: a vertex touches more communities than its table holds
+constexpr uint32_t GFICF_ST_EXPLICIT_ZERO = 16u; // gficf_csc_device met an explicitly stored zero (its fast count is then not exact)
+
+constexpr int GFICF_POOL_SLOTS = 8;
 
 struct gficf_host_plan;  // gficf_csc.hip
 struct gficf_edge_plan;  // jaccard.hip
@@ -28,8 +31,9 @@ struct gficf_ctx {
   void* d_ws = nullptr;           // scan ticket + tile descriptors (fixed size, allocated and zeroed at create)
   uint32_t scan_epoch = 0;        // tag of the current scan launch's descriptors (22 bits, never 0)
   size_t ws_bytes = 0;
-  // Conditional re-execution (gficf_csc_device): kernels launched while cur_gate is set return at once
-  // unless *cur_gate != 0; the scaling pass raises *cur_zero when it meets an explicitly stored zero.
+  // cur_gate: kernels launched while it is set return at once unless *cur_gate != 0 (not used by any entry at present).
+  // cur_zero: when set, the scaling pass ORs GFICF_ST_EXPLICIT_ZERO into it on meeting an explicitly stored zero
+  // (gficf_csc_device points it at d_status: the violation surfaces at the next gficf_ctx_sync).
   uint32_t* d_flags = nullptr;
   const uint32_t* cur_gate = nullptr;
   uint32_t* cur_zero = nullptr;
@@ -43,13 +47,38 @@ struct gficf_ctx {
   gficf_host_plan* plan = nullptr;
   gficf_edge_plan* edge_plan = nullptr;
   gficf_adj_plan* adj_plan = nullptr;
-  // grow-only device scratch of the host entry points (kept between calls, released at destroy)
-  void* pool[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t pool_bytes[4] = {0, 0, 0, 0};
+  // grow-only device scratch of the host entry points (kept between calls, released at destroy or by
+  // gficf_ctx_trim): slots 0-3 scratch of one-call entries, 4 GF-ICF host plan, 5 filtered-edge plan,
+  // 6 adjacency plan, 7 outputs of the GF-ICF finish call.  No host entry allocates device memory per call.
+  void* pool[GFICF_POOL_SLOTS] = {};
+  size_t pool_bytes[GFICF_POOL_SLOTS] = {};
+  // print hook (R glue: Rprintf); NULL = stdout
+  void (*print_fn)(const char*) = nullptr;
 };
 
 // Device scratch slot of at least `bytes` bytes (reallocated only when it has to grow).
 hipError_t gficf_pool_get(gficf_ctx* ctx, int slot, size_t bytes, void** out);
+
+// Sub-allocation of one pool slot: take() the pieces (256 B aligned), then bind() once.
+struct gficf_arena {
+  size_t off = 0;
+  char* base = nullptr;
+  size_t take(size_t bytes) {
+    const size_t o = off;
+    off = (off + (bytes ? bytes : 1) + 255) & ~(size_t)255;
+    return o;
+  }
+  hipError_t bind(gficf_ctx* ctx, int slot) { return gficf_pool_get(ctx, slot, off ? off : 256, (void**)&base); }
+  template <typename T>
+  T* at(size_t o) const { return reinterpret_cast<T*>(base + o); }
+};
+
+// banner lines of the host entries (the reference prints with Rprintf)
+void gficf_print(gficf_ctx* ctx, const char* line);
+
+// Touch every page of a freshly allocated host buffer from several threads (first-touch page faults of a large
+// result buffer otherwise run on the one thread doing the device-to-host copy and dominate it).
+void gficf_prefault(void* p, size_t bytes);
 
 // releases the host-form GF-ICF plan held by the context, if any (gficf_csc.hip)
 void gficf_host_plan_free(gficf_ctx* ctx);

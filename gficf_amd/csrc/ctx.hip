@@ -1,5 +1,8 @@
 // ctx.hip — library context, error strings, and the int64 exclusive scan helper.
+#include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "common.h"
 
@@ -28,9 +31,64 @@ hipError_t gficf_pool_get(gficf_ctx* ctx, int slot, size_t bytes, void** out) {
   return hipSuccess;
 }
 
+void gficf_print(gficf_ctx* ctx, const char* line) {
+  if (ctx && ctx->print_fn) { ctx->print_fn(line); return; }
+  fputs(line, stdout);
+  fflush(stdout);
+}
+
+void gficf_prefault(void* p, size_t bytes) {
+  constexpr size_t PAGE = 4096, MIN_PER_THREAD = 8u << 20;
+  if (!p || bytes < 2 * MIN_PER_THREAD) return;               // small buffers: not worth the threads
+  unsigned hw = std::thread::hardware_concurrency();
+  size_t nt = hw ? hw : 4;
+  if (nt > 16) nt = 16;
+  if (nt > bytes / MIN_PER_THREAD) nt = bytes / MIN_PER_THREAD;
+  if (const char* e = getenv("GFICF_HIP_PREFAULT_THREADS")) {
+    const int v = atoi(e);
+    if (v <= 0) return;
+    nt = (size_t)v;
+  }
+  volatile char* const base = (volatile char*)p;
+  const size_t per = ((bytes / nt + PAGE - 1) / PAGE) * PAGE;
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; ++t) {
+    const size_t b = t * per, e = b + per < bytes ? b + per : bytes;
+    if (b >= e) break;
+    th.emplace_back([=] {
+      // the buffer is output-only (fully overwritten afterwards): writing is allowed and is what maps the page
+      size_t q = b;
+      const size_t mis = (size_t)((uintptr_t)(base + q) & (PAGE - 1));
+      if (mis) { base[q] = 0; q += PAGE - mis; }
+      for (; q < e; q += PAGE) base[q] = 0;
+    });
+  }
+  for (auto& t : th) t.join();
+}
+
 extern "C" {
 
 int gficf_hip_abi_version(void) { return GFICF_HIP_ABI_VERSION; }
+
+int gficf_ctx_set_print(gficf_ctx* ctx, void (*fn)(const char*)) {
+  if (!ctx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ctx is NULL");
+  ctx->print_fn = fn;
+  return GFICF_OK;
+}
+
+int gficf_ctx_trim(gficf_ctx* ctx) {
+  GFICF_CTX_ENTER(ctx);
+  GFICF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  gficf_host_plan_free(ctx);
+  gficf_edge_plan_free(ctx);
+  gficf_adj_plan_free(ctx);
+  for (int s = 0; s < GFICF_POOL_SLOTS; ++s) {
+    if (ctx->pool[s]) (void)hipFree(ctx->pool[s]);
+    ctx->pool[s] = nullptr;
+    ctx->pool_bytes[s] = 0;
+  }
+  return GFICF_OK;
+}
 
 const char* gficf_last_error(void) { return g_err; }
 
@@ -127,6 +185,9 @@ int gficf_ctx_sync(gficf_ctx* ctx) {
     GFICF_FAIL(GFICF_ERR_BAD_VALUE, "a non-finite kNN coordinate, or an edge weight that is negative / not finite");
   if (st & GFICF_ST_BAD_CSC)
     GFICF_FAIL(GFICF_ERR_BAD_CSC, "CSC matrix malformed: row index outside [0, G) or colptr not monotone");
+  if (st & GFICF_ST_EXPLICIT_ZERO)
+    GFICF_FAIL(GFICF_ERR_EXPLICIT_ZEROS, "the CSC matrix stores explicit zeros, which gficf_csc_device's count of stored entries takes for "
+                                         "non-zero cells (rowSums(M != 0), reference R/gficf.R:40,88): call gficf_csc_exact_device");
   if (st & GFICF_ST_TOO_DENSE)
     GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "Louvain: one hash class of a vertex's neighbouring communities overflowed the 8192-slot table");
   return GFICF_OK;

@@ -40,7 +40,7 @@ __device__ inline void count_one(int32_t g, double v, int64_t G, uint32_t* hist,
 
 // HAS_X == false counts every stored entry (4 B/nnz): exact whenever the matrix stores no explicit
 // zeros, which the scaling pass verifies for free (it reads x anyway) — see gficf_csc_device.
-template <bool USE_LDS, bool VEC, bool HAS_X>
+template <bool USE_LDS, bool VEC, bool HAS_X, bool NARROW = true>
 __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __restrict__ rowidx,
                                                             const double* __restrict__ x, int64_t nnz, int64_t G,
                                                             unsigned long long* __restrict__ nt,
@@ -93,7 +93,12 @@ __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __res
       if (g >= G) g -= G;
       if (g >= G) g %= G;
       const uint32_t c = s_hist[g];
-      if (c) atomicAdd(&nt[g], (unsigned long long)c);
+      // the flush is bound by the memory-side atomic rate in BYTES (5.9 M adds at config 3): the counters are 64-bit, the
+      // add is done on their low words (little endian; a count never reaches 2^32: cells carry int32 ids) — half the bytes
+      if (c) {
+        if (NARROW) atomicAdd(reinterpret_cast<uint32_t*>(&nt[g]), c);
+        else atomicAdd(&nt[g], (unsigned long long)c);
+      }
     }
   }
 }
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
       }
     }
   }
-  if (zero_flag != nullptr && saw_zero) atomicOr(zero_flag, 1u);
+  if (zero_flag != nullptr && saw_zero) atomicOr(zero_flag, GFICF_ST_EXPLICIT_ZERO);
 }
 
 // ------------------------------------------------ pass B, LDS-resident gene tables
@@ -596,7 +601,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
       }
     }
   }
-  if (zero_flag != nullptr && saw_zero) atomicOr(zero_flag, 1u);
+  if (zero_flag != nullptr && saw_zero) atomicOr(zero_flag, GFICF_ST_EXPLICIT_ZERO);
 }
 
 __global__ __launch_bounds__(256) void k_zero_i64(int64_t* __restrict__ p, int64_t n, const uint32_t* gate) {
@@ -896,13 +901,13 @@ int gficf_cluster_signatures_host(gficf_ctx* ctx, int64_t G, int64_t N, const vo
     if (cp[(size_t)c + 1] < cp[(size_t)c] || cp[0] != 0) GFICF_FAIL(GFICF_ERR_BAD_CSC, "colptr not monotone at cell %lld", (long long)c);
   const int64_t nnz = cp[(size_t)N];
   if (nnz > 0 && (!rowidx || !x)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
-  int64_t* d_cp = nullptr; int32_t* d_ri = nullptr; double* d_x = nullptr; int32_t* d_cl = nullptr; double* d_out = nullptr;
   const size_t nsz = (size_t)(nnz > 0 ? nnz : 1), csz = (size_t)(N > 0 ? N : 1);
-  hipError_t e = hipMalloc((void**)&d_cp, sizeof(int64_t) * ((size_t)N + 1));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_ri, sizeof(int32_t) * nsz);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_x, sizeof(double) * nsz);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_cl, sizeof(int32_t) * csz);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_out, sizeof(double) * (size_t)G * (size_t)C);
+  gficf_arena ar;                                   // pool slot 0 (the device form takes slot 3 for its own scratch)
+  const size_t o_cp = ar.take(sizeof(int64_t) * ((size_t)N + 1)), o_ri = ar.take(sizeof(int32_t) * nsz), o_x = ar.take(sizeof(double) * nsz);
+  const size_t o_cl = ar.take(sizeof(int32_t) * csz), o_out = ar.take(sizeof(double) * (size_t)G * (size_t)C);
+  hipError_t e = ar.bind(ctx, 0);
+  int64_t* const d_cp = ar.at<int64_t>(o_cp); int32_t* const d_ri = ar.at<int32_t>(o_ri); double* const d_x = ar.at<double>(o_x);
+  int32_t* const d_cl = ar.at<int32_t>(o_cl); double* const d_out = ar.at<double>(o_out);
   if (e == hipSuccess) e = hipMemcpyAsync(d_cp, cp.data(), sizeof(int64_t) * cp.size(), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_ri, rowidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
@@ -914,8 +919,6 @@ int gficf_cluster_signatures_host(gficf_ctx* ctx, int64_t G, int64_t N, const vo
     if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
     else (void)hipStreamSynchronize(ctx->stream);
   }
-  void* ptrs[] = {d_cp, d_ri, d_x, d_cl, d_out};
-  for (void* q : ptrs) if (q) (void)hipFree(q);
   if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_cluster_signatures_host: %s", hipGetErrorString(e));
   return rc;
 }
@@ -925,46 +928,56 @@ size_t gficf_csc_genes_bytes(int64_t G) {
   return g * sizeof(gficf_gene_entry) + g * sizeof(double) + ((g * sizeof(uint16_t) + 63) & ~(size_t)63) + 64;
 }
 
-int gficf_csc_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colptr, const int32_t* d_rowidx,
-                     const double* d_x, int64_t nnz, double prop_min, double prop_max, const double* d_w_in,
-                     int64_t* d_nt, uint8_t* d_keep, gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept,
-                     int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
+static int csc_sequence(gficf_ctx* ctx, bool exact, int64_t G, int64_t N, const int64_t* d_colptr, const int32_t* d_rowidx,
+                        const double* d_x, int64_t nnz, double prop_min, double prop_max, const double* d_w_in,
+                        int64_t* d_nt, uint8_t* d_keep, gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept,
+                        int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
   GFICF_CTX_ENTER(ctx);
   if (G < 0 || N < 0 || nnz < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (G > 0) {
     if (!d_nt) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
     GFICF_HIP_CHECK(hipMemsetAsync(d_nt, 0, sizeof(int64_t) * (size_t)G, ctx->stream));
   }
-  // Fast sequence: pass A counts stored entries without reading x (4 B/nnz instead of 12).  That equals
-  // nt_g = #{x != 0} unless the matrix stores explicit zeros, which the scaling pass checks for free
-  // (it reads every x anyway) and reports in a device flag.  The exact sequence (pass A reading x) is
-  // enqueued behind it, gated on that flag: with no explicit zeros its kernels return at once.
-  uint32_t* const flag = ctx->d_flags;
-  GFICF_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
   int rc = GFICF_OK;
-  for (int pass = 0; pass < 2 && rc == GFICF_OK; ++pass) {
-    const bool exact = pass == 1;
-    ctx->cur_gate = exact ? flag : nullptr;
-    if (exact && G > 0) {
-      hipLaunchKernelGGL(k_zero_i64, dim3((unsigned)gficf_ceil_div(G, 256)), dim3(256), 0, ctx->stream, d_nt, G, ctx->cur_gate);
-    }
-    if (nnz > 0 && G > 0) {
-      if (!d_rowidx || !d_x || !d_nt) { ctx->cur_gate = nullptr; GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer"); }
-      rc = launch_count(ctx, G, d_rowidx, exact ? d_x : (const double*)nullptr, nnz, d_nt);
-    }
-    if (!rc) rc = gficf_csc_genes_device(ctx, G, N, d_nt, prop_min, prop_max, d_w_in, d_keep, d_genes, d_w, d_gkept);
-    if (!rc) rc = gficf_csc_colptr_device(ctx, G, N, d_colptr, d_rowidx, d_keep, d_gkept, d_out_colptr);
-    ctx->cur_zero = exact ? nullptr : flag;
-    if (!rc) rc = gficf_csc_scale_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x);
-    ctx->cur_zero = nullptr;
+  if (nnz > 0 && G > 0) {
+    if (!d_rowidx || !d_x || !d_nt) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+    rc = launch_count(ctx, G, d_rowidx, exact ? d_x : (const double*)nullptr, nnz, d_nt);
   }
-  ctx->cur_gate = nullptr;
+  if (!rc) rc = gficf_csc_genes_device(ctx, G, N, d_nt, prop_min, prop_max, d_w_in, d_keep, d_genes, d_w, d_gkept);
+  if (!rc) rc = gficf_csc_colptr_device(ctx, G, N, d_colptr, d_rowidx, d_keep, d_gkept, d_out_colptr);
+  ctx->cur_zero = exact ? nullptr : ctx->d_status;
+  if (!rc) rc = gficf_csc_scale_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x);
+  ctx->cur_zero = nullptr;
   return rc;
+}
+
+/* Fast sequence: pass A counts stored entries without reading x (4 B/nnz instead of 12).  That equals
+ * nt_g = #{x != 0} unless the matrix stores explicit zeros, which the scaling pass checks for free (it reads every x
+ * anyway): it then raises a deferred status and the next gficf_ctx_sync() returns GFICF_ERR_EXPLICIT_ZEROS — the outputs
+ * are to be discarded and gficf_csc_exact_device called instead.  (Round 1 enqueued the exact sequence behind every
+ * call, gated on a device flag: eight launches that returned at once in the common case, 6 % of the pass.) */
+int gficf_csc_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colptr, const int32_t* d_rowidx,
+                     const double* d_x, int64_t nnz, double prop_min, double prop_max, const double* d_w_in,
+                     int64_t* d_nt, uint8_t* d_keep, gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept,
+                     int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
+  return csc_sequence(ctx, false, G, N, d_colptr, d_rowidx, d_x, nnz, prop_min, prop_max, d_w_in, d_nt, d_keep, d_genes, d_w, d_gkept,
+                      d_out_colptr, d_out_rowidx, d_out_x);
+}
+
+/* Exact sequence: pass A reads x and counts the non-zero entries (12 B/nnz); explicit zeros are handled. */
+int gficf_csc_exact_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colptr, const int32_t* d_rowidx,
+                           const double* d_x, int64_t nnz, double prop_min, double prop_max, const double* d_w_in,
+                           int64_t* d_nt, uint8_t* d_keep, gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept,
+                           int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
+  return csc_sequence(ctx, true, G, N, d_colptr, d_rowidx, d_x, nnz, prop_min, prop_max, d_w_in, d_nt, d_keep, d_genes, d_w, d_gkept,
+                      d_out_colptr, d_out_rowidx, d_out_x);
 }
 
 }  // extern "C"
 
 // ------------------------------------------------------------------- host form (R glue)
+// Device buffers are pieces of the context's pool (slot 4 for the plan, slot 7 for the outputs of the finish
+// call): kept between calls, nothing is allocated or freed per call.
 struct gficf_host_plan {
   int64_t G = 0, N = 0, nnz = 0, nnz_kept = 0, g_kept = 0;
   int colptr_is_i64 = 0;
@@ -981,12 +994,7 @@ struct gficf_host_plan {
 };
 
 void gficf_host_plan_free(gficf_ctx* ctx) {
-  gficf_host_plan* p = ctx->plan;
-  if (!p) return;
-  void* ptrs[] = {p->d_colptr, p->d_rowidx, p->d_x, p->d_w_in, p->d_nt, p->d_keep, p->d_genes, p->d_w, p->d_gkept, p->d_out_colptr};
-  for (void* q : ptrs)
-    if (q) (void)hipFree(q);
-  delete p;
+  delete ctx->plan;
   ctx->plan = nullptr;
 }
 
@@ -1022,22 +1030,22 @@ int gficf_normalize_csc_host_plan(gficf_ctx* ctx, int64_t G, int64_t N, const vo
   ctx->plan = p;
   p->G = G; p->N = N; p->nnz = nnz; p->colptr_is_i64 = colptr_is_i64;
   const size_t gsz = (size_t)(G > 0 ? G : 1), nsz = (size_t)(nnz > 0 ? nnz : 1);
-  PLAN_HIP(hipMalloc((void**)&p->d_colptr, sizeof(int64_t) * ((size_t)N + 1)));
-  PLAN_HIP(hipMalloc((void**)&p->d_rowidx, sizeof(int32_t) * nsz));
-  PLAN_HIP(hipMalloc((void**)&p->d_x, sizeof(double) * nsz));
-  PLAN_HIP(hipMalloc((void**)&p->d_nt, sizeof(int64_t) * gsz));
-  PLAN_HIP(hipMalloc((void**)&p->d_keep, gsz));
-  PLAN_HIP(hipMalloc((void**)&p->d_genes, gficf_csc_genes_bytes(G)));
-  PLAN_HIP(hipMalloc((void**)&p->d_w, sizeof(double) * gsz));
-  PLAN_HIP(hipMalloc((void**)&p->d_gkept, sizeof(int64_t)));
-  PLAN_HIP(hipMalloc((void**)&p->d_out_colptr, sizeof(int64_t) * ((size_t)N + 1)));
+  gficf_arena ar;
+  const size_t o_cp = ar.take(sizeof(int64_t) * ((size_t)N + 1)), o_ri = ar.take(sizeof(int32_t) * nsz), o_x = ar.take(sizeof(double) * nsz);
+  const size_t o_nt = ar.take(sizeof(int64_t) * gsz), o_keep = ar.take(gsz), o_genes = ar.take(gficf_csc_genes_bytes(G));
+  const size_t o_w = ar.take(sizeof(double) * gsz), o_gk = ar.take(sizeof(int64_t)), o_ocp = ar.take(sizeof(int64_t) * ((size_t)N + 1));
+  const size_t o_win = ar.take(sizeof(double) * gsz);
+  PLAN_HIP(ar.bind(ctx, 4));
+  p->d_colptr = ar.at<int64_t>(o_cp); p->d_rowidx = ar.at<int32_t>(o_ri); p->d_x = ar.at<double>(o_x);
+  p->d_nt = ar.at<int64_t>(o_nt); p->d_keep = ar.at<uint8_t>(o_keep); p->d_genes = ar.at<gficf_gene_entry>(o_genes);
+  p->d_w = ar.at<double>(o_w); p->d_gkept = ar.at<int64_t>(o_gk); p->d_out_colptr = ar.at<int64_t>(o_ocp);
   PLAN_HIP(hipMemcpyAsync(p->d_colptr, cp.data(), sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice, ctx->stream));
   if (nnz > 0) {
     PLAN_HIP(hipMemcpyAsync(p->d_rowidx, rowidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
     PLAN_HIP(hipMemcpyAsync(p->d_x, x, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
   }
   if (w_in && G > 0) {
-    PLAN_HIP(hipMalloc((void**)&p->d_w_in, sizeof(double) * gsz));
+    p->d_w_in = ar.at<double>(o_win);
     PLAN_HIP(hipMemcpyAsync(p->d_w_in, w_in, sizeof(double) * (size_t)G, hipMemcpyHostToDevice, ctx->stream));
   }
   PLAN_HIP(hipMemsetAsync(p->d_nt, 0, sizeof(int64_t) * gsz, ctx->stream));
@@ -1066,14 +1074,20 @@ int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, 
   gficf_host_plan* p = ctx->plan;
   if (!p) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "gficf_normalize_csc_host_finish without a plan");
   if (!out_colptr || (p->nnz_kept > 0 && (!out_rowidx || !out_x))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
-  int32_t* d_ori = nullptr;
-  double* d_ox = nullptr;
   const size_t ksz = (size_t)(p->nnz_kept > 0 ? p->nnz_kept : 1);
-  PLAN_HIP(hipMalloc((void**)&d_ori, sizeof(int32_t) * ksz));
-  hipError_t e2 = hipMalloc((void**)&d_ox, sizeof(double) * ksz);
-  if (e2 != hipSuccess) { (void)hipFree(d_ori); PLAN_HIP(e2); }
+  gficf_arena ar;
+  const size_t o_ri = ar.take(sizeof(int32_t) * ksz), o_x = ar.take(sizeof(double) * ksz);
+  PLAN_HIP(ar.bind(ctx, 7));
+  int32_t* const d_ori = ar.at<int32_t>(o_ri);
+  double* const d_ox = ar.at<double>(o_x);
   int rc = gficf_csc_scale_device(ctx, p->G, p->N, p->d_colptr, p->d_rowidx, p->d_x, p->nnz, p->d_genes, p->d_gkept,
                                   p->d_out_colptr, d_ori, d_ox);
+  // the caller's result vectors are freshly allocated as a rule: map their pages from several threads while the
+  // scaling pass runs, instead of one page fault at a time under the device-to-host copy
+  if (!rc && p->nnz_kept > 0) {
+    gficf_prefault(out_x, sizeof(double) * (size_t)p->nnz_kept);
+    gficf_prefault(out_rowidx, sizeof(int32_t) * (size_t)p->nnz_kept);
+  }
   std::vector<int64_t> cp((size_t)p->N + 1);
   hipError_t e = hipSuccess;
   if (!rc) {
@@ -1086,8 +1100,6 @@ int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, 
     if (e == hipSuccess) rc = gficf_ctx_sync(ctx);
   }
   if (e != hipSuccess || rc) (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_ori);
-  (void)hipFree(d_ox);
   if (e != hipSuccess) { gficf_set_error("HIP failure in gficf_normalize_csc_host_finish: %s", hipGetErrorString(e)); rc = GFICF_ERR_HIP; }
   if (!rc) {
     if (p->colptr_is_i64) std::memcpy(out_colptr, cp.data(), sizeof(int64_t) * cp.size());

@@ -19,9 +19,12 @@
 //               double, so they are bit-identical to the reference's division.
 //   * rows with duplicate ids (multiset semantics), hash overflow: exact slow path in the
 //               same kernel (all-pairs with occurrence ranks).
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 
@@ -33,6 +36,58 @@ constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 
 __host__ __device__ inline int kpad_for(int k) {
   return k <= 16 ? 16 : k <= 32 ? 32 : k <= 64 ? 64 : k <= 128 ? 128 : 256;
+}
+
+// ------------------------------------------------------------------------ table row formats
+// wide    : KPAD x uint32 ids (zero padded); bit 31 of word 0 = "row holds duplicate ids".
+// compact : for data sets of fewer than 2^17 cells (ids fit 17 bits) a row of KPAD slots takes half the
+//           bytes: KC = KPAD - KPAD/16 ids as uint16 low halves, then NW = KPAD/32 words of high bits
+//           (bit j of the bitmap = bit 16 of id j); bit 31 of the row's last word = the duplicate flag.
+//           k = 30 -> 64 B instead of 128 B per row.  The edge kernel is bound by the row gathers (one
+//           L1 miss per edge, served by L2 / Infinity Cache): half the table means twice the L2 hit rate.
+// The format is a function of (N_total, k) alone, so every rank of a sharded build agrees on it.
+template <int KPAD>
+struct CFmt {
+  static constexpr int KC = KPAD - KPAD / 16;   // usable slots
+  static constexpr int NW = KPAD / 32;          // words of high bits
+  static constexpr int ROWW = KPAD / 2;         // row pitch in 32-bit words
+  static constexpr int HIW = ROWW - NW;         // word index of the first high-bit word
+};
+
+struct TableFmt {
+  int kpad;
+  bool compact;
+  int row_words;
+};
+
+inline bool compact_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("GFICF_JACCARD_COMPACT");       // test hook: 0 keeps every table in the wide format
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+
+inline TableFmt table_fmt(int64_t N_total, int k) {
+  TableFmt f;
+  f.kpad = kpad_for(k);
+  static const bool force_big = getenv("GFICF_JACCARD_FORCE_BIG") != nullptr;     // test hook of the 64-bit kernel variant: wide rows
+  f.compact = compact_enabled() && !force_big && N_total < (1ll << 17) && f.kpad >= 32 && k <= f.kpad - f.kpad / 16;
+  f.row_words = f.compact ? f.kpad / 2 : f.kpad;
+  return f;
+}
+
+// id of slot j (0 = none) / duplicate flag of a row given as 32-bit words (global memory or LDS)
+__device__ inline uint32_t row_slot_id(const uint32_t* roww, int j, int kpad, bool compact) {
+  if (!compact) return roww[j] & ID_MASK;
+  const int kc = kpad - kpad / 16;
+  if (j >= kc) return 0u;
+  const uint32_t lo = (roww[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+  const uint32_t hw = roww[kpad / 2 - kpad / 32 + (j >> 5)];
+  return lo | (((hw >> (j & 31)) & 1u) << 16);
+}
+__device__ inline bool row_dup_flag(const uint32_t* roww, int kpad, bool compact) {
+  return ((compact ? roww[kpad / 2 - 1] : roww[0]) & ROW_DUP_FLAG) != 0;
 }
 
 // ------------------------------------------------------------------------------ ingest
@@ -53,13 +108,14 @@ __device__ inline uint32_t decode_id<double>(double raw, int64_t N, bool& ok) {
 constexpr int INGEST_ROWS = 64;
 
 // Tile transpose: 64 cells x KPAD slots per step.  Reads are coalesced along cells
-// (column-major input), writes are one contiguous 64*KPAD*4 B run of the table.
-template <typename T, int KPAD>
+// (column-major input), writes are one contiguous run of the table (64 rows).
+template <typename T, int KPAD, bool CMP>
 __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                 int64_t N_total, uint32_t* __restrict__ table,
                                                 uint32_t* __restrict__ status) {
   __shared__ uint32_t tile[INGEST_ROWS][KPAD + 1];
   __shared__ uint32_t dup[INGEST_ROWS];
+  constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int64_t row0 = (int64_t)blockIdx.x * INGEST_ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * INGEST_ROWS) {
     const int64_t r = row0 + lane;
@@ -86,12 +142,107 @@ __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64
     if (d) dup[lane] = 1;
     __syncthreads();
     const int64_t rows_here = (n_rows - row0) < INGEST_ROWS ? (n_rows - row0) : INGEST_ROWS;
-    const int n_out = (int)rows_here * KPAD;
+    const int n_out = (int)rows_here * ROWW;
     for (int e = tid; e < n_out; e += 256) {
-      const int rr = e / KPAD, j = e % KPAD;
-      uint32_t v = tile[rr][j];
-      if (j == 0 && dup[rr]) v |= ROW_DUP_FLAG;
-      table[row0 * KPAD + e] = v;
+      const int rr = e / ROWW, j = e % ROWW;
+      uint32_t v;
+      if (!CMP) {
+        v = tile[rr][j];
+        if (j == 0 && dup[rr]) v |= ROW_DUP_FLAG;
+      } else if (j < CFmt<KPAD>::HIW) {
+        v = (tile[rr][2 * j] & 0xFFFFu) | (tile[rr][2 * j + 1] << 16);
+      } else {
+        const int j0 = (j - CFmt<KPAD>::HIW) * 32;
+        v = 0;
+        for (int b = 0; b < 32 && j0 + b < CFmt<KPAD>::KC; ++b) v |= ((tile[rr][j0 + b] >> 16) & 1u) << b;
+        if (j == ROWW - 1 && dup[rr]) v |= ROW_DUP_FLAG;
+      }
+      table[row0 * ROWW + e] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// Tile variant for KPAD <= 64 (the common sizes): 64 cells per workgroup of 256 threads.  Reads are coalesced along
+// cells, every (cell, slot) element is one thread's: validation, then duplicate detection by inserting the id into the
+// cell's own little hash set in LDS (2*KPAD slots, linear probing: a compare-and-swap that finds its own value has
+// found a duplicate), then the rows are packed and leave as contiguous 16 B-per-lane runs.  ~1 LDS atomic per id
+// instead of the KPAD^2/2 register compares per cell of k_ingest_reg, and four times the threads in flight.
+template <typename T, int KPAD, bool CMP>
+__global__ __launch_bounds__(256) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
+                                                     int64_t N_total, uint32_t* __restrict__ table,
+                                                     uint32_t* __restrict__ status) {
+  constexpr int ROWS = 64, HS = 2 * KPAD;
+  constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
+  __shared__ uint32_t tile[ROWS][KPAD + 1];
+  __shared__ uint32_t hs[ROWS][HS];
+  __shared__ uint32_t dup[ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int64_t row0 = (int64_t)blockIdx.x * ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * ROWS) {
+    const int64_t r = row0 + lane;
+    // all loads of the thread are issued before the first is looked at
+    T raw[KPAD / 4];
+#pragma unroll
+    for (int m = 0; m < KPAD / 4; ++m) {
+      const int j = wave + 4 * m;
+      raw[m] = (j < k && r < n_rows) ? idx[(int64_t)j * ld + r] : (T)0;
+    }
+    for (int e = tid; e < ROWS * HS; e += 256) (&hs[0][0])[e] = EMPTY;
+    if (tid < ROWS) dup[tid] = 0;
+    bool bad = false;
+    uint32_t v[KPAD / 4];
+#pragma unroll
+    for (int m = 0; m < KPAD / 4; ++m) {
+      const int j = wave + 4 * m;
+      v[m] = 0;
+      if (j < k && r < n_rows) {
+        bool ok;
+        v[m] = decode_id<T>(raw[m], N_total, ok);
+        bad |= !ok;
+      }
+      tile[lane][j] = v[m];
+    }
+    if (bad) atomicOr(status, GFICF_ST_BAD_ID);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < KPAD / 4; ++m) {
+      if (v[m] != 0) {
+        uint32_t h = (v[m] * 0x9E3779B1u) >> (32 - (KPAD == 16 ? 5 : KPAD == 32 ? 6 : 7));
+        for (int probe = 0; probe < HS; ++probe) {          // at most KPAD of the 2*KPAD slots are ever taken
+          const uint32_t old = atomicCAS(&hs[lane][h], EMPTY, v[m]);
+          if (old == EMPTY) break;
+          if (old == v[m]) { dup[lane] = 1; break; }
+          h = (h + 1) & (HS - 1);
+        }
+      }
+    }
+    __syncthreads();
+    const int64_t rows_here = (n_rows - row0) < ROWS ? (n_rows - row0) : ROWS;
+    const int n_out4 = (int)rows_here * (ROWW / 4);
+    uint4* const out4 = reinterpret_cast<uint4*>(table + row0 * ROWW);
+    for (int e = tid; e < n_out4; e += 256) {
+      const int rr = e / (ROWW / 4), j0 = (e % (ROWW / 4)) * 4;
+      uint32_t w4[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int j = j0 + c;
+        uint32_t x;
+        if (!CMP) {
+          x = tile[rr][j];
+          if (j == 0 && dup[rr]) x |= ROW_DUP_FLAG;
+        } else if (j < CFmt<KPAD>::HIW) {
+          x = (tile[rr][2 * j] & 0xFFFFu) | (tile[rr][2 * j + 1] << 16);
+        } else {
+          const int b0 = (j - CFmt<KPAD>::HIW) * 32;
+          x = 0;
+#pragma unroll
+          for (int b = 0; b < 32; ++b)
+            if (b0 + b < CFmt<KPAD>::KC) x |= ((tile[rr][b0 + b] >> 16) & 1u) << b;
+          if (j == ROWW - 1 && dup[rr]) x |= ROW_DUP_FLAG;
+        }
+        w4[c] = x;
+      }
+      out4[e] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
     __syncthreads();
   }
@@ -103,11 +254,12 @@ __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64
 // contiguous 16 B-per-lane runs.
 constexpr int INGEST2_ROWS = 64;
 
-template <typename T, int KPAD>
+template <typename T, int KPAD, bool CMP>
 __global__ __launch_bounds__(INGEST2_ROWS) void k_ingest_reg(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                              int64_t N_total, uint32_t* __restrict__ table,
                                                              uint32_t* __restrict__ status) {
-  __shared__ uint32_t tile[INGEST2_ROWS][KPAD + 1];
+  constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
+  __shared__ uint32_t tile[INGEST2_ROWS][ROWW + 1];
   const int tid = threadIdx.x;
   for (int64_t row0 = (int64_t)blockIdx.x * INGEST2_ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * INGEST2_ROWS) {
     const int64_t r = row0 + tid;
@@ -131,15 +283,30 @@ __global__ __launch_bounds__(INGEST2_ROWS) void k_ingest_reg(const T* __restrict
       for (int j2 = 0; j2 < j; ++j2) dj |= (v[j] == v[j2]);
       dup |= dj && v[j] != 0;
     }
-    if (dup) v[0] |= ROW_DUP_FLAG;
+    if (!CMP) {
+      if (dup) v[0] |= ROW_DUP_FLAG;
 #pragma unroll
-    for (int j = 0; j < KPAD; ++j) tile[tid][j] = v[j];
+      for (int j = 0; j < KPAD; ++j) tile[tid][j] = v[j];
+    } else {
+      using F = CFmt<KPAD>;
+#pragma unroll
+      for (int w = 0; w < F::HIW; ++w) tile[tid][w] = (v[2 * w] & 0xFFFFu) | (v[2 * w + 1] << 16);
+#pragma unroll
+      for (int h = 0; h < F::NW; ++h) {
+        uint32_t hw = 0;
+#pragma unroll
+        for (int b = 0; b < 32; ++b)
+          if (h * 32 + b < F::KC) hw |= ((v[h * 32 + b] >> 16) & 1u) << b;
+        if (h == F::NW - 1 && dup) hw |= ROW_DUP_FLAG;
+        tile[tid][F::HIW + h] = hw;
+      }
+    }
     __syncthreads();
     const int64_t rows_here = (n_rows - row0) < INGEST2_ROWS ? (n_rows - row0) : INGEST2_ROWS;
-    const int n_out4 = (int)rows_here * (KPAD / 4);
-    uint4* const out4 = reinterpret_cast<uint4*>(table + row0 * KPAD);
+    const int n_out4 = (int)rows_here * (ROWW / 4);
+    uint4* const out4 = reinterpret_cast<uint4*>(table + row0 * ROWW);
     for (int e = tid; e < n_out4; e += INGEST2_ROWS) {
-      const int rr = e / (KPAD / 4), jj = (e % (KPAD / 4)) * 4;
+      const int rr = e / (ROWW / 4), jj = (e % (ROWW / 4)) * 4;
       out4[e] = make_uint4(tile[rr][jj], tile[rr][jj + 1], tile[rr][jj + 2], tile[rr][jj + 3]);
     }
     __syncthreads();
@@ -148,9 +315,15 @@ __global__ __launch_bounds__(INGEST2_ROWS) void k_ingest_reg(const T* __restrict
 
 // ------------------------------------------------------------------------------- edges
 template <int KPAD>
+constexpr int jc_threads = (KPAD <= 128 ? 4 : 2) * 64;        // threads of an edge-kernel workgroup
+
+template <int KPAD, bool CMP>
 struct JCfg {
-  static constexpr int LPR = KPAD / 4;                        // lanes per neighbour row (16 B per lane)
+  static constexpr int ROWB = CMP ? KPAD * 2 : KPAD * 4;      // bytes per table row
+  static constexpr int LPR = ROWB / 16;                       // lanes per neighbour row (16 B per lane)
   static constexpr int RPS = 64 / LPR;                        // neighbour rows per wave-instruction ("step")
+  static constexpr int IPL = CMP ? 8 : 4;                     // ids a lane holds of a gathered row
+  static constexpr int NSLOT = CMP ? CFmt<KPAD>::KC : KPAD;   // usable slots of a row
   static constexpr int EPL = KPAD > 64 ? KPAD / 64 : 1;       // registers holding row i (slot s -> reg s/64, lane s%64)
   static constexpr int SPQ = (KPAD < 64 ? KPAD : 64) / RPS;   // steps per register of row i
   static constexpr int NB = 8 * KPAD;                         // 2-slot buckets in the hash set
@@ -167,7 +340,7 @@ extern "C" __device__ uint32_t gficf_mul_u24(uint32_t a, uint32_t b) __asm("llvm
 
 template <int KPAD, bool BIG>
 __device__ inline uint32_t bucket_off(uint32_t id) {
-  constexpr uint32_t HMASK = (uint32_t)(JCfg<KPAD>::NB - 1) << 3;
+  constexpr uint32_t HMASK = (uint32_t)(JCfg<KPAD, false>::NB - 1) << 3;
   return (BIG ? id * 0x9E3779B1u : gficf_mul_u24(id, 0x9E3779u)) & HMASK;
 }
 
@@ -204,35 +377,43 @@ struct EdgeOut {
                     // 1 = set intersection (Rcpp::intersect of the serial jaccard_coeff entry)
 };
 
+// Output modes of the edge kernel (a template parameter, so that the number of stores per cell is known to the
+// compiler: it can then wait for the row gathers alone, leaving the stores issued behind them in flight)
+constexpr int OUT_RMAT = 0;       // the three columns of the reference's edge matrix
+constexpr int OUT_RMAT_U = 1;     // the same + int32 intersection counts
+constexpr int OUT_U16 = 2;        // uint16 intersection counts only (edge filter, compact host return)
+
+template <int OUT>
 __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint32_t dst, int u,
                                   const double* lut) {
   const bool pos = u > 0;
   // written once, never re-read by this kernel: non-temporal, so the table rows keep the L2
-  if (o.src) {
+  if (OUT != OUT_U16) {
     __builtin_nontemporal_store(pos ? (double)(uint32_t)(cell + 1) : 0.0, o.src + r);   // reference :49 (cell + 1 <= 2^31)
     __builtin_nontemporal_store(pos ? (double)dst : 0.0, o.dst + r);                    // reference :50
     __builtin_nontemporal_store(pos ? lut[u] : 0.0, o.w + r);                           // reference :51
   }
-  if (o.u) __builtin_nontemporal_store(u, o.u + r);
-  if (o.u16) o.u16[r] = (uint16_t)u;
+  if (OUT == OUT_RMAT_U) __builtin_nontemporal_store(u, o.u + r);
+  if (OUT == OUT_U16) o.u16[r] = (uint16_t)u;
 }
 
 // Exact multiset path for one cell whose own row or one of whose neighbour rows holds
 // duplicate ids (never the case for real kNN output).
 // u = sum over distinct values of min(multiplicity in A, multiplicity in B), evaluated as
 // "element e of B counts iff its occurrence rank within B is below the value's multiplicity in A".
-template <int KPAD>
+template <int KPAD, bool CMP, int OUT>
 __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64_t i, int k, int64_t out_base,
                                        uint32_t* sA, uint32_t* sB, int lane, double* o_src, double* o_dst,
                                        double* o_w, int32_t* o_u, uint16_t* o_u16, int set_mode, const double* lut) {
   const EdgeOut o{o_src, o_dst, o_w, o_u, o_u16, set_mode};
-  for (int e = lane; e < KPAD; e += 64) sA[e] = table[i * KPAD + e] & ID_MASK;
+  constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
+  for (int e = lane; e < KPAD; e += 64) sA[e] = row_slot_id(table + i * ROWW, e, KPAD, CMP);
   wave_lds_fence();
   for (int s = 0; s < k; ++s) {
     const uint32_t dst = sA[s];
     int u = 0;
     if (dst != 0) {
-      for (int e = lane; e < KPAD; e += 64) sB[e] = table[(int64_t)(dst - 1) * KPAD + e] & ID_MASK;
+      for (int e = lane; e < KPAD; e += 64) sB[e] = row_slot_id(table + (int64_t)(dst - 1) * ROWW, e, KPAD, CMP);
       wave_lds_fence();
       int cnt = 0;
       for (int e = lane; e < k; e += 64) {
@@ -251,7 +432,7 @@ __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64
       u = cnt;
       wave_lds_fence();
     }
-    if (lane == 0) store_edge(o, out_base + s, i, dst, u, lut);
+    if (lane == 0) store_edge<OUT>(o, out_base + s, i, dst, u, lut);
   }
 }
 
@@ -271,17 +452,19 @@ __device__ inline int group_sum(int x) {
 // One wave per cell, cells strided over all waves of the grid.  Per cell:
 //   * row i (one id per lane) is inserted into the wave's LDS hash set; keys that find both
 //     slots of their bucket taken go to a small per-wave overflow list;
-//   * "steps": each lane loads 16 B (4 ids) of a neighbour row, so KPAD/4 lanes cover one row
-//     and a wave-instruction gathers RPS = 256/KPAD rows; U steps are in flight together;
-//   * every lane probes the set with its 4 ids (one ds_read_b64 per id), the per-row
+//   * "steps": each lane loads 16 B of a neighbour row (4 ids wide / 8 ids compact), so ROWB/16 lanes cover
+//     one row and a wave-instruction gathers RPS = 1024/ROWB rows; U steps are in flight together;
+//   * every lane probes the set with its ids (one ds_read_b64 per id), the per-row
 //     intersection count is a DPP sum over the row's lanes;
 //   * counts are permuted back to one-slot-per-lane and stored as three coalesced runs.
 // The load of the next cell's own row is issued ahead of the gathers and the stores of the
 // previous cell's edges behind them, so neither sits on the wait for the gathers.
-template <int KPAD, bool BIG>
-__global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
+template <int KPAD, bool BIG, bool CMP, int OUT>
+__global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
-  using C = JCfg<KPAD>;
+  using C = JCfg<KPAD, CMP>;
+  using F = CFmt<KPAD>;
+  static_assert(!(BIG && CMP), "compact rows hold 17-bit ids");
   using off_t = typename std::conditional<BIG, uint64_t, uint32_t>::type;
   // LDS (dynamic, laid out here so that a wave's hash set starts at a multiple of its size and a probe
   // address is (hash & mask) | wave_base):  hash sets | overflow list / slow-path rows | weight table
@@ -302,29 +485,118 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
   const uint32_t wave_off = lds_address(smem) + (uint32_t)wave * HBYTES;
   uint32_t* const ovlist = s_rows[wave][0];
   const char* const tbytes = reinterpret_cast<const char*>(table);
-  const bool arow_lane = KPAD >= 64 || lane < KPAD;         // lanes that hold an id of row i
   const int grow = lane / C::LPR;                           // which of the RPS rows of a step this lane reads
-  const uint32_t gcol = (uint32_t)(lane % C::LPR) * 16u;    // byte offset of this lane's 4 ids inside a row
+  const int gl = lane % C::LPR;                             // this lane's 16 B piece of that row
+  const uint32_t gcol = (uint32_t)gl * 16u;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const int64_t nwaves = (int64_t)gridDim.x * C::WAVES;
-  constexpr uint32_t ROWB = KPAD * 4;
+  constexpr uint32_t ROWB = C::ROWB;
+  constexpr int ROWW = ROWB / 4;
+  // compact rows: where this lane finds the high bits of its 8 ids — byte (gl & 3) of high word gl / 4, which
+  // sits in component hi_c of the piece held by lane hi_l of the row's lane group
+  const int hi_abs = F::HIW + (gl >> 2);
+  const int hi_l = lane - gl + (hi_abs >> 2), hi_c = hi_abs & 3;
+  const bool tail = gl >= F::KC / 8;                        // the lane(s) holding the high-bit words
+
+  // Own row of a cell: slot s -> register s / 64, lane s % 64.  The loads are issued one cell ahead and their
+  // results stay untouched in registers until the next iteration decodes them (any arithmetic on them here would
+  // put the wait for the load in front of the gathers).
+  struct OwnRaw {
+    uint32_t v[C::EPL];      // wide: the id word; compact: the 16-bit low half
+    uint32_t hw[C::EPL];     // compact: the word of high bits covering the slot
+    uint32_t last;           // compact: the row's last word (duplicate flag)
+  };
+  auto load_own = [&](int64_t row, OwnRaw& r) {
+    const uint32_t* const rw = table + row * ROWW;
+    if (CMP) r.last = rw[ROWW - 1];
+#pragma unroll
+    for (int q = 0; q < C::EPL; ++q) {
+      const int s = q * 64 + lane;
+      r.v[q] = 0;
+      r.hw[q] = 0;
+      if (s < C::NSLOT) {
+        if (!CMP) {
+          r.v[q] = rw[s];
+        } else {
+          r.v[q] = reinterpret_cast<const uint16_t*>(rw)[s];
+          r.hw[q] = (KPAD == 32) ? 0u : rw[F::HIW + (s >> 5)];      // KPAD = 32: the only high word is the last word
+        }
+      }
+    }
+  };
+  auto decode_own = [&](const OwnRaw& r, uint32_t (&out)[C::EPL]) {
+#pragma unroll
+    for (int q = 0; q < C::EPL; ++q) {
+      if (!CMP) {
+        out[q] = r.v[q];
+      } else {
+        const int s = q * 64 + lane;
+        const uint32_t hw = (KPAD == 32) ? r.last : r.hw[q];
+        out[q] = s < C::NSLOT ? (r.v[q] | (((hw >> (s & 31)) & 1u) << 16) | (r.last & ROW_DUP_FLAG)) : 0u;
+      }
+    }
+  };
 
   int64_t i = cell_begin + (int64_t)blockIdx.x * C::WAVES + wave;
-  uint32_t araw[C::EPL];
+  OwnRaw raw;
+  raw.last = 0;
 #pragma unroll
-  for (int q = 0; q < C::EPL; ++q) araw[q] = 0;
-  if (i < cell_end && arow_lane) {
-#pragma unroll
-    for (int q = 0; q < C::EPL; ++q) araw[q] = table[i * KPAD + q * 64 + lane];
-  }
+  for (int q = 0; q < C::EPL; ++q) { raw.v[q] = 0; raw.hw[q] = 0; }
+  if (i < cell_end) load_own(i, raw);
   // edges of the previous cell, stored while the current cell's gathers are in flight
   bool have_prev = false;
   int64_t prev_i = 0;
   uint32_t prev_a[C::EPL];
   int prev_u[C::EPL];
 
+  auto store_prev = [&]() {
+    const int64_t pb = (prev_i - cell_begin) * (int64_t)k;
+#pragma unroll
+    for (int qq = 0; qq < C::EPL; ++qq) {
+      const int slot = qq * 64 + lane;
+      if (slot < C::NSLOT && slot < k) store_edge<OUT>(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
+    }
+    have_prev = false;
+  };
+
+  // ids of a gathered piece (bv) -> id[]; returns the word that may carry the row's duplicate flag
+  auto piece_ids = [&](const uint4& bv, uint32_t (&id)[C::IPL]) -> uint32_t {
+    if (!CMP) {
+      id[0] = bv.x & ID_MASK;                // only a row's first id can carry the duplicate flag
+      id[1] = bv.y;
+      id[2] = bv.z;
+      id[3] = bv.w;
+      return bv.x;
+    }
+    // the high-bit word of this lane's ids, from the lane that holds it
+    uint32_t hw;
+    if (KPAD == 32) {
+      hw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv.w, 0xFF, 0xf, 0xf, false);   // quad_perm [3,3,3,3]
+    } else {
+      hw = 0;
+      if (F::NW >= 4) { const uint32_t v = (uint32_t)__shfl((int)bv.x, hi_l); hw = hi_c == 0 ? v : hw; }
+      if (F::NW >= 4) { const uint32_t v = (uint32_t)__shfl((int)bv.y, hi_l); hw = hi_c == 1 ? v : hw; }
+      { const uint32_t v = (uint32_t)__shfl((int)bv.z, hi_l); hw = hi_c == 2 ? v : hw; }
+      { const uint32_t v = (uint32_t)__shfl((int)bv.w, hi_l); hw = hi_c == 3 ? v : hw; }
+    }
+    uint32_t hb = (hw >> ((gl & 3) * 8)) & 0xFFu;
+    uint32_t wd[4] = {bv.x, bv.y, bv.z, bv.w};
+    if (tail) {                              // high-bit words are not ids
+      hb &= (1u << (F::KC % 8)) - 1u;
+#pragma unroll
+      for (int c = (F::KC % 8) / 2; c < 4; ++c) wd[c] = 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const uint32_t lo = (t & 1) ? (wd[t >> 1] >> 16) : (wd[t >> 1] & 0xFFFFu);
+      id[t] = lo | ((hb << (16 - t)) & 0x10000u);
+    }
+    return (gl == C::LPR - 1) ? bv.w : 0u;   // the row's last word holds the flag
+  };
+
   for (; i < cell_end; i += nwaves) {
-    uint32_t a[C::EPL], asafe[C::EPL];
+    uint32_t araw[C::EPL], a[C::EPL], asafe[C::EPL];
+    decode_own(raw, araw);
     uint32_t flags = 0;
 #pragma unroll
     for (int q = 0; q < C::EPL; ++q) {
@@ -337,50 +609,25 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
     bool slow = __ballot((flags & ROW_DUP_FLAG) != 0) != 0ull;
     // next cell's own row: ahead of the gathers, so that it has landed by the next iteration
     const int64_t i_next = i + nwaves;
-    if (i_next < cell_end && arow_lane) {
-#pragma unroll
-      for (int q = 0; q < C::EPL; ++q) araw[q] = table[i_next * KPAD + q * 64 + lane];
-    }
-    int myslot[C::EPL];
-    int nov = 0;
-#pragma unroll
-    for (int q = 0; q < C::EPL; ++q) myslot[q] = -1;
-    if (!slow) {
-#pragma unroll
-      for (int q = 0; q < C::EPL; ++q) {
-        bool over = false;
-        if (a[q] != 0) {
-          const uint32_t bo = bucket_off<KPAD, BIG>(a[q]) + (uint32_t)wave * HBYTES;   // byte offset of the bucket in smem
-          uint32_t old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo), EMPTY, a[q]);
-          if (old == EMPTY) {
-            myslot[q] = (int)bo;
-          } else {
-            old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo + 4), EMPTY, a[q]);
-            if (old == EMPTY) myslot[q] = (int)bo + 4;
-            else over = true;
-          }
-        }
-        const unsigned long long om = __ballot(over);
-        if (om) {
-          if (over) ovlist[nov + __popcll(om & lt_mask)] = a[q];
-          nov += __popcll(om);
-        }
-      }
-      wave_lds_fence();
-    }
+    if (i_next < cell_end) load_own(i_next, raw);
 
     int myu[C::EPL];
 #pragma unroll
     for (int q = 0; q < C::EPL; ++q) myu[q] = 0;
+    int myslot[C::EPL];
+    int nov = 0;
+#pragma unroll
+    for (int q = 0; q < C::EPL; ++q) myslot[q] = -1;
     bool prev_stored = false;
 
     if (!slow) {
       uint32_t dupflags = 0;
+      bool inserted = false;
 #pragma unroll
       for (int q = 0; q < C::EPL; ++q) {        // q: which register of row i holds the slots of these steps
         for (int t0 = 0; t0 < C::SPQ && (q * 64 + t0 * C::RPS) < k; t0 += C::U) {
           uint4 bv[C::U];
-          // issue the gathers of U steps (U*RPS neighbour rows) before consuming any
+          // issue the gathers of U steps (U*RPS neighbour rows) before anything else
 #pragma unroll
           for (int uu = 0; uu < C::U; ++uu) {
             const uint32_t dst = (uint32_t)__shfl((int)asafe[q], (t0 + uu) * C::RPS + grow);
@@ -388,42 +635,56 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
             bv[uu] = *reinterpret_cast<const uint4*>(tbytes + off);
           }
           if (!prev_stored) {
-            // the previous cell's edges ride behind the gathers (younger in vmcnt order, so the
-            // wait for the gathers does not wait for them)
+            // the previous cell's edges ride behind the gathers (younger in vmcnt order, and of a count the compiler
+            // knows, so the wait for the gathers does not wait for them)
             prev_stored = true;
-            if (have_prev) {
-              const int64_t pb = (prev_i - cell_begin) * (int64_t)k;
+            if (have_prev) store_prev();
+          }
+          if (!inserted) {
+            // row i into the hash set, under the latency of the first gathers
+            inserted = true;
 #pragma unroll
-              for (int qq = 0; qq < C::EPL; ++qq) {
-                const int slot = qq * 64 + lane;
-                if (arow_lane && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
+            for (int qi = 0; qi < C::EPL; ++qi) {
+              bool over = false;
+              if (a[qi] != 0) {
+                const uint32_t bo = bucket_off<KPAD, BIG>(a[qi]) + (uint32_t)wave * HBYTES;   // byte offset of the bucket in smem
+                uint32_t old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo), EMPTY, a[qi]);
+                if (old == EMPTY) {
+                  myslot[qi] = (int)bo;
+                } else {
+                  old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo + 4), EMPTY, a[qi]);
+                  if (old == EMPTY) myslot[qi] = (int)bo + 4;
+                  else over = true;
+                }
               }
-              have_prev = false;
+              const unsigned long long om = __ballot(over);
+              if (om) {
+                if (over) ovlist[nov + __popcll(om & lt_mask)] = a[qi];
+                nov += __popcll(om);
+              }
             }
+            wave_lds_fence();
           }
           int cnt[C::U];
 #pragma unroll
           for (int uu = 0; uu < C::U; ++uu) {
-            dupflags |= bv[uu].x;
-            bv[uu].x &= ID_MASK;             // only a row's first id can carry the duplicate flag
-            const uint2 h0 = lds_read_b64(bucket_off<KPAD, BIG>(bv[uu].x) | wave_off);
-            const uint2 h1 = lds_read_b64(bucket_off<KPAD, BIG>(bv[uu].y) | wave_off);
-            const uint2 h2 = lds_read_b64(bucket_off<KPAD, BIG>(bv[uu].z) | wave_off);
-            const uint2 h3 = lds_read_b64(bucket_off<KPAD, BIG>(bv[uu].w) | wave_off);
-            int c = 0;
-            c = add_lane_bit(c, __ballot(h0.x == bv[uu].x) | __ballot(h0.y == bv[uu].x));
-            c = add_lane_bit(c, __ballot(h1.x == bv[uu].y) | __ballot(h1.y == bv[uu].y));
-            c = add_lane_bit(c, __ballot(h2.x == bv[uu].z) | __ballot(h2.y == bv[uu].z));
-            c = add_lane_bit(c, __ballot(h3.x == bv[uu].w) | __ballot(h3.y == bv[uu].w));
-            cnt[uu] = c;
-          }
-          if (nov) {                          // wave-uniform, rare: ids that overflowed the set
-            for (int t = 0; t < nov; ++t) {
-              const uint32_t ov = ovlist[t];
+            uint32_t id[C::IPL];
+            dupflags |= piece_ids(bv[uu], id);
+            // all probes of the piece are issued before the first is compared
+            uint2 h[C::IPL];
 #pragma unroll
-              for (int uu = 0; uu < C::U; ++uu)
-                cnt[uu] += (bv[uu].x == ov) + (bv[uu].y == ov) + (bv[uu].z == ov) + (bv[uu].w == ov);
+            for (int t = 0; t < C::IPL; ++t) h[t] = lds_read_b64(bucket_off<KPAD, BIG>(id[t]) | wave_off);
+            int c = 0;
+#pragma unroll
+            for (int t = 0; t < C::IPL; ++t) c = add_lane_bit(c, __ballot(h[t].x == id[t]) | __ballot(h[t].y == id[t]));
+            if (nov) {                          // wave-uniform, rare: ids that overflowed the set
+              for (int t = 0; t < nov; ++t) {
+                const uint32_t ov = ovlist[t];
+#pragma unroll
+                for (int tt = 0; tt < C::IPL; ++tt) c += (id[tt] == ov);
+              }
             }
+            cnt[uu] = c;
           }
 #pragma unroll
           for (int uu = 0; uu < C::U; ++uu) {
@@ -437,23 +698,15 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
       // a neighbour row with duplicate ids: redo this cell exactly
       slow = __ballot((dupflags & ROW_DUP_FLAG) != 0) != 0ull;
     }
-    if (!prev_stored && have_prev) {    // own row with duplicates: the gather loop was skipped
-      const int64_t pb = (prev_i - cell_begin) * (int64_t)k;
-#pragma unroll
-      for (int qq = 0; qq < C::EPL; ++qq) {
-        const int slot = qq * 64 + lane;
-        if (arow_lane && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
-      }
-      have_prev = false;
-    }
+    if (!prev_stored && have_prev) store_prev();    // own row with duplicates (or k == 0): the gather loop was skipped
     // ---- clear this cell's keys from the set
 #pragma unroll
     for (int q = 0; q < C::EPL; ++q)
       if (myslot[q] >= 0) *reinterpret_cast<uint32_t*>(smem + myslot[q]) = EMPTY;
     wave_lds_fence();
     if (slow) {
-      slow_cell<KPAD>(table, i, k, (i - cell_begin) * (int64_t)k, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w,
-                      o.u, o.u16, o.set_mode, s_lut);
+      slow_cell<KPAD, CMP, OUT>(table, i, k, (i - cell_begin) * (int64_t)k, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w,
+                                o.u, o.u16, o.set_mode, s_lut);
     } else {
       have_prev = true;
       prev_i = i;
@@ -464,14 +717,7 @@ __global__ __launch_bounds__(JCfg<KPAD>::WAVES * 64) void k_jaccard_edges(
       }
     }
   }
-  if (have_prev) {
-    const int64_t pb = (prev_i - cell_begin) * (int64_t)k;
-#pragma unroll
-    for (int qq = 0; qq < C::EPL; ++qq) {
-      const int slot = qq * 64 + lane;
-      if (arow_lane && slot < k) store_edge(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
-    }
-  }
+  if (have_prev) store_prev();
 }
 
 // ------------------------------------------------------------------ edge filter (N1)
@@ -487,7 +733,7 @@ __global__ __launch_bounds__(256) void k_edge_kept_count(const uint16_t* __restr
   out[c] = n;
 }
 
-template <int KPAD>
+template <int KPAD, bool CMP>
 __global__ __launch_bounds__(256) void k_edge_write(const uint32_t* __restrict__ table, const uint16_t* __restrict__ u16,
                                                     int k, int64_t cell_begin, int64_t n_cells,
                                                     const int64_t* __restrict__ ptr, double* __restrict__ from,
@@ -506,7 +752,7 @@ __global__ __launch_bounds__(256) void k_edge_write(const uint32_t* __restrict__
       uint32_t dst = 0;
       if (s < k) {
         u = u16[c * k + s];
-        dst = table[(cell_begin + c) * KPAD + s] & ID_MASK;
+        dst = row_slot_id(table + (cell_begin + c) * (CMP ? CFmt<KPAD>::ROWW : KPAD), s, KPAD, CMP);
       }
       const bool kp = u > 0;
       const unsigned long long m = __ballot(kp);
@@ -536,25 +782,26 @@ __host__ __device__ inline int packed_words(int64_t N, int k) { return (k * id_b
 // contiguous runs; every thread assembles whole 32-bit output words.
 constexpr int PACK_ROWS = 64;
 
-__global__ __launch_bounds__(256) void k_pack_rows(const uint32_t* __restrict__ table, int64_t n_rows, int k, int kpad,
+__global__ __launch_bounds__(256) void k_pack_rows(const uint32_t* __restrict__ table, int64_t n_rows, int k, int kpad, int compact,
                                                    int bits, int wpr, uint32_t* __restrict__ packed) {
-  extern __shared__ uint32_t s_tb[];                        // PACK_ROWS * kpad words
+  extern __shared__ uint32_t s_tb[];                        // PACK_ROWS * row_words words
+  const int roww = compact ? kpad / 2 : kpad;
   const int fl = k * bits;                                  // bit position of the duplicate flag
   for (int64_t row0 = (int64_t)blockIdx.x * PACK_ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * PACK_ROWS) {
     const int rows_here = (int)((n_rows - row0) < PACK_ROWS ? (n_rows - row0) : PACK_ROWS);
-    for (int e = threadIdx.x; e < rows_here * kpad; e += 256) s_tb[e] = table[row0 * kpad + e];
+    for (int e = threadIdx.x; e < rows_here * roww; e += 256) s_tb[e] = table[row0 * roww + e];
     __syncthreads();
     for (int e = threadIdx.x; e < rows_here * wpr; e += 256) {
       const int rr = e / wpr, w = e % wpr;
-      const uint32_t* row = s_tb + rr * kpad;
+      const uint32_t* row = s_tb + rr * roww;
       const int lo = 32 * w, hi = lo + 32;
       uint32_t v = 0;
       for (int j = lo / bits; j < k && j * bits < hi; ++j) {
-        const uint32_t id = row[j] & ID_MASK;
+        const uint32_t id = row_slot_id(row, j, kpad, compact != 0);
         const int pos = j * bits - lo;
         v |= pos >= 0 ? id << pos : id >> (-pos);
       }
-      if (fl >= lo && fl < hi) v |= (row[0] >> 31) << (fl - lo);
+      if (fl >= lo && fl < hi) v |= (row_dup_flag(row, kpad, compact != 0) ? 1u : 0u) << (fl - lo);
       packed[row0 * wpr + e] = v;
     }
     __syncthreads();
@@ -562,30 +809,44 @@ __global__ __launch_bounds__(256) void k_pack_rows(const uint32_t* __restrict__ 
 }
 
 // 64 rows per workgroup: the packed words are staged in LDS with coalesced loads, every thread then
-// extracts ids for consecutive slots, so the table is written as contiguous runs.
+// assembles whole table words, so the table is written as contiguous runs.
 constexpr int UNPACK_ROWS = 64;
 
-__global__ __launch_bounds__(256) void k_unpack_rows(const uint32_t* __restrict__ packed, int64_t n_rows, int k, int kpad,
+__device__ inline uint32_t packed_id(const uint32_t* in, int j, int bits, int wpr, uint32_t mask) {
+  const int off = j * bits, w = off >> 5, sh = off & 31;
+  unsigned long long v = in[w];
+  if (w + 1 < wpr) v |= (unsigned long long)in[w + 1] << 32;
+  return (uint32_t)(v >> sh) & mask;
+}
+
+__global__ __launch_bounds__(256) void k_unpack_rows(const uint32_t* __restrict__ packed, int64_t n_rows, int k, int kpad, int compact,
                                                      int bits, int wpr, uint32_t* __restrict__ table) {
   extern __shared__ uint32_t s_pk[];                        // UNPACK_ROWS * wpr words
   const uint32_t mask = (uint32_t)(((unsigned long long)1 << bits) - 1ull);
   const int fl_w = (k * bits) >> 5, fl_b = (k * bits) & 31; // position of the duplicate flag
+  const int roww = compact ? kpad / 2 : kpad;
+  const int hiw = kpad / 2 - kpad / 32;                     // compact rows: first word of high bits
   for (int64_t row0 = (int64_t)blockIdx.x * UNPACK_ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * UNPACK_ROWS) {
     const int rows_here = (int)((n_rows - row0) < UNPACK_ROWS ? (n_rows - row0) : UNPACK_ROWS);
     for (int e = threadIdx.x; e < rows_here * wpr; e += 256) s_pk[e] = packed[row0 * wpr + e];
     __syncthreads();
-    for (int e = threadIdx.x; e < rows_here * kpad; e += 256) {
-      const int rr = e / kpad, j = e % kpad;
-      uint32_t id = 0;
-      if (j < k) {
-        const uint32_t* in = s_pk + rr * wpr;
-        const int off = j * bits, w = off >> 5, sh = off & 31;
-        unsigned long long v = in[w];
-        if (w + 1 < wpr) v |= (unsigned long long)in[w + 1] << 32;
-        id = (uint32_t)(v >> sh) & mask;
-        if (j == 0) id |= ((in[fl_w] >> fl_b) & 1u) << 31;
+    for (int e = threadIdx.x; e < rows_here * roww; e += 256) {
+      const int rr = e / roww, j = e % roww;
+      const uint32_t* in = s_pk + rr * wpr;
+      const uint32_t dupf = ((in[fl_w] >> fl_b) & 1u) << 31;
+      uint32_t v = 0;
+      if (!compact) {
+        if (j < k) v = packed_id(in, j, bits, wpr, mask);
+        if (j == 0) v |= dupf;
+      } else if (j < hiw) {
+        if (2 * j < k) v = packed_id(in, 2 * j, bits, wpr, mask) & 0xFFFFu;
+        if (2 * j + 1 < k) v |= packed_id(in, 2 * j + 1, bits, wpr, mask) << 16;
+      } else {
+        const int j0 = (j - hiw) * 32;
+        for (int b = 0; b < 32 && j0 + b < k; ++b) v |= ((packed_id(in, j0 + b, bits, wpr, mask) >> 16) & 1u) << b;
+        if (j == roww - 1) v |= dupf;
       }
-      table[row0 * kpad + e] = id;
+      table[row0 * roww + e] = v;
     }
     __syncthreads();
   }
@@ -594,24 +855,31 @@ __global__ __launch_bounds__(256) void k_unpack_rows(const uint32_t* __restrict_
 template <typename T>
 int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t ld, int64_t N_total,
                   uint32_t* table) {
-  const int kpad = kpad_for(k);
+  const TableFmt f = table_fmt(N_total, k);
   const int64_t cap = (int64_t)ctx->num_cus * 8;
   const int64_t tiles2 = gficf_ceil_div(n_rows, INGEST2_ROWS);
   const unsigned grid2 = (unsigned)(tiles2 < cap ? tiles2 : cap);
   const int64_t tiles = gficf_ceil_div(n_rows, INGEST_ROWS);
   const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
-#define LAUNCH_INGEST_REG(KP)                                                                                          \
-  hipLaunchKernelGGL((k_ingest_reg<T, KP>), dim3(grid2), dim3(INGEST2_ROWS), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
+  static const bool use_reg = getenv("GFICF_JACCARD_INGEST_REG") != nullptr;     // test hook: the one-thread-per-cell variant
+#define LAUNCH_INGEST_REG(KP, CM)                                                                                          \
+  do {                                                                                                                     \
+    if (use_reg)                                                                                                           \
+      hipLaunchKernelGGL((k_ingest_reg<T, KP, CM>), dim3(grid2), dim3(INGEST2_ROWS), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
+                         table, ctx->d_status);                                                                            \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((k_ingest_tile<T, KP, CM>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total,  \
+                         table, ctx->d_status);                                                                            \
+  } while (0)
+#define LAUNCH_INGEST(KP, CM)                                                                                   \
+  hipLaunchKernelGGL((k_ingest<T, KP, CM>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
                      table, ctx->d_status)
-#define LAUNCH_INGEST(KP)                                                                                   \
-  hipLaunchKernelGGL((k_ingest<T, KP>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
-                     table, ctx->d_status)
-  switch (kpad) {
-    case 16: LAUNCH_INGEST_REG(16); break;
-    case 32: LAUNCH_INGEST_REG(32); break;
-    case 64: LAUNCH_INGEST_REG(64); break;
-    case 128: LAUNCH_INGEST(128); break;
-    default: LAUNCH_INGEST(256); break;
+  switch (f.kpad) {
+    case 16: LAUNCH_INGEST_REG(16, false); break;
+    case 32: if (f.compact) LAUNCH_INGEST_REG(32, true); else LAUNCH_INGEST_REG(32, false); break;
+    case 64: if (f.compact) LAUNCH_INGEST_REG(64, true); else LAUNCH_INGEST_REG(64, false); break;
+    case 128: if (f.compact) LAUNCH_INGEST(128, true); else LAUNCH_INGEST(128, false); break;
+    default: if (f.compact) LAUNCH_INGEST(256, true); else LAUNCH_INGEST(256, false); break;
   }
 #undef LAUNCH_INGEST
 #undef LAUNCH_INGEST_REG
@@ -621,35 +889,42 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
 
 template <int KPAD>
 constexpr size_t edges_lds_bytes() {
-  using C = JCfg<KPAD>;
+  using C = JCfg<KPAD, false>;
   return (size_t)C::WAVES * C::NB * 8 + (size_t)C::WAVES * 2 * KPAD * 4 + (GFICF_JACCARD_MAX_K + 1) * sizeof(double);
 }
 
-template <int KPAD, bool BIG>
-int launch_edges_t(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
-  using C = JCfg<KPAD>;
+template <int KPAD, bool BIG, bool CMP, int OUT>
+int launch_edges_o(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+  using C = JCfg<KPAD, CMP>;
   // grid = what is resident at once (occupancy x CUs); waves stride over the cells
-  static int blocks_per_cu = 0;
+  static std::atomic<int> blocks_per_cu_cached{0};
+  int blocks_per_cu = blocks_per_cu_cached.load(std::memory_order_relaxed);
   if (blocks_per_cu == 0) {
     int nb = 0;
-    GFICF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_jaccard_edges<KPAD, BIG>, C::WAVES * 64, edges_lds_bytes<KPAD>()));
-    // 3 workgroups per CU already saturate the L2-miss path that bounds this kernel (measured: 3..16
-    // per CU run at the same speed, 2 is 20 % slower); not taking every wave slot leaves room for the
-    // neighbouring step's edge kernel and the next batch's ingest / all-gather kernels, which the
-    // pipelined caller runs concurrently on other streams (measured best there: 3)
-    blocks_per_cu = nb > 3 ? 3 : nb > 0 ? nb : 1;
+    GFICF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_jaccard_edges<KPAD, BIG, CMP, OUT>, C::WAVES * 64, edges_lds_bytes<KPAD>()));
+    // The kernel is bound by the L1's outstanding row gathers, not by wave slots: beyond 6 workgroups per CU nothing
+    // is gained (measured on the memory-pattern model, tools/lab/gather_lab.hip: 3 -> 6 per CU is 10-20 % faster).
+    blocks_per_cu = nb > 6 ? 6 : nb > 0 ? nb : 1;
     if (const char* e = getenv("GFICF_JACCARD_BLOCKS_PER_CU")) {   // tuning knob
       const int v = atoi(e);
       if (v > 0) blocks_per_cu = v;
     }
+    blocks_per_cu_cached.store(blocks_per_cu, std::memory_order_relaxed);   // same value whoever computes it
   }
   const int64_t blocks_needed = gficf_ceil_div(ce - cb, C::WAVES);
   const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
   const unsigned grid = (unsigned)(blocks_needed < cap ? blocks_needed : cap);
-  hipLaunchKernelGGL((k_jaccard_edges<KPAD, BIG>), dim3(grid), dim3(C::WAVES * 64), edges_lds_bytes<KPAD>(), ctx->stream, table,
+  hipLaunchKernelGGL((k_jaccard_edges<KPAD, BIG, CMP, OUT>), dim3(grid), dim3(C::WAVES * 64), edges_lds_bytes<KPAD>(), ctx->stream, table,
                      N, k, cb, ce, o);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
+}
+
+template <int KPAD, bool BIG, bool CMP>
+int launch_edges_t(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+  if (o.u16) return launch_edges_o<KPAD, BIG, CMP, OUT_U16>(ctx, table, N, k, cb, ce, o);
+  if (o.u) return launch_edges_o<KPAD, BIG, CMP, OUT_RMAT_U>(ctx, table, N, k, cb, ce, o);
+  return launch_edges_o<KPAD, BIG, CMP, OUT_RMAT>(ctx, table, N, k, cb, ce, o);
 }
 
 template <int KPAD>
@@ -657,8 +932,20 @@ int launch_edges(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_
   // 32-bit byte offsets and the 24-bit hash multiply need table < 4 GiB and ids < 2^24
   static const bool force_big = getenv("GFICF_JACCARD_FORCE_BIG") != nullptr;   // test hook for the 64-bit variant
   const bool big = force_big || N >= (1ll << 24) || N * (int64_t)KPAD * 4 >= (1ll << 32);
-  return big ? launch_edges_t<KPAD, true>(ctx, table, N, k, cb, ce, o)
-             : launch_edges_t<KPAD, false>(ctx, table, N, k, cb, ce, o);
+  if (KPAD >= 32 && table_fmt(N, k).compact)          // compact rows: N < 2^17, never the 64-bit variant (the test hook switches them off)
+    return launch_edges_t<KPAD, false, KPAD >= 32>(ctx, table, N, k, cb, ce, o);
+  return big ? launch_edges_t<KPAD, true, false>(ctx, table, N, k, cb, ce, o)
+             : launch_edges_t<KPAD, false, false>(ctx, table, N, k, cb, ce, o);
+}
+
+int launch_edges_k(gficf_ctx* ctx, const uint32_t* t, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+  switch (kpad_for(k)) {
+    case 16: return launch_edges<16>(ctx, t, N, k, cb, ce, o);
+    case 32: return launch_edges<32>(ctx, t, N, k, cb, ce, o);
+    case 64: return launch_edges<64>(ctx, t, N, k, cb, ce, o);
+    case 128: return launch_edges<128>(ctx, t, N, k, cb, ce, o);
+    default: return launch_edges<256>(ctx, t, N, k, cb, ce, o);
+  }
 }
 
 int check_nk(int64_t N, int k) {
@@ -675,6 +962,11 @@ int check_nk(int64_t N, int k) {
 extern "C" {
 
 int gficf_jaccard_kpad(int k) { return (k < 0 || k > GFICF_JACCARD_MAX_K) ? -1 : kpad_for(k); }
+
+int gficf_jaccard_row_words(int64_t N_total, int k) {
+  if (N_total < 0 || N_total > 0x7FFFFFFFll || k < 0 || k > GFICF_JACCARD_MAX_K) return -1;
+  return table_fmt(N_total, k).row_words;
+}
 
 int gficf_jaccard_ingest_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int64_t n_rows, int k,
                                 int64_t ld, int64_t N_total, int32_t* d_table_rows) {
@@ -699,14 +991,7 @@ int gficf_jaccard_edges_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N
   if (cell_end == cell_begin || k == 0) return GFICF_OK;
   if (!d_table || !d_src || !d_dst || !d_w) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   EdgeOut o{d_src, d_dst, d_w, d_u, nullptr, 0};
-  const uint32_t* t = (const uint32_t*)d_table;
-  switch (kpad_for(k)) {
-    case 16: return launch_edges<16>(ctx, t, N, k, cell_begin, cell_end, o);
-    case 32: return launch_edges<32>(ctx, t, N, k, cell_begin, cell_end, o);
-    case 64: return launch_edges<64>(ctx, t, N, k, cell_begin, cell_end, o);
-    case 128: return launch_edges<128>(ctx, t, N, k, cell_begin, cell_end, o);
-    default: return launch_edges<256>(ctx, t, N, k, cell_begin, cell_end, o);
-  }
+  return launch_edges_k(ctx, (const uint32_t*)d_table, N, k, cell_begin, cell_end, o);
 }
 
 int gficf_jaccard_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int64_t N, int k, int64_t ld,
@@ -722,19 +1007,19 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
   GFICF_CTX_ENTER(ctx);
   int rc = check_nk(N, k);
   if (rc) return rc;
-  if (print_output) { printf("Running Parallell Jaccard Coefficient Estimation...\n"); fflush(stdout); }  // reference :63
+  if (print_output) gficf_print(ctx, "Running Parallell Jaccard Coefficient Estimation...\n");  // reference :63
   const int64_t E = N * (int64_t)k;
   if (E > 0) {
     if (!idx || !rmat) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
     if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
     const size_t esz = idx_is_f64 ? sizeof(double) : sizeof(int32_t);
-    const int kpad = kpad_for(k);
+    const int roww = table_fmt(N, k).row_words;
     void* d_idx = nullptr;
     int32_t* d_table = nullptr;
     double* d_rmat = nullptr;
     // device scratch comes from the context's grow-only pool: no hipMalloc/hipFree per call
     hipError_t e = gficf_pool_get(ctx, 0, esz * (size_t)ld * (size_t)k, &d_idx);
-    if (e == hipSuccess) e = gficf_pool_get(ctx, 1, sizeof(int32_t) * (size_t)N * (size_t)kpad, (void**)&d_table);
+    if (e == hipSuccess) e = gficf_pool_get(ctx, 1, sizeof(int32_t) * (size_t)N * (size_t)roww, (void**)&d_table);
     if (e == hipSuccess) e = gficf_pool_get(ctx, 2, sizeof(double) * 3 * (size_t)E, (void**)&d_rmat);
     if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, esz * (size_t)ld * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
     rc = GFICF_OK;
@@ -747,7 +1032,82 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
     if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_jaccard_host: %s", hipGetErrorString(e));
     if (rc) return rc;
   }
-  if (print_output) { printf("Done!!\n"); fflush(stdout); }  // reference :77
+  if (print_output) gficf_print(ctx, "Done!!\n");  // reference :77
+  return GFICF_OK;
+}
+
+/* Compact host return: the intersection counts alone, 2 B per edge instead of the reference's 24 B row (a row is a
+ * function of (i, idx[i,j], u): gficf_jaccard_expand_host rebuilds the reference matrix from them on the host). */
+int gficf_jaccard_counts_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, uint16_t* u) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = check_nk(N, k);
+  if (rc) return rc;
+  const int64_t E = N * (int64_t)k;
+  if (E == 0) return GFICF_OK;
+  if (!idx || !u) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
+  if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
+  const size_t esz = idx_is_f64 ? sizeof(double) : sizeof(int32_t);
+  const int roww = table_fmt(N, k).row_words;
+  void* d_idx = nullptr;
+  int32_t* d_table = nullptr;
+  uint16_t* d_u = nullptr;
+  hipError_t e = gficf_pool_get(ctx, 0, esz * (size_t)ld * (size_t)k, &d_idx);
+  if (e == hipSuccess) e = gficf_pool_get(ctx, 1, sizeof(int32_t) * (size_t)N * (size_t)roww, (void**)&d_table);
+  if (e == hipSuccess) e = gficf_pool_get(ctx, 2, sizeof(uint16_t) * (size_t)E, (void**)&d_u);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, esz * (size_t)ld * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    rc = gficf_jaccard_ingest_device(ctx, d_idx, idx_is_f64, N, k, ld, N, d_table);
+    if (!rc) {
+      EdgeOut o{nullptr, nullptr, nullptr, nullptr, d_u, 0};
+      rc = launch_edges_k(ctx, (const uint32_t*)d_table, N, k, 0, N, o);
+    }
+    if (!rc) e = hipMemcpyAsync(u, d_u, sizeof(uint16_t) * (size_t)E, hipMemcpyDeviceToHost, ctx->stream);
+    if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
+    else (void)hipStreamSynchronize(ctx->stream);
+  }
+  if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_jaccard_counts_host: %s", hipGetErrorString(e));
+  return rc;
+}
+
+/* Host-side expansion of the counts into the reference's (N*k) x 3 matrix (src/rcpp_parallel_jaccard_coeff.cpp:48-52):
+ * row i*k+j = (i+1, idx[i,j], u/(2.0*k-u)) when u > 0, zeros otherwise.  Pure host code (no device, no context);
+ * n_threads <= 0: one per hardware thread, at most 16.  Inputs are not validated again (the counts come from a call
+ * that validated the ids). */
+int gficf_jaccard_expand_host(const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, const uint16_t* u, double* rmat,
+                              int n_threads) {
+  if (N < 0 || k < 0 || k > GFICF_JACCARD_MAX_K) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N or k out of range");
+  const int64_t E = N * (int64_t)k;
+  if (E == 0) return GFICF_OK;
+  if (!idx || !u || !rmat) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
+  if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
+  double lut[GFICF_JACCARD_MAX_K + 1];
+  for (int v = 0; v <= k; ++v) lut[v] = (double)v / (2.0 * (double)k - (double)v);     // reference :51
+  unsigned hw = std::thread::hardware_concurrency();
+  int64_t nt = n_threads > 0 ? n_threads : (hw ? (hw > 16 ? 16 : hw) : 4);
+  if (nt > N) nt = N;
+  if (E < (1 << 16)) nt = 1;
+  const int32_t* const ii = (const int32_t*)idx;
+  const double* const id = (const double*)idx;
+  auto work = [&](int64_t c0, int64_t c1) {
+    for (int64_t i = c0; i < c1; ++i) {
+      for (int j = 0; j < k; ++j) {
+        const int64_t r = i * k + j;
+        const int v = u[r];
+        const double dst = idx_is_f64 ? id[(int64_t)j * ld + i] : (double)ii[(int64_t)j * ld + i];
+        rmat[r] = v > 0 ? (double)(i + 1) : 0.0;
+        rmat[E + r] = v > 0 ? dst : 0.0;
+        rmat[2 * E + r] = v > 0 ? lut[v <= k ? v : k] : 0.0;
+      }
+    }
+  };
+  if (nt <= 1) { work(0, N); return GFICF_OK; }
+  std::vector<std::thread> th;
+  const int64_t per = (N + nt - 1) / nt;
+  for (int64_t t = 0; t < nt; ++t) {
+    const int64_t c0 = t * per, c1 = c0 + per < N ? c0 + per : N;
+    if (c0 < c1) th.emplace_back(work, c0, c1);
+  }
+  for (auto& t : th) t.join();
   return GFICF_OK;
 }
 
@@ -766,8 +1126,9 @@ int gficf_jaccard_pack_rows_device(gficf_ctx* ctx, const int32_t* d_table_rows, 
   if (!d_table_rows || !d_packed) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   int64_t blocks = gficf_ceil_div(n_rows, PACK_ROWS);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
-  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(256), (size_t)PACK_ROWS * kpad_for(k) * sizeof(uint32_t), ctx->stream,
-                     (const uint32_t*)d_table_rows, n_rows, k, kpad_for(k), id_bits(N_total), packed_words(N_total, k), d_packed);
+  const TableFmt f = table_fmt(N_total, k);
+  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(256), (size_t)PACK_ROWS * f.row_words * sizeof(uint32_t), ctx->stream,
+                     (const uint32_t*)d_table_rows, n_rows, k, f.kpad, f.compact ? 1 : 0, id_bits(N_total), packed_words(N_total, k), d_packed);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -783,8 +1144,9 @@ int gficf_jaccard_unpack_rows_device(gficf_ctx* ctx, const uint32_t* d_packed, i
   const int wpr = packed_words(N_total, k);
   int64_t blocks = gficf_ceil_div(n_rows, UNPACK_ROWS);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+  const TableFmt f = table_fmt(N_total, k);
   hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)blocks), dim3(256), (size_t)UNPACK_ROWS * wpr * sizeof(uint32_t), ctx->stream,
-                     d_packed, n_rows, k, kpad_for(k), id_bits(N_total), wpr, (uint32_t*)d_table_rows);
+                     d_packed, n_rows, k, f.kpad, f.compact ? 1 : 0, id_bits(N_total), wpr, (uint32_t*)d_table_rows);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -806,13 +1168,7 @@ static int edges_filtered(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int
   // 1. intersection counts only (no 24 B/edge matrix)
   EdgeOut o{nullptr, nullptr, nullptr, nullptr, d_u_ws, set_mode};
   const uint32_t* t = (const uint32_t*)d_table;
-  switch (kpad_for(k)) {
-    case 16: rc = launch_edges<16>(ctx, t, N, k, cell_begin, cell_end, o); break;
-    case 32: rc = launch_edges<32>(ctx, t, N, k, cell_begin, cell_end, o); break;
-    case 64: rc = launch_edges<64>(ctx, t, N, k, cell_begin, cell_end, o); break;
-    case 128: rc = launch_edges<128>(ctx, t, N, k, cell_begin, cell_end, o); break;
-    default: rc = launch_edges<256>(ctx, t, N, k, cell_begin, cell_end, o); break;
-  }
+  rc = launch_edges_k(ctx, t, N, k, cell_begin, cell_end, o);
   if (rc) return rc;
   // 2. kept edges per cell -> offsets
   hipLaunchKernelGGL(k_edge_kept_count, dim3((unsigned)gficf_ceil_div(n_cells, 256)), dim3(256), 0, ctx->stream, d_u_ws,
@@ -823,15 +1179,16 @@ static int edges_filtered(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int
   // 3. ordered compacted write
   int64_t blocks = gficf_ceil_div(n_cells, 4);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
-#define LAUNCH_EW(KP)                                                                                               \
-  hipLaunchKernelGGL((k_edge_write<KP>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, t, d_u_ws, k, cell_begin, \
+#define LAUNCH_EW(KP, CM)                                                                                               \
+  hipLaunchKernelGGL((k_edge_write<KP, CM>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, t, d_u_ws, k, cell_begin, \
                      n_cells, d_cell_ptr, d_from, d_to, d_weight)
+  const bool cm = table_fmt(N, k).compact;
   switch (kpad_for(k)) {
-    case 16: LAUNCH_EW(16); break;
-    case 32: LAUNCH_EW(32); break;
-    case 64: LAUNCH_EW(64); break;
-    case 128: LAUNCH_EW(128); break;
-    default: LAUNCH_EW(256); break;
+    case 16: LAUNCH_EW(16, false); break;
+    case 32: if (cm) LAUNCH_EW(32, true); else LAUNCH_EW(32, false); break;
+    case 64: if (cm) LAUNCH_EW(64, true); else LAUNCH_EW(64, false); break;
+    case 128: if (cm) LAUNCH_EW(128, true); else LAUNCH_EW(128, false); break;
+    default: if (cm) LAUNCH_EW(256, true); else LAUNCH_EW(256, false); break;
   }
 #undef LAUNCH_EW
   GFICF_HIP_CHECK(hipGetLastError());
@@ -844,7 +1201,8 @@ int gficf_jaccard_edges_filtered_device(gficf_ctx* ctx, const int32_t* d_table, 
   return edges_filtered(ctx, d_table, N, k, cell_begin, cell_end, d_u_ws, d_cell_ptr, d_from, d_to, d_weight, 0);
 }
 
-// host form of the filtered build: plan runs everything and returns the edge count, finish copies out
+// host form of the filtered build: plan runs everything and returns the edge count, finish copies out.
+// Device buffers are pieces of the context's pool slot 5 (kept between calls; nothing is allocated per call).
 struct gficf_edge_plan {
   int64_t n_edges = 0;
   double* d_from = nullptr;
@@ -853,12 +1211,7 @@ struct gficf_edge_plan {
 };
 
 static void edge_plan_free(gficf_ctx* ctx) {
-  gficf_edge_plan* p = ctx->edge_plan;
-  if (!p) return;
-  if (p->d_from) (void)hipFree(p->d_from);
-  if (p->d_to) (void)hipFree(p->d_to);
-  if (p->d_weight) (void)hipFree(p->d_weight);
-  delete p;
+  delete ctx->edge_plan;
   ctx->edge_plan = nullptr;
 }
 
@@ -879,18 +1232,17 @@ int gficf_jaccard_filtered_host_plan(gficf_ctx* ctx, const void* idx, int idx_is
   if (!idx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
   if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
   const size_t esz = idx_is_f64 ? sizeof(double) : sizeof(int32_t);
-  const int kpad = kpad_for(k);
-  void* d_idx = nullptr;
-  int32_t* d_table = nullptr;
-  uint16_t* d_u = nullptr;
-  int64_t* d_ptr = nullptr;
-  hipError_t e = hipMalloc(&d_idx, esz * (size_t)ld * (size_t)k);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_table, sizeof(int32_t) * (size_t)N * (size_t)kpad);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_u, sizeof(uint16_t) * (size_t)E);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_ptr, sizeof(int64_t) * (size_t)(N + 1));
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_from, sizeof(double) * (size_t)E);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_to, sizeof(double) * (size_t)E);
-  if (e == hipSuccess) e = hipMalloc((void**)&p->d_weight, sizeof(double) * (size_t)E);
+  const int roww = table_fmt(N, k).row_words;
+  gficf_arena ar;
+  const size_t o_idx = ar.take(esz * (size_t)ld * (size_t)k), o_tab = ar.take(sizeof(int32_t) * (size_t)N * (size_t)roww);
+  const size_t o_u = ar.take(sizeof(uint16_t) * (size_t)E), o_ptr = ar.take(sizeof(int64_t) * (size_t)(N + 1));
+  const size_t o_f = ar.take(sizeof(double) * (size_t)E), o_t = ar.take(sizeof(double) * (size_t)E), o_w = ar.take(sizeof(double) * (size_t)E);
+  hipError_t e = ar.bind(ctx, 5);
+  void* d_idx = ar.at<void>(o_idx);
+  int32_t* d_table = ar.at<int32_t>(o_tab);
+  uint16_t* d_u = ar.at<uint16_t>(o_u);
+  int64_t* d_ptr = ar.at<int64_t>(o_ptr);
+  p->d_from = ar.at<double>(o_f); p->d_to = ar.at<double>(o_t); p->d_weight = ar.at<double>(o_w);
   if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, esz * (size_t)ld * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
   rc = GFICF_OK;
   int64_t total = 0;
@@ -901,10 +1253,6 @@ int gficf_jaccard_filtered_host_plan(gficf_ctx* ctx, const void* idx, int idx_is
     if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
     else (void)hipStreamSynchronize(ctx->stream);
   }
-  if (d_idx) (void)hipFree(d_idx);
-  if (d_table) (void)hipFree(d_table);
-  if (d_u) (void)hipFree(d_u);
-  if (d_ptr) (void)hipFree(d_ptr);
   if (e != hipSuccess) { gficf_set_error("HIP failure in gficf_jaccard_filtered_host_plan: %s", hipGetErrorString(e)); rc = GFICF_ERR_HIP; }
   if (rc) { edge_plan_free(ctx); return rc; }
   p->n_edges = total;
@@ -921,16 +1269,16 @@ int gficf_jaccard_coeff_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, in
   GFICF_CTX_ENTER(ctx);
   int rc = check_nk(N, k);
   if (rc) return rc;
-  if (print_output) { printf("Running Jaccard Coefficient Estimation...\n"); fflush(stdout); }  // reference :25
+  if (print_output) gficf_print(ctx, "Running Jaccard Coefficient Estimation...\n");  // reference :25
   const int64_t E = N * (int64_t)k;
   if (E == 0) return GFICF_OK;
   if (!idx || !weights) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
   if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
   const size_t esz = idx_is_f64 ? sizeof(double) : sizeof(int32_t);
-  const int kpad = kpad_for(k);
+  const int roww = table_fmt(N, k).row_words;
   void *d_idx = nullptr, *d_table = nullptr, *d_out = nullptr, *d_aux = nullptr;
   hipError_t e = gficf_pool_get(ctx, 0, esz * (size_t)ld * (size_t)k, &d_idx);
-  if (e == hipSuccess) e = gficf_pool_get(ctx, 1, sizeof(int32_t) * (size_t)N * (size_t)kpad, &d_table);
+  if (e == hipSuccess) e = gficf_pool_get(ctx, 1, sizeof(int32_t) * (size_t)N * (size_t)roww, &d_table);
   if (e == hipSuccess) e = gficf_pool_get(ctx, 2, sizeof(double) * 3 * (size_t)E, &d_out);
   if (e == hipSuccess) e = gficf_pool_get(ctx, 3, sizeof(uint16_t) * (size_t)E + 64 + sizeof(int64_t) * (size_t)(N + 1), &d_aux);
   if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, esz * (size_t)ld * (size_t)k, hipMemcpyHostToDevice, ctx->stream);

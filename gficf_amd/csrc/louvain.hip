@@ -43,6 +43,8 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -846,22 +848,21 @@ int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr
   if (modularity) *modularity = 0.0;
   if (N == 0) return GFICF_OK;
   if (!indptr || !labels || !n_clusters) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
-  int64_t* h_ptr = nullptr;
-  GFICF_HIP_CHECK(hipHostMalloc((void**)&h_ptr, sizeof(int64_t) * ((size_t)N + 1), hipHostMallocDefault));
-  for (int64_t c = 0; c <= N; ++c) h_ptr[c] = indptr_is_i64 ? ((const int64_t*)indptr)[c] : (int64_t)((const int32_t*)indptr)[c];
+  std::vector<int64_t> h_ptr((size_t)N + 1);
+  for (int64_t c = 0; c <= N; ++c) h_ptr[(size_t)c] = indptr_is_i64 ? ((const int64_t*)indptr)[c] : (int64_t)((const int32_t*)indptr)[c];
   bool mono = h_ptr[0] == 0;
-  for (int64_t c = 0; c < N && mono; ++c) mono = h_ptr[c + 1] >= h_ptr[c];
-  const int64_t nnz = h_ptr[N];
-  if (!mono) { (void)hipHostFree(h_ptr); GFICF_FAIL(GFICF_ERR_BAD_CSC, "indptr does not start at 0 or is not monotone"); }
-  if (nnz > 0 && (!indices || !x)) { (void)hipHostFree(h_ptr); GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer"); }
+  for (int64_t c = 0; c < N && mono; ++c) mono = h_ptr[(size_t)c + 1] >= h_ptr[(size_t)c];
+  const int64_t nnz = h_ptr[(size_t)N];
+  if (!mono) GFICF_FAIL(GFICF_ERR_BAD_CSC, "indptr does not start at 0 or is not monotone");
+  if (nnz > 0 && (!indices || !x)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
   const size_t nsz = (size_t)(nnz > 0 ? nnz : 1), wsb = gficf_louvain_workspace_bytes(N, nnz);
-  int64_t* d_ptr = nullptr; int32_t *d_idx = nullptr, *d_lab = nullptr; double* d_x = nullptr; void* d_ws = nullptr;
-  hipError_t e = hipMalloc((void**)&d_ptr, sizeof(int64_t) * ((size_t)N + 1));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_idx, sizeof(int32_t) * nsz);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_x, sizeof(double) * nsz);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_lab, sizeof(int32_t) * (size_t)N);
-  if (e == hipSuccess) e = hipMalloc(&d_ws, wsb);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_ptr, h_ptr, sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice, ctx->stream);
+  gficf_arena ar;                                   // pool slot 0: no allocation per call
+  const size_t o_ptr = ar.take(sizeof(int64_t) * ((size_t)N + 1)), o_idx = ar.take(sizeof(int32_t) * nsz), o_x = ar.take(sizeof(double) * nsz);
+  const size_t o_lab = ar.take(sizeof(int32_t) * (size_t)N), o_ws = ar.take(wsb);
+  hipError_t e = ar.bind(ctx, 0);
+  int64_t* const d_ptr = ar.at<int64_t>(o_ptr); int32_t* const d_idx = ar.at<int32_t>(o_idx); double* const d_x = ar.at<double>(o_x);
+  int32_t* const d_lab = ar.at<int32_t>(o_lab); void* const d_ws = ar.at<void>(o_ws);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ptr, h_ptr.data(), sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
   int rc = GFICF_OK;
@@ -871,9 +872,6 @@ int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr
     if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
     else (void)hipStreamSynchronize(ctx->stream);
   }
-  void* ptrs[] = {d_ptr, d_idx, d_x, d_lab, d_ws};
-  for (void* q : ptrs) if (q) (void)hipFree(q);
-  (void)hipHostFree(h_ptr);
   if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_louvain_host: %s", hipGetErrorString(e));
   return rc;
 }

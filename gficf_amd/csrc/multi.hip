@@ -1,0 +1,416 @@
+// multi.hip — the host entry points over several GPUs of one node, single process (C ABI: gficf_multi_*).
+//
+// What an R session can bind: the reference's call sites are one `.Call` each (R/clustCells.R:65 for the Jaccard
+// build, gficf() R/gficf.R:17-33 for the normalisation), so a drop-in that shards over the GPUs of a node has to do
+// it underneath that one call — one host thread, one context and one stream per device, everything asynchronous
+// until the final wait.  The partitioning is the one of the multi-process path (gficf_amd/dist.py):
+//   * Jaccard: cells in contiguous equal-pitch blocks; every device uploads and ingests ITS block of the kNN
+//     matrix, the table rows are exchanged device to device (hipMemcpyPeerAsync over xGMI, pulled by the receiving
+//     device on its own stream behind an event of the sending one; with no peer access every device ingests the
+//     whole matrix instead), every device builds the edges of its block and copies them straight into its three
+//     column slices of the caller's (N*k) x 3 matrix.
+//   * GF-ICF: cells in contiguous blocks balanced by stored entries; the per-gene cell counts nt_g are the only
+//     global quantity: each device counts its block, the G counters are summed on the host (G x 8 B per device —
+//     for a host entry the all-reduce is two small copies) and handed back; filter, weights and the scaling pass
+//     then run per block and the kept entries land at their offsets in the caller's arrays.
+// Kernels and arithmetic are those of the single-device entries: same bits.
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+struct gficf_multi_block {
+  int64_t b = 0, e = 0;            // cells [b, e)
+  int64_t p0 = 0, p1 = 0;          // stored entries [p0, p1) (GF-ICF)
+  int64_t nnz_kept = 0, out_off = 0;
+  // plan state (device pointers into pool slot 4 of the block's context)
+  int64_t* d_colptr = nullptr;
+  int32_t* d_rowidx = nullptr;
+  double* d_x = nullptr;
+  double* d_w_in = nullptr;
+  int64_t* d_nt = nullptr;
+  uint8_t* d_keep = nullptr;
+  gficf_gene_entry* d_genes = nullptr;
+  double* d_w = nullptr;
+  int64_t* d_gkept = nullptr;
+  int64_t* d_out_colptr = nullptr;
+};
+
+struct gficf_multi {
+  int ndev = 0;
+  std::vector<int> dev;
+  std::vector<gficf_ctx*> ctx;
+  std::vector<hipStream_t> stream;
+  std::vector<hipEvent_t> ev;
+  bool peer = true;                // every pair of distinct devices can access each other
+  // GF-ICF plan
+  bool has_plan = false;
+  int64_t G = 0, N = 0, g_kept = 0, nnz_kept = 0;
+  int colptr_is_i64 = 0;
+  std::vector<gficf_multi_block> blk;
+};
+
+namespace {
+
+// first error of a sweep over the devices wins; the others are still synchronised
+struct FirstError {
+  int rc = GFICF_OK;
+  char msg[768] = "";
+  void note(int r) {
+    if (r != GFICF_OK && rc == GFICF_OK) {
+      rc = r;
+      snprintf(msg, sizeof(msg), "%s", gficf_last_error());
+    }
+  }
+  int done() {
+    if (rc != GFICF_OK) gficf_set_error("%s", msg);
+    return rc;
+  }
+};
+
+int hip_fail(const char* what, hipError_t e) {
+  gficf_set_error("%s failed: %s", what, hipGetErrorString(e));
+  return GFICF_ERR_HIP;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Cell blocks of the Jaccard build: block r = [r*pitch, min(N, (r+1)*pitch)), pitch = ceil(N / ndev)
+ * (gficf_amd/dist.py: shard_bounds).  bounds: ndev + 1 entries. */
+int gficf_multi_cell_blocks(int64_t N, int ndev, int64_t* bounds) {
+  if (N < 0 || ndev < 1 || !bounds) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N < 0, ndev < 1 or bounds is NULL");
+  const int64_t pitch = (N + ndev - 1) / ndev;
+  for (int r = 0; r <= ndev; ++r) {
+    const int64_t b = (int64_t)r * pitch;
+    bounds[r] = b < N ? b : N;
+  }
+  return GFICF_OK;
+}
+
+/* Cell blocks of the GF-ICF passes, balanced by stored entries: block r ends at the first cell boundary at or after
+ * r + 1 equal shares of the entries (gficf_amd/dist.py: shard_bounds_by_nnz).  bounds: ndev + 1 entries. */
+int gficf_multi_cell_blocks_by_nnz(int64_t N, const void* colptr, int colptr_is_i64, int ndev, int64_t* bounds) {
+  if (N < 0 || ndev < 1 || !bounds || !colptr) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N < 0, ndev < 1 or a NULL pointer");
+  auto cp = [&](int64_t c) -> int64_t { return colptr_is_i64 ? ((const int64_t*)colptr)[c] : (int64_t)((const int32_t*)colptr)[c]; };
+  const int64_t base = cp(0), nnz = N > 0 ? cp(N) - base : 0;
+  bounds[0] = 0;
+  for (int r = 1; r < ndev; ++r) {
+    const int64_t target = base + (nnz * r + ndev - 1) / ndev;
+    int64_t lo = 0, hi = N + 1;                     // first c with cp(c) >= target
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) / 2;
+      if (mid <= N && cp(mid) < target) lo = mid + 1;
+      else hi = mid;
+    }
+    int64_t c = lo < bounds[r - 1] ? bounds[r - 1] : lo;
+    bounds[r] = c < N ? c : N;
+  }
+  bounds[ndev] = N;
+  return GFICF_OK;
+}
+
+int gficf_multi_create(const int* devices, int ndev, gficf_multi** out) {
+  if (!out) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (ndev < 1 || ndev > 64) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ndev = %d outside [1, 64]", ndev);
+  gficf_multi* m = new gficf_multi();
+  m->ndev = ndev;
+  for (int r = 0; r < ndev; ++r) {
+    const int d = devices ? devices[r] : r;
+    hipStream_t st = nullptr;
+    gficf_ctx* c = nullptr;
+    hipEvent_t ev = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { gficf_multi_destroy(m); GFICF_FAIL(GFICF_ERR_NO_DEVICE, "no HIP device visible (libgficf_hip needs an AMD GPU; there is no CPU fallback)"); }
+    if (d < 0 || d >= n) { gficf_multi_destroy(m); GFICF_FAIL(GFICF_ERR_NO_DEVICE, "device %d out of range (%d visible)", d, n); }
+    hipError_t e = hipSetDevice(d);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) { gficf_multi_destroy(m); return hip_fail("stream / event creation", e); }
+    m->dev.push_back(d);
+    m->stream.push_back(st);
+    m->ev.push_back(ev);
+    m->ctx.push_back(nullptr);
+    const int rc = gficf_ctx_create(d, st, &c);
+    if (rc) { gficf_multi_destroy(m); return rc; }
+    m->ctx[r] = c;
+  }
+  // peer access between every pair of distinct devices (the same device may be named twice: one block each)
+  for (int a = 0; a < ndev && m->peer; ++a) {
+    for (int b = 0; b < ndev; ++b) {
+      if (m->dev[a] == m->dev[b]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, m->dev[a], m->dev[b]) != hipSuccess || !can) { m->peer = false; break; }
+      (void)hipSetDevice(m->dev[a]);
+      const hipError_t e = hipDeviceEnablePeerAccess(m->dev[b], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { m->peer = false; break; }
+      (void)hipGetLastError();
+    }
+  }
+  if (getenv("GFICF_HIP_NO_PEER")) m->peer = false;        // test hook: the every-device-ingests-everything form
+  *out = m;
+  return GFICF_OK;
+}
+
+void gficf_multi_destroy(gficf_multi* m) {
+  if (!m) return;
+  for (size_t r = 0; r < m->ctx.size(); ++r) {
+    if (m->ctx[r]) gficf_ctx_destroy(m->ctx[r]);
+  }
+  for (size_t r = 0; r < m->stream.size(); ++r) {
+    (void)hipSetDevice(m->dev[r]);
+    if (m->ev[r]) (void)hipEventDestroy(m->ev[r]);
+    if (m->stream[r]) (void)hipStreamDestroy(m->stream[r]);
+  }
+  delete m;
+}
+
+int gficf_multi_device_count(const gficf_multi* m) { return m ? m->ndev : 0; }
+
+int gficf_multi_set_print(gficf_multi* m, void (*fn)(const char*)) {
+  if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  for (gficf_ctx* c : m->ctx) c->print_fn = fn;
+  return GFICF_OK;
+}
+
+/* The Jaccard entry of clustcells() (R/clustCells.R:65 -> src/rcpp_parallel_jaccard_coeff.cpp:59-80) over the
+ * devices of the context.  Same arguments and the same (N*k) x 3 result as gficf_jaccard_host. */
+int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, double* rmat,
+                             int print_output) {
+  if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  if (N < 0 || k < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N = %lld or k = %d is negative", (long long)N, k);
+  const int roww = gficf_jaccard_row_words(N, k);
+  if (roww < 0) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d exceeds GFICF_JACCARD_MAX_K = %d or N = %lld exceeds int32 ids", k, GFICF_JACCARD_MAX_K, (long long)N);
+  if (print_output) gficf_print(m->ctx[0], "Running Parallell Jaccard Coefficient Estimation...\n");  // reference :63
+  const int64_t E = N * (int64_t)k;
+  if (E > 0) {
+    if (!idx || !rmat) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
+    if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
+    const int P = m->ndev;
+    std::vector<int64_t> bd((size_t)P + 1);
+    gficf_multi_cell_blocks(N, P, bd.data());
+    const size_t esz = idx_is_f64 ? sizeof(double) : sizeof(int32_t);
+    std::vector<void*> d_idx(P, nullptr);
+    std::vector<int32_t*> d_table(P, nullptr);
+    std::vector<double*> d_out(P, nullptr);
+    FirstError fe;
+    // 1. upload + ingest: each device its own block (peer exchange) or the whole matrix (no peer access)
+    for (int r = 0; r < P && fe.rc == GFICF_OK; ++r) {
+      gficf_ctx* c = m->ctx[r];
+      const int64_t n = bd[r + 1] - bd[r];
+      hipError_t e = hipSetDevice(m->dev[r]);
+      const int64_t rows_up = m->peer ? n : N, row0 = m->peer ? bd[r] : 0;
+      if (e == hipSuccess) e = gficf_pool_get(c, 0, esz * (size_t)(rows_up > 0 ? rows_up : 1) * (size_t)k, &d_idx[r]);
+      if (e == hipSuccess) e = gficf_pool_get(c, 1, sizeof(int32_t) * (size_t)N * (size_t)roww, (void**)&d_table[r]);
+      if (e == hipSuccess) e = gficf_pool_get(c, 2, sizeof(double) * 3 * (size_t)(n > 0 ? n : 1) * (size_t)k, (void**)&d_out[r]);
+      if (e == hipSuccess && rows_up > 0)     // k columns of rows_up ids out of the column-major matrix (leading dimension ld)
+        e = hipMemcpy2DAsync(d_idx[r], esz * (size_t)rows_up, (const char*)idx + esz * (size_t)row0, esz * (size_t)ld, esz * (size_t)rows_up,
+                             (size_t)k, hipMemcpyHostToDevice, m->stream[r]);
+      if (e != hipSuccess) { fe.note(hip_fail("upload of the kNN block", e)); break; }
+      if (rows_up > 0) fe.note(gficf_jaccard_ingest_device(c, d_idx[r], idx_is_f64, rows_up, k, rows_up, N, d_table[r] + (size_t)row0 * roww));
+      if (fe.rc == GFICF_OK && m->peer) {
+        e = hipEventRecord(m->ev[r], m->stream[r]);
+        if (e != hipSuccess) fe.note(hip_fail("hipEventRecord", e));
+      }
+    }
+    // 2. exchange: every device pulls the other blocks' table rows behind their ingest
+    if (fe.rc == GFICF_OK && m->peer && P > 1) {
+      for (int d = 0; d < P && fe.rc == GFICF_OK; ++d) {
+        hipError_t e = hipSetDevice(m->dev[d]);
+        for (int t = 1; t < P && e == hipSuccess; ++t) {
+          const int s = (d + t) % P;                           // start with the next device: the pulls of a step are spread over the links
+          const int64_t n = bd[s + 1] - bd[s];
+          if (n <= 0) continue;
+          e = hipStreamWaitEvent(m->stream[d], m->ev[s], 0);
+          const size_t off = (size_t)bd[s] * roww, bytes = sizeof(int32_t) * (size_t)n * roww;
+          if (e == hipSuccess) e = hipMemcpyPeerAsync(d_table[d] + off, m->dev[d], d_table[s] + off, m->dev[s], bytes, m->stream[d]);
+        }
+        if (e != hipSuccess) fe.note(hip_fail("exchange of table rows", e));
+      }
+    }
+    // 3. edges of the own block, straight into the three column slices of rmat
+    for (int r = 0; r < P && fe.rc == GFICF_OK; ++r) {
+      const int64_t n = bd[r + 1] - bd[r];
+      if (n <= 0) continue;
+      hipError_t e = hipSetDevice(m->dev[r]);
+      const size_t ne = (size_t)n * (size_t)k;
+      if (e == hipSuccess)
+        fe.note(gficf_jaccard_edges_device(m->ctx[r], d_table[r], N, k, bd[r], bd[r + 1], d_out[r], d_out[r] + ne, d_out[r] + 2 * ne, nullptr));
+      for (int col = 0; col < 3 && e == hipSuccess && fe.rc == GFICF_OK; ++col)
+        e = hipMemcpyAsync(rmat + (size_t)col * (size_t)E + (size_t)bd[r] * (size_t)k, d_out[r] + (size_t)col * ne, sizeof(double) * ne,
+                           hipMemcpyDeviceToHost, m->stream[r]);
+      if (e != hipSuccess) fe.note(hip_fail("download of the edge block", e));
+    }
+    // 4. wait for every device (also on failure: nothing may still read the caller's buffers) and collect deferred errors
+    for (int r = 0; r < P; ++r) fe.note(gficf_ctx_sync(m->ctx[r]));
+    const int rc = fe.done();
+    if (rc) return rc;
+  }
+  if (print_output) gficf_print(m->ctx[0], "Done!!\n");  // reference :77
+  return GFICF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ GF-ICF
+static void multi_plan_clear(gficf_multi* m) {
+  m->has_plan = false;
+  m->blk.clear();
+}
+
+/* gficf() over the devices of the context: same arguments and results as gficf_normalize_csc_host_plan / _finish. */
+int gficf_normalize_csc_host_multi_plan(gficf_multi* m, int64_t G, int64_t N, const void* colptr, int colptr_is_i64,
+                                        const int32_t* rowidx, const double* x, double prop_min, double prop_max,
+                                        const double* w_in, int64_t* G_kept, int64_t* nnz_kept) {
+  if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  if (G < 0 || N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative dimension");
+  if (G > 0x7FFFFFFFll) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "G = %lld exceeds int32 row indices", (long long)G);
+  if (!colptr || !G_kept || !nnz_kept) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
+  multi_plan_clear(m);
+  std::vector<int64_t> cp((size_t)N + 1);
+  for (int64_t c = 0; c <= N; ++c)
+    cp[(size_t)c] = colptr_is_i64 ? ((const int64_t*)colptr)[c] : (int64_t)((const int32_t*)colptr)[c];
+  if (cp[0] != 0) GFICF_FAIL(GFICF_ERR_BAD_CSC, "colptr[0] = %lld, expected 0", (long long)cp[0]);
+  for (int64_t c = 0; c < N; ++c)
+    if (cp[(size_t)c + 1] < cp[(size_t)c]) GFICF_FAIL(GFICF_ERR_BAD_CSC, "colptr not monotone at cell %lld", (long long)c);
+  const int64_t nnz = cp[(size_t)N];
+  if (nnz > 0 && (!rowidx || !x)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
+  const int P = m->ndev;
+  std::vector<int64_t> bd((size_t)P + 1);
+  gficf_multi_cell_blocks_by_nnz(N, cp.data(), 1, P, bd.data());
+  m->G = G; m->N = N; m->colptr_is_i64 = colptr_is_i64;
+  m->blk.assign((size_t)P, gficf_multi_block());
+  const size_t gsz = (size_t)(G > 0 ? G : 1);
+  std::vector<std::vector<int64_t>> cpl((size_t)P), ntl((size_t)P);
+  FirstError fe;
+  // 1. per block: upload, count
+  for (int r = 0; r < P && fe.rc == GFICF_OK; ++r) {
+    gficf_multi_block& B = m->blk[r];
+    gficf_ctx* c = m->ctx[r];
+    B.b = bd[r]; B.e = bd[r + 1]; B.p0 = cp[(size_t)B.b]; B.p1 = cp[(size_t)B.e];
+    const int64_t n = B.e - B.b, nz = B.p1 - B.p0;
+    cpl[r].resize((size_t)n + 1);
+    for (int64_t t = 0; t <= n; ++t) cpl[r][(size_t)t] = cp[(size_t)(B.b + t)] - B.p0;      // the block's colptr starts at 0
+    ntl[r].assign(gsz, 0);
+    hipError_t e = hipSetDevice(m->dev[r]);
+    gficf_arena ar;
+    const size_t nsz = (size_t)(nz > 0 ? nz : 1);
+    const size_t o_cp = ar.take(sizeof(int64_t) * ((size_t)n + 1)), o_ri = ar.take(sizeof(int32_t) * nsz), o_x = ar.take(sizeof(double) * nsz);
+    const size_t o_nt = ar.take(sizeof(int64_t) * gsz), o_keep = ar.take(gsz), o_genes = ar.take(gficf_csc_genes_bytes(G));
+    const size_t o_w = ar.take(sizeof(double) * gsz), o_gk = ar.take(sizeof(int64_t)), o_ocp = ar.take(sizeof(int64_t) * ((size_t)n + 1));
+    const size_t o_win = ar.take(sizeof(double) * gsz);
+    if (e == hipSuccess) e = ar.bind(c, 4);
+    if (e != hipSuccess) { fe.note(hip_fail("device buffers of the GF-ICF block", e)); break; }
+    B.d_colptr = ar.at<int64_t>(o_cp); B.d_rowidx = ar.at<int32_t>(o_ri); B.d_x = ar.at<double>(o_x);
+    B.d_nt = ar.at<int64_t>(o_nt); B.d_keep = ar.at<uint8_t>(o_keep); B.d_genes = ar.at<gficf_gene_entry>(o_genes);
+    B.d_w = ar.at<double>(o_w); B.d_gkept = ar.at<int64_t>(o_gk); B.d_out_colptr = ar.at<int64_t>(o_ocp);
+    B.d_w_in = (w_in && G > 0) ? ar.at<double>(o_win) : nullptr;
+    hipStream_t st = m->stream[r];
+    e = hipMemcpyAsync(B.d_colptr, cpl[r].data(), sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && nz > 0) e = hipMemcpyAsync(B.d_rowidx, rowidx + B.p0, sizeof(int32_t) * (size_t)nz, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && nz > 0) e = hipMemcpyAsync(B.d_x, x + B.p0, sizeof(double) * (size_t)nz, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && B.d_w_in) e = hipMemcpyAsync(B.d_w_in, w_in, sizeof(double) * (size_t)G, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(B.d_nt, 0, sizeof(int64_t) * gsz, st);
+    if (e != hipSuccess) { fe.note(hip_fail("upload of the GF-ICF block", e)); break; }
+    fe.note(gficf_csc_count_device(c, G, n, B.d_colptr, B.d_rowidx, B.d_x, nz, B.d_nt));
+    if (fe.rc == GFICF_OK && G > 0) {
+      e = hipMemcpyAsync(ntl[r].data(), B.d_nt, sizeof(int64_t) * (size_t)G, hipMemcpyDeviceToHost, st);
+      if (e != hipSuccess) fe.note(hip_fail("download of the gene counts", e));
+    }
+  }
+  for (int r = 0; r < P; ++r) fe.note(gficf_ctx_sync(m->ctx[r]));
+  if (fe.rc) { multi_plan_clear(m); return fe.done(); }
+  // 2. the one global quantity: nt_g summed over the blocks (the all-reduce of the sharded path)
+  std::vector<int64_t> nt(gsz, 0);
+  for (int r = 0; r < P; ++r)
+    for (int64_t g = 0; g < G; ++g) nt[(size_t)g] += ntl[r][(size_t)g];
+  // 3. per block: filter + weights from the global counts, kept entries per cell
+  std::vector<int64_t> hk((size_t)P * 2, 0);
+  for (int r = 0; r < P && fe.rc == GFICF_OK; ++r) {
+    gficf_multi_block& B = m->blk[r];
+    gficf_ctx* c = m->ctx[r];
+    const int64_t n = B.e - B.b;
+    hipStream_t st = m->stream[r];
+    hipError_t e = hipSetDevice(m->dev[r]);
+    if (e == hipSuccess && G > 0) e = hipMemcpyAsync(B.d_nt, nt.data(), sizeof(int64_t) * (size_t)G, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { fe.note(hip_fail("upload of the summed gene counts", e)); break; }
+    fe.note(gficf_csc_genes_device(c, G, N, B.d_nt, prop_min, prop_max, B.d_w_in, B.d_keep, B.d_genes, B.d_w, B.d_gkept));
+    if (fe.rc == GFICF_OK) fe.note(gficf_csc_colptr_device(c, G, n, B.d_colptr, B.d_rowidx, B.d_keep, B.d_gkept, B.d_out_colptr));
+    if (fe.rc == GFICF_OK) {
+      e = hipMemcpyAsync(&hk[(size_t)r * 2], B.d_gkept, sizeof(int64_t), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(&hk[(size_t)r * 2 + 1], B.d_out_colptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, st);
+      if (e != hipSuccess) fe.note(hip_fail("download of the kept counts", e));
+    }
+  }
+  for (int r = 0; r < P; ++r) fe.note(gficf_ctx_sync(m->ctx[r]));
+  if (fe.rc) { multi_plan_clear(m); return fe.done(); }
+  int64_t total = 0;
+  for (int r = 0; r < P; ++r) {
+    m->blk[r].nnz_kept = hk[(size_t)r * 2 + 1];
+    m->blk[r].out_off = total;
+    total += hk[(size_t)r * 2 + 1];
+  }
+  m->g_kept = hk[0];
+  m->nnz_kept = total;
+  m->has_plan = true;
+  *G_kept = m->g_kept;
+  *nnz_kept = total;
+  return GFICF_OK;
+}
+
+int gficf_normalize_csc_host_multi_finish(gficf_multi* m, uint8_t* keep, int64_t* nt, double* w, void* out_colptr,
+                                          int32_t* out_rowidx, double* out_x) {
+  if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  if (!m->has_plan) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "gficf_normalize_csc_host_multi_finish without a plan");
+  if (!out_colptr || (m->nnz_kept > 0 && (!out_rowidx || !out_x))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
+  const int P = m->ndev;
+  const int64_t G = m->G, N = m->N;
+  std::vector<std::vector<int64_t>> ocp((size_t)P);
+  FirstError fe;
+  for (int r = 0; r < P && fe.rc == GFICF_OK; ++r) {
+    gficf_multi_block& B = m->blk[r];
+    gficf_ctx* c = m->ctx[r];
+    const int64_t n = B.e - B.b, nz = B.p1 - B.p0;
+    hipStream_t st = m->stream[r];
+    hipError_t e = hipSetDevice(m->dev[r]);
+    const size_t ksz = (size_t)(B.nnz_kept > 0 ? B.nnz_kept : 1);
+    gficf_arena ar;
+    const size_t o_ri = ar.take(sizeof(int32_t) * ksz), o_x = ar.take(sizeof(double) * ksz);
+    if (e == hipSuccess) e = ar.bind(c, 7);
+    if (e != hipSuccess) { fe.note(hip_fail("output buffers of the GF-ICF block", e)); break; }
+    int32_t* const d_ori = ar.at<int32_t>(o_ri);
+    double* const d_ox = ar.at<double>(o_x);
+    fe.note(gficf_csc_scale_device(c, G, n, B.d_colptr, B.d_rowidx, B.d_x, nz, B.d_genes, B.d_gkept, B.d_out_colptr, d_ori, d_ox));
+    if (fe.rc != GFICF_OK) break;
+    ocp[r].resize((size_t)n + 1);
+    e = hipMemcpyAsync(ocp[r].data(), B.d_out_colptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && B.nnz_kept > 0) e = hipMemcpyAsync(out_rowidx + B.out_off, d_ori, sizeof(int32_t) * (size_t)B.nnz_kept, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && B.nnz_kept > 0) e = hipMemcpyAsync(out_x + B.out_off, d_ox, sizeof(double) * (size_t)B.nnz_kept, hipMemcpyDeviceToHost, st);
+    if (r == 0 && G > 0) {                   // the per-gene results are the same on every device
+      if (e == hipSuccess && keep) e = hipMemcpyAsync(keep, B.d_keep, (size_t)G, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess && nt) e = hipMemcpyAsync(nt, B.d_nt, sizeof(int64_t) * (size_t)G, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess && w) e = hipMemcpyAsync(w, B.d_w, sizeof(double) * (size_t)G, hipMemcpyDeviceToHost, st);
+    }
+    if (e != hipSuccess) fe.note(hip_fail("download of the GF-ICF block", e));
+  }
+  for (int r = 0; r < P; ++r) fe.note(gficf_ctx_sync(m->ctx[r]));
+  int rc = fe.done();
+  if (!rc) {
+    for (int r = 0; r < P; ++r) {
+      const gficf_multi_block& B = m->blk[r];
+      for (int64_t t = (r == 0 ? 0 : 1); t <= B.e - B.b; ++t) {
+        const int64_t v = ocp[r][(size_t)t] + B.out_off;
+        if (m->colptr_is_i64) ((int64_t*)out_colptr)[B.b + t] = v;
+        else ((int32_t*)out_colptr)[B.b + t] = (int32_t)v;
+      }
+    }
+    if (N == 0) {
+      if (m->colptr_is_i64) ((int64_t*)out_colptr)[0] = 0;
+      else ((int32_t*)out_colptr)[0] = 0;
+    }
+  }
+  multi_plan_clear(m);
+  return rc;
+}
+
+}  // extern "C"

@@ -15,6 +15,8 @@
 // HBM-bound integer/byte work: 4 B/entry for the count, 12 B read + 12 B written for the scatter (28 B/entry
 // algorithmic); the scattered 4 + 8 B stores are what bounds it (partial lines until a gene's run in the block fills).
 // Matrices with more than TR_GENES genes take ceil(G / TR_GENES) sweeps (gene ranges in grid.y).
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -265,29 +267,33 @@ int gficf_csc_transpose_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* c
   GFICF_CTX_ENTER(ctx);
   if (G < 0 || N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (!colptr || !out_ptr) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
-  int64_t* h_cp = nullptr;
-  GFICF_HIP_CHECK(hipHostMalloc((void**)&h_cp, sizeof(int64_t) * ((size_t)N + 1), hipHostMallocDefault));
-  for (int64_t c = 0; c <= N; ++c) h_cp[c] = colptr_is_i64 ? ((const int64_t*)colptr)[c] : (int64_t)((const int32_t*)colptr)[c];
+  std::vector<int64_t> h_cp((size_t)N + 1);
+  for (int64_t c = 0; c <= N; ++c) h_cp[(size_t)c] = colptr_is_i64 ? ((const int64_t*)colptr)[c] : (int64_t)((const int32_t*)colptr)[c];
   bool mono = h_cp[0] == 0;
-  for (int64_t c = 0; c < N && mono; ++c) mono = h_cp[c + 1] >= h_cp[c];
-  const int64_t nnz = h_cp[N];
-  if (!mono) { (void)hipHostFree(h_cp); GFICF_FAIL(GFICF_ERR_BAD_CSC, "colptr does not start at 0 or is not monotone"); }
-  if (nnz > 0 && (!rowidx || !x || !out_idx || !out_x)) { (void)hipHostFree(h_cp); GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer"); }
+  for (int64_t c = 0; c < N && mono; ++c) mono = h_cp[(size_t)c + 1] >= h_cp[(size_t)c];
+  const int64_t nnz = h_cp[(size_t)N];
+  if (!mono) GFICF_FAIL(GFICF_ERR_BAD_CSC, "colptr does not start at 0 or is not monotone");
+  if (nnz > 0 && (!rowidx || !x || !out_idx || !out_x)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
   const size_t nsz = (size_t)(nnz > 0 ? nnz : 1), wsb = gficf_csc_transpose_workspace_bytes(G, N);
-  int64_t *d_cp = nullptr, *d_op = nullptr; int32_t *d_ri = nullptr, *d_oi = nullptr; double *d_x = nullptr, *d_ox = nullptr; void* d_ws = nullptr;
-  hipError_t e = hipMalloc((void**)&d_cp, sizeof(int64_t) * ((size_t)N + 1));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_op, sizeof(int64_t) * ((size_t)G + 1));
-  if (e == hipSuccess) e = hipMalloc((void**)&d_ri, sizeof(int32_t) * nsz);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_oi, sizeof(int32_t) * nsz);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_x, sizeof(double) * nsz);
-  if (e == hipSuccess) e = hipMalloc((void**)&d_ox, sizeof(double) * nsz);
-  if (e == hipSuccess) e = hipMalloc(&d_ws, wsb);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_cp, h_cp, sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice, ctx->stream);
+  gficf_arena ar;                                   // pool slot 0: no allocation per call
+  const size_t o_cp = ar.take(sizeof(int64_t) * ((size_t)N + 1)), o_op = ar.take(sizeof(int64_t) * ((size_t)G + 1));
+  const size_t o_ri = ar.take(sizeof(int32_t) * nsz), o_oi = ar.take(sizeof(int32_t) * nsz);
+  const size_t o_x = ar.take(sizeof(double) * nsz), o_ox = ar.take(sizeof(double) * nsz), o_ws = ar.take(wsb);
+  hipError_t e = ar.bind(ctx, 0);
+  int64_t* const d_cp = ar.at<int64_t>(o_cp); int64_t* const d_op = ar.at<int64_t>(o_op);
+  int32_t* const d_ri = ar.at<int32_t>(o_ri); int32_t* const d_oi = ar.at<int32_t>(o_oi);
+  double* const d_x = ar.at<double>(o_x); double* const d_ox = ar.at<double>(o_ox);
+  void* const d_ws = ar.at<void>(o_ws);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_cp, h_cp.data(), sizeof(int64_t) * ((size_t)N + 1), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_ri, rowidx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_x, x, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
   int rc = GFICF_OK;
   if (e == hipSuccess) {
     rc = gficf_csc_transpose_device(ctx, G, N, d_cp, d_ri, d_x, nnz, d_op, d_oi, d_ox, d_ws, wsb);
+    if (!rc && nnz > 0) {                          // map the caller's fresh result pages while the kernels run
+      gficf_prefault(out_x, sizeof(double) * (size_t)nnz);
+      gficf_prefault(out_idx, sizeof(int32_t) * (size_t)nnz);
+    }
     // validate (status word) before the results are handed back
     if (!rc) rc = gficf_ctx_sync(ctx);
     else (void)hipStreamSynchronize(ctx->stream);
@@ -297,9 +303,6 @@ int gficf_csc_transpose_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* c
     if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
     else (void)hipStreamSynchronize(ctx->stream);
   }
-  void* ptrs[] = {d_cp, d_op, d_ri, d_oi, d_x, d_ox, d_ws};
-  for (void* q : ptrs) if (q) (void)hipFree(q);
-  (void)hipHostFree(h_cp);
   if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_csc_transpose_host: %s", hipGetErrorString(e));
   return rc;
 }

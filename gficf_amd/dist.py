@@ -94,13 +94,14 @@ class JaccardShard:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.kpad = ops.kpad(k)
+        self.row_words = ops.row_words(self.N, self.k)      # row pitch of the table (the library's choice for this N, k)
         self.rpr = rows_per_rank(self.N, self.world)
         self.b, self.e = shard_bounds(self.N, self.world, self.rank)
         self.n_local = self.e - self.b
         self.pipeline = bool(pipeline) and device is not None and torch.device(device).type == "cuda"
         nbuf = 2 if self.pipeline else 1
         # full table(s), padded to world*rpr rows so that every rank contributes an equal block
-        self.tables = [torch.zeros((self.world * self.rpr, self.kpad), dtype=torch.int32, device=device) for _ in range(nbuf)]
+        self.tables = [torch.zeros((self.world * self.rpr, self.row_words), dtype=torch.int32, device=device) for _ in range(nbuf)]
         self.outs = [torch.zeros((3, self.n_local * self.k), dtype=torch.float64, device=device) for _ in range(nbuf)]
         self.us = [torch.zeros(self.n_local * self.k, dtype=torch.int32, device=device) if with_u else None for _ in range(nbuf)]
         self.table, self.out, self.u = self.tables[0], self.outs[0], self.us[0]
@@ -109,7 +110,8 @@ class JaccardShard:
         self.packed = None
         if self.world > 1 and packed_transport:
             self.pw = ops.packed_words(self.N, self.k)
-            self.packed = torch.zeros((self.world * self.rpr, self.pw), dtype=torch.int32, device=device)
+            if self.pw < self.row_words:                     # (compact rows of a small data set may already be as short)
+                self.packed = torch.zeros((self.world * self.rpr, self.pw), dtype=torch.int32, device=device)
         if self.pipeline:
             self.side = torch.cuda.Stream(device=device)
             self.edge_streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]

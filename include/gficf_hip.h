@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFICF_HIP_ABI_VERSION 1
+#define GFICF_HIP_ABI_VERSION 2
 
 typedef enum gficf_status {
   GFICF_OK = 0,
@@ -42,8 +42,11 @@ typedef enum gficf_status {
   GFICF_ERR_UNSUPPORTED = 6,   /* k > GFICF_JACCARD_MAX_K, table too large for the kernel,
                                   edge weights too large for the Louvain fixed point ...   */
   GFICF_ERR_CAPACITY = 7,      /* caller-provided output buffer too small                  */
-  GFICF_ERR_BAD_VALUE = 8      /* a non-finite coordinate in the kNN point matrix, a
+  GFICF_ERR_BAD_VALUE = 8,     /* a non-finite coordinate in the kNN point matrix, a
                                   negative / non-finite edge weight (Louvain)             */
+  GFICF_ERR_EXPLICIT_ZEROS = 9 /* gficf_csc_device met an explicitly stored zero: its count of
+                                  stored entries is then not rowSums(M != 0); discard the
+                                  outputs and call gficf_csc_exact_device                  */
 } gficf_status;
 
 #define GFICF_JACCARD_MAX_K 256
@@ -65,6 +68,12 @@ int gficf_ctx_set_stream(gficf_ctx* ctx, void* stream);
  * *_device calls enqueued since last sync. */
 int gficf_ctx_sync(gficf_ctx* ctx);
 const char* gficf_last_error(void);
+/* Where the banner lines of the host entries go (the reference prints them with Rprintf,
+ * src/rcpp_parallel_jaccard_coeff.cpp:61-64,75-78): NULL = stdout; the R glue passes a wrapper of Rprintf. */
+int gficf_ctx_set_print(gficf_ctx* ctx, void (*fn)(const char* line));
+/* Device memory of the host entry points comes from a grow-only pool kept by the context between calls (no
+ * allocation per call); this releases it (and any unfinished plan). */
+int gficf_ctx_trim(gficf_ctx* ctx);
 
 /* ----------------------------------------------------------------------------- Jaccard
  * Replaces  SEXP _gficf_rcpp_parallel_jaccard_coef(SEXP mat, SEXP printOutput)
@@ -85,6 +94,14 @@ const char* gficf_last_error(void);
 int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k,
                        int64_t ld, double* rmat, int print_output);
 
+/* Compact host return (the reference's 24 B row is a function of (i, idx[i,j], u)): the intersection counts alone,
+ * u[i*k + j], 2 B per edge across PCIe instead of 24.  gficf_jaccard_expand_host rebuilds the reference's (N*k) x 3
+ * matrix from them on the host (pure host code, several threads; n_threads <= 0: one per hardware thread, at most 16):
+ * row i*k+j = (i+1, idx[i,j], u/(2.0*k-u)) when u > 0, zeros otherwise (src/rcpp_parallel_jaccard_coeff.cpp:48-52). */
+int gficf_jaccard_counts_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, uint16_t* u);
+int gficf_jaccard_expand_host(const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, const uint16_t* u, double* rmat,
+                              int n_threads);
+
 /* The package's second Jaccard entry:  SEXP _gficf_jaccard_coeff(SEXP idx, SEXP printOutput)
  *   (src/RcppExports.cpp:36-45, registered :87) -> jaccard_coeff() (src/jaccard_coeff.cpp:19-44), the serial form
  *   (not called by clustcells(), but exported).  Same edges and weights u / (2k - u); two differences:
@@ -100,12 +117,18 @@ int gficf_jaccard_coeff_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, in
  *   3. edges  : table + a block of cells -> that block's rows of rmat
  */
 
-/* Row pitch (int32 elements) of the table for a given k: 16, 32, 64, 128 or 256. */
+/* Slots of a table row for a given k: 16, 32, 64, 128 or 256 (k rounded up). */
 int gficf_jaccard_kpad(int k);
+/* Row pitch of the table in 32-bit words, a function of (N_total, k) alone (every rank of a sharded build computes the
+ * same): gficf_jaccard_kpad(k) words of 32-bit ids, or — for data sets of fewer than 2^17 cells, whose ids fit 17 bits,
+ * and k <= kpad - kpad/16 (k = 30: 16 words = 64 B) — half of that: 16-bit low halves + one bitmap of high bits.  The row
+ * layout is private to the library; callers only size and slice the table by this pitch.  A buffer of N * kpad words
+ * always suffices. */
+int gficf_jaccard_row_words(int64_t N_total, int k);
 
 /* d_idx: n_rows x k column-major (ld >= n_rows) device matrix holding the neighbour ids
  * of cells [row0, row0+n_rows) of an N_total-cell data set.  Writes d_table_rows
- * (n_rows x kpad int32, row-major; caller passes the address of the block's first row).
+ * (n_rows x gficf_jaccard_row_words(N_total, k) int32, row-major; caller passes the address of the block's first row).
  * Ids are validated against [1, N_total]; failures are reported by gficf_ctx_sync(). */
 int gficf_jaccard_ingest_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64,
                                 int64_t n_rows, int k, int64_t ld, int64_t N_total,
@@ -121,7 +144,7 @@ int gficf_jaccard_pack_rows_device(gficf_ctx* ctx, const int32_t* d_table_rows, 
 int gficf_jaccard_unpack_rows_device(gficf_ctx* ctx, const uint32_t* d_packed, int64_t n_rows, int k,
                                      int64_t N_total, int32_t* d_table_rows);
 
-/* d_table: the FULL N x kpad table.  Computes edges of cells [cell_begin, cell_end).
+/* d_table: the FULL N x row_words table.  Computes edges of cells [cell_begin, cell_end).
  * d_src/d_dst/d_w: three arrays of (cell_end-cell_begin)*k doubles — the block's slice of
  * the three columns of rmat (pass rmat + cell_begin*k, rmat + E + cell_begin*k,
  * rmat + 2E + cell_begin*k to land directly in the reference layout).
@@ -131,7 +154,7 @@ int gficf_jaccard_edges_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N
                                double* d_dst, double* d_w, int32_t* d_u);
 
 /* Single-GPU convenience: ingest + edges, d_rmat in the reference layout ((N*k) x 3
- * column-major).  d_table_ws: caller-provided workspace of N*kpad int32 (kept by the
+ * column-major).  d_table_ws: caller-provided workspace of N*row_words int32 (kept by the
  * caller so that no allocation happens per call), d_u optional. */
 int gficf_jaccard_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int64_t N, int k,
                          int64_t ld, int32_t* d_table_ws, double* d_rmat, int32_t* d_u);
@@ -210,7 +233,7 @@ int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, 
 
 /* Device-resident pipeline (all pointers are device memory; colptr is int64 here), split
  * where a multi-GPU caller needs the seam (cells sharded by column block):
- *   1. count   : d_nt[g] += #{local cells with non-zero entry of gene g}   (d_nt zeroed by caller)
+ *   1. count   : d_nt[g] += #{local cells with non-zero entry of gene g}   (d_nt zeroed by caller; a counter stays below 2^32)
  *   2. (multi-GPU only) caller all-reduces d_nt (sum) over ranks
  *   3. genes   : d_nt, N_total -> d_keep[G] (uint8), d_w[G], d_genes (the per-gene tables the
  *                scaling pass looks up: gficf_csc_genes_bytes(G) bytes, opaque), d_gkept[1] (int64)
@@ -243,12 +266,51 @@ int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
                            const int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x);
 
 /* Single-GPU convenience: steps 1,3,4,5 back to back on the context's stream.  Output
- * buffers need capacity nnz (upper bound); *d_out_colptr[n_cells] holds the kept nnz. */
+ * buffers need capacity nnz (upper bound); *d_out_colptr[n_cells] holds the kept nnz.
+ * gficf_csc_device counts STORED entries in step 1 without reading x (4 B/nnz instead of 12), which is nt_g unless the
+ * matrix stores explicit zeros; the scaling pass notices one for free and the next gficf_ctx_sync() then returns
+ * GFICF_ERR_EXPLICIT_ZEROS: discard the outputs and call gficf_csc_exact_device (same arguments; step 1 reads x).
+ * The host and multi-GPU entries always count exactly. */
 int gficf_csc_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colptr,
                      const int32_t* d_rowidx, const double* d_x, int64_t nnz, double prop_min,
                      double prop_max, const double* d_w_in, int64_t* d_nt, uint8_t* d_keep,
                      gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept, int64_t* d_out_colptr,
                      int32_t* d_out_rowidx, double* d_out_x);
+int gficf_csc_exact_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* d_colptr,
+                           const int32_t* d_rowidx, const double* d_x, int64_t nnz, double prop_min,
+                           double prop_max, const double* d_w_in, int64_t* d_nt, uint8_t* d_keep,
+                           gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept, int64_t* d_out_colptr,
+                           int32_t* d_out_rowidx, double* d_out_x);
+
+/* ------------------------------------------------------------------- several GPUs behind the host entries
+ * The reference's call sites are one `.Call` each (R/clustCells.R:65; gficf() R/gficf.R:17-33), so a drop-in that
+ * shards over the GPUs of a node does it underneath that one call: single process, one context and one stream per
+ * device, the partitioning of the multi-process path (gficf_amd/dist.py) —
+ *   Jaccard: contiguous equal-pitch cell blocks; every device uploads and ingests its block of the kNN matrix, the table
+ *            rows are exchanged device to device (hipMemcpyPeerAsync over xGMI; without peer access every device ingests the
+ *            whole matrix), every device builds its block's edges and copies them into its three column slices of rmat;
+ *   GF-ICF : contiguous cell blocks balanced by stored entries; the per-gene counts nt_g are summed across the devices
+ *            through the host (G x 8 B each way), everything else is per block.
+ * Same kernels and arithmetic as the single-device entries: same bits.  devices: HIP ordinals (NULL = 0 .. ndev-1; the
+ * same ordinal may appear more than once — one block each, which is how the N > 1 path is tested on a one-GPU box).
+ * The R glue reads the list from the environment variable GFICF_HIP_DEVICES ("0,1,2,3"). */
+typedef struct gficf_multi gficf_multi;
+int gficf_multi_create(const int* devices, int ndev, gficf_multi** out);
+void gficf_multi_destroy(gficf_multi* m);
+int gficf_multi_device_count(const gficf_multi* m);
+int gficf_multi_set_print(gficf_multi* m, void (*fn)(const char* line));
+/* The block arithmetic (pure host code): bounds[r] .. bounds[r+1] = cells of device r, ndev + 1 entries. */
+int gficf_multi_cell_blocks(int64_t N, int ndev, int64_t* bounds);
+int gficf_multi_cell_blocks_by_nnz(int64_t N, const void* colptr, int colptr_is_i64, int ndev, int64_t* bounds);
+/* gficf_jaccard_host over the devices of m (same arguments, same result). */
+int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, double* rmat,
+                             int print_output);
+/* gficf_normalize_csc_host_plan / _finish over the devices of m (same arguments, same results). */
+int gficf_normalize_csc_host_multi_plan(gficf_multi* m, int64_t G, int64_t N, const void* colptr, int colptr_is_i64,
+                                        const int32_t* rowidx, const double* x, double prop_min, double prop_max,
+                                        const double* w_in, int64_t* G_kept, int64_t* nnz_kept);
+int gficf_normalize_csc_host_multi_finish(gficf_multi* m, uint8_t* keep, int64_t* nt, double* w, void* out_colptr,
+                                          int32_t* out_rowidx, double* out_x);
 
 /* ------------------------------------------------------------------- cluster signatures
  * "Next" row N3: data$cluster.gene.rnk of clustcells() (R/clustCells.R:121-123):

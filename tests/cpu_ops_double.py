@@ -14,6 +14,10 @@ class CpuOpsDouble:
     def kpad(k):
         return 16 if k <= 16 else 32 if k <= 32 else 64 if k <= 64 else 128 if k <= 128 else 256
 
+    @classmethod
+    def row_words(cls, N_total, k):
+        return cls.kpad(k)             # the double keeps plain int32 rows whatever the size
+
     def sync(self):
         pass
 

@@ -31,10 +31,16 @@ def test_header_symbols_exported_and_bound():
 
 def test_abi_version_and_kpad():
     L = _lib.load()
-    assert L.gficf_hip_abi_version() == 1
+    assert L.gficf_hip_abi_version() == 2
     assert [L.gficf_jaccard_kpad(k) for k in (0, 1, 15, 16, 17, 30, 32, 33, 50, 64, 65, 128, 129, 256)] == \
         [16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 128, 128, 256, 256]
     assert L.gficf_jaccard_kpad(257) == -1 and L.gficf_jaccard_kpad(-1) == -1
+    # row pitch of the table: half the slots for data sets of fewer than 2^17 cells when k leaves room for the bitmap
+    rw = L.gficf_jaccard_row_words
+    assert [rw(100000, k) for k in (15, 16, 17, 30, 31, 32, 33, 50, 60, 61, 100, 120, 121, 240, 241, 256)] == \
+        [16, 16, 16, 16, 32, 32, 32, 32, 32, 64, 64, 64, 128, 128, 256, 256]
+    assert rw(131071, 30) == 16 and rw(131072, 30) == 32 and rw(1000000, 30) == 32 and rw(1000000, 50) == 64
+    assert rw(-1, 30) == -1 and rw(100, 257) == -1
 
 
 def test_status_enum_matches_header():

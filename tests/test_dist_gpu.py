@@ -41,7 +41,7 @@ def _worker(rank, world, port, outdir):
         b, e = shard_bounds(N, world, rank)
         idx = [torch.from_numpy(np.ascontiguousarray(m[b:e].T)).cuda() for m in mats]
         sh = JaccardShard(ops, N, k, device="cuda", pipeline=True, packed_transport=True)
-        assert sh.packed is not None and sh.pw * 4 < sh.kpad * 4
+        assert sh.packed is not None and sh.pw < sh.row_words
         res = []
         for rep in range(2):
             for i in range(3):

@@ -282,10 +282,128 @@ def test_config4_shape_properties_device_resident():
         assert torch.allclose(got, ref, rtol=1e-10, atol=1e-14)
 
 
+def _device_properties(torch, ops, G, N, colptr, rowidx, x, ws, chunk):
+    """Size-independent checks of a device-resident GF-ICF result, cell block by cell block (bounded temporaries):
+    structure (kept entries of every cell, renumbered, in order), nt, w, unit L2 norm, value range."""
+    nk = int(ws["out_colptr"][N])
+    gk = int(ws["gkept"][0])
+    ocp, ori, ox = ws["out_colptr"], ws["out_rowidx"], ws["out_x"]
+    keep = ws["keep"].bool()
+    assert gk == int(keep.sum()) and 0 < gk < G
+    remap = torch.cumsum(keep.long(), 0) - 1
+    wk = ws["w"]
+    nt = torch.zeros(G, dtype=torch.int64, device="cuda")
+    kept_total = 0
+    xmin, xmax = 1.0, 0.0
+    for c0 in range(0, N, chunk):
+        c1 = min(N, c0 + chunk)
+        p0, p1 = int(colptr[c0]), int(colptr[c1])
+        q0, q1 = int(ocp[c0]), int(ocp[c1])
+        ri, xv = rowidx[p0:p1].long(), x[p0:p1]
+        nt += torch.bincount(ri[xv != 0], minlength=G)
+        kept_entry = keep[ri]
+        assert q1 - q0 == int(kept_entry.sum())
+        kept_total += q1 - q0
+        assert torch.equal(ori[q0:q1].long(), remap[ri[kept_entry]])
+        lens = colptr[c0 + 1:c1 + 1] - colptr[c0:c1]
+        col_of = torch.repeat_interleave(torch.arange(c1 - c0, device="cuda"), lens)
+        cnt = torch.zeros(c1 - c0, dtype=torch.int64, device="cuda").index_add_(0, col_of, kept_entry.long())
+        assert torch.equal(ocp[c0 + 1:c1 + 1] - ocp[c0:c1], cnt)
+        ocol = torch.repeat_interleave(torch.arange(c1 - c0, device="cuda"), cnt)
+        oxs = ox[q0:q1]
+        sq = torch.zeros(c1 - c0, dtype=torch.float64, device="cuda").index_add_(0, ocol, oxs * oxs)
+        has_w = torch.zeros(c1 - c0, dtype=torch.float64, device="cuda").index_add_(0, ocol, (wk[keep][ori[q0:q1].long()] > 0).double()) > 0
+        sel = (cnt > 0) & has_w
+        assert torch.allclose(sq[sel], torch.ones_like(sq[sel]), rtol=1e-12, atol=0)
+        if q1 > q0:
+            xmin, xmax = min(xmin, float(oxs.min())), max(xmax, float(oxs.max()))
+        del ri, xv, kept_entry, col_of, cnt, ocol, sq, has_w, sel
+    assert kept_total == nk
+    assert torch.equal(ws["nt"], nt)
+    w_ref = torch.log((N + 1.0) / (nt.double() + 1.0))
+    assert torch.allclose(wk[keep], w_ref[keep], rtol=1e-12, atol=0)
+    lo, hi = float(N) * 0.05, float(N) * 1.0
+    assert torch.equal(keep, (nt.double() > lo) & (nt.double() <= hi))
+    assert xmin >= 0.0 and xmax <= 1.0 + 1e-12
+    # and the closed form of R/gficf.R:59,79,100-103 on a sample of cells
+    for c in (0, 1, N // 3, N // 2, N - 2, N - 1):
+        sl = slice(int(colptr[c]), int(colptr[c + 1]))
+        kp = keep[rowidx[sl].long()]
+        xs, gsel = x[sl][kp], rowidx[sl][kp].long()
+        v = (xs / xs.sum()) * wk[gsel]
+        ref = v / torch.sqrt((v * v).sum())
+        got = ox[int(ocp[c]):int(ocp[c + 1])]
+        assert torch.allclose(got, ref, rtol=1e-10, atol=1e-14)
+    return nk, gk
+
+
+def _import_bench():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    return bench
+
+
+def test_config3_shape_54k_cells_23k_genes_vs_oracle():
+    """BASELINE config 3 (Tabula-Muris-sized stand-in: 23 k genes x 54 k cells, ~6e7 stored entries): the device
+    pipeline and the host C ABI against the oracle — keep mask, nt, structure exact; values and weights <= 1e-6."""
+    import torch
+
+    bench = _import_bench()
+    ops = gficf_amd.HipOps(0)
+    G, N = 23000, 54000
+    colptr, rowidx, x = bench.synth_counts_device(torch, G, N)
+    ws = ops.gficf_csc(G, N, colptr, rowidx, x, 0.05, 1.0)
+    ops.sync()
+    cp, ri, xv = colptr.cpu().numpy(), rowidx.cpu().numpy(), x.cpu().numpy()
+    ref = oracle.gficf_csc(G, N, cp, ri, xv, 0.05, 1.0)
+    nk = int(ws["out_colptr"][N])
+    assert nk == len(ref["x"]) and int(ws["gkept"][0]) == int(ref["keep"].sum())
+    assert np.array_equal(ws["keep"].cpu().numpy().astype(bool), ref["keep"])
+    assert np.array_equal(ws["nt"].cpu().numpy(), ref["nt"])
+    assert np.array_equal(ws["out_colptr"].cpu().numpy(), ref["colptr"])
+    assert np.array_equal(ws["out_rowidx"][:nk].cpu().numpy(), ref["rowidx"])
+    got = ws["out_x"][:nk].cpu().numpy()
+    assert np.allclose(got, ref["x"], rtol=TOL, atol=TOL) and np.abs(got - ref["x"]).max() < 1e-12
+    assert np.allclose(ws["w"].cpu().numpy()[ref["keep"]], ref["w"][ref["keep"]], rtol=TOL, atol=TOL)
+    # the reference-shaped host entry (gficf(), through gficf_normalize_csc_host_plan/_finish) on the same matrix
+    M = sp.csc_matrix((xv, ri, cp), shape=(G, N))
+    res = gficf_amd.gficf(M, normalize=False, verbose=False, storeRaw=False)
+    check_against_oracle(res, ref, N)
+
+
+def test_config5_shape_1M_cells_30k_genes_properties_device_resident():
+    """BASELINE config 5, GF-ICF half (1 M cells x 30 k genes, at most 2 147 stored entries per cell so that
+    nnz < 2^31 — SURVEY.md 8d; ~1.8e9 entries, ~22 GB of input), device-generated and device-resident:
+    the size-independent properties and the sampled closed form (no host oracle at this size)."""
+    import torch
+
+    bench = _import_bench()
+    ops = gficf_amd.HipOps(0)
+    G, N = 30000, 1_000_000
+    colptr, rowidx, x = bench.synth_counts_device(torch, G, N, seed=5, max_per_cell=2147, chunk_cells=125_000)
+    nnz = int(rowidx.numel())
+    assert 1.0e9 < nnz < 2 ** 31 and int(colptr[N]) == nnz
+    assert int((colptr[1:] - colptr[:-1]).max()) <= 2147
+    ws = ops.gficf_csc(G, N, colptr, rowidx, x, 0.05, 1.0)
+    ops.sync()
+    nk, gk = _device_properties(torch, ops, G, N, colptr, rowidx, x, ws, chunk=125_000)
+    assert 0 < nk <= nnz
+    # idempotence of the per-cell scale (x / colSums(x) is invariant to scaling a cell's counts): same values
+    first = ws["out_x"][:nk].clone()
+    x *= torch.repeat_interleave(1.0 + (torch.arange(N, device="cuda") % 7).double(), colptr[1:] - colptr[:-1])
+    ws = ops.gficf_csc(G, N, colptr, rowidx, x, 0.05, 1.0, None, ws)
+    ops.sync()
+    assert int(ws["out_colptr"][N]) == nk
+    assert torch.allclose(ws["out_x"][:nk], first, rtol=1e-12, atol=1e-15)
+
+
 @pytest.mark.parametrize("n_zero", [0, 1, 500])
-def test_device_path_with_explicit_zeros_redoes_exactly(n_zero):
-    """gficf_csc_device counts stored entries first (no x read) and re-runs with the exact count when
-    the scaling pass meets an explicitly stored zero: results must match R's rowSums(M != 0) rule."""
+def test_device_path_with_explicit_zeros_is_reported_and_the_exact_entry_handles_them(n_zero):
+    """gficf_csc_device counts stored entries (no x read); the scaling pass notices an explicitly stored zero and the next
+    sync reports GFICF_ERR_EXPLICIT_ZEROS; gficf_csc_exact_device then gives R's rowSums(M != 0) rule."""
     import torch
 
     ops = gficf_amd.HipOps(0)
@@ -297,14 +415,22 @@ def test_device_path_with_explicit_zeros_redoes_exactly(n_zero):
         x[pos] = 0.0
     ref = oracle.gficf_csc(G, N, cp, ri, x, 0.05, 1.0)
     d = lambda a: torch.from_numpy(a).cuda()
-    for rep in range(2):                        # twice: the flag is reset per call
+    for rep in range(2):                        # twice: the deferred status is cleared by the sync that reports it
         ws = ops.gficf_csc(G, N, d(cp), d(ri), d(x), 0.05, 1.0)
+        if n_zero:
+            with pytest.raises(gficf_amd.GficfError) as ei:
+                ops.sync()
+            assert ei.value.status == "GFICF_ERR_EXPLICIT_ZEROS"
+            ws = ops.gficf_csc(G, N, d(cp), d(ri), d(x), 0.05, 1.0, None, ws, exact=True)
         ops.sync()
         nk = int(ws["out_colptr"][N])
         assert np.array_equal(ws["keep"].cpu().numpy().astype(bool), ref["keep"])
         assert np.array_equal(ws["nt"].cpu().numpy()[ref["keep"]], ref["nt"][ref["keep"]])
         assert nk == len(ref["x"]) and np.array_equal(ws["out_rowidx"][:nk].cpu().numpy(), ref["rowidx"])
         assert np.allclose(ws["out_x"][:nk].cpu().numpy(), ref["x"], rtol=TOL, atol=TOL)
+    # the host entry (what gficf() binds) always counts exactly
+    res = gficf_amd.gficf(sp.csc_matrix((x, ri, cp), shape=(G, N)), normalize=False, verbose=False)
+    assert np.array_equal(res["gficf"].indices, ref["rowidx"]) and np.allclose(res["gficf"].data, ref["x"], rtol=TOL, atol=TOL)
 
 
 def test_cluster_signatures_next_row_n3():

@@ -185,7 +185,7 @@ def test_cell_block_seam_matches_full(ops):
     N, k = 5001, 30
     mat = synth.knn_windowed(N, k, seed=8)
     full, fu = device_jaccard(ops, mat)
-    kp = ops.kpad(k)
+    kp = ops.row_words(N, k)
     table = torch.zeros((N, kp), dtype=torch.int32, device="cuda")
     cut = 2600
     outs = []
@@ -260,6 +260,44 @@ def test_wide_offset_variant_matches(tmp_path):
     env = dict(os.environ, GFICF_JACCARD_FORCE_BIG="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_wide_rows_for_small_data_sets_match(tmp_path):
+    """Data sets of fewer than 2^17 cells store their table rows compactly (16-bit low halves + a bitmap of high
+    bits); GFICF_JACCARD_COMPACT=0 keeps the 32-bit rows that larger data sets use.  Same bits either way, duplicate
+    rows (slow path), the filtered build and ids above 2^16 included."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, gficf_amd, oracle\n"
+        "from gficf_amd import synth\n"
+        "for N, k in ((5000, 30), (70000, 30), (3000, 50), (2000, 17), (700, 100), (1000, 31), (400, 130)):\n"
+        "    mat = synth.knn_windowed(N, k, W=max(100, k), seed=N)\n"
+        "    mat[5, 2] = mat[5, 0]\n"
+        "    want = oracle.jaccard(mat, nthreads=4)[0]\n"
+        "    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(mat, False), want)\n"
+        "    ed = gficf_amd.jaccard_edges(np.concatenate([np.arange(1, N + 1, dtype=mat.dtype)[:, None], mat], axis=1))\n"
+        "    kp = want[:, 2] > 0\n"
+        "    assert np.array_equal(ed['from'], want[kp, 0]) and np.array_equal(ed['to'], want[kp, 1]) and np.array_equal(ed['weight'], want[kp, 2])\n"
+        "print('ok')\n")
+    for compact in ("0", "1"):
+        env = dict(os.environ, GFICF_JACCARD_COMPACT=compact, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (compact, r.stderr[-2000:])
+
+
+def test_config3_shape_54k_cells_k30_bit_exact(ops):
+    """BASELINE config 3 (Tabula-Muris-sized: ~54 k cells, k = 30 Phenograph graph): whole edge matrix and
+    intersection counts bit-exact vs the oracle, through the device pipeline and through the host C ABI."""
+    mat = synth.knn_windowed(54000, 30, seed=3)
+    want, wu = oracle.jaccard(mat, nthreads=os.cpu_count() or 8)
+    rm, u = device_jaccard(ops, mat)
+    assert np.array_equal(u, wu)
+    assert np.array_equal(rm, want)
+    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(mat, False), want)
+    # ids as doubles (what Rcpp hands the reference after its INTSXP -> REALSXP copy)
+    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(mat.astype(np.float64), False), want)
 
 
 def test_pipelined_steps_give_the_same_bits(ops):
@@ -398,9 +436,10 @@ def test_packed_transport_rows_roundtrip(ops, N, k):
     mat[7, 1] = mat[7, 0]                       # a row with duplicate ids: its flag must survive
     mat[N - 1, :] = mat[N - 1, 0]
     idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
-    kp, pw = ops.kpad(k), ops.packed_words(N, k)
+    kp, pw = ops.row_words(N, k), ops.packed_words(N, k)
     bits = int(np.ceil(np.log2(N + 1)))
-    assert pw == (k * bits + 1 + 31) // 32 and pw * 4 <= kp * 4
+    assert pw == (k * bits + 1 + 31) // 32 and pw * 4 <= ops.kpad(k) * 4
+    assert kp == (ops.kpad(k) // 2 if N < 2 ** 17 and ops.kpad(k) >= 32 and k <= ops.kpad(k) * 15 // 16 else ops.kpad(k))
     table = torch.empty((N, kp), dtype=torch.int32, device="cuda")
     ops.jaccard_ingest(idx, N, k, N, table)
     packed = torch.empty((N, pw), dtype=torch.int32, device="cuda")
@@ -411,7 +450,8 @@ def test_packed_transport_rows_roundtrip(ops, N, k):
     ops.jaccard_unpack_rows(packed[cut:], N - cut, k, N, back[cut:])
     ops.sync()
     assert torch.equal(back, table)
-    assert int(table[7, 0]) < 0 and int(table[N - 1, 0]) < 0      # duplicate flags set and preserved
+    flag_word = kp - 1 if kp < ops.kpad(k) else 0                   # compact rows keep the flag in their last word
+    assert int(table[7, flag_word]) < 0 and int(table[N - 1, flag_word]) < 0      # duplicate flags set and preserved
     if N <= 70000:
         out = torch.empty((3, N * k), dtype=torch.float64, device="cuda")
         ops.jaccard_edges(back, N, k, 0, N, out)

@@ -1,0 +1,233 @@
+// gather_lab.hip — what bounds the row gather of the Jaccard edge kernel?  (tools only, not product code)
+//
+// A stripped model of k_jaccard_edges' memory pattern (one wave per cell; own row; k random row gathers of
+// 16 B per lane, all in flight together; 24 B/edge written as three coalesced runs), without the hash set,
+// so that the memory side can be varied alone:
+//   * row bytes 128 (k ids x 4 B, the product's table) or 64 (k <= 30 ids as 16-bit low halves + one word of high bits)
+//   * load flavour: plain / nt (non-temporal) / sc1 (L1 bypass)
+//   * ids: windowed kNN relabelled by a random permutation (the bench input), the same without the relabelling
+//     (perfect locality), uniformly random
+//   * with / without the output stores
+// and, linked against libgficf_hip.so, the product kernel on the same inputs for reference.
+//
+// Build: hipcc -O3 --offload-arch=gfx950 -I include tools/lab/gather_lab.hip -L gficf_amd -lgficf_hip -Wl,-rpath,'$ORIGIN/../../gficf_amd' -o tools/lab/gather_lab
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "gficf_hip.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+template <int FLAV>
+__device__ inline v4u load16(const char* p) {
+  if (FLAV == 1) return __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+  if (FLAV == 2) {
+    v4u r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+    return r;
+  }
+  return *reinterpret_cast<const v4u*>(p);
+}
+
+// ROWB: bytes per table row.  128: uint32 ids[32].  64: uint16 lo[30], uint32 hi (bit j = bit 16 of id j).
+template <int ROWB, int FLAV, bool STORES>
+__global__ __launch_bounds__(256) void k_model(const char* __restrict__ table, long N, int k, double* __restrict__ o_src,
+                                               double* __restrict__ o_dst, double* __restrict__ o_w) {
+  constexpr int LPR = ROWB / 16, RPS = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const long w0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((long)gridDim.x * 256) >> 6;
+  const int grow = lane / LPR;
+  const uint32_t gcol = (uint32_t)(lane % LPR) * 16u;
+  auto own = [&](long i) -> uint32_t {
+    if (lane >= k) return 0u;
+    if (ROWB == 128) return reinterpret_cast<const uint32_t*>(table + i * ROWB)[lane];
+    const uint32_t lo = reinterpret_cast<const uint16_t*>(table + i * ROWB)[lane];
+    const uint32_t hi = reinterpret_cast<const uint32_t*>(table + i * ROWB)[15];
+    return lo | (((hi >> lane) & 1u) << 16);
+  };
+  long i = w0;
+  uint32_t a_next = i < N ? own(i) : 0u;
+  for (; i < N; i += nw) {
+    const uint32_t a = a_next;
+    const uint32_t asafe = a != 0 ? a : (uint32_t)(i + 1);
+    if (i + nw < N) a_next = own(i + nw);
+    const int steps = (k + RPS - 1) / RPS;
+    uint32_t acc[4] = {0, 0, 0, 0};
+    v4u bv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < steps) {
+        const uint32_t dst = (uint32_t)__shfl((int)asafe, s * RPS + grow);
+        bv[s] = load16<FLAV>(table + (size_t)(dst - 1) * ROWB + gcol);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < steps) acc[s] = bv[s].x ^ bv[s].y ^ bv[s].z ^ bv[s].w;
+    // fold to one value per slot (stands for the intersection count)
+    uint32_t u = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < steps) {
+        uint32_t x = acc[s];
+        for (int d = 1; d < LPR; d <<= 1) x ^= __shfl_xor((int)x, d);
+        const uint32_t v = (uint32_t)__shfl((int)x, (lane % RPS) * LPR);
+        u = (lane / RPS == s) ? v : u;
+      }
+    }
+    if (STORES && lane < k) {
+      const long r = i * k + lane;
+      __builtin_nontemporal_store((double)(uint32_t)(i + 1), o_src + r);
+      __builtin_nontemporal_store((double)a, o_dst + r);
+      __builtin_nontemporal_store((double)(u & 0xffu), o_w + r);
+    }
+    if (!STORES && u == 0xdeadbeefu) o_w[0] = 1.0;
+  }
+}
+
+static uint64_t rng_state = 88172645463325252ull;
+static inline uint64_t rnd() {
+  rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+  return rng_state;
+}
+
+// ids: N x k row-major, 1-based.  mode 0: windowed (W = 100) + random relabelling, 1: windowed, cells in order, 2: uniform
+static std::vector<uint32_t> make_ids(long N, int k, int mode) {
+  std::vector<uint32_t> ids((size_t)N * k);
+  std::vector<uint32_t> pi(N);
+  for (long i = 0; i < N; ++i) pi[i] = (uint32_t)i;
+  if (mode == 0)
+    for (long i = N - 1; i > 0; --i) std::swap(pi[i], pi[rnd() % (i + 1)]);
+  const int W = 100;
+  std::vector<int> cand(2 * W);
+  for (long c = 0; c < N; ++c) {
+    uint32_t* row = &ids[(size_t)pi[c] * k];
+    if (mode == 2) {
+      for (int t = 0; t < k; ++t) {
+        for (;;) {
+          uint32_t v = (uint32_t)(rnd() % N);
+          bool ok = v != (uint32_t)c;
+          for (int t2 = 0; t2 < t && ok; ++t2) ok = row[t2] != v + 1;
+          if (ok) { row[t] = v + 1; break; }
+        }
+      }
+      continue;
+    }
+    for (int t = 0; t < W; ++t) { cand[t] = t - W; cand[W + t] = t + 1; }
+    for (int t = 0; t < k; ++t) {
+      const int r = t + (int)(rnd() % (2 * W - t));
+      std::swap(cand[t], cand[r]);
+      const long nb = ((c + cand[t]) % N + N) % N;
+      row[t] = pi[nb] + 1;
+    }
+  }
+  return ids;
+}
+
+int main(int argc, char** argv) {
+  const long N = argc > 1 ? atol(argv[1]) : 100000;
+  const int k = argc > 2 ? atoi(argv[2]) : 30;
+  const bool product_only = argc > 3 && atoi(argv[3]) != 0;
+  const long E = N * k;
+  if (k > 30 || N >= (1 << 17)) { printf("the 64 B row model needs k <= 30 and N < 2^17\n"); return 1; }
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  printf("device %s, %d CUs; N = %ld, k = %d, E = %ld\n", prop.name, cus, N, k, E);
+  double *s, *d, *w;
+  CK(hipMalloc(&s, E * 8)); CK(hipMalloc(&d, E * 8)); CK(hipMalloc(&w, E * 8));
+  char *t128, *t64;
+  CK(hipMalloc(&t128, N * 128)); CK(hipMalloc(&t64, N * 64));
+  int32_t* d_idx_cm;
+  CK(hipMalloc(&d_idx_cm, E * 4));
+  int32_t* d_table;
+  CK(hipMalloc(&d_table, N * 128));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  gficf_ctx* ctx = nullptr;
+  if (gficf_ctx_create(0, nullptr, &ctx) != 0) { printf("ctx: %s\n", gficf_last_error()); return 1; }
+
+  const char* mode_name[3] = {"windowed+permuted", "windowed in order", "uniform random"};
+  for (int mode = 0; mode < 3; ++mode) {
+    std::vector<uint32_t> ids = make_ids(N, k, mode);
+    std::vector<uint32_t> h128((size_t)N * 32, 0);
+    std::vector<uint16_t> h64((size_t)N * 32, 0);
+    std::vector<int32_t> cm((size_t)E);
+    for (long i = 0; i < N; ++i) {
+      uint32_t hi = 0;
+      for (int j = 0; j < k; ++j) {
+        const uint32_t v = ids[(size_t)i * k + j];
+        h128[(size_t)i * 32 + j] = v;
+        h64[(size_t)i * 32 + j] = (uint16_t)(v & 0xffffu);
+        hi |= ((v >> 16) & 1u) << j;
+        cm[(size_t)j * N + i] = (int32_t)v;
+      }
+      h64[(size_t)i * 32 + 30] = (uint16_t)(hi & 0xffffu);
+      h64[(size_t)i * 32 + 31] = (uint16_t)(hi >> 16);
+    }
+    CK(hipMemcpy(t128, h128.data(), N * 128, hipMemcpyHostToDevice));
+    CK(hipMemcpy(t64, h64.data(), N * 64, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_idx_cm, cm.data(), E * 4, hipMemcpyHostToDevice));
+    printf("---- ids: %s\n", mode_name[mode]);
+    auto run = [&](const char* name, auto kern, const char* table, int grid) {
+      float best = 1e9, sum = 0;
+      const int reps = 20;
+      for (int rep = 0; rep < reps + 3; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, table, N, k, s, d, w);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep >= 3) { best = std::min(best, ms); sum += ms; }
+      }
+      printf("  %-44s grid %5d: best %6.1f us  mean %6.1f us  %5.1f G edges/s\n", name, grid, best * 1e3, sum / reps * 1e3, E / (best * 1e-3) / 1e9);
+    };
+    for (int bpc : {3, 6, 8}) {
+      if (product_only) break;
+      const int grid = cus * bpc;
+      run("128 B rows, plain loads, stores", k_model<128, 0, true>, t128, grid);
+      run("128 B rows, nt loads, stores", k_model<128, 1, true>, t128, grid);
+      run("128 B rows, plain loads, no stores", k_model<128, 0, false>, t128, grid);
+      run(" 64 B rows, plain loads, stores", k_model<64, 0, true>, t64, grid);
+      run(" 64 B rows, nt loads, stores", k_model<64, 1, true>, t64, grid);
+      run(" 64 B rows, plain loads, no stores", k_model<64, 0, false>, t64, grid);
+    }
+    if (!product_only) run("128 B rows, sc1 loads (waited one by one)", k_model<128, 2, true>, t128, cus * 6);
+    // the product kernel on the same ids
+    if (gficf_jaccard_ingest_device(ctx, d_idx_cm, 0, N, k, N, N, d_table) != 0) { printf("ingest: %s\n", gficf_last_error()); return 1; }
+    float best = 1e9, sum = 0, besti = 1e9;
+    for (int rep = 0; rep < 23; ++rep) {
+      CK(hipEventRecord(e0));
+      gficf_jaccard_edges_device(ctx, d_table, N, k, 0, N, s, d, w, nullptr);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep >= 3) { best = std::min(best, ms); sum += ms; }
+      CK(hipEventRecord(e0));
+      gficf_jaccard_ingest_device(ctx, d_idx_cm, 0, N, k, N, N, d_table);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (rep >= 3) besti = std::min(besti, ms);
+    }
+    if (gficf_ctx_sync(ctx) != 0) { printf("sync: %s\n", gficf_last_error()); return 1; }
+    {   // the same two kernels, 20 launches each between one pair of events (launch gaps amortised)
+      float ms_i, ms_e;
+      CK(hipEventRecord(e0));
+      for (int rep = 0; rep < 20; ++rep) gficf_jaccard_ingest_device(ctx, d_idx_cm, 0, N, k, N, N, d_table);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_i, e0, e1));
+      CK(hipEventRecord(e0));
+      for (int rep = 0; rep < 20; ++rep) gficf_jaccard_edges_device(ctx, d_table, N, k, 0, N, s, d, w, nullptr);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_e, e0, e1));
+      printf("  %-44s            : ingest %5.1f us  edges %5.1f us per launch\n", "PRODUCT, 20 launches back to back", ms_i / 20 * 1e3, ms_e / 20 * 1e3);
+    }
+    printf("  %-44s            : best %6.1f us  mean %6.1f us  %5.1f G edges/s   (ingest best %5.1f us)\n", "PRODUCT k_jaccard_edges", best * 1e3, sum / 20 * 1e3,
+           E / (best * 1e-3) / 1e9, besti * 1e3);
+  }
+  gficf_ctx_destroy(ctx);
+  return 0;
+}
