@@ -164,18 +164,31 @@ __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64
 }
 
 // Tile variant for KPAD <= 64 (the common sizes): 64 cells per workgroup of 256 threads.  Reads are coalesced along
-// cells, every (cell, slot) element is one thread's: validation, then duplicate detection by inserting the id into the
-// cell's own little hash set in LDS (2*KPAD slots, linear probing: a compare-and-swap that finds its own value has
-// found a duplicate), then the rows are packed and leave as contiguous 16 B-per-lane runs.  ~1 LDS atomic per id
-// instead of the KPAD^2/2 register compares per cell of k_ingest_reg, and four times the threads in flight.
-template <typename T, int KPAD, bool CMP>
+// cells, every (cell, slot) element is one thread's; the tile goes through LDS, then thread (cell = lane, part = wave)
+// holds the cell's row in registers and checks its quarter of the id pairs for duplicates — min over the pairs of
+// a XOR b, VALU only (a compare per pair would funnel through the scalar unit: v_cmp -> s_or, a dependent chain that
+// cost 13 us at 100 k x 30) —, then the rows are packed and leave as contiguous 16 B-per-lane runs.
+template <int KPAD, int W>
+__device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD]) {
+  uint32_t m = 0xFFFFFFFFu;                 // min over this part's pairs (j, j2 < j), j = W, W + 4, ...
+#pragma unroll
+  for (int j = W; j < KPAD; j += 4) {
+#pragma unroll
+    for (int j2 = 0; j2 < j; ++j2) {
+      const uint32_t x = r[j] ^ r[j2];
+      m = x < m ? x : m;
+    }
+  }
+  return m;
+}
+
+template <typename T, int KPAD, bool CMP, bool DUPCHK = true>
 __global__ __launch_bounds__(256) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                      int64_t N_total, uint32_t* __restrict__ table,
                                                      uint32_t* __restrict__ status) {
-  constexpr int ROWS = 64, HS = 2 * KPAD;
+  constexpr int ROWS = 64;
   constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
   __shared__ uint32_t tile[ROWS][KPAD + 1];
-  __shared__ uint32_t hs[ROWS][HS];
   __shared__ uint32_t dup[ROWS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int64_t row0 = (int64_t)blockIdx.x * ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * ROWS) {
@@ -187,36 +200,38 @@ __global__ __launch_bounds__(256) void k_ingest_tile(const T* __restrict__ idx, 
       const int j = wave + 4 * m;
       raw[m] = (j < k && r < n_rows) ? idx[(int64_t)j * ld + r] : (T)0;
     }
-    for (int e = tid; e < ROWS * HS; e += 256) (&hs[0][0])[e] = EMPTY;
     if (tid < ROWS) dup[tid] = 0;
     bool bad = false;
-    uint32_t v[KPAD / 4];
 #pragma unroll
     for (int m = 0; m < KPAD / 4; ++m) {
       const int j = wave + 4 * m;
-      v[m] = 0;
+      uint32_t v = 0;
       if (j < k && r < n_rows) {
         bool ok;
-        v[m] = decode_id<T>(raw[m], N_total, ok);
+        v = decode_id<T>(raw[m], N_total, ok);
         bad |= !ok;
       }
-      tile[lane][j] = v[m];
+      tile[lane][j] = v;
     }
     if (bad) atomicOr(status, GFICF_ST_BAD_ID);
     __syncthreads();
+    if (DUPCHK) {
+      uint32_t rr[KPAD];
 #pragma unroll
-    for (int m = 0; m < KPAD / 4; ++m) {
-      if (v[m] != 0) {
-        uint32_t h = (v[m] * 0x9E3779B1u) >> (32 - (KPAD == 16 ? 5 : KPAD == 32 ? 6 : 7));
-        for (int probe = 0; probe < HS; ++probe) {          // at most KPAD of the 2*KPAD slots are ever taken
-          const uint32_t old = atomicCAS(&hs[lane][h], EMPTY, v[m]);
-          if (old == EMPTY) break;
-          if (old == v[m]) { dup[lane] = 1; break; }
-          h = (h + 1) & (HS - 1);
-        }
+      for (int j = 0; j < KPAD; ++j) {
+        const uint32_t v = tile[lane][j];
+        rr[j] = v != 0 ? v : (0x80000000u | (uint32_t)j);       // empty slots: values no id and no other slot has
       }
+      uint32_t m;
+      switch (wave) {
+        case 0: m = dup_part<KPAD, 0>(rr); break;
+        case 1: m = dup_part<KPAD, 1>(rr); break;
+        case 2: m = dup_part<KPAD, 2>(rr); break;
+        default: m = dup_part<KPAD, 3>(rr); break;
+      }
+      if (m == 0) dup[lane] = 1;
+      __syncthreads();
     }
-    __syncthreads();
     const int64_t rows_here = (n_rows - row0) < ROWS ? (n_rows - row0) : ROWS;
     const int n_out4 = (int)rows_here * (ROWW / 4);
     uint4* const out4 = reinterpret_cast<uint4*>(table + row0 * ROWW);
@@ -862,10 +877,14 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
   const int64_t tiles = gficf_ceil_div(n_rows, INGEST_ROWS);
   const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
   static const bool use_reg = getenv("GFICF_JACCARD_INGEST_REG") != nullptr;     // test hook: the one-thread-per-cell variant
+  static const bool lab_nodup = getenv("GFICF_LAB_INGEST_NODUP") != nullptr;      // timing experiment only: no duplicate detection (WRONG flags)
 #define LAUNCH_INGEST_REG(KP, CM)                                                                                          \
   do {                                                                                                                     \
     if (use_reg)                                                                                                           \
       hipLaunchKernelGGL((k_ingest_reg<T, KP, CM>), dim3(grid2), dim3(INGEST2_ROWS), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
+                         table, ctx->d_status);                                                                            \
+    else if (lab_nodup)                                                                                                    \
+      hipLaunchKernelGGL((k_ingest_tile<T, KP, CM, false>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
                          table, ctx->d_status);                                                                            \
     else                                                                                                                   \
       hipLaunchKernelGGL((k_ingest_tile<T, KP, CM>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total,  \

@@ -62,12 +62,37 @@ def shard_bounds_by_nnz(colptr, world: int) -> list[tuple[int, int]]:
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+_FLAT_ALL_GATHER: dict = {}          # backend name -> does all_gather_into_tensor exist there (decided once, not per call)
+
+
 def _all_gather_rows(table, local_view, group):
-    """All-gather equal-sized row blocks into ``table`` (``local_view`` aliases this rank's block)."""
-    try:
+    """All-gather equal-sized row blocks into ``table`` (``local_view`` aliases this rank's block).
+
+    The form of the collective is a property of the backend, decided once: a communication failure is never
+    answered with a different collective (the other ranks would not issue it) — it propagates."""
+    backend = dist.get_backend(group)
+    flat = _FLAT_ALL_GATHER.get(backend)
+    if flat is None:
+        if backend == "nccl":                              # RCCL: in-place flat all-gather
+            flat = True
+        else:
+            # gloo grew all_gather_into_tensor over time: probe on a throw-away tensor, every rank alike
+            world = dist.get_world_size(group)
+            probe_in = torch.zeros(1, dtype=torch.int32, device=table.device)
+            probe_out = torch.zeros(world, dtype=torch.int32, device=table.device)
+            try:
+                dist.all_gather_into_tensor(probe_out, probe_in, group=group)
+                flat = True
+            except (NotImplementedError, RuntimeError) as ex:
+                msg = str(ex).lower()
+                if isinstance(ex, NotImplementedError) or "not supported" in msg or "not implemented" in msg or "no backend" in msg:
+                    flat = False
+                else:
+                    raise
+        _FLAT_ALL_GATHER[backend] = flat
+    if flat:
         dist.all_gather_into_tensor(table, local_view, group=group)
-    except (RuntimeError, NotImplementedError):
-        # backend without a flat all-gather (older gloo): gather into per-rank views
+    else:
         world = dist.get_world_size(group)
         chunks = list(table.view(world, -1).unbind(0))
         dist.all_gather(chunks, local_view.reshape(-1).clone(), group=group)
@@ -81,9 +106,11 @@ class JaccardShard:
     so it overlaps the edge kernel of the step before it, which still reads the other table; the edge
     kernels of consecutive steps run on two alternating streams, so the tail of one overlaps the ramp
     of the next.  Every step does the same work and yields the same bits; only stream placement
-    changes.  Contract in this mode: the input block handed to :meth:`step` must already be valid on
-    the device; the returned buffer is one of two and is overwritten by the step after next; call
-    :meth:`wait` to make the caller's current stream wait for the latest step before reading it.
+    changes.  Contract in this mode: the input block handed to :meth:`step` is read in stream order behind
+    the caller's current stream (the side stream waits for it); the returned buffer is one of two and is
+    overwritten by the step after next; call :meth:`wait` to make the caller's current stream wait for the
+    latest step before reading it, and :meth:`release` once it has been read (the step that reuses the buffer
+    then waits for that point instead of racing the reader).
     """
 
     def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False,
@@ -117,7 +144,9 @@ class JaccardShard:
             self.edge_streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
             self.ev_table_ready = [torch.cuda.Event(), torch.cuda.Event()]
             self.ev_edges_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_consumed = [None, None]      # recorded by release(): the reader of outs[p] has got past it
             self.last_done = None
+            self.last_p = None
 
     def _fill_table(self, table, idx_local_cm):
         my_rows = table[self.rank * self.rpr:(self.rank + 1) * self.rpr]
@@ -155,6 +184,8 @@ class JaccardShard:
             return self.out
         p = self.t & 1
         table = self.tables[p]
+        # the input block may have been produced just before this call on the caller's stream (e.g. by KnnShard.step)
+        self.side.wait_stream(torch.cuda.current_stream(self.out.device))
         if self.t >= 2:
             self.side.wait_event(self.ev_edges_done[p])      # edges of step t-2 have finished reading this table
         with torch.cuda.stream(self.side):
@@ -162,6 +193,9 @@ class JaccardShard:
             self.ev_table_ready[p].record(self.side)
         es = self.edge_streams[p]                            # in order behind step t-2, which wrote the same buffers
         es.wait_event(self.ev_table_ready[p])
+        if self.ev_consumed[p] is not None:                  # ... and behind whoever read what step t-2 wrote there
+            es.wait_event(self.ev_consumed[p])
+            self.ev_consumed[p] = None
         with torch.cuda.stream(es):
             if self.time_edges:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -174,6 +208,7 @@ class JaccardShard:
             self.ev_edges_done[p].record(es)
         self.table, self.out, self.u = table, self.outs[p], self.us[p]
         self.last_done = self.ev_edges_done[p]
+        self.last_p = p
         self.t += 1
         return self.out
 
@@ -186,6 +221,14 @@ class JaccardShard:
         """Make the caller's current stream wait for the latest step (pipelined mode; no-op otherwise)."""
         if self.pipeline and self.last_done is not None:
             torch.cuda.current_stream(self.out.device).wait_event(self.last_done)
+
+    def release(self):
+        """Pipelined mode: the caller's current stream has read the latest returned buffer up to this point; the step
+        that overwrites that buffer (the one after next) waits for it.  No-op otherwise."""
+        if self.pipeline and self.last_p is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.out.device))
+            self.ev_consumed[self.last_p] = ev
 
     def sync(self):
         """Wait for all streams and surface deferred input-validation errors."""

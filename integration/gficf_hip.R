@@ -59,6 +59,7 @@ cluster_signatures_hip = function(M, cluster.map)
   u = base::unique(cluster.map)
   r = .Call(`_gficf_cluster_signatures`, M@i, M@p, M@x, M@Dim, match(cluster.map, u) - 1L, length(u))
   rownames(r) = rownames(M)
+  colnames(r) = u          # sapply(u, ...) names the columns by cluster label (reference R/clustCells.R:122-123)
   r
 }
 

@@ -1,7 +1,8 @@
 /* gficf_hip_glue.c — R `.Call` glue over libgficf_hip.so (C ABI: include/gficf_hip.h).
  *
- * NOT compiled in this repository's CI: R and <Rinternals.h> are absent from the build image.
- * A maintainer of the gficf R package drops this file into src/, removes
+ * R and <Rinternals.h> are absent from the build image, so this file is never linked here; it IS syntax- and
+ * type-checked against clearly-labelled mock declarations (tests/r_mock/, tests/test_glue_compile.py), which pins
+ * nothing about R's behaviour.  A maintainer of the gficf R package drops this file into src/, removes
  * src/rcpp_parallel_jaccard_coeff.cpp, deletes the `_gficf_rcpp_parallel_jaccard_coef` wrapper and
  * its CallEntries row from the generated src/RcppExports.cpp (reference :59-70, :89) and adds
  *   PKG_CPPFLAGS += -I$(GFICF_HIP_HOME)/include
@@ -30,11 +31,17 @@
 #include <R.h>
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
+#include <limits.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "gficf_hip.h"
 
 static gficf_ctx* g_ctx = NULL;
+static gficf_multi* g_multi = NULL;      /* GFICF_HIP_DEVICES names more than one GPU */
+static int g_multi_tried = 0;
+
+static void print_line(const char* line) { Rprintf("%s", line); }   /* the reference's banners go through Rprintf */
 
 static gficf_ctx* ctx_get(void) {
   if (!g_ctx) {
@@ -42,8 +49,38 @@ static gficf_ctx* ctx_get(void) {
     const char* e = getenv("GFICF_HIP_DEVICE");
     if (e) dev = atoi(e);
     if (gficf_ctx_create(dev, NULL, &g_ctx) != GFICF_OK) Rf_error("gficf_hip: %s", gficf_last_error());
+    gficf_ctx_set_print(g_ctx, print_line);
   }
   return g_ctx;
+}
+
+/* GFICF_HIP_DEVICES="0,1,2,3": the Jaccard build and gficf() shard their cells over these GPUs (single process,
+ * gficf_multi_* of the C ABI).  Unset, or one device: the single-device entries. */
+static gficf_multi* multi_get(void) {
+  if (!g_multi_tried) {
+    g_multi_tried = 1;
+    const char* e = getenv("GFICF_HIP_DEVICES");
+    int devs[64], n = 0;
+    while (e && *e && n < 64) {
+      char* end = NULL;
+      const long v = strtol(e, &end, 10);
+      if (end == e) break;
+      devs[n++] = (int)v;
+      e = end;
+      while (*e == ',' || *e == ';' || *e == ' ') ++e;
+    }
+    if (n > 1) {
+      if (gficf_multi_create(devs, n, &g_multi) != GFICF_OK) Rf_error("gficf_hip: %s", gficf_last_error());
+      gficf_multi_set_print(g_multi, print_line);
+    }
+  }
+  return g_multi;
+}
+
+/* rows of the (N*k) x 3 result: R matrices hold at most INT_MAX rows (Rf_allocMatrix takes int) */
+static int edge_rows(int64_t N, int k) {
+  if (k > 0 && N > (int64_t)INT_MAX / k) Rf_error("gficf_hip: N * k = %.0f rows exceed what an R matrix holds", (double)N * (double)k);
+  return (int)(N * k);
 }
 
 /* replaces src/RcppExports.cpp:61-70 + src/rcpp_parallel_jaccard_coeff.cpp:59-80 */
@@ -55,8 +92,10 @@ SEXP _gficf_rcpp_parallel_jaccard_coef(SEXP matSEXP, SEXP printOutputSEXP) {
   const int k = INTEGER(dim)[1];
   const int is_f64 = TYPEOF(matSEXP) == REALSXP;          /* uwot returns INTSXP; no coercion copy needed */
   const void* idx = is_f64 ? (const void*)REAL(matSEXP) : (const void*)INTEGER(matSEXP);
-  SEXP rmat = PROTECT(Rf_allocMatrix(REALSXP, (int)(N * k), 3));   /* reference :67 */
-  int rc = gficf_jaccard_host(ctx_get(), idx, is_f64, N, k, N, REAL(rmat), Rf_asLogical(printOutputSEXP));
+  SEXP rmat = PROTECT(Rf_allocMatrix(REALSXP, edge_rows(N, k), 3));   /* reference :67 */
+  gficf_multi* m = multi_get();
+  int rc = m ? gficf_jaccard_host_multi(m, idx, is_f64, N, k, N, REAL(rmat), Rf_asLogical(printOutputSEXP))
+             : gficf_jaccard_host(ctx_get(), idx, is_f64, N, k, N, REAL(rmat), Rf_asLogical(printOutputSEXP));
   if (rc != GFICF_OK) {
     UNPROTECT(1);
     Rf_error("gficf_hip: %s", gficf_last_error());         /* BEGIN_RCPP/END_RCPP equivalent */
@@ -74,7 +113,7 @@ SEXP _gficf_jaccard_coeff(SEXP idxSEXP, SEXP printOutputSEXP) {
   const int k = INTEGER(dim)[1];
   const int is_f64 = TYPEOF(idxSEXP) == REALSXP;
   const void* idx = is_f64 ? (const void*)REAL(idxSEXP) : (const void*)INTEGER(idxSEXP);
-  SEXP weights = PROTECT(Rf_allocMatrix(REALSXP, (int)(N * k), 3));
+  SEXP weights = PROTECT(Rf_allocMatrix(REALSXP, edge_rows(N, k), 3));
   if (gficf_jaccard_coeff_host(ctx_get(), idx, is_f64, N, k, N, REAL(weights), Rf_asLogical(printOutputSEXP)) != GFICF_OK) {
     UNPROTECT(1);
     Rf_error("gficf_hip: %s", gficf_last_error());
@@ -88,15 +127,19 @@ SEXP _gficf_gficf_csc(SEXP iS, SEXP pS, SEXP xS, SEXP dimS, SEXP wS, SEXP minS, 
   const int64_t G = INTEGER(dimS)[0], N = INTEGER(dimS)[1];
   const double* w_in = Rf_isNull(wS) ? NULL : REAL(wS);
   int64_t gk = 0, nk = 0;
-  if (gficf_normalize_csc_host_plan(ctx_get(), G, N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(minS),
-                                    Rf_asReal(maxS), w_in, &gk, &nk) != GFICF_OK)
-    Rf_error("gficf_hip: %s", gficf_last_error());
+  gficf_multi* m = multi_get();
+  const int prc = m ? gficf_normalize_csc_host_multi_plan(m, G, N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(minS), Rf_asReal(maxS), w_in, &gk, &nk)
+                    : gficf_normalize_csc_host_plan(ctx_get(), G, N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(minS), Rf_asReal(maxS), w_in, &gk, &nk);
+  if (prc != GFICF_OK) Rf_error("gficf_hip: %s", gficf_last_error());
+  if (nk > (int64_t)INT_MAX) Rf_error("gficf_hip: %.0f kept entries exceed a dgCMatrix (its @p is integer)", (double)nk);
   SEXP out = PROTECT(Rf_allocVector(VECSXP, 6));
   SEXP oi = PROTECT(Rf_allocVector(INTSXP, nk)), op = PROTECT(Rf_allocVector(INTSXP, N + 1));
   SEXP ox = PROTECT(Rf_allocVector(REALSXP, nk)), keep = PROTECT(Rf_allocVector(RAWSXP, G));
   SEXP w = PROTECT(Rf_allocVector(REALSXP, G));
   int64_t* nt = (int64_t*)R_alloc((size_t)G, sizeof(int64_t));
-  if (gficf_normalize_csc_host_finish(ctx_get(), RAW(keep), nt, REAL(w), INTEGER(op), INTEGER(oi), REAL(ox)) != GFICF_OK) {
+  const int frc = m ? gficf_normalize_csc_host_multi_finish(m, RAW(keep), nt, REAL(w), INTEGER(op), INTEGER(oi), REAL(ox))
+                    : gficf_normalize_csc_host_finish(ctx_get(), RAW(keep), nt, REAL(w), INTEGER(op), INTEGER(oi), REAL(ox));
+  if (frc != GFICF_OK) {
     UNPROTECT(6);
     Rf_error("gficf_hip: %s", gficf_last_error());
   }
@@ -238,9 +281,13 @@ SEXP _gficf_phenograph(SEXP XS, SEXP kS, SEXP metricS, SEXP resolutionS, SEXP al
     UNPROTECT(1);
     Rf_error("gficf_hip: %s", gficf_last_error());
   }
-  Rf_setAttrib(out, Rf_install("modularity"), Rf_ScalarReal(q));
-  Rf_setAttrib(out, Rf_install("n.edges"), Rf_ScalarReal((double)n_edges));
-  UNPROTECT(1);
+  /* symbols first (Rf_install may allocate), the fresh scalars protected while the attribute is set */
+  SEXP sym_q = Rf_install("modularity"), sym_e = Rf_install("n.edges");
+  SEXP vq = PROTECT(Rf_ScalarReal(q));
+  Rf_setAttrib(out, sym_q, vq);
+  SEXP ve = PROTECT(Rf_ScalarReal((double)n_edges));
+  Rf_setAttrib(out, sym_e, ve);
+  UNPROTECT(3);
   return out;
 }
 
@@ -263,4 +310,6 @@ void gficf_hip_register(DllInfo* dll) { R_registerRoutines(dll, NULL, HipCallEnt
 void R_unload_gficf(DllInfo* dll) {
   (void)dll;
   if (g_ctx) { gficf_ctx_destroy(g_ctx); g_ctx = NULL; }
+  if (g_multi) { gficf_multi_destroy(g_multi); g_multi = NULL; }
+  g_multi_tried = 0;
 }

@@ -48,6 +48,7 @@ def _worker(rank, world, port, outdir):
                 out = sh.step(idx[i])
                 sh.wait()
                 res.append((i, out.clone()))
+                sh.release()
         sh.sync()
         torch.cuda.synchronize()
         for n, (i, r) in enumerate(res):
