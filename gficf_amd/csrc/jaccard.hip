@@ -369,6 +369,14 @@ __device__ inline uint2 lds_read_b64(uint32_t addr) {
   return make_uint2(v.x, v.y);
 }
 
+// min(a, b, 1): 0 iff a == 0 or b == 0.  Bound to v_min3_u32 by hand: written as C the compiler turns the "min with 1"
+// back into a compare + conditional add through VCC.
+__device__ inline uint32_t min3u_one(uint32_t a, uint32_t b) {
+  uint32_t m;
+  asm("v_min3_u32 %0, %1, %2, 1" : "=v"(m) : "v"(a), "v"(b));
+  return m;
+}
+
 // c + (this lane's bit of the 64-bit lane mask m): one v_addc with the mask as carry-in.
 __device__ inline int add_lane_bit(int c, unsigned long long m) {
   int r;
@@ -689,9 +697,16 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
             uint2 h[C::IPL];
 #pragma unroll
             for (int t = 0; t < C::IPL; ++t) h[t] = lds_read_b64(bucket_off<KPAD, BIG>(id[t]) | wave_off);
-            int c = 0;
+            // misses, counted on the vector ALU alone: min(slot0 ^ id, slot1 ^ id, 1) is 0 on a hit and 1 on a miss (a compare
+            // per slot would go v_cmp -> s_or -> v_addc through the scalar unit and its wait states for every probe)
+            uint32_t miss = 0;
 #pragma unroll
-            for (int t = 0; t < C::IPL; ++t) c = add_lane_bit(c, __ballot(h[t].x == id[t]) | __ballot(h[t].y == id[t]));
+            for (int t = 0; t < C::IPL; t += 2) {
+              const uint32_t m0 = min3u_one(h[t].x ^ id[t], h[t].y ^ id[t]);
+              const uint32_t m1 = min3u_one(h[t + 1].x ^ id[t + 1], h[t + 1].y ^ id[t + 1]);
+              miss += m0 + m1;                 // one v_add3_u32
+            }
+            int c = C::IPL - (int)miss;
             if (nov) {                          // wave-uniform, rare: ids that overflowed the set
               for (int t = 0; t < nov; ++t) {
                 const uint32_t ov = ovlist[t];

@@ -23,7 +23,14 @@ for f in glob.glob(os.path.join(root, "p*", "pmc_counter_collection.csv")):
         m = re.search(r"(k_[a-z_0-9]+)", row["Kernel_Name"])
         if m:
             acc[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
-mean = lambda v: sum(v) / len(v)
+def mean(v):
+    """Mean over the launches that did real work: a launch whose counter is below 5 % of the kernel's largest is an empty
+    one (a variant that returns at once because the other variant handles the input) and would dilute the per-launch figure."""
+    top = max(v)
+    real = [x for x in v if x >= 0.05 * top] if top > 0 else v
+    return sum(real) / len(real)
+
+
 res = {}
 for kern, c in acc.items():
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
