@@ -41,10 +41,17 @@ __host__ __device__ inline int kpad_for(int k) {
 // ------------------------------------------------------------------------ table row formats
 // wide    : KPAD x uint32 ids (zero padded); bit 31 of word 0 = "row holds duplicate ids".
 // compact : for data sets of fewer than 2^17 cells (ids fit 17 bits) a row of KPAD slots takes half the
-//           bytes: KC = KPAD - KPAD/16 ids as uint16 low halves, then NW = KPAD/32 words of high bits
+//           bytes: KC = KPAD - KPAD/16 ids as uint16 halves, then NW = KPAD/32 words of high bits
 //           (bit j of the bitmap = bit 16 of id j); bit 31 of the row's last word = the duplicate flag.
 //           k = 30 -> 64 B instead of 128 B per row.  The edge kernel is bound by the row gathers (one
 //           L1 miss per edge, served by L2 / Infinity Cache): half the table means twice the L2 hit rate.
+//           The 16-bit halves are stored PRE-HASHED: half = rotr16((id & 0xFFFF) * A mod 2^16, 5), a bijection of
+//           the low 16 id bits whose bits 3..10 are the top byte of the multiplicative hash — the byte offset of the
+//           id's bucket in the edge kernel's hash set is then one AND of the stored half, and membership is tested
+//           on the stored form itself (stored halves are equal iff the ids' low halves are).  On gfx950 most integer
+//           vector instructions (shifts left, 24-bit multiplies, three-operand and/or, min3, every SDWA / DPP / packed
+//           form) issue at half the rate of and / or / xor / add / shift-right / v_bitop3 (tools/lab/valu_lab.hip,
+//           profiles/r02_valu_rates.txt), and the edge kernel spends its time in exactly those per probed id.
 // The format is a function of (N_total, k) alone, so every rank of a sharded build agrees on it.
 template <int KPAD>
 struct CFmt {
@@ -53,6 +60,16 @@ struct CFmt {
   static constexpr int ROWW = KPAD / 2;         // row pitch in 32-bit words
   static constexpr int HIW = ROWW - NW;         // word index of the first high-bit word
 };
+
+constexpr uint32_t SCR_A = 0x9E37u, SCR_AINV = 0x7787u;     // A * AINV = 1 (mod 2^16)
+__host__ __device__ inline uint32_t scramble16(uint32_t lo) {
+  const uint32_t s = (lo * SCR_A) & 0xFFFFu;
+  return ((s >> 5) | (s << 11)) & 0xFFFFu;
+}
+__host__ __device__ inline uint32_t unscramble16(uint32_t half) {
+  const uint32_t s = ((half << 5) | (half >> 11)) & 0xFFFFu;
+  return (s * SCR_AINV) & 0xFFFFu;
+}
 
 struct TableFmt {
   int kpad;
@@ -82,7 +99,7 @@ __device__ inline uint32_t row_slot_id(const uint32_t* roww, int j, int kpad, bo
   if (!compact) return roww[j] & ID_MASK;
   const int kc = kpad - kpad / 16;
   if (j >= kc) return 0u;
-  const uint32_t lo = (roww[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+  const uint32_t lo = unscramble16((roww[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
   const uint32_t hw = roww[kpad / 2 - kpad / 32 + (j >> 5)];
   return lo | (((hw >> (j & 31)) & 1u) << 16);
 }
@@ -150,7 +167,7 @@ __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64
         v = tile[rr][j];
         if (j == 0 && dup[rr]) v |= ROW_DUP_FLAG;
       } else if (j < CFmt<KPAD>::HIW) {
-        v = (tile[rr][2 * j] & 0xFFFFu) | (tile[rr][2 * j + 1] << 16);
+        v = scramble16(tile[rr][2 * j] & 0xFFFFu) | (scramble16(tile[rr][2 * j + 1] & 0xFFFFu) << 16);
       } else {
         const int j0 = (j - CFmt<KPAD>::HIW) * 32;
         v = 0;
@@ -182,7 +199,7 @@ __device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD]) {
   return m;
 }
 
-template <typename T, int KPAD, bool CMP, bool DUPCHK = true>
+template <typename T, int KPAD, bool CMP>
 __global__ __launch_bounds__(256) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                      int64_t N_total, uint32_t* __restrict__ table,
                                                      uint32_t* __restrict__ status) {
@@ -215,7 +232,7 @@ __global__ __launch_bounds__(256) void k_ingest_tile(const T* __restrict__ idx, 
     }
     if (bad) atomicOr(status, GFICF_ST_BAD_ID);
     __syncthreads();
-    if (DUPCHK) {
+    {
       uint32_t rr[KPAD];
 #pragma unroll
       for (int j = 0; j < KPAD; ++j) {
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(256) void k_ingest_tile(const T* __restrict__ idx, 
           x = tile[rr][j];
           if (j == 0 && dup[rr]) x |= ROW_DUP_FLAG;
         } else if (j < CFmt<KPAD>::HIW) {
-          x = (tile[rr][2 * j] & 0xFFFFu) | (tile[rr][2 * j + 1] << 16);
+          x = scramble16(tile[rr][2 * j] & 0xFFFFu) | (scramble16(tile[rr][2 * j + 1] & 0xFFFFu) << 16);
         } else {
           const int b0 = (j - CFmt<KPAD>::HIW) * 32;
           x = 0;
@@ -305,7 +322,7 @@ __global__ __launch_bounds__(INGEST2_ROWS) void k_ingest_reg(const T* __restrict
     } else {
       using F = CFmt<KPAD>;
 #pragma unroll
-      for (int w = 0; w < F::HIW; ++w) tile[tid][w] = (v[2 * w] & 0xFFFFu) | (v[2 * w + 1] << 16);
+      for (int w = 0; w < F::HIW; ++w) tile[tid][w] = scramble16(v[2 * w] & 0xFFFFu) | (scramble16(v[2 * w + 1] & 0xFFFFu) << 16);
 #pragma unroll
       for (int h = 0; h < F::NW; ++h) {
         uint32_t hw = 0;
@@ -377,6 +394,15 @@ __device__ inline uint32_t min3u_one(uint32_t a, uint32_t b) {
   return m;
 }
 
+// v_bitop3_b32: any bitwise function of three inputs at the FULL vector rate (v_and_or_b32, v_or3_b32, v_xor3 forms issue at
+// half of it on gfx950).  TT: truth table, bit (a << 2 | b << 1 | c) = f(a, b, c).  0xEA = (a & b) | c, 0x96 = a ^ b ^ c.
+template <int TT>
+__device__ inline uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(r) : "v"(a), "v"(b), "v"(c), "n"(TT));
+  return r;
+}
+
 // c + (this lane's bit of the 64-bit lane mask m): one v_addc with the mask as carry-in.
 __device__ inline int add_lane_bit(int c, unsigned long long m) {
   int r;
@@ -414,7 +440,7 @@ __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint
   if (OUT != OUT_U16) {
     __builtin_nontemporal_store(pos ? (double)(uint32_t)(cell + 1) : 0.0, o.src + r);   // reference :49 (cell + 1 <= 2^31)
     __builtin_nontemporal_store(pos ? (double)dst : 0.0, o.dst + r);                    // reference :50
-    __builtin_nontemporal_store(pos ? lut[u] : 0.0, o.w + r);                           // reference :51
+    __builtin_nontemporal_store(lut[u], o.w + r);                                       // reference :51 (lut[0] = 0/(2k) = 0.0: the zero row)
   }
   if (OUT == OUT_RMAT_U) __builtin_nontemporal_store(u, o.u + r);
   if (OUT == OUT_U16) o.u16[r] = (uint16_t)u;
@@ -459,6 +485,32 @@ __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64
   }
 }
 
+// Hits among the 8 ids of a gathered piece of a compact row against the wave's hash set, on the stored form of the ids
+// (pre-hashed half | bit 16): wd = the piece's four words (words of high bits zeroed), hb = the byte of bit-16 values of
+// the 8 ids, bmask / bit16 = (NB-1) << 3 and 0x10000 in vector registers, base = LDS byte address of the set.  Per id: half
+// (and / shift right), bucket address (one v_bitop3), its bit 16 (shift right + and), two three-way XORs against the
+// bucket's slots (v_bitop3), a min3 and an add — 18 issue cycles against 29 for the assembled-id form.  key / hs are
+// returned for the (rare) pass over the overflow list.
+__device__ inline int probe_compact_piece(const uint32_t (&wd)[4], uint32_t hb, uint32_t bmask, uint32_t bit16, uint32_t base,
+                                          uint32_t (&key)[8], uint32_t (&hs)[8]) {
+  uint2 h[8];
+  const uint32_t H = hb << 16;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    key[t] = (t & 1) ? (wd[t >> 1] >> 16) : (wd[t >> 1] & 0xFFFFu);
+    h[t] = lds_read_b64(bitop3<0xEA>(key[t], bmask, base));          // (half & mask) | base
+    hs[t] = (t ? (H >> t) : H) & bit16;
+  }
+  uint32_t miss = 0;
+#pragma unroll
+  for (int t = 0; t < 8; t += 2) {
+    const uint32_t m0 = min3u_one(bitop3<0x96>(h[t].x, key[t], hs[t]), bitop3<0x96>(h[t].y, key[t], hs[t]));
+    const uint32_t m1 = min3u_one(bitop3<0x96>(h[t + 1].x, key[t + 1], hs[t + 1]), bitop3<0x96>(h[t + 1].y, key[t + 1], hs[t + 1]));
+    miss += m0 + m1;
+  }
+  return 8 - (int)miss;
+}
+
 // Sum over the LPR consecutive lanes that share one neighbour row; every lane of the group
 // gets the sum.  DPP inside a 16-lane row, shuffles above.
 template <int LPR>
@@ -492,20 +544,30 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
   // LDS (dynamic, laid out here so that a wave's hash set starts at a multiple of its size and a probe
   // address is (hash & mask) | wave_base):  hash sets | overflow list / slow-path rows | weight table
   extern __shared__ unsigned char smem[];
-  constexpr uint32_t HBYTES = C::NB * 8;                      // bytes of one wave's hash set
-  uint32_t(*const s_rows)[2][KPAD] = reinterpret_cast<uint32_t(*)[2][KPAD]>(smem + C::WAVES * HBYTES);
-  double* const s_lut = reinterpret_cast<double*>(smem + C::WAVES * HBYTES + C::WAVES * 2 * KPAD * 4);
+  constexpr uint32_t HBYTES = C::NB * 8;                      // bytes of one hash set
+  constexpr uint32_t SETS = 1;
+  constexpr uint32_t WBYTES = SETS * HBYTES;                  // bytes of one wave's set(s)
+  uint32_t(*const s_rows)[2][KPAD] = reinterpret_cast<uint32_t(*)[2][KPAD]>(smem + C::WAVES * WBYTES);
+  double* const s_lut = reinterpret_cast<double*>(smem + C::WAVES * WBYTES + C::WAVES * 2 * KPAD * 4);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned char* const hbase = smem + wave * HBYTES;          // this wave's hash set
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave's number as a scalar: everything derived from it (the cell index, row and output addresses) then lives in
+  // scalar registers and is computed on the scalar unit instead of per lane
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* const hbase = smem + wave * WBYTES;          // this wave's hash set(s)
   // W[u] = u / (2.0*k - u): same IEEE-754 double division as reference :51
   for (int u = tid; u <= k; u += C::WAVES * 64) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);
-  for (int b = lane; b < C::NB; b += 64) reinterpret_cast<uint2*>(hbase)[b] = make_uint2(EMPTY, EMPTY);
+  for (int b = lane; b < (int)(SETS * C::NB); b += 64) reinterpret_cast<uint2*>(hbase)[b] = make_uint2(EMPTY, EMPTY);
   __syncthreads();
 
-  // LDS byte address of this wave's hash set (a multiple of HBYTES: dynamic LDS starts at 0 here,
-  // there is no static LDS in this kernel), OR-ed with a bucket offset per probe
-  const uint32_t wave_off = lds_address(smem) + (uint32_t)wave * HBYTES;
+  // LDS byte address of this wave's hash set (a multiple of WBYTES: dynamic LDS starts at 0 here,
+  // there is no static LDS in this kernel), OR-ed with a bucket offset per probe.  Kept in a vector register (derived
+  // from the vector thread id) so that mask-and-base is ONE v_and_or_b32 per probe (a scalar base would take the
+  // instruction's only scalar operand slot away from the mask).
+  const uint32_t wave_off = lds_address(smem) + (uint32_t)(tid >> 6) * WBYTES;
+  // compact rows: the bucket mask and bit 16 as vector registers (operands of v_bitop3_b32)
+  uint32_t bmask_v = (uint32_t)(C::NB - 1) << 3, bit16_v = 0x10000u;
+  asm volatile("" : "+v"(bmask_v), "+v"(bit16_v));
   uint32_t* const ovlist = s_rows[wave][0];
   const char* const tbytes = reinterpret_cast<const char*>(table);
   const int grow = lane / C::LPR;                           // which of the RPS rows of a step this lane reads
@@ -547,15 +609,21 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
       }
     }
   };
-  auto decode_own = [&](const OwnRaw& r, uint32_t (&out)[C::EPL]) {
+  // out: id | bit 31 = the row's duplicate flag; key: the form the hash set holds (wide: the id; compact: the stored,
+  // pre-hashed half | bit 16 of the id)
+  auto decode_own = [&](const OwnRaw& r, uint32_t (&out)[C::EPL], uint32_t (&key)[C::EPL]) {
 #pragma unroll
     for (int q = 0; q < C::EPL; ++q) {
       if (!CMP) {
         out[q] = r.v[q];
+        key[q] = r.v[q] & ID_MASK;
       } else {
         const int s = q * 64 + lane;
         const uint32_t hw = (KPAD == 32) ? r.last : r.hw[q];
-        out[q] = s < C::NSLOT ? (r.v[q] | (((hw >> (s & 31)) & 1u) << 16) | (r.last & ROW_DUP_FLAG)) : 0u;
+        const uint32_t hbit = ((hw >> (s & 31)) & 1u) << 16;
+        const bool ok = s < C::NSLOT;
+        key[q] = ok ? (r.v[q] | hbit) : 0u;
+        out[q] = ok ? (unscramble16(r.v[q]) | hbit | (r.last & ROW_DUP_FLAG)) : 0u;
       }
     }
   };
@@ -617,9 +685,32 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
     return (gl == C::LPR - 1) ? bv.w : 0u;   // the row's last word holds the flag
   };
 
+  // compact rows: the piece's four words with the high-bit words zeroed (wd), and the byte of high bits of this
+  // lane's 8 ids (hb); returns the word that may carry the row's duplicate flag
+  auto piece_words = [&](const uint4& bv, uint32_t (&wd)[4], uint32_t& hb) -> uint32_t {
+    uint32_t hw;
+    if (KPAD == 32) {
+      hw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv.w, 0xFF, 0xf, 0xf, false);   // quad_perm [3,3,3,3]
+    } else {
+      hw = 0;
+      if (F::NW >= 4) { const uint32_t v = (uint32_t)__shfl((int)bv.x, hi_l); hw = hi_c == 0 ? v : hw; }
+      if (F::NW >= 4) { const uint32_t v = (uint32_t)__shfl((int)bv.y, hi_l); hw = hi_c == 1 ? v : hw; }
+      { const uint32_t v = (uint32_t)__shfl((int)bv.z, hi_l); hw = hi_c == 2 ? v : hw; }
+      { const uint32_t v = (uint32_t)__shfl((int)bv.w, hi_l); hw = hi_c == 3 ? v : hw; }
+    }
+    hb = (hw >> ((gl & 3) * 8)) & 0xFFu;
+    wd[0] = bv.x; wd[1] = bv.y; wd[2] = bv.z; wd[3] = bv.w;
+    if (tail) {                              // high-bit words are not ids
+      hb &= (1u << (F::KC % 8)) - 1u;
+#pragma unroll
+      for (int c = (F::KC % 8) / 2; c < 4; ++c) wd[c] = 0u;
+    }
+    return (gl == C::LPR - 1) ? bv.w : 0u;   // the row's last word holds the flag
+  };
+
   for (; i < cell_end; i += nwaves) {
-    uint32_t araw[C::EPL], a[C::EPL], asafe[C::EPL];
-    decode_own(raw, araw);
+    uint32_t araw[C::EPL], a[C::EPL], akey[C::EPL], asafe[C::EPL];
+    decode_own(raw, araw, akey);
     uint32_t flags = 0;
 #pragma unroll
     for (int q = 0; q < C::EPL; ++q) {
@@ -670,19 +761,22 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
             for (int qi = 0; qi < C::EPL; ++qi) {
               bool over = false;
               if (a[qi] != 0) {
-                const uint32_t bo = bucket_off<KPAD, BIG>(a[qi]) + (uint32_t)wave * HBYTES;   // byte offset of the bucket in smem
-                uint32_t old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo), EMPTY, a[qi]);
+                // wide rows: keyed by the id through the multiplicative hash; compact rows: keyed by the stored form,
+                // whose bits 3.. ARE the hash
+                const uint32_t key = akey[qi];
+                const uint32_t bo = (CMP ? (key & ((uint32_t)(C::NB - 1) << 3)) : bucket_off<KPAD, BIG>(key)) + (uint32_t)wave * WBYTES;   // byte offset of the bucket in smem
+                uint32_t old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo), EMPTY, key);
                 if (old == EMPTY) {
                   myslot[qi] = (int)bo;
                 } else {
-                  old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo + 4), EMPTY, a[qi]);
+                  old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo + 4), EMPTY, key);
                   if (old == EMPTY) myslot[qi] = (int)bo + 4;
                   else over = true;
                 }
               }
               const unsigned long long om = __ballot(over);
               if (om) {
-                if (over) ovlist[nov + __popcll(om & lt_mask)] = a[qi];
+                if (over) ovlist[nov + __popcll(om & lt_mask)] = akey[qi];
                 nov += __popcll(om);
               }
             }
@@ -691,27 +785,41 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
           int cnt[C::U];
 #pragma unroll
           for (int uu = 0; uu < C::U; ++uu) {
-            uint32_t id[C::IPL];
-            dupflags |= piece_ids(bv[uu], id);
-            // all probes of the piece are issued before the first is compared
-            uint2 h[C::IPL];
-#pragma unroll
-            for (int t = 0; t < C::IPL; ++t) h[t] = lds_read_b64(bucket_off<KPAD, BIG>(id[t]) | wave_off);
-            // misses, counted on the vector ALU alone: min(slot0 ^ id, slot1 ^ id, 1) is 0 on a hit and 1 on a miss (a compare
-            // per slot would go v_cmp -> s_or -> v_addc through the scalar unit and its wait states for every probe)
             uint32_t miss = 0;
+            int c;
+            if (!CMP) {
+              uint32_t id[C::IPL];
+              dupflags |= piece_ids(bv[uu], id);
+              // all probes of the piece are issued before the first is compared
+              uint2 h[C::IPL];
 #pragma unroll
-            for (int t = 0; t < C::IPL; t += 2) {
-              const uint32_t m0 = min3u_one(h[t].x ^ id[t], h[t].y ^ id[t]);
-              const uint32_t m1 = min3u_one(h[t + 1].x ^ id[t + 1], h[t + 1].y ^ id[t + 1]);
-              miss += m0 + m1;                 // one v_add3_u32
-            }
-            int c = C::IPL - (int)miss;
-            if (nov) {                          // wave-uniform, rare: ids that overflowed the set
-              for (int t = 0; t < nov; ++t) {
-                const uint32_t ov = ovlist[t];
+              for (int t = 0; t < C::IPL; ++t) h[t] = lds_read_b64(bucket_off<KPAD, BIG>(id[t]) | wave_off);
+              // misses, counted on the vector ALU alone: min(slot0 ^ id, slot1 ^ id, 1) is 0 on a hit and 1 on a miss (a compare
+              // per slot would go v_cmp -> s_or -> v_addc through the scalar unit and its wait states for every probe)
 #pragma unroll
-                for (int tt = 0; tt < C::IPL; ++tt) c += (id[tt] == ov);
+              for (int t = 0; t < C::IPL; t += 2) {
+                const uint32_t m0 = min3u_one(h[t].x ^ id[t], h[t].y ^ id[t]);
+                const uint32_t m1 = min3u_one(h[t + 1].x ^ id[t + 1], h[t + 1].y ^ id[t + 1]);
+                miss += m0 + m1;                 // one v_add3_u32
+              }
+              c = C::IPL - (int)miss;
+              if (nov) {                          // wave-uniform, rare: ids that overflowed the set
+                for (int t = 0; t < nov; ++t) {
+                  const uint32_t ov = ovlist[t];
+#pragma unroll
+                  for (int tt = 0; tt < C::IPL; ++tt) c += (id[tt] == ov);
+                }
+              }
+            } else {
+              uint32_t wd[4], hb, key[8], hs[8];
+              dupflags |= piece_words(bv[uu], wd, hb);
+              c = probe_compact_piece(wd, hb, bmask_v, bit16_v, wave_off, key, hs);
+              if (nov) {                          // wave-uniform, rare: ids that overflowed the set (kept in their stored form)
+                for (int t = 0; t < nov; ++t) {
+                  const uint32_t ov = ovlist[t];
+#pragma unroll
+                  for (int tt = 0; tt < 8; ++tt) c += ((key[tt] | hs[tt]) == ov);
+                }
               }
             }
             cnt[uu] = c;
@@ -748,6 +856,292 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
     }
   }
   if (have_prev) store_prev();
+}
+
+// ------------------------------------------------------------------ edge kernel, software-pipelined (k <= 32)
+// The kernel above is bound by neither its arithmetic nor its LDS probes (tools/lab: taking ALL probes out leaves its time
+// unchanged, 40 fewer vector instructions per cell likewise) but by the latency of a cell's row gathers, which nothing in
+// the wave overlaps: a wave issues the gathers of cell i and waits for them before it can do anything else.  This variant,
+// for the row sizes whose gathers all fit in registers at once (k <= 32: one batch per cell), keeps TWO cells in
+// flight per wave: the gathers of cell i+1 (and the own row of cell i+2) are issued before cell i's pieces are probed, so
+// the memory system always has the wave's next requests while the wave computes.  For the wait on cell i's pieces to
+// leave the younger requests alone the compiler must know how many there are: every load and store between two
+// waits is unconditional (indices are clamped instead of branched on, the first cell is peeled instead of guarded), and
+// cells that need the exact multiset path (rows with duplicate ids) are only flagged here and redone after the loop.
+template <int KPAD, bool BIG, bool CMP, int OUT>
+__global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
+    const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
+  using C = JCfg<KPAD, CMP>;
+  using F = CFmt<KPAD>;
+  static_assert(C::EPL == 1 && C::SPQ <= 4, "one batch of gathers per cell");
+  static_assert(!(BIG && CMP), "compact rows hold 17-bit ids");
+  using off_t = typename std::conditional<BIG, uint64_t, uint32_t>::type;
+  constexpr int NST = C::SPQ;                                 // gather steps of a cell, all in flight together
+  extern __shared__ unsigned char smem[];
+  constexpr uint32_t HBYTES = C::NB * 8;
+  constexpr uint32_t SETS = 1;
+  constexpr uint32_t WBYTES = SETS * HBYTES;
+  uint32_t(*const s_rows)[2][KPAD] = reinterpret_cast<uint32_t(*)[2][KPAD]>(smem + C::WAVES * WBYTES);
+  double* const s_lut = reinterpret_cast<double*>(smem + C::WAVES * WBYTES + C::WAVES * 2 * KPAD * 4);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* const hbase = smem + wave * WBYTES;
+  for (int u = tid; u <= k; u += C::WAVES * 64) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);   // reference :51
+  for (int b = lane; b < (int)(SETS * C::NB); b += 64) reinterpret_cast<uint2*>(hbase)[b] = make_uint2(EMPTY, EMPTY);
+  __syncthreads();
+
+  const uint32_t wave_off = lds_address(smem) + (uint32_t)(tid >> 6) * WBYTES;
+  // compact rows: the bucket mask and bit 16 as vector registers (operands of v_bitop3_b32)
+  uint32_t bmask_v = (uint32_t)(C::NB - 1) << 3, bit16_v = 0x10000u;
+  asm volatile("" : "+v"(bmask_v), "+v"(bit16_v));
+  uint32_t* const ovlist = s_rows[wave][0];
+  const char* const tbytes = reinterpret_cast<const char*>(table);
+  const int grow = lane / C::LPR, gl = lane % C::LPR;
+  const uint32_t gcol = (uint32_t)gl * 16u;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int64_t nwaves = (int64_t)gridDim.x * C::WAVES;
+  constexpr uint32_t ROWB = C::ROWB;
+  constexpr int ROWW = ROWB / 4;
+  const int hi_abs = F::HIW + (gl >> 2);
+  const int hi_l = lane - gl + (hi_abs >> 2), hi_c = hi_abs & 3;
+  const bool tail = gl >= F::KC / 8;
+  const int slot_c = lane < C::NSLOT ? lane : C::NSLOT - 1;  // lanes beyond the row's slots load a valid slot and are masked at the decode
+  const bool slot_ok = lane < C::NSLOT;
+
+  const int64_t first = cell_begin + (int64_t)blockIdx.x * C::WAVES + wave;
+  if (first >= cell_end) return;                              // (after the barrier; wave-uniform)
+  const int64_t last_cell = cell_end - 1;
+
+  struct OwnRaw { uint32_t v, hw, last; };
+  // own row of a cell: loads only (unconditional), decoded one iteration later
+  auto load_own = [&](int64_t row, OwnRaw& r) {
+    const uint32_t* const rw = table + row * ROWW;
+    if (!CMP) {
+      r.v = rw[slot_c];
+      r.hw = 0; r.last = 0;
+    } else {
+      r.last = rw[ROWW - 1];
+      r.v = reinterpret_cast<const uint16_t*>(rw)[slot_c];
+      r.hw = (KPAD == 32) ? 0u : rw[F::HIW + (slot_c >> 5)];
+    }
+  };
+  // The own row in the form the hash set holds (wide: id | bit 31 = the row's duplicate flag; compact: stored, pre-hashed
+  // half | bit 16 of the id | bit 31 = the flag); 0 for lanes without a slot.  true_id() gives the id itself.
+  auto decode_own = [&](const OwnRaw& r) -> uint32_t {
+    uint32_t x;
+    if (!CMP) x = r.v;
+    else x = r.v | ((((KPAD == 32 ? r.last : r.hw) >> (lane & 31)) & 1u) << 16) | (r.last & ROW_DUP_FLAG);
+    return slot_ok ? x : 0u;
+  };
+  auto true_id = [&](uint32_t keyraw) -> uint32_t {
+    const uint32_t x = keyraw & ID_MASK;
+    return CMP ? (unscramble16(x & 0xFFFFu) | (x & 0x10000u)) : x;
+  };
+  auto issue_gathers = [&](uint32_t asafe, uint4 (&bv)[NST]) {
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const uint32_t dst = (uint32_t)__shfl((int)asafe, st * C::RPS + grow);
+      const off_t off = (off_t)(dst - 1) * ROWB + gcol;
+      bv[st] = *reinterpret_cast<const uint4*>(tbytes + off);
+    }
+  };
+  auto piece_words = [&](const uint4& bv, uint32_t (&wd)[4], uint32_t& hb) -> uint32_t {
+    uint32_t hw;
+    if (KPAD == 32) hw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv.w, 0xFF, 0xf, 0xf, false);   // quad_perm [3,3,3,3]
+    else {
+      hw = 0;
+      { const uint32_t v = (uint32_t)__shfl((int)bv.z, hi_l); hw = hi_c == 2 ? v : hw; }
+      { const uint32_t v = (uint32_t)__shfl((int)bv.w, hi_l); hw = hi_c == 3 ? v : hw; }
+    }
+    hb = (hw >> ((gl & 3) * 8)) & 0xFFu;
+    wd[0] = bv.x; wd[1] = bv.y; wd[2] = bv.z; wd[3] = bv.w;
+    if (tail) {
+      hb &= (1u << (F::KC % 8)) - 1u;
+#pragma unroll
+      for (int c = (F::KC % 8) / 2; c < 4; ++c) wd[c] = 0u;
+    }
+    return (gl == C::LPR - 1) ? bv.w : 0u;
+  };
+
+  // counts of cell `a`'s slots from its gathered pieces (fast path); returns whether the cell needs the exact path
+  auto process = [&](uint32_t araw, const uint4 (&bv)[NST], int& u_out) -> bool {
+    const uint32_t a = araw & ID_MASK;            // the hash set's form of the id (see decode_own)
+    bool slow = __ballot((araw & ROW_DUP_FLAG) != 0) != 0ull;
+    // row i into the hash set
+    int myslot = -1, nov = 0;
+    bool dup_here = false;
+    {
+      bool over = false;
+      if (a != 0) {
+        // wide rows: keyed by the id through the multiplicative hash; compact rows: keyed by the stored form, whose bits 3.. ARE the hash
+        const uint32_t key = a;
+        const uint32_t bo = (CMP ? (key & ((uint32_t)(C::NB - 1) << 3)) : bucket_off<KPAD, BIG>(key)) + (uint32_t)wave * WBYTES;
+        uint32_t old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo), EMPTY, key);
+        if (old == EMPTY) myslot = (int)bo;
+        else {
+          dup_here |= old == key;               // an id twice in the row (the flag says so too)
+          old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo + 4), EMPTY, key);
+          if (old == EMPTY) myslot = (int)bo + 4;
+          else over = true;
+        }
+      }
+      const unsigned long long om = __ballot(over);
+      if (om) {
+        if (over) ovlist[nov + __popcll(om & lt_mask)] = a;
+        nov += __popcll(om);
+      }
+    }
+    wave_lds_fence();
+    uint32_t dupflags = 0;
+    int myu = 0;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      int c;
+      if (!CMP) {
+        uint32_t miss = 0;
+        uint32_t id[4] = {bv[st].x & ID_MASK, bv[st].y, bv[st].z, bv[st].w};
+        dupflags |= bv[st].x;
+        uint2 h[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h[t] = lds_read_b64(bucket_off<KPAD, BIG>(id[t]) | wave_off);
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+          const uint32_t m0 = min3u_one(h[t].x ^ id[t], h[t].y ^ id[t]);
+          const uint32_t m1 = min3u_one(h[t + 1].x ^ id[t + 1], h[t + 1].y ^ id[t + 1]);
+          miss += m0 + m1;
+        }
+        c = 4 - (int)miss;
+        if (nov) {
+          for (int t = 0; t < nov; ++t) {
+            const uint32_t ov = ovlist[t];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) c += (id[tt] == ov);
+          }
+        }
+      } else {
+        uint32_t wd[4], hb, key[8], hs[8];
+        dupflags |= piece_words(bv[st], wd, hb);
+        c = probe_compact_piece(wd, hb, bmask_v, bit16_v, wave_off, key, hs);
+        if (nov) {                                  // wave-uniform, rare: ids that overflowed the set (kept in their stored form)
+          for (int t = 0; t < nov; ++t) {
+            const uint32_t ov = ovlist[t];
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) c += ((key[tt] | hs[tt]) == ov);
+          }
+        }
+      }
+      const int rowcnt = group_sum<C::LPR>(c);
+      const int v = __shfl(rowcnt, (lane % C::RPS) * C::LPR);
+      myu = (lane / C::RPS == st) ? v : myu;
+    }
+    slow |= __ballot(dup_here || (dupflags & ROW_DUP_FLAG) != 0) != 0ull;      // wave-uniform
+    if (myslot >= 0) *reinterpret_cast<uint32_t*>(smem + myslot) = EMPTY;
+    wave_lds_fence();
+    u_out = a != 0 ? myu : 0;                   // rejected id: zero row
+    return slow;
+  };
+
+  // ---- prologue: own row and gathers of the first cell, own row of the second
+  OwnRaw raw;
+  load_own(first, raw);
+  uint32_t araw_cur = decode_own(raw);
+  uint4 bv_cur[NST];
+  uint32_t id_cur = true_id(araw_cur);
+  issue_gathers(id_cur != 0 ? id_cur : (uint32_t)(first + 1), bv_cur);
+  {
+    const int64_t i1 = first + nwaves;
+    load_own(i1 < cell_end ? i1 : last_cell, raw);
+  }
+  bool any_slow = false;
+  int64_t prev_i = first;
+  uint32_t prev_a = 0;
+  int prev_u = 0;
+
+  // Edges of the previous cell, as buffer stores through a descriptor that covers exactly the cell's k entries of the
+  // array: lanes beyond k fall outside the descriptor's range and the hardware drops their stores — no lane predicate, so
+  // no branch around the stores (the compiler guards a predicated block with one that skips it when no lane is active,
+  // which would make the number of memory operations between two waits unknown to it).  Non-temporal (aux = 2): written
+  // once, never re-read here.
+  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+  auto store_prev = [&]() {
+    const int64_t pb = (prev_i - cell_begin) * (int64_t)k;          // scalar: first entry of the cell
+    const bool pos = prev_u > 0;
+    const int voff8 = lane * 8;
+    if (OUT != OUT_U16) {
+      const double vs = pos ? (double)(uint32_t)(prev_i + 1) : 0.0;   // reference :49
+      const double vd = pos ? (double)prev_a : 0.0;                   // reference :50
+      const double vw = s_lut[prev_u];                                // reference :51 (lut[0] = 0.0: the zero row)
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(o.src + pb, 0, k * 8, 0x00020000);
+      const auto rd = __builtin_amdgcn_make_buffer_rsrc(o.dst + pb, 0, k * 8, 0x00020000);
+      const auto rw = __builtin_amdgcn_make_buffer_rsrc(o.w + pb, 0, k * 8, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vs), rs, voff8, 0, 2);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vd), rd, voff8, 0, 2);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vw), rw, voff8, 0, 2);
+    }
+    if (OUT == OUT_RMAT_U) {
+      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u + pb, 0, k * 4, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b32((uint32_t)prev_u, ru, lane * 4, 0, 2);
+    }
+    if (OUT == OUT_U16) {
+      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u16 + pb, 0, k * 2, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b16((uint16_t)prev_u, ru, lane * 2, 0, 0);
+    }
+  };
+
+  // one cell: prefetch the next one's requests into `nxt`, [store the previous one's edges,] count this one's
+  // intersections from `cur`.  The two piece buffers swap roles from cell to cell (the loop is unrolled by two): copying
+  // one into the other would need the data, i.e. wait for the very gathers that are meant to stay in flight.
+  auto body = [&](int64_t i, const uint4 (&cur)[NST], uint4 (&nxt)[NST], auto store_tag) {
+    constexpr bool STORE = decltype(store_tag)::value;
+    const int64_t i1 = i + nwaves, i2 = i1 + nwaves;
+    const bool valid1 = i1 < cell_end;
+    // next cell: its own row was requested an iteration ago
+    const uint32_t araw_next = valid1 ? decode_own(raw) : 0u;
+    const uint32_t a1 = true_id(araw_next);
+    // the own row of the cell after next FIRST: next iteration's wait for it then leaves the gathers issued behind it in flight
+    load_own(i2 < cell_end ? i2 : last_cell, raw);
+    __builtin_amdgcn_sched_barrier(0);                                 // (the scheduler would hoist the gathers above the own-row load)
+    issue_gathers(a1 != 0 ? a1 : (uint32_t)(i + 1), nxt);              // no next cell: every lane reads row i (one line)
+    __builtin_amdgcn_sched_barrier(0);
+    if (STORE) store_prev();
+    __builtin_amdgcn_sched_barrier(0);
+    int u;
+    const bool slow = process(araw_cur, cur, u);
+    any_slow |= slow;
+    prev_i = i;
+    prev_a = id_cur;
+    prev_u = u;
+    araw_cur = araw_next;
+    id_cur = a1;
+  };
+
+  uint4 bv_b[NST];
+  int64_t i = first;
+  body(i, bv_cur, bv_b, std::false_type{});
+  i += nwaves;
+  while (i < cell_end) {
+    body(i, bv_b, bv_cur, std::true_type{});
+    i += nwaves;
+    if (i >= cell_end) break;
+    body(i, bv_cur, bv_b, std::true_type{});
+    i += nwaves;
+  }
+  store_prev();
+  // ---- cells with duplicate ids in their own row or in a neighbour row (never the case for real kNN output): the exact
+  // multiset path, after the loop; their fast-path rows written above are overwritten (same wave, program order)
+  if (any_slow) {
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int64_t c = first; c < cell_end; c += nwaves) {
+      const uint32_t* const rw = table + c * ROWW;
+      const uint32_t a = lane < k ? row_slot_id(rw, lane, KPAD, CMP) : 0u;
+      bool f = row_dup_flag(rw, KPAD, CMP);
+      if (a != 0) f |= row_dup_flag(table + (int64_t)(a - 1) * ROWW, KPAD, CMP);
+      if (__ballot(f) != 0ull)
+        slow_cell<KPAD, CMP, OUT>(table, c, k, (c - cell_begin) * (int64_t)k, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w,
+                                  o.u, o.u16, o.set_mode, s_lut);
+    }
+  }
 }
 
 // ------------------------------------------------------------------ edge filter (N1)
@@ -869,8 +1263,8 @@ __global__ __launch_bounds__(256) void k_unpack_rows(const uint32_t* __restrict_
         if (j < k) v = packed_id(in, j, bits, wpr, mask);
         if (j == 0) v |= dupf;
       } else if (j < hiw) {
-        if (2 * j < k) v = packed_id(in, 2 * j, bits, wpr, mask) & 0xFFFFu;
-        if (2 * j + 1 < k) v |= packed_id(in, 2 * j + 1, bits, wpr, mask) << 16;
+        if (2 * j < k) v = scramble16(packed_id(in, 2 * j, bits, wpr, mask) & 0xFFFFu);
+        if (2 * j + 1 < k) v |= scramble16(packed_id(in, 2 * j + 1, bits, wpr, mask) & 0xFFFFu) << 16;
       } else {
         const int j0 = (j - hiw) * 32;
         for (int b = 0; b < 32 && j0 + b < k; ++b) v |= ((packed_id(in, j0 + b, bits, wpr, mask) >> 16) & 1u) << b;
@@ -892,14 +1286,10 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
   const int64_t tiles = gficf_ceil_div(n_rows, INGEST_ROWS);
   const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
   static const bool use_reg = getenv("GFICF_JACCARD_INGEST_REG") != nullptr;     // test hook: the one-thread-per-cell variant
-  static const bool lab_nodup = getenv("GFICF_LAB_INGEST_NODUP") != nullptr;      // timing experiment only: no duplicate detection (WRONG flags)
 #define LAUNCH_INGEST_REG(KP, CM)                                                                                          \
   do {                                                                                                                     \
     if (use_reg)                                                                                                           \
       hipLaunchKernelGGL((k_ingest_reg<T, KP, CM>), dim3(grid2), dim3(INGEST2_ROWS), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
-                         table, ctx->d_status);                                                                            \
-    else if (lab_nodup)                                                                                                    \
-      hipLaunchKernelGGL((k_ingest_tile<T, KP, CM, false>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
                          table, ctx->d_status);                                                                            \
     else                                                                                                                   \
       hipLaunchKernelGGL((k_ingest_tile<T, KP, CM>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total,  \
@@ -921,10 +1311,10 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
   return GFICF_OK;
 }
 
-template <int KPAD>
+template <int KPAD, bool CMP>
 constexpr size_t edges_lds_bytes() {
-  using C = JCfg<KPAD, false>;
-  return (size_t)C::WAVES * C::NB * 8 + (size_t)C::WAVES * 2 * KPAD * 4 + (GFICF_JACCARD_MAX_K + 1) * sizeof(double);
+  using C = JCfg<KPAD, CMP>;
+  return (size_t)C::WAVES * C::NB * 8 * (CMP ? 2 : 1) + (size_t)C::WAVES * 2 * KPAD * 4 + (GFICF_JACCARD_MAX_K + 1) * sizeof(double);
 }
 
 template <int KPAD, bool BIG, bool CMP, int OUT>
@@ -935,10 +1325,11 @@ int launch_edges_o(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
   int blocks_per_cu = blocks_per_cu_cached.load(std::memory_order_relaxed);
   if (blocks_per_cu == 0) {
     int nb = 0;
-    GFICF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_jaccard_edges<KPAD, BIG, CMP, OUT>, C::WAVES * 64, edges_lds_bytes<KPAD>()));
-    // The kernel is bound by the L1's outstanding row gathers, not by wave slots: beyond 6 workgroups per CU nothing
-    // is gained (measured on the memory-pattern model, tools/lab/gather_lab.hip: 3 -> 6 per CU is 10-20 % faster).
-    blocks_per_cu = nb > 6 ? 6 : nb > 0 ? nb : 1;
+    constexpr size_t lds_b = edges_lds_bytes<KPAD, CMP>();
+    GFICF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_jaccard_edges<KPAD, BIG, CMP, OUT>, C::WAVES * 64, lds_b));
+    // As many workgroups per CU as fit, up to 8 (measured at 100 k x 30, tools/r02_sweep.sh: 4 per CU 44-47 us, 6: 43-46,
+    // 8: 41-42, 10-12: 40-42 — the row gathers are latency-bound, more waves keep more of them in flight).
+    blocks_per_cu = nb > 8 ? 8 : nb > 0 ? nb : 1;
     if (const char* e = getenv("GFICF_JACCARD_BLOCKS_PER_CU")) {   // tuning knob
       const int v = atoi(e);
       if (v > 0) blocks_per_cu = v;
@@ -948,7 +1339,17 @@ int launch_edges_o(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
   const int64_t blocks_needed = gficf_ceil_div(ce - cb, C::WAVES);
   const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
   const unsigned grid = (unsigned)(blocks_needed < cap ? blocks_needed : cap);
-  hipLaunchKernelGGL((k_jaccard_edges<KPAD, BIG, CMP, OUT>), dim3(grid), dim3(C::WAVES * 64), edges_lds_bytes<KPAD>(), ctx->stream, table,
+  constexpr size_t lds_bytes = edges_lds_bytes<KPAD, CMP>();
+  static const bool no_pipe = getenv("GFICF_JACCARD_NO_PIPE") != nullptr;        // test hook: the one-cell-at-a-time kernel for every k
+  if constexpr (C::EPL == 1 && C::SPQ <= 4) {
+    if (!no_pipe) {
+      hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT>), dim3(grid), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
+                         N, k, cb, ce, o);
+      GFICF_HIP_CHECK(hipGetLastError());
+      return GFICF_OK;
+    }
+  }
+  hipLaunchKernelGGL((k_jaccard_edges<KPAD, BIG, CMP, OUT>), dim3(grid), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
                      N, k, cb, ce, o);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
