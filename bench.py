@@ -65,6 +65,13 @@ def parse():
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline line only (no stress / host ABI / GF-ICF / kNN sub-objects)")
     ap.add_argument("--pipeline", action="store_true", help="also report the software-pipelined mode (steps overlapped on side streams)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="rehearsal of the N > 1 code path on a one-GPU box: every rank uses device 0 and the gloo backend (numbers are meaningless)")
+    ap.add_argument("--ids", choices=["permuted", "spatial"], default="permuted",
+                    help="permuted: ids relabelled by a random permutation (what Annoy output looks like; the default); "
+                         "spatial: cells numbered in their spatial order (what the device kNN search's pivot order gives)")
+    ap.add_argument("--exchange", choices=["allgather", "halo"], default="allgather",
+                    help="N > 1: all-gather of every rank's table rows, or the halo form (only the rows a block names)")
     return ap.parse_args()
 
 
@@ -261,9 +268,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (gficf_amd has no CPU fallback)")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     strong = args.config in CONFIGS
@@ -282,11 +294,11 @@ def main():
     n_local = e - b
     mats, idx_local, shards = [], [], []
     for d in range(batch):
-        m = synth.knn_windowed(N_total, k, seed=42 + 7 * d, perm_seed=43 + 7 * d)   # N_total x k, 1-based ids (same on every rank)
+        m = synth.knn_windowed(N_total, k, seed=42 + 7 * d, perm_seed=(43 + 7 * d) if args.ids == "permuted" else None)   # N_total x k, 1-based ids (same on every rank)
         if d == 0:
             mats.append(m)                                              # kept for the oracle check / CPU baseline
         idx_local.append(torch.from_numpy(np.ascontiguousarray(m[b:e].T)).to(dev))   # (k, n_local) == column-major block
-        shards.append(JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=False))
+        shards.append(JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=False, exchange=args.exchange))
         del m
     mat = mats[0]
 
@@ -375,7 +387,7 @@ def main():
         "metric": "jaccard_edges_per_sec", "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": wl + f", windowed kNN (W=100) with permuted ids; per data set: ingest + {'RCCL all-gather + ' if world > 1 else ''}"
+        "config": {"workload": wl + f", windowed kNN (W=100) with {args.ids} ids; per data set: ingest + {'RCCL all-gather + ' if world > 1 else ''}"
                                "edge kernel, device-resident, one stream, in order (no overlap between data sets or steps)",
                    "cells_total": N_total, "k": k, "data_sets_per_step": batch, "edges_per_step": edges_per_step,
                    "partition": f"cell blocks x{world}" + (", 1 all-gather of table rows per data set" if world > 1 else "")},
@@ -386,8 +398,10 @@ def main():
     if world > 1:
         sh0 = shards[0]
         row_b = 4 * (sh0.pw if sh0.packed is not None else sh0.row_words)
-        out["exchange"] = {"bytes_received_per_rank_per_data_set": int((N_total - n_local) * row_b), "row_bytes_on_the_wire": row_b,
-                           "form": "all-gather of table rows" + (" (bit-packed)" if sh0.packed is not None else "")}
+        out["exchange"] = {"bytes_received_per_rank_per_data_set": int(sh0.bytes_received), "rows_received_per_rank_per_data_set": int(sh0.rows_received),
+                           "row_bytes_on_the_wire": row_b, "ids": args.ids,
+                           "form": ("halo: unique-id request lists + the named rows, two all-to-alls" if args.exchange == "halo" else
+                                    "all-gather of table rows" + (" (bit-packed)" if sh0.packed is not None else ""))}
 
     if args.pipeline:
         # the overlapped mode (not `value`): ingest / exchange of data set d+1 on a side stream under the edge kernel of d

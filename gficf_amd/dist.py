@@ -98,6 +98,16 @@ def _all_gather_rows(table, local_view, group):
         dist.all_gather(chunks, local_view.reshape(-1).clone(), group=group)
 
 
+def _all_to_all(out, inp, out_split, in_split, group):
+    """all_to_all_single; device tensors under the gloo backend (test set-ups: ranks sharing one GPU) go through the host."""
+    if out.is_cuda and dist.get_backend(group) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+
+
 class JaccardShard:
     """Per-rank state of the sharded Jaccard build (buffers allocated once, reused per step).
 
@@ -114,7 +124,13 @@ class JaccardShard:
     """
 
     def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False,
-                 pipeline: bool = False, packed_transport: bool = True, time_edges: bool = False):
+                 pipeline: bool = False, packed_transport: bool = True, time_edges: bool = False,
+                 exchange: str = "allgather"):
+        if exchange not in ("allgather", "halo"):
+            raise ValueError("exchange must be 'allgather' or 'halo'")
+        self.exchange = exchange
+        self.bytes_received = 0                 # table-row bytes this rank received in the last step (both forms)
+        self.rows_received = 0
         self.ops, self.N, self.k, self.group = ops, int(N_total), int(k), group
         self.time_edges = bool(time_edges)      # HIP events around every edge-kernel launch, on its launch stream
         self.edge_events = []
@@ -135,7 +151,7 @@ class JaccardShard:
         self.t = 0
         # N > 1: rows travel bit-packed (ceil(log2(N+1)) bits per id) and are unpacked after the all-gather
         self.packed = None
-        if self.world > 1 and packed_transport:
+        if self.world > 1 and packed_transport and exchange == "allgather":
             self.pw = ops.packed_words(self.N, self.k)
             if self.pw < self.row_words:                     # (compact rows of a small data set may already be as short)
                 self.packed = torch.zeros((self.world * self.rpr, self.pw), dtype=torch.int32, device=device)
@@ -148,8 +164,44 @@ class JaccardShard:
             self.last_done = None
             self.last_p = None
 
-    def _fill_table(self, table, idx_local_cm):
+    def _fill_table_halo(self, table, idx_local_cm):
+        """Exchange form for inputs whose ids have locality (cells numbered in a spatial order — e.g. the pivot order of
+        the device kNN search): a rank fetches only the remote rows its own block names.  Request lists (sorted unique ids
+        per owner) go out in one all-to-all, the rows come back in a second; the split sizes need one host round trip.
+        With scrambled ids nearly every row is named and the all-gather is the better form (same result either way)."""
         my_rows = table[self.rank * self.rpr:(self.rank + 1) * self.rpr]
+        if self.n_local > 0:
+            self.ops.jaccard_ingest(idx_local_cm, self.n_local, self.k, self.N, my_rows)
+        if self.world == 1:
+            return
+        ids = idx_local_cm.reshape(-1)
+        if ids.dtype != torch.int64:
+            ids = ids.to(torch.int64)
+        ids = ids[(ids >= 1) & (ids <= self.N)]                         # (invalid ids are reported by the ingest)
+        need = torch.unique(ids[(ids <= self.b) | (ids > self.e)])      # sorted: grouped by owner, ascending
+        owner = torch.div(need - 1, self.rpr, rounding_mode="floor")
+        send_counts = torch.bincount(owner, minlength=self.world).to(torch.int64)
+        recv_counts = torch.empty_like(send_counts)
+        _all_to_all(recv_counts, send_counts, None, None, self.group)
+        sc, rc = send_counts.tolist(), recv_counts.tolist()             # the one host round trip
+        req_in = torch.empty(sum(rc), dtype=torch.int64, device=need.device)
+        _all_to_all(req_in, need, rc, sc, self.group)
+        rw = table.shape[1]
+        rows_out = table.index_select(0, req_in - 1).contiguous()       # the requested rows of my block
+        rows_in = torch.empty((len(need), rw), dtype=table.dtype, device=table.device)
+        _all_to_all(rows_in.view(-1), rows_out.view(-1), [c * rw for c in sc], [c * rw for c in rc], self.group)
+        table.index_copy_(0, need - 1, rows_in)
+        self.rows_received = int(len(need))
+        self.bytes_received = int(len(need)) * rw * 4 + sum(rc) * 8
+
+    def _fill_table(self, table, idx_local_cm):
+        if self.exchange == "halo":
+            return self._fill_table_halo(table, idx_local_cm)
+        my_rows = table[self.rank * self.rpr:(self.rank + 1) * self.rpr]
+        if self.world > 1:
+            wire = self.pw if self.packed is not None else self.row_words
+            self.rows_received = self.N - self.n_local
+            self.bytes_received = self.rows_received * wire * 4
         if self.n_local > 0:
             self.ops.jaccard_ingest(idx_local_cm, self.n_local, self.k, self.N, my_rows)
         if self.world > 1 and self.packed is not None:

@@ -62,12 +62,41 @@ class CpuOpsDouble:
             rows[r, 0] |= ((acc >> (k * bits)) & 1) << 31
 
     def jaccard_edges(self, table, N, k, cell_begin, cell_end, out3, u=None):
-        mat = table.numpy()[:N, :k]
-        rm, uu = oracle.jaccard(np.ascontiguousarray(mat), nthreads=2)
-        sl = slice(cell_begin * k, cell_end * k)
-        out3.copy_(torch.from_numpy(np.ascontiguousarray(rm[sl].T)))
+        # only the rows the block names are read (after a halo exchange the others are not filled): the oracle on the
+        # sub-matrix of those rows, ids relabelled to its row numbers (a bijection: intersection counts are unchanged)
+        tab = table.numpy()[:N, :k].astype(np.int64)
+        rows = tab[cell_begin:cell_end]
+        used = np.unique(np.concatenate([np.arange(cell_begin + 1, cell_end + 1), rows.reshape(-1)]))
+        assert used.min() >= 1, "a named row was not fetched"
+        sub = tab[used - 1]
+        ids = np.unique(sub.reshape(-1))
+        assert ids.min() >= 1, "a named row was not fetched"
+        # ids that are not rows of the sub-matrix get fresh row numbers beyond it (they are never dereferenced by the rows we keep)
+        label = {int(v): i + 1 for i, v in enumerate(used)}
+        nxt = len(used) + 1
+        for v in ids:
+            if int(v) not in label:
+                label[int(v)] = nxt
+                nxt += 1
+        lut = np.zeros(int(ids.max()) + 1, dtype=np.int64)
+        for v, l in label.items():
+            if v < len(lut):
+                lut[v] = l
+        rel = lut[sub]
+        pad = np.tile(np.arange(1, k + 1, dtype=np.int64), (nxt - 1 - len(used), 1)) if nxt - 1 > len(used) else np.zeros((0, k), np.int64)
+        full = np.concatenate([rel, pad]).astype(np.int32)
+        rm, uu = oracle.jaccard(np.ascontiguousarray(full), nthreads=2)
+        pos = np.searchsorted(used, np.arange(cell_begin + 1, cell_end + 1))
+        sel = (pos[:, None] * k + np.arange(k)[None, :]).reshape(-1)
+        uu = uu[sel]
+        src = np.repeat(np.arange(cell_begin + 1, cell_end + 1, dtype=np.float64), k)
+        dst = rows.reshape(-1).astype(np.float64)
+        w = uu / (2.0 * k - uu)
+        posm = uu > 0
+        out = np.stack([np.where(posm, src, 0.0), np.where(posm, dst, 0.0), np.where(posm, w, 0.0)])
+        out3.copy_(torch.from_numpy(out))
         if u is not None:
-            u.copy_(torch.from_numpy(uu[sl]))
+            u.copy_(torch.from_numpy(uu.astype(np.int32)))
 
     # ---- GF-ICF
     def csc_count(self, G, n_cells, colptr, rowidx, x, nt):

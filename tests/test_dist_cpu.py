@@ -149,3 +149,52 @@ def test_nnz_balanced_column_blocks():
     assert shard_bounds_by_nnz([0], 4) == [(0, 0)] * 4
     assert shard_bounds_by_nnz([0, 5], 3)[-1][1] == 1 and sum(e - b for b, e in shard_bounds_by_nnz([0, 5], 3)) == 1
     assert sum(e - b for b, e in shard_bounds_by_nnz([0, 0, 0, 9, 9], 2)) == 4
+
+
+def _halo_worker(rank, world, port, N, k, perm, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpu_ops_double import CpuOpsDouble
+        from gficf_amd import synth
+        from gficf_amd.dist import JaccardShard, shard_bounds
+
+        ops = CpuOpsDouble()
+        mat = synth.knn_windowed(N, k, seed=5, perm_seed=43 if perm else None)
+        b, e = shard_bounds(N, world, rank)
+        idx_local = torch.from_numpy(np.ascontiguousarray(mat[b:e].T))
+        res = {}
+        for form in ("allgather", "halo"):
+            sh = JaccardShard(ops, N, k, with_u=True, exchange=form)
+            out = sh.step(idx_local).clone()
+            res[form] = (out, sh.u.clone(), sh.rows_received, sh.bytes_received)
+        assert torch.equal(res["halo"][0], res["allgather"][0]) and torch.equal(res["halo"][1], res["allgather"][1])
+        np.save(os.path.join(outdir, f"halo_{rank}.npy"), res["halo"][0].numpy())
+        np.save(os.path.join(outdir, f"halo_rows_{rank}.npy"), np.array([res["halo"][2], res["allgather"][2], res["halo"][3], res["allgather"][3]]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("perm", [False, True])
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_matches_allgather_gloo(tmp_path, perm, world):
+    """The halo form of the exchange (a rank fetches only the remote rows its block names) gives the bits of the
+    all-gather form and of the oracle — on spatially ordered ids, where it moves a few hundred rows instead of the other
+    ranks' whole blocks, and on scrambled ids, where it moves nearly all of them."""
+    import oracle
+    from gficf_amd import synth
+
+    N, k = 1501, 15
+    mp.spawn(_halo_worker, args=(world, _free_port(), N, k, perm, str(tmp_path)), nprocs=world, join=True)
+    mat = synth.knn_windowed(N, k, seed=5, perm_seed=43 if perm else None)
+    want, _ = oracle.jaccard(mat, nthreads=2)
+    got = np.concatenate([np.load(tmp_path / f"halo_{r}.npy") for r in range(world)], axis=1).T
+    assert np.array_equal(got, want)
+    for r in range(world):
+        halo_rows, ag_rows, halo_bytes, ag_bytes = np.load(tmp_path / f"halo_rows_{r}.npy")
+        assert ag_rows == N - len(range(*__import__("gficf_amd.dist", fromlist=["shard_bounds"]).shard_bounds(N, world, r)))
+        if perm:
+            assert 0.8 * ag_rows <= halo_rows <= ag_rows           # scrambled ids: (nearly) every remote row is named
+        else:
+            assert halo_rows <= 2 * 2 * 100 and halo_rows < 0.5 * ag_rows    # ordered ids: the window either side of the block's two seams

@@ -53,6 +53,15 @@ def _worker(rank, world, port, outdir):
         torch.cuda.synchronize()
         for n, (i, r) in enumerate(res):
             np.save(os.path.join(outdir, f"j_{rank}_{n}.npy"), r.cpu().numpy())
+        # the halo form of the exchange (only the rows the block names) on device tables, ordered ids: same bits as the all-gather form
+        mo = synth.knn_windowed(N, k, seed=9, perm_seed=None)
+        io = torch.from_numpy(np.ascontiguousarray(mo[b:e].T)).cuda()
+        sa = JaccardShard(ops, N, k, device="cuda", exchange="allgather")
+        shh = JaccardShard(ops, N, k, device="cuda", exchange="halo")
+        oa, oh = sa.step(io).clone(), shh.step(io).clone()
+        ops.sync()
+        assert torch.equal(oa, oh) and 0 < shh.rows_received < 500 < sa.rows_received
+        np.save(os.path.join(outdir, f"halo_{rank}.npy"), oh.cpu().numpy())
         # exact kNN sharded by the same cell blocks, its index block chained into a sharded Jaccard build
         from gficf_amd.dist import KnnShard
 
@@ -94,6 +103,8 @@ def test_two_ranks_one_gpu_full_sharded_path(tmp_path):
     for n in range(6):
         got = np.concatenate([np.load(tmp_path / f"j_{r}_{n}.npy") for r in range(world)], axis=1).T
         assert np.array_equal(got, want[n % 3]), n
+    hwant = oracle.jaccard(synth.knn_windowed(N, k, seed=9, perm_seed=None), nthreads=8)[0]
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"halo_{r}.npy") for r in range(world)], axis=1).T, hwant)
     Nk, dk, kk = 5003, 50, 16
     X = np.random.default_rng(23).normal(size=(Nk, dk)) * np.linspace(0.5, 3.0, dk)
     widx, _ = oracle.knn(X, kk, "manhattan", nthreads=8)

@@ -14,7 +14,7 @@ for rep in range(3):
     check(L.gficf_normalize_csc_host_plan(ctx.handle, G, N, _np_ptr(cp64), 1, _np_ptr(ri), _np_ptr(x), 0.05, 1.0, None, ctypes.byref(gk), ctypes.byref(nk)))
     t1 = time.perf_counter()
     keep = np.zeros(G, np.uint8); nt = np.zeros(G, np.int64); w = np.zeros(G); ocp = np.zeros(N + 1, np.int64)
-    ori = np.zeros(nk.value, np.int32); ox = np.zeros(nk.value)
+    ori = np.empty(nk.value, np.int32); ox = np.empty(nk.value)
     t2 = time.perf_counter()
     check(L.gficf_normalize_csc_host_finish(ctx.handle, _np_ptr(keep), _np_ptr(nt), _np_ptr(w), _np_ptr(ocp), _np_ptr(ori), _np_ptr(ox)))
     t3 = time.perf_counter()
