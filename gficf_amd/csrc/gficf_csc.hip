@@ -442,8 +442,10 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
 // reads instead of L2 requests (the global-gather variant above issues one L2 request per
 // entry).  A lane keeps x and the new row id of its entries in registers (3 VGPRs per entry), the
 // weight is read from LDS when it is needed.  Same arithmetic and order of operations.
-constexpr int SL_THREADS = 1024;
-constexpr int SL_CH = 24;                         // chunks of 64 entries a wave keeps in registers
+// 896 threads and 28 register chunks (1792 entries per wave without re-reading): measured against 1024 / 24, 768 / 36, 640 / 40
+// and 512 / 48 at config 3's shape (profiles/r02_gficf_scale_ab.txt): the whole pass 0.451 -> 0.427 ms.
+constexpr int SL_THREADS = 896;
+constexpr int SL_CH = 28;                         // chunks of 64 entries a wave keeps in registers
 constexpr int SL_LB = 8;                          // chunks per batch on the long-cell path
 __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64_t n_cells,
                                                                 const int64_t* __restrict__ colptr,
