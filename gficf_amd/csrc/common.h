@@ -16,7 +16,7 @@ constexpr uint32_t GFICF_ST_BAD_VALUE = 4u; // non-finite coordinate handed to t
 constexpr uint32_t GFICF_ST_TOO_DENSE = 8u; // Louvain: a vertex touches more communities than its table holds
 constexpr uint32_t GFICF_ST_EXPLICIT_ZERO = 16u; // gficf_csc_device met an explicitly stored zero (its fast count is then not exact)
 
-constexpr int GFICF_POOL_SLOTS = 8;
+constexpr int GFICF_POOL_SLOTS = 9;
 
 struct gficf_host_plan;  // gficf_csc.hip
 struct gficf_edge_plan;  // jaccard.hip
@@ -31,11 +31,9 @@ struct gficf_ctx {
   void* d_ws = nullptr;           // scan ticket + tile descriptors (fixed size, allocated and zeroed at create)
   uint32_t scan_epoch = 0;        // tag of the current scan launch's descriptors (22 bits, never 0)
   size_t ws_bytes = 0;
-  // cur_gate: kernels launched while it is set return at once unless *cur_gate != 0 (not used by any entry at present).
   // cur_zero: when set, the scaling pass ORs GFICF_ST_EXPLICIT_ZERO into it on meeting an explicitly stored zero
   // (gficf_csc_device points it at d_status: the violation surfaces at the next gficf_ctx_sync).
   uint32_t* d_flags = nullptr;
-  const uint32_t* cur_gate = nullptr;
   uint32_t* cur_zero = nullptr;
   // options of the GF-ICF chain that the reference's internal helpers take (gficf() itself always uses the defaults):
   // getIdfW(type = classic / prob / smooth) R/gficf.R:89-91, l.norm(norm = l2 / l1) R/gficf.R:100
@@ -49,7 +47,8 @@ struct gficf_ctx {
   gficf_adj_plan* adj_plan = nullptr;
   // grow-only device scratch of the host entry points (kept between calls, released at destroy or by
   // gficf_ctx_trim): slots 0-3 scratch of one-call entries, 4 GF-ICF host plan, 5 filtered-edge plan,
-  // 6 adjacency plan, 7 outputs of the GF-ICF finish call.  No host entry allocates device memory per call.
+  // 6 adjacency plan, 7 outputs of the GF-ICF finish call, 8 per-workgroup partial histograms of the GF-ICF count pass
+  // (the one scratch a device entry draws from the pool).  No host entry allocates device memory per call.
   void* pool[GFICF_POOL_SLOTS] = {};
   size_t pool_bytes[GFICF_POOL_SLOTS] = {};
   // print hook (R glue: Rprintf); NULL = stdout
@@ -112,10 +111,6 @@ void gficf_set_error(const char* fmt, ...);
     if (!(ctx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ctx is NULL");    \
     GFICF_HIP_CHECK(hipSetDevice((ctx)->device));                    \
   } while (0)
-
-// first statement of a gated kernel
-#define GFICF_GATE(gate) \
-  if ((gate) != nullptr && *(gate) == 0u) return
 
 __host__ __device__ static inline int64_t gficf_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -247,9 +247,7 @@ __device__ inline unsigned long long scan_desc(uint32_t epoch, uint32_t status, 
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(int64_t* __restrict__ d, int64_t n, unsigned long long* ws,
-                                                                uint32_t epoch, uint32_t* __restrict__ status,
-                                                                const uint32_t* gate) {
-  GFICF_GATE(gate);
+                                                                uint32_t epoch, uint32_t* __restrict__ status) {
   __shared__ unsigned long long s_tile;
   __shared__ int64_t s_prefix;
   if (threadIdx.x == 0) s_tile = atomicAdd(&ws[0], 1ull);
@@ -305,7 +303,7 @@ int gficf_exclusive_scan_i64(gficf_ctx* ctx, int64_t* d_data, int64_t n) {
     ctx->scan_epoch = 1;
   }
   hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_data, n, (unsigned long long*)ctx->d_ws,
-                     ctx->scan_epoch, ctx->d_status, ctx->cur_gate);
+                     ctx->scan_epoch, ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }

@@ -21,12 +21,13 @@ namespace {
 
 // ------------------------------------------------------------------ pass A: nt_g counts
 // nt_g = #{cells c : x[g,c] != 0}  (explicitly stored zeros do not count, as in
-// rowSums(M != 0)).  Per-workgroup histogram in LDS (G counters), flushed with one global
-// atomic per touched gene; falls back to global atomics when G does not fit LDS.
+// rowSums(M != 0)).  Per-workgroup histogram in LDS (G counters), written out as one row of a
+// workgroups x G table of partial counts that k_nt_sum adds up (round 1 flushed with one global
+// atomic per touched gene: 5.9 M memory-side atomics = 21 of the pass's 69 us at config 3);
+// falls back to global atomics per entry when G does not fit LDS.
 // Each workgroup sweeps one contiguous slab; a thread takes 4 consecutive entries per load
 // (16 B of rowidx, 2 x 16 B of x) and keeps two such groups in flight.
 constexpr int CNT_THREADS = 1024;
-constexpr int GATED_BLOCKS = 32;            // grid cap of launches that normally return at once (see launch_count)
 constexpr int CNT_LDS_MAX_G = 36 * 1024;   // 144 KiB of uint32 counters
 
 template <bool USE_LDS>
@@ -40,15 +41,15 @@ __device__ inline void count_one(int32_t g, double v, int64_t G, uint32_t* hist,
 
 // HAS_X == false counts every stored entry (4 B/nnz): exact whenever the matrix stores no explicit
 // zeros, which the scaling pass verifies for free (it reads x anyway) — see gficf_csc_device.
-template <bool USE_LDS, bool VEC, bool HAS_X, bool NARROW = true>
+template <bool USE_LDS, bool VEC, bool HAS_X>
 __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __restrict__ rowidx,
                                                             const double* __restrict__ x, int64_t nnz, int64_t G,
                                                             unsigned long long* __restrict__ nt,
-                                                            uint32_t* __restrict__ status, const uint32_t* gate) {
-  GFICF_GATE(gate);
+                                                            uint32_t* __restrict__ part, uint32_t* __restrict__ status) {
   extern __shared__ uint32_t s_hist[];
+  const int64_t Gp = (G + 3) & ~(int64_t)3;                  // row pitch of the partial table (16 B rows)
   if (USE_LDS) {
-    for (int64_t g = threadIdx.x; g < G; g += CNT_THREADS) s_hist[g] = 0;
+    for (int64_t g = threadIdx.x; g < Gp; g += CNT_THREADS) s_hist[g] = 0;
     __syncthreads();
   }
   bool bad = false;
@@ -85,21 +86,35 @@ __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __res
   if (bad) atomicOr(status, GFICF_ST_BAD_CSC);
   if (USE_LDS) {
     __syncthreads();
-    // every workgroup starts its flush at another gene: all of them finish streaming at about the same time, and in
-    // step they would put gridDim.x atomics on the same address at once while the other L2 channels idle
-    const int64_t rot = (int64_t)blockIdx.x * (G / gridDim.x + 1);
-    for (int64_t t = threadIdx.x; t < G; t += CNT_THREADS) {
-      int64_t g = t + rot;
-      if (g >= G) g -= G;
-      if (g >= G) g %= G;
-      const uint32_t c = s_hist[g];
-      // the flush is bound by the memory-side atomic rate in BYTES (5.9 M adds at config 3): the counters are 64-bit, the
-      // add is done on their low words (little endian; a count never reaches 2^32: cells carry int32 ids) — half the bytes
-      if (c) {
-        if (NARROW) atomicAdd(reinterpret_cast<uint32_t*>(&nt[g]), c);
-        else atomicAdd(&nt[g], (unsigned long long)c);
-      }
-    }
+    // this workgroup's row of the partial table, 16 B per lane, plain stores (k_nt_sum reads it next)
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    v4u* const dst = reinterpret_cast<v4u*>(part + (int64_t)blockIdx.x * Gp);
+    const v4u* const src = reinterpret_cast<const v4u*>(s_hist);
+    for (int64_t t = threadIdx.x; t < Gp / 4; t += CNT_THREADS) dst[t] = src[t];
+  }
+}
+
+// nt[g] += sum over the partial rows.  A workgroup takes 64 genes: wave w adds rows w, w + 16, ... (coalesced 256 B runs,
+// all loads of a thread independent), the 16 partial sums meet in LDS.  One writer per gene: no atomics.
+constexpr int NS_WAVES = 16;
+
+__global__ __launch_bounds__(NS_WAVES * 64) void k_nt_sum(const uint32_t* __restrict__ part, int64_t Gp, int rows, int64_t G,
+                                                          unsigned long long* __restrict__ nt) {
+  __shared__ uint32_t s_acc[NS_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t g = (int64_t)blockIdx.x * 64 + lane;
+  uint32_t acc = 0;
+  if (g < G) {
+#pragma unroll 8
+    for (int r = wave; r < rows; r += NS_WAVES) acc += part[(int64_t)r * Gp + g];
+  }
+  s_acc[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && g < G) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < NS_WAVES; ++w) t += s_acc[w][lane];
+    if (t) nt[g] += t;
   }
 }
 
@@ -135,8 +150,7 @@ __global__ __launch_bounds__(GT_THREADS) void k_gene_table(int64_t G, int64_t N_
                                                            double prop_min, double prop_max,
                                                            const double* __restrict__ w_in, uint8_t* __restrict__ keep,
                                                            gficf_gene_entry* __restrict__ genes, double* __restrict__ w,
-                                                           int64_t* __restrict__ gkept, int icf_type, const uint32_t* gate) {
-  GFICF_GATE(gate);
+                                                           int64_t* __restrict__ gkept, int icf_type) {
   __shared__ int s_red[GT_THREADS / 64];
   __shared__ int s_wave_excl[GT_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,7 +158,8 @@ __global__ __launch_bounds__(GT_THREADS) void k_gene_table(int64_t G, int64_t N_
   const int64_t tile0 = (int64_t)blockIdx.x * GT_THREADS;
   // kept genes in front of this tile
   int before = 0;
-  for (int64_t g = tid; g < tile0; g += GT_THREADS) {
+#pragma unroll 8
+  for (int64_t g = tid; g < tile0; g += GT_THREADS) {          // independent loads: all in flight (was one at a time, 10 us)
     const double c = (double)nt[g];
     before += (c > lo && c <= hi) ? 1 : 0;
   }
@@ -199,9 +214,7 @@ __global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64
                                                                 const int32_t* __restrict__ rowidx,
                                                                 const uint8_t* __restrict__ keep,
                                                                 const int64_t* __restrict__ gkept,
-                                                                int64_t* __restrict__ out, uint32_t* __restrict__ status,
-                                                                const uint32_t* gate) {
-  GFICF_GATE(gate);
+                                                                int64_t* __restrict__ out, uint32_t* __restrict__ status) {
   extern __shared__ uint32_t s_bits[];      // ceil(G/32) words
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * CC_THREADS + threadIdx.x) >> 6;
@@ -301,9 +314,8 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
                                                             const int64_t* __restrict__ gkept_p,
                                                             const int64_t* __restrict__ out_colptr,
                                                             int32_t* __restrict__ out_rowidx,
-                                                            double* __restrict__ out_x, int norm_l1, const uint32_t* gate,
+                                                            double* __restrict__ out_x, int norm_l1,
                                                             uint32_t* zero_flag) {
-  GFICF_GATE(gate);
   __shared__ double s_sum[SC_WAVES];
   if (gkept_p && sl_fits(G, *gkept_p)) return;    // the LDS-resident variant handles this input
   bool saw_zero = false;                          // an explicitly stored zero (see gficf_csc_device)
@@ -455,9 +467,8 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
                                                                 const int64_t* __restrict__ gkept_p,
                                                                 const int64_t* __restrict__ out_colptr,
                                                                 int32_t* __restrict__ out_rowidx,
-                                                                double* __restrict__ out_x, int norm_l1, const uint32_t* gate,
+                                                                double* __restrict__ out_x, int norm_l1,
                                                                 uint32_t* zero_flag) {
-  GFICF_GATE(gate);
   extern __shared__ unsigned char s_raw[];
   bool saw_zero = false;                          // an explicitly stored zero (see gficf_csc_device)
   const int64_t gkept = *gkept_p;
@@ -606,8 +617,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
   if (zero_flag != nullptr && saw_zero) atomicOr(zero_flag, GFICF_ST_EXPLICIT_ZERO);
 }
 
-__global__ __launch_bounds__(256) void k_zero_i64(int64_t* __restrict__ p, int64_t n, const uint32_t* gate) {
-  GFICF_GATE(gate);
+__global__ __launch_bounds__(256) void k_zero_i64(int64_t* __restrict__ p, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0;
 }
@@ -726,9 +736,11 @@ static int launch_count(gficf_ctx* ctx, int64_t G, const int32_t* d_rowidx, cons
   const bool vec = (((uintptr_t)d_rowidx | (uintptr_t)d_x) & 15u) == 0;
   const bool lds_hist = G <= CNT_LDS_MAX_G;
   size_t lds = 0;
+  const int64_t Gp = (G + 3) & ~(int64_t)3;
+  uint32_t* d_part = nullptr;
   if (lds_hist) {
     // LDS histogram: G counters per workgroup; as many workgroups per CU as LDS allows
-    lds = (size_t)G * sizeof(uint32_t);
+    lds = (size_t)Gp * sizeof(uint32_t);
     int per_cu = (int)((160 * 1024) / (lds + 256));
     per_cu = per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu;
     if (blocks > (int64_t)ctx->num_cus * per_cu) blocks = (int64_t)ctx->num_cus * per_cu;
@@ -741,15 +753,13 @@ static int launch_count(gficf_ctx* ctx, int64_t G, const int32_t* d_rowidx, cons
       GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_gene_count<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       attr_set[ctx->device & 63] = true;
     }
+    GFICF_HIP_CHECK(gficf_pool_get(ctx, 8, sizeof(uint32_t) * (size_t)Gp * (size_t)blocks, (void**)&d_part));
   } else if (blocks > (int64_t)ctx->num_cus * 2) {
     blocks = (int64_t)ctx->num_cus * 2;
   }
-  // A gated launch (the exact re-run behind the explicit-zero flag, gficf_csc_device) returns at once in the common
-  // case, and an empty launch costs by its number of workgroups: give it a small grid (all kernels stride).
-  if (ctx->cur_gate && blocks > GATED_BLOCKS) blocks = GATED_BLOCKS;
 #define LAUNCH_CNT(L, V, X)                                                                                          \
   hipLaunchKernelGGL((k_gene_count<L, V, X>), dim3((unsigned)blocks), dim3(CNT_THREADS), lds, ctx->stream, d_rowidx, d_x, \
-                     nnz, G, (unsigned long long*)d_nt, ctx->d_status, ctx->cur_gate)
+                     nnz, G, (unsigned long long*)d_nt, d_part, ctx->d_status)
   const int sel = (lds_hist ? 4 : 0) | (vec ? 2 : 0) | (d_x ? 1 : 0);
   switch (sel) {
     case 7: LAUNCH_CNT(true, true, true); break;
@@ -762,6 +772,9 @@ static int launch_count(gficf_ctx* ctx, int64_t G, const int32_t* d_rowidx, cons
     default: LAUNCH_CNT(false, false, false); break;
   }
 #undef LAUNCH_CNT
+  if (lds_hist)
+    hipLaunchKernelGGL(k_nt_sum, dim3((unsigned)gficf_ceil_div(G, 64)), dim3(NS_WAVES * 64), 0, ctx->stream, d_part, Gp, (int)blocks, G,
+                       (unsigned long long*)d_nt);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -786,7 +799,7 @@ int gficf_csc_genes_device(gficf_ctx* ctx, int64_t G, int64_t N_total, const int
   if (!d_gkept || (G > 0 && (!d_nt || !d_keep || !d_genes || !d_w))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   const int64_t tiles = G > 0 ? gficf_ceil_div(G, GT_THREADS) : 1;
   hipLaunchKernelGGL(k_gene_table, dim3((unsigned)tiles), dim3(GT_THREADS), 0, ctx->stream, G, N_total, d_nt, prop_min, prop_max,
-                     d_w_in, d_keep, d_genes, d_w, d_gkept, ctx->icf_type, ctx->cur_gate);
+                     d_w_in, d_keep, d_genes, d_w, d_gkept, ctx->icf_type);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -799,11 +812,10 @@ int gficf_csc_colptr_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const in
   if (!d_colptr || !d_out_colptr || !d_gkept || !d_keep) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   int64_t blocks = gficf_ceil_div(n_cells > 0 ? n_cells : 1, CC_THREADS / 64);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
-  if (ctx->cur_gate && blocks > GATED_BLOCKS) blocks = GATED_BLOCKS;
   const size_t lds = (size_t)((G + 31) / 32) * sizeof(uint32_t);     // G <= 2^31 -> at most 256 MiB: checked below
   if (lds > 64 * 1024) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "G = %lld too large for the LDS keep bitmask", (long long)G);
   hipLaunchKernelGGL(k_cell_kept_count, dim3((unsigned)blocks), dim3(CC_THREADS), lds, ctx->stream, G, n_cells, d_colptr,
-                     d_rowidx, d_keep, d_gkept, d_out_colptr, ctx->d_status, ctx->cur_gate);
+                     d_rowidx, d_keep, d_gkept, d_out_colptr, ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
   return gficf_exclusive_scan_i64(ctx, d_out_colptr, n_cells + 1);
 }
@@ -828,16 +840,18 @@ int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
     }
     int64_t blocks = gficf_ceil_div(n_cells, SL_THREADS / 64);
     if (blocks > ctx->num_cus) blocks = ctx->num_cus;
-    if (ctx->cur_gate && blocks > GATED_BLOCKS) blocks = GATED_BLOCKS;
     hipLaunchKernelGGL(k_scale_cells_lds, dim3((unsigned)blocks), dim3(SL_THREADS), SL_LDS_BYTES, ctx->stream, G, n_cells,
-                       d_colptr, d_rowidx, d_x, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x, ctx->norm_l1, ctx->cur_gate, ctx->cur_zero);
+                       d_colptr, d_rowidx, d_x, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x, ctx->norm_l1, ctx->cur_zero);
+  }
+  if (try_lds && sl_fits(G, G)) {                           // every possible number of kept genes fits: no second variant to offer
+    GFICF_HIP_CHECK(hipGetLastError());
+    return GFICF_OK;
   }
   int64_t blocks = n_cells;
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
-  if (ctx->cur_gate && blocks > GATED_BLOCKS) blocks = GATED_BLOCKS;
   hipLaunchKernelGGL(k_scale_cells, dim3((unsigned)blocks), dim3(SC_THREADS), 0, ctx->stream, G, n_cells, d_colptr,
                      d_rowidx, d_x, d_genes, try_lds ? d_gkept : (const int64_t*)nullptr, d_out_colptr, d_out_rowidx, d_out_x,
-                     ctx->norm_l1, ctx->cur_gate, ctx->cur_zero);
+                     ctx->norm_l1, ctx->cur_zero);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }

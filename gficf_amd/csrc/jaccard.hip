@@ -1064,6 +1064,10 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   // which would make the number of memory operations between two waits unknown to it).  Non-temporal (aux = 2): written
   // once, never re-read here.
   typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+#ifndef GFICF_EDGE_STORE_AUX
+#define GFICF_EDGE_STORE_AUX 2
+#endif
+  constexpr int EDGE_STORE_AUX = GFICF_EDGE_STORE_AUX;
   auto store_prev = [&]() {
     const int64_t pb = (prev_i - cell_begin) * (int64_t)k;          // scalar: first entry of the cell
     const bool pos = prev_u > 0;
@@ -1075,9 +1079,9 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
       const auto rs = __builtin_amdgcn_make_buffer_rsrc(o.src + pb, 0, k * 8, 0x00020000);
       const auto rd = __builtin_amdgcn_make_buffer_rsrc(o.dst + pb, 0, k * 8, 0x00020000);
       const auto rw = __builtin_amdgcn_make_buffer_rsrc(o.w + pb, 0, k * 8, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vs), rs, voff8, 0, 2);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vd), rd, voff8, 0, 2);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vw), rw, voff8, 0, 2);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vs), rs, voff8, 0, EDGE_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vd), rd, voff8, 0, EDGE_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vw), rw, voff8, 0, EDGE_STORE_AUX);
     }
     if (OUT == OUT_RMAT_U) {
       const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u + pb, 0, k * 4, 0x00020000);

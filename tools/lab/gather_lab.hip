@@ -37,9 +37,11 @@ __device__ inline v4u load16(const char* p) {
 }
 
 // ROWB: bytes per table row.  128: uint32 ids[32].  64: uint16 lo[30], uint32 hi (bit j = bit 16 of id j).
-template <int ROWB, int FLAV, bool STORES>
+// STORES: 0 none, 1 non-temporal, 2 plain.  fold: gathered row index & fold (0xffffffff: the real table; a smaller
+// power of two minus one keeps the gathers random but inside a table prefix that fits an L2)
+template <int ROWB, int FLAV, int STORES>
 __global__ __launch_bounds__(256) void k_model(const char* __restrict__ table, long N, int k, double* __restrict__ o_src,
-                                               double* __restrict__ o_dst, double* __restrict__ o_w) {
+                                               double* __restrict__ o_dst, double* __restrict__ o_w, uint32_t fold) {
   constexpr int LPR = ROWB / 16, RPS = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const long w0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((long)gridDim.x * 256) >> 6;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void k_model(const char* __restrict__ table, l
     for (int s = 0; s < 4; ++s) {
       if (s < steps) {
         const uint32_t dst = (uint32_t)__shfl((int)asafe, s * RPS + grow);
-        bv[s] = load16<FLAV>(table + (size_t)(dst - 1) * ROWB + gcol);
+        bv[s] = load16<FLAV>(table + (size_t)((dst - 1) & fold) * ROWB + gcol);
       }
     }
 #pragma unroll
@@ -82,13 +84,81 @@ __global__ __launch_bounds__(256) void k_model(const char* __restrict__ table, l
         u = (lane / RPS == s) ? v : u;
       }
     }
-    if (STORES && lane < k) {
+    if (STORES == 1 && lane < k) {
       const long r = i * k + lane;
       __builtin_nontemporal_store((double)(uint32_t)(i + 1), o_src + r);
       __builtin_nontemporal_store((double)a, o_dst + r);
       __builtin_nontemporal_store((double)(u & 0xffu), o_w + r);
     }
+    if (STORES == 2 && lane < k) {
+      const long r = i * k + lane;
+      o_src[r] = (double)(uint32_t)(i + 1);
+      o_dst[r] = (double)a;
+      o_w[r] = (double)(u & 0xffu);
+    }
     if (!STORES && u == 0xdeadbeefu) o_w[0] = 1.0;
+  }
+}
+
+
+// Range passes: the same model, but one launch gathers only the neighbour rows whose id lies in [lo, hi) (the other lanes of
+// the gather instruction are masked off and issue no request), so that the rows a launch touches fit an XCD's L2.  Partial
+// per-slot results travel between the passes in a byte plane (32 B per cell); the last pass adds them and writes the edges.
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(256) void k_model_range(const char* __restrict__ table, long N, int k, double* __restrict__ o_src,
+                                                     double* __restrict__ o_dst, double* __restrict__ o_w, uint8_t* __restrict__ plane,
+                                                     uint32_t lo, uint32_t hi) {
+  constexpr int ROWB = 64, LPR = ROWB / 16, RPS = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const long w0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((long)gridDim.x * 256) >> 6;
+  const int grow = lane / LPR;
+  const uint32_t gcol = (uint32_t)(lane % LPR) * 16u;
+  auto own = [&](long i) -> uint32_t {
+    if (lane >= k) return 0u;
+    const uint32_t lo16 = reinterpret_cast<const uint16_t*>(table + i * ROWB)[lane];
+    const uint32_t hi16 = reinterpret_cast<const uint32_t*>(table + i * ROWB)[15];
+    return lo16 | (((hi16 >> lane) & 1u) << 16);
+  };
+  long i = w0;
+  uint32_t a_next = i < N ? own(i) : 0u;
+  for (; i < N; i += nw) {
+    const uint32_t a = a_next;
+    const uint32_t asafe = a != 0 ? a : (uint32_t)(i + 1);
+    if (i + nw < N) a_next = own(i + nw);
+    uint32_t part = 0;
+    if (!FIRST && lane < k) part = plane[i * 32 + lane];
+    const int steps = (k + RPS - 1) / RPS;
+    uint32_t acc[4] = {0, 0, 0, 0};
+    v4u bv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bv[s] = v4u{0, 0, 0, 0};
+      if (s < steps) {
+        const uint32_t dst = (uint32_t)__shfl((int)asafe, s * RPS + grow) - 1u;
+        if (dst >= lo && dst < hi) bv[s] = load16<0>(table + (size_t)dst * ROWB + gcol);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < steps) acc[s] = bv[s].x ^ bv[s].y ^ bv[s].z ^ bv[s].w;
+    uint32_t u = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < steps) {
+        uint32_t x = acc[s];
+        for (int d = 1; d < LPR; d <<= 1) x ^= __shfl_xor((int)x, d);
+        const uint32_t v = (uint32_t)__shfl((int)x, (lane % RPS) * LPR);
+        u = (lane / RPS == s) ? v : u;
+      }
+    }
+    u = (u + part) & 0xffu;
+    if (!LAST && lane < k) plane[i * 32 + lane] = (uint8_t)u;
+    if (LAST && lane < k) {
+      const long r = i * k + lane;
+      __builtin_nontemporal_store((double)(uint32_t)(i + 1), o_src + r);
+      __builtin_nontemporal_store((double)a, o_dst + r);
+      __builtin_nontemporal_store((double)u, o_w + r);
+    }
   }
 }
 
@@ -176,12 +246,12 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(t64, h64.data(), N * 64, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_idx_cm, cm.data(), E * 4, hipMemcpyHostToDevice));
     printf("---- ids: %s\n", mode_name[mode]);
-    auto run = [&](const char* name, auto kern, const char* table, int grid) {
+    auto run = [&](const char* name, auto kern, const char* table, int grid, uint32_t fold = 0xffffffffu) {
       float best = 1e9, sum = 0;
       const int reps = 20;
       for (int rep = 0; rep < reps + 3; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, table, N, k, s, d, w);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, table, N, k, s, d, w, fold);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep >= 3) { best = std::min(best, ms); sum += ms; }
@@ -191,14 +261,51 @@ int main(int argc, char** argv) {
     for (int bpc : {3, 6, 8}) {
       if (product_only) break;
       const int grid = cus * bpc;
-      run("128 B rows, plain loads, stores", k_model<128, 0, true>, t128, grid);
-      run("128 B rows, nt loads, stores", k_model<128, 1, true>, t128, grid);
-      run("128 B rows, plain loads, no stores", k_model<128, 0, false>, t128, grid);
-      run(" 64 B rows, plain loads, stores", k_model<64, 0, true>, t64, grid);
-      run(" 64 B rows, nt loads, stores", k_model<64, 1, true>, t64, grid);
-      run(" 64 B rows, plain loads, no stores", k_model<64, 0, false>, t64, grid);
+      run("128 B rows, plain loads, stores", k_model<128, 0, 1>, t128, grid);
+      run("128 B rows, nt loads, stores", k_model<128, 1, 1>, t128, grid);
+      run("128 B rows, plain loads, no stores", k_model<128, 0, 0>, t128, grid);
+      run(" 64 B rows, plain loads, stores", k_model<64, 0, 1>, t64, grid);
+      run(" 64 B rows, nt loads, stores", k_model<64, 1, 1>, t64, grid);
+      run(" 64 B rows, plain loads, no stores", k_model<64, 0, 0>, t64, grid);
     }
-    if (!product_only) run("128 B rows, sc1 loads (waited one by one)", k_model<128, 2, true>, t128, cus * 6);
+    if (!product_only) {
+      const int grid = cus * 8;
+      run(" 64 B rows, plain loads, PLAIN stores", k_model<64, 0, 2>, t64, grid);
+      run("128 B rows, plain loads, PLAIN stores", k_model<128, 0, 2>, t128, grid);
+      run(" 64 B rows, gathers folded into 4 MB", k_model<64, 0, 1>, t64, grid, 0xffffu);
+      run(" 64 B rows, gathers folded into 2 MB", k_model<64, 0, 1>, t64, grid, 0x7fffu);
+      run(" 64 B rows, gathers folded into 0.5 MB", k_model<64, 0, 1>, t64, grid, 0x1fffu);
+      run(" 64 B rows, folded into 2 MB, no stores", k_model<64, 0, 0>, t64, grid, 0x7fffu);
+      run(" 64 B rows, folded into 0.5 MB, no stores", k_model<64, 0, 0>, t64, grid, 0x1fffu);
+      run(" 64 B rows, folded into 16 KB, no stores", k_model<64, 0, 0>, t64, grid, 0xffu);
+    }
+
+    if (!product_only) {
+      uint8_t* plane;
+      CK(hipMalloc(&plane, N * 32));
+      for (int P : {1, 2, 3, 4}) {
+        const int grid = cus * 8;
+        float best = 1e9, sum = 0;
+        const int reps = 20;
+        for (int rep = 0; rep < reps + 3; ++rep) {
+          CK(hipEventRecord(e0));
+          for (int ps = 0; ps < P; ++ps) {
+            const uint32_t lo = (uint32_t)(N * ps / P), hi = (uint32_t)(N * (ps + 1) / P);
+            if (P == 1) hipLaunchKernelGGL((k_model_range<true, true>), dim3(grid), dim3(256), 0, 0, t64, N, k, s, d, w, plane, lo, hi);
+            else if (ps == 0) hipLaunchKernelGGL((k_model_range<true, false>), dim3(grid), dim3(256), 0, 0, t64, N, k, s, d, w, plane, lo, hi);
+            else if (ps == P - 1) hipLaunchKernelGGL((k_model_range<false, true>), dim3(grid), dim3(256), 0, 0, t64, N, k, s, d, w, plane, lo, hi);
+            else hipLaunchKernelGGL((k_model_range<false, false>), dim3(grid), dim3(256), 0, 0, t64, N, k, s, d, w, plane, lo, hi);
+          }
+          CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          if (rep >= 3) { best = std::min(best, ms); sum += ms; }
+        }
+        printf("   64 B rows, %d range pass(es), all launches   grid %5d: best %6.1f us  mean %6.1f us  %5.1f G edges/s\n", P, grid, best * 1e3, sum / reps * 1e3,
+               E / (best * 1e-3) / 1e9);
+      }
+      CK(hipFree(plane));
+    }
+    if (!product_only) run("128 B rows, sc1 loads (waited one by one)", k_model<128, 2, 1>, t128, cus * 6);
     // the product kernel on the same ids
     if (gficf_jaccard_ingest_device(ctx, d_idx_cm, 0, N, k, N, N, d_table) != 0) { printf("ingest: %s\n", gficf_last_error()); return 1; }
     float best = 1e9, sum = 0, besti = 1e9;
