@@ -369,7 +369,8 @@ def main():
             pmc = json.load(open(prof))
         except Exception:
             pmc = {}
-    traffic = pmc.get(f"jaccard_edges_N{N_total}_k{k}", {}).get("hbm_bytes_per_launch")
+    # the edge kernel of this shape is k_jaccard_edges_pipe (k <= 32) or k_jaccard_edges; make_traffic.py keys by kernel name
+    traffic = (pmc.get(f"jaccard_edges_pipe_N{N_total}_k{k}") or pmc.get(f"jaccard_edges_N{N_total}_k{k}") or {}).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "k_jaccard_edges", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_copy_rate": round(achieved / HBM_COPY_GBS, 4), "traffic": traffic,
                 "kernel_ms": round(t_edges_ms, 5), "kernel_ms_back_to_back": round(t_edges_b2b_ms, 5),
@@ -527,7 +528,7 @@ def main():
                                "achieved": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_PEAK_GBS, 4),
                                "frac_of_copy_rate": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_COPY_GBS, 4),
-                               "traffic": (sum(pmc[kk]["hbm_bytes_per_launch"] for kk in ("gene_count", "gene_table", "cell_kept_count", "scale_cells", "scale_cells_lds") if kk in pmc)
+                               "traffic": (sum(pmc[kk]["hbm_bytes_per_launch"] for kk in ("gene_count", "nt_sum", "gene_table", "cell_kept_count", "scan_lookback", "scale_cells", "scale_cells_lds") if kk in pmc)
                                            if all(kk in pmc for kk in ("gene_count", "cell_kept_count")) and nnz == 59809258 else None),
                                "scale_kernel_ms": round(t_scale, 4), "count_exact_kernel_ms": round(t_count, 4),
                                "count_note": "count_exact_kernel_ms is gficf_csc_count_device (reads x: 12 B/nnz), the form the sharded and host entries use; the timed pass (gficf_csc_device) counts stored entries without reading x (about half that time, see the rocprof summary)",
@@ -566,11 +567,18 @@ def main():
                 hcp, hri, hx = colptr.cpu().numpy(), rowidx.cpu().numpy(), x.cpu().numpy()
                 t1 = time.perf_counter()
                 ref = oracle.gficf_csc(G, Nc, hcp, hri, hx, 0.05, 1.0)
+                tc1 = time.perf_counter() - t1
+                cores = os.cpu_count() or 1
+                t1 = time.perf_counter()
+                ref_mt = oracle.gficf_csc(G, Nc, hcp, hri, hx, 0.05, 1.0, threads=cores)
                 tc = time.perf_counter() - t1
                 kn = int(ws["out_colptr"][Nc])
-                gf["cpu_baseline"] = {"value": Nc / tc, "unit": "cells/s", "cores": 1, "kind": "port",
-                                      "sample": "the full matrix, one pass of the oracle's single-threaded restatement of R/gficf.R "
-                                                "(the reference path is single-threaded R on the Matrix package and cannot run here)",
+                gf["cpu_baseline"] = {"value": Nc / tc, "unit": "cells/s", "cores": cores, "kind": "port",
+                                      "sample": "the full matrix, one pass of the oracle's multi-threaded restatement of R/gficf.R (cells cut into "
+                                                "ranges of equal stored entries, one host thread each; same bits as the single-threaded one)",
+                                      "single_thread_value": Nc / tc1,
+                                      "single_thread_note": "the reference path itself is single-threaded R on the Matrix package (cannot run here)",
+                                      "threads_give_same_bits": bool(np.array_equal(ref["x"], ref_mt["x"]) and np.array_equal(ref["nt"], ref_mt["nt"])),
                                       "gpu_over_cpu": (Nc / tg) / (Nc / tc)}
                 gf["checked_vs_oracle"] = bool(kn == len(ref["x"]) and np.array_equal(ws["out_rowidx"][:kn].cpu().numpy(), ref["rowidx"])
                                                and np.allclose(ws["out_x"][:kn].cpu().numpy(), ref["x"], rtol=1e-6, atol=1e-6))

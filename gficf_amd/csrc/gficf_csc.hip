@@ -15,6 +15,8 @@
 #include <cstring>
 #include <vector>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -744,7 +746,7 @@ static int launch_count(gficf_ctx* ctx, int64_t G, const int32_t* d_rowidx, cons
     int per_cu = (int)((160 * 1024) / (lds + 256));
     per_cu = per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu;
     if (blocks > (int64_t)ctx->num_cus * per_cu) blocks = (int64_t)ctx->num_cus * per_cu;
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     if (!attr_set[ctx->device & 63]) {
       const int mx = CNT_LDS_MAX_G * (int)sizeof(uint32_t);
       GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_gene_count<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
@@ -833,7 +835,7 @@ int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
   static const bool force_global = getenv("GFICF_SCALE_FORCE_GLOBAL") != nullptr;   // test hook
   const bool try_lds = sl_fits(G, 0) && !force_global;     // else not even the row ids fit LDS
   if (try_lds) {
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     if (!attr_set[ctx->device & 63]) {
       GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_scale_cells_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SL_LDS_BYTES));
       attr_set[ctx->device & 63] = true;
@@ -882,7 +884,7 @@ int gficf_cluster_signatures_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, 
     if (rc) return rc;
     hipLaunchKernelGGL(k_sig_fill, dim3((unsigned)gficf_ceil_div(n_cells, 256)), dim3(256), 0, ctx->stream, n_cells, d_cluster, C, start, cursor,
                        order);
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     if (!attr_set[ctx->device & 63]) {
       GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_sig_sum, hipFuncAttributeMaxDynamicSharedMemorySize, SIG_MAX_G * (int)sizeof(double)));
       attr_set[ctx->device & 63] = true;

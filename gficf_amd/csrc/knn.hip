@@ -38,6 +38,8 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -664,10 +666,13 @@ __global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, con
   if (lane == 0) s_red[wave] = rq;
   __syncthreads();
   rq = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-  auto to_key = [](float e, float slack_sign) {     // distance of the bound's metric -> key domain, pushed by the slack
+  // cosine / correlation keys are 1 - dot of unit vectors, a d-term f32 sum: its computed value is within d * 2^-24 of the
+  // exact one (sum |a_i b_i| <= 1), plus a few roundings of the normalisation; the absolute slack is twice that bound
+  const float key_abs_slack = (float)(d + 8) * 1.1920929e-7f;
+  auto to_key = [key_abs_slack](float e, float slack_sign) {     // distance of the bound's metric -> key domain, pushed by the slack
     if (METRIC == GFICF_KNN_MANHATTAN) return e;
     if (METRIC == GFICF_KNN_EUCLIDEAN) return e * e * (1.0f + slack_sign * KNN_LB_SLACK);
-    return 0.5f * e * e * (1.0f + slack_sign * KNN_LB_SLACK) + slack_sign * 4e-6f;
+    return 0.5f * e * e * (1.0f + slack_sign * KNN_LB_SLACK) + slack_sign * key_abs_slack;
   };
   // one thread per candidate tile: centre-to-centre distance; every query is within rq of the query centre and every
   // point of the tile within its radius of the tile centre, so  dist(q, x) >= dcc - rq - r  and  <= dcc + rq + r
@@ -823,7 +828,7 @@ template <int METRIC, int KL, bool PRUNE>
 int knn_launch(gficf_ctx* ctx, const KnnTileArgs& a) {
   const int64_t n_ct = gficf_ceil_div(a.N, KNN_TC);
   const size_t lds = (size_t)a.dpad * KNN_TQ * 4 + 2 * KNN_DK * KNN_TC * 4 + (KL > 64 ? (size_t)KNN_TQ * KL * 8 : 0) + (PRUNE ? (size_t)n_ct * 4 : 0);
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   if (!attr_set[ctx->device & 63]) {
     GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_knn_tiles<METRIC, KL, KNN_RQ, PRUNE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_set[ctx->device & 63] = true;

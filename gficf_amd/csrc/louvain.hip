@@ -45,6 +45,8 @@
 
 #include <vector>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -591,7 +593,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   if (N > INT32_MAX) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "more than 2^31 - 1 vertices");
   if (ws_bytes < gficf_louvain_workspace_bytes(N, nnz))
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "workspace too small: %zu < %zu bytes", ws_bytes, gficf_louvain_workspace_bytes(N, nnz));
-  static bool attr_set[64] = {};                 // per device: the attribute belongs to the device's copy of the kernel
+  static std::atomic<bool> attr_set[64];                 // per device: the attribute belongs to the device's copy of the kernel
   if (!attr_set[ctx->device & 63]) {
     GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_lv_move_big<LV_BIG_SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_BIG_SLOTS * 12));
     attr_set[ctx->device & 63] = true;

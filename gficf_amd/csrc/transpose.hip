@@ -17,6 +17,8 @@
 // Matrices with more than TR_GENES genes take ceil(G / TR_GENES) sweeps (gene ranges in grid.y).
 #include <vector>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -240,7 +242,7 @@ int gficf_csc_transpose_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const
   if (n_cells > INT32_MAX) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "more than 2^31 - 1 cells");
   const TrShape s = tr_shape(G, n_cells, nnz);
   const size_t lds = tr_lds_bytes(s);
-  static bool attr_set[64] = {};                 // per device: the attribute belongs to the device's copy of the kernel
+  static std::atomic<bool> attr_set[64];                 // per device: the attribute belongs to the device's copy of the kernel
   if (!attr_set[ctx->device & 63]) {
     const int mx = (int)((size_t)TR_GENES * 4 + (size_t)(TR_MAX_CPB + 1) * 8);   // 155 656 B of the CU's 160 KB
     GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_tr_count, hipFuncAttributeMaxDynamicSharedMemorySize, mx));

@@ -106,6 +106,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_gficf_csc.argtypes = [i64, i64, vp, vp, vp, dbl, dbl, vp] + [vp] * 8
         L.oracle_gficf_csc_ex.restype = i32
         L.oracle_gficf_csc_ex.argtypes = [i64, i64, vp, vp, vp, dbl, dbl, vp, i32, i32] + [vp] * 8
+        L.oracle_gficf_csc_mt.restype = i32
+        L.oracle_gficf_csc_mt.argtypes = [i64, i64, vp, vp, vp, dbl, dbl, vp, i32, i32, i32] + [vp] * 8
         L.oracle_knn.restype = i32
         L.oracle_knn.argtypes = [vp, i64, i32, i64, i32, i32, vp, vp, i32]
         L.oracle_knn_block.restype = i32
@@ -152,10 +154,11 @@ def jaccard_coeff(mat: np.ndarray) -> np.ndarray:
     return w.T
 
 
-def gficf_csc(G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None, icf_type="classic", norm="l2"):
+def gficf_csc(G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None, icf_type="classic", norm="l2", threads=1):
     """GF-ICF on a CSC genes x cells matrix (reference R/gficf.R:17-33, normalize=FALSE).
 
-    Returns dict(keep, nt, w, colptr, rowidx, x, G_kept).
+    ``threads > 1`` runs the multi-threaded restatement (cells cut into ranges; same sums in the same order, so the
+    same bits).  Returns dict(keep, nt, w, colptr, rowidx, x, G_kept).
     """
     colptr = np.ascontiguousarray(colptr, dtype=np.int64)
     rowidx = np.ascontiguousarray(rowidx, dtype=np.int32)
@@ -171,9 +174,10 @@ def gficf_csc(G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None, i
     nk = ctypes.c_int64(0)
     if w_in is not None:
         w_in = np.ascontiguousarray(w_in, dtype=np.float64)
-    rc = lib().oracle_gficf_csc_ex(
-        G, N, _p(colptr), _p(rowidx), _p(x), float(prop_min), float(prop_max), _p(w_in),
-        {"classic": 0, "prob": 1, "smooth": 2}[icf_type], {"l2": 0, "l1": 1}[norm],
+    opts = ({"classic": 0, "prob": 1, "smooth": 2}[icf_type], {"l2": 0, "l1": 1}[norm])
+    fn, extra = (lib().oracle_gficf_csc_mt, (int(threads),)) if threads > 1 else (lib().oracle_gficf_csc_ex, ())
+    rc = fn(
+        G, N, _p(colptr), _p(rowidx), _p(x), float(prop_min), float(prop_max), _p(w_in), *opts, *extra,
         _p(keep), _p(nt), _p(w), _p(ocp), _p(ori), _p(ox),
         ctypes.cast(ctypes.byref(gk), ctypes.c_void_p), ctypes.cast(ctypes.byref(nk), ctypes.c_void_p))
     if rc != 0:

@@ -31,8 +31,11 @@
 // kept entry of such a cell is written as 0.0.  Inputs are
 // expected to be non-negative counts.
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
+#include <thread>
 #include <vector>
 
 extern "C" {
@@ -119,6 +122,110 @@ int oracle_gficf_csc_ex(int64_t G, int64_t N, const int64_t* colptr, const int32
     if (std::isinf(nv)) nv = 0.0;                  // R/gficf.R:101
     for (int64_t t = out_colptr[c]; t < out_colptr[c + 1]; ++t) out_x[t] = nv * out_x[t];
   }
+  return 0;
+}
+
+// The same computation over several host threads (the CPU baseline SURVEY.md §8d asks for: R itself runs this path on one
+// thread; a multi-threaded restatement is the stronger host-side competitor).  Cells are cut into contiguous ranges, one
+// per thread; the per-gene counts are per-thread histograms added up afterwards (integers: order does not matter); every
+// per-cell sum runs in storage order exactly as in oracle_gficf_csc_ex, so the outputs are bit-identical to it.
+int oracle_gficf_csc_mt(int64_t G, int64_t N, const int64_t* colptr, const int32_t* rowidx,
+                        const double* x, double prop_min, double prop_max, const double* w_in, int icf_type, int norm_l1,
+                        int threads, uint8_t* keep, int64_t* nt, double* w, int64_t* out_colptr,
+                        int32_t* out_rowidx, double* out_x, int64_t* G_kept, int64_t* nnz_kept) {
+  if (G < 0 || N < 0 || colptr[0] != 0) return -1;
+  const int64_t nnz = colptr[N];
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, std::max<int64_t>(N, 1)));
+  // cell ranges with about equal numbers of stored entries
+  std::vector<int64_t> cut((size_t)T + 1, N);
+  cut[0] = 0;
+  for (int t = 1; t < T; ++t) cut[t] = std::lower_bound(colptr, colptr + N + 1, nnz * t / T) - colptr;
+  for (int t = 1; t <= T; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+  cut[T] = N;
+  auto run = [&](const std::function<void(int)>& fn) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
+    fn(0);
+    for (auto& h : th) h.join();
+  };
+  std::vector<int> bad((size_t)T, 0);
+  std::vector<std::vector<int64_t>> part((size_t)T);
+  run([&](int t) {                                   // R/gficf.R:40  ix = rowSums(M != 0)
+    part[t].assign((size_t)G, 0);
+    for (int64_t p = colptr[cut[t]]; p < colptr[cut[t + 1]]; ++p) {
+      if (rowidx[p] < 0 || rowidx[p] >= G) { bad[t] = 1; return; }
+      if (x[p] != 0.0) part[t][rowidx[p]]++;
+    }
+  });
+  for (int t = 0; t < T; ++t)
+    if (bad[t]) return -1;
+  std::vector<int32_t> remap((size_t)G, -1);
+  int64_t gk = 0;
+  for (int64_t g = 0; g < G; ++g) {                  // R/gficf.R:41
+    int64_t ix = 0;
+    for (int t = 0; t < T; ++t) ix += part[t][g];
+    const bool kp = ((double)ix > (double)N * prop_min) && ((double)ix <= (double)N * prop_max);
+    keep[g] = kp ? 1 : 0;
+    if (kp) remap[g] = (int32_t)gk++;
+    nt[g] = 0;
+    w[g] = 0.0;
+  }
+  *G_kept = gk;
+  run([&](int t) {                                   // kept entries per cell
+    for (int64_t c = cut[t]; c < cut[t + 1]; ++c) {
+      int64_t n = 0;
+      for (int64_t p = colptr[c]; p < colptr[c + 1]; ++p) n += keep[rowidx[p]];
+      out_colptr[c + 1] = n;
+    }
+  });
+  out_colptr[0] = 0;
+  for (int64_t c = 0; c < N; ++c) out_colptr[c + 1] += out_colptr[c];
+  *nnz_kept = out_colptr[N];
+  run([&](int t) {                                   // subset + tf (R/gficf.R:41,59), nt of the kept genes (R/gficf.R:88)
+    part[t].assign((size_t)gk, 0);
+    for (int64_t c = cut[t]; c < cut[t + 1]; ++c) {
+      int64_t q = out_colptr[c];
+      double S = 0.0;
+      for (int64_t p = colptr[c]; p < colptr[c + 1]; ++p) {
+        const int32_t g = rowidx[p];
+        if (!keep[g]) continue;
+        out_rowidx[q] = remap[g];
+        out_x[q] = x[p];
+        S += x[p];
+        ++q;
+      }
+      for (int64_t u = out_colptr[c]; u < q; ++u) {
+        out_x[u] = (S != 0.0) ? out_x[u] / S : 0.0;
+        if (out_x[u] != 0.0) part[t][out_rowidx[u]]++;
+      }
+    }
+  });
+  std::vector<double> wk((size_t)gk, 0.0);
+  for (int64_t g = 0; g < G; ++g) {                  // R/gficf.R:89-91
+    if (!keep[g]) continue;
+    const int32_t r = remap[g];
+    int64_t n = 0;
+    for (int t = 0; t < T; ++t) n += part[t][r];
+    nt[g] = n;
+    const double c = (double)n;
+    if (w_in) wk[r] = w_in[g];
+    else if (icf_type == 1) wk[r] = std::log(((double)N - c) / c);
+    else if (icf_type == 2) wk[r] = std::log(1.0 + (double)N / c);
+    else wk[r] = std::log(((double)N + 1.0) / (c + 1.0));
+    w[g] = wk[r];
+  }
+  run([&](int t) {                                   // R/gficf.R:79, :100-103
+    for (int64_t c = cut[t]; c < cut[t + 1]; ++c) {
+      double ss = 0.0;
+      for (int64_t u = out_colptr[c]; u < out_colptr[c + 1]; ++u) {
+        out_x[u] = out_x[u] * wk[out_rowidx[u]];
+        ss += norm_l1 ? out_x[u] : out_x[u] * out_x[u];
+      }
+      double nv = 1.0 / (norm_l1 ? ss : std::sqrt(ss));
+      if (std::isinf(nv)) nv = 0.0;
+      for (int64_t u = out_colptr[c]; u < out_colptr[c + 1]; ++u) out_x[u] = nv * out_x[u];
+    }
+  });
   return 0;
 }
 

@@ -173,6 +173,25 @@ def test_gficf_empty_cell_and_explicit_zero():
     assert np.all(D[:, 1] == 0) and D[0, 2] == 0.0 and D[1, 2] == 1.0
 
 
+def test_gficf_threads_do_not_change_results():
+    # the multi-threaded restatement (bench.py's GF-ICF cpu_baseline) gives the single-threaded one's bits
+    for G, N, mn, mx, seed, T in [(400, 300, 0.05, 1.0, 1, 3), (250, 350, 0.0, 1.0, 2, 8), (300, 7, 0.1, 0.9, 3, 16), (50, 1, 0.0, 1.0, 4, 4)]:
+        cp, ri, x = synth.counts_csc(G, N, seed=seed)
+        w_in = None if seed != 2 else 0.5 + synth.rand_unit(5, np.arange(G))
+        a = oracle.gficf_csc(G, N, cp, ri, x, mn, mx, w_in=w_in)
+        b = oracle.gficf_csc(G, N, cp, ri, x, mn, mx, w_in=w_in, threads=T)
+        for key in ("keep", "nt", "w", "colptr", "rowidx", "x"):
+            assert np.array_equal(a[key], b[key]), key
+        assert a["G_kept"] == b["G_kept"]
+    colptr = np.array([0, 2, 2, 4], dtype=np.int64)            # empty cell, explicit zero
+    rowidx = np.array([0, 1, 0, 1], dtype=np.int32)
+    x = np.array([1.0, 3.0, 0.0, 2.0])
+    a, b = oracle.gficf_csc(2, 3, colptr, rowidx, x, 0.0, 1.0), oracle.gficf_csc(2, 3, colptr, rowidx, x, 0.0, 1.0, threads=2)
+    assert np.array_equal(a["x"], b["x"]) and a["nt"].tolist() == b["nt"].tolist() == [1, 2]
+    with pytest.raises(ValueError):
+        oracle.gficf_csc(2, 3, colptr, np.array([0, 5, 0, 1], dtype=np.int32), x, 0.0, 1.0, threads=2)
+
+
 def test_gficf_golden(golden_dir):
     z = np.load(os.path.join(golden_dir, "gficf_cases.npz"))
     for nm in ("g600_n400", "g300_n500_nofilter", "g500_n300_max"):
