@@ -16,6 +16,7 @@
 #include <vector>
 
 #include <atomic>
+#include <thread>
 
 #include "common.h"
 
@@ -1100,23 +1101,29 @@ int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, 
   double* const d_ox = ar.at<double>(o_x);
   int rc = gficf_csc_scale_device(ctx, p->G, p->N, p->d_colptr, p->d_rowidx, p->d_x, p->nnz, p->d_genes, p->d_gkept,
                                   p->d_out_colptr, d_ori, d_ox);
-  // the caller's result vectors are freshly allocated as a rule: map their pages from several threads while the
-  // scaling pass runs, instead of one page fault at a time under the device-to-host copy
+  // the caller's result vectors are freshly allocated as a rule: map their pages from several threads instead of one
+  // page fault at a time under the device-to-host copy — the row indices while the scaling pass runs, the values (twice
+  // as many bytes) on a helper thread while the row indices are being copied (a pageable copy holds the calling thread)
+  std::thread fault_x;
   if (!rc && p->nnz_kept > 0) {
-    gficf_prefault(out_x, sizeof(double) * (size_t)p->nnz_kept);
     gficf_prefault(out_rowidx, sizeof(int32_t) * (size_t)p->nnz_kept);
+    double* const ox = out_x;
+    const size_t xb = sizeof(double) * (size_t)p->nnz_kept;
+    fault_x = std::thread([ox, xb] { gficf_prefault(ox, xb); });
   }
   std::vector<int64_t> cp((size_t)p->N + 1);
   hipError_t e = hipSuccess;
   if (!rc) {
     e = hipMemcpyAsync(cp.data(), p->d_out_colptr, sizeof(int64_t) * cp.size(), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && p->nnz_kept > 0) e = hipMemcpyAsync(out_rowidx, d_ori, sizeof(int32_t) * (size_t)p->nnz_kept, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && p->nnz_kept > 0) e = hipMemcpyAsync(out_x, d_ox, sizeof(double) * (size_t)p->nnz_kept, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && keep && p->G > 0) e = hipMemcpyAsync(keep, p->d_keep, (size_t)p->G, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && nt && p->G > 0) e = hipMemcpyAsync(nt, p->d_nt, sizeof(int64_t) * (size_t)p->G, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && w && p->G > 0) e = hipMemcpyAsync(w, p->d_w, sizeof(double) * (size_t)p->G, hipMemcpyDeviceToHost, ctx->stream);
+    if (fault_x.joinable()) fault_x.join();
+    if (e == hipSuccess && p->nnz_kept > 0) e = hipMemcpyAsync(out_x, d_ox, sizeof(double) * (size_t)p->nnz_kept, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) rc = gficf_ctx_sync(ctx);
   }
+  if (fault_x.joinable()) fault_x.join();
   if (e != hipSuccess || rc) (void)hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { gficf_set_error("HIP failure in gficf_normalize_csc_host_finish: %s", hipGetErrorString(e)); rc = GFICF_ERR_HIP; }
   if (!rc) {
