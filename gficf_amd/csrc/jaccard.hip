@@ -868,6 +868,10 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
 // leave the younger requests alone the compiler must know how many there are: every load and store between two
 // waits is unconditional (indices are clamped instead of branched on, the first cell is peeled instead of guarded), and
 // cells that need the exact multiset path (rows with duplicate ids) are only flagged here and redone after the loop.
+// Output: a wave takes its cells four consecutive ones at a time, parks (neighbour id, count) of each in LDS and writes
+// the quad's 4k edges of every array with ONE store of 16 B per lane (k = 30: 960 B = 15 whole 64 B segments) instead of
+// four runs of k x 8 B that straddle segments: 17 % fewer write requests, none of them partial (memory-only model,
+// tools/lab/gather_lab.hip: 39.8 -> 35.5 us at 100 k x 30).
 template <int KPAD, bool BIG, bool CMP, int OUT>
 __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
@@ -883,12 +887,15 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   constexpr uint32_t WBYTES = SETS * HBYTES;
   uint32_t(*const s_rows)[2][KPAD] = reinterpret_cast<uint32_t(*)[2][KPAD]>(smem + C::WAVES * WBYTES);
   double* const s_lut = reinterpret_cast<double*>(smem + C::WAVES * WBYTES + C::WAVES * 2 * KPAD * 4);
+  constexpr uint32_t STAGE_OFF = C::WAVES * WBYTES + C::WAVES * 2 * KPAD * 4 + (GFICF_JACCARD_MAX_K + 1) * 8;   // behind the weight table
+  constexpr uint32_t STAGE_WAVE = 4 * 64 * 8;                 // 4 cells x 64 lanes x {id, count}
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned char* const hbase = smem + wave * WBYTES;
   for (int u = tid; u <= k; u += C::WAVES * 64) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);   // reference :51
   for (int b = lane; b < (int)(SETS * C::NB); b += 64) reinterpret_cast<uint2*>(hbase)[b] = make_uint2(EMPTY, EMPTY);
+  for (int t = lane; t < 4 * 64; t += 64) reinterpret_cast<uint2*>(smem + STAGE_OFF + (uint32_t)wave * STAGE_WAVE)[t] = make_uint2(0u, 0u);
   __syncthreads();
 
   const uint32_t wave_off = lds_address(smem) + (uint32_t)(tid >> 6) * WBYTES;
@@ -909,9 +916,25 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   const int slot_c = lane < C::NSLOT ? lane : C::NSLOT - 1;  // lanes beyond the row's slots load a valid slot and are masked at the decode
   const bool slot_ok = lane < C::NSLOT;
 
-  const int64_t first = cell_begin + (int64_t)blockIdx.x * C::WAVES + wave;
+  // the wave's cells: quads of four consecutive cells, quad q0 + m * nwaves for m = 0, 1, ...
+  const int64_t first = cell_begin + 4 * ((int64_t)blockIdx.x * C::WAVES + wave);
   if (first >= cell_end) return;                              // (after the barrier; wave-uniform)
   const int64_t last_cell = cell_end - 1;
+  const int64_t quad_step = 4 * nwaves - 3;                   // from the last cell of a quad to the first of the wave's next
+  // quad store: lane L holds edges 2L and 2L + 1 of the quad's 4k; (cell in quad, slot) of both, as LDS addresses
+  const uint32_t stage_w = lds_address(smem) + STAGE_OFF + (uint32_t)(tid >> 6) * STAGE_WAVE;
+  int qc0, qc1;
+  uint32_t qra0, qra1;
+  {
+    const int e0 = 2 * lane, e1 = e0 + 1;
+    qc0 = (e0 >= k) + (e0 >= 2 * k) + (e0 >= 3 * k);
+    qc1 = (e1 >= k) + (e1 >= 2 * k) + (e1 >= 3 * k);
+    int j0 = e0 - qc0 * k, j1 = e1 - qc1 * k;               // lanes past the quad's edges: clamped (their stores fall outside the descriptor)
+    j0 = j0 < 63 ? j0 : 63;
+    j1 = j1 < 63 ? j1 : 63;
+    qra0 = stage_w + (uint32_t)(qc0 * 64 + j0) * 8u;
+    qra1 = stage_w + (uint32_t)(qc1 * 64 + j1) * 8u;
+  }
 
   struct OwnRaw { uint32_t v, hw, last; };
   // own row of a cell: loads only (unconditional), decoded one iteration later
@@ -1050,7 +1073,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   uint32_t id_cur = true_id(araw_cur);
   issue_gathers(id_cur != 0 ? id_cur : (uint32_t)(first + 1), bv_cur);
   {
-    const int64_t i1 = first + nwaves;
+    const int64_t i1 = first + 1;
     load_own(i1 < cell_end ? i1 : last_cell, raw);
   }
   bool any_slow = false;
@@ -1058,47 +1081,62 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   uint32_t prev_a = 0;
   int prev_u = 0;
 
-  // Edges of the previous cell, as buffer stores through a descriptor that covers exactly the cell's k entries of the
-  // array: lanes beyond k fall outside the descriptor's range and the hardware drops their stores — no lane predicate, so
-  // no branch around the stores (the compiler guards a predicated block with one that skips it when no lane is active,
-  // which would make the number of memory operations between two waits unknown to it).  Non-temporal (aux = 2): written
-  // once, never re-read here.
+  // Edges leave a quad of cells at a time.  park_prev: (neighbour id, count) of the cell just counted into the wave's
+  // staging rows (all 64 lanes write: no predicate, no branch).  store_quad: 4k edges of each array through a buffer
+  // descriptor that covers exactly them — lanes past 2k fall outside its range and the hardware drops their stores, so
+  // there is no lane predicate and no branch around the stores (the compiler guards a predicated block with a branch
+  // that skips it when no lane is active, which would make the number of memory operations between two waits unknown
+  // to it).  Non-temporal (aux = 2): written once, never re-read here.
   typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  typedef double v2d __attribute__((ext_vector_type(2)));
 #ifndef GFICF_EDGE_STORE_AUX
 #define GFICF_EDGE_STORE_AUX 2
 #endif
   constexpr int EDGE_STORE_AUX = GFICF_EDGE_STORE_AUX;
-  auto store_prev = [&]() {
-    const int64_t pb = (prev_i - cell_begin) * (int64_t)k;          // scalar: first entry of the cell
-    const bool pos = prev_u > 0;
-    const int voff8 = lane * 8;
+  auto park_prev = [&](int c) {                                       // c: the cell's place in its quad
+    reinterpret_cast<uint2*>(smem + STAGE_OFF + (uint32_t)wave * STAGE_WAVE)[c * 64 + lane] = make_uint2(prev_a, (uint32_t)prev_u);
+  };
+  // ncells < 4: the wave's last, shorter quad.  Its edges may end in the middle of a lane's pair (k odd): a raw buffer
+  // access is range-checked dword by dword, so the first half of such a lane is written and the second dropped.
+  auto store_quad = [&](int64_t qfirst, int ncells) {
+    wave_lds_fence();
+    const uint2 p0 = lds_read_b64(qra0), p1 = lds_read_b64(qra1);     // {id, count} of the lane's two edges
+    const int64_t pb = (qfirst - cell_begin) * (int64_t)k;            // scalar: first entry of the quad
+    const int nedges = ncells * k;
     if (OUT != OUT_U16) {
-      const double vs = pos ? (double)(uint32_t)(prev_i + 1) : 0.0;   // reference :49
-      const double vd = pos ? (double)prev_a : 0.0;                   // reference :50
-      const double vw = s_lut[prev_u];                                // reference :51 (lut[0] = 0.0: the zero row)
-      const auto rs = __builtin_amdgcn_make_buffer_rsrc(o.src + pb, 0, k * 8, 0x00020000);
-      const auto rd = __builtin_amdgcn_make_buffer_rsrc(o.dst + pb, 0, k * 8, 0x00020000);
-      const auto rw = __builtin_amdgcn_make_buffer_rsrc(o.w + pb, 0, k * 8, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vs), rs, voff8, 0, EDGE_STORE_AUX);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vd), rd, voff8, 0, EDGE_STORE_AUX);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vw), rw, voff8, 0, EDGE_STORE_AUX);
+      const uint32_t c1st = (uint32_t)(qfirst + 1);
+      const bool pos0 = p0.y > 0, pos1 = p1.y > 0;
+      const v2d vs = {pos0 ? (double)(c1st + (uint32_t)qc0) : 0.0, pos1 ? (double)(c1st + (uint32_t)qc1) : 0.0};   // reference :49
+      const v2d vd = {pos0 ? (double)p0.x : 0.0, pos1 ? (double)p1.x : 0.0};                                     // reference :50
+      const v2d vw = {s_lut[p0.y], s_lut[p1.y]};                                                                 // reference :51 (lut[0] = 0.0: the zero row)
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(o.src + pb, 0, nedges * 8, 0x00020000);
+      const auto rd = __builtin_amdgcn_make_buffer_rsrc(o.dst + pb, 0, nedges * 8, 0x00020000);
+      const auto rw = __builtin_amdgcn_make_buffer_rsrc(o.w + pb, 0, nedges * 8, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, vs), rs, lane * 16, 0, EDGE_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, vd), rd, lane * 16, 0, EDGE_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, vw), rw, lane * 16, 0, EDGE_STORE_AUX);
     }
     if (OUT == OUT_RMAT_U) {
-      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u + pb, 0, k * 4, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b32((uint32_t)prev_u, ru, lane * 4, 0, 2);
+      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u + pb, 0, nedges * 4, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b64(v2u{p0.y, p1.y}, ru, lane * 8, 0, 2);
     }
-    if (OUT == OUT_U16) {
-      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u16 + pb, 0, k * 2, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b16((uint16_t)prev_u, ru, lane * 2, 0, 0);
+    if (OUT == OUT_U16) {        // 2 B per edge: a dword holds a lane's pair, and the range is checked per dword — the odd last edge goes out on its own
+      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u16 + pb, 0, nedges * 2, 0x00020000);
+      const auto ru_even = __builtin_amdgcn_make_buffer_rsrc(o.u16 + pb, 0, (nedges & ~1) * 2, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b32(p0.y | (p1.y << 16), ru_even, lane * 4, 0, 0);
+      if (nedges & 1) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)p0.y, ru, lane * 4, 0, 0);   // wave-uniform condition (rewrites the even edges with the same values)
     }
   };
 
-  // one cell: prefetch the next one's requests into `nxt`, [store the previous one's edges,] count this one's
-  // intersections from `cur`.  The two piece buffers swap roles from cell to cell (the loop is unrolled by two): copying
-  // one into the other would need the data, i.e. wait for the very gathers that are meant to stay in flight.
-  auto body = [&](int64_t i, const uint4 (&cur)[NST], uint4 (&nxt)[NST], auto store_tag) {
-    constexpr bool STORE = decltype(store_tag)::value;
-    const int64_t i1 = i + nwaves, i2 = i1 + nwaves;
+  // one cell (place CQ in its quad): prefetch the next one's requests into `nxt`, [park the previous cell's edges; behind
+  // the fourth of a quad: store the quad,] count this one's intersections from `cur`.  The two piece buffers swap roles
+  // from cell to cell (the loop is unrolled by four, an even number): copying one into the other would need the data,
+  // i.e. wait for the very gathers that are meant to stay in flight.
+  auto body = [&](int64_t i, const uint4 (&cur)[NST], uint4 (&nxt)[NST], auto cq_tag, auto park_tag) {
+    constexpr int CQ = decltype(cq_tag)::value;
+    constexpr bool PARK = decltype(park_tag)::value;
+    const int64_t i1 = i + (CQ == 3 ? quad_step : 1), i2 = i1 + (CQ == 2 ? quad_step : 1);
     const bool valid1 = i1 < cell_end;
     // next cell: its own row was requested an iteration ago
     const uint32_t araw_next = valid1 ? decode_own(raw) : 0u;
@@ -1108,7 +1146,8 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     __builtin_amdgcn_sched_barrier(0);                                 // (the scheduler would hoist the gathers above the own-row load)
     issue_gathers(a1 != 0 ? a1 : (uint32_t)(i + 1), nxt);              // no next cell: every lane reads row i (one line)
     __builtin_amdgcn_sched_barrier(0);
-    if (STORE) store_prev();
+    if (PARK) park_prev((CQ + 3) & 3);
+    if (PARK && CQ == 0) store_quad(i - 4 * nwaves, 4);   // the quad before this one is complete
     __builtin_amdgcn_sched_barrier(0);
     int u;
     const bool slow = process(araw_cur, cur, u);
@@ -1121,22 +1160,33 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   };
 
   uint4 bv_b[NST];
+  using T_ = std::true_type;
   int64_t i = first;
-  body(i, bv_cur, bv_b, std::false_type{});
-  i += nwaves;
-  while (i < cell_end) {
-    body(i, bv_b, bv_cur, std::true_type{});
-    i += nwaves;
-    if (i >= cell_end) break;
-    body(i, bv_cur, bv_b, std::true_type{});
-    i += nwaves;
+  int cq_last = 0;                                                     // place in its quad of the last cell counted
+  body(i, bv_cur, bv_b, std::integral_constant<int, 0>{}, std::false_type{});
+  for (;;) {
+    if (i + 1 >= cell_end) break;
+    i += 1; cq_last = 1;
+    body(i, bv_b, bv_cur, std::integral_constant<int, 1>{}, T_{});
+    if (i + 1 >= cell_end) break;
+    i += 1; cq_last = 2;
+    body(i, bv_cur, bv_b, std::integral_constant<int, 2>{}, T_{});
+    if (i + 1 >= cell_end) break;
+    i += 1; cq_last = 3;
+    body(i, bv_b, bv_cur, std::integral_constant<int, 3>{}, T_{});
+    if (i + quad_step >= cell_end) break;
+    i += quad_step; cq_last = 0;
+    body(i, bv_cur, bv_b, std::integral_constant<int, 0>{}, T_{});
   }
-  store_prev();
+  park_prev(cq_last);
+  store_quad(prev_i - cq_last, cq_last + 1);
   // ---- cells with duplicate ids in their own row or in a neighbour row (never the case for real kNN output): the exact
   // multiset path, after the loop; their fast-path rows written above are overwritten (same wave, program order)
   if (any_slow) {
     __builtin_amdgcn_s_waitcnt(0);
-    for (int64_t c = first; c < cell_end; c += nwaves) {
+    for (int64_t n = 0;; ++n) {                                       // the wave's cells again, in the same order
+      const int64_t c = first + (n >> 2) * 4 * nwaves + (n & 3);
+      if (c >= cell_end) break;
       const uint32_t* const rw = table + c * ROWW;
       const uint32_t a = lane < k ? row_slot_id(rw, lane, KPAD, CMP) : 0u;
       bool f = row_dup_flag(rw, KPAD, CMP);
@@ -1318,7 +1368,9 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
 template <int KPAD, bool CMP>
 constexpr size_t edges_lds_bytes() {
   using C = JCfg<KPAD, CMP>;
-  return (size_t)C::WAVES * C::NB * 8 * (CMP ? 2 : 1) + (size_t)C::WAVES * 2 * KPAD * 4 + (GFICF_JACCARD_MAX_K + 1) * sizeof(double);
+  // hash sets | own rows and overflow lists | weight table | (pipelined kernel) staging rows of the quad stores
+  return (size_t)C::WAVES * C::NB * 8 + (size_t)C::WAVES * 2 * KPAD * 4 + (GFICF_JACCARD_MAX_K + 1) * sizeof(double) +
+         ((C::EPL == 1 && C::SPQ <= 4) ? (size_t)C::WAVES * 4 * 64 * 8 : 0);
 }
 
 template <int KPAD, bool BIG, bool CMP, int OUT>
@@ -1347,7 +1399,9 @@ int launch_edges_o(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
   static const bool no_pipe = getenv("GFICF_JACCARD_NO_PIPE") != nullptr;        // test hook: the one-cell-at-a-time kernel for every k
   if constexpr (C::EPL == 1 && C::SPQ <= 4) {
     if (!no_pipe) {
-      hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT>), dim3(grid), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
+      const int64_t need4 = gficf_ceil_div(gficf_ceil_div(ce - cb, 4), C::WAVES);       // a wave takes four cells at a time
+      const unsigned grid4 = (unsigned)(need4 < cap ? need4 : cap);
+      hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT>), dim3(grid4), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
                          N, k, cb, ce, o);
       GFICF_HIP_CHECK(hipGetLastError());
       return GFICF_OK;

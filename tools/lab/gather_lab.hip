@@ -162,6 +162,64 @@ __global__ __launch_bounds__(256) void k_model_range(const char* __restrict__ ta
   }
 }
 
+// Quad stores: a wave takes FOUR consecutive cells, parks (dst id, count) of each in LDS and writes the three output
+// arrays once per quad as 60 lanes x 16 B (4 cells x 30 slots x 8 B = 960 B = 15 whole 64 B segments per array) instead
+// of four times 30 lanes x 8 B (240 B runs that straddle segments).  k = 30 only.
+__global__ __launch_bounds__(256) void k_model_quad(const char* __restrict__ table, long N, int k, double* __restrict__ o_src,
+                                                    double* __restrict__ o_dst, double* __restrict__ o_w, uint32_t fold) {
+  constexpr int ROWB = 64, LPR = ROWB / 16, RPS = 64 / LPR;
+  __shared__ uint32_t stage[4][4][32][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long w0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((long)gridDim.x * 256) >> 6;
+  const int grow = lane / LPR;
+  const uint32_t gcol = (uint32_t)(lane % LPR) * 16u;
+  auto own = [&](long i) -> uint32_t {
+    if (lane >= k || i >= N) return 0u;
+    const uint32_t lo = reinterpret_cast<const uint16_t*>(table + i * ROWB)[lane];
+    const uint32_t hi = reinterpret_cast<const uint32_t*>(table + i * ROWB)[15];
+    return lo | (((hi >> lane) & 1u) << 16);
+  };
+  const long nq = (N + 3) / 4;
+  for (long q = w0; q < nq; q += nw) {
+    uint32_t a_next = own(4 * q);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const long i = 4 * q + c;
+      const uint32_t a = a_next;
+      const uint32_t asafe = a != 0 ? a : (uint32_t)((i < N ? i : 0) + 1);
+      if (c < 3) a_next = own(i + 1);
+      v4u bv[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const uint32_t dst = (uint32_t)__shfl((int)asafe, s * RPS + grow);
+        bv[s] = load16<0>(table + (size_t)((dst - 1) & fold) * ROWB + gcol);
+      }
+      uint32_t u = 0;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        uint32_t x = bv[s].x ^ bv[s].y ^ bv[s].z ^ bv[s].w;
+        for (int d = 1; d < LPR; d <<= 1) x ^= __shfl_xor((int)x, d);
+        const uint32_t v = (uint32_t)__shfl((int)x, (lane % RPS) * LPR);
+        u = (lane / RPS == s) ? v : u;
+      }
+      if (lane < 32) { stage[wave][c][lane][0] = a; stage[wave][c][lane][1] = u & 0xffu; }
+    }
+    // 120 edges of the quad, two per lane
+    if (lane < 60) {
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      const int e0 = 2 * lane, c0 = e0 / 30, j0 = e0 % 30, e1 = e0 + 1, c1 = e1 / 30, j1 = e1 % 30;
+      const uint32_t a0 = stage[wave][c0][j0][0], u0 = stage[wave][c0][j0][1];
+      const uint32_t a1 = stage[wave][c1][j1][0], u1 = stage[wave][c1][j1][1];
+      const long r = 4 * q * 30 + e0;
+      if (4 * q + 3 < N) {
+        __builtin_nontemporal_store(v2d{(double)(uint32_t)(4 * q + c0 + 1), (double)(uint32_t)(4 * q + c1 + 1)}, reinterpret_cast<v2d*>(o_src + r));
+        __builtin_nontemporal_store(v2d{(double)a0, (double)a1}, reinterpret_cast<v2d*>(o_dst + r));
+        __builtin_nontemporal_store(v2d{(double)u0, (double)u1}, reinterpret_cast<v2d*>(o_w + r));
+      }
+    }
+  }
+}
+
 static uint64_t rng_state = 88172645463325252ull;
 static inline uint64_t rnd() {
   rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
@@ -270,6 +328,11 @@ int main(int argc, char** argv) {
     }
     if (!product_only) {
       const int grid = cus * 8;
+      if (k == 30 && N % 4 == 0) {
+        run(" 64 B rows, QUAD stores (60 lanes x 16 B)", k_model_quad, t64, grid);
+        run(" 64 B rows, QUAD stores, grid x 6/8", k_model_quad, t64, cus * 6);
+        run(" 64 B rows, QUAD stores, folded into 2 MB", k_model_quad, t64, grid, 0x7fffu);
+      }
       run(" 64 B rows, plain loads, PLAIN stores", k_model<64, 0, 2>, t64, grid);
       run("128 B rows, plain loads, PLAIN stores", k_model<128, 0, 2>, t128, grid);
       run(" 64 B rows, gathers folded into 4 MB", k_model<64, 0, 1>, t64, grid, 0xffffu);

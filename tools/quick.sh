@@ -1,14 +1,7 @@
 #!/bin/bash
-# Quick GPU check: Jaccard parity tests + a short bench.  Usage: bash tools/quick.sh <tag> [pytest -k expr]
+# Quick GPU check of the Jaccard path: product kernel timings on the three id models, then the parity tests that touch it.
+# Usage: bash tools/quick.sh <tag>
 TAG=${1:-q}
-OUT=gpurun_out/$TAG
-mkdir -p $OUT
-timeout 900 python -m pytest tests -x -q -m gpu ${2:+-k "$2"} > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest.log
-timeout 300 python bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
-python - <<PY
-import json
-d=json.load(open("$OUT/bench.json"))
-print("value %.4g edges/s  ms/step %.4f"%(d["value"], d["ms_per_step"]), d["roofline"], d.get("checked_vs_oracle"))
-g=d.get("gficf")
-if g: print("gficf %.4g cells/s ms %.4f"%(g["value"], g["ms_per_pass"]), g["roofline"])
-PY
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+timeout -k 10 120 ./tools/lab/gather_lab 100000 30 1 2>&1 | grep -E "ids|PRODUCT" > $OUT/product.txt; cat $OUT/product.txt
+timeout -k 10 1000 python -m pytest tests/test_jaccard_gpu.py tests/test_multi_gpu.py tests/test_dist_gpu.py tests/test_adjacency_gpu.py -x -q -m gpu > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest.log
