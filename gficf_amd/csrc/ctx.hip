@@ -263,24 +263,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(int64_t* __restr
   }
   int64_t total;
   int64_t ex = block_exclusive_scan(s, &total);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {
+    // look-back by the first wave, 64 descriptors at a time (one round trip instead of one per predecessor): lane l
+    // reads tile t0 - l; tiles before the first count as an inclusive prefix of 0
+    const int lane = threadIdx.x;
     unsigned long long* const desc = ws + 1;
-    if (total < 0 || (total >> SCAN_VALUE_BITS) != 0) atomicOr(status, GFICF_ST_BAD_CSC);    // counts out of range
+    if (lane == 0 && (total < 0 || (total >> SCAN_VALUE_BITS) != 0)) atomicOr(status, GFICF_ST_BAD_CSC);    // counts out of range
     int64_t run = 0;
     if (tile > 0) {
-      __hip_atomic_store(desc + tile, scan_desc(epoch, 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int64_t t = tile - 1;; --t) {
-        unsigned long long x;
-        do {
-          x = __hip_atomic_load(desc + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while ((uint32_t)(x >> 42) != epoch || ((x >> SCAN_VALUE_BITS) & 3ull) == 0ull);
-        run += (int64_t)(x & ((1ull << SCAN_VALUE_BITS) - 1ull));
-        if (((x >> SCAN_VALUE_BITS) & 3ull) == 2ull) break;
+      if (lane == 0) __hip_atomic_store(desc + tile, scan_desc(epoch, 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int64_t t0 = tile - 1;; t0 -= 64) {
+        const int64_t t = t0 - lane;
+        unsigned long long x = scan_desc(epoch, 2u, 0);
+        if (t >= 0) {
+          do {      // tickets are handed out in order: every earlier tile is running or done, its descriptor will appear
+            x = __hip_atomic_load(desc + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((uint32_t)(x >> 42) != epoch || ((x >> SCAN_VALUE_BITS) & 3ull) == 0ull);
+        }
+        const unsigned long long incl = __ballot(((x >> SCAN_VALUE_BITS) & 3ull) == 2ull);   // never 0 in the block that reaches tile 0
+        const int stop = incl ? __builtin_ctzll(incl) : 63;                                  // nearest inclusive prefix
+        int64_t v = lane <= stop ? (int64_t)(x & ((1ull << SCAN_VALUE_BITS) - 1ull)) : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        run += v;
+        if (incl) break;
       }
     }
-    __hip_atomic_store(desc + tile, scan_desc(epoch, 2u, run + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tile == (int64_t)gridDim.x - 1) __hip_atomic_store(ws, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket is out
-    s_prefix = run;
+    if (lane == 0) {
+      __hip_atomic_store(desc + tile, scan_desc(epoch, 2u, run + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tile == (int64_t)gridDim.x - 1) __hip_atomic_store(ws, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket is out
+      s_prefix = run;
+    }
   }
   __syncthreads();
   ex += s_prefix;

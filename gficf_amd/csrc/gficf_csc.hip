@@ -101,6 +101,7 @@ __global__ __launch_bounds__(CNT_THREADS) void k_gene_count(const int32_t* __res
 // all loads of a thread independent), the 16 partial sums meet in LDS.  One writer per gene: no atomics.
 constexpr int NS_WAVES = 16;
 
+template <bool ADD>      // ADD: nt[g] += (the C ABI's count step accumulates into the caller's zeroed counters); else nt[g] =
 __global__ __launch_bounds__(NS_WAVES * 64) void k_nt_sum(const uint32_t* __restrict__ part, int64_t Gp, int rows, int64_t G,
                                                           unsigned long long* __restrict__ nt) {
   __shared__ uint32_t s_acc[NS_WAVES][64];
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(NS_WAVES * 64) void k_nt_sum(const uint32_t* __rest
     uint32_t t = 0;
 #pragma unroll
     for (int w = 0; w < NS_WAVES; ++w) t += s_acc[w][lane];
-    if (t) nt[g] += t;
+    if (ADD) { if (t) nt[g] += t; }
+    else nt[g] = t;
   }
 }
 
@@ -733,7 +735,9 @@ __global__ __launch_bounds__(256) void k_sig_sum(int64_t G, const int64_t* __res
 // ----------------------------------------------------------------------------- C ABI
 extern "C" {
 
-static int launch_count(gficf_ctx* ctx, int64_t G, const int32_t* d_rowidx, const double* d_x, int64_t nnz, int64_t* d_nt) {
+// overwrite: d_nt need not be zeroed (the LDS-histogram form then writes every counter; *overwrote says whether it did)
+static int launch_count(gficf_ctx* ctx, int64_t G, const int32_t* d_rowidx, const double* d_x, int64_t nnz, int64_t* d_nt,
+                        bool overwrite = false) {
   int64_t blocks = gficf_ceil_div(nnz, (int64_t)CNT_THREADS * 16);
   // 16 B vector loads need 16 B-aligned bases (slab starts are multiples of 16384 entries)
   const bool vec = (((uintptr_t)d_rowidx | (uintptr_t)d_x) & 15u) == 0;
@@ -775,9 +779,14 @@ static int launch_count(gficf_ctx* ctx, int64_t G, const int32_t* d_rowidx, cons
     default: LAUNCH_CNT(false, false, false); break;
   }
 #undef LAUNCH_CNT
-  if (lds_hist)
-    hipLaunchKernelGGL(k_nt_sum, dim3((unsigned)gficf_ceil_div(G, 64)), dim3(NS_WAVES * 64), 0, ctx->stream, d_part, Gp, (int)blocks, G,
-                       (unsigned long long*)d_nt);
+  if (lds_hist) {
+    if (overwrite)
+      hipLaunchKernelGGL(k_nt_sum<false>, dim3((unsigned)gficf_ceil_div(G, 64)), dim3(NS_WAVES * 64), 0, ctx->stream, d_part, Gp,
+                         (int)blocks, G, (unsigned long long*)d_nt);
+    else
+      hipLaunchKernelGGL(k_nt_sum<true>, dim3((unsigned)gficf_ceil_div(G, 64)), dim3(NS_WAVES * 64), 0, ctx->stream, d_part, Gp,
+                         (int)blocks, G, (unsigned long long*)d_nt);
+  }
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -953,14 +962,14 @@ static int csc_sequence(gficf_ctx* ctx, bool exact, int64_t G, int64_t N, const 
                         int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
   GFICF_CTX_ENTER(ctx);
   if (G < 0 || N < 0 || nnz < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
-  if (G > 0) {
-    if (!d_nt) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
-    GFICF_HIP_CHECK(hipMemsetAsync(d_nt, 0, sizeof(int64_t) * (size_t)G, ctx->stream));
-  }
+  if (G > 0 && !d_nt) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  // the LDS-histogram form of the count writes every counter itself (k_nt_sum): no fill launch in front of it
+  const bool count_writes_all = nnz > 0 && G > 0 && G <= CNT_LDS_MAX_G;
+  if (G > 0 && !count_writes_all) GFICF_HIP_CHECK(hipMemsetAsync(d_nt, 0, sizeof(int64_t) * (size_t)G, ctx->stream));
   int rc = GFICF_OK;
   if (nnz > 0 && G > 0) {
     if (!d_rowidx || !d_x || !d_nt) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
-    rc = launch_count(ctx, G, d_rowidx, exact ? d_x : (const double*)nullptr, nnz, d_nt);
+    rc = launch_count(ctx, G, d_rowidx, exact ? d_x : (const double*)nullptr, nnz, d_nt, count_writes_all);
   }
   if (!rc) rc = gficf_csc_genes_device(ctx, G, N, d_nt, prop_min, prop_max, d_w_in, d_keep, d_genes, d_w, d_gkept);
   if (!rc) rc = gficf_csc_colptr_device(ctx, G, N, d_colptr, d_rowidx, d_keep, d_gkept, d_out_colptr);
