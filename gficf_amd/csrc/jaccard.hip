@@ -489,24 +489,47 @@ __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64
 // (pre-hashed half | bit 16): wd = the piece's four words (words of high bits zeroed), hb = the byte of bit-16 values of
 // the 8 ids, bmask / bit16 = (NB-1) << 3 and 0x10000 in vector registers, base = LDS byte address of the set.  Per id: half
 // (and / shift right), bucket address (one v_bitop3), its bit 16 (shift right + and), two three-way XORs against the
-// bucket's slots (v_bitop3), a min3 and an add — 18 issue cycles against 29 for the assembled-id form.  key / hs are
-// returned for the (rare) pass over the overflow list.
-__device__ inline int probe_compact_piece(const uint32_t (&wd)[4], uint32_t hb, uint32_t bmask, uint32_t bit16, uint32_t base,
-                                          uint32_t (&key)[8], uint32_t (&hs)[8]) {
-  uint2 h[8];
+// bucket's slots (v_bitop3), a min3 and an add — 18 issue cycles against 29 for the assembled-id form.  The (rare) pass over
+// the overflow list rebuilds the stored form with piece_key().
+#ifndef GFICF_PROBE_BATCH
+#define GFICF_PROBE_BATCH 8
+#endif
+// stored form (half | bit 16) of id t of a piece, as the hash set holds it
+__device__ inline uint32_t piece_key(const uint32_t (&wd)[4], uint32_t hb, int t) {
+  const uint32_t half = (t & 1) ? (wd[t >> 1] >> 16) : (wd[t >> 1] & 0xFFFFu);
+  return half | (((hb >> t) & 1u) << 16);
+}
+// B16 = false: every id of the data set is below 2^16 (no bit 16 anywhere): the compare is a two-way XOR on the halves.
+template <bool B16 = true>
+__device__ inline int probe_compact_piece(const uint32_t (&wd)[4], uint32_t hb, uint32_t bmask, uint32_t bit16, uint32_t base) {
   const uint32_t H = hb << 16;
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    key[t] = (t & 1) ? (wd[t >> 1] >> 16) : (wd[t >> 1] & 0xFFFFu);
-    h[t] = lds_read_b64(bitop3<0xEA>(key[t], bmask, base));          // (half & mask) | base
-    hs[t] = (t ? (H >> t) : H) & bit16;
-  }
   uint32_t miss = 0;
 #pragma unroll
-  for (int t = 0; t < 8; t += 2) {
-    const uint32_t m0 = min3u_one(bitop3<0x96>(h[t].x, key[t], hs[t]), bitop3<0x96>(h[t].y, key[t], hs[t]));
-    const uint32_t m1 = min3u_one(bitop3<0x96>(h[t + 1].x, key[t + 1], hs[t + 1]), bitop3<0x96>(h[t + 1].y, key[t + 1], hs[t + 1]));
-    miss += m0 + m1;
+  for (int b = 0; b < 8; b += GFICF_PROBE_BATCH) {
+    uint2 h[GFICF_PROBE_BATCH];
+    uint32_t key[GFICF_PROBE_BATCH], hs[GFICF_PROBE_BATCH];
+#pragma unroll
+    for (int t = 0; t < GFICF_PROBE_BATCH; ++t) {
+      const int tt = b + t;
+      key[t] = (tt & 1) ? (wd[tt >> 1] >> 16) : (wd[tt >> 1] & 0xFFFFu);
+      h[t] = lds_read_b64(bitop3<0xEA>(key[t], bmask, base));          // (half & mask) | base
+      hs[t] = B16 ? ((tt ? (H >> tt) : H) & bit16) : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < GFICF_PROBE_BATCH; t += 2) {
+      uint32_t m0, m1;
+      if (B16) {
+        m0 = min3u_one(bitop3<0x96>(h[t].x, key[t], hs[t]), bitop3<0x96>(h[t].y, key[t], hs[t]));
+        m1 = min3u_one(bitop3<0x96>(h[t + 1].x, key[t + 1], hs[t + 1]), bitop3<0x96>(h[t + 1].y, key[t + 1], hs[t + 1]));
+      } else {
+        m0 = min3u_one(h[t].x ^ key[t], h[t].y ^ key[t]);
+        m1 = min3u_one(h[t + 1].x ^ key[t + 1], h[t + 1].y ^ key[t + 1]);
+      }
+      miss += m0 + m1;
+    }
+#if GFICF_PROBE_BATCH < 8
+    __builtin_amdgcn_sched_barrier(0);
+#endif
   }
   return 8 - (int)miss;
 }
@@ -811,14 +834,14 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
                 }
               }
             } else {
-              uint32_t wd[4], hb, key[8], hs[8];
+              uint32_t wd[4], hb;
               dupflags |= piece_words(bv[uu], wd, hb);
-              c = probe_compact_piece(wd, hb, bmask_v, bit16_v, wave_off, key, hs);
+              c = probe_compact_piece(wd, hb, bmask_v, bit16_v, wave_off);
               if (nov) {                          // wave-uniform, rare: ids that overflowed the set (kept in their stored form)
                 for (int t = 0; t < nov; ++t) {
                   const uint32_t ov = ovlist[t];
 #pragma unroll
-                  for (int tt = 0; tt < 8; ++tt) c += ((key[tt] | hs[tt]) == ov);
+                  for (int tt = 0; tt < 8; ++tt) c += (piece_key(wd, hb, tt) == ov);
                 }
               }
             }
@@ -872,7 +895,8 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
 // the quad's 4k edges of every array with ONE store of 16 B per lane (k = 30: 960 B = 15 whole 64 B segments) instead of
 // four runs of k x 8 B that straddle segments: 17 % fewer write requests, none of them partial (memory-only model,
 // tools/lab/gather_lab.hip: 39.8 -> 35.5 us at 100 k x 30).
-template <int KPAD, bool BIG, bool CMP, int OUT>
+// B16 = false (compact rows only): N < 2^16, no id has bit 16 — the bitmap words of the rows are zero and are not looked at.
+template <int KPAD, bool BIG, bool CMP, int OUT, bool B16 = true>
 __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
   using C = JCfg<KPAD, CMP>;
@@ -954,7 +978,8 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   auto decode_own = [&](const OwnRaw& r) -> uint32_t {
     uint32_t x;
     if (!CMP) x = r.v;
-    else x = r.v | ((((KPAD == 32 ? r.last : r.hw) >> (lane & 31)) & 1u) << 16) | (r.last & ROW_DUP_FLAG);
+    else if (B16) x = r.v | ((((KPAD == 32 ? r.last : r.hw) >> (lane & 31)) & 1u) << 16) | (r.last & ROW_DUP_FLAG);
+    else x = r.v | (r.last & ROW_DUP_FLAG);
     return slot_ok ? x : 0u;
   };
   auto true_id = [&](uint32_t keyraw) -> uint32_t {
@@ -970,14 +995,17 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     }
   };
   auto piece_words = [&](const uint4& bv, uint32_t (&wd)[4], uint32_t& hb) -> uint32_t {
-    uint32_t hw;
-    if (KPAD == 32) hw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv.w, 0xFF, 0xf, 0xf, false);   // quad_perm [3,3,3,3]
-    else {
-      hw = 0;
-      { const uint32_t v = (uint32_t)__shfl((int)bv.z, hi_l); hw = hi_c == 2 ? v : hw; }
-      { const uint32_t v = (uint32_t)__shfl((int)bv.w, hi_l); hw = hi_c == 3 ? v : hw; }
+    hb = 0;
+    if (B16) {
+      uint32_t hw;
+      if (KPAD == 32) hw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv.w, 0xFF, 0xf, 0xf, false);   // quad_perm [3,3,3,3]
+      else {
+        hw = 0;
+        { const uint32_t v = (uint32_t)__shfl((int)bv.z, hi_l); hw = hi_c == 2 ? v : hw; }
+        { const uint32_t v = (uint32_t)__shfl((int)bv.w, hi_l); hw = hi_c == 3 ? v : hw; }
+      }
+      hb = (hw >> ((gl & 3) * 8)) & 0xFFu;
     }
-    hb = (hw >> ((gl & 3) * 8)) & 0xFFu;
     wd[0] = bv.x; wd[1] = bv.y; wd[2] = bv.z; wd[3] = bv.w;
     if (tail) {
       hb &= (1u << (F::KC % 8)) - 1u;
@@ -1043,14 +1071,14 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
           }
         }
       } else {
-        uint32_t wd[4], hb, key[8], hs[8];
+        uint32_t wd[4], hb;
         dupflags |= piece_words(bv[st], wd, hb);
-        c = probe_compact_piece(wd, hb, bmask_v, bit16_v, wave_off, key, hs);
+        c = probe_compact_piece<B16>(wd, hb, bmask_v, bit16_v, wave_off);
         if (nov) {                                  // wave-uniform, rare: ids that overflowed the set (kept in their stored form)
           for (int t = 0; t < nov; ++t) {
             const uint32_t ov = ovlist[t];
 #pragma unroll
-            for (int tt = 0; tt < 8; ++tt) c += ((key[tt] | hs[tt]) == ov);
+            for (int tt = 0; tt < 8; ++tt) c += (piece_key(wd, hb, tt) == ov);
           }
         }
       }
@@ -1401,8 +1429,12 @@ int launch_edges_o(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
     if (!no_pipe) {
       const int64_t need4 = gficf_ceil_div(gficf_ceil_div(ce - cb, 4), C::WAVES);       // a wave takes four cells at a time
       const unsigned grid4 = (unsigned)(need4 < cap ? need4 : cap);
-      hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT>), dim3(grid4), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
-                         N, k, cb, ce, o);
+      if (CMP && N < 65536)     // no id carries bit 16: the kernel variant that does not look for it (configs 1-3 of BASELINE.json)
+        hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, !CMP>), dim3(grid4), dim3(C::WAVES * 64), lds_bytes, ctx->stream,
+                           table, N, k, cb, ce, o);
+      else
+        hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT>), dim3(grid4), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
+                           N, k, cb, ce, o);
       GFICF_HIP_CHECK(hipGetLastError());
       return GFICF_OK;
     }
