@@ -76,6 +76,32 @@ DEFKERNEL(k_lshlor, "v_lshl_or_b32 %0, %0, 3, %1")
 DEFKERNEL(k_xad, "v_xad_u32 %0, %0, %1, %2")
 DEFKERNEL(k_dot4, "v_dot4_u32_u8 %0, %0, %1, %2")
 
+// Same loop with the source registers varying from instruction to instruction (register i, i+5, i+10 of the same file):
+// shows what operand fetch costs beyond the issue rate (VGPR bank conflicts of three-source forms).
+#define DEFKERNEL3(NAME, ASMTEXT)                                                                             \
+  __global__ __launch_bounds__(256) void NAME(unsigned* out, unsigned long long* cyc) {                       \
+    unsigned r[16];                                                                                           \
+    for (int i = 0; i < 16; ++i) r[i] = threadIdx.x * 2654435761u + i * 40503u;                              \
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                               \
+    for (int it = 0; it < ITER; ++it) {                                                                       \
+      _Pragma("unroll") for (int rep = 0; rep < 4; ++rep) {                                                   \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                        \
+          asm volatile(ASMTEXT : "+v"(r[i]) : "v"(r[(i + 5) & 15]), "v"(r[(i + 10) & 15]));                   \
+      }                                                                                                       \
+    }                                                                                                         \
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                               \
+    unsigned x = 0;                                                                                           \
+    for (int i = 0; i < 16; ++i) x ^= r[i];                                                                   \
+    out[blockIdx.x * 256 + threadIdx.x] = x;                                                                  \
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;                                                          \
+  }
+DEFKERNEL3(k3_bitop3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+DEFKERNEL3(k3_xor, "v_xor_b32 %0, %0, %1")
+DEFKERNEL3(k3_min3, "v_min3_u32 %0, %0, %1, %2")
+DEFKERNEL3(k3_fma, "v_fma_f32 %0, %0, %1, %2")
+DEFKERNEL3(k3_and, "v_and_b32 %0, %1, %2")
+DEFKERNEL3(k3_lshr, "v_lshrrev_b32 %0, %1, %2")
+
 int main() {
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
@@ -151,5 +177,12 @@ int main() {
   run("v_lshl_or_b32", k_lshlor);
   run("v_xad_u32", k_xad);
   run("v_dot4_u32_u8", k_dot4);
+  printf("varying source registers:\n");
+  run("v_xor_b32 (2 regs)", k3_xor);
+  run("v_and_b32 (2 other regs)", k3_and);
+  run("v_lshrrev_b32 (2 regs)", k3_lshr);
+  run("v_bitop3_b32 (3 regs)", k3_bitop3);
+  run("v_min3_u32 (3 regs)", k3_min3);
+  run("v_fma_f32 (3 regs)", k3_fma);
   return 0;
 }
