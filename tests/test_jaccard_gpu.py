@@ -201,6 +201,40 @@ def test_cell_block_seam_matches_full(ops):
     assert np.array_equal(got, full)
 
 
+@pytest.mark.parametrize("k", [1, 3, 15, 17, 29, 31, 32])
+def test_quad_stores_tails_and_seams_all_output_forms(ops, k):
+    """The k <= 32 kernel writes its edges four consecutive cells at a time; the last quad of a wave may be short and, for odd
+    k, end in the middle of a lane's pair of edges.  Every output form (matrix, matrix + uint32 counts, uint16 counts), cell
+    counts with every remainder mod 4, and cell blocks that start at odd cells, against the oracle."""
+    import torch
+
+    for N in (k + 2 if k + 2 > 4 else 5, 101, 102, 103, 1001, 4099):
+        if N <= k + 1:
+            continue
+        mat = synth.knn_uniform(N, k, seed=N + k) if N < 2 * k + 3 else synth.knn_windowed(N, k, W=max(100, k), seed=N + k)
+        want, want_u = oracle.jaccard(mat, nthreads=4)
+        got, got_u = device_jaccard(ops, mat, with_u=True)            # matrix + uint32 counts
+        assert np.array_equal(got, want), (N, k)
+        assert np.array_equal(got_u, want_u.reshape(-1)), (N, k)
+        got2, _ = device_jaccard(ops, mat, with_u=False)              # matrix only
+        assert np.array_equal(got2, want), (N, k)
+        cnt = gficf_amd.jaccard_counts(mat)                           # uint16 counts through the host entry
+        assert np.array_equal(np.asarray(cnt).reshape(-1).astype(np.int64), want_u.reshape(-1).astype(np.int64)), (N, k)
+        # blocks that begin at odd cells
+        table = torch.zeros((N, ops.row_words(N, k)), dtype=torch.int32, device="cuda")
+        ops.jaccard_ingest(torch.from_numpy(np.ascontiguousarray(mat.T)).cuda(), N, k, N, table)
+        cuts = [0, 1, min(7, N), min(50, N), N]
+        outs = []
+        for b, e in zip(cuts[:-1], cuts[1:]):
+            if e <= b:
+                continue
+            out = torch.full((3, (e - b) * k), -7.0, dtype=torch.float64, device="cuda")
+            ops.jaccard_edges(table, N, k, b, e, out)
+            outs.append(out)
+        ops.sync()
+        assert np.array_equal(torch.cat(outs, dim=1).cpu().numpy().T, want), (N, k, "blocks")
+
+
 def test_full_size_north_star_point_bit_exact(ops):
     """100 k cells x k = 30 (the north-star point): whole edge matrix bit-exact vs the oracle."""
     mat = synth.knn_windowed(100000, 30)
