@@ -904,6 +904,8 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
   using C = JCfg<KPAD, CMP>;
   using F = CFmt<KPAD>;
+  // (Extended to 32 < k <= 64 — eight gather steps per cell, edges leaving a pair of cells at a time — the kernel needs 177
+  // vector registers: two waves per SIMD, 164 us against 129 us of the one-cell-at-a-time kernel at 100 k x 50.  Not kept.)
   static_assert(C::EPL == 1 && C::SPQ <= 4, "one batch of gathers per cell");
   static_assert(!(BIG && CMP), "compact rows hold 17-bit ids");
   using off_t = typename std::conditional<BIG, uint64_t, uint32_t>::type;
