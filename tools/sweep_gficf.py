@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""GF-ICF pass over the shapes of BASELINE.json's configs (synthetic counts generated on the device, device-resident pass,
+5 % gene filter).  Usage: python tools/sweep_gficf.py [out.txt]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import bench
+import gficf_amd
+
+ops = gficf_amd.HipOps(0)
+lines = []
+for name, G, N, kw in [("config 1: 3 k cells x 5 k genes", 5000, 3000, {}),
+                       ("config 2: 10 k cells x 20 k genes", 20000, 10000, {}),
+                       ("config 3: 54 k cells x 23 k genes", 23000, 54000, {}),
+                       ("config 4: 100 k cells x 30 k genes", 30000, 100000, {}),
+                       ("config 5: 1 M cells x 30 k genes (at most 2147 entries per cell)", 30000, 1000000,
+                        dict(seed=5, max_per_cell=2147, chunk_cells=125_000))]:
+    colptr, rowidx, x = bench.synth_counts_device(torch, G, N, **kw)
+    nnz = int(rowidx.numel())
+    ws = ops.csc_workspace(G, N, nnz)
+    run = lambda: ops.gficf_csc(G, N, colptr, rowidx, x, 0.05, 1.0, None, ws)
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / reps
+    ops.sync()
+    kept, gk = int(ws["out_colptr"][N]), int(ws["gkept"][0])
+    lines.append("%-68s nnz %11d  kept genes %6d  kept entries %11d  %9.3f ms  %7.1f M cells/s  %5.2f TB/s algorithmic (24 B/entry) = %.3f of 8 TB/s"
+                 % (name, nnz, gk, kept, t * 1e3, N / t / 1e6, 24 * nnz / t / 1e12, 24 * nnz / t / 8e12))
+    print(lines[-1], flush=True)
+    del colptr, rowidx, x, ws
+    torch.cuda.empty_cache()
+if len(sys.argv) > 1:
+    open(sys.argv[1], "w").write("\n".join(lines) + "\n")
