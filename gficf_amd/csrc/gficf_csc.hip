@@ -207,6 +207,36 @@ __global__ __launch_bounds__(GT_THREADS) void k_gene_table(int64_t G, int64_t N_
   }
 }
 
+// The contiguous range of cells that holds share number `share` (of gridDim.x) of the stored entries: range[0] = the smallest
+// cell c with colptr[c] >= nnz * share / shares, range[1] the same for share + 1 (the last share ends with the last cell).  Called
+// by the first wave of the workgroup: a 32-way search, lanes 0..31 for the start, 32..63 for the end (3-4 dependent loads).
+__device__ inline void cell_range_by_entries(const int64_t* __restrict__ colptr, int64_t n_cells, int64_t* range, int64_t share) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31;
+  const int64_t nb = (int64_t)gridDim.x, b = share + half, nnz_all = colptr[n_cells];
+  const int64_t target = nnz_all / nb * b + (nnz_all % nb) * b / nb;
+  int64_t lo = 0, hi = n_cells;                  // the answer lies in [lo, hi]; colptr[hi] >= target throughout
+  if (b >= nb) lo = hi;
+  while (__any(hi > lo)) {
+    const bool active = hi > lo;
+    const int64_t step = active ? (hi - lo + 31) / 32 : 1;
+    int64_t p = lo + step * l;
+    if (p > hi) p = hi;
+    const bool ge = active ? colptr[p] >= target : true;
+    const unsigned int m = (unsigned int)(__ballot(ge) >> (half * 32));
+    if (active) {
+      const int f = m ? __builtin_ctz(m) : 32;   // first probe at or past the target
+      if (f == 0) hi = lo;
+      else {
+        int64_t below = lo + step * (f - 1), at = hi;
+        if (f < 32) { at = lo + step * f; if (at > hi) at = hi; }
+        lo = below + 1 < at ? below + 1 : at;
+        hi = at;
+      }
+    }
+  }
+  if (l == 0) range[half] = lo;
+}
+
 // ------------------------------------------------------- pass B0: kept entries per cell
 // One wave per cell; out[c] = #{entries of cell c whose gene is kept}; out[n_cells] = 0,
 // turned into the new colptr by an exclusive scan.  The keep mask is staged as a bitmask in
@@ -221,11 +251,17 @@ __global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64
                                                                 const int64_t* __restrict__ gkept,
                                                                 int64_t* __restrict__ out, uint32_t* __restrict__ status) {
   extern __shared__ uint32_t s_bits[];      // ceil(G/32) words
+  __shared__ int64_t s_range[2];
+  __shared__ unsigned int s_next;
   const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * CC_THREADS + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * CC_THREADS) >> 6;
   const bool all_kept = (*gkept == G);
-  if (wave == 0 && lane == 0) out[n_cells] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n_cells] = 0;
+  // the workgroup's cells: its share of the stored entries (cell_range_by_entries), dealt to its waves one by one
+  if (threadIdx.x < 64) {
+    cell_range_by_entries(colptr, n_cells, s_range, (int64_t)gridDim.x - 1 - (int64_t)blockIdx.x);   // first workgroups: last cells
+    if (threadIdx.x == 0) s_next = 0u;
+  }
+  if (all_kept) __syncthreads();
   if (!all_kept) {
     const int64_t words = (G + 31) / 32;
     const bool aligned4 = ((uintptr_t)keep & 3u) == 0;
@@ -249,8 +285,16 @@ __global__ __launch_bounds__(CC_THREADS) void k_cell_kept_count(int64_t G, int64
   }
   // Cells are swept from the last to the first: pass A has just streamed rowidx front to back, so its
   // tail is what the 256 MiB Infinity Cache still holds; reading backwards re-uses it before it ages out.
-  for (int64_t cr = wave; cr < n_cells; cr += nwaves) {
-    const int64_t c = n_cells - 1 - cr;
+  // (the workgroups take the ranges from the last to the first, and each walks its own backwards)
+  const int64_t cell_lo = s_range[0], cell_hi = s_range[1];
+  auto grab = [&]() -> int64_t {
+    unsigned int v = 0;
+    if (lane == 0) v = atomicAdd(&s_next, 1u);
+    return cell_hi - 1 - (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  int64_t c_next = grab();
+  for (int64_t c = c_next; c >= cell_lo; c = c_next) {
+    c_next = grab();
     const int64_t p0 = colptr[c], p1 = colptr[c + 1];
     if (p1 < p0) { if (lane == 0) { atomicOr(status, GFICF_ST_BAD_CSC); out[c] = 0; } continue; }
     int64_t cnt;
@@ -459,10 +503,18 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
 // reads instead of L2 requests (the global-gather variant above issues one L2 request per
 // entry).  A lane keeps x and the new row id of its entries in registers (3 VGPRs per entry), the
 // weight is read from LDS when it is needed.  Same arithmetic and order of operations.
-// 896 threads and 28 register chunks (1792 entries per wave without re-reading): measured against 1024 / 24, 768 / 36, 640 / 40
-// and 512 / 48 at config 3's shape (profiles/r02_gficf_scale_ab.txt): the whole pass 0.451 -> 0.427 ms.
-constexpr int SL_THREADS = 896;
-constexpr int SL_CH = 28;                         // chunks of 64 entries a wave keeps in registers
+// 768 threads and 32 register chunks (2048 entries per wave without re-reading; config 5 caps a cell at 2147).  With the cells
+// dealt round-robin 896 / 28 was the best of 1024 / 24, 768 / 36, 640 / 40, 512 / 48 (profiles/r02_gficf_scale_ab.txt: the whole
+// pass 0.451 -> 0.427 ms); with the cells dealt by entries (below) 768 / 32 is ahead of 896 / 28, 832 / 30, 768 / 28, 768 / 36, 704 / 34,
+// 640 / 36 by 1-4 % (runs in separate processes, each variant in both modes of the process-to-process spread).
+#ifndef GFICF_SL_THREADS
+#define GFICF_SL_THREADS 768
+#endif
+#ifndef GFICF_SL_CH
+#define GFICF_SL_CH 32
+#endif
+constexpr int SL_THREADS = GFICF_SL_THREADS;     // (A/B of these two: profiles/r02_gficf_scale_ab.txt)
+constexpr int SL_CH = GFICF_SL_CH;               // chunks of 64 entries a wave keeps in registers
 constexpr int SL_LB = 8;                          // chunks per batch on the long-cell path
 __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64_t n_cells,
                                                                 const int64_t* __restrict__ colptr,
@@ -473,7 +525,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
                                                                 const int64_t* __restrict__ out_colptr,
                                                                 int32_t* __restrict__ out_rowidx,
                                                                 double* __restrict__ out_x, int norm_l1,
-                                                                uint32_t* zero_flag) {
+                                                                uint32_t* zero_flag, int static_cells) {
   extern __shared__ unsigned char s_raw[];
   bool saw_zero = false;                          // an explicitly stored zero (see gficf_csc_device)
   const int64_t gkept = *gkept_p;
@@ -487,12 +539,30 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
     const double* wk = genes_wkept(genes, G);
     for (int64_t t = threadIdx.x; t < gkept; t += SL_THREADS) s_w[t] = wk[t];
   }
-  __syncthreads();
+  // Cells: the workgroup owns the contiguous range of cells that holds its share of the stored ENTRIES (cells differ in
+  // length by a factor of several: a static deal of cells to waves leaves the last waves working alone for ~15 of the
+  // kernel's 270 us), and its waves take that range's cells one by one from a counter in LDS.
+  __shared__ int64_t s_range[2];
+  __shared__ unsigned int s_next;
   const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    cell_range_by_entries(colptr, n_cells, s_range, (int64_t)blockIdx.x);
+    if (threadIdx.x == 0) s_next = 0u;
+  }
+  __syncthreads();
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  const int64_t wave0 = ((int64_t)blockIdx.x * SL_THREADS + threadIdx.x) >> 6;
+  const int64_t cell_lo = static_cells ? 0 : s_range[0], cell_hi = static_cells ? n_cells : s_range[1];
+  int64_t static_c = ((int64_t)blockIdx.x * SL_THREADS + threadIdx.x) >> 6;     // test hook: the round-robin deal of cells to waves
   const int64_t nwaves = ((int64_t)gridDim.x * SL_THREADS) >> 6;
-  for (int64_t c = wave0; c < n_cells; c += nwaves) {
+  auto grab = [&]() -> int64_t {                   // next cell of the range (one LDS atomic per wave and cell)
+    if (static_cells) { const int64_t c = static_c; static_c += nwaves; return c; }
+    unsigned int v = 0;
+    if (lane == 0) v = atomicAdd(&s_next, 1u);
+    return cell_lo + (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  int64_t c_next = grab();
+  for (int64_t c = c_next; c < cell_hi; c = c_next) {
+    c_next = grab();                               // asked for early: the round trip hides behind this cell's loads
     const int64_t p0 = colptr[c], p1 = colptr[c + 1];
     const int64_t len = p1 - p0;
     if (len <= 0) continue;                       // uniform over the wave
@@ -853,7 +923,8 @@ int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
     int64_t blocks = gficf_ceil_div(n_cells, SL_THREADS / 64);
     if (blocks > ctx->num_cus) blocks = ctx->num_cus;
     hipLaunchKernelGGL(k_scale_cells_lds, dim3((unsigned)blocks), dim3(SL_THREADS), SL_LDS_BYTES, ctx->stream, G, n_cells,
-                       d_colptr, d_rowidx, d_x, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x, ctx->norm_l1, ctx->cur_zero);
+                       d_colptr, d_rowidx, d_x, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x, ctx->norm_l1, ctx->cur_zero,
+                       getenv("GFICF_SCALE_STATIC_CELLS") != nullptr ? 1 : 0);       // test hook, read per call (A/B inside one process)
   }
   if (try_lds && sl_fits(G, G)) {                           // every possible number of kept genes fits: no second variant to offer
     GFICF_HIP_CHECK(hipGetLastError());
