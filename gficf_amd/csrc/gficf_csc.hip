@@ -210,9 +210,15 @@ __global__ __launch_bounds__(GT_THREADS) void k_gene_table(int64_t G, int64_t N_
 // The contiguous range of cells that holds share number `share` (of gridDim.x) of the stored entries: range[0] = the smallest
 // cell c with colptr[c] >= nnz * share / shares, range[1] the same for share + 1 (the last share ends with the last cell).  Called
 // by the first wave of the workgroup: a 32-way search, lanes 0..31 for the start, 32..63 for the end (3-4 dependent loads).
+constexpr int64_t SMALL_CELLS = 16384;           // below: cells are split evenly by number
 __device__ inline void cell_range_by_entries(const int64_t* __restrict__ colptr, int64_t n_cells, int64_t* range, int64_t share) {
   const int lane = threadIdx.x & 63, half = lane >> 5, l = lane & 31;
-  const int64_t nb = (int64_t)gridDim.x, b = share + half, nnz_all = colptr[n_cells];
+  const int64_t nb = (int64_t)gridDim.x;
+  if (n_cells < SMALL_CELLS) {                   // small inputs: the search's dependent loads cost more than balance gains
+    if (l == 0) range[half] = n_cells / nb * (share + half) + (n_cells % nb) * (share + half) / nb;
+    return;
+  }
+  const int64_t b = share + half, nnz_all = colptr[n_cells];
   const int64_t target = nnz_all / nb * b + (nnz_all % nb) * b / nb;
   int64_t lo = 0, hi = n_cells;                  // the answer lies in [lo, hi]; colptr[hi] >= target throughout
   if (b >= nb) lo = hi;
