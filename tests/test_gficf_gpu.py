@@ -58,6 +58,42 @@ def test_matches_oracle(G, N, mn, mx, seed):
     assert (res["rawCounts"] != M[res["genes"], :]).nnz == 0
 
 
+@pytest.mark.parametrize("shape", ["giants_first", "giants_last", "empty_blocks", "one_cell_has_it_all", "all_equal"])
+def test_skewed_cell_lengths_above_the_range_search_threshold(shape):
+    """The scaling and kept-count passes cut the cells into contiguous ranges of equal stored entries (a search on colptr by
+    every workgroup, used from 16384 cells on) and hand a range's cells to the waves through a counter: cell-length
+    distributions that put range boundaries inside runs of empty cells, on giant cells, or all in one place."""
+    rng = np.random.default_rng(123)
+    G, N = 4000, 20000
+    lens = rng.integers(0, 6, size=N)
+    if shape == "giants_first":
+        lens[:40] = G
+    elif shape == "giants_last":
+        lens[-40:] = G
+    elif shape == "empty_blocks":
+        lens[:6000] = 0
+        lens[9000:15000] = 0
+        lens[-500:] = 0
+        lens[7000:7010] = 3500
+    elif shape == "one_cell_has_it_all":
+        lens[:] = 0
+        lens[12345] = G
+        lens[3] = 1
+    elif shape == "all_equal":
+        lens[:] = 17
+    cp = np.zeros(N + 1, dtype=np.int64)
+    cp[1:] = np.cumsum(lens)
+    ri = np.empty(int(cp[-1]), dtype=np.int32)
+    for c in np.flatnonzero(lens):
+        ri[cp[c]:cp[c + 1]] = np.sort(rng.choice(G, size=int(lens[c]), replace=False)) if lens[c] < G else np.arange(G)
+    x = 1.0 + rng.integers(0, 9, size=ri.size).astype(np.float64)
+    M = sp.csc_matrix((x, ri, cp), shape=(G, N))
+    for mn in (0.0, 0.001):
+        res = gficf_amd.gficf(M, 1.0, mn, normalize=False, verbose=False)
+        ref = oracle.gficf_csc(G, N, cp, ri, x, mn, 1.0, threads=4)
+        check_against_oracle(res, ref, N)
+
+
 def test_golden_fixtures(golden_dir):
     z = np.load(os.path.join(golden_dir, "gficf_cases.npz"))
     for nm in ("g600_n400", "g300_n500_nofilter", "g500_n300_max"):
