@@ -6,19 +6,20 @@
 // (i+1, idx[i,j], u/(2k-u)), zero when u == 0.
 //
 // This is integer set work bounded by memory, not a contraction: no MFMA.  Design:
-//   * ingest  : the R matrix (column-major, int32 or double) is transposed once into a
-//               row-major int32 table with rows padded to KPAD in {16,32,64,128,256}
-//               entries, so that one neighbour row is one (or a few) contiguous 64..1024 B
-//               reads.  Ids are validated here; bit 31 of a row's first entry flags a
-//               row that holds duplicate ids (never the case for real kNN output).
-//   * edges   : one wave64 per cell.  Row i is staged in LDS as a 2-slot-bucket hash set
-//               (one ds_read_b64 per probe, no probing loop); 256/KPAD neighbour rows are
-//               gathered per wave-instruction (16 B per lane), every lane probes the set with
-//               its ids, and the per-edge intersection count is a DPP sum over the row's lanes.
-//               Weights come from a per-block LDS table W[u] = u/(2k-u) computed in IEEE
-//               double, so they are bit-identical to the reference's division.
-//   * rows with duplicate ids (multiset semantics), hash overflow: exact slow path in the
-//               same kernel (all-pairs with occurrence ranks).
+//   * ingest  : the R matrix (column-major, int32 or double) is transposed once into a row-major table, one row per
+//               cell, so that one neighbour row is one (or a few) contiguous 64..1024 B reads: wide rows (KPAD uint32
+//               ids, KPAD in {16,32,64,128,256}) or, below 2^17 cells, compact rows of half the bytes (pre-hashed 16-bit
+//               halves + a bitmap of bit 16; "table row formats" below).  Ids are validated here; one bit of a row
+//               flags a row that holds duplicate ids (never the case for real kNN output).
+//   * edges   : one wave64 per cell.  Row i is staged in LDS as a 2-slot-bucket hash set (one ds_read_b64 per
+//               probe, no probing loop); 4..16 neighbour rows are gathered per wave-instruction (16 B per lane), every
+//               lane probes the set with its ids, and the per-edge intersection count is a DPP sum over the row's
+//               lanes.  Weights come from a per-block LDS table W[u] = u/(2k-u) computed in IEEE double, so they are
+//               bit-identical to the reference's division.  For k <= 32 (k_jaccard_edges_pipe) a wave keeps two cells
+//               in flight and writes its edges four consecutive cells at a time; k_jaccard_edges is the general form.
+//   * rows with duplicate ids (multiset semantics): exact slow path (all-pairs with occurrence ranks), keys that
+//               overflow a bucket: a short per-wave list.
+// DESIGN.md section 3 has the measurements behind these choices (memory-only model, ablations, instruction rates).
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
