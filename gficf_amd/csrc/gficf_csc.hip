@@ -372,7 +372,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
                                                             double* __restrict__ out_x, int norm_l1,
                                                             uint32_t* zero_flag) {
   __shared__ double s_sum[SC_WAVES];
-  if (gkept_p && sl_fits(G, *gkept_p)) return;    // the LDS-resident variant handles this input
+  if (gkept_p && *gkept_p < 0xFFFF) return;       // the LDS-resident variant handles this input (launched whenever the row ids fit LDS)
   bool saw_zero = false;                          // an explicitly stored zero (see gficf_csc_device)
   __shared__ int32_t s_cnt[SC_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -522,28 +522,26 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
 constexpr int SL_THREADS = GFICF_SL_THREADS;     // (A/B of these two: profiles/r02_gficf_scale_ab.txt)
 constexpr int SL_CH = GFICF_SL_CH;               // chunks of 64 entries a wave keeps in registers
 constexpr int SL_LB = 8;                          // chunks per batch on the long-cell path
-__global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64_t n_cells,
-                                                                const int64_t* __restrict__ colptr,
-                                                                const int32_t* __restrict__ rowidx,
-                                                                const double* __restrict__ x,
-                                                                const gficf_gene_entry* __restrict__ genes,
-                                                                const int64_t* __restrict__ gkept_p,
-                                                                const int64_t* __restrict__ out_colptr,
-                                                                int32_t* __restrict__ out_rowidx,
-                                                                double* __restrict__ out_x, int norm_l1,
-                                                                uint32_t* zero_flag, int static_cells) {
+// W_LDS: the weights of the kept genes are staged in LDS too (they fit next to the row ids); otherwise they are read
+// from the gene table in global memory (8 G_kept bytes, L2-resident) — same kernel, same launch: the host cannot know
+// G_kept without a sync, and a second kernel that returns at once still costs 5 us plus a launch gap.
+template <bool W_LDS>
+__device__ inline void sl_body(int64_t G, int64_t n_cells, const int64_t* __restrict__ colptr, const int32_t* __restrict__ rowidx,
+                               const double* __restrict__ x, const gficf_gene_entry* __restrict__ genes, int64_t gkept,
+                               const int64_t* __restrict__ out_colptr, int32_t* __restrict__ out_rowidx,
+                               double* __restrict__ out_x, int norm_l1, uint32_t* zero_flag, int static_cells) {
   extern __shared__ unsigned char s_raw[];
   bool saw_zero = false;                          // an explicitly stored zero (see gficf_csc_device)
-  const int64_t gkept = *gkept_p;
-  if (!sl_fits(G, gkept)) return;                 // the global-gather variant handles this input
   uint16_t* const s_remap = reinterpret_cast<uint16_t*>(s_raw);
   double* const s_w = reinterpret_cast<double*>(s_raw + (((size_t)G * 2 + 15) & ~(size_t)15));
+  const double* const g_w = genes_wkept(genes, G);
+  auto weight = [&](int32_t r) -> double { return W_LDS ? s_w[r] : g_w[r]; };
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(genes_remap16(genes, G));
     uint32_t* dst = reinterpret_cast<uint32_t*>(s_remap);
     for (int64_t t = threadIdx.x; t < (G + 1) / 2; t += SL_THREADS) dst[t] = src[t];
-    const double* wk = genes_wkept(genes, G);
-    for (int64_t t = threadIdx.x; t < gkept; t += SL_THREADS) s_w[t] = wk[t];
+    if (W_LDS)
+      for (int64_t t = threadIdx.x; t < gkept; t += SL_THREADS) s_w[t] = g_w[t];
   }
   // Cells: the workgroup owns the contiguous range of cells that holds its share of the stored ENTRIES (cells differ in
   // length by a factor of several: a static deal of cells to waves leaves the last waves working alone for ~15 of the
@@ -604,7 +602,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
       for (int m = 0; m < SL_CH; ++m) {
         if (m < n_it) {
           double v = 0.0;
-          if (rv[m] >= 0 && Sc != 0.0) v = (xv[m] / Sc) * s_w[rv[m]];
+          if (rv[m] >= 0 && Sc != 0.0) v = (xv[m] / Sc) * weight(rv[m]);
           xv[m] = v;
           q += norm_l1 ? v : v * v;
         }
@@ -660,7 +658,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
           for (int m = 0; m < SL_LB; ++m) {
             const uint32_t g = (uint32_t)gz[m];
             const uint32_t r = g < (uint32_t)G ? (uint32_t)s_remap[g] : 0xFFFFu;
-            if (r != 0xFFFFu) { const double v = (xb[m] / Sc) * s_w[r]; q += norm_l1 ? v : v * v; }
+            if (r != 0xFFFFu) { const double v = (xb[m] / Sc) * weight((int32_t)r); q += norm_l1 ? v : v * v; }
           }
         }
       }
@@ -685,7 +683,7 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
             const unsigned long long mk = __ballot(kp);
             if (kp) {
               const int64_t dst = opos + __popcll(mk & lt_mask);
-              const double v = Sc != 0.0 ? nv * ((xb[m] / Sc) * s_w[r]) : 0.0;
+              const double v = Sc != 0.0 ? nv * ((xb[m] / Sc) * weight((int32_t)r)) : 0.0;
               __builtin_nontemporal_store((int32_t)r, out_rowidx + dst);
               __builtin_nontemporal_store(v, out_x + dst);
             }
@@ -696,6 +694,25 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
     }
   }
   if (zero_flag != nullptr && saw_zero) atomicOr(zero_flag, GFICF_ST_EXPLICIT_ZERO);
+}
+
+// mode: 0 = by the data (weights in LDS when they fit), 1 = test hook: weights from global memory whatever their size
+__global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64_t n_cells,
+                                                                const int64_t* __restrict__ colptr,
+                                                                const int32_t* __restrict__ rowidx,
+                                                                const double* __restrict__ x,
+                                                                const gficf_gene_entry* __restrict__ genes,
+                                                                const int64_t* __restrict__ gkept_p,
+                                                                const int64_t* __restrict__ out_colptr,
+                                                                int32_t* __restrict__ out_rowidx,
+                                                                double* __restrict__ out_x, int norm_l1,
+                                                                uint32_t* zero_flag, int static_cells, int mode) {
+  const int64_t gkept = *gkept_p;
+  if (gkept >= 0xFFFF) return;                    // new row ids do not fit 16 bits: the global-gather variant handles this input
+  if (mode == 0 && sl_fits(G, gkept))
+    sl_body<true>(G, n_cells, colptr, rowidx, x, genes, gkept, out_colptr, out_rowidx, out_x, norm_l1, zero_flag, static_cells);
+  else
+    sl_body<false>(G, n_cells, colptr, rowidx, x, genes, gkept, out_colptr, out_rowidx, out_x, norm_l1, zero_flag, static_cells);
 }
 
 __global__ __launch_bounds__(256) void k_zero_i64(int64_t* __restrict__ p, int64_t n) {
@@ -919,6 +936,7 @@ int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
   // Two variants, selected on the device by the number of kept genes (unknown to the host without a
   // sync): each kernel returns at once when the input is the other one's.
   static const bool force_global = getenv("GFICF_SCALE_FORCE_GLOBAL") != nullptr;   // test hook
+  static const bool force_semi = getenv("GFICF_SCALE_FORCE_SEMI") != nullptr;       // test hook: LDS variant, weights from global memory
   const bool try_lds = sl_fits(G, 0) && !force_global;     // else not even the row ids fit LDS
   if (try_lds) {
     static std::atomic<bool> attr_set[64];
@@ -930,9 +948,12 @@ int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
     if (blocks > ctx->num_cus) blocks = ctx->num_cus;
     hipLaunchKernelGGL(k_scale_cells_lds, dim3((unsigned)blocks), dim3(SL_THREADS), SL_LDS_BYTES, ctx->stream, G, n_cells,
                        d_colptr, d_rowidx, d_x, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x, ctx->norm_l1, ctx->cur_zero,
-                       getenv("GFICF_SCALE_STATIC_CELLS") != nullptr ? 1 : 0);       // test hook, read per call (A/B inside one process)
+                       getenv("GFICF_SCALE_STATIC_CELLS") != nullptr ? 1 : 0,       // test hook, read per call (A/B inside one process)
+                       force_semi ? 1 : 0);
   }
-  if (try_lds && sl_fits(G, G)) {                           // every possible number of kept genes fits: no second variant to offer
+  // The LDS variant takes every input whose new row ids fit 16 bits (G_kept < 65535, decided on the device); with fewer
+  // than 65535 genes that is every input, and the global-gather variant is not launched at all.
+  if (try_lds && G < 0xFFFF) {
     GFICF_HIP_CHECK(hipGetLastError());
     return GFICF_OK;
   }

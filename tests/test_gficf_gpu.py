@@ -244,9 +244,30 @@ def test_global_gather_variant_matches():
         "    assert np.array_equal(res['gficf'].indices, ref['rowidx']) and np.array_equal(res['gficf'].indptr, ref['colptr'])\n"
         "    assert np.allclose(res['gficf'].data, ref['x'], rtol=1e-6, atol=1e-6) and np.abs(res['gficf'].data - ref['x']).max() < 1e-12\n"
         "print('ok')\n")
-    env = dict(os.environ, GFICF_SCALE_FORCE_GLOBAL="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    # GFICF_SCALE_FORCE_SEMI: the LDS variant with the weights read from global memory (what it does by itself when the row
+    # ids fit LDS but the kept genes' weights do not, e.g. 23 k genes all kept; the second case below is that situation)
+    for hook in ("GFICF_SCALE_FORCE_GLOBAL", "GFICF_SCALE_FORCE_SEMI"):
+        env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        env[hook] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (hook, r.stderr[-2000:])
+
+
+def test_weights_that_do_not_fit_lds_next_to_the_row_ids():
+    """23 k genes, none dropped: the 16-bit row ids fit the LDS, the 23 k weights next to them do not — the LDS variant of the
+    scaling pass then reads the weights from global memory (no second kernel).  Long cells included (batched sweeps)."""
+    G, N = 23000, 600
+    cp, ri, x = synth.counts_csc(G, N, seed=77)
+    M = sp.csc_matrix((x, ri, cp), shape=(G, N))
+    res = gficf_amd.gficf(M, 1.0, 0.0, normalize=False, verbose=False)
+    ref = oracle.gficf_csc(G, N, cp, ri, x, 0.0, 1.0)
+    assert int(ref["keep"].sum()) > 15000          # more kept genes than fit LDS as doubles next to 46 KB of row ids
+    check_against_oracle(res, ref, N)
+    w_in = 0.25 + synth.rand_unit(9, np.arange(G))
+    out2, kept2 = gficf_amd.gficf_with_weights(M, w_in)
+    ref2 = oracle.gficf_csc(G, N, cp, ri, x, 0.0, 2.0, w_in=w_in)
+    assert np.array_equal(kept2, np.flatnonzero(ref2["keep"]))
+    assert np.array_equal(out2.indices, ref2["rowidx"]) and np.allclose(out2.data, ref2["x"], rtol=TOL, atol=TOL)
 
 
 def test_long_cells_take_the_batched_path():
