@@ -114,6 +114,56 @@ void gficf_set_error(const char* fmt, ...);
 
 __host__ __device__ static inline int64_t gficf_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+
+// ---------------------------------------------------------------- decoupled look-back over ticketed tiles (ctx->d_ws)
+// ws[0] is the ticket word (tiles are claimed in ticket order, so a tile's predecessors always belong to running
+// workgroups), ws[1 + t] tile t's descriptor:  bits 63..42 epoch | 41..40 status (1 = aggregate, 2 = inclusive prefix) |
+// 39..0 value, one 8-byte granule written by ONE store and polled with agent-scope loads (the data is the flag, valid
+// across XCDs).  The epoch (host counter, never 0; gficf_ws_next_epoch) tells a launch's descriptors from older ones, so
+// nothing is zeroed between launches; the workgroup that draws the last ticket resets the ticket word.
+constexpr int GFICF_LB_VALUE_BITS = 40;
+
+__device__ inline unsigned long long gficf_lb_desc(uint32_t epoch, uint32_t status, int64_t value) {
+  return ((unsigned long long)epoch << 42) | ((unsigned long long)status << GFICF_LB_VALUE_BITS) |
+         ((unsigned long long)value & ((1ull << GFICF_LB_VALUE_BITS) - 1ull));
+}
+
+// Called by the FIRST WAVE of a workgroup (all 64 lanes) that holds ticket `tile` and the tile's own `total`: publishes the
+// aggregate, sums the predecessors' (64 descriptors per round trip: lane l reads tile t0 - l; tiles before the first count
+// as an inclusive prefix of 0), publishes the inclusive prefix and returns the exclusive one (same value in every lane).
+__device__ inline int64_t gficf_lookback_exclusive(unsigned long long* ws, int64_t tile, int64_t n_tiles, uint32_t epoch, int64_t total) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long* const desc = ws + 1;
+  int64_t run = 0;
+  if (tile > 0) {
+    if (lane == 0) __hip_atomic_store(desc + tile, gficf_lb_desc(epoch, 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int64_t t0 = tile - 1;; t0 -= 64) {
+      const int64_t t = t0 - lane;
+      unsigned long long x = gficf_lb_desc(epoch, 2u, 0);
+      if (t >= 0) {
+        do {      // tickets are handed out in order: every earlier tile is running or done, its descriptor will appear
+          x = __hip_atomic_load(desc + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((uint32_t)(x >> 42) != epoch || ((x >> GFICF_LB_VALUE_BITS) & 3ull) == 0ull);
+      }
+      const unsigned long long incl = __ballot(((x >> GFICF_LB_VALUE_BITS) & 3ull) == 2ull);   // never 0 in the round that reaches tile 0
+      const int stop = incl ? __builtin_ctzll(incl) : 63;                                      // nearest inclusive prefix
+      int64_t v = lane <= stop ? (int64_t)(x & ((1ull << GFICF_LB_VALUE_BITS) - 1ull)) : 0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+      run += v;
+      if (incl) break;
+    }
+  }
+  if (lane == 0) {
+    __hip_atomic_store(desc + tile, gficf_lb_desc(epoch, 2u, run + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tile == n_tiles - 1) __hip_atomic_store(ws, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket is out
+  }
+  return run;
+}
+
+// Next epoch of the context's look-back workspace (zeroes the workspace on wrap); checks that n_tiles descriptors fit.
+int gficf_ws_next_epoch(gficf_ctx* ctx, int64_t n_tiles, uint32_t* epoch);
+
 // In-place exclusive scan of n int64 values on the context's stream (scan.hip).
 // One launch (decoupled look-back); uses ctx->d_ws.  Sums must stay below 2^40.
 int gficf_exclusive_scan_i64(gficf_ctx* ctx, int64_t* d_data, int64_t n);

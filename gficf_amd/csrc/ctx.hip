@@ -233,19 +233,7 @@ __device__ inline int64_t block_exclusive_scan(int64_t v, int64_t* total) {
   return r;
 }
 
-// Single-pass scan with decoupled look-back over tiles of SCAN_TILE elements.  Tiles are claimed by ticket
-// (ws[0]), so a tile's predecessors always belong to running workgroups; ws[1 + t] is tile t's descriptor
-//   bits 63..42 epoch | 41..40 status (1 = aggregate, 2 = inclusive prefix) | 39..0 value,
-// one 8-byte granule written by ONE write-through store and polled with agent-scope loads (the data is the flag,
-// valid across XCDs).  The epoch (host counter, never 0) tells this launch's descriptors from older ones, so
-// nothing has to be zeroed between launches; the workgroup that draws the last ticket resets the ticket word.
-constexpr int SCAN_VALUE_BITS = 40;
-
-__device__ inline unsigned long long scan_desc(uint32_t epoch, uint32_t status, int64_t value) {
-  return ((unsigned long long)epoch << 42) | ((unsigned long long)status << SCAN_VALUE_BITS) |
-         ((unsigned long long)value & ((1ull << SCAN_VALUE_BITS) - 1ull));
-}
-
+// Single-pass scan with decoupled look-back over tiles of SCAN_TILE elements (gficf_lookback_exclusive, common.h).
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(int64_t* __restrict__ d, int64_t n, unsigned long long* ws,
                                                                 uint32_t epoch, uint32_t* __restrict__ status) {
   __shared__ unsigned long long s_tile;
@@ -264,36 +252,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(int64_t* __restr
   int64_t total;
   int64_t ex = block_exclusive_scan(s, &total);
   if (threadIdx.x < 64) {
-    // look-back by the first wave, 64 descriptors at a time (one round trip instead of one per predecessor): lane l
-    // reads tile t0 - l; tiles before the first count as an inclusive prefix of 0
-    const int lane = threadIdx.x;
-    unsigned long long* const desc = ws + 1;
-    if (lane == 0 && (total < 0 || (total >> SCAN_VALUE_BITS) != 0)) atomicOr(status, GFICF_ST_BAD_CSC);    // counts out of range
-    int64_t run = 0;
-    if (tile > 0) {
-      if (lane == 0) __hip_atomic_store(desc + tile, scan_desc(epoch, 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int64_t t0 = tile - 1;; t0 -= 64) {
-        const int64_t t = t0 - lane;
-        unsigned long long x = scan_desc(epoch, 2u, 0);
-        if (t >= 0) {
-          do {      // tickets are handed out in order: every earlier tile is running or done, its descriptor will appear
-            x = __hip_atomic_load(desc + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } while ((uint32_t)(x >> 42) != epoch || ((x >> SCAN_VALUE_BITS) & 3ull) == 0ull);
-        }
-        const unsigned long long incl = __ballot(((x >> SCAN_VALUE_BITS) & 3ull) == 2ull);   // never 0 in the block that reaches tile 0
-        const int stop = incl ? __builtin_ctzll(incl) : 63;                                  // nearest inclusive prefix
-        int64_t v = lane <= stop ? (int64_t)(x & ((1ull << SCAN_VALUE_BITS) - 1ull)) : 0;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-        run += v;
-        if (incl) break;
-      }
-    }
-    if (lane == 0) {
-      __hip_atomic_store(desc + tile, scan_desc(epoch, 2u, run + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (tile == (int64_t)gridDim.x - 1) __hip_atomic_store(ws, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket is out
-      s_prefix = run;
-    }
+    if (threadIdx.x == 0 && (total < 0 || (total >> GFICF_LB_VALUE_BITS) != 0)) atomicOr(status, GFICF_ST_BAD_CSC);    // counts out of range
+    const int64_t run = gficf_lookback_exclusive(ws, tile, (int64_t)gridDim.x, epoch, total);
+    if (threadIdx.x == 0) s_prefix = run;
   }
   __syncthreads();
   ex += s_prefix;
@@ -306,17 +267,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(int64_t* __restr
 
 }  // namespace
 
-int gficf_exclusive_scan_i64(gficf_ctx* ctx, int64_t* d_data, int64_t n) {
-  if (n <= 0) return GFICF_OK;
-  const int64_t nb = gficf_ceil_div(n, SCAN_TILE);
-  if ((size_t)(nb + 1) * sizeof(unsigned long long) > ctx->ws_bytes)
-    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "scan of %lld elements exceeds the workspace", (long long)n);
+int gficf_ws_next_epoch(gficf_ctx* ctx, int64_t n_tiles, uint32_t* epoch) {
+  if ((size_t)(n_tiles + 1) * sizeof(unsigned long long) > ctx->ws_bytes)
+    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "%lld tiles exceed the look-back workspace", (long long)n_tiles);
   if (++ctx->scan_epoch >= (1u << 22)) {            // epoch wrap: start over from clean descriptors
     GFICF_HIP_CHECK(hipMemsetAsync(ctx->d_ws, 0, ctx->ws_bytes, ctx->stream));
     ctx->scan_epoch = 1;
   }
+  *epoch = ctx->scan_epoch;
+  return GFICF_OK;
+}
+
+int gficf_exclusive_scan_i64(gficf_ctx* ctx, int64_t* d_data, int64_t n) {
+  if (n <= 0) return GFICF_OK;
+  const int64_t nb = gficf_ceil_div(n, SCAN_TILE);
+  uint32_t epoch = 0;
+  const int rc = gficf_ws_next_epoch(ctx, nb, &epoch);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_scan_lookback, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_data, n, (unsigned long long*)ctx->d_ws,
-                     ctx->scan_epoch, ctx->d_status);
+                     epoch, ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }

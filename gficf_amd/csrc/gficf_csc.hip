@@ -207,6 +207,61 @@ __global__ __launch_bounds__(GT_THREADS) void k_gene_table(int64_t G, int64_t N_
   }
 }
 
+// Row sum and gene table in one launch (the fused sequence, gficf_csc_device): the workgroup that has summed a tile of
+// 64 genes also knows how many of them are kept; the new row ids need the kept genes in front of the tile, which come from a
+// look-back over the earlier tiles' counts (gficf_lookback_exclusive; tiles taken in ticket order) instead of a second
+// launch that counts them again.  Writes nt, keep, w, the gene records and the compact tables, and the number of kept genes.
+__global__ __launch_bounds__(NS_WAVES * 64) void k_nt_sum_table(const uint32_t* __restrict__ part, int64_t Gp, int rows, int64_t G,
+                                                                int64_t N_total, double prop_min, double prop_max,
+                                                                const double* __restrict__ w_in, unsigned long long* __restrict__ nt,
+                                                                uint8_t* __restrict__ keep, gficf_gene_entry* __restrict__ genes,
+                                                                double* __restrict__ w, int64_t* __restrict__ gkept, int icf_type,
+                                                                unsigned long long* ws, uint32_t epoch) {
+  __shared__ uint32_t s_acc[NS_WAVES][64];
+  __shared__ unsigned long long s_tile;
+  if (threadIdx.x == 0) s_tile = atomicAdd(&ws[0], 1ull);
+  __syncthreads();
+  const int64_t tile = (int64_t)s_tile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t g = tile * 64 + lane;
+  uint32_t acc = 0;
+  if (g < G) {
+#pragma unroll 8
+    for (int r = wave; r < rows; r += NS_WAVES) acc += part[(int64_t)r * Gp + g];
+  }
+  s_acc[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  uint32_t t = 0;
+#pragma unroll
+  for (int wv = 0; wv < NS_WAVES; ++wv) t += s_acc[wv][lane];
+  const double c = (double)t;
+  const bool kp = g < G && c > (double)N_total * prop_min && c <= (double)N_total * prop_max;   // R/gficf.R:41, comparison in double
+  const unsigned long long m = __ballot(kp);
+  const int64_t before = gficf_lookback_exclusive(ws, tile, (int64_t)gridDim.x, epoch, (int64_t)__popcll(m));
+  if (lane == 0 && tile == (int64_t)gridDim.x - 1) *gkept = before + __popcll(m);
+  if (g < G) {
+    const int64_t r = before + __popcll(m & ((1ull << lane) - 1ull));
+    double wv = 0.0;
+    if (kp) {
+      if (w_in) wv = w_in[g];
+      else if (icf_type == 1) wv = log(((double)N_total - c) / c);               // "prob"    R/gficf.R:90
+      else if (icf_type == 2) wv = log(1.0 + (double)N_total / c);               // "smooth"  R/gficf.R:91
+      else wv = log(((double)N_total + 1.0) / (c + 1.0));                        // "classic" R/gficf.R:89
+    }
+    nt[g] = t;
+    keep[g] = kp ? 1 : 0;
+    w[g] = wv;
+    gficf_gene_entry e;
+    e.w = wv;
+    e.remap = kp ? (int32_t)r : -1;
+    e.reserved = 0;
+    genes[g] = e;
+    if (kp) genes_wkept(genes, G)[r] = wv;
+    genes_remap16(genes, G)[g] = (kp && r < 0xFFFF) ? (uint16_t)r : (uint16_t)0xFFFF;
+  }
+}
+
 // The contiguous range of cells that holds share number `share` (of gridDim.x) of the stored entries: range[0] = the smallest
 // cell c with colptr[c] >= nnz * share / shares, range[1] the same for share + 1 (the last share ends with the last cell).  Called
 // by the first wave of the workgroup: a 32-way search, lanes 0..31 for the start, 32..63 for the end (3-4 dependent loads).
@@ -828,9 +883,11 @@ __global__ __launch_bounds__(256) void k_sig_sum(int64_t G, const int64_t* __res
 // ----------------------------------------------------------------------------- C ABI
 extern "C" {
 
-// overwrite: d_nt need not be zeroed (the LDS-histogram form then writes every counter; *overwrote says whether it did)
+// sum_mode (LDS-histogram form): 0 = d_nt[g] += the row sum (the C ABI's count step), 1 = d_nt[g] = it (d_nt need not be
+// zeroed), 2 = no row sum here: the caller runs k_nt_sum_table on *part_out / *rows_out.
 static int launch_count(gficf_ctx* ctx, int64_t G, const int32_t* d_rowidx, const double* d_x, int64_t nnz, int64_t* d_nt,
-                        bool overwrite = false) {
+                        int sum_mode = 0, uint32_t** part_out = nullptr, int* rows_out = nullptr) {
+  const bool overwrite = sum_mode == 1;
   int64_t blocks = gficf_ceil_div(nnz, (int64_t)CNT_THREADS * 16);
   // 16 B vector loads need 16 B-aligned bases (slab starts are multiples of 16384 entries)
   const bool vec = (((uintptr_t)d_rowidx | (uintptr_t)d_x) & 15u) == 0;
@@ -872,7 +929,8 @@ static int launch_count(gficf_ctx* ctx, int64_t G, const int32_t* d_rowidx, cons
     default: LAUNCH_CNT(false, false, false); break;
   }
 #undef LAUNCH_CNT
-  if (lds_hist) {
+  if (part_out) { *part_out = d_part; *rows_out = (int)blocks; }
+  if (lds_hist && sum_mode != 2) {
     if (overwrite)
       hipLaunchKernelGGL(k_nt_sum<false>, dim3((unsigned)gficf_ceil_div(G, 64)), dim3(NS_WAVES * 64), 0, ctx->stream, d_part, Gp,
                          (int)blocks, G, (unsigned long long*)d_nt);
@@ -1065,11 +1123,30 @@ static int csc_sequence(gficf_ctx* ctx, bool exact, int64_t G, int64_t N, const 
   const bool count_writes_all = nnz > 0 && G > 0 && G <= CNT_LDS_MAX_G;
   if (G > 0 && !count_writes_all) GFICF_HIP_CHECK(hipMemsetAsync(d_nt, 0, sizeof(int64_t) * (size_t)G, ctx->stream));
   int rc = GFICF_OK;
+  bool table_done = false;
   if (nnz > 0 && G > 0) {
     if (!d_rowidx || !d_x || !d_nt) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
-    rc = launch_count(ctx, G, d_rowidx, exact ? d_x : (const double*)nullptr, nnz, d_nt, count_writes_all);
+    if (count_writes_all) {
+      // count, then row sum + gene table in ONE launch (k_nt_sum_table)
+      if (!d_gkept || !d_keep || !d_genes || !d_w) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+      uint32_t* d_part = nullptr;
+      int rows = 0;
+      rc = launch_count(ctx, G, d_rowidx, exact ? d_x : (const double*)nullptr, nnz, d_nt, 2, &d_part, &rows);
+      const int64_t tiles = gficf_ceil_div(G, 64);
+      uint32_t epoch = 0;
+      if (!rc) rc = gficf_ws_next_epoch(ctx, tiles, &epoch);
+      if (!rc) {
+        hipLaunchKernelGGL(k_nt_sum_table, dim3((unsigned)tiles), dim3(NS_WAVES * 64), 0, ctx->stream, d_part, (G + 3) & ~(int64_t)3, rows, G, N,
+                           prop_min, prop_max, d_w_in, (unsigned long long*)d_nt, d_keep, d_genes, d_w, d_gkept, ctx->icf_type,
+                           (unsigned long long*)ctx->d_ws, epoch);
+        GFICF_HIP_CHECK(hipGetLastError());
+        table_done = true;
+      }
+    } else {
+      rc = launch_count(ctx, G, d_rowidx, exact ? d_x : (const double*)nullptr, nnz, d_nt, 0);
+    }
   }
-  if (!rc) rc = gficf_csc_genes_device(ctx, G, N, d_nt, prop_min, prop_max, d_w_in, d_keep, d_genes, d_w, d_gkept);
+  if (!rc && !table_done) rc = gficf_csc_genes_device(ctx, G, N, d_nt, prop_min, prop_max, d_w_in, d_keep, d_genes, d_w, d_gkept);
   if (!rc) rc = gficf_csc_colptr_device(ctx, G, N, d_colptr, d_rowidx, d_keep, d_gkept, d_out_colptr);
   ctx->cur_zero = exact ? nullptr : ctx->d_status;
   if (!rc) rc = gficf_csc_scale_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x);
