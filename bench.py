@@ -529,7 +529,7 @@ def main():
                                "achieved": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_PEAK_GBS, 4),
                                "frac_of_copy_rate": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_COPY_GBS, 4),
-                               "traffic": (sum(pmc[kk]["hbm_bytes_per_launch"] for kk in ("gene_count", "nt_sum", "gene_table", "cell_kept_count", "scan_lookback", "scale_cells", "scale_cells_lds") if kk in pmc)
+                               "traffic": (sum(pmc[kk]["hbm_bytes_per_launch"] for kk in ("gene_count", "nt_sum_table", "cell_kept_count", "scan_lookback", "scale_cells_lds") if kk in pmc)
                                            if all(kk in pmc for kk in ("gene_count", "cell_kept_count")) and nnz == 59809258 else None),
                                "scale_kernel_ms": round(t_scale, 4), "count_exact_kernel_ms": round(t_count, 4),
                                "count_note": "count_exact_kernel_ms is gficf_csc_count_device (reads x: 12 B/nnz), the form the sharded and host entries use; the timed pass (gficf_csc_device) counts stored entries without reading x (about half that time, see the rocprof summary)",
