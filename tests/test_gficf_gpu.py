@@ -246,7 +246,8 @@ def test_global_gather_variant_matches():
         "print('ok')\n")
     # GFICF_SCALE_FORCE_SEMI: the LDS variant with the weights read from global memory (what it does by itself when the row
     # ids fit LDS but the kept genes' weights do not, e.g. 23 k genes all kept; the second case below is that situation)
-    for hook in ("GFICF_SCALE_FORCE_GLOBAL", "GFICF_SCALE_FORCE_SEMI"):
+    # GFICF_SCALE_STATIC_CELLS: the round-robin deal of cells to waves (the A/B partner of the entry-balanced ranges)
+    for hook in ("GFICF_SCALE_FORCE_GLOBAL", "GFICF_SCALE_FORCE_SEMI", "GFICF_SCALE_STATIC_CELLS"):
         env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         env[hook] = "1"
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
