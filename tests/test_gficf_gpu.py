@@ -94,6 +94,24 @@ def test_skewed_cell_lengths_above_the_range_search_threshold(shape):
         check_against_oracle(res, ref, N)
 
 
+def test_filter_boundaries_hand_derived():
+    """Strict below, inclusive above (R/gficf.R:41), on counts that sit exactly on N*min and N*max; expectations by hand,
+    not from the oracle (tests/test_oracle.py holds the same case for the oracle)."""
+    N = 20
+    nts = [0, 1, 2, 9, 10, 11, 20]
+    M = np.zeros((len(nts), N))
+    for g, n in enumerate(nts):
+        M[g, :n] = 1.0
+    res = gficf_amd.gficf(sp.csc_matrix(M), 0.5, 0.05, normalize=False, verbose=False)
+    assert res["genes"].tolist() == [2, 3, 4]
+    assert res["nt"].tolist() == [2, 9, 10]
+    w = np.log(21.0 / (np.array([2, 9, 10]) + 1.0))
+    assert np.allclose(res["w"], w, rtol=1e-14)
+    D = res["gficf"].toarray()
+    assert np.allclose(D[:, 0], (w / 3) / np.sqrt(((w / 3) ** 2).sum()), rtol=1e-13)
+    assert D[:, 9].tolist() == [0.0, 0.0, 1.0] and not D[:, 10:].any()
+
+
 def test_golden_fixtures(golden_dir):
     z = np.load(os.path.join(golden_dir, "gficf_cases.npz"))
     for nm in ("g600_n400", "g300_n500_nofilter", "g500_n300_max"):

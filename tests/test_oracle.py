@@ -192,6 +192,39 @@ def test_gficf_threads_do_not_change_results():
         oracle.gficf_csc(2, 3, colptr, np.array([0, 5, 0, 1], dtype=np.int32), x, 0.0, 1.0, threads=2)
 
 
+def _boundary_matrix():
+    """20 cells; gene g is present (value 1) in the first nt[g] cells.  With min = 0.05 (N*min = 1.0) and max = 0.5 (N*max = 10.0)
+    the reference keeps a gene iff nt > 1.0 and nt <= 10.0 (R/gficf.R:41: strict below, inclusive above)."""
+    N = 20
+    nts = [0, 1, 2, 9, 10, 11, 20]
+    M = np.zeros((len(nts), N))
+    for g, n in enumerate(nts):
+        M[g, :n] = 1.0
+    keep = np.array([False, False, True, True, True, False, False])     # by hand from the two inequalities
+    return sp.csc_matrix(M), np.array(nts), keep
+
+
+def test_gficf_filter_boundaries_hand_derived():
+    M, nts, keep = _boundary_matrix()
+    G, N = M.shape
+    r = oracle.gficf_csc(G, N, M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data, 0.05, 0.5)
+    assert r["keep"].tolist() == keep.tolist()
+    assert r["nt"].tolist() == [0, 0, 2, 9, 10, 0, 0]                 # nt of dropped genes is reported as 0
+    # closed form: kept genes 2, 3, 4 with nt 2, 9, 10; w = log(21 / (nt + 1)); cell 0 holds all three with x = 1:
+    # tf = 1/3 each, value_g = w_g / 3, then divided by the cell's L2 norm
+    w = np.log(21.0 / (np.array([2, 9, 10]) + 1.0))
+    assert np.allclose(r["w"][keep], w, rtol=1e-15)
+    col0 = r["x"][r["colptr"][0]:r["colptr"][1]]
+    assert np.allclose(col0, (w / 3) / np.sqrt(((w / 3) ** 2).sum()), rtol=1e-14)
+    # cell 9 (10th) holds genes with nt >= 10 among the kept ones: only gene 4 -> a single entry of value 1
+    col9 = r["x"][r["colptr"][9]:r["colptr"][10]]
+    assert col9.tolist() == [1.0]
+    # cells 10..19 hold no kept gene
+    assert r["colptr"][10] == r["colptr"][20]
+    r2 = oracle_np.gficf_np(M, 0.05, 0.5)
+    assert np.array_equal(r2["keep"], keep)
+
+
 def test_gficf_golden(golden_dir):
     z = np.load(os.path.join(golden_dir, "gficf_cases.npz"))
     for nm in ("g600_n400", "g300_n500_nofilter", "g500_n300_max"):
