@@ -18,8 +18,9 @@ Workloads (`--config`, named in config.workload):
   c4 / c5    BASELINE configs 4 / 5: ONE data set (100 000 x k = 50 / 1 000 000 x k = 30) split over the ranks by cell
              block — strong scaling.
 
-Launch: `python bench.py` (1 GPU) or
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
+Launch: `python bench.py` (1 GPU); for N > 1 either
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`
+or plain `python bench.py --gpus N`, which starts its own N ranks (gficf_amd/launch.py) before anything touches a GPU.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -254,6 +255,15 @@ def bench_knn(torch, ops, args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and never touches a
+        # GPU itself; rank 0 prints the JSON line straight to our stdout.  (Under torch.distributed.run the rank
+        # environment is already there and this branch is not taken.)
+        from gficf_amd import launch
+
+        raise SystemExit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                            need_gpus=None if args.rehearse_one_gpu else args.gpus,
+                                            timeout_s=float(os.environ.get("GFICF_BENCH_LAUNCH_TIMEOUT", "1500"))))
     import torch
     import torch.distributed as dist
 
@@ -265,11 +275,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree (plain `python bench.py --gpus N` starts its own ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (gficf_amd has no CPU fallback)")
     if args.rehearse_one_gpu:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
+                         "(one rank per GPU; --rehearse-one-gpu shares device 0 over gloo)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         if args.rehearse_one_gpu:
@@ -426,14 +439,29 @@ def main():
 
     extras = not args.no_extras and not strong
     shard = shards[0]
-    if rank == 0 and world == 1 and extras:
-        if True:
-            # one step against the oracle on a bounded sample of source cells (checker only)
-            import oracle
+    if rank == 0:
+        # every line carries a check against the oracle (checker only, after the timed region): the whole matrix of data
+        # set 0 when that takes seconds (one GPU, <= 200 k cells, extras on), otherwise a bounded sample of this rank's
+        # cells — three runs of 1024 consecutive source cells at the start, the middle and the end of its block
+        import oracle
 
-            rm = shard.out.cpu().numpy().T
-            want, _ = oracle.jaccard(mat, nthreads=os.cpu_count() or 1) if N_total <= 200_000 else (None, None)
-            out["checked_vs_oracle"] = bool(np.array_equal(rm, want)) if want is not None else None      # None: not checked at this size
+        cores = os.cpu_count() or 1
+        if world == 1 and extras and N_total <= 200_000:
+            want, _ = oracle.jaccard(mat, nthreads=cores)
+            ok, checked = bool(np.array_equal(shard.out.cpu().numpy().T, want)), N_total
+            del want
+        else:
+            run = min(1024, n_local)
+            ok, checked = True, 0
+            for c0 in sorted({b, b + (n_local - run) // 2, e - run}):
+                want, _ = oracle.jaccard_cells(mat, c0, c0 + run, nthreads=cores)
+                got = shard.out[:, (c0 - b) * k:(c0 - b + run) * k].cpu().numpy().T
+                ok = ok and bool(np.array_equal(got, want))
+                checked += run
+        out["checked_vs_oracle"] = ok
+        out["oracle_check"] = {"cells": checked, "of": n_local, "kind": "whole matrix" if checked == N_total else "sample of source cells",
+                               "what": "bit-exact rows of the reference's (N*k) x 3 matrix, data set 0"}
+    if rank == 0 and world == 1 and extras:
         if not args.no_cpu_baseline:
             import oracle
 

@@ -293,9 +293,14 @@ def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx, icf_type="classic", no
     G, N = M.shape
     L = _lib.load()
     mc = _multi(devices) if ctx is None else None
-    if mc is not None:
-        if icf_type != "classic" or norm != "l2":
+    if mc is not None and (icf_type != "classic" or norm != "l2"):
+        # the multi-GPU entry runs gficf() as the reference calls it (icf_type classic, norm l2).  A device list passed
+        # by the caller together with other options is a contradiction; one that only came from GFICF_HIP_DEVICES must
+        # not break a call that works without the variable: the helper branches run on the default device.
+        if devices is not None:
             raise ValueError("the multi-GPU entry runs gficf() as the reference calls it: icf_type classic, norm l2")
+        mc = None
+    if mc is not None:
         return _normalize_csc_host_run(L, mc, M, colptr, rowidx, x, G, N, prop_min, prop_max, w_in,
                                        L.gficf_normalize_csc_host_multi_plan, L.gficf_normalize_csc_host_multi_finish)
     ctx = ctx or default_context()
@@ -803,17 +808,33 @@ class HipOps:
             out_x=tc.zeros(max(nnz, 1), dtype=tc.float64, device=dev),
         )
 
-    def gficf_csc(self, G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None, ws=None, exact: bool = False) -> dict:
+    def gficf_csc(self, G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None, ws=None, exact: bool = False,
+                  auto_exact: bool = False) -> dict:
         """Single-GPU GF-ICF on a device-resident CSC matrix (colptr int64).  Returns the workspace dict;
         ``out_colptr[N]`` is the kept nnz, ``gkept[0]`` the number of kept genes.
 
         ``exact=False``: the count pass does not read ``x`` (stored entries are taken for non-zero cells); if the matrix
         stores explicit zeros the next :meth:`sync` raises ``GFICF_ERR_EXPLICIT_ZEROS`` and the call is to be repeated
-        with ``exact=True`` (the count pass reads ``x``: ``rowSums(M != 0)``, reference R/gficf.R:40,88)."""
+        with ``exact=True`` (the count pass reads ``x``: ``rowSums(M != 0)``, reference R/gficf.R:40,88).
+        ``auto_exact=True`` does that here: the call synchronises, and if — and only if — the deferred status is
+        ``GFICF_ERR_EXPLICIT_ZEROS`` the exact form runs in its place (any other deferred error of the same sync has
+        precedence in ``gficf_ctx_sync`` and propagates); what returns is then complete and checked.  A caller that keeps
+        the pass asynchronous (the bench's timed loop) leaves it off and owes the sync + retry itself."""
         ws = ws or self.csc_workspace(G, N, int(rowidx.numel()))
-        fn = self.L.gficf_csc_exact_device if exact else self.L.gficf_csc_device
-        check(fn(self._bind(), G, N, _tptr(colptr), _tptr(rowidx), _tptr(x), int(rowidx.numel()),
-                                      float(prop_min), float(prop_max), _tptr(w_in), _tptr(ws["nt"]),
-                                      _tptr(ws["keep"]), _tptr(ws["genes"]), _tptr(ws["w"]), _tptr(ws["gkept"]),
-                                      _tptr(ws["out_colptr"]), _tptr(ws["out_rowidx"]), _tptr(ws["out_x"])))
+
+        def run(fn):
+            check(fn(self._bind(), G, N, _tptr(colptr), _tptr(rowidx), _tptr(x), int(rowidx.numel()),
+                     float(prop_min), float(prop_max), _tptr(w_in), _tptr(ws["nt"]),
+                     _tptr(ws["keep"]), _tptr(ws["genes"]), _tptr(ws["w"]), _tptr(ws["gkept"]),
+                     _tptr(ws["out_colptr"]), _tptr(ws["out_rowidx"]), _tptr(ws["out_x"])))
+
+        run(self.L.gficf_csc_exact_device if exact else self.L.gficf_csc_device)
+        if auto_exact:
+            try:
+                self.sync()
+            except GficfError as ex:
+                if exact or ex.code != 9:                       # 9 = GFICF_ERR_EXPLICIT_ZEROS
+                    raise
+                run(self.L.gficf_csc_exact_device)
+                self.sync()
         return ws

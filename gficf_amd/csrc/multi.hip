@@ -2,8 +2,10 @@
 //
 // What an R session can bind: the reference's call sites are one `.Call` each (R/clustCells.R:65 for the Jaccard
 // build, gficf() R/gficf.R:17-33 for the normalisation), so a drop-in that shards over the GPUs of a node has to do
-// it underneath that one call — one host thread, one context and one stream per device, everything asynchronous
-// until the final wait.  The partitioning is the one of the multi-process path (gficf_amd/dist.py):
+// it underneath that one call — one context and one stream per device, and ONE HOST THREAD PER DEVICE for every stage
+// that moves host data (the caller's buffers are pageable: hipMemcpyAsync from or to pageable memory holds the calling
+// thread until the copy is done, so a single thread would run the devices one after another); the threads are joined
+// before the call returns and never touch the R API.  The partitioning is the one of the multi-process path (gficf_amd/dist.py):
 //   * Jaccard: cells in contiguous equal-pitch blocks; every device uploads and ingests ITS block of the kNN
 //     matrix, the table rows are exchanged device to device (hipMemcpyPeerAsync over xGMI, pulled by the receiving
 //     device on its own stream behind an event of the sending one; with no peer access every device ingests the
@@ -15,6 +17,8 @@
 //     then run per block and the kept entries land at their offsets in the caller's arrays.
 // Kernels and arithmetic are those of the single-device entries: same bits.
 #include <cstring>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -73,6 +77,21 @@ int hip_fail(const char* what, hipError_t e) {
   return GFICF_ERR_HIP;
 }
 
+// One stage of a multi-device entry: body(r) for every device r, each on its own host thread (inline for one device),
+// joined before returning.  body returns a gficf_status; its message is thread-local to the worker, so the worker keeps
+// a copy and the first failing device (in device order) is the one reported.  A stage is skipped once `fe` holds an error.
+void for_each_device(int P, FirstError& fe, const std::function<int(int)>& body) {
+  if (fe.rc != GFICF_OK) return;
+  if (P == 1) { fe.note(body(0)); return; }
+  std::vector<FirstError> each((size_t)P);
+  std::vector<std::thread> th;
+  th.reserve((size_t)P);
+  for (int r = 0; r < P; ++r) th.emplace_back([&, r]() { each[(size_t)r].note(body(r)); });
+  for (auto& t : th) t.join();
+  for (int r = 0; r < P && fe.rc == GFICF_OK; ++r)
+    if (each[(size_t)r].rc != GFICF_OK) { fe.rc = each[(size_t)r].rc; snprintf(fe.msg, sizeof(fe.msg), "%s", each[(size_t)r].msg); }
+}
+
 }  // namespace
 
 extern "C" {
@@ -128,7 +147,12 @@ int gficf_multi_create(const int* devices, int ndev, gficf_multi** out) {
     hipError_t e = hipSetDevice(d);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    if (e != hipSuccess) { gficf_multi_destroy(m); return hip_fail("stream / event creation", e); }
+    if (e != hipSuccess) {
+      if (ev) (void)hipEventDestroy(ev);             // not yet owned by m
+      if (st) (void)hipStreamDestroy(st);
+      gficf_multi_destroy(m);
+      return hip_fail("stream / event creation", e);
+    }
     m->dev.push_back(d);
     m->stream.push_back(st);
     m->ev.push_back(ev);
@@ -196,8 +220,9 @@ int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, in
     std::vector<int32_t*> d_table(P, nullptr);
     std::vector<double*> d_out(P, nullptr);
     FirstError fe;
-    // 1. upload + ingest: each device its own block (peer exchange) or the whole matrix (no peer access)
-    for (int r = 0; r < P && fe.rc == GFICF_OK; ++r) {
+    // 1. upload + ingest: each device its own block (peer exchange) or the whole matrix (no peer access); one host
+    //    thread per device, so the uploads of the pageable matrix run side by side
+    for_each_device(P, fe, [&](int r) -> int {
       gficf_ctx* c = m->ctx[r];
       const int64_t n = bd[r + 1] - bd[r];
       hipError_t e = hipSetDevice(m->dev[r]);
@@ -208,13 +233,17 @@ int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, in
       if (e == hipSuccess && rows_up > 0)     // k columns of rows_up ids out of the column-major matrix (leading dimension ld)
         e = hipMemcpy2DAsync(d_idx[r], esz * (size_t)rows_up, (const char*)idx + esz * (size_t)row0, esz * (size_t)ld, esz * (size_t)rows_up,
                              (size_t)k, hipMemcpyHostToDevice, m->stream[r]);
-      if (e != hipSuccess) { fe.note(hip_fail("upload of the kNN block", e)); break; }
-      if (rows_up > 0) fe.note(gficf_jaccard_ingest_device(c, d_idx[r], idx_is_f64, rows_up, k, rows_up, N, d_table[r] + (size_t)row0 * roww));
-      if (fe.rc == GFICF_OK && m->peer) {
-        e = hipEventRecord(m->ev[r], m->stream[r]);
-        if (e != hipSuccess) fe.note(hip_fail("hipEventRecord", e));
+      if (e != hipSuccess) return hip_fail("upload of the kNN block", e);
+      if (rows_up > 0) {
+        const int rc = gficf_jaccard_ingest_device(c, d_idx[r], idx_is_f64, rows_up, k, rows_up, N, d_table[r] + (size_t)row0 * roww);
+        if (rc) return rc;
       }
-    }
+      if (m->peer) {
+        e = hipEventRecord(m->ev[r], m->stream[r]);
+        if (e != hipSuccess) return hip_fail("hipEventRecord", e);
+      }
+      return GFICF_OK;
+    });
     // 2. exchange: every device pulls the other blocks' table rows behind their ingest
     if (fe.rc == GFICF_OK && m->peer && P > 1) {
       for (int d = 0; d < P && fe.rc == GFICF_OK; ++d) {
@@ -230,19 +259,22 @@ int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, in
         if (e != hipSuccess) fe.note(hip_fail("exchange of table rows", e));
       }
     }
-    // 3. edges of the own block, straight into the three column slices of rmat
-    for (int r = 0; r < P && fe.rc == GFICF_OK; ++r) {
+    // 3. edges of the own block, straight into the three column slices of rmat (a host thread per device: the
+    //    device-to-host copies into the pageable result hold their thread)
+    for_each_device(P, fe, [&](int r) -> int {
       const int64_t n = bd[r + 1] - bd[r];
-      if (n <= 0) continue;
+      if (n <= 0) return GFICF_OK;
       hipError_t e = hipSetDevice(m->dev[r]);
+      if (e != hipSuccess) return hip_fail("hipSetDevice", e);
       const size_t ne = (size_t)n * (size_t)k;
-      if (e == hipSuccess)
-        fe.note(gficf_jaccard_edges_device(m->ctx[r], d_table[r], N, k, bd[r], bd[r + 1], d_out[r], d_out[r] + ne, d_out[r] + 2 * ne, nullptr));
-      for (int col = 0; col < 3 && e == hipSuccess && fe.rc == GFICF_OK; ++col)
+      const int rc = gficf_jaccard_edges_device(m->ctx[r], d_table[r], N, k, bd[r], bd[r + 1], d_out[r], d_out[r] + ne, d_out[r] + 2 * ne, nullptr);
+      if (rc) return rc;
+      for (int col = 0; col < 3 && e == hipSuccess; ++col)
         e = hipMemcpyAsync(rmat + (size_t)col * (size_t)E + (size_t)bd[r] * (size_t)k, d_out[r] + (size_t)col * ne, sizeof(double) * ne,
                            hipMemcpyDeviceToHost, m->stream[r]);
-      if (e != hipSuccess) fe.note(hip_fail("download of the edge block", e));
-    }
+      if (e != hipSuccess) return hip_fail("download of the edge block", e);
+      return GFICF_OK;
+    });
     // 4. wait for every device (also on failure: nothing may still read the caller's buffers) and collect deferred errors
     for (int r = 0; r < P; ++r) fe.note(gficf_ctx_sync(m->ctx[r]));
     const int rc = fe.done();
@@ -283,8 +315,8 @@ int gficf_normalize_csc_host_multi_plan(gficf_multi* m, int64_t G, int64_t N, co
   const size_t gsz = (size_t)(G > 0 ? G : 1);
   std::vector<std::vector<int64_t>> cpl((size_t)P), ntl((size_t)P);
   FirstError fe;
-  // 1. per block: upload, count
-  for (int r = 0; r < P && fe.rc == GFICF_OK; ++r) {
+  // 1. per block: upload, count (a host thread per device: the uploads of the pageable matrix run side by side)
+  for_each_device(P, fe, [&](int r) -> int {
     gficf_multi_block& B = m->blk[r];
     gficf_ctx* c = m->ctx[r];
     B.b = bd[r]; B.e = bd[r + 1]; B.p0 = cp[(size_t)B.b]; B.p1 = cp[(size_t)B.e];
@@ -300,7 +332,7 @@ int gficf_normalize_csc_host_multi_plan(gficf_multi* m, int64_t G, int64_t N, co
     const size_t o_w = ar.take(sizeof(double) * gsz), o_gk = ar.take(sizeof(int64_t)), o_ocp = ar.take(sizeof(int64_t) * ((size_t)n + 1));
     const size_t o_win = ar.take(sizeof(double) * gsz);
     if (e == hipSuccess) e = ar.bind(c, 4);
-    if (e != hipSuccess) { fe.note(hip_fail("device buffers of the GF-ICF block", e)); break; }
+    if (e != hipSuccess) return hip_fail("device buffers of the GF-ICF block", e);
     B.d_colptr = ar.at<int64_t>(o_cp); B.d_rowidx = ar.at<int32_t>(o_ri); B.d_x = ar.at<double>(o_x);
     B.d_nt = ar.at<int64_t>(o_nt); B.d_keep = ar.at<uint8_t>(o_keep); B.d_genes = ar.at<gficf_gene_entry>(o_genes);
     B.d_w = ar.at<double>(o_w); B.d_gkept = ar.at<int64_t>(o_gk); B.d_out_colptr = ar.at<int64_t>(o_ocp);
@@ -311,13 +343,15 @@ int gficf_normalize_csc_host_multi_plan(gficf_multi* m, int64_t G, int64_t N, co
     if (e == hipSuccess && nz > 0) e = hipMemcpyAsync(B.d_x, x + B.p0, sizeof(double) * (size_t)nz, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && B.d_w_in) e = hipMemcpyAsync(B.d_w_in, w_in, sizeof(double) * (size_t)G, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(B.d_nt, 0, sizeof(int64_t) * gsz, st);
-    if (e != hipSuccess) { fe.note(hip_fail("upload of the GF-ICF block", e)); break; }
-    fe.note(gficf_csc_count_device(c, G, n, B.d_colptr, B.d_rowidx, B.d_x, nz, B.d_nt));
-    if (fe.rc == GFICF_OK && G > 0) {
+    if (e != hipSuccess) return hip_fail("upload of the GF-ICF block", e);
+    const int rc = gficf_csc_count_device(c, G, n, B.d_colptr, B.d_rowidx, B.d_x, nz, B.d_nt);
+    if (rc) return rc;
+    if (G > 0) {
       e = hipMemcpyAsync(ntl[r].data(), B.d_nt, sizeof(int64_t) * (size_t)G, hipMemcpyDeviceToHost, st);
-      if (e != hipSuccess) fe.note(hip_fail("download of the gene counts", e));
+      if (e != hipSuccess) return hip_fail("download of the gene counts", e);
     }
-  }
+    return GFICF_OK;
+  });
   for (int r = 0; r < P; ++r) fe.note(gficf_ctx_sync(m->ctx[r]));
   if (fe.rc) { multi_plan_clear(m); return fe.done(); }
   // 2. the one global quantity: nt_g summed over the blocks (the all-reduce of the sharded path)
@@ -326,22 +360,22 @@ int gficf_normalize_csc_host_multi_plan(gficf_multi* m, int64_t G, int64_t N, co
     for (int64_t g = 0; g < G; ++g) nt[(size_t)g] += ntl[r][(size_t)g];
   // 3. per block: filter + weights from the global counts, kept entries per cell
   std::vector<int64_t> hk((size_t)P * 2, 0);
-  for (int r = 0; r < P && fe.rc == GFICF_OK; ++r) {
+  for_each_device(P, fe, [&](int r) -> int {
     gficf_multi_block& B = m->blk[r];
     gficf_ctx* c = m->ctx[r];
     const int64_t n = B.e - B.b;
     hipStream_t st = m->stream[r];
     hipError_t e = hipSetDevice(m->dev[r]);
     if (e == hipSuccess && G > 0) e = hipMemcpyAsync(B.d_nt, nt.data(), sizeof(int64_t) * (size_t)G, hipMemcpyHostToDevice, st);
-    if (e != hipSuccess) { fe.note(hip_fail("upload of the summed gene counts", e)); break; }
-    fe.note(gficf_csc_genes_device(c, G, N, B.d_nt, prop_min, prop_max, B.d_w_in, B.d_keep, B.d_genes, B.d_w, B.d_gkept));
-    if (fe.rc == GFICF_OK) fe.note(gficf_csc_colptr_device(c, G, n, B.d_colptr, B.d_rowidx, B.d_keep, B.d_gkept, B.d_out_colptr));
-    if (fe.rc == GFICF_OK) {
-      e = hipMemcpyAsync(&hk[(size_t)r * 2], B.d_gkept, sizeof(int64_t), hipMemcpyDeviceToHost, st);
-      if (e == hipSuccess) e = hipMemcpyAsync(&hk[(size_t)r * 2 + 1], B.d_out_colptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, st);
-      if (e != hipSuccess) fe.note(hip_fail("download of the kept counts", e));
-    }
-  }
+    if (e != hipSuccess) return hip_fail("upload of the summed gene counts", e);
+    int rc = gficf_csc_genes_device(c, G, N, B.d_nt, prop_min, prop_max, B.d_w_in, B.d_keep, B.d_genes, B.d_w, B.d_gkept);
+    if (!rc) rc = gficf_csc_colptr_device(c, G, n, B.d_colptr, B.d_rowidx, B.d_keep, B.d_gkept, B.d_out_colptr);
+    if (rc) return rc;
+    e = hipMemcpyAsync(&hk[(size_t)r * 2], B.d_gkept, sizeof(int64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&hk[(size_t)r * 2 + 1], B.d_out_colptr + n, sizeof(int64_t), hipMemcpyDeviceToHost, st);
+    if (e != hipSuccess) return hip_fail("download of the kept counts", e);
+    return GFICF_OK;
+  });
   for (int r = 0; r < P; ++r) fe.note(gficf_ctx_sync(m->ctx[r]));
   if (fe.rc) { multi_plan_clear(m); return fe.done(); }
   int64_t total = 0;
@@ -367,7 +401,7 @@ int gficf_normalize_csc_host_multi_finish(gficf_multi* m, uint8_t* keep, int64_t
   const int64_t G = m->G, N = m->N;
   std::vector<std::vector<int64_t>> ocp((size_t)P);
   FirstError fe;
-  for (int r = 0; r < P && fe.rc == GFICF_OK; ++r) {
+  for_each_device(P, fe, [&](int r) -> int {          // a host thread per device: the downloads into the pageable results run side by side
     gficf_multi_block& B = m->blk[r];
     gficf_ctx* c = m->ctx[r];
     const int64_t n = B.e - B.b, nz = B.p1 - B.p0;
@@ -377,11 +411,11 @@ int gficf_normalize_csc_host_multi_finish(gficf_multi* m, uint8_t* keep, int64_t
     gficf_arena ar;
     const size_t o_ri = ar.take(sizeof(int32_t) * ksz), o_x = ar.take(sizeof(double) * ksz);
     if (e == hipSuccess) e = ar.bind(c, 7);
-    if (e != hipSuccess) { fe.note(hip_fail("output buffers of the GF-ICF block", e)); break; }
+    if (e != hipSuccess) return hip_fail("output buffers of the GF-ICF block", e);
     int32_t* const d_ori = ar.at<int32_t>(o_ri);
     double* const d_ox = ar.at<double>(o_x);
-    fe.note(gficf_csc_scale_device(c, G, n, B.d_colptr, B.d_rowidx, B.d_x, nz, B.d_genes, B.d_gkept, B.d_out_colptr, d_ori, d_ox));
-    if (fe.rc != GFICF_OK) break;
+    const int rc = gficf_csc_scale_device(c, G, n, B.d_colptr, B.d_rowidx, B.d_x, nz, B.d_genes, B.d_gkept, B.d_out_colptr, d_ori, d_ox);
+    if (rc) return rc;
     ocp[r].resize((size_t)n + 1);
     e = hipMemcpyAsync(ocp[r].data(), B.d_out_colptr, sizeof(int64_t) * ((size_t)n + 1), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && B.nnz_kept > 0) e = hipMemcpyAsync(out_rowidx + B.out_off, d_ori, sizeof(int32_t) * (size_t)B.nnz_kept, hipMemcpyDeviceToHost, st);
@@ -391,8 +425,9 @@ int gficf_normalize_csc_host_multi_finish(gficf_multi* m, uint8_t* keep, int64_t
       if (e == hipSuccess && nt) e = hipMemcpyAsync(nt, B.d_nt, sizeof(int64_t) * (size_t)G, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess && w) e = hipMemcpyAsync(w, B.d_w, sizeof(double) * (size_t)G, hipMemcpyDeviceToHost, st);
     }
-    if (e != hipSuccess) fe.note(hip_fail("download of the GF-ICF block", e));
-  }
+    if (e != hipSuccess) return hip_fail("download of the GF-ICF block", e);
+    return GFICF_OK;
+  });
   for (int r = 0; r < P; ++r) fe.note(gficf_ctx_sync(m->ctx[r]));
   int rc = fe.done();
   if (!rc) {

@@ -58,7 +58,6 @@ static gficf_ctx* ctx_get(void) {
  * gficf_multi_* of the C ABI).  Unset, or one device: the single-device entries. */
 static gficf_multi* multi_get(void) {
   if (!g_multi_tried) {
-    g_multi_tried = 1;
     const char* e = getenv("GFICF_HIP_DEVICES");
     int devs[64], n = 0;
     while (e && *e && n < 64) {
@@ -70,9 +69,12 @@ static gficf_multi* multi_get(void) {
       while (*e == ',' || *e == ';' || *e == ' ') ++e;
     }
     if (n > 1) {
-      if (gficf_multi_create(devs, n, &g_multi) != GFICF_OK) Rf_error("gficf_hip: %s", gficf_last_error());
+      /* on failure (say, an ordinal that does not exist) the error repeats at every call: g_multi_tried stays 0, so
+       * a session that asked for several GPUs never runs single-device in silence (Rf_error does not return) */
+      if (gficf_multi_create(devs, n, &g_multi) != GFICF_OK) Rf_error("gficf_hip: GFICF_HIP_DEVICES: %s", gficf_last_error());
       gficf_multi_set_print(g_multi, print_line);
     }
+    g_multi_tried = 1;
   }
   return g_multi;
 }

@@ -98,6 +98,8 @@ def lib() -> ctypes.CDLL:
         vp = ctypes.c_void_p
         L.oracle_jaccard_f64.restype = i32
         L.oracle_jaccard_f64.argtypes = [vp, i64, i32, vp, vp, i32]
+        L.oracle_jaccard_cells_f64.restype = i32
+        L.oracle_jaccard_cells_f64.argtypes = [vp, i64, i32, i64, i64, vp, vp, i32]
         L.oracle_jaccard_i32.restype = i32
         L.oracle_jaccard_i32.argtypes = [vp, i64, i32, vp, vp, i32]
         L.oracle_jaccard_coeff_f64.restype = i32
@@ -140,6 +142,20 @@ def jaccard(mat: np.ndarray, nthreads: int = 1):
     if rc != 0:
         raise ValueError(f"oracle_jaccard: invalid input (rc={rc})")
     return rm.T, u  # view: (E x 3), Fortran-ordered like the R matrix
+
+
+def jaccard_cells(mat: np.ndarray, begin: int, end: int, nthreads: int = 1):
+    """The rows of ``jaccard(mat)`` that belong to the cells [begin, end): ((end-begin)*k) x 3 matrix and counts
+    (same per-edge code; a bounded sample for checks at sizes where the whole matrix takes too long)."""
+    N, k = mat.shape
+    n = (end - begin) * k
+    rm = np.empty((3, n), dtype=np.float64)
+    u = np.empty(n, dtype=np.int32)
+    m = np.asfortranarray(mat, dtype=np.float64)
+    rc = lib().oracle_jaccard_cells_f64(_p(m), N, k, int(begin), int(end), _p(rm), _p(u), nthreads)
+    if rc != 0:
+        raise ValueError(f"oracle_jaccard_cells: invalid input (rc={rc})")
+    return rm.T, u
 
 
 def jaccard_coeff(mat: np.ndarray) -> np.ndarray:

@@ -52,13 +52,15 @@ struct JaccardArgs {
   int k;
   double* rmat;        // (N*k) x 3, column-major, zero-initialised by the caller-facing entry
   int32_t* u_out;      // optional N*k intersection counts (row-major edge order i*k+j)
+  int64_t col_stride;  // rows of the output matrix (N*k for the whole matrix; (end-begin)*k for a block of cells)
+  int64_t row_base;    // output row of edge (i, j) = i*k + j - row_base
 };
 
 // reference :24-55, one cell range
 void jaccard_range(const JaccardArgs& a, int64_t begin, int64_t end) {
   const int64_t N = a.N;
   const int k = a.k;
-  const int64_t E = N * (int64_t)k;
+  const int64_t E = a.col_stride;
   std::vector<double> v1(k), v2(k);
   for (int64_t i = begin; i < end; ++i) {
     for (int j = 0; j < k; ++j) {
@@ -71,7 +73,7 @@ void jaccard_range(const JaccardArgs& a, int64_t begin, int64_t end) {
       std::set_intersection(v1.begin(), v1.end(), v2.begin(), v2.end(),
                             std::back_inserter(v_intersection));           // :43-45
       int u = (int)v_intersection.size();                                  // :46
-      const int64_t r = i * (int64_t)k + j;
+      const int64_t r = i * (int64_t)k + j - a.row_base;
       if (a.u_out) a.u_out[r] = u;
       if (u > 0) {                                                         // :48
         a.rmat[r] = (double)(i + 1);                                       // :49
@@ -80,6 +82,28 @@ void jaccard_range(const JaccardArgs& a, int64_t begin, int64_t end) {
       }
     }
   }
+}
+
+// cells [begin, end) over std::thread workers pulling fixed-size chunks from an atomic counter
+void run_cells(const JaccardArgs& a, int64_t begin, int64_t end, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads == 1 || end - begin < 64) {
+    jaccard_range(a, begin, end);
+    return;
+  }
+  std::atomic<int64_t> next(begin);
+  const int64_t chunk = 64;
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nthreads; ++t) {
+    pool.emplace_back([&]() {
+      for (;;) {
+        int64_t b = next.fetch_add(chunk);
+        if (b >= end) break;
+        jaccard_range(a, b, std::min(end, b + chunk));
+      }
+    });
+  }
+  for (auto& th : pool) th.join();
 }
 
 }  // namespace
@@ -100,25 +124,26 @@ int oracle_jaccard_f64(const double* mat, int64_t N, int k, double* rmat, int32_
     if (!(v >= 1.0) || !(v < (double)N + 1.0)) return -1;
   }
   std::memset(rmat, 0, sizeof(double) * 3 * (size_t)E);
-  JaccardArgs a{mat, N, k, rmat, u_out};
-  if (nthreads < 1) nthreads = 1;
-  if (nthreads == 1 || N < 64) {
-    jaccard_range(a, 0, N);
-    return 0;
+  JaccardArgs a{mat, N, k, rmat, u_out, E, 0};
+  run_cells(a, 0, N, nthreads);
+  return 0;
+}
+
+// The rows of the reference's matrix that belong to the cells [begin, end) only (a bounded sample for checks at sizes
+// where the whole matrix would take minutes on a few cores): rmat_rows is ((end-begin)*k) x 3 column-major, row
+// (i-begin)*k + j = the reference's row i*k + j.  Same per-edge code as above.
+int oracle_jaccard_cells_f64(const double* mat, int64_t N, int k, int64_t begin, int64_t end, double* rmat_rows,
+                             int32_t* u_rows, int nthreads) {
+  if (N < 0 || k < 0 || begin < 0 || end < begin || end > N) return -2;
+  const int64_t E = N * (int64_t)k;
+  for (int64_t p = 0; p < E; ++p) {
+    double v = mat[p];
+    if (!(v >= 1.0) || !(v < (double)N + 1.0)) return -1;
   }
-  std::atomic<int64_t> next(0);
-  const int64_t chunk = 64;
-  std::vector<std::thread> pool;
-  for (int t = 0; t < nthreads; ++t) {
-    pool.emplace_back([&]() {
-      for (;;) {
-        int64_t b = next.fetch_add(chunk);
-        if (b >= N) break;
-        jaccard_range(a, b, std::min(N, b + chunk));
-      }
-    });
-  }
-  for (auto& th : pool) th.join();
+  const int64_t rows = (end - begin) * (int64_t)k;
+  std::memset(rmat_rows, 0, sizeof(double) * 3 * (size_t)rows);
+  JaccardArgs a{mat, N, k, rmat_rows, u_rows, rows, begin * (int64_t)k};
+  run_cells(a, begin, end, nthreads);
   return 0;
 }
 

@@ -119,3 +119,25 @@ def test_two_ranks_one_gpu_full_sharded_path(tmp_path):
     assert all(np.array_equal(p["keep"].astype(bool), ref["keep"]) for p in parts)
     assert np.array_equal(np.concatenate([p["rowidx"] for p in parts]), ref["rowidx"])
     assert np.allclose(np.concatenate([p["x"] for p in parts]), ref["x"], rtol=1e-6, atol=1e-6)
+
+
+def test_plain_bench_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run (how the driver's N = 1 command looks with another N): the
+    script spawns one rank per GPU itself before anything touches a device.  Here the two ranks share the box's one GPU
+    over gloo (--rehearse-one-gpu); the line must be the N = 2 line, with the exchange's byte counts."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1",
+                        "--no-extras", "--cells-per-gpu", "20000"], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["metric"] == "jaccard_edges_per_sec" and out["value"] > 0
+    assert out["config"]["cells_total"] == 40000
+    ex = out["exchange"]
+    assert ex["rows_received_per_rank_per_data_set"] == 20000 and ex["bytes_received_per_rank_per_data_set"] > 0

@@ -504,6 +504,26 @@ def test_device_path_with_explicit_zeros_is_reported_and_the_exact_entry_handles
         assert np.array_equal(ws["nt"].cpu().numpy()[ref["keep"]], ref["nt"][ref["keep"]])
         assert nk == len(ref["x"]) and np.array_equal(ws["out_rowidx"][:nk].cpu().numpy(), ref["rowidx"])
         assert np.allclose(ws["out_x"][:nk].cpu().numpy(), ref["x"], rtol=TOL, atol=TOL)
+    # the self-healing form: one call, synchronised, the exact pass taken only when the status asks for it
+    ws = ops.gficf_csc(G, N, d(cp), d(ri), d(x), 0.05, 1.0, auto_exact=True)
+    nk = int(ws["out_colptr"][N])
+    assert np.array_equal(ws["nt"].cpu().numpy()[ref["keep"]], ref["nt"][ref["keep"]])
+    assert nk == len(ref["x"]) and np.array_equal(ws["out_rowidx"][:nk].cpu().numpy(), ref["rowidx"])
+    assert np.allclose(ws["out_x"][:nk].cpu().numpy(), ref["x"], rtol=TOL, atol=TOL)
+    ops.sync()                                  # nothing left pending
+    if n_zero:
+        # another deferred error of the same sync is neither masked nor replaced by the explicit-zero bit: a row index
+        # outside [0, G) next to the stored zeros surfaces as BAD_CSC, from the plain and from the self-healing call
+        bad = ri.copy()
+        bad[len(bad) // 2] = G + 5
+        ops.gficf_csc(G, N, d(cp), d(bad), d(x), 0.05, 1.0)
+        with pytest.raises(gficf_amd.GficfError) as ei:
+            ops.sync()
+        assert ei.value.status == "GFICF_ERR_BAD_CSC"
+        with pytest.raises(gficf_amd.GficfError) as ei:
+            ops.gficf_csc(G, N, d(cp), d(bad), d(x), 0.05, 1.0, auto_exact=True)
+        assert ei.value.status == "GFICF_ERR_BAD_CSC"
+        ops.sync()                              # and the status word is clean again
     # the host entry (what gficf() binds) always counts exactly
     res = gficf_amd.gficf(sp.csc_matrix((x, ri, cp), shape=(G, N)), normalize=False, verbose=False)
     assert np.array_equal(res["gficf"].indices, ref["rowidx"]) and np.allclose(res["gficf"].data, ref["x"], rtol=TOL, atol=TOL)

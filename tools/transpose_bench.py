@@ -13,7 +13,7 @@ import gficf_amd
 G, N = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (23000, 54000)
 ops = gficf_amd.HipOps(0)
 colptr, rowidx, x = bench.synth_counts_device(torch, G, N)
-res = ops.gficf_csc(G, N, colptr, rowidx, x)
+res = ops.gficf_csc(G, N, colptr, rowidx, x, auto_exact=True)
 ops.sync()
 gk, nk = int(res["gkept"][0]), int(res["out_colptr"][N])
 cp, ri, xv = res["out_colptr"], res["out_rowidx"][:nk], res["out_x"][:nk]
