@@ -90,13 +90,20 @@ def time_kernel_ms(torch, fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def synth_counts_device(torch, G, N, seed=7, median_frac=0.07, sigma=0.5, zipf_s=0.9, max_per_cell=None, chunk_cells=None):
+def synth_counts_device(torch, G, N, seed=7, median_frac=0.07, sigma=0.5, zipf_s=0.9, max_per_cell=None, chunk_cells=None, density="survey"):
     """Device-side generator of the BASELINE-shaped synthetic CSC count matrix (same recipe as
     gficf_amd.synth.counts_csc, torch RNG instead of splitmix64 so that ~1e8 draws take seconds).
-    max_per_cell caps the draws of a cell (SURVEY.md §8d: 2 147 for config 5, so that nnz < 2^31);
+
+    density="survey" (default): SURVEY.md §8d's density — the number of STORED entries of a cell follows the clipped
+      lognormal (median 0.07 G, sigma 0.5, clipped to [0.25, 1.5] x the median; `max_per_cell` caps it: 2 147 for config 5 so
+      that nnz < 2^31), the genes are drawn by Zipf-like popularity WITHOUT replacement: a cell over-draws by the expected
+      collision rate of its target (distinct(m) = sum_g 1 - (1 - p_g)^m, inverted by interpolation), duplicates are
+      collapsed and a random subset of the surplus is dropped.  Config 3: 88 M entries (survey: ~87 M).
+    density="light": rounds 1-2's generator — the lognormal number is the number of DRAWS, duplicate (cell, gene) draws
+      collapse (config 3: 59.8 M entries; kept for comparisons with profiles/r01*, r02*).
     chunk_cells generates the cells in blocks of that many (bounds the generator's temporaries at config 5's size)."""
     if chunk_cells is not None and N > chunk_cells:
-        parts = [synth_counts_device(torch, G, min(chunk_cells, N - c0), seed + 1000003 * (i + 1), median_frac, sigma, zipf_s, max_per_cell)
+        parts = [synth_counts_device(torch, G, min(chunk_cells, N - c0), seed + 1000003 * (i + 1), median_frac, sigma, zipf_s, max_per_cell, None, density)
                  for i, c0 in enumerate(range(0, N, chunk_cells))]
         colptr = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
         off, c0 = 0, 0
@@ -112,17 +119,46 @@ def synth_counts_device(torch, G, N, seed=7, median_frac=0.07, sigma=0.5, zipf_s
         return colptr, rowidx, x
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
-    n_draw = torch.clamp(torch.round(median_frac * G * torch.exp(sigma * torch.randn(N, generator=g, device="cuda", dtype=torch.float64))), 1, G).long()
-    if max_per_cell is not None:
-        n_draw = torch.clamp(n_draw, max=int(max_per_cell))
+    med = median_frac * G
+    n_target = torch.round(med * torch.exp(sigma * torch.randn(N, generator=g, device="cuda", dtype=torch.float64)))
     pop = 1.0 / torch.arange(1, G + 1, device="cuda", dtype=torch.float64).pow(zipf_s)
-    cdf = torch.cumsum(pop, 0)
+    p = pop / pop.sum()
+    cdf = torch.cumsum(p, 0)
     cdf = cdf / cdf[-1]
+    if density == "light":
+        n_draw = torch.clamp(n_target, 1, G).long()
+        if max_per_cell is not None:
+            n_draw = torch.clamp(n_draw, max=int(max_per_cell))
+        n_keep = None
+    else:
+        n_keep = torch.clamp(n_target, max(1.0, 0.25 * med), min(float(G), 1.5 * med))
+        if max_per_cell is not None:
+            n_keep = torch.clamp(n_keep, max=float(max_per_cell))
+        n_keep = n_keep.long().clamp_(min=1)
+        # draws m(n) such that the expected number of distinct genes is 1.03 n (the surplus is trimmed below)
+        m_grid = torch.logspace(0, np.log10(40.0 * G), 512, device="cuda", dtype=torch.float64)
+        d_grid = (1.0 - torch.exp(m_grid[:, None] * torch.log1p(-p)[None, :])).sum(1)            # distinct(m), increasing
+        want = (1.03 * n_keep.double()).clamp_(max=float(d_grid[-1]) * 0.999)
+        hi = torch.searchsorted(d_grid, want).clamp_(1, 511)
+        t = (want - d_grid[hi - 1]) / (d_grid[hi] - d_grid[hi - 1])
+        n_draw = torch.ceil(m_grid[hi - 1] + t * (m_grid[hi] - m_grid[hi - 1])).long().clamp_(min=1)
     cell_of = torch.repeat_interleave(torch.arange(N, device="cuda"), n_draw)
     gene = torch.searchsorted(cdf, torch.rand(cell_of.numel(), generator=g, device="cuda", dtype=torch.float64)).clamp_(max=G - 1)
     key = torch.unique(cell_of * G + gene)          # sorted by (cell, gene), de-duplicated
     del cell_of, gene
     col = torch.div(key, G, rounding_mode="floor")
+    if n_keep is not None:
+        # trim the cells that ended above their target: keep a random n_keep of a cell's entries
+        cnt = torch.bincount(col, minlength=N)
+        if bool((cnt > n_keep).any()):
+            start = torch.cumsum(cnt, 0) - cnt
+            order = torch.argsort(col.double() + torch.rand(key.numel(), generator=g, device="cuda", dtype=torch.float64))   # random order inside a cell
+            rank = torch.empty_like(order)
+            rank[order] = torch.arange(key.numel(), device="cuda") - start[col[order]]
+            del order
+            key = key[rank < n_keep[col]]
+            del rank
+            col = torch.div(key, G, rounding_mode="floor")
     rowidx = (key - col * G).to(torch.int32)
     colptr = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
     colptr[1:] = torch.cumsum(torch.bincount(col, minlength=N), 0)
@@ -550,15 +586,18 @@ def main():
             t_scale = time_kernel_ms(torch, lambda: ops.csc_scale(G, Nc, colptr, rowidx, x, ws["genes"], ws["gkept"], ws["out_colptr"], ws["out_rowidx"], ws["out_x"]), 10)
             t_count = time_kernel_ms(torch, lambda: ops.csc_count(G, Nc, colptr, rowidx, x, ws["nt"]), 10)
             gf = {"metric": "gficf_cells_per_sec", "value": Nc / tg, "unit": "cells/s", "ms_per_pass": tg * 1e3,
-                  "config": {"workload": f"BASELINE config 3 shape: {G} genes x {Nc} cells synthetic UMI CSC (nnz={nnz}), "
-                                         "gene filter 5 % + GF + ICF + L2, device-resident, compacted output"},
+                  "config": {"workload": f"BASELINE config 3 shape: {G} genes x {Nc} cells synthetic UMI CSC (nnz={nnz}, SURVEY.md 8d density: "
+                                         "clipped-lognormal stored entries per cell, Zipf genes drawn without replacement), "
+                                         "gene filter 5 % + GF + ICF + L2, device-resident, compacted output",
+                             "nnz": nnz, "nnz_per_cell_median": float((colptr[1:] - colptr[:-1]).double().median().item()),
+                             "nnz_per_cell_max": int((colptr[1:] - colptr[:-1]).max().item())},
                   "nnz": nnz, "kept_nnz": int(ws["out_colptr"][Nc]), "kept_genes": int(ws["gkept"][0]), "dtype": "f64",
                   "roofline": {"bound": "hbm", "kernel": "whole pass (count + colptr + scale)",
                                "achieved": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_PEAK_GBS, 4),
                                "frac_of_copy_rate": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_COPY_GBS, 4),
                                "traffic": (sum(pmc[kk]["hbm_bytes_per_launch"] for kk in ("gene_count", "nt_sum_table", "cell_kept_count", "scan_lookback", "scale_cells_lds") if kk in pmc)
-                                           if all(kk in pmc for kk in ("gene_count", "cell_kept_count")) and nnz == 59809258 else None),
+                                           if all(kk in pmc for kk in ("gene_count", "cell_kept_count")) and pmc.get("gficf_nnz") == nnz else None),
                                "scale_kernel_ms": round(t_scale, 4), "count_exact_kernel_ms": round(t_count, 4),
                                "count_note": "count_exact_kernel_ms is gficf_csc_count_device (reads x: 12 B/nnz), the form the sharded and host entries use; the timed pass (gficf_csc_device) counts stored entries without reading x (about half that time, see the rocprof summary)",
                                "algorithmic_bytes_per_pass": GFICF_BYTES_PER_NNZ * nnz}}

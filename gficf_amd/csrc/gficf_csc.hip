@@ -626,21 +626,54 @@ __device__ inline void sl_body(int64_t G, int64_t n_cells, const int64_t* __rest
     const int64_t len = p1 - p0;
     if (len <= 0) continue;                       // uniform over the wave
     int64_t opos = out_colptr[c];
-    if (len <= 64 * SL_CH) {
-      const int n_it = (int)((len + 63) >> 6);
+    // A wave keeps the first 64 * SL_CH entries of its cell (the "head") in registers and reads them from HBM exactly once.
+    // Entries beyond that (the "tail": cells of more than 2048 stored entries — a third of the cells at SURVEY.md 8d's
+    // density, common in real droplet data) are swept first, in batches of SL_LB chunks, for their part of the two sums
+    // only, and read a second time (from L2: they were just read) when they are written, behind the head.  For the tail's
+    // part of the norm the two reductions run in ONE sweep: sum_tail ((x / S) w)^2 is taken as (sum_tail (x w)^2) / S^2
+    // — the same number up to rounding (a few 1e-16 relative, the contract is 1e-6) — because S is only known once the head
+    // is in; the head's part keeps the reference's order of operations.  (Rounds 1-2 swept a long cell three times.)
+    const int64_t head_len = len < 64 * SL_CH ? len : 64 * SL_CH;
+    const int64_t t0 = p0 + head_len;             // first tail entry
+    double S = 0.0, Qt = 0.0;
+    if (t0 < p1) {
+      for (int64_t base = t0; base < p1; base += 64 * SL_LB) {
+        int32_t gz[SL_LB];
+        double xb[SL_LB];
+#pragma unroll
+        for (int m = 0; m < SL_LB; ++m) {
+          const int64_t p = base + m * 64 + lane;
+          gz[m] = -1; xb[m] = 0.0;
+          if (p < p1) { gz[m] = rowidx[p]; xb[m] = x[p]; }
+        }
+#pragma unroll
+        for (int m = 0; m < SL_LB; ++m) {
+          const uint32_t g = (uint32_t)gz[m];
+          saw_zero |= g < (uint32_t)G && xb[m] == 0.0;
+          const uint32_t r = g < (uint32_t)G ? (uint32_t)s_remap[g] : 0xFFFFu;
+          if (r != 0xFFFFu) {
+            S += xb[m];
+            const double xw = xb[m] * weight((int32_t)r);
+            Qt += norm_l1 ? xw : xw * xw;
+          }
+        }
+      }
+    }
+    {
+      const int n_it = (int)((head_len + 63) >> 6);
+      const int64_t h1 = p0 + head_len;
       double xv[SL_CH];
       int32_t rv[SL_CH];
-      // entries: all loads of the cell are issued before any is consumed
+      // entries: all loads of the head are issued before any is consumed
 #pragma unroll
       for (int m = 0; m < SL_CH; ++m) {
         rv[m] = -1;
         xv[m] = 0.0;
         if (m < n_it) {
           const int64_t p = p0 + m * 64 + lane;
-          if (p < p1) { rv[m] = __builtin_nontemporal_load(rowidx + p); xv[m] = __builtin_nontemporal_load(x + p); }
+          if (p < h1) { rv[m] = __builtin_nontemporal_load(rowidx + p); xv[m] = __builtin_nontemporal_load(x + p); }
         }
       }
-      double S = 0.0;
 #pragma unroll
       for (int m = 0; m < SL_CH; ++m) {
         if (m < n_it) {
@@ -662,7 +695,11 @@ __device__ inline void sl_body(int64_t G, int64_t n_cells, const int64_t* __rest
           q += norm_l1 ? v : v * v;
         }
       }
-      const double qc = wave_sum(q);
+      double qc = wave_sum(q);
+      if (t0 < p1 && Sc != 0.0) {                 // uniform over the wave: the tail's share of the norm
+        const double qt = wave_sum(Qt);
+        qc += norm_l1 ? qt / Sc : qt / (Sc * Sc);
+      }
       double nv = 1.0 / (norm_l1 ? qc : sqrt(qc));
       if (isinf(nv)) nv = 0.0;                    // R/gficf.R:101
 #pragma unroll
@@ -678,49 +715,8 @@ __device__ inline void sl_body(int64_t G, int64_t n_cells, const int64_t* __rest
           opos += __popcll(mk);
         }
       }
-    } else {
-      // long cell: three sweeps in batches of SL_LB chunks; the 2nd and 3rd sweep re-read it from L2
-      double S = 0.0;
-      for (int64_t base = p0; base < p1; base += 64 * SL_LB) {
-        int32_t gz[SL_LB];
-        double xb[SL_LB];
-#pragma unroll
-        for (int m = 0; m < SL_LB; ++m) {
-          const int64_t p = base + m * 64 + lane;
-          gz[m] = -1; xb[m] = 0.0;
-          if (p < p1) { gz[m] = rowidx[p]; xb[m] = x[p]; }
-        }
-#pragma unroll
-        for (int m = 0; m < SL_LB; ++m) {
-          const uint32_t g = (uint32_t)gz[m];
-          saw_zero |= g < (uint32_t)G && xb[m] == 0.0;
-          if (g < (uint32_t)G && s_remap[g] != 0xFFFFu) S += xb[m];
-        }
-      }
-      const double Sc = wave_sum(S);
-      double q = 0.0;
-      if (Sc != 0.0) {
-        for (int64_t base = p0; base < p1; base += 64 * SL_LB) {
-          int32_t gz[SL_LB];
-          double xb[SL_LB];
-#pragma unroll
-          for (int m = 0; m < SL_LB; ++m) {
-            const int64_t p = base + m * 64 + lane;
-            gz[m] = -1; xb[m] = 0.0;
-            if (p < p1) { gz[m] = rowidx[p]; xb[m] = x[p]; }
-          }
-#pragma unroll
-          for (int m = 0; m < SL_LB; ++m) {
-            const uint32_t g = (uint32_t)gz[m];
-            const uint32_t r = g < (uint32_t)G ? (uint32_t)s_remap[g] : 0xFFFFu;
-            if (r != 0xFFFFu) { const double v = (xb[m] / Sc) * weight((int32_t)r); q += norm_l1 ? v : v * v; }
-          }
-        }
-      }
-      const double qc = wave_sum(q);
-      double nv = 1.0 / (norm_l1 ? qc : sqrt(qc));
-      if (isinf(nv)) nv = 0.0;                    // R/gficf.R:101
-      for (int64_t base = p0; base < p1; base += 64 * SL_LB) {
+      // the tail again (from L2), written behind the head
+      for (int64_t base = t0; base < p1; base += 64 * SL_LB) {
         int32_t gz[SL_LB];
         double xb[SL_LB];
 #pragma unroll

@@ -190,14 +190,16 @@ __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64
 // pair of elements — 30 us against 10 at 100 k x 30: returning LDS atomics are far slower than the 186 vector instructions
 // per thread of the all-pairs scan.)
 template <int KPAD, int W>
-__device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD]) {
+__device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD], int k) {
   uint32_t m = 0xFFFFFFFFu;                 // min over this part's pairs (j, j2 < j), j = W, W + 4, ...
 #pragma unroll
   for (int j = W; j < KPAD; j += 4) {
+    if (j < k) {                            // wave-uniform: slots past k hold no id (k = 50 in 64 slots: 1225 of the 2016 pairs)
 #pragma unroll
-    for (int j2 = 0; j2 < j; ++j2) {
-      const uint32_t x = r[j] ^ r[j2];
-      m = x < m ? x : m;
+      for (int j2 = 0; j2 < j; ++j2) {
+        const uint32_t x = r[j] ^ r[j2];
+        m = x < m ? x : m;
+      }
     }
   }
   return m;
@@ -245,10 +247,10 @@ __global__ __launch_bounds__(256) void k_ingest_tile(const T* __restrict__ idx, 
       }
       uint32_t m;
       switch (wave) {
-        case 0: m = dup_part<KPAD, 0>(rr); break;
-        case 1: m = dup_part<KPAD, 1>(rr); break;
-        case 2: m = dup_part<KPAD, 2>(rr); break;
-        default: m = dup_part<KPAD, 3>(rr); break;
+        case 0: m = dup_part<KPAD, 0>(rr, k); break;
+        case 1: m = dup_part<KPAD, 1>(rr, k); break;
+        case 2: m = dup_part<KPAD, 2>(rr, k); break;
+        default: m = dup_part<KPAD, 3>(rr, k); break;
       }
       if (m == 0) dup[lane] = 1;
       __syncthreads();
@@ -1407,35 +1409,45 @@ constexpr size_t edges_lds_bytes() {
          ((C::EPL == 1 && C::SPQ <= 4) ? (size_t)C::WAVES * 4 * 64 * 8 : 0);
 }
 
+// workgroups per CU for an edge kernel: as many as fit, up to 8 (measured at 100 k x 30, tools/r02_sweep.sh: 4 per CU 44-47 us,
+// 6: 43-46, 8: 41-42, 10-12: 40-42 — the row gathers are latency-bound, more waves keep more of them in flight).  Asked of the
+// runtime for the kernel that is launched (the pipelined and the general form differ in registers), once per kernel.
+template <typename K>
+int edge_blocks_per_cu(K kernel, int threads, size_t lds_bytes, std::atomic<int>& cache, int* out) {
+  int v = cache.load(std::memory_order_relaxed);
+  if (v == 0) {
+    int nb = 0;
+    GFICF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds_bytes));
+    v = nb > 8 ? 8 : nb > 0 ? nb : 1;
+    if (const char* e = getenv("GFICF_JACCARD_BLOCKS_PER_CU")) {   // tuning knob
+      const int t = atoi(e);
+      if (t > 0) v = t;
+    }
+    cache.store(v, std::memory_order_relaxed);   // same value whoever computes it
+  }
+  *out = v;
+  return GFICF_OK;
+}
+
 template <int KPAD, bool BIG, bool CMP, int OUT>
 int launch_edges_o(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
   using C = JCfg<KPAD, CMP>;
   // grid = what is resident at once (occupancy x CUs); waves stride over the cells
-  static std::atomic<int> blocks_per_cu_cached{0};
-  int blocks_per_cu = blocks_per_cu_cached.load(std::memory_order_relaxed);
-  if (blocks_per_cu == 0) {
-    int nb = 0;
-    constexpr size_t lds_b = edges_lds_bytes<KPAD, CMP>();
-    GFICF_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_jaccard_edges<KPAD, BIG, CMP, OUT>, C::WAVES * 64, lds_b));
-    // As many workgroups per CU as fit, up to 8 (measured at 100 k x 30, tools/r02_sweep.sh: 4 per CU 44-47 us, 6: 43-46,
-    // 8: 41-42, 10-12: 40-42 — the row gathers are latency-bound, more waves keep more of them in flight).
-    blocks_per_cu = nb > 8 ? 8 : nb > 0 ? nb : 1;
-    if (const char* e = getenv("GFICF_JACCARD_BLOCKS_PER_CU")) {   // tuning knob
-      const int v = atoi(e);
-      if (v > 0) blocks_per_cu = v;
-    }
-    blocks_per_cu_cached.store(blocks_per_cu, std::memory_order_relaxed);   // same value whoever computes it
-  }
-  const int64_t blocks_needed = gficf_ceil_div(ce - cb, C::WAVES);
-  const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
-  const unsigned grid = (unsigned)(blocks_needed < cap ? blocks_needed : cap);
+  static std::atomic<int> bpc_general{0}, bpc_pipe{0}, bpc_pipe_nob16{0};
   constexpr size_t lds_bytes = edges_lds_bytes<KPAD, CMP>();
+  int blocks_per_cu = 1;
   static const bool no_pipe = getenv("GFICF_JACCARD_NO_PIPE") != nullptr;        // test hook: the one-cell-at-a-time kernel for every k
   if constexpr (C::EPL == 1 && C::SPQ <= 4) {
     if (!no_pipe) {
+      const bool nob16 = CMP && N < 65536;     // no id carries bit 16: the kernel variant that does not look for it (configs 1-3 of BASELINE.json)
+      int rc;
+      if (nob16) rc = edge_blocks_per_cu(k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, !CMP>, C::WAVES * 64, lds_bytes, bpc_pipe_nob16, &blocks_per_cu);
+      else rc = edge_blocks_per_cu(k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT>, C::WAVES * 64, lds_bytes, bpc_pipe, &blocks_per_cu);
+      if (rc) return rc;
+      const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
       const int64_t need4 = gficf_ceil_div(gficf_ceil_div(ce - cb, 4), C::WAVES);       // a wave takes four cells at a time
       const unsigned grid4 = (unsigned)(need4 < cap ? need4 : cap);
-      if (CMP && N < 65536)     // no id carries bit 16: the kernel variant that does not look for it (configs 1-3 of BASELINE.json)
+      if (nob16)
         hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, !CMP>), dim3(grid4), dim3(C::WAVES * 64), lds_bytes, ctx->stream,
                            table, N, k, cb, ce, o);
       else
@@ -1445,6 +1457,11 @@ int launch_edges_o(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
       return GFICF_OK;
     }
   }
+  const int rc = edge_blocks_per_cu(k_jaccard_edges<KPAD, BIG, CMP, OUT>, C::WAVES * 64, lds_bytes, bpc_general, &blocks_per_cu);
+  if (rc) return rc;
+  const int64_t blocks_needed = gficf_ceil_div(ce - cb, C::WAVES);
+  const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
+  const unsigned grid = (unsigned)(blocks_needed < cap ? blocks_needed : cap);
   hipLaunchKernelGGL((k_jaccard_edges<KPAD, BIG, CMP, OUT>), dim3(grid), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
                      N, k, cb, ce, o);
   GFICF_HIP_CHECK(hipGetLastError());

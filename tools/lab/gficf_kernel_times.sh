@@ -8,7 +8,7 @@ for V in "" "$@"; do
   python - <<PY
 import csv, re
 for r in csv.DictReader(open("$OUT/trace$V/t_kernel_stats.csv")):
-    m = re.search(r"(k_[a-z_0-9]+(<[^>]*>)?)", r["Name"])
+    m = re.search(r"(?<![A-Za-z0-9_])(k_[a-z_0-9]+(<[^>]*>)?)", r["Name"])
     if m and float(r["AverageNs"]) > 1500: print("  %-40s calls %4s avg %9.1f us  min %8.1f max %9.1f" % (m.group(1), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY
 done

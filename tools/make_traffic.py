@@ -20,7 +20,7 @@ root, N, k, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "p*", "pmc_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(k_[a-z_0-9]+)", row["Kernel_Name"])
+        m = re.search(r"(?<![A-Za-z0-9_])(k_[a-z_0-9]+)", row["Kernel_Name"])
         if m:
             acc[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
 def mean(v):

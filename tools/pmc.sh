@@ -21,12 +21,12 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/pmc_counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(k_[a-z_0-9]+)", row["Kernel_Name"])
+        m = re.search(r"(?<![A-Za-z0-9_])(k_[a-z_0-9]+)", row["Kernel_Name"])
         if m and re.search("$PAT", m.group(1)):
             acc[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for f in glob.glob("$OUT/p*/pmc_kernel_trace.csv"):
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(k_[a-z_0-9]+)", row["Kernel_Name"])
+        m = re.search(r"(?<![A-Za-z0-9_])(k_[a-z_0-9]+)", row["Kernel_Name"])
         if m and re.search("$PAT", m.group(1)):
             dur[m.group(1)].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 for k in acc:
