@@ -71,8 +71,10 @@ def parse():
     ap.add_argument("--ids", choices=["permuted", "spatial"], default="permuted",
                     help="permuted: ids relabelled by a random permutation (what Annoy output looks like; the default); "
                          "spatial: cells numbered in their spatial order (what the device kNN search's pivot order gives)")
-    ap.add_argument("--exchange", choices=["allgather", "halo"], default="allgather",
-                    help="N > 1: all-gather of every rank's table rows, or the halo form (only the rows a block names)")
+    ap.add_argument("--exchange", choices=["auto", "allgather", "halo", "halo_generic"], default="auto",
+                    help="N > 1: all-gather of every rank's table rows; halo: sub-problems in local ids, only the rows a block names travel "
+                         "(fixed-capacity request slots, gficf_amd.dist.JaccardHaloShard); halo_generic: round 2's torch-side halo on global ids; "
+                         "auto (default): halo when the warm-up step of data set 0 fits the request slots on every rank, all-gather otherwise")
     return ap.parse_args()
 
 
@@ -347,9 +349,42 @@ def main():
         if d == 0:
             mats.append(m)                                              # kept for the oracle check / CPU baseline
         idx_local.append(torch.from_numpy(np.ascontiguousarray(m[b:e].T)).to(dev))   # (k, n_local) == column-major block
-        shards.append(JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=False, exchange=args.exchange))
         del m
     mat = mats[0]
+    # the exchange form is a property of the input (do the blocks name few rows outside themselves?): decided once, on data
+    # set 0, before anything is timed; every rank must reach the same decision
+    exchange = args.exchange
+    named_outside = None
+    if world == 1:
+        exchange = "allgather"                                          # nothing to exchange; the plain single-device path
+    elif exchange in ("auto", "halo"):
+        from gficf_amd.dist import JaccardHaloShard
+
+        probe = JaccardHaloShard(ops, N_total, k, device=dev)
+        probe.step(idx_local[0])
+        fits = 1
+        try:
+            probe.sync()
+        except gficf_amd.GficfError as ex:
+            if ex.status != "GFICF_ERR_CAPACITY":
+                raise
+            fits = 0
+        named_outside = probe.rows_named_outside()
+        t_fit = torch.tensor([fits], dtype=torch.int32, device=dev)
+        dist.all_reduce(t_fit, op=dist.ReduceOp.MIN)
+        if int(t_fit.item()) == 0:
+            if exchange == "halo":
+                raise SystemExit("--exchange halo: the blocks name more rows than the request slots hold (ids without locality); use allgather / auto")
+            exchange = "allgather"
+        else:
+            exchange = "halo"
+        del probe
+    for d in range(batch):
+        if exchange == "halo":
+            shards.append(JaccardHaloShard(ops, N_total, k, device=dev))
+        else:
+            shards.append(JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=False,
+                                       exchange="halo" if exchange == "halo_generic" else "allgather"))
 
     def step():
         for d in range(batch):
@@ -395,15 +430,25 @@ def main():
     t_edges_ms = sum(sh.edge_kernel_ms(last=args.steps) for sh in shards) / batch
     rot = {"i": 0}
 
+    halo_form = exchange == "halo"
+
     def one_edges():
         d = rot["i"] % batch
         rot["i"] += 1
-        ops.jaccard_edges(shards[d].table, N_total, k, b, e, shards[d].out, None)
+        sh = shards[d]
+        if halo_form:
+            ops.jaccard_edges_mapped(sh.table, sh.n_ext, k, n_local, b, sh.l2g, sh.out, None)
+        else:
+            ops.jaccard_edges(sh.table, N_total, k, b, e, sh.out, None)
 
     def one_ingest():
         d = rot["i"] % batch
         rot["i"] += 1
-        ops.jaccard_ingest(idx_local[d], n_local, k, N_total, shards[d].table[rank * shards[d].rpr:(rank + 1) * shards[d].rpr])
+        sh = shards[d]
+        if halo_form:
+            ops.jaccard_ingest_local(sh.idx_ext, sh.n_ext, k, sh.table)
+        else:
+            ops.jaccard_ingest(idx_local[d], n_local, k, N_total, sh.table[rank * sh.rpr:(rank + 1) * sh.rpr])
 
     t_edges_b2b_ms = time_kernel_ms(torch, one_edges, max(args.steps * batch, 40))
     t_ingest_ms = time_kernel_ms(torch, one_ingest, max(args.steps * batch, 40))
@@ -419,14 +464,15 @@ def main():
         except Exception:
             pmc = {}
     # the edge kernel of this shape is k_jaccard_edges_pipe (k <= 32) or k_jaccard_edges; make_traffic.py keys by kernel name
-    traffic = (pmc.get(f"jaccard_edges_pipe_N{N_total}_k{k}") or pmc.get(f"jaccard_edges_N{N_total}_k{k}") or {}).get("hbm_bytes_per_launch")
+    traffic = None if halo_form else (pmc.get(f"jaccard_edges_pipe_N{N_total}_k{k}") or pmc.get(f"jaccard_edges_N{N_total}_k{k}") or {}).get("hbm_bytes_per_launch")
     edge_kernel = "k_jaccard_edges_pipe" if (k <= 32 and not os.environ.get("GFICF_JACCARD_NO_PIPE")) else "k_jaccard_edges"   # the name rocprofv3 shows
     roofline = {"bound": "hbm", "kernel": edge_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_copy_rate": round(achieved / HBM_COPY_GBS, 4), "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json (separate --pmc passes of tools/pmc_round.sh, read requests priced by their width: tools/make_traffic.py)" if traffic else None,
                 "kernel_ms": round(t_edges_ms, 5), "kernel_ms_back_to_back": round(t_edges_b2b_ms, 5),
                 "ingest_kernel_ms": round(t_ingest_ms, 5),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "row_bytes": 4 * ops.row_words(N_total, k),
+                "row_bytes": 4 * (shards[0].row_words if halo_form else ops.row_words(N_total, k)),
                 "note": "kernel_ms: mean of HIP-event pairs around every edge-kernel launch of a second run of the K steps "
                         "(same stream, same order as the timed region); kernel_ms_back_to_back: the kernel alone, launched back to "
                         "back over the batch's tables"}
@@ -438,25 +484,38 @@ def main():
         "metric": "jaccard_edges_per_sec", "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": wl + f", windowed kNN (W=100) with {args.ids} ids; per data set: ingest + {'RCCL all-gather + ' if world > 1 else ''}"
-                               "edge kernel, device-resident, one stream, in order (no overlap between data sets or steps)",
+        "config": {"workload": wl + f", windowed kNN (W=100) with {args.ids} ids; per data set: " +
+                               ("ingest + edge kernel" if world == 1 else
+                                "halo plan + 2 all-to-alls (request slots, rows) + relabel + ingest + edge kernel on local ids" if halo_form else
+                                "ingest + RCCL all-gather of table rows + edge kernel") +
+                               ", device-resident, one stream, in order (no overlap between data sets or steps)",
                    "cells_total": N_total, "k": k, "data_sets_per_step": batch, "edges_per_step": edges_per_step,
-                   "partition": f"cell blocks x{world}" + (", 1 all-gather of table rows per data set" if world > 1 else "")},
+                   "partition": f"cell blocks x{world}" + ("" if world == 1 else f", exchange: {exchange}")},
         "timed_region_ms": round(region_ms, 4),
         "ms_per_data_set": dt / args.steps / batch * 1e3,
         "roofline": roofline,
     }
     if world > 1:
         sh0 = shards[0]
-        row_b = 4 * (sh0.pw if sh0.packed is not None else sh0.row_words)
-        out["exchange"] = {"bytes_received_per_rank_per_data_set": int(sh0.bytes_received), "rows_received_per_rank_per_data_set": int(sh0.rows_received),
-                           "row_bytes_on_the_wire": row_b, "ids": args.ids,
-                           "form": ("halo: unique-id request lists + the named rows, two all-to-alls" if args.exchange == "halo" else
-                                    "all-gather of table rows" + (" (bit-packed)" if sh0.packed is not None else ""))}
+        if halo_form:
+            out["exchange"] = {"bytes_received_per_rank_per_data_set": int(sh0.bytes_received),
+                               "rows_received_per_rank_per_data_set": int(sh0.rows_named_outside()),
+                               "row_bytes_on_the_wire": 4 * k, "ids": args.ids, "request_slots_per_owner": sh0.cap,
+                               "rows_of_the_sub_problem": sh0.n_ext, "table_row_bytes": 4 * sh0.row_words,
+                               "rows_named_outside_the_block_data_set_0": named_outside, "chosen_by": args.exchange,
+                               "form": "halo on local ids: P x cap request slots out, P x cap raw index rows back (two all-to-alls with equal splits, "
+                                       "no host round trip); bytes = the fixed slot traffic, rows = the slots in use"}
+        else:
+            row_b = 4 * (sh0.pw if sh0.packed is not None else sh0.row_words)
+            out["exchange"] = {"bytes_received_per_rank_per_data_set": int(sh0.bytes_received), "rows_received_per_rank_per_data_set": int(sh0.rows_received),
+                               "row_bytes_on_the_wire": row_b, "ids": args.ids, "rows_named_outside_the_block_data_set_0": named_outside,
+                               "chosen_by": args.exchange,
+                               "form": ("halo: unique-id request lists + the named rows, two all-to-alls" if exchange == "halo_generic" else
+                                        "all-gather of table rows" + (" (bit-packed)" if sh0.packed is not None else ""))}
 
     if args.pipeline:
         # the overlapped mode (not `value`): ingest / exchange of data set d+1 on a side stream under the edge kernel of d
-        psh = JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=True)
+        psh = JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=True)      # (all-gather form)
         for _ in range(3 * batch):
             psh.step(idx_local[0])
         fence()

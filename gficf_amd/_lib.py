@@ -44,6 +44,7 @@ SIGNATURES = {
     "gficf_ctx_sync": (_int, [_vp]),
     "gficf_ctx_set_gficf_options": (_int, [_vp, _int, _int]),
     "gficf_ctx_set_louvain_options": (_int, [_vp, _int]),
+    "gficf_ctx_set_jaccard_options": (_int, [_vp, _int]),
     "gficf_last_error": (ctypes.c_char_p, []),
     "gficf_ctx_set_print": (_int, [_vp, _vp]),
     "gficf_ctx_trim": (_int, [_vp]),
@@ -68,6 +69,12 @@ SIGNATURES = {
     "gficf_jaccard_pack_rows_device": (_int, [_vp, _vp, _i64, _int, _i64, _vp]),
     "gficf_jaccard_unpack_rows_device": (_int, [_vp, _vp, _i64, _int, _i64, _vp]),
     "gficf_jaccard_edges_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "gficf_jaccard_halo_workspace_bytes": (ctypes.c_size_t, [_i64, _int]),
+    "gficf_jaccard_halo_plan_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp]),
+    "gficf_jaccard_halo_serve_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp]),
+    "gficf_jaccard_halo_relabel_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_jaccard_ingest_local_device": (_int, [_vp, _vp, _i64, _int, _i64, _vp]),
+    "gficf_jaccard_edges_mapped_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _vp, _vp]),
     "gficf_jaccard_edges_filtered_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_filtered_host_plan": (_int, [_vp, _vp, _int, _i64, _int, _i64, ctypes.POINTER(_i64)]),

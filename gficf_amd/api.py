@@ -152,7 +152,8 @@ def _knn_matrix(mat, name="mat"):
 
 
 # ------------------------------------------------------------- Jaccard, reference-shaped
-def rcpp_parallel_jaccard_coef(mat, printOutput: bool = False, ctx: Context | None = None, devices=None) -> np.ndarray:
+def rcpp_parallel_jaccard_coef(mat, printOutput: bool = False, ctx: Context | None = None, devices=None,
+                               truncate_noninteger_ids: bool = False) -> np.ndarray:
     """Drop-in for the reference's ``rcpp_parallel_jaccard_coef(mat, printOutput)``.
 
     ``mat``: N x k matrix of 1-based neighbour ids (integer or float64, as R hands it over:
@@ -162,11 +163,24 @@ def rcpp_parallel_jaccard_coef(mat, printOutput: bool = False, ctx: Context | No
 
     ``devices`` (or the environment variable GFICF_HIP_DEVICES): a list of GPUs to shard the cells over, single process
     (``gficf_jaccard_host_multi``); same result.
+
+    ``truncate_noninteger_ids``: strict drop-in mode for ids given as non-integer doubles (rejected by default): the
+    reference's ``int k = mat(i,j) - 1`` (src/rcpp_parallel_jaccard_coeff.cpp:28) — the row is addressed by truncation, the
+    rows are intersected as the doubles they hold (``gficf_ctx_set_jaccard_options``; single device).
     """
     m, is_f64 = _knn_matrix(mat)
     N, k = m.shape
     E = N * k
     rm = np.zeros((3, E), dtype=np.float64)  # C-order (3, E) == column-major (E, 3)
+    if truncate_noninteger_ids:
+        ctx = ctx or default_context()
+        L = _lib.load()
+        check(L.gficf_ctx_set_jaccard_options(ctx.handle, 1))
+        try:
+            check(L.gficf_jaccard_host(ctx.handle, _np_ptr(m), is_f64, N, k, max(N, 1), _np_ptr(rm), 1 if printOutput else 0))
+        finally:
+            L.gficf_ctx_set_jaccard_options(ctx.handle, 0)
+        return rm.T
     mc = _multi(devices) if ctx is None else None
     if mc is not None:
         check(_lib.load().gficf_jaccard_host_multi(mc.handle, _np_ptr(m), is_f64, N, k, max(N, 1), _np_ptr(rm),
@@ -689,6 +703,42 @@ class HipOps:
         check(self.L.gficf_jaccard_edges_device(self._bind(), _tptr(table), N, k, cell_begin, cell_end,
                                                 ctypes.c_void_p(base), ctypes.c_void_p(base + 8 * n),
                                                 ctypes.c_void_p(base + 16 * n), _tptr(u)))
+
+    # -- the sharded build on local ids (csrc/halo.hip; gficf_amd.dist.JaccardHaloShard)
+    def halo_workspace_bytes(self, N_total: int, P: int) -> int:
+        return int(self.L.gficf_jaccard_halo_workspace_bytes(int(N_total), int(P)))
+
+    def halo_plan(self, idx_cm, n_local, k, N_total, cell_begin, P, rows_per_rank, cap, ws, req_out):
+        """idx_cm: (k, ld) int32, the block's global ids.  Fills req_out (P * cap int32: ids asked of every owner, 0 = empty)."""
+        if idx_cm.dtype != self.torch.int32:
+            raise ValueError("the halo exchange carries int32 ids")
+        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else n_local
+        check(self.L.gficf_jaccard_halo_plan_device(self._bind(), _tptr(idx_cm), n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap,
+                                                    _tptr(ws), _tptr(req_out)))
+
+    def halo_serve(self, idx_cm, n_local, k, cell_begin, req_in, rows_out):
+        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else n_local
+        check(self.L.gficf_jaccard_halo_serve_device(self._bind(), _tptr(idx_cm), n_local, k, ld, cell_begin, _tptr(req_in), int(req_in.numel()),
+                                                     _tptr(rows_out)))
+
+    def halo_relabel(self, idx_cm, n_local, k, N_total, cell_begin, P, rows_per_rank, cap, ws, req_out, rows_in, idx_ext, l2g):
+        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else n_local
+        check(self.L.gficf_jaccard_halo_relabel_device(self._bind(), _tptr(idx_cm), n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap,
+                                                       _tptr(ws), _tptr(req_out), _tptr(rows_in), _tptr(idx_ext), _tptr(l2g)))
+
+    def jaccard_ingest_local(self, idx_ext, n_ext, k, table):
+        """idx_ext: (k, n_ext) int32 local ids (0 = no id).  table: (n_ext, row_words(n_ext, k)) int32."""
+        check(self.L.gficf_jaccard_ingest_local_device(self._bind(), _tptr(idx_ext), n_ext, k, n_ext, _tptr(table)))
+
+    def jaccard_edges_mapped(self, table, n_ext, k, n_cells, src_offset, l2g, out3, u=None):
+        """Edges of the first n_cells rows of a local-id table; column 1 = src_offset + cell + 1, column 2 = l2g[local - 1]."""
+        n = n_cells * k
+        if out3.shape != (3, n) or out3.dtype != self.torch.float64:
+            raise ValueError(f"out3 must be float64 of shape (3, {n})")
+        base = out3.data_ptr()
+        check(self.L.gficf_jaccard_edges_mapped_device(self._bind(), _tptr(table), n_ext, k, n_cells, src_offset, _tptr(l2g),
+                                                       ctypes.c_void_p(base), ctypes.c_void_p(base + 8 * n), ctypes.c_void_p(base + 16 * n),
+                                                       _tptr(u)))
 
     def jaccard_edges_filtered(self, table, N: int, k: int, cell_begin: int, cell_end: int, u_ws, cell_ptr, out3):
         """Edges with u > 0 only, in order (reference R/clustCells.R:66).  u_ws: int16 workspace of n*k;

@@ -15,6 +15,7 @@ constexpr uint32_t GFICF_ST_BAD_CSC = 2u;   // rowidx outside [0, G) / colptr no
 constexpr uint32_t GFICF_ST_BAD_VALUE = 4u; // non-finite coordinate handed to the kNN search / bad edge weight
 constexpr uint32_t GFICF_ST_TOO_DENSE = 8u; // Louvain: a vertex touches more communities than its table holds
 constexpr uint32_t GFICF_ST_EXPLICIT_ZERO = 16u; // gficf_csc_device met an explicitly stored zero (its fast count is then not exact)
+constexpr uint32_t GFICF_ST_HALO_OVERFLOW = 32u; // sharded Jaccard, halo form: a block names more rows of one owner than the request slots hold
 
 constexpr int GFICF_POOL_SLOTS = 9;
 
@@ -42,6 +43,8 @@ struct gficf_ctx {
   // RunModularityClustering(modularity = 1 standard / 2 alternative), reference src/RModularityOptimizer.cpp:36,100 (clustcells()
   // always passes 1)
   int lv_modularity_fn = 1;
+  // gficf_ctx_set_jaccard_options: non-integer double ids are truncated as the reference does (src/rcpp_parallel_jaccard_coeff.cpp:28)
+  int jaccard_trunc = 0;
   gficf_host_plan* plan = nullptr;
   gficf_edge_plan* edge_plan = nullptr;
   gficf_adj_plan* adj_plan = nullptr;

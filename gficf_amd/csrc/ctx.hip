@@ -173,6 +173,12 @@ int gficf_ctx_set_louvain_options(gficf_ctx* ctx, int modularity_function) {
   return GFICF_OK;
 }
 
+int gficf_ctx_set_jaccard_options(gficf_ctx* ctx, int truncate_noninteger_ids) {
+  if (!ctx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ctx is NULL");
+  ctx->jaccard_trunc = truncate_noninteger_ids ? 1 : 0;
+  return GFICF_OK;
+}
+
 int gficf_ctx_sync(gficf_ctx* ctx) {
   GFICF_CTX_ENTER(ctx);
   GFICF_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -188,6 +194,9 @@ int gficf_ctx_sync(gficf_ctx* ctx) {
   if (st & GFICF_ST_EXPLICIT_ZERO)
     GFICF_FAIL(GFICF_ERR_EXPLICIT_ZEROS, "the CSC matrix stores explicit zeros, which gficf_csc_device's count of stored entries takes for "
                                          "non-zero cells (rowSums(M != 0), reference R/gficf.R:40,88): call gficf_csc_exact_device");
+  if (st & GFICF_ST_HALO_OVERFLOW)
+    GFICF_FAIL(GFICF_ERR_CAPACITY, "sharded Jaccard, halo exchange: the block names more rows of one owner than the request slots hold "
+                                   "(ids without locality): use the all-gather exchange for this input");
   if (st & GFICF_ST_TOO_DENSE)
     GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "Louvain: one hash class of a vertex's neighbouring communities overflowed the 8192-slot table");
   return GFICF_OK;

@@ -21,6 +21,7 @@
 //               overflow a bucket: a short per-wave list.
 // DESIGN.md section 3 has the measurements behind these choices (memory-only model, ablations, instruction rates).
 #include <atomic>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -109,17 +110,18 @@ __device__ inline bool row_dup_flag(const uint32_t* roww, int kpad, bool compact
 }
 
 // ------------------------------------------------------------------------------ ingest
+// zero_ok: 0 stands for "no id in this slot" (rows of a sharded sub-problem in local ids, halo.hip) instead of being an error
 template <typename T>
-__device__ inline uint32_t decode_id(T raw, int64_t N, bool& ok);
+__device__ inline uint32_t decode_id(T raw, int64_t N, bool& ok, int zero_ok = 0);
 template <>
-__device__ inline uint32_t decode_id<int32_t>(int32_t raw, int64_t N, bool& ok) {
-  ok = raw >= 1 && (int64_t)raw <= N;
+__device__ inline uint32_t decode_id<int32_t>(int32_t raw, int64_t N, bool& ok, int zero_ok) {
+  ok = (raw >= 1 && (int64_t)raw <= N) || (zero_ok && raw == 0);
   return ok ? (uint32_t)raw : 0u;
 }
 template <>
-__device__ inline uint32_t decode_id<double>(double raw, int64_t N, bool& ok) {
+__device__ inline uint32_t decode_id<double>(double raw, int64_t N, bool& ok, int zero_ok) {
   // reference: int k = mat(i,j) - 1  (:28) — only integer-valued ids are meaningful.
-  ok = raw >= 1.0 && raw <= (double)N && raw == trunc(raw);
+  ok = (raw >= 1.0 && raw <= (double)N && raw == trunc(raw)) || (zero_ok && raw == 0.0);
   return ok ? (uint32_t)raw : 0u;
 }
 
@@ -130,7 +132,7 @@ constexpr int INGEST_ROWS = 64;
 template <typename T, int KPAD, bool CMP>
 __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                 int64_t N_total, uint32_t* __restrict__ table,
-                                                uint32_t* __restrict__ status) {
+                                                uint32_t* __restrict__ status, int zero_ok) {
   __shared__ uint32_t tile[INGEST_ROWS][KPAD + 1];
   __shared__ uint32_t dup[INGEST_ROWS];
   constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64
       uint32_t v = 0;
       if (j < k && r < n_rows) {
         bool ok;
-        v = decode_id<T>(idx[(int64_t)j * ld + r], N_total, ok);
+        v = decode_id<T>(idx[(int64_t)j * ld + r], N_total, ok, zero_ok);
         bad |= !ok;
       }
       tile[lane][j] = v;
@@ -208,7 +210,7 @@ __device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD], int k) {
 template <typename T, int KPAD, bool CMP>
 __global__ __launch_bounds__(256) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                      int64_t N_total, uint32_t* __restrict__ table,
-                                                     uint32_t* __restrict__ status) {
+                                                     uint32_t* __restrict__ status, int zero_ok) {
   constexpr int ROWS = 64;
   constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
   __shared__ uint32_t tile[ROWS][KPAD + 1];
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void k_ingest_tile(const T* __restrict__ idx, 
       uint32_t v = 0;
       if (j < k && r < n_rows) {
         bool ok;
-        v = decode_id<T>(raw[m], N_total, ok);
+        v = decode_id<T>(raw[m], N_total, ok, zero_ok);
         bad |= !ok;
       }
       tile[lane][j] = v;
@@ -295,7 +297,7 @@ constexpr int INGEST2_ROWS = 64;
 template <typename T, int KPAD, bool CMP>
 __global__ __launch_bounds__(INGEST2_ROWS) void k_ingest_reg(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                              int64_t N_total, uint32_t* __restrict__ table,
-                                                             uint32_t* __restrict__ status) {
+                                                             uint32_t* __restrict__ status, int zero_ok) {
   constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
   __shared__ uint32_t tile[INGEST2_ROWS][ROWW + 1];
   const int tid = threadIdx.x;
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(INGEST2_ROWS) void k_ingest_reg(const T* __restrict
       v[j] = 0;
       if (j < k && r < n_rows) {
         bool ok;
-        v[j] = decode_id<T>(idx[(int64_t)j * ld + r], N_total, ok);
+        v[j] = decode_id<T>(idx[(int64_t)j * ld + r], N_total, ok, zero_ok);
         bad |= !ok;
       }
     }
@@ -430,6 +432,9 @@ struct EdgeOut {
   uint16_t* u16;    // optional intersection counts, compact (input of the edge filter)
   int set_mode;     // rows with duplicate ids: 0 = multiset intersection (std::set_intersection of the parallel entry),
                     // 1 = set intersection (Rcpp::intersect of the serial jaccard_coeff entry)
+  // sharded sub-problem in local ids (halo.hip): column 1 is src_off + cell + 1, column 2 l2g[local id - 1] (NULL: the id itself)
+  const int32_t* l2g = nullptr;
+  uint32_t src_off = 0;
 };
 
 // Output modes of the edge kernel (a template parameter, so that the number of stores per cell is known to the
@@ -444,7 +449,7 @@ __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint
   const bool pos = u > 0;
   // written once, never re-read by this kernel: non-temporal, so the table rows keep the L2
   if (OUT != OUT_U16) {
-    __builtin_nontemporal_store(pos ? (double)(uint32_t)(cell + 1) : 0.0, o.src + r);   // reference :49 (cell + 1 <= 2^31)
+    __builtin_nontemporal_store(pos ? (double)((uint32_t)(cell + 1) + o.src_off) : 0.0, o.src + r);   // reference :49 (cell + 1 <= 2^31)
     __builtin_nontemporal_store(pos ? (double)dst : 0.0, o.dst + r);                    // reference :50
     __builtin_nontemporal_store(lut[u], o.w + r);                                       // reference :51 (lut[0] = 0/(2k) = 0.0: the zero row)
   }
@@ -459,8 +464,9 @@ __device__ inline void store_edge(const EdgeOut o, int64_t r, int64_t cell, uint
 template <int KPAD, bool CMP, int OUT>
 __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64_t i, int k, int64_t out_base,
                                        uint32_t* sA, uint32_t* sB, int lane, double* o_src, double* o_dst,
-                                       double* o_w, int32_t* o_u, uint16_t* o_u16, int set_mode, const double* lut) {
-  const EdgeOut o{o_src, o_dst, o_w, o_u, o_u16, set_mode};
+                                       double* o_w, int32_t* o_u, uint16_t* o_u16, int set_mode, const double* lut,
+                                       const int32_t* l2g, uint32_t src_off) {
+  const EdgeOut o{o_src, o_dst, o_w, o_u, o_u16, set_mode, nullptr, src_off};
   constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
   for (int e = lane; e < KPAD; e += 64) sA[e] = row_slot_id(table + i * ROWW, e, KPAD, CMP);
   wave_lds_fence();
@@ -487,7 +493,7 @@ __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64
       u = cnt;
       wave_lds_fence();
     }
-    if (lane == 0) store_edge<OUT>(o, out_base + s, i, dst, u, lut);
+    if (lane == 0) store_edge<OUT>(o, out_base + s, i, (l2g && dst) ? (uint32_t)l2g[dst - 1] : dst, u, lut);
   }
 }
 
@@ -563,7 +569,10 @@ __device__ inline int group_sum(int x) {
 //   * counts are permuted back to one-slot-per-lane and stored as three coalesced runs.
 // The load of the next cell's own row is issued ahead of the gathers and the stores of the
 // previous cell's edges behind them, so neither sits on the wait for the gathers.
-template <int KPAD, bool BIG, bool CMP, int OUT>
+// MAP: the table holds the local ids of a sharded sub-problem; the neighbour column is written through o.l2g (loaded per cell
+// right after the own row is decoded, long before the edges are stored: a load at the store would put the wait for the gathers
+// in front of it).
+template <int KPAD, bool BIG, bool CMP, int OUT, bool MAP = false>
 __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
   using C = JCfg<KPAD, CMP>;
@@ -749,6 +758,9 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
       // count is discarded at the store
       asafe[q] = a[q] != 0 ? a[q] : (uint32_t)(i + 1);
     }
+    uint32_t ag[C::EPL];                         // what column 2 shows for the slot
+#pragma unroll
+    for (int q = 0; q < C::EPL; ++q) ag[q] = MAP ? (uint32_t)o.l2g[asafe[q] - 1] : a[q];
     bool slow = __ballot((flags & ROW_DUP_FLAG) != 0) != 0ull;
     // next cell's own row: ahead of the gathers, so that it has landed by the next iteration
     const int64_t i_next = i + nwaves;
@@ -873,13 +885,13 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
     wave_lds_fence();
     if (slow) {
       slow_cell<KPAD, CMP, OUT>(table, i, k, (i - cell_begin) * (int64_t)k, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w,
-                                o.u, o.u16, o.set_mode, s_lut);
+                                o.u, o.u16, o.set_mode, s_lut, o.l2g, o.src_off);
     } else {
       have_prev = true;
       prev_i = i;
 #pragma unroll
       for (int q = 0; q < C::EPL; ++q) {
-        prev_a[q] = a[q];
+        prev_a[q] = ag[q];
         prev_u[q] = a[q] != 0 ? myu[q] : 0;      // rejected id: zero row
       }
     }
@@ -902,7 +914,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
 // four runs of k x 8 B that straddle segments: 17 % fewer write requests, none of them partial (memory-only model,
 // tools/lab/gather_lab.hip: 39.8 -> 35.5 us at 100 k x 30).
 // B16 = false (compact rows only): N < 2^16, no id has bit 16 — the bitmap words of the rows are zero and are not looked at.
-template <int KPAD, bool BIG, bool CMP, int OUT, bool B16 = true>
+template <int KPAD, bool BIG, bool CMP, int OUT, bool B16 = true, bool MAP = false>
 __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
   using C = JCfg<KPAD, CMP>;
@@ -1107,6 +1119,9 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   uint32_t araw_cur = decode_own(raw);
   uint4 bv_cur[NST];
   uint32_t id_cur = true_id(araw_cur);
+  // MAP: what column 2 shows for the slot, o.l2g[id - 1] — one more unconditional load per cell, issued with the cell's
+  // gathers and first looked at when the cell's edges are parked, an iteration later
+  uint32_t gid_cur = MAP ? (uint32_t)o.l2g[(id_cur != 0 ? id_cur : (uint32_t)(first + 1)) - 1] : 0u;
   issue_gathers(id_cur != 0 ? id_cur : (uint32_t)(first + 1), bv_cur);
   {
     const int64_t i1 = first + 1;
@@ -1141,7 +1156,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     const int64_t pb = (qfirst - cell_begin) * (int64_t)k;            // scalar: first entry of the quad
     const int nedges = ncells * k;
     if (OUT != OUT_U16) {
-      const uint32_t c1st = (uint32_t)(qfirst + 1);
+      const uint32_t c1st = (uint32_t)(qfirst + 1) + o.src_off;
       const bool pos0 = p0.y > 0, pos1 = p1.y > 0;
       const v2d vs = {pos0 ? (double)(c1st + (uint32_t)qc0) : 0.0, pos1 ? (double)(c1st + (uint32_t)qc1) : 0.0};   // reference :49
       const v2d vd = {pos0 ? (double)p0.x : 0.0, pos1 ? (double)p1.x : 0.0};                                     // reference :50
@@ -1180,6 +1195,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     // the own row of the cell after next FIRST: next iteration's wait for it then leaves the gathers issued behind it in flight
     load_own(i2 < cell_end ? i2 : last_cell, raw);
     __builtin_amdgcn_sched_barrier(0);                                 // (the scheduler would hoist the gathers above the own-row load)
+    const uint32_t gid_next = MAP ? (uint32_t)o.l2g[(a1 != 0 ? a1 : (uint32_t)(i + 1)) - 1] : 0u;
     issue_gathers(a1 != 0 ? a1 : (uint32_t)(i + 1), nxt);              // no next cell: every lane reads row i (one line)
     __builtin_amdgcn_sched_barrier(0);
     if (PARK) park_prev((CQ + 3) & 3);
@@ -1189,10 +1205,11 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     const bool slow = process(araw_cur, cur, u);
     any_slow |= slow;
     prev_i = i;
-    prev_a = id_cur;
+    prev_a = MAP ? gid_cur : id_cur;
     prev_u = u;
     araw_cur = araw_next;
     id_cur = a1;
+    gid_cur = gid_next;
   };
 
   uint4 bv_b[NST];
@@ -1229,7 +1246,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
       if (a != 0) f |= row_dup_flag(table + (int64_t)(a - 1) * ROWW, KPAD, CMP);
       if (__ballot(f) != 0ull)
         slow_cell<KPAD, CMP, OUT>(table, c, k, (c - cell_begin) * (int64_t)k, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w,
-                                  o.u, o.u16, o.set_mode, s_lut);
+                                  o.u, o.u16, o.set_mode, s_lut, o.l2g, o.src_off);
     }
   }
 }
@@ -1278,6 +1295,63 @@ __global__ __launch_bounds__(256) void k_edge_write(const uint32_t* __restrict__
       }
       pos += __popcll(m);
     }
+  }
+}
+
+// ------------------------------------------------- non-integer double ids, the reference's way (gficf_ctx_set_jaccard_options)
+// src/rcpp_parallel_jaccard_coeff.cpp:28-52 on the raw doubles: kk = (int)(mat(i,j) - 1) addresses the neighbour row, the two
+// rows are intersected as multisets of doubles (std::sort + std::set_intersection), the edge row is (i+1, kk+1, u/(2k-u)).
+// One wave per cell, rows staged in LDS, all-pairs with occurrence ranks (the multiset rule of slow_cell).  Values outside
+// (0, N+1) — where the reference reads outside the matrix — and NaN raise GFICF_ST_BAD_ID; their edges are left zero.
+__global__ __launch_bounds__(256) void k_jaccard_trunc_f64(const double* __restrict__ mat, int64_t N, int k, int64_t ld,
+                                                           double* __restrict__ o_src, double* __restrict__ o_dst,
+                                                           double* __restrict__ o_w, uint32_t* __restrict__ status) {
+  __shared__ double sA[4][GFICF_JACCARD_MAX_K], sB[4][GFICF_JACCARD_MAX_K];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* const A = sA[wave];
+  double* const B = sB[wave];
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
+  const double hi = (double)N + 1.0;
+  for (int64_t i = w0; i < N; i += nw) {
+    bool bad = false;
+    for (int e = lane; e < k; e += 64) {
+      const double v = mat[(int64_t)e * ld + i];
+      bad |= !(v > 0.0 && v < hi);
+      A[e] = v;
+    }
+    if (bad) atomicOr(status, GFICF_ST_BAD_ID);
+    wave_lds_fence();
+    for (int s = 0; s < k; ++s) {
+      const double v = A[s];
+      const int64_t r = i * (int64_t)k + s;
+      int u = 0;
+      int64_t kk = 0;
+      if (v > 0.0 && v < hi) {                                      // wave-uniform (A[s] is one value)
+        kk = (int64_t)(int)(v - 1.0);                               // reference :28, truncation toward zero
+        for (int e = lane; e < k; e += 64) B[e] = mat[(int64_t)e * ld + kk];
+        wave_lds_fence();
+        int cnt = 0;
+        for (int e = lane; e < k; e += 64) {
+          const double b = B[e];
+          int rank = 0, ca = 0;
+          for (int t = 0; t < k; ++t) {
+            ca += (A[t] == b);
+            rank += (t < e && B[t] == b);
+          }
+          cnt += rank < ca;                                         // min multiplicity (std::set_intersection)
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        u = cnt;
+        wave_lds_fence();
+      }
+      if (lane == 0) {
+        o_src[r] = u > 0 ? (double)(i + 1) : 0.0;                   // :49
+        o_dst[r] = u > 0 ? (double)(kk + 1) : 0.0;                  // :50
+        o_w[r] = u > 0 ? (double)u / (2.0 * (double)k - (double)u) : 0.0;   // :51
+      }
+    }
+    wave_lds_fence();
   }
 }
 
@@ -1368,7 +1442,7 @@ __global__ __launch_bounds__(256) void k_unpack_rows(const uint32_t* __restrict_
 
 template <typename T>
 int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t ld, int64_t N_total,
-                  uint32_t* table) {
+                  uint32_t* table, int zero_ok = 0) {
   const TableFmt f = table_fmt(N_total, k);
   const int64_t cap = (int64_t)ctx->num_cus * 8;
   const int64_t tiles2 = gficf_ceil_div(n_rows, INGEST2_ROWS);
@@ -1380,14 +1454,14 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
   do {                                                                                                                     \
     if (use_reg)                                                                                                           \
       hipLaunchKernelGGL((k_ingest_reg<T, KP, CM>), dim3(grid2), dim3(INGEST2_ROWS), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
-                         table, ctx->d_status);                                                                            \
+                         table, ctx->d_status, zero_ok);                                                                   \
     else                                                                                                                   \
       hipLaunchKernelGGL((k_ingest_tile<T, KP, CM>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total,  \
-                         table, ctx->d_status);                                                                            \
+                         table, ctx->d_status, zero_ok);                                                                   \
   } while (0)
 #define LAUNCH_INGEST(KP, CM)                                                                                   \
   hipLaunchKernelGGL((k_ingest<T, KP, CM>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
-                     table, ctx->d_status)
+                     table, ctx->d_status, zero_ok)
   switch (f.kpad) {
     case 16: LAUNCH_INGEST_REG(16, false); break;
     case 32: if (f.compact) LAUNCH_INGEST_REG(32, true); else LAUNCH_INGEST_REG(32, false); break;
@@ -1429,8 +1503,8 @@ int edge_blocks_per_cu(K kernel, int threads, size_t lds_bytes, std::atomic<int>
   return GFICF_OK;
 }
 
-template <int KPAD, bool BIG, bool CMP, int OUT>
-int launch_edges_o(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+template <int KPAD, bool BIG, bool CMP, int OUT, bool MAP>
+int launch_edges_m(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
   using C = JCfg<KPAD, CMP>;
   // grid = what is resident at once (occupancy x CUs); waves stride over the cells
   static std::atomic<int> bpc_general{0}, bpc_pipe{0}, bpc_pipe_nob16{0};
@@ -1441,31 +1515,39 @@ int launch_edges_o(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
     if (!no_pipe) {
       const bool nob16 = CMP && N < 65536;     // no id carries bit 16: the kernel variant that does not look for it (configs 1-3 of BASELINE.json)
       int rc;
-      if (nob16) rc = edge_blocks_per_cu(k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, !CMP>, C::WAVES * 64, lds_bytes, bpc_pipe_nob16, &blocks_per_cu);
-      else rc = edge_blocks_per_cu(k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT>, C::WAVES * 64, lds_bytes, bpc_pipe, &blocks_per_cu);
+      if (nob16) rc = edge_blocks_per_cu(k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, !CMP, MAP>, C::WAVES * 64, lds_bytes, bpc_pipe_nob16, &blocks_per_cu);
+      else rc = edge_blocks_per_cu(k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, true, MAP>, C::WAVES * 64, lds_bytes, bpc_pipe, &blocks_per_cu);
       if (rc) return rc;
       const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
       const int64_t need4 = gficf_ceil_div(gficf_ceil_div(ce - cb, 4), C::WAVES);       // a wave takes four cells at a time
       const unsigned grid4 = (unsigned)(need4 < cap ? need4 : cap);
       if (nob16)
-        hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, !CMP>), dim3(grid4), dim3(C::WAVES * 64), lds_bytes, ctx->stream,
+        hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, !CMP, MAP>), dim3(grid4), dim3(C::WAVES * 64), lds_bytes, ctx->stream,
                            table, N, k, cb, ce, o);
       else
-        hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT>), dim3(grid4), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
+        hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, true, MAP>), dim3(grid4), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
                            N, k, cb, ce, o);
       GFICF_HIP_CHECK(hipGetLastError());
       return GFICF_OK;
     }
   }
-  const int rc = edge_blocks_per_cu(k_jaccard_edges<KPAD, BIG, CMP, OUT>, C::WAVES * 64, lds_bytes, bpc_general, &blocks_per_cu);
+  const int rc = edge_blocks_per_cu(k_jaccard_edges<KPAD, BIG, CMP, OUT, MAP>, C::WAVES * 64, lds_bytes, bpc_general, &blocks_per_cu);
   if (rc) return rc;
   const int64_t blocks_needed = gficf_ceil_div(ce - cb, C::WAVES);
   const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
   const unsigned grid = (unsigned)(blocks_needed < cap ? blocks_needed : cap);
-  hipLaunchKernelGGL((k_jaccard_edges<KPAD, BIG, CMP, OUT>), dim3(grid), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
+  hipLaunchKernelGGL((k_jaccard_edges<KPAD, BIG, CMP, OUT, MAP>), dim3(grid), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
                      N, k, cb, ce, o);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
+}
+
+template <int KPAD, bool BIG, bool CMP, int OUT>
+int launch_edges_o(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+  if constexpr (OUT != OUT_U16) {              // (the counts-only output has no neighbour column)
+    if (o.l2g) return launch_edges_m<KPAD, BIG, CMP, OUT, true>(ctx, table, N, k, cb, ce, o);
+  }
+  return launch_edges_m<KPAD, BIG, CMP, OUT, false>(ctx, table, N, k, cb, ce, o);
 }
 
 template <int KPAD, bool BIG, bool CMP>
@@ -1500,7 +1582,8 @@ int check_nk(int64_t N, int k) {
   if (N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N = %lld is negative", (long long)N);
   if (k < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "k = %d is negative", k);
   if (k > GFICF_JACCARD_MAX_K)
-    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d exceeds GFICF_JACCARD_MAX_K = %d", k, GFICF_JACCARD_MAX_K);
+    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d neighbours per cell: this build handles at most GFICF_JACCARD_MAX_K = %d (the reference has no limit)", k,
+               GFICF_JACCARD_MAX_K);
   if (N > 0x7FFFFFFFll) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "N = %lld exceeds int32 ids", (long long)N);
   return GFICF_OK;
 }
@@ -1542,6 +1625,31 @@ int gficf_jaccard_edges_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N
   return launch_edges_k(ctx, (const uint32_t*)d_table, N, k, cell_begin, cell_end, o);
 }
 
+/* Rows of a sharded sub-problem in local ids (halo.hip): n_ext rows, ids in [1, n_ext], 0 = no id in the slot. */
+int gficf_jaccard_ingest_local_device(gficf_ctx* ctx, const int32_t* d_idx_ext, int64_t n_ext, int k, int64_t ld, int32_t* d_table) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = check_nk(n_ext, k);
+  if (rc) return rc;
+  if (n_ext == 0 || k == 0) return GFICF_OK;
+  if (!d_idx_ext || !d_table) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (ld < n_ext) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < n_ext = %lld", (long long)ld, (long long)n_ext);
+  return launch_ingest<int32_t>(ctx, d_idx_ext, n_ext, k, ld, n_ext, (uint32_t*)d_table, 1);
+}
+
+/* Edges of the first n_cells rows of such a table; column 1 = src_offset + cell + 1, column 2 = d_l2g[local id - 1]. */
+int gficf_jaccard_edges_mapped_device(gficf_ctx* ctx, const int32_t* d_table, int64_t n_ext, int k, int64_t n_cells, int64_t src_offset,
+                                      const int32_t* d_l2g, double* d_src, double* d_dst, double* d_w, int32_t* d_u) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = check_nk(n_ext, k);
+  if (rc) return rc;
+  if (n_cells < 0 || n_cells > n_ext || src_offset < 0 || src_offset + n_cells > 0x7FFFFFFFll)
+    GFICF_FAIL(GFICF_ERR_INVALID_ARG, "n_cells = %lld / src_offset = %lld out of range", (long long)n_cells, (long long)src_offset);
+  if (n_cells == 0 || k == 0) return GFICF_OK;
+  if (!d_table || !d_l2g || !d_src || !d_dst || !d_w) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  EdgeOut o{d_src, d_dst, d_w, d_u, nullptr, 0, d_l2g, (uint32_t)src_offset};
+  return launch_edges_k(ctx, (const uint32_t*)d_table, n_ext, k, 0, n_cells, o);
+}
+
 int gficf_jaccard_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int64_t N, int k, int64_t ld,
                          int32_t* d_table_ws, double* d_rmat, int32_t* d_u) {
   int rc = gficf_jaccard_ingest_device(ctx, d_idx, idx_is_f64, N, k, ld, N, d_table_ws);
@@ -1557,7 +1665,37 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
   if (rc) return rc;
   if (print_output) gficf_print(ctx, "Running Parallell Jaccard Coefficient Estimation...\n");  // reference :63
   const int64_t E = N * (int64_t)k;
-  if (E > 0) {
+  bool trunc_path = false;
+  if (E > 0 && idx && idx_is_f64 && ctx->jaccard_trunc && ld >= N) {
+    // strict drop-in mode: does the matrix hold a non-integer value at all?  (host scan, only with the option on)
+    const double* const m = (const double*)idx;
+    for (int j = 0; j < k && !trunc_path; ++j)
+      for (int64_t i = 0; i < N; ++i) {
+        const double v = m[(int64_t)j * ld + i];
+        if (v != std::trunc(v)) { trunc_path = true; break; }     // (NaN too: the kernel rejects it)
+      }
+  }
+  if (trunc_path) {
+    if (!rmat) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
+    void* d_idx = nullptr;
+    double* d_rmat = nullptr;
+    hipError_t e = gficf_pool_get(ctx, 0, sizeof(double) * (size_t)ld * (size_t)k, &d_idx);
+    if (e == hipSuccess) e = gficf_pool_get(ctx, 2, sizeof(double) * 3 * (size_t)E, (void**)&d_rmat);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, sizeof(double) * (size_t)ld * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
+    rc = GFICF_OK;
+    if (e == hipSuccess) {
+      int64_t blocks = gficf_ceil_div(N, 4);
+      if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+      hipLaunchKernelGGL(k_jaccard_trunc_f64, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const double*)d_idx, N, k, ld, d_rmat, d_rmat + E,
+                         d_rmat + 2 * E, ctx->d_status);
+      e = hipGetLastError();
+      if (e == hipSuccess) e = hipMemcpyAsync(rmat, d_rmat, sizeof(double) * 3 * (size_t)E, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) rc = gficf_ctx_sync(ctx);
+      else (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_jaccard_host: %s", hipGetErrorString(e));
+    if (rc) return rc;
+  } else if (E > 0) {
     if (!idx || !rmat) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
     if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
     const size_t esz = idx_is_f64 ? sizeof(double) : sizeof(int32_t);

@@ -291,6 +291,97 @@ class JaccardShard:
         self.ops.sync()
 
 
+class JaccardHaloShard:
+    """The sharded Jaccard build on LOCAL ids (csrc/halo.hip): a rank's sub-problem is its own block of cells plus the remote
+    rows the block names, renumbered 1..n_ext — with n_ext < 2^17 it runs on the compact 64 B-row table and the fast edge
+    kernel whatever N_total is (the all-gather form takes 128 B rows from 2^17 cells on), and only the named rows travel.
+
+    Exchange: two all-to-alls with EQUAL, host-known splits (``cap`` request slots per owner: ids out, raw index rows back) —
+    no count exchange and no host round trip inside a step.  ``cap`` defaults to what keeps n_ext below 2^17 (at most 8192).
+    A block that names more than ``cap`` rows of one owner (ids without locality) makes the next :meth:`sync` raise
+    ``GFICF_ERR_CAPACITY``; the caller then builds a :class:`JaccardShard` (all-gather) for that input — the choice is a
+    property of the data (bench.py makes it on the warm-up step).  Same interface and the same bits as JaccardShard.
+    Input blocks must be int32 (what the kNN search and uwot produce)."""
+
+    def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False, cap: int | None = None,
+                 time_edges: bool = False):
+        self.ops, self.N, self.k, self.group = ops, int(N_total), int(k), group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rpr = rows_per_rank(self.N, self.world)
+        self.b, self.e = shard_bounds(self.N, self.world, self.rank)
+        self.n_local = self.e - self.b
+        if cap is None:
+            room = (1 << 17) - 1 - self.rpr                      # rows left below 2^17 next to the largest block
+            cap = max(64, min(8192, room // self.world)) if room >= 64 * self.world else 1024
+        self.cap = int(cap)
+        self.n_ext = self.n_local + self.world * self.cap
+        self.exchange = "halo"
+        self.time_edges = bool(time_edges)
+        self.edge_events = []
+        i32 = dict(dtype=torch.int32, device=device)
+        self.ws = torch.zeros(ops.halo_workspace_bytes(self.N, self.world), dtype=torch.uint8, device=device)
+        self.req_out = torch.zeros(self.world * self.cap, **i32)
+        self.req_in = torch.zeros(self.world * self.cap, **i32)
+        self.rows_out = torch.zeros(self.world * self.cap * self.k, **i32)
+        self.rows_in = torch.zeros(self.world * self.cap * self.k, **i32)
+        self.idx_ext = torch.zeros((self.k, max(self.n_ext, 1)), **i32)
+        self.l2g = torch.zeros(max(self.n_ext, 1), **i32)
+        self.row_words = ops.row_words(self.n_ext, self.k)
+        self.table = torch.zeros((max(self.n_ext, 1), self.row_words), **i32)
+        self.out = torch.zeros((3, self.n_local * self.k), dtype=torch.float64, device=device)
+        self.u = torch.zeros(self.n_local * self.k, **i32) if with_u else None
+        self.packed = None
+        # what a step moves: the request slots and the reply slots of the other ranks (fixed), and what of it is used
+        self.bytes_received = (self.world - 1) * self.cap * 4 * (1 + self.k)
+        self.rows_received = 0
+
+    def step(self, idx_local_cm):
+        """idx_local_cm: (k, n_local) int32 == column-major block of the kNN matrix, global 1-based ids.  Returns this rank's
+        (3, n_local*k) slice of the edge matrix."""
+        o, P, k, nl = self.ops, self.world, self.k, self.n_local
+        o.halo_plan(idx_local_cm, nl, k, self.N, self.b, P, self.rpr, self.cap, self.ws, self.req_out)
+        if P > 1:
+            _all_to_all(self.req_in, self.req_out, None, None, self.group)
+        else:
+            self.req_in.copy_(self.req_out)
+        o.halo_serve(idx_local_cm, nl, k, self.b, self.req_in, self.rows_out)
+        if P > 1:
+            _all_to_all(self.rows_in, self.rows_out, None, None, self.group)
+        else:
+            self.rows_in.copy_(self.rows_out)
+        o.halo_relabel(idx_local_cm, nl, k, self.N, self.b, P, self.rpr, self.cap, self.ws, self.req_out, self.rows_in, self.idx_ext, self.l2g)
+        o.jaccard_ingest_local(self.idx_ext, self.n_ext, k, self.table)
+        if self.time_edges:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if nl > 0:
+            o.jaccard_edges_mapped(self.table, self.n_ext, k, nl, self.b, self.l2g, self.out, self.u)
+        if self.time_edges:
+            e1.record()
+            self.edge_events.append((e0, e1))
+        return self.out
+
+    def rows_named_outside(self) -> int:
+        """Rows this rank's block named outside itself in the last step (a device read: not for a timed loop)."""
+        self.rows_received = int((self.req_out != 0).sum().item())
+        return self.rows_received
+
+    def edge_kernel_ms(self, last: int | None = None) -> float:
+        ev = self.edge_events if last is None else self.edge_events[-last:]
+        return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+
+    def wait(self):
+        pass
+
+    def release(self):
+        pass
+
+    def sync(self):
+        """Wait for the stream; raises GficfError(GFICF_ERR_CAPACITY) when a step overflowed the request slots."""
+        self.ops.sync()
+
+
 class GficfShard:
     """Per-rank state of the sharded GF-ICF normalisation (local CSC block of cells)."""
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFICF_HIP_ABI_VERSION 2
+#define GFICF_HIP_ABI_VERSION 3
 
 typedef enum gficf_status {
   GFICF_OK = 0,
@@ -41,7 +41,8 @@ typedef enum gficf_status {
   GFICF_ERR_HIP = 5,           /* a HIP runtime call failed; message has hipGetErrorString */
   GFICF_ERR_UNSUPPORTED = 6,   /* k > GFICF_JACCARD_MAX_K, table too large for the kernel,
                                   edge weights too large for the Louvain fixed point ...   */
-  GFICF_ERR_CAPACITY = 7,      /* caller-provided output buffer too small                  */
+  GFICF_ERR_CAPACITY = 7,      /* caller-provided output buffer too small; halo request
+                                  slots of the sharded Jaccard build too few (deferred)    */
   GFICF_ERR_BAD_VALUE = 8,     /* a non-finite coordinate in the kNN point matrix, a
                                   negative / non-finite edge weight (Louvain)             */
   GFICF_ERR_EXPLICIT_ZEROS = 9 /* gficf_csc_device met an explicitly stored zero: its count of
@@ -93,6 +94,19 @@ int gficf_ctx_trim(gficf_ctx* ctx);
  * print_output mirrors the reference's printOutput banners (:61-64, :75-78) on stdout. */
 int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k,
                        int64_t ld, double* rmat, int print_output);
+
+/* Strict drop-in mode for ids given as NON-INTEGER doubles (never the case for kNN output; default off: such a matrix is
+ * rejected with GFICF_ERR_BAD_ID).  With truncate_noninteger_ids != 0 gficf_jaccard_host reproduces what the reference
+ * does with them (src/rcpp_parallel_jaccard_coeff.cpp:28-46): the neighbour ROW is addressed by truncation,
+ * kk = (int)(mat(i,j) - 1), while the two rows are intersected as the raw doubles they hold (3.2 and 3.7 both name row 3
+ * but are different set elements), and column 2 of the result is kk + 1.  Accepted values: 0 < v < N + 1 (v in (0, 1)
+ * truncates to row 0 like 1.0 does); anything else — the reference would read outside the matrix — is GFICF_ERR_BAD_ID.
+ * A matrix whose doubles are all integer-valued takes the ordinary kernels; one with non-integer values an exact
+ * all-pairs kernel on the doubles (one wave per cell; not tuned: the case is a curiosity).  Applies to
+ * gficf_jaccard_host on this context (the entry the .Call binds); the R glue turns it on with GFICF_HIP_TRUNCATE_IDS=1.
+ * k is limited to GFICF_JACCARD_MAX_K = 256 neighbours per cell in every Jaccard entry (the reference has no limit;
+ * clustcells() defaults to 15 and Phenograph to 30): beyond it the calls return GFICF_ERR_UNSUPPORTED and the message says so. */
+int gficf_ctx_set_jaccard_options(gficf_ctx* ctx, int truncate_noninteger_ids);
 
 /* Compact host return (the reference's 24 B row is a function of (i, idx[i,j], u)): the intersection counts alone,
  * u[i*k + j], 2 B per edge across PCIe instead of 24.  gficf_jaccard_expand_host rebuilds the reference's (N*k) x 3
@@ -152,6 +166,37 @@ int gficf_jaccard_unpack_rows_device(gficf_ctx* ctx, const uint32_t* d_packed, i
 int gficf_jaccard_edges_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k,
                                int64_t cell_begin, int64_t cell_end, double* d_src,
                                double* d_dst, double* d_w, int32_t* d_u);
+
+/* ---- The sharded build on LOCAL ids ("halo" exchange; csrc/halo.hip).  What is sharded: the cells of the reference's
+ * parallelFor(0, N, worker) (src/rcpp_parallel_jaccard_coeff.cpp:73); a block of cells needs its own rows and the rows it names
+ * (:28-36).  When the ids have locality (cells in a spatial / cluster order) those are few, and a rank fetches just them
+ * instead of taking part in an all-gather of the whole table:
+ *   plan    (every rank)  marks the ids its block names outside itself and lists them per owner in P x cap request slots
+ *                         (0 = empty): d_req_out, to be exchanged by an all-to-all with EQUAL splits of cap ids (no counts
+ *                         to exchange, no host round trip).  A block that names more than cap rows of one owner raises
+ *                         GFICF_ERR_CAPACITY at the next gficf_ctx_sync: the caller then uses the all-gather form;
+ *   serve   (every rank)  copies the rows asked of it — raw global ids from ITS input block — into P x cap x k reply slots
+ *                         (second all-to-all, equal splits of cap * k ids);
+ *   relabel (every rank)  writes the index matrix of the rank's sub-problem, (k, n_ext) column-major with
+ *                         n_ext = n_local + P * cap: own cells first, then the halo slots, all in local ids (own cell c ->
+ *                         c - cell_begin + 1, halo slot q -> n_local + q + 1, anything else a halo row names -> 0: it is in
+ *                         no own row), and d_l2g[n_ext], the global id of every local row (0 for an empty slot);
+ *   then gficf_jaccard_ingest_local_device (ids in [0, n_ext], 0 = no id) and gficf_jaccard_edges_mapped_device (the first
+ *   n_local rows' edges; column 1 = src_offset + cell + 1, column 2 through d_l2g) give the block's rows of the
+ *   reference's matrix, bit for bit what the all-gather form gives.  With n_ext < 2^17 the sub-problem takes the compact
+ *   64 B-row table whatever N_total is.  d_idx: the block's (k, ld) column-major int32 ids (what the sharded path carries);
+ *   d_ws: gficf_jaccard_halo_workspace_bytes(N_total, P) bytes, written by plan and read by relabel. */
+size_t gficf_jaccard_halo_workspace_bytes(int64_t N_total, int P);
+int gficf_jaccard_halo_plan_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                   int64_t cell_begin, int P, int64_t rows_per_rank, int cap, void* d_ws, int32_t* d_req_out);
+int gficf_jaccard_halo_serve_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t cell_begin,
+                                    const int32_t* d_req_in, int64_t n_req, int32_t* d_rows_out);
+int gficf_jaccard_halo_relabel_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                      int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
+                                      const int32_t* d_rows_in, int32_t* d_idx_ext, int32_t* d_l2g);
+int gficf_jaccard_ingest_local_device(gficf_ctx* ctx, const int32_t* d_idx_ext, int64_t n_ext, int k, int64_t ld, int32_t* d_table);
+int gficf_jaccard_edges_mapped_device(gficf_ctx* ctx, const int32_t* d_table, int64_t n_ext, int k, int64_t n_cells, int64_t src_offset,
+                                      const int32_t* d_l2g, double* d_src, double* d_dst, double* d_w, int32_t* d_u);
 
 /* Single-GPU convenience: ingest + edges, d_rmat in the reference layout ((N*k) x 3
  * column-major).  d_table_ws: caller-provided workspace of N*row_words int32 (kept by the

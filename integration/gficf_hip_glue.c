@@ -50,6 +50,10 @@ static gficf_ctx* ctx_get(void) {
     if (e) dev = atoi(e);
     if (gficf_ctx_create(dev, NULL, &g_ctx) != GFICF_OK) Rf_error("gficf_hip: %s", gficf_last_error());
     gficf_ctx_set_print(g_ctx, print_line);
+    /* GFICF_HIP_TRUNCATE_IDS=1: non-integer double ids are truncated as the reference does (`int k = mat(i,j) - 1`,
+     * src/rcpp_parallel_jaccard_coeff.cpp:28) instead of being rejected */
+    e = getenv("GFICF_HIP_TRUNCATE_IDS");
+    if (e && atoi(e) != 0) gficf_ctx_set_jaccard_options(g_ctx, 1);
   }
   return g_ctx;
 }

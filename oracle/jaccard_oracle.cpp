@@ -27,9 +27,11 @@
 // vector<int>) is kept here on purpose: this file is also what bench.py times as the
 // "RcppParallel CPU path" (cpu_baseline.kind = "port").
 //
-// Defined behaviour where the reference has none: an id outside [1, N] is undefined
-// behaviour in the reference (mat.row(kk) out of range, :34).  Here it is rejected up
-// front with return code -1.
+// Defined behaviour where the reference has none: a value v whose truncation (int)(v - 1) falls
+// outside [0, N) is undefined behaviour in the reference (mat.row(kk) out of range, :34).  Here it is
+// rejected up front with return code -1.  Non-integer values inside (0, N + 1) are what the reference
+// handles by truncation (row addressed by (int)(v - 1), rows intersected as the doubles they are) and
+// are restated as such.
 //
 // Threading: the reference uses RcppParallel::parallelFor(0, N, worker) (:73), i.e. TBB
 // blocked ranges over cells with work stealing.  Here: std::thread workers pulling
@@ -121,7 +123,7 @@ int oracle_jaccard_f64(const double* mat, int64_t N, int k, double* rmat, int32_
   const int64_t E = N * (int64_t)k;
   for (int64_t p = 0; p < E; ++p) {
     double v = mat[p];
-    if (!(v >= 1.0) || !(v < (double)N + 1.0)) return -1;
+    if (!(v > 0.0) || !(v < (double)N + 1.0)) return -1;      // (int)(v - 1) in [0, N): what the reference can address (:28,:34)
   }
   std::memset(rmat, 0, sizeof(double) * 3 * (size_t)E);
   JaccardArgs a{mat, N, k, rmat, u_out, E, 0};
@@ -138,7 +140,7 @@ int oracle_jaccard_cells_f64(const double* mat, int64_t N, int k, int64_t begin,
   const int64_t E = N * (int64_t)k;
   for (int64_t p = 0; p < E; ++p) {
     double v = mat[p];
-    if (!(v >= 1.0) || !(v < (double)N + 1.0)) return -1;
+    if (!(v > 0.0) || !(v < (double)N + 1.0)) return -1;      // (int)(v - 1) in [0, N): what the reference can address (:28,:34)
   }
   const int64_t rows = (end - begin) * (int64_t)k;
   std::memset(rmat_rows, 0, sizeof(double) * 3 * (size_t)rows);
@@ -157,7 +159,7 @@ int oracle_jaccard_coeff_f64(const double* mat, int64_t N, int k, double* weight
   const int64_t E = N * (int64_t)k;
   for (int64_t p = 0; p < E; ++p) {
     double v = mat[p];
-    if (!(v >= 1.0) || !(v < (double)N + 1.0)) return -1;
+    if (!(v > 0.0) || !(v < (double)N + 1.0)) return -1;      // (int)(v - 1) in [0, N): what the reference can address (:28,:34)
   }
   std::memset(weights, 0, sizeof(double) * 3 * (size_t)E);
   std::vector<double> a(k), b(k), common;

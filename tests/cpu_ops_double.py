@@ -19,7 +19,88 @@ class CpuOpsDouble:
         return cls.kpad(k)             # the double keeps plain int32 rows whatever the size
 
     def sync(self):
-        pass
+        if getattr(self, "_halo_overflow", False):
+            self._halo_overflow = False
+            from gficf_amd import GficfError
+
+            raise GficfError(7, "halo request slots overflowed (test double)")
+
+    # ---- the sharded build on local ids (mirrors csrc/halo.hip; numpy, tests only)
+    @staticmethod
+    def halo_workspace_bytes(N_total, P):
+        return 8 * (N_total + 2) + 8 * (P + 2)          # the double keeps an int64 rank per id instead of a bitmap
+
+    def halo_plan(self, idx_cm, n_local, k, N_total, cell_begin, P, rpr, cap, ws, req_out):
+        ids = idx_cm.numpy().reshape(k, -1)[:, :n_local].reshape(-1).astype(np.int64)
+        ids = ids[(ids >= 1) & (ids <= N_total)]
+        need = np.unique(ids[(ids <= cell_begin) | (ids > cell_begin + n_local)])
+        owner = (need - 1) // rpr
+        req = req_out.numpy().reshape(P, cap)
+        req[:] = 0
+        local = np.zeros(N_total + 2, dtype=np.int64)    # global id -> local id of its halo slot (0: not requested)
+        for r in range(P):
+            mine = need[owner == r]
+            if len(mine) > cap:
+                self._halo_overflow = True
+                mine = mine[:cap]
+            req[r, :len(mine)] = mine
+            local[mine] = n_local + r * cap + np.arange(len(mine)) + 1
+        ws.numpy().view(np.int64)[:N_total + 2] = local
+
+    def halo_serve(self, idx_cm, n_local, k, cell_begin, req_in, rows_out):
+        rows = idx_cm.numpy().reshape(k, -1)[:, :n_local].T
+        q = req_in.numpy().astype(np.int64)
+        out = rows_out.numpy().reshape(-1, k)
+        out[:] = 0
+        sel = q != 0
+        assert np.all((q[sel] > cell_begin) & (q[sel] <= cell_begin + n_local)), "asked for a row this rank does not own"
+        out[sel] = rows[q[sel] - 1 - cell_begin]
+
+    def halo_relabel(self, idx_cm, n_local, k, N_total, cell_begin, P, rpr, cap, ws, req_out, rows_in, idx_ext, l2g):
+        local = ws.numpy().view(np.int64)[:N_total + 2].copy()
+        own = np.arange(cell_begin + 1, cell_begin + n_local + 1)
+        local[own] = np.arange(1, n_local + 1)
+        rows = idx_cm.numpy().reshape(k, -1)[:, :n_local].T.astype(np.int64)
+        assert rows.min() >= 1 and rows.max() <= N_total
+        ext = idx_ext.numpy().reshape(k, -1)
+        n_ext = n_local + P * cap
+        ext[:, :n_local] = local[rows].T
+        req = req_out.numpy().astype(np.int64)
+        hal = rows_in.numpy().reshape(-1, k).astype(np.int64)
+        hl = np.where((hal >= 1) & (hal <= N_total), local[np.clip(hal, 0, N_total + 1)], 0)
+        hl[req == 0] = 0
+        ext[:, n_local:n_ext] = hl.T
+        g = l2g.numpy()
+        g[:n_local] = own
+        g[n_local:n_ext] = req
+
+    def jaccard_ingest_local(self, idx_ext, n_ext, k, table):
+        rows = idx_ext.numpy().reshape(k, -1)[:, :n_ext].T
+        assert rows.min() >= 0 and rows.max() <= n_ext
+        table[:n_ext, :k] = torch.from_numpy(np.ascontiguousarray(rows.astype(np.int32)))
+        table[:n_ext, k:] = 0
+
+    def jaccard_edges_mapped(self, table, n_ext, k, n_cells, src_offset, l2g, out3, u=None):
+        tab = table.numpy()[:n_ext, :k].astype(np.int64)
+        g = l2g.numpy().astype(np.int64)
+        uu = np.zeros(n_cells * k, dtype=np.int64)
+        for i in range(n_cells):
+            a, ca = np.unique(tab[i][tab[i] != 0], return_counts=True)
+            for j in range(k):
+                nb = tab[i, j]
+                if nb == 0:
+                    continue
+                b, cb = np.unique(tab[nb - 1][tab[nb - 1] != 0], return_counts=True)
+                _, ia, ib = np.intersect1d(a, b, return_indices=True)
+                uu[i * k + j] = int(np.minimum(ca[ia], cb[ib]).sum())          # multiset intersection (reference :41-46)
+        src = np.repeat(np.arange(src_offset + 1, src_offset + n_cells + 1, dtype=np.float64), k)
+        loc = tab[:n_cells].reshape(-1)
+        dst = np.where(loc != 0, g[np.maximum(loc, 1) - 1], 0).astype(np.float64)
+        w = uu / (2.0 * k - uu)
+        posm = uu > 0
+        out3.copy_(torch.from_numpy(np.stack([np.where(posm, src, 0.0), np.where(posm, dst, 0.0), np.where(posm, w, 0.0)])))
+        if u is not None:
+            u.copy_(torch.from_numpy(uu.astype(np.int32)))
 
     # ---- Jaccard
     def jaccard_ingest(self, idx_cm, n_rows, k, N_total, table_rows):

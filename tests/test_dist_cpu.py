@@ -198,3 +198,57 @@ def test_halo_exchange_matches_allgather_gloo(tmp_path, perm, world):
             assert 0.8 * ag_rows <= halo_rows <= ag_rows           # scrambled ids: (nearly) every remote row is named
         else:
             assert halo_rows <= 2 * 2 * 100 and halo_rows < 0.5 * ag_rows    # ordered ids: the window either side of the block's two seams
+
+
+def _local_worker(rank, world, port, N, k, perm, cap, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpu_ops_double import CpuOpsDouble
+        from gficf_amd import GficfError, synth
+        from gficf_amd.dist import JaccardHaloShard, shard_bounds
+
+        ops = CpuOpsDouble()
+        mat = synth.knn_windowed(N, k, seed=5, perm_seed=43 if perm else None)
+        b, e = shard_bounds(N, world, rank)
+        idx_local = torch.from_numpy(np.ascontiguousarray(mat[b:e].T))
+        sh = JaccardHaloShard(ops, N, k, with_u=True, cap=cap)
+        assert sh.n_ext == (e - b) + world * sh.cap
+        out = sh.step(idx_local).clone()
+        over = False
+        try:
+            sh.sync()
+        except GficfError as ex:
+            over = ex.status == "GFICF_ERR_CAPACITY"
+        np.save(os.path.join(outdir, f"loc_{rank}.npy"), out.numpy())
+        np.save(os.path.join(outdir, f"locmeta_{rank}.npy"), np.array([int(over), sh.rows_named_outside(), sh.bytes_received]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_local_id_halo_shard_matches_oracle_gloo(tmp_path, world):
+    """JaccardHaloShard: every rank builds its block's edges on a sub-problem in local ids (own cells + the rows it names,
+    fetched through fixed-capacity request slots: two all-to-alls with equal splits) — the oracle's bits on ordered ids."""
+    import oracle
+    from gficf_amd import synth
+
+    N, k = 1501, 15
+    mp.spawn(_local_worker, args=(world, _free_port(), N, k, False, 256, str(tmp_path)), nprocs=world, join=True)
+    want, _ = oracle.jaccard(synth.knn_windowed(N, k, seed=5, perm_seed=None), nthreads=2)
+    got = np.concatenate([np.load(tmp_path / f"loc_{r}.npy") for r in range(world)], axis=1).T
+    assert np.array_equal(got, want)
+    for r in range(world):
+        over, named, moved = np.load(tmp_path / f"locmeta_{r}.npy")
+        assert over == 0 and 0 < named <= 2 * 2 * 100
+        assert moved == (world - 1) * 256 * 4 * (1 + k)
+
+
+def test_local_id_halo_shard_reports_overflow_on_scrambled_ids(tmp_path):
+    """Ids without locality name nearly every remote row: more than the request slots hold -> GFICF_ERR_CAPACITY at the sync
+    (the caller then takes the all-gather form)."""
+    world = 2
+    mp.spawn(_local_worker, args=(world, _free_port(), 1501, 15, True, 64, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.load(tmp_path / f"locmeta_{r}.npy")[0] == 1

@@ -62,6 +62,13 @@ def _worker(rank, world, port, outdir):
         ops.sync()
         assert torch.equal(oa, oh) and 0 < shh.rows_received < 500 < sa.rows_received
         np.save(os.path.join(outdir, f"halo_{rank}.npy"), oh.cpu().numpy())
+        # the local-id form (fixed-capacity request slots, compact rows for the sub-problem): the same bits again
+        from gficf_amd.dist import JaccardHaloShard
+
+        sl = JaccardHaloShard(ops, N, k, device="cuda")
+        ol = sl.step(io).clone()
+        sl.sync()
+        assert torch.equal(ol, oa) and 0 < sl.rows_named_outside() < 500
         # exact kNN sharded by the same cell blocks, its index block chained into a sharded Jaccard build
         from gficf_amd.dist import KnnShard
 

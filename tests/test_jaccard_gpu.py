@@ -517,3 +517,69 @@ def test_serial_entry_empty_and_error_paths():
     with pytest.raises(gficf_amd.GficfError) as ei:
         gficf_amd.jaccard_coeff(np.array([[2, 9], [1, 1]], dtype=np.int32))
     assert ei.value.status == "GFICF_ERR_BAD_ID"
+
+
+@pytest.mark.parametrize("N,k,P,cap,perm", [(30011, 30, 3, 512, False), (140000, 30, 2, 4096, False), (20000, 50, 4, 1024, False),
+                                            (9000, 100, 2, 512, False), (6000, 15, 2, 4096, True), (5000, 30, 1, 64, False)])
+def test_local_id_sub_problems_of_emulated_ranks(N, k, P, cap, perm):
+    """The halo form of the sharded build (csrc/halo.hip + the mapped edge kernels), all ranks emulated one after the other on
+    this GPU: plan -> (the two all-to-alls done by slicing) -> serve -> relabel -> ingest in local ids -> edges written through
+    the local -> global map.  Bit-exact against the oracle on the whole matrix: pipelined and general kernels, compact rows
+    for a data set of more than 2^17 cells (sub-problems below 2^17), wide rows (k = 100), scrambled ids with slots to spare."""
+    import torch
+
+    from gficf_amd.dist import rows_per_rank, shard_bounds
+
+    ops = gficf_amd.HipOps(0)
+    mat = synth.knn_windowed(N, k, seed=11, perm_seed=(5 if perm else None))
+    want, _ = oracle.jaccard(mat, nthreads=8)
+    rpr = rows_per_rank(N, P)
+    blocks = [shard_bounds(N, P, r) for r in range(P)]
+    idx = [torch.from_numpy(np.ascontiguousarray(mat[b:e].T)).cuda() for b, e in blocks]
+    i32 = dict(dtype=torch.int32, device="cuda")
+    req_out = [torch.zeros(P * cap, **i32) for _ in range(P)]
+    wss = [torch.zeros(ops.halo_workspace_bytes(N, P), dtype=torch.uint8, device="cuda") for _ in range(P)]
+    for r, (b, e) in enumerate(blocks):
+        ops.halo_plan(idx[r], e - b, k, N, b, P, rpr, cap, wss[r], req_out[r])
+    ops.sync()                                                   # (no overflow)
+    # all-to-all #1: rank r's slots for owner p arrive at p as its slots from r
+    req_in = [torch.cat([req_out[r][p * cap:(p + 1) * cap] for r in range(P)]) for p in range(P)]
+    rows_out = [torch.zeros(P * cap * k, **i32) for _ in range(P)]
+    for p, (b, e) in enumerate(blocks):
+        ops.halo_serve(idx[p], e - b, k, b, req_in[p], rows_out[p])
+    rows_in = [torch.cat([rows_out[p][r * cap * k:(r + 1) * cap * k] for p in range(P)]) for r in range(P)]
+    got = []
+    for r, (b, e) in enumerate(blocks):
+        nl = e - b
+        n_ext = nl + P * cap
+        idx_ext, l2g = torch.zeros((k, n_ext), **i32), torch.zeros(n_ext, **i32)
+        ops.halo_relabel(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in[r], idx_ext, l2g)
+        table = torch.zeros((n_ext, ops.row_words(n_ext, k)), **i32)
+        ops.jaccard_ingest_local(idx_ext, n_ext, k, table)
+        out = torch.zeros((3, nl * k), dtype=torch.float64, device="cuda")
+        ops.jaccard_edges_mapped(table, n_ext, k, nl, b, l2g, out)
+        ops.sync()
+        if N >= (1 << 17):
+            assert n_ext < (1 << 17) and ops.row_words(n_ext, k) < ops.row_words(N, k)      # compact rows for the sub-problem
+        named = int((req_out[r] != 0).sum())
+        if not perm and P > 1:
+            assert 0 < named <= 4 * 100                         # the window either side of the block's seams
+        got.append(out.cpu().numpy())
+    assert np.array_equal(np.concatenate(got, axis=1).T, want)
+
+
+def test_local_id_request_slots_overflow_is_reported():
+    import torch
+
+    ops = gficf_amd.HipOps(0)
+    N, k, P, cap = 8000, 30, 2, 256
+    mat = synth.knn_windowed(N, k, seed=3)                       # scrambled ids: the block names ~ every remote row
+    idx = torch.from_numpy(np.ascontiguousarray(mat[:4000].T)).cuda()
+    ws = torch.zeros(ops.halo_workspace_bytes(N, P), dtype=torch.uint8, device="cuda")
+    req = torch.zeros(P * cap, dtype=torch.int32, device="cuda")
+    ops.halo_plan(idx, 4000, k, N, 0, P, 4000, cap, ws, req)
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        ops.sync()
+    assert ei.value.status == "GFICF_ERR_CAPACITY"
+    assert int((req[cap:] != 0).sum()) == cap and int((req[:cap] != 0).sum()) == 0     # the first cap ids of the other owner, none of its own
+    ops.sync()

@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc csv output -> per-kernel HBM traffic per launch (profiles/pmc_traffic.json).
+"""rocprofv3 --pmc csv output -> per-kernel fabric-side traffic per launch (profiles/pmc_traffic.json).
 
-Correction (MI355X_MICROARCH.md §HBM): on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B while the read
-requests are 128 B wide, so FETCH_SIZE is doubled.  Calibrated on this code's own access patterns
-against known byte counts (23 k x 54 k matrix, nnz = 59 809 258): k_gene_count reads exactly
-12 B/nnz = 717.7 MB (16 B vector loads) and reports FETCH_SIZE = 351 MiB-units -> x2 = 719 MB;
-k_cell_kept_count reads 4 B/nnz = 239 MB (4 B-per-lane loads) and reports 120 -> x2 = 246 MB;
-k_ingest_reg reads 12.0 MB (4 B-per-lane loads) and reports 5.96 -> x2 = 12.2 MB.  WRITE_SIZE is
-taken as is (k_ingest_reg writes 12.8 MB, reports 12.8).  Both counters are in KiB.  Usage: make_traffic.py <pmc dir> <N> <k> <out.json>"""
+Read bytes.  FETCH_SIZE (KiB) = TCC_EA0_RDREQ x 64 B: it counts the L2's read REQUESTS to the fabric and prices each at
+64 B.  Calibration on known bytes (tools/lab/fetch_calib + tools/calib_fetch.sh, profiles/r03_fetch_calibration.txt; a 2 GiB
+table, every row touched exactly once, far beyond the 256 MiB Infinity Cache):
+  * coalesced 16 B-per-lane streaming and 128 B row gathers: FETCH_SIZE x 1024 = 0.500 of the bytes, TCC_EA0_RDREQ_128B x 128 B =
+    1.000 of them — every request is a 128 B line: the x2 of MI355X_MICROARCH.md §HBM;
+  * 64 B row gathers (4 lanes x 16 B, the edge kernel's shape): FETCH_SIZE x 1024 = 0.975 of the USEFUL bytes, but the split
+    counters say every one of those requests is a 128 B request too (TCC_EA0_RDREQ_64B = 0) and the clock agrees: the same
+    2.2 GB of rows take 760 us as 64 B gathers against 405 us as 128 B gathers (5.9 TB/s of 128 B lines either way).  An L2
+    miss fills a whole 128 B line: a 64 B gather moves 128 B across the fabric.
+So the factor is 2 for every kernel here (VERDICT r2 item 4 asked whether it should be 1 for the gathers: no), i.e.
+    read_bytes = 32 x TCC_EA0_RDREQ_32B + 64 x TCC_EA0_RDREQ_64B + 128 x TCC_EA0_RDREQ_128B
+where the pass collected the split counters (`read_bytes_from: "split"`; `fetch_correction` = read_bytes / (FETCH_SIZE x 1024) is
+reported next to it), FETCH_SIZE x 2 otherwise.  WRITE_SIZE (KiB) is taken as is (k_ingest_* writes 12.8 MB at 100 k x 30
+and reports 12.8).
+Usage: make_traffic.py <pmc dir> <N> <k> <out.json> [--merge old.json] [--gficf-nnz NNZ]"""
 import collections
 import csv
 import glob
@@ -16,13 +24,21 @@ import os
 import re
 import sys
 
-root, N, k, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+args = sys.argv[1:]
+merge, gficf_nnz = None, None
+if "--merge" in args:
+    i = args.index("--merge"); merge = args[i + 1]; del args[i:i + 2]
+if "--gficf-nnz" in args:
+    i = args.index("--gficf-nnz"); gficf_nnz = int(args[i + 1]); del args[i:i + 2]
+root, N, k, out = args[0], int(args[1]), int(args[2]), args[3]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "p*", "pmc_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
         m = re.search(r"(?<![A-Za-z0-9_])(k_[a-z_0-9]+)", row["Kernel_Name"])
         if m:
             acc[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
+
+
 def mean(v):
     """Mean over the launches that did real work: a launch whose counter is below 5 % of the kernel's largest is an empty
     one (a variant that returns at once because the other variant handles the input) and would dilute the per-launch figure."""
@@ -31,14 +47,36 @@ def mean(v):
     return sum(real) / len(real)
 
 
+def fallback_factor(kern):
+    """FETCH_SIZE factor when the split counters are missing: every read request seen in the calibration is a 128 B line."""
+    return 2.0
+
+
 res = {}
+if merge and os.path.exists(merge):
+    res = json.load(open(merge))
 for kern, c in acc.items():
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         continue
     f, w = mean(c["FETCH_SIZE"]), mean(c["WRITE_SIZE"])
-    fcorr = 2.0
+    split = [c.get("TCC_EA0_RDREQ_%s_sum" % s) for s in ("32B", "64B", "128B")]
+    if all(split):
+        rd = 32 * mean(split[0]) if max(split[0]) > 0 else 0.0
+        rd += 64 * mean(split[1]) if max(split[1]) > 0 else 0.0
+        rd += 128 * mean(split[2]) if max(split[2]) > 0 else 0.0
+        src = "split"
+    else:
+        rd = fallback_factor(kern) * f * 1024
+        src = "FETCH_SIZE x %.1f" % fallback_factor(kern)
     key = f"{kern[2:]}_N{N}_k{k}" if kern.startswith("k_jaccard") or kern.startswith("k_ingest") else kern[2:]
-    res[key] = {"kernel": kern, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "fetch_correction": fcorr,
-                "hbm_bytes_per_launch": int((fcorr * f + w) * 1024)}
+    res[key] = {"kernel": kern, "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "read_bytes": int(rd), "read_bytes_from": src,
+                "fetch_correction": round(rd / (f * 1024), 3) if f > 0 else None,
+                "hbm_bytes_per_launch": int(rd + w * 1024)}
+    if all(split):
+        res[key]["read_requests"] = {s: mean(v) if max(v) > 0 else 0.0 for s, v in zip(("32B", "64B", "128B"), split)}
+        if c.get("TCC_EA0_RDREQ_DRAM_sum"):
+            res[key]["read_requests"]["to_DRAM"] = mean(c["TCC_EA0_RDREQ_DRAM_sum"]) if max(c["TCC_EA0_RDREQ_DRAM_sum"]) > 0 else 0.0
+if gficf_nnz is not None:
+    res["gficf_nnz"] = gficf_nnz
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))

@@ -11,6 +11,7 @@ for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_A
             "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
             "SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVES_EQ_64 SQ_THREAD_CYCLES_VALU SQ_INSTS_FLAT" \
             "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_REQ_sum TCC_EA0_WRREQ_64B_sum" \
+            "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum" \
             "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum" ; do
   P=$((P+1))
   (cd /tmp && timeout 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/p$P -o pmc -- python3 $GRAFT_REPO_ROOT/tools/${PROF_DRIVER:-prof_driver.py} > $GRAFT_REPO_ROOT/$OUT/p$P.log 2>&1) || echo "pass $P failed: $(tail -2 $OUT/p$P.log)"

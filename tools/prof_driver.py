@@ -32,5 +32,7 @@ if os.environ.get("PROF_GFICF", "1") == "1":
     ws = ops.csc_workspace(G, Nc, int(rowidx.numel()))
     for _ in range(reps):
         ops.gficf_csc(G, Nc, colptr, rowidx, x, 0.05, 1.0, None, ws)
-    ops.sync()
+    ops.sync()                                   # (synthetic counts hold no stored zeros: nothing to retry)
+    if os.environ.get("PROF_META"):
+        open(os.environ["PROF_META"], "w").write(str(int(rowidx.numel())))
 print("prof_driver done")

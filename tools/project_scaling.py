@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-GPU efficiency of the N > 1 Jaccard step, projected from what can be measured on one GPU: the per-rank stage times of
+tools/halo_stage_times.py (kernels, HIP events) and the bytes each exchange form moves, plus a stated model of the collectives.
+Nothing here is a measurement of a multi-GPU run; the driver's SCALE run is.  Usage: project_scaling.py stage_times.jsonl [single_gpu_ms]
+
+Model (constants below): an all-gather moves every rank's block over each of its xGMI links once -> time = block bytes / LINK_GBS
++ LAT_US; an all-to-all with equal splits of s bytes per peer -> s / LINK_GBS + LAT_US (one link per peer); kernels of one data
+set run in order on one stream with GAP_US between dependent launches (non-pipelined: what bench.py reports as `value`);
+pipelined = max(compute, exchange) (exchange of the next data set under the edge kernel of this one; `--pipeline`, never `value`)."""
+import json
+import sys
+
+LINK_GBS = 55.0      # achieved per link and direction in RCCL collectives (xGMI, 76.8 GB/s nominal per direction); VERDICT r2 item 2 uses 55
+LAT_US = 20.0        # launch + protocol latency of one small RCCL collective
+GAP_US = 2.0         # between dependent kernel launches on one stream
+
+rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip().startswith("{")]
+one = next(r for r in rows if r["P"] == 1)
+base_ms = float(sys.argv[2]) if len(sys.argv) > 2 else one["allgather_permuted"]["compute_ms"] + GAP_US * 1e-3
+print("single GPU, per data set: %.1f us (ingest + edges + one launch gap; the bench's own figure may be passed as argv[2])" % (base_ms * 1e3))
+print()
+hdr = "| P | ids | exchange | rows named outside | bytes received / rank | table row | compute (kernels) | exchange (model) | step, in order | efficiency | step, overlapped | efficiency |"
+print(hdr)
+print("|" + "---|" * (hdr.count("|") - 1))
+for r in rows:
+    P = r["P"]
+    if P == 1:
+        continue
+    for ids in ("spatial", "permuted"):
+        for form in ("allgather", "halo"):
+            d = r.get(f"{form}_{ids}")
+            if not d or (form == "halo" and not d.get("fits")):
+                if d is not None and form == "halo":
+                    print(f"| {P} | {ids} | halo | {d['rows_named_outside']}+ | - | - | - | request slots overflow: falls back to the all-gather | | | | |")
+                continue
+            n_k = sum(1 for kk in d if kk.endswith("_ms") and kk not in ("compute_ms", "chain_ms"))
+            comp = d["compute_ms"] * 1e3 + GAP_US * n_k
+            if form == "allgather":
+                ex = d["bytes_received"] / (P - 1) / (LINK_GBS * 1e3) + LAT_US           # one block per link
+                named = "all"
+            else:
+                per_peer_req, per_peer_rows = d["cap"] * 4, d["cap"] * 4 * r["k"]
+                ex = per_peer_req / (LINK_GBS * 1e3) + LAT_US + per_peer_rows / (LINK_GBS * 1e3) + LAT_US
+                named = str(d["rows_named_outside"])
+            step = comp + ex
+            over = max(comp, ex)
+            print(f"| {P} | {ids} | {form} | {named} | {d['bytes_received'] / 1e6:.2f} MB | {d['table_row_bytes']} B | {comp:.0f} us | {ex:.0f} us | "
+                  f"{step:.0f} us | {base_ms * 1e3 / step:.2f} | {over:.0f} us | {base_ms * 1e3 / over:.2f} |")
