@@ -368,7 +368,12 @@ struct JCfg {
   static constexpr int SPQ = (KPAD < 64 ? KPAD : 64) / RPS;   // steps per register of row i
   static constexpr int NB = 8 * KPAD;                         // 2-slot buckets in the hash set
   static constexpr int WAVES = KPAD <= 128 ? 4 : 2;           // waves per workgroup
-  static constexpr int U = SPQ < 4 ? SPQ : 4;                 // steps whose gathers are in flight together
+#ifndef GFICF_JACCARD_U
+#define GFICF_JACCARD_U 8
+#endif
+  // steps whose gathers are in flight together in the one-cell-at-a-time kernel: 8 = the whole cell at 32 < k <= 64 (32 registers
+  // of pieces; 95 registers in all, five waves per SIMD as before): 145 -> 139.5 us at 100 k x 50 against two batches of 4
+  static constexpr int U = SPQ < GFICF_JACCARD_U ? SPQ : GFICF_JACCARD_U;
   static constexpr int LOG2NB = KPAD == 16 ? 7 : KPAD == 32 ? 8 : KPAD == 64 ? 9 : KPAD == 128 ? 10 : 11;
 };
 

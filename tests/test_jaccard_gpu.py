@@ -583,3 +583,35 @@ def test_local_id_request_slots_overflow_is_reported():
     assert ei.value.status == "GFICF_ERR_CAPACITY"
     assert int((req[cap:] != 0).sum()) == cap and int((req[:cap] != 0).sum()) == 0     # the first cap ids of the other owner, none of its own
     ops.sync()
+
+
+def test_truncate_noninteger_ids_strict_drop_in_mode():
+    """gficf_ctx_set_jaccard_options: non-integer double ids handled as the reference does (row addressed by truncation,
+    rows intersected as doubles, src/rcpp_parallel_jaccard_coeff.cpp:28-46) — against the oracle, which restates exactly
+    that; rejected (GFICF_ERR_BAD_ID) by default; an all-integer double matrix takes the ordinary kernels either way."""
+    rng = np.random.default_rng(8)
+    N, k = 700, 12
+    base = synth.knn_windowed(N, k, seed=2).astype(np.float64)
+    frac = base + np.where(rng.random(base.shape) < 0.3, rng.choice([0.25, 0.5, 0.75], size=base.shape), 0.0)
+    frac[5, 3] = 0.5                                              # (0, 1) -> row 1
+    frac[7, :4] = frac[7, 0]                                      # the same double four times: multiset counting
+    want, _ = oracle.jaccard(frac)
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        gficf_amd.rcpp_parallel_jaccard_coef(frac, False)
+    assert ei.value.status == "GFICF_ERR_BAD_ID"
+    got = gficf_amd.rcpp_parallel_jaccard_coef(frac, False, truncate_noninteger_ids=True)
+    assert np.array_equal(got, want)
+    assert (got[:, 2] > 0).sum() > 100 and np.any(got[:, 1] != np.floor(frac.reshape(-1)))      # truncated ids in column 2
+    # integer-valued doubles: same result with and without the option (the ordinary path)
+    w2, _ = oracle.jaccard(base)
+    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(base, False, truncate_noninteger_ids=True), w2)
+    # values the reference cannot address are still an error in strict mode
+    bad = frac.copy()
+    bad[0, 0] = N + 1.5
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        gficf_amd.rcpp_parallel_jaccard_coef(bad, False, truncate_noninteger_ids=True)
+    assert ei.value.status == "GFICF_ERR_BAD_ID"
+    # k beyond the build's limit: the message says what the limit is
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        gficf_amd.rcpp_parallel_jaccard_coef(np.ones((4, 300), dtype=np.int32), False)
+    assert ei.value.status == "GFICF_ERR_UNSUPPORTED" and "256" in str(ei.value)

@@ -366,3 +366,22 @@ def test_modularity_restatement_against_reference_outputs(golden_dir):
         res, alg, n_start, n_iter, seed = z[n + "/params"]
         labels, q = oracle.modularity_reference(A, res, int(alg), int(n_start), int(n_iter), int(seed))
         assert np.array_equal(labels, z[n + "/labels"]) and q == float(z[n + "/printed_q"][0])
+
+
+def test_jaccard_noninteger_doubles_reference_truncation_hand_derived():
+    """What the reference does with non-integer double ids (src/rcpp_parallel_jaccard_coeff.cpp:28-46): the row is addressed by
+    kk = (int)(v - 1), the rows are intersected as the doubles they hold.  Expectations by hand (3 cells, k = 2)."""
+    mat = np.array([[2.0, 3.5], [1.0, 3.0], [1.2, 2.0]])
+    rm, u = oracle.jaccard(mat)
+    assert u.tolist() == [0, 1, 0, 0, 1, 0]
+    third = 1.0 / (2.0 * 2 - 1)
+    want = np.zeros((6, 3))
+    want[1] = (1.0, 3.0, third)          # 3.5 -> row 3 = {1.2, 2.0}; shares 2.0 with row 1
+    want[4] = (3.0, 1.0, third)          # 1.2 -> row 1 = {2.0, 3.5}; shares 2.0 with row 3
+    assert np.array_equal(rm, want)
+    # a value in (0, 1) truncates to row 1 like 1.0 does; 0 and N + 1 are outside what the reference can address
+    rm2, _ = oracle.jaccard(np.array([[0.5, 2.0], [0.5, 1.0]]))
+    assert rm2[0].tolist() == [1.0, 1.0, 1.0] and rm2[2].tolist() == [2.0, 1.0, 1.0 / 3.0]
+    for bad in (0.0, 3.0, -1.5, np.nan):
+        with pytest.raises(ValueError):
+            oracle.jaccard(np.array([[bad, 2.0], [1.0, 2.0]]))
