@@ -301,10 +301,15 @@ class JaccardHaloShard:
     A block that names more than ``cap`` rows of one owner (ids without locality) makes the next :meth:`sync` raise
     ``GFICF_ERR_CAPACITY``; the caller then builds a :class:`JaccardShard` (all-gather) for that input — the choice is a
     property of the data (bench.py makes it on the warm-up step).  Same interface and the same bits as JaccardShard.
-    Input blocks must be int32 (what the kNN search and uwot produce)."""
+    Input blocks must be int32 (what the kNN search and uwot produce).
+
+    ``pipeline=True`` (GPU only): everything in front of the edge kernel — plan, the two all-to-alls, serve, relabel,
+    ingest — runs on a side stream over two sets of buffers, so the exchange of a step overlaps the edge kernel of the step
+    before it (same contract as JaccardShard's pipelined mode: :meth:`wait` before reading the returned buffer,
+    :meth:`release` after; the input block is read in stream order behind the caller's current stream)."""
 
     def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False, cap: int | None = None,
-                 time_edges: bool = False):
+                 time_edges: bool = False, pipeline: bool = False):
         self.ops, self.N, self.k, self.group = ops, int(N_total), int(k), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -319,47 +324,90 @@ class JaccardHaloShard:
         self.exchange = "halo"
         self.time_edges = bool(time_edges)
         self.edge_events = []
+        self.pipeline = bool(pipeline) and device is not None and torch.device(device).type == "cuda"
+        nbuf = 2 if self.pipeline else 1
         i32 = dict(dtype=torch.int32, device=device)
-        self.ws = torch.zeros(ops.halo_workspace_bytes(self.N, self.world), dtype=torch.uint8, device=device)
-        self.req_out = torch.zeros(self.world * self.cap, **i32)
-        self.req_in = torch.zeros(self.world * self.cap, **i32)
-        self.rows_out = torch.zeros(self.world * self.cap * self.k, **i32)
-        self.rows_in = torch.zeros(self.world * self.cap * self.k, **i32)
-        self.idx_ext = torch.zeros((self.k, max(self.n_ext, 1)), **i32)
-        self.l2g = torch.zeros(max(self.n_ext, 1), **i32)
         self.row_words = ops.row_words(self.n_ext, self.k)
-        self.table = torch.zeros((max(self.n_ext, 1), self.row_words), **i32)
-        self.out = torch.zeros((3, self.n_local * self.k), dtype=torch.float64, device=device)
-        self.u = torch.zeros(self.n_local * self.k, **i32) if with_u else None
+        ws_bytes = ops.halo_workspace_bytes(self.N, self.world)
+        self.bufs = [dict(ws=torch.zeros(ws_bytes, dtype=torch.uint8, device=device),
+                          req_out=torch.zeros(self.world * self.cap, **i32), req_in=torch.zeros(self.world * self.cap, **i32),
+                          rows_out=torch.zeros(self.world * self.cap * self.k, **i32), rows_in=torch.zeros(self.world * self.cap * self.k, **i32),
+                          idx_ext=torch.zeros((self.k, max(self.n_ext, 1)), **i32), l2g=torch.zeros(max(self.n_ext, 1), **i32),
+                          table=torch.zeros((max(self.n_ext, 1), self.row_words), **i32),
+                          out=torch.zeros((3, self.n_local * self.k), dtype=torch.float64, device=device),
+                          u=torch.zeros(self.n_local * self.k, **i32) if with_u else None) for _ in range(nbuf)]
+        self._use(0)
+        self.t = 0
         self.packed = None
         # what a step moves: the request slots and the reply slots of the other ranks (fixed), and what of it is used
         self.bytes_received = (self.world - 1) * self.cap * 4 * (1 + self.k)
         self.rows_received = 0
+        if self.pipeline:
+            self.side = torch.cuda.Stream(device=device)
+            self.edge_stream = torch.cuda.Stream(device=device)
+            self.ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_consumed = [None, None]
+            self.last_done = None
+            self.last_p = None
+
+    def _use(self, p):
+        bf = self.bufs[p]
+        self.ws, self.req_out, self.req_in, self.rows_out, self.rows_in = bf["ws"], bf["req_out"], bf["req_in"], bf["rows_out"], bf["rows_in"]
+        self.idx_ext, self.l2g, self.table, self.out, self.u = bf["idx_ext"], bf["l2g"], bf["table"], bf["out"], bf["u"]
+
+    def _front(self, bf, idx_local_cm):
+        """Everything in front of the edge kernel, on the current stream."""
+        o, P, k, nl = self.ops, self.world, self.k, self.n_local
+        o.halo_plan(idx_local_cm, nl, k, self.N, self.b, P, self.rpr, self.cap, bf["ws"], bf["req_out"])
+        if P > 1:
+            _all_to_all(bf["req_in"], bf["req_out"], None, None, self.group)
+        else:
+            bf["req_in"].copy_(bf["req_out"])
+        o.halo_serve(idx_local_cm, nl, k, self.b, bf["req_in"], bf["rows_out"])
+        if P > 1:
+            _all_to_all(bf["rows_in"], bf["rows_out"], None, None, self.group)
+        else:
+            bf["rows_in"].copy_(bf["rows_out"])
+        o.halo_relabel(idx_local_cm, nl, k, self.N, self.b, P, self.rpr, self.cap, bf["ws"], bf["req_out"], bf["rows_in"], bf["idx_ext"], bf["l2g"])
+        o.jaccard_ingest_local(bf["idx_ext"], self.n_ext, k, bf["table"])
+
+    def _edges(self, bf, stream=None):
+        if self.time_edges:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream) if stream is not None else e0.record()
+        if self.n_local > 0:
+            self.ops.jaccard_edges_mapped(bf["table"], self.n_ext, self.k, self.n_local, self.b, bf["l2g"], bf["out"], bf["u"])
+        if self.time_edges:
+            e1.record(stream) if stream is not None else e1.record()
+            self.edge_events.append((e0, e1))
 
     def step(self, idx_local_cm):
         """idx_local_cm: (k, n_local) int32 == column-major block of the kNN matrix, global 1-based ids.  Returns this rank's
         (3, n_local*k) slice of the edge matrix."""
-        o, P, k, nl = self.ops, self.world, self.k, self.n_local
-        o.halo_plan(idx_local_cm, nl, k, self.N, self.b, P, self.rpr, self.cap, self.ws, self.req_out)
-        if P > 1:
-            _all_to_all(self.req_in, self.req_out, None, None, self.group)
-        else:
-            self.req_in.copy_(self.req_out)
-        o.halo_serve(idx_local_cm, nl, k, self.b, self.req_in, self.rows_out)
-        if P > 1:
-            _all_to_all(self.rows_in, self.rows_out, None, None, self.group)
-        else:
-            self.rows_in.copy_(self.rows_out)
-        o.halo_relabel(idx_local_cm, nl, k, self.N, self.b, P, self.rpr, self.cap, self.ws, self.req_out, self.rows_in, self.idx_ext, self.l2g)
-        o.jaccard_ingest_local(self.idx_ext, self.n_ext, k, self.table)
-        if self.time_edges:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        if nl > 0:
-            o.jaccard_edges_mapped(self.table, self.n_ext, k, nl, self.b, self.l2g, self.out, self.u)
-        if self.time_edges:
-            e1.record()
-            self.edge_events.append((e0, e1))
+        if not self.pipeline:
+            self._front(self.bufs[0], idx_local_cm)
+            self._edges(self.bufs[0])
+            return self.out
+        p = self.t & 1
+        bf = self.bufs[p]
+        self.side.wait_stream(torch.cuda.current_stream(bf["out"].device))      # the input block may have just been produced there
+        if self.t >= 2:
+            self.side.wait_event(self.ev_done[p])                               # the edges of step t-2 have finished with these buffers
+        with torch.cuda.stream(self.side):
+            self._front(bf, idx_local_cm)
+            self.ev_ready[p].record(self.side)
+        es = self.edge_stream                                                   # one edge stream: steps stay in order
+        es.wait_event(self.ev_ready[p])
+        if self.ev_consumed[p] is not None:
+            es.wait_event(self.ev_consumed[p])
+            self.ev_consumed[p] = None
+        with torch.cuda.stream(es):
+            self._edges(bf, es)
+            self.ev_done[p].record(es)
+        self._use(p)
+        self.last_done, self.last_p = self.ev_done[p], p
+        self.t += 1
         return self.out
 
     def rows_named_outside(self) -> int:
@@ -372,13 +420,22 @@ class JaccardHaloShard:
         return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
 
     def wait(self):
-        pass
+        """Make the caller's current stream wait for the latest step (pipelined mode; no-op otherwise)."""
+        if self.pipeline and self.last_done is not None:
+            torch.cuda.current_stream(self.out.device).wait_event(self.last_done)
 
     def release(self):
-        pass
+        """Pipelined mode: the caller's current stream has read the latest returned buffer up to this point."""
+        if self.pipeline and self.last_p is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.out.device))
+            self.ev_consumed[self.last_p] = ev
 
     def sync(self):
-        """Wait for the stream; raises GficfError(GFICF_ERR_CAPACITY) when a step overflowed the request slots."""
+        """Wait for the streams; raises GficfError(GFICF_ERR_CAPACITY) when a step overflowed the request slots."""
+        if self.pipeline:
+            self.side.synchronize()
+            self.edge_stream.synchronize()
         self.ops.sync()
 
 
