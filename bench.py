@@ -513,9 +513,12 @@ def main():
                                "form": ("halo: unique-id request lists + the named rows, two all-to-alls" if exchange == "halo_generic" else
                                         "all-gather of table rows" + (" (bit-packed)" if sh0.packed is not None else ""))}
 
-    if args.pipeline:
+    if args.pipeline or (world == 1 and not args.no_extras and not strong):
         # the overlapped mode (not `value`): ingest / exchange of data set d+1 on a side stream under the edge kernel of d
-        psh = JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=True)      # (all-gather form)
+        if halo_form:
+            psh = JaccardHaloShard(ops, N_total, k, device=dev, pipeline=True)
+        else:
+            psh = JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=True)      # (all-gather form)
         for _ in range(3 * batch):
             psh.step(idx_local[0])
         fence()

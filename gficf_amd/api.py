@@ -726,6 +726,16 @@ class HipOps:
         check(self.L.gficf_jaccard_halo_relabel_device(self._bind(), _tptr(idx_cm), n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap,
                                                        _tptr(ws), _tptr(req_out), _tptr(rows_in), _tptr(idx_ext), _tptr(l2g)))
 
+    def halo_ingest(self, idx_cm, n_local, k, N_total, cell_begin, P, rows_per_rank, cap, ws, req_out, rows_in, table, l2g) -> bool:
+        """relabel + ingest in one launch (k <= 64).  Returns False when the fused form does not cover this k (nothing was
+        enqueued): the caller runs halo_relabel + jaccard_ingest_local."""
+        if k > 64:
+            return False
+        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else n_local
+        check(self.L.gficf_jaccard_halo_ingest_device(self._bind(), _tptr(idx_cm), n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap,
+                                                      _tptr(ws), _tptr(req_out), _tptr(rows_in), _tptr(table), _tptr(l2g)))
+        return True
+
     def jaccard_ingest_local(self, idx_ext, n_ext, k, table):
         """idx_ext: (k, n_ext) int32 local ids (0 = no id).  table: (n_ext, row_words(n_ext, k)) int32."""
         check(self.L.gficf_jaccard_ingest_local_device(self._bind(), _tptr(idx_ext), n_ext, k, n_ext, _tptr(table)))

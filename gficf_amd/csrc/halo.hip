@@ -15,6 +15,7 @@
 // N_total is (the all-gather form falls back to 128 B rows from 2^17 cells on).  Kernels here are O(n_local * k) elementwise /
 // small scans; the edge build is jaccard.hip's, with the map applied where the edges are written.
 #include "common.h"
+#include "halo_map.h"
 
 namespace {
 
@@ -147,20 +148,6 @@ __global__ __launch_bounds__(256) void k_halo_serve(const int32_t* __restrict__ 
   }
 }
 
-// local id of a global id (1-based both); 0: not part of this rank's sub-problem
-__device__ inline int32_t halo_local(int64_t id, int64_t N_total, int64_t b, int64_t n_local, int64_t rpr, int cap,
-                                     const uint32_t* __restrict__ bitmap, const int32_t* __restrict__ word_rank,
-                                     const int32_t* __restrict__ owner_start) {
-  if (id < 1 || id > N_total) return -1;                               // the ingest reports it
-  if (id > b && id <= b + n_local) return (int32_t)(id - b);
-  const int64_t bit = id - 1, w = bit >> 5;
-  const uint32_t word = bitmap[w], m = 1u << (bit & 31);
-  if ((word & m) == 0u) return 0;
-  const int owner = (int)(bit / rpr);
-  const int pos = word_rank[w] + __popc(word & (m - 1u)) - owner_start[owner];
-  return pos < cap ? (int32_t)(n_local + (int64_t)owner * cap + pos + 1) : 0;
-}
-
 // K4: extended index matrix (k, n_ext) in local ids + the local -> global map.  n_ext = n_local + P * cap.
 __global__ __launch_bounds__(256) void k_halo_relabel(const int32_t* __restrict__ idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
                                                       int64_t b, int P, int64_t rpr, int cap, const uint32_t* __restrict__ bitmap,
@@ -173,14 +160,14 @@ __global__ __launch_bounds__(256) void k_halo_relabel(const int32_t* __restrict_
     const int64_t j = t / n_ext, i = t - j * n_ext;
     int32_t v;
     if (i < n_local) {
-      v = halo_local(idx[j * ld + i], N_total, b, n_local, rpr, cap, bitmap, word_rank, owner_start);
+      v = gficf_halo_local(idx[j * ld + i], N_total, b, n_local, rpr, cap, bitmap, word_rank, owner_start);
       if (j == 0) l2g[i] = (int32_t)(b + i + 1);
     } else {
       const int64_t q = i - n_local;
       const int32_t gid = req_out[q];
       v = 0;
       if (gid != 0) {
-        v = halo_local(rows_in[q * k + j], N_total, b, n_local, rpr, cap, bitmap, word_rank, owner_start);
+        v = gficf_halo_local(rows_in[q * k + j], N_total, b, n_local, rpr, cap, bitmap, word_rank, owner_start);
         if (v < 0) v = 0;                          // (its owner's ingest reports the bad id)
       }
       if (j == 0) l2g[i] = gid;

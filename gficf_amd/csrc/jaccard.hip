@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "common.h"
+#include "halo_map.h"
 
 namespace {
 
@@ -196,7 +197,8 @@ __device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD], int k) {
   uint32_t m = 0xFFFFFFFFu;                 // min over this part's pairs (j, j2 < j), j = W, W + 4, ...
 #pragma unroll
   for (int j = W; j < KPAD; j += 4) {
-    if (j < k) {                            // wave-uniform: slots past k hold no id (k = 50 in 64 slots: 1225 of the 2016 pairs)
+    if (KPAD < 64 || j < k) {               // wave-uniform: slots past k hold no id (k = 50 in 64 slots: 1225 of the 2016 pairs; at
+                                            // 32 slots the branches cost more than the few pairs they save: +0.9 us at k = 30)
 #pragma unroll
       for (int j2 = 0; j2 < j; ++j2) {
         const uint32_t x = r[j] ^ r[j2];
@@ -207,10 +209,13 @@ __device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD], int k) {
   return m;
 }
 
-template <typename T, int KPAD, bool CMP>
-__global__ __launch_bounds__(256) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
+// HALO (int32 ids only): the rows of a sharded sub-problem (csrc/halo.hip) read straight from the block's global ids — own cells
+// from idx, halo slots from the reply slots — and mapped to local ids on the fly (the unfused form writes the mapped index
+// matrix first: one more kernel and 2 x 16 MB of traffic per step at 100 k cells); also writes the local -> global map.
+template <typename T, int KPAD, bool CMP, bool HALO = false>
+__global__ __launch_bounds__(256, HALO ? 4 : 1) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                      int64_t N_total, uint32_t* __restrict__ table,
-                                                     uint32_t* __restrict__ status, int zero_ok) {
+                                                     uint32_t* __restrict__ status, int zero_ok, const gficf_halo_map hm) {
   constexpr int ROWS = 64;
   constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
   __shared__ uint32_t tile[ROWS][KPAD + 1];
@@ -220,10 +225,43 @@ __global__ __launch_bounds__(256) void k_ingest_tile(const T* __restrict__ idx, 
     const int64_t r = row0 + lane;
     // all loads of the thread are issued before the first is looked at
     T raw[KPAD / 4];
+    if constexpr (HALO) {
+      const int64_t q = r - hm.n_local;                      // halo slot of this row (own cells: negative)
+      const int32_t gid = (r < n_rows && q >= 0) ? hm.req_out[q] : 0;
+      if (wave == 0 && r < n_rows) hm.l2g[r] = q < 0 ? (int32_t)(hm.b + r + 1) : gid;
+      if (row0 + ROWS <= hm.n_local) {                       // a tile of own cells (workgroup-uniform): the plain loads, all in flight
 #pragma unroll
-    for (int m = 0; m < KPAD / 4; ++m) {
-      const int j = wave + 4 * m;
-      raw[m] = (j < k && r < n_rows) ? idx[(int64_t)j * ld + r] : (T)0;
+        for (int m = 0; m < KPAD / 4; ++m) {
+          const int j = wave + 4 * m;
+          raw[m] = j < k ? idx[(int64_t)j * ld + r] : (T)0;
+        }
+      } else {                                               // the seam tile and the halo slots (most of them empty)
+#pragma unroll
+        for (int m = 0; m < KPAD / 4; ++m) {
+          const int j = wave + 4 * m;
+          int32_t g = 0;
+          if (j < k && r < n_rows) g = q < 0 ? (int32_t)idx[(int64_t)j * ld + r] : (gid != 0 ? hm.rows_in[q * k + j] : 0);
+          raw[m] = (T)g;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < KPAD / 4; ++m) {                   // global -> local (own rows: an invalid id stays invalid; halo rows: 0)
+        const int j = wave + 4 * m;
+        if (j < k && r < n_rows) {
+          int32_t v = 0;
+          if (q < 0 || gid != 0) {
+            v = gficf_halo_local((int64_t)raw[m], hm.N_total, hm.b, hm.n_local, hm.rpr, hm.cap, hm.bitmap, hm.word_rank, hm.owner_start);
+            if (q >= 0 && v < 0) v = 0;
+          }
+          raw[m] = (T)v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < KPAD / 4; ++m) {
+        const int j = wave + 4 * m;
+        raw[m] = (j < k && r < n_rows) ? idx[(int64_t)j * ld + r] : (T)0;
+      }
     }
     if (tid < ROWS) dup[tid] = 0;
     bool bad = false;
@@ -1462,7 +1500,7 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
                          table, ctx->d_status, zero_ok);                                                                   \
     else                                                                                                                   \
       hipLaunchKernelGGL((k_ingest_tile<T, KP, CM>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total,  \
-                         table, ctx->d_status, zero_ok);                                                                   \
+                         table, ctx->d_status, zero_ok, gficf_halo_map{});                                                 \
   } while (0)
 #define LAUNCH_INGEST(KP, CM)                                                                                   \
   hipLaunchKernelGGL((k_ingest<T, KP, CM>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
@@ -1639,6 +1677,43 @@ int gficf_jaccard_ingest_local_device(gficf_ctx* ctx, const int32_t* d_idx_ext, 
   if (!d_idx_ext || !d_table) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   if (ld < n_ext) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < n_ext = %lld", (long long)ld, (long long)n_ext);
   return launch_ingest<int32_t>(ctx, d_idx_ext, n_ext, k, ld, n_ext, (uint32_t*)d_table, 1);
+}
+
+/* relabel + ingest in one launch (k <= 64): the sub-problem's table straight from the block's global ids, the reply slots and
+ * the plan's workspace (csrc/halo.hip); also writes d_l2g.  Returns GFICF_ERR_UNSUPPORTED for k > 64 (the caller then runs
+ * gficf_jaccard_halo_relabel_device + gficf_jaccard_ingest_local_device). */
+int gficf_jaccard_halo_ingest_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                     int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
+                                     const int32_t* d_rows_in, int32_t* d_table, int32_t* d_l2g) {
+  GFICF_CTX_ENTER(ctx);
+  if (n_local < 0 || k < 0 || N_total < 0 || P < 1 || cap < 1 || rows_per_rank < 1 || cell_begin < 0 || cell_begin + n_local > N_total)
+    GFICF_FAIL(GFICF_ERR_INVALID_ARG, "halo ingest: sizes out of range");
+  const int64_t n_ext = n_local + (int64_t)P * cap;
+  int rc = check_nk(n_ext, k);
+  if (rc) return rc;
+  if (k > 64) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "halo ingest: the fused form covers k <= 64");
+  if (n_ext == 0 || k == 0) return GFICF_OK;
+  if (!d_ws || !d_req_out || !d_rows_in || !d_table || !d_l2g || (n_local > 0 && !d_idx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (n_local > 0 && ld < n_local) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld < n_local");
+  const int64_t words = ((N_total + 31) / 32 + 4) & ~(int64_t)3;          // layout of gficf_jaccard_halo_workspace_bytes
+  const size_t seg = ((size_t)words * 4 + 255) & ~(size_t)255;
+  gficf_halo_map hm{(const uint32_t*)d_ws, (const int32_t*)((const char*)d_ws + seg), (const int32_t*)((const char*)d_ws + 2 * seg),
+                    d_req_out, d_rows_in, d_l2g, n_local, N_total, cell_begin, rows_per_rank, cap};
+  const TableFmt f = table_fmt(n_ext, k);
+  const int64_t tiles = gficf_ceil_div(n_ext, INGEST_ROWS);
+  const int64_t gcap = (int64_t)ctx->num_cus * 8;
+  const unsigned grid = (unsigned)(tiles < gcap ? tiles : gcap);
+#define LAUNCH_HALO_INGEST(KP, CM)                                                                                              \
+  hipLaunchKernelGGL((k_ingest_tile<int32_t, KP, CM, true>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_ext, k, ld, n_ext, \
+                     (uint32_t*)d_table, ctx->d_status, 1, hm)
+  switch (f.kpad) {
+    case 16: LAUNCH_HALO_INGEST(16, false); break;
+    case 32: if (f.compact) LAUNCH_HALO_INGEST(32, true); else LAUNCH_HALO_INGEST(32, false); break;
+    default: if (f.compact) LAUNCH_HALO_INGEST(64, true); else LAUNCH_HALO_INGEST(64, false); break;
+  }
+#undef LAUNCH_HALO_INGEST
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
 }
 
 /* Edges of the first n_cells rows of such a table; column 1 = src_offset + cell + 1, column 2 = d_l2g[local id - 1]. */

@@ -195,6 +195,11 @@ int gficf_jaccard_halo_relabel_device(gficf_ctx* ctx, const int32_t* d_idx, int6
                                       int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
                                       const int32_t* d_rows_in, int32_t* d_idx_ext, int32_t* d_l2g);
 int gficf_jaccard_ingest_local_device(gficf_ctx* ctx, const int32_t* d_idx_ext, int64_t n_ext, int k, int64_t ld, int32_t* d_table);
+/* relabel + ingest_local in one launch, for k <= 64 (GFICF_ERR_UNSUPPORTED beyond: run the two calls above): the table of the
+ * sub-problem straight from the block's global ids, the reply slots and the plan's workspace; writes d_l2g as relabel does. */
+int gficf_jaccard_halo_ingest_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                     int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
+                                     const int32_t* d_rows_in, int32_t* d_table, int32_t* d_l2g);
 int gficf_jaccard_edges_mapped_device(gficf_ctx* ctx, const int32_t* d_table, int64_t n_ext, int k, int64_t n_cells, int64_t src_offset,
                                       const int32_t* d_l2g, double* d_src, double* d_dst, double* d_w, int32_t* d_u);
 

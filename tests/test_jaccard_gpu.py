@@ -556,6 +556,12 @@ def test_local_id_sub_problems_of_emulated_ranks(N, k, P, cap, perm):
         ops.halo_relabel(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in[r], idx_ext, l2g)
         table = torch.zeros((n_ext, ops.row_words(n_ext, k)), **i32)
         ops.jaccard_ingest_local(idx_ext, n_ext, k, table)
+        # relabel + ingest in one launch (k <= 64): the same table and the same map
+        t2, g2 = torch.full_like(table, -1), torch.full_like(l2g, -1)
+        if ops.halo_ingest(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in[r], t2, g2):
+            assert k <= 64 and torch.equal(t2, table) and torch.equal(g2, l2g)
+        else:
+            assert k > 64
         out = torch.zeros((3, nl * k), dtype=torch.float64, device="cuda")
         ops.jaccard_edges_mapped(table, n_ext, k, nl, b, l2g, out)
         ops.sync()
