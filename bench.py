@@ -469,6 +469,10 @@ def main():
     roofline = {"bound": "hbm", "kernel": edge_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_copy_rate": round(achieved / HBM_COPY_GBS, 4), "traffic": traffic,
                 "traffic_source": "profiles/pmc_traffic.json (separate --pmc passes of tools/pmc_round.sh, read requests priced by their width: tools/make_traffic.py)" if traffic else None,
+                # what the kernel really moves: a gathered row fills a whole 128 B line (profiles/r03_fetch_calibration.txt)
+                "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
+                "traffic_GBps": round(traffic / (t_edges_ms * 1e-3) / 1e9, 1) if traffic else None,
+                "traffic_frac_of_copy_rate": round(traffic / (t_edges_ms * 1e-3) / 1e9 / HBM_COPY_GBS, 4) if traffic else None,
                 "kernel_ms": round(t_edges_ms, 5), "kernel_ms_back_to_back": round(t_edges_b2b_ms, 5),
                 "ingest_kernel_ms": round(t_ingest_ms, 5),
                 "algorithmic_bytes_per_launch": alg_bytes,
