@@ -108,6 +108,7 @@ SIGNATURES = {
     "gficf_knn_prepare_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _int, _vp]),
     "gficf_knn_workspace_bytes": (ctypes.c_size_t, [_vp, _i64, _i64, _int]),
     "gficf_knn_search_device": (_int, [_vp, _vp, _i64, _int, _int, _int, _i64, _i64, _vp, ctypes.c_size_t, _vp, _vp, _i64]),
+    "gficf_knn_pivot_order_device": (_int, [_vp, _vp, _i64, _int, _int, _vp, ctypes.c_size_t, _vp]),
     "gficf_knn_host": (_int, [_vp, _vp, _i64, _int, _i64, _int, _int, _vp, _vp]),
     "gficf_csc_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),

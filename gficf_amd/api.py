@@ -807,6 +807,12 @@ class HipOps:
         check(self.L.gficf_knn_search_device(self._bind(), _tptr(points), N, d, k, _lib.KNN_METRICS[metric], q_begin, q_end,
                                              _tptr(ws), int(ws.numel()), _tptr(idx_cm), _tptr(dist_cm), ld))
 
+    def knn_pivot_order(self, points, N: int, d: int, metric: str, ws, order):
+        """order (N int32): order[p] = 0-based row of the point at position p of the pruned search's (coarse, fine) pivot order —
+        a cell numbering with locality.  ws: uint8 scratch of knn_workspace_bytes(N, N, 1)."""
+        check(self.L.gficf_knn_pivot_order_device(self._bind(), _tptr(points), N, d, _lib.KNN_METRICS[metric], _tptr(ws), int(ws.numel()),
+                                                  _tptr(order)))
+
     # -- GF-ICF
     def csc_count(self, G, n_cells, colptr, rowidx, x, nt):
         check(self.L.gficf_csc_count_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),

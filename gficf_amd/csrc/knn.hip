@@ -1069,6 +1069,52 @@ int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, in
   return GFICF_OK;
 }
 
+/* The cell order of the pruned search, for callers that want ids with LOCALITY (the sharded Jaccard build's halo form,
+ * gficf_amd/dist.py): d_order[p] = 0-based row of the point at position p when the points are sorted by their (coarse, fine)
+ * pivot — steps 1-2 of the pruned search above, nothing else.  Points whose nearest neighbours share their pivot cell end up
+ * next to each other, so a contiguous block of the order names few rows outside itself.  A function of the points alone: every
+ * rank of a sharded job computes the same order from the same (all-gathered) points.  Workspace as for a search with N queries. */
+int gficf_knn_pivot_order_device(gficf_ctx* ctx, const float* d_points, int64_t N, int d, int metric, void* d_ws, size_t ws_bytes,
+                                 int32_t* d_order) {
+  GFICF_CTX_ENTER(ctx);
+  int rc = knn_check(N, d, 1, metric);
+  if (rc) return rc;
+  if (N == 0) return GFICF_OK;
+  if (d == 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "points have no dimensions");
+  if (!d_points || !d_ws || !d_order) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (ws_bytes < gficf_knn_workspace_bytes(ctx, N, N, 1)) GFICF_FAIL(GFICF_ERR_CAPACITY, "kNN workspace too small");
+  if (metric == GFICF_KNN_CORRELATION) metric = GFICF_KNN_COSINE;
+  auto blocks_for = [](int64_t n) { return dim3((unsigned)gficf_ceil_div(n, 256)); };
+  if (gficf_ceil_div(N, KNN_TC) > KNN_PRUNE_MAX_TILES || knn_pivots(N) < 2) {      // no pivots at this size: the order as given
+    hipLaunchKernelGGL(k_knn_iota, blocks_for(N), dim3(256), 0, ctx->stream, d_order, N);
+    GFICF_HIP_CHECK(hipGetLastError());
+    return GFICF_OK;
+  }
+  const int dpad = knn_dpad(d);
+  const KnnPruneWs w = knn_prune_ws((char*)d_ws, N, N, dpad, 1);
+  const int nq4 = dpad >> 2;
+  const int64_t C = w.C;
+  hipLaunchKernelGGL(k_knn_gather_rows, blocks_for(C * nq4), dim3(256), 0, ctx->stream, d_points, (const int32_t*)nullptr, C, nq4, N / C, w.pivots);
+  KnnTileArgs as{};
+  as.Q = d_points; as.n_q = N; as.X = w.pivots; as.N = C; as.d = d; as.dpad = dpad; as.kk = 1; as.S = 1; as.part = w.apart;
+  rc = knn_launch_m<false>(ctx, metric, as);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_knn_merge, blocks_for(N), dim3(256), 0, ctx->stream, w.apart, N, 1, 1, metric, (const int32_t*)nullptr, w.pivot_of, (float*)nullptr, N, (const uint32_t*)nullptr, 0u);
+  const int64_t Cc = knn_coarse(C);
+  hipLaunchKernelGGL(k_knn_gather_rows, blocks_for(Cc * nq4), dim3(256), 0, ctx->stream, w.pivots, (const int32_t*)nullptr, Cc, nq4, C / Cc, w.coarse);
+  KnnTileArgs ac{};
+  ac.Q = w.pivots; ac.n_q = C; ac.X = w.coarse; ac.N = Cc; ac.d = d; ac.dpad = dpad; ac.kk = 1; ac.S = 1; ac.part = w.apart;
+  rc = knn_launch_m<false>(ctx, metric, ac);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_knn_merge, blocks_for(C), dim3(256), 0, ctx->stream, w.apart, C, 1, 1, metric, (const int32_t*)nullptr, w.coarse_of, (float*)nullptr, C, (const uint32_t*)nullptr, 0u);
+  hipLaunchKernelGGL(k_knn_sort_keys, blocks_for(N), dim3(256), 0, ctx->stream, w.pivot_of, w.coarse_of, N, w.keys);
+  hipLaunchKernelGGL(k_knn_iota, blocks_for(N), dim3(256), 0, ctx->stream, w.iota, N);
+  size_t tb = w.sort_tmp_bytes;
+  GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys, w.key_tmp, w.iota, d_order, (size_t)N, 0u, 26u, ctx->stream));
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
+}
+
 int gficf_knn_host(gficf_ctx* ctx, const double* X, int64_t N, int d, int64_t ld, int k, int metric, int32_t* idx, double* dist) {
   GFICF_CTX_ENTER(ctx);
   int rc = knn_check(N, d, k, metric);

@@ -507,3 +507,36 @@ class KnnShard:
             # blocks are equal-pitch and only the last can be short, so rows [0, N) of the table are the N points
             self.ops.knn_search(self.points, self.N, self.d, self.k, self.metric, self.b, self.e, self.ws, self.idx, self.dist)
         return self.idx
+
+    def step_ordered(self, X_local_cm):
+        """The search with the cells RENUMBERED in the pruned search's pivot order (R/clustCells.R:57-65: find_nn -> neigh[,-1] ->
+        the Jaccard build): every rank derives the same order from the all-gathered points (``gficf_knn_pivot_order_device``), lays
+        the points out in it and searches the cells at positions [b, e) of the order.  Returns ``(idx, order)``: ``idx`` (k, n_local)
+        int32 holds 1-based ids IN THE NEW NUMBERING (column 0 = the cell itself) — ids with locality: a block names few rows
+        outside itself, which is what :class:`JaccardHaloShard` wants; ``order`` (N int32, the same on every rank): ``order[p]`` =
+        original 0-based cell at position p, so this rank's cells are ``order[b:e]`` and :func:`edges_to_original_ids` maps a
+        block of edges back.  The neighbour lists are those of :meth:`step` (ties between equal distances are broken by the
+        position in the order instead of the original index)."""
+        mine = self.points[self.rank * self.rpr:(self.rank + 1) * self.rpr]
+        if self.n_local > 0:
+            self.ops.knn_prepare(X_local_cm, self.n_local, self.d, self.metric, mine)
+        if self.world > 1:
+            _all_gather_rows(self.points.view(-1), mine.reshape(-1), self.group)
+        if not hasattr(self, "order"):
+            dev = self.points.device
+            self.order = torch.zeros(max(self.N, 1), dtype=torch.int32, device=dev)
+            self.ws_order = torch.zeros(max(self.ops.knn_workspace_bytes(self.N, self.N, 1), 16), dtype=torch.uint8, device=dev)
+        self.ops.knn_pivot_order(self.points, self.N, self.d, self.metric, self.ws_order, self.order)
+        self.points_sorted = self.points[:self.N].index_select(0, self.order[:self.N].long())
+        if self.n_local > 0:
+            self.ops.knn_search(self.points_sorted, self.N, self.d, self.k, self.metric, self.b, self.e, self.ws, self.idx, self.dist)
+        return self.idx, self.order[:self.N]
+
+
+def edges_to_original_ids(out3, order):
+    """Columns 1 and 2 (from, to) of a block of edges built on renumbered cells (:meth:`KnnShard.step_ordered`) back in the
+    original 1-based ids: id -> order[id - 1] + 1, zero rows stay zero.  out3: (3, n) float64, changed in place."""
+    o1 = torch.cat([torch.zeros(1, dtype=torch.float64, device=out3.device), order.to(torch.float64) + 1.0])
+    out3[0] = o1[out3[0].long()]
+    out3[1] = o1[out3[1].long()]
+    return out3

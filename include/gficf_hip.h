@@ -472,6 +472,14 @@ size_t gficf_knn_workspace_bytes(gficf_ctx* ctx, int64_t n_queries, int64_t N, i
 int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, int d, int k, int metric,
                             int64_t q_begin, int64_t q_end, void* d_ws, size_t ws_bytes,
                             int32_t* d_idx, float* d_dist, int64_t ld_out);
+
+/* The cell order of the pruned search, for callers that want neighbour ids with LOCALITY (the halo form of the sharded Jaccard
+ * build, R/clustCells.R:57-65: find_nn -> neigh[,-1] -> rcpp_parallel_jaccard_coef): d_order[p] = 0-based row of the point at
+ * position p when the points are sorted by their (coarse, fine) pivot.  A function of the prepared points alone (every rank of
+ * a sharded job computes the same order from the all-gathered points); a search over the points re-laid in this order returns
+ * ids in which a contiguous block of cells names few rows outside itself.  d_ws: gficf_knn_workspace_bytes(ctx, N, N, 1). */
+int gficf_knn_pivot_order_device(gficf_ctx* ctx, const float* d_points, int64_t N, int d, int metric, void* d_ws, size_t ws_bytes,
+                                 int32_t* d_order);
 /* Host form: X = N x d column-major doubles (an R numeric matrix); idx: N x k column-major int32
  * (1-based), dist: N x k column-major doubles or NULL. */
 int gficf_knn_host(gficf_ctx* ctx, const double* X, int64_t N, int d, int64_t ld, int k, int metric,

@@ -148,3 +148,80 @@ def test_plain_bench_command_starts_its_own_ranks():
     assert out["config"]["cells_total"] == 40000
     ex = out["exchange"]
     assert ex["rows_received_per_rank_per_data_set"] == 20000 and ex["bytes_received_per_rank_per_data_set"] > 0
+
+
+def _ordered_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gficf_amd
+        from gficf_amd.dist import JaccardHaloShard, KnnShard, edges_to_original_ids, shard_bounds
+
+        ops = gficf_amd.HipOps(0)
+        N, d, kk = 40000, 20, 16
+        X = _blobs(N, d)
+        b, e = shard_bounds(N, world, rank)
+        ks = KnnShard(ops, N, d, kk, "euclidean", device="cuda")
+        xl = torch.from_numpy(np.ascontiguousarray(X[b:e].T)).cuda()
+        # cells in the order they came (clusters scattered): the block names nearly every remote row -> the slots overflow
+        idx_plain = ks.step(xl).clone()
+        hs = JaccardHaloShard(ops, N, kk - 1, device="cuda")
+        hs.step(idx_plain[1:].contiguous())
+        over = False
+        try:
+            hs.sync()
+        except gficf_amd.GficfError as ex:
+            over = ex.status == "GFICF_ERR_CAPACITY"
+        named_plain = hs.rows_named_outside()
+        # cells renumbered in the search's pivot order: few rows named outside the block, the halo form fits
+        idx_ord, order = ks.step_ordered(xl)
+        hs2 = JaccardHaloShard(ops, N, kk - 1, device="cuda")
+        out = hs2.step(idx_ord[1:].contiguous()).clone()
+        hs2.sync()
+        named_ord = hs2.rows_named_outside()
+        edges_to_original_ids(out, order)
+        np.save(os.path.join(outdir, f"ord_edges_{rank}.npy"), out.cpu().numpy())
+        np.save(os.path.join(outdir, f"ord_cells_{rank}.npy"), order[b:e].cpu().numpy())
+        np.save(os.path.join(outdir, f"ord_meta_{rank}.npy"), np.array([int(over), named_plain, named_ord, hs2.cap]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _blobs(N, d):
+    rng = np.random.default_rng(77)
+    centers = rng.normal(scale=8.0, size=(25, d))
+    lab = rng.integers(0, 25, size=N)                       # clusters scattered over the cell order, as in real input
+    return centers[lab] + rng.normal(size=(N, d)) * rng.uniform(0.6, 1.5, size=(25, 1))[lab]
+
+
+def test_knn_chain_in_pivot_order_feeds_the_halo_form(tmp_path):
+    """kNN -> Jaccard sharded over two ranks on clustered points that arrive in no particular order (R/clustCells.R:57-65).
+    In the given numbering a block names nearly every remote row (request slots overflow: the all-gather form is the one to
+    take); with the cells renumbered in the search's pivot order (KnnShard.step_ordered) the halo form fits, names a small
+    fraction of the remote rows, and — mapped back to the original ids — gives the oracle's edges bit for bit."""
+    import torch.multiprocessing as mp
+
+    import oracle
+
+    world = 2
+    mp.spawn(_ordered_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    N, d, kk = 40000, 20, 16
+    X = _blobs(N, d)
+    widx, _ = oracle.knn(X, kk, "euclidean", nthreads=8)
+    want, _ = oracle.jaccard(np.ascontiguousarray(widx[:, 1:]), nthreads=8)
+    k = kk - 1
+    got = np.zeros_like(want)
+    for r in range(world):
+        cells = np.load(tmp_path / f"ord_cells_{r}.npy").astype(np.int64)          # original 0-based ids of the rank's cells, in its order
+        edges = np.load(tmp_path / f"ord_edges_{r}.npy").T.reshape(len(cells), k, 3)
+        got.reshape(N, k, 3)[cells] = edges
+        over, named_plain, named_ord, cap = np.load(tmp_path / f"ord_meta_{r}.npy")
+        assert over == 1 and named_plain == cap                                  # scattered clusters: every slot of the other owner in use
+        assert 0 < named_ord < 0.25 * (N // world)
+    assert np.array_equal(got, want)
