@@ -5,7 +5,9 @@ A "step" is one pass of the Jaccard hot path over one batch of synthetic input t
 every data set of the batch, the column-major int32 kNN index block of this rank's cells (what
 `uwot:::find_nn(...)$idx[,-1]` hands to the reference, R/clustCells.R:63-65)
   -> ingest (transpose / validate into the row-major table)
-  -> [N > 1: RCCL all-gather of the table rows over xGMI]
+  -> [N > 1: the exchange over xGMI — an RCCL all-gather of the table rows, or, when the blocks name few rows outside
+      themselves (`--exchange auto` decides on data set 0 before anything is timed), the halo form on local ids: two
+      equal-split all-to-alls of request slots and index rows, gficf_amd/dist.py JaccardHaloShard]
   -> edge kernel -> this rank's rows of the reference's (N*k) x 3 double matrix,
 all on ONE stream, in order: every data set pays its own ingest + edge kernel (+ exchange), nothing of one data set
 overlaps another (no software pipelining in `value`; `--pipeline` keeps the overlapped mode as a separate figure).
