@@ -194,6 +194,7 @@ int gficf_jaccard_halo_plan_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "halo plan: sizes out of range");
   if ((int64_t)P * rows_per_rank < N_total) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "halo plan: P * rows_per_rank < N_total");
   if (N_total > 0x7FFFFFFFll || P > HP_THREADS - 1) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "halo plan: N_total beyond int32 ids or more than %d ranks", HP_THREADS - 1);
+  if (k > GFICF_JACCARD_MAX_K) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d neighbours per cell: this build handles at most GFICF_JACCARD_MAX_K = %d", k, GFICF_JACCARD_MAX_K);
   if (!d_ws || !d_req_out || (n_local > 0 && k > 0 && !d_idx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   if (n_local > 0 && ld < n_local) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld < n_local");
   const int64_t words = ((N_total + 31) / 32 + 4) & ~(int64_t)3;

@@ -101,6 +101,69 @@ __global__ __launch_bounds__(256) void k_model(const char* __restrict__ table, l
 }
 
 
+// XCD split inside ONE launch: the blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), so block b
+// belongs to group (b % 8) * NS / 8; a group walks ALL cells but gathers only the neighbour rows in ITS 1/NS of the table
+// (the rows one XCD's L2 sees then fit it) and writes only those slots' edges (scattered 8 B stores: the other groups write
+// the neighbouring slots of the same lines).  Memory-side model only (no hash set): is the L2 residency worth the scattered
+// writes and the NS-fold own-row reads?
+template <int NS, int STORES>
+__global__ __launch_bounds__(256) void k_model_xcd(const char* __restrict__ table, long N, int k, double* __restrict__ o_src,
+                                                   double* __restrict__ o_dst, double* __restrict__ o_w, uint32_t fold) {
+  constexpr int ROWB = 64, LPR = ROWB / 16, RPS = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int x = blockIdx.x % 8, g = x * NS / 8;
+  const uint32_t lo = (uint32_t)((unsigned long long)N * g / NS), hi = (uint32_t)((unsigned long long)N * (g + 1) / NS);
+  const long bg = (long)(blockIdx.x / 8) * (8 / NS) + x % (8 / NS), nbg = (long)gridDim.x / NS;
+  const long w0 = (bg * 256 + threadIdx.x) >> 6, nw = (nbg * 256) >> 6;
+  const int grow = lane / LPR;
+  const uint32_t gcol = (uint32_t)(lane % LPR) * 16u;
+  auto own = [&](long i) -> uint32_t {
+    if (lane >= k) return 0u;
+    const uint32_t lo16 = reinterpret_cast<const uint16_t*>(table + i * ROWB)[lane];
+    const uint32_t hi16 = reinterpret_cast<const uint32_t*>(table + i * ROWB)[15];
+    return lo16 | (((hi16 >> lane) & 1u) << 16);
+  };
+  long i = w0;
+  uint32_t a_next = i < N ? own(i) : 0u;
+  for (; i < N; i += nw) {
+    const uint32_t a = a_next;
+    const uint32_t asafe = a != 0 ? a : (uint32_t)(i + 1);
+    if (i + nw < N) a_next = own(i + nw);
+    const int steps = (k + RPS - 1) / RPS;
+    uint32_t acc[4] = {0, 0, 0, 0};
+    v4u bv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bv[s] = v4u{0, 0, 0, 0};
+      if (s < steps) {
+        const uint32_t dst = (uint32_t)__shfl((int)asafe, s * RPS + grow) - 1u;
+        if (dst >= lo && dst < hi) bv[s] = load16<0>(table + (size_t)(dst & fold) * ROWB + gcol);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < steps) acc[s] = bv[s].x ^ bv[s].y ^ bv[s].z ^ bv[s].w;
+    uint32_t u = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < steps) {
+        uint32_t xx = acc[s];
+        for (int d = 1; d < LPR; d <<= 1) xx ^= __shfl_xor((int)xx, d);
+        const uint32_t v = (uint32_t)__shfl((int)xx, (lane % RPS) * LPR);
+        u = (lane / RPS == s) ? v : u;
+      }
+    }
+    const bool mine = lane < k && a != 0 && (a - 1u) >= lo && (a - 1u) < hi;
+    if (STORES == 1 && mine) {
+      const long r = i * k + lane;
+      __builtin_nontemporal_store((double)(uint32_t)(i + 1), o_src + r);
+      __builtin_nontemporal_store((double)a, o_dst + r);
+      __builtin_nontemporal_store((double)(u & 0xffu), o_w + r);
+    }
+    if (!STORES && u == 0xdeadbeefu) o_w[0] = 1.0;
+  }
+}
+
 // Range passes: the same model, but one launch gathers only the neighbour rows whose id lies in [lo, hi) (the other lanes of
 // the gather instruction are masked off and issue no request), so that the rows a launch touches fit an XCD's L2.  Partial
 // per-slot results travel between the passes in a byte plane (32 B per cell); the last pass adds them and writes the edges.
@@ -325,6 +388,16 @@ int main(int argc, char** argv) {
       run(" 64 B rows, plain loads, stores", k_model<64, 0, 1>, t64, grid);
       run(" 64 B rows, nt loads, stores", k_model<64, 1, 1>, t64, grid);
       run(" 64 B rows, plain loads, no stores", k_model<64, 0, 0>, t64, grid);
+    }
+    if (!product_only) {
+      for (int bpc : {8, 16}) {
+        const int grid = cus * bpc;
+        run(" 64 B rows, XCD split 2, stores", k_model_xcd<2, 1>, t64, grid);
+        run(" 64 B rows, XCD split 4, stores", k_model_xcd<4, 1>, t64, grid);
+        run(" 64 B rows, XCD split 8, stores", k_model_xcd<8, 1>, t64, grid);
+        run(" 64 B rows, XCD split 2, no stores", k_model_xcd<2, 0>, t64, grid);
+        run(" 64 B rows, XCD split 8, no stores", k_model_xcd<8, 0>, t64, grid);
+      }
     }
     if (!product_only) {
       const int grid = cus * 8;
