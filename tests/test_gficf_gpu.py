@@ -640,3 +640,45 @@ def test_helper_branches_icf_type_and_norm(icf_type, norm):
     assert np.allclose(d["gficf"].data, ref0["x"], rtol=1e-6, atol=1e-6)
     with pytest.raises(ValueError):
         gficf_amd.gficf(M, normalize=False, verbose=False, icf_type="bm25")
+
+
+def test_config4_shape_as_eight_cell_blocks_matches_the_single_shot_pass():
+    """BASELINE config 4's GF-ICF half is an 8-GPU config (100 k cells x 30 k genes): eight cell blocks cut by stored entries,
+    each counted on its own, the per-gene counts summed (the all-reduce of the sharded path), gene table / colptr / scale per
+    block — the seam the multi-GPU forms run through — against the single-shot device pass on the same matrix: identical
+    structure, values equal to 1e-12."""
+    import torch
+
+    from gficf_amd.dist import shard_bounds_by_nnz
+
+    bench = _import_bench()
+    ops = gficf_amd.HipOps(0)
+    G, N, P = 30000, 100000, 8
+    colptr, rowidx, x = bench.synth_counts_device(torch, G, N, seed=11)
+    ws = ops.gficf_csc(G, N, colptr, rowidx, x, 0.05, 1.0, exact=True)
+    ops.sync()
+    nk = int(ws["out_colptr"][N])
+    blocks = shard_bounds_by_nnz(colptr.cpu().numpy(), P)
+    nt = torch.zeros(G, dtype=torch.int64, device="cuda")
+    parts = []
+    for b, e in blocks:
+        p0, p1 = int(colptr[b]), int(colptr[e])
+        lcp = (colptr[b:e + 1] - colptr[b]).contiguous()
+        parts.append((e - b, lcp, rowidx[p0:p1], x[p0:p1], int(ws["out_colptr"][b]), int(ws["out_colptr"][e])))
+        ops.csc_count(G, e - b, lcp, rowidx[p0:p1], x[p0:p1], nt)
+    ops.sync()
+    assert torch.equal(nt, ws["nt"])
+    share = [p[2].numel() for p in parts]
+    assert max(share) - min(share) < 3 * int((colptr[1:] - colptr[:-1]).max())           # blocks balanced by entries
+    for n, lcp, lri, lx, q0, q1 in parts:
+        w2 = ops.csc_workspace(G, n, int(lri.numel()))
+        ops.csc_genes(G, N, nt, 0.05, 1.0, None, w2["keep"], w2["genes"], w2["w"], w2["gkept"])
+        ops.csc_colptr(G, n, lcp, lri, w2["keep"], w2["gkept"], w2["out_colptr"])
+        ops.csc_scale(G, n, lcp, lri, lx, w2["genes"], w2["gkept"], w2["out_colptr"], w2["out_rowidx"], w2["out_x"])
+        ops.sync()
+        m = int(w2["out_colptr"][n])
+        assert m == q1 - q0 and torch.equal(w2["keep"], ws["keep"])
+        assert torch.equal(w2["out_rowidx"][:m], ws["out_rowidx"][q0:q1])
+        assert torch.allclose(w2["out_x"][:m], ws["out_x"][q0:q1], rtol=1e-12, atol=1e-15)
+        del w2
+    assert sum(p[5] - p[4] for p in parts) == nk

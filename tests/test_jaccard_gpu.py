@@ -621,3 +621,56 @@ def test_truncate_noninteger_ids_strict_drop_in_mode():
     with pytest.raises(gficf_amd.GficfError) as ei:
         gficf_amd.rcpp_parallel_jaccard_coef(np.ones((4, 300), dtype=np.int32), False)
     assert ei.value.status == "GFICF_ERR_UNSUPPORTED" and "256" in str(ei.value)
+
+
+@pytest.mark.parametrize("N,k", [(100_000, 50), (1_000_000, 30)])
+def test_configs_4_and_5_as_eight_blocks_on_local_ids(N, k):
+    """BASELINE configs 4 (100 k x k = 50) and 5 (1 M x k = 30) are 8-GPU configs: the data set as eight cell blocks, every
+    block built as a sub-problem in local ids (plan / serve / fused relabel-and-ingest / mapped edge kernel), ranks emulated one
+    after the other on this GPU, ids in spatial order (what the halo form is for).  Each block against the oracle on a sample
+    of its cells (start, middle, end), and the whole by properties: source column, zero rows exactly where u = 0."""
+    import torch
+
+    from gficf_amd.dist import rows_per_rank, shard_bounds
+
+    ops = gficf_amd.HipOps(0)
+    P = 8
+    mat = synth.knn_windowed(N, k, seed=4, perm_seed=None)
+    rpr = rows_per_rank(N, P)
+    cap = max(64, min(8192, ((1 << 17) - 1 - rpr) // P))
+    blocks = [shard_bounds(N, P, r) for r in range(P)]
+    i32 = dict(dtype=torch.int32, device="cuda")
+    idx = [torch.from_numpy(np.ascontiguousarray(mat[b:e].T)).cuda() for b, e in blocks]
+    req_out = [torch.zeros(P * cap, **i32) for _ in range(P)]
+    wss = [torch.zeros(ops.halo_workspace_bytes(N, P), dtype=torch.uint8, device="cuda") for _ in range(P)]
+    for r, (b, e) in enumerate(blocks):
+        ops.halo_plan(idx[r], e - b, k, N, b, P, rpr, cap, wss[r], req_out[r])
+    ops.sync()
+    req_in = [torch.cat([req_out[r][p * cap:(p + 1) * cap] for r in range(P)]) for p in range(P)]
+    rows_out = [torch.zeros(P * cap * k, **i32) for _ in range(P)]
+    for p, (b, e) in enumerate(blocks):
+        ops.halo_serve(idx[p], e - b, k, b, req_in[p], rows_out[p])
+    for r, (b, e) in enumerate(blocks):
+        nl, n_ext = e - b, e - b + P * cap
+        rows_in = torch.cat([rows_out[p][r * cap * k:(r + 1) * cap * k] for p in range(P)])
+        table = torch.zeros((n_ext, ops.row_words(n_ext, k)), **i32)
+        l2g = torch.zeros(n_ext, **i32)
+        if not ops.halo_ingest(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, table, l2g):
+            idx_ext = torch.zeros((k, n_ext), **i32)
+            ops.halo_relabel(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, idx_ext, l2g)
+            ops.jaccard_ingest_local(idx_ext, n_ext, k, table)
+        out = torch.zeros((3, nl * k), dtype=torch.float64, device="cuda")
+        ops.jaccard_edges_mapped(table, n_ext, k, nl, b, l2g, out)
+        ops.sync()
+        assert n_ext < (1 << 17) and 4 * ops.row_words(n_ext, k) == (64 if k <= 30 else 128)      # compact rows at any N_total
+        run = 512
+        for c0 in sorted({b, b + (nl - run) // 2, e - run}):
+            want, _ = oracle.jaccard_cells(mat, c0, c0 + run, nthreads=8)
+            assert np.array_equal(out[:, (c0 - b) * k:(c0 - b + run) * k].cpu().numpy().T, want), (r, c0)
+        src, dst, w = out[0], out[1], out[2]
+        pos = w > 0
+        cells = torch.repeat_interleave(torch.arange(b + 1, e + 1, device="cuda", dtype=torch.float64), k)
+        assert torch.equal(src[pos], cells[pos]) and not bool(src[~pos].any()) and not bool(dst[~pos].any())
+        assert torch.equal(dst[pos], idx[r].T.reshape(-1).double()[pos])
+        assert float(pos.double().mean()) > 0.9
+        del table, out, rows_in
