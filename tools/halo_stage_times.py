@@ -58,11 +58,10 @@ for P in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             ag["pack_ms"] = t_ms(lambda: ops.jaccard_pack_rows(table[b:e], nl, k, N, packed[b:e]))
             ops.jaccard_pack_rows(table[:N], N, k, N, packed[:N])
 
-            def unpack_others():
-                for q in range(P):
-                    if q != r:
-                        qb, qe = shard_bounds(N, P, q)
-                        ops.jaccard_unpack_rows(packed[qb:qe], qe - qb, k, N, table[qb:qe])
+            def unpack_others():                      # as dist.JaccardShard does it: the rows in front of the own block, the rows behind it
+                for lo, hi in ((0, b), (e, N)):
+                    if hi > lo:
+                        ops.jaccard_unpack_rows(packed[lo:hi], hi - lo, k, N, table[lo:hi])
             ag["unpack_ms"] = t_ms(unpack_others, 10)
         ag["edges_ms"] = t_ms(lambda: ops.jaccard_edges(table, N, k, b, e, out, None))
         ag["table_row_bytes"] = 4 * roww
