@@ -674,3 +674,84 @@ def test_configs_4_and_5_as_eight_blocks_on_local_ids(N, k):
         assert torch.equal(dst[pos], idx[r].T.reshape(-1).double()[pos])
         assert float(pos.double().mean()) > 0.9
         del table, out, rows_in
+
+
+def _emulated_halo_build(ops, mat, P, cap):
+    """All P ranks of the halo form, one after the other on this GPU; returns the full edge matrix and the rows named per rank."""
+    import torch
+
+    from gficf_amd.dist import rows_per_rank, shard_bounds
+
+    N, k = mat.shape
+    rpr = rows_per_rank(N, P)
+    blocks = [shard_bounds(N, P, r) for r in range(P)]
+    i32 = dict(dtype=torch.int32, device="cuda")
+    idx = [torch.from_numpy(np.ascontiguousarray(mat[b:e].T)).cuda() if e > b else torch.zeros((k, 0), **i32) for b, e in blocks]
+    req_out = [torch.zeros(P * cap, **i32) for _ in range(P)]
+    wss = [torch.zeros(ops.halo_workspace_bytes(N, P), dtype=torch.uint8, device="cuda") for _ in range(P)]
+    for r, (b, e) in enumerate(blocks):
+        ops.halo_plan(idx[r], e - b, k, N, b, P, rpr, cap, wss[r], req_out[r])
+    ops.sync()
+    req_in = [torch.cat([req_out[r][p * cap:(p + 1) * cap] for r in range(P)]) for p in range(P)]
+    rows_out = [torch.zeros(P * cap * k, **i32) for _ in range(P)]
+    for p, (b, e) in enumerate(blocks):
+        ops.halo_serve(idx[p], e - b, k, b, req_in[p], rows_out[p])
+    got, named = [], []
+    for r, (b, e) in enumerate(blocks):
+        nl, n_ext = e - b, e - b + P * cap
+        rows_in = torch.cat([rows_out[p][r * cap * k:(r + 1) * cap * k] for p in range(P)])
+        table = torch.zeros((n_ext, ops.row_words(n_ext, k)), **i32)
+        l2g = torch.zeros(n_ext, **i32)
+        if not ops.halo_ingest(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, table, l2g):
+            idx_ext = torch.zeros((k, n_ext), **i32)
+            ops.halo_relabel(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, idx_ext, l2g)
+            ops.jaccard_ingest_local(idx_ext, n_ext, k, table)
+        out = torch.zeros((3, nl * k), dtype=torch.float64, device="cuda")
+        ops.jaccard_edges_mapped(table, n_ext, k, nl, b, l2g, out)
+        ops.sync()
+        got.append(out.cpu().numpy())
+        named.append(int((req_out[r] != 0).sum()))
+    return np.concatenate(got, axis=1).T, named
+
+
+def test_local_id_sub_problems_fuzz():
+    """Random small cases of the halo form against the oracle: N not a multiple of the ranks, more ranks than cells (empty
+    blocks), k from 1 to beyond the fused ingest's range, rows with duplicate ids and self references, ids without any
+    locality with slots that are exactly enough, one slot too few (-> GFICF_ERR_CAPACITY)."""
+    rng = np.random.default_rng(2024)
+    ops = gficf_amd.HipOps(0)
+    for case in range(24):
+        N = int(rng.integers(1, 400))
+        k = int(rng.choice([1, 2, 7, 15, 30, 33, 64, 65, 100]))
+        P = int(rng.choice([1, 2, 3, 5, 8]))
+        mat = rng.integers(1, N + 1, size=(N, k)).astype(np.int32)        # no locality, duplicates and self references included
+        want, _ = oracle.jaccard(mat, nthreads=4)
+        got, named = _emulated_halo_build(ops, mat, P, cap=max(N, 1))
+        assert np.array_equal(got, want), (case, N, k, P)
+    # the slots exactly suffice / are one short
+    import torch
+
+    from gficf_amd.dist import rows_per_rank
+
+    N, k, P = 300, 10, 2
+    mat = rng.integers(1, N + 1, size=(N, k)).astype(np.int32)
+    _, named = _emulated_halo_build(ops, mat, P, cap=N)
+    need = max(named)
+    got, _ = _emulated_halo_build(ops, mat, P, cap=need)
+    assert np.array_equal(got, oracle.jaccard(mat)[0])
+    idx0 = torch.from_numpy(np.ascontiguousarray(mat[:150].T)).cuda() if named[0] >= named[1] else torch.from_numpy(np.ascontiguousarray(mat[150:].T)).cuda()
+    b0 = 0 if named[0] >= named[1] else 150
+    ws = torch.zeros(ops.halo_workspace_bytes(N, P), dtype=torch.uint8, device="cuda")
+    req = torch.zeros(P * (need - 1), dtype=torch.int32, device="cuda")
+    ops.halo_plan(idx0, 150, k, N, b0, P, rows_per_rank(N, P), need - 1, ws, req)
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        ops.sync()
+    assert ei.value.status == "GFICF_ERR_CAPACITY"
+
+
+def test_truncation_mode_small_and_degenerate_shapes():
+    """Strict truncation mode on the smallest shapes: one cell, k = 1, a value that truncates to the cell itself."""
+    for mat in (np.array([[1.5]]), np.array([[1.0, 1.9]]), np.array([[2.5], [1.25]]), np.array([[0.25, 2.75, 3.0], [1.5, 1.5, 2.0], [3.9, 0.9, 1.0]])):
+        want, _ = oracle.jaccard(mat)
+        got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False, truncate_noninteger_ids=True)
+        assert np.array_equal(got, want), mat
