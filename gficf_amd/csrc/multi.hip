@@ -86,7 +86,13 @@ void for_each_device(int P, FirstError& fe, const std::function<int(int)>& body)
   std::vector<FirstError> each((size_t)P);
   std::vector<std::thread> th;
   th.reserve((size_t)P);
-  for (int r = 0; r < P; ++r) th.emplace_back([&, r]() { each[(size_t)r].note(body(r)); });
+  for (int r = 0; r < P; ++r) {
+    try {
+      th.emplace_back([&, r]() { each[(size_t)r].note(body(r)); });
+    } catch (...) {                                 // no thread to be had (std::system_error must not cross the C ABI): this device's stage runs here
+      each[(size_t)r].note(body(r));
+    }
+  }
   for (auto& t : th) t.join();
   for (int r = 0; r < P && fe.rc == GFICF_OK; ++r)
     if (each[(size_t)r].rc != GFICF_OK) { fe.rc = each[(size_t)r].rc; snprintf(fe.msg, sizeof(fe.msg), "%s", each[(size_t)r].msg); }

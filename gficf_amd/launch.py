@@ -67,8 +67,19 @@ def spawn_ranks(argv: list[str], n: int, *, need_gpus: int | None = None, timeou
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
         if extra_env:
             env.update({k: str(v) for k, v in extra_env.items()})
-        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
-                                      text=(r == 0) or None))
+        try:
+            procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                          text=(r == 0) or None))
+        except OSError as ex:                                      # could not start rank r: the ranks already running would wait for it forever
+            sys.stderr.write(f"could not start rank {r}: {ex}\n")
+            for q in procs:
+                q.terminate()
+            for q in procs:
+                try:
+                    q.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    q.kill()
+            return 1
 
     def forward():                                                 # rank 0's stdout: JSON lines through, the rest to stderr
         for line in procs[0].stdout:
