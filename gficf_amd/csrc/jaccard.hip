@@ -478,7 +478,16 @@ struct EdgeOut {
   // sharded sub-problem in local ids (halo.hip): column 1 is src_off + cell + 1, column 2 l2g[local id - 1] (NULL: the id itself)
   const int32_t* l2g = nullptr;
   uint32_t src_off = 0;
+  uint32_t xcd = 1;   // workgroups renumbered so that each XCD (workgroup index mod 8) works on one contiguous run of cells
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2.  Renumbered, the workgroups of XCD x are
+// x*nb/8 ... (x+1)*nb/8 - 1: at any time an XCD then counts one contiguous run of cells, and table rows that cells next to
+// each other share (ids with locality) are found in that XCD's L2 instead of being fetched once per XCD.  Ids in order:
+// 1 M x 30 +4 %, 100 k x 30 +1.4 %, 100 k x 50 +2 %; scrambled ids: no difference (profiles/r03_xcd_renumbering.txt).
+__device__ inline uint32_t xcd_block(uint32_t b, uint32_t nb, uint32_t on) {
+  return (on && (nb & 7u) == 0) ? (b & 7u) * (nb >> 3) + (b >> 3) : b;
+}
 
 // Output modes of the edge kernel (a template parameter, so that the number of stores per cell is known to the
 // compiler: it can then wait for the row gathers alone, leaving the stores issued behind them in flight)
@@ -709,7 +718,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
     }
   };
 
-  int64_t i = cell_begin + (int64_t)blockIdx.x * C::WAVES + wave;
+  int64_t i = cell_begin + (int64_t)xcd_block(blockIdx.x, gridDim.x, o.xcd) * C::WAVES + wave;
   OwnRaw raw;
   raw.last = 0;
 #pragma unroll
@@ -1004,7 +1013,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   const bool slot_ok = lane < C::NSLOT;
 
   // the wave's cells: quads of four consecutive cells, quad q0 + m * nwaves for m = 0, 1, ...
-  const int64_t first = cell_begin + 4 * ((int64_t)blockIdx.x * C::WAVES + wave);
+  const int64_t first = cell_begin + 4 * ((int64_t)xcd_block(blockIdx.x, gridDim.x, o.xcd) * C::WAVES + wave);
   if (first >= cell_end) return;                              // (after the barrier; wave-uniform)
   const int64_t last_cell = cell_end - 1;
   const int64_t quad_step = 4 * nwaves - 3;                   // from the last cell of a quad to the first of the wave's next
@@ -1563,7 +1572,8 @@ int launch_edges_m(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
       if (rc) return rc;
       const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
       const int64_t need4 = gficf_ceil_div(gficf_ceil_div(ce - cb, 4), C::WAVES);       // a wave takes four cells at a time
-      const unsigned grid4 = (unsigned)(need4 < cap ? need4 : cap);
+      unsigned grid4 = (unsigned)(need4 < cap ? need4 : cap);
+      if (o.xcd && grid4 > 8) grid4 = (grid4 + 7u) & ~7u;       // (surplus workgroups find no cell and leave)
       if (nob16)
         hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, !CMP, MAP>), dim3(grid4), dim3(C::WAVES * 64), lds_bytes, ctx->stream,
                            table, N, k, cb, ce, o);
@@ -1578,7 +1588,8 @@ int launch_edges_m(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
   if (rc) return rc;
   const int64_t blocks_needed = gficf_ceil_div(ce - cb, C::WAVES);
   const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
-  const unsigned grid = (unsigned)(blocks_needed < cap ? blocks_needed : cap);
+  unsigned grid = (unsigned)(blocks_needed < cap ? blocks_needed : cap);
+  if (o.xcd && grid > 8) grid = (grid + 7u) & ~7u;
   hipLaunchKernelGGL((k_jaccard_edges<KPAD, BIG, CMP, OUT, MAP>), dim3(grid), dim3(C::WAVES * 64), lds_bytes, ctx->stream, table,
                      N, k, cb, ce, o);
   GFICF_HIP_CHECK(hipGetLastError());
@@ -1612,6 +1623,7 @@ int launch_edges(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_
 }
 
 int launch_edges_k(gficf_ctx* ctx, const uint32_t* t, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+  if (const char* e = getenv("GFICF_JACCARD_XCD")) o.xcd = atoi(e) != 0 ? 1u : 0u;     // A/B switch, read per call
   switch (kpad_for(k)) {
     case 16: return launch_edges<16>(ctx, t, N, k, cb, ce, o);
     case 32: return launch_edges<32>(ctx, t, N, k, cb, ce, o);
