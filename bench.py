@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--ids", choices=["permuted", "spatial"], default="permuted",
                     help="permuted: ids relabelled by a random permutation (what Annoy output looks like; the default); "
                          "spatial: cells numbered in their spatial order (what the device kNN search's pivot order gives)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed profiles/pmc_traffic.json instead of two rocprofv3 --pmc passes of this run (N = 1)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # internal: the process rocprofv3 wraps
     ap.add_argument("--exchange", choices=["auto", "allgather", "halo", "halo_generic"], default="auto",
                     help="N > 1: all-gather of every rank's table rows; halo: sub-problems in local ids, only the rows a block names travel "
                          "(fixed-capacity request slots, gficf_amd.dist.JaccardHaloShard); halo_generic: round 2's torch-side halo on global ids; "
@@ -293,8 +296,78 @@ def bench_knn(torch, ops, args):
     return res
 
 
+def traffic_child(args):
+    """What the live --pmc passes profile: one data set of the workload, ingested, four launches of the edge kernel."""
+    import torch
+
+    import gficf_amd
+    from gficf_amd import synth
+
+    N_total, k = CONFIGS[args.config] if args.config in CONFIGS else (args.cells_per_gpu, K)
+    k = args.k or k
+    ops = gficf_amd.HipOps(0)
+    m = synth.knn_windowed(N_total, k, seed=42, perm_seed=43 if args.ids == "permuted" else None)
+    idx = torch.from_numpy(np.ascontiguousarray(m.T)).cuda()
+    table = torch.zeros((N_total, ops.row_words(N_total, k)), dtype=torch.int32, device="cuda")
+    out = torch.zeros((3, N_total * k), dtype=torch.float64, device="cuda")
+    ops.jaccard_ingest(idx, N_total, k, N_total, table)
+    for _ in range(4):
+        ops.jaccard_edges(table, N_total, k, 0, N_total, out, None)
+    ops.sync()
+
+
+def live_traffic(args, kernel_name: str, timeout_s: float = 150.0):
+    """HBM-side bytes per launch of the edge kernel, measured NOW: two `rocprofv3 --pmc` passes (counters in their own runs,
+    as MI355X_MICROARCH.md's HBM section prescribes) over a child process that launches the kernel on this workload.
+    Reads: the L2's read requests to the fabric priced by their width (32 / 64 / 128 B; profiles/r03_fetch_calibration.txt: a
+    miss fills a whole 128 B line, also for a 64 B row gather); writes: WRITE_SIZE (KiB).  Returns (bytes, detail) or
+    (None, reason); never raises — the caller falls back to the committed figure."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="gficf_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--config", args.config, "--ids", args.ids,
+             "--cells-per-gpu", str(args.cells_per_gpu)] + (["--k", str(args.k)] if args.k else [])
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for tag, ctrs in (("rd", ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]), ("wr", ["WRITE_SIZE"])):
+            cmd = [exe, "--pmc"] + ctrs + ["--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, tag), "-o", "pmc", "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 pass '{tag}' exited {r.returncode}: {r.stdout[-200:]}"
+            acc = {}
+            for f in glob.glob(os.path.join(tmp, tag, "**", "pmc_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel_name + "<" in row["Kernel_Name"] or row["Kernel_Name"].split("(")[0].endswith(kernel_name):
+                        acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c in ctrs:
+                if not acc.get(c):
+                    return None, f"counter {c} missing from the '{tag}' pass"
+                vals[c] = sum(acc[c]) / len(acc[c])
+                vals["launches"] = len(acc[c])
+    except subprocess.TimeoutExpired:
+        return None, f"rocprofv3 pass timed out after {timeout_s:.0f} s"
+    except Exception as ex:                                            # a profiler that misbehaves must not cost the bench line
+        return None, f"{type(ex).__name__}: {ex}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd = 32 * vals["TCC_EA0_RDREQ_32B_sum"] + 64 * vals["TCC_EA0_RDREQ_64B_sum"] + 128 * vals["TCC_EA0_RDREQ_128B_sum"]
+    wr = 1024 * vals["WRITE_SIZE"]
+    return int(rd + wr), {"read_bytes": int(rd), "written_bytes": int(wr), "launches_profiled": vals["launches"],
+                          "read_requests": {"32B": vals["TCC_EA0_RDREQ_32B_sum"], "64B": vals["TCC_EA0_RDREQ_64B_sum"], "128B": vals["TCC_EA0_RDREQ_128B_sum"]}}
+
+
 def main():
     args = parse()
+    if args.traffic_child:
+        return traffic_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and never touches a
         # GPU itself; rank 0 prints the JSON line straight to our stdout.  (Under torch.distributed.run the rank
@@ -468,9 +541,21 @@ def main():
     # the edge kernel of this shape is k_jaccard_edges_pipe (k <= 32) or k_jaccard_edges; make_traffic.py keys by kernel name
     traffic = None if halo_form else (pmc.get(f"jaccard_edges_pipe_N{N_total}_k{k}") or pmc.get(f"jaccard_edges_N{N_total}_k{k}") or {}).get("hbm_bytes_per_launch")
     edge_kernel = "k_jaccard_edges_pipe" if (k <= 32 and not os.environ.get("GFICF_JACCARD_NO_PIPE")) else "k_jaccard_edges"   # the name rocprofv3 shows
+    traffic_source = "profiles/pmc_traffic.json (separate --pmc passes of tools/pmc_round.sh, read requests priced by their width: tools/make_traffic.py)" if traffic else None
+    traffic_detail = None
+    if world == 1 and not args.no_live_traffic and not args.no_extras:
+        # measured in THIS run (after the timed region; the child is a fresh process under rocprofv3, nothing of it is timed)
+        live, detail = live_traffic(args, edge_kernel)
+        if live is not None:
+            traffic_detail = dict(detail, committed_figure=traffic)
+            traffic = live
+            traffic_source = ("live: two rocprofv3 --pmc passes of this run over a child process launching the same kernel on the same workload "
+                              "(TCC_EA0_RDREQ_{32,64,128}B priced by width + WRITE_SIZE)")
+        else:
+            traffic_detail = {"live_failed": detail}
     roofline = {"bound": "hbm", "kernel": edge_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_copy_rate": round(achieved / HBM_COPY_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic.json (separate --pmc passes of tools/pmc_round.sh, read requests priced by their width: tools/make_traffic.py)" if traffic else None,
+                "traffic_source": traffic_source, "traffic_detail": traffic_detail,
                 # what the kernel really moves: a gathered row fills a whole 128 B line (profiles/r03_fetch_calibration.txt)
                 "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
                 "traffic_GBps": round(traffic / (t_edges_ms * 1e-3) / 1e9, 1) if traffic else None,

@@ -150,6 +150,29 @@ def test_plain_bench_command_starts_its_own_ranks():
     assert ex["rows_received_per_rank_per_data_set"] == 20000 and ex["bytes_received_per_rank_per_data_set"] > 0
 
 
+def test_bench_line_measures_the_edge_kernels_traffic_in_the_same_run():
+    """`roofline.traffic` of the N = 1 line comes from two `rocprofv3 --pmc` passes bench.py runs itself after the timed region
+    (a child process launching the same kernel on the same workload), not from a committed file: the line says so, and the bytes
+    lie between the algorithmic 28 B/edge and a few times that (a gathered row fills a whole 128 B line)."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-gficf",
+                        "--no-knn", "--batch", "2"], capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    rf = out["roofline"]
+    assert rf["traffic_source"].startswith("live"), (rf["traffic_source"], rf.get("traffic_detail"))
+    alg = rf["algorithmic_bytes_per_launch"]
+    assert alg == 28 * 100000 * 30
+    assert 1.2 * alg < rf["traffic"] < 6 * alg, rf
+    d = rf["traffic_detail"]
+    assert d["launches_profiled"] >= 4 and d["read_requests"]["128B"] > 10 * (d["read_requests"]["64B"] + d["read_requests"]["32B"])
+
+
 def _ordered_worker(rank, world, port, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
