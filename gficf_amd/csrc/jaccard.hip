@@ -191,7 +191,10 @@ __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64
 // cost 13 us at 100 k x 30) —, then the rows are packed and leave as contiguous 16 B-per-lane runs.  (Tried instead: every id
 // inserted into a small per-row hash table in LDS with ds_cmpst, one returning atomic per element in place of a compare per
 // pair of elements — 30 us against 10 at 100 k x 30: returning LDS atomics are far slower than the 186 vector instructions
-// per thread of the all-pairs scan.)
+// per thread of the all-pairs scan.  Round 3, at 64 slots where the scan is 1 225 pairs per row and holds the row in 181
+// registers: an open-addressing table of 128 words per row, every swap of a round in flight together, 94 registers — 55 us
+// against 29 at 100 k x 50; and `dup |= a == b` again, now as v_cmp_eq_u32 + s_or_b64 straight: 38 us against 29, 12.0
+// against 10.7 at 100 k x 30.  The XOR + v_min_u32 form stays.)
 template <int KPAD, int W>
 __device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD], int k) {
   uint32_t m = 0xFFFFFFFFu;                 // min over this part's pairs (j, j2 < j), j = W, W + 4, ...
