@@ -14,6 +14,11 @@
 // The sub-problem has n_local + P * cap rows: below 2^17 it takes the compact 64 B-row table and the fast edge kernel whatever
 // N_total is (the all-gather form falls back to 128 B rows from 2^17 cells on).  Kernels here are O(n_local * k) elementwise /
 // small scans; the edge build is jaccard.hip's, with the map applied where the edges are written.
+// (The plan as ONE launch — every marking workgroup draws a ticket, the last one ranks the words and lists the bits alone — was
+// built and measured at the end of round 3: bit-identical, 180-210 us with an agent-scope fence per workgroup (each one writes
+// the XCD's L2 back), 44-78 us without fences (s_waitcnt + agent-scope loads of the bitmap) against the 14-20 us of the fill +
+// three launches below: what the plan costs is its chain of dependent memory round trips, which one workgroup on one CU walks
+// more slowly than three small grids do, not the launches.)
 #include "common.h"
 #include "halo_map.h"
 

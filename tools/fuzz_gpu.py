@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Randomised parity run of the HIP path against the oracle, longer than the test suite allows (minutes, not seconds).
+
+Jaccard: random shapes (N 1 .. 6000, now and then 131 000 .. 180 000 for the wide-row table; k 1 .. 256), five kinds of index
+matrix (windowed scrambled / windowed in order / uniform / few distinct ids = rows full of duplicates and self-references /
+a window of 2), int32 or float64 input, through every entry that returns edges: the `.Call` entry (reference matrix), the
+compact counts + host expansion, the filtered call-site form, the serial `jaccard_coeff` entry, the device-resident path
+with counts, and the strict truncation mode on matrices with non-integer doubles.  Bit-exact or the run stops.
+GF-ICF: random CSC matrices (G 1 .. 30 000, N 1 .. 3000; densities; empty cells, empty genes, explicit zeros, cells beyond
+2048 entries), random filter bounds, supplied weights, icf types and norms; structure exact, values within 1e-12 (gficf() as the
+reference runs it) / 1e-11 relative (the prob / smooth / l1 helper branches, whose sums can nearly cancel).
+Usage: python tools/fuzz_gpu.py [seconds] [seed] [out.txt]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import scipy.sparse as sp
+
+import gficf_amd
+import oracle
+from gficf_amd import synth
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+out_path = sys.argv[3] if len(sys.argv) > 3 else None
+rng = np.random.default_rng(seed0)
+NT = os.cpu_count() or 8
+counts = {}
+
+
+def bump(name):
+    counts[name] = counts.get(name, 0) + 1
+
+
+def knn_matrix(case):
+    big = rng.random() < 0.04
+    k = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 29, 30, 31, 32, 33, 50, 60, 61, 64, 65, 100, 120, 128, 129, 200, 255, 256])) if rng.random() < 0.6 \
+        else int(rng.integers(1, 257))
+    if big:
+        k = min(k, 64)
+        N = int(rng.integers(131_000, 180_000))
+    else:
+        N = int(rng.integers(max(k + 2, 3), 6000)) if rng.random() < 0.9 else int(rng.integers(1, 40))
+    kind = int(rng.integers(0, 5))
+    if N <= 2 * k + 2 and kind in (0, 1):
+        kind = 3
+    if kind == 0:
+        m = synth.knn_windowed(N, k, W=max(100, k), seed=case, perm_seed=case + 1)
+    elif kind == 1:
+        m = synth.knn_windowed(N, k, W=max(100, k), seed=case, perm_seed=None)
+    elif kind == 2 and N - 1 >= k:
+        m = synth.knn_uniform(N, k, seed=case)
+    elif kind == 4 and N > 2 * k + 2:
+        m = synth.knn_windowed(N, k, W=max((k + 1) // 2, 1), seed=case, perm_seed=case + 1)     # the tightest window: every row almost the same set
+    else:                                                           # few distinct ids: duplicates inside rows, self-references
+        distinct = int(rng.integers(1, max(2, min(N, 3 * k)) + 1))
+        m = (synth.rand_u64(case, np.arange(N * k)).reshape(N, k) % np.uint64(distinct)).astype(np.int32) + 1
+        kind = 3
+    if rng.random() < 0.15 and N > 4:                               # a few duplicate ids planted into otherwise clean rows
+        for _ in range(int(rng.integers(1, 6))):
+            r = int(rng.integers(0, N))
+            a, b = int(rng.integers(0, k)), int(rng.integers(0, k))
+            m[r, a] = m[r, b]
+    return m, N, k, kind, big
+
+
+def jaccard_case(case):
+    m, N, k, kind, big = knn_matrix(case)
+    want, wu = oracle.jaccard(m, nthreads=NT)
+    as_f64 = rng.random() < 0.3
+    mat = m.astype(np.float64) if as_f64 else m
+    entry = int(rng.integers(0, 6)) if not big else int(rng.integers(0, 3))
+    tag = f"jaccard case {case}: N={N} k={k} kind={kind} f64={as_f64} entry={entry}"
+    if entry == 0:
+        got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
+        assert np.array_equal(got, want), tag
+        bump("jaccard .Call entry")
+    elif entry == 1:
+        u = gficf_amd.jaccard_counts(mat)
+        assert np.array_equal(u.astype(np.int32).reshape(-1), wu), tag
+        assert np.array_equal(gficf_amd.jaccard_expand(mat, u), want), tag
+        bump("jaccard counts + expand")
+    elif entry == 2:
+        neigh = np.concatenate([np.arange(1, N + 1, dtype=mat.dtype)[:, None], mat], axis=1)
+        e = gficf_amd.jaccard_edges(neigh, False)
+        keep = want[:, 2] > 0
+        assert np.array_equal(e["from"], want[keep, 0]) and np.array_equal(e["to"], want[keep, 1]) and np.array_equal(e["weight"], want[keep, 2]), tag
+        bump("jaccard filtered call-site")
+    elif entry == 3:
+        got = gficf_amd.jaccard_coeff(mat, False)
+        assert np.array_equal(got, oracle.jaccard_coeff(m)), tag
+        bump("jaccard_coeff (serial entry)")
+    elif entry == 4:
+        import torch
+
+        ops = gficf_amd.HipOps(0)
+        idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
+        table = torch.empty((N, ops.kpad(k)), dtype=torch.int32, device="cuda")
+        rmat = torch.full((3, N * k), -7.0, dtype=torch.float64, device="cuda")
+        u = torch.full((N * k,), -7, dtype=torch.int32, device="cuda")
+        ops.jaccard(idx, N, k, table, rmat, u)
+        ops.sync()
+        assert np.array_equal(rmat.cpu().numpy().T, want) and np.array_equal(u.cpu().numpy(), wu), tag
+        bump("jaccard device-resident with counts")
+    else:
+        md = m.astype(np.float64)
+        frac = synth.rand_unit(case + 9, np.arange(N * k)).reshape(N, k)
+        sel = synth.rand_unit(case + 10, np.arange(N * k)).reshape(N, k) < 0.2
+        md = np.where(sel, np.minimum(md + 0.9 * frac, N + 0.999), md)
+        wt, _ = oracle.jaccard(md, nthreads=NT)
+        got = gficf_amd.rcpp_parallel_jaccard_coef(md, False, truncate_noninteger_ids=True)
+        assert np.array_equal(got, wt), tag
+        bump("jaccard strict truncation mode")
+
+
+def gficf_case(case):
+    G = int(rng.choice([1, 2, 50, 600, 5000, 20000, 30000])) if rng.random() < 0.5 else int(rng.integers(1, 30001))
+    N = int(rng.integers(1, 3001)) if rng.random() < 0.9 else int(rng.integers(1, 12))
+    mf = float(rng.choice([0.002, 0.02, 0.07, 0.3]))
+    if G * mf * N > 6e6:
+        mf = 6e6 / (G * N)
+    sg = float(rng.choice([0.3, 0.5, 1.2]))
+    cp, ri, x = synth.counts_csc(G, N, median_frac=mf, sigma=sg, seed=case)
+    x = x.copy()
+    zeros = rng.random() < 0.25
+    if zeros and len(x):                                             # explicit zeros: the exact sequence must take over
+        z = rng.integers(0, len(x), size=max(1, len(x) // 50))
+        x[z] = 0.0
+    if rng.random() < 0.3 and N > 3:                                 # empty cells
+        M = sp.csc_matrix((x, ri, cp), shape=(G, N)).tolil()
+        for c in rng.integers(0, N, size=max(1, N // 20)):
+            M[:, int(c)] = 0
+        M = M.tocsc()
+        if not zeros:
+            M.eliminate_zeros()
+        M.sort_indices()
+        cp, ri, x = M.indptr.astype(np.int64), M.indices.astype(np.int32), M.data.astype(np.float64)
+    mn = float(rng.choice([0.0, 0.01, 0.05, 0.2]))
+    mx = float(rng.choice([1.0, 1.0, 0.9, 0.5]))
+    M = sp.csc_matrix((x, ri, cp), shape=(G, N))
+    tag = f"gficf case {case}: G={G} N={N} nnz={len(x)} zeros={zeros} min={mn} max={mx} median_frac={mf} sigma={sg}"
+    mode = int(rng.integers(0, 3))
+    if mode == 0:
+        res = gficf_amd.gficf(M, cell_proportion_max=mx, cell_proportion_min=mn, normalize=False, verbose=False)
+        ref = oracle.gficf_csc(G, N, cp, ri, x, mn, mx)
+        keep = ref["keep"]
+        g = res["gficf"]
+        assert np.array_equal(res["genes"], np.flatnonzero(keep)) and np.array_equal(res["nt"], ref["nt"][keep]), tag
+        assert np.array_equal(g.indptr, ref["colptr"]) and np.array_equal(g.indices, ref["rowidx"]), tag
+        assert np.abs(g.data - ref["x"]).max(initial=0.0) < 1e-12 and np.allclose(res["w"], ref["w"][keep], rtol=1e-12, atol=1e-12), tag
+        bump("gficf()")
+    elif mode == 1:
+        w_in = 0.25 + synth.rand_unit(case + 3, np.arange(G))
+        out, genes = gficf_amd.gficf_with_weights(M, w_in)
+        ref = oracle.gficf_csc(G, N, cp, ri, x, 0.0, 2.0, w_in=w_in)
+        assert np.array_equal(genes, np.flatnonzero(ref["keep"])), tag
+        assert np.array_equal(out.indices, ref["rowidx"]) and np.array_equal(out.indptr, ref["colptr"]), tag
+        assert np.abs(out.data - ref["x"]).max(initial=0.0) < 1e-12, tag
+        bump("gficf with supplied weights")
+    else:
+        icf = str(rng.choice(["classic", "prob", "smooth"]))
+        norm = str(rng.choice(["l2", "l1"]))
+        res = gficf_amd.gficf(M, cell_proportion_max=mx, cell_proportion_min=mn, normalize=False, verbose=False, icf_type=icf, norm=norm)
+        ref = oracle.gficf_csc(G, N, cp, ri, x, mn, mx, None, icf, norm)
+        g = res["gficf"]
+        assert np.array_equal(g.indptr, ref["colptr"]) and np.array_equal(g.indices, ref["rowidx"]), tag
+        fin = np.isfinite(ref["x"])
+        tag += f" icf={icf} norm={norm}"
+        if not np.array_equal(np.isfinite(g.data), fin):
+            bad = np.flatnonzero(np.isfinite(g.data) != fin)
+            raise AssertionError(tag + f": finiteness differs at {bad[:5]}: got {g.data[bad[:5]]} want {ref['x'][bad[:5]]}")
+        d = np.abs(g.data[fin] - ref["x"][fin]) / np.maximum(1.0, np.abs(ref["x"][fin]))   # prob weights + l1 norm: sums that nearly cancel, values of 1e2 and more
+        if d.max(initial=0.0) >= 1e-11:
+            i = int(np.argmax(d))
+            raise AssertionError(tag + f": max diff {d.max()} at {i}: got {g.data[fin][i]} want {ref['x'][fin][i]}")
+        bump(f"gficf icf/norm variants")
+
+
+t0 = time.time()
+case = seed0 * 1_000_000
+n = 0
+last = t0
+while time.time() - t0 < budget:
+    if n % 3 == 2:
+        gficf_case(case)
+    else:
+        jaccard_case(case)
+    case += 1
+    n += 1
+    if time.time() - last > 60:
+        print(f"... {n} cases, {time.time() - t0:.0f} s", flush=True)
+        last = time.time()
+lines = [f"tools/fuzz_gpu.py: {n} random cases in {time.time() - t0:.0f} s (seed {seed0}), every one equal to the oracle"]
+lines += [f"  {v:6d}  {k}" for k, v in sorted(counts.items())]
+print("\n".join(lines))
+if out_path:
+    open(out_path, "w").write("\n".join(lines) + "\n")
