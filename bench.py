@@ -328,6 +328,8 @@ def live_traffic(args, kernel_name: str, timeout_s: float = 150.0):
     import subprocess
     import tempfile
 
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler (no profiler inside a profiler)"
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
