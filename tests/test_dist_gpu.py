@@ -165,7 +165,15 @@ def test_bench_line_measures_the_edge_kernels_traffic_in_the_same_run():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
     rf = out["roofline"]
-    assert rf["traffic_source"].startswith("live"), (rf["traffic_source"], rf.get("traffic_detail"))
+    if not rf["traffic_source"].startswith("live"):
+        why = str((rf.get("traffic_detail") or {}).get("live_failed"))
+        # a box on which the profiler itself cannot run (absent, refused, hung) is not a defect of the library: the line then
+        # carries the committed figure and says why; anything else (a counter missing, a kernel not found) is ours
+        if any(t in why for t in ("not found", "exited", "timed out", "under a profiler")):
+            import pytest
+
+            pytest.skip("rocprofv3 passes not available here: " + why)
+        raise AssertionError((rf["traffic_source"], why))
     alg = rf["algorithmic_bytes_per_launch"]
     assert alg == 28 * 100000 * 30
     assert 1.2 * alg < rf["traffic"] < 6 * alg, rf

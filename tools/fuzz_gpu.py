@@ -8,7 +8,10 @@ compact counts + host expansion, the filtered call-site form, the serial `jaccar
 with counts, and the strict truncation mode on matrices with non-integer doubles.  Bit-exact or the run stops.
 GF-ICF: random CSC matrices (G 1 .. 30 000, N 1 .. 3000; densities; empty cells, empty genes, explicit zeros, cells beyond
 2048 entries), random filter bounds, supplied weights, icf types and norms; structure exact, values within 1e-12 (gficf() as the
-reference runs it) / 1e-11 relative (the prob / smooth / l1 helper branches, whose sums can nearly cancel).
+reference runs it) / 1e-11 relative x the cell's condition number (the prob / smooth / l1 helper branches: an l1 sum over
+weights of both signs can nearly cancel).
+Every fourth case is one of the rows either side of the path (§8f): exact kNN (four metrics, plain and pruned form) against
+the f32 oracle bit for bit, the adjacency matrix against scipy, cluster signatures and the transpose against restatements.
 Usage: python tools/fuzz_gpu.py [seconds] [seed] [out.txt]"""
 import os
 import sys
@@ -55,7 +58,7 @@ def knn_matrix(case):
     elif kind == 4 and N > 2 * k + 2:
         m = synth.knn_windowed(N, k, W=max((k + 1) // 2, 1), seed=case, perm_seed=case + 1)     # the tightest window: every row almost the same set
     else:                                                           # few distinct ids: duplicates inside rows, self-references
-        distinct = int(rng.integers(1, max(2, min(N, 3 * k)) + 1))
+        distinct = int(rng.integers(1, max(1, min(N, 3 * k)) + 1))     # (ids must stay within [1, N])
         m = (synth.rand_u64(case, np.arange(N * k)).reshape(N, k) % np.uint64(distinct)).astype(np.int32) + 1
         kind = 3
     if rng.random() < 0.15 and N > 4:                               # a few duplicate ids planted into otherwise clean rows
@@ -171,11 +174,85 @@ def gficf_case(case):
         if not np.array_equal(np.isfinite(g.data), fin):
             bad = np.flatnonzero(np.isfinite(g.data) != fin)
             raise AssertionError(tag + f": finiteness differs at {bad[:5]}: got {g.data[bad[:5]]} want {ref['x'][bad[:5]]}")
-        d = np.abs(g.data[fin] - ref["x"][fin]) / np.maximum(1.0, np.abs(ref["x"][fin]))   # prob weights + l1 norm: sums that nearly cancel, values of 1e2 and more
+        # l1 norm with prob weights (negative ones among them): the cell's sum can nearly cancel, and the result is then as
+        # ill-conditioned for the reference as for anyone — the bound grows with the cell's condition number sum|v| / |sum v|
+        cond = np.ones(len(ref["x"]))
+        if norm == "l1":
+            cellof = np.repeat(np.arange(N), np.diff(ref["colptr"]))
+            v = ref["x"]                                            # v / sum(v): recover sum|.| / |sum .| of the unnormalised values
+            sabs = np.bincount(cellof, weights=np.abs(np.where(np.isfinite(v), v, 0.0)), minlength=N)
+            ssum = np.abs(np.bincount(cellof, weights=np.where(np.isfinite(v), v, 0.0), minlength=N))
+            cond = np.maximum(1.0, (sabs / np.maximum(ssum, 1e-300)))[cellof]
+        d = np.abs(g.data[fin] - ref["x"][fin]) / (np.maximum(1.0, np.abs(ref["x"][fin])) * cond[fin])
         if d.max(initial=0.0) >= 1e-11:
             i = int(np.argmax(d))
-            raise AssertionError(tag + f": max diff {d.max()} at {i}: got {g.data[fin][i]} want {ref['x'][fin][i]}")
+            raise AssertionError(tag + f": max scaled diff {d.max()} at {i}: got {g.data[fin][i]} want {ref['x'][fin][i]} cond {cond[fin][i]}")
         bump(f"gficf icf/norm variants")
+
+
+def next_rows_case(case):
+    """The rows either side of the path: exact kNN against the f32 oracle, adjacency against scipy,
+    cluster signatures and the transpose against numpy / scipy restatements."""
+    which = int(rng.integers(0, 4))
+    if which == 0:
+        from oracle import oracle_np  # noqa: F401  (restatements live next to the oracle)
+
+        N = int(rng.integers(2, 3000)); d = int(rng.choice([1, 2, 3, 7, 20, 50, 64, 100, 128])); k = int(min(N, rng.choice([1, 2, 5, 16, 31, 33, 51, 64, 100, 128])))
+        metric = str(rng.choice(["manhattan", "euclidean", "cosine", "correlation"]))
+        if metric == "correlation" and d < 2:
+            metric = "euclidean"
+        r2 = np.random.default_rng(case)
+        c = r2.normal(scale=6.0, size=(8, d)); lab = r2.integers(0, 8, size=N)
+        X = c[lab] + r2.normal(size=(N, d)) * r2.uniform(0.5, 2.0, size=(8, 1))[lab]
+        if rng.random() < 0.3:
+            os.environ["GFICF_KNN_PRUNE"] = "1"                     # the pruned form on small inputs too
+        else:
+            os.environ.pop("GFICF_KNN_PRUNE", None)
+        tag = f"knn case {case}: N={N} d={d} k={k} {metric} prune={'GFICF_KNN_PRUNE' in os.environ}"
+        got = gficf_amd.find_nn(X, k, True, metric)
+        widx, wdist = oracle.knn(X, k, metric, nthreads=NT)
+        os.environ.pop("GFICF_KNN_PRUNE", None)
+        assert np.array_equal(got["idx"], widx), tag
+        assert np.array_equal(got["dist"].astype(np.float32), wdist.astype(np.float32)), tag
+        bump("kNN (N2)")
+    elif which == 1:
+        N = int(rng.integers(1, 5000)); E = int(rng.integers(0, 40000))
+        r2 = np.random.default_rng(case)
+        f = r2.integers(1, N + 1, size=E).astype(np.float64); t = r2.integers(1, N + 1, size=E).astype(np.float64)
+        w = r2.integers(1, 60, size=E) / 64.0                         # exactly representable: sums are exact in any order
+        A = gficf_amd.jaccard_adjacency({"from": f, "to": t, "weight": w}, N)
+        i, j = f.astype(np.int64) - 1, t.astype(np.int64) - 1
+        W = sp.coo_matrix((w, (i, j)), shape=(N, N)).tocsc()          # igraph's undirected graph: A = W + W^T, a self edge once
+        R = (W + W.T - sp.diags(W.diagonal())).tocsc()
+        R.sum_duplicates(); R.sort_indices()
+        assert A.shape == R.shape and np.array_equal(A.indptr, R.indptr) and np.array_equal(A.indices, R.indices) and np.array_equal(A.data, R.data), \
+            f"adjacency case {case}: N={N} E={E}"
+        bump("adjacency (N1)")
+    else:
+        G = int(rng.integers(1, 20000)); N = int(rng.integers(1, 2500))
+        mf = float(rng.choice([0.005, 0.02, 0.07]))
+        if G * mf * N > 4e6:
+            mf = 4e6 / (G * N)
+        cp, ri, x = synth.counts_csc(G, N, median_frac=mf, seed=case)
+        if which == 2:
+            C = int(rng.integers(1, min(N, 300) + 1))
+            M = sp.csc_matrix((x * 0.25, ri, cp), shape=(G, N))
+            lab = (synth.rand_u64(case, np.arange(N)) % np.uint64(C)).astype(np.int64)
+            got, labels = gficf_amd.cluster_signatures(M, lab)
+            onehot = sp.csr_matrix((np.ones(N), (np.arange(N), np.unique(lab, return_inverse=True)[1])), shape=(N, len(np.unique(lab))))
+            want = np.asarray((M @ onehot).todense())
+            col_of = {u: jj for jj, u in enumerate(np.unique(lab))}
+            want = want[:, [col_of[u] for u in labels]]
+            assert got.shape == want.shape and np.allclose(got, want, rtol=1e-9, atol=1e-9), f"signatures case {case}: G={G} N={N} C={C}"
+            bump("cluster signatures (N3)")
+        else:
+            x = x.copy(); x[::17] = 0.0
+            M = sp.csc_matrix((x, ri, cp), shape=(G, N))
+            T = gficf_amd.transpose_gficf(M)
+            S = M.T.tocsc(); S.sort_indices()
+            assert T.shape == (N, G) and np.array_equal(T.indptr, S.indptr) and np.array_equal(T.indices, S.indices) and np.array_equal(T.data, S.data), \
+                f"transpose case {case}: G={G} N={N}"
+            bump("transpose (N3)")
 
 
 t0 = time.time()
@@ -183,8 +260,10 @@ case = seed0 * 1_000_000
 n = 0
 last = t0
 while time.time() - t0 < budget:
-    if n % 3 == 2:
+    if n % 4 == 2:
         gficf_case(case)
+    elif n % 4 == 3:
+        next_rows_case(case)
     else:
         jaccard_case(case)
     case += 1
