@@ -316,7 +316,7 @@ def traffic_child(args):
     ops.sync()
 
 
-def live_traffic(args, kernel_name: str, timeout_s: float = 150.0):
+def live_traffic(args, kernel_name: str, timeout_s: float = 90.0):
     """HBM-side bytes per launch of the edge kernel, measured NOW: two `rocprofv3 --pmc` passes (counters in their own runs,
     as MI355X_MICROARCH.md's HBM section prescribes) over a child process that launches the kernel on this workload.
     Reads: the L2's read requests to the fabric priced by their width (32 / 64 / 128 B; profiles/r03_fetch_calibration.txt: a
@@ -341,9 +341,21 @@ def live_traffic(args, kernel_name: str, timeout_s: float = 150.0):
     try:
         for tag, ctrs in (("rd", ["TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]), ("wr", ["WRITE_SIZE"])):
             cmd = [exe, "--pmc"] + ctrs + ["--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, tag), "-o", "pmc", "--"] + child
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
-            if r.returncode != 0:
-                return None, f"rocprofv3 pass '{tag}' exited {r.returncode}: {r.stdout[-200:]}"
+            # own session: on a timeout the profiler AND the process it wraps are ended, by process group (exact ids, no patterns)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+            try:
+                out_txt, _ = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.communicate()
+                raise
+            if pr.returncode != 0:
+                return None, f"rocprofv3 pass '{tag}' exited {pr.returncode}: {out_txt[-200:]}"
             acc = {}
             for f in glob.glob(os.path.join(tmp, tag, "**", "pmc_counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
