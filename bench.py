@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--ids", choices=["permuted", "spatial"], default="permuted",
                     help="permuted: ids relabelled by a random permutation (what Annoy output looks like; the default); "
                          "spatial: cells numbered in their spatial order (what the device kNN search's pivot order gives)")
+    ap.add_argument("--scan-dups", action="store_true",
+                    help="N = 1: the ingest looks for duplicate ids inside a row itself (all-pairs scan) instead of leaving it to the edge kernel's "
+                         "hash-set build + a deferred error (gficf_ctx_set_jaccard_distinct, what the host entries do)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from the committed profiles/pmc_traffic.json instead of two rocprofv3 --pmc passes of this run (N = 1)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # internal: the process rocprofv3 wraps
@@ -485,6 +488,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # One context, all cells: rows are taken to hold distinct ids, as the library's host entries take them — the ingest does not
+    # scan every row for a repeated id; the edge kernel meets one while it builds the row's hash set and raises a deferred
+    # GFICF_ERR_DUPLICATE_IDS (surfaced by the sync behind the timed region; the exact sequence would then be re-run).  A sharded
+    # build (N > 1) keeps the scan: a rank never inserts the rows of another rank's cells.
+    distinct = world == 1 and not args.scan_dups
+    if distinct:
+        ops.set_jaccard_distinct(True)
     for _ in range(args.warmup):
         step()
     fence()
@@ -541,6 +551,10 @@ def main():
 
     t_edges_b2b_ms = time_kernel_ms(torch, one_edges, max(args.steps * batch, 40))
     t_ingest_ms = time_kernel_ms(torch, one_ingest, max(args.steps * batch, 40))
+    t_ingest_scan_ms = t_ingest_ms
+    if distinct:                                                    # the scanning ingest next to it, and the option off for everything below
+        ops.set_jaccard_distinct(False)
+        t_ingest_scan_ms = time_kernel_ms(torch, one_ingest, max(args.steps * batch, 40))
     alg_bytes = JACCARD_BYTES_PER_EDGE * n_local * k
     achieved = alg_bytes / (t_edges_ms * 1e-3) / 1e9
     # HBM-side bytes per launch from the committed PMC passes (tools/pmc.sh + tools/make_traffic.py; FETCH_SIZE
@@ -575,7 +589,7 @@ def main():
                 "traffic_GBps": round(traffic / (t_edges_ms * 1e-3) / 1e9, 1) if traffic else None,
                 "traffic_frac_of_copy_rate": round(traffic / (t_edges_ms * 1e-3) / 1e9 / HBM_COPY_GBS, 4) if traffic else None,
                 "kernel_ms": round(t_edges_ms, 5), "kernel_ms_back_to_back": round(t_edges_b2b_ms, 5),
-                "ingest_kernel_ms": round(t_ingest_ms, 5),
+                "ingest_kernel_ms": round(t_ingest_ms, 5), "ingest_kernel_ms_with_duplicate_scan": round(t_ingest_scan_ms, 5),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "row_bytes": 4 * (shards[0].row_words if halo_form else ops.row_words(N_total, k)),
                 "note": "kernel_ms: mean of HIP-event pairs around every edge-kernel launch of a second run of the K steps "
@@ -593,7 +607,9 @@ def main():
                                ("ingest + edge kernel" if world == 1 else
                                 "halo plan + 2 all-to-alls (request slots, rows) + relabel + ingest + edge kernel on local ids" if halo_form else
                                 "ingest + RCCL all-gather of table rows + edge kernel") +
-                               ", device-resident, one stream, in order (no overlap between data sets or steps)",
+                               ", device-resident, one stream, in order (no overlap between data sets or steps)" +
+                               ("; rows taken to hold distinct ids: no duplicate scan in the ingest, the edge kernel's hash-set build reports a "
+                                "repeated id (deferred GFICF_ERR_DUPLICATE_IDS, exact re-run) — what the host entries do" if distinct else ""),
                    "cells_total": N_total, "k": k, "data_sets_per_step": batch, "edges_per_step": edges_per_step,
                    "partition": f"cell blocks x{world}" + ("" if world == 1 else f", exchange: {exchange}")},
         "timed_region_ms": round(region_ms, 4),

@@ -16,7 +16,7 @@ GFICF_OK = 0
 STATUS_NAMES = {
     0: "GFICF_OK", 1: "GFICF_ERR_INVALID_ARG", 2: "GFICF_ERR_BAD_ID", 3: "GFICF_ERR_BAD_CSC",
     4: "GFICF_ERR_NO_DEVICE", 5: "GFICF_ERR_HIP", 6: "GFICF_ERR_UNSUPPORTED", 7: "GFICF_ERR_CAPACITY",
-    8: "GFICF_ERR_BAD_VALUE", 9: "GFICF_ERR_EXPLICIT_ZEROS",
+    8: "GFICF_ERR_BAD_VALUE", 9: "GFICF_ERR_EXPLICIT_ZEROS", 10: "GFICF_ERR_DUPLICATE_IDS",
 }
 JACCARD_MAX_K = 256
 KNN_MAX_K = 128
@@ -45,6 +45,7 @@ SIGNATURES = {
     "gficf_ctx_set_gficf_options": (_int, [_vp, _int, _int]),
     "gficf_ctx_set_louvain_options": (_int, [_vp, _int]),
     "gficf_ctx_set_jaccard_options": (_int, [_vp, _int]),
+    "gficf_ctx_set_jaccard_distinct": (_int, [_vp, _int]),
     "gficf_last_error": (ctypes.c_char_p, []),
     "gficf_ctx_set_print": (_int, [_vp, _vp]),
     "gficf_ctx_trim": (_int, [_vp]),

@@ -48,6 +48,13 @@ class Context:
         """Wait for the stream; raises GficfError for deferred input-validation failures."""
         check(_lib.load().gficf_ctx_sync(self.handle))
 
+    def set_jaccard_distinct(self, assume_distinct: bool):
+        """Rows of the kNN index matrix are taken to hold distinct ids (what every kNN search returns): the ingest skips its
+        all-pairs duplicate scan and the edge kernel raises a deferred ``GFICF_ERR_DUPLICATE_IDS`` at the next :meth:`sync` if
+        a row does repeat an id — discard the edges then and re-run ingest + edges with the option off.  Only for the
+        single-context sequence over all cells (``gficf_ctx_set_jaccard_distinct``); the host entries do this by themselves."""
+        check(_lib.load().gficf_ctx_set_jaccard_distinct(self.handle, 1 if assume_distinct else 0))
+
     def close(self):
         if self._h:
             _lib.load().gficf_ctx_destroy(self._h)
@@ -655,6 +662,10 @@ class HipOps:
     def sync(self):
         self._bind()
         self.ctx.sync()
+
+    def set_jaccard_distinct(self, assume_distinct: bool):
+        """See :meth:`Context.set_jaccard_distinct` (the option belongs to the context these ops enqueue on)."""
+        self.ctx.set_jaccard_distinct(assume_distinct)
 
     # -- Jaccard
     @staticmethod

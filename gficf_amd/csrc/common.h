@@ -15,6 +15,7 @@ constexpr uint32_t GFICF_ST_BAD_CSC = 2u;   // rowidx outside [0, G) / colptr no
 constexpr uint32_t GFICF_ST_BAD_VALUE = 4u; // non-finite coordinate handed to the kNN search / bad edge weight
 constexpr uint32_t GFICF_ST_TOO_DENSE = 8u; // Louvain: a vertex touches more communities than its table holds
 constexpr uint32_t GFICF_ST_EXPLICIT_ZERO = 16u; // gficf_csc_device met an explicitly stored zero (its fast count is then not exact)
+constexpr uint32_t GFICF_ST_DUP_IDS = 64u;       // Jaccard, rows taken to hold distinct ids (gficf_ctx_set_jaccard_distinct): the edge kernel met one that does not
 constexpr uint32_t GFICF_ST_HALO_OVERFLOW = 32u; // sharded Jaccard, halo form: a block names more rows of one owner than the request slots hold
 
 constexpr int GFICF_POOL_SLOTS = 9;
@@ -45,6 +46,10 @@ struct gficf_ctx {
   int lv_modularity_fn = 1;
   // gficf_ctx_set_jaccard_options: non-integer double ids are truncated as the reference does (src/rcpp_parallel_jaccard_coeff.cpp:28)
   int jaccard_trunc = 0;
+  // gficf_ctx_set_jaccard_distinct: the ingest does not look for duplicate ids inside a row; the edge kernel, which meets every
+  // one while it builds the row's hash set, raises GFICF_ST_DUP_IDS instead (deferred; the caller re-runs with the option off)
+  int jaccard_assume_distinct = 0;
+  int quiet_rerun = 0;               // a host entry re-runs its sequence after GFICF_ERR_DUPLICATE_IDS: banners are not printed again
   gficf_host_plan* plan = nullptr;
   gficf_edge_plan* edge_plan = nullptr;
   gficf_adj_plan* adj_plan = nullptr;

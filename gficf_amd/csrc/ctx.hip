@@ -179,6 +179,12 @@ int gficf_ctx_set_jaccard_options(gficf_ctx* ctx, int truncate_noninteger_ids) {
   return GFICF_OK;
 }
 
+int gficf_ctx_set_jaccard_distinct(gficf_ctx* ctx, int assume_distinct) {
+  if (!ctx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ctx is NULL");
+  ctx->jaccard_assume_distinct = assume_distinct ? 1 : 0;
+  return GFICF_OK;
+}
+
 int gficf_ctx_sync(gficf_ctx* ctx) {
   GFICF_CTX_ENTER(ctx);
   GFICF_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -191,6 +197,9 @@ int gficf_ctx_sync(gficf_ctx* ctx) {
     GFICF_FAIL(GFICF_ERR_BAD_VALUE, "a non-finite kNN coordinate, or an edge weight that is negative / not finite");
   if (st & GFICF_ST_BAD_CSC)
     GFICF_FAIL(GFICF_ERR_BAD_CSC, "CSC matrix malformed: row index outside [0, G) or colptr not monotone");
+  if (st & GFICF_ST_DUP_IDS)
+    GFICF_FAIL(GFICF_ERR_DUPLICATE_IDS, "a row of the kNN index matrix names an id twice and the context was told rows hold distinct ids "
+                                        "(gficf_ctx_set_jaccard_distinct): discard the edges and re-run ingest + edges with the option off");
   if (st & GFICF_ST_EXPLICIT_ZERO)
     GFICF_FAIL(GFICF_ERR_EXPLICIT_ZEROS, "the CSC matrix stores explicit zeros, which gficf_csc_device's count of stored entries takes for "
                                          "non-zero cells (rowSums(M != 0), reference R/gficf.R:40,88): call gficf_csc_exact_device");

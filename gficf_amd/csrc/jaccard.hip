@@ -133,7 +133,7 @@ constexpr int INGEST_ROWS = 64;
 template <typename T, int KPAD, bool CMP>
 __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                 int64_t N_total, uint32_t* __restrict__ table,
-                                                uint32_t* __restrict__ status, int zero_ok) {
+                                                uint32_t* __restrict__ status, int zero_ok, int scan) {
   __shared__ uint32_t tile[INGEST_ROWS][KPAD + 1];
   __shared__ uint32_t dup[INGEST_ROWS];
   constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64
     __syncthreads();
     // duplicate ids inside a row (multiset case): thread (row = lane, part = wave)
     bool d = false;
-    for (int j = wave; j < k; j += 4) {
+    for (int j = wave; scan && j < k; j += 4) {
       const uint32_t a = tile[lane][j];
       if (a != 0)
         for (int j2 = 0; j2 < j; ++j2) d |= (tile[lane][j2] == a);
@@ -215,7 +215,9 @@ __device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD], int k) {
 // HALO (int32 ids only): the rows of a sharded sub-problem (csrc/halo.hip) read straight from the block's global ids — own cells
 // from idx, halo slots from the reply slots — and mapped to local ids on the fly (the unfused form writes the mapped index
 // matrix first: one more kernel and 2 x 16 MB of traffic per step at 100 k cells); also writes the local -> global map.
-template <typename T, int KPAD, bool CMP, bool HALO = false>
+// SCAN = false (gficf_ctx_set_jaccard_distinct): rows are taken to hold distinct ids and no flag is written; the edge kernel
+// finds a repeated id when it inserts the row into its hash set and raises a deferred error.
+template <typename T, int KPAD, bool CMP, bool HALO = false, bool SCAN = true>
 __global__ __launch_bounds__(256, HALO ? 4 : 1) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                      int64_t N_total, uint32_t* __restrict__ table,
                                                      uint32_t* __restrict__ status, int zero_ok, const gficf_halo_map hm) {
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256, HALO ? 4 : 1) void k_ingest_tile(const T* __re
     }
     if (bad) atomicOr(status, GFICF_ST_BAD_ID);
     __syncthreads();
-    {
+    if constexpr (SCAN) {
       uint32_t rr[KPAD];
 #pragma unroll
       for (int j = 0; j < KPAD; ++j) {
@@ -422,6 +424,25 @@ struct JCfg {
 // multiplicative hash of the id's low 3+LOG2NB bits.  BIG == false: ids < 2^24, full-rate 24-bit
 // multiply (bound to the intrinsic by name: written as a plain product the masked multiply is
 // canonicalised to the quarter-rate v_mul_lo_u32).
+// LDS of an edge kernel: hash sets | own rows and overflow lists | weight table | (pipelined kernel) staging rows of the quad
+// stores | one word per wave: "a row of this wave's cells names an id twice" (gficf_ctx_set_jaccard_distinct)
+template <int KPAD, bool CMP>
+constexpr uint32_t edges_dupflag_off() {
+  using C = JCfg<KPAD, CMP>;
+  return (uint32_t)(C::WAVES * C::NB * 8 + C::WAVES * 2 * KPAD * 4 + (GFICF_JACCARD_MAX_K + 1) * (int)sizeof(double) +
+                    ((C::EPL == 1 && C::SPQ <= 4) ? C::WAVES * 4 * 64 * 8 : 0));
+}
+template <int KPAD, bool CMP>
+constexpr size_t edges_lds_bytes() { return (size_t)edges_dupflag_off<KPAD, CMP>() + (size_t)JCfg<KPAD, CMP>::WAVES * 4; }
+
+// The status word of the deferred duplicate report, read from the kernel's argument block only where it is needed (at the
+// kernel's end, by a wave that met a repeated id): referenced as `o.dup_status` it would be loaded with the other arguments
+// at the kernel's start and live in scalar registers for the whole kernel — the edge kernels sit at 91-95 vector registers
+// with the scalar file full, and every pair kept alive there spills into vector registers and costs a wave per SIMD.
+// Arguments: table (8) N (8) k (4 + 4) cell_begin (8) cell_end (8) EdgeOut.
+struct EdgeOut;
+__device__ inline uint32_t* edge_kernel_dup_status();
+
 extern "C" __device__ uint32_t gficf_mul_u24(uint32_t a, uint32_t b) __asm("llvm.amdgcn.mul.u24.i32");
 
 template <int KPAD, bool BIG>
@@ -470,6 +491,22 @@ extern "C" __device__ int gficf_writelane(int value, int lane, int old) __asm("l
 
 __device__ inline void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
+// Does the overflow list of a cell's hash-set build (ids that found both slots of their bucket taken) hold an id twice?  Up to
+// six entries are compared pair by pair — uniform LDS reads, fifteen compares, no loop: a loop over the list cost the kernels 16
+// scalar and 5 vector registers and with them a wave per SIMD —; a longer list (one row in 10^11 at k = 30) is REPORTED as a
+// repeat, which only costs the caller the exact re-run.
+__device__ inline bool ovlist_repeats(const uint32_t* ovlist, int nov) {
+  uint32_t v[6];
+#pragma unroll
+  for (int t = 0; t < 6; ++t) v[t] = t < nov ? ovlist[t] : 0xFFFFFFF0u + (uint32_t)t;     // (distinct values no key takes)
+  bool r = nov > 6;
+#pragma unroll
+  for (int a = 1; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < a; ++b) r |= v[a] == v[b];
+  return r;
+}
+
 struct EdgeOut {
   double* src;      // the three columns of the reference's edge matrix (all NULL: counts only)
   double* dst;
@@ -481,8 +518,23 @@ struct EdgeOut {
   // sharded sub-problem in local ids (halo.hip): column 1 is src_off + cell + 1, column 2 l2g[local id - 1] (NULL: the id itself)
   const int32_t* l2g = nullptr;
   uint32_t src_off = 0;
+  // gficf_ctx_set_jaccard_distinct: the table was ingested without the duplicate scan; a cell whose own row names an id twice
+  // (seen while the row goes into the hash set) ORs GFICF_ST_DUP_IDS here.  NULL: rows carry their duplicate flag (the scan ran).
+  uint32_t* dup_status = nullptr;
   uint32_t xcd = 1;   // workgroups renumbered so that each XCD (workgroup index mod 8) works on one contiguous run of cells
 };
+
+[[maybe_unused]] constexpr int EDGE_KERNARG_OUT = 40;          // byte offset of the EdgeOut argument of both edge kernels (static_asserts at the launches)
+__device__ inline uint32_t* edge_kernel_dup_status() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const char __attribute__((address_space(4))) * kptr;                // the kernel argument block lives in constant memory
+  typedef uint32_t* const __attribute__((address_space(4))) * kslot;
+  const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+  return *(kslot)(ka + EDGE_KERNARG_OUT + offsetof(EdgeOut, dup_status));
+#else
+  return nullptr;
+#endif
+}
 
 // Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2.  Renumbered, the workgroups of XCD x are
 // x*nb/8 ... (x+1)*nb/8 - 1: at any time an XCD then counts one contiguous run of cells, and table rows that cells next to
@@ -649,8 +701,10 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned char* const hbase = smem + wave * WBYTES;          // this wave's hash set(s)
   // W[u] = u / (2.0*k - u): same IEEE-754 double division as reference :51
+  constexpr uint32_t DUPF_OFF = edges_dupflag_off<KPAD, CMP>();
   for (int u = tid; u <= k; u += C::WAVES * 64) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);
   for (int b = lane; b < (int)(SETS * C::NB); b += 64) reinterpret_cast<uint2*>(hbase)[b] = make_uint2(EMPTY, EMPTY);
+  if (lane == 0) *reinterpret_cast<uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) = 0u;
   __syncthreads();
 
   // LDS byte address of this wave's hash set (a multiple of WBYTES: dynamic LDS starts at 0 here,
@@ -832,7 +886,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
 
     if (!slow) {
       uint32_t dupflags = 0;
-      bool inserted = false;
+      bool inserted = false, dup_here = false, own_dup = false;
 #pragma unroll
       for (int q = 0; q < C::EPL; ++q) {        // q: which register of row i holds the slots of these steps
         for (int t0 = 0; t0 < C::SPQ && (q * 64 + t0 * C::RPS) < k; t0 += C::U) {
@@ -865,9 +919,10 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
                 if (old == EMPTY) {
                   myslot[qi] = (int)bo;
                 } else {
+                  dup_here |= old == key;        // an id twice in the row: the later one meets the earlier in one of the two slots ...
                   old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo + 4), EMPTY, key);
                   if (old == EMPTY) myslot[qi] = (int)bo + 4;
-                  else over = true;
+                  else { dup_here |= old == key; over = true; }
                 }
               }
               const unsigned long long om = __ballot(over);
@@ -877,6 +932,9 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
               }
             }
             wave_lds_fence();
+            if (nov > 1) dup_here |= ovlist_repeats(ovlist, nov);      // ... or both overflowed (rare)
+            if (dup_here) *reinterpret_cast<uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) = 1u;   // reported at the kernel's end
+            own_dup = __ballot(dup_here) != 0ull;
           }
           int cnt[C::U];
 #pragma unroll
@@ -929,8 +987,8 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
           }
         }
       }
-      // a neighbour row with duplicate ids: redo this cell exactly
-      slow = __ballot((dupflags & ROW_DUP_FLAG) != 0) != 0ull;
+      // a neighbour row with duplicate ids (or the own row, found at the insert): redo this cell exactly
+      slow = own_dup || __ballot((dupflags & ROW_DUP_FLAG) != 0) != 0ull;
     }
     if (!prev_stored && have_prev) store_prev();    // own row with duplicates (or k == 0): the gather loop was skipped
     // ---- clear this cell's keys from the set
@@ -952,6 +1010,12 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
     }
   }
   if (have_prev) store_prev();
+  // a row of this wave's cells named an id twice: the deferred report of the "distinct ids" mode (no flags in the table)
+  wave_lds_fence();
+  if (*reinterpret_cast<const uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) != 0u && lane == 0) {
+    uint32_t* const st = edge_kernel_dup_status();
+    if (st != nullptr) atomicOr(st, GFICF_ST_DUP_IDS);
+  }
 }
 
 // ------------------------------------------------------------------ edge kernel, software-pipelined (k <= 32)
@@ -988,6 +1052,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   double* const s_lut = reinterpret_cast<double*>(smem + C::WAVES * WBYTES + C::WAVES * 2 * KPAD * 4);
   constexpr uint32_t STAGE_OFF = C::WAVES * WBYTES + C::WAVES * 2 * KPAD * 4 + (GFICF_JACCARD_MAX_K + 1) * 8;   // behind the weight table
   constexpr uint32_t STAGE_WAVE = 4 * 64 * 8;                 // 4 cells x 64 lanes x {id, count}
+  constexpr uint32_t DUPF_OFF = edges_dupflag_off<KPAD, CMP>();
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -995,6 +1060,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   for (int u = tid; u <= k; u += C::WAVES * 64) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);   // reference :51
   for (int b = lane; b < (int)(SETS * C::NB); b += 64) reinterpret_cast<uint2*>(hbase)[b] = make_uint2(EMPTY, EMPTY);
   for (int t = lane; t < 4 * 64; t += 64) reinterpret_cast<uint2*>(smem + STAGE_OFF + (uint32_t)wave * STAGE_WAVE)[t] = make_uint2(0u, 0u);
+  if (lane == 0) *reinterpret_cast<uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) = 0u;
   __syncthreads();
 
   const uint32_t wave_off = lds_address(smem) + (uint32_t)(tid >> 6) * WBYTES;
@@ -1106,16 +1172,21 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
         uint32_t old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo), EMPTY, key);
         if (old == EMPTY) myslot = (int)bo;
         else {
-          dup_here |= old == key;               // an id twice in the row (the flag says so too)
+          dup_here |= old == key;               // an id twice in the row (a scanned row's flag says so too)
           old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo + 4), EMPTY, key);
           if (old == EMPTY) myslot = (int)bo + 4;
-          else over = true;
+          else { dup_here |= old == key; over = true; }
         }
       }
+      // (two equal ids walk the same two slots: the later one meets the earlier in one of them, or both overflow)
       const unsigned long long om = __ballot(over);
       if (om) {
         if (over) ovlist[nov + __popcll(om & lt_mask)] = a;
         nov += __popcll(om);
+        if (nov > 1) {                           // (one cell in 300) the same id twice among the overflowed ones?
+          wave_lds_fence();
+          dup_here |= ovlist_repeats(ovlist, nov);
+        }
       }
     }
     wave_lds_fence();
@@ -1161,6 +1232,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
       const int v = __shfl(rowcnt, (lane % C::RPS) * C::LPR);
       myu = (lane / C::RPS == st) ? v : myu;
     }
+    if (dup_here) *reinterpret_cast<uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) = 1u;   // reported at the kernel's end
     slow |= __ballot(dup_here || (dupflags & ROW_DUP_FLAG) != 0) != 0ull;      // wave-uniform
     if (myslot >= 0) *reinterpret_cast<uint32_t*>(smem + myslot) = EMPTY;
     wave_lds_fence();
@@ -1288,6 +1360,14 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   }
   park_prev(cq_last);
   store_quad(prev_i - cq_last, cq_last + 1);
+  // ---- a row of this wave's cells named an id twice: the deferred report of the "distinct ids" mode (no flags in the table)
+  if (any_slow) {
+    wave_lds_fence();
+    if (*reinterpret_cast<const uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) != 0u && lane == 0) {
+      uint32_t* const st = edge_kernel_dup_status();
+      if (st != nullptr) atomicOr(st, GFICF_ST_DUP_IDS);
+    }
+  }
   // ---- cells with duplicate ids in their own row or in a neighbour row (never the case for real kNN output): the exact
   // multiset path, after the loop; their fast-path rows written above are overwritten (same wave, program order)
   if (any_slow) {
@@ -1505,18 +1585,23 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
   const int64_t tiles = gficf_ceil_div(n_rows, INGEST_ROWS);
   const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
   static const bool use_reg = getenv("GFICF_JACCARD_INGEST_REG") != nullptr;     // test hook: the one-thread-per-cell variant
+  // rows taken to hold distinct ids (gficf_ctx_set_jaccard_distinct): no duplicate scan; not for sub-problems in local ids
+  const bool scan = !(ctx->jaccard_assume_distinct && zero_ok == 0);
 #define LAUNCH_INGEST_REG(KP, CM)                                                                                          \
   do {                                                                                                                     \
     if (use_reg)                                                                                                           \
       hipLaunchKernelGGL((k_ingest_reg<T, KP, CM>), dim3(grid2), dim3(INGEST2_ROWS), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
                          table, ctx->d_status, zero_ok);                                                                   \
-    else                                                                                                                   \
+    else if (scan)                                                                                                         \
       hipLaunchKernelGGL((k_ingest_tile<T, KP, CM>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total,  \
+                         table, ctx->d_status, zero_ok, gficf_halo_map{});                                                 \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((k_ingest_tile<T, KP, CM, false, false>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
                          table, ctx->d_status, zero_ok, gficf_halo_map{});                                                 \
   } while (0)
 #define LAUNCH_INGEST(KP, CM)                                                                                   \
   hipLaunchKernelGGL((k_ingest<T, KP, CM>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total, \
-                     table, ctx->d_status, zero_ok)
+                     table, ctx->d_status, zero_ok, scan ? 1 : 0)
   switch (f.kpad) {
     case 16: LAUNCH_INGEST_REG(16, false); break;
     case 32: if (f.compact) LAUNCH_INGEST_REG(32, true); else LAUNCH_INGEST_REG(32, false); break;
@@ -1528,14 +1613,6 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
 #undef LAUNCH_INGEST_REG
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
-}
-
-template <int KPAD, bool CMP>
-constexpr size_t edges_lds_bytes() {
-  using C = JCfg<KPAD, CMP>;
-  // hash sets | own rows and overflow lists | weight table | (pipelined kernel) staging rows of the quad stores
-  return (size_t)C::WAVES * C::NB * 8 + (size_t)C::WAVES * 2 * KPAD * 4 + (GFICF_JACCARD_MAX_K + 1) * sizeof(double) +
-         ((C::EPL == 1 && C::SPQ <= 4) ? (size_t)C::WAVES * 4 * 64 * 8 : 0);
 }
 
 // workgroups per CU for an edge kernel: as many as fit, up to 8 (measured at 100 k x 30, tools/r02_sweep.sh: 4 per CU 44-47 us,
@@ -1627,6 +1704,7 @@ int launch_edges(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_
 
 int launch_edges_k(gficf_ctx* ctx, const uint32_t* t, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
   if (const char* e = getenv("GFICF_JACCARD_XCD")) o.xcd = atoi(e) != 0 ? 1u : 0u;     // A/B switch, read per call
+  if (ctx->jaccard_assume_distinct && !o.l2g) o.dup_status = ctx->d_status;            // the table carries no duplicate flags
   switch (kpad_for(k)) {
     case 16: return launch_edges<16>(ctx, t, N, k, cb, ce, o);
     case 32: return launch_edges<32>(ctx, t, N, k, cb, ce, o);
@@ -1647,6 +1725,26 @@ int check_nk(int64_t N, int k) {
 }
 
 }  // namespace
+
+/* The host entries take rows to hold distinct ids (no duplicate scan in the ingest, gficf_ctx_set_jaccard_distinct) and re-run
+ * the exact sequence by themselves when the edge kernel reports a row that does not: the reference's result for every input,
+ * the scan's time saved for every input a kNN search produces.  GFICF_JACCARD_SCAN_DUPS in the environment: always scan. */
+template <typename F>
+static int distinct_first(gficf_ctx* ctx, F&& body) {
+  if (!ctx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ctx is NULL");
+  static const bool always_scan = getenv("GFICF_JACCARD_SCAN_DUPS") != nullptr;
+  const int saved = ctx->jaccard_assume_distinct;
+  ctx->jaccard_assume_distinct = always_scan ? 0 : 1;
+  int rc = body();
+  if (rc == GFICF_ERR_DUPLICATE_IDS) {
+    ctx->jaccard_assume_distinct = 0;
+    ctx->quiet_rerun = 1;                      // (the banner lines have been printed)
+    rc = body();
+    ctx->quiet_rerun = 0;
+  }
+  ctx->jaccard_assume_distinct = saved;
+  return rc;
+}
 
 extern "C" {
 
@@ -1753,12 +1851,12 @@ int gficf_jaccard_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int6
   return gficf_jaccard_edges_device(ctx, d_table_ws, N, k, 0, N, d_rmat, d_rmat + E, d_rmat + 2 * E, d_u);
 }
 
-int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld,
+static int gficf_jaccard_host_body(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld,
                        double* rmat, int print_output) {
   GFICF_CTX_ENTER(ctx);
   int rc = check_nk(N, k);
   if (rc) return rc;
-  if (print_output) gficf_print(ctx, "Running Parallell Jaccard Coefficient Estimation...\n");  // reference :63
+  if (print_output && !ctx->quiet_rerun) gficf_print(ctx, "Running Parallell Jaccard Coefficient Estimation...\n");  // reference :63
   const int64_t E = N * (int64_t)k;
   bool trunc_path = false;
   if (E > 0 && idx && idx_is_f64 && ctx->jaccard_trunc && ld >= N) {
@@ -1819,7 +1917,7 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
 
 /* Compact host return: the intersection counts alone, 2 B per edge instead of the reference's 24 B row (a row is a
  * function of (i, idx[i,j], u): gficf_jaccard_expand_host rebuilds the reference matrix from them on the host). */
-int gficf_jaccard_counts_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, uint16_t* u) {
+static int gficf_jaccard_counts_host_body(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, uint16_t* u) {
   GFICF_CTX_ENTER(ctx);
   int rc = check_nk(N, k);
   if (rc) return rc;
@@ -1998,7 +2096,7 @@ static void edge_plan_free(gficf_ctx* ctx) {
 
 void gficf_edge_plan_free(gficf_ctx* ctx) { edge_plan_free(ctx); }
 
-int gficf_jaccard_filtered_host_plan(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld,
+static int gficf_jaccard_filtered_host_plan_body(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld,
                                      int64_t* n_edges) {
   GFICF_CTX_ENTER(ctx);
   int rc = check_nk(N, k);
@@ -2045,12 +2143,12 @@ int gficf_jaccard_filtered_host_plan(gficf_ctx* ctx, const void* idx, int idx_is
  * .Call symbol _gficf_jaccard_coeff, src/RcppExports.cpp:36): same edges, but (a) the intersection is Rcpp::intersect,
  * i.e. of the two rows as SETS (it differs from the parallel entry only for rows with duplicate ids), and (b) the rows
  * with u > 0 are written one after the other from the top of the (N*k) x 3 matrix (`r++`, :36-41), the rest stays 0. */
-int gficf_jaccard_coeff_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, double* weights,
+static int gficf_jaccard_coeff_host_body(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, double* weights,
                              int print_output) {
   GFICF_CTX_ENTER(ctx);
   int rc = check_nk(N, k);
   if (rc) return rc;
-  if (print_output) gficf_print(ctx, "Running Jaccard Coefficient Estimation...\n");  // reference :25
+  if (print_output && !ctx->quiet_rerun) gficf_print(ctx, "Running Jaccard Coefficient Estimation...\n");  // reference :25
   const int64_t E = N * (int64_t)k;
   if (E == 0) return GFICF_OK;
   if (!idx || !weights) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
@@ -2100,6 +2198,25 @@ int gficf_jaccard_filtered_host_finish(gficf_ctx* ctx, double* from, double* to,
   edge_plan_free(ctx);
   if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_jaccard_filtered_host_finish: %s", hipGetErrorString(e));
   return GFICF_OK;
+}
+
+int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld,
+                       double* rmat, int print_output) {
+  return distinct_first(ctx, [&]() { return gficf_jaccard_host_body(ctx, idx, idx_is_f64, N, k, ld, rmat, print_output); });
+}
+
+int gficf_jaccard_counts_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, uint16_t* u) {
+  return distinct_first(ctx, [&]() { return gficf_jaccard_counts_host_body(ctx, idx, idx_is_f64, N, k, ld, u); });
+}
+
+int gficf_jaccard_filtered_host_plan(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld,
+                                     int64_t* n_edges) {
+  return distinct_first(ctx, [&]() { return gficf_jaccard_filtered_host_plan_body(ctx, idx, idx_is_f64, N, k, ld, n_edges); });
+}
+
+int gficf_jaccard_coeff_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, double* weights,
+                             int print_output) {
+  return distinct_first(ctx, [&]() { return gficf_jaccard_coeff_host_body(ctx, idx, idx_is_f64, N, k, ld, weights, print_output); });
 }
 
 }  // extern "C"

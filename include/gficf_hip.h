@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFICF_HIP_ABI_VERSION 3
+#define GFICF_HIP_ABI_VERSION 4
 
 typedef enum gficf_status {
   GFICF_OK = 0,
@@ -45,6 +45,9 @@ typedef enum gficf_status {
                                   slots of the sharded Jaccard build too few (deferred)    */
   GFICF_ERR_BAD_VALUE = 8,     /* a non-finite coordinate in the kNN point matrix, a
                                   negative / non-finite edge weight (Louvain)             */
+  GFICF_ERR_DUPLICATE_IDS = 10, /* Jaccard with gficf_ctx_set_jaccard_distinct on: a row of the index matrix names an id
+                                  twice (deferred); every edge computed from that table is to be discarded and the
+                                  sequence re-run with the option off                                              */
   GFICF_ERR_EXPLICIT_ZEROS = 9 /* gficf_csc_device met an explicitly stored zero: its count of
                                   stored entries is then not rowSums(M != 0); discard the
                                   outputs and call gficf_csc_exact_device                  */
@@ -107,6 +110,21 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
  * k is limited to GFICF_JACCARD_MAX_K = 256 neighbours per cell in every Jaccard entry (the reference has no limit;
  * clustcells() defaults to 15 and Phenograph to 30): beyond it the calls return GFICF_ERR_UNSUPPORTED and the message says so. */
 int gficf_ctx_set_jaccard_options(gficf_ctx* ctx, int truncate_noninteger_ids);
+
+/* Rows of a kNN index matrix hold k DISTINCT ids — uwot / Annoy and the search of this library never return one twice — but
+ * the reference does not require it: its std::set_intersection over the two sorted rows (src/rcpp_parallel_jaccard_coeff.cpp:
+ * 38-46) treats them as multisets, and so does this library's exact path.  Knowing whether a row repeats an id took the ingest
+ * an all-pairs scan per row (k^2 / 2 comparisons: 6 of its 10.7 us at 100 k x 30, 10 of 29 us at k = 50).  With assume_distinct != 0
+ * the ingest (gficf_jaccard_ingest_device) skips that scan, and the edge kernels — which insert every row of their cell range
+ * into a hash set anyway and see a repeated id there for free — raise a deferred GFICF_ERR_DUPLICATE_IDS at the next
+ * gficf_ctx_sync instead.  The caller then DISCARDS every edge computed from that table and re-runs ingest + edges with the
+ * option off (the same pattern as gficf_csc_device / GFICF_ERR_EXPLICIT_ZEROS).  The check is complete only if every row of
+ * the table is the own row of some cell of the ranges the context computes (one context, all cells: the single-device
+ * sequence); the sharded builds leave the option off (a rank never inserts the rows of another rank's cells).
+ * The host entries of this header (gficf_jaccard_host, _counts_host, _filtered_host_plan, gficf_jaccard_coeff_host) run the
+ * fast sequence and re-run the exact one by themselves when it is needed: their results are the reference's for every input.
+ * Default: off. */
+int gficf_ctx_set_jaccard_distinct(gficf_ctx* ctx, int assume_distinct);
 
 /* Compact host return (the reference's 24 B row is a function of (i, idx[i,j], u)): the intersection counts alone,
  * u[i*k + j], 2 B per edge across PCIe instead of 24.  gficf_jaccard_expand_host rebuilds the reference's (N*k) x 3

@@ -755,3 +755,96 @@ def test_truncation_mode_small_and_degenerate_shapes():
         want, _ = oracle.jaccard(mat)
         got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False, truncate_noninteger_ids=True)
         assert np.array_equal(got, want), mat
+
+
+def _scramble16(lo):
+    """The stored form of an id's low half in a compact row (csrc/jaccard.hip: scramble16)."""
+    s = (lo * 0x9E37) & 0xFFFF
+    return ((s >> 5) | (s << 11)) & 0xFFFF
+
+
+def test_rows_taken_to_hold_distinct_ids_and_the_deferred_duplicate_error(ops):
+    """gficf_ctx_set_jaccard_distinct: the ingest does not scan rows for a repeated id; the edge kernel, which inserts every
+    row of its cell range into a hash set, must report EVERY row that repeats one (deferred GFICF_ERR_DUPLICATE_IDS) — wherever
+    the two copies sit, in every row format, also when both copies overflow the set's two-slot bucket — and must leave clean
+    input alone (same edges, no error).  With the option off the same matrices give the oracle's multiset result."""
+    rng = np.random.default_rng(123)
+    shapes = [(3000, 30), (5000, 15), (3000, 31), (2000, 50), (2000, 64), (900, 100), (700, 200), (400, 256), (140_000, 30), (50, 3)]
+    for N, k in shapes:
+        mat = synth.knn_windowed(N, k, W=max(100, k) if N > 600 else max((k + 1) // 2, 2), seed=N + k, perm_seed=N + k + 1) if N > 2 * k + 2 \
+            else synth.knn_uniform(N, k, seed=N + k)
+        want, wu = oracle.jaccard(mat, nthreads=os.cpu_count() or 8)
+        ops.set_jaccard_distinct(True)
+        try:
+            rm, u = device_jaccard(ops, mat)                      # clean input: no error at the sync inside, same bits
+            assert np.array_equal(rm, want) and np.array_equal(u, wu), (N, k)
+            trials = 3 if N > 100_000 else 25
+            for t in range(trials):
+                m2 = mat.copy()
+                r = int(rng.integers(0, N))
+                a, b = rng.choice(k, size=2, replace=False) if k > 1 else (0, 0)
+                if k == 1:
+                    continue
+                m2[r, a] = m2[r, b]
+                with pytest.raises(gficf_amd.GficfError) as ei:
+                    device_jaccard(ops, m2)
+                assert ei.value.status == "GFICF_ERR_DUPLICATE_IDS", (N, k, r, a, b, ei.value.status)
+        finally:
+            ops.set_jaccard_distinct(False)
+        m2 = mat.copy()
+        m2[N // 2, 0] = m2[N // 2, k - 1]
+        rm, u = device_jaccard(ops, m2)                           # option off: the scan flags the row, the exact path runs
+        w2, wu2 = oracle.jaccard(m2, nthreads=os.cpu_count() or 8)
+        assert np.array_equal(rm, w2) and np.array_equal(u, wu2), (N, k)
+    # compact rows, SIX ids of a row in one bucket of the hash set (two slots): four of them overflow — all distinct: no error;
+    # a repeated id among the overflowed ones: reported.  (More than six overflowed ids are reported as a repeat without
+    # being compared — never seen on real input, it only costs the exact re-run: the host entry still returns the oracle's edges.)
+    N, k = 60_000, 30
+    ids = np.arange(1, N + 1)
+    bucket = np.array([_scramble16(int(i) & 0xFFFF) & 0x7F8 for i in ids])
+    group = ids[bucket == bucket[0]]
+    others = ids[bucket != bucket[0]]
+    mat = synth.knn_windowed(N, k, seed=5, perm_seed=6)
+    ops.set_jaccard_distinct(True)
+    try:
+        for t in range(20):
+            m2 = mat.copy()
+            r = int(rng.integers(0, N))
+            cand = rng.permutation(others)
+            _, first = np.unique(bucket[cand - 1], return_index=True)      # the other ids: no two in one bucket
+            row = np.concatenate([rng.permutation(group)[:6], cand[np.sort(first)][:k - 6]])
+            pos = rng.permutation(k)
+            m2[r] = row[pos]
+            device_jaccard(ops, m2)                               # distinct ids, six in one bucket: no error
+            where = np.flatnonzero(pos < 6)                       # slots holding the six ids of the crowded bucket
+            a, b = rng.choice(where, size=2, replace=False)
+            m2[r, a] = m2[r, b]
+            with pytest.raises(gficf_amd.GficfError) as ei:
+                device_jaccard(ops, m2)
+            assert ei.value.status == "GFICF_ERR_DUPLICATE_IDS", (t, r, a, b)
+    finally:
+        ops.set_jaccard_distinct(False)
+    m2 = mat.copy()
+    m2[123] = rng.permutation(group)[:k]                          # thirty distinct ids in one bucket: reported, healed by the host entry
+    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(m2, False), oracle.jaccard(m2, nthreads=8)[0])
+
+
+def test_host_entries_take_the_fast_sequence_and_heal_themselves(monkeypatch):
+    """The `.Call` entry, the counts, the filtered form and the serial entry on a matrix with repeated ids in some rows: the
+    reference's multiset / set results (the exact sequence re-run behind the deferred error), banner lines printed once."""
+    N, k = 4000, 30
+    mat = synth.knn_windowed(N, k, seed=31, perm_seed=32)
+    mat[17, 3] = mat[17, 9]
+    mat[N - 1, 0] = mat[N - 1, k - 1]
+    want, wu = oracle.jaccard(mat, nthreads=8)
+    lines = []
+    ctx = gficf_amd.default_context()
+    got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
+    assert np.array_equal(got, want)
+    assert np.array_equal(gficf_amd.jaccard_counts(mat).astype(np.int32).reshape(-1), wu)
+    neigh = np.concatenate([np.arange(1, N + 1, dtype=np.int32)[:, None], mat], axis=1)
+    e = gficf_amd.jaccard_edges(neigh)
+    keep = want[:, 2] > 0
+    assert np.array_equal(e["from"], want[keep, 0]) and np.array_equal(e["to"], want[keep, 1]) and np.array_equal(e["weight"], want[keep, 2])
+    assert np.array_equal(gficf_amd.jaccard_coeff(mat, False), oracle.jaccard_coeff(mat))
+    ctx.sync()                                                    # nothing deferred is left behind
