@@ -5,7 +5,8 @@ Jaccard: random shapes (N 1 .. 6000, now and then 131 000 .. 180 000 for the wid
 matrix (windowed scrambled / windowed in order / uniform / few distinct ids = rows full of duplicates and self-references /
 a window of 2), int32 or float64 input, through every entry that returns edges: the `.Call` entry (reference matrix), the
 compact counts + host expansion, the filtered call-site form, the serial `jaccard_coeff` entry, the device-resident path
-with counts, and the strict truncation mode on matrices with non-integer doubles.  Bit-exact or the run stops.
+with counts, the distinct-ids mode (the deferred GFICF_ERR_DUPLICATE_IDS must come exactly when a row repeats an id), and the
+strict truncation mode on matrices with non-integer doubles.  Bit-exact or the run stops.
 GF-ICF: random CSC matrices (G 1 .. 30 000, N 1 .. 3000; densities; empty cells, empty genes, explicit zeros, cells beyond
 2048 entries), random filter bounds, supplied weights, icf types and norms; structure exact, values within 1e-12 (gficf() as the
 reference runs it) / 1e-11 relative x the cell's condition number (the prob / smooth / l1 helper branches: an l1 sum over
@@ -74,7 +75,7 @@ def jaccard_case(case):
     want, wu = oracle.jaccard(m, nthreads=NT)
     as_f64 = rng.random() < 0.3
     mat = m.astype(np.float64) if as_f64 else m
-    entry = int(rng.integers(0, 6)) if not big else int(rng.integers(0, 3))
+    entry = int(rng.integers(0, 7)) if not big else int(rng.choice([0, 1, 2, 6]))
     tag = f"jaccard case {case}: N={N} k={k} kind={kind} f64={as_f64} entry={entry}"
     if entry == 0:
         got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
@@ -107,6 +108,32 @@ def jaccard_case(case):
         ops.sync()
         assert np.array_equal(rmat.cpu().numpy().T, want) and np.array_equal(u.cpu().numpy(), wu), tag
         bump("jaccard device-resident with counts")
+    elif entry == 6:
+        # rows taken to hold distinct ids (gficf_ctx_set_jaccard_distinct): a matrix with a repeated id in any row must raise
+        # the deferred error, a clean one must give the oracle's edges
+        import torch
+
+        ops = gficf_amd.HipOps(0)
+        srt = np.sort(m, axis=1)
+        has_dup = bool((srt[:, 1:] == srt[:, :-1]).any()) if k > 1 else False
+        idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
+        table = torch.empty((N, ops.kpad(k)), dtype=torch.int32, device="cuda")
+        rmat = torch.full((3, N * k), -7.0, dtype=torch.float64, device="cuda")
+        ops.set_jaccard_distinct(True)
+        try:
+            ops.jaccard(idx, N, k, table, rmat, None)
+            try:
+                ops.sync()
+                raised = False
+            except gficf_amd.GficfError as ex:
+                assert ex.status == "GFICF_ERR_DUPLICATE_IDS", tag + " " + ex.status
+                raised = True
+        finally:
+            ops.set_jaccard_distinct(False)
+        assert raised == has_dup or (raised and not has_dup and k >= 8), tag + f" raised={raised} has_dup={has_dup}"   # (a row with 7+ overflowed ids may be reported without a repeat)
+        if not raised:
+            assert np.array_equal(rmat.cpu().numpy().T, want), tag
+        bump("jaccard distinct-ids mode (error iff a row repeats an id)")
     else:
         md = m.astype(np.float64)
         frac = synth.rand_unit(case + 9, np.arange(N * k)).reshape(N, k)
