@@ -119,8 +119,9 @@ int gficf_ctx_set_jaccard_options(gficf_ctx* ctx, int truncate_noninteger_ids);
  * into a hash set anyway and see a repeated id there for free — raise a deferred GFICF_ERR_DUPLICATE_IDS at the next
  * gficf_ctx_sync instead.  The caller then DISCARDS every edge computed from that table and re-runs ingest + edges with the
  * option off (the same pattern as gficf_csc_device / GFICF_ERR_EXPLICIT_ZEROS).  The check is complete only if every row of
- * the table is the own row of some cell of the ranges the context computes (one context, all cells: the single-device
- * sequence); the sharded builds leave the option off (a rank never inserts the rows of another rank's cells).
+ * the table is the own row of some cell that is computed: one context over all cells (the single-device sequence), or cell
+ * blocks over several contexts / ranks that between them cover every cell — the error then comes from the context that owns
+ * the row, and EVERY context's edges are to be discarded.  Sub-problems in local ids (halo form) always scan.
  * The host entries of this header (gficf_jaccard_host, _counts_host, _filtered_host_plan, gficf_jaccard_coeff_host) run the
  * fast sequence and re-run the exact one by themselves when it is needed: their results are the reference's for every input.
  * Default: off. */
