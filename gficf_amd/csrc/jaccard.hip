@@ -1033,7 +1033,10 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
 // four runs of k x 8 B that straddle segments: 17 % fewer write requests, none of them partial (memory-only model,
 // tools/lab/gather_lab.hip: 39.8 -> 35.5 us at 100 k x 30).
 // B16 = false (compact rows only): N < 2^16, no id has bit 16 — the bitmap words of the rows are zero and are not looked at.
-template <int KPAD, bool BIG, bool CMP, int OUT, bool B16 = true, bool MAP = false>
+// NOFLAG: the table was ingested without the duplicate scan (gficf_ctx_set_jaccard_distinct) and carries no row flags: the
+// kernel does not look for them (own row, every gathered piece: ~8 of its ~200 vector instructions per cell); a repeated id
+// is found at the own row's insert, as in every variant.
+template <int KPAD, bool BIG, bool CMP, int OUT, bool B16 = true, bool MAP = false, bool NOFLAG = false>
 __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
   using C = JCfg<KPAD, CMP>;
@@ -1119,8 +1122,8 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   auto decode_own = [&](const OwnRaw& r) -> uint32_t {
     uint32_t x;
     if (!CMP) x = r.v;
-    else if (B16) x = r.v | ((((KPAD == 32 ? r.last : r.hw) >> (lane & 31)) & 1u) << 16) | (r.last & ROW_DUP_FLAG);
-    else x = r.v | (r.last & ROW_DUP_FLAG);
+    else if (B16) x = r.v | ((((KPAD == 32 ? r.last : r.hw) >> (lane & 31)) & 1u) << 16) | (NOFLAG ? 0u : (r.last & ROW_DUP_FLAG));
+    else x = r.v | (NOFLAG ? 0u : (r.last & ROW_DUP_FLAG));
     return slot_ok ? x : 0u;
   };
   auto true_id = [&](uint32_t keyraw) -> uint32_t {
@@ -1159,7 +1162,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   // counts of cell `a`'s slots from its gathered pieces (fast path); returns whether the cell needs the exact path
   auto process = [&](uint32_t araw, const uint4 (&bv)[NST], int& u_out) -> bool {
     const uint32_t a = araw & ID_MASK;            // the hash set's form of the id (see decode_own)
-    bool slow = __ballot((araw & ROW_DUP_FLAG) != 0) != 0ull;
+    bool slow = NOFLAG ? false : __ballot((araw & ROW_DUP_FLAG) != 0) != 0ull;
     // row i into the hash set
     int myslot = -1, nov = 0;
     bool dup_here = false;
@@ -1198,7 +1201,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
       if (!CMP) {
         uint32_t miss = 0;
         uint32_t id[4] = {bv[st].x & ID_MASK, bv[st].y, bv[st].z, bv[st].w};
-        dupflags |= bv[st].x;
+        if (!NOFLAG) dupflags |= bv[st].x;
         uint2 h[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) h[t] = lds_read_b64(bucket_off<KPAD, BIG>(id[t]) | wave_off);
@@ -1218,7 +1221,8 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
         }
       } else {
         uint32_t wd[4], hb;
-        dupflags |= piece_words(bv[st], wd, hb);
+        const uint32_t fw = piece_words(bv[st], wd, hb);
+        if (!NOFLAG) dupflags |= fw;
         c = probe_compact_piece<B16>(wd, hb, bmask_v, bit16_v, wave_off);
         if (nov) {                                  // wave-uniform, rare: ids that overflowed the set (kept in their stored form)
           for (int t = 0; t < nov; ++t) {
@@ -1233,7 +1237,7 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
       myu = (lane / C::RPS == st) ? v : myu;
     }
     if (dup_here) *reinterpret_cast<uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) = 1u;   // reported at the kernel's end
-    slow |= __ballot(dup_here || (dupflags & ROW_DUP_FLAG) != 0) != 0ull;      // wave-uniform
+    slow |= __ballot(dup_here || (!NOFLAG && (dupflags & ROW_DUP_FLAG) != 0)) != 0ull;      // wave-uniform
     if (myslot >= 0) *reinterpret_cast<uint32_t*>(smem + myslot) = EMPTY;
     wave_lds_fence();
     u_out = a != 0 ? myu : 0;                   // rejected id: zero row
@@ -1647,6 +1651,26 @@ int launch_edges_m(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
     if (!no_pipe) {
       const bool nob16 = CMP && N < 65536;     // no id carries bit 16: the kernel variant that does not look for it (configs 1-3 of BASELINE.json)
       int rc;
+      if constexpr (!MAP) {
+        if (o.dup_status != nullptr) {           // a table without row flags (gficf_ctx_set_jaccard_distinct)
+          static std::atomic<int> bpc_nf{0}, bpc_nf_nob16{0};
+          if (nob16) rc = edge_blocks_per_cu(k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, !CMP, false, true>, C::WAVES * 64, lds_bytes, bpc_nf_nob16, &blocks_per_cu);
+          else rc = edge_blocks_per_cu(k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, true, false, true>, C::WAVES * 64, lds_bytes, bpc_nf, &blocks_per_cu);
+          if (rc) return rc;
+          const int64_t cap_n = (int64_t)ctx->num_cus * blocks_per_cu;
+          const int64_t need_n = gficf_ceil_div(gficf_ceil_div(ce - cb, 4), C::WAVES);
+          unsigned grid_n = (unsigned)(need_n < cap_n ? need_n : cap_n);
+          if (o.xcd && grid_n > 8) grid_n = (grid_n + 7u) & ~7u;
+          if (nob16)
+            hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, !CMP, false, true>), dim3(grid_n), dim3(C::WAVES * 64), lds_bytes, ctx->stream,
+                               table, N, k, cb, ce, o);
+          else
+            hipLaunchKernelGGL((k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, true, false, true>), dim3(grid_n), dim3(C::WAVES * 64), lds_bytes, ctx->stream,
+                               table, N, k, cb, ce, o);
+          GFICF_HIP_CHECK(hipGetLastError());
+          return GFICF_OK;
+        }
+      }
       if (nob16) rc = edge_blocks_per_cu(k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, !CMP, MAP>, C::WAVES * 64, lds_bytes, bpc_pipe_nob16, &blocks_per_cu);
       else rc = edge_blocks_per_cu(k_jaccard_edges_pipe<KPAD, BIG, CMP, OUT, true, MAP>, C::WAVES * 64, lds_bytes, bpc_pipe, &blocks_per_cu);
       if (rc) return rc;
