@@ -1728,7 +1728,7 @@ int launch_edges(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_
 
 int launch_edges_k(gficf_ctx* ctx, const uint32_t* t, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
   if (const char* e = getenv("GFICF_JACCARD_XCD")) o.xcd = atoi(e) != 0 ? 1u : 0u;     // A/B switch, read per call
-  if (ctx->jaccard_assume_distinct && !o.l2g) o.dup_status = ctx->d_status;            // the table carries no duplicate flags
+  if (ctx->jaccard_assume_distinct) o.dup_status = ctx->d_status;                      // the table may carry no duplicate flags
   switch (kpad_for(k)) {
     case 16: return launch_edges<16>(ctx, t, N, k, cb, ce, o);
     case 32: return launch_edges<32>(ctx, t, N, k, cb, ce, o);
@@ -1840,9 +1840,18 @@ int gficf_jaccard_halo_ingest_device(gficf_ctx* ctx, const int32_t* d_idx, int64
   const int64_t tiles = gficf_ceil_div(n_ext, INGEST_ROWS);
   const int64_t gcap = (int64_t)ctx->num_cus * 8;
   const unsigned grid = (unsigned)(tiles < gcap ? tiles : gcap);
-#define LAUNCH_HALO_INGEST(KP, CM)                                                                                              \
-  hipLaunchKernelGGL((k_ingest_tile<int32_t, KP, CM, true>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_ext, k, ld, n_ext, \
-                     (uint32_t*)d_table, ctx->d_status, 1, hm)
+  // rows taken to hold distinct ids (gficf_ctx_set_jaccard_distinct): no duplicate scan here either — a rank's own rows are
+  // inserted by its mapped edge kernel, which reports a repeated id; the halo rows are own rows of the ranks that sent them
+  const bool scan = !ctx->jaccard_assume_distinct;
+#define LAUNCH_HALO_INGEST(KP, CM)                                                                                                \
+  do {                                                                                                                            \
+    if (scan)                                                                                                                     \
+      hipLaunchKernelGGL((k_ingest_tile<int32_t, KP, CM, true>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_ext, k, ld, n_ext, \
+                         (uint32_t*)d_table, ctx->d_status, 1, hm);                                                               \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((k_ingest_tile<int32_t, KP, CM, true, false>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_ext, k, ld, \
+                         n_ext, (uint32_t*)d_table, ctx->d_status, 1, hm);                                                        \
+  } while (0)
   switch (f.kpad) {
     case 16: LAUNCH_HALO_INGEST(16, false); break;
     case 32: if (f.compact) LAUNCH_HALO_INGEST(32, true); else LAUNCH_HALO_INGEST(32, false); break;

@@ -848,3 +848,34 @@ def test_host_entries_take_the_fast_sequence_and_heal_themselves(monkeypatch):
     assert np.array_equal(e["from"], want[keep, 0]) and np.array_equal(e["to"], want[keep, 1]) and np.array_equal(e["weight"], want[keep, 2])
     assert np.array_equal(gficf_amd.jaccard_coeff(mat, False), oracle.jaccard_coeff(mat))
     ctx.sync()                                                    # nothing deferred is left behind
+
+
+@pytest.mark.parametrize("N,k,P", [(30_000, 30, 3), (20_000, 50, 2), (9_000, 15, 4)])
+def test_halo_form_with_rows_taken_to_hold_distinct_ids(ops, N, k, P):
+    """The scan-less sequence in the sharded build on local ids (emulated ranks): clean input gives the oracle's edges with no
+    error on any rank; a repeated id planted in a cell raises GFICF_ERR_DUPLICATE_IDS at the sync of the rank that OWNS the
+    cell (its mapped edge kernel inserts the row) — the job's signal to re-run with the option off."""
+    from gficf_amd.dist import shard_bounds
+
+    mat = synth.knn_windowed(N, k, seed=N + k, perm_seed=None)      # ids with locality: the halo form fits
+    want, _ = oracle.jaccard(mat, nthreads=8)
+    ops.set_jaccard_distinct(True)
+    try:
+        got, named = _emulated_halo_build(ops, mat, P, 1024)
+        assert np.array_equal(got, want) and max(named) < 1024
+        rng = np.random.default_rng(N)
+        for owner in range(P):
+            b, e = shard_bounds(N, P, owner)
+            m2 = mat.copy()
+            r = int(rng.integers(b, e))
+            a, c = rng.choice(k, size=2, replace=False)
+            m2[r, a] = m2[r, c]
+            with pytest.raises(gficf_amd.GficfError) as ei:
+                _emulated_halo_build(ops, m2, P, 1024)
+            assert ei.value.status == "GFICF_ERR_DUPLICATE_IDS", (owner, r)
+    finally:
+        ops.set_jaccard_distinct(False)
+    m2 = mat.copy()
+    m2[N // 2, 0] = m2[N // 2, k - 1]
+    got, _ = _emulated_halo_build(ops, m2, P, 1024)                  # option off: flags, exact path, the oracle's multiset result
+    assert np.array_equal(got, oracle.jaccard(m2, nthreads=8)[0])

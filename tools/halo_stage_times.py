@@ -18,6 +18,7 @@ from gficf_amd import synth
 from gficf_amd.dist import rows_per_rank, shard_bounds
 
 ops = gficf_amd.HipOps(0)
+ops.set_jaccard_distinct(True)          # the sequence bench.py and the host entries run: no duplicate scan in the ingests
 n_per, k = 100_000, 30
 
 
