@@ -492,8 +492,8 @@ def main():
     # scan every row for a repeated id; the edge kernel meets one while it builds the row's hash set and raises a deferred
     # GFICF_ERR_DUPLICATE_IDS (surfaced by the sync behind the timed region; the exact sequence would then be re-run).  Sharded
     # by cell blocks with an all-gather of rows the check stays complete across the job — every row is the own row of a cell of
-    # exactly one rank, whose sync raises (the job then fails loudly on that rank) —; the halo form's sub-problems in local ids
-    # keep the scan whatever the option says (their ingest and their mapped edge kernel do not take it).
+    # exactly one rank, whose sync raises (the job then fails loudly on that rank) —, and so it does in the halo form (the rank
+    # that owns a cell inserts its row).
     distinct = not args.scan_dups
     if distinct:
         ops.set_jaccard_distinct(True)
@@ -611,7 +611,7 @@ def main():
                                 "ingest + RCCL all-gather of table rows + edge kernel") +
                                ", device-resident, one stream, in order (no overlap between data sets or steps)" +
                                ("; rows taken to hold distinct ids: no duplicate scan in the ingest, the edge kernel's hash-set build reports a "
-                                "repeated id (deferred GFICF_ERR_DUPLICATE_IDS, exact re-run) — what the host entries do" if distinct and not halo_form else ""),
+                                "repeated id (deferred GFICF_ERR_DUPLICATE_IDS, exact re-run) — what the host entries do" if distinct else ""),
                    "cells_total": N_total, "k": k, "data_sets_per_step": batch, "edges_per_step": edges_per_step,
                    "partition": f"cell blocks x{world}" + ("" if world == 1 else f", exchange: {exchange}")},
         "timed_region_ms": round(region_ms, 4),

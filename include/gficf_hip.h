@@ -121,7 +121,8 @@ int gficf_ctx_set_jaccard_options(gficf_ctx* ctx, int truncate_noninteger_ids);
  * option off (the same pattern as gficf_csc_device / GFICF_ERR_EXPLICIT_ZEROS).  The check is complete only if every row of
  * the table is the own row of some cell that is computed: one context over all cells (the single-device sequence), or cell
  * blocks over several contexts / ranks that between them cover every cell — the error then comes from the context that owns
- * the row, and EVERY context's edges are to be discarded.  Sub-problems in local ids (halo form) always scan.
+ * the row, and EVERY context's edges are to be discarded.  The halo form follows the option too (gficf_jaccard_halo_ingest_device
+ * and the mapped edge kernels); gficf_jaccard_ingest_local_device always scans.
  * The host entries of this header (gficf_jaccard_host, _counts_host, _filtered_host_plan, gficf_jaccard_coeff_host) run the
  * fast sequence and re-run the exact one by themselves when it is needed: their results are the reference's for every input.
  * Default: off. */
