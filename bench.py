@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--ids", choices=["permuted", "spatial"], default="permuted",
                     help="permuted: ids relabelled by a random permutation (what Annoy output looks like; the default); "
                          "spatial: cells numbered in their spatial order (what the device kNN search's pivot order gives)")
+    ap.add_argument("--pre-warm-ms", type=float, default=200.0,
+                    help="run the step untimed for this long BEFORE the W warm-up steps, so that the K timed steps see settled clocks "
+                         "(from idle the first ~20 ms of work run 10-12 %% slower: tools/lab/distinct_ab.py); 0 = off")
     ap.add_argument("--scan-dups", action="store_true",
                     help="N = 1: the ingest looks for duplicate ids inside a row itself (all-pairs scan) instead of leaving it to the edge kernel's "
                          "hash-set build + a deferred error (gficf_ctx_set_jaccard_distinct, what the host entries do)")
@@ -497,6 +500,27 @@ def main():
     distinct = not args.scan_dups
     if distinct:
         ops.set_jaccard_distinct(True)
+    # settle the clocks: W = 5 steps are 2 ms of work and K = 20 another 9 ms — from idle the GPU is still ramping through all of
+    # that (the same K steps measured 0.42 ms right after start-up and 0.375-0.38 ms from the third repetition on).  The step is
+    # run untimed for a fixed wall time first (every rank the same number of steps: collectives stay matched), then the W warm-up
+    # steps, then the K timed ones.
+    pre_warm_steps = 0
+    if args.pre_warm_ms > 0:
+        step()                                                     # (first call: allocations, occupancy queries)
+        fence()
+        t_pw = time.perf_counter()
+        step()
+        fence()
+        one = max(time.perf_counter() - t_pw, 1e-5)
+        if world > 1:                                              # every rank takes the same decision and the same number of steps
+            t_one = torch.tensor([one], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_one, op=dist.ReduceOp.MAX)
+            one = float(t_one.item())
+        if one < 0.02:                                             # (steps of tens of milliseconds — a rehearsal over gloo — settle the clocks by themselves)
+            pre_warm_steps = int(min(5000, max(1, args.pre_warm_ms * 1e-3 / one)))
+            for _ in range(pre_warm_steps):
+                step()
+            fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -517,6 +541,24 @@ def main():
         dt = float(tmax.item())
     edges_per_step = N_total * k * batch
     value = edges_per_step * args.steps / dt
+    # the same K steps with the ingest's own duplicate scan (the sequence of rounds 1-3, `--scan-dups`), for comparison
+    value_scan = value
+    if distinct:
+        ops.set_jaccard_distinct(False)
+        for _ in range(2):
+            step()
+        fence()
+        t0s = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dts = time.perf_counter() - t0s
+        if world > 1:
+            tms = torch.tensor([dts], dtype=torch.float64, device=dev)
+            dist.all_reduce(tms, op=dist.ReduceOp.MAX)
+            dts = float(tms.item())
+        value_scan = edges_per_step * args.steps / dts
+        ops.set_jaccard_distinct(True)
 
     # ---- roofline of the dominant kernel (k_jaccard_edges): HIP events around every launch of a second run of the same
     # K steps, recorded on the stream the kernel is launched on (the event pairs cost a few us per launch, so they stay out of
@@ -615,6 +657,9 @@ def main():
                    "cells_total": N_total, "k": k, "data_sets_per_step": batch, "edges_per_step": edges_per_step,
                    "partition": f"cell blocks x{world}" + ("" if world == 1 else f", exchange: {exchange}")},
         "timed_region_ms": round(region_ms, 4),
+        "pre_warm": {"ms_asked": args.pre_warm_ms, "steps": pre_warm_steps,
+                     "note": "the step run untimed before the W warm-up steps so that the K timed steps see settled clocks; --pre-warm-ms 0 turns it off"},
+        "value_with_ingest_duplicate_scan": value_scan,
         "ms_per_data_set": dt / args.steps / batch * 1e3,
         "roofline": roofline,
     }
