@@ -58,6 +58,9 @@ SIGNATURES = {
     "gficf_multi_cell_blocks": (_int, [_i64, _int, _vp]),
     "gficf_multi_cell_blocks_by_nnz": (_int, [_i64, _vp, _int, _int, _vp]),
     "gficf_jaccard_host_multi": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _int]),
+    "gficf_multi_jaccard_device": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _vp]),
+    "gficf_multi_sync": (_int, [_vp]),
+    "gficf_multi_set_jaccard_distinct": (_int, [_vp, _int]),
     "gficf_normalize_csc_host_multi_plan": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _dbl, _dbl, _vp,
                                                    ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "gficf_normalize_csc_host_multi_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),

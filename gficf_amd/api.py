@@ -106,6 +106,42 @@ class MultiContext:
             raise RuntimeError("multi context is closed")
         return self._h
 
+    # ---- the device-resident step: blocks already in HBM, table slices exchanged by direct peer copies
+    def cell_blocks(self, N: int) -> list[int]:
+        """bounds[r] .. bounds[r + 1] = cells of device slot r (``gficf_multi_cell_blocks``)."""
+        bd = (ctypes.c_int64 * (len(self.devices) + 1))()
+        check(_lib.load().gficf_multi_cell_blocks(int(N), len(self.devices), bd))
+        return list(bd)
+
+    def set_jaccard_distinct(self, assume_distinct: bool):
+        check(_lib.load().gficf_multi_set_jaccard_distinct(self.handle, 1 if assume_distinct else 0))
+
+    def jaccard_device(self, idx_blocks, N: int, k: int, tables, outs):
+        """``gficf_multi_jaccard_device``: ``idx_blocks[r]`` the (k, n_r) int32 / float64 tensor of block r on device slot r
+        (column-major n_r x k, global 1-based ids), ``tables[r]`` an (N, row_words) int32 tensor and ``outs[r]`` a (3, n_r*k)
+        float64 tensor on the same device.  Enqueues only (on the contexts' own streams: the inputs must be complete —
+        synchronise the torch streams that made them first); :meth:`sync` waits and raises deferred errors."""
+        P = len(self.devices)
+        if not (len(idx_blocks) == len(tables) == len(outs) == P):
+            raise ValueError("one block, table and output per device slot")
+        bd = self.cell_blocks(N)
+        f64 = {str(t.dtype) for t in idx_blocks if t is not None and t.numel()}
+        if len(f64) > 1 or (f64 and f64 - {"torch.int32", "torch.float64"}):
+            raise ValueError("idx blocks must all be int32 or all float64")
+        is_f64 = 1 if f64 == {"torch.float64"} else 0
+        ptr = lambda ts: (ctypes.c_void_p * P)(*[(t.data_ptr() if t is not None and t.numel() else None) for t in ts])
+        lds = (ctypes.c_int64 * P)(*[(int(t.shape[1]) if t is not None and t.dim() == 2 else bd[r + 1] - bd[r]) for r, t in enumerate(idx_blocks)])
+        for r in range(P):
+            n = bd[r + 1] - bd[r]
+            if n > 0 and (tuple(outs[r].shape) != (3, n * k) or str(outs[r].dtype) != "torch.float64" or not outs[r].is_contiguous()):
+                raise ValueError(f"outs[{r}] must be a contiguous float64 tensor of shape (3, {n * k})")
+            if not tables[r].is_contiguous() or (n > 0 and not idx_blocks[r].is_contiguous()):
+                raise ValueError("expected contiguous tensors")
+        check(_lib.load().gficf_multi_jaccard_device(self.handle, ptr(idx_blocks), is_f64, lds, int(N), int(k), ptr(tables), ptr(outs)))
+
+    def sync(self):
+        check(_lib.load().gficf_multi_sync(self.handle))
+
     def close(self):
         if self._h:
             _lib.load().gficf_multi_destroy(self._h)

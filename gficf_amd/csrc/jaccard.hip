@@ -526,7 +526,13 @@ struct EdgeOut {
   uint32_t xcd = 1;   // workgroups renumbered so that each XCD (workgroup index mod 8) works on one contiguous run of cells
 };
 
-[[maybe_unused]] constexpr int EDGE_KERNARG_OUT = 40;          // byte offset of the EdgeOut argument of both edge kernels (static_asserts at the launches)
+// The parameter list of BOTH edge kernels as the kernel argument block lays it out (every argument at its natural alignment):
+// the byte offset of the EdgeOut argument is derived from it, and the kernels' signatures are checked against it right behind
+// their definitions (static_assert on the function types) — a parameter added or moved without this struct following fails to compile.
+struct EdgeKernArgs { const uint32_t* table; int64_t N; int k; int64_t cell_begin; int64_t cell_end; EdgeOut o; };
+using EdgeKernFn = void (*)(const uint32_t*, int64_t, int, int64_t, int64_t, EdgeOut);
+constexpr int EDGE_KERNARG_OUT = (int)offsetof(EdgeKernArgs, o);
+static_assert(EDGE_KERNARG_OUT == 40 && offsetof(EdgeKernArgs, cell_end) == 32, "kernel argument block of the edge kernels");
 __device__ inline uint32_t* edge_kernel_dup_status() {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef const char __attribute__((address_space(4))) * kptr;                // the kernel argument block lives in constant memory
@@ -1391,6 +1397,13 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     }
   }
 }
+
+// edge_kernel_dup_status() reads the EdgeOut argument at EDGE_KERNARG_OUT: both kernels must take exactly EdgeKernArgs' list
+static_assert(std::is_same<decltype(&k_jaccard_edges<32, false, false, OUT_RMAT, false>), EdgeKernFn>::value &&
+              std::is_same<decltype(&k_jaccard_edges<64, false, true, OUT_U16, true>), EdgeKernFn>::value &&
+              std::is_same<decltype(&k_jaccard_edges_pipe<32, false, true, OUT_RMAT, true, false, true>), EdgeKernFn>::value &&
+              std::is_same<decltype(&k_jaccard_edges_pipe<16, true, false, OUT_RMAT_U, true, true, false>), EdgeKernFn>::value,
+              "the edge kernels' parameter list and EdgeKernArgs differ: edge_kernel_dup_status() would read a wrong slot");
 
 // ------------------------------------------------------------------ edge filter (N1)
 // The caller's next line, relations[relations[,3] > 0, ] (reference R/clustCells.R:66), on the

@@ -17,7 +17,9 @@
 //     then run per block and the kept entries land at their offsets in the caller's arrays.
 // Kernels and arithmetic are those of the single-device entries: same bits.
 #include <cstring>
+#include <exception>
 #include <functional>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -47,6 +49,13 @@ struct gficf_multi {
   std::vector<hipStream_t> stream;
   std::vector<hipEvent_t> ev;
   bool peer = true;                // every pair of distinct devices can access each other
+  // device-resident step (gficf_multi_jaccard_device): device d pulls the other devices' table slices on P - 1 copy streams of
+  // its own, all pairs at once; events order the pulls against the ingests (this step) and the edge kernels (the step before)
+  std::vector<std::vector<hipStream_t>> cstream;   // [d][t - 1]: the stream of device d's t-th pull
+  std::vector<std::vector<hipEvent_t>> cev;        // ... and "that pull is done"
+  std::vector<hipEvent_t> ev_prev;                 // device d: everything enqueued before this step (the last step's edge kernel) is done
+  std::vector<hipEvent_t> ev_pulled;               // device d: has pulled every other slice of this step
+  bool step_valid = false;                         // ev_pulled holds a recorded step
   // GF-ICF plan
   bool has_plan = false;
   int64_t G = 0, N = 0, g_kept = 0, nnz_kept = 0;
@@ -80,17 +89,41 @@ int hip_fail(const char* what, hipError_t e) {
 // One stage of a multi-device entry: body(r) for every device r, each on its own host thread (inline for one device),
 // joined before returning.  body returns a gficf_status; its message is thread-local to the worker, so the worker keeps
 // a copy and the first failing device (in device order) is the one reported.  A stage is skipped once `fe` holds an error.
+// A stage body may allocate (std::vector, std::function copies): no C++ exception may leave a worker thread (std::terminate
+// would take the R session down) nor cross the C ABI — it becomes a status with a message.
+int guarded(const std::function<int(int)>& body, int r) {
+  try {
+    return body(r);
+  } catch (const std::bad_alloc&) {
+    gficf_set_error("out of host memory in a multi-device stage (device slot %d)", r);
+    return GFICF_ERR_HIP;
+  } catch (const std::exception& ex) {
+    gficf_set_error("C++ exception in a multi-device stage (device slot %d): %s", r, ex.what());
+    return GFICF_ERR_INVALID_ARG;
+  } catch (...) {
+    gficf_set_error("unknown C++ exception in a multi-device stage (device slot %d)", r);
+    return GFICF_ERR_INVALID_ARG;
+  }
+}
+
 void for_each_device(int P, FirstError& fe, const std::function<int(int)>& body) {
   if (fe.rc != GFICF_OK) return;
-  if (P == 1) { fe.note(body(0)); return; }
-  std::vector<FirstError> each((size_t)P);
+  if (P == 1) { fe.note(guarded(body, 0)); return; }
+  std::vector<FirstError> each;
   std::vector<std::thread> th;
-  th.reserve((size_t)P);
+  try {
+    each.resize((size_t)P);
+    th.reserve((size_t)P);
+  } catch (...) {
+    gficf_set_error("out of host memory setting up the per-device threads");
+    fe.note(GFICF_ERR_HIP);
+    return;
+  }
   for (int r = 0; r < P; ++r) {
     try {
-      th.emplace_back([&, r]() { each[(size_t)r].note(body(r)); });
+      th.emplace_back([&, r]() { each[(size_t)r].note(guarded(body, r)); });
     } catch (...) {                                 // no thread to be had (std::system_error must not cross the C ABI): this device's stage runs here
-      each[(size_t)r].note(body(r));
+      each[(size_t)r].note(guarded(body, r));
     }
   }
   for (auto& t : th) t.join();
@@ -188,6 +221,13 @@ void gficf_multi_destroy(gficf_multi* m) {
   if (!m) return;
   for (size_t r = 0; r < m->ctx.size(); ++r) {
     if (m->ctx[r]) gficf_ctx_destroy(m->ctx[r]);
+  }
+  for (size_t r = 0; r < m->cstream.size(); ++r) {
+    (void)hipSetDevice(m->dev[r]);
+    for (hipStream_t cs : m->cstream[r]) if (cs) (void)hipStreamDestroy(cs);
+    for (hipEvent_t ce : m->cev[r]) if (ce) (void)hipEventDestroy(ce);
+    if (r < m->ev_prev.size() && m->ev_prev[r]) (void)hipEventDestroy(m->ev_prev[r]);
+    if (r < m->ev_pulled.size() && m->ev_pulled[r]) (void)hipEventDestroy(m->ev_pulled[r]);
   }
   for (size_t r = 0; r < m->stream.size(); ++r) {
     (void)hipSetDevice(m->dev[r]);
@@ -288,6 +328,115 @@ int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, in
   }
   if (print_output) gficf_print(m->ctx[0], "Done!!\n");  // reference :77
   return GFICF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ device-resident step
+// lazily: the copy streams and events of gficf_multi_jaccard_device
+static int multi_step_resources(gficf_multi* m) {
+  const int P = m->ndev;
+  if ((int)m->cstream.size() == P) return GFICF_OK;
+  m->cstream.assign((size_t)P, {});
+  m->cev.assign((size_t)P, {});
+  m->ev_prev.assign((size_t)P, nullptr);
+  m->ev_pulled.assign((size_t)P, nullptr);
+  for (int d = 0; d < P; ++d) {
+    hipError_t e = hipSetDevice(m->dev[d]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_prev[d], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_pulled[d], hipEventDisableTiming);
+    for (int t = 1; t < P && e == hipSuccess; ++t) {
+      hipStream_t cs = nullptr;
+      hipEvent_t ce = nullptr;
+      e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ce, hipEventDisableTiming);
+      m->cstream[d].push_back(cs);
+      m->cev[d].push_back(ce);
+    }
+    if (e != hipSuccess) return hip_fail("copy streams of the device-resident step", e);
+  }
+  return GFICF_OK;
+}
+
+int gficf_multi_set_jaccard_distinct(gficf_multi* m, int assume_distinct) {
+  if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  for (gficf_ctx* c : m->ctx) {
+    const int rc = gficf_ctx_set_jaccard_distinct(c, assume_distinct);
+    if (rc) return rc;
+  }
+  return GFICF_OK;
+}
+
+/* The sharded Jaccard step with everything resident in HBM, single process (what is sharded: the cells of the
+ * reference's parallelFor(0, N, worker), src/rcpp_parallel_jaccard_coeff.cpp:73; the call being sharded: R/clustCells.R:64-65).
+ * Enqueue only — nothing here waits for a device. */
+int gficf_multi_jaccard_device(gficf_multi* m, const void* const* d_idx, int idx_is_f64, const int64_t* ld, int64_t N, int k,
+                               int32_t* const* d_table, double* const* d_out) {
+  if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  if (N < 0 || k < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N = %lld or k = %d is negative", (long long)N, k);
+  const int roww = gficf_jaccard_row_words(N, k);
+  if (roww < 0) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d exceeds GFICF_JACCARD_MAX_K = %d or N = %lld exceeds int32 ids", k, GFICF_JACCARD_MAX_K, (long long)N);
+  if (N == 0 || k == 0) return GFICF_OK;
+  if (!d_idx || !d_table || !d_out) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer array");
+  const int P = m->ndev;
+  std::vector<int64_t> bd;
+  try { bd.resize((size_t)P + 1); } catch (...) { GFICF_FAIL(GFICF_ERR_HIP, "out of host memory"); }
+  gficf_multi_cell_blocks(N, P, bd.data());
+  for (int r = 0; r < P; ++r) {
+    const int64_t n = bd[r + 1] - bd[r];
+    if (!d_table[r] || (n > 0 && (!d_idx[r] || !d_out[r]))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer for device slot %d", r);
+    if (ld && ld[r] < n) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld[%d] = %lld < %lld rows of the block", r, (long long)ld[r], (long long)n);
+  }
+  int rc = multi_step_resources(m);
+  if (rc) return rc;
+  // 1. every device: its own block of ids -> its slice of ITS table, behind (a) its own last edge kernel (same stream) and
+  //    (b) the other devices' pulls of that slice in the step before
+  for (int r = 0; r < P; ++r) {
+    const int64_t n = bd[r + 1] - bd[r];
+    hipError_t e = hipSetDevice(m->dev[r]);
+    if (e == hipSuccess) e = hipEventRecord(m->ev_prev[r], m->stream[r]);
+    for (int d = 0; d < P && e == hipSuccess && m->step_valid; ++d)
+      if (d != r) e = hipStreamWaitEvent(m->stream[r], m->ev_pulled[d], 0);
+    if (e != hipSuccess) return hip_fail("ordering the ingest behind the last step", e);
+    if (n > 0) {
+      rc = gficf_jaccard_ingest_device(m->ctx[r], d_idx[r], idx_is_f64, n, k, ld ? ld[r] : n, N, d_table[r] + (size_t)bd[r] * roww);
+      if (rc) return rc;
+    }
+    e = hipEventRecord(m->ev[r], m->stream[r]);
+    if (e != hipSuccess) return hip_fail("hipEventRecord", e);
+  }
+  // 2. every device pulls the P - 1 other slices, each on a copy stream of its own (all pairs at once: a device's pulls
+  //    run side by side over its links instead of one after the other), then builds the edges of its block
+  for (int d = 0; d < P; ++d) {
+    hipError_t e = hipSetDevice(m->dev[d]);
+    for (int t = 1; t < P && e == hipSuccess; ++t) {
+      const int s = (d + t) % P;                              // start with the next device: the pulls of a step are spread over the links
+      const int64_t n = bd[s + 1] - bd[s];
+      if (n <= 0) continue;
+      hipStream_t cs = m->cstream[d][(size_t)t - 1];
+      e = hipStreamWaitEvent(cs, m->ev[s], 0);                // the slice has been ingested on its owner
+      if (e == hipSuccess) e = hipStreamWaitEvent(cs, m->ev_prev[d], 0);   // this device's last edge kernel no longer reads its table
+      const size_t off = (size_t)bd[s] * roww, bytes = sizeof(int32_t) * (size_t)n * roww;
+      if (e == hipSuccess) e = hipMemcpyPeerAsync(d_table[d] + off, m->dev[d], d_table[s] + off, m->dev[s], bytes, cs);
+      if (e == hipSuccess) e = hipEventRecord(m->cev[d][(size_t)t - 1], cs);
+      if (e == hipSuccess) e = hipStreamWaitEvent(m->stream[d], m->cev[d][(size_t)t - 1], 0);
+    }
+    if (e == hipSuccess) e = hipEventRecord(m->ev_pulled[d], m->stream[d]);
+    if (e != hipSuccess) return hip_fail("exchange of table slices (peer copies)", e);
+    const int64_t n = bd[d + 1] - bd[d];
+    if (n > 0) {
+      const size_t ne = (size_t)n * (size_t)k;
+      rc = gficf_jaccard_edges_device(m->ctx[d], d_table[d], N, k, bd[d], bd[d + 1], d_out[d], d_out[d] + ne, d_out[d] + 2 * ne, nullptr);
+      if (rc) return rc;
+    }
+  }
+  m->step_valid = true;
+  return GFICF_OK;
+}
+
+int gficf_multi_sync(gficf_multi* m) {
+  if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  FirstError fe;
+  for (int r = 0; r < m->ndev; ++r) fe.note(gficf_ctx_sync(m->ctx[r]));      // (the copy streams were joined into the device's stream)
+  return fe.done();
 }
 
 // ------------------------------------------------------------------------------------------------ GF-ICF

@@ -290,6 +290,10 @@ class JaccardShard:
         self.ops.sync()
 
 
+# deferred statuses a sharded step can end in, by severity (the collective sync raises the most severe one on every rank)
+_STATUS_SEVERITY = {"GFICF_ERR_CAPACITY": 1, "GFICF_ERR_DUPLICATE_IDS": 2, "GFICF_ERR_BAD_ID": 3, "GFICF_ERR_HIP": 4}
+
+
 class JaccardHaloShard:
     """The sharded Jaccard build on LOCAL ids (csrc/halo.hip): a rank's sub-problem is its own block of cells plus the remote
     rows the block names, renumbered 1..n_ext — with n_ext < 2^17 it runs on the compact 64 B-row table and the fast edge
@@ -433,12 +437,41 @@ class JaccardHaloShard:
             ev.record(torch.cuda.current_stream(self.out.device))
             self.ev_consumed[self.last_p] = ev
 
-    def sync(self):
-        """Wait for the streams; raises GficfError(GFICF_ERR_CAPACITY) when a step overflowed the request slots."""
+    def sync(self, collective: bool = False):
+        """Wait for the streams; raises GficfError(GFICF_ERR_CAPACITY) when a step overflowed the request slots (or
+        GFICF_ERR_DUPLICATE_IDS in distinct mode).
+
+        A deferred error is raised on the rank whose block overflowed (or owns the offending row) ONLY.  A caller that answers
+        it by switching forms — building a :class:`JaccardShard` — must do so on EVERY rank or the ranks issue different
+        collectives and the job hangs.  ``collective=True`` makes that agreement here: every rank calls it (it is a
+        collective), the ranks all-reduce their status and every rank raises the SAME error — the most severe status any rank
+        saw, with the number of the first rank that saw it — or none does."""
         if self.pipeline:
             self.side.synchronize()
             self.edge_stream.synchronize()
-        self.ops.sync()
+        if not collective or self.world == 1:
+            self.ops.sync()
+            return
+        from ._lib import STATUS_NAMES, GficfError
+
+        err, code = None, 0
+        try:
+            self.ops.sync()
+        except GficfError as ex:
+            err, code = ex, _STATUS_SEVERITY.get(ex.status, 1)
+        # one small all-reduce: (severity, -rank) MAX picks the most severe status and, among equals, the lowest rank
+        dev = self.out.device if dist.get_backend(self.group) != "gloo" else torch.device("cpu")
+        t = torch.tensor([code * 4096 + (4095 - self.rank) if code else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        top = int(t.item())
+        if top == 0:
+            return
+        sev, who = top // 4096, 4095 - top % 4096
+        if err is not None and code == sev:
+            raise err
+        status = next(s for s, v in _STATUS_SEVERITY.items() if v == sev)
+        num = next(c for c, n in STATUS_NAMES.items() if n == status)
+        raise GficfError(num, f"rank {who} reported {status} in the sharded Jaccard step (this rank's own block was fine); every rank fails alike")
 
 
 class GficfShard:

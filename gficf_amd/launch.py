@@ -4,8 +4,8 @@
 asked for N > 1 GPUs but was not started by `torch.distributed.run`: it starts N fresh interpreters of the same script
 with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, waits for them, hands rank 0's stdout through and
 returns a non-zero code if any rank failed.  The caller must not have touched the GPU yet (the children are new
-processes, nothing is re-exec'ed, but a parent holding a HIP context would only be in the way); counting devices with
-`torch.cuda.device_count()` does not initialise it.
+processes, nothing is re-exec'ed, but a parent holding a HIP context would only be in the way); the GPUs are counted from
+the KFD topology in sysfs (`visible_gpus`), so the launcher never loads the HIP runtime at all.
 
 What is sharded by the ranks so started: the cells of the reference's `parallelFor(0, N, worker)`
 (src/rcpp_parallel_jaccard_coeff.cpp:73), see gficf_amd/dist.py.
@@ -33,11 +33,53 @@ def launched_by_torchrun() -> bool:
     return "WORLD_SIZE" in os.environ and "RANK" in os.environ
 
 
-def visible_gpus() -> int:
-    """Number of GPUs this process could use, without initialising any of them."""
-    import torch
+def _parse_visible(var: str) -> list[str] | None:
+    v = os.environ.get(var)
+    if v is None:
+        return None
+    return [t.strip() for t in v.split(",") if t.strip() != ""]
 
-    return int(torch.cuda.device_count())
+
+def kfd_gpu_nodes(root: str = "/sys/class/kfd/kfd/topology/nodes") -> int | None:
+    """GPUs the kernel driver lists (KFD topology nodes with SIMDs: CPU nodes have ``simd_count 0``), read from sysfs —
+    no HIP, no HSA, nothing initialised.  None when the topology is not readable (no amdgpu driver: a CPU box)."""
+    try:
+        nodes = sorted(os.listdir(root), key=lambda s: int(s) if s.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    n = 0
+    for d in nodes:
+        try:
+            props = open(os.path.join(root, d, "properties")).read()
+        except OSError:
+            continue
+        for line in props.splitlines():
+            parts = line.split()
+            if len(parts) == 2 and parts[0] == "simd_count" and parts[1].isdigit() and int(parts[1]) > 0:
+                n += 1
+                break
+    return n
+
+
+def visible_gpus() -> int:
+    """Number of GPUs a rank of this job could use, WITHOUT initialising any of them and without the HIP runtime: the KFD
+    topology in sysfs, narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES as the runtime would
+    (a list shorter than the node count wins; an empty list is 0).  Where sysfs says nothing (no driver) a throw-away child
+    process counts with torch — the launcher itself never loads the HIP runtime either way (on ROCm builds without
+    amdsmi `torch.cuda.device_count()` falls back to hipGetDeviceCount, which does initialise it)."""
+    n = kfd_gpu_nodes()
+    if n is None:
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+            n = int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+        except (OSError, ValueError, subprocess.TimeoutExpired):
+            n = 0
+        return n
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        lst = _parse_visible(var)
+        if lst is not None:
+            n = min(n, len(lst))
+    return n
 
 
 def spawn_ranks(argv: list[str], n: int, *, need_gpus: int | None = None, timeout_s: float | None = None,

@@ -51,27 +51,44 @@ def permutation(n: int, seed: int) -> np.ndarray:
 
 
 def knn_windowed(N: int, k: int, W: int = 100, seed: int = 42, perm_seed: int | None = 43,
-                 dtype=np.int32, chunk: int = 65536) -> np.ndarray:
-    """N x k matrix (C order) of 1-based neighbour ids, self excluded, distinct per row."""
+                 dtype=np.int32, chunk: int = 65536, rows: tuple | None = None) -> np.ndarray:
+    """N x k matrix (C order) of 1-based neighbour ids, self excluded, distinct per row.
+    ``rows=(b, e)``: only rows [b, e) of that matrix (an (e-b) x k array, the same values) — what one rank of a sharded job
+    holds; costs (e-b)/N of the full generation (plus the permutation)."""
     W = int(min(W, (N - 1) // 2))
     if 2 * W < k:
         raise ValueError(f"window 2*{W} smaller than k={k} (N={N})")
     offs = np.concatenate([np.arange(-W, 0), np.arange(1, W + 1)]).astype(np.int64)
     pi = permutation(N, perm_seed) if perm_seed is not None else np.arange(N, dtype=np.int64)
-    out = np.empty((N, k), dtype=dtype)
-    for c0 in range(0, N, chunk):
-        c1 = min(N, c0 + chunk)
+    if rows is None:
+        b, e = 0, N
+        src = None                                 # row pi[c] of the matrix belongs to (pre-permutation) cell c
+    else:
+        b, e = int(rows[0]), int(rows[1])
+        if perm_seed is not None:
+            inv = np.empty(N, dtype=np.int64)
+            inv[pi] = np.arange(N, dtype=np.int64)
+            src = inv[b:e]                         # the cells whose rows land in [b, e), in row order
+        else:
+            src = np.arange(b, e, dtype=np.int64)
+    n_out = e - b
+    out = np.empty((n_out, k), dtype=dtype)
+    for c0 in range(0, N if src is None else n_out, chunk):
+        c1 = min(N if src is None else n_out, c0 + chunk)
         n = c1 - c0
-        cells = np.arange(c0, c1, dtype=np.int64)
+        cells = np.arange(c0, c1, dtype=np.int64) if src is None else src[c0:c1]
         cand = np.broadcast_to(offs, (n, 2 * W)).copy()
-        rows = np.arange(n)
+        rws = np.arange(n)
         for t in range(k):
             r = t + (rand_u64(seed, cells, t) % np.uint64(2 * W - t)).astype(np.int64)
-            a = cand[rows, t].copy()
-            cand[rows, t] = cand[rows, r]
-            cand[rows, r] = a
+            a = cand[rws, t].copy()
+            cand[rws, t] = cand[rws, r]
+            cand[rws, r] = a
         nb = (cells[:, None] + cand[:, :k]) % N
-        out[pi[c0:c1]] = (pi[nb] + 1).astype(dtype)
+        if src is None:
+            out[pi[c0:c1]] = (pi[nb] + 1).astype(dtype)
+        else:
+            out[c0:c1] = (pi[nb] + 1).astype(dtype)
     return out
 
 

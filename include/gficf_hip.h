@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFICF_HIP_ABI_VERSION 4
+#define GFICF_HIP_ABI_VERSION 5
 
 typedef enum gficf_status {
   GFICF_OK = 0,
@@ -381,6 +381,23 @@ int gficf_normalize_csc_host_multi_plan(gficf_multi* m, int64_t G, int64_t N, co
                                         const double* w_in, int64_t* G_kept, int64_t* nnz_kept);
 int gficf_normalize_csc_host_multi_finish(gficf_multi* m, uint8_t* keep, int64_t* nt, double* w, void* out_colptr,
                                           int32_t* out_rowidx, double* out_x);
+
+/* The same sharded Jaccard step with EVERYTHING RESIDENT IN HBM (no host buffers): block r of the kNN matrix already lies on
+ * device r of m (d_idx[r]: its (k, ld[r]) column-major ids, global 1-based; ld NULL = the block's row count); every device
+ * ingests its block into its slice of ITS copy of the table (d_table[r]: N x gficf_jaccard_row_words(N, k) int32 on device r),
+ * pulls the other P - 1 slices straight from the other devices with hipMemcpyPeerAsync — each pull on a copy stream of its own,
+ * all pairs at once, ordered by events behind the owners' ingests: no collective, no host round trip — and builds the edges of
+ * its block into d_out[r] (3 x n_r*k doubles on device r: the block's slices of the three columns of rmat).  Blocks are those of
+ * gficf_multi_cell_blocks.  The call only ENQUEUES (on the contexts' own streams): the caller's inputs must be complete before
+ * it, results and deferred input errors are collected by gficf_multi_sync.  Consecutive calls may reuse the same buffers (a
+ * step's ingest waits for the pulls of the step before).  What is sharded: the cells of the reference's parallelFor(0, N, worker)
+ * (src/rcpp_parallel_jaccard_coeff.cpp:73) under the one call of R/clustCells.R:64-65.
+ * gficf_multi_set_jaccard_distinct: gficf_ctx_set_jaccard_distinct on every device's context — the blocks cover every cell,
+ * so the deferred duplicate check stays complete; the error comes from gficf_multi_sync. */
+int gficf_multi_jaccard_device(gficf_multi* m, const void* const* d_idx, int idx_is_f64, const int64_t* ld, int64_t N, int k,
+                               int32_t* const* d_table, double* const* d_out);
+int gficf_multi_sync(gficf_multi* m);
+int gficf_multi_set_jaccard_distinct(gficf_multi* m, int assume_distinct);
 
 /* ------------------------------------------------------------------- cluster signatures
  * "Next" row N3: data$cluster.gene.rnk of clustcells() (R/clustCells.R:121-123):

@@ -252,3 +252,45 @@ def test_local_id_halo_shard_reports_overflow_on_scrambled_ids(tmp_path):
     mp.spawn(_local_worker, args=(world, _free_port(), 1501, 15, True, 64, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert np.load(tmp_path / f"locmeta_{r}.npy")[0] == 1
+
+
+def _collective_sync_worker(rank, world, port, N, k, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpu_ops_double import CpuOpsDouble
+        from gficf_amd import GficfError, synth
+        from gficf_amd.dist import JaccardHaloShard, shard_bounds
+
+        mat = synth.knn_windowed(N, k, seed=5, perm_seed=None)
+        b1, e1 = shard_bounds(N, world, 1)
+        # 120 cells in the middle of rank 0's block each name one more distinct row of rank 1's block: only rank 0's request slots overflow
+        for t in range(120):
+            mat[200 + t, 0] = b1 + 150 + t + 1
+        b, e = shard_bounds(N, world, rank)
+        sh = JaccardHaloShard(CpuOpsDouble(), N, k, cap=128)
+        sh.step(torch.from_numpy(np.ascontiguousarray(mat[b:e].T)))
+        msg = ""
+        try:
+            sh.sync(collective=True)
+        except GficfError as ex:
+            msg = f"{ex.status}|{ex}"
+        # a clean step afterwards: nobody raises, and the collective is still matched on every rank
+        sh2 = JaccardHaloShard(CpuOpsDouble(), N, k, cap=512)
+        sh2.step(torch.from_numpy(np.ascontiguousarray(mat[b:e].T)))
+        sh2.sync(collective=True)
+        open(os.path.join(outdir, f"csync_{rank}.txt"), "w").write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collective_sync_raises_the_same_error_on_every_rank(tmp_path):
+    """a deferred error of the halo form is local to the rank whose block overflowed; a caller that switches forms on
+    that rank alone would deadlock the job.  sync(collective=True) all-reduces the status: every rank raises, or none."""
+    world = 3
+    mp.spawn(_collective_sync_worker, args=(world, _free_port(), 1501, 15, str(tmp_path)), nprocs=world, join=True)
+    msgs = [open(tmp_path / f"csync_{r}.txt").read() for r in range(world)]
+    assert all(m.startswith("GFICF_ERR_CAPACITY|") for m in msgs), msgs
+    assert "test double" in msgs[0]                                   # rank 0 saw it itself
+    assert all("rank 0 reported GFICF_ERR_CAPACITY" in m for m in msgs[1:])

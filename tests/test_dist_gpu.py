@@ -256,3 +256,58 @@ def test_knn_chain_in_pivot_order_feeds_the_halo_form(tmp_path):
         assert over == 1 and named_plain == cap                                  # scattered clusters: every slot of the other owner in use
         assert 0 < named_ord < 0.25 * (N // world)
     assert np.array_equal(got, want)
+
+
+def test_launcher_counts_the_gpus_of_this_box_from_sysfs_and_need_gpus_runs():
+    """gficf_amd.launch on hardware: the sysfs count agrees with the HIP runtime's (asked of a child process, so that this
+    process' launcher code path stays runtime-free), and the branch the driver's `bench.py --gpus N` takes — spawn_ranks with
+    need_gpus — has executed on a GPU box: one rank, one GPU, the real bench line."""
+    import json
+    import subprocess
+
+    from gficf_amd import launch
+
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+    assert launch.kfd_gpu_nodes() is not None, "no KFD topology in sysfs on a GPU box"
+    assert launch.visible_gpus() == int(r.stdout.strip().splitlines()[-1]) >= 1
+    env = dict(os.environ)
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    drv = ("import sys; sys.path.insert(0, %r)\nfrom gficf_amd import launch\n"
+           "sys.exit(launch.spawn_ranks(sys.argv[1:], 1, need_gpus=1, timeout_s=250))\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", drv, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-extras",
+                        "--cells-per-gpu", "20000", "--pre-warm-ms", "0"], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["checked_vs_oracle"] is True
+    # more GPUs asked for than the box has: exit code 2 before anything is started
+    r = subprocess.run([sys.executable, "-c", drv.replace("need_gpus=1", "need_gpus=64"), os.path.join(ROOT, "bench.py")], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 2 and "64 GPUs asked for" in r.stderr
+
+
+def test_plain_multi_gpu_bench_line_carries_the_whole_scaling_answer():
+    """One `python bench.py --gpus 2` line (rehearsed on the one GPU of the box: numbers meaningless, structure and byte counts
+    real): value + exchange, pipelined, the other id model in both modes, the single-GPU step timed in the same run, the
+    single-process peer-copy leg, and the efficiencies computed from them."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1",
+                        "--cells-per-gpu", "20000", "--no-gficf", "--no-chain"], capture_output=True, text=True, timeout=580, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert out["n_gpus"] == 2 and out["checked_vs_oracle"] is True and out["config"]["cells_total"] == 40000
+    assert out["pipelined"]["edges_per_sec"] > 0
+    sp = out["spatial_ids"]
+    assert sp["exchange"] == "halo" and 0 < sp["rows_named_outside"] <= 400 and sp["checked_vs_oracle"] is True
+    assert sp["in_order"]["edges_per_sec"] > 0 and sp["overlapped"]["edges_per_sec"] > 0
+    assert out["single_gpu_step"]["cells"] == 20000 and out["single_gpu_step"]["edges_per_sec"] > 0
+    pe = out["peer"]
+    assert "error" not in pe, pe
+    assert pe["checked_vs_oracle"] is True and pe["devices"] == [0, 0] and pe["edges_per_sec"] > 0
+    eff = out["efficiency"]
+    for key in ("in_order_permuted", "overlapped_permuted", "in_order_spatial", "overlapped_spatial", "peer_in_order_permuted"):
+        assert eff[key] > 0, key

@@ -1,0 +1,243 @@
+"""The R `.Call` glue (integration/gficf_hip_glue.c) EXECUTED: compiled against a runnable stand-in of the R C API
+(tests/r_mock/r_runtime.c — NOT R; a tagged-heap SEXP model with a PROTECT stack, a torture collector that frees every
+unprotected object at every allocation, Rf_error by longjmp, Rprintf capture and R_registerRoutines) and called through the
+routine table it registers, by name and arity, as `.Call` does (reference: src/RcppExports.cpp:61-70 the entry, :85-97 the
+table).  Results are compared with the oracle; the protect stack must balance and no collected object may be touched.
+Without a GPU only the registration and the error path run (no compute calls)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import gficf_amd
+from gficf_amd import synth
+from tests.helpers import rmock
+
+
+@pytest.fixture(scope="module")
+def R():
+    rt = rmock.RMock()
+    yield rt
+    rt.unload()
+
+
+def test_glue_registers_its_routines_by_name_and_arity(R):
+    tab = R.routines()
+    # the two entries that REPLACE reference entries keep name and arity (src/RcppExports.cpp:87,89)
+    assert tab["_gficf_rcpp_parallel_jaccard_coef"] == 2 and tab["_gficf_jaccard_coeff"] == 2
+    assert tab["_gficf_gficf_csc"] == 7 and len(tab) == 9
+    with pytest.raises(KeyError):
+        R.call("_gficf_no_such_entry")
+    with pytest.raises(TypeError):                      # `.Call` with the wrong number of arguments is refused by the table
+        R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(np.ones((2, 1), dtype=np.int32)))
+
+
+def test_torture_collector_catches_a_missing_protect(R):
+    R.L.rmock_selftest_missing_protect.restype = int
+    assert R.L.rmock_selftest_missing_protect() == 1
+
+
+def test_argument_checks_reach_rf_error(R):
+    with pytest.raises(rmock.RError, match="integer or numeric matrix"):
+        R.call("_gficf_rcpp_parallel_jaccard_coef", R.vector(np.arange(6, dtype=np.int32)), R.vector(np.array([False])))
+    with pytest.raises(rmock.RError, match="integer or numeric matrix"):
+        R.call("_gficf_jaccard_coeff", R.vector(np.arange(6.0)), R.vector(np.array([False])))
+    assert R.L.rmock_protect_depth() == 0
+
+
+@pytest.mark.skipif(gficf_amd.device_count() > 0, reason="GPU present")
+def test_without_a_gpu_the_call_is_an_r_error_not_a_fallback(R):
+    with pytest.raises(rmock.RError, match="no HIP device"):
+        R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(np.array([[2], [1]], dtype=np.int32)), R.vector(np.array([False])))
+    assert R.L.rmock_protect_depth() == 0               # (R's context unwinding resets the stack after an error)
+
+
+# ------------------------------------------------------------------------------------------------------------- GPU
+def _check_call_hygiene(R):
+    assert R.last_protect_exit == 0 and R.L.rmock_protect_depth() == 0
+    assert R.L.rmock_dead_touched() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("as_double", [False, True])
+def test_dot_call_jaccard_entry_matches_the_oracle(R, as_double):
+    import oracle
+
+    mat = synth.knn_windowed(3000, 15, seed=5, perm_seed=6)
+    want, _ = oracle.jaccard(mat, nthreads=4)
+    arg = R.matrix(mat.astype(np.float64) if as_double else mat)        # REALSXP (what Rcpp coerces to) / INTSXP (what uwot returns)
+    res = R.call("_gficf_rcpp_parallel_jaccard_coef", arg, R.vector(np.array([True])))
+    _check_call_hygiene(R)
+    assert res.type == rmock.REALSXP and res.dim == (3000 * 15, 3)      # reference :67
+    assert np.array_equal(res.numpy(), want)
+    # printOutput = TRUE: the reference's two banner lines (src/rcpp_parallel_jaccard_coeff.cpp:63,77) went through Rprintf
+    assert "Running Parallell Jaccard Coefficient Estimation" in R.printed() and "Done" in R.printed()
+    R.call("_gficf_rcpp_parallel_jaccard_coef", arg, R.vector(np.array([False])))
+    assert R.printed() == ""
+
+
+@pytest.mark.gpu
+def test_dot_call_jaccard_edge_shapes(R):
+    import oracle
+
+    for N, k in ((1, 1), (5, 3), (64, 1), (200, 50), (300, 100)):
+        rng = np.random.default_rng(N * 1000 + k)
+        mat = rng.integers(1, N + 1, size=(N, k)).astype(np.int32)     # repeated ids, self ids: the multiset path
+        want, _ = oracle.jaccard(mat, nthreads=2)
+        res = R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(mat), R.vector(np.array([False])))
+        _check_call_hygiene(R)
+        assert res.dim == (N * k, 3) and np.array_equal(res.numpy(), want), (N, k)
+    res = R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(np.zeros((0, 5), dtype=np.int32)), R.vector(np.array([False])))
+    assert res.dim == (0, 3)
+
+
+@pytest.mark.gpu
+def test_dot_call_bad_id_is_an_r_error(R):
+    mat = synth.knn_windowed(500, 10, seed=1)
+    mat[17, 3] = 501                                                   # the reference reads outside the matrix here (:34)
+    with pytest.raises(rmock.RError, match="gficf_hip: .*(id|ids)"):
+        R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(mat), R.vector(np.array([False])))
+    assert R.L.rmock_protect_depth() == 0
+    m2 = mat.astype(np.float64)
+    m2[17, 3] = 4.5                                                    # non-integer double: rejected unless GFICF_HIP_TRUNCATE_IDS=1
+    with pytest.raises(rmock.RError, match="gficf_hip"):
+        R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(m2), R.vector(np.array([False])))
+    # and the session goes on: the next call is served
+    mat[17, 3] = 20
+    res = R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(mat), R.vector(np.array([False])))
+    assert res.dim == (5000, 3)
+
+
+@pytest.mark.gpu
+def test_dot_call_serial_entry_matches_the_oracle(R):
+    import oracle
+
+    rng = np.random.default_rng(3)
+    mat = rng.integers(1, 401, size=(400, 12)).astype(np.int32)
+    res = R.call("_gficf_jaccard_coeff", R.matrix(mat), R.vector(np.array([False])))
+    _check_call_hygiene(R)
+    assert np.array_equal(res.numpy(), oracle.jaccard_coeff(mat))
+
+
+def _counts(G, N, seed=7):
+    colptr, rowidx, x = synth.counts_csc(G, N, seed=seed)
+    return sp.csc_matrix((x, rowidx, colptr), shape=(G, N))
+
+
+def _call_gficf(R, M, w=None, pmin=0.05, pmax=1.0):
+    G, N = M.shape
+    return R.call("_gficf_gficf_csc", R.vector(M.indices.astype(np.int32)), R.vector(M.indptr.astype(np.int32)), R.vector(M.data),
+                  R.vector(np.array([G, N], dtype=np.int32)), R.null() if w is None else R.vector(np.asarray(w, dtype=np.float64)),
+                  R.vector(np.array([pmin])), R.vector(np.array([pmax])))
+
+
+def _check_gficf(res, ref, G, N):
+    assert res.type == rmock.VECSXP and len(res) == 6
+    oi, op, ox, keep, nt, w = (res.elt(i).numpy() for i in range(6))
+    assert np.array_equal(keep.astype(bool), ref["keep"].astype(bool)) and np.array_equal(nt, ref["nt"].astype(np.float64))
+    assert np.array_equal(op, ref["colptr"]) and np.array_equal(oi, ref["rowidx"])
+    assert np.allclose(ox, ref["x"], rtol=1e-6, atol=1e-6) and np.allclose(w, ref["w"], rtol=1e-6, atol=1e-6)   # north_star's tolerance
+    assert np.abs(ox - ref["x"]).max(initial=0.0) < 1e-12                                                        # (observed)
+
+
+@pytest.mark.gpu
+def test_dot_call_gficf_entry_matches_the_oracle(R):
+    import oracle
+
+    G, N = 1200, 700
+    M = _counts(G, N)
+    ref = oracle.gficf_csc(G, N, M.indptr.astype(np.int64), M.indices, M.data, 0.05, 1.0)
+    res = _call_gficf(R, M)
+    _check_call_hygiene(R)
+    _check_gficf(res, ref, G, N)
+    # embedNewCells(): the ICF weights supplied (R/cellClassifier.R:50-53), filter open (max = 2, min = 0)
+    w_in = np.abs(np.random.default_rng(2).normal(size=G)) + 0.1
+    ref2 = oracle.gficf_csc(G, N, M.indptr.astype(np.int64), M.indices, M.data, 0.0, 2.0, w_in=w_in)
+    res2 = _call_gficf(R, M, w=w_in, pmin=0.0, pmax=2.0)
+    _check_call_hygiene(R)
+    _check_gficf(res2, ref2, G, N)
+
+
+@pytest.mark.gpu
+def test_dot_call_device_list_from_the_environment_takes_the_multi_path(R):
+    """GFICF_HIP_DEVICES=0,0: two contexts on the one GPU of the box — the same results, through gficf_*_host_multi."""
+    import oracle
+
+    mat = synth.knn_windowed(4001, 30, seed=9, perm_seed=10)
+    want, _ = oracle.jaccard(mat, nthreads=4)
+    M = _counts(900, 501, seed=3)
+    ref = oracle.gficf_csc(900, 501, M.indptr.astype(np.int64), M.indices, M.data, 0.05, 1.0)
+    R.unload()                                                          # R_unload_gficf: the device list is read again
+    os.environ["GFICF_HIP_DEVICES"] = "0,0"
+    try:
+        res = R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(mat), R.vector(np.array([True])))
+        _check_call_hygiene(R)
+        assert np.array_equal(res.numpy(), want) and "Done" in R.printed()
+        _check_gficf(_call_gficf(R, M), ref, 900, 501)
+        _check_call_hygiene(R)
+        R.unload()
+        os.environ["GFICF_HIP_DEVICES"] = "0,99"                        # an ordinal that does not exist: an error at EVERY call, never a silent single-device run
+        for _ in range(2):
+            with pytest.raises(rmock.RError, match="GFICF_HIP_DEVICES"):
+                R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(mat), R.vector(np.array([False])))
+    finally:
+        del os.environ["GFICF_HIP_DEVICES"]
+        R.unload()
+    res = R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(mat), R.vector(np.array([False])))
+    assert np.array_equal(res.numpy(), want)
+
+
+@pytest.mark.gpu
+def test_dot_call_optional_entries(R):
+    """The other registered routines, each against the Python mirror of the same C ABI call (whose parity tests live in
+    tests/test_knn_gpu.py, test_adjacency_gpu.py, test_gficf_gpu.py, test_louvain_gpu.py) — what is checked HERE is the glue:
+    argument unpacking, allocation, list assembly, names, attributes."""
+    rng = np.random.default_rng(0)
+    centers = rng.normal(scale=5.0, size=(6, 8))
+    X = centers[rng.integers(0, 6, 1500)] + rng.normal(size=(1500, 8))
+    nn = R.call("_gficf_find_nn", R.matrix(X), R.vector(np.array([11], dtype=np.int32)), R.vector(np.array([0], dtype=np.int32)))
+    _check_call_hygiene(R)
+    assert nn.attr("names").strings() == ["idx", "dist"]
+    ref = gficf_amd.find_nn(X, 11, metric="manhattan")
+    assert np.array_equal(nn.elt(0).numpy(), ref["idx"]) and np.allclose(nn.elt(1).numpy(), ref["dist"])
+    # edges -> adjacency
+    ed = gficf_amd.jaccard_edges(ref["idx"], False)
+    adj = R.call("_gficf_jaccard_adjacency", R.vector(ed["from"]), R.vector(ed["to"]), R.vector(ed["weight"]), R.vector(np.array([1500.0])))
+    _check_call_hygiene(R)
+    A = gficf_amd.jaccard_adjacency(ed, 1500)
+    assert np.array_equal(adj.elt(0).numpy(), A.indices) and np.array_equal(adj.elt(1).numpy(), A.indptr) and np.array_equal(adj.elt(2).numpy(), A.data)
+    # Louvain on it: an S4 object with the slots of a dgCMatrix, the reference's argument list (src/RcppExports.cpp:17)
+    lab = R.call("_gficf_RunModularityClusteringHip", R.dgcmatrix(A), R.vector(np.array([1], dtype=np.int32)), R.vector(np.array([0.8])),
+                 R.vector(np.array([1], dtype=np.int32)), R.vector(np.array([1], dtype=np.int32)), R.vector(np.array([10], dtype=np.int32)),
+                 R.vector(np.array([0], dtype=np.int32)), R.vector(np.array([True])), R.string(""))
+    _check_call_hygiene(R)
+    want_lab = gficf_amd.run_modularity_clustering(A, 1, 0.8, 1, 1, 10, 0, False)
+    assert np.array_equal(lab.numpy(), np.asarray(want_lab)) and "Number of communities" in R.printed()
+    with pytest.raises(rmock.RError, match="Modularity parameter"):
+        R.call("_gficf_RunModularityClusteringHip", R.dgcmatrix(A), R.vector(np.array([3], dtype=np.int32)), R.vector(np.array([0.8])),
+               R.vector(np.array([1], dtype=np.int32)), R.vector(np.array([1], dtype=np.int32)), R.vector(np.array([10], dtype=np.int32)),
+               R.vector(np.array([0], dtype=np.int32)), R.vector(np.array([False])), R.string(""))
+    # signatures + transpose of a normalised matrix
+    M = _counts(600, 400, seed=11)
+    g = gficf_amd.gficf(M, normalize=False, verbose=False)["gficf"]
+    dim = R.vector(np.array(g.shape, dtype=np.int32))
+    cl = (np.arange(400) * 7 % 5).astype(np.int32)
+    sig = R.call("_gficf_cluster_signatures", R.vector(g.indices), R.vector(g.indptr.astype(np.int32)), R.vector(g.data), dim, R.vector(cl),
+                 R.vector(np.array([5], dtype=np.int32)))
+    _check_call_hygiene(R)
+    want_sig = np.stack([np.asarray(g[:, cl == c].sum(axis=1)).ravel() for c in range(5)], axis=1)
+    assert sig.dim == (g.shape[0], 5) and np.allclose(sig.numpy(), want_sig, rtol=1e-9, atol=1e-12)
+    tr = R.call("_gficf_transpose_csc", R.vector(g.indices), R.vector(g.indptr.astype(np.int32)), R.vector(g.data), dim)
+    _check_call_hygiene(R)
+    gt = sp.csc_matrix(g.T)
+    gt.sort_indices()
+    assert np.array_equal(tr.elt(0).numpy(), gt.indices) and np.array_equal(tr.elt(1).numpy(), gt.indptr) and np.array_equal(tr.elt(2).numpy(), gt.data)
+    # clustcells() lines 57-86 in one call: labels + two attributes
+    ph = R.call("_gficf_phenograph", R.matrix(X), R.vector(np.array([10], dtype=np.int32)), R.vector(np.array([0], dtype=np.int32)), R.vector(np.array([0.8])),
+                R.vector(np.array([1], dtype=np.int32)), R.vector(np.array([1], dtype=np.int32)), R.vector(np.array([10], dtype=np.int32)),
+                R.vector(np.array([0], dtype=np.int32)))
+    _check_call_hygiene(R)
+    want_ph = gficf_amd.phenograph(X, 10, "manhattan", 0.8, 1, 1, 10, 0)
+    assert np.array_equal(ph.numpy(), np.asarray(want_ph))
+    assert abs(float(ph.attr("modularity").numpy()[0]) - want_ph.modularity) < 1e-12 and float(ph.attr("n.edges").numpy()[0]) == want_ph.n_edges

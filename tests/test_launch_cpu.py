@@ -76,3 +76,31 @@ def test_bench_self_launch_reaches_the_ranks_on_a_cpu_box():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "1", "--warmup", "0", "--no-extras"],
                        capture_output=True, text=True, timeout=240, env=e)
     assert r.returncode != 0 and "needs a GPU" in r.stderr and r.stdout.strip() == ""
+
+
+def test_gpu_count_comes_from_sysfs_not_from_the_hip_runtime(tmp_path, monkeypatch):
+    """The launcher counts GPUs from the KFD topology (nodes with SIMDs), narrowed by the *_VISIBLE_DEVICES lists — the HIP
+    runtime is never loaded in the parent."""
+    sys.path.insert(0, ROOT)
+    from gficf_amd import launch
+
+    root = tmp_path / "nodes"
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):              # two CPU nodes, three GPUs
+        (root / str(i)).mkdir(parents=True)
+        (root / str(i) / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    assert launch.kfd_gpu_nodes(str(root)) == 3
+    assert launch.kfd_gpu_nodes(str(tmp_path / "missing")) is None
+    monkeypatch.setattr(launch, "kfd_gpu_nodes", lambda root=None: 8)
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert launch.visible_gpus() == 8
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert launch.visible_gpus() == 3
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "4")
+    assert launch.visible_gpus() == 1
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "")
+    assert launch.visible_gpus() == 0
+    # and the module does not pull torch (hence no HIP runtime) into the launcher
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); import gficf_amd.launch as l; l.visible_gpus(); "
+                        "print('torch' in sys.modules)"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "False", (r.stdout, r.stderr[-500:])

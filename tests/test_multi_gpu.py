@@ -145,3 +145,54 @@ def test_host_entries_do_not_allocate_per_call_and_trim_releases():
     assert torch.cuda.mem_get_info()[0] > free1
     calls()                                                    # usable after a trim
     ctx.close()
+
+
+@pytest.mark.parametrize("devices,N,k,f64", [([0, 0], 5001, 30, False), ([0, 0, 0], 20000, 15, False), ([0, 0], 3000, 50, True),
+                                             ([0, 0, 0], 140000, 30, False), ([0], 4000, 30, False)])
+def test_device_resident_multi_step_with_peer_copies(devices, N, k, f64):
+    """gficf_multi_jaccard_device: every block already in HBM, every device (here: contexts on the one GPU of the box) ingests its
+    block, pulls the other table slices with hipMemcpyPeerAsync on copy streams of its own and builds its block's edges — bit for
+    bit the single-device result; a second step over the same buffers (ordered behind the first by events) gives it again."""
+    import torch
+
+    import oracle
+    from gficf_amd.api import MultiContext
+
+    mat = synth.knn_windowed(N, k, seed=4, perm_seed=5)
+    mat2 = synth.knn_windowed(N, k, seed=6, perm_seed=7)
+    want, _ = oracle.jaccard(mat, nthreads=8) if N <= 20000 else (gficf_amd.rcpp_parallel_jaccard_coef(mat, False), None)
+    mc = MultiContext(devices)
+    P = len(devices)
+    bd = mc.cell_blocks(N)
+    rw = gficf_amd.HipOps.row_words(N, k)
+    dt = torch.float64 if f64 else torch.int32
+    blocks = lambda m: [torch.from_numpy(np.ascontiguousarray(m[bd[r]:bd[r + 1]].T)).to("cuda:0").to(dt).contiguous() for r in range(P)]
+    i1, i2 = blocks(mat), blocks(mat2)
+    tables = [torch.zeros((N, rw), dtype=torch.int32, device="cuda:0") for _ in range(P)]
+    outs = [torch.zeros((3, (bd[r + 1] - bd[r]) * k), dtype=torch.float64, device="cuda:0") for r in range(P)]
+    torch.cuda.synchronize()
+    for distinct in (False, True):
+        mc.set_jaccard_distinct(distinct)
+        mc.jaccard_device(i2, N, k, tables, outs)          # a step on other data first: the next one must wait for its pulls
+        mc.jaccard_device(i1, N, k, tables, outs)
+        mc.sync()
+        got = torch.cat(outs, dim=1).cpu().numpy().T
+        assert np.array_equal(got, want), (devices, N, k, distinct)
+        for t in tables[1:]:
+            assert torch.equal(t, tables[0])                # every device ends with the whole table
+    # deferred errors come out of the sync: a bad id in the last block
+    bad = blocks(mat)
+    bad[-1][0, 0] = N + 1
+    mc.jaccard_device(bad, N, k, tables, outs)
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        mc.sync()
+    assert ei.value.status == "GFICF_ERR_BAD_ID"
+    if not f64:
+        dup = blocks(mat)
+        dup[0][1, 3] = dup[0][0, 3]                          # a repeated id in a row: reported in distinct mode, exact otherwise
+        mc.set_jaccard_distinct(True)
+        mc.jaccard_device(dup, N, k, tables, outs)
+        with pytest.raises(gficf_amd.GficfError) as ei:
+            mc.sync()
+        assert ei.value.status == "GFICF_ERR_DUPLICATE_IDS"
+    mc.close()
