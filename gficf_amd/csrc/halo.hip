@@ -3,8 +3,8 @@
 // What is sharded: the cells of the reference's parallelFor(0, N, worker) (src/rcpp_parallel_jaccard_coeff.cpp:73); the edges of
 // cell i need row i and the k rows it names (:28-36).  With the all-gather form every rank holds the whole table; when the ids
 // have locality (cells in a spatial / cluster order) a block names few rows outside itself, and this form fetches only those:
-//   plan    : mark the ids the block names outside itself in a bitmap over all cells, rank the set bits, and list them per
-//             owner in fixed-capacity request slots (cap ids per owner: the all-to-alls that follow have equal, host-known
+//   plan    : mark the ids the block names outside itself in an owner-aligned bitmap over all cells (k_halo_mark), then — one
+//             workgroup per owner, one launch — rank each owner's set bits and list them in the owner's fixed-capacity request slots (cap ids per owner: the all-to-alls that follow have equal, host-known
 //             sizes — no count exchange, no host round trip; a block that names more than cap rows of one owner raises
 //             GFICF_ERR_CAPACITY at the next sync and the caller switches to the all-gather form);
 //   serve   : the owner copies the requested rows of ITS input block (raw global ids) into reply slots;
@@ -26,12 +26,19 @@ namespace {
 
 constexpr int HP_THREADS = 1024;
 
+// owner-aligned position of a global id's bit: word r * wpo + (local >> 5), bit local & 31 (halo_map.h)
+__device__ inline void halo_bit_of(uint32_t id, uint32_t rpr, uint32_t wpo, uint32_t& w, uint32_t& m) {
+  const uint32_t bit = id - 1u, owner = bit / rpr, local = bit - owner * rpr;
+  w = owner * wpo + (local >> 5);
+  m = 1u << (local & 31u);
+}
+
 // K1: bits of the ids this block names outside itself.  idx: (k, ld) column-major block, global 1-based ids.  With locality the few outside ids of a wave fall into one or two bitmap words,
 // named ~k times each across the block: the lanes of a wave that hit the same word OR their bits together and ONE lane issues
 // the atomic (a first version issued one atomic per reference: a few thousand atomics on a dozen words = 30 us of L2
 // serialisation at 100 k cells).
 __global__ __launch_bounds__(256) void k_halo_mark(const int32_t* __restrict__ idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
-                                                   int64_t b, uint32_t* __restrict__ bitmap) {
+                                                   int64_t b, uint32_t rpr, uint32_t wpo, uint32_t* __restrict__ bitmap) {
   // grid: x over the cells (whole waves), y over the slots — the few waves that sit on a block seam have outside ids in every
   // slot; one slot per wave spreads their serial word-by-word loop below over k waves instead of one
   const int lane = threadIdx.x & 63;
@@ -40,8 +47,10 @@ __global__ __launch_bounds__(256) void k_halo_mark(const int32_t* __restrict__ i
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_round; i += (int64_t)gridDim.x * 256) {
     const int64_t id = i < n_local ? (int64_t)idx[(int64_t)j * ld + i] : 0;
     bool pend = id >= 1 && id <= N_total && (id <= b || id > b + n_local);
-    const uint32_t w = (uint32_t)((id - 1) >> 5), m = 1u << ((id - 1) & 31);
     unsigned long long pm = __ballot(pend);
+    if (pm == 0ull) continue;                                    // (the common case: every id of the wave lies inside the block)
+    uint32_t w = 0, m = 0;
+    if (pend) halo_bit_of((uint32_t)id, rpr, wpo, w, m);
     while (pm) {                                                 // wave-uniform; rarely entered
       const int leader = __builtin_ctzll(pm);
       const uint32_t wl = (uint32_t)__shfl((int)w, leader);
@@ -57,32 +66,34 @@ __global__ __launch_bounds__(256) void k_halo_mark(const int32_t* __restrict__ i
   }
 }
 
-// K2 (one workgroup): exclusive rank of every bitmap word and the first rank of every owner; clears the request slots.
-// word_rank[w] = set bits in words < w; owner_start[r] = rank of the first bit of owner r (r = 0..P; [P] = all set bits).
-// The bitmap is swept in super-tiles of 1024 threads x 32 words; a thread's 32 words are 8 independent 16 B loads (a first
-// version walked its words one dependent load at a time: 78 us at 800 k cells against 4).  `words` is a multiple of 4 and the
-// buffers are 16 B aligned (gficf_jaccard_halo_workspace_bytes).
-constexpr int HP_PER = 32;                          // words per thread and super-tile
-
-__global__ __launch_bounds__(HP_THREADS) void k_halo_compact(const uint32_t* __restrict__ bitmap, int64_t words, int64_t N_total, int P, int64_t rpr,
-                                                             int cap, int32_t* __restrict__ word_rank, int32_t* __restrict__ owner_start,
-                                                             int32_t* __restrict__ req_out, uint32_t* __restrict__ status) {
+// K2 (one workgroup PER OWNER): rank of every bitmap word inside its owner, the owner's request slots, and the bitmap handed back
+// all zero.  Round 3 ranked the whole bitmap in ONE workgroup and listed the bits in a third launch (plus a memset in front of
+// the marking): 20 us of a 79 us chain at 8 ranks.  Owner-aligned words make the owners independent — a rank inside the owner IS
+// the request slot — so P workgroups do rank + list side by side in one launch, and the word a thread has read it clears (the next
+// step's marking finds zeros: no memset launch); what later kernels look up is winfo = {word, rank}, one 8 B load.
+// A thread owns 4 consecutive words of a sweep (one 16 B load); the owner's wpo words are swept in super-tiles of 4096 words.
+__global__ __launch_bounds__(HP_THREADS) void k_halo_rank_emit(uint32_t* __restrict__ bitmap, uint2* __restrict__ winfo, uint32_t wpo, int64_t rpr,
+                                                               int cap, int32_t* __restrict__ req_out, uint32_t* __restrict__ status) {
   __shared__ int s_wave[HP_THREADS / 64];
   __shared__ int s_run;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int owner = blockIdx.x;
   typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-  typedef int v4i __attribute__((ext_vector_type(4)));
+  uint32_t* const bm = bitmap + (size_t)owner * wpo;
+  uint2* const wi = winfo + (size_t)owner * wpo;
+  int32_t* const slots = req_out + (int64_t)owner * cap;
   if (tid == 0) s_run = 0;
-  for (int64_t t = tid; t < (int64_t)P * cap; t += HP_THREADS) req_out[t] = 0;       // clear the request slots
+  for (int t = tid; t < cap; t += HP_THREADS) slots[t] = 0;      // clear the owner's request slots
   __syncthreads();
-  for (int64_t st = 0; st < words; st += (int64_t)HP_THREADS * HP_PER) {
-    const int64_t w0 = st + (int64_t)tid * HP_PER;
-    v4u v[HP_PER / 4];
-#pragma unroll
-    for (int c = 0; c < HP_PER / 4; ++c) v[c] = (w0 + 4 * c < words) ? *reinterpret_cast<const v4u*>(bitmap + w0 + 4 * c) : v4u{0u, 0u, 0u, 0u};
-    int cnt = 0;
-#pragma unroll
-    for (int c = 0; c < HP_PER / 4; ++c) cnt += __popc(v[c].x) + __popc(v[c].y) + __popc(v[c].z) + __popc(v[c].w);
+  bool over = false;
+  for (uint32_t st = 0; st < wpo; st += HP_THREADS * 4) {
+    const uint32_t w0 = st + (uint32_t)tid * 4u;
+    v4u v = {0u, 0u, 0u, 0u};
+    if (w0 < wpo) {                                              // (wpo is a multiple of 4)
+      v = *reinterpret_cast<const v4u*>(bm + w0);
+      if ((v.x | v.y | v.z | v.w) != 0u) *reinterpret_cast<v4u*>(bm + w0) = v4u{0u, 0u, 0u, 0u};   // hand the bitmap back clear
+    }
+    const int cnt = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
     int incl = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -94,69 +105,40 @@ __global__ __launch_bounds__(HP_THREADS) void k_halo_compact(const uint32_t* __r
     int run = s_run + incl - cnt;
 #pragma unroll
     for (int w = 0; w < HP_THREADS / 64; ++w) run += w < wave ? s_wave[w] : 0;
+    if (w0 < wpo) {
+      const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+      int r = run;
 #pragma unroll
-    for (int c = 0; c < HP_PER / 4; ++c) {
-      if (w0 + 4 * c < words) {
-        v4i o;
-        o.x = run; run += __popc(v[c].x);
-        o.y = run; run += __popc(v[c].y);
-        o.z = run; run += __popc(v[c].z);
-        o.w = run; run += __popc(v[c].w);
-        *reinterpret_cast<v4i*>(word_rank + w0 + 4 * c) = o;
+      for (int c = 0; c < 4; ++c) {
+        wi[w0 + c] = make_uint2(wd[c], (uint32_t)r);
+        uint32_t rest = wd[c];
+        while (rest) {                                           // the word's set bits into their slots (independent stores)
+          const int bpos = __builtin_ctz(rest);
+          rest &= rest - 1u;
+          if (r < cap) slots[r] = (int32_t)((int64_t)owner * rpr + (int64_t)(w0 + c) * 32 + bpos + 1);
+          else over = true;
+          ++r;
+        }
       }
     }
     __syncthreads();
-    if (tid == HP_THREADS - 1) s_run = run;          // (the last thread's running count is the tile's inclusive total)
+    if (tid == HP_THREADS - 1) s_run = run + cnt;                // the last thread's inclusive count is the sweep's total
     __syncthreads();
   }
-  const int total = s_run;
-  if (tid <= P) {                                   // word_rank is complete (same workgroup, behind the barriers above)
-    int64_t bit = (int64_t)tid * rpr;               // first bit of owner tid
-    if (bit > N_total) bit = N_total;
-    int v = total;
-    if (bit < N_total) {
-      const int64_t w = bit >> 5;
-      v = word_rank[w] + __popc(bitmap[w] & ((1u << (bit & 31)) - 1u));
-    }
-    owner_start[tid] = v;
-  }
+  if (over) atomicOr(status, GFICF_ST_HALO_OVERFLOW);
 }
 
-// K2b: every set bit into its owner's list — one thread per id (a first version let the thread that owns a bitmap word walk its
-// bits: with locality the set bits sit in a dozen words, i.e. in three or four threads, 50 dependent steps each: 60-90 us).
-__global__ __launch_bounds__(256) void k_halo_emit(const uint32_t* __restrict__ bitmap, int64_t N_total, int P, int64_t rpr, int cap,
-                                                   const int32_t* __restrict__ word_rank, const int32_t* __restrict__ owner_start,
-                                                   int32_t* __restrict__ req_out, uint32_t* __restrict__ status) {
-  for (int64_t bit = (int64_t)blockIdx.x * 256 + threadIdx.x; bit < N_total; bit += (int64_t)gridDim.x * 256) {
-    const int64_t w = bit >> 5;
-    const uint32_t word = bitmap[w], m = 1u << (bit & 31);
-    if ((word & m) == 0u) continue;
-    const int owner = (int)(bit / rpr);
-    const int pos = word_rank[w] + __popc(word & (m - 1u)) - owner_start[owner];
-    if (pos < cap) req_out[(int64_t)owner * cap + pos] = (int32_t)(bit + 1);
-    else atomicOr(status, GFICF_ST_HALO_OVERFLOW);
-  }
-}
-
-// K3: the rows asked of this rank.  req_in: n_req ids (0 = empty slot: nothing is written, the requester reads a slot's row only
-// where it asked for one), all inside this rank's block (b, b + n_local].  One thread per (slot, j).
+// K3: the rows asked of this rank (halo_map.h: gficf_halo_serve_rows) as a launch of its own; the fused form lets it ride in the
+// launch that ingests the own cells (jaccard.hip: gficf_jaccard_halo_serve_ingest_device).
 __global__ __launch_bounds__(256) void k_halo_serve(const int32_t* __restrict__ idx, int64_t n_local, int k, int64_t ld, int64_t b,
                                                     const int32_t* __restrict__ req_in, int64_t n_req, int32_t* __restrict__ rows_out,
                                                     uint32_t* __restrict__ status) {
-  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n_req; q += (int64_t)gridDim.x * 256) {
-    const int64_t id = req_in[q];
-    if (id == 0) continue;
-    const int64_t row = id - 1 - b;
-    const bool ok = row >= 0 && row < n_local;
-    if (!ok) atomicOr(status, GFICF_ST_BAD_ID);    // a request for a row this rank does not own: the ranks disagree on the blocks
-    for (int j = 0; j < k; ++j) rows_out[q * k + j] = ok ? idx[(int64_t)j * ld + row] : 0;
-  }
+  gficf_halo_serve_rows(idx, n_local, k, ld, b, req_in, n_req, rows_out, status, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
 }
 
 // K4: extended index matrix (k, n_ext) in local ids + the local -> global map.  n_ext = n_local + P * cap.
 __global__ __launch_bounds__(256) void k_halo_relabel(const int32_t* __restrict__ idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
-                                                      int64_t b, int P, int64_t rpr, int cap, const uint32_t* __restrict__ bitmap,
-                                                      const int32_t* __restrict__ word_rank, const int32_t* __restrict__ owner_start,
+                                                      int64_t b, int P, int64_t rpr, int cap, const uint2* __restrict__ winfo, uint32_t wpo,
                                                       const int32_t* __restrict__ req_out, const int32_t* __restrict__ rows_in,
                                                       int32_t* __restrict__ idx_ext, int32_t* __restrict__ l2g) {
   const int64_t n_ext = n_local + (int64_t)P * cap;
@@ -165,14 +147,14 @@ __global__ __launch_bounds__(256) void k_halo_relabel(const int32_t* __restrict_
     const int64_t j = t / n_ext, i = t - j * n_ext;
     int32_t v;
     if (i < n_local) {
-      v = gficf_halo_local(idx[j * ld + i], N_total, b, n_local, rpr, cap, bitmap, word_rank, owner_start);
+      v = gficf_halo_local(idx[j * ld + i], N_total, b, n_local, rpr, cap, winfo, wpo);
       if (j == 0) l2g[i] = (int32_t)(b + i + 1);
     } else {
       const int64_t q = i - n_local;
       const int32_t gid = req_out[q];
       v = 0;
       if (gid != 0) {
-        v = gficf_halo_local(rows_in[q * k + j], N_total, b, n_local, rpr, cap, bitmap, word_rank, owner_start);
+        v = gficf_halo_local(rows_in[q * k + j], N_total, b, n_local, rpr, cap, winfo, wpo);
         if (v < 0) v = 0;                          // (its owner's ingest reports the bad id)
       }
       if (j == 0) l2g[i] = gid;
@@ -187,9 +169,9 @@ extern "C" {
 
 size_t gficf_jaccard_halo_workspace_bytes(int64_t N_total, int P) {
   if (N_total < 0 || P < 1) return 0;
-  const size_t words = ((size_t)((N_total + 31) / 32) + 4) & ~(size_t)3;
-  // bitmap | word_rank | owner_start (P + 1)
-  return ((words * 4 + 255) & ~(size_t)255) * 2 + (((size_t)P + 1) * 4 + 255 & ~(size_t)255);
+  const size_t wpo = (size_t)gficf_halo_wpo(gficf_ceil_div(N_total > 0 ? N_total : 1, P));
+  // bitmap (P * wpo words) | winfo (P * wpo x 8 B)
+  return (((size_t)P * wpo * 4 + 255) & ~(size_t)255) + (size_t)P * wpo * 8 + 256;
 }
 
 int gficf_jaccard_halo_plan_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
@@ -197,30 +179,25 @@ int gficf_jaccard_halo_plan_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t
   GFICF_CTX_ENTER(ctx);
   if (n_local < 0 || k < 0 || N_total < 0 || cell_begin < 0 || cell_begin + n_local > N_total || P < 1 || rows_per_rank < 1 || cap < 1)
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "halo plan: sizes out of range");
-  if ((int64_t)P * rows_per_rank < N_total) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "halo plan: P * rows_per_rank < N_total");
-  if (N_total > 0x7FFFFFFFll || P > HP_THREADS - 1) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "halo plan: N_total beyond int32 ids or more than %d ranks", HP_THREADS - 1);
+  if (rows_per_rank != gficf_ceil_div(N_total > 0 ? N_total : 1, P))
+    GFICF_FAIL(GFICF_ERR_INVALID_ARG, "halo plan: rows_per_rank = %lld, expected ceil(N_total / P) = %lld (equal-pitch blocks; the workspace is laid out for it)",
+               (long long)rows_per_rank, (long long)gficf_ceil_div(N_total > 0 ? N_total : 1, P));
+  if (N_total > 0x7FFFFFFFll || P > 65535) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "halo plan: N_total beyond int32 ids or more than 65535 ranks");
   if (k > GFICF_JACCARD_MAX_K) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d neighbours per cell: this build handles at most GFICF_JACCARD_MAX_K = %d", k, GFICF_JACCARD_MAX_K);
   if (!d_ws || !d_req_out || (n_local > 0 && k > 0 && !d_idx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   if (n_local > 0 && ld < n_local) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld < n_local");
-  const int64_t words = ((N_total + 31) / 32 + 4) & ~(int64_t)3;
-  const size_t seg = ((size_t)words * 4 + 255) & ~(size_t)255;
+  const int64_t wpo = gficf_halo_wpo(rows_per_rank);
   uint32_t* const bitmap = (uint32_t*)d_ws;
-  int32_t* const word_rank = (int32_t*)((char*)d_ws + seg);
-  int32_t* const owner_start = (int32_t*)((char*)d_ws + 2 * seg);
-  GFICF_HIP_CHECK(hipMemsetAsync(bitmap, 0, (size_t)words * 4, ctx->stream));
+  uint2* const winfo = (uint2*)((char*)d_ws + (((size_t)P * (size_t)wpo * 4 + 255) & ~(size_t)255));
+  // (no memset: the bitmap is zero when the workspace is new — the caller zeroes it once — and k_halo_rank_emit hands it back zero)
   if (n_local > 0 && k > 0) {
     int64_t blocks = gficf_ceil_div(n_local, 256 * 4);
     if (blocks > (int64_t)ctx->num_cus * 4) blocks = (int64_t)ctx->num_cus * 4;
-    hipLaunchKernelGGL(k_halo_mark, dim3((unsigned)blocks, (unsigned)k), dim3(256), 0, ctx->stream, d_idx, n_local, k, ld, N_total, cell_begin, bitmap);
+    hipLaunchKernelGGL(k_halo_mark, dim3((unsigned)blocks, (unsigned)k), dim3(256), 0, ctx->stream, d_idx, n_local, k, ld, N_total, cell_begin,
+                       (uint32_t)rows_per_rank, (uint32_t)wpo, bitmap);
   }
-  hipLaunchKernelGGL(k_halo_compact, dim3(1), dim3(HP_THREADS), 0, ctx->stream, bitmap, words, N_total, P, rows_per_rank, cap, word_rank,
-                     owner_start, d_req_out, ctx->d_status);
-  if (N_total > 0) {
-    int64_t eb = gficf_ceil_div(N_total, 256);
-    if (eb > (int64_t)ctx->num_cus * 16) eb = (int64_t)ctx->num_cus * 16;
-    hipLaunchKernelGGL(k_halo_emit, dim3((unsigned)eb), dim3(256), 0, ctx->stream, bitmap, N_total, P, rows_per_rank, cap, word_rank, owner_start,
-                       d_req_out, ctx->d_status);
-  }
+  hipLaunchKernelGGL(k_halo_rank_emit, dim3((unsigned)P), dim3(HP_THREADS), 0, ctx->stream, bitmap, winfo, (uint32_t)wpo, rows_per_rank, cap, d_req_out,
+                     ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -247,15 +224,12 @@ int gficf_jaccard_halo_relabel_device(gficf_ctx* ctx, const int32_t* d_idx, int6
   if (!d_ws || !d_req_out || !d_rows_in || !d_idx_ext || !d_l2g || (n_local > 0 && k > 0 && !d_idx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   const int64_t n_ext = n_local + (int64_t)P * cap;
   if (n_ext * (int64_t)k == 0) return GFICF_OK;
-  const int64_t words = ((N_total + 31) / 32 + 4) & ~(int64_t)3;
-  const size_t seg = ((size_t)words * 4 + 255) & ~(size_t)255;
-  const uint32_t* const bitmap = (const uint32_t*)d_ws;
-  const int32_t* const word_rank = (const int32_t*)((const char*)d_ws + seg);
-  const int32_t* const owner_start = (const int32_t*)((const char*)d_ws + 2 * seg);
+  const int64_t wpo = gficf_halo_wpo(rows_per_rank);
+  const uint2* const winfo = (const uint2*)((const char*)d_ws + (((size_t)P * (size_t)wpo * 4 + 255) & ~(size_t)255));
   int64_t blocks = gficf_ceil_div(n_ext * (int64_t)k, 256 * 8);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
   hipLaunchKernelGGL(k_halo_relabel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_idx, n_local, k, ld, N_total, cell_begin, P,
-                     rows_per_rank, cap, bitmap, word_rank, owner_start, d_req_out, d_rows_in, d_idx_ext, d_l2g);
+                     rows_per_rank, cap, winfo, (uint32_t)wpo, d_req_out, d_rows_in, d_idx_ext, d_l2g);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }

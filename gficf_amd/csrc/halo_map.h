@@ -1,17 +1,30 @@
-// halo_map.h — global id -> local id of a rank's sub-problem (csrc/halo.hip builds the bitmap and the ranks; the ingest of
-// jaccard.hip applies the map on the fly in its fused form).
+// halo_map.h — global id -> local id of a rank's sub-problem (csrc/halo.hip builds the per-owner bitmap and its ranks; the ingest
+// of jaccard.hip applies the map on the fly in its fused form), and the owner-side "serve" step that shares a launch with it.
 #pragma once
 #include "common.h"
 
+// The plan's workspace (gficf_jaccard_halo_workspace_bytes): OWNER-ALIGNED — owner r's rows are bits [0, rpr) of the wpo words
+// that start at word r * wpo (wpo = words per owner, a multiple of 4) — so that one workgroup ranks one owner's bits on its own
+// and a rank is a rank WITHIN the owner (= the request slot): no global scan, no owner_start table.
+//   bitmap : P * wpo words, all zero between steps (the ranking kernel clears what it has read: no memset launch per step)
+//   winfo  : P * wpo x {word, set bits of the owner in front of the word}: what the lookups read (one 8 B load)
+__host__ __device__ inline int64_t gficf_halo_wpo(int64_t rpr) { return (((rpr + 31) / 32) + 3) & ~(int64_t)3; }
+
 struct gficf_halo_map {
-  const uint32_t* bitmap;        // bit (id - 1): the block names id outside itself
-  const int32_t* word_rank;      // set bits in the words before a word
-  const int32_t* owner_start;    // rank of the first bit of every owner
+  const uint2* winfo;            // P * wpo x {bitmap word, rank of its first bit inside the owner}
   const int32_t* req_out;        // P * cap requested ids (0 = empty slot)
   const int32_t* rows_in;        // P * cap x k reply slots (raw global ids)
   int32_t* l2g;                  // out: global id of every local row
   int64_t n_local, N_total, b, rpr;
   int cap;
+  uint32_t wpo;
+  // rows [row_begin, row_end) of the sub-problem are ingested by this launch (own cells: [0, n_local); halo slots: behind them)
+  int64_t row_begin, row_end;
+  // the owner-side serve step riding in the same launch (the LAST serve_blocks workgroups): copies the rows asked of this rank
+  const int32_t* req_in;
+  int64_t n_req;
+  int32_t* rows_out;
+  int serve_blocks;
 };
 
 // local id of a global id (1-based both); 0: not part of this rank's sub-problem; -1: not an id at all.  32-bit arithmetic on the
@@ -20,22 +33,36 @@ struct gficf_halo_map {
 // (the outside-the-block path is kept out of line: inlined eight times into the fused ingest it took the kernel from 103 to 181
 // vector registers and halved its occupancy)
 __device__ __noinline__ static int32_t gficf_halo_local_outside(uint32_t id, uint32_t N_total, uint32_t n_local, uint32_t rpr, int cap,
-                                                                const uint32_t* __restrict__ bitmap, const int32_t* __restrict__ word_rank,
-                                                                const int32_t* __restrict__ owner_start) {
+                                                                const uint2* __restrict__ winfo, uint32_t wpo) {
   const uint32_t bit = id - 1u;
   if (bit >= N_total) return -1;                                       // 0, negative or beyond N_total: the ingest reports it
-  const uint32_t w = bit >> 5, word = bitmap[w], m = 1u << (bit & 31u);
-  if ((word & m) == 0u) return 0;
-  const int owner = (int)(bit / rpr);
-  const int pos = word_rank[w] + __popc(word & (m - 1u)) - owner_start[owner];
-  return pos < cap ? (int32_t)(n_local + (uint32_t)owner * (uint32_t)cap + (uint32_t)pos + 1u) : 0;
+  const uint32_t owner = bit / rpr, local = bit - owner * rpr;
+  const uint2 wi = winfo[(size_t)owner * wpo + (local >> 5)];
+  const uint32_t m = 1u << (local & 31u);
+  if ((wi.x & m) == 0u) return 0;
+  const int pos = (int)wi.y + __popc(wi.x & (m - 1u));
+  return pos < cap ? (int32_t)(n_local + owner * (uint32_t)cap + (uint32_t)pos + 1u) : 0;
 }
 
 __device__ inline int32_t gficf_halo_local(int64_t id64, int64_t N_total, int64_t b, int64_t n_local, int64_t rpr, int cap,
-                                           const uint32_t* __restrict__ bitmap, const int32_t* __restrict__ word_rank,
-                                           const int32_t* __restrict__ owner_start) {
+                                           const uint2* __restrict__ winfo, uint32_t wpo) {
   const uint32_t id = (uint32_t)id64;                                  // (callers hand in int32 ids: a negative one wraps above N_total)
   const uint32_t rel = id - 1u - (uint32_t)b;
   if (rel < (uint32_t)n_local) return (int32_t)(rel + 1u);             // inside the block
-  return gficf_halo_local_outside(id, (uint32_t)N_total, (uint32_t)n_local, (uint32_t)rpr, cap, bitmap, word_rank, owner_start);
+  return gficf_halo_local_outside(id, (uint32_t)N_total, (uint32_t)n_local, (uint32_t)rpr, cap, winfo, wpo);
+}
+
+// The rows asked of this rank: req_in holds n_req ids (0 = empty slot: nothing is written, the requester reads a slot's row only
+// where it asked for one), all inside this rank's block (b, b + n_local].  One thread per slot; `first` / `stride` in threads.
+__device__ inline void gficf_halo_serve_rows(const int32_t* __restrict__ idx, int64_t n_local, int k, int64_t ld, int64_t b,
+                                             const int32_t* __restrict__ req_in, int64_t n_req, int32_t* __restrict__ rows_out,
+                                             uint32_t* __restrict__ status, int64_t first, int64_t stride) {
+  for (int64_t q = first; q < n_req; q += stride) {
+    const int64_t id = req_in[q];
+    if (id == 0) continue;
+    const int64_t row = id - 1 - b;
+    const bool ok = row >= 0 && row < n_local;
+    if (!ok) atomicOr(status, GFICF_ST_BAD_ID);    // a request for a row this rank does not own: the ranks disagree on the blocks
+    for (int j = 0; j < k; ++j) rows_out[q * k + j] = ok ? idx[(int64_t)j * ld + row] : 0;
+  }
 }

@@ -228,13 +228,29 @@ __global__ __launch_bounds__(256, HALO ? 4 : 1) void k_ingest_tile(const T* __re
   __shared__ uint32_t tile[ROWS][KPAD + 1];
   __shared__ uint32_t dup[ROWS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int64_t row0 = (int64_t)blockIdx.x * ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * ROWS) {
+  // HALO: the launch ingests rows [row_begin, row_end) of the sub-problem (n_rows = row_end); its LAST serve_blocks workgroups do the
+  // owner-side serve step instead (the rows other ranks asked of this one: independent of the ingest, one launch saved per step)
+  int64_t row_first = 0;
+  unsigned ingest_blocks = gridDim.x;
+  if constexpr (HALO) {
+    ingest_blocks = gridDim.x - (unsigned)hm.serve_blocks;
+    if (blockIdx.x >= ingest_blocks) {
+      gficf_halo_serve_rows(reinterpret_cast<const int32_t*>(idx), hm.n_local, k, ld, hm.b, hm.req_in, hm.n_req, hm.rows_out, status,
+                            (int64_t)(blockIdx.x - ingest_blocks) * 256 + tid, (int64_t)hm.serve_blocks * 256);
+      return;
+    }
+    row_first = hm.row_begin;
+  }
+  for (int64_t row0 = row_first + (int64_t)blockIdx.x * ROWS; row0 < n_rows; row0 += (int64_t)ingest_blocks * ROWS) {
     const int64_t r = row0 + lane;
     // all loads of the thread are issued before the first is looked at
     T raw[KPAD / 4];
     if constexpr (HALO) {
       const int64_t q = r - hm.n_local;                      // halo slot of this row (own cells: negative)
       const int32_t gid = (r < n_rows && q >= 0) ? hm.req_out[q] : 0;
+      // a tile of halo slots nobody asked for (most of them: the slots in use sit at the front of every owner's cap): nothing refers to
+      // its rows — skipped whole (every wave of the workgroup sees the same 64 slots: the decision is workgroup-uniform)
+      if (row0 >= hm.n_local && __ballot(gid != 0) == 0ull) continue;
       if (wave == 0 && r < n_rows) hm.l2g[r] = q < 0 ? (int32_t)(hm.b + r + 1) : gid;
       if (row0 + ROWS <= hm.n_local) {                       // a tile of own cells (workgroup-uniform): the plain loads, all in flight
 #pragma unroll
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(256, HALO ? 4 : 1) void k_ingest_tile(const T* __re
         if (j < k && r < n_rows) {
           int32_t v = 0;
           if (q < 0 || gid != 0) {
-            v = gficf_halo_local((int64_t)raw[m], hm.N_total, hm.b, hm.n_local, hm.rpr, hm.cap, hm.bitmap, hm.word_rank, hm.owner_start);
+            v = gficf_halo_local((int64_t)raw[m], hm.N_total, hm.b, hm.n_local, hm.rpr, hm.cap, hm.winfo, hm.wpo);
             if (q >= 0 && v < 0) v = 0;
           }
           raw[m] = (T)v;
@@ -1833,10 +1849,15 @@ int gficf_jaccard_ingest_local_device(gficf_ctx* ctx, const int32_t* d_idx_ext, 
 
 /* relabel + ingest in one launch (k <= 64): the sub-problem's table straight from the block's global ids, the reply slots and
  * the plan's workspace (csrc/halo.hip); also writes d_l2g.  Returns GFICF_ERR_UNSUPPORTED for k > 64 (the caller then runs
- * gficf_jaccard_halo_relabel_device + gficf_jaccard_ingest_local_device). */
-int gficf_jaccard_halo_ingest_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
-                                     int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
-                                     const int32_t* d_rows_in, int32_t* d_table, int32_t* d_l2g) {
+ * gficf_jaccard_halo_relabel_device + gficf_jaccard_ingest_local_device).
+ * Three forms of the one kernel: rows [0, n_ext) after both exchanges (gficf_jaccard_halo_ingest_device); the OWN cells' rows
+ * together with the owner-side serve step, between the two exchanges (gficf_jaccard_halo_serve_ingest_device: the own rows need
+ * the plan, not the replies); the halo slots' rows behind the second exchange (gficf_jaccard_halo_ingest_slots_device: a few
+ * hundred rows — what is left on the critical path between the replies and the edge kernel). */
+static int halo_ingest_launch(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total, int64_t cell_begin,
+                              int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out, const int32_t* d_rows_in,
+                              int32_t* d_table, int32_t* d_l2g, int64_t row_begin, int64_t row_end, const int32_t* d_req_in, int64_t n_req,
+                              int32_t* d_rows_out) {
   GFICF_CTX_ENTER(ctx);
   if (n_local < 0 || k < 0 || N_total < 0 || P < 1 || cap < 1 || rows_per_rank < 1 || cell_begin < 0 || cell_begin + n_local > N_total)
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "halo ingest: sizes out of range");
@@ -1845,26 +1866,30 @@ int gficf_jaccard_halo_ingest_device(gficf_ctx* ctx, const int32_t* d_idx, int64
   if (rc) return rc;
   if (k > 64) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "halo ingest: the fused form covers k <= 64");
   if (n_ext == 0 || k == 0) return GFICF_OK;
-  if (!d_ws || !d_req_out || !d_rows_in || !d_table || !d_l2g || (n_local > 0 && !d_idx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (!d_ws || !d_req_out || (row_end > n_local && !d_rows_in) || !d_table || !d_l2g || (n_local > 0 && !d_idx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (n_req > 0 && (!d_req_in || !d_rows_out)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer (serve step)");
   if (n_local > 0 && ld < n_local) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld < n_local");
-  const int64_t words = ((N_total + 31) / 32 + 4) & ~(int64_t)3;          // layout of gficf_jaccard_halo_workspace_bytes
-  const size_t seg = ((size_t)words * 4 + 255) & ~(size_t)255;
-  gficf_halo_map hm{(const uint32_t*)d_ws, (const int32_t*)((const char*)d_ws + seg), (const int32_t*)((const char*)d_ws + 2 * seg),
-                    d_req_out, d_rows_in, d_l2g, n_local, N_total, cell_begin, rows_per_rank, cap};
-  const TableFmt f = table_fmt(n_ext, k);
-  const int64_t tiles = gficf_ceil_div(n_ext, INGEST_ROWS);
+  const int64_t wpo = gficf_halo_wpo(rows_per_rank);                   // layout of gficf_jaccard_halo_workspace_bytes
   const int64_t gcap = (int64_t)ctx->num_cus * 8;
-  const unsigned grid = (unsigned)(tiles < gcap ? tiles : gcap);
+  const int64_t tiles = gficf_ceil_div(row_end - row_begin, INGEST_ROWS);
+  const unsigned grid_i = (unsigned)(tiles < gcap ? tiles : gcap);
+  int64_t sb = n_req > 0 ? gficf_ceil_div(n_req, 256) : 0;
+  if (sb > (int64_t)ctx->num_cus) sb = ctx->num_cus;
+  if (grid_i == 0 && sb == 0) return GFICF_OK;
+  gficf_halo_map hm{(const uint2*)((const char*)d_ws + (((size_t)P * (size_t)wpo * 4 + 255) & ~(size_t)255)), d_req_out, d_rows_in, d_l2g, n_local,
+                    N_total, cell_begin, rows_per_rank, cap, (uint32_t)wpo, row_begin, row_end, d_req_in, n_req, d_rows_out, (int)sb};
+  const TableFmt f = table_fmt(n_ext, k);
+  const unsigned grid = grid_i + (unsigned)sb;
   // rows taken to hold distinct ids (gficf_ctx_set_jaccard_distinct): no duplicate scan here either — a rank's own rows are
   // inserted by its mapped edge kernel, which reports a repeated id; the halo rows are own rows of the ranks that sent them
   const bool scan = !ctx->jaccard_assume_distinct;
 #define LAUNCH_HALO_INGEST(KP, CM)                                                                                                \
   do {                                                                                                                            \
     if (scan)                                                                                                                     \
-      hipLaunchKernelGGL((k_ingest_tile<int32_t, KP, CM, true>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_ext, k, ld, n_ext, \
+      hipLaunchKernelGGL((k_ingest_tile<int32_t, KP, CM, true>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, row_end, k, ld, n_ext, \
                          (uint32_t*)d_table, ctx->d_status, 1, hm);                                                               \
     else                                                                                                                          \
-      hipLaunchKernelGGL((k_ingest_tile<int32_t, KP, CM, true, false>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_ext, k, ld, \
+      hipLaunchKernelGGL((k_ingest_tile<int32_t, KP, CM, true, false>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, row_end, k, ld, \
                          n_ext, (uint32_t*)d_table, ctx->d_status, 1, hm);                                                        \
   } while (0)
   switch (f.kpad) {
@@ -1875,6 +1900,28 @@ int gficf_jaccard_halo_ingest_device(gficf_ctx* ctx, const int32_t* d_idx, int64
 #undef LAUNCH_HALO_INGEST
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
+}
+
+int gficf_jaccard_halo_ingest_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                     int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
+                                     const int32_t* d_rows_in, int32_t* d_table, int32_t* d_l2g) {
+  return halo_ingest_launch(ctx, d_idx, n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap, d_ws, d_req_out, d_rows_in, d_table, d_l2g, 0,
+                            n_local + (int64_t)P * cap, nullptr, 0, nullptr);
+}
+
+int gficf_jaccard_halo_serve_ingest_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                           int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
+                                           const int32_t* d_req_in, int64_t n_req, int32_t* d_rows_out, int32_t* d_table, int32_t* d_l2g) {
+  if (n_req < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "halo serve: negative size");
+  return halo_ingest_launch(ctx, d_idx, n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap, d_ws, d_req_out, nullptr, d_table, d_l2g, 0, n_local,
+                            d_req_in, n_req, d_rows_out);
+}
+
+int gficf_jaccard_halo_ingest_slots_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                           int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
+                                           const int32_t* d_rows_in, int32_t* d_table, int32_t* d_l2g) {
+  return halo_ingest_launch(ctx, d_idx, n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap, d_ws, d_req_out, d_rows_in, d_table, d_l2g, n_local,
+                            n_local + (int64_t)P * cap, nullptr, 0, nullptr);
 }
 
 /* Edges of the first n_cells rows of such a table; column 1 = src_offset + cell + 1, column 2 = d_l2g[local id - 1]. */

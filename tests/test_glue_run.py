@@ -135,7 +135,8 @@ def _call_gficf(R, M, w=None, pmin=0.05, pmax=1.0):
 def _check_gficf(res, ref, G, N):
     assert res.type == rmock.VECSXP and len(res) == 6
     oi, op, ox, keep, nt, w = (res.elt(i).numpy() for i in range(6))
-    assert np.array_equal(keep.astype(bool), ref["keep"].astype(bool)) and np.array_equal(nt, ref["nt"].astype(np.float64))
+    kb = ref["keep"].astype(bool)
+    assert np.array_equal(keep.astype(bool), kb) and np.array_equal(nt[kb], ref["nt"][kb].astype(np.float64))   # (the oracle reports 0 for dropped genes)
     assert np.array_equal(op, ref["colptr"]) and np.array_equal(oi, ref["rowidx"])
     assert np.allclose(ox, ref["x"], rtol=1e-6, atol=1e-6) and np.allclose(w, ref["w"], rtol=1e-6, atol=1e-6)   # north_star's tolerance
     assert np.abs(ox - ref["x"]).max(initial=0.0) < 1e-12                                                        # (observed)
@@ -151,6 +152,7 @@ def test_dot_call_gficf_entry_matches_the_oracle(R):
     res = _call_gficf(R, M)
     _check_call_hygiene(R)
     _check_gficf(res, ref, G, N)
+    assert np.array_equal(res.elt(4).numpy(), np.asarray((M != 0).sum(axis=1)).ravel().astype(np.float64))      # nt of EVERY gene: rowSums(M != 0), R/gficf.R:40
     # embedNewCells(): the ICF weights supplied (R/cellClassifier.R:50-53), filter open (max = 2, min = 0)
     w_in = np.abs(np.random.default_rng(2).normal(size=G)) + 0.1
     ref2 = oracle.gficf_csc(G, N, M.indptr.astype(np.int64), M.indices, M.data, 0.0, 2.0, w_in=w_in)
