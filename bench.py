@@ -745,10 +745,10 @@ def main():
         rot["i"] += 1
         sh = shards[d]
         if halo_form:
-            # the step's own ingest: relabel + ingest in one launch (k <= 64) over what the last step's plan and exchange left in
-            # the shard's buffers; the table it writes is the one the step wrote (the unfused kernel on an unused,
+            # the step's own ingest: the own cells' rows (relabel + ingest) and the serve step in one launch (k <= 64) over what the
+            # last step's plan and exchange left in the shard's buffers; the table rows it writes are the ones the step wrote (the unfused kernel on an unused,
             # all-zero index matrix was timed here before — not the step's kernel, and it clobbered the table)
-            if not ops.halo_ingest(idx_local[d], n_local, k, N_total, b, world, sh.rpr, sh.cap, sh.ws, sh.req_out, sh.rows_in, sh.table, sh.l2g):
+            if not ops.halo_serve_ingest(idx_local[d], n_local, k, N_total, b, world, sh.rpr, sh.cap, sh.ws, sh.req_out, sh.req_in, sh.rows_out, sh.table, sh.l2g):
                 ops.halo_relabel(idx_local[d], n_local, k, N_total, b, world, sh.rpr, sh.cap, sh.ws, sh.req_out, sh.rows_in, sh.idx_ext, sh.l2g)
                 ops.jaccard_ingest_local(sh.idx_ext, sh.n_ext, k, sh.table)
         else:

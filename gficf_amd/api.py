@@ -783,6 +783,23 @@ class HipOps:
                                                       _tptr(ws), _tptr(req_out), _tptr(rows_in), _tptr(table), _tptr(l2g)))
         return True
 
+    def halo_serve_ingest(self, idx_cm, n_local, k, N_total, cell_begin, P, rows_per_rank, cap, ws, req_out, req_in, rows_out, table, l2g) -> bool:
+        """Between the two exchanges, ONE launch (k <= 64): the rows asked of this rank (``req_in`` -> ``rows_out``) and the table
+        rows of the own cells (they need the plan, not the replies).  False: k > 64, nothing enqueued (run the unfused calls)."""
+        if k > 64:
+            return False
+        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else n_local
+        check(self.L.gficf_jaccard_halo_serve_ingest_device(self._bind(), _tptr(idx_cm), n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap,
+                                                            _tptr(ws), _tptr(req_out), _tptr(req_in), int(req_in.numel()), _tptr(rows_out),
+                                                            _tptr(table), _tptr(l2g)))
+        return True
+
+    def halo_ingest_slots(self, idx_cm, n_local, k, N_total, cell_begin, P, rows_per_rank, cap, ws, req_out, rows_in, table, l2g):
+        """Behind the second exchange: the table rows of the halo slots in use, from the replies (k <= 64)."""
+        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else n_local
+        check(self.L.gficf_jaccard_halo_ingest_slots_device(self._bind(), _tptr(idx_cm), n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap,
+                                                            _tptr(ws), _tptr(req_out), _tptr(rows_in), _tptr(table), _tptr(l2g)))
+
     def jaccard_ingest_local(self, idx_ext, n_ext, k, table):
         """idx_ext: (k, n_ext) int32 local ids (0 = no id).  table: (n_ext, row_words(n_ext, k)) int32."""
         check(self.L.gficf_jaccard_ingest_local_device(self._bind(), _tptr(idx_ext), n_ext, k, n_ext, _tptr(table)))

@@ -367,6 +367,16 @@ class JaccardHaloShard:
             _all_to_all(bf["req_in"], bf["req_out"], None, None, self.group)
         else:
             bf["req_in"].copy_(bf["req_out"])
+        split = getattr(o, "halo_serve_ingest", None)     # k <= 64: serve + the own cells' table rows in ONE launch between the exchanges
+        if split is not None and split(idx_local_cm, nl, k, self.N, self.b, P, self.rpr, self.cap, bf["ws"], bf["req_out"], bf["req_in"], bf["rows_out"],
+                                       bf["table"], bf["l2g"]):
+            if P > 1:
+                _all_to_all(bf["rows_in"], bf["rows_out"], None, None, self.group)
+            else:
+                bf["rows_in"].copy_(bf["rows_out"])
+            # ... and only the halo slots in use (a few hundred rows) behind the second one
+            o.halo_ingest_slots(idx_local_cm, nl, k, self.N, self.b, P, self.rpr, self.cap, bf["ws"], bf["req_out"], bf["rows_in"], bf["table"], bf["l2g"])
+            return
         o.halo_serve(idx_local_cm, nl, k, self.b, bf["req_in"], bf["rows_out"])
         if P > 1:
             _all_to_all(bf["rows_in"], bf["rows_out"], None, None, self.group)

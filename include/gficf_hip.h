@@ -206,6 +206,15 @@ int gficf_jaccard_edges_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N
  *   reference's matrix, bit for bit what the all-gather form gives.  With n_ext < 2^17 the sub-problem takes the compact
  *   64 B-row table whatever N_total is.  d_idx: the block's (k, ld) column-major int32 ids (what the sharded path carries);
  *   d_ws: gficf_jaccard_halo_workspace_bytes(N_total, P) bytes, written by plan and read by relabel. */
+/* Round 4: the workspace is OWNER-ALIGNED (owner r's rows are the bits of its own run of words), so the plan is TWO launches —
+ * mark, then one workgroup per owner that ranks the owner's bits, lists them in its request slots and hands the bitmap back
+ * zero (no memset per step: the CALLER ZEROES d_ws ONCE, before its first plan; after that the library keeps it consistent) —
+ * and rows_per_rank must be ceil(N_total / P), the pitch of gficf_multi_cell_blocks.  For k <= 64 the rest of a step is two more
+ * launches around the second all-to-all: gficf_jaccard_halo_serve_ingest_device (the rows asked of this rank -> d_rows_out, and
+ * IN THE SAME LAUNCH the table rows of the own cells, which need the plan but not the replies) and
+ * gficf_jaccard_halo_ingest_slots_device (the table rows of the halo slots in use, from the replies: what is left between the
+ * second exchange and the edge kernel).  gficf_jaccard_halo_ingest_device (all rows in one launch, behind both exchanges) and the
+ * unfused serve / relabel / ingest_local calls stay. */
 size_t gficf_jaccard_halo_workspace_bytes(int64_t N_total, int P);
 int gficf_jaccard_halo_plan_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
                                    int64_t cell_begin, int P, int64_t rows_per_rank, int cap, void* d_ws, int32_t* d_req_out);
@@ -220,6 +229,12 @@ int gficf_jaccard_ingest_local_device(gficf_ctx* ctx, const int32_t* d_idx_ext, 
 int gficf_jaccard_halo_ingest_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
                                      int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
                                      const int32_t* d_rows_in, int32_t* d_table, int32_t* d_l2g);
+int gficf_jaccard_halo_serve_ingest_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                           int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
+                                           const int32_t* d_req_in, int64_t n_req, int32_t* d_rows_out, int32_t* d_table, int32_t* d_l2g);
+int gficf_jaccard_halo_ingest_slots_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                           int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
+                                           const int32_t* d_rows_in, int32_t* d_table, int32_t* d_l2g);
 int gficf_jaccard_edges_mapped_device(gficf_ctx* ctx, const int32_t* d_table, int64_t n_ext, int k, int64_t n_cells, int64_t src_offset,
                                       const int32_t* d_l2g, double* d_src, double* d_dst, double* d_w, int32_t* d_u);
 

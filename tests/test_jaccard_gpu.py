@@ -676,8 +676,10 @@ def test_configs_4_and_5_as_eight_blocks_on_local_ids(N, k):
         del table, out, rows_in
 
 
-def _emulated_halo_build(ops, mat, P, cap):
-    """All P ranks of the halo form, one after the other on this GPU; returns the full edge matrix and the rows named per rank."""
+def _emulated_halo_build(ops, mat, P, cap, split=False, wss=None):
+    """All P ranks of the halo form, one after the other on this GPU; returns the full edge matrix and the rows named per rank.
+    split: round 4's step — serve + the own cells' rows in one launch between the exchanges, the halo slots behind the second
+    (k <= 64; beyond it the unfused calls).  wss: workspaces of an earlier build (the plan hands its bitmap back clear)."""
     import torch
 
     from gficf_amd.dist import rows_per_rank, shard_bounds
@@ -688,21 +690,28 @@ def _emulated_halo_build(ops, mat, P, cap):
     i32 = dict(dtype=torch.int32, device="cuda")
     idx = [torch.from_numpy(np.ascontiguousarray(mat[b:e].T)).cuda() if e > b else torch.zeros((k, 0), **i32) for b, e in blocks]
     req_out = [torch.zeros(P * cap, **i32) for _ in range(P)]
-    wss = [torch.zeros(ops.halo_workspace_bytes(N, P), dtype=torch.uint8, device="cuda") for _ in range(P)]
+    if wss is None:
+        wss = [torch.zeros(ops.halo_workspace_bytes(N, P), dtype=torch.uint8, device="cuda") for _ in range(P)]
     for r, (b, e) in enumerate(blocks):
         ops.halo_plan(idx[r], e - b, k, N, b, P, rpr, cap, wss[r], req_out[r])
     ops.sync()
     req_in = [torch.cat([req_out[r][p * cap:(p + 1) * cap] for r in range(P)]) for p in range(P)]
     rows_out = [torch.zeros(P * cap * k, **i32) for _ in range(P)]
+    tables = [torch.zeros((e - b + P * cap, ops.row_words(e - b + P * cap, k)), **i32) for b, e in blocks]
+    l2gs = [torch.zeros(e - b + P * cap, **i32) for b, e in blocks]
+    done = []
     for p, (b, e) in enumerate(blocks):
-        ops.halo_serve(idx[p], e - b, k, b, req_in[p], rows_out[p])
+        done.append(split and ops.halo_serve_ingest(idx[p], e - b, k, N, b, P, rpr, cap, wss[p], req_out[p], req_in[p], rows_out[p], tables[p], l2gs[p]))
+        if not done[p]:
+            ops.halo_serve(idx[p], e - b, k, b, req_in[p], rows_out[p])
     got, named = [], []
     for r, (b, e) in enumerate(blocks):
         nl, n_ext = e - b, e - b + P * cap
         rows_in = torch.cat([rows_out[p][r * cap * k:(r + 1) * cap * k] for p in range(P)])
-        table = torch.zeros((n_ext, ops.row_words(n_ext, k)), **i32)
-        l2g = torch.zeros(n_ext, **i32)
-        if not ops.halo_ingest(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, table, l2g):
+        table, l2g = tables[r], l2gs[r]
+        if done[r]:
+            ops.halo_ingest_slots(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, table, l2g)
+        elif not ops.halo_ingest(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, table, l2g):
             idx_ext = torch.zeros((k, n_ext), **i32)
             ops.halo_relabel(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, idx_ext, l2g)
             ops.jaccard_ingest_local(idx_ext, n_ext, k, table)
@@ -711,6 +720,7 @@ def _emulated_halo_build(ops, mat, P, cap):
         ops.sync()
         got.append(out.cpu().numpy())
         named.append(int((req_out[r] != 0).sum()))
+    _emulated_halo_build.last_wss = wss
     return np.concatenate(got, axis=1).T, named
 
 
@@ -728,6 +738,13 @@ def test_local_id_sub_problems_fuzz():
         want, _ = oracle.jaccard(mat, nthreads=4)
         got, named = _emulated_halo_build(ops, mat, P, cap=max(N, 1))
         assert np.array_equal(got, want), (case, N, k, P)
+        # round 4's step (serve riding with the own rows' ingest, the slots behind the second exchange), on the workspaces the
+        # build above has used — the plan hands its bitmap back clear — and then once more on other data of the same shape
+        got2, named2 = _emulated_halo_build(ops, mat, P, cap=max(N, 1), split=True, wss=_emulated_halo_build.last_wss)
+        assert np.array_equal(got2, want) and named2 == named, (case, N, k, P, "split")
+        mat_b = rng.integers(1, N + 1, size=(N, k)).astype(np.int32)
+        got3, _ = _emulated_halo_build(ops, mat_b, P, cap=max(N, 1), split=True, wss=_emulated_halo_build.last_wss)
+        assert np.array_equal(got3, oracle.jaccard(mat_b, nthreads=4)[0]), (case, N, k, P, "split, reused workspace")
     # the slots exactly suffice / are one short
     import torch
 
