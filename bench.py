@@ -313,6 +313,132 @@ def bench_knn(torch, ops, args):
     return res
 
 
+def bench_chain(torch, dist, ops, args, world, rank, dev, fence, max_over_ranks):
+    """The sharded kNN -> Jaccard CHAIN (what a sharded clustcells() runs, R/clustCells.R:57-68): every rank prepares its block of
+    points, ONE all-gather replicates them, every rank derives the same pivot order and searches the cells at its positions of
+    that order (KnnShard.step_ordered) — the index block comes out in the new numbering, whose locality is what the halo form
+    wants —, then the Jaccard build on local ids (JaccardHaloShard; the all-gather form if the request slots overflow) and the
+    edges mapped back to the original ids.  cells/s of the whole job, and the same chain on ONE GPU (rank 0, own cells only,
+    after the N-rank region) for the efficiency.  Weak scaling: cells_per_gpu cells per rank."""
+    import gficf_amd
+    from gficf_amd.dist import JaccardHaloShard, JaccardShard, KnnShard, edges_to_original_ids, shard_bounds
+
+    n_per, d, kk, metric = args.cells_per_gpu, KNN_D, KNN_K, "manhattan"
+    N = n_per * world
+    k = kk - 1
+    b, e = shard_bounds(N, world, rank)
+    centers = np.random.default_rng(11).normal(scale=6.0, size=(40, d))
+    spread = np.random.default_rng(12).uniform(0.5, 2.0, size=(40, 1))
+
+    def block(r):                                                      # rank r's block of the clustered point set (clusters scattered over the cell order)
+        rng = np.random.default_rng(1000 + r)
+        br, er = shard_bounds(N, world, r)
+        lab = rng.integers(0, 40, size=er - br)
+        return centers[lab] + rng.normal(size=(er - br, d)) * spread[lab]
+
+    xl = torch.from_numpy(np.ascontiguousarray(block(rank).T)).to(dev)
+    ks = KnnShard(ops, N, d, kk, metric, device=dev)
+    # the exchange form of the Jaccard stage: decided once on the first result, by every rank alike
+    idx_ord, order = ks.step_ordered(xl)
+    probe = JaccardHaloShard(ops, N, k, device=dev)
+    probe.step(idx_ord[1:].contiguous())
+    fits = 1
+    try:
+        probe.sync()
+    except gficf_amd.GficfError as ex:
+        if ex.status != "GFICF_ERR_CAPACITY":
+            raise
+        fits = 0
+    named = probe.rows_named_outside()
+    t_fit = torch.tensor([fits], dtype=torch.int32, device=dev)
+    dist.all_reduce(t_fit, op=dist.ReduceOp.MIN)
+    halo = int(t_fit.item()) == 1
+    del probe
+    js = JaccardHaloShard(ops, N, k, device=dev) if halo else JaccardShard(ops, N, k, device=dev, with_u=False, pipeline=False)
+
+    def step():
+        io, od = ks.step_ordered(xl)
+        out = js.step(io[1:].contiguous())
+        return edges_to_original_ids(out, od), io, od
+
+    reps = max(2, min(args.steps, 5))
+    step()
+    fence()
+    t_search = t_all = 0.0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ks.step_ordered(xl)
+        torch.cuda.synchronize()
+        t_search += time.perf_counter() - t0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out, io, od = step()
+    fence()
+    t_all = max_over_ranks((time.perf_counter() - t0) / reps)
+    t_search = max_over_ranks(t_search / reps)
+    js.sync()
+    res = {"cells_per_sec": N / t_all, "ms_per_pass": t_all * 1e3, "ms_search_ordered": t_search * 1e3, "cells_total": N, "k": k, "components": d,
+           "jaccard_exchange": "halo on local ids" if halo else "all-gather (request slots overflow)", "rows_named_outside_the_block": named,
+           "rows_of_a_block": e - b,
+           "note": "per pass: prepare + all-gather of the points + pivot order + search of the rank's positions (exact, pruned) + Jaccard build on "
+                   "the ordered ids + edges mapped back to the original ids; in order, one stream"}
+    # ---- checked against the oracle (after the timed region): the first cells of rank 0's block — the search on the ordered layout,
+    # and the Jaccard stage on the index matrix the ranks produced (gathered to rank 0 for this check only)
+    nq = 128
+    blocks_idx = [torch.zeros((kk, shard_bounds(N, world, r)[1] - shard_bounds(N, world, r)[0]), dtype=torch.int32, device=dev) for r in range(world)]
+    if dist.get_backend() == "gloo":
+        tmp = [t.cpu() for t in blocks_idx]
+        dist.all_gather(tmp, io[:, :e - b].contiguous().cpu())
+        blocks_idx = tmp
+    else:
+        dist.all_gather(blocks_idx, io[:, :e - b].contiguous())
+    if rank == 0:
+        import oracle
+
+        cores = os.cpu_count() or 1
+        mat_ord = np.ascontiguousarray(torch.cat([t.cpu() for t in blocks_idx], dim=1).numpy().T)     # N x kk, new numbering, column 0 = self
+        X = np.concatenate([block(r) for r in range(world)], axis=0)
+        Xq = X[od.cpu().numpy().astype(np.int64)]                       # the layout the ranks searched
+        widx, _ = oracle.knn(Xq, kk, metric, nthreads=cores, queries=(0, nq))
+        ok_knn = bool(np.array_equal(mat_ord[:nq], widx[:nq]))
+        want, _ = oracle.jaccard_cells(np.ascontiguousarray(mat_ord[:, 1:]), 0, nq, nthreads=cores)
+        o1 = np.concatenate([np.zeros(1), od.cpu().numpy().astype(np.float64) + 1.0])
+        want[:, 0], want[:, 1] = o1[want[:, 0].astype(np.int64)], o1[want[:, 1].astype(np.int64)]     # new numbering -> original ids
+        ok_j = bool(np.array_equal(out[:, :nq * k].cpu().numpy().T, want))
+        res["checked_vs_oracle"] = ok_knn and ok_j
+        res["oracle_check"] = {"cells": nq, "search_rows_equal": ok_knn, "edges_equal": ok_j}
+        del X, Xq, mat_ord
+    del js, ks
+    # ---- the same chain on ONE GPU: rank 0, its n_per cells only (the N = 1 chain: search + Jaccard build, device-resident)
+    if rank == 0:
+        x1 = torch.from_numpy(np.ascontiguousarray(block(0)[:n_per].T)).to(dev)
+        pts = torch.zeros((n_per, ops.knn_dpad(d)), dtype=torch.float32, device=dev)
+        ws = torch.zeros(ops.knn_workspace_bytes(n_per, n_per, kk), dtype=torch.uint8, device=dev)
+        idx1 = torch.zeros((kk, n_per), dtype=torch.int32, device=dev)
+        tb = torch.zeros((n_per, ops.row_words(n_per, k)), dtype=torch.int32, device=dev)
+        o1 = torch.zeros((3, n_per * k), dtype=torch.float64, device=dev)
+
+        def chain1():
+            ops.knn_prepare(x1, n_per, d, metric, pts)
+            ops.knn_search(pts, n_per, d, kk, metric, 0, n_per, ws, idx1, None)
+            ops.jaccard_ingest(idx1[1:], n_per, k, n_per, tb)
+            ops.jaccard_edges(tb, n_per, k, 0, n_per, o1, None)
+
+        chain1()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            chain1()
+        torch.cuda.synchronize()
+        t1 = (time.perf_counter() - t0) / reps
+        ops.sync()
+        res["single_gpu_chain"] = {"cells_per_sec": n_per / t1, "ms_per_pass": t1 * 1e3, "cells": n_per}
+        res["efficiency"] = round((N / t_all) / (world * n_per / t1), 4)
+    fence()
+    return res
+
+
 def traffic_child(args):
     """What the live --pmc passes profile: one data set of the workload, ingested, four launches of the edge kernel."""
     import torch
@@ -913,6 +1039,14 @@ def main():
                                               "ingest + edge kernel per data set, one stream, in order — the step `python bench.py` times"}
             del tb1, o1, i1
         fence()
+        # (2b) the kNN -> Jaccard chain in the search's pivot order (what a sharded clustcells() runs)
+        if not args.no_chain and not strong:
+            try:
+                ch = bench_chain(torch, dist, ops, args, world, rank, dev, fence, max_over_ranks)
+            except gficf_amd.GficfError as ex:                          # (a failure of this leg must not cost the line; collectives stay matched: every rank runs the same code)
+                ch = {"error": str(ex)}
+            if rank == 0:
+                out["chain"] = ch
         # (3) the single-process form with direct peer copies, in a process of its own (rank 0 starts it; the ranks wait)
         if rank == 0 and not args.no_peer:
             out["peer"] = run_peer_leg(args)

@@ -25,6 +25,7 @@
 namespace {
 
 constexpr int HP_THREADS = 1024;
+constexpr int HP_LIST = 64;              // non-empty words of a sweep whose bits are listed by all threads together
 
 // owner-aligned position of a global id's bit: word r * wpo + (local >> 5), bit local & 31 (halo_map.h)
 __device__ inline void halo_bit_of(uint32_t id, uint32_t rpr, uint32_t wpo, uint32_t& w, uint32_t& m) {
@@ -74,19 +75,22 @@ __global__ __launch_bounds__(256) void k_halo_mark(const int32_t* __restrict__ i
 // A thread owns 4 consecutive words of a sweep (one 16 B load); the owner's wpo words are swept in super-tiles of 4096 words.
 __global__ __launch_bounds__(HP_THREADS) void k_halo_rank_emit(uint32_t* __restrict__ bitmap, uint2* __restrict__ winfo, uint32_t wpo, int64_t rpr,
                                                                int cap, int32_t* __restrict__ req_out, uint32_t* __restrict__ status) {
-  __shared__ int s_wave[HP_THREADS / 64];
-  __shared__ int s_run;
+  __shared__ int s_wave[2][HP_THREADS / 64];
+  __shared__ int s_nlist[2];
+  __shared__ uint4 s_list[2][HP_LIST];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int owner = blockIdx.x;
   typedef uint32_t v4u __attribute__((ext_vector_type(4)));
   uint32_t* const bm = bitmap + (size_t)owner * wpo;
   uint2* const wi = winfo + (size_t)owner * wpo;
   int32_t* const slots = req_out + (int64_t)owner * cap;
-  if (tid == 0) s_run = 0;
-  for (int t = tid; t < cap; t += HP_THREADS) slots[t] = 0;      // clear the owner's request slots
-  __syncthreads();
   bool over = false;
-  for (uint32_t st = 0; st < wpo; st += HP_THREADS * 4) {
+  int base = 0;                                                  // set bits of the owner in front of the sweep (every thread keeps its own copy)
+  int par = 0;
+  // One barrier per sweep, and one that waits for the LDS only: a __syncthreads() here also waits for the thread's global stores
+  // (the cleared bitmap words, the winfo records, the slots) — four store round trips in a kernel whose whole job is a dozen
+  // memory operations per thread: 10.9 us at 8 owners x 3125 words against the ~5 us a launch costs anyway.
+  for (uint32_t st = 0; st < wpo; st += HP_THREADS * 4, par ^= 1) {
     const uint32_t w0 = st + (uint32_t)tid * 4u;
     v4u v = {0u, 0u, 0u, 0u};
     if (w0 < wpo) {                                              // (wpo is a multiple of 4)
@@ -100,19 +104,55 @@ __global__ __launch_bounds__(HP_THREADS) void k_halo_rank_emit(uint32_t* __restr
       const int t = __shfl_up(incl, d);
       if (lane >= d) incl += t;
     }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    int run = s_run + incl - cnt;
+    if (lane == 63) s_wave[par][wave] = incl;                    // (two sets of slots: the next sweep's writes cannot pass this sweep's reads)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int run = base + incl - cnt, total = 0;
 #pragma unroll
-    for (int w = 0; w < HP_THREADS / 64; ++w) run += w < wave ? s_wave[w] : 0;
+    for (int w = 0; w < HP_THREADS / 64; ++w) {
+      const int t = s_wave[par][w];
+      run += w < wave ? t : 0;
+      total += t;
+    }
+    base += total;
+    // The set bits into their slots.  With locality they sit in a dozen words, i.e. in three or four threads: walking a word's
+    // bits in its own thread is up to 128 dependent turns of one lane (7 of this kernel's 11 us at 190 rows in 8 owners).  So
+    // the non-empty words go on a short list in LDS and ALL threads take one (word, bit) pair each; only a sweep with more
+    // non-empty words than the list holds (ids without locality) is walked by the owning threads, in parallel across them.
+    if (tid == 0) s_nlist[par] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+    int rr[4];
     if (w0 < wpo) {
-      const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
       int r = run;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+        rr[c] = r;
         wi[w0 + c] = make_uint2(wd[c], (uint32_t)r);
+        r += __popc(wd[c]);
+        if (wd[c] != 0u) {
+          const int e = atomicAdd(&s_nlist[par], 1);
+          if (e < HP_LIST) s_list[par][e] = make_uint4(w0 + c, wd[c], (uint32_t)rr[c], 0u);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int nl = s_nlist[par];
+    if (nl <= HP_LIST) {
+      for (int t = tid; t < nl * 32; t += HP_THREADS) {
+        const uint4 en = s_list[par][t >> 5];
+        const uint32_t m = 1u << (t & 31);
+        if (en.y & m) {
+          const int r = (int)en.z + __popc(en.y & (m - 1u));
+          if (r < cap) slots[r] = (int32_t)((int64_t)owner * rpr + (int64_t)en.x * 32 + (t & 31) + 1);
+          else over = true;
+        }
+      }
+    } else if (w0 < wpo) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        int r = rr[c];
         uint32_t rest = wd[c];
-        while (rest) {                                           // the word's set bits into their slots (independent stores)
+        while (rest) {
           const int bpos = __builtin_ctz(rest);
           rest &= rest - 1u;
           if (r < cap) slots[r] = (int32_t)((int64_t)owner * rpr + (int64_t)(w0 + c) * 32 + bpos + 1);
@@ -121,10 +161,9 @@ __global__ __launch_bounds__(HP_THREADS) void k_halo_rank_emit(uint32_t* __restr
         }
       }
     }
-    __syncthreads();
-    if (tid == HP_THREADS - 1) s_run = run + cnt;                // the last thread's inclusive count is the sweep's total
-    __syncthreads();
   }
+  // the slots behind the ones in use are empty (the ones in use were written above: no thread clears what another one fills)
+  for (int t = base + tid; t < cap; t += HP_THREADS) slots[t] = 0;
   if (over) atomicOr(status, GFICF_ST_HALO_OVERFLOW);
 }
 
@@ -208,7 +247,7 @@ int gficf_jaccard_halo_serve_device(gficf_ctx* ctx, const int32_t* d_idx, int64_
   if (n_local < 0 || k < 0 || n_req < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "halo serve: negative size");
   if (n_req == 0 || k == 0) return GFICF_OK;
   if (!d_req_in || !d_rows_out || (n_local > 0 && !d_idx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
-  int64_t blocks = gficf_ceil_div(n_req, 256);
+  int64_t blocks = gficf_ceil_div(gficf_halo_serve_items(n_req, k), 256);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
   hipLaunchKernelGGL(k_halo_serve, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_idx, n_local, k, ld, cell_begin, d_req_in, n_req,
                      d_rows_out, ctx->d_status);

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, HALO ? 4 : 1) void k_ingest_tile(const T* __re
       const int32_t gid = (r < n_rows && q >= 0) ? hm.req_out[q] : 0;
       // a tile of halo slots nobody asked for (most of them: the slots in use sit at the front of every owner's cap): nothing refers to
       // its rows — skipped whole (every wave of the workgroup sees the same 64 slots: the decision is workgroup-uniform)
-      if (row0 >= hm.n_local && __ballot(gid != 0) == 0ull) continue;
+      if (hm.skip_empty && row0 >= hm.n_local && __ballot(gid != 0) == 0ull) continue;
       if (wave == 0 && r < n_rows) hm.l2g[r] = q < 0 ? (int32_t)(hm.b + r + 1) : gid;
       if (row0 + ROWS <= hm.n_local) {                       // a tile of own cells (workgroup-uniform): the plain loads, all in flight
 #pragma unroll
@@ -1873,11 +1873,12 @@ static int halo_ingest_launch(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_lo
   const int64_t gcap = (int64_t)ctx->num_cus * 8;
   const int64_t tiles = gficf_ceil_div(row_end - row_begin, INGEST_ROWS);
   const unsigned grid_i = (unsigned)(tiles < gcap ? tiles : gcap);
-  int64_t sb = n_req > 0 ? gficf_ceil_div(n_req, 256) : 0;
-  if (sb > (int64_t)ctx->num_cus) sb = ctx->num_cus;
+  int64_t sb = n_req > 0 ? gficf_ceil_div(gficf_halo_serve_items(n_req, k), 256) : 0;
+  if (sb > (int64_t)ctx->num_cus * 2) sb = (int64_t)ctx->num_cus * 2;
   if (grid_i == 0 && sb == 0) return GFICF_OK;
   gficf_halo_map hm{(const uint2*)((const char*)d_ws + (((size_t)P * (size_t)wpo * 4 + 255) & ~(size_t)255)), d_req_out, d_rows_in, d_l2g, n_local,
-                    N_total, cell_begin, rows_per_rank, cap, (uint32_t)wpo, row_begin, row_end, d_req_in, n_req, d_rows_out, (int)sb};
+                    N_total, cell_begin, rows_per_rank, cap, (uint32_t)wpo, row_begin, row_end, d_req_in, n_req, d_rows_out, (int)sb,
+                    row_begin >= n_local ? 1 : 0};
   const TableFmt f = table_fmt(n_ext, k);
   const unsigned grid = grid_i + (unsigned)sb;
   // rows taken to hold distinct ids (gficf_ctx_set_jaccard_distinct): no duplicate scan here either — a rank's own rows are

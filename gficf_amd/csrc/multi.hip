@@ -16,10 +16,13 @@
 //     for a host entry the all-reduce is two small copies) and handed back; filter, weights and the scaling pass
 //     then run per block and the kept entries land at their offsets in the caller's arrays.
 // Kernels and arithmetic are those of the single-device entries: same bits.
+#include <condition_variable>
 #include <cstring>
 #include <exception>
 #include <functional>
+#include <mutex>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -56,6 +59,18 @@ struct gficf_multi {
   std::vector<hipEvent_t> ev_prev;                 // device d: everything enqueued before this step (the last step's edge kernel) is done
   std::vector<hipEvent_t> ev_pulled;               // device d: has pulled every other slice of this step
   bool step_valid = false;                         // ev_pulled holds a recorded step
+  // ... enqueued by one PERSISTENT host thread per device (a step is ~45 runtime calls per device — launches, peer copies, event
+  // records and waits: from one thread that is 8 x 45 calls in a row, several hundred microseconds per step at 8 devices against
+  // ~100 us of device work; threads made per call would cost as much).  Parked on a condition variable between the phases.
+  std::vector<std::thread> workers;
+  std::mutex wmu;
+  std::condition_variable wcv_job, wcv_done;
+  unsigned long long wgen = 0;
+  int wpending = 0;
+  bool wquit = false;
+  const std::function<int(int)>* wbody = nullptr;
+  std::vector<int> wrc;
+  std::vector<std::string> wmsg;
   // GF-ICF plan
   bool has_plan = false;
   int64_t G = 0, N = 0, g_kept = 0, nnz_kept = 0;
@@ -219,6 +234,15 @@ int gficf_multi_create(const int* devices, int ndev, gficf_multi** out) {
 
 void gficf_multi_destroy(gficf_multi* m) {
   if (!m) return;
+  if (!m->workers.empty()) {
+    {
+      std::lock_guard<std::mutex> lk(m->wmu);
+      m->wquit = true;
+    }
+    m->wcv_job.notify_all();
+    for (auto& t : m->workers) t.join();
+    m->workers.clear();
+  }
   for (size_t r = 0; r < m->ctx.size(); ++r) {
     if (m->ctx[r]) gficf_ctx_destroy(m->ctx[r]);
   }
@@ -331,6 +355,75 @@ int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, in
 }
 
 // ------------------------------------------------------------------------------------------------ device-resident step
+// body(r) for every device slot r on the slot's persistent thread; returns when all are done.  First failing slot wins.
+static int multi_workers_start(gficf_multi* m) {
+  if (!m->workers.empty() || m->ndev == 1) return GFICF_OK;
+  try {
+    m->wrc.assign((size_t)m->ndev, GFICF_OK);
+    m->wmsg.assign((size_t)m->ndev, std::string());
+    for (int r = 0; r < m->ndev; ++r) {
+      m->workers.emplace_back([m, r]() {
+        (void)hipSetDevice(m->dev[r]);
+        unsigned long long seen = 0;
+        for (;;) {
+          const std::function<int(int)>* body = nullptr;
+          {
+            std::unique_lock<std::mutex> lk(m->wmu);
+            m->wcv_job.wait(lk, [&] { return m->wquit || m->wgen != seen; });
+            if (m->wquit) return;
+            seen = m->wgen;
+            body = m->wbody;
+          }
+          const int rc = guarded(*body, r);
+          std::string msg = rc != GFICF_OK ? std::string(gficf_last_error()) : std::string();
+          {
+            std::lock_guard<std::mutex> lk(m->wmu);
+            m->wrc[(size_t)r] = rc;
+            m->wmsg[(size_t)r].swap(msg);
+            if (--m->wpending == 0) m->wcv_done.notify_one();
+          }
+        }
+      });
+    }
+  } catch (...) {                                   // no threads to be had: the caller's thread does the work (workers stays short: never used)
+    {
+      std::lock_guard<std::mutex> lk(m->wmu);
+      m->wquit = true;
+    }
+    m->wcv_job.notify_all();
+    for (auto& t : m->workers) t.join();
+    m->workers.clear();
+    m->wquit = false;
+  }
+  return GFICF_OK;
+}
+
+static int multi_run(gficf_multi* m, const std::function<int(int)>& body) {
+  const int P = m->ndev;
+  if ((int)m->workers.size() != P) {                // one device, or no threads: in line
+    for (int r = 0; r < P; ++r) {
+      const int rc = guarded(body, r);
+      if (rc) return rc;
+    }
+    return GFICF_OK;
+  }
+  {
+    std::unique_lock<std::mutex> lk(m->wmu);
+    m->wbody = &body;
+    m->wpending = P;
+    ++m->wgen;
+    m->wcv_job.notify_all();
+    m->wcv_done.wait(lk, [&] { return m->wpending == 0; });
+    m->wbody = nullptr;
+  }
+  for (int r = 0; r < P; ++r)
+    if (m->wrc[(size_t)r] != GFICF_OK) {
+      gficf_set_error("%s", m->wmsg[(size_t)r].c_str());
+      return m->wrc[(size_t)r];
+    }
+  return GFICF_OK;
+}
+
 // lazily: the copy streams and events of gficf_multi_jaccard_device
 static int multi_step_resources(gficf_multi* m) {
   const int P = m->ndev;
@@ -386,26 +479,31 @@ int gficf_multi_jaccard_device(gficf_multi* m, const void* const* d_idx, int idx
     if (ld && ld[r] < n) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld[%d] = %lld < %lld rows of the block", r, (long long)ld[r], (long long)n);
   }
   int rc = multi_step_resources(m);
+  if (!rc) rc = multi_workers_start(m);
   if (rc) return rc;
-  // 1. every device: its own block of ids -> its slice of ITS table, behind (a) its own last edge kernel (same stream) and
-  //    (b) the other devices' pulls of that slice in the step before
-  for (int r = 0; r < P; ++r) {
+  const bool prev_valid = m->step_valid;
+  // 1. every device (on its own host thread): its block of ids -> its slice of ITS table, behind (a) its own last edge kernel
+  //    (same stream) and (b) the other devices' pulls of that slice in the step before
+  rc = multi_run(m, [&](int r) -> int {
     const int64_t n = bd[r + 1] - bd[r];
     hipError_t e = hipSetDevice(m->dev[r]);
     if (e == hipSuccess) e = hipEventRecord(m->ev_prev[r], m->stream[r]);
-    for (int d = 0; d < P && e == hipSuccess && m->step_valid; ++d)
+    for (int d = 0; d < P && e == hipSuccess && prev_valid; ++d)
       if (d != r) e = hipStreamWaitEvent(m->stream[r], m->ev_pulled[d], 0);
     if (e != hipSuccess) return hip_fail("ordering the ingest behind the last step", e);
     if (n > 0) {
-      rc = gficf_jaccard_ingest_device(m->ctx[r], d_idx[r], idx_is_f64, n, k, ld ? ld[r] : n, N, d_table[r] + (size_t)bd[r] * roww);
-      if (rc) return rc;
+      const int irc = gficf_jaccard_ingest_device(m->ctx[r], d_idx[r], idx_is_f64, n, k, ld ? ld[r] : n, N, d_table[r] + (size_t)bd[r] * roww);
+      if (irc) return irc;
     }
     e = hipEventRecord(m->ev[r], m->stream[r]);
     if (e != hipSuccess) return hip_fail("hipEventRecord", e);
-  }
+    return GFICF_OK;
+  });
+  if (rc) return rc;
+  // (every ev[s] has been RECORDED by now: a wait enqueued on an event captures the record in force at that moment)
   // 2. every device pulls the P - 1 other slices, each on a copy stream of its own (all pairs at once: a device's pulls
   //    run side by side over its links instead of one after the other), then builds the edges of its block
-  for (int d = 0; d < P; ++d) {
+  rc = multi_run(m, [&](int d) -> int {
     hipError_t e = hipSetDevice(m->dev[d]);
     for (int t = 1; t < P && e == hipSuccess; ++t) {
       const int s = (d + t) % P;                              // start with the next device: the pulls of a step are spread over the links
@@ -424,10 +522,12 @@ int gficf_multi_jaccard_device(gficf_multi* m, const void* const* d_idx, int idx
     const int64_t n = bd[d + 1] - bd[d];
     if (n > 0) {
       const size_t ne = (size_t)n * (size_t)k;
-      rc = gficf_jaccard_edges_device(m->ctx[d], d_table[d], N, k, bd[d], bd[d + 1], d_out[d], d_out[d] + ne, d_out[d] + 2 * ne, nullptr);
-      if (rc) return rc;
+      const int erc = gficf_jaccard_edges_device(m->ctx[d], d_table[d], N, k, bd[d], bd[d + 1], d_out[d], d_out[d] + ne, d_out[d] + 2 * ne, nullptr);
+      if (erc) return erc;
     }
-  }
+    return GFICF_OK;
+  });
+  if (rc) return rc;
   m->step_valid = true;
   return GFICF_OK;
 }

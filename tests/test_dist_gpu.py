@@ -231,7 +231,8 @@ def _blobs(N, d):
     return centers[lab] + rng.normal(size=(N, d)) * rng.uniform(0.6, 1.5, size=(25, 1))[lab]
 
 
-def test_knn_chain_in_pivot_order_feeds_the_halo_form(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_knn_chain_in_pivot_order_feeds_the_halo_form(tmp_path, world):
     """kNN -> Jaccard sharded over two ranks on clustered points that arrive in no particular order (R/clustCells.R:57-65).
     In the given numbering a block names nearly every remote row (request slots overflow: the all-gather form is the one to
     take); with the cells renumbered in the search's pivot order (KnnShard.step_ordered) the halo form fits, names a small
@@ -240,7 +241,6 @@ def test_knn_chain_in_pivot_order_feeds_the_halo_form(tmp_path):
 
     import oracle
 
-    world = 2
     mp.spawn(_ordered_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     N, d, kk = 40000, 20, 16
     X = _blobs(N, d)
@@ -253,8 +253,8 @@ def test_knn_chain_in_pivot_order_feeds_the_halo_form(tmp_path):
         edges = np.load(tmp_path / f"ord_edges_{r}.npy").T.reshape(len(cells), k, 3)
         got.reshape(N, k, 3)[cells] = edges
         over, named_plain, named_ord, cap = np.load(tmp_path / f"ord_meta_{r}.npy")
-        assert over == 1 and named_plain == cap                                  # scattered clusters: every slot of the other owner in use
-        assert 0 < named_ord < 0.25 * (N // world)
+        assert over == 1 and named_plain == (world - 1) * cap                    # scattered clusters: every slot of the other owners in use
+        assert 0 < named_ord < (0.25 if world == 2 else 0.5) * (N // world)
     assert np.array_equal(got, want)
 
 

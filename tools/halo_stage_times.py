@@ -22,10 +22,19 @@ ops.set_jaccard_distinct(True)          # the sequence bench.py and the host ent
 n_per, k = 100_000, 30
 
 
+_blk = torch.zeros(256 << 20, dtype=torch.uint8, device="cuda")
+
+
 def t_ms(fn, iters=30):
+    """GPU time per launch of `fn`, back to back: the launches are enqueued BEHIND a few milliseconds of other work (so the host,
+    which needs ~10 us of Python + ctypes per call, is far ahead of the device by the time the first one starts) and timed by two
+    events on the stream.  Without the blocker a kernel of a few microseconds measures the host's enqueue rate, not the device
+    (round 3's stage times for plan / serve / ingest were inflated that way; rocprofv3's kernel trace agrees with this form)."""
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(12):
+        _blk.add_(1)                                                # ~12 x 0.1 ms: the device stays busy while the host enqueues
     e0.record()
     for _ in range(iters):
         fn()
