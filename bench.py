@@ -1191,6 +1191,33 @@ def main():
                                "scale_kernel_ms": round(t_scale, 4), "count_exact_kernel_ms": round(t_count, 4),
                                "count_note": "count_exact_kernel_ms is gficf_csc_count_device (reads x: 12 B/nnz), the form the sharded and host entries use; the timed pass (gficf_csc_device) counts stored entries without reading x (about half that time, see the rocprof summary)",
                                "algorithmic_bytes_per_pass": GFICF_BYTES_PER_NNZ * nnz}}
+            # the same pass with the result in the pointerB / pointerE form (cells compact inside their own input range: no global
+            # positions, so the kept-count pass and its scan do not run — three launches instead of five), which is what the
+            # device-resident chain hands on: t() of it, below, is an ordinary compact CSC again
+            ops.gficf_csc_be(G, Nc, colptr, rowidx, x, 0.05, 1.0, None, ws)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                ops.gficf_csc_be(G, Nc, colptr, rowidx, x, 0.05, 1.0, None, ws)
+            torch.cuda.synchronize()
+            tb = (time.perf_counter() - t1) / reps
+            ops.sync()
+            be_end, be_ri, be_x = ws["out_end"].clone(), ws["out_rowidx"].clone(), ws["out_x"].clone()
+            run()                                                   # the canonical result back in the workspace for what follows
+            ops.sync()
+            lens_be = be_end[:Nc] - colptr[:Nc]
+            cell_b = torch.repeat_interleave(torch.arange(Nc, device=dev), lens_be)
+            kn_b = int(cell_b.numel())
+            pos_b = torch.arange(kn_b, device=dev) - ws["out_colptr"][:Nc][cell_b] + colptr[:Nc][cell_b]
+            gf["begin_end_form"] = {"ms_per_pass": tb * 1e3, "cells_per_sec": Nc / tb,
+                                    "roofline_frac": round(GFICF_BYTES_PER_NNZ * nnz / tb / 1e9 / HBM_PEAK_GBS, 4),
+                                    "achieved_GBps": round(GFICF_BYTES_PER_NNZ * nnz / tb / 1e9, 2),
+                                    "equals_canonical_result": bool(kn_b == int(ws["out_colptr"][Nc]) and torch.equal(be_ri[pos_b], ws["out_rowidx"][:kn_b])
+                                                                    and torch.equal(be_x[pos_b], ws["out_x"][:kn_b])),
+                                    "note": "gficf_csc_be_device: count + gene table + scale (3 launches); cell c's kept entries at [colptr[c], out_end[c]) of the "
+                                            "output arrays — same entries, order and bits as the canonical compacted CSC (`value`), without the third read of "
+                                            "rowidx that global output positions cost; read directly by gficf_csc_transpose_be_device / gficf_cluster_signatures_be_device"}
+            del cell_b, pos_b, lens_be
             # next row N3: t(gficf), the PCA input (R/dimensinalityReduction.R:33), on the matrix just produced
             gk, kn = int(ws["gkept"][0]), int(ws["out_colptr"][Nc])
             tws = torch.zeros(ops.csc_transpose_workspace_bytes(gk, Nc), dtype=torch.uint8, device=dev)
@@ -1201,6 +1228,12 @@ def main():
             t_tr = time_kernel_ms(torch, run_t, 10)
             order = torch.sort(ws["out_rowidx"][:kn].long(), stable=True)[1]
             cell = torch.repeat_interleave(torch.arange(Nc, device=dev, dtype=torch.int32), ws["out_colptr"][1:] - ws["out_colptr"][:-1])
+            t_ptr2, t_idx2, t_val2 = torch.zeros_like(t_ptr), torch.zeros_like(t_idx), torch.zeros_like(t_val)
+            run_tb = lambda: ops.csc_transpose_be(gk, Nc, colptr, be_end, be_ri, be_x, t_ptr2, t_idx2, t_val2, tws)
+            t_trb = time_kernel_ms(torch, run_tb, 10)
+            gf["begin_end_form"]["transpose_ms"] = round(t_trb, 4)
+            gf["begin_end_form"]["transpose_equals_canonical"] = bool(torch.equal(t_ptr2, t_ptr) and torch.equal(t_idx2, t_idx) and torch.equal(t_val2, t_val))
+            del t_ptr2, t_idx2, t_val2, be_end, be_ri, be_x
             gf["transpose"] = {"ms": round(t_tr, 4), "entries": kn, "cells_per_sec": Nc / (t_tr * 1e-3),
                                "algorithmic_GBps": round(28 * kn / t_tr / 1e6, 1),
                                "note": "t(gficf): kept genes x cells CSC -> cells x genes CSC, 28 B/entry (4 count + 12 read + 12 written)",

@@ -98,6 +98,10 @@ SIGNATURES = {
     "gficf_csc_genes_device": (_int, [_vp, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp]),
     "gficf_csc_colptr_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_csc_scale_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_csc_scale_be_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_csc_be_device": (_int, [_vp, _int, _i64, _i64, _vp, _vp, _vp, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_cluster_signatures_be_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
+    "gficf_csc_transpose_be_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, ctypes.c_size_t]),
     "gficf_cluster_signatures_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _vp]),
     "gficf_cluster_signatures_host": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _vp, _int, _vp]),
     "gficf_csc_transpose_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),

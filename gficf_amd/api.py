@@ -896,6 +896,33 @@ class HipOps:
                                             int(rowidx.numel()), _tptr(genes), _tptr(gkept), _tptr(out_colptr),
                                             _tptr(out_rowidx), _tptr(out_x)))
 
+    # -- the chain in the pointerB / pointerE form (cells compact inside their own input range; no global positions, no kept-count pass)
+    def csc_scale_be(self, G, n_cells, colptr, rowidx, x, genes, gkept, out_end, out_rowidx, out_x):
+        check(self.L.gficf_csc_scale_be_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x), int(rowidx.numel()),
+                                               _tptr(genes), _tptr(gkept), _tptr(out_end), _tptr(out_rowidx), _tptr(out_x)))
+
+    def gficf_csc_be(self, G, N, colptr, rowidx, x, prop_min=0.05, prop_max=1.0, w_in=None, ws=None, exact: bool = False) -> dict:
+        """:meth:`gficf_csc` with the matrix returned in the pointerB / pointerE form: cell c's kept entries are
+        ``out_rowidx / out_x [colptr[c] : out_end[c]]`` (``ws["out_end"]``, int64[N]) — same entries, order and values as the
+        canonical form, three launches instead of five.  :meth:`csc_transpose_be` and :meth:`cluster_signatures_be` read it."""
+        ws = ws or self.csc_workspace(G, N, int(rowidx.numel()))
+        if "out_end" not in ws:
+            ws["out_end"] = self.torch.zeros(max(N, 1), dtype=self.torch.int64, device=f"cuda:{self.device}")
+        check(self.L.gficf_csc_be_device(self._bind(), 1 if exact else 0, G, N, _tptr(colptr), _tptr(rowidx), _tptr(x), int(rowidx.numel()),
+                                         float(prop_min), float(prop_max), _tptr(w_in), _tptr(ws["nt"]), _tptr(ws["keep"]), _tptr(ws["genes"]),
+                                         _tptr(ws["w"]), _tptr(ws["gkept"]), _tptr(ws["out_end"]), _tptr(ws["out_rowidx"]), _tptr(ws["out_x"])))
+        return ws
+
+    def cluster_signatures_be(self, G, n_cells, col_begin, col_end, rowidx, x, cluster, C, out):
+        check(self.L.gficf_cluster_signatures_be_device(self._bind(), G, n_cells, _tptr(col_begin), _tptr(col_end), _tptr(rowidx), _tptr(x),
+                                                        _tptr(cluster), int(C), _tptr(out)))
+
+    def csc_transpose_be(self, G, n_cells, col_begin, col_end, rowidx, x, out_ptr, out_idx, out_x, ws):
+        """t() of a matrix in the pointerB / pointerE form; the result is a compact CSC (out_ptr[G] entries)."""
+        check(self.L.gficf_csc_transpose_be_device(self._bind(), G, n_cells, _tptr(col_begin), _tptr(col_end), _tptr(rowidx), _tptr(x),
+                                                   int(rowidx.numel()), _tptr(out_ptr), _tptr(out_idx), _tptr(out_x), _tptr(ws),
+                                                   int(ws.numel() * ws.element_size())))
+
     def cluster_signatures(self, G, n_cells, colptr, rowidx, x, cluster, C, out):
         """out: (C, G) float64 == column-major G x C; cluster: int32 ids in [0, C)."""
         check(self.L.gficf_cluster_signatures_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
                                                             const int64_t* __restrict__ out_colptr,
                                                             int32_t* __restrict__ out_rowidx,
                                                             double* __restrict__ out_x, int norm_l1,
-                                                            uint32_t* zero_flag) {
+                                                            uint32_t* zero_flag, int64_t* __restrict__ out_end) {
   __shared__ double s_sum[SC_WAVES];
   if (gkept_p && *gkept_p < 0xFFFF) return;       // the LDS-resident variant handles this input (launched whenever the row ids fit LDS)
   bool saw_zero = false;                          // an explicitly stored zero (see gficf_csc_device)
@@ -436,7 +436,10 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
   for (int64_t c = blockIdx.x; c < n_cells; c += gridDim.x) {
     const int64_t p0 = colptr[c], p1 = colptr[c + 1];
     const int64_t len = p1 - p0;
-    if (len <= 0) continue;                         // uniform over the workgroup
+    if (len <= 0) {                                 // uniform over the workgroup
+      if (out_end != nullptr && threadIdx.x == 0) out_end[c] = out_colptr[c];
+      continue;
+    }
     const int64_t seg = gficf_ceil_div(gficf_ceil_div(len, SC_WAVES), 64) * 64;
     const int64_t a0 = p0 + (int64_t)wave * seg < p1 ? p0 + (int64_t)wave * seg : p1;
     const int64_t a1 = a0 + seg < p1 ? a0 + seg : p1;
@@ -553,6 +556,8 @@ __global__ __launch_bounds__(SC_THREADS) void k_scale_cells(int64_t G, int64_t n
         opos += __popcll(mk);
       }
     }
+    // pointerB / pointerE form: the position behind the cell's last kept entry (the last wave's running position)
+    if (out_end != nullptr && wave == SC_WAVES - 1 && lane == 0) out_end[c] = opos;
   }
   if (zero_flag != nullptr && saw_zero) atomicOr(zero_flag, GFICF_ST_EXPLICIT_ZERO);
 }
@@ -584,7 +589,8 @@ template <bool W_LDS>
 __device__ inline void sl_body(int64_t G, int64_t n_cells, const int64_t* __restrict__ colptr, const int32_t* __restrict__ rowidx,
                                const double* __restrict__ x, const gficf_gene_entry* __restrict__ genes, int64_t gkept,
                                const int64_t* __restrict__ out_colptr, int32_t* __restrict__ out_rowidx,
-                               double* __restrict__ out_x, int norm_l1, uint32_t* zero_flag, int static_cells) {
+                               double* __restrict__ out_x, int norm_l1, uint32_t* zero_flag, int static_cells,
+                               int64_t* __restrict__ out_end) {
   extern __shared__ unsigned char s_raw[];
   bool saw_zero = false;                          // an explicitly stored zero (see gficf_csc_device)
   uint16_t* const s_remap = reinterpret_cast<uint16_t*>(s_raw);
@@ -624,7 +630,10 @@ __device__ inline void sl_body(int64_t G, int64_t n_cells, const int64_t* __rest
     c_next = grab();                               // asked for early: the round trip hides behind this cell's loads
     const int64_t p0 = colptr[c], p1 = colptr[c + 1];
     const int64_t len = p1 - p0;
-    if (len <= 0) continue;                       // uniform over the wave
+    if (len <= 0) {                               // uniform over the wave
+      if (out_end != nullptr && lane == 0) out_end[c] = out_colptr[c];
+      continue;
+    }
     int64_t opos = out_colptr[c];
     // A wave keeps the first 64 * SL_CH entries of its cell (the "head") in registers and reads them from HBM exactly once.
     // Entries beyond that (the "tail": cells of more than 2048 stored entries — a third of the cells at SURVEY.md 8d's
@@ -742,6 +751,8 @@ __device__ inline void sl_body(int64_t G, int64_t n_cells, const int64_t* __rest
           }
         }
       }
+      // pointerB / pointerE form: the position behind the cell's last kept entry
+      if (out_end != nullptr && lane == 0) out_end[c] = opos;
     }
   }
   if (zero_flag != nullptr && saw_zero) atomicOr(zero_flag, GFICF_ST_EXPLICIT_ZERO);
@@ -757,13 +768,14 @@ __global__ __launch_bounds__(SL_THREADS) void k_scale_cells_lds(int64_t G, int64
                                                                 const int64_t* __restrict__ out_colptr,
                                                                 int32_t* __restrict__ out_rowidx,
                                                                 double* __restrict__ out_x, int norm_l1,
-                                                                uint32_t* zero_flag, int static_cells, int mode) {
+                                                                uint32_t* zero_flag, int static_cells, int mode,
+                                                                int64_t* __restrict__ out_end) {
   const int64_t gkept = *gkept_p;
   if (gkept >= 0xFFFF) return;                    // new row ids do not fit 16 bits: the global-gather variant handles this input
   if (mode == 0 && sl_fits(G, gkept))
-    sl_body<true>(G, n_cells, colptr, rowidx, x, genes, gkept, out_colptr, out_rowidx, out_x, norm_l1, zero_flag, static_cells);
+    sl_body<true>(G, n_cells, colptr, rowidx, x, genes, gkept, out_colptr, out_rowidx, out_x, norm_l1, zero_flag, static_cells, out_end);
   else
-    sl_body<false>(G, n_cells, colptr, rowidx, x, genes, gkept, out_colptr, out_rowidx, out_x, norm_l1, zero_flag, static_cells);
+    sl_body<false>(G, n_cells, colptr, rowidx, x, genes, gkept, out_colptr, out_rowidx, out_x, norm_l1, zero_flag, static_cells, out_end);
 }
 
 __global__ __launch_bounds__(256) void k_zero_i64(int64_t* __restrict__ p, int64_t n) {
@@ -776,7 +788,9 @@ __global__ __launch_bounds__(256) void k_zero_i64(int64_t* __restrict__ p, int64
 // (reference R/clustCells.R:121-123): out[g, c] = sum over the cells of cluster c of gficf[g, cell].
 // One wave per cell; f64 atomic adds into the dense G x C result (column-major).  The order of the
 // additions is not fixed, so the last bits can differ from run to run (well inside 1e-6).
-__global__ __launch_bounds__(256) void k_cluster_signatures(int64_t G, int64_t n_cells, const int64_t* __restrict__ colptr,
+// (columns are given as begin / end pointers: the canonical CSC hands in colptr and colptr + 1, the pointerB / pointerE form of
+// gficf_csc_scale_be_device its two arrays)
+__global__ __launch_bounds__(256) void k_cluster_signatures(int64_t G, int64_t n_cells, const int64_t* __restrict__ ptr_b, const int64_t* __restrict__ ptr_e,
                                                             const int32_t* __restrict__ rowidx, const double* __restrict__ x,
                                                             const int32_t* __restrict__ cluster, int32_t C,
                                                             double* __restrict__ out, uint32_t* __restrict__ status) {
@@ -786,7 +800,7 @@ __global__ __launch_bounds__(256) void k_cluster_signatures(int64_t G, int64_t n
     const int32_t cl = cluster[c];
     if (cl < 0 || cl >= C) { if (lane == 0) atomicOr(status, GFICF_ST_BAD_CSC); continue; }
     double* const col = out + (int64_t)cl * G;
-    const int64_t p0 = colptr[c], p1 = colptr[c + 1];
+    const int64_t p0 = ptr_b[c], p1 = ptr_e[c];
     for (int64_t p = p0 + lane; p < p1; p += 64) {
       const int32_t g = rowidx[p];
       if (g >= 0 && g < G) unsafeAtomicAdd(col + g, x[p]);      // the hardware f64 add (atomicAdd compiles to a compare-and-swap loop)
@@ -846,7 +860,7 @@ __global__ __launch_bounds__(256) void k_sig_fill(int64_t n_cells, const int32_t
 }
 
 // grid (slices, C): workgroup (b, cl) sums slice b of cluster cl's cells
-__global__ __launch_bounds__(256) void k_sig_sum(int64_t G, const int64_t* __restrict__ colptr, const int32_t* __restrict__ rowidx,
+__global__ __launch_bounds__(256) void k_sig_sum(int64_t G, const int64_t* __restrict__ ptr_b, const int64_t* __restrict__ ptr_e, const int32_t* __restrict__ rowidx,
                                                  const double* __restrict__ x, const int64_t* __restrict__ start,
                                                  const int32_t* __restrict__ order, double* __restrict__ out) {
   extern __shared__ double s_acc[];
@@ -860,7 +874,7 @@ __global__ __launch_bounds__(256) void k_sig_sum(int64_t G, const int64_t* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t t = lo + wave; t < hi; t += 4) {
     const int64_t c = order[t];
-    const int64_t p0 = colptr[c], p1 = colptr[c + 1];
+    const int64_t p0 = ptr_b[c], p1 = ptr_e[c];
     for (int64_t p = p0 + lane; p < p1; p += 64) {
       const int32_t g = rowidx[p];
       if (g >= 0 && g < G) unsafeAtomicAdd(&s_acc[g], x[p]);       // ds_add_f64
@@ -979,9 +993,36 @@ int gficf_csc_colptr_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const in
   return gficf_exclusive_scan_i64(ctx, d_out_colptr, n_cells + 1);
 }
 
+static int scale_launch(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr, const int32_t* d_rowidx, const double* d_x,
+                        int64_t nnz, const gficf_gene_entry* d_genes, const int64_t* d_gkept, const int64_t* d_out_colptr,
+                        int32_t* d_out_rowidx, double* d_out_x, int64_t* d_out_end);
+
 int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
                            const int32_t* d_rowidx, const double* d_x, int64_t nnz, const gficf_gene_entry* d_genes,
                            const int64_t* d_gkept, const int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
+  return scale_launch(ctx, G, n_cells, d_colptr, d_rowidx, d_x, nnz, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x, nullptr);
+}
+
+/* The scaling pass in the pointerB / pointerE ("four-array") form of a compressed matrix: the kept entries of cell c are written
+ * from position d_colptr[c] on — every cell compacts inside its own input range — and d_out_end[c] is the position behind its
+ * last kept entry.  No global output positions are needed, so the kept-count pass and its scan (gficf_csc_colptr_device: a third
+ * read of rowidx, 14 % of the pass at config 3) do not run.  For the device-resident chain: gficf_csc_transpose_be_device and
+ * gficf_cluster_signatures_be_device read this form; the canonical compacted CSC stays what the host entries return. */
+int gficf_csc_scale_be_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr, const int32_t* d_rowidx,
+                              const double* d_x, int64_t nnz, const gficf_gene_entry* d_genes, const int64_t* d_gkept,
+                              int64_t* d_out_end, int32_t* d_out_rowidx, double* d_out_x) {
+  if (!d_out_end && n_cells > 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (n_cells > 0 && nnz == 0) {                   // no stored entry: every cell ends where it begins (position 0)
+    GFICF_CTX_ENTER(ctx);
+    GFICF_HIP_CHECK(hipMemsetAsync(d_out_end, 0, sizeof(int64_t) * (size_t)n_cells, ctx->stream));
+    return GFICF_OK;
+  }
+  return scale_launch(ctx, G, n_cells, d_colptr, d_rowidx, d_x, nnz, d_genes, d_gkept, d_colptr, d_out_rowidx, d_out_x, d_out_end);
+}
+
+static int scale_launch(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr, const int32_t* d_rowidx, const double* d_x,
+                        int64_t nnz, const gficf_gene_entry* d_genes, const int64_t* d_gkept, const int64_t* d_out_colptr,
+                        int32_t* d_out_rowidx, double* d_out_x, int64_t* d_out_end) {
   GFICF_CTX_ENTER(ctx);
   if (G < 0 || n_cells < 0 || nnz < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (n_cells == 0 || nnz == 0) return GFICF_OK;
@@ -1003,7 +1044,7 @@ int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
     hipLaunchKernelGGL(k_scale_cells_lds, dim3((unsigned)blocks), dim3(SL_THREADS), SL_LDS_BYTES, ctx->stream, G, n_cells,
                        d_colptr, d_rowidx, d_x, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x, ctx->norm_l1, ctx->cur_zero,
                        getenv("GFICF_SCALE_STATIC_CELLS") != nullptr ? 1 : 0,       // test hook, read per call (A/B inside one process)
-                       force_semi ? 1 : 0);
+                       force_semi ? 1 : 0, d_out_end);
   }
   // The LDS variant takes every input whose new row ids fit 16 bits (G_kept < 65535, decided on the device); with fewer
   // than 65535 genes that is every input, and the global-gather variant is not launched at all.
@@ -1015,14 +1056,30 @@ int gficf_csc_scale_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
   hipLaunchKernelGGL(k_scale_cells, dim3((unsigned)blocks), dim3(SC_THREADS), 0, ctx->stream, G, n_cells, d_colptr,
                      d_rowidx, d_x, d_genes, try_lds ? d_gkept : (const int64_t*)nullptr, d_out_colptr, d_out_rowidx, d_out_x,
-                     ctx->norm_l1, ctx->cur_zero);
+                     ctx->norm_l1, ctx->cur_zero, d_out_end);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
 
+static int signatures_launch(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr, const int64_t* d_col_end,
+                             const int32_t* d_rowidx, const double* d_x, const int32_t* d_cluster, int32_t C, double* d_out);
+
 int gficf_cluster_signatures_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
                                     const int32_t* d_rowidx, const double* d_x, const int32_t* d_cluster, int32_t C,
                                     double* d_out) {
+  return signatures_launch(ctx, G, n_cells, d_colptr, d_colptr ? d_colptr + 1 : nullptr, d_rowidx, d_x, d_cluster, C, d_out);
+}
+
+/* The same sums over a matrix in the pointerB / pointerE form (gficf_csc_scale_be_device): cell c's entries are
+ * [d_col_begin[c], d_col_end[c]). */
+int gficf_cluster_signatures_be_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_col_begin, const int64_t* d_col_end,
+                                       const int32_t* d_rowidx, const double* d_x, const int32_t* d_cluster, int32_t C, double* d_out) {
+  if (n_cells > 0 && G > 0 && C > 0 && !d_col_end) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  return signatures_launch(ctx, G, n_cells, d_col_begin, d_col_end, d_rowidx, d_x, d_cluster, C, d_out);
+}
+
+static int signatures_launch(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr, const int64_t* d_col_end,
+                             const int32_t* d_rowidx, const double* d_x, const int32_t* d_cluster, int32_t C, double* d_out) {
   GFICF_CTX_ENTER(ctx);
   if (G < 0 || n_cells < 0 || C < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (G == 0 || C == 0) return GFICF_OK;
@@ -1055,14 +1112,14 @@ int gficf_cluster_signatures_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, 
     int64_t slices = gficf_ceil_div((int64_t)ctx->num_cus * 4, (int64_t)C);
     if (slices < 1) slices = 1;
     if (slices > 1024) slices = 1024;
-    hipLaunchKernelGGL(k_sig_sum, dim3((unsigned)slices, (unsigned)C), dim3(256), (size_t)G * sizeof(double), ctx->stream, G, d_colptr, d_rowidx, d_x,
+    hipLaunchKernelGGL(k_sig_sum, dim3((unsigned)slices, (unsigned)C), dim3(256), (size_t)G * sizeof(double), ctx->stream, G, d_colptr, d_col_end, d_rowidx, d_x,
                        start, order, d_out);
     GFICF_HIP_CHECK(hipGetLastError());
     return GFICF_OK;
   }
   int64_t blocks = gficf_ceil_div(n_cells, 4);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
-  hipLaunchKernelGGL(k_cluster_signatures, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, G, n_cells, d_colptr, d_rowidx,
+  hipLaunchKernelGGL(k_cluster_signatures, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, G, n_cells, d_colptr, d_col_end, d_rowidx,
                      d_x, d_cluster, C, d_out, ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
@@ -1111,7 +1168,7 @@ size_t gficf_csc_genes_bytes(int64_t G) {
 static int csc_sequence(gficf_ctx* ctx, bool exact, int64_t G, int64_t N, const int64_t* d_colptr, const int32_t* d_rowidx,
                         const double* d_x, int64_t nnz, double prop_min, double prop_max, const double* d_w_in,
                         int64_t* d_nt, uint8_t* d_keep, gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept,
-                        int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x) {
+                        int64_t* d_out_colptr, int32_t* d_out_rowidx, double* d_out_x, bool be = false) {
   GFICF_CTX_ENTER(ctx);
   if (G < 0 || N < 0 || nnz < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (G > 0 && !d_nt) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
@@ -1143,11 +1200,22 @@ static int csc_sequence(gficf_ctx* ctx, bool exact, int64_t G, int64_t N, const 
     }
   }
   if (!rc && !table_done) rc = gficf_csc_genes_device(ctx, G, N, d_nt, prop_min, prop_max, d_w_in, d_keep, d_genes, d_w, d_gkept);
-  if (!rc) rc = gficf_csc_colptr_device(ctx, G, N, d_colptr, d_rowidx, d_keep, d_gkept, d_out_colptr);
+  if (!rc && !be) rc = gficf_csc_colptr_device(ctx, G, N, d_colptr, d_rowidx, d_keep, d_gkept, d_out_colptr);
   ctx->cur_zero = exact ? nullptr : ctx->d_status;
-  if (!rc) rc = gficf_csc_scale_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x);
+  if (!rc && !be) rc = gficf_csc_scale_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x);
+  if (!rc && be) rc = gficf_csc_scale_be_device(ctx, G, N, d_colptr, d_rowidx, d_x, nnz, d_genes, d_gkept, d_out_colptr, d_out_rowidx, d_out_x);
   ctx->cur_zero = nullptr;
   return rc;
+}
+
+/* gficf_csc_device / gficf_csc_exact_device with the output in the pointerB / pointerE form (gficf_csc_scale_be_device): three
+ * launches — count, gene table, scale — instead of five; d_out_end[N] takes the place of d_out_colptr[N + 1]. */
+int gficf_csc_be_device(gficf_ctx* ctx, int exact, int64_t G, int64_t N, const int64_t* d_colptr, const int32_t* d_rowidx,
+                        const double* d_x, int64_t nnz, double prop_min, double prop_max, const double* d_w_in,
+                        int64_t* d_nt, uint8_t* d_keep, gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept,
+                        int64_t* d_out_end, int32_t* d_out_rowidx, double* d_out_x) {
+  return csc_sequence(ctx, exact != 0, G, N, d_colptr, d_rowidx, d_x, nnz, prop_min, prop_max, d_w_in, d_nt, d_keep, d_genes, d_w, d_gkept,
+                      d_out_end, d_out_rowidx, d_out_x, true);
 }
 
 /* Fast sequence: pass A counts stored entries without reading x (4 B/nnz instead of 12).  That equals

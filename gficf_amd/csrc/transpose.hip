@@ -51,34 +51,37 @@ static TrShape tr_shape(int64_t G, int64_t N, int64_t nnz, bool may_pair = true)
   return s;
 }
 
+// counters (+ the waiting entries of the pairing form) | begin of every cell of the block (8 B) | its length (4 B)
 static size_t tr_lds_bytes(const TrShape& s) {
-  return (size_t)((s.gcap + 1) & ~1) * (s.pair ? 16 : 4) + (size_t)(s.cpb + 1) * 8;
+  return (size_t)((s.gcap + 1) & ~1) * (s.pair ? 16 : 4) + (size_t)(s.cpb + 1) * 12;
 }
 
 // a column's entry range, clamped into the arrays (a bad colptr is reported by k_tr_count and must not fault)
 __device__ static inline int64_t tr_clamp(int64_t e, int64_t nnz) { return e < 0 ? 0 : e > nnz ? nnz : e; }
 
-__global__ __launch_bounds__(TR_THREADS) void k_tr_count(TrShape s, const int64_t* __restrict__ colptr,
+// Columns are given as begin / end pointers (the canonical CSC hands in colptr and colptr + 1, the pointerB / pointerE form of
+// gficf_csc_scale_be_device its two arrays): a wave takes a cell at a time, its lanes the cell's entries.
+__global__ __launch_bounds__(TR_THREADS) void k_tr_count(TrShape s, const int64_t* __restrict__ ptr_b, const int64_t* __restrict__ ptr_e,
                                                          const int32_t* __restrict__ rowidx, uint32_t* __restrict__ cnt,
                                                          uint32_t* __restrict__ status) {
   extern __shared__ uint32_t s_cnt[];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t g0 = (int64_t)blockIdx.y * s.gcap;
   const int gn = (int)(s.G - g0 < s.gcap ? s.G - g0 : s.gcap);
   for (int t = tid; t < gn; t += TR_THREADS) s_cnt[t] = 0u;
   __syncthreads();
   const int64_t c0 = (int64_t)b * s.cpb, c1 = c0 + s.cpb < s.n_cells ? c0 + s.cpb : s.n_cells;
   bool bad = false;
-  for (int64_t c = c0 + tid; c < c1; c += TR_THREADS) {
-    const int64_t lo = colptr[c], hi = colptr[c + 1];
+  for (int64_t c = c0 + wave; c < c1; c += TR_THREADS / 64) {
+    const int64_t lo = ptr_b[c], hi = ptr_e[c];
     bad |= lo < 0 || hi < lo || hi > s.nnz;
-  }
-  const int64_t e0 = tr_clamp(colptr[c0], s.nnz), e1 = tr_clamp(colptr[c1], s.nnz);
-  for (int64_t e = e0 + tid; e < e1; e += TR_THREADS) {
-    const int64_t g = rowidx[e];
-    if (g < 0 || g >= s.G) { bad = true; continue; }
-    const int64_t t = g - g0;
-    if (t >= 0 && t < gn) atomicAdd(&s_cnt[t], 1u);
+    const int64_t e0 = tr_clamp(lo, s.nnz), e1 = tr_clamp(hi, s.nnz);
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+      const int64_t g = rowidx[e];
+      if (g < 0 || g >= s.G) { bad = true; continue; }
+      const int64_t t = g - g0;
+      if (t >= 0 && t < gn) atomicAdd(&s_cnt[t], 1u);
+    }
   }
   if (bad) atomicOr(status, GFICF_ST_BAD_CSC);
   __syncthreads();
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void k_tr_prefix(TrShape s, uint32_t* __restri
 //         its odd neighbour — the same gene in a later cell of the block — and both go out as one 8-byte and one 16-byte
 //         store.  The scattered stores are what this kernel costs, and this halves them.
 template <int MODE>
-__global__ __launch_bounds__(TR_THREADS) void k_tr_scatter(TrShape s, const int64_t* __restrict__ colptr,
+__global__ __launch_bounds__(TR_THREADS) void k_tr_scatter(TrShape s, const int64_t* __restrict__ ptr_b, const int64_t* __restrict__ ptr_e,
                                                            const int32_t* __restrict__ rowidx, const double* __restrict__ x,
                                                            const uint32_t* __restrict__ cnt, const int64_t* __restrict__ out_ptr,
                                                            int32_t* __restrict__ out_idx, double* __restrict__ out_x) {
@@ -128,9 +131,10 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_scatter(TrShape s, const int6
   const int64_t g0 = (int64_t)blockIdx.y * s.gcap;
   const int gn = (int)(s.G - g0 < s.gcap ? s.G - g0 : s.gcap);
   const int gpad = (s.gcap + 1) & ~1;
-  int64_t* s_cp = (int64_t*)(s_cnt + gpad);                             // 8-byte aligned behind the counters
+  int64_t* s_cp = (int64_t*)(s_cnt + gpad);                             // 8-byte aligned behind the counters: begin of every cell
   double* s_sx = (double*)(s_cp + s.cpb + 1);                           // MODE 2: the waiting entry of every gene
-  int32_t* s_sc = (int32_t*)(s_sx + gpad);                              //         its cell, -1 = none
+  int32_t* s_sc = (int32_t*)(s_sx + (MODE == 2 ? gpad : 0));            //         its cell, -1 = none
+  uint32_t* s_len = (uint32_t*)(s_sc + (MODE == 2 ? gpad : 0));         // entries of every cell (a column holds fewer than 2^32)
   const int64_t c0 = (int64_t)b * s.cpb, c1 = c0 + s.cpb < s.n_cells ? c0 + s.cpb : s.n_cells;
   const int nc = (int)(c1 - c0);
   const uint32_t* row = cnt + (size_t)b * (size_t)s.G + g0;
@@ -138,7 +142,11 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_scatter(TrShape s, const int6
     s_cnt[t] = row[t] + (MODE ? (uint32_t)out_ptr[g0 + t] : 0u);
     if (MODE == 2) s_sc[t] = -1;
   }
-  for (int t = tid; t <= nc; t += TR_THREADS) s_cp[t] = tr_clamp(colptr[c0 + t], s.nnz);
+  for (int t = tid; t < nc; t += TR_THREADS) {
+    const int64_t lo = tr_clamp(ptr_b[c0 + t], s.nnz), hi = tr_clamp(ptr_e[c0 + t], s.nnz);
+    s_cp[t] = lo;
+    s_len[t] = hi > lo ? (uint32_t)(hi - lo) : 0u;
+  }
   __syncthreads();
 
   auto place = [&](int t, int64_t base, int32_t cell, double xv) {
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_scatter(TrShape s, const int6
   double px[TR_PRE];
   int64_t pb[TR_PRE];
   auto fetch = [&](int ci) {
-    const int64_t lo = s_cp[ci], hi = s_cp[ci + 1];
+    const int64_t lo = s_cp[ci], hi = lo + (int64_t)s_len[ci];
 #pragma unroll
     for (int u = 0; u < TR_PRE; ++u) {
       const int64_t e = lo + tid + u * TR_THREADS;
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(TR_THREADS) void k_tr_scatter(TrShape s, const int6
     for (int u = 0; u < TR_PRE; ++u)
       if (cg[u] >= 0) place(cg[u], cb[u], cell, cx[u]);
     // the part of a long column beyond the entries fetched ahead
-    const int64_t hi = s_cp[ci + 1];
+    const int64_t hi = s_cp[ci] + (int64_t)s_len[ci];
     for (int64_t e = s_cp[ci] + tid + (int64_t)TR_PRE * TR_THREADS; e < hi; e += TR_THREADS) {
       const int64_t g = rowidx[e];
       const int64_t t = g - g0;
@@ -226,9 +234,27 @@ size_t gficf_csc_transpose_workspace_bytes(int64_t G, int64_t n_cells) {
   return (size_t)s.n_blocks * (size_t)(G > 0 ? G : 1) * sizeof(uint32_t) + 256;
 }
 
+static int transpose_launch(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr, const int64_t* d_col_end, const int32_t* d_rowidx,
+                            const double* d_x, int64_t nnz, int64_t* d_out_ptr, int32_t* d_out_idx, double* d_out_x, void* d_ws, size_t ws_bytes);
+
 int gficf_csc_transpose_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr, const int32_t* d_rowidx,
                                const double* d_x, int64_t nnz, int64_t* d_out_ptr, int32_t* d_out_idx, double* d_out_x, void* d_ws,
                                size_t ws_bytes) {
+  return transpose_launch(ctx, G, n_cells, d_colptr, d_colptr ? d_colptr + 1 : nullptr, d_rowidx, d_x, nnz, d_out_ptr, d_out_idx, d_out_x, d_ws, ws_bytes);
+}
+
+/* t() of a matrix in the pointerB / pointerE form (gficf_csc_scale_be_device): cell c's entries are [d_col_begin[c], d_col_end[c])
+ * of arrays with `capacity` entries; the result is an ordinary compact cells x genes CSC (d_out_ptr[G] = number of entries;
+ * d_out_idx / d_out_x need room for them: `capacity` always suffices). */
+int gficf_csc_transpose_be_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_col_begin, const int64_t* d_col_end,
+                                  const int32_t* d_rowidx, const double* d_x, int64_t capacity, int64_t* d_out_ptr, int32_t* d_out_idx,
+                                  double* d_out_x, void* d_ws, size_t ws_bytes) {
+  if (G > 0 && n_cells > 0 && !d_col_end) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  return transpose_launch(ctx, G, n_cells, d_col_begin, d_col_end, d_rowidx, d_x, capacity, d_out_ptr, d_out_idx, d_out_x, d_ws, ws_bytes);
+}
+
+static int transpose_launch(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr, const int64_t* d_col_end, const int32_t* d_rowidx,
+                            const double* d_x, int64_t nnz, int64_t* d_out_ptr, int32_t* d_out_idx, double* d_out_x, void* d_ws, size_t ws_bytes) {
   GFICF_CTX_ENTER(ctx);
   if (G < 0 || n_cells < 0 || nnz < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (!d_out_ptr) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
@@ -244,7 +270,7 @@ int gficf_csc_transpose_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const
   const size_t lds = tr_lds_bytes(s);
   static std::atomic<bool> attr_set[64];                 // per device: the attribute belongs to the device's copy of the kernel
   if (!attr_set[ctx->device & 63]) {
-    const int mx = (int)((size_t)TR_GENES * 4 + (size_t)(TR_MAX_CPB + 1) * 8);   // 155 656 B of the CU's 160 KB
+    const int mx = (int)((size_t)TR_GENES * 4 + (size_t)(TR_MAX_CPB + 1) * 12);  // 159 756 B of the CU's 160 KB
     GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_tr_count, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_tr_scatter<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
     GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_tr_scatter<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
@@ -253,13 +279,13 @@ int gficf_csc_transpose_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const
   }
   uint32_t* cnt = (uint32_t*)d_ws;
   const dim3 grid((unsigned)s.n_blocks, (unsigned)s.n_ranges);
-  hipLaunchKernelGGL(k_tr_count, grid, dim3(TR_THREADS), (size_t)((s.gcap + 1) & ~1) * 4, ctx->stream, s, d_colptr, d_rowidx, cnt, ctx->d_status);
+  hipLaunchKernelGGL(k_tr_count, grid, dim3(TR_THREADS), (size_t)((s.gcap + 1) & ~1) * 4, ctx->stream, s, d_colptr, d_col_end, d_rowidx, cnt, ctx->d_status);
   hipLaunchKernelGGL(k_tr_prefix, dim3((unsigned)gficf_ceil_div(G, 16)), dim3(256), 0, ctx->stream, s, cnt, d_out_ptr);
   GFICF_HIP_CHECK(hipGetLastError());
   const int rc = gficf_exclusive_scan_i64(ctx, d_out_ptr, G + 1);
   if (rc) return rc;
   auto* kern = nnz >= ((int64_t)1 << 32) ? k_tr_scatter<0> : s.pair ? k_tr_scatter<2> : k_tr_scatter<1>;
-  hipLaunchKernelGGL(kern, grid, dim3(TR_THREADS), lds, ctx->stream, s, d_colptr, d_rowidx, d_x, cnt, d_out_ptr, d_out_idx, d_out_x);
+  hipLaunchKernelGGL(kern, grid, dim3(TR_THREADS), lds, ctx->stream, s, d_colptr, d_col_end, d_rowidx, d_x, cnt, d_out_ptr, d_out_idx, d_out_x);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }

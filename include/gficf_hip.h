@@ -367,6 +367,25 @@ int gficf_csc_exact_device(gficf_ctx* ctx, int64_t G, int64_t N, const int64_t* 
                            gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept, int64_t* d_out_colptr,
                            int32_t* d_out_rowidx, double* d_out_x);
 
+/* The device-resident chain in the pointerB / pointerE ("four-array") form of a compressed matrix — what sparse BLAS libraries
+ * call CSC with separate column-begin and column-end arrays.  The canonical output above needs GLOBAL positions (the compacted
+ * column pointer), i.e. a pass of its own over rowidx between the gene table and the scaling pass (gficf_csc_colptr_device: 14 % of
+ * the whole pass at 88 M entries).  Here every cell compacts INSIDE ITS OWN INPUT RANGE: the kept entries of cell c are written
+ * from position d_colptr[c] on and d_out_end[c] is the position behind the last one; (d_colptr, d_out_end, d_out_rowidx, d_out_x)
+ * is the matrix — same entries, same order, same values as the canonical form, with unused room between the columns (the arrays
+ * keep the input's nnz entries of capacity).  The steps that follow gficf() on the device read this form directly:
+ * gficf_csc_transpose_be_device (t(gficf), whose result is an ordinary compact CSC) and gficf_cluster_signatures_be_device.
+ * The host entries and gficf_csc_device keep returning the canonical form (R/gficf.R:17-33: a dgCMatrix).
+ *   gficf_csc_scale_be_device : step 5 of the device pipeline in this form (no step 4);
+ *   gficf_csc_be_device       : gficf_csc_device (exact == 0) / gficf_csc_exact_device (exact != 0) in this form: three launches. */
+int gficf_csc_scale_be_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr, const int32_t* d_rowidx,
+                              const double* d_x, int64_t nnz, const gficf_gene_entry* d_genes, const int64_t* d_gkept,
+                              int64_t* d_out_end, int32_t* d_out_rowidx, double* d_out_x);
+int gficf_csc_be_device(gficf_ctx* ctx, int exact, int64_t G, int64_t N, const int64_t* d_colptr, const int32_t* d_rowidx,
+                        const double* d_x, int64_t nnz, double prop_min, double prop_max, const double* d_w_in,
+                        int64_t* d_nt, uint8_t* d_keep, gficf_gene_entry* d_genes, double* d_w, int64_t* d_gkept,
+                        int64_t* d_out_end, int32_t* d_out_rowidx, double* d_out_x);
+
 /* ------------------------------------------------------------------- several GPUs behind the host entries
  * The reference's call sites are one `.Call` each (R/clustCells.R:65; gficf() R/gficf.R:17-33), so a drop-in that
  * shards over the GPUs of a node does it underneath that one call: single process, one context and one stream per
@@ -422,6 +441,9 @@ int gficf_multi_set_jaccard_distinct(gficf_multi* m, int assume_distinct);
 int gficf_cluster_signatures_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_colptr,
                                     const int32_t* d_rowidx, const double* d_x,
                                     const int32_t* d_cluster, int32_t C, double* d_out);
+/* the same over a matrix in the pointerB / pointerE form (cell c = [d_col_begin[c], d_col_end[c])) */
+int gficf_cluster_signatures_be_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_col_begin, const int64_t* d_col_end,
+                                       const int32_t* d_rowidx, const double* d_x, const int32_t* d_cluster, int32_t C, double* d_out);
 int gficf_cluster_signatures_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* colptr,
                                   int colptr_is_i64, const int32_t* rowidx, const double* x,
                                   const int32_t* cluster, int32_t C, double* out);
@@ -439,6 +461,11 @@ int gficf_csc_transpose_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const
                                const int32_t* d_rowidx, const double* d_x, int64_t nnz,
                                int64_t* d_out_ptr, int32_t* d_out_idx, double* d_out_x, void* d_ws,
                                size_t ws_bytes);
+/* the same of a matrix in the pointerB / pointerE form; `capacity` = entries the input arrays hold (the clamp for bad pointers);
+ * the result is compact: d_out_ptr[G] entries. */
+int gficf_csc_transpose_be_device(gficf_ctx* ctx, int64_t G, int64_t n_cells, const int64_t* d_col_begin, const int64_t* d_col_end,
+                                  const int32_t* d_rowidx, const double* d_x, int64_t capacity, int64_t* d_out_ptr, int32_t* d_out_idx,
+                                  double* d_out_x, void* d_ws, size_t ws_bytes);
 int gficf_csc_transpose_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* colptr,
                              int colptr_is_i64, const int32_t* rowidx, const double* x,
                              int64_t* out_ptr, int32_t* out_idx, double* out_x);

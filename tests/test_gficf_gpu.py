@@ -4,6 +4,7 @@ within 1e-6 (absolute and relative) as BASELINE.json states — f64 throughout, 
 differences are ~1e-16 (summation order only)."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -12,6 +13,8 @@ import scipy.sparse as sp
 import gficf_amd
 import oracle
 from gficf_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -682,3 +685,74 @@ def test_config4_shape_as_eight_cell_blocks_matches_the_single_shot_pass():
         assert torch.allclose(w2["out_x"][:m], ws["out_x"][q0:q1], rtol=1e-12, atol=1e-15)
         del w2
     assert sum(p[5] - p[4] for p in parts) == nk
+
+
+@pytest.mark.parametrize("G,N,mn,mx,seed,env", [(1500, 900, 0.05, 1.0, 1, {}), (5000, 3000, 0.05, 1.0, 2, {}), (23000, 6000, 0.0, 2.0, 3, {}),
+                                               (800, 400, 0.3, 0.9, 4, {}), (3000, 2000, 0.05, 1.0, 5, {"GFICF_SCALE_FORCE_GLOBAL": "1"}),
+                                               (70000, 300, 0.0, 2.0, 6, {}), (64, 1, 0.0, 2.0, 7, {}), (2000, 1200, 0.99, 1.0, 8, {})])
+def test_pointer_begin_end_form_equals_the_canonical_pass(G, N, mn, mx, seed, env):
+    """The device-resident chain's form of the result (gficf_csc_be_device): every cell compacts inside its own input range —
+    cell c = out[colptr[c] : out_end[c]] — so no global positions, no kept-count pass and no scan are needed (three launches
+    instead of five).  Entry for entry the canonical compacted CSC (same kernels, same arithmetic: the values are bit-equal),
+    which in turn is checked against the oracle; t() and the cluster sums of the form equal those of the canonical matrix."""
+    import subprocess
+
+    if env:                      # (the variant switches are read once per process)
+        code = (f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+                f"import test_gficf_gpu as t; t.test_pointer_begin_end_form_equals_the_canonical_pass({G}, {N}, {mn}, {mx}, {seed}, {{}})\n")
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return
+    import torch
+
+    ops = gficf_amd.HipOps(0)
+    colptr, rowidx, x = synth.counts_csc(G, N, seed=seed)
+    if N > 2:                    # an empty cell, and one whose entries are all dropped or all kept
+        colptr = colptr.copy()
+        cut = colptr[2] - colptr[1]
+        rowidx, x = np.delete(rowidx, slice(colptr[1], colptr[2])), np.delete(x, slice(colptr[1], colptr[2]))
+        colptr[2:] -= cut
+    cp, ri, xv = torch.from_numpy(colptr.astype(np.int64)).cuda(), torch.from_numpy(rowidx.astype(np.int32)).cuda(), torch.from_numpy(x).cuda()
+    nnz = int(ri.numel())
+    can = ops.gficf_csc(G, N, cp, ri, xv, mn, mx, None, None, exact=True)
+    ops.sync()
+    ref = oracle.gficf_csc(G, N, colptr.astype(np.int64), rowidx, x, mn, mx)
+    kn = int(can["out_colptr"][N])
+    assert kn == len(ref["x"]) and np.array_equal(can["out_rowidx"][:kn].cpu().numpy(), ref["rowidx"])
+    assert np.allclose(can["out_x"][:kn].cpu().numpy(), ref["x"], rtol=1e-6, atol=1e-6)
+    be = ops.gficf_csc_be(G, N, cp, ri, xv, mn, mx, None, None, exact=True)
+    ops.sync()
+    end = be["out_end"][:N]
+    lens = end - cp[:N]
+    assert torch.equal(lens, can["out_colptr"][1:N + 1] - can["out_colptr"][:N])            # kept entries per cell
+    assert bool((end <= cp[1:N + 1]).all()) and bool((lens >= 0).all())
+    # gather the form into a compact matrix: entry for entry the canonical one, bit-equal values
+    if kn:
+        cell = torch.repeat_interleave(torch.arange(N, device="cuda"), lens)
+        pos = torch.arange(kn, device="cuda") - can["out_colptr"][:N][cell] + cp[:N][cell]
+        assert torch.equal(be["out_rowidx"][pos], can["out_rowidx"][:kn]) and torch.equal(be["out_x"][pos], can["out_x"][:kn])
+    assert torch.equal(be["keep"], can["keep"]) and torch.equal(be["nt"], can["nt"]) and torch.equal(be["w"], can["w"])
+    gk = int(can["gkept"][0])
+    if gk == 0 or kn == 0:
+        return
+    # t(): the result is an ordinary compact CSC, equal to the transpose of the canonical matrix
+    tws = torch.zeros(ops.csc_transpose_workspace_bytes(gk, N), dtype=torch.uint8, device="cuda")
+    outs = []
+    for form in ("canonical", "be"):
+        t_ptr = torch.zeros(gk + 1, dtype=torch.int64, device="cuda")
+        t_idx, t_val = torch.full((nnz,), -7, dtype=torch.int32, device="cuda"), torch.zeros(nnz, dtype=torch.float64, device="cuda")
+        if form == "canonical":
+            ops.csc_transpose(gk, N, can["out_colptr"], can["out_rowidx"][:kn], can["out_x"][:kn], t_ptr, t_idx, t_val, tws)
+        else:
+            ops.csc_transpose_be(gk, N, cp, be["out_end"], be["out_rowidx"], be["out_x"], t_ptr, t_idx, t_val, tws)
+        ops.sync()
+        outs.append((t_ptr, t_idx[:kn], t_val[:kn]))
+    assert int(outs[1][0][gk]) == kn and all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    # cluster sums
+    C = 7
+    cl = (torch.arange(N, device="cuda", dtype=torch.int64) * 2654435761 % C).to(torch.int32)
+    s_can, s_be = torch.zeros((C, gk), dtype=torch.float64, device="cuda"), torch.zeros((C, gk), dtype=torch.float64, device="cuda")
+    ops.cluster_signatures(gk, N, can["out_colptr"], can["out_rowidx"][:kn], can["out_x"][:kn], cl, C, s_can)
+    ops.cluster_signatures_be(gk, N, cp, be["out_end"], be["out_rowidx"], be["out_x"], cl, C, s_be)
+    ops.sync()
+    assert torch.allclose(s_can, s_be, rtol=1e-12, atol=1e-14)

@@ -7,13 +7,17 @@ Model (constants below): an all-gather moves every rank's block over each of its
 + LAT_US; an all-to-all with equal splits of s bytes per peer -> s / LINK_GBS + LAT_US (one link per peer); kernels of one data
 set run in order on one stream with GAP_US between dependent launches (non-pipelined: what bench.py reports as `value`);
 pipelined = max(sum of the kernel times, exchange) (exchange of the next data set under the edge kernel of this one; `--pipeline`,
-never `value`)."""
+never `value`).  Third form, round 4: "peer" — the single-process step of the C ABI (gficf_multi_jaccard_device): ingest, then
+every device pulls the other P - 1 UNPACKED table slices with hipMemcpyPeerAsync (one slice per link, all pairs at once), then
+edges on the full table; no collective, so the fixed cost of the exchange is a copy's start-up (PEER_LAT_US) instead of LAT_US,
+but the rows travel as the table holds them (128 B from 2^17 cells on) and no pack / unpack kernels run."""
 import json
 import sys
 
 LINK_GBS = 55.0      # achieved per link and direction in RCCL collectives (xGMI, 76.8 GB/s nominal per direction); VERDICT r2 item 2 uses 55
 LAT_US = 20.0        # launch + protocol latency of one small RCCL collective
 GAP_US = 2.0         # between dependent kernel launches on one stream
+PEER_LAT_US = 6.0    # start-up of a peer copy behind an event (SDMA engine); the host's enqueue of a step runs ahead on its own threads
 
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip().startswith("{")]
 one = next(r for r in rows if r["P"] == 1)
@@ -28,8 +32,16 @@ for r in rows:
     if P == 1:
         continue
     for ids in ("spatial", "permuted"):
-        for form in ("allgather", "halo"):
+        for form in ("allgather", "peer", "halo"):
             d = r.get(f"{form}_{ids}")
+            if form == "peer":
+                ag = r.get(f"allgather_{ids}")
+                if not ag:
+                    continue
+                n_rem = ag["bytes_received"] // ag["wire_bytes_per_row"]        # rows of the other ranks
+                d = {"ingest_ms": ag["ingest_ms"], "edges_ms": ag["edges_ms"], "table_row_bytes": ag["table_row_bytes"],
+                     "bytes_received": n_rem * ag["table_row_bytes"]}
+                d["compute_ms"] = d["ingest_ms"] + d["edges_ms"]
             if not d or (form == "halo" and not d.get("fits")):
                 if d is not None and form == "halo":
                     print(f"| {P} | {ids} | halo | {d['rows_named_outside']}+ | - | - | - | request slots overflow: falls back to the all-gather | | | | |")
@@ -38,6 +50,9 @@ for r in rows:
             comp = d["compute_ms"] * 1e3 + GAP_US * n_k
             if form == "allgather":
                 ex = d["bytes_received"] / (P - 1) / (LINK_GBS * 1e3) + LAT_US           # one block per link
+                named = "all"
+            elif form == "peer":
+                ex = d["bytes_received"] / (P - 1) / (LINK_GBS * 1e3) + PEER_LAT_US      # one unpacked slice per link, pulled side by side
                 named = "all"
             else:
                 per_peer_req, per_peer_rows = d["cap"] * 4, d["cap"] * 4 * r["k"]
