@@ -900,6 +900,8 @@ def main():
     # the edge kernel of this shape is k_jaccard_edges_pipe (k <= 32) or k_jaccard_edges; make_traffic.py keys by kernel name
     traffic = None if halo_form else (pmc.get(f"jaccard_edges_pipe_N{N_total}_k{k}") or pmc.get(f"jaccard_edges_N{N_total}_k{k}") or {}).get("hbm_bytes_per_launch")
     edge_kernel = "k_jaccard_edges_pipe" if (k <= 32 and not os.environ.get("GFICF_JACCARD_NO_PIPE")) else "k_jaccard_edges"   # the name rocprofv3 shows
+    if 32 < k <= 55 and (shards[0].row_words if halo_form else ops.row_words(N_total, k)) == 64 and (shards[0].n_ext if halo_form else N_total) <= 131070:
+        edge_kernel = "k_jaccard_edges_bits"                         # dual rows: the direct-address bit-set kernel
     traffic_source = "profiles/pmc_traffic.json (separate --pmc passes of tools/pmc_round.sh, read requests priced by their width: tools/make_traffic.py)" if traffic else None
     traffic_detail = None
     if world == 1 and not args.no_live_traffic and not args.no_extras:

@@ -77,8 +77,31 @@ __host__ __device__ inline uint32_t unscramble16(uint32_t half) {
 struct TableFmt {
   int kpad;
   bool compact;
-  int row_words;
+  bool dual;         // compact rows + a second, "planar" copy of the ids for the gathers of k_jaccard_edges_bits (below)
+  int row_words;     // row PITCH of the table in 32-bit words
 };
+
+// ---- dual rows (round 4): 32 < k <= 55 and N <= 131070.  The general edge kernel is bound by its probe arithmetic at these row
+// sizes (100 k x 50: 6.6e7 vector instructions, 47 % of its LDS time conflict replays — profiles/r03_pmc_summary_c4.txt), and two of
+// the ~7.5 issue slots of a probed id go into pulling the id's bit 16 out of the row's bitmap.  A direct-address BIT SET in LDS
+// (2^17 bits = 16 KiB per wave) needs no hash, no key compare and no overflow list — word address, one ds_read_b32, shift, and,
+// add — IF the plane (bit 16) of an id costs nothing per id.  So a table row becomes 64 words:
+//   words  0..31  the compact row as before: what a cell's OWN row is read from (slot order = the reference's edge order), what
+//                 every other kernel (exact path, edge filter, transport) reads;
+//   words 32..63  the same ids once more, regrouped for the GATHERS: the ids below 2^16 first, in groups of 8 halves (one 16 B
+//                 lane piece each) padded with 0x0000, then the ids from 2^16 on as (id - 2^16), padded with 0xFFFF — so every
+//                 lane's 8 ids lie in ONE plane and the plane is a property of the lane; plain halves, not pre-hashed.  Word 63
+//                 is a header: bits 0..3 = number of groups of the first plane, bit 31 = the row's duplicate flag.  62 slots hold
+//                 any split of k <= 55 ids into two padded runs; id 0 ("none") pads the first plane, id 131071 the second:
+//                 neither is ever in a set (ids are 1..N, N <= 131070).
+// The counts do not depend on the order of a GATHERED row's ids, only the own row needs its slots in order: hence two copies.
+// The gathered 128 B are one line, as before; the table doubles (25.6 MB at 100 k cells) but the lines the gathers touch do not.
+constexpr int DUAL_PITCH = 64;
+constexpr uint32_t DUAL_PAD1 = 0xFFFFu;
+inline bool dual_enabled() {
+  const char* e = getenv("GFICF_JACCARD_DUAL");            // A/B switch, read per call: 0 = the general kernel on plain compact rows
+  return !(e && atoi(e) == 0);
+}
 
 inline bool compact_enabled() {
   static const bool on = [] {
@@ -93,7 +116,8 @@ inline TableFmt table_fmt(int64_t N_total, int k) {
   f.kpad = kpad_for(k);
   static const bool force_big = getenv("GFICF_JACCARD_FORCE_BIG") != nullptr;     // test hook of the 64-bit kernel variant: wide rows
   f.compact = compact_enabled() && !force_big && N_total < (1ll << 17) && f.kpad >= 32 && k <= f.kpad - f.kpad / 16;
-  f.row_words = f.compact ? f.kpad / 2 : f.kpad;
+  f.dual = f.compact && f.kpad == 64 && k <= 55 && N_total <= 131070 && dual_enabled();
+  f.row_words = f.dual ? DUAL_PITCH : f.compact ? f.kpad / 2 : f.kpad;
   return f;
 }
 
@@ -108,6 +132,58 @@ __device__ inline uint32_t row_slot_id(const uint32_t* roww, int j, int kpad, bo
 }
 __device__ inline bool row_dup_flag(const uint32_t* roww, int kpad, bool compact) {
   return ((compact ? roww[kpad / 2 - 1] : roww[0]) & ROW_DUP_FLAG) != 0;
+}
+
+__device__ inline void wave_lds_fence_early() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+// The planar part of a dual row (32 words, built in LDS by one wave): ids = the row's slot ids (0 = none), lane = slot.
+__device__ inline void planar_row_build(const uint32_t* ids, int k, bool dupflag, uint32_t* prow, int lane) {
+  const bool valid = lane < k;
+  const uint32_t id = valid ? ids[lane] : 0u;
+  const bool p1 = valid && id >= 65536u, p0 = valid && !p1;
+  const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+  const int g0 = (__popcll(m0) + 7) >> 3;                      // groups of 8 halves of the first plane
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint16_t* const ph = reinterpret_cast<uint16_t*>(prow);
+  ph[lane] = lane < 8 * g0 ? (uint16_t)0u : (uint16_t)DUAL_PAD1;   // 64 halves: the pads of both planes (the last two become the header)
+  wave_lds_fence_early();
+  if (p0) ph[__popcll(m0 & lt)] = (uint16_t)id;
+  if (p1) ph[8 * g0 + __popcll(m1 & lt)] = (uint16_t)(id & 0xFFFFu);
+  wave_lds_fence_early();
+  if (lane == 0) prow[31] = (uint32_t)g0 | (dupflag ? ROW_DUP_FLAG : 0u);
+  wave_lds_fence_early();
+}
+
+// Four rows at a time (the LDS round trips of the three phases are shared by the four): ids[r] = row r's slot ids, prow[r] its
+// 32-word scratch, n = rows that exist (1..4); dup bit r of dupmask = row r's duplicate flag.
+__device__ inline void planar_rows_build4(const uint32_t* const (&ids)[4], int n, int k, uint32_t dupmask, uint32_t (*prow)[32], int lane) {
+  const bool valid = lane < k;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t id[4];
+  unsigned long long m0[4], m1[4];
+  int g0[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    id[r] = (valid && r < n) ? ids[r][lane] : 0u;
+    const bool p1 = valid && id[r] >= 65536u, p0 = valid && !p1;
+    m0[r] = __ballot(p0);
+    m1[r] = __ballot(p1);
+    g0[r] = (__popcll(m0[r]) + 7) >> 3;
+    reinterpret_cast<uint16_t*>(prow[r])[lane] = lane < 8 * g0[r] ? (uint16_t)0u : (uint16_t)DUAL_PAD1;
+  }
+  wave_lds_fence_early();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    uint16_t* const ph = reinterpret_cast<uint16_t*>(prow[r]);
+    const bool p1 = valid && id[r] >= 65536u;
+    if (valid) ph[p1 ? 8 * g0[r] + __popcll(m1[r] & lt) : __popcll(m0[r] & lt)] = (uint16_t)(id[r] & 0xFFFFu);
+  }
+  wave_lds_fence_early();
+  {
+    const int gsel = lane == 0 ? g0[0] : lane == 1 ? g0[1] : lane == 2 ? g0[2] : g0[3];
+    if (lane < 4) prow[lane][31] = (uint32_t)gsel | (((dupmask >> lane) & 1u) ? ROW_DUP_FLAG : 0u);
+  }
+  wave_lds_fence_early();
 }
 
 // ------------------------------------------------------------------------------ ingest
@@ -219,14 +295,22 @@ __device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD], int k) {
 // matrix first: one more kernel and 2 x 16 MB of traffic per step at 100 k cells); also writes the local -> global map.
 // SCAN = false (gficf_ctx_set_jaccard_distinct): rows are taken to hold distinct ids and no flag is written; the edge kernel
 // finds a repeated id when it inserts the row into its hash set and raises a deferred error.
-template <typename T, int KPAD, bool CMP, bool HALO = false, bool SCAN = true>
-__global__ __launch_bounds__(256, HALO ? 4 : 1) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
+template <typename T, int KPAD, bool CMP, bool HALO = false, bool SCAN = true, bool DUAL = false>
+// (second launch bound = waves per SIMD the kernel must fit: 100 k cells are 1563 tiles, one per workgroup; at the 79 / 93 vector
+// registers the scan-less 64-slot variants would take, a CU holds 6 / 5 workgroups — 1536 / 1280 resident ones, and the last tiles
+// wait for a second round: 7 per SIMD = 1792)
+__global__ __launch_bounds__(256, (KPAD == 64 && !SCAN) ? 7 : HALO ? 4 : 1) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                      int64_t N_total, uint32_t* __restrict__ table,
                                                      uint32_t* __restrict__ status, int zero_ok, const gficf_halo_map hm) {
   constexpr int ROWS = 64;
   constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
+  static_assert(!DUAL || (CMP && KPAD == 64), "dual rows are compact rows of 64 slots");
+  constexpr int PITCH = DUAL ? DUAL_PITCH : ROWW;            // words from one table row to the next
   __shared__ uint32_t tile[ROWS][KPAD + 1];
   __shared__ uint32_t dup[ROWS];
+  // dual rows: a wave's scratch for the planar part of ONE row (a whole tile of them would cost 8 KB of LDS: six workgroups per CU
+  // instead of nine, 1536 resident ones for the 1563 tiles of 100 k cells — a second round for the last 27: 26 us against 13)
+  __shared__ uint32_t prow[DUAL ? 16 : 1][DUAL ? 32 : 1];     // (four rows in flight per wave)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // HALO: the launch ingests rows [row_begin, row_end) of the sub-problem (n_rows = row_end); its LAST serve_blocks workgroups do the
   // owner-side serve step instead (the rows other ranks asked of this one: independent of the ingest, one launch saved per step)
@@ -319,10 +403,24 @@ __global__ __launch_bounds__(256, HALO ? 4 : 1) void k_ingest_tile(const T* __re
       __syncthreads();
     }
     const int64_t rows_here = (n_rows - row0) < ROWS ? (n_rows - row0) : ROWS;
+    if constexpr (DUAL) {                                   // a wave builds the planar parts of 16 rows of the tile, one after the other,
+      for (int r0 = wave * 16; r0 < (int)rows_here && r0 < wave * 16 + 16; r0 += 4) {   // rows 16 w .. 16 w + 15, four at a time,
+        const int n = (int)rows_here - r0 < 4 ? (int)rows_here - r0 : 4;                 // each written as one 128 B run
+        const uint32_t* const ids[4] = {&tile[r0][0], &tile[r0 + 1 < ROWS ? r0 + 1 : r0][0], &tile[r0 + 2 < ROWS ? r0 + 2 : r0][0],
+                                        &tile[r0 + 3 < ROWS ? r0 + 3 : r0][0]};
+        uint32_t dm = 0;
+        if (SCAN)
+          for (int r = 0; r < n; ++r) dm |= (dup[r0 + r] != 0u ? 1u : 0u) << r;
+        planar_rows_build4(ids, n, k, dm, &prow[wave * 4], lane);
+        const int r = lane >> 4, w2 = (lane & 15) * 2;                                   // 16 lanes per row, 8 B each
+        if (r < n) *reinterpret_cast<uint2*>(table + (row0 + r0 + r) * PITCH + ROWW + w2) = make_uint2(prow[wave * 4 + r][w2], prow[wave * 4 + r][w2 + 1]);
+        wave_lds_fence_early();
+      }
+    }
     const int n_out4 = (int)rows_here * (ROWW / 4);
-    uint4* const out4 = reinterpret_cast<uint4*>(table + row0 * ROWW);
     for (int e = tid; e < n_out4; e += 256) {
       const int rr = e / (ROWW / 4), j0 = (e % (ROWW / 4)) * 4;
+      uint4* const dst4 = reinterpret_cast<uint4*>(table + (row0 + rr) * PITCH + j0);       // (PITCH == ROWW unless the rows are dual)
       uint32_t w4[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -343,7 +441,7 @@ __global__ __launch_bounds__(256, HALO ? 4 : 1) void k_ingest_tile(const T* __re
         }
         w4[c] = x;
       }
-      out4[e] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+      *dst4 = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
     __syncthreads();
   }
@@ -596,9 +694,9 @@ template <int KPAD, bool CMP, int OUT>
 __device__ __noinline__ void slow_cell(const uint32_t* __restrict__ table, int64_t i, int k, int64_t out_base,
                                        uint32_t* sA, uint32_t* sB, int lane, double* o_src, double* o_dst,
                                        double* o_w, int32_t* o_u, uint16_t* o_u16, int set_mode, const double* lut,
-                                       const int32_t* l2g, uint32_t src_off) {
+                                       const int32_t* l2g, uint32_t src_off, int pitch = 0) {
   const EdgeOut o{o_src, o_dst, o_w, o_u, o_u16, set_mode, nullptr, src_off};
-  constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
+  const int ROWW = pitch ? pitch : (CMP ? CFmt<KPAD>::ROWW : KPAD);     // row pitch (dual rows: 64 words, the compact part in front)
   for (int e = lane; e < KPAD; e += 64) sA[e] = row_slot_id(table + i * ROWW, e, KPAD, CMP);
   wave_lds_fence();
   for (int s = 0; s < k; ++s) {
@@ -1414,11 +1512,291 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
   }
 }
 
+// ------------------------------------------------------------------ edge kernel on dual rows: a direct-address bit set (32 < k <= 55)
+// One wave per cell, two cells in flight per wave (the pipelined kernel's scheme: cell i+1's gathers and cell i+2's own row are
+// requested before cell i's pieces are probed; every load and store between two waits is unconditional, so the wait counts stay
+// exact).  Row i goes into the wave's BIT SET — 2^17 bits = 16 KiB of LDS, plane 0 = ids below 2^16, plane 1 = the rest, the wave's
+// region 16 KiB-aligned so that a probe address is (bits of the half) | base, one v_bitop3 —: ds_or with return (an id already
+// there = the row repeats it: the deferred duplicate report).  A lane gathers 16 B = 8 halves of the PLANAR part of a neighbour
+// row; all eight lie in one plane, which the lane knows from the row's header (one ds_bpermute per piece).  Per id: word address
+// (shift, bitop3), ds_read_b32, shift by the id's low five bits (v_lshrrev takes them straight from the packed word), and 1,
+// add: 5-6 issue slots against ~7.5 of the hash-set probe, no overflow list, no set clearing beyond the k words touched, and the
+// LDS reads are 4 B wide instead of 8.  LDS bounds the residency (3 waves of 16 KiB per workgroup, 3 workgroups per CU), which a
+// kernel limited by its vector instructions tolerates; NST = gather steps of a cell (8 rows each), a template parameter so that
+// the number of requests between two waits is a constant.
+// waves per workgroup x cells in flight per wave, measured at 100 k x 50 on permuted ids (tools/bits_ab.sh, profiles/r04_bits_kernel.txt;
+// the general kernel: 121 us): 2 x 2: 99 us, 4 x 2: 99, 2 x 3: 102, 3 x 2: 113, 3 x 3: 114, 1 x 2: 118 — what matters is that the
+// waves a CU holds (LDS: 16 KiB each) divide evenly over its four SIMDs: 8 per CU (2 or 4 per workgroup), not 9.
+#ifndef GFICF_BITS_WAVES
+#define GFICF_BITS_WAVES 2
+#endif
+#ifndef GFICF_BITS_DEPTH
+#define GFICF_BITS_DEPTH 2
+#endif
+constexpr int BITS_WAVES = GFICF_BITS_WAVES;
+constexpr int BITS_DEPTH = GFICF_BITS_DEPTH;                  // cells in flight per wave (2..4)
+constexpr uint32_t BITS_WB = 16384u;                          // LDS bytes of one wave's bit set
+constexpr uint32_t BITS_LUT_OFF = BITS_WAVES * BITS_WB;
+constexpr uint32_t BITS_DUPF_OFF = BITS_LUT_OFF + 64u * 8u;   // weight table: k + 1 <= 56 doubles
+constexpr size_t BITS_LDS_BYTES = BITS_DUPF_OFF + BITS_WAVES * 4u;
+
+__device__ inline uint32_t lds_read_b32(uint32_t addr) { return *(__attribute__((address_space(3))) const uint32_t*)(size_t)addr; }
+__device__ inline void lds_write_b32(uint32_t addr, uint32_t v) { *(__attribute__((address_space(3))) uint32_t*)(size_t)addr = v; }
+__device__ inline uint32_t lds_or_rtn_b32(uint32_t addr, uint32_t v) {
+  return __hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t*)(size_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int NST, int OUT, bool MAP>
+__global__ __launch_bounds__(BITS_WAVES * 64) void k_jaccard_edges_bits(
+    const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
+  using F = CFmt<64>;
+  extern __shared__ unsigned char smem[];
+  double* const s_lut = reinterpret_cast<double*>(smem + BITS_LUT_OFF);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int u = tid; u <= k; u += BITS_WAVES * 64) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);   // reference :51
+  {
+    uint4* const z = reinterpret_cast<uint4*>(smem + (uint32_t)wave * BITS_WB);
+    for (int t = lane; t < (int)(BITS_WB / 16); t += 64) z[t] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (lane == 0) *reinterpret_cast<uint32_t*>(smem + BITS_DUPF_OFF + (uint32_t)wave * 4u) = 0u;
+  __syncthreads();
+
+  const uint32_t wbase = lds_address(smem) + (uint32_t)(tid >> 6) * BITS_WB;   // a multiple of 16 KiB (dynamic LDS starts at 0: no static LDS here)
+  uint32_t mask_v = 0x1FFCu;                                   // word offset inside a plane, as a vector register (operand of v_bitop3_b32)
+  asm volatile("" : "+v"(mask_v));
+  const char* const tbytes = reinterpret_cast<const char*>(table);
+  const int grow = lane >> 3, gl = lane & 7;
+  const uint32_t gcol = 128u + (uint32_t)gl * 16u;            // this lane's piece of the planar part of a row
+  const int64_t nwaves = (int64_t)gridDim.x * BITS_WAVES;
+  // Lane (row group g = lane / 8, position gl = lane % 8) OWNS slot gl * 8 + g of the cell's row: gather step st serves slots
+  // st * 8 .. st * 8 + 7, row group g of the step gathers the row named by slot st * 8 + g — which is held by lane st OF THE SAME
+  // GROUP.  So the neighbour id a group needs is a broadcast inside 8 lanes (two DPP moves), the group's count for the step lands
+  // in the lane that owns the slot by a select, and the row header (in the group's eighth lane) is a DPP broadcast too: no
+  // ds_bpermute anywhere.  The kernel is bound by its LDS pipe (random ds_read_b32 probes replay on bank conflicts); with
+  // cross-lane traffic through LDS as well — id, header and count of every step — a cell cost 81 LDS instructions, now 58.
+  const int slot = gl * 8 + grow;
+  const int slot_c = slot < F::KC ? slot : F::KC - 1;
+  const bool slot_ok = slot < F::KC;
+  const int64_t first = cell_begin + (int64_t)xcd_block(blockIdx.x, gridDim.x, o.xcd) * BITS_WAVES + wave;
+  if (first >= cell_end) return;                               // (after the barrier; wave-uniform)
+  const int64_t last_cell = cell_end - 1;
+  // lane P (compile-time) of every group of 8 lanes, broadcast to the group's 8 lanes
+  auto bcast8 = [](uint32_t v, auto p_tag) -> uint32_t {
+    constexpr int P = decltype(p_tag)::value;
+    const int x = __builtin_amdgcn_update_dpp(0, (int)v, (P & 3) * 0x55, 0xf, 0xf, false);        // quad_perm [P%4 x 4]: each quad its own lane P%4
+    // the quad that holds lane P hands its value to the other quad of the group: row_shr:4 into lanes 4-7 (banks 1, 3), row_shl:4 into 0-3
+    return (uint32_t)(P < 4 ? __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xa, false) : __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false));
+  };
+
+  struct OwnRaw { uint32_t v, hw, last; };
+  auto load_own = [&](int64_t row, OwnRaw& r) {                // the compact part of the row: loads only, decoded one iteration later
+    const uint32_t* const rw = table + row * DUAL_PITCH;
+    r.last = rw[F::ROWW - 1];
+    r.v = reinterpret_cast<const uint16_t*>(rw)[slot_c];
+    r.hw = rw[F::HIW + (slot_c >> 5)];
+  };
+  // id of the lane's slot | bit 31 = the row's duplicate flag; 0 for a lane without a slot or a slot without an id
+  auto decode_own = [&](const OwnRaw& r) -> uint32_t {
+    const uint32_t half = unscramble16(r.v);
+    const uint32_t x = (half | (((r.hw >> (slot & 31)) & 1u) << 16));
+    return (slot_ok && x != 0u) ? (x | (r.last & ROW_DUP_FLAG)) : (slot_ok ? (r.last & ROW_DUP_FLAG) : 0u);
+  };
+  auto gather_step = [&](uint32_t asafe, uint4& piece, auto st_tag) {
+    const uint32_t dst = bcast8(asafe, st_tag);                // slot st * 8 + g: lane st of group g
+    piece = *reinterpret_cast<const uint4*>(tbytes + (dst - 1u) * (uint32_t)(DUAL_PITCH * 4) + gcol);
+  };
+  auto issue_gathers = [&](uint32_t asafe, uint4 (&bv)[NST]) {
+    gather_step(asafe, bv[0], std::integral_constant<int, 0>{});
+    gather_step(asafe, bv[1], std::integral_constant<int, 1>{});
+    gather_step(asafe, bv[2], std::integral_constant<int, 2>{});
+    gather_step(asafe, bv[3], std::integral_constant<int, 3>{});
+    gather_step(asafe, bv[4], std::integral_constant<int, 4>{});
+    if constexpr (NST > 5) gather_step(asafe, bv[5], std::integral_constant<int, 5>{});
+    if constexpr (NST > 6) gather_step(asafe, bv[6], std::integral_constant<int, 6>{});
+  };
+  // hits of the two halves of a packed word in the plane at `base`
+  // v_lshrrev_b32 takes its shift from the low five bits of the operand: the packed word itself serves for the low half (written
+  // in C the compiler masks the operand first and then extracts the bit with the half-rate v_bfe_u32: 6-7 issue slots per id
+  // instead of 5-6)
+  auto shr5 = [](uint32_t v, uint32_t by) -> uint32_t {
+    uint32_t r;
+    asm("v_lshrrev_b32 %0, %1, %2" : "=v"(r) : "v"(by), "v"(v));
+    return r;
+  };
+  // hits of the 8 halves of a piece (four packed words) in the plane at `base`: all eight reads are issued before the first is used
+  auto probe_piece = [&](const uint32_t (&w)[4], uint32_t base) -> int {
+    uint32_t ad[8], bw[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ad[2 * c] = bitop3<0xEA>(w[c] >> 3, mask_v, base);         // ((half >> 5) << 2) | base, the low half
+      ad[2 * c + 1] = bitop3<0xEA>(w[c] >> 19, mask_v, base);    // ... the high half
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bw[t] = lds_read_b32(ad[t]);
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cnt += (shr5(bw[2 * c], w[c]) & 1u) + (shr5(bw[2 * c + 1], w[c] >> 16) & 1u);
+    return (int)cnt;
+  };
+
+  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+  // the edges of a cell: buffer stores through descriptors that cover exactly its k edges (lanes >= k fall outside and are
+  // dropped by the hardware: no predicate, no branch); valid == false: a range of zero (nothing is written)
+  auto store_cell = [&](int64_t cell, uint32_t dstid, int u, bool valid) {
+    const int64_t pb = (cell - cell_begin) * (int64_t)k;
+    const int n = valid ? k : 0;
+    const bool pos = u > 0;
+    if (OUT != OUT_U16) {
+      const double vs = pos ? (double)((uint32_t)(cell + 1) + o.src_off) : 0.0;     // reference :49
+      const double vd = pos ? (double)dstid : 0.0;                                    // reference :50
+      const double vw = s_lut[u];                                                      // reference :51 (lut[0] = 0.0: the zero row)
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(o.src + pb, 0, n * 8, 0x00020000);
+      const auto rd = __builtin_amdgcn_make_buffer_rsrc(o.dst + pb, 0, n * 8, 0x00020000);
+      const auto rw = __builtin_amdgcn_make_buffer_rsrc(o.w + pb, 0, n * 8, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vs), rs, slot * 8, 0, 2);      // (a lane's edge is its SLOT's)
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vd), rd, slot * 8, 0, 2);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vw), rw, slot * 8, 0, 2);
+    }
+    if (OUT == OUT_RMAT_U) {
+      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u + pb, 0, n * 4, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b32((uint32_t)u, ru, slot * 4, 0, 2);
+    }
+    if (OUT == OUT_U16) {
+      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u16 + pb, 0, n * 2, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b16((uint16_t)u, ru, slot * 2, 0, 0);
+    }
+  };
+
+  // counts of the cell's slots from its gathered pieces; returns whether the cell needs the exact path
+  auto process = [&](uint32_t araw, const uint4 (&bv)[NST], int& u_out) -> bool {
+    const uint32_t a = araw & 0x1FFFFu;
+    const bool has = a != 0u;
+    bool dup_here = false;
+    uint32_t my_addr = wbase;
+    if (has) {                                                  // row i into the bit set
+      my_addr = wbase + ((a >> 16) << 13) + (((a & 0xFFFFu) >> 5) << 2);
+      const uint32_t m = 1u << (a & 31u);
+      dup_here = (lds_or_rtn_b32(my_addr, m) & m) != 0u;        // already there: the row names the id twice
+    }
+    wave_lds_fence();
+    uint32_t hflags = araw;
+    int myu = 0;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const uint32_t hdr = bcast8(bv[st].w, std::integral_constant<int, 7>{});   // the row's header word sits in its eighth lane
+      hflags |= hdr;
+      const bool p1 = (uint32_t)gl >= (hdr & 15u);                               // this lane's 8 ids: first or second plane
+      const uint32_t base = wbase | (p1 ? 0x2000u : 0u);
+      const uint32_t w4[4] = {bv[st].x, bv[st].y, bv[st].z, gl == 7 ? (p1 ? 0xFFFFFFFFu : 0u) : bv[st].w};   // (the header is not an id: the plane's pad instead)
+      const int c = probe_piece(w4, base);
+      const int rowcnt = group_sum<8>(c);                                        // every lane of the group: the row's count
+      myu = gl == st ? rowcnt : myu;                                             // ... kept by the lane that owns slot st * 8 + g
+    }
+    if (has) lds_write_b32(my_addr, 0u);                        // the set is empty again (lanes sharing a word write the same zero)
+    if (dup_here) *reinterpret_cast<uint32_t*>(smem + BITS_DUPF_OFF + (uint32_t)wave * 4u) = 1u;   // reported at the kernel's end
+    wave_lds_fence();
+    u_out = has ? myu : 0;                                      // rejected id / no slot: zero row
+    return __ballot(dup_here || (hflags & ROW_DUP_FLAG) != 0u) != 0ull;
+  };
+
+  // ---- BITS_DEPTH cells in flight per wave: while cell m is counted, the gathers of cells m+1 .. m+DEPTH-1 and the own row of cell
+  // m+DEPTH are outstanding.  Ring slots are compile-time indices (the loop is unrolled by DEPTH).  Two — the pipelined kernel's
+  // depth — is enough: three or four changed nothing (the kernel is not waiting for its gathers; profiles/r04_bits_kernel.txt).
+  constexpr int DEPTH = BITS_DEPTH;
+  OwnRaw raw;
+  uint4 bv[DEPTH][NST];
+  uint32_t araw_r[DEPTH], gid_r[DEPTH];
+#pragma unroll
+  for (int j = 0; j < DEPTH; ++j) { araw_r[j] = 0u; gid_r[j] = 0u; }
+  load_own(first, raw);
+#pragma unroll
+  for (int j = 0; j < DEPTH - 1; ++j) {                        // cells 0 .. DEPTH-2 of the wave: own row, gathers
+    const int64_t c = first + (int64_t)j * nwaves;
+    const uint32_t ar = c < cell_end ? decode_own(raw) : 0u;
+    const uint32_t a = ar & 0x1FFFFu;
+    const int64_t cn = c + nwaves;
+    load_own(cn < cell_end ? cn : last_cell, raw);
+    const uint32_t fb = (uint32_t)((c < cell_end ? c : last_cell) + 1);
+    araw_r[j] = ar;
+    gid_r[j] = MAP ? (uint32_t)o.l2g[(a != 0u ? a : fb) - 1u] : 0u;
+    issue_gathers(a != 0u ? a : fb, bv[j]);
+  }
+  bool any_slow = false, have_prev = false;
+  int64_t prev_i = first;
+  uint32_t prev_a = 0;
+  int prev_u = 0;
+
+  auto body = [&](int64_t i, auto j_tag) {
+    constexpr int J = decltype(j_tag)::value, JN = (J + DEPTH - 1) % DEPTH;
+    const int64_t ig = i + (int64_t)(DEPTH - 1) * nwaves, io = ig + nwaves;
+    const uint32_t araw_n = ig < cell_end ? decode_own(raw) : 0u;              // its own row was requested an iteration ago
+    const uint32_t an = araw_n & 0x1FFFFu;
+    load_own(io < cell_end ? io : last_cell, raw);                            // the own row of the cell after that one FIRST
+    __builtin_amdgcn_sched_barrier(0);
+    gid_r[JN] = MAP ? (uint32_t)o.l2g[(an != 0u ? an : (uint32_t)(i + 1)) - 1u] : 0u;
+    issue_gathers(an != 0u ? an : (uint32_t)(i + 1), bv[JN]);                 // no such cell / no id: the lane reads row i (one line)
+    araw_r[JN] = araw_n;
+    __builtin_amdgcn_sched_barrier(0);
+    store_cell(prev_i, prev_a, prev_u, have_prev);                            // the cell before this one: behind the gathers
+    __builtin_amdgcn_sched_barrier(0);
+    int u;
+    any_slow |= process(araw_r[J], bv[J], u);
+    prev_i = i;
+    prev_a = MAP ? gid_r[J] : (araw_r[J] & 0x1FFFFu);
+    prev_u = u;
+    have_prev = true;
+  };
+
+  for (int64_t i = first;;) {
+    body(i, std::integral_constant<int, 0>{});
+    if (i + nwaves >= cell_end) break;
+    i += nwaves;
+    body(i, std::integral_constant<int, 1 % DEPTH>{});
+    if (i + nwaves >= cell_end) break;
+    i += nwaves;
+    if constexpr (DEPTH >= 3) {
+      body(i, std::integral_constant<int, 2 % DEPTH>{});
+      if (i + nwaves >= cell_end) break;
+      i += nwaves;
+    }
+    if constexpr (DEPTH >= 4) {
+      body(i, std::integral_constant<int, 3 % DEPTH>{});
+      if (i + nwaves >= cell_end) break;
+      i += nwaves;
+    }
+  }
+  store_cell(prev_i, prev_a, prev_u, true);
+  // ---- the deferred report of the "distinct ids" mode, and the exact path for cells whose own row or a neighbour row holds an id
+  // twice (never the case for real kNN output): after the loop; their fast-path rows written above are overwritten
+  if (any_slow) {
+    __builtin_amdgcn_s_waitcnt(0);
+    wave_lds_fence();
+    if (*reinterpret_cast<const uint32_t*>(smem + BITS_DUPF_OFF + (uint32_t)wave * 4u) != 0u && lane == 0) {
+      uint32_t* const st = edge_kernel_dup_status();
+      if (st != nullptr) atomicOr(st, GFICF_ST_DUP_IDS);
+    }
+    uint32_t* const sA = reinterpret_cast<uint32_t*>(smem + (uint32_t)wave * BITS_WB);      // (the wave's bit set is no longer needed)
+    uint32_t* const sB = sA + 64;
+    for (int64_t c = first; c < cell_end; c += nwaves) {
+      const uint32_t* const rw = table + c * DUAL_PITCH;
+      const uint32_t a = lane < k ? row_slot_id(rw, lane, 64, true) : 0u;
+      bool f = row_dup_flag(rw, 64, true);
+      if (a != 0u) f |= row_dup_flag(table + (int64_t)(a - 1u) * DUAL_PITCH, 64, true);
+      if (__ballot(f) != 0ull)
+        slow_cell<64, true, OUT>(table, c, k, (c - cell_begin) * (int64_t)k, sA, sB, lane, o.src, o.dst, o.w, o.u, o.u16, o.set_mode, s_lut, o.l2g,
+                                 o.src_off, DUAL_PITCH);
+    }
+  }
+}
+
 // edge_kernel_dup_status() reads the EdgeOut argument at EDGE_KERNARG_OUT: both kernels must take exactly EdgeKernArgs' list
 static_assert(std::is_same<decltype(&k_jaccard_edges<32, false, false, OUT_RMAT, false>), EdgeKernFn>::value &&
               std::is_same<decltype(&k_jaccard_edges<64, false, true, OUT_U16, true>), EdgeKernFn>::value &&
               std::is_same<decltype(&k_jaccard_edges_pipe<32, false, true, OUT_RMAT, true, false, true>), EdgeKernFn>::value &&
-              std::is_same<decltype(&k_jaccard_edges_pipe<16, true, false, OUT_RMAT_U, true, true, false>), EdgeKernFn>::value,
+              std::is_same<decltype(&k_jaccard_edges_pipe<16, true, false, OUT_RMAT_U, true, true, false>), EdgeKernFn>::value &&
+              std::is_same<decltype(&k_jaccard_edges_bits<7, OUT_RMAT, false>), EdgeKernFn>::value,
               "the edge kernels' parameter list and EdgeKernArgs differ: edge_kernel_dup_status() would read a wrong slot");
 
 // ------------------------------------------------------------------ edge filter (N1)
@@ -1438,7 +1816,7 @@ template <int KPAD, bool CMP>
 __global__ __launch_bounds__(256) void k_edge_write(const uint32_t* __restrict__ table, const uint16_t* __restrict__ u16,
                                                     int k, int64_t cell_begin, int64_t n_cells,
                                                     const int64_t* __restrict__ ptr, double* __restrict__ from,
-                                                    double* __restrict__ to, double* __restrict__ weight) {
+                                                    double* __restrict__ to, double* __restrict__ weight, int pitch) {
   __shared__ double s_lut[GFICF_JACCARD_MAX_K + 1];
   for (int u = threadIdx.x; u <= k; u += 256) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);   // reference :51
   __syncthreads();
@@ -1453,7 +1831,7 @@ __global__ __launch_bounds__(256) void k_edge_write(const uint32_t* __restrict__
       uint32_t dst = 0;
       if (s < k) {
         u = u16[c * k + s];
-        dst = row_slot_id(table + (cell_begin + c) * (CMP ? CFmt<KPAD>::ROWW : KPAD), s, KPAD, CMP);
+        dst = row_slot_id(table + (cell_begin + c) * pitch, s, KPAD, CMP);
       }
       const bool kp = u > 0;
       const unsigned long long m = __ballot(kp);
@@ -1541,13 +1919,13 @@ __host__ __device__ inline int packed_words(int64_t N, int k) { return (k * id_b
 constexpr int PACK_ROWS = 64;
 
 __global__ __launch_bounds__(256) void k_pack_rows(const uint32_t* __restrict__ table, int64_t n_rows, int k, int kpad, int compact,
-                                                   int bits, int wpr, uint32_t* __restrict__ packed) {
+                                                   int bits, int wpr, uint32_t* __restrict__ packed, int pitch) {
   extern __shared__ uint32_t s_tb[];                        // PACK_ROWS * row_words words
-  const int roww = compact ? kpad / 2 : kpad;
+  const int roww = compact ? kpad / 2 : kpad;               // words of the row that hold its ids (dual rows: the compact part; pitch = 64)
   const int fl = k * bits;                                  // bit position of the duplicate flag
   for (int64_t row0 = (int64_t)blockIdx.x * PACK_ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * PACK_ROWS) {
     const int rows_here = (int)((n_rows - row0) < PACK_ROWS ? (n_rows - row0) : PACK_ROWS);
-    for (int e = threadIdx.x; e < rows_here * roww; e += 256) s_tb[e] = table[row0 * roww + e];
+    for (int e = threadIdx.x; e < rows_here * roww; e += 256) s_tb[e] = table[(row0 + e / roww) * pitch + e % roww];
     __syncthreads();
     for (int e = threadIdx.x; e < rows_here * wpr; e += 256) {
       const int rr = e / wpr, w = e % wpr;
@@ -1578,8 +1956,9 @@ __device__ inline uint32_t packed_id(const uint32_t* in, int j, int bits, int wp
 }
 
 __global__ __launch_bounds__(256) void k_unpack_rows(const uint32_t* __restrict__ packed, int64_t n_rows, int k, int kpad, int compact,
-                                                     int bits, int wpr, uint32_t* __restrict__ table) {
+                                                     int bits, int wpr, uint32_t* __restrict__ table, int pitch) {
   extern __shared__ uint32_t s_pk[];                        // UNPACK_ROWS * wpr words
+  __shared__ uint32_t s_ids[4][64], s_prow[4][32];          // dual rows: a wave's row as ids / its planar part
   const uint32_t mask = (uint32_t)(((unsigned long long)1 << bits) - 1ull);
   const int fl_w = (k * bits) >> 5, fl_b = (k * bits) & 31; // position of the duplicate flag
   const int roww = compact ? kpad / 2 : kpad;
@@ -1604,7 +1983,18 @@ __global__ __launch_bounds__(256) void k_unpack_rows(const uint32_t* __restrict_
         for (int b = 0; b < 32 && j0 + b < k; ++b) v |= ((packed_id(in, j0 + b, bits, wpr, mask) >> 16) & 1u) << b;
         if (j == roww - 1) v |= dupf;
       }
-      table[row0 * roww + e] = v;
+      table[(row0 + rr) * pitch + j] = v;
+    }
+    if (pitch == DUAL_PITCH && compact && kpad == 64) {     // dual rows: the planar part of every row, a wave per row
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      for (int rr = wave; rr < rows_here; rr += 4) {
+        const uint32_t* in = s_pk + rr * wpr;
+        s_ids[wave][lane] = lane < k ? packed_id(in, lane, bits, wpr, mask) : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        planar_row_build(s_ids[wave], k, ((in[fl_w] >> fl_b) & 1u) != 0u, s_prow[wave], lane);
+        if (lane < 32) table[(row0 + rr) * pitch + 32 + lane] = s_prow[wave][lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
     }
     __syncthreads();
   }
@@ -1640,7 +2030,16 @@ int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t
   switch (f.kpad) {
     case 16: LAUNCH_INGEST_REG(16, false); break;
     case 32: if (f.compact) LAUNCH_INGEST_REG(32, true); else LAUNCH_INGEST_REG(32, false); break;
-    case 64: if (f.compact) LAUNCH_INGEST_REG(64, true); else LAUNCH_INGEST_REG(64, false); break;
+    case 64:
+      if (f.dual) {                                          // dual rows: the tile kernel writes both parts of every row
+        if (scan)
+          hipLaunchKernelGGL((k_ingest_tile<T, 64, true, false, true, true>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total,
+                             table, ctx->d_status, zero_ok, gficf_halo_map{});
+        else
+          hipLaunchKernelGGL((k_ingest_tile<T, 64, true, false, false, true>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, n_rows, k, ld, N_total,
+                             table, ctx->d_status, zero_ok, gficf_halo_map{});
+      } else if (f.compact) LAUNCH_INGEST_REG(64, true); else LAUNCH_INGEST_REG(64, false);
+      break;
     case 128: if (f.compact) LAUNCH_INGEST(128, true); else LAUNCH_INGEST(128, false); break;
     default: if (f.compact) LAUNCH_INGEST(256, true); else LAUNCH_INGEST(256, false); break;
   }
@@ -1746,8 +2145,43 @@ int launch_edges_t(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int6
   return launch_edges_o<KPAD, BIG, CMP, OUT_RMAT>(ctx, table, N, k, cb, ce, o);
 }
 
+// dual rows (32 < k <= 55, N <= 131070): the bit-set kernel
+template <int NST, int OUT, bool MAP>
+int launch_bits_m(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+  static std::atomic<int> bpc{0};
+  static std::atomic<bool> attr_set[64];
+  if (!attr_set[ctx->device & 63]) {
+    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_jaccard_edges_bits<NST, OUT, MAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BITS_LDS_BYTES));
+    attr_set[ctx->device & 63] = true;
+  }
+  int blocks_per_cu = 1;
+  const int rc = edge_blocks_per_cu(k_jaccard_edges_bits<NST, OUT, MAP>, BITS_WAVES * 64, BITS_LDS_BYTES, bpc, &blocks_per_cu);
+  if (rc) return rc;
+  const int64_t need = gficf_ceil_div(ce - cb, BITS_WAVES);
+  const int64_t cap = (int64_t)ctx->num_cus * blocks_per_cu;
+  unsigned grid = (unsigned)(need < cap ? need : cap);
+  if (o.xcd && grid > 8) grid = (grid + 7u) & ~7u;
+  hipLaunchKernelGGL((k_jaccard_edges_bits<NST, OUT, MAP>), dim3(grid), dim3(BITS_WAVES * 64), BITS_LDS_BYTES, ctx->stream, table, N, k, cb, ce, o);
+  GFICF_HIP_CHECK(hipGetLastError());
+  return GFICF_OK;
+}
+
+template <int NST>
+int launch_bits(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+  if (o.u16) return launch_bits_m<NST, OUT_U16, false>(ctx, table, N, k, cb, ce, o);
+  if (o.u) return o.l2g ? launch_bits_m<NST, OUT_RMAT_U, true>(ctx, table, N, k, cb, ce, o) : launch_bits_m<NST, OUT_RMAT_U, false>(ctx, table, N, k, cb, ce, o);
+  return o.l2g ? launch_bits_m<NST, OUT_RMAT, true>(ctx, table, N, k, cb, ce, o) : launch_bits_m<NST, OUT_RMAT, false>(ctx, table, N, k, cb, ce, o);
+}
+
 template <int KPAD>
 int launch_edges(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+  if constexpr (KPAD == 64) {
+    if (table_fmt(N, k).dual) {
+      const int nst = (k + 7) / 8;                           // gather steps of a cell, 8 neighbour rows each
+      return nst <= 5 ? launch_bits<5>(ctx, table, N, k, cb, ce, o) : nst == 6 ? launch_bits<6>(ctx, table, N, k, cb, ce, o)
+                                                                                : launch_bits<7>(ctx, table, N, k, cb, ce, o);
+    }
+  }
   // 32-bit byte offsets and the 24-bit hash multiply need table < 4 GiB and ids < 2^24
   static const bool force_big = getenv("GFICF_JACCARD_FORCE_BIG") != nullptr;   // test hook for the 64-bit variant
   const bool big = force_big || N >= (1ll << 24) || N * (int64_t)KPAD * 4 >= (1ll << 32);
@@ -1896,7 +2330,16 @@ static int halo_ingest_launch(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_lo
   switch (f.kpad) {
     case 16: LAUNCH_HALO_INGEST(16, false); break;
     case 32: if (f.compact) LAUNCH_HALO_INGEST(32, true); else LAUNCH_HALO_INGEST(32, false); break;
-    default: if (f.compact) LAUNCH_HALO_INGEST(64, true); else LAUNCH_HALO_INGEST(64, false); break;
+    default:
+      if (f.dual) {
+        if (scan)
+          hipLaunchKernelGGL((k_ingest_tile<int32_t, 64, true, true, true, true>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, row_end, k, ld, n_ext,
+                             (uint32_t*)d_table, ctx->d_status, 1, hm);
+        else
+          hipLaunchKernelGGL((k_ingest_tile<int32_t, 64, true, true, false, true>), dim3(grid), dim3(256), 0, ctx->stream, d_idx, row_end, k, ld, n_ext,
+                             (uint32_t*)d_table, ctx->d_status, 1, hm);
+      } else if (f.compact) LAUNCH_HALO_INGEST(64, true); else LAUNCH_HALO_INGEST(64, false);
+      break;
   }
 #undef LAUNCH_HALO_INGEST
   GFICF_HIP_CHECK(hipGetLastError());
@@ -2103,7 +2546,8 @@ int gficf_jaccard_pack_rows_device(gficf_ctx* ctx, const int32_t* d_table_rows, 
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
   const TableFmt f = table_fmt(N_total, k);
   hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)blocks), dim3(256), (size_t)PACK_ROWS * f.row_words * sizeof(uint32_t), ctx->stream,
-                     (const uint32_t*)d_table_rows, n_rows, k, f.kpad, f.compact ? 1 : 0, id_bits(N_total), packed_words(N_total, k), d_packed);
+                     (const uint32_t*)d_table_rows, n_rows, k, f.kpad, f.compact ? 1 : 0, id_bits(N_total), packed_words(N_total, k), d_packed,
+                     f.row_words);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -2121,7 +2565,7 @@ int gficf_jaccard_unpack_rows_device(gficf_ctx* ctx, const uint32_t* d_packed, i
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
   const TableFmt f = table_fmt(N_total, k);
   hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)blocks), dim3(256), (size_t)UNPACK_ROWS * wpr * sizeof(uint32_t), ctx->stream,
-                     d_packed, n_rows, k, f.kpad, f.compact ? 1 : 0, id_bits(N_total), wpr, (uint32_t*)d_table_rows);
+                     d_packed, n_rows, k, f.kpad, f.compact ? 1 : 0, id_bits(N_total), wpr, (uint32_t*)d_table_rows, f.row_words);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -2156,8 +2600,9 @@ static int edges_filtered(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
 #define LAUNCH_EW(KP, CM)                                                                                               \
   hipLaunchKernelGGL((k_edge_write<KP, CM>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, t, d_u_ws, k, cell_begin, \
-                     n_cells, d_cell_ptr, d_from, d_to, d_weight)
+                     n_cells, d_cell_ptr, d_from, d_to, d_weight, pitch)
   const bool cm = table_fmt(N, k).compact;
+  const int pitch = table_fmt(N, k).row_words;
   switch (kpad_for(k)) {
     case 16: LAUNCH_EW(16, false); break;
     case 32: if (cm) LAUNCH_EW(32, true); else LAUNCH_EW(32, false); break;

@@ -37,8 +37,10 @@ def test_abi_version_and_kpad():
     assert L.gficf_jaccard_kpad(257) == -1 and L.gficf_jaccard_kpad(-1) == -1
     # row pitch of the table: half the slots for data sets of fewer than 2^17 cells when k leaves room for the bitmap
     rw = L.gficf_jaccard_row_words
-    assert [rw(100000, k) for k in (15, 16, 17, 30, 31, 32, 33, 50, 60, 61, 100, 120, 121, 240, 241, 256)] == \
-        [16, 16, 16, 16, 32, 32, 32, 32, 32, 64, 64, 64, 128, 128, 256, 256]
+    # (32 < k <= 55 below 131071 cells: dual rows — the compact row and a planar copy for the bit-set edge kernel: 64 words)
+    assert [rw(100000, k) for k in (15, 16, 17, 30, 31, 32, 33, 50, 55, 56, 60, 61, 100, 120, 121, 240, 241, 256)] == \
+        [16, 16, 16, 16, 32, 32, 64, 64, 64, 32, 32, 64, 64, 64, 128, 128, 256, 256]
+    assert rw(131070, 50) == 64 and rw(131071, 50) == 32
     assert rw(131071, 30) == 16 and rw(131072, 30) == 32 and rw(1000000, 30) == 32 and rw(1000000, 50) == 64
     assert rw(-1, 30) == -1 and rw(100, 257) == -1
 

@@ -473,7 +473,8 @@ def test_packed_transport_rows_roundtrip(ops, N, k):
     kp, pw = ops.row_words(N, k), ops.packed_words(N, k)
     bits = int(np.ceil(np.log2(N + 1)))
     assert pw == (k * bits + 1 + 31) // 32 and pw * 4 <= ops.kpad(k) * 4
-    assert kp == (ops.kpad(k) // 2 if N < 2 ** 17 and ops.kpad(k) >= 32 and k <= ops.kpad(k) * 15 // 16 else ops.kpad(k))
+    dual = 32 < k <= 55 and N <= 131070        # compact row + planar copy for the bit-set kernel: 64 words
+    assert kp == (64 if dual else ops.kpad(k) // 2 if N < 2 ** 17 and ops.kpad(k) >= 32 and k <= ops.kpad(k) * 15 // 16 else ops.kpad(k))
     table = torch.empty((N, kp), dtype=torch.int32, device="cuda")
     ops.jaccard_ingest(idx, N, k, N, table)
     packed = torch.empty((N, pw), dtype=torch.int32, device="cuda")
@@ -662,7 +663,7 @@ def test_configs_4_and_5_as_eight_blocks_on_local_ids(N, k):
         out = torch.zeros((3, nl * k), dtype=torch.float64, device="cuda")
         ops.jaccard_edges_mapped(table, n_ext, k, nl, b, l2g, out)
         ops.sync()
-        assert n_ext < (1 << 17) and 4 * ops.row_words(n_ext, k) == (64 if k <= 30 else 128)      # compact rows at any N_total
+        assert n_ext < (1 << 17) and 4 * ops.row_words(n_ext, k) == (64 if k <= 30 else 256)      # compact (k = 50: dual) rows at any N_total
         run = 512
         for c0 in sorted({b, b + (nl - run) // 2, e - run}):
             want, _ = oracle.jaccard_cells(mat, c0, c0 + run, nthreads=8)
