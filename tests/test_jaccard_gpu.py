@@ -485,8 +485,10 @@ def test_packed_transport_rows_roundtrip(ops, N, k):
     ops.jaccard_unpack_rows(packed[cut:], N - cut, k, N, back[cut:])
     ops.sync()
     assert torch.equal(back, table)
-    flag_word = kp - 1 if kp < ops.kpad(k) else 0                   # compact rows keep the flag in their last word
+    flag_word = 31 if dual else kp - 1 if kp < ops.kpad(k) else 0   # compact rows keep the flag in their last word (dual rows: of the compact part ...)
     assert int(table[7, flag_word]) < 0 and int(table[N - 1, flag_word]) < 0      # duplicate flags set and preserved
+    if dual:                                                        # ... and in the header of the planar part, with the groups of the first plane
+        assert int(table[7, 63]) < 0 and int(table[N - 1, 63]) < 0 and 0 <= (int(table[0, 63]) & 15) <= 7
     if N <= 70000:
         out = torch.empty((3, N * k), dtype=torch.float64, device="cuda")
         ops.jaccard_edges(back, N, k, 0, N, out)
