@@ -898,7 +898,8 @@ def main():
         except Exception:
             pmc = {}
     # the edge kernel of this shape is k_jaccard_edges_pipe (k <= 32) or k_jaccard_edges; make_traffic.py keys by kernel name
-    traffic = None if halo_form else (pmc.get(f"jaccard_edges_pipe_N{N_total}_k{k}") or pmc.get(f"jaccard_edges_N{N_total}_k{k}") or {}).get("hbm_bytes_per_launch")
+    traffic = None if halo_form else (pmc.get(f"jaccard_edges_pipe_N{N_total}_k{k}") or pmc.get(f"jaccard_edges_bits_N{N_total}_k{k}")
+                                      or pmc.get(f"jaccard_edges_N{N_total}_k{k}") or {}).get("hbm_bytes_per_launch")
     edge_kernel = "k_jaccard_edges_pipe" if (k <= 32 and not os.environ.get("GFICF_JACCARD_NO_PIPE")) else "k_jaccard_edges"   # the name rocprofv3 shows
     if 32 < k <= 55 and (shards[0].row_words if halo_form else ops.row_words(N_total, k)) == 64 and (shards[0].n_ext if halo_form else N_total) <= 131070:
         edge_kernel = "k_jaccard_edges_bits"                         # dual rows: the direct-address bit-set kernel
@@ -1211,6 +1212,7 @@ def main():
             cell_b = torch.repeat_interleave(torch.arange(Nc, device=dev), lens_be)
             kn_b = int(cell_b.numel())
             pos_b = torch.arange(kn_b, device=dev) - ws["out_colptr"][:Nc][cell_b] + colptr[:Nc][cell_b]
+            gf["roofline"]["frac_begin_end_form"] = round(GFICF_BYTES_PER_NNZ * nnz / tb / 1e9 / HBM_PEAK_GBS, 4)
             gf["begin_end_form"] = {"ms_per_pass": tb * 1e3, "cells_per_sec": Nc / tb,
                                     "roofline_frac": round(GFICF_BYTES_PER_NNZ * nnz / tb / 1e9 / HBM_PEAK_GBS, 4),
                                     "achieved_GBps": round(GFICF_BYTES_PER_NNZ * nnz / tb / 1e9, 2),
