@@ -974,6 +974,56 @@ def main():
                                "form": ("halo: unique-id request lists + the named rows, two all-to-alls" if exchange == "halo_generic" else
                                         "all-gather of table rows" + (" (bit-packed)" if sh0.packed is not None else ""))}
 
+    extras = not args.no_extras and not strong
+    shard = shards[0]
+    if rank == 0:
+        # every line carries a check against the oracle (checker only, after the timed region): the whole matrix of data
+        # set 0 when that takes seconds (one GPU, <= 200 k cells, extras on), otherwise a bounded sample of this rank's
+        # cells — three runs of 1024 consecutive source cells at the start, the middle and the end of its block
+        import oracle
+
+        cores = os.cpu_count() or 1
+        if world == 1 and extras and N_total <= 200_000:
+            want, _ = oracle.jaccard(mat, nthreads=cores)
+            ok, checked = bool(np.array_equal(shard.out.cpu().numpy().T, want)), N_total
+            del want
+        else:
+            run = min(1024, n_local)
+            ok, checked = True, 0
+            for c0 in sorted({b, b + (n_local - run) // 2, e - run}):
+                want, _ = oracle.jaccard_cells(mat, c0, c0 + run, nthreads=cores)
+                got = shard.out[:, (c0 - b) * k:(c0 - b + run) * k].cpu().numpy().T
+                ok = ok and bool(np.array_equal(got, want))
+                checked += run
+        out["checked_vs_oracle"] = ok
+        out["oracle_check"] = {"cells": checked, "of": n_local, "kind": "whole matrix" if checked == N_total else "sample of source cells",
+                               "what": "bit-exact rows of the reference's (N*k) x 3 matrix, data set 0"}
+    # N > 1: from here on the line holds `value`, its roofline and the exchange; what follows are further legs of the same run.
+    # If one of them hangs (a rank lost in a collective: first contact with real RCCL happens in the driver's own run), rank 0
+    # still prints what it has — a watchdog thread, fed by `progress()`, prints the line as it stands after 400 s without
+    # progress and ends the process; the normal end prints the full line exactly once.
+    guard = {"t": time.monotonic(), "line": None, "done": False}
+
+    def progress(stage=None):
+        guard["t"] = time.monotonic()
+        if rank == 0:
+            guard["line"] = json.dumps(dict(out, unfinished_leg=stage) if stage else out)
+
+    if world > 1 and rank == 0:
+        import threading
+
+        def watchdog():
+            while not guard["done"]:
+                time.sleep(5.0)
+                if not guard["done"] and guard["line"] is not None and time.monotonic() - guard["t"] > float(os.environ.get("GFICF_BENCH_LEG_TIMEOUT", "400")):
+                    guard["done"] = True
+                    sys.stderr.write("bench.py: no progress in a later leg; printing the line as it stands\n")
+                    sys.stdout.write(guard["line"] + "\n")
+                    sys.stdout.flush()
+                    os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+    progress("pipelined")
     if distinct:
         ops.set_jaccard_distinct(True)                              # the legs below run what `value` ran
     if args.pipeline or (not args.no_extras and (world > 1 or not strong)):
@@ -983,6 +1033,7 @@ def main():
         # (1) the other id model: ids WITH locality (what the device kNN search's pivot order gives, gficf_knn_pivot_order_device)
         #     when `value` ran on permuted ids, and the other way round
         other = "spatial" if args.ids == "permuted" else "permuted"
+        progress(f"{other}_ids")
         shards_value = shards
         idx_o, _ = make_inputs(other, False)
         ex_o, named_o = pick_exchange(idx_o[0], "auto")
@@ -1015,6 +1066,7 @@ def main():
         # (2) the N = 1 step, timed by rank 0 in this same process once the N-rank region is over (the other ranks wait at the
         #     fence): ingest + edge kernel per data set, one stream, in order, on `cells_1` cells — what `python bench.py` times
         cells_1 = N_total if strong else args.cells_per_gpu
+        progress("single_gpu_step")
         single = None
         if rank == 0:
             tb1 = [torch.zeros((cells_1, ops.row_words(cells_1, k)), dtype=torch.int32, device=dev) for _ in range(batch)]
@@ -1043,6 +1095,7 @@ def main():
             del tb1, o1, i1
         fence()
         # (2b) the kNN -> Jaccard chain in the search's pivot order (what a sharded clustcells() runs)
+        progress("chain")
         if not args.no_chain and not strong:
             try:
                 ch = bench_chain(torch, dist, ops, args, world, rank, dev, fence, max_over_ranks)
@@ -1051,8 +1104,9 @@ def main():
             if rank == 0:
                 out["chain"] = ch
         # (3) the single-process form with direct peer copies, in a process of its own (rank 0 starts it; the ranks wait)
+        progress("peer")
         if rank == 0 and not args.no_peer:
-            out["peer"] = run_peer_leg(args)
+            out["peer"] = run_peer_leg(args, timeout_s=300.0)
         fence()
         if rank == 0:
             per = lambda v: round(v / (world * single), 4)
@@ -1066,30 +1120,6 @@ def main():
     if distinct:
         ops.set_jaccard_distinct(False)
 
-    extras = not args.no_extras and not strong
-    shard = shards[0]
-    if rank == 0:
-        # every line carries a check against the oracle (checker only, after the timed region): the whole matrix of data
-        # set 0 when that takes seconds (one GPU, <= 200 k cells, extras on), otherwise a bounded sample of this rank's
-        # cells — three runs of 1024 consecutive source cells at the start, the middle and the end of its block
-        import oracle
-
-        cores = os.cpu_count() or 1
-        if world == 1 and extras and N_total <= 200_000:
-            want, _ = oracle.jaccard(mat, nthreads=cores)
-            ok, checked = bool(np.array_equal(shard.out.cpu().numpy().T, want)), N_total
-            del want
-        else:
-            run = min(1024, n_local)
-            ok, checked = True, 0
-            for c0 in sorted({b, b + (n_local - run) // 2, e - run}):
-                want, _ = oracle.jaccard_cells(mat, c0, c0 + run, nthreads=cores)
-                got = shard.out[:, (c0 - b) * k:(c0 - b + run) * k].cpu().numpy().T
-                ok = ok and bool(np.array_equal(got, want))
-                checked += run
-        out["checked_vs_oracle"] = ok
-        out["oracle_check"] = {"cells": checked, "of": n_local, "kind": "whole matrix" if checked == N_total else "sample of source cells",
-                               "what": "bit-exact rows of the reference's (N*k) x 3 matrix, data set 0"}
     if rank == 0 and world == 1 and extras:
         if not args.no_cpu_baseline:
             import oracle
@@ -1281,6 +1311,7 @@ def main():
         if not args.no_knn:
             out["knn"] = bench_knn(torch, ops, args)
 
+    progress("gficf")
     if world > 1 and not args.no_gficf and not strong and not args.no_extras:
         # GF-ICF, cell-sharded: every rank owns a 54 k-cell block of a (54 k x n_gpus)-cell matrix; the only
         # exchange is the all-reduce(sum) of the G per-gene cell counts between the count and the scale pass
@@ -1310,7 +1341,8 @@ def main():
                         "roofline": {"bound": "hbm", "kernel": "whole pass, all ranks", "achieved": round(GFICF_BYTES_PER_NNZ * nnz_all / tg / 1e9, 2),
                                      "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                                      "frac": round(GFICF_BYTES_PER_NNZ * nnz_all / tg / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None}}
-    if rank == 0:
+    if rank == 0 and not guard["done"]:
+        guard["done"] = True
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

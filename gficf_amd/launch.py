@@ -61,6 +61,15 @@ def kfd_gpu_nodes(root: str = "/sys/class/kfd/kfd/topology/nodes") -> int | None
     return n
 
 
+def runtime_gpus_in_a_child() -> int:
+    """What the HIP runtime itself counts, asked of a throw-away child process (this process stays runtime-free)."""
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+    except (OSError, ValueError, subprocess.TimeoutExpired):
+        return 0
+
+
 def visible_gpus() -> int:
     """Number of GPUs a rank of this job could use, WITHOUT initialising any of them and without the HIP runtime: the KFD
     topology in sysfs, narrowed by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES as the runtime would
@@ -69,12 +78,7 @@ def visible_gpus() -> int:
     amdsmi `torch.cuda.device_count()` falls back to hipGetDeviceCount, which does initialise it)."""
     n = kfd_gpu_nodes()
     if n is None:
-        try:
-            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
-            n = int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
-        except (OSError, ValueError, subprocess.TimeoutExpired):
-            n = 0
-        return n
+        return runtime_gpus_in_a_child()
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         lst = _parse_visible(var)
         if lst is not None:
@@ -97,6 +101,8 @@ def spawn_ranks(argv: list[str], n: int, *, need_gpus: int | None = None, timeou
         raise ValueError("spawn_ranks: n must be >= 1")
     if need_gpus is not None:
         have = visible_gpus()
+        if have < need_gpus:                                       # before refusing the job: what the runtime itself says (a topology this
+            have = max(have, runtime_gpus_in_a_child())            # parser misreads must not cost a run on a box that has the GPUs)
         if have < need_gpus:
             sys.stderr.write(f"{os.path.basename(argv[0])}: {need_gpus} GPUs asked for, {have} visible on this node\n")
             return 2
