@@ -99,3 +99,29 @@ def test_committed_bench_line_keeps_the_contract():
     edges = d["config"]["edges_per_step"]
     assert abs(d["value"] - edges / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["checked_vs_oracle"] is True and d["gficf"]["checked_vs_oracle"] is True and d["knn"]["checked_vs_oracle"] is True
+
+
+def test_round4_records_are_consistent_and_results_md_is_generated_from_them():
+    """The committed round-4 line (profiles/r04_bench.json) carries what round 4 added — `value_from_idle`, the GF-ICF pass in the
+    pointerB / pointerE form equal to the canonical result — and RESULTS.md is what tools/make_results.py makes of profiles/."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r04_bench.json")))
+    assert d["checked_vs_oracle"] is True and 0 < d["value_from_idle"] < d["value"]
+    be = d["gficf"]["begin_end_form"]
+    assert be["equals_canonical_result"] is True and be["transpose_equals_canonical"] is True
+    assert be["ms_per_pass"] < d["gficf"]["ms_per_pass"] and be["roofline_frac"] > d["gficf"]["roofline"]["frac"]
+    for cfg, kern in (("c4", "k_jaccard_edges_bits"), ("c5", "k_jaccard_edges_pipe")):
+        c = json.load(open(os.path.join(root, "profiles", f"r04_bench_{cfg}.json")))
+        assert c["checked_vs_oracle"] is True and c["roofline"]["kernel"] == kern and c["scaling"] == "strong"
+    for n in (2, 3):
+        r = json.load(open(os.path.join(root, "profiles", f"r04_rehearsal_gpus{n}.json")))
+        assert r["n_gpus"] == n and r["checked_vs_oracle"] and r["spatial_ids"]["checked_vs_oracle"] and r["peer"]["checked_vs_oracle"] and r["chain"]["checked_vs_oracle"]
+        assert set(r["efficiency"]) >= {"in_order_permuted", "overlapped_permuted", "in_order_spatial", "overlapped_spatial", "peer_in_order_permuted"}
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "make_results.py"), "r04"], capture_output=True, text=True, timeout=120)
+    assert gen.returncode == 0, gen.stderr[-2000:]
+    assert gen.stdout == open(os.path.join(root, "RESULTS.md")).read(), "RESULTS.md is stale: python tools/make_results.py r04 > RESULTS.md"
