@@ -155,7 +155,10 @@ int gficf_jaccard_coeff_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, in
 int gficf_jaccard_kpad(int k);
 /* Row pitch of the table in 32-bit words, a function of (N_total, k) alone (every rank of a sharded build computes the
  * same): gficf_jaccard_kpad(k) words of 32-bit ids, or — for data sets of fewer than 2^17 cells, whose ids fit 17 bits,
- * and k <= kpad - kpad/16 (k = 30: 16 words = 64 B) — half of that: 16-bit low halves + one bitmap of high bits.  The row
+ * and k <= kpad - kpad/16 (k = 30: 16 words = 64 B) — half of that: 16-bit low halves + one bitmap of high bits; for
+ * 32 < k <= 55 and N_total <= 131070 (round 4) 64 words: that compact row plus a second copy of the ids regrouped for the
+ * gathers of the bit-set edge kernel ("dual" rows; GFICF_JACCARD_DUAL=0 in the environment, read per call, keeps the plain
+ * compact rows and the general kernel: an A/B switch — every caller of one table must see the same setting).  The row
  * layout is private to the library; callers only size and slice the table by this pitch.  A buffer of N * kpad words
  * always suffices. */
 int gficf_jaccard_row_words(int64_t N_total, int k);
