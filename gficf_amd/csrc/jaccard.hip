@@ -297,8 +297,12 @@ __device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD], int k) {
 // finds a repeated id when it inserts the row into its hash set and raises a deferred error.
 template <typename T, int KPAD, bool CMP, bool HALO = false, bool SCAN = true, bool DUAL = false>
 // (Holding the scan-less 64-slot variants to 7 waves per SIMD — so that the 1563 tiles of 100 k cells are all resident, where 79 / 93
-// vector registers give 6 / 5 workgroups per CU — spills 5 / 16 registers and is no faster: 13.1 / 26.5 us against 12.8 / 20.8.)
-__global__ __launch_bounds__(256, HALO ? 4 : 1) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
+// vector registers give 6 / 5 workgroups per CU — spills 5 / 16 registers and is no faster: 13.1 / 26.5 us against 12.8 / 20.8; the
+// dual variant at 6 waves per SIMD, -DGFICF_INGEST_DUAL_WAVES=6: 9 spills, 24.5 us.)
+#ifndef GFICF_INGEST_DUAL_WAVES
+#define GFICF_INGEST_DUAL_WAVES 1
+#endif
+__global__ __launch_bounds__(256, HALO ? 4 : (DUAL && !SCAN) ? GFICF_INGEST_DUAL_WAVES : 1) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
                                                      int64_t N_total, uint32_t* __restrict__ table,
                                                      uint32_t* __restrict__ status, int zero_ok, const gficf_halo_map hm) {
   constexpr int ROWS = 64;
