@@ -899,3 +899,50 @@ def test_halo_form_with_rows_taken_to_hold_distinct_ids(ops, N, k, P):
     m2[N // 2, 0] = m2[N // 2, k - 1]
     got, _ = _emulated_halo_build(ops, m2, P, 1024)                  # option off: flags, exact path, the oracle's multiset result
     assert np.array_equal(got, oracle.jaccard(m2, nthreads=8)[0])
+
+
+@pytest.mark.parametrize("N,k", [(200, 33), (5000, 40), (5000, 41), (70000, 48), (70000, 49), (66000, 55), (131070, 50), (131071, 50),
+                                 (65535, 50), (65536, 50), (65537, 35), (3000, 56)])
+def test_dual_rows_and_the_bit_set_kernel_across_their_boundaries(ops, N, k):
+    """Round 4: 32 < k <= 55 below 131 071 cells takes dual rows (compact row + planar copy) and k_jaccard_edges_bits — 5 / 6 / 7
+    gather steps (k = 40 | 41, 48 | 49), ids in one plane only (N <= 65 535), the first id of the second plane (65 536), the last
+    N the format serves (131 070) and the first it does not, k = 56 back on plain compact rows — every output form (matrix, matrix +
+    counts, uint16 counts through the edge filter), cell ranges that do not start at 0, both settings of the distinct-ids option and
+    the A/B switch GFICF_JACCARD_DUAL=0 on the same input: bit-exact against the oracle on a sample of cells."""
+    import torch
+
+    mat = synth.knn_windowed(N, k, W=max(100, k), seed=N % 1000 + k, perm_seed=11)
+    mat[5] = [N, N - 1] + list(range(1, k - 1))             # the largest ids in a row and the smallest: both ends of both planes (distinct)
+    dual = 32 < k <= 55 and N <= 131070
+    assert ops.row_words(N, k) == (64 if dual else 32)
+    idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
+    cb, ce = (0, N) if N <= 5000 else (N // 3, N // 3 + 4001)
+    want, wu = oracle.jaccard_cells(mat, cb, ce, nthreads=8)
+    n = (ce - cb) * k
+    for env in ({}, {"GFICF_JACCARD_DUAL": "0"}):
+        os.environ.update(env)
+        try:
+            rw = ops.row_words(N, k)
+            for distinct in (False, True):
+                ops.set_jaccard_distinct(distinct)
+                table = torch.zeros((N, rw), dtype=torch.int32, device="cuda")
+                ops.jaccard_ingest(idx, N, k, N, table)
+                out, u = torch.zeros((3, n), dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda")
+                ops.jaccard_edges(table, N, k, cb, ce, out, None)
+                ops.sync()
+                assert np.array_equal(out.cpu().numpy().T, want), (env, distinct, "matrix")
+                out.zero_()
+                ops.jaccard_edges(table, N, k, cb, ce, out, u)
+                ops.sync()
+                assert np.array_equal(out.cpu().numpy().T, want) and np.array_equal(u.cpu().numpy(), wu), (env, distinct, "matrix + counts")
+                u16 = torch.zeros(n, dtype=torch.int16, device="cuda")
+                ptr = torch.zeros(ce - cb + 1, dtype=torch.int64, device="cuda")
+                out.zero_()
+                ops.jaccard_edges_filtered(table, N, k, cb, ce, u16, ptr, out)
+                ops.sync()
+                kept = want[want[:, 2] > 0]
+                assert int(ptr[-1]) == len(kept) and np.array_equal(out[:, :len(kept)].cpu().numpy().T, kept), (env, distinct, "filtered")
+        finally:
+            ops.set_jaccard_distinct(False)
+            for key in env:
+                del os.environ[key]
