@@ -17,8 +17,9 @@ Workloads (`--config`, named in config.workload):
              rank owns 100 000 cells of a (100 000 x n_gpus)-cell data set; a batch of 8 independent data sets per step
              (different seeds), so that K = 20 steps time >= 10 ms and no launch re-reads what the one before left in
              the caches;
-  c4 / c5    BASELINE configs 4 / 5: ONE data set (100 000 x k = 50 / 1 000 000 x k = 30) split over the ranks by cell
-             block — strong scaling.
+  c1 .. c5   the Jaccard halves of BASELINE configs 1 .. 5: ONE data set (3 000 x k = 15, 10 000 x 30, 54 000 x 30, 100 000 x 50,
+             1 000 000 x 30) split over the ranks by cell block — strong scaling (c1 - c3 are single-GPU configs: a few
+             microseconds of work per data set, bound by launches).
 
 N > 1: ONE line carries the whole scaling answer — `value` (permuted ids, in order, exchange chosen from the data), `pipelined`
 (the same, overlapped), `spatial_ids` (ids with locality: the halo form, in order and overlapped, rows named outside the block),
@@ -49,7 +50,10 @@ sys.path.insert(0, ROOT)
 CELLS_PER_GPU = 100_000
 K = 30
 BATCH = 8                        # independent data sets per step (north_star)
-CONFIGS = {                      # strong-scaling configs of BASELINE.json: cells_total, k
+CONFIGS = {                      # the Jaccard halves of BASELINE.json's configs: cells_total, k (ONE data set, split over the ranks: strong scaling)
+    "c1": (3_000, 15),
+    "c2": (10_000, 30),
+    "c3": (54_000, 30),
     "c4": (100_000, 50),
     "c5": (1_000_000, 30),
 }
@@ -66,7 +70,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["north_star", "c4", "c5"], default="north_star")
+    ap.add_argument("--config", choices=["north_star", "c1", "c2", "c3", "c4", "c5"], default="north_star")
     ap.add_argument("--cells-per-gpu", type=int, default=CELLS_PER_GPU, help="north_star only")
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--batch", type=int, default=None, help="independent data sets per step (default 8 for north_star, 1 for c4 / c5)")
