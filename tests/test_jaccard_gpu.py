@@ -442,6 +442,15 @@ def test_rccl_single_rank_collectives_and_bench_launch_path():
         "dist.all_reduce(ws['nt'], op=dist.ReduceOp.SUM)\n"
         "ops.sync(); ref = oracle.gficf_csc(900, 500, cp, ri, x, 0.05, 1.0)\n"
         "n = int(ws['out_colptr'][500]); assert np.allclose(ws['out_x'][:n].cpu().numpy(), ref['x'], rtol=1e-6, atol=1e-6)\n"
+        # the halo form's two all-to-alls (equal splits, int32) and the bench's checker gather (list form), on RCCL
+        "from gficf_amd.dist import _all_to_all\n"
+        "a = torch.arange(4096, dtype=torch.int32, device='cuda'); b2 = torch.zeros_like(a)\n"
+        "_all_to_all(b2, a, None, None, None); assert torch.equal(a, b2)\n"
+        "b2.zero_(); _all_to_all(b2, a, [4096], [4096], None); assert torch.equal(a, b2)\n"
+        "c64 = torch.tensor([7], dtype=torch.int64, device='cuda'); r64 = torch.zeros_like(c64)\n"
+        "_all_to_all(r64, c64, None, None, None); assert int(r64) == 7\n"
+        "lst = [torch.zeros(3, 5, dtype=torch.int32, device='cuda')]\n"
+        "dist.all_gather(lst, torch.ones(3, 5, dtype=torch.int32, device='cuda')); assert int(lst[0].sum()) == 15\n"
         "dist.barrier(); dist.destroy_process_group(); print('ok')\n")
     env = dict(os.environ, PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
