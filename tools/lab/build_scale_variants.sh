@@ -5,6 +5,8 @@
 #           what the pass's memory pattern alone costs
 #   plain   no non-temporal hints on the loads and stores
 #   t<T>c<C> GFICF_SL_THREADS = T, GFICF_SL_CH = C
+#   rev     with GFICF_SCALE_STATIC_CELLS=1 (cells dealt round-robin to all waves of the grid: the grid sweeps the matrix as one front)
+#           the sweep runs from the LAST cell backwards — towards what the count pass left in the memory-side cache
 set -e
 cd "$(dirname "$0")/../../gficf_amd/csrc"
 make -s
@@ -30,6 +32,15 @@ PY
     plain)
       sed -e 's/__builtin_nontemporal_load(\([^)]*\))/(*(\1))/g' -e 's/__builtin_nontemporal_store(\([^,]*\), \([^)]*\))/(*(\2) = (\1))/g' gficf_csc.hip > /tmp/gficf_csc_plain.hip
       /opt/rocm/bin/hipcc $FLAGS -c /tmp/gficf_csc_plain.hip -o /tmp/gficf_csc_plain.o; link plain /tmp/gficf_csc_plain.o ;;
+    rev)
+      python3 - <<'PY'
+s = open("gficf_csc.hip").read()
+a = "    c_next = grab();                               // asked for early: the round trip hides behind this cell's loads\n"
+assert s.count(a) == 1
+s = s.replace(a, a + "    if (static_cells) c = n_cells - 1 - c;\n")
+open("/tmp/gficf_csc_rev.hip", "w").write(s)
+PY
+      /opt/rocm/bin/hipcc $FLAGS -c /tmp/gficf_csc_rev.hip -o /tmp/gficf_csc_rev.o; link rev /tmp/gficf_csc_rev.o ;;
     t*c*)
       T=${V#t}; T=${T%c*}; C=${V#*c}
       /opt/rocm/bin/hipcc $FLAGS -DGFICF_SL_THREADS=$T -DGFICF_SL_CH=$C -c gficf_csc.hip -o /tmp/gficf_csc_$V.o; link $V /tmp/gficf_csc_$V.o ;;
