@@ -59,6 +59,7 @@ SIGNATURES = {
     "gficf_multi_cell_blocks_by_nnz": (_int, [_i64, _vp, _int, _int, _vp]),
     "gficf_jaccard_host_multi": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _int]),
     "gficf_multi_jaccard_device": (_int, [_vp, _vp, _int, _vp, _i64, _int, _vp, _vp]),
+    "gficf_multi_jaccard_halo_device": (_int, [_vp, _vp, _vp, _i64, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "gficf_multi_sync": (_int, [_vp]),
     "gficf_multi_set_jaccard_distinct": (_int, [_vp, _int]),
     "gficf_normalize_csc_host_multi_plan": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _dbl, _dbl, _vp,
@@ -81,6 +82,7 @@ SIGNATURES = {
     "gficf_jaccard_halo_ingest_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_halo_serve_ingest_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gficf_jaccard_halo_ingest_slots_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_jaccard_halo_ingest_slots_peer_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_edges_mapped_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _vp, _vp]),
     "gficf_jaccard_edges_filtered_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -139,6 +139,51 @@ class MultiContext:
                 raise ValueError("expected contiguous tensors")
         check(_lib.load().gficf_multi_jaccard_device(self.handle, ptr(idx_blocks), is_f64, lds, int(N), int(k), ptr(tables), ptr(outs)))
 
+    def halo_buffers(self, N: int, k: int, cap: int | None = None) -> dict:
+        """Per-device buffers of :meth:`jaccard_halo_device` (allocated once, reused by every step): the plan's workspace (zeroed
+        here, once), request slots, the sub-problem's table and local -> global map, the block's output."""
+        import torch
+
+        L = _lib.load()
+        P = len(self.devices)
+        bd = self.cell_blocks(N)
+        rpr = -(-max(int(N), 1) // P)
+        if cap is None:
+            room = (1 << 17) - 1 - rpr                                   # rows left below 2^17 next to the largest block (compact rows)
+            cap = max(64, min(8192, room // P)) if room >= 64 * P else 1024
+        wsb = int(L.gficf_jaccard_halo_workspace_bytes(int(N), P))
+        bufs = dict(cap=int(cap), ws=[], req=[], table=[], l2g=[], out=[])
+        for r, d in enumerate(self.devices):
+            n = bd[r + 1] - bd[r]
+            n_ext = n + P * cap
+            dev = torch.device("cuda", d)
+            roww = int(L.gficf_jaccard_row_words(n_ext, int(k)))
+            if roww < 0:
+                raise GficfError(5, f"k = {k} / {n_ext} rows: no table format")
+            bufs["ws"].append(torch.zeros(wsb, dtype=torch.uint8, device=dev))
+            bufs["req"].append(torch.zeros(P * cap, dtype=torch.int32, device=dev))
+            bufs["table"].append(torch.zeros((n_ext, roww), dtype=torch.int32, device=dev))
+            bufs["l2g"].append(torch.zeros(n_ext, dtype=torch.int32, device=dev))
+            bufs["out"].append(torch.zeros((3, n * k), dtype=torch.float64, device=dev))
+        return bufs
+
+    def jaccard_halo_device(self, idx_blocks, N: int, k: int, bufs: dict):
+        """``gficf_multi_jaccard_halo_device``: the device-resident step for blocks whose ids have locality — nothing is exchanged,
+        a device reads the few rows its block names outside where they lie, in the other devices' blocks (peer mapping).  ``idx_blocks[r]``:
+        the (k, n_r) int32 tensor of block r on device slot r; ``bufs`` from :meth:`halo_buffers` (results in ``bufs["out"][r]``).
+        Enqueues only; :meth:`sync` waits and raises deferred errors (``GFICF_ERR_CAPACITY``: ids without locality)."""
+        P = len(self.devices)
+        if len(idx_blocks) != P:
+            raise ValueError("one block per device slot")
+        bd = self.cell_blocks(N)
+        for r, t in enumerate(idx_blocks):
+            if bd[r + 1] - bd[r] > 0 and (str(t.dtype) != "torch.int32" or not t.is_contiguous() or t.dim() != 2 or t.shape[0] != k):
+                raise ValueError(f"idx_blocks[{r}] must be a contiguous int32 tensor of shape ({k}, n_r)")
+        ptr = lambda ts: (ctypes.c_void_p * P)(*[(t.data_ptr() if t is not None and t.numel() else None) for t in ts])
+        lds = (ctypes.c_int64 * P)(*[(int(t.shape[1]) if t is not None and t.dim() == 2 and t.numel() else bd[r + 1] - bd[r]) for r, t in enumerate(idx_blocks)])
+        check(_lib.load().gficf_multi_jaccard_halo_device(self.handle, ptr(idx_blocks), lds, int(N), int(k), int(bufs["cap"]), ptr(bufs["ws"]), ptr(bufs["req"]),
+                                                          ptr(bufs["table"]), ptr(bufs["l2g"]), ptr(bufs["out"])))
+
     def sync(self):
         check(_lib.load().gficf_multi_sync(self.handle))
 

@@ -10,6 +10,8 @@
 //   winfo  : P * wpo x {word, set bits of the owner in front of the word}: what the lookups read (one 8 B load)
 __host__ __device__ inline int64_t gficf_halo_wpo(int64_t rpr) { return (((rpr + 31) / 32) + 3) & ~(int64_t)3; }
 
+constexpr int GFICF_HALO_MAX_PEERS = 16;       // owners of the peer form (the kernel argument carries their pointers)
+
 struct gficf_halo_map {
   const uint2* winfo;            // P * wpo x {bitmap word, rank of its first bit inside the owner}
   const int32_t* req_out;        // P * cap requested ids (0 = empty slot)
@@ -26,6 +28,12 @@ struct gficf_halo_map {
   int32_t* rows_out;
   int serve_blocks;
   int skip_empty;                // tiles of halo slots nobody asked for are not written (the launch that ingests ONLY the slots)
+  // peer form (gficf_multi_jaccard_halo_device: one process, every device maps the others' memory): nothing is exchanged — the row of a
+  // requested id is read where it lies, in its owner's block of global ids, by the launch that ingests the slots (peer_n owners with
+  // equal-pitch blocks: owner o holds rows [o * rpr, ...), column j of its row i at peer_idx[o][j * peer_ld[o] + i]; 0: the rows come from rows_in)
+  int peer_n;
+  const int32_t* peer_idx[GFICF_HALO_MAX_PEERS];
+  int64_t peer_ld[GFICF_HALO_MAX_PEERS];
 };
 
 // local id of a global id (1-based both); 0: not part of this rank's sub-problem; -1: not an id at all.  32-bit arithmetic on the

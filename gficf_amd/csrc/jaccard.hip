@@ -314,6 +314,8 @@ __global__ __launch_bounds__(256, HALO ? 4 : (DUAL && !SCAN) ? GFICF_INGEST_DUAL
   // dual rows: a wave's scratch for the planar part of ONE row (a whole tile of them would cost 8 KB of LDS: six workgroups per CU
   // instead of nine, 1536 resident ones for the 1563 tiles of 100 k cells — a second round for the last 27: 26 us against 13)
   __shared__ uint32_t prow[DUAL ? 16 : 1][DUAL ? 32 : 1];     // (four rows in flight per wave)
+  __shared__ const int32_t* s_peer_idx[HALO ? GFICF_HALO_MAX_PEERS : 1];
+  __shared__ int64_t s_peer_ld[HALO ? GFICF_HALO_MAX_PEERS : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // HALO: the launch ingests rows [row_begin, row_end) of the sub-problem (n_rows = row_end); its LAST serve_blocks workgroups do the
   // owner-side serve step instead (the rows other ranks asked of this one: independent of the ingest, one launch saved per step)
@@ -327,6 +329,13 @@ __global__ __launch_bounds__(256, HALO ? 4 : (DUAL && !SCAN) ? GFICF_INGEST_DUAL
       return;
     }
     row_first = hm.row_begin;
+    // peer form: the owners' blocks, indexed by a lane's own owner below (a by-value array indexed per lane would go through scratch)
+    if (hm.peer_n > 0) {
+#pragma unroll
+      for (int o = 0; o < GFICF_HALO_MAX_PEERS; ++o)
+        if (tid == o) { s_peer_idx[o] = hm.peer_idx[o]; s_peer_ld[o] = hm.peer_ld[o]; }
+      __syncthreads();
+    }
   }
   for (int64_t row0 = row_first + (int64_t)blockIdx.x * ROWS; row0 < n_rows; row0 += (int64_t)ingest_blocks * ROWS) {
     const int64_t r = row0 + lane;
@@ -350,7 +359,15 @@ __global__ __launch_bounds__(256, HALO ? 4 : (DUAL && !SCAN) ? GFICF_INGEST_DUAL
         for (int m = 0; m < KPAD / 4; ++m) {
           const int j = wave + 4 * m;
           int32_t g = 0;
-          if (j < k && r < n_rows) g = q < 0 ? (int32_t)idx[(int64_t)j * ld + r] : (gid != 0 ? hm.rows_in[q * k + j] : 0);
+          if (j < k && r < n_rows) {
+            if (q < 0) g = (int32_t)idx[(int64_t)j * ld + r];
+            else if (gid != 0) {
+              if (hm.peer_n > 0) {                             // the row where it lies: its owner's block (the plan asks owner o only for ids of o's block)
+                const uint32_t o = (uint32_t)q / (uint32_t)hm.cap;
+                g = s_peer_idx[o][(int64_t)j * s_peer_ld[o] + ((int64_t)gid - 1 - (int64_t)o * hm.rpr)];
+              } else g = hm.rows_in[q * k + j];
+            }
+          }
           raw[m] = (T)g;
         }
       }
@@ -2294,7 +2311,7 @@ int gficf_jaccard_ingest_local_device(gficf_ctx* ctx, const int32_t* d_idx_ext, 
 static int halo_ingest_launch(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total, int64_t cell_begin,
                               int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out, const int32_t* d_rows_in,
                               int32_t* d_table, int32_t* d_l2g, int64_t row_begin, int64_t row_end, const int32_t* d_req_in, int64_t n_req,
-                              int32_t* d_rows_out) {
+                              int32_t* d_rows_out, const int32_t* const* peer_idx = nullptr, const int64_t* peer_ld = nullptr) {
   GFICF_CTX_ENTER(ctx);
   if (n_local < 0 || k < 0 || N_total < 0 || P < 1 || cap < 1 || rows_per_rank < 1 || cell_begin < 0 || cell_begin + n_local > N_total)
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "halo ingest: sizes out of range");
@@ -2303,7 +2320,15 @@ static int halo_ingest_launch(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_lo
   if (rc) return rc;
   if (k > 64) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "halo ingest: the fused form covers k <= 64");
   if (n_ext == 0 || k == 0) return GFICF_OK;
-  if (!d_ws || !d_req_out || (row_end > n_local && !d_rows_in) || !d_table || !d_l2g || (n_local > 0 && !d_idx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (!d_ws || !d_req_out || (row_end > n_local && !d_rows_in && !peer_idx) || !d_table || !d_l2g || (n_local > 0 && !d_idx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (peer_idx) {
+    if (!peer_ld) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer (peer_ld)");
+    if (P > GFICF_HALO_MAX_PEERS) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "halo ingest, peer form: %d owners, at most %d", P, GFICF_HALO_MAX_PEERS);
+    for (int o = 0; o < P; ++o) {
+      const int64_t ob = (int64_t)o * rows_per_rank, on = ob >= N_total ? 0 : (N_total - ob < rows_per_rank ? N_total - ob : rows_per_rank);
+      if (on > 0 && (!peer_idx[o] || peer_ld[o] < on)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "halo ingest, peer form: block of owner %d missing or its ld below its %lld rows", o, (long long)on);
+    }
+  }
   if (n_req > 0 && (!d_req_in || !d_rows_out)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer (serve step)");
   if (n_local > 0 && ld < n_local) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld < n_local");
   const int64_t wpo = gficf_halo_wpo(rows_per_rank);                   // layout of gficf_jaccard_halo_workspace_bytes
@@ -2316,6 +2341,10 @@ static int halo_ingest_launch(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_lo
   gficf_halo_map hm{(const uint2*)((const char*)d_ws + (((size_t)P * (size_t)wpo * 4 + 255) & ~(size_t)255)), d_req_out, d_rows_in, d_l2g, n_local,
                     N_total, cell_begin, rows_per_rank, cap, (uint32_t)wpo, row_begin, row_end, d_req_in, n_req, d_rows_out, (int)sb,
                     row_begin >= n_local ? 1 : 0};
+  if (peer_idx) {
+    hm.peer_n = P;
+    for (int o = 0; o < P; ++o) { hm.peer_idx[o] = peer_idx[o]; hm.peer_ld[o] = peer_ld[o]; }
+  }
   const TableFmt f = table_fmt(n_ext, k);
   const unsigned grid = grid_i + (unsigned)sb;
   // rows taken to hold distinct ids (gficf_ctx_set_jaccard_distinct): no duplicate scan here either — a rank's own rows are
@@ -2369,6 +2398,17 @@ int gficf_jaccard_halo_ingest_slots_device(gficf_ctx* ctx, const int32_t* d_idx,
                                            const int32_t* d_rows_in, int32_t* d_table, int32_t* d_l2g) {
   return halo_ingest_launch(ctx, d_idx, n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap, d_ws, d_req_out, d_rows_in, d_table, d_l2g, n_local,
                             n_local + (int64_t)P * cap, nullptr, 0, nullptr);
+}
+
+/* The halo slots' rows with NO exchange (one process, every device maps the others' memory: gficf_multi_jaccard_halo_device): the row of
+ * every requested id is read where it lies — d_peer_idx[o] is owner o's block of global ids (a device pointer this device can
+ * dereference, column-major with leading dimension peer_ld[o]; blocks of equal pitch rows_per_rank), P <= 16 owners. */
+int gficf_jaccard_halo_ingest_slots_peer_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                                int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
+                                                const int32_t* const* d_peer_idx, const int64_t* peer_ld, int32_t* d_table, int32_t* d_l2g) {
+  if (!d_peer_idx || !peer_ld) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer (peer blocks)");
+  return halo_ingest_launch(ctx, d_idx, n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap, d_ws, d_req_out, nullptr, d_table, d_l2g, n_local,
+                            n_local + (int64_t)P * cap, nullptr, 0, nullptr, d_peer_idx, peer_ld);
 }
 
 /* Edges of the first n_cells rows of such a table; column 1 = src_offset + cell + 1, column 2 = d_l2g[local id - 1]. */

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "common.h"
+#include "halo_map.h"
 
 struct gficf_multi_block {
   int64_t b = 0, e = 0;            // cells [b, e)
@@ -530,6 +531,62 @@ int gficf_multi_jaccard_device(gficf_multi* m, const void* const* d_idx, int idx
   if (rc) return rc;
   m->step_valid = true;
   return GFICF_OK;
+}
+
+/* The same step for blocks whose ids have LOCALITY, with nothing exchanged at all: every device plans the rows its block names outside
+ * (halo.hip), builds the table of its own sub-problem — own cells from its block, the few requested rows READ WHERE THEY LIE, in the
+ * owners' blocks of ids, through the peer mapping — and its edges.  Four launches per device and no event between devices inside the step
+ * beyond "the inputs are complete".  Same blocks, same rows of rmat, bit for bit. */
+int gficf_multi_jaccard_halo_device(gficf_multi* m, const int32_t* const* d_idx, const int64_t* ld, int64_t N, int k, int cap,
+                                    void* const* d_ws, int32_t* const* d_req, int32_t* const* d_table, int32_t* const* d_l2g, double* const* d_out) {
+  if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  if (N < 0 || k < 0 || cap < 1) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N = %lld, k = %d or cap = %d out of range", (long long)N, k, cap);
+  if (k > 64) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "the halo step of the multi-device context covers k <= 64 (k = %d): use gficf_multi_jaccard_device", k);
+  const int P = m->ndev;
+  if (P > GFICF_HALO_MAX_PEERS) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "the halo step of the multi-device context covers %d devices, %d given", GFICF_HALO_MAX_PEERS, P);
+  if (!m->peer && P > 1) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "the halo step reads the other devices' blocks in place: it needs peer access between every pair of devices");
+  if (N == 0 || k == 0) return GFICF_OK;
+  if (!d_idx || !d_ws || !d_req || !d_table || !d_l2g || !d_out) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer array");
+  std::vector<int64_t> bd, lds;
+  std::vector<const int32_t*> blocks;
+  try { bd.resize((size_t)P + 1); lds.resize((size_t)P); blocks.resize((size_t)P); } catch (...) { GFICF_FAIL(GFICF_ERR_HIP, "out of host memory"); }
+  gficf_multi_cell_blocks(N, P, bd.data());
+  const int64_t rpr = (N + P - 1) / P;
+  for (int r = 0; r < P; ++r) {
+    const int64_t n = bd[r + 1] - bd[r];
+    if (!d_ws[r] || !d_req[r] || !d_table[r] || !d_l2g[r] || (n > 0 && (!d_idx[r] || !d_out[r]))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer for device slot %d", r);
+    if (ld && ld[r] < n) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld[%d] = %lld < %lld rows of the block", r, (long long)ld[r], (long long)n);
+    lds[r] = ld ? ld[r] : n;
+    blocks[r] = d_idx[r];
+  }
+  int rc = multi_step_resources(m);
+  if (!rc) rc = multi_workers_start(m);
+  if (rc) return rc;
+  // 1. "the inputs of this device are complete" (whatever wrote the block did so in stream order on the device's stream, or before the call)
+  rc = multi_run(m, [&](int r) -> int {
+    hipError_t e = hipSetDevice(m->dev[r]);
+    if (e == hipSuccess) e = hipEventRecord(m->ev[r], m->stream[r]);
+    return e == hipSuccess ? GFICF_OK : hip_fail("hipEventRecord", e);
+  });
+  if (rc) return rc;
+  // 2. every device on its own: plan -> own cells' rows -> the requested rows, read in the owners' blocks -> edges
+  rc = multi_run(m, [&](int r) -> int {
+    const int64_t n = bd[r + 1] - bd[r], n_ext = n + (int64_t)P * cap;
+    hipError_t e = hipSetDevice(m->dev[r]);
+    for (int s = 0; s < P && e == hipSuccess; ++s)
+      if (s != r) e = hipStreamWaitEvent(m->stream[r], m->ev[s], 0);
+    if (e != hipSuccess) return hip_fail("ordering the step behind the other devices' inputs", e);
+    gficf_ctx* c = m->ctx[r];
+    int q = gficf_jaccard_halo_plan_device(c, d_idx[r], n, k, lds[r], N, bd[r], P, rpr, cap, d_ws[r], d_req[r]);
+    if (!q) q = gficf_jaccard_halo_serve_ingest_device(c, d_idx[r], n, k, lds[r], N, bd[r], P, rpr, cap, d_ws[r], d_req[r], nullptr, 0, nullptr, d_table[r], d_l2g[r]);
+    if (!q) q = gficf_jaccard_halo_ingest_slots_peer_device(c, d_idx[r], n, k, lds[r], N, bd[r], P, rpr, cap, d_ws[r], d_req[r], blocks.data(), lds.data(), d_table[r], d_l2g[r]);
+    if (!q && n > 0) {
+      const size_t ne = (size_t)n * (size_t)k;
+      q = gficf_jaccard_edges_mapped_device(c, d_table[r], n_ext, k, n, bd[r], d_l2g[r], d_out[r], d_out[r] + ne, d_out[r] + 2 * ne, nullptr);
+    }
+    return q;
+  });
+  return rc;
 }
 
 int gficf_multi_sync(gficf_multi* m) {

@@ -196,3 +196,58 @@ def test_device_resident_multi_step_with_peer_copies(devices, N, k, f64):
             mc.sync()
         assert ei.value.status == "GFICF_ERR_DUPLICATE_IDS"
     mc.close()
+
+
+@pytest.mark.parametrize("devices,N,k", [([0, 0], 5001, 30), ([0, 0, 0], 20000, 15), ([0, 0, 0, 0], 30001, 50), ([0, 0], 260000, 30), ([0], 4000, 30),
+                                         ([0, 0, 0], 700, 64)])
+def test_device_resident_halo_step_reads_the_named_rows_in_place(devices, N, k):
+    """gficf_multi_jaccard_halo_device: blocks whose ids have locality, nothing exchanged — every device plans the rows its block names
+    outside, reads them where they lie (the other devices' blocks of ids; here contexts on the one GPU of the box) and builds its
+    sub-problem's table and edges: bit for bit the single-device result, step after step over the same buffers; ids without
+    locality raise GFICF_ERR_CAPACITY at the sync (and the context stays usable)."""
+    import torch
+
+    import oracle
+    from gficf_amd.api import MultiContext
+
+    mat = synth.knn_windowed(N, k, W=max(100, k), seed=4, perm_seed=None)
+    mat2 = synth.knn_windowed(N, k, W=max(100, k), seed=6, perm_seed=None)
+    mat[N // 2, 0] = 1                                         # rows far outside the band too: a slot of owner 0 / of the last owner
+    mat2[N // 3, k - 1] = N
+    ref = lambda m: oracle.jaccard(m, nthreads=8)[0] if N <= 40000 else gficf_amd.rcpp_parallel_jaccard_coef(m, False)
+    want, want2 = ref(mat), ref(mat2)
+    mc = MultiContext(devices)
+    P = len(devices)
+    bd = mc.cell_blocks(N)
+    blocks = lambda m: [torch.from_numpy(np.ascontiguousarray(m[bd[r]:bd[r + 1]].T)).to("cuda:0").contiguous() for r in range(P)]
+    i1, i2 = blocks(mat), blocks(mat2)
+    bufs = mc.halo_buffers(N, k)
+    torch.cuda.synchronize()
+    for distinct in (False, True):
+        mc.set_jaccard_distinct(distinct)
+        for blk, w in ((i2, want2), (i1, want), (i1, want)):
+            mc.jaccard_halo_device(blk, N, k, bufs)
+            mc.sync()
+            got = torch.cat(bufs["out"], dim=1).cpu().numpy().T
+            assert np.array_equal(got, w), (devices, N, k, distinct)
+    mc.set_jaccard_distinct(False)
+    if P > 1:
+        # a block that names more rows of one owner than there are slots: the deferred CAPACITY error, then a good step again
+        small = mc.halo_buffers(N, k, cap=2)
+        mc.jaccard_halo_device(i1, N, k, small)
+        with pytest.raises(gficf_amd.GficfError) as ei:
+            mc.sync()
+        assert ei.value.status == "GFICF_ERR_CAPACITY"
+        mc.jaccard_halo_device(i1, N, k, bufs)
+        mc.sync()
+        assert np.array_equal(torch.cat(bufs["out"], dim=1).cpu().numpy().T, want)
+    bad = blocks(mat)
+    bad[-1][0, 0] = N + 1
+    mc.jaccard_halo_device(bad, N, k, bufs)
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        mc.sync()
+    assert ei.value.status == "GFICF_ERR_BAD_ID"
+    with pytest.raises(gficf_amd.GficfError) as ei:           # k > 64: this form is the fused one
+        mc.jaccard_halo_device([b[:1].repeat(65, 1).contiguous() for b in i1], N, 65, bufs)
+    assert ei.value.status == "GFICF_ERR_UNSUPPORTED"
+    mc.close()
