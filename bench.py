@@ -600,13 +600,97 @@ def peer_child(args):
         want, _ = oracle.jaccard_cells(mat0, bd[r], bd[r] + run, nthreads=os.cpu_count() or 1)
         ok = ok and bool(np.array_equal(outs[0][r][:, :run * k].cpu().numpy().T, want))
         checked += run
-    print(json.dumps({"edges_per_sec": N_total * k * batch * args.steps / dt, "ms_per_data_set": dt / args.steps / batch * 1e3,
-                      "host_enqueue_us_per_data_set": t_enq / args.steps / batch * 1e6, "devices": devices, "ids": args.ids,
-                      "table_row_bytes": 4 * rw, "bytes_pulled_per_device_per_data_set": 4 * rw * (N_total - (bd[1] - bd[0])),
-                      "checked_vs_oracle": ok, "oracle_check_cells": checked,
-                      "form": "single process, one context per GPU (gficf_multi_jaccard_device): ingest -> every device pulls the other "
-                              "P - 1 table slices with hipMemcpyPeerAsync on copy streams of its own, all pairs at once -> edges; "
-                              "device-resident, in order, no collective"}))
+    res = {"edges_per_sec": N_total * k * batch * args.steps / dt, "ms_per_data_set": dt / args.steps / batch * 1e3,
+           "host_enqueue_us_per_data_set": t_enq / args.steps / batch * 1e6, "devices": devices, "ids": args.ids,
+           "table_row_bytes": 4 * rw, "bytes_pulled_per_device_per_data_set": 4 * rw * (N_total - (bd[1] - bd[0])),
+           "checked_vs_oracle": ok, "oracle_check_cells": checked,
+           "form": "single process, one context per GPU (gficf_multi_jaccard_device): ingest -> every device pulls the other "
+                   "P - 1 table slices with hipMemcpyPeerAsync on copy streams of its own, all pairs at once -> edges; "
+                   "device-resident, in order, no collective"}
+    print(json.dumps(res), flush=True)                                  # (kept if the leg below fails: the parent reads the last JSON line)
+    if k > 64 or P > 16:
+        return
+    # The same protocol on ids with locality, with NOTHING exchanged (gficf_multi_jaccard_halo_device): every device reads the few rows
+    # its block names outside where they lie, in the other devices' blocks of ids.
+    del idx, tables, outs
+    with cf.ThreadPoolExecutor(max_workers=min(batch, 8)) as ex:
+        mats = list(ex.map(lambda d: synth.knn_windowed(N_total, k, seed=42 + 7 * d, perm_seed=None), range(batch)))
+    idx = [[torch.from_numpy(np.ascontiguousarray(mats[d][bd[r]:bd[r + 1]].T)).to(f"cuda:{devices[r]}") for r in range(P)] for d in range(batch)]
+    bufs = [mc.halo_buffers(N_total, k) for _ in range(batch)]
+    mat0 = mats[0]
+    del mats
+    for dv in set(devices):
+        torch.cuda.synchronize(dv)
+
+    def hstep():
+        for d in range(batch):
+            mc.jaccard_halo_device(idx[d], N_total, k, bufs[d])
+
+    hstep()
+    mc.sync()
+    t0 = time.perf_counter()
+    hstep()
+    mc.sync()
+    one = max(time.perf_counter() - t0, 1e-5)
+    if args.pre_warm_ms > 0 and one < 0.02:
+        for _ in range(int(min(5000, max(1, args.pre_warm_ms * 1e-3 / one)))):
+            hstep()
+        mc.sync()
+    for _ in range(args.warmup):
+        hstep()
+    mc.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hstep()
+    t_enq = time.perf_counter() - t0
+    mc.sync()
+    dt = time.perf_counter() - t0
+    ok, checked = True, 0
+    for r in sorted({0, P // 2, P - 1}):
+        run = min(512, bd[r + 1] - bd[r])
+        want, _ = oracle.jaccard_cells(mat0, bd[r], bd[r] + run, nthreads=os.cpu_count() or 1)
+        ok = ok and bool(np.array_equal(bufs[0]["out"][r][:, :run * k].cpu().numpy().T, want))
+        checked += run
+    named = [int((bufs[0]["req"][r] != 0).sum()) for r in range(P)]
+    # ... and overlapped: a second context of the same devices (streams of its own), the data sets taken in turn — the front end of one
+    # context's step runs under the edge kernel of the other's
+    over = None
+    try:
+        mc2 = MultiContext(devices)
+        if not args.scan_dups:
+            mc2.set_jaccard_distinct(True)
+
+        def ostep():
+            for d in range(batch):
+                (mc2 if d & 1 else mc).jaccard_halo_device(idx[d], N_total, k, bufs[d])
+
+        for _ in range(max(args.warmup, 2)):
+            ostep()
+        mc.sync(); mc2.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ostep()
+        mc.sync(); mc2.sync()
+        dto = time.perf_counter() - t0
+        oko = True
+        run = min(256, bd[P] - bd[P - 1])
+        for d in sorted({0, min(1, batch - 1)}):                        # one data set of either context
+            want, _ = oracle.jaccard_cells(mat0 if d == 0 else synth.knn_windowed(N_total, k, seed=42 + 7 * d, perm_seed=None), bd[P - 1], bd[P - 1] + run,
+                                           nthreads=os.cpu_count() or 1)
+            oko = oko and bool(np.array_equal(bufs[d]["out"][P - 1][:, :run * k].cpu().numpy().T, want))
+        over = {"edges_per_sec": N_total * k * batch * args.steps / dto, "ms_per_data_set": dto / args.steps / batch * 1e3, "checked_vs_oracle": oko,
+                "form": "two contexts of the same devices take the data sets in turn"}
+        mc2.close()
+    except gficf_amd.GficfError as ex:
+        over = {"error": str(ex)}
+    res["spatial_ids"] = {"edges_per_sec": N_total * k * batch * args.steps / dt, "ms_per_data_set": dt / args.steps / batch * 1e3,
+                          "overlapped": over,
+                          "host_enqueue_us_per_data_set": t_enq / args.steps / batch * 1e6, "cap": bufs[0]["cap"],
+                          "rows_named_outside_per_device": named, "checked_vs_oracle": ok, "oracle_check_cells": checked,
+                          "form": "single process, one context per GPU (gficf_multi_jaccard_halo_device): plan -> own cells' table rows -> the rows "
+                                  "named outside, read where they lie in the owners' blocks of ids (peer mapping) -> edges; four launches per "
+                                  "device, nothing exchanged, no collective, no copy; in order"}
+    print(json.dumps(res), flush=True)
 
 
 def run_peer_leg(args, timeout_s=420.0):
@@ -632,9 +716,12 @@ def run_peer_leg(args, timeout_s=420.0):
             pr.communicate()
             return {"error": f"the peer leg did not finish within {timeout_s:.0f} s"}
         lines = [l for l in so.splitlines() if l.lstrip().startswith("{")]
-        if pr.returncode != 0 or not lines:
+        if not lines:
             return {"error": f"the peer leg exited {pr.returncode}: {se[-400:]}"}
-        return json.loads(lines[-1])
+        res = json.loads(lines[-1])
+        if pr.returncode != 0:                                          # (the first form's figures were printed before the second one failed)
+            res["error_after_this"] = f"the peer leg exited {pr.returncode}: {se[-400:]}"
+        return res
     except Exception as ex:
         return {"error": f"{type(ex).__name__}: {ex}"}
 
@@ -1121,6 +1208,10 @@ def main():
                 f"in_order_{other}": per(oo["in_order"]["edges_per_sec"]), f"overlapped_{other}": per(oo["overlapped"]["edges_per_sec"])}
             if "edges_per_sec" in out.get("peer", {}):
                 out["efficiency"][f"peer_in_order_{args.ids}"] = per(out["peer"]["edges_per_sec"])
+            if "edges_per_sec" in out.get("peer", {}).get("spatial_ids", {}):
+                out["efficiency"]["peer_halo_in_order_spatial"] = per(out["peer"]["spatial_ids"]["edges_per_sec"])
+                if "edges_per_sec" in (out["peer"]["spatial_ids"].get("overlapped") or {}):
+                    out["efficiency"]["peer_halo_overlapped_spatial"] = per(out["peer"]["spatial_ids"]["overlapped"]["edges_per_sec"])
     if distinct:
         ops.set_jaccard_distinct(False)
 

@@ -16,7 +16,10 @@
 //     for a host entry the all-reduce is two small copies) and handed back; filter, weights and the scaling pass
 //     then run per block and the kept entries land at their offsets in the caller's arrays.
 // Kernels and arithmetic are those of the single-device entries: same bits.
+#include <atomic>
 #include <condition_variable>
+#include <deque>
+#include <memory>
 #include <cstring>
 #include <exception>
 #include <functional>
@@ -46,6 +49,17 @@ struct gficf_multi_block {
   int64_t* d_out_colptr = nullptr;
 };
 
+struct gficf_multi_worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_idle;
+  std::deque<std::shared_ptr<const std::function<int(int)>>> q;
+  std::atomic<unsigned> posted{0};
+  bool busy = false, quit = false;
+  int rc = GFICF_OK;               // first failure since the failures were last collected (multi_drain)
+  std::string msg;
+};
+
 struct gficf_multi {
   int ndev = 0;
   std::vector<int> dev;
@@ -62,16 +76,12 @@ struct gficf_multi {
   bool step_valid = false;                         // ev_pulled holds a recorded step
   // ... enqueued by one PERSISTENT host thread per device (a step is ~45 runtime calls per device — launches, peer copies, event
   // records and waits: from one thread that is 8 x 45 calls in a row, several hundred microseconds per step at 8 devices against
-  // ~100 us of device work; threads made per call would cost as much).  Parked on a condition variable between the phases.
-  std::vector<std::thread> workers;
-  std::mutex wmu;
-  std::condition_variable wcv_job, wcv_done;
-  unsigned long long wgen = 0;
-  int wpending = 0;
-  bool wquit = false;
-  const std::function<int(int)>* wbody = nullptr;
-  std::vector<int> wrc;
-  std::vector<std::string> wmsg;
+  // ~100 us of device work; threads made per call would cost as much).  Every thread has a queue of jobs of its own: a job is POSTED
+  // to all of them and either waited for (the phases of the peer-copy step, which depend on each other across devices) or not (the
+  // halo step: its devices do not depend on each other, so the caller's thread is free to post the next step while this one is
+  // still being enqueued; failures are kept and come out of gficf_multi_sync).  A thread spins for a few tens of microseconds
+  // before it parks on its condition variable: inside a burst of steps the next job arrives within that.
+  std::vector<std::unique_ptr<gficf_multi_worker>> workers;
   // GF-ICF plan
   bool has_plan = false;
   int64_t G = 0, N = 0, g_kept = 0, nnz_kept = 0;
@@ -233,17 +243,12 @@ int gficf_multi_create(const int* devices, int ndev, gficf_multi** out) {
   return GFICF_OK;
 }
 
+static void multi_workers_stop(gficf_multi* m);
+static int multi_drain(gficf_multi* m);
+
 void gficf_multi_destroy(gficf_multi* m) {
   if (!m) return;
-  if (!m->workers.empty()) {
-    {
-      std::lock_guard<std::mutex> lk(m->wmu);
-      m->wquit = true;
-    }
-    m->wcv_job.notify_all();
-    for (auto& t : m->workers) t.join();
-    m->workers.clear();
-  }
+  multi_workers_stop(m);
   for (size_t r = 0; r < m->ctx.size(); ++r) {
     if (m->ctx[r]) gficf_ctx_destroy(m->ctx[r]);
   }
@@ -275,6 +280,7 @@ int gficf_multi_set_print(gficf_multi* m, void (*fn)(const char*)) {
 int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, double* rmat,
                              int print_output) {
   if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  { const int drc = multi_drain(m); if (drc) return drc; }                     // device-resident steps still being enqueued come first
   if (N < 0 || k < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N = %lld or k = %d is negative", (long long)N, k);
   const int roww = gficf_jaccard_row_words(N, k);
   if (roww < 0) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d exceeds GFICF_JACCARD_MAX_K = %d or N = %lld exceeds int32 ids", k, GFICF_JACCARD_MAX_K, (long long)N);
@@ -360,69 +366,105 @@ int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, in
 static int multi_workers_start(gficf_multi* m) {
   if (!m->workers.empty() || m->ndev == 1) return GFICF_OK;
   try {
-    m->wrc.assign((size_t)m->ndev, GFICF_OK);
-    m->wmsg.assign((size_t)m->ndev, std::string());
     for (int r = 0; r < m->ndev; ++r) {
-      m->workers.emplace_back([m, r]() {
+      m->workers.emplace_back(new gficf_multi_worker());
+      gficf_multi_worker* const w = m->workers.back().get();
+      w->th = std::thread([m, w, r]() {
         (void)hipSetDevice(m->dev[r]);
-        unsigned long long seen = 0;
+        unsigned taken = 0;
         for (;;) {
-          const std::function<int(int)>* body = nullptr;
+          for (int spin = 0; spin < 4000 && w->posted.load(std::memory_order_acquire) == taken; ++spin) __builtin_ia32_pause();
+          std::shared_ptr<const std::function<int(int)>> job;
           {
-            std::unique_lock<std::mutex> lk(m->wmu);
-            m->wcv_job.wait(lk, [&] { return m->wquit || m->wgen != seen; });
-            if (m->wquit) return;
-            seen = m->wgen;
-            body = m->wbody;
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv_job.wait(lk, [&] { return w->quit || !w->q.empty(); });
+            if (w->q.empty()) return;                 // (quit: only once every posted job has run)
+            job = std::move(w->q.front());
+            w->q.pop_front();
+            w->busy = true;
           }
-          const int rc = guarded(*body, r);
-          std::string msg = rc != GFICF_OK ? std::string(gficf_last_error()) : std::string();
+          ++taken;
+          const int rc = guarded(*job, r);
+          std::string msg;
+          if (rc != GFICF_OK) {
+            try { msg = gficf_last_error(); } catch (...) {}
+          }
+          job.reset();
           {
-            std::lock_guard<std::mutex> lk(m->wmu);
-            m->wrc[(size_t)r] = rc;
-            m->wmsg[(size_t)r].swap(msg);
-            if (--m->wpending == 0) m->wcv_done.notify_one();
+            std::lock_guard<std::mutex> lk(w->mu);
+            if (rc != GFICF_OK && w->rc == GFICF_OK) { w->rc = rc; w->msg.swap(msg); }
+            w->busy = false;
+            if (w->q.empty()) w->cv_idle.notify_all();
           }
         }
       });
     }
   } catch (...) {                                   // no threads to be had: the caller's thread does the work (workers stays short: never used)
-    {
-      std::lock_guard<std::mutex> lk(m->wmu);
-      m->wquit = true;
-    }
-    m->wcv_job.notify_all();
-    for (auto& t : m->workers) t.join();
-    m->workers.clear();
-    m->wquit = false;
+    multi_workers_stop(m);
   }
   return GFICF_OK;
 }
 
-static int multi_run(gficf_multi* m, const std::function<int(int)>& body) {
+static void multi_workers_stop(gficf_multi* m) {
+  for (auto& w : m->workers) {
+    if (!w || !w->th.joinable()) continue;
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->quit = true;
+    }
+    w->cv_job.notify_all();
+    w->th.join();
+  }
+  m->workers.clear();
+}
+
+// Posts body(r) to every device slot r's thread and returns (one device, or no threads: runs it here).  The job is kept alive by the queues.
+static int multi_post(gficf_multi* m, std::function<int(int)> body) {
   const int P = m->ndev;
-  if ((int)m->workers.size() != P) {                // one device, or no threads: in line
+  if ((int)m->workers.size() != P) {
     for (int r = 0; r < P; ++r) {
       const int rc = guarded(body, r);
       if (rc) return rc;
     }
     return GFICF_OK;
   }
-  {
-    std::unique_lock<std::mutex> lk(m->wmu);
-    m->wbody = &body;
-    m->wpending = P;
-    ++m->wgen;
-    m->wcv_job.notify_all();
-    m->wcv_done.wait(lk, [&] { return m->wpending == 0; });
-    m->wbody = nullptr;
-  }
-  for (int r = 0; r < P; ++r)
-    if (m->wrc[(size_t)r] != GFICF_OK) {
-      gficf_set_error("%s", m->wmsg[(size_t)r].c_str());
-      return m->wrc[(size_t)r];
+  std::shared_ptr<const std::function<int(int)>> job;
+  try {
+    job = std::make_shared<const std::function<int(int)>>(std::move(body));
+    for (auto& w : m->workers) {
+      {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->q.push_back(job);
+      }
+      w->posted.fetch_add(1, std::memory_order_release);
+      w->cv_job.notify_one();
     }
+  } catch (...) {
+    GFICF_FAIL(GFICF_ERR_HIP, "out of host memory posting a multi-device job");
+  }
   return GFICF_OK;
+}
+
+// Waits until every posted job has run; the first failure (in device order) since the last call is returned and forgotten.
+static int multi_drain(gficf_multi* m) {
+  int rc = GFICF_OK;
+  std::string msg;
+  for (auto& w : m->workers) {
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv_idle.wait(lk, [&] { return w->q.empty() && !w->busy; });
+    if (w->rc != GFICF_OK && rc == GFICF_OK) { rc = w->rc; msg.swap(w->msg); }
+    w->rc = GFICF_OK;
+    w->msg.clear();
+  }
+  if (rc != GFICF_OK) gficf_set_error("%s", msg.c_str());
+  return rc;
+}
+
+// body(r) for every device slot r on the slot's thread; returns when all are done.  First failing slot wins.
+static int multi_run(gficf_multi* m, const std::function<int(int)>& body) {
+  const int rc = multi_post(m, body);
+  if (rc) return rc;
+  return multi_drain(m);
 }
 
 // lazily: the copy streams and events of gficf_multi_jaccard_device
@@ -452,6 +494,8 @@ static int multi_step_resources(gficf_multi* m) {
 
 int gficf_multi_set_jaccard_distinct(gficf_multi* m, int assume_distinct) {
   if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  const int drc = multi_drain(m);                                              // (posted steps read the setting when they are enqueued)
+  if (drc) return drc;
   for (gficf_ctx* c : m->ctx) {
     const int rc = gficf_ctx_set_jaccard_distinct(c, assume_distinct);
     if (rc) return rc;
@@ -547,51 +591,52 @@ int gficf_multi_jaccard_halo_device(gficf_multi* m, const int32_t* const* d_idx,
   if (!m->peer && P > 1) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "the halo step reads the other devices' blocks in place: it needs peer access between every pair of devices");
   if (N == 0 || k == 0) return GFICF_OK;
   if (!d_idx || !d_ws || !d_req || !d_table || !d_l2g || !d_out) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer array");
-  std::vector<int64_t> bd, lds;
-  std::vector<const int32_t*> blocks;
-  try { bd.resize((size_t)P + 1); lds.resize((size_t)P); blocks.resize((size_t)P); } catch (...) { GFICF_FAIL(GFICF_ERR_HIP, "out of host memory"); }
-  gficf_multi_cell_blocks(N, P, bd.data());
+  // (the step is posted, not waited for: everything the job reads is its own copy)
+  struct Step {
+    std::vector<int64_t> bd, lds;
+    std::vector<const int32_t*> idx;
+    std::vector<void*> ws;
+    std::vector<int32_t*> req, table, l2g;
+    std::vector<double*> out;
+  };
+  std::shared_ptr<Step> st;
+  try {
+    st = std::make_shared<Step>();
+    st->bd.resize((size_t)P + 1); st->lds.resize((size_t)P); st->idx.resize((size_t)P); st->ws.resize((size_t)P);
+    st->req.resize((size_t)P); st->table.resize((size_t)P); st->l2g.resize((size_t)P); st->out.resize((size_t)P);
+  } catch (...) { GFICF_FAIL(GFICF_ERR_HIP, "out of host memory"); }
+  gficf_multi_cell_blocks(N, P, st->bd.data());
   const int64_t rpr = (N + P - 1) / P;
   for (int r = 0; r < P; ++r) {
-    const int64_t n = bd[r + 1] - bd[r];
+    const int64_t n = st->bd[r + 1] - st->bd[r];
     if (!d_ws[r] || !d_req[r] || !d_table[r] || !d_l2g[r] || (n > 0 && (!d_idx[r] || !d_out[r]))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer for device slot %d", r);
     if (ld && ld[r] < n) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld[%d] = %lld < %lld rows of the block", r, (long long)ld[r], (long long)n);
-    lds[r] = ld ? ld[r] : n;
-    blocks[r] = d_idx[r];
+    st->lds[r] = ld ? ld[r] : n;
+    st->idx[r] = d_idx[r]; st->ws[r] = d_ws[r]; st->req[r] = d_req[r]; st->table[r] = d_table[r]; st->l2g[r] = d_l2g[r]; st->out[r] = d_out[r];
   }
-  int rc = multi_step_resources(m);
-  if (!rc) rc = multi_workers_start(m);
+  if (gficf_jaccard_row_words(rpr + (int64_t)P * cap, k) < 0) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "no table format for %lld rows of k = %d", (long long)(rpr + (int64_t)P * cap), k);
+  int rc = multi_workers_start(m);
   if (rc) return rc;
-  // 1. "the inputs of this device are complete" (whatever wrote the block did so in stream order on the device's stream, or before the call)
-  rc = multi_run(m, [&](int r) -> int {
-    hipError_t e = hipSetDevice(m->dev[r]);
-    if (e == hipSuccess) e = hipEventRecord(m->ev[r], m->stream[r]);
-    return e == hipSuccess ? GFICF_OK : hip_fail("hipEventRecord", e);
-  });
-  if (rc) return rc;
-  // 2. every device on its own: plan -> own cells' rows -> the requested rows, read in the owners' blocks -> edges
-  rc = multi_run(m, [&](int r) -> int {
-    const int64_t n = bd[r + 1] - bd[r], n_ext = n + (int64_t)P * cap;
-    hipError_t e = hipSetDevice(m->dev[r]);
-    for (int s = 0; s < P && e == hipSuccess; ++s)
-      if (s != r) e = hipStreamWaitEvent(m->stream[r], m->ev[s], 0);
-    if (e != hipSuccess) return hip_fail("ordering the step behind the other devices' inputs", e);
+  // every device on its own: plan -> own cells' rows -> the requested rows, read in the owners' blocks -> edges.  No event between the
+  // devices: the blocks of ids are inputs, complete before the call (the contract of every device entry).
+  return multi_post(m, [m, st, N, k, cap, P, rpr](int r) -> int {
+    const int64_t n = st->bd[r + 1] - st->bd[r], n_ext = n + (int64_t)P * cap, b = st->bd[r];
     gficf_ctx* c = m->ctx[r];
-    int q = gficf_jaccard_halo_plan_device(c, d_idx[r], n, k, lds[r], N, bd[r], P, rpr, cap, d_ws[r], d_req[r]);
-    if (!q) q = gficf_jaccard_halo_serve_ingest_device(c, d_idx[r], n, k, lds[r], N, bd[r], P, rpr, cap, d_ws[r], d_req[r], nullptr, 0, nullptr, d_table[r], d_l2g[r]);
-    if (!q) q = gficf_jaccard_halo_ingest_slots_peer_device(c, d_idx[r], n, k, lds[r], N, bd[r], P, rpr, cap, d_ws[r], d_req[r], blocks.data(), lds.data(), d_table[r], d_l2g[r]);
+    int q = gficf_jaccard_halo_plan_device(c, st->idx[r], n, k, st->lds[r], N, b, P, rpr, cap, st->ws[r], st->req[r]);
+    if (!q) q = gficf_jaccard_halo_serve_ingest_device(c, st->idx[r], n, k, st->lds[r], N, b, P, rpr, cap, st->ws[r], st->req[r], nullptr, 0, nullptr, st->table[r], st->l2g[r]);
+    if (!q) q = gficf_jaccard_halo_ingest_slots_peer_device(c, st->idx[r], n, k, st->lds[r], N, b, P, rpr, cap, st->ws[r], st->req[r], st->idx.data(), st->lds.data(), st->table[r], st->l2g[r]);
     if (!q && n > 0) {
       const size_t ne = (size_t)n * (size_t)k;
-      q = gficf_jaccard_edges_mapped_device(c, d_table[r], n_ext, k, n, bd[r], d_l2g[r], d_out[r], d_out[r] + ne, d_out[r] + 2 * ne, nullptr);
+      q = gficf_jaccard_edges_mapped_device(c, st->table[r], n_ext, k, n, b, st->l2g[r], st->out[r], st->out[r] + ne, st->out[r] + 2 * ne, nullptr);
     }
     return q;
   });
-  return rc;
 }
 
 int gficf_multi_sync(gficf_multi* m) {
   if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
   FirstError fe;
+  fe.note(multi_drain(m));                                                     // steps still being enqueued; what their enqueue reported
   for (int r = 0; r < m->ndev; ++r) fe.note(gficf_ctx_sync(m->ctx[r]));      // (the copy streams were joined into the device's stream)
   return fe.done();
 }
@@ -607,6 +652,7 @@ int gficf_normalize_csc_host_multi_plan(gficf_multi* m, int64_t G, int64_t N, co
                                         const int32_t* rowidx, const double* x, double prop_min, double prop_max,
                                         const double* w_in, int64_t* G_kept, int64_t* nnz_kept) {
   if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  { const int drc = multi_drain(m); if (drc) return drc; }                     // device-resident steps still being enqueued come first
   if (G < 0 || N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative dimension");
   if (G > 0x7FFFFFFFll) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "G = %lld exceeds int32 row indices", (long long)G);
   if (!colptr || !G_kept || !nnz_kept) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
@@ -707,6 +753,7 @@ int gficf_normalize_csc_host_multi_plan(gficf_multi* m, int64_t G, int64_t N, co
 int gficf_normalize_csc_host_multi_finish(gficf_multi* m, uint8_t* keep, int64_t* nt, double* w, void* out_colptr,
                                           int32_t* out_rowidx, double* out_x) {
   if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
+  { const int drc = multi_drain(m); if (drc) return drc; }                     // device-resident steps still being enqueued come first
   if (!m->has_plan) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "gficf_normalize_csc_host_multi_finish without a plan");
   if (!out_colptr || (m->nnz_kept > 0 && (!out_rowidx || !out_x))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
   const int P = m->ndev;

@@ -10,13 +10,18 @@ pipelined = max(sum of the kernel times, exchange) (exchange of the next data se
 never `value`).  Third form, round 4: "peer" — the single-process step of the C ABI (gficf_multi_jaccard_device): ingest, then
 every device pulls the other P - 1 UNPACKED table slices with hipMemcpyPeerAsync (one slice per link, all pairs at once), then
 edges on the full table; no collective, so the fixed cost of the exchange is a copy's start-up (PEER_LAT_US) instead of LAT_US,
-but the rows travel as the table holds them (128 B from 2^17 cells on) and no pack / unpack kernels run."""
+but the rows travel as the table holds them (128 B from 2^17 cells on) and no pack / unpack kernels run.  Fourth form: "peer halo"
+(gficf_multi_jaccard_halo_device) — the halo step's kernels with NOTHING exchanged: the launch that ingests the halo slots reads
+the rows named outside where they lie, in the owners' blocks of ids, through the peer mapping (a few hundred rows of k ids: one
+dependent remote read per lane, PEER_READ_US on top of the kernel); no collective, no copy, no event between devices.  Its
+"overlapped" column is two such contexts taking the data sets in turn (the front end of one under the edge kernel of the other)."""
 import json
 import sys
 
 LINK_GBS = 55.0      # achieved per link and direction in RCCL collectives (xGMI, 76.8 GB/s nominal per direction); VERDICT r2 item 2 uses 55
 LAT_US = 20.0        # launch + protocol latency of one small RCCL collective
 GAP_US = 2.0         # between dependent kernel launches on one stream
+PEER_READ_US = 3.0   # a dependent read over xGMI inside a kernel (the peer halo form's slots launch)
 PEER_LAT_US = 6.0    # start-up of a peer copy behind an event (SDMA engine); the host's enqueue of a step runs ahead on its own threads
 
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip().startswith("{")]
@@ -32,8 +37,10 @@ for r in rows:
     if P == 1:
         continue
     for ids in ("spatial", "permuted"):
-        for form in ("allgather", "peer", "halo"):
-            d = r.get(f"{form}_{ids}")
+        for form in ("allgather", "peer", "halo", "peer halo"):
+            d = r.get(f"{form}_{ids}") if form != "peer halo" else r.get(f"halo_{ids}")
+            if form == "peer halo" and (not d or not d.get("fits") or "slots_ms" not in d):
+                continue
             if form == "peer":
                 ag = r.get(f"allgather_{ids}")
                 if not ag:
@@ -54,11 +61,22 @@ for r in rows:
             elif form == "peer":
                 ex = d["bytes_received"] / (P - 1) / (LINK_GBS * 1e3) + PEER_LAT_US      # one unpacked slice per link, pulled side by side
                 named = "all"
+            elif form == "peer halo":
+                ex = PEER_READ_US
+                named = str(d["rows_named_outside"])
             else:
                 per_peer_req, per_peer_rows = d["cap"] * 4, d["cap"] * 4 * r["k"]
                 ex = per_peer_req / (LINK_GBS * 1e3) + LAT_US + per_peer_rows / (LINK_GBS * 1e3) + LAT_US
                 named = str(d["rows_named_outside"])
             step = comp + ex
             over = max(d["compute_ms"] * 1e3, ex)                 # overlapped: the launch gaps are filled by the other stream
-            print(f"| {P} | {ids} | {form} | {named} | {d['bytes_received'] / 1e6:.2f} MB | {d['table_row_bytes']} B | {comp:.0f} us | {ex:.0f} us | "
+            if form == "peer halo":                               # two contexts in turn: the longer of the edge kernel and the front end (+ the remote read)
+                front = d["compute_ms"] * 1e3 - d["edges_ms"] * 1e3 + ex
+                over = max(d["edges_ms"] * 1e3 + GAP_US, front)
+            recv = d["bytes_received"] if form != "peer halo" else d["rows_named_outside"] * 4 * r["k"]
+            print(f"| {P} | {ids} | {form} | {named} | {recv / 1e6:.2f} MB | {d['table_row_bytes']} B | {comp:.0f} us | {ex:.0f} us | "
                   f"{step:.0f} us | {base_ms * 1e3 / step:.2f} | {over:.0f} us | {base_ms * 1e3 / over:.2f} |")
+print()
+print("(Both efficiency columns divide the single GPU's IN-ORDER step by the step of the form; a form that overlaps data sets can exceed 1 "
+      "against it — the single GPU overlapping its own data sets runs a step in about %.0f us, its edge kernel plus a launch gap.)"
+      % (one["allgather_permuted"]["edges_ms"] * 1e3 + GAP_US))
