@@ -82,7 +82,7 @@ SIGNATURES = {
     "gficf_jaccard_halo_ingest_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_halo_serve_ingest_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gficf_jaccard_halo_ingest_slots_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
-    "gficf_jaccard_halo_ingest_slots_peer_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_jaccard_halo_ingest_peer_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_edges_mapped_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _vp, _vp]),
     "gficf_jaccard_edges_filtered_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -800,6 +800,17 @@ class HipOps:
     def halo_workspace_bytes(self, N_total: int, P: int) -> int:
         return int(self.L.gficf_jaccard_halo_workspace_bytes(int(N_total), int(P)))
 
+    def halo_ingest_peer(self, idx_cm, n_local, k, N_total, cell_begin, P, rows_per_rank, cap, ws, req_out, owner_blocks, table, l2g):
+        """The whole table of the sub-problem in one launch behind the plan, with nothing exchanged: ``owner_blocks[o]`` is owner o's
+        (k, ld_o) int32 block of global ids in memory this device can read (its own, or a peer's through the peer mapping)."""
+        if len(owner_blocks) != P:
+            raise ValueError("one block per owner")
+        ptrs = (ctypes.c_void_p * P)(*[(t.data_ptr() if t is not None and t.numel() else None) for t in owner_blocks])
+        lds = (ctypes.c_int64 * P)(*[(int(t.shape[1]) if t is not None and t.dim() == 2 and t.numel() else 0) for t in owner_blocks])
+        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else n_local
+        check(self.L.gficf_jaccard_halo_ingest_peer_device(self._bind(), _tptr(idx_cm), n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap,
+                                                           _tptr(ws), _tptr(req_out), ptrs, lds, _tptr(table), _tptr(l2g)))
+
     def halo_plan(self, idx_cm, n_local, k, N_total, cell_begin, P, rows_per_rank, cap, ws, req_out):
         """idx_cm: (k, ld) int32, the block's global ids.  Fills req_out (P * cap int32: ids asked of every owner, 0 = empty)."""
         if idx_cm.dtype != self.torch.int32:

@@ -337,7 +337,14 @@ __global__ __launch_bounds__(256, HALO ? 4 : (DUAL && !SCAN) ? GFICF_INGEST_DUAL
       __syncthreads();
     }
   }
-  for (int64_t row0 = row_first + (int64_t)blockIdx.x * ROWS; row0 < n_rows; row0 += (int64_t)ingest_blocks * ROWS) {
+  // (peer form: the tiles are taken from the LAST one down — the few tiles of halo slots in use read their rows through a chain of
+  // dependent loads, request -> owner's pointer -> the owner's block, possibly over xGMI: started first, that latency lies under the
+  // own cells' tiles instead of behind them)
+  const int64_t n_tiles = (n_rows - row_first + ROWS - 1) / ROWS;
+  bool from_last = false;
+  if constexpr (HALO) from_last = hm.peer_n > 0;
+  for (int64_t tile_i = blockIdx.x; tile_i < n_tiles; tile_i += ingest_blocks) {
+    const int64_t row0 = row_first + (from_last ? n_tiles - 1 - tile_i : tile_i) * ROWS;
     const int64_t r = row0 + lane;
     // all loads of the thread are issued before the first is looked at
     T raw[KPAD / 4];
@@ -2343,6 +2350,7 @@ static int halo_ingest_launch(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_lo
                     row_begin >= n_local ? 1 : 0};
   if (peer_idx) {
     hm.peer_n = P;
+    hm.skip_empty = 1;                                       // (also when the launch covers the own cells too: a tile of slots nobody asked for is never referred to)
     for (int o = 0; o < P; ++o) { hm.peer_idx[o] = peer_idx[o]; hm.peer_ld[o] = peer_ld[o]; }
   }
   const TableFmt f = table_fmt(n_ext, k);
@@ -2400,14 +2408,15 @@ int gficf_jaccard_halo_ingest_slots_device(gficf_ctx* ctx, const int32_t* d_idx,
                             n_local + (int64_t)P * cap, nullptr, 0, nullptr);
 }
 
-/* The halo slots' rows with NO exchange (one process, every device maps the others' memory: gficf_multi_jaccard_halo_device): the row of
- * every requested id is read where it lies — d_peer_idx[o] is owner o's block of global ids (a device pointer this device can
- * dereference, column-major with leading dimension peer_ld[o]; blocks of equal pitch rows_per_rank), P <= 16 owners. */
-int gficf_jaccard_halo_ingest_slots_peer_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
-                                                int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
-                                                const int32_t* const* d_peer_idx, const int64_t* peer_ld, int32_t* d_table, int32_t* d_l2g) {
+/* The whole table of a sub-problem with NO exchange, in one launch (one process, every device maps the others' memory:
+ * gficf_multi_jaccard_halo_device): the own cells' rows from the block, and the row of every requested id read where it lies —
+ * d_peer_idx[o] is owner o's block of global ids (a device pointer this device can dereference, column-major with leading
+ * dimension peer_ld[o]; blocks of equal pitch rows_per_rank), P <= 16 owners.  Needs the plan only. */
+int gficf_jaccard_halo_ingest_peer_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                          int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
+                                          const int32_t* const* d_peer_idx, const int64_t* peer_ld, int32_t* d_table, int32_t* d_l2g) {
   if (!d_peer_idx || !peer_ld) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer (peer blocks)");
-  return halo_ingest_launch(ctx, d_idx, n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap, d_ws, d_req_out, nullptr, d_table, d_l2g, n_local,
+  return halo_ingest_launch(ctx, d_idx, n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap, d_ws, d_req_out, nullptr, d_table, d_l2g, 0,
                             n_local + (int64_t)P * cap, nullptr, 0, nullptr, d_peer_idx, peer_ld);
 }
 

@@ -579,8 +579,8 @@ int gficf_multi_jaccard_device(gficf_multi* m, const void* const* d_idx, int idx
 
 /* The same step for blocks whose ids have LOCALITY, with nothing exchanged at all: every device plans the rows its block names outside
  * (halo.hip), builds the table of its own sub-problem — own cells from its block, the few requested rows READ WHERE THEY LIE, in the
- * owners' blocks of ids, through the peer mapping — and its edges.  Four launches per device and no event between devices inside the step
- * beyond "the inputs are complete".  Same blocks, same rows of rmat, bit for bit. */
+ * owners' blocks of ids, through the peer mapping — and its edges.  Three kernels after the plan's mark (four launches) per device and no
+ * event between devices: the blocks of ids are inputs.  Same blocks, same rows of rmat, bit for bit. */
 int gficf_multi_jaccard_halo_device(gficf_multi* m, const int32_t* const* d_idx, const int64_t* ld, int64_t N, int k, int cap,
                                     void* const* d_ws, int32_t* const* d_req, int32_t* const* d_table, int32_t* const* d_l2g, double* const* d_out) {
   if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
@@ -617,14 +617,13 @@ int gficf_multi_jaccard_halo_device(gficf_multi* m, const int32_t* const* d_idx,
   if (gficf_jaccard_row_words(rpr + (int64_t)P * cap, k) < 0) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "no table format for %lld rows of k = %d", (long long)(rpr + (int64_t)P * cap), k);
   int rc = multi_workers_start(m);
   if (rc) return rc;
-  // every device on its own: plan -> own cells' rows -> the requested rows, read in the owners' blocks -> edges.  No event between the
+  // every device on its own: plan -> the table (own cells' rows, and the requested rows read in the owners' blocks) -> edges.  No event between the
   // devices: the blocks of ids are inputs, complete before the call (the contract of every device entry).
   return multi_post(m, [m, st, N, k, cap, P, rpr](int r) -> int {
     const int64_t n = st->bd[r + 1] - st->bd[r], n_ext = n + (int64_t)P * cap, b = st->bd[r];
     gficf_ctx* c = m->ctx[r];
     int q = gficf_jaccard_halo_plan_device(c, st->idx[r], n, k, st->lds[r], N, b, P, rpr, cap, st->ws[r], st->req[r]);
-    if (!q) q = gficf_jaccard_halo_serve_ingest_device(c, st->idx[r], n, k, st->lds[r], N, b, P, rpr, cap, st->ws[r], st->req[r], nullptr, 0, nullptr, st->table[r], st->l2g[r]);
-    if (!q) q = gficf_jaccard_halo_ingest_slots_peer_device(c, st->idx[r], n, k, st->lds[r], N, b, P, rpr, cap, st->ws[r], st->req[r], st->idx.data(), st->lds.data(), st->table[r], st->l2g[r]);
+    if (!q) q = gficf_jaccard_halo_ingest_peer_device(c, st->idx[r], n, k, st->lds[r], N, b, P, rpr, cap, st->ws[r], st->req[r], st->idx.data(), st->lds.data(), st->table[r], st->l2g[r]);
     if (!q && n > 0) {
       const size_t ne = (size_t)n * (size_t)k;
       q = gficf_jaccard_edges_mapped_device(c, st->table[r], n_ext, k, n, b, st->l2g[r], st->out[r], st->out[r] + ne, st->out[r] + 2 * ne, nullptr);

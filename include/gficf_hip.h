@@ -238,12 +238,13 @@ int gficf_jaccard_halo_serve_ingest_device(gficf_ctx* ctx, const int32_t* d_idx,
 int gficf_jaccard_halo_ingest_slots_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
                                            int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
                                            const int32_t* d_rows_in, int32_t* d_table, int32_t* d_l2g);
-/* The slots' rows with NO exchange (one process whose devices map each other's memory, see gficf_multi_jaccard_halo_device): the row
- * of every requested id is read where it lies — d_peer_idx[o]: owner o's block of global ids, a device pointer THIS device can
- * dereference ((k, peer_ld[o]) column-major; blocks of equal pitch rows_per_rank; both arrays are host arrays of P <= 16 entries). */
-int gficf_jaccard_halo_ingest_slots_peer_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
-                                                int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
-                                                const int32_t* const* d_peer_idx, const int64_t* peer_ld, int32_t* d_table, int32_t* d_l2g);
+/* The whole table of the sub-problem with NO exchange, in one launch behind the plan (one process whose devices map each other's
+ * memory, see gficf_multi_jaccard_halo_device): the own cells' rows, and the row of every requested id read where it lies —
+ * d_peer_idx[o]: owner o's block of global ids, a device pointer THIS device can dereference ((k, peer_ld[o]) column-major;
+ * blocks of equal pitch rows_per_rank; both arrays are host arrays of P <= 16 entries). */
+int gficf_jaccard_halo_ingest_peer_device(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_local, int k, int64_t ld, int64_t N_total,
+                                          int64_t cell_begin, int P, int64_t rows_per_rank, int cap, const void* d_ws, const int32_t* d_req_out,
+                                          const int32_t* const* d_peer_idx, const int64_t* peer_ld, int32_t* d_table, int32_t* d_l2g);
 int gficf_jaccard_edges_mapped_device(gficf_ctx* ctx, const int32_t* d_table, int64_t n_ext, int k, int64_t n_cells, int64_t src_offset,
                                       const int32_t* d_l2g, double* d_src, double* d_dst, double* d_w, int32_t* d_u);
 
@@ -443,8 +444,8 @@ int gficf_multi_jaccard_device(gficf_multi* m, const void* const* d_idx, int idx
  * order): NOTHING is exchanged.  Every device plans the rows its block names outside (gficf_jaccard_halo_plan_device), builds the
  * table of its own sub-problem — its own cells' rows from its block, the requested rows READ WHERE THEY LIE, in the owners' blocks
  * of ids, through the peer mapping (needs peer access between every pair of devices; at most 16 devices; int32 ids; k <= 64) —
- * and the edges of its block: four launches per device, no collective, no copy, no event between devices beyond "the inputs are
- * complete".  Per device r: d_ws[r] gficf_jaccard_halo_workspace_bytes(N, P) bytes ZEROED ONCE by the caller, d_req[r] P * cap
+ * and the edges of its block: four launches per device (mark, rank + list, table, edges), no collective, no copy, no event between
+ * devices.  Per device r: d_ws[r] gficf_jaccard_halo_workspace_bytes(N, P) bytes ZEROED ONCE by the caller, d_req[r] P * cap
  * int32, d_table[r] (n_r + P * cap) x gficf_jaccard_row_words(n_r + P * cap, k) int32, d_l2g[r] n_r + P * cap int32, d_out[r] as
  * in gficf_multi_jaccard_device.  A block that names more than cap rows of one owner raises GFICF_ERR_CAPACITY from
  * gficf_multi_sync (ids without locality: use gficf_multi_jaccard_device).  The blocks of ids must stay unchanged until the step has

@@ -128,7 +128,21 @@ for P in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
                 ops.jaccard_edges_mapped(tab2, n_ext, k, nl, b, l2g, out, None)
             h["chain_ms"] = t_ms(chain)
             want, _ = __import__("oracle").jaccard_cells(mat, b, b + 512, nthreads=os.cpu_count() or 1)
-            h["checked_vs_oracle"] = bool(np.array_equal(out[:, :512 * k].cpu().numpy().T, want))
+            out_halo = out[:, :512 * k].cpu().numpy().T.copy()
+            out.zero_()
+            # the peer halo form (gficf_multi_jaccard_halo_device): nothing exchanged — the whole table in ONE launch behind the plan, the rows
+            # named outside read in the owners' blocks of ids (here: all on this GPU; over xGMI one dependent remote read more)
+            owners = [torch.from_numpy(np.ascontiguousarray(mat[o * rpr:min(N, (o + 1) * rpr)].T)).cuda() for o in range(P)]
+            tab3, l2g3 = torch.zeros_like(tab2), torch.zeros_like(l2g)
+            h["peer_ingest_us"] = 1e3 * t_ms(lambda: ops.halo_ingest_peer(idx, nl, k, N, b, P, rpr, cap, ws, req_out, owners, tab3, l2g3))
+            def peer_chain():
+                ops.halo_plan(idx, nl, k, N, b, P, rpr, cap, ws, req_out)
+                ops.halo_ingest_peer(idx, nl, k, N, b, P, rpr, cap, ws, req_out, owners, tab3, l2g3)
+                ops.jaccard_edges_mapped(tab3, n_ext, k, nl, b, l2g3, out, None)
+            h["peer_chain_us"] = 1e3 * t_ms(peer_chain)
+            h["peer_checked_vs_oracle"] = bool(np.array_equal(out[:, :512 * k].cpu().numpy().T, want))
+            del owners, tab3, l2g3
+            h["checked_vs_oracle"] = bool(np.array_equal(out_halo, want))
         res[f"halo_{ids}"] = h
         ops.sync()
         del table, out, idx

@@ -39,8 +39,12 @@ for r in rows:
     for ids in ("spatial", "permuted"):
         for form in ("allgather", "peer", "halo", "peer halo"):
             d = r.get(f"{form}_{ids}") if form != "peer halo" else r.get(f"halo_{ids}")
-            if form == "peer halo" and (not d or not d.get("fits") or "slots_ms" not in d):
-                continue
+            if form == "peer halo":
+                if not d or not d.get("fits") or "peer_ingest_us" not in d:
+                    continue
+                d = {"plan_ms": d["plan_ms"], "table_ms": d["peer_ingest_us"] * 1e-3, "edges_ms": d["edges_ms"], "table_row_bytes": d["table_row_bytes"],
+                     "rows_named_outside": d["rows_named_outside"], "bytes_received": 0, "fits": True}
+                d["compute_ms"] = d["plan_ms"] + d["table_ms"] + d["edges_ms"]
             if form == "peer":
                 ag = r.get(f"allgather_{ids}")
                 if not ag:
