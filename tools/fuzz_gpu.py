@@ -5,7 +5,7 @@ Jaccard: random shapes (N 1 .. 6000, now and then 131 000 .. 180 000 for the wid
 matrix (windowed scrambled / windowed in order / uniform / few distinct ids = rows full of duplicates and self-references /
 a window of 2), int32 or float64 input, through every entry that returns edges: the `.Call` entry (reference matrix), the
 compact counts + host expansion, the filtered call-site form, the serial `jaccard_coeff` entry, the device-resident path
-with counts, the distinct-ids mode (the deferred GFICF_ERR_DUPLICATE_IDS must come exactly when a row repeats an id), and the
+with counts, the single-process multi-device steps (peer copies; halo with nothing exchanged), the distinct-ids mode (the deferred GFICF_ERR_DUPLICATE_IDS must come exactly when a row repeats an id), and the
 strict truncation mode on matrices with non-integer doubles.  Bit-exact or the run stops.
 GF-ICF: random CSC matrices (G 1 .. 30 000, N 1 .. 3000; densities; empty cells, empty genes, explicit zeros, cells beyond
 2048 entries), random filter bounds, supplied weights, icf types and norms; structure exact, values within 1e-12 (gficf() as the
@@ -75,7 +75,9 @@ def jaccard_case(case):
     want, wu = oracle.jaccard(m, nthreads=NT)
     as_f64 = rng.random() < 0.3
     mat = m.astype(np.float64) if as_f64 else m
-    entry = int(rng.integers(0, 7)) if not big else int(rng.choice([0, 1, 2, 6]))
+    entry = int(rng.integers(0, 9)) if not big else int(rng.choice([0, 1, 2, 6, 7, 8]))
+    if entry == 8 and k > 64:
+        entry = 7
     tag = f"jaccard case {case}: N={N} k={k} kind={kind} f64={as_f64} entry={entry}"
     if entry == 0:
         got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
@@ -134,6 +136,57 @@ def jaccard_case(case):
         if not raised:
             assert np.array_equal(rmat.cpu().numpy().T, want), tag
         bump("jaccard distinct-ids mode (error iff a row repeats an id)")
+    elif entry in (7, 8):
+        # the single-process multi-device steps on P contexts of the one GPU: peer copies of table slices (any ids), and the halo step
+        # with nothing exchanged (int32, k <= 64: CAPACITY exactly when a block names more rows of one owner than there are slots)
+        import torch
+
+        from gficf_amd.api import MultiContext
+
+        P = int(rng.integers(1, 5))
+        mc = MultiContext([0] * P)
+        try:
+            bd = mc.cell_blocks(N)
+            if entry == 7:
+                rw = gficf_amd.HipOps.row_words(N, k)
+                blocks = [torch.from_numpy(np.ascontiguousarray(mat[bd[r]:bd[r + 1]].T)).cuda() for r in range(P)]
+                tables = [torch.zeros((N, rw), dtype=torch.int32, device="cuda") for _ in range(P)]
+                outs = [torch.full((3, (bd[r + 1] - bd[r]) * k), -7.0, dtype=torch.float64, device="cuda") for r in range(P)]
+                torch.cuda.synchronize()
+                for _ in range(2):
+                    mc.jaccard_device(blocks, N, k, tables, outs)
+                mc.sync()
+                assert np.array_equal(torch.cat(outs, dim=1).cpu().numpy().T, want), tag + f" P={P}"
+                bump("multi-device step, peer copies")
+            else:
+                cap = int(rng.choice([1, 3, 64, 500])) if rng.random() < 0.5 else None
+                bufs = mc.halo_buffers(N, k, cap)
+                cap = bufs["cap"]
+                rpr = -(-N // P)
+                over = False
+                for r in range(P):
+                    ids = np.unique(m[bd[r]:bd[r + 1]])
+                    ids = ids[(ids >= 1) & (ids <= N)]
+                    own = (ids - 1) // rpr
+                    for o in range(P):
+                        if o != r and int((own == o).sum()) > cap:
+                            over = True
+                blocks = [torch.from_numpy(np.ascontiguousarray(m[bd[r]:bd[r + 1]].T)).cuda() for r in range(P)]
+                torch.cuda.synchronize()
+                raised = False
+                try:
+                    for _ in range(2):
+                        mc.jaccard_halo_device(blocks, N, k, bufs)
+                    mc.sync()
+                except gficf_amd.GficfError as ex:
+                    assert ex.status == "GFICF_ERR_CAPACITY", tag + " " + ex.status
+                    raised = True
+                assert raised == over, tag + f" P={P} cap={cap} raised={raised} over={over}"
+                if not raised:
+                    assert np.array_equal(torch.cat(bufs["out"], dim=1).cpu().numpy().T, want), tag + f" P={P} cap={cap}"
+                bump("multi-device halo step, nothing exchanged" + (" (capacity error)" if raised else ""))
+        finally:
+            mc.close()
     else:
         md = m.astype(np.float64)
         frac = synth.rand_unit(case + 9, np.arange(N * k)).reshape(N, k)
