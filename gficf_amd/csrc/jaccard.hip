@@ -156,7 +156,9 @@ __device__ inline void planar_row_build(const uint32_t* ids, int k, bool dupflag
 
 // Four rows at a time (the LDS round trips of the three phases are shared by the four): ids[r] = row r's slot ids, prow[r] its
 // 32-word scratch, n = rows that exist (1..4); dup bit r of dupmask = row r's duplicate flag.
-__device__ inline void planar_rows_build4(const uint32_t* const (&ids)[4], int n, int k, uint32_t dupmask, uint32_t (*prow)[32], int lane) {
+// bm (may be null): bm[r] = the 64-bit mask of row r's slots whose id is >= 65536 — the bit-16 bitmap of the row's compact part.
+__device__ inline void planar_rows_build4(const uint32_t* const (&ids)[4], int n, int k, uint32_t dupmask, uint32_t (*prow)[32], int lane,
+                                          uint32_t (*bm)[2] = nullptr) {
   const bool valid = lane < k;
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t id[4];
@@ -182,6 +184,11 @@ __device__ inline void planar_rows_build4(const uint32_t* const (&ids)[4], int n
   {
     const int gsel = lane == 0 ? g0[0] : lane == 1 ? g0[1] : lane == 2 ? g0[2] : g0[3];
     if (lane < 4) prow[lane][31] = (uint32_t)gsel | (((dupmask >> lane) & 1u) ? ROW_DUP_FLAG : 0u);
+    if (bm != nullptr && lane < 4) {
+      const unsigned long long msel = lane == 0 ? m1[0] : lane == 1 ? m1[1] : lane == 2 ? m1[2] : m1[3];
+      bm[lane][0] = (uint32_t)msel;
+      bm[lane][1] = (uint32_t)(msel >> 32);
+    }
   }
   wave_lds_fence_early();
 }
@@ -314,9 +321,14 @@ __global__ __launch_bounds__(256, HALO ? 4 : (DUAL && !SCAN) ? GFICF_INGEST_DUAL
   // dual rows: a wave's scratch for the planar part of ONE row (a whole tile of them would cost 8 KB of LDS: six workgroups per CU
   // instead of nine, 1536 resident ones for the 1563 tiles of 100 k cells — a second round for the last 27: 26 us against 13)
   __shared__ uint32_t prow[DUAL ? 16 : 1][DUAL ? 32 : 1];     // (four rows in flight per wave)
+  // dual rows: the planar build holds every row's "id >= 65536" mask as a ballot — the two bitmap words of the compact part, which
+  // the writers below would otherwise gather bit by bit from 60 slots (the longest chain of the kernel, on one thread in four)
+  __shared__ uint32_t bmap[DUAL ? ROWS + 3 : 1][2];
   __shared__ const int32_t* s_peer_idx[HALO ? GFICF_HALO_MAX_PEERS : 1];
   __shared__ int64_t s_peer_ld[HALO ? GFICF_HALO_MAX_PEERS : 1];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave number as a scalar: a slot index j = wave + 4 m is then uniform and the 64-bit products j * ld stay in scalar registers —
+  // as a vector value they cost two registers per load in flight, 32 of the 64-slot variants' 96, and a whole workgroup per CU)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // HALO: the launch ingests rows [row_begin, row_end) of the sub-problem (n_rows = row_end); its LAST serve_blocks workgroups do the
   // owner-side serve step instead (the rows other ranks asked of this one: independent of the ingest, one launch saved per step)
   int64_t row_first = 0;
@@ -438,11 +450,12 @@ __global__ __launch_bounds__(256, HALO ? 4 : (DUAL && !SCAN) ? GFICF_INGEST_DUAL
         uint32_t dm = 0;
         if (SCAN)
           for (int r = 0; r < n; ++r) dm |= (dup[r0 + r] != 0u ? 1u : 0u) << r;
-        planar_rows_build4(ids, n, k, dm, &prow[wave * 4], lane);
+        planar_rows_build4(ids, n, k, dm, &prow[wave * 4], lane, &bmap[r0]);
         const int r = lane >> 4, w2 = (lane & 15) * 2;                                   // 16 lanes per row, 8 B each
         if (r < n) *reinterpret_cast<uint2*>(table + (row0 + r0 + r) * PITCH + ROWW + w2) = make_uint2(prow[wave * 4 + r][w2], prow[wave * 4 + r][w2 + 1]);
         wave_lds_fence_early();
       }
+      __syncthreads();                                      // (the masks are read by whichever thread writes the row's last words)
     }
     const int n_out4 = (int)rows_here * (ROWW / 4);
     for (int e = tid; e < n_out4; e += 256) {
@@ -458,6 +471,9 @@ __global__ __launch_bounds__(256, HALO ? 4 : (DUAL && !SCAN) ? GFICF_INGEST_DUAL
           if (j == 0 && dup[rr]) x |= ROW_DUP_FLAG;
         } else if (j < CFmt<KPAD>::HIW) {
           x = scramble16(tile[rr][2 * j] & 0xFFFFu) | (scramble16(tile[rr][2 * j + 1] & 0xFFFFu) << 16);
+        } else if (DUAL) {
+          x = bmap[rr][j - CFmt<KPAD>::HIW];
+          if (j == ROWW - 1 && dup[rr]) x |= ROW_DUP_FLAG;
         } else {
           const int b0 = (j - CFmt<KPAD>::HIW) * 32;
           x = 0;
