@@ -728,6 +728,7 @@ def run_peer_leg(args, timeout_s=420.0):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL and peer mappings across processes need on this driver (before any HIP call)
     if args.traffic_child:
         return traffic_child(args)
     if args.peer_child:
