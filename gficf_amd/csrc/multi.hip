@@ -363,6 +363,14 @@ int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, in
 
 // ------------------------------------------------------------------------------------------------ device-resident step
 // body(r) for every device slot r on the slot's persistent thread; returns when all are done.  First failing slot wins.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
+
 static int multi_workers_start(gficf_multi* m) {
   if (!m->workers.empty() || m->ndev == 1) return GFICF_OK;
   try {
@@ -373,7 +381,7 @@ static int multi_workers_start(gficf_multi* m) {
         (void)hipSetDevice(m->dev[r]);
         unsigned taken = 0;
         for (;;) {
-          for (int spin = 0; spin < 4000 && w->posted.load(std::memory_order_acquire) == taken; ++spin) __builtin_ia32_pause();
+          for (int spin = 0; spin < 4000 && w->posted.load(std::memory_order_acquire) == taken; ++spin) cpu_relax();
           std::shared_ptr<const std::function<int(int)>> job;
           {
             std::unique_lock<std::mutex> lk(w->mu);
