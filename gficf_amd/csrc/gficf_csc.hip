@@ -911,6 +911,19 @@ static int launch_count(gficf_ctx* ctx, int64_t G, const int32_t* d_rowidx, cons
     int per_cu = (int)((160 * 1024) / (lds + 256));
     per_cu = per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu;
     if (blocks > (int64_t)ctx->num_cus * per_cu) blocks = (int64_t)ctx->num_cus * per_cu;
+    {
+      // every workgroup flushes its G counters as a row of the partial table (written here, read by the row sum): on a small input
+      // that traffic exceeds the input's own (config 2: 512 rows x 80 KB against 57 MB of row indices) — bounded to a quarter of the
+      // bytes read: configs 1 / 2 pass 25.5 -> 24.0 / 115.5 -> 108.9 us, config 3 and up unchanged (tools/lab/count_flush_probe.py;
+      // GFICF_COUNT_FLUSH_RATIO: the A/B hook, 0 = no bound; read per call)
+      const char* const e = getenv("GFICF_COUNT_FLUSH_RATIO");
+      const int64_t ratio = e ? atoll(e) : 4;
+      if (ratio > 0) {
+        int64_t cap = nnz / (ratio * Gp);
+        if (cap < 32) cap = 32;
+        if (blocks > cap) blocks = cap;
+      }
+    }
     static std::atomic<bool> attr_set[64];
     if (!attr_set[ctx->device & 63]) {
       const int mx = CNT_LDS_MAX_G * (int)sizeof(uint32_t);
