@@ -18,7 +18,8 @@ STATUS_NAMES = {
     4: "GFICF_ERR_NO_DEVICE", 5: "GFICF_ERR_HIP", 6: "GFICF_ERR_UNSUPPORTED", 7: "GFICF_ERR_CAPACITY",
     8: "GFICF_ERR_BAD_VALUE", 9: "GFICF_ERR_EXPLICIT_ZEROS", 10: "GFICF_ERR_DUPLICATE_IDS",
 }
-JACCARD_MAX_K = 256
+JACCARD_MAX_K = 256          # the fast kernels; beyond it the exact sorted-row path, up to JACCARD_MAX_K_EXACT
+JACCARD_MAX_K_EXACT = 65535
 KNN_MAX_K = 128
 KNN_METRICS = {"manhattan": 0, "euclidean": 1, "cosine": 2, "correlation": 3}
 

@@ -753,7 +753,7 @@ class HipOps:
     def kpad(k: int) -> int:
         kp = _lib.load().gficf_jaccard_kpad(int(k))
         if kp < 0:
-            raise GficfError(6, f"k = {k} outside [0, {_lib.JACCARD_MAX_K}]")
+            raise GficfError(6, f"k = {k} outside [0, {_lib.JACCARD_MAX_K_EXACT}]")
         return kp
 
     @staticmethod
@@ -762,7 +762,7 @@ class HipOps:
         library stores the rows compactly (fewer than 2^17 cells).  Tables are (N, row_words) int32."""
         rw = _lib.load().gficf_jaccard_row_words(int(N_total), int(k))
         if rw < 0:
-            raise GficfError(6, f"k = {k} outside [0, {_lib.JACCARD_MAX_K}] or N_total = {N_total} beyond int32 ids")
+            raise GficfError(6, f"k = {k} outside [0, {_lib.JACCARD_MAX_K_EXACT}] or N_total = {N_total} beyond int32 ids")
         return rw
 
     def jaccard_ingest(self, idx_cm, n_rows: int, k: int, N_total: int, table_rows):

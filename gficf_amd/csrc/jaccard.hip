@@ -79,6 +79,7 @@ struct TableFmt {
   bool compact;
   bool dual;         // compact rows + a second, "planar" copy of the ids for the gathers of k_jaccard_edges_bits (below)
   int row_words;     // row PITCH of the table in 32-bit words
+  bool sorted;       // k > GFICF_JACCARD_MAX_K: slot-order ids + the same ids ascending (jaccard_sorted.h)
 };
 
 // ---- dual rows (round 4): 32 < k <= 55 and N <= 131070.  The general edge kernel is bound by its probe arithmetic at these row
@@ -113,6 +114,13 @@ inline bool compact_enabled() {
 
 inline TableFmt table_fmt(int64_t N_total, int k) {
   TableFmt f;
+  f.sorted = k > GFICF_JACCARD_MAX_K;
+  if (f.sorted) {                                            // (a function of k alone)
+    f.kpad = 2 * ((k + 63) & ~63);
+    f.compact = f.dual = false;
+    f.row_words = f.kpad;
+    return f;
+  }
   f.kpad = kpad_for(k);
   static const bool force_big = getenv("GFICF_JACCARD_FORCE_BIG") != nullptr;     // test hook of the 64-bit kernel variant: wide rows
   f.compact = compact_enabled() && !force_big && N_total < (1ll << 17) && f.kpad >= 32 && k <= f.kpad - f.kpad / 16;
@@ -1842,6 +1850,8 @@ static_assert(std::is_same<decltype(&k_jaccard_edges<32, false, false, OUT_RMAT,
               std::is_same<decltype(&k_jaccard_edges_bits<7, OUT_RMAT, false>), EdgeKernFn>::value,
               "the edge kernels' parameter list and EdgeKernArgs differ: edge_kernel_dup_status() would read a wrong slot");
 
+#include "jaccard_sorted.h"
+
 // ------------------------------------------------------------------ edge filter (N1)
 // The caller's next line, relations[relations[,3] > 0, ] (reference R/clustCells.R:66), on the
 // device: per-cell count of edges with u > 0 -> exclusive scan -> ordered compacted write.
@@ -2046,6 +2056,7 @@ __global__ __launch_bounds__(256) void k_unpack_rows(const uint32_t* __restrict_
 template <typename T>
 int launch_ingest(gficf_ctx* ctx, const T* d_idx, int64_t n_rows, int k, int64_t ld, int64_t N_total,
                   uint32_t* table, int zero_ok = 0) {
+  if (sorted_fmt(k)) return launch_ingest_sorted<T>(ctx, d_idx, n_rows, k, ld, N_total, table, zero_ok);
   const TableFmt f = table_fmt(N_total, k);
   const int64_t cap = (int64_t)ctx->num_cus * 8;
   const int64_t tiles2 = gficf_ceil_div(n_rows, INGEST2_ROWS);
@@ -2235,6 +2246,7 @@ int launch_edges(gficf_ctx* ctx, const uint32_t* table, int64_t N, int k, int64_
 }
 
 int launch_edges_k(gficf_ctx* ctx, const uint32_t* t, int64_t N, int k, int64_t cb, int64_t ce, EdgeOut o) {
+  if (sorted_fmt(k)) return launch_edges_sorted(ctx, t, N, k, cb, ce, o);      // exact for every row: no flags, no deferred report
   if (const char* e = getenv("GFICF_JACCARD_XCD")) o.xcd = atoi(e) != 0 ? 1u : 0u;     // A/B switch, read per call
   if (ctx->jaccard_assume_distinct) o.dup_status = ctx->d_status;                      // the table may carry no duplicate flags
   switch (kpad_for(k)) {
@@ -2249,9 +2261,9 @@ int launch_edges_k(gficf_ctx* ctx, const uint32_t* t, int64_t N, int k, int64_t 
 int check_nk(int64_t N, int k) {
   if (N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N = %lld is negative", (long long)N);
   if (k < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "k = %d is negative", k);
-  if (k > GFICF_JACCARD_MAX_K)
-    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d neighbours per cell: this build handles at most GFICF_JACCARD_MAX_K = %d (the reference has no limit)", k,
-               GFICF_JACCARD_MAX_K);
+  if (k > SORTED_MAX_K)
+    GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d neighbours per cell: this build handles at most %d (uint16 intersection counts; the reference has no limit)", k,
+               SORTED_MAX_K);
   if (N > 0x7FFFFFFFll) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "N = %lld exceeds int32 ids", (long long)N);
   return GFICF_OK;
 }
@@ -2280,10 +2292,10 @@ static int distinct_first(gficf_ctx* ctx, F&& body) {
 
 extern "C" {
 
-int gficf_jaccard_kpad(int k) { return (k < 0 || k > GFICF_JACCARD_MAX_K) ? -1 : kpad_for(k); }
+int gficf_jaccard_kpad(int k) { return (k < 0 || k > SORTED_MAX_K) ? -1 : sorted_fmt(k) ? 2 * sorted_kp(k) : kpad_for(k); }
 
 int gficf_jaccard_row_words(int64_t N_total, int k) {
-  if (N_total < 0 || N_total > 0x7FFFFFFFll || k < 0 || k > GFICF_JACCARD_MAX_K) return -1;
+  if (N_total < 0 || N_total > 0x7FFFFFFFll || k < 0 || k > SORTED_MAX_K) return -1;
   return table_fmt(N_total, k).row_words;
 }
 
@@ -2477,6 +2489,8 @@ static int gficf_jaccard_host_body(gficf_ctx* ctx, const void* idx, int idx_is_f
   }
   if (trunc_path) {
     if (!rmat) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
+    if (k > GFICF_JACCARD_MAX_K)
+      GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "non-integer ids (GFICF_HIP_TRUNCATE_IDS) with k = %d: the truncating kernel covers k <= %d", k, GFICF_JACCARD_MAX_K);
     void* d_idx = nullptr;
     double* d_rmat = nullptr;
     hipError_t e = gficf_pool_get(ctx, 0, sizeof(double) * (size_t)ld * (size_t)k, &d_idx);
@@ -2561,12 +2575,12 @@ static int gficf_jaccard_counts_host_body(gficf_ctx* ctx, const void* idx, int i
  * that validated the ids). */
 int gficf_jaccard_expand_host(const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, const uint16_t* u, double* rmat,
                               int n_threads) {
-  if (N < 0 || k < 0 || k > GFICF_JACCARD_MAX_K) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N or k out of range");
+  if (N < 0 || k < 0 || k > SORTED_MAX_K) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N or k out of range");
   const int64_t E = N * (int64_t)k;
   if (E == 0) return GFICF_OK;
   if (!idx || !u || !rmat) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
   if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
-  double lut[GFICF_JACCARD_MAX_K + 1];
+  std::vector<double> lut((size_t)k + 1);
   for (int v = 0; v <= k; ++v) lut[v] = (double)v / (2.0 * (double)k - (double)v);     // reference :51
   unsigned hw = std::thread::hardware_concurrency();
   int64_t nt = n_threads > 0 ? n_threads : (hw ? (hw > 16 ? 16 : hw) : 4);
@@ -2598,7 +2612,8 @@ int gficf_jaccard_expand_host(const void* idx, int idx_is_f64, int64_t N, int k,
 }
 
 int gficf_jaccard_packed_words(int64_t N_total, int k) {
-  if (N_total < 0 || N_total > 0x7FFFFFFFll || k < 0 || k > GFICF_JACCARD_MAX_K) return -1;
+  if (N_total < 0 || N_total > 0x7FFFFFFFll || k < 0 || k > SORTED_MAX_K) return -1;
+  if (sorted_fmt(k)) return table_fmt(N_total, k).row_words;        // sorted rows travel as they are
   return packed_words(N_total, k);
 }
 
@@ -2610,6 +2625,11 @@ int gficf_jaccard_pack_rows_device(gficf_ctx* ctx, const int32_t* d_table_rows, 
   if (n_rows < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative n_rows");
   if (n_rows == 0 || k == 0) return GFICF_OK;
   if (!d_table_rows || !d_packed) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (sorted_fmt(k)) {
+    GFICF_HIP_CHECK(hipMemcpyAsync(d_packed, d_table_rows, sizeof(uint32_t) * (size_t)n_rows * (size_t)table_fmt(N_total, k).row_words,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    return GFICF_OK;
+  }
   int64_t blocks = gficf_ceil_div(n_rows, PACK_ROWS);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
   const TableFmt f = table_fmt(N_total, k);
@@ -2628,6 +2648,11 @@ int gficf_jaccard_unpack_rows_device(gficf_ctx* ctx, const uint32_t* d_packed, i
   if (n_rows < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative n_rows");
   if (n_rows == 0 || k == 0) return GFICF_OK;
   if (!d_table_rows || !d_packed) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
+  if (sorted_fmt(k)) {
+    GFICF_HIP_CHECK(hipMemcpyAsync(d_table_rows, d_packed, sizeof(uint32_t) * (size_t)n_rows * (size_t)table_fmt(N_total, k).row_words,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    return GFICF_OK;
+  }
   const int wpr = packed_words(N_total, k);
   int64_t blocks = gficf_ceil_div(n_rows, UNPACK_ROWS);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
@@ -2666,6 +2691,12 @@ static int edges_filtered(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int
   // 3. ordered compacted write
   int64_t blocks = gficf_ceil_div(n_cells, 4);
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+  if (sorted_fmt(k)) {
+    hipLaunchKernelGGL(k_edge_write_sorted, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, t, d_u_ws, k, cell_begin, n_cells, d_cell_ptr, d_from,
+                       d_to, d_weight, sorted_kp(k));
+    GFICF_HIP_CHECK(hipGetLastError());
+    return GFICF_OK;
+  }
 #define LAUNCH_EW(KP, CM)                                                                                               \
   hipLaunchKernelGGL((k_edge_write<KP, CM>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, t, d_u_ws, k, cell_begin, \
                      n_cells, d_cell_ptr, d_from, d_to, d_weight, pitch)

@@ -283,7 +283,7 @@ int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, in
   { const int drc = multi_drain(m); if (drc) return drc; }                     // device-resident steps still being enqueued come first
   if (N < 0 || k < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N = %lld or k = %d is negative", (long long)N, k);
   const int roww = gficf_jaccard_row_words(N, k);
-  if (roww < 0) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d exceeds GFICF_JACCARD_MAX_K = %d or N = %lld exceeds int32 ids", k, GFICF_JACCARD_MAX_K, (long long)N);
+  if (roww < 0) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d exceeds GFICF_JACCARD_MAX_K_EXACT = %d or N = %lld exceeds int32 ids", k, GFICF_JACCARD_MAX_K_EXACT, (long long)N);
   if (print_output) gficf_print(m->ctx[0], "Running Parallell Jaccard Coefficient Estimation...\n");  // reference :63
   const int64_t E = N * (int64_t)k;
   if (E > 0) {
@@ -519,7 +519,7 @@ int gficf_multi_jaccard_device(gficf_multi* m, const void* const* d_idx, int idx
   if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");
   if (N < 0 || k < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N = %lld or k = %d is negative", (long long)N, k);
   const int roww = gficf_jaccard_row_words(N, k);
-  if (roww < 0) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d exceeds GFICF_JACCARD_MAX_K = %d or N = %lld exceeds int32 ids", k, GFICF_JACCARD_MAX_K, (long long)N);
+  if (roww < 0) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "k = %d exceeds GFICF_JACCARD_MAX_K_EXACT = %d or N = %lld exceeds int32 ids", k, GFICF_JACCARD_MAX_K_EXACT, (long long)N);
   if (N == 0 || k == 0) return GFICF_OK;
   if (!d_idx || !d_table || !d_out) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer array");
   const int P = m->ndev;

@@ -121,6 +121,12 @@ class JaccardShard:
     overwritten by the step after next; call :meth:`wait` to make the caller's current stream wait for the
     latest step before reading it, and :meth:`release` once it has been read (the step that reuses the buffer
     then waits for that point instead of racing the reader).
+
+    With ONE rank there is no exchange to hide, and what is left to overlap (a 6 us ingest under the tail of a 41 us edge kernel
+    that already fills every CU) is worth less than the stream hops cost: measured 50.8 G edges/s against 63.4 in order at
+    100 k x 30 (profiles/r04_bench.json; the pipelined step is ~10 runtime calls and host-bound).  So ``pipeline=True`` on one rank
+    RUNS IN ORDER on the caller's stream (``pipeline_in_order`` is set; wait / release are no-ops, the returned buffer is valid in
+    stream order); ``pipeline="force"`` keeps the two-stream machinery (tests of that machinery on a one-GPU box).
     """
 
     def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False,
@@ -142,6 +148,9 @@ class JaccardShard:
         self.b, self.e = shard_bounds(self.N, self.world, self.rank)
         self.n_local = self.e - self.b
         self.pipeline = bool(pipeline) and device is not None and torch.device(device).type == "cuda"
+        self.pipeline_in_order = self.pipeline and self.world == 1 and pipeline != "force"
+        if self.pipeline_in_order:
+            self.pipeline = False
         nbuf = 2 if self.pipeline else 1
         # full table(s), padded to world*rpr rows so that every rank contributes an equal block
         self.tables = [torch.zeros((self.world * self.rpr, self.row_words), dtype=torch.int32, device=device) for _ in range(nbuf)]

@@ -39,7 +39,7 @@ typedef enum gficf_status {
   GFICF_ERR_BAD_CSC = 3,       /* rowidx outside [0, G), colptr not monotone               */
   GFICF_ERR_NO_DEVICE = 4,     /* no HIP device / device index out of range                */
   GFICF_ERR_HIP = 5,           /* a HIP runtime call failed; message has hipGetErrorString */
-  GFICF_ERR_UNSUPPORTED = 6,   /* k > GFICF_JACCARD_MAX_K, table too large for the kernel,
+  GFICF_ERR_UNSUPPORTED = 6,   /* k > GFICF_JACCARD_MAX_K_EXACT, table too large for the kernel,
                                   edge weights too large for the Louvain fixed point ...   */
   GFICF_ERR_CAPACITY = 7,      /* caller-provided output buffer too small; halo request
                                   slots of the sharded Jaccard build too few (deferred)    */
@@ -53,7 +53,12 @@ typedef enum gficf_status {
                                   outputs and call gficf_csc_exact_device                  */
 } gficf_status;
 
+/* k <= GFICF_JACCARD_MAX_K neighbours per cell take the hash-set / bit-set edge kernels; the reference's loop has no limit
+ * (src/rcpp_parallel_jaccard_coeff.cpp:26-36), so beyond it every Jaccard entry switches to an exact sort + search path on
+ * "sorted" table rows (csrc/jaccard_sorted.h: rows sorted once at ingest, an edge is k binary searches; multiset / set
+ * semantics as the reference's; slower per edge), up to GFICF_JACCARD_MAX_K_EXACT (the uint16 intersection counts). */
 #define GFICF_JACCARD_MAX_K 256
+#define GFICF_JACCARD_MAX_K_EXACT 65535
 
 typedef struct gficf_ctx gficf_ctx;  /* one per (thread, device): stream, workspace, status */
 
@@ -107,8 +112,8 @@ int gficf_jaccard_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t 
  * A matrix whose doubles are all integer-valued takes the ordinary kernels; one with non-integer values an exact
  * all-pairs kernel on the doubles (one wave per cell; not tuned: the case is a curiosity).  Applies to
  * gficf_jaccard_host on this context (the entry the .Call binds); the R glue turns it on with GFICF_HIP_TRUNCATE_IDS=1.
- * k is limited to GFICF_JACCARD_MAX_K = 256 neighbours per cell in every Jaccard entry (the reference has no limit;
- * clustcells() defaults to 15 and Phenograph to 30): beyond it the calls return GFICF_ERR_UNSUPPORTED and the message says so. */
+ * The truncating kernel covers k <= GFICF_JACCARD_MAX_K (a matrix WITH non-integer values and more neighbours per cell is
+ * GFICF_ERR_UNSUPPORTED); integer-valued ids have no such limit (see GFICF_JACCARD_MAX_K above). */
 int gficf_ctx_set_jaccard_options(gficf_ctx* ctx, int truncate_noninteger_ids);
 
 /* Rows of a kNN index matrix hold k DISTINCT ids — uwot / Annoy and the search of this library never return one twice — but
@@ -151,16 +156,17 @@ int gficf_jaccard_coeff_host(gficf_ctx* ctx, const void* idx, int idx_is_f64, in
  *   3. edges  : table + a block of cells -> that block's rows of rmat
  */
 
-/* Slots of a table row for a given k: 16, 32, 64, 128 or 256 (k rounded up). */
+/* Slots of a table row for a given k: 16, 32, 64, 128 or 256 (k rounded up); k > 256: 2 * (k rounded up to 64) — the row
+ * pitch of the sorted format (slot-order ids + the same ids ascending).  -1 beyond GFICF_JACCARD_MAX_K_EXACT. */
 int gficf_jaccard_kpad(int k);
 /* Row pitch of the table in 32-bit words, a function of (N_total, k) alone (every rank of a sharded build computes the
  * same): gficf_jaccard_kpad(k) words of 32-bit ids, or — for data sets of fewer than 2^17 cells, whose ids fit 17 bits,
  * and k <= kpad - kpad/16 (k = 30: 16 words = 64 B) — half of that: 16-bit low halves + one bitmap of high bits; for
  * 32 < k <= 55 and N_total <= 131070 (round 4) 64 words: that compact row plus a second copy of the ids regrouped for the
  * gathers of the bit-set edge kernel ("dual" rows; GFICF_JACCARD_DUAL=0 in the environment, read per call, keeps the plain
- * compact rows and the general kernel: an A/B switch — every caller of one table must see the same setting).  The row
- * layout is private to the library; callers only size and slice the table by this pitch.  A buffer of N * kpad words
- * always suffices. */
+ * compact rows and the general kernel: an A/B switch — every caller of one table must see the same setting); for
+ * k > GFICF_JACCARD_MAX_K gficf_jaccard_kpad(k) words (sorted rows).  The row layout is private to the library; callers
+ * only size and slice the table by this pitch.  A buffer of N * kpad words always suffices. */
 int gficf_jaccard_row_words(int64_t N_total, int k);
 
 /* d_idx: n_rows x k column-major (ld >= n_rows) device matrix holding the neighbour ids
@@ -174,7 +180,8 @@ int gficf_jaccard_ingest_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f6
 /* Transport form of table rows for step 2 (the all-gather is what bounds the N > 1 path): k ids of
  * ceil(log2(N_total+1)) bits each + the row's duplicate flag, bit-packed into
  * gficf_jaccard_packed_words(N_total, k) 32-bit words per row (76 B instead of 128 B at k = 30,
- * N_total = 800 k).  pack: table rows -> packed rows; unpack: the inverse (pads zeroed). */
+ * N_total = 800 k).  pack: table rows -> packed rows; unpack: the inverse (pads zeroed).  Sorted rows (k > 256) travel as
+ * they are: packed_words == row_words, pack / unpack are copies. */
 int gficf_jaccard_packed_words(int64_t N_total, int k);
 int gficf_jaccard_pack_rows_device(gficf_ctx* ctx, const int32_t* d_table_rows, int64_t n_rows, int k,
                                    int64_t N_total, uint32_t* d_packed);

@@ -34,7 +34,9 @@ def test_abi_version_and_kpad():
     assert L.gficf_hip_abi_version() == 5
     assert [L.gficf_jaccard_kpad(k) for k in (0, 1, 15, 16, 17, 30, 32, 33, 50, 64, 65, 128, 129, 256)] == \
         [16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 128, 128, 256, 256]
-    assert L.gficf_jaccard_kpad(257) == -1 and L.gficf_jaccard_kpad(-1) == -1
+    # k > 256: "sorted" rows (slot-order ids + the same ids ascending, each half padded to 64): kpad = row pitch = 2 * ceil64(k)
+    assert [L.gficf_jaccard_kpad(k) for k in (257, 300, 320, 321, 513, 65535)] == [640, 640, 640, 768, 1152, 131072]
+    assert L.gficf_jaccard_kpad(65536) == -1 and L.gficf_jaccard_kpad(-1) == -1
     # row pitch of the table: half the slots for data sets of fewer than 2^17 cells when k leaves room for the bitmap
     rw = L.gficf_jaccard_row_words
     # (32 < k <= 55 below 131071 cells: dual rows — the compact row and a planar copy for the bit-set edge kernel: 64 words)
@@ -42,7 +44,8 @@ def test_abi_version_and_kpad():
         [16, 16, 16, 16, 32, 32, 64, 64, 64, 32, 32, 64, 64, 64, 128, 128, 256, 256]
     assert rw(131070, 50) == 64 and rw(131071, 50) == 32
     assert rw(131071, 30) == 16 and rw(131072, 30) == 32 and rw(1000000, 30) == 32 and rw(1000000, 50) == 64
-    assert rw(-1, 30) == -1 and rw(100, 257) == -1
+    assert rw(-1, 30) == -1 and rw(100, 257) == 640 and rw(10**6, 513) == 1152 and rw(100, 65536) == -1
+    assert L.gficf_jaccard_packed_words(5000, 300) == 640           # sorted rows travel as they are
 
 
 def test_status_enum_matches_header():

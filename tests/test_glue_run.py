@@ -17,6 +17,10 @@ from tests.helpers import rmock
 
 @pytest.fixture(scope="module")
 def R():
+    import shutil
+
+    if not os.path.exists(rmock.SO) and shutil.which("gcc") is None:
+        pytest.skip("no gcc and no pre-built glue stand-in: nothing to execute")
     rt = rmock.RMock()
     yield rt
     rt.unload()
@@ -75,6 +79,24 @@ def test_dot_call_jaccard_entry_matches_the_oracle(R, as_double):
     assert "Running Parallell Jaccard Coefficient Estimation" in R.printed() and "Done" in R.printed()
     R.call("_gficf_rcpp_parallel_jaccard_coef", arg, R.vector(np.array([False])))
     assert R.printed() == ""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [600, 5000])
+@pytest.mark.parametrize("k", [257, 300, 513])
+def test_dot_call_jaccard_beyond_256_neighbours(R, N, k):
+    """The reference's loop has no limit on mat.ncol() (src/rcpp_parallel_jaccard_coeff.cpp:26-36): neither has the `.Call`
+    (k > 256 takes the sorted-row path, csrc/jaccard_sorted.h)."""
+    import oracle
+
+    if N > 2 * k + 2:
+        mat = synth.knn_windowed(N, k, W=max(100, k), seed=k, perm_seed=N)
+    else:
+        mat = np.stack([np.random.default_rng(N + k + i).permutation(N)[:k] + 1 for i in range(N)]).astype(np.int32)
+    want, _ = oracle.jaccard(mat, nthreads=8)
+    res = R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(mat), R.vector(np.array([False])))
+    _check_call_hygiene(R)
+    assert res.type == rmock.REALSXP and res.dim == (N * k, 3) and np.array_equal(res.numpy(), want)
 
 
 @pytest.mark.gpu

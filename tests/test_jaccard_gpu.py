@@ -629,9 +629,10 @@ def test_truncate_noninteger_ids_strict_drop_in_mode():
     with pytest.raises(gficf_amd.GficfError) as ei:
         gficf_amd.rcpp_parallel_jaccard_coef(bad, False, truncate_noninteger_ids=True)
     assert ei.value.status == "GFICF_ERR_BAD_ID"
-    # k beyond the build's limit: the message says what the limit is
+    # k beyond 256 is the sorted-row path (exact, see test_k_beyond_256_*); non-integer ids there are refused, and the message says so
+    frac_wide = np.tile(frac[:, :1], (1, 300))
     with pytest.raises(gficf_amd.GficfError) as ei:
-        gficf_amd.rcpp_parallel_jaccard_coef(np.ones((4, 300), dtype=np.int32), False)
+        gficf_amd.rcpp_parallel_jaccard_coef(frac_wide, False, truncate_noninteger_ids=True)
     assert ei.value.status == "GFICF_ERR_UNSUPPORTED" and "256" in str(ei.value)
 
 
@@ -955,3 +956,120 @@ def test_dual_rows_and_the_bit_set_kernel_across_their_boundaries(ops, N, k):
             ops.set_jaccard_distinct(False)
             for key in env:
                 del os.environ[key]
+
+
+# ---------------------------------------------------------------- k > 256: the sorted-row path (csrc/jaccard_sorted.h; round 5)
+# The reference loops over mat.ncol() without a limit (src/rcpp_parallel_jaccard_coeff.cpp:26-46); the fast kernels stop at 256
+# slots, beyond that rows are sorted once at ingest and an edge is k binary searches.  Same entries, same bits.
+@pytest.mark.parametrize("N", [600, 5000])
+@pytest.mark.parametrize("k", [257, 300, 513])
+def test_k_beyond_256_matches_oracle(N, k):
+    if N > 2 * k + 2:
+        mat = synth.knn_windowed(N, k, W=max(100, k), seed=N + k, perm_seed=7)
+    else:                                                       # 600 cells cannot hold a window of 2 x 513 + 1: distinct random ids
+        mat = np.stack([np.random.default_rng(N * 1000 + k + i).permutation(N)[:k] + 1 for i in range(N)]).astype(np.int32)
+    got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
+    want, _ = oracle.jaccard(mat, nthreads=8)
+    assert got.shape == (N * k, 3) and np.array_equal(got, want)
+    assert (want[:, 2] > 0).mean() > 0.5
+    if N == 600:                                                # REALSXP input (what Rcpp coerces to) and Fortran order
+        assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(np.asfortranarray(mat.astype(np.float64)), False), want)
+
+
+@pytest.mark.parametrize("k,mod", [(257, 300), (300, 90), (400, 1000)])
+def test_k_beyond_256_multiset_and_set_semantics(ops, k, mod):
+    """Rows that repeat ids (and name themselves): std::set_intersection's multiset counts for the parallel entry,
+    Rcpp::intersect's set counts for the serial one (src/jaccard_coeff.cpp:33), the weight > 0 filter and the compact return."""
+    N = 1100
+    mat = (synth.rand_u64(k, np.arange(N * k)).reshape(N, k) % np.uint64(mod)).astype(np.int32) + 1
+    rm, u = device_jaccard(ops, mat)
+    want, wu = oracle.jaccard(mat, nthreads=8)
+    assert np.array_equal(u, wu) and np.array_equal(rm, want)
+    assert wu.max() > 1
+    assert np.array_equal(gficf_amd.jaccard_coeff(mat, False), oracle.jaccard_coeff(mat))
+    cnt = gficf_amd.jaccard_counts(mat)
+    assert np.array_equal(cnt.astype(np.int32), wu)
+    assert np.array_equal(gficf_amd.jaccard_expand(mat, cnt), want)
+    neigh = np.concatenate([np.arange(1, N + 1, dtype=np.int32)[:, None], mat], axis=1)
+    rel = gficf_amd.jaccard_edges(neigh)
+    keep = want[:, 2] > 0
+    assert np.array_equal(rel["from"], want[keep, 0]) and np.array_equal(rel["to"], want[keep, 1]) and np.array_equal(rel["weight"], want[keep, 2])
+
+
+def test_k_beyond_256_cell_ranges_bad_ids_and_devices(ops):
+    import torch
+
+    N, k = 900, 320
+    mat = np.stack([np.random.default_rng(77 + i).permutation(N)[:k] + 1 for i in range(N)]).astype(np.int32)
+    want, wu = oracle.jaccard(mat, nthreads=8)
+    idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
+    rw = ops.row_words(N, k)
+    assert rw == 640 == ops.kpad(k)
+    table = torch.zeros((N, rw), dtype=torch.int32, device="cuda")
+    # ingest in two blocks (the seam a sharded caller uses), edges of a cell range in the middle, with counts
+    ops.jaccard_ingest(idx[:, :500].contiguous(), 500, k, N, table[:500])
+    ops.jaccard_ingest(idx[:, 500:].contiguous(), 400, k, N, table[500:])
+    b, e = 123, 777
+    out = torch.full((3, (e - b) * k), -7.0, dtype=torch.float64, device="cuda")
+    u = torch.full(((e - b) * k,), -7, dtype=torch.int32, device="cuda")
+    ops.jaccard_edges(table, N, k, b, e, out, u)
+    ops.sync()
+    assert np.array_equal(out.cpu().numpy().T, want[b * k:e * k]) and np.array_equal(u.cpu().numpy(), wu[b * k:e * k])
+    # the sorted half of a row is the row sorted (what the edge kernel searches)
+    t = table.cpu().numpy().view(np.uint32)
+    assert np.array_equal(t[:, :k], mat.astype(np.uint32)) and np.array_equal(t[:, 320:320 + k], np.sort(mat, axis=1).astype(np.uint32))
+    # transport form of the rows: the rows themselves
+    packed = torch.zeros((N, ops.packed_words(N, k)), dtype=torch.int32, device="cuda")
+    ops.jaccard_pack_rows(table, N, k, N, packed)
+    t2 = torch.zeros_like(table)
+    ops.jaccard_unpack_rows(packed, N, k, N, t2)
+    ops.sync()
+    assert torch.equal(t2, table)
+    # an id outside [1, N] is an error, as below 256
+    bad = mat.copy()
+    bad[5, 300] = N + 1
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        gficf_amd.rcpp_parallel_jaccard_coef(bad, False)
+    assert ei.value.status == "GFICF_ERR_BAD_ID"
+    # several devices behind the host entry (blocks + peer copies of sorted rows): same matrix
+    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(mat, False, devices=[0, 0, 0]), want)
+
+
+def test_k_in_the_thousands_rows_searched_in_the_table(ops):
+    """k = 3000 (the edge kernel no longer stages rows in LDS) against the oracle on a few cells (the whole matrix would take it
+    minutes), and k = 17000 > N (rows sorted in place in the table; every row repeats ids) against the multiset rule written out
+    with numpy: u = sum over ids of min(multiplicity in row i, multiplicity in the neighbour's row)."""
+    import torch
+
+    N, k, (b, e) = 3200, 3000, (0, 3)
+    mat = np.stack([np.random.default_rng(5 + i).permutation(N)[:k] + 1 for i in range(N)]).astype(np.int32)
+    mat[1, :40] = mat[1, 40]                                         # one row that repeats an id
+    idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
+    table = torch.zeros((N, ops.row_words(N, k)), dtype=torch.int32, device="cuda")
+    ops.jaccard_ingest(idx, N, k, N, table)
+    out = torch.zeros((3, (e - b) * k), dtype=torch.float64, device="cuda")
+    ops.jaccard_edges(table, N, k, b, e, out, None)
+    ops.sync()
+    want, _ = oracle.jaccard_cells(mat, b, e, nthreads=8)
+    assert np.array_equal(out.cpu().numpy().T, want)
+    del table, idx, out
+
+    N, k, cell = 1500, 17000, 700
+    mat = (synth.rand_u64(k, np.arange(N * k)).reshape(N, k) % np.uint64(N)).astype(np.int32) + 1
+    idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
+    kp = (k + 63) // 64 * 64
+    assert ops.row_words(N, k) == 2 * kp
+    table = torch.zeros((N, 2 * kp), dtype=torch.int32, device="cuda")
+    ops.jaccard_ingest(idx, N, k, N, table)
+    out = torch.zeros((3, k), dtype=torch.float64, device="cuda")
+    u = torch.zeros(k, dtype=torch.int32, device="cuda")
+    ops.jaccard_edges(table, N, k, cell, cell + 1, out, u)
+    ops.sync()
+    t = table[:64].cpu().numpy().view(np.uint32)
+    assert np.array_equal(t[:, kp:kp + k], np.sort(mat[:64], axis=1).astype(np.uint32)) and (t[:, kp + k:] == 0xFFFFFFFF).all()
+    cnt = np.stack([np.bincount(mat[r], minlength=N + 1) for r in range(N)])             # multiplicity of every id in every row
+    wu = np.minimum(cnt[cell][None, :], cnt[mat[cell] - 1]).sum(axis=1).astype(np.int32)
+    assert np.array_equal(u.cpu().numpy(), wu) and wu.min() > 0
+    got = out.cpu().numpy()
+    assert np.array_equal(got[0], np.full(k, cell + 1.0)) and np.array_equal(got[1], mat[cell].astype(np.float64))
+    assert np.array_equal(got[2], wu / (2.0 * k - wu))                                    # reference :51, same IEEE division
