@@ -85,6 +85,13 @@ def parse():
                     help="id model of `value`: permuted: ids relabelled by a random permutation (what Annoy output looks like; the default); "
                          "spatial: cells numbered in their spatial order (what the device kNN search's pivot order gives).  "
                          "N > 1 lines carry the other model too, as an object")
+    ap.add_argument("--legs", default=None,
+                    help="comma-separated legs to run besides `value` (one GPU: pipelined, cpu_baseline, stress, host_abi, gficf, knn; "
+                         "N > 1: pipelined, other_ids, single_gpu_step, chain, peer, gficf); default: all")
+    ap.add_argument("--budget-s", type=float, default=420.0,
+                    help="wall budget of the whole run in seconds: a leg that would start with less than its reserve left is skipped and "
+                         "named in `skipped_legs`; child-process and launcher limits are derived from it")
+    ap.add_argument("--no-host-gficf", action="store_true", help="skip the GF-ICF host-ABI figure (plan + finish over PCIe) of the gficf leg")
     ap.add_argument("--no-peer", action="store_true", help="N > 1: skip the single-process peer-copy leg (`peer` object)")
     ap.add_argument("--no-chain", action="store_true", help="N > 1: skip the kNN -> Jaccard chain leg (`chain` object)")
     ap.add_argument("--pre-warm-ms", type=float, default=200.0,
@@ -457,9 +464,14 @@ def traffic_child(args):
     idx = torch.from_numpy(np.ascontiguousarray(m.T)).cuda()
     table = torch.zeros((N_total, ops.row_words(N_total, k)), dtype=torch.int32, device="cuda")
     out = torch.zeros((3, N_total * k), dtype=torch.float64, device="cuda")
-    ops.jaccard_ingest(idx, N_total, k, N_total, table)
-    for _ in range(4):
-        ops.jaccard_edges(table, N_total, k, 0, N_total, out, None)
+    ops.set_jaccard_distinct(True)                                      # what the timed step runs under
+    if ops.jaccard_one_launch(N_total, k):                              # a small problem: the step is ONE kernel (csrc/jaccard_direct.h)
+        for _ in range(4):
+            ops.jaccard(idx, N_total, k, table, out, None)
+    else:
+        ops.jaccard_ingest(idx, N_total, k, N_total, table)
+        for _ in range(4):
+            ops.jaccard_edges(table, N_total, k, 0, N_total, out, None)
     ops.sync()
 
 
@@ -726,99 +738,112 @@ def run_peer_leg(args, timeout_s=420.0):
         return {"error": f"{type(ex).__name__}: {ex}"}
 
 
-def main():
-    args = parse()
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL and peer mappings across processes need on this driver (before any HIP call)
-    if args.traffic_child:
-        return traffic_child(args)
-    if args.peer_child:
-        return peer_child(args)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and never touches a
-        # GPU itself; rank 0 prints the JSON line straight to our stdout.  (Under torch.distributed.run the rank
-        # environment is already there and this branch is not taken.)
-        from gficf_amd import launch
+T_PROCESS_START = time.monotonic()
 
-        raise SystemExit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
-                                            need_gpus=None if args.rehearse_one_gpu else args.gpus,
-                                            timeout_s=float(os.environ.get("GFICF_BENCH_LAUNCH_TIMEOUT", "1500"))))
-    import torch
-    import torch.distributed as dist
+# Legs of a run, in order.  `value` (the timed region, its roofline, the exchange figures and the oracle check) always runs; the
+# others are further objects of the same line and can be selected with --legs.  N > 1: every leg is entered by all ranks together.
+LEGS_ONE_GPU = ["value", "pipelined", "cpu_baseline", "stress", "host_abi", "gficf", "knn"]
+LEGS_MULTI = ["value", "pipelined", "other_ids", "single_gpu_step", "chain", "peer", "gficf"]
+# seconds a leg is expected to need at most (a leg is skipped, and named in `skipped_legs`, when less than this is left of --budget-s)
+LEG_RESERVE_S = {"pipelined": 10, "other_ids": 40, "single_gpu_step": 20, "chain": 60, "peer": 60, "gficf": 40, "cpu_baseline": 40,
+                 "stress": 10, "host_abi": 15, "knn": 60}
 
-    import gficf_amd
-    from gficf_amd import synth
-    from gficf_amd.dist import JaccardShard, shard_bounds
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree (plain `python bench.py --gpus N` starts its own ranks)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (gficf_amd has no CPU fallback)")
-    if args.rehearse_one_gpu:
-        local_rank = 0
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
-                         "(one rank per GPU; --rehearse-one-gpu shares device 0 over gloo)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
+class Bench:
+    """One rank of a bench run: the workload, the timing helpers and one method per leg.  `out` is the line (rank 0 prints it)."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+
+        import gficf_amd
+        from gficf_amd import synth
+        from gficf_amd.dist import JaccardHaloShard, JaccardShard, shard_bounds
+
+        self.args, self.torch, self.dist, self.gficf_amd, self.synth = args, torch, dist, gficf_amd, synth
+        self.JaccardShard, self.JaccardHaloShard = JaccardShard, JaccardHaloShard
+        self.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree (plain `python bench.py --gpus N` starts its own ranks)")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (gficf_amd has no CPU fallback)")
         if args.rehearse_one_gpu:
-            dist.init_process_group("gloo")
+            local_rank = 0
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
+                             "(one rank per GPU; --rehearse-one-gpu shares device 0 over gloo)")
+        self.local_rank = local_rank
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            if args.rehearse_one_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        self.dev = torch.device("cuda", local_rank)
+        self.strong = strong = args.config in CONFIGS
+        if strong:
+            self.N_total, k = CONFIGS[args.config]
+            self.k = args.k or k
+            self.batch = args.batch or 1
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+            self.k = args.k or K
+            self.N_total = args.cells_per_gpu * world
+            self.batch = args.batch or BATCH
+        self.ops = gficf_amd.HipOps(local_rank)
+        self.b, self.e = shard_bounds(self.N_total, world, rank)
+        self.n_local = self.e - self.b
+        self.edges_per_step = self.N_total * self.k * self.batch
+        self.distinct = not args.scan_dups
+        self.out = {}
+        self.legs_done, self.leg_seconds, self.skipped_legs = [], {}, []
+        sel = LEGS_ONE_GPU if world == 1 else LEGS_MULTI
+        if args.legs:
+            asked = [x.strip() for x in args.legs.split(",") if x.strip()]
+            unknown = [x for x in asked if x not in sel]
+            if unknown:
+                raise SystemExit(f"--legs: {unknown} not among the legs of an N {'=' if world == 1 else '>'} 1 run: {sel}")
+            sel = [x for x in sel if x == "value" or x in asked]
+        self.selected = sel
+        self.guard = {"t": time.monotonic(), "line": None, "done": False}
+        self.single = None
 
-    strong = args.config in CONFIGS
-    if strong:
-        N_total, k = CONFIGS[args.config]
-        k = args.k or k
-        batch = args.batch or 1
-    else:
-        k = args.k or K
-        N_total = args.cells_per_gpu * world
-        batch = args.batch or BATCH
-    ops = gficf_amd.HipOps(local_rank)
-
-    # ---- synthetic input, resident in HBM before the timed region: `batch` independent data sets
-    b, e = shard_bounds(N_total, world, rank)
-    n_local = e - b
-    from gficf_amd.dist import JaccardHaloShard
-
-    def make_inputs(ids_kind, need_full0):
+    # ------------------------------------------------------------------------------------------------ helpers
+    def make_inputs(self, ids_kind, need_full0):
         """This rank's block of `batch` independent data sets ((k, n_local) device tensors == column-major blocks, 1-based
         global ids) and, where asked, the full matrix of data set 0 (oracle check, CPU baseline).  Only the block is generated
         (synth.knn_windowed(rows=...)): at 8 ranks a rank does an eighth of the work of the full matrix."""
         loc, full0 = [], None
-        for d in range(batch):
+        for d in range(self.batch):
             perm = (43 + 7 * d) if ids_kind == "permuted" else None
             if d == 0 and need_full0:
-                full0 = synth.knn_windowed(N_total, k, seed=42, perm_seed=perm)
-                blk = full0[b:e]
+                full0 = self.synth.knn_windowed(self.N_total, self.k, seed=42, perm_seed=perm)
+                blk = full0[self.b:self.e]
             else:
-                blk = synth.knn_windowed(N_total, k, seed=42 + 7 * d, perm_seed=perm, rows=(b, e))
-            loc.append(torch.from_numpy(np.ascontiguousarray(blk.T)).to(dev))
+                blk = self.synth.knn_windowed(self.N_total, self.k, seed=42 + 7 * d, perm_seed=perm, rows=(self.b, self.e))
+            loc.append(self.torch.from_numpy(np.ascontiguousarray(blk.T)).to(self.dev))
         return loc, full0
 
-    def pick_exchange(idx0, asked):
+    def pick_exchange(self, idx0, asked):
         """The exchange form is a property of the input (do the blocks name few rows outside themselves?): decided once, on
         data set 0, before anything is timed; every rank reaches the same decision (one all-reduce)."""
-        if world == 1:
+        if self.world == 1:
             return "allgather", None                                    # nothing to exchange; the plain single-device path
         if asked not in ("auto", "halo"):
             return asked, None
-        probe = JaccardHaloShard(ops, N_total, k, device=dev)
+        probe = self.JaccardHaloShard(self.ops, self.N_total, self.k, device=self.dev)
         probe.step(idx0)
         fits = 1
         try:
             probe.sync()
-        except gficf_amd.GficfError as ex:
+        except self.gficf_amd.GficfError as ex:
             if ex.status != "GFICF_ERR_CAPACITY":
                 raise
             fits = 0
         named = probe.rows_named_outside()
-        t_fit = torch.tensor([fits], dtype=torch.int32, device=dev)
-        dist.all_reduce(t_fit, op=dist.ReduceOp.MIN)
+        t_fit = self.torch.tensor([fits], dtype=self.torch.int32, device=self.dev)
+        self.dist.all_reduce(t_fit, op=self.dist.ReduceOp.MIN)
         del probe
         if int(t_fit.item()) == 0:
             if asked == "halo":
@@ -826,256 +851,384 @@ def main():
             return "allgather", named
         return "halo", named
 
-    def make_shards(exch, n, pipeline=False):
+    def make_shards(self, exch, n, pipeline=False):
         if exch == "halo":
-            return [JaccardHaloShard(ops, N_total, k, device=dev, pipeline=pipeline) for _ in range(n)]
-        return [JaccardShard(ops, N_total, k, device=dev, with_u=False, pipeline=pipeline,
-                             exchange="halo" if exch == "halo_generic" else "allgather") for _ in range(n)]
+            return [self.JaccardHaloShard(self.ops, self.N_total, self.k, device=self.dev, pipeline=pipeline) for _ in range(n)]
+        return [self.JaccardShard(self.ops, self.N_total, self.k, device=self.dev, with_u=False, pipeline=pipeline,
+                                  exchange="halo" if exch == "halo_generic" else "allgather") for _ in range(n)]
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
 
-    def max_over_ranks(x):
-        if world == 1:
+    def max_over_ranks(self, x):
+        if self.world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def settle(step_fn):
+    def settle(self, step_fn):
         """Settle the clocks: W = 5 steps are 2 ms of work and K = 20 another 9 ms — from idle the GPU is still ramping through
         all of that (the same K steps measured 0.42 ms right after start-up and 0.375-0.38 ms from the third repetition on).
         The step is run untimed for a fixed wall time (every rank the same number of steps: collectives stay matched)."""
-        if args.pre_warm_ms <= 0:
+        if self.args.pre_warm_ms <= 0:
             return 0
         step_fn()                                                  # (first call: allocations, occupancy queries)
-        fence()
+        self.fence()
         t_pw = time.perf_counter()
         step_fn()
-        fence()
-        one = max_over_ranks(max(time.perf_counter() - t_pw, 1e-5))
+        self.fence()
+        one = self.max_over_ranks(max(time.perf_counter() - t_pw, 1e-5))
         if one >= 0.02:                                            # (steps of tens of milliseconds — a rehearsal over gloo — settle the clocks by themselves)
             return 0
-        n = int(min(5000, max(1, args.pre_warm_ms * 1e-3 / one)))
+        n = int(min(5000, max(1, self.args.pre_warm_ms * 1e-3 / one)))
         for _ in range(n):
             step_fn()
-        fence()
+        self.fence()
         return n
 
-    def timed(step_fn, steps, warmup):
+    def timed(self, step_fn, steps, warmup):
         """W untimed steps, then exactly K steps between two fences (barrier + device sync on both sides); MAX over ranks."""
         for _ in range(warmup):
             step_fn()
-        fence()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.fence()
+        ev0, ev1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
         for _ in range(steps):
             step_fn()
         ev1.record()
-        fence()
+        self.fence()
         dt = time.perf_counter() - t0
-        return max_over_ranks(dt), ev0.elapsed_time(ev1)
+        return self.max_over_ranks(dt), ev0.elapsed_time(ev1)
 
-    def measure_overlapped(exch, idx):
-        """The overlapped mode (never `value`): ingest / exchange of data set d+1 on a side stream under the edge kernel of d."""
-        psh = make_shards(exch, 1, pipeline=True)[0]
-        for _ in range(3 * batch):
+    def measure_overlapped(self, exch, idx):
+        """The overlapped mode (never `value`): ingest / exchange of data set d+1 on a side stream under the edge kernel of d.
+        One rank: there is no exchange to hide and JaccardShard(pipeline=True) runs in order (gficf_amd/dist.py says why)."""
+        a = self.args
+        psh = self.make_shards(exch, 1, pipeline=True)[0]
+        for _ in range(3 * self.batch):
             psh.step(idx[0])
-        fence()
+        self.fence()
         t1 = time.perf_counter()
-        for i in range(args.steps * batch):
-            psh.step(idx[i % batch])
-        fence()
-        tp = max_over_ranks(time.perf_counter() - t1)
+        for i in range(a.steps * self.batch):
+            psh.step(idx[i % self.batch])
+        self.fence()
+        tp = self.max_over_ranks(time.perf_counter() - t1)
         psh.sync()
+        in_order = bool(getattr(psh, "pipeline_in_order", False))
         del psh
-        return {"edges_per_sec": N_total * k * batch * args.steps / tp, "ms_per_data_set": tp / (args.steps * batch) * 1e3,
-                "note": "software-pipelined over two tables and two output buffers; a steady-state rate over many data sets, not a call"}
+        return {"edges_per_sec": self.N_total * self.k * self.batch * a.steps / tp, "ms_per_data_set": tp / (a.steps * self.batch) * 1e3,
+                "note": ("one rank: nothing to exchange, so the pipelined form is refused and the steps run in order on one stream "
+                         "(the two-table / three-stream form measured 20 % SLOWER on one GPU: its ~10 runtime calls per step are host-bound)"
+                         if in_order else
+                         "software-pipelined over two tables and two output buffers; a steady-state rate over many data sets, not a call")}
 
-    idx_local, mat = make_inputs(args.ids, rank == 0)
-    exchange, named_outside = pick_exchange(idx_local[0], args.exchange)
-    shards = make_shards(exchange, batch)
+    # ------------------------------------------------------------------------------------------------ progress, budget, printing
+    def elapsed(self):
+        return time.monotonic() - T_PROCESS_START
 
-    def step():
-        for d in range(batch):
-            shards[d].step(idx_local[d])
+    def line(self, unfinished=None):
+        o = dict(self.out, legs_done=list(self.legs_done), leg_seconds={k_: round(v, 2) for k_, v in self.leg_seconds.items()},
+                 skipped_legs=list(self.skipped_legs), wall_s=round(self.elapsed(), 1), budget_s=self.args.budget_s)
+        if unfinished:
+            o["unfinished_leg"] = unfinished
+        return json.dumps(o)
 
-    # One context, all cells: rows are taken to hold distinct ids, as the library's host entries take them — the ingest does not
-    # scan every row for a repeated id; the edge kernel meets one while it builds the row's hash set and raises a deferred
-    # GFICF_ERR_DUPLICATE_IDS (surfaced by the sync behind the timed region; the exact sequence would then be re-run).  Sharded
-    # by cell blocks with an all-gather of rows the check stays complete across the job — every row is the own row of a cell of
-    # exactly one rank, whose sync raises (the job then fails loudly on that rank) —, and so it does in the halo form (the rank
-    # that owns a cell inserts its row).
-    distinct = not args.scan_dups
-    if distinct:
-        ops.set_jaccard_distinct(True)
-    # N = 1: the same W + K steps FROM IDLE first (what rounds 1-3 reported as `value`, and what one call from a cold R session
-    # sees: the clocks are still ramping) ...
-    value_from_idle = None
-    edges_per_step = N_total * k * batch
-    if world == 1 and args.pre_warm_ms > 0:
-        dt_idle, _ = timed(step, args.steps, args.warmup)
-        value_from_idle = edges_per_step * args.steps / dt_idle
-    # ... then the clocks are settled, then W warm-up steps, then the K timed ones
-    pre_warm_steps = settle(step)
-    dt, region_ms = timed(step, args.steps, args.warmup)
-    for sh in shards:
-        sh.sync()                                                   # surfaces deferred validation errors
-    value = edges_per_step * args.steps / dt
-    # the same K steps with the ingest's own duplicate scan (the sequence of rounds 1-3, `--scan-dups`), for comparison
-    value_scan = value
-    if distinct:
-        ops.set_jaccard_distinct(False)
-        dts, _ = timed(step, args.steps, 2)
-        value_scan = edges_per_step * args.steps / dts
-        ops.set_jaccard_distinct(True)
+    def progress(self, stage=None):
+        self.guard["t"] = time.monotonic()
+        if self.rank == 0:
+            self.guard["line"] = self.line(stage)
 
-    # ---- roofline of the dominant kernel (k_jaccard_edges): HIP events around every launch of a second run of the same
-    # K steps, recorded on the stream the kernel is launched on (the event pairs cost a few us per launch, so they stay out of
-    # the timed region); and the two kernels of a data set launched back to back alone
-    for sh in shards:
-        sh.time_edges = True
-    for _ in range(args.steps):
-        step()
-    fence()
-    for sh in shards:
-        sh.time_edges = False
-    t_edges_ms = sum(sh.edge_kernel_ms(last=args.steps) for sh in shards) / batch
-    rot = {"i": 0}
+    def emit(self):
+        """N > 1: the cumulative line, printed as soon as `value` exists and again after every leg (the LAST line of stdout is
+        the most complete one; a run cut short at any moment leaves a whole line behind).  One GPU: one line, at the end."""
+        if self.rank == 0 and self.world > 1:
+            sys.stdout.write(self.line() + "\n")
+            sys.stdout.flush()
 
-    halo_form = exchange == "halo"
+    def start_watchdog(self):
+        """A leg that hangs (a rank lost in a collective: first contact with real RCCL happens in the driver's own run) must not cost
+        the line: rank 0 re-prints what it has, marked `unfinished_leg`, and ends the process with a NON-ZERO code, so that the
+        launcher tears the other ranks down at once (they are blocked in the collective) and a harness sees the failure."""
+        if self.world == 1 or self.rank != 0:
+            return
+        import threading
 
-    def one_edges():
-        d = rot["i"] % batch
-        rot["i"] += 1
-        sh = shards[d]
-        if halo_form:
-            ops.jaccard_edges_mapped(sh.table, sh.n_ext, k, n_local, b, sh.l2g, sh.out, None)
+        limit = float(os.environ.get("GFICF_BENCH_LEG_TIMEOUT", str(max(60.0, min(240.0, self.args.budget_s * 0.6)))))
+
+        def watchdog():
+            while not self.guard["done"]:
+                time.sleep(2.0)
+                stuck = time.monotonic() - self.guard["t"] > limit
+                over = self.elapsed() > self.args.budget_s + 120.0
+                if not self.guard["done"] and self.guard["line"] is not None and (stuck or over):
+                    self.guard["done"] = True
+                    sys.stderr.write("bench.py: no progress in a later leg; printing the line as it stands and leaving with code 3\n")
+                    sys.stdout.write(self.guard["line"] + "\n")
+                    sys.stdout.flush()
+                    os._exit(3)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+
+    def run_leg(self, name, fn):
+        """Run one leg if it is selected and the wall budget allows (every rank takes rank 0's decision), record its seconds,
+        re-print the line."""
+        if name not in self.selected:
+            return
+        skip = 1 if (self.rank == 0 and self.elapsed() + LEG_RESERVE_S.get(name, 10) > self.args.budget_s) else 0
+        if self.world > 1:
+            t = self.torch.tensor([skip], dtype=self.torch.int32, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            skip = int(t.item())
+        if skip:
+            self.skipped_legs.append(name)
+            self.progress()
+            self.emit()
+            return
+        self.progress(name)
+        t0 = time.monotonic()
+        fn()
+        self.leg_seconds[name] = time.monotonic() - t0
+        self.legs_done.append(name)
+        self.progress()
+        self.emit()
+
+    # ------------------------------------------------------------------------------------------------ leg: value
+    def assert_same_format(self):
+        """N > 1: the table format is a function of (N, k) AND of the library build and its GFICF_JACCARD_* switches — a rank
+        started under another environment would silently disagree on the row pitch.  Exchanged and compared once, before the
+        first step (gficf_amd.dist.assert_same_format)."""
+        if self.world > 1:
+            from gficf_amd.dist import assert_same_format
+
+            assert_same_format(self.ops, self.N_total, self.k, device=self.dev)
+
+    def leg_value(self):
+        a, torch, ops = self.args, self.torch, self.ops
+        N_total, k, batch, world, rank = self.N_total, self.k, self.batch, self.world, self.rank
+        self.assert_same_format()
+        self.idx_local, self.mat = self.make_inputs(a.ids, rank == 0)
+        self.exchange, self.named_outside = self.pick_exchange(self.idx_local[0], a.exchange)
+        self.shards = self.make_shards(self.exchange, batch)
+
+        def step():
+            for d in range(batch):
+                self.shards[d].step(self.idx_local[d])
+
+        self.step = step
+        # One context, all cells: rows are taken to hold distinct ids, as the library's host entries take them — the ingest does not
+        # scan every row for a repeated id; the edge kernel meets one while it builds the row's hash set and raises a deferred
+        # GFICF_ERR_DUPLICATE_IDS (surfaced by the sync behind the timed region; the exact sequence would then be re-run).  Sharded
+        # by cell blocks with an all-gather of rows the check stays complete across the job — every row is the own row of a cell of
+        # exactly one rank, whose sync raises (the job then fails loudly on that rank) —, and so it does in the halo form (the rank
+        # that owns a cell inserts its row).
+        if self.distinct:
+            ops.set_jaccard_distinct(True)
+        # N = 1: the same W + K steps FROM IDLE first (what rounds 1-3 reported as `value`, and what one call from a cold R session
+        # sees: the clocks are still ramping) ...
+        value_from_idle = None
+        if world == 1 and a.pre_warm_ms > 0:
+            dt_idle, _ = self.timed(step, a.steps, a.warmup)
+            value_from_idle = self.edges_per_step * a.steps / dt_idle
+        # ... then the clocks are settled, then W warm-up steps, then the K timed ones
+        pre_warm_steps = self.settle(step)
+        dt, region_ms = self.timed(step, a.steps, a.warmup)
+        for sh in self.shards:
+            sh.sync()                                                   # surfaces deferred validation errors
+        self.value = value = self.edges_per_step * a.steps / dt
+        # the same K steps with the ingest's own duplicate scan (the sequence of rounds 1-3, `--scan-dups`), for comparison
+        value_scan = value
+        if self.distinct:
+            ops.set_jaccard_distinct(False)
+            dts, _ = self.timed(step, a.steps, 2)
+            value_scan = self.edges_per_step * a.steps / dts
+            ops.set_jaccard_distinct(True)
+        halo_form = self.exchange == "halo"
+        wl = (f"BASELINE config {a.config[1]}: ONE data set of {N_total} cells x k={k} split over {world} GPU(s) by cell block (strong scaling)"
+              if self.strong else
+              f"north-star point: {a.cells_per_gpu} cells x k={k} per GPU; N_total={N_total}; {batch} independent data sets per step")
+        one_launch = self.one_launch_form()
+        self.out.update({
+            "metric": "jaccard_edges_per_sec", "value": value, "unit": "edges/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if self.strong else "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": wl + f", windowed kNN (W=100) with {a.ids} ids; per data set: " +
+                                   ("ONE launch straight from the column-major input (no table: csrc/jaccard_direct.h), one library call" if one_launch else
+                                    "ingest + edge kernel, one library call" if world == 1 else
+                                    "halo plan + 2 all-to-alls (request slots, rows) + relabel + ingest + edge kernel on local ids" if halo_form else
+                                    "ingest + RCCL all-gather of table rows + edge kernel") +
+                                   ", device-resident, one stream, in order (no overlap between data sets or steps)" +
+                                   ("; rows taken to hold distinct ids: no duplicate scan in the ingest, the edge kernel's hash-set build reports a "
+                                    "repeated id (deferred GFICF_ERR_DUPLICATE_IDS, exact re-run) — what the host entries do" if self.distinct else ""),
+                       "cells_total": N_total, "k": k, "data_sets_per_step": batch, "edges_per_step": self.edges_per_step,
+                       "partition": f"cell blocks x{world}" + ("" if world == 1 else f", exchange: {self.exchange}")},
+            "timed_region_ms": round(region_ms, 4),
+            "value_from_idle": value_from_idle,
+            "value_from_idle_note": ("the same W warm-up + K timed steps run FIRST, right after start-up, before the clock-settling pre-warm: "
+                                     "what rounds 1-3 reported as `value` and what one call from a cold session costs" if value_from_idle is not None else None),
+            "pre_warm": {"ms_asked": a.pre_warm_ms, "steps": pre_warm_steps,
+                         "note": "the step run untimed before the W warm-up steps so that the K timed steps see settled clocks; --pre-warm-ms 0 turns it off"},
+            "value_with_ingest_duplicate_scan": value_scan,
+            "ms_per_data_set": dt / a.steps / batch * 1e3,
+        })
+        self.out["roofline"] = self.roofline()
+        if world > 1:
+            self.out["exchange"] = self.exchange_figures()
+        self.oracle_check()
+
+    def one_launch_form(self):
+        """Does the step of this workload take the one-launch form (small problem, one rank, distinct ids)?"""
+        return self.world == 1 and self.exchange == "allgather" and self.ops.jaccard_one_launch(self.N_total, self.k)
+
+    def roofline(self):
+        """Roofline of the dominant kernel.  Times are ONE HIP-event pair around a long run of launches on the launch stream, divided
+        by the launches (a pair per launch overstated every kernel by the events' own cost: round 4's 43.9 us against rocprofv3's
+        41.2): `kernel_ms` = the edge kernel launched back to back over the batch's tables (what the rocprofv3 trace of the same
+        command averages); `step_ms_per_data_set_device` = the step's own sequence, same bracket; `ingest_kernel_ms` = the
+        difference — what the ingest adds to a data set inside the step, boundary included — so that
+        data_sets x (kernel + ingest) is the device time of a step by construction."""
+        a, torch, ops = self.args, self.torch, self.ops
+        N_total, k, batch, world, rank, b, e, n_local = self.N_total, self.k, self.batch, self.world, self.rank, self.b, self.e, self.n_local
+        shards, idx_local = self.shards, self.idx_local
+        halo_form = self.exchange == "halo"
+        one_launch = self.one_launch_form()
+        rot = {"i": 0}
+
+        def one_edges():
+            d = rot["i"] % batch
+            rot["i"] += 1
+            sh = shards[d]
+            if halo_form:
+                ops.jaccard_edges_mapped(sh.table, sh.n_ext, k, n_local, b, sh.l2g, sh.out, None)
+            else:
+                ops.jaccard_edges(sh.table, N_total, k, b, e, sh.out, None)
+
+        def one_ingest():
+            d = rot["i"] % batch
+            rot["i"] += 1
+            sh = shards[d]
+            if halo_form:
+                # the step's own ingest: the own cells' rows (relabel + ingest) and the serve step in one launch (k <= 64) over what the
+                # last step's plan and exchange left in the shard's buffers; the table rows it writes are the ones the step wrote
+                if not ops.halo_serve_ingest(idx_local[d], n_local, k, N_total, b, world, sh.rpr, sh.cap, sh.ws, sh.req_out, sh.req_in, sh.rows_out, sh.table, sh.l2g):
+                    ops.halo_relabel(idx_local[d], n_local, k, N_total, b, world, sh.rpr, sh.cap, sh.ws, sh.req_out, sh.rows_in, sh.idx_ext, sh.l2g)
+                    ops.jaccard_ingest_local(sh.idx_ext, sh.n_ext, k, sh.table)
+            else:
+                ops.jaccard_ingest(idx_local[d], n_local, k, N_total, sh.table[rank * sh.rpr:(rank + 1) * sh.rpr])
+
+        launches = max(a.steps * batch, 40)
+        # the step's own sequence, bracketed once (world > 1: the exchange is inside; every rank runs the same number of steps)
+        reps = max(a.steps, 40 // batch + 1)
+        self.step()
+        self.fence()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            self.step()
+        e1.record()
+        self.fence()
+        t_step_ds = e0.elapsed_time(e1) / (reps * batch)
+        if one_launch:
+            t_edges_ms, t_ingest_ms, t_ingest_b2b, t_ingest_scan_ms = t_step_ds, 0.0, 0.0, 0.0
         else:
-            ops.jaccard_edges(sh.table, N_total, k, b, e, sh.out, None)
-
-    def one_ingest():
-        d = rot["i"] % batch
-        rot["i"] += 1
-        sh = shards[d]
-        if halo_form:
-            # the step's own ingest: the own cells' rows (relabel + ingest) and the serve step in one launch (k <= 64) over what the
-            # last step's plan and exchange left in the shard's buffers; the table rows it writes are the ones the step wrote (ADVICE r3: the unfused kernel on an unused,
-            # all-zero index matrix was timed here before — not the step's kernel, and it clobbered the table)
-            if not ops.halo_serve_ingest(idx_local[d], n_local, k, N_total, b, world, sh.rpr, sh.cap, sh.ws, sh.req_out, sh.req_in, sh.rows_out, sh.table, sh.l2g):
-                ops.halo_relabel(idx_local[d], n_local, k, N_total, b, world, sh.rpr, sh.cap, sh.ws, sh.req_out, sh.rows_in, sh.idx_ext, sh.l2g)
-                ops.jaccard_ingest_local(sh.idx_ext, sh.n_ext, k, sh.table)
-        else:
-            ops.jaccard_ingest(idx_local[d], n_local, k, N_total, sh.table[rank * sh.rpr:(rank + 1) * sh.rpr])
-
-    t_edges_b2b_ms = time_kernel_ms(torch, one_edges, max(args.steps * batch, 40))
-    t_ingest_ms = time_kernel_ms(torch, one_ingest, max(args.steps * batch, 40))
-    t_ingest_scan_ms = t_ingest_ms
-    if distinct:                                                    # the scanning ingest next to it, and the option off for everything below
-        ops.set_jaccard_distinct(False)
-        t_ingest_scan_ms = time_kernel_ms(torch, one_ingest, max(args.steps * batch, 40))
-    alg_bytes = JACCARD_BYTES_PER_EDGE * n_local * k
-    achieved = alg_bytes / (t_edges_ms * 1e-3) / 1e9
-    # HBM-side bytes per launch from the committed PMC passes (tools/pmc.sh + tools/make_traffic.py; FETCH_SIZE
-    # correction documented there); null when no pass was taken for this workload
-    pmc = {}
-    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(prof):
-        try:
-            pmc = json.load(open(prof))
-        except Exception:
-            pmc = {}
-    # the edge kernel of this shape is k_jaccard_edges_pipe (k <= 32) or k_jaccard_edges; make_traffic.py keys by kernel name
-    traffic = None if halo_form else (pmc.get(f"jaccard_edges_pipe_N{N_total}_k{k}") or pmc.get(f"jaccard_edges_bits_N{N_total}_k{k}")
-                                      or pmc.get(f"jaccard_edges_N{N_total}_k{k}") or {}).get("hbm_bytes_per_launch")
-    edge_kernel = "k_jaccard_edges_pipe" if (k <= 32 and not os.environ.get("GFICF_JACCARD_NO_PIPE")) else "k_jaccard_edges"   # the name rocprofv3 shows
-    if 32 < k <= 55 and (shards[0].row_words if halo_form else ops.row_words(N_total, k)) == 64 and (shards[0].n_ext if halo_form else N_total) <= 131070:
-        edge_kernel = "k_jaccard_edges_bits"                         # dual rows: the direct-address bit-set kernel
-    traffic_source = "profiles/pmc_traffic.json (separate --pmc passes of tools/pmc_round.sh, read requests priced by their width: tools/make_traffic.py)" if traffic else None
-    traffic_detail = None
-    if world == 1 and not args.no_live_traffic and not args.no_extras:
-        # measured in THIS run (after the timed region; the child is a fresh process under rocprofv3, nothing of it is timed)
-        live, detail = live_traffic(args, edge_kernel)
-        if live is not None:
-            traffic_detail = dict(detail, committed_figure=traffic)
-            traffic = live
-            traffic_source = ("live: two rocprofv3 --pmc passes of this run over a child process launching the same kernel on the same workload "
-                              "(TCC_EA0_RDREQ_{32,64,128}B priced by width + WRITE_SIZE)")
-        else:
-            traffic_detail = {"live_failed": detail}
-    roofline = {"bound": "hbm", "kernel": edge_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            if not halo_form and world == 1:
+                # (the step ran the library's one-call sequence; the separate calls below need the table it left — the same table)
+                pass
+            t_edges_ms = time_kernel_ms(torch, one_edges, launches)
+            t_ingest_b2b = time_kernel_ms(torch, one_ingest, launches)
+            t_ingest_scan_ms = t_ingest_b2b
+            if self.distinct:                                           # the scanning ingest next to it, and the option back on
+                ops.set_jaccard_distinct(False)
+                t_ingest_scan_ms = time_kernel_ms(torch, one_ingest, launches)
+                ops.set_jaccard_distinct(True)
+            t_ingest_ms = max(t_step_ds - t_edges_ms, 0.0) if world == 1 else t_ingest_b2b
+        alg_bytes = JACCARD_BYTES_PER_EDGE * n_local * k
+        achieved = alg_bytes / (t_edges_ms * 1e-3) / 1e9
+        # HBM-side bytes per launch from the committed PMC passes (tools/pmc.sh + tools/make_traffic.py; FETCH_SIZE
+        # correction documented there); null when no pass was taken for this workload
+        pmc = {}
+        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(prof):
+            try:
+                pmc = json.load(open(prof))
+            except Exception:
+                pmc = {}
+        self.pmc = pmc
+        traffic = None if (halo_form or one_launch) else (pmc.get(f"jaccard_edges_pipe_N{N_total}_k{k}") or pmc.get(f"jaccard_edges_bits_N{N_total}_k{k}")
+                                                         or pmc.get(f"jaccard_edges_N{N_total}_k{k}") or {}).get("hbm_bytes_per_launch")
+        edge_kernel = "k_jaccard_edges_pipe" if (k <= 32 and not os.environ.get("GFICF_JACCARD_NO_PIPE")) else "k_jaccard_edges"   # the name rocprofv3 shows
+        row_words = shards[0].row_words if halo_form else ops.row_words(N_total, k)
+        if 32 < k <= 55 and row_words == 64 and (shards[0].n_ext if halo_form else N_total) <= 131070:
+            edge_kernel = "k_jaccard_edges_bits"                         # dual rows: the direct-address bit-set kernel
+        if k > 256:
+            edge_kernel = "k_jaccard_edges_sorted"
+        if one_launch:
+            edge_kernel = "k_jaccard_direct"
+        traffic_source = "profiles/pmc_traffic.json (separate --pmc passes of tools/pmc_round.sh, read requests priced by their width: tools/make_traffic.py)" if traffic else None
+        traffic_detail = None
+        if world == 1 and not a.no_live_traffic and not a.no_extras:
+            # measured in THIS run (after the timed region; the child is a fresh process under rocprofv3, nothing of it is timed)
+            live, detail = live_traffic(a, edge_kernel, timeout_s=min(90.0, max(20.0, a.budget_s - self.elapsed() - 60.0)))
+            if live is not None:
+                traffic_detail = dict(detail, committed_figure=traffic)
+                traffic = live
+                traffic_source = ("live: two rocprofv3 --pmc passes of this run over a child process launching the same kernel on the same workload "
+                                  "(TCC_EA0_RDREQ_{32,64,128}B priced by width + WRITE_SIZE)")
+            else:
+                traffic_detail = {"live_failed": detail}
+        return {"bound": "hbm", "kernel": edge_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_copy_rate": round(achieved / HBM_COPY_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_source, "traffic_detail": traffic_detail,
                 # what the kernel really moves: a gathered row fills a whole 128 B line (profiles/r03_fetch_calibration.txt)
                 "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
                 "traffic_GBps": round(traffic / (t_edges_ms * 1e-3) / 1e9, 1) if traffic else None,
                 "traffic_frac_of_copy_rate": round(traffic / (t_edges_ms * 1e-3) / 1e9 / HBM_COPY_GBS, 4) if traffic else None,
-                "kernel_ms": round(t_edges_ms, 5), "kernel_ms_back_to_back": round(t_edges_b2b_ms, 5),
-                "ingest_kernel_ms": round(t_ingest_ms, 5), "ingest_kernel_ms_with_duplicate_scan": round(t_ingest_scan_ms, 5),
+                "kernel_ms": round(t_edges_ms, 5), "kernel_ms_back_to_back": round(t_edges_ms, 5),
+                "ingest_kernel_ms": round(t_ingest_ms, 5), "ingest_kernel_ms_back_to_back": round(t_ingest_b2b, 5),
+                "ingest_kernel_ms_with_duplicate_scan": round(t_ingest_scan_ms, 5),
+                "step_ms_per_data_set_device": round(t_step_ds, 5),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "row_bytes": 4 * (shards[0].row_words if halo_form else ops.row_words(N_total, k)),
-                "note": "kernel_ms: mean of HIP-event pairs around every edge-kernel launch of a second run of the K steps "
-                        "(same stream, same order as the timed region); kernel_ms_back_to_back: the kernel alone, launched back to "
-                        "back over the batch's tables"}
+                "row_bytes": 4 * row_words,
+                "note": "kernel_ms: ONE HIP-event pair on the launch stream around a run of back-to-back launches of the kernel over the batch's "
+                        "tables, divided by the launches (a pair per launch overstated it); step_ms_per_data_set_device: the step's own sequence "
+                        "in the same bracket; ingest_kernel_ms (one rank): their difference — what the ingest adds inside the step; its own "
+                        "back-to-back figure is bound by the host's enqueue rate at these sizes, not by the device" +
+                        ("; ONE-LAUNCH form: the step is one kernel, kernel_ms is the step" if one_launch else "")}
 
-    wl = (f"BASELINE config {args.config[1]}: ONE data set of {N_total} cells x k={k} split over {world} GPU(s) by cell block (strong scaling)"
-          if strong else
-          f"north-star point: {args.cells_per_gpu} cells x k={k} per GPU; N_total={N_total}; {batch} independent data sets per step")
-    out = {
-        "metric": "jaccard_edges_per_sec", "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": wl + f", windowed kNN (W=100) with {args.ids} ids; per data set: " +
-                               ("ingest + edge kernel" if world == 1 else
-                                "halo plan + 2 all-to-alls (request slots, rows) + relabel + ingest + edge kernel on local ids" if halo_form else
-                                "ingest + RCCL all-gather of table rows + edge kernel") +
-                               ", device-resident, one stream, in order (no overlap between data sets or steps)" +
-                               ("; rows taken to hold distinct ids: no duplicate scan in the ingest, the edge kernel's hash-set build reports a "
-                                "repeated id (deferred GFICF_ERR_DUPLICATE_IDS, exact re-run) — what the host entries do" if distinct else ""),
-                   "cells_total": N_total, "k": k, "data_sets_per_step": batch, "edges_per_step": edges_per_step,
-                   "partition": f"cell blocks x{world}" + ("" if world == 1 else f", exchange: {exchange}")},
-        "timed_region_ms": round(region_ms, 4),
-        "value_from_idle": value_from_idle,
-        "value_from_idle_note": ("the same W warm-up + K timed steps run FIRST, right after start-up, before the clock-settling pre-warm: "
-                                 "what rounds 1-3 reported as `value` and what one call from a cold session costs" if value_from_idle is not None else None),
-        "pre_warm": {"ms_asked": args.pre_warm_ms, "steps": pre_warm_steps,
-                     "note": "the step run untimed before the W warm-up steps so that the K timed steps see settled clocks; --pre-warm-ms 0 turns it off"},
-        "value_with_ingest_duplicate_scan": value_scan,
-        "ms_per_data_set": dt / args.steps / batch * 1e3,
-        "roofline": roofline,
-    }
-    if world > 1:
-        sh0 = shards[0]
-        if halo_form:
-            out["exchange"] = {"bytes_received_per_rank_per_data_set": int(sh0.bytes_received),
-                               "rows_received_per_rank_per_data_set": int(sh0.rows_named_outside()),
-                               "row_bytes_on_the_wire": 4 * k, "ids": args.ids, "request_slots_per_owner": sh0.cap,
-                               "rows_of_the_sub_problem": sh0.n_ext, "table_row_bytes": 4 * sh0.row_words,
-                               "rows_named_outside_the_block_data_set_0": named_outside, "chosen_by": args.exchange,
-                               "form": "halo on local ids: P x cap request slots out, P x cap raw index rows back (two all-to-alls with equal splits, "
-                                       "no host round trip); bytes = the fixed slot traffic, rows = the slots in use"}
-        else:
-            row_b = 4 * (sh0.pw if sh0.packed is not None else sh0.row_words)
-            out["exchange"] = {"bytes_received_per_rank_per_data_set": int(sh0.bytes_received), "rows_received_per_rank_per_data_set": int(sh0.rows_received),
-                               "row_bytes_on_the_wire": row_b, "ids": args.ids, "rows_named_outside_the_block_data_set_0": named_outside,
-                               "chosen_by": args.exchange,
-                               "form": ("halo: unique-id request lists + the named rows, two all-to-alls" if exchange == "halo_generic" else
-                                        "all-gather of table rows" + (" (bit-packed)" if sh0.packed is not None else ""))}
+    def exchange_figures(self):
+        a, sh0 = self.args, self.shards[0]
+        if self.exchange == "halo":
+            return {"bytes_received_per_rank_per_data_set": int(sh0.bytes_received),
+                    "rows_received_per_rank_per_data_set": int(sh0.rows_named_outside()),
+                    "row_bytes_on_the_wire": 4 * self.k, "ids": a.ids, "request_slots_per_owner": sh0.cap,
+                    "rows_of_the_sub_problem": sh0.n_ext, "table_row_bytes": 4 * sh0.row_words,
+                    "rows_named_outside_the_block_data_set_0": self.named_outside, "chosen_by": a.exchange,
+                    "form": "halo on local ids: P x cap request slots out, P x cap raw index rows back (two all-to-alls with equal splits, "
+                            "no host round trip); bytes = the fixed slot traffic, rows = the slots in use"}
+        row_b = 4 * (sh0.pw if sh0.packed is not None else sh0.row_words)
+        return {"bytes_received_per_rank_per_data_set": int(sh0.bytes_received), "rows_received_per_rank_per_data_set": int(sh0.rows_received),
+                "row_bytes_on_the_wire": row_b, "ids": a.ids, "rows_named_outside_the_block_data_set_0": self.named_outside,
+                "chosen_by": a.exchange,
+                "form": ("halo: unique-id request lists + the named rows, two all-to-alls" if self.exchange == "halo_generic" else
+                         "all-gather of table rows" + (" (bit-packed)" if sh0.packed is not None else ""))}
 
-    extras = not args.no_extras and not strong
-    shard = shards[0]
-    if rank == 0:
-        # every line carries a check against the oracle (checker only, after the timed region): the whole matrix of data
-        # set 0 when that takes seconds (one GPU, <= 200 k cells, extras on), otherwise a bounded sample of this rank's
-        # cells — three runs of 1024 consecutive source cells at the start, the middle and the end of its block
+    def oracle_check(self):
+        """Every line carries a check against the oracle (checker only, after the timed region): the whole matrix of data
+        set 0 when that takes seconds (one GPU, <= 200 k cells, extras on), otherwise a bounded sample of this rank's
+        cells — three runs of 1024 consecutive source cells at the start, the middle and the end of its block."""
+        if self.rank != 0:
+            return
         import oracle
 
+        a, N_total, k, b, e, n_local = self.args, self.N_total, self.k, self.b, self.e, self.n_local
+        shard, mat = self.shards[0], self.mat
         cores = os.cpu_count() or 1
-        if world == 1 and extras and N_total <= 200_000:
+        extras = not a.no_extras and not self.strong
+        if self.world == 1 and (extras or N_total * k <= 2_000_000) and N_total <= 200_000:
             want, _ = oracle.jaccard(mat, nthreads=cores)
             ok, checked = bool(np.array_equal(shard.out.cpu().numpy().T, want)), N_total
             del want
@@ -1087,185 +1240,217 @@ def main():
                 got = shard.out[:, (c0 - b) * k:(c0 - b + run) * k].cpu().numpy().T
                 ok = ok and bool(np.array_equal(got, want))
                 checked += run
-        out["checked_vs_oracle"] = ok
-        out["oracle_check"] = {"cells": checked, "of": n_local, "kind": "whole matrix" if checked == N_total else "sample of source cells",
-                               "what": "bit-exact rows of the reference's (N*k) x 3 matrix, data set 0"}
-    # N > 1: from here on the line holds `value`, its roofline and the exchange; what follows are further legs of the same run.
-    # If one of them hangs (a rank lost in a collective: first contact with real RCCL happens in the driver's own run), rank 0
-    # still prints what it has — a watchdog thread, fed by `progress()`, prints the line as it stands after 400 s without
-    # progress and ends the process; the normal end prints the full line exactly once.
-    guard = {"t": time.monotonic(), "line": None, "done": False}
+        self.out["checked_vs_oracle"] = ok
+        self.out["oracle_check"] = {"cells": checked, "of": n_local, "kind": "whole matrix" if checked == N_total else "sample of source cells",
+                                    "what": "bit-exact rows of the reference's (N*k) x 3 matrix, data set 0"}
 
-    def progress(stage=None):
-        guard["t"] = time.monotonic()
-        if rank == 0:
-            guard["line"] = json.dumps(dict(out, unfinished_leg=stage) if stage else out)
+    # ------------------------------------------------------------------------------------------------ legs shared by N = 1 and N > 1
+    def leg_pipelined(self):
+        self.out["pipelined"] = self.measure_overlapped(self.exchange, self.idx_local)
 
-    if world > 1 and rank == 0:
-        import threading
+    # ------------------------------------------------------------------------------------------------ legs of an N > 1 run
+    def leg_other_ids(self):
+        """The other id model: ids WITH locality (what the device kNN search's pivot order gives, gficf_knn_pivot_order_device)
+        when `value` ran on permuted ids, and the other way round."""
+        a, torch = self.args, self.torch
+        other = "spatial" if a.ids == "permuted" else "permuted"
+        self.other = other
+        idx_o, _ = self.make_inputs(other, False)
+        ex_o, named_o = self.pick_exchange(idx_o[0], "auto")
+        shards_o = self.make_shards(ex_o, self.batch)
 
-        def watchdog():
-            while not guard["done"]:
-                time.sleep(5.0)
-                if not guard["done"] and guard["line"] is not None and time.monotonic() - guard["t"] > float(os.environ.get("GFICF_BENCH_LEG_TIMEOUT", "400")):
-                    guard["done"] = True
-                    sys.stderr.write("bench.py: no progress in a later leg; printing the line as it stands\n")
-                    sys.stdout.write(guard["line"] + "\n")
-                    sys.stdout.flush()
-                    os._exit(0)
+        def step_o():
+            for d in range(self.batch):
+                shards_o[d].step(idx_o[d])
 
-        threading.Thread(target=watchdog, daemon=True).start()
-    progress("pipelined")
-    if distinct:
-        ops.set_jaccard_distinct(True)                              # the legs below run what `value` ran
-    if args.pipeline or (not args.no_extras and (world > 1 or not strong)):
-        out["pipelined"] = measure_overlapped(exchange, idx_local)
-    if world > 1 and not args.no_extras:
-        # ---- the rest of the scaling answer, in this one run (same box, same processes, same clocks)
-        # (1) the other id model: ids WITH locality (what the device kNN search's pivot order gives, gficf_knn_pivot_order_device)
-        #     when `value` ran on permuted ids, and the other way round
-        other = "spatial" if args.ids == "permuted" else "permuted"
-        progress(f"{other}_ids")
-        shards_value = shards
-        idx_o, _ = make_inputs(other, False)
-        ex_o, named_o = pick_exchange(idx_o[0], "auto")
-        shards = make_shards(ex_o, batch)                           # (`step` closes over `shards` / `idx_local`)
-        idx_value, idx_local = idx_local, idx_o
-        dt_o, _ = timed(step, args.steps, args.warmup)
-        for sh in shards:
+        dt_o, _ = self.timed(step_o, a.steps, a.warmup)
+        for sh in shards_o:
             sh.sync()
-        sh0 = shards[0]
+        sh0 = shards_o[0]
         obj = {"ids": other, "exchange": ex_o, "rows_named_outside_the_block_data_set_0": named_o,
-               "in_order": {"edges_per_sec": edges_per_step * args.steps / dt_o, "ms_per_data_set": dt_o / args.steps / batch * 1e3},
+               "in_order": {"edges_per_sec": self.edges_per_step * a.steps / dt_o, "ms_per_data_set": dt_o / a.steps / self.batch * 1e3},
                "bytes_received_per_rank_per_data_set": int(sh0.bytes_received),
                "table_row_bytes": 4 * sh0.row_words}
         if ex_o == "halo":
             obj.update({"rows_named_outside": int(sh0.rows_named_outside()), "request_slots_per_owner": sh0.cap, "rows_of_the_sub_problem": sh0.n_ext})
         # checked like `value`: a bounded oracle sample of this rank's block (rank 0), data set 0
-        if rank == 0:
+        if self.rank == 0:
             import oracle
 
-            mat_o = synth.knn_windowed(N_total, k, seed=42, perm_seed=43 if other == "permuted" else None)
-            run = min(512, n_local)
-            want, _ = oracle.jaccard_cells(mat_o, b, b + run, nthreads=os.cpu_count() or 1)
-            obj["checked_vs_oracle"] = bool(np.array_equal(sh0.out[:, :run * k].cpu().numpy().T, want))
+            mat_o = self.synth.knn_windowed(self.N_total, self.k, seed=42, perm_seed=43 if other == "permuted" else None)
+            run = min(512, self.n_local)
+            want, _ = oracle.jaccard_cells(mat_o, self.b, self.b + run, nthreads=os.cpu_count() or 1)
+            obj["checked_vs_oracle"] = bool(np.array_equal(sh0.out[:, :run * self.k].cpu().numpy().T, want))
             del mat_o, want
-        del shards, sh0
-        obj["overlapped"] = measure_overlapped(ex_o, idx_o)
-        out[f"{other}_ids"] = obj
-        shards, idx_local = shards_value, idx_value
-        del idx_o
-        # (2) the N = 1 step, timed by rank 0 in this same process once the N-rank region is over (the other ranks wait at the
-        #     fence): ingest + edge kernel per data set, one stream, in order, on `cells_1` cells — what `python bench.py` times
-        cells_1 = N_total if strong else args.cells_per_gpu
-        progress("single_gpu_step")
-        single = None
-        if rank == 0:
-            tb1 = [torch.zeros((cells_1, ops.row_words(cells_1, k)), dtype=torch.int32, device=dev) for _ in range(batch)]
-            o1 = [torch.zeros((3, cells_1 * k), dtype=torch.float64, device=dev) for _ in range(batch)]
-            i1 = [torch.from_numpy(np.ascontiguousarray(synth.knn_windowed(cells_1, k, seed=42 + 7 * d, perm_seed=(43 + 7 * d) if args.ids == "permuted" else None).T)).to(dev)
+        del shards_o, sh0
+        self.out[f"{other}_ids"] = obj
+        self.emit()                                                     # (the in-order figure is out before the overlapped one is taken)
+        obj["overlapped"] = self.measure_overlapped(ex_o, idx_o)
+
+    def leg_single_gpu_step(self):
+        """The N = 1 step, timed by rank 0 in this same process once the N-rank region is over (the other ranks wait at the
+        fence): one library call per data set (ingest + edge kernel), one stream, in order, on `cells_1` cells — what `python bench.py` times."""
+        a, torch, ops, k, batch = self.args, self.torch, self.ops, self.k, self.batch
+        cells_1 = self.N_total if self.strong else a.cells_per_gpu
+        if self.rank == 0:
+            tb1 = [torch.zeros((cells_1, ops.row_words(cells_1, k)), dtype=torch.int32, device=self.dev) for _ in range(batch)]
+            o1 = [torch.zeros((3, cells_1 * k), dtype=torch.float64, device=self.dev) for _ in range(batch)]
+            i1 = [torch.from_numpy(np.ascontiguousarray(self.synth.knn_windowed(cells_1, k, seed=42 + 7 * d, perm_seed=(43 + 7 * d) if a.ids == "permuted" else None).T)).to(self.dev)
                   for d in range(batch)]
+            runs = [ops.jaccard_prepared(i1[d], cells_1, k, tb1[d], o1[d], None) for d in range(batch)]
 
             def step1():
-                for d in range(batch):
-                    ops.jaccard_ingest(i1[d], cells_1, k, cells_1, tb1[d])
-                    ops.jaccard_edges(tb1[d], cells_1, k, 0, cells_1, o1[d], None)
+                for r in runs:
+                    r()
 
-            for _ in range(max(args.warmup, 3)):
+            for _ in range(max(a.warmup, 3)):
                 step1()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(a.steps):
                 step1()
             torch.cuda.synchronize()
             t_1 = time.perf_counter() - t1
             ops.sync()
-            single = cells_1 * k * batch * args.steps / t_1
-            out["single_gpu_step"] = {"edges_per_sec": single, "ms_per_data_set": t_1 / args.steps / batch * 1e3, "cells": cells_1, "ids": args.ids,
-                                      "note": "rank 0 alone, after the N-rank region of this same process (the other ranks wait): "
-                                              "ingest + edge kernel per data set, one stream, in order — the step `python bench.py` times"}
-            del tb1, o1, i1
-        fence()
-        # (2b) the kNN -> Jaccard chain in the search's pivot order (what a sharded clustcells() runs)
-        progress("chain")
-        if not args.no_chain and not strong:
-            try:
-                ch = bench_chain(torch, dist, ops, args, world, rank, dev, fence, max_over_ranks)
-            except gficf_amd.GficfError as ex:                          # (a failure of this leg must not cost the line; collectives stay matched: every rank runs the same code)
-                ch = {"error": str(ex)}
-            if rank == 0:
-                out["chain"] = ch
-        # (3) the single-process form with direct peer copies, in a process of its own (rank 0 starts it; the ranks wait)
-        progress("peer")
-        if rank == 0 and not args.no_peer:
-            out["peer"] = run_peer_leg(args, timeout_s=300.0)
-        fence()
-        if rank == 0:
-            per = lambda v: round(v / (world * single), 4)
-            oo = out[f"{other}_ids"]
-            out["efficiency"] = {
-                "definition": "whole-job edges/s / (n_gpus x single_gpu_step.edges_per_sec), all measured in this run",
-                f"in_order_{args.ids}": per(value), f"overlapped_{args.ids}": per(out["pipelined"]["edges_per_sec"]),
-                f"in_order_{other}": per(oo["in_order"]["edges_per_sec"]), f"overlapped_{other}": per(oo["overlapped"]["edges_per_sec"])}
-            if "edges_per_sec" in out.get("peer", {}):
-                out["efficiency"][f"peer_in_order_{args.ids}"] = per(out["peer"]["edges_per_sec"])
-            if "edges_per_sec" in out.get("peer", {}).get("spatial_ids", {}):
-                out["efficiency"]["peer_halo_in_order_spatial"] = per(out["peer"]["spatial_ids"]["edges_per_sec"])
-                if "edges_per_sec" in (out["peer"]["spatial_ids"].get("overlapped") or {}):
-                    out["efficiency"]["peer_halo_overlapped_spatial"] = per(out["peer"]["spatial_ids"]["overlapped"]["edges_per_sec"])
-    if distinct:
-        ops.set_jaccard_distinct(False)
+            self.single = cells_1 * k * batch * a.steps / t_1
+            self.out["single_gpu_step"] = {"edges_per_sec": self.single, "ms_per_data_set": t_1 / a.steps / batch * 1e3, "cells": cells_1, "ids": a.ids,
+                                           "note": "rank 0 alone, after the N-rank region of this same process (the other ranks wait): "
+                                                   "ingest + edge kernel per data set, one stream, in order — the step `python bench.py` times"}
+            del tb1, o1, i1, runs
+        self.fence()
 
-    if rank == 0 and world == 1 and extras:
-        if not args.no_cpu_baseline:
-            import oracle
-
-            cores = os.cpu_count() or 1
-            mf = np.asfortranarray(mat.astype(np.float64))
-            rmh = np.empty((3, N_total * k))
-            uh = np.empty(N_total * k, dtype=np.int32)
-            L = oracle.lib()
-            ts = []
-            for _ in range(3):
-                t1 = time.perf_counter()
-                L.oracle_jaccard_f64(mf.ctypes.data, N_total, k, rmh.ctypes.data, uh.ctypes.data, cores)
-                ts.append(time.perf_counter() - t1)
-            t1 = time.perf_counter()
-            L.oracle_jaccard_f64(mf.ctypes.data, N_total, k, rmh.ctypes.data, uh.ctypes.data, 2)
-            t_nt2 = time.perf_counter() - t1
-            edges_ds = N_total * k                                      # one data set
-            cpu_v = edges_ds / statistics.median(ts)
-            out["cpu_baseline"] = {"value": cpu_v, "unit": "edges/s", "cores": cores, "kind": "port",
-                                   "sample": f"the full workload ({N_total} cells x k={k}, same input), median of 3 passes of the oracle's "
-                                             "faithful restatement of the RcppParallel worker (g++ -O2, dynamic chunks over std::thread)",
-                                   "nt2_value": edges_ds / t_nt2, "nt2_note": "clustcells() default nt = 2 (reference R/clustCells.R:46)",
-                                   "gpu_over_cpu": value / cpu_v}
-        # stress row: uniformly random neighbour ids — u ~ 0, no overlap to exploit, same traffic
+    def leg_chain(self):
+        """The kNN -> Jaccard chain in the search's pivot order (what a sharded clustcells() runs)."""
+        if self.strong:
+            return
         try:
-            umat = synth.knn_uniform(N_total, k)
-            uidx = torch.from_numpy(np.ascontiguousarray(umat.T)).to(dev)
-            ush = JaccardShard(ops, N_total, k, device=dev, pipeline=False)
+            ch = bench_chain(self.torch, self.dist, self.ops, self.args, self.world, self.rank, self.dev, self.fence, self.max_over_ranks)
+        except self.gficf_amd.GficfError as ex:                          # (a failure of this leg must not cost the line; collectives stay matched: every rank runs the same code)
+            ch = {"error": str(ex)}
+        if self.rank == 0:
+            self.out["chain"] = ch
+
+    def leg_peer(self):
+        """The single-process form with direct peer copies, in a process of its own (rank 0 starts it; the ranks wait)."""
+        if self.rank == 0:
+            left = self.args.budget_s - self.elapsed()
+            self.out["peer"] = run_peer_leg(self.args, timeout_s=max(30.0, min(300.0, left - 10.0)))
+        self.fence()
+
+    def efficiency(self):
+        if self.rank != 0 or self.world == 1 or not self.single:
+            return
+        a, out, world = self.args, self.out, self.world
+        per = lambda v: round(v / (world * self.single), 4)
+        eff = {"definition": "whole-job edges/s / (n_gpus x single_gpu_step.edges_per_sec), all measured in this run",
+               f"in_order_{a.ids}": per(self.value)}
+        if "pipelined" in out:
+            eff[f"overlapped_{a.ids}"] = per(out["pipelined"]["edges_per_sec"])
+        other = getattr(self, "other", None)
+        oo = out.get(f"{other}_ids") if other else None
+        if oo:
+            eff[f"in_order_{other}"] = per(oo["in_order"]["edges_per_sec"])
+            if "overlapped" in oo:
+                eff[f"overlapped_{other}"] = per(oo["overlapped"]["edges_per_sec"])
+        if "edges_per_sec" in out.get("peer", {}):
+            eff[f"peer_in_order_{a.ids}"] = per(out["peer"]["edges_per_sec"])
+        if "edges_per_sec" in out.get("peer", {}).get("spatial_ids", {}):
+            eff["peer_halo_in_order_spatial"] = per(out["peer"]["spatial_ids"]["edges_per_sec"])
+            if "edges_per_sec" in (out["peer"]["spatial_ids"].get("overlapped") or {}):
+                eff["peer_halo_overlapped_spatial"] = per(out["peer"]["spatial_ids"]["overlapped"]["edges_per_sec"])
+        out["efficiency"] = eff
+
+    def leg_gficf_sharded(self):
+        """GF-ICF, cell-sharded: every rank owns a 54 k-cell block of a (54 k x n_gpus)-cell matrix; the only
+        exchange is the all-reduce(sum) of the G per-gene cell counts between the count and the scale pass."""
+        if self.strong:
+            return
+        from gficf_amd.dist import GficfShard
+
+        torch, dist, ops, world = self.torch, self.dist, self.ops, self.world
+        G, Nc = GFICF_G, GFICF_N
+        colptr, rowidx, x = synth_counts_device(torch, G, Nc, seed=7 + self.rank)
+        gs = GficfShard(ops, G, Nc * world, Nc, int(rowidx.numel()), device=self.dev)
+        for _ in range(3):
+            gs.step(colptr, rowidx, x, 0.05, 1.0)
+        self.fence()
+        reps = 10
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            gs.step(colptr, rowidx, x, 0.05, 1.0)
+        self.fence()
+        tg = torch.tensor([(time.perf_counter() - t1) / reps], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        nnz_all = torch.tensor([float(rowidx.numel())], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(nnz_all, op=dist.ReduceOp.SUM)
+        ops.sync()
+        tg, nnz_all = float(tg.item()), float(nnz_all.item())
+        self.out["gficf"] = {"metric": "gficf_cells_per_sec", "value": Nc * world / tg, "unit": "cells/s", "ms_per_pass": tg * 1e3,
+                             "config": {"workload": f"{G} genes x {Nc} cells per GPU (synthetic UMI CSC, one block per rank), "
+                                                    f"{Nc * world} cells total; 1 all-reduce of {G} int64 gene counts per pass"},
+                             "nnz_total": nnz_all, "dtype": "f64", "scaling": "weak",
+                             "roofline": {"bound": "hbm", "kernel": "whole pass, all ranks", "achieved": round(GFICF_BYTES_PER_NNZ * nnz_all / tg / 1e9, 2),
+                                          "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                          "frac": round(GFICF_BYTES_PER_NNZ * nnz_all / tg / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None}}
+
+    # ------------------------------------------------------------------------------------------------ legs of a one-GPU run
+    def leg_cpu_baseline(self):
+        if self.args.no_cpu_baseline:
+            return
+        import oracle
+
+        N_total, k = self.N_total, self.k
+        cores = os.cpu_count() or 1
+        mf = np.asfortranarray(self.mat.astype(np.float64))
+        rmh = np.empty((3, N_total * k))
+        uh = np.empty(N_total * k, dtype=np.int32)
+        L = oracle.lib()
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            L.oracle_jaccard_f64(mf.ctypes.data, N_total, k, rmh.ctypes.data, uh.ctypes.data, cores)
+            ts.append(time.perf_counter() - t1)
+        t1 = time.perf_counter()
+        L.oracle_jaccard_f64(mf.ctypes.data, N_total, k, rmh.ctypes.data, uh.ctypes.data, 2)
+        t_nt2 = time.perf_counter() - t1
+        edges_ds = N_total * k                                      # one data set
+        cpu_v = edges_ds / statistics.median(ts)
+        self.out["cpu_baseline"] = {"value": cpu_v, "unit": "edges/s", "cores": cores, "kind": "port",
+                                    "sample": f"the full workload ({N_total} cells x k={k}, same input), median of 3 passes of the oracle's "
+                                              "faithful restatement of the RcppParallel worker (g++ -O2, dynamic chunks over std::thread)",
+                                    "nt2_value": edges_ds / t_nt2, "nt2_note": "clustcells() default nt = 2 (reference R/clustCells.R:46)",
+                                    "gpu_over_cpu": self.value / cpu_v}
+
+    def leg_stress(self):
+        """Stress row: uniformly random neighbour ids — u ~ 0, no overlap to exploit, same traffic."""
+        torch, N_total, k = self.torch, self.N_total, self.k
+        try:
+            umat = self.synth.knn_uniform(N_total, k)
+            uidx = torch.from_numpy(np.ascontiguousarray(umat.T)).to(self.dev)
+            ush = self.JaccardShard(self.ops, N_total, k, device=self.dev, pipeline=False)
             t_u = time_kernel_ms(torch, lambda: ush.step(uidx), 40)
-            out["stress_uniform_ids"] = {"edges_per_sec": N_total * k / (t_u * 1e-3), "ms_per_data_set": t_u,
-                                         "nonzero_edge_fraction": float((ush.out[2] > 0).double().mean().item())}
-            del ush, uidx, umat
+            self.out["stress_uniform_ids"] = {"edges_per_sec": N_total * k / (t_u * 1e-3), "ms_per_data_set": t_u,
+                                              "nonzero_edge_fraction": float((ush.out[2] > 0).double().mean().item())}
         except Exception as ex:  # pragma: no cover
-            out["stress_uniform_ids"] = {"error": str(ex)}
-        # end-to-end through the host C ABI (what the R glue calls): H2D + ingest + edges + D2H, device scratch from the
-        # context's pool.  PCIe-inclusive: reported, never `value`.  Two forms: the reference's 24 B/edge matrix, and the
-        # compact return (2 B/edge intersection counts; gficf_jaccard_expand_host rebuilds the matrix on the host)
+            self.out["stress_uniform_ids"] = {"error": str(ex)}
+
+    def leg_host_abi(self):
+        """End to end through the host C ABI (what the R glue calls): H2D + ingest + edges + D2H, device scratch from the
+        context's pool.  PCIe-inclusive: reported, never `value`.  Two forms: the reference's 24 B/edge matrix, and the
+        compact return (2 B/edge intersection counts; gficf_jaccard_expand_host rebuilds the matrix on the host)."""
+        N_total, k = self.N_total, self.k
         try:
             import ctypes
 
             from gficf_amd import _lib
 
             L = _lib.load()
-            hm = np.asfortranarray(mat)
+            hm = np.asfortranarray(self.mat)
             E1 = N_total * k
             hr = np.empty((3, E1), dtype=np.float64)
             hu = np.empty(E1, dtype=np.uint16)
-            hctx = gficf_amd.default_context(local_rank)
-            vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+            hctx = self.gficf_amd.default_context(self.local_rank)
+            vp = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
 
             def timed(call, reps=5):
                 call()
@@ -1275,180 +1460,264 @@ def main():
                 return (time.perf_counter() - t1) / reps, rc
 
             th, rc = timed(lambda: L.gficf_jaccard_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(hr), 0))
-            out["host_abi"] = {"edges_per_sec": E1 / th, "ms_per_call": th * 1e3, "rc": rc,
-                               "note": "gficf_jaccard_host: pageable host buffers, device scratch from the context pool, PCIe both ways (12 MB in, 72 MB out)"}
+            self.out["host_abi"] = {"edges_per_sec": E1 / th, "ms_per_call": th * 1e3, "rc": rc,
+                                    "note": f"gficf_jaccard_host: pageable host buffers, device scratch from the context pool, PCIe both ways "
+                                            f"({4 * E1 / 1e6:.0f} MB in, {24 * E1 / 1e6:.0f} MB out)"}
             tc, rc = timed(lambda: L.gficf_jaccard_counts_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(hu)))
             tx, rc2 = timed(lambda: L.gficf_jaccard_expand_host(vp(hm), 0, N_total, k, N_total, vp(hu), vp(hr), 0))
-            want_full = shard.out.cpu().numpy()
-            out["host_abi_counts"] = {"edges_per_sec": E1 / tc, "ms_per_call": tc * 1e3, "rc": rc, "expand_on_host_ms": tx * 1e3,
-                                      "expanded_equals_device_matrix": bool(rc2 == 0 and np.array_equal(hr, want_full)),
-                                      "note": "gficf_jaccard_counts_host: uint16 intersection counts only (12 MB in, 6 MB out); "
-                                              "expand_on_host_ms = gficf_jaccard_expand_host rebuilding the 72 MB reference matrix on the host cores"}
+            want_full = self.shards[0].out.cpu().numpy()
+            self.out["host_abi_counts"] = {"edges_per_sec": E1 / tc, "ms_per_call": tc * 1e3, "rc": rc, "expand_on_host_ms": tx * 1e3,
+                                           "expanded_equals_device_matrix": bool(rc2 == 0 and np.array_equal(hr, want_full)),
+                                           "note": "gficf_jaccard_counts_host: uint16 intersection counts only (2 B/edge out); "
+                                                   "expand_on_host_ms = gficf_jaccard_expand_host rebuilding the reference matrix on the host cores"}
         except Exception as ex:  # pragma: no cover
-            out["host_abi"] = {"error": str(ex)}
-        if not args.no_gficf:
-            G, Nc = GFICF_G, GFICF_N
-            colptr, rowidx, x = synth_counts_device(torch, G, Nc)
-            nnz = int(rowidx.numel())
-            ws = ops.csc_workspace(G, Nc, nnz)
-            run = lambda: ops.gficf_csc(G, Nc, colptr, rowidx, x, 0.05, 1.0, None, ws)
-            for _ in range(3):
-                run()
-            torch.cuda.synchronize()
-            reps = 10
+            self.out["host_abi"] = {"error": str(ex)}
 
-            def batches(fn, n=3):
-                """n batches of `reps` passes each, device-synchronised around every batch; the figure is the FASTEST batch's mean
-                (one stall of a millisecond — seen once in ten runs — inside a 5 ms batch would otherwise move the pass by 25 %);
-                all batch means are reported."""
-                ts = []
-                for _ in range(n):
-                    t1 = time.perf_counter()
-                    for _ in range(reps):
-                        fn()
-                    torch.cuda.synchronize()
-                    ts.append((time.perf_counter() - t1) / reps)
-                return min(ts), ts
-
-            tg, tg_all = batches(run)
-            ops.sync()
-            t_scale = time_kernel_ms(torch, lambda: ops.csc_scale(G, Nc, colptr, rowidx, x, ws["genes"], ws["gkept"], ws["out_colptr"], ws["out_rowidx"], ws["out_x"]), 10)
-            t_count = time_kernel_ms(torch, lambda: ops.csc_count(G, Nc, colptr, rowidx, x, ws["nt"]), 10)
-            gf = {"metric": "gficf_cells_per_sec", "value": Nc / tg, "unit": "cells/s", "ms_per_pass": tg * 1e3,
-                  "config": {"workload": f"BASELINE config 3 shape: {G} genes x {Nc} cells synthetic UMI CSC (nnz={nnz}, SURVEY.md 8d density: "
-                                         "clipped-lognormal stored entries per cell, Zipf genes drawn without replacement), "
-                                         "gene filter 5 % + GF + ICF + L2, device-resident, compacted output",
-                             "nnz": nnz, "nnz_per_cell_median": float((colptr[1:] - colptr[:-1]).double().median().item()),
-                             "nnz_per_cell_max": int((colptr[1:] - colptr[:-1]).max().item())},
-                  "ms_per_pass_batches": [round(t * 1e3, 4) for t in tg_all],
-                  "nnz": nnz, "kept_nnz": int(ws["out_colptr"][Nc]), "kept_genes": int(ws["gkept"][0]), "dtype": "f64",
-                  "roofline": {"bound": "hbm", "kernel": "whole pass (count + colptr + scale)",
-                               "achieved": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_PEAK_GBS, 4),
-                               "frac_of_copy_rate": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_COPY_GBS, 4),
-                               "traffic": (sum(pmc[kk]["hbm_bytes_per_launch"] for kk in ("gene_count", "nt_sum_table", "cell_kept_count", "scan_lookback", "scale_cells_lds") if kk in pmc)
-                                           if all(kk in pmc for kk in ("gene_count", "cell_kept_count")) and pmc.get("gficf_nnz") == nnz else None),
-                               "scale_kernel_ms": round(t_scale, 4), "count_exact_kernel_ms": round(t_count, 4),
-                               "count_note": "count_exact_kernel_ms is gficf_csc_count_device (reads x: 12 B/nnz), the form the sharded and host entries use; the timed pass (gficf_csc_device) counts stored entries without reading x (about half that time, see the rocprof summary)",
-                               "algorithmic_bytes_per_pass": GFICF_BYTES_PER_NNZ * nnz}}
-            # the same pass with the result in the pointerB / pointerE form (cells compact inside their own input range: no global
-            # positions, so the kept-count pass and its scan do not run — three launches instead of five), which is what the
-            # device-resident chain hands on: t() of it, below, is an ordinary compact CSC again
-            ops.gficf_csc_be(G, Nc, colptr, rowidx, x, 0.05, 1.0, None, ws)
-            torch.cuda.synchronize()
-            tb, tb_all = batches(lambda: ops.gficf_csc_be(G, Nc, colptr, rowidx, x, 0.05, 1.0, None, ws))
-            ops.sync()
-            be_end, be_ri, be_x = ws["out_end"].clone(), ws["out_rowidx"].clone(), ws["out_x"].clone()
-            run()                                                   # the canonical result back in the workspace for what follows
-            ops.sync()
-            lens_be = be_end[:Nc] - colptr[:Nc]
-            cell_b = torch.repeat_interleave(torch.arange(Nc, device=dev), lens_be)
-            kn_b = int(cell_b.numel())
-            pos_b = torch.arange(kn_b, device=dev) - ws["out_colptr"][:Nc][cell_b] + colptr[:Nc][cell_b]
-            gf["roofline"]["frac_begin_end_form"] = round(GFICF_BYTES_PER_NNZ * nnz / tb / 1e9 / HBM_PEAK_GBS, 4)
-            gf["begin_end_form"] = {"ms_per_pass": tb * 1e3, "ms_per_pass_batches": [round(t * 1e3, 4) for t in tb_all], "cells_per_sec": Nc / tb,
-                                    "roofline_frac": round(GFICF_BYTES_PER_NNZ * nnz / tb / 1e9 / HBM_PEAK_GBS, 4),
-                                    "achieved_GBps": round(GFICF_BYTES_PER_NNZ * nnz / tb / 1e9, 2),
-                                    "equals_canonical_result": bool(kn_b == int(ws["out_colptr"][Nc]) and torch.equal(be_ri[pos_b], ws["out_rowidx"][:kn_b])
-                                                                    and torch.equal(be_x[pos_b], ws["out_x"][:kn_b])),
-                                    "note": "gficf_csc_be_device: count + gene table + scale (3 launches); cell c's kept entries at [colptr[c], out_end[c]) of the "
-                                            "output arrays — same entries, order and bits as the canonical compacted CSC (`value`), without the third read of "
-                                            "rowidx that global output positions cost; read directly by gficf_csc_transpose_be_device / gficf_cluster_signatures_be_device"}
-            del cell_b, pos_b, lens_be
-            # next row N3: t(gficf), the PCA input (R/dimensinalityReduction.R:33), on the matrix just produced
-            gk, kn = int(ws["gkept"][0]), int(ws["out_colptr"][Nc])
-            tws = torch.zeros(ops.csc_transpose_workspace_bytes(gk, Nc), dtype=torch.uint8, device=dev)
-            t_ptr = torch.zeros(gk + 1, dtype=torch.int64, device=dev)
-            t_idx = torch.zeros(kn, dtype=torch.int32, device=dev)
-            t_val = torch.zeros(kn, dtype=torch.float64, device=dev)
-            run_t = lambda: ops.csc_transpose(gk, Nc, ws["out_colptr"], ws["out_rowidx"][:kn], ws["out_x"][:kn], t_ptr, t_idx, t_val, tws)
-            t_tr = time_kernel_ms(torch, run_t, 10)
-            order = torch.sort(ws["out_rowidx"][:kn].long(), stable=True)[1]
-            cell = torch.repeat_interleave(torch.arange(Nc, device=dev, dtype=torch.int32), ws["out_colptr"][1:] - ws["out_colptr"][:-1])
-            t_ptr2, t_idx2, t_val2 = torch.zeros_like(t_ptr), torch.zeros_like(t_idx), torch.zeros_like(t_val)
-            run_tb = lambda: ops.csc_transpose_be(gk, Nc, colptr, be_end, be_ri, be_x, t_ptr2, t_idx2, t_val2, tws)
-            t_trb = time_kernel_ms(torch, run_tb, 10)
-            gf["begin_end_form"]["transpose_ms"] = round(t_trb, 4)
-            gf["begin_end_form"]["transpose_equals_canonical"] = bool(torch.equal(t_ptr2, t_ptr) and torch.equal(t_idx2, t_idx) and torch.equal(t_val2, t_val))
-            del t_ptr2, t_idx2, t_val2, be_end, be_ri, be_x
-            gf["transpose"] = {"ms": round(t_tr, 4), "entries": kn, "cells_per_sec": Nc / (t_tr * 1e-3),
-                               "algorithmic_GBps": round(28 * kn / t_tr / 1e6, 1),
-                               "note": "t(gficf): kept genes x cells CSC -> cells x genes CSC, 28 B/entry (4 count + 12 read + 12 written)",
-                               "checked_vs_stable_sort": bool(torch.equal(t_idx, cell[order]) and torch.equal(t_val, ws["out_x"][:kn][order]))}
-            del order, cell, tws, t_idx, t_val
-            # next row N3, first half: cluster signatures (R/clustCells.R:121-123) of the same matrix, 30 synthetic clusters
-            n_cl = 30
-            cl = (torch.arange(Nc, device=dev, dtype=torch.int64) * 2654435761 % n_cl).to(torch.int32)
-            sig = torch.zeros((n_cl, gk), dtype=torch.float64, device=dev)
-            run_s = lambda: (sig.zero_(), ops.cluster_signatures(gk, Nc, ws["out_colptr"], ws["out_rowidx"][:kn], ws["out_x"][:kn], cl, n_cl, sig))
-            t_sig = time_kernel_ms(torch, run_s, 10)
-            want = torch.zeros((n_cl, gk), dtype=torch.float64, device=dev)
-            cell_of = torch.repeat_interleave(torch.arange(Nc, device=dev), ws["out_colptr"][1:] - ws["out_colptr"][:-1])
-            want.index_put_((cl[cell_of].long(), ws["out_rowidx"][:kn].long()), ws["out_x"][:kn], accumulate=True)
-            gf["cluster_signatures"] = {"ms": round(t_sig, 4), "clusters": n_cl, "algorithmic_GBps": round(12 * kn / t_sig / 1e6, 1),
-                                        "note": "G x C sums of gficf[, cluster == c] (12 B/entry read; cells grouped by cluster, sums kept in LDS per workgroup)",
-                                        "checked_vs_torch": bool(torch.allclose(sig, want, rtol=1e-9, atol=1e-12))}
-            del cell_of, want, sig
-            if not args.no_cpu_baseline:
-                import oracle
-
-                hcp, hri, hx = colptr.cpu().numpy(), rowidx.cpu().numpy(), x.cpu().numpy()
-                t1 = time.perf_counter()
-                ref = oracle.gficf_csc(G, Nc, hcp, hri, hx, 0.05, 1.0)
-                tc1 = time.perf_counter() - t1
-                cores = os.cpu_count() or 1
-                t1 = time.perf_counter()
-                ref_mt = oracle.gficf_csc(G, Nc, hcp, hri, hx, 0.05, 1.0, threads=cores)
-                tc = time.perf_counter() - t1
-                kn = int(ws["out_colptr"][Nc])
-                gf["cpu_baseline"] = {"value": Nc / tc, "unit": "cells/s", "cores": cores, "kind": "port",
-                                      "sample": "the full matrix, one pass of the oracle's multi-threaded restatement of R/gficf.R (cells cut into "
-                                                "ranges of equal stored entries, one host thread each; same bits as the single-threaded one)",
-                                      "single_thread_value": Nc / tc1,
-                                      "single_thread_note": "the reference path itself is single-threaded R on the Matrix package (cannot run here)",
-                                      "threads_give_same_bits": bool(np.array_equal(ref["x"], ref_mt["x"]) and np.array_equal(ref["nt"], ref_mt["nt"])),
-                                      "gpu_over_cpu": (Nc / tg) / (Nc / tc)}
-                gf["checked_vs_oracle"] = bool(kn == len(ref["x"]) and np.array_equal(ws["out_rowidx"][:kn].cpu().numpy(), ref["rowidx"])
-                                               and np.allclose(ws["out_x"][:kn].cpu().numpy(), ref["x"], rtol=1e-6, atol=1e-6))
-            out["gficf"] = gf
-        if not args.no_knn:
-            out["knn"] = bench_knn(torch, ops, args)
-
-    progress("gficf")
-    if world > 1 and not args.no_gficf and not strong and not args.no_extras:
-        # GF-ICF, cell-sharded: every rank owns a 54 k-cell block of a (54 k x n_gpus)-cell matrix; the only
-        # exchange is the all-reduce(sum) of the G per-gene cell counts between the count and the scale pass
-        from gficf_amd.dist import GficfShard
-
+    def leg_gficf(self):
+        a, torch, ops, dev = self.args, self.torch, self.ops, self.dev
         G, Nc = GFICF_G, GFICF_N
-        colptr, rowidx, x = synth_counts_device(torch, G, Nc, seed=7 + rank)
-        gs = GficfShard(ops, G, Nc * world, Nc, int(rowidx.numel()), device=dev)
+        pmc = getattr(self, "pmc", {})
+        colptr, rowidx, x = synth_counts_device(torch, G, Nc)
+        nnz = int(rowidx.numel())
+        ws = ops.csc_workspace(G, Nc, nnz)
+        run = lambda: ops.gficf_csc(G, Nc, colptr, rowidx, x, 0.05, 1.0, None, ws)
         for _ in range(3):
-            gs.step(colptr, rowidx, x, 0.05, 1.0)
-        fence()
+            run()
+        torch.cuda.synchronize()
         reps = 10
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            gs.step(colptr, rowidx, x, 0.05, 1.0)
-        fence()
-        tg = torch.tensor([(time.perf_counter() - t1) / reps], dtype=torch.float64, device=dev)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
-        nnz_all = torch.tensor([float(rowidx.numel())], dtype=torch.float64, device=dev)
-        dist.all_reduce(nnz_all, op=dist.ReduceOp.SUM)
+
+        def batches(fn, n=5):
+            """n batches of `reps` passes each, device-synchronised around every batch; the figure is the MEDIAN batch's mean (round 4
+            quoted the fastest batch, and its record the fastest of four boxes on top: one selection too many); all batch means are
+            reported."""
+            ts = []
+            for _ in range(n):
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t1) / reps)
+            return statistics.median(ts), ts
+
+        tg, tg_all = batches(run)
         ops.sync()
-        tg, nnz_all = float(tg.item()), float(nnz_all.item())
-        out["gficf"] = {"metric": "gficf_cells_per_sec", "value": Nc * world / tg, "unit": "cells/s", "ms_per_pass": tg * 1e3,
-                        "config": {"workload": f"{G} genes x {Nc} cells per GPU (synthetic UMI CSC, one block per rank), "
-                                               f"{Nc * world} cells total; 1 all-reduce of {G} int64 gene counts per pass"},
-                        "nnz_total": nnz_all, "dtype": "f64", "scaling": "weak",
-                        "roofline": {"bound": "hbm", "kernel": "whole pass, all ranks", "achieved": round(GFICF_BYTES_PER_NNZ * nnz_all / tg / 1e9, 2),
-                                     "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                                     "frac": round(GFICF_BYTES_PER_NNZ * nnz_all / tg / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None}}
-    if rank == 0 and not guard["done"]:
-        guard["done"] = True
-        print(json.dumps(out))
+        t_scale = time_kernel_ms(torch, lambda: ops.csc_scale(G, Nc, colptr, rowidx, x, ws["genes"], ws["gkept"], ws["out_colptr"], ws["out_rowidx"], ws["out_x"]), 10)
+        t_count = time_kernel_ms(torch, lambda: ops.csc_count(G, Nc, colptr, rowidx, x, ws["nt"]), 10)
+        gf = {"metric": "gficf_cells_per_sec", "value": Nc / tg, "unit": "cells/s", "ms_per_pass": tg * 1e3,
+              "config": {"workload": f"BASELINE config 3 shape: {G} genes x {Nc} cells synthetic UMI CSC (nnz={nnz}, SURVEY.md 8d density: "
+                                     "clipped-lognormal stored entries per cell, Zipf genes drawn without replacement), "
+                                     "gene filter 5 % + GF + ICF + L2, device-resident, compacted output",
+                         "nnz": nnz, "nnz_per_cell_median": float((colptr[1:] - colptr[:-1]).double().median().item()),
+                         "nnz_per_cell_max": int((colptr[1:] - colptr[:-1]).max().item())},
+              "ms_per_pass_batches": [round(t * 1e3, 4) for t in tg_all], "ms_per_pass_is": "median of the batch means",
+              "nnz": nnz, "kept_nnz": int(ws["out_colptr"][Nc]), "kept_genes": int(ws["gkept"][0]), "dtype": "f64",
+              "roofline": {"bound": "hbm", "kernel": "whole pass (count + colptr + scale)",
+                           "achieved": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_PEAK_GBS, 4),
+                           "frac_of_copy_rate": round(GFICF_BYTES_PER_NNZ * nnz / tg / 1e9 / HBM_COPY_GBS, 4),
+                           "traffic": (sum(pmc[kk]["hbm_bytes_per_launch"] for kk in ("gene_count", "nt_sum_table", "cell_kept_count", "scan_lookback", "scale_cells_lds") if kk in pmc)
+                                       if all(kk in pmc for kk in ("gene_count", "cell_kept_count")) and pmc.get("gficf_nnz") == nnz else None),
+                           "scale_kernel_ms": round(t_scale, 4), "count_exact_kernel_ms": round(t_count, 4),
+                           "count_note": "count_exact_kernel_ms is gficf_csc_count_device (reads x: 12 B/nnz), the form the sharded and host entries use; the timed pass (gficf_csc_device) counts stored entries without reading x (about half that time, see the rocprof summary)",
+                           "algorithmic_bytes_per_pass": GFICF_BYTES_PER_NNZ * nnz}}
+        # the same pass with the result in the pointerB / pointerE form (cells compact inside their own input range: no global
+        # positions, so the kept-count pass and its scan do not run — three launches instead of five), which is what the
+        # device-resident chain hands on: t() of it, below, is an ordinary compact CSC again
+        ops.gficf_csc_be(G, Nc, colptr, rowidx, x, 0.05, 1.0, None, ws)
+        torch.cuda.synchronize()
+        tb, tb_all = batches(lambda: ops.gficf_csc_be(G, Nc, colptr, rowidx, x, 0.05, 1.0, None, ws))
+        ops.sync()
+        be_end, be_ri, be_x = ws["out_end"].clone(), ws["out_rowidx"].clone(), ws["out_x"].clone()
+        run()                                                   # the canonical result back in the workspace for what follows
+        ops.sync()
+        lens_be = be_end[:Nc] - colptr[:Nc]
+        cell_b = torch.repeat_interleave(torch.arange(Nc, device=dev), lens_be)
+        kn_b = int(cell_b.numel())
+        pos_b = torch.arange(kn_b, device=dev) - ws["out_colptr"][:Nc][cell_b] + colptr[:Nc][cell_b]
+        gf["roofline"]["frac_begin_end_form"] = round(GFICF_BYTES_PER_NNZ * nnz / tb / 1e9 / HBM_PEAK_GBS, 4)
+        gf["begin_end_form"] = {"ms_per_pass": tb * 1e3, "ms_per_pass_batches": [round(t * 1e3, 4) for t in tb_all], "cells_per_sec": Nc / tb,
+                                "roofline_frac": round(GFICF_BYTES_PER_NNZ * nnz / tb / 1e9 / HBM_PEAK_GBS, 4),
+                                "achieved_GBps": round(GFICF_BYTES_PER_NNZ * nnz / tb / 1e9, 2),
+                                "equals_canonical_result": bool(kn_b == int(ws["out_colptr"][Nc]) and torch.equal(be_ri[pos_b], ws["out_rowidx"][:kn_b])
+                                                                and torch.equal(be_x[pos_b], ws["out_x"][:kn_b])),
+                                "note": "gficf_csc_be_device: count + gene table + scale (3 launches); cell c's kept entries at [colptr[c], out_end[c]) of the "
+                                        "output arrays — same entries, order and bits as the canonical compacted CSC (`value`), without the third read of "
+                                        "rowidx that global output positions cost; read directly by gficf_csc_transpose_be_device / gficf_cluster_signatures_be_device"}
+        del cell_b, pos_b, lens_be
+        # next row N3: t(gficf), the PCA input (R/dimensinalityReduction.R:33), on the matrix just produced
+        gk, kn = int(ws["gkept"][0]), int(ws["out_colptr"][Nc])
+        tws = torch.zeros(ops.csc_transpose_workspace_bytes(gk, Nc), dtype=torch.uint8, device=dev)
+        t_ptr = torch.zeros(gk + 1, dtype=torch.int64, device=dev)
+        t_idx = torch.zeros(kn, dtype=torch.int32, device=dev)
+        t_val = torch.zeros(kn, dtype=torch.float64, device=dev)
+        run_t = lambda: ops.csc_transpose(gk, Nc, ws["out_colptr"], ws["out_rowidx"][:kn], ws["out_x"][:kn], t_ptr, t_idx, t_val, tws)
+        t_tr = time_kernel_ms(torch, run_t, 10)
+        order = torch.sort(ws["out_rowidx"][:kn].long(), stable=True)[1]
+        cell = torch.repeat_interleave(torch.arange(Nc, device=dev, dtype=torch.int32), ws["out_colptr"][1:] - ws["out_colptr"][:-1])
+        t_ptr2, t_idx2, t_val2 = torch.zeros_like(t_ptr), torch.zeros_like(t_idx), torch.zeros_like(t_val)
+        run_tb = lambda: ops.csc_transpose_be(gk, Nc, colptr, be_end, be_ri, be_x, t_ptr2, t_idx2, t_val2, tws)
+        t_trb = time_kernel_ms(torch, run_tb, 10)
+        gf["begin_end_form"]["transpose_ms"] = round(t_trb, 4)
+        gf["begin_end_form"]["transpose_equals_canonical"] = bool(torch.equal(t_ptr2, t_ptr) and torch.equal(t_idx2, t_idx) and torch.equal(t_val2, t_val))
+        del t_ptr2, t_idx2, t_val2, be_end, be_ri, be_x
+        gf["transpose"] = {"ms": round(t_tr, 4), "entries": kn, "cells_per_sec": Nc / (t_tr * 1e-3),
+                           "algorithmic_GBps": round(28 * kn / t_tr / 1e6, 1),
+                           "note": "t(gficf): kept genes x cells CSC -> cells x genes CSC, 28 B/entry (4 count + 12 read + 12 written)",
+                           "checked_vs_stable_sort": bool(torch.equal(t_idx, cell[order]) and torch.equal(t_val, ws["out_x"][:kn][order]))}
+        del order, cell, tws, t_idx, t_val
+        # next row N3, first half: cluster signatures (R/clustCells.R:121-123) of the same matrix, 30 synthetic clusters
+        n_cl = 30
+        cl = (torch.arange(Nc, device=dev, dtype=torch.int64) * 2654435761 % n_cl).to(torch.int32)
+        sig = torch.zeros((n_cl, gk), dtype=torch.float64, device=dev)
+        run_s = lambda: (sig.zero_(), ops.cluster_signatures(gk, Nc, ws["out_colptr"], ws["out_rowidx"][:kn], ws["out_x"][:kn], cl, n_cl, sig))
+        t_sig = time_kernel_ms(torch, run_s, 10)
+        want = torch.zeros((n_cl, gk), dtype=torch.float64, device=dev)
+        cell_of = torch.repeat_interleave(torch.arange(Nc, device=dev), ws["out_colptr"][1:] - ws["out_colptr"][:-1])
+        want.index_put_((cl[cell_of].long(), ws["out_rowidx"][:kn].long()), ws["out_x"][:kn], accumulate=True)
+        gf["cluster_signatures"] = {"ms": round(t_sig, 4), "clusters": n_cl, "algorithmic_GBps": round(12 * kn / t_sig / 1e6, 1),
+                                    "note": "G x C sums of gficf[, cluster == c] (12 B/entry read; cells grouped by cluster, sums kept in LDS per workgroup)",
+                                    "checked_vs_torch": bool(torch.allclose(sig, want, rtol=1e-9, atol=1e-12))}
+        del cell_of, want, sig
+        hcp = hri = hx = None
+        if not a.no_cpu_baseline or not a.no_host_gficf:
+            hcp, hri, hx = colptr.cpu().numpy(), rowidx.cpu().numpy(), x.cpu().numpy()
+        ref = None
+        if not a.no_cpu_baseline:
+            import oracle
+
+            t1 = time.perf_counter()
+            ref = oracle.gficf_csc(G, Nc, hcp, hri, hx, 0.05, 1.0)
+            tc1 = time.perf_counter() - t1
+            cores = os.cpu_count() or 1
+            t1 = time.perf_counter()
+            ref_mt = oracle.gficf_csc(G, Nc, hcp, hri, hx, 0.05, 1.0, threads=cores)
+            tc = time.perf_counter() - t1
+            kn = int(ws["out_colptr"][Nc])
+            gf["cpu_baseline"] = {"value": Nc / tc, "unit": "cells/s", "cores": cores, "kind": "port",
+                                  "sample": "the full matrix, one pass of the oracle's multi-threaded restatement of R/gficf.R (cells cut into "
+                                            "ranges of equal stored entries, one host thread each; same bits as the single-threaded one)",
+                                  "single_thread_value": Nc / tc1,
+                                  "single_thread_note": "the reference path itself is single-threaded R on the Matrix package (cannot run here)",
+                                  "threads_give_same_bits": bool(np.array_equal(ref["x"], ref_mt["x"]) and np.array_equal(ref["nt"], ref_mt["nt"])),
+                                  "gpu_over_cpu": (Nc / tg) / (Nc / tc)}
+            gf["checked_vs_oracle"] = bool(kn == len(ref["x"]) and np.array_equal(ws["out_rowidx"][:kn].cpu().numpy(), ref["rowidx"])
+                                           and np.allclose(ws["out_x"][:kn].cpu().numpy(), ref["x"], rtol=1e-6, atol=1e-6))
+            del ref_mt
+        if not a.no_host_gficf:
+            # end to end through the host C ABI (what `.Call("_gficf_gficf_csc", ...)` binds): plan (H2D of @p / @i / @x, count, filter) +
+            # finish (scale, D2H of the compacted matrix), pageable host buffers.  PCIe-inclusive: reported, never `value`.
+            try:
+                gf["host_abi"] = host_gficf_figure(self.gficf_amd, self.local_rank, G, Nc, hcp, hri, hx, ref)
+            except Exception as ex:  # pragma: no cover
+                gf["host_abi"] = {"error": f"{type(ex).__name__}: {ex}"}
+        self.out["gficf"] = gf
+
+    def leg_knn(self):
+        self.out["knn"] = bench_knn(self.torch, self.ops, self.args)
+
+
+def host_gficf_figure(gficf_amd, device, G, N, colptr, rowidx, x, ref=None, reps=2):
+    """gficf_normalize_csc_host_plan + _finish on host arrays (int32 colptr when it fits, as a dgCMatrix holds it)."""
+    import ctypes
+
+    from gficf_amd import _lib
+
+    L = _lib.load()
+    ctx = gficf_amd.default_context(device)
+    nnz = int(len(rowidx))
+    i64 = nnz >= 2**31
+    cp = np.ascontiguousarray(colptr, dtype=np.int64 if i64 else np.int32)
+    vp = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
+    gk, nk = ctypes.c_int64(0), ctypes.c_int64(0)
+    ts, out = [], None
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        rc = L.gficf_normalize_csc_host_plan(ctx.handle, G, N, vp(cp), 1 if i64 else 0, vp(rowidx), vp(x), ctypes.c_double(0.05), ctypes.c_double(1.0), None,
+                                             ctypes.byref(gk), ctypes.byref(nk))
+        if rc != 0:
+            raise RuntimeError(f"gficf_normalize_csc_host_plan returned {rc}: {_lib.last_error()}")
+        t_plan = time.perf_counter() - t0
+        keep = np.empty(G, dtype=np.uint8)
+        nt = np.empty(G, dtype=np.int64)
+        w = np.empty(G, dtype=np.float64)
+        ocp = np.empty(N + 1, dtype=cp.dtype)
+        ori = np.empty(nk.value, dtype=np.int32)
+        ox = np.empty(nk.value, dtype=np.float64)
+        rc = L.gficf_normalize_csc_host_finish(ctx.handle, vp(keep), vp(nt), vp(w), vp(ocp), vp(ori), vp(ox))
+        if rc != 0:
+            raise RuntimeError(f"gficf_normalize_csc_host_finish returned {rc}: {_lib.last_error()}")
+        ts.append((time.perf_counter() - t0, t_plan))
+        out = (ori, ox)
+    t_all, t_plan = min(ts[1:])                                         # (the first call grows the context's pool)
+    res = {"ms_per_call": t_all * 1e3, "ms_plan": t_plan * 1e3, "ms_finish": (t_all - t_plan) * 1e3, "cells_per_sec": N / t_all,
+           "bytes_in": int(cp.nbytes + rowidx.nbytes + x.nbytes), "bytes_out": int(12 * nk.value + cp.nbytes + 17 * G),
+           "kept_nnz": int(nk.value), "kept_genes": int(gk.value),
+           "note": "gficf_normalize_csc_host_plan + _finish: pageable host arrays in, freshly allocated host arrays out (as the R glue allocates them), "
+                   "device scratch from the context pool, PCIe both ways; the faster of 2 calls after a first one that grows the pool"}
+    if ref is not None:
+        res["checked_vs_oracle"] = bool(len(ref["x"]) == nk.value and np.array_equal(out[0], ref["rowidx"]) and np.allclose(out[1], ref["x"], rtol=1e-6, atol=1e-6))
+    ctx_trim = getattr(L, "gficf_ctx_trim", None)
+    if ctx_trim is not None:
+        ctx_trim(ctx.handle)                                            # (a GB of pooled scratch handed back before the next leg)
+    return res
+
+
+def main():
+    args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL and peer mappings across processes need on this driver (before any HIP call)
+    if args.traffic_child:
+        return traffic_child(args)
+    if args.peer_child:
+        return peer_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and never touches a
+        # GPU itself; rank 0 prints its JSON lines straight to our stdout.  (Under torch.distributed.run the rank
+        # environment is already there and this branch is not taken.)  The launcher's own limit follows the wall budget.
+        from gficf_amd import launch
+
+        raise SystemExit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                            need_gpus=None if args.rehearse_one_gpu else args.gpus,
+                                            timeout_s=float(os.environ.get("GFICF_BENCH_LAUNCH_TIMEOUT", str(args.budget_s + 150.0)))))
+    B = Bench(args)
+    world, rank, ops = B.world, B.rank, B.ops
+    extras = not args.no_extras
+    B.start_watchdog()
+    B.progress("value")
+    t0 = time.monotonic()
+    B.leg_value()
+    B.leg_seconds["value"] = time.monotonic() - t0
+    B.legs_done.append("value")
+    # N > 1: from here on the line holds `value`, its roofline, the exchange and the oracle check: printed NOW, and again after every leg
+    B.progress()
+    B.emit()
+    if args.pipeline or (extras and (world > 1 or not B.strong)):
+        B.run_leg("pipelined", B.leg_pipelined)
+    if world > 1 and extras:
+        # ---- the rest of the scaling answer, in this one run (same box, same processes, same clocks)
+        B.run_leg("other_ids", B.leg_other_ids)
+        B.run_leg("single_gpu_step", B.leg_single_gpu_step)
+        if not args.no_chain:
+            B.run_leg("chain", B.leg_chain)
+        if not args.no_peer:
+            B.run_leg("peer", B.leg_peer)
+        B.efficiency()
+    if B.distinct:
+        ops.set_jaccard_distinct(False)
+    if world == 1 and extras and not B.strong:
+        B.run_leg("cpu_baseline", B.leg_cpu_baseline)
+        B.run_leg("stress", B.leg_stress)
+        B.run_leg("host_abi", B.leg_host_abi)
+        if not args.no_gficf:
+            B.run_leg("gficf", B.leg_gficf)
+        if not args.no_knn:
+            B.run_leg("knn", B.leg_knn)
+    if world > 1 and extras and not args.no_gficf:
+        B.run_leg("gficf", B.leg_gficf_sharded)
+    if rank == 0 and not B.guard["done"]:
+        B.guard["done"] = True
+        print(B.line(), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        B.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

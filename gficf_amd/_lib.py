@@ -47,6 +47,8 @@ SIGNATURES = {
     "gficf_ctx_set_louvain_options": (_int, [_vp, _int]),
     "gficf_ctx_set_jaccard_options": (_int, [_vp, _int]),
     "gficf_ctx_set_jaccard_distinct": (_int, [_vp, _int]),
+    "gficf_ctx_set_jaccard_direct_max_edges": (_int, [_vp, _i64]),
+    "gficf_jaccard_one_launch": (_int, [_vp, _i64, _int]),
     "gficf_last_error": (ctypes.c_char_p, []),
     "gficf_ctx_set_print": (_int, [_vp, _vp]),
     "gficf_ctx_trim": (_int, [_vp]),

@@ -34,6 +34,7 @@ class Context:
         self._h = ctypes.c_void_p()
         check(_lib.load().gficf_ctx_create(int(device), ctypes.c_void_p(stream or 0), ctypes.byref(self._h)))
         self.device = int(device)
+        self._stream = int(stream or 0)          # what the library's context is bound to (set_stream skips the call when unchanged)
 
     @property
     def handle(self):
@@ -42,7 +43,10 @@ class Context:
         return self._h
 
     def set_stream(self, stream: int | None):
-        check(_lib.load().gficf_ctx_set_stream(self.handle, ctypes.c_void_p(stream or 0)))
+        s = int(stream or 0)
+        if s != self._stream:
+            check(_lib.load().gficf_ctx_set_stream(self.handle, ctypes.c_void_p(s)))
+            self._stream = s
 
     def sync(self):
         """Wait for the stream; raises GficfError for deferred input-validation failures."""
@@ -54,6 +58,11 @@ class Context:
         a row does repeat an id — discard the edges then and re-run ingest + edges with the option off.  Only for the
         single-context sequence over all cells (``gficf_ctx_set_jaccard_distinct``); the host entries do this by themselves."""
         check(_lib.load().gficf_ctx_set_jaccard_distinct(self.handle, 1 if assume_distinct else 0))
+
+    def set_jaccard_direct_max_edges(self, max_edges: int):
+        """Edges (N * k) up to which the single-device Jaccard sequence runs as ONE launch without a table, k <= 32, rows taken
+        to hold distinct ids (``gficf_ctx_set_jaccard_direct_max_edges``); -1 = the build's default, 0 = never."""
+        check(_lib.load().gficf_ctx_set_jaccard_direct_max_edges(self.handle, int(max_edges)))
 
     def close(self):
         if self._h:
@@ -735,9 +744,15 @@ class HipOps:
         self.device = int(device)
         self.ctx = Context(self.device)
         self.L = _lib.load()
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+    def current_stream(self) -> int:
+        """torch's current stream of this device as a raw hipStream_t (no Stream object built: this sits on every enqueue)."""
+        raw = self._raw_stream
+        return raw(self.device) if raw is not None else self.torch.cuda.current_stream(self.device).cuda_stream
 
     def _bind(self):
-        self.ctx.set_stream(self.torch.cuda.current_stream(self.device).cuda_stream)
+        self.ctx.set_stream(self.current_stream())
         return self.ctx.handle
 
     def sync(self):
@@ -747,6 +762,14 @@ class HipOps:
     def set_jaccard_distinct(self, assume_distinct: bool):
         """See :meth:`Context.set_jaccard_distinct` (the option belongs to the context these ops enqueue on)."""
         self.ctx.set_jaccard_distinct(assume_distinct)
+
+    def set_jaccard_direct_max_edges(self, max_edges: int):
+        """See :meth:`Context.set_jaccard_direct_max_edges`."""
+        self.ctx.set_jaccard_direct_max_edges(max_edges)
+
+    def jaccard_one_launch(self, N: int, k: int) -> bool:
+        """Would :meth:`jaccard` build an N x k problem in ONE launch, as the context is set up now?"""
+        return bool(self.L.gficf_jaccard_one_launch(self.ctx.handle, int(N), int(k)))
 
     # -- Jaccard
     @staticmethod
@@ -897,6 +920,33 @@ class HipOps:
         ld = idx_cm.shape[1] if idx_cm.dim() == 2 else N
         check(self.L.gficf_jaccard_device(self._bind(), _tptr(idx_cm), is_f64, N, k, ld, _tptr(table_ws),
                                           _tptr(rmat3), _tptr(u)))
+
+    def jaccard_prepared(self, idx_cm, N: int, k: int, table_ws, rmat3, u=None):
+        """The same call with every argument converted ONCE: returns ``run()``, one call into the library per invocation
+        (gficf_jaccard_device: for a small problem under gficf_ctx_set_jaccard_distinct ONE launch, otherwise ingest + edges), on
+        torch's current stream at the time of the invocation.  For steps of a few microseconds, where building the ctypes
+        arguments of :meth:`jaccard` costs as much as the kernels (BASELINE configs 1 - 3).  The tensors are kept alive by the
+        callable and must not be resized."""
+        tc = self.torch
+        is_f64 = 1 if idx_cm.dtype == tc.float64 else 0
+        if not is_f64 and idx_cm.dtype != tc.int32:
+            raise ValueError("idx must be int32 or float64")
+        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else N
+        if rmat3.shape != (3, N * k) or rmat3.dtype != tc.float64:
+            raise ValueError(f"rmat3 must be float64 of shape (3, {N * k})")
+        fn, ctx, cur = self.L.gficf_jaccard_device, self.ctx, self.current_stream
+        args = (ctx.handle, _tptr(idx_cm), is_f64, int(N), int(k), int(ld), _tptr(table_ws), _tptr(rmat3), _tptr(u))
+
+        def run():
+            s = cur()
+            if s != ctx._stream:
+                ctx.set_stream(s)
+            rc = fn(*args)
+            if rc:
+                check(rc)
+
+        run.keep = (idx_cm, table_ws, rmat3, u)
+        return run
 
     # -- exact kNN (next row N2)
     @staticmethod

@@ -49,6 +49,8 @@ struct gficf_ctx {
   // gficf_ctx_set_jaccard_distinct: the ingest does not look for duplicate ids inside a row; the edge kernel, which meets every
   // one while it builds the row's hash set, raises GFICF_ST_DUP_IDS instead (deferred; the caller re-runs with the option off)
   int jaccard_assume_distinct = 0;
+  // gficf_ctx_set_jaccard_direct_max_edges: edges up to which gficf_jaccard_device takes the one-launch form (-1: the build's default)
+  int64_t jaccard_direct_max_edges = -1;
   int quiet_rerun = 0;               // a host entry re-runs its sequence after GFICF_ERR_DUPLICATE_IDS: banners are not printed again
   gficf_host_plan* plan = nullptr;
   gficf_edge_plan* edge_plan = nullptr;

@@ -185,6 +185,12 @@ int gficf_ctx_set_jaccard_distinct(gficf_ctx* ctx, int assume_distinct) {
   return GFICF_OK;
 }
 
+int gficf_ctx_set_jaccard_direct_max_edges(gficf_ctx* ctx, int64_t max_edges) {
+  if (!ctx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ctx is NULL");
+  ctx->jaccard_direct_max_edges = max_edges < 0 ? -1 : max_edges;
+  return GFICF_OK;
+}
+
 int gficf_ctx_sync(gficf_ctx* ctx) {
   GFICF_CTX_ENTER(ctx);
   GFICF_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

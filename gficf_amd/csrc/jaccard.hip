@@ -1586,7 +1586,13 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
 #endif
 constexpr int BITS_WAVES = GFICF_BITS_WAVES;
 constexpr int BITS_DEPTH = GFICF_BITS_DEPTH;                  // cells in flight per wave (2..4)
+#ifdef GFICF_BITS_WHATIF_HALF_SET
+// LAB ONLY (tools/lab/build_bits_variants.sh): a bit set of half the size — ids alias, the counts are WRONG — to see what the kernel
+// would gain from sixteen resident waves per CU instead of eight (profiles/r05_bits_kernel.txt).  Never in the product build.
+constexpr uint32_t BITS_WB = 8192u;
+#else
 constexpr uint32_t BITS_WB = 16384u;                          // LDS bytes of one wave's bit set
+#endif
 constexpr uint32_t BITS_LUT_OFF = BITS_WAVES * BITS_WB;
 constexpr uint32_t BITS_DUPF_OFF = BITS_LUT_OFF + 64u * 8u;   // weight table: k + 1 <= 56 doubles
 constexpr size_t BITS_LDS_BYTES = BITS_DUPF_OFF + BITS_WAVES * 4u;
@@ -1614,7 +1620,11 @@ __global__ __launch_bounds__(BITS_WAVES * 64) void k_jaccard_edges_bits(
   __syncthreads();
 
   const uint32_t wbase = lds_address(smem) + (uint32_t)(tid >> 6) * BITS_WB;   // a multiple of 16 KiB (dynamic LDS starts at 0: no static LDS here)
+#ifdef GFICF_BITS_WHATIF_HALF_SET
+  uint32_t mask_v = 0x0FFCu;
+#else
   uint32_t mask_v = 0x1FFCu;                                   // word offset inside a plane, as a vector register (operand of v_bitop3_b32)
+#endif
   asm volatile("" : "+v"(mask_v));
   const char* const tbytes = reinterpret_cast<const char*>(table);
   const int grow = lane >> 3, gl = lane & 7;
@@ -1727,24 +1737,64 @@ __global__ __launch_bounds__(BITS_WAVES * 64) void k_jaccard_edges_bits(
     bool dup_here = false;
     uint32_t my_addr = wbase;
     if (has) {                                                  // row i into the bit set
+#ifdef GFICF_BITS_WHATIF_HALF_SET
+      my_addr = wbase + ((a >> 16) << 12) + ((((a & 0xFFFFu) >> 5) << 2) & 0x0FFCu);
+      const uint32_t m = 1u << (a & 31u);
+      (void)lds_or_rtn_b32(my_addr, m);
+#else
       my_addr = wbase + ((a >> 16) << 13) + (((a & 0xFFFFu) >> 5) << 2);
       const uint32_t m = 1u << (a & 31u);
       dup_here = (lds_or_rtn_b32(my_addr, m) & m) != 0u;        // already there: the row names the id twice
+#endif
     }
     wave_lds_fence();
     uint32_t hflags = araw;
     int myu = 0;
+#ifdef GFICF_BITS_PREFETCH
+    // LAB VARIANT (profiles/r05_bits_kernel.txt): the eight set reads of step st + 1 are issued before the counts of step st are taken
+    {
+      uint32_t w4[2][4], bw[2][8];
+      auto issue = [&](int st, uint32_t (&w)[4], uint32_t (&b)[8]) {
+        const uint32_t hdr = bcast8(bv[st].w, std::integral_constant<int, 7>{});
+        hflags |= hdr;
+        const bool p1 = (uint32_t)gl >= (hdr & 15u);
+        const uint32_t base = wbase | (p1 ? (BITS_WB >> 1) : 0u);
+        w[0] = bv[st].x; w[1] = bv[st].y; w[2] = bv[st].z; w[3] = gl == 7 ? (p1 ? 0xFFFFFFFFu : 0u) : bv[st].w;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          b[2 * c] = lds_read_b32(bitop3<0xEA>(w[c] >> 3, mask_v, base));
+          b[2 * c + 1] = lds_read_b32(bitop3<0xEA>(w[c] >> 19, mask_v, base));
+        }
+      };
+      issue(0, w4[0], bw[0]);
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        if (st + 1 < NST) issue(st + 1, w4[(st + 1) & 1], bw[(st + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cnt += (shr5(bw[st & 1][2 * c], w4[st & 1][c]) & 1u) + (shr5(bw[st & 1][2 * c + 1], w4[st & 1][c] >> 16) & 1u);
+        const int rowcnt = group_sum<8>((int)cnt);
+        myu = gl == st ? rowcnt : myu;
+      }
+    }
+#else
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
       const uint32_t hdr = bcast8(bv[st].w, std::integral_constant<int, 7>{});   // the row's header word sits in its eighth lane
       hflags |= hdr;
       const bool p1 = (uint32_t)gl >= (hdr & 15u);                               // this lane's 8 ids: first or second plane
+#ifdef GFICF_BITS_WHATIF_HALF_SET
+      const uint32_t base = wbase | (p1 ? 0x1000u : 0u);
+#else
       const uint32_t base = wbase | (p1 ? 0x2000u : 0u);
+#endif
       const uint32_t w4[4] = {bv[st].x, bv[st].y, bv[st].z, gl == 7 ? (p1 ? 0xFFFFFFFFu : 0u) : bv[st].w};   // (the header is not an id: the plane's pad instead)
       const int c = probe_piece(w4, base);
       const int rowcnt = group_sum<8>(c);                                        // every lane of the group: the row's count
       myu = gl == st ? rowcnt : myu;                                             // ... kept by the lane that owns slot st * 8 + g
     }
+#endif
     if (has) lds_write_b32(my_addr, 0u);                        // the set is empty again (lanes sharing a word write the same zero)
     if (dup_here) *reinterpret_cast<uint32_t*>(smem + BITS_DUPF_OFF + (uint32_t)wave * 4u) = 1u;   // reported at the kernel's end
     wave_lds_fence();
@@ -1851,6 +1901,13 @@ static_assert(std::is_same<decltype(&k_jaccard_edges<32, false, false, OUT_RMAT,
               "the edge kernels' parameter list and EdgeKernArgs differ: edge_kernel_dup_status() would read a wrong slot");
 
 #include "jaccard_sorted.h"
+
+// edges up to which gficf_jaccard_device builds a small problem in ONE launch, without a table (jaccard_direct.h; measured
+// crossover against ingest + edge kernel: profiles/r05_direct_ab.txt)
+#ifndef GFICF_JACCARD_DIRECT_DEFAULT_EDGES
+#define GFICF_JACCARD_DIRECT_DEFAULT_EDGES 65536
+#endif
+#include "jaccard_direct.h"
 
 // ------------------------------------------------------------------ edge filter (N1)
 // The caller's next line, relations[relations[,3] > 0, ] (reference R/clustCells.R:66), on the
@@ -2462,11 +2519,19 @@ int gficf_jaccard_edges_mapped_device(gficf_ctx* ctx, const int32_t* d_table, in
   return launch_edges_k(ctx, (const uint32_t*)d_table, n_ext, k, 0, n_cells, o);
 }
 
+int gficf_jaccard_one_launch(gficf_ctx* ctx, int64_t N, int k) { return (ctx && direct_applies(ctx, N, k)) ? 1 : 0; }
+
 int gficf_jaccard_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int64_t N, int k, int64_t ld,
                          int32_t* d_table_ws, double* d_rmat, int32_t* d_u) {
+  const int64_t E = N * (int64_t)k;
+  if (ctx && direct_applies(ctx, N, k) && d_idx && d_rmat && ld >= N) {
+    // a small problem whose rows are taken to hold distinct ids: one launch straight from the input, no table (d_table_ws unused)
+    GFICF_CTX_ENTER(ctx);
+    EdgeOut o{d_rmat, d_rmat + E, d_rmat + 2 * E, d_u, nullptr, 0};
+    return launch_direct(ctx, d_idx, idx_is_f64, N, k, ld, o);
+  }
   int rc = gficf_jaccard_ingest_device(ctx, d_idx, idx_is_f64, N, k, ld, N, d_table_ws);
   if (rc) return rc;
-  const int64_t E = N * (int64_t)k;
   return gficf_jaccard_edges_device(ctx, d_table_ws, N, k, 0, N, d_rmat, d_rmat + E, d_rmat + 2 * E, d_u);
 }
 
@@ -2556,10 +2621,11 @@ static int gficf_jaccard_counts_host_body(gficf_ctx* ctx, const void* idx, int i
   if (e == hipSuccess) e = gficf_pool_get(ctx, 2, sizeof(uint16_t) * (size_t)E, (void**)&d_u);
   if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, esz * (size_t)ld * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    rc = gficf_jaccard_ingest_device(ctx, d_idx, idx_is_f64, N, k, ld, N, d_table);
-    if (!rc) {
-      EdgeOut o{nullptr, nullptr, nullptr, nullptr, d_u, 0};
-      rc = launch_edges_k(ctx, (const uint32_t*)d_table, N, k, 0, N, o);
+    EdgeOut o{nullptr, nullptr, nullptr, nullptr, d_u, 0};
+    if (direct_applies(ctx, N, k)) rc = launch_direct(ctx, d_idx, idx_is_f64, N, k, ld, o);      // small problem: one launch, no table
+    else {
+      rc = gficf_jaccard_ingest_device(ctx, d_idx, idx_is_f64, N, k, ld, N, d_table);
+      if (!rc) rc = launch_edges_k(ctx, (const uint32_t*)d_table, N, k, 0, N, o);
     }
     if (!rc) e = hipMemcpyAsync(u, d_u, sizeof(uint16_t) * (size_t)E, hipMemcpyDeviceToHost, ctx->stream);
     if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);

@@ -158,6 +158,7 @@ class JaccardShard:
         self.us = [torch.zeros(self.n_local * self.k, dtype=torch.int32, device=device) if with_u else None for _ in range(nbuf)]
         self.table, self.out, self.u = self.tables[0], self.outs[0], self.us[0]
         self.t = 0
+        self._prepared = {}                     # one rank: prepared single-call steps by input block (see step)
         # N > 1: rows travel bit-packed (ceil(log2(N+1)) bits per id) and are unpacked after the all-gather
         self.packed = None
         if self.world > 1 and packed_transport and exchange == "allgather":
@@ -232,6 +233,17 @@ class JaccardShard:
         (global 1-based ids).  Returns this rank's (3, n_local*k) slice of the edge matrix (valid in
         stream order on the caller's current stream)."""
         if not self.pipeline:
+            if self.world == 1 and self.exchange == "allgather" and not self.time_edges and self.n_local > 0:
+                # one rank: nothing to exchange — the library's single-device sequence in ONE call (for a small problem under
+                # set_jaccard_distinct that is one launch), its arguments converted once per input block
+                key = (idx_local_cm.data_ptr(), tuple(idx_local_cm.shape))
+                run = self._prepared.get(key)
+                if run is None:
+                    if len(self._prepared) >= 64:
+                        self._prepared.clear()
+                    run = self._prepared[key] = self.ops.jaccard_prepared(idx_local_cm, self.N, self.k, self.table, self.out, self.u)
+                run()
+                return self.out
             self._fill_table(self.table, idx_local_cm)
             if self.time_edges:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -473,24 +485,59 @@ class JaccardHaloShard:
             return
         from ._lib import STATUS_NAMES, GficfError
 
-        err, code = None, 0
+        # Every rank joins the all-reduce whatever its own sync did (an exception that skipped it would leave the others waiting),
+        # and the reduced word carries the NUMERIC status (severity, status code, rank), so a status outside the severity table
+        # arrives as itself.
+        err, other, sev, num = None, None, 0, 0
         try:
             self.ops.sync()
         except GficfError as ex:
-            err, code = ex, _STATUS_SEVERITY.get(ex.status, 1)
-        # one small all-reduce: (severity, -rank) MAX picks the most severe status and, among equals, the lowest rank
+            err, sev, num = ex, _STATUS_SEVERITY.get(ex.status, 5), int(ex.code)
+        except BaseException as ex:                               # noqa: BLE001  (re-raised below, behind the collective)
+            other, sev, num = ex, 6, 5                            # counted as a HIP-level failure on the other ranks
         dev = self.out.device if dist.get_backend(self.group) != "gloo" else torch.device("cpu")
-        t = torch.tensor([code * 4096 + (4095 - self.rank) if code else 0], dtype=torch.int64, device=dev)
+        t = torch.tensor([(sev * 256 + num) * 4096 + (4095 - self.rank) if sev else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        if other is not None:
+            raise other
         top = int(t.item())
         if top == 0:
             return
-        sev, who = top // 4096, 4095 - top % 4096
-        if err is not None and code == sev:
+        who, word = 4095 - top % 4096, top // 4096
+        top_sev, top_num = word // 256, word % 256
+        if err is not None and sev == top_sev and num == top_num:
             raise err
-        status = next(s for s, v in _STATUS_SEVERITY.items() if v == sev)
-        num = next(c for c, n in STATUS_NAMES.items() if n == status)
-        raise GficfError(num, f"rank {who} reported {status} in the sharded Jaccard step (this rank's own block was fine); every rank fails alike")
+        status = STATUS_NAMES.get(top_num, f"status {top_num}")
+        raise GficfError(top_num, f"rank {who} reported {status} in the sharded Jaccard step (this rank's own block was fine); every rank fails alike")
+
+
+def assert_same_format(ops, N_total: int, k: int, group=None, device=None, extra: tuple = ()):
+    """Every rank of a sharded Jaccard build must lay table rows out alike: the row pitch is a function of (N, k) AND of the
+    library build (ABI version) and its GFICF_JACCARD_* switches, which are read from each rank's own environment.  One
+    all-gather of a few words, once, before the first step; raises on EVERY rank (they all see the same gathered words) when
+    two ranks differ.  ``extra``: further integers the caller wants agreed on (e.g. the halo form's capacity)."""
+    import os
+    import zlib
+
+    from . import _lib
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return
+    L = _lib.load()
+    env = "|".join(f"{k_}={v}" for k_, v in sorted(os.environ.items()) if k_.startswith("GFICF_JACCARD_") or k_ in ("GFICF_BITS_WAVES", "GFICF_BITS_DEPTH"))
+    words = [int(L.gficf_hip_abi_version()), int(ops.row_words(N_total, k)), int(ops.kpad(k)), int(ops.packed_words(N_total, k)),
+             zlib.crc32(env.encode()), int(N_total), int(k)] + [int(v) for v in extra]
+    gloo = dist.get_backend(group) == "gloo"
+    mine = torch.tensor(words, dtype=torch.int64, device="cpu" if gloo or device is None else device)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine, group=group)
+    rows = [tuple(int(v) for v in t.tolist()) for t in got]
+    if any(r != rows[0] for r in rows):
+        names = ["abi_version", "row_words", "kpad", "packed_words", "crc32(GFICF_JACCARD_* environment)", "N_total", "k"] + [f"extra[{i}]" for i in range(len(extra))]
+        diff = [n for i, n in enumerate(names) if any(r[i] != rows[0][i] for r in rows)]
+        raise RuntimeError(f"the ranks of this sharded Jaccard build do not agree on the table format: {diff} differ across ranks "
+                           f"(per rank: {rows}); start every rank with the same library and the same GFICF_JACCARD_* environment")
 
 
 class GficfShard:

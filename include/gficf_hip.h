@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFICF_HIP_ABI_VERSION 5
+#define GFICF_HIP_ABI_VERSION 6
 
 typedef enum gficf_status {
   GFICF_OK = 0,
@@ -132,6 +132,17 @@ int gficf_ctx_set_jaccard_options(gficf_ctx* ctx, int truncate_noninteger_ids);
  * fast sequence and re-run the exact one by themselves when it is needed: their results are the reference's for every input.
  * Default: off. */
 int gficf_ctx_set_jaccard_distinct(gficf_ctx* ctx, int assume_distinct);
+
+/* Small problems in ONE launch (round 5; csrc/jaccard_direct.h).  With gficf_ctx_set_jaccard_distinct on, gficf_jaccard_device (and
+ * with it gficf_jaccard_host / gficf_jaccard_counts_host, which turn the option on themselves) builds a problem of at most
+ * max_edges = N * k edges, k <= 32, straight from the column-major input in one kernel, without a table (d_table_ws is not
+ * touched): at BASELINE config 1 (3 000 x 15) a step is bound by its two launches, not by bytes (6.2 us against 8.0).  A row that
+ * repeats an id raises the same deferred GFICF_ERR_DUPLICATE_IDS as the table path.  max_edges < 0: the build's default — k <= 16
+ * and N * k <= 65 536, the measured crossover (GFICF_JACCARD_DIRECT_MAX_EDGES in the environment overrides the edge count);
+ * 0: never. */
+int gficf_ctx_set_jaccard_direct_max_edges(gficf_ctx* ctx, int64_t max_edges);
+/* 1 if gficf_jaccard_device on this context, as it is set up now, builds an N x k problem in that one launch; 0 otherwise. */
+int gficf_jaccard_one_launch(gficf_ctx* ctx, int64_t N, int k);
 
 /* Compact host return (the reference's 24 B row is a function of (i, idx[i,j], u)): the intersection counts alone,
  * u[i*k + j], 2 B per edge across PCIe instead of 24.  gficf_jaccard_expand_host rebuilds the reference's (N*k) x 3

@@ -31,7 +31,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_abi_version_and_kpad():
     L = _lib.load()
-    assert L.gficf_hip_abi_version() == 5
+    assert L.gficf_hip_abi_version() == 6
     assert [L.gficf_jaccard_kpad(k) for k in (0, 1, 15, 16, 17, 30, 32, 33, 50, 64, 65, 128, 129, 256)] == \
         [16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 128, 128, 256, 256]
     # k > 256: "sorted" rows (slot-order ids + the same ids ascending, each half padded to 64): kpad = row pitch = 2 * ceil64(k)

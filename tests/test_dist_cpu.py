@@ -294,3 +294,38 @@ def test_collective_sync_raises_the_same_error_on_every_rank(tmp_path):
     assert all(m.startswith("GFICF_ERR_CAPACITY|") for m in msgs), msgs
     assert "test double" in msgs[0]                                   # rank 0 saw it itself
     assert all("rank 0 reported GFICF_ERR_CAPACITY" in m for m in msgs[1:])
+
+
+def _format_worker(rank, world, port, outdir, differ):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if differ and rank == 1:
+        os.environ["GFICF_JACCARD_DUAL"] = "0"          # one rank started under another environment: it would lay 100 k x 50 rows out in 32 words, not 64
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import gficf_amd
+        from gficf_amd.dist import assert_same_format
+
+        res = "same"
+        try:
+            assert_same_format(gficf_amd.HipOps, 100_000, 50)      # (row_words / kpad / packed_words are static: pure host functions of the library)
+        except RuntimeError as ex:
+            res = str(ex)
+        with open(os.path.join(outdir, f"fmt_{rank}.txt"), "w") as f:
+            f.write(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("differ", [False, True])
+def test_ranks_compare_their_table_format_before_the_first_step(tmp_path, differ):
+    """the table format is a function of (N, k) only while every rank has the same library and the same
+    GFICF_JACCARD_* environment — exchanged and asserted once; a rank that differs makes EVERY rank raise, naming what differs."""
+    world = 2
+    mp.spawn(_format_worker, args=(world, _free_port(), str(tmp_path), differ), nprocs=world, join=True)
+    msgs = [open(tmp_path / f"fmt_{r}.txt").read() for r in range(world)]
+    if not differ:
+        assert msgs == ["same", "same"]
+    else:
+        for m in msgs:
+            assert "row_words" in m and "crc32(GFICF_JACCARD_* environment)" in m and "do not agree" in m

@@ -9,7 +9,7 @@ import pytest
 
 import gficf_amd
 import oracle
-from gficf_amd import synth
+from gficf_amd import _lib, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -153,9 +153,11 @@ def test_out_of_range_ids_are_rejected():
 
 
 def test_unsupported_k_and_empty_inputs():
-    with pytest.raises(gficf_amd.GficfError) as ei:
-        gficf_amd.rcpp_parallel_jaccard_coef(np.ones((300, 257), dtype=np.int32), False)
-    assert ei.value.status == "GFICF_ERR_UNSUPPORTED"
+    # k beyond 256 is supported since round 5 (the sorted-row path); what stays unsupported is k beyond the uint16 counts
+    got = gficf_amd.rcpp_parallel_jaccard_coef(np.ones((300, 257), dtype=np.int32), False)     # every row names cell 1, 257 times
+    want, _ = oracle.jaccard(np.ones((300, 257), dtype=np.int32), nthreads=4)
+    assert np.array_equal(got, want) and np.all(got[:, 2] == 1.0)
+    assert _lib.load().gficf_jaccard_row_words(100, 65536) == -1
     assert gficf_amd.rcpp_parallel_jaccard_coef(np.zeros((0, 5), dtype=np.int32), False).shape == (0, 3)
     assert gficf_amd.rcpp_parallel_jaccard_coef(np.zeros((7, 0), dtype=np.int32), False).shape == (0, 3)
 
@@ -988,7 +990,7 @@ def test_k_beyond_256_multiset_and_set_semantics(ops, k, mod):
     assert wu.max() > 1
     assert np.array_equal(gficf_amd.jaccard_coeff(mat, False), oracle.jaccard_coeff(mat))
     cnt = gficf_amd.jaccard_counts(mat)
-    assert np.array_equal(cnt.astype(np.int32), wu)
+    assert np.array_equal(cnt.astype(np.int32).reshape(-1), wu)
     assert np.array_equal(gficf_amd.jaccard_expand(mat, cnt), want)
     neigh = np.concatenate([np.arange(1, N + 1, dtype=np.int32)[:, None], mat], axis=1)
     rel = gficf_amd.jaccard_edges(neigh)
@@ -1073,3 +1075,70 @@ def test_k_in_the_thousands_rows_searched_in_the_table(ops):
     got = out.cpu().numpy()
     assert np.array_equal(got[0], np.full(k, cell + 1.0)) and np.array_equal(got[1], mat[cell].astype(np.float64))
     assert np.array_equal(got[2], wu / (2.0 * k - wu))                                    # reference :51, same IEEE division
+
+
+# ---------------------------------------------------------------- small problems in ONE launch (csrc/jaccard_direct.h; round 5)
+@pytest.mark.parametrize("N,k", [(1, 1), (2, 1), (64, 5), (500, 1), (777, 16), (777, 17), (1000, 32), (3000, 15), (10000, 30), (40000, 9)])
+def test_one_launch_form_matches_oracle_and_the_table_path(ops, N, k):
+    """gficf_jaccard_device under set_jaccard_distinct for N * k below the threshold: one kernel straight from the column-major
+    input (no table).  Bit for bit the oracle's matrix and the table path's, int32 and double ids, with and without counts."""
+    import torch
+
+    if N > 2 * k + 2:
+        mat = synth.knn_windowed(N, k, W=max(100, k), seed=N + k, perm_seed=3)
+    else:
+        mat = np.stack([np.random.default_rng(i).permutation(N)[:k] + 1 for i in range(N)]).astype(np.int32).reshape(N, k)
+    want, wu = oracle.jaccard(mat, nthreads=8)
+    ops.set_jaccard_distinct(True)
+    try:
+        for limit, dt in ((10**7, torch.int32), (10**7, torch.float64), (0, torch.int32)):          # 0: the table path, for comparison
+            ops.set_jaccard_direct_max_edges(limit)
+            idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda().to(dt)
+            table = torch.full((N, ops.kpad(k)), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+            rmat = torch.full((3, N * k), -7.0, dtype=torch.float64, device="cuda")
+            u = torch.full((N * k,), -7, dtype=torch.int32, device="cuda")
+            ops.jaccard(idx, N, k, table, rmat, u)
+            ops.sync()
+            assert np.array_equal(rmat.cpu().numpy().T, want) and np.array_equal(u.cpu().numpy(), wu), (limit, dt)
+            assert bool((table == 0x5A5A5A5A).all()) == (limit > 0)                               # one launch: the table is not touched
+            run = ops.jaccard_prepared(idx, N, k, table, rmat.fill_(-7.0), None)                   # the prepared single-call form
+            run()
+            ops.sync()
+            assert np.array_equal(rmat.cpu().numpy().T, want)
+    finally:
+        ops.set_jaccard_direct_max_edges(-1)
+        ops.set_jaccard_distinct(False)
+
+
+def test_one_launch_form_reports_bad_and_repeated_ids(ops):
+    import torch
+
+    N, k = 2000, 15
+    mat = synth.knn_windowed(N, k, seed=4)
+    table = torch.zeros((N, ops.kpad(k)), dtype=torch.int32, device="cuda")
+    rmat = torch.zeros((3, N * k), dtype=torch.float64, device="cuda")
+    ops.set_jaccard_distinct(True)
+    ops.set_jaccard_direct_max_edges(10**7)
+    try:
+        for r, c, v, status in ((17, 3, N + 1, "GFICF_ERR_BAD_ID"), (1999, 14, 0, "GFICF_ERR_BAD_ID"), (5, 2, None, "GFICF_ERR_DUPLICATE_IDS")):
+            m = mat.copy()
+            m[r, c] = m[r, c + 1 if c + 1 < k else 0] if v is None else v
+            ops.jaccard(torch.from_numpy(np.ascontiguousarray(m.T)).cuda(), N, k, table, rmat, None)
+            with pytest.raises(gficf_amd.GficfError) as ei:
+                ops.sync()
+            assert ei.value.status == status
+        # a non-integer double is a bad id here too
+        md = mat.astype(np.float64)
+        md[100, 0] += 0.5
+        ops.jaccard(torch.from_numpy(np.ascontiguousarray(md.T)).cuda(), N, k, table, rmat, None)
+        with pytest.raises(gficf_amd.GficfError) as ei:
+            ops.sync()
+        assert ei.value.status == "GFICF_ERR_BAD_ID"
+    finally:
+        ops.set_jaccard_direct_max_edges(-1)
+        ops.set_jaccard_distinct(False)
+    # the host entries take the one-launch form first and re-run the exact sequence for a matrix whose rows repeat ids
+    dup = (synth.rand_u64(3, np.arange(900 * 12)).reshape(900, 12) % np.uint64(40)).astype(np.int32) + 1
+    want, wu = oracle.jaccard(dup, nthreads=4)
+    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(dup, False), want)
+    assert np.array_equal(gficf_amd.jaccard_counts(dup).astype(np.int32).reshape(-1), wu)

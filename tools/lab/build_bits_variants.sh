@@ -6,7 +6,8 @@ cd "$(dirname "$0")/../../gficf_amd/csrc"
 make -s
 mkdir -p ../../tools/lab/abl_bits
 for V in "$@"; do
-  set -- $V; D=$1; W=$2
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -I../../include -DGFICF_BITS_DEPTH=$D -DGFICF_BITS_WAVES=$W -c jaccard.hip -o /tmp/jaccard_d${D}w${W}.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/lab/abl_bits/libgficf_hip_d${D}w${W}.so ctx.o /tmp/jaccard_d${D}w${W}.o halo.o gficf_csc.o knn.o adjacency.o transpose.o louvain.o phenograph.o multi.o
+  set -- $V; D=$1; W=$2; X=${3:-}     # X: extra macro of a lab variant (PREFETCH, WHATIF_HALF_SET — the latter gives WRONG counts: timing only)
+  N=d${D}w${W}${X:+_$X}
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -I../../include -DGFICF_BITS_DEPTH=$D -DGFICF_BITS_WAVES=$W ${X:+-DGFICF_BITS_$X} -c jaccard.hip -o /tmp/jaccard_$N.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/lab/abl_bits/libgficf_hip_$N.so ctx.o /tmp/jaccard_$N.o halo.o gficf_csc.o knn.o adjacency.o transpose.o louvain.o phenograph.o multi.o
 done
