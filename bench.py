@@ -742,11 +742,11 @@ T_PROCESS_START = time.monotonic()
 
 # Legs of a run, in order.  `value` (the timed region, its roofline, the exchange figures and the oracle check) always runs; the
 # others are further objects of the same line and can be selected with --legs.  N > 1: every leg is entered by all ranks together.
-LEGS_ONE_GPU = ["value", "pipelined", "cpu_baseline", "stress", "host_abi", "gficf", "knn"]
+LEGS_ONE_GPU = ["value", "pipelined", "spatial_ids", "cpu_baseline", "stress", "host_abi", "gficf", "knn"]
 LEGS_MULTI = ["value", "pipelined", "other_ids", "single_gpu_step", "chain", "peer", "gficf"]
 # seconds a leg is expected to need at most (a leg is skipped, and named in `skipped_legs`, when less than this is left of --budget-s)
 LEG_RESERVE_S = {"pipelined": 10, "other_ids": 40, "single_gpu_step": 20, "chain": 60, "peer": 60, "gficf": 40, "cpu_baseline": 40,
-                 "stress": 10, "host_abi": 15, "knn": 60}
+                 "stress": 10, "host_abi": 15, "knn": 60, "spatial_ids": 30}
 
 
 class Bench:
@@ -1246,7 +1246,39 @@ class Bench:
 
     # ------------------------------------------------------------------------------------------------ legs shared by N = 1 and N > 1
     def leg_pipelined(self):
+        if self.world == 1:
+            # one rank: nothing to exchange and nothing worth overlapping — JaccardShard(pipeline=True) refuses the two-table / three-stream
+            # form and runs its steps in order on the caller's stream (gficf_amd/dist.py says why), i.e. it runs `value`'s own loop: the
+            # figure IS `value`, no second measurement
+            self.out["pipelined"] = {"edges_per_sec": self.value, "ms_per_data_set": self.out["ms_per_data_set"], "refused_on_one_rank": True,
+                                     "note": "one rank: JaccardShard(pipeline=True) runs in order (pipeline_in_order): the steps of `value`, not a second measurement"}
+            return
         self.out["pipelined"] = self.measure_overlapped(self.exchange, self.idx_local)
+
+    def leg_spatial_ids_one_gpu(self):
+        """One GPU, the big single-data-set configs (4 and 5): the same step on ids WITH locality — cells numbered in their spatial
+        order, what the device kNN search's pivot order gives (gficf_knn_pivot_order_device; KnnShard.step_ordered) — next to `value`
+        on permuted ids: what the walk order is worth to the edge kernel when it comes for free."""
+        a, torch, ops = self.args, self.torch, self.ops
+        other = "spatial" if a.ids == "permuted" else "permuted"
+        idx_o, _ = self.make_inputs(other, False)
+        sh = self.make_shards("allgather", 1)[0]
+        step_o = lambda: sh.step(idx_o[0])
+        if self.distinct:
+            ops.set_jaccard_distinct(True)
+        dt_o, _ = self.timed(step_o, a.steps, a.warmup)
+        sh.sync()
+        t_edges = time_kernel_ms(torch, lambda: ops.jaccard_edges(sh.table, self.N_total, self.k, 0, self.N_total, sh.out, None), max(a.steps, 20))
+        import oracle
+
+        mat_o = self.synth.knn_windowed(self.N_total, self.k, seed=42, perm_seed=43 if other == "permuted" else None)
+        run = min(1024, self.n_local)
+        want, _ = oracle.jaccard_cells(mat_o, 0, run, nthreads=os.cpu_count() or 1)
+        alg = JACCARD_BYTES_PER_EDGE * self.N_total * self.k
+        self.out[f"{other}_ids"] = {"ids": other, "edges_per_sec": self.N_total * self.k * a.steps / dt_o, "ms_per_data_set": dt_o / a.steps * 1e3,
+                                    "kernel_ms": round(t_edges, 5), "roofline_frac": round(alg / (t_edges * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "checked_vs_oracle": bool(np.array_equal(sh.out[:, :run * self.k].cpu().numpy().T, want)),
+                                    "note": "the same single-GPU step on the other id model (one data set, in order); kernel_ms: the edge kernel back to back, one event pair"}
 
     # ------------------------------------------------------------------------------------------------ legs of an N > 1 run
     def leg_other_ids(self):
@@ -1701,6 +1733,8 @@ def main():
         if not args.no_peer:
             B.run_leg("peer", B.leg_peer)
         B.efficiency()
+    if world == 1 and extras and B.strong and B.N_total >= 100_000:
+        B.run_leg("spatial_ids", B.leg_spatial_ids_one_gpu)
     if B.distinct:
         ops.set_jaccard_distinct(False)
     if world == 1 and extras and not B.strong:

@@ -89,6 +89,7 @@ SIGNATURES = {
     "gficf_jaccard_edges_mapped_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _vp, _vp]),
     "gficf_jaccard_edges_filtered_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_jaccard_edges_filtered_mapped_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_filtered_host_plan": (_int, [_vp, _vp, _int, _i64, _int, _i64, ctypes.POINTER(_i64)]),
     "gficf_jaccard_filtered_host_finish": (_int, [_vp, _vp, _vp, _vp]),
     "gficf_adjacency_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),

@@ -1926,7 +1926,8 @@ template <int KPAD, bool CMP>
 __global__ __launch_bounds__(256) void k_edge_write(const uint32_t* __restrict__ table, const uint16_t* __restrict__ u16,
                                                     int k, int64_t cell_begin, int64_t n_cells,
                                                     const int64_t* __restrict__ ptr, double* __restrict__ from,
-                                                    double* __restrict__ to, double* __restrict__ weight, int pitch) {
+                                                    double* __restrict__ to, double* __restrict__ weight, int pitch,
+                                                    const int32_t* __restrict__ order) {
   __shared__ double s_lut[GFICF_JACCARD_MAX_K + 1];
   for (int u = threadIdx.x; u <= k; u += 256) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);   // reference :51
   __syncthreads();
@@ -1947,8 +1948,9 @@ __global__ __launch_bounds__(256) void k_edge_write(const uint32_t* __restrict__
       const unsigned long long m = __ballot(kp);
       if (kp) {
         const int64_t d = pos + __popcll(m & lt_mask);
-        from[d] = (double)(uint32_t)(cell_begin + c + 1);
-        to[d] = (double)dst;
+        // order != NULL: the table is in a renumbering of the cells (row p = original cell order[p]): both columns in original ids
+        from[d] = order ? (double)(order[cell_begin + c] + 1) : (double)(uint32_t)(cell_begin + c + 1);
+        to[d] = order ? (double)(order[dst - 1u] + 1) : (double)dst;
         weight[d] = s_lut[u];
       }
       pos += __popcll(m);
@@ -2730,7 +2732,8 @@ int gficf_jaccard_unpack_rows_device(gficf_ctx* ctx, const uint32_t* d_packed, i
 }
 
 static int edges_filtered(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k, int64_t cell_begin, int64_t cell_end,
-                          uint16_t* d_u_ws, int64_t* d_cell_ptr, double* d_from, double* d_to, double* d_weight, int set_mode) {
+                          uint16_t* d_u_ws, int64_t* d_cell_ptr, double* d_from, double* d_to, double* d_weight, int set_mode,
+                          const int32_t* d_order = nullptr) {
   GFICF_CTX_ENTER(ctx);
   int rc = check_nk(N, k);
   if (rc) return rc;
@@ -2759,13 +2762,13 @@ static int edges_filtered(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int
   if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
   if (sorted_fmt(k)) {
     hipLaunchKernelGGL(k_edge_write_sorted, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, t, d_u_ws, k, cell_begin, n_cells, d_cell_ptr, d_from,
-                       d_to, d_weight, sorted_kp(k));
+                       d_to, d_weight, sorted_kp(k), d_order);
     GFICF_HIP_CHECK(hipGetLastError());
     return GFICF_OK;
   }
 #define LAUNCH_EW(KP, CM)                                                                                               \
   hipLaunchKernelGGL((k_edge_write<KP, CM>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, t, d_u_ws, k, cell_begin, \
-                     n_cells, d_cell_ptr, d_from, d_to, d_weight, pitch)
+                     n_cells, d_cell_ptr, d_from, d_to, d_weight, pitch, d_order)
   const bool cm = table_fmt(N, k).compact;
   const int pitch = table_fmt(N, k).row_words;
   switch (kpad_for(k)) {
@@ -2784,6 +2787,13 @@ int gficf_jaccard_edges_filtered_device(gficf_ctx* ctx, const int32_t* d_table, 
                                         int64_t cell_end, uint16_t* d_u_ws, int64_t* d_cell_ptr, double* d_from,
                                         double* d_to, double* d_weight) {
   return edges_filtered(ctx, d_table, N, k, cell_begin, cell_end, d_u_ws, d_cell_ptr, d_from, d_to, d_weight, 0);
+}
+
+int gficf_jaccard_edges_filtered_mapped_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k, int64_t cell_begin,
+                                               int64_t cell_end, uint16_t* d_u_ws, int64_t* d_cell_ptr, double* d_from,
+                                               double* d_to, double* d_weight, const int32_t* d_order) {
+  if (!d_order) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer (d_order)");
+  return edges_filtered(ctx, d_table, N, k, cell_begin, cell_end, d_u_ws, d_cell_ptr, d_from, d_to, d_weight, 0, d_order);
 }
 
 // host form of the filtered build: plan runs everything and returns the edge count, finish copies out.

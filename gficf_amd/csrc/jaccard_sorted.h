@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void k_jaccard_edges_sorted(const uint32_t* __
 // ordered compacted write of the edge filter for sorted rows (k_edge_write's job; the neighbour column from the slot-order half)
 __global__ __launch_bounds__(256) void k_edge_write_sorted(const uint32_t* __restrict__ table, const uint16_t* __restrict__ u16, int k,
                                                            int64_t cell_begin, int64_t n_cells, const int64_t* __restrict__ ptr,
-                                                           double* __restrict__ from, double* __restrict__ to, double* __restrict__ weight, int kp) {
+                                                           double* __restrict__ from, double* __restrict__ to, double* __restrict__ weight, int kp,
+                                                           const int32_t* __restrict__ order) {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const double twok = 2.0 * (double)k;
@@ -195,8 +196,8 @@ __global__ __launch_bounds__(256) void k_edge_write_sorted(const uint32_t* __res
       const unsigned long long m = __ballot(keep);
       if (keep) {
         const int64_t d = pos + __popcll(m & lt_mask);
-        from[d] = (double)(uint32_t)(cell_begin + c + 1);
-        to[d] = (double)dst;
+        from[d] = order ? (double)(order[cell_begin + c] + 1) : (double)(uint32_t)(cell_begin + c + 1);
+        to[d] = order ? (double)(order[dst - 1u] + 1) : (double)dst;
         weight[d] = (double)u / (twok - (double)u);           // reference :51
       }
       pos += __popcll(m);

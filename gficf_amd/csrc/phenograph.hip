@@ -23,6 +23,35 @@ struct Carver {
   }
 };
 
+// ---- the Jaccard stage on cells renumbered by locality (round 5).  From 2^17 cells on the table takes 128 B rows and, with ids in
+// the order the caller's matrix happens to have, nearly every gathered row is an L2 miss (1 M x 30: 697 us, 5.5 x the algorithmic
+// bytes).  The search has just computed an order in which neighbours sit next to each other — its (coarse, fine) pivot order — so
+// the index matrix is relabelled into that numbering (row p = original cell order[p], ids through the inverse), the edge kernel
+// walks cells whose rows its XCD's L2 already holds, and the kept edges come out in the ORIGINAL ids
+// (gficf_jaccard_edges_filtered_mapped_device); the adjacency build sorts them anyway.  The neighbour lists are the plain
+// search's own (the relabelling happens behind it): the graph, and so the labels, are those of the unordered chain for every input.
+__global__ __launch_bounds__(256) void k_invert_order(const int32_t* __restrict__ order, int32_t* __restrict__ inv, int64_t N) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < N) inv[order[p]] = (int32_t)p;
+}
+
+// out (k x N column-major, new numbering) from idx (kk x N column-major, original ids, column 0 = the cell itself: dropped)
+__global__ __launch_bounds__(256) void k_relabel_idx(const int32_t* __restrict__ idx, const int32_t* __restrict__ order,
+                                                     const int32_t* __restrict__ inv, int32_t* __restrict__ out, int64_t N, int k) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= N) return;
+  const int64_t c = order[p];
+  for (int j = 0; j < k; ++j) {
+    const int32_t id = idx[(int64_t)(j + 1) * N + c];
+    out[(int64_t)j * N + p] = (id >= 1 && id <= N) ? inv[id - 1] + 1 : id;      // (an id the search cannot produce stays what it is: the ingest reports it)
+  }
+}
+
+bool phenograph_ordered(int64_t N) {
+  if (const char* e = getenv("GFICF_PHENOGRAPH_ORDER")) return atoi(e) != 0;    // A/B switch, read per call
+  return N >= (1ll << 17);
+}
+
 }  // namespace
 
 extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N, int d, int64_t ld, int k, int metric, double resolution,
@@ -43,13 +72,16 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
   const int kk = k + 1;
   const int64_t cap = N * (int64_t)k;
   const size_t knn_ws = gficf_knn_workspace_bytes(ctx, N, N, kk), adj_ws = gficf_adjacency_workspace_bytes(N, cap);
+  const bool ordered = phenograph_ordered(N);
+  const size_t order_ws = ordered ? gficf_knn_workspace_bytes(ctx, N, N, 1) : 0;
   void *d_X, *d_P, *d_kws, *d_idx, *d_table, *d_u, *d_cptr, *d_e3, *d_aws, *d_indptr, *d_indices, *d_ax, *d_lab;
+  void *d_order = nullptr, *d_inv = nullptr, *d_idx2 = nullptr;
   Carver cv;
   for (int pass = 0; pass < 2; ++pass) {               // pass 0 sizes the block, pass 1 hands the pointers out
     cv.off = 0;
     d_X = cv.take<double>((size_t)ld * (size_t)d);
     d_P = cv.take<float>((size_t)N * (size_t)dpad);
-    d_kws = cv.take<char>(knn_ws);
+    d_kws = cv.take<char>(knn_ws > order_ws ? knn_ws : order_ws);
     d_idx = cv.take<int32_t>((size_t)N * (size_t)kk);
     d_table = cv.take<int32_t>((size_t)N * (size_t)kpad);
     d_u = cv.take<uint16_t>((size_t)cap);
@@ -60,6 +92,11 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
     d_indices = cv.take<int32_t>(2 * (size_t)cap);
     d_ax = cv.take<double>(2 * (size_t)cap);
     d_lab = cv.take<int32_t>((size_t)N);
+    if (ordered) {
+      d_order = cv.take<int32_t>((size_t)N);
+      d_inv = cv.take<int32_t>((size_t)N);
+      d_idx2 = cv.take<int32_t>((size_t)N * (size_t)k);
+    }
     if (pass == 0) {
       void* blk = nullptr;
       const hipError_t e0 = gficf_pool_get(ctx, 0, cv.off + 256, &blk);
@@ -74,9 +111,23 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
   double* from = (double*)d_e3;
   int rc = gficf_knn_prepare_device(ctx, d_X, 1, N, d, ld, metric, (float*)d_P);
   if (!rc) rc = gficf_knn_search_device(ctx, (const float*)d_P, N, d, kk, metric, 0, N, d_kws, knn_ws, (int32_t*)d_idx, nullptr, N);
-  if (!rc) rc = gficf_jaccard_ingest_device(ctx, (const int32_t*)d_idx + N, 0, N, k, N, N, (int32_t*)d_table);
-  if (!rc) rc = gficf_jaccard_edges_filtered_device(ctx, (const int32_t*)d_table, N, k, 0, N, (uint16_t*)d_u, (int64_t*)d_cptr, from, from + cap,
-                                                    from + 2 * cap);
+  if (!rc && ordered) {
+    rc = gficf_knn_pivot_order_device(ctx, (const float*)d_P, N, d, metric, d_kws, knn_ws > order_ws ? knn_ws : order_ws, (int32_t*)d_order);
+    if (!rc) {
+      const unsigned nb = (unsigned)gficf_ceil_div(N, 256);
+      hipLaunchKernelGGL(k_invert_order, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t*)d_order, (int32_t*)d_inv, N);
+      hipLaunchKernelGGL(k_relabel_idx, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t*)d_idx, (const int32_t*)d_order, (const int32_t*)d_inv,
+                         (int32_t*)d_idx2, N, k);
+      if (hipGetLastError() != hipSuccess) rc = GFICF_ERR_HIP;
+    }
+    if (!rc) rc = gficf_jaccard_ingest_device(ctx, (const int32_t*)d_idx2, 0, N, k, N, N, (int32_t*)d_table);
+    if (!rc) rc = gficf_jaccard_edges_filtered_mapped_device(ctx, (const int32_t*)d_table, N, k, 0, N, (uint16_t*)d_u, (int64_t*)d_cptr, from, from + cap,
+                                                             from + 2 * cap, (const int32_t*)d_order);
+  } else {
+    if (!rc) rc = gficf_jaccard_ingest_device(ctx, (const int32_t*)d_idx + N, 0, N, k, N, N, (int32_t*)d_table);
+    if (!rc) rc = gficf_jaccard_edges_filtered_device(ctx, (const int32_t*)d_table, N, k, 0, N, (uint16_t*)d_u, (int64_t*)d_cptr, from, from + cap,
+                                                      from + 2 * cap);
+  }
   if (!rc) rc = gficf_adjacency_device(ctx, N, cap, (const int64_t*)d_cptr + N, from, from + cap, from + 2 * cap, d_aws, adj_ws,
                                        (int64_t*)d_indptr, (int32_t*)d_indices, (double*)d_ax);
   int64_t h_cnt[2] = {0, 0};                      // kept edges, adjacency entries

@@ -282,6 +282,15 @@ int gficf_jaccard_edges_filtered_device(gficf_ctx* ctx, const int32_t* d_table, 
                                         int64_t cell_begin, int64_t cell_end, uint16_t* d_u_ws,
                                         int64_t* d_cell_ptr, double* d_from, double* d_to,
                                         double* d_weight);
+/* The same on a table built from RENUMBERED cells (row p of the table = original cell d_order[p], 0-based; ids inside the table in
+ * the new numbering, 1-based): both columns come out in the ORIGINAL ids — from = d_order[p] + 1, to = d_order[id - 1] + 1 —, the
+ * edges in the order of the new numbering.  For callers that renumber the cells by locality in front of the edge build (the pivot
+ * order of the device search, gficf_knn_pivot_order_device: gficf_phenograph_host does for N >= 2^17) and hand the edges to a
+ * consumer that does not care about their order (the adjacency build sorts them). */
+int gficf_jaccard_edges_filtered_mapped_device(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k,
+                                               int64_t cell_begin, int64_t cell_end, uint16_t* d_u_ws,
+                                               int64_t* d_cell_ptr, double* d_from, double* d_to,
+                                               double* d_weight, const int32_t* d_order);
 /* Host form (two calls so that the caller can allocate exactly n_edges rows): R/clustCells.R:65-66. */
 int gficf_jaccard_filtered_host_plan(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k,
                                      int64_t ld, int64_t* n_edges);

@@ -142,8 +142,13 @@ def test_plain_bench_command_starts_its_own_ranks():
                         "--no-extras", "--cells-per-gpu", "20000"], capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout
-    out = json.loads(lines[0])
+    # N > 1 (round 5): the line is printed as soon as `value` exists and again, cumulative, after every further leg — every line a
+    # whole record (a run cut short leaves a parseable last line behind), the last one the most complete
+    recs = [json.loads(l) for l in lines]
+    assert len(recs) >= 1 and all(x["value"] == recs[0]["value"] and x["checked_vs_oracle"] is True and "roofline" in x and "exchange" in x for x in recs)
+    assert all(len(a["legs_done"]) <= len(b["legs_done"]) for a, b in zip(recs, recs[1:])) and recs[0]["legs_done"] == ["value"]
+    out = recs[-1]
+    assert out["skipped_legs"] == [] and out["leg_seconds"]["value"] > 0 and out["budget_s"] == 420.0
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["metric"] == "jaccard_edges_per_sec" and out["value"] > 0
     assert out["config"]["cells_total"] == 40000
     ex = out["exchange"]

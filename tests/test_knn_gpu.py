@@ -236,3 +236,23 @@ def test_knn_feeds_jaccard_on_device(ops):
     keep = want[:, 2] > 0
     assert np.array_equal(edges["from"], want[keep, 0]) and np.array_equal(edges["to"], want[keep, 1])
     assert np.array_equal(edges["weight"], want[keep, 2])
+
+
+def test_phenograph_on_cells_renumbered_in_pivot_order_gives_the_same_graph_and_labels(monkeypatch):
+    """gficf_phenograph_host from 2^17 cells on (here forced at 60 k and taken by default at 140 k): the Jaccard stage runs on cells
+    renumbered in the search's pivot order (locality for the row gathers) and hands the kept edges over in the ORIGINAL ids — the
+    same neighbour lists, the same graph, the same labels as the chain on the caller's order (VERDICT r4 item 7;
+    reference chain R/clustCells.R:57-68)."""
+    rng = np.random.default_rng(21)
+    for N, forced in ((60_000, True), (140_000, False)):
+        centers = rng.normal(scale=8.0, size=(40, 8))
+        X = centers[rng.integers(0, 40, size=N)] + rng.normal(size=(N, 8))
+        monkeypatch.setenv("GFICF_PHENOGRAPH_ORDER", "0")
+        a = gficf_amd.phenograph(X, k=15, n_start=1, n_iter=2)
+        if forced:
+            monkeypatch.setenv("GFICF_PHENOGRAPH_ORDER", "1")
+        else:
+            monkeypatch.delenv("GFICF_PHENOGRAPH_ORDER")
+        b = gficf_amd.phenograph(X, k=15, n_start=1, n_iter=2)
+        assert a.n_edges == b.n_edges > 0 and a.modularity == b.modularity and a.n_clusters == b.n_clusters
+        assert np.array_equal(np.asarray(a), np.asarray(b))
