@@ -705,9 +705,11 @@ def peer_child(args):
     print(json.dumps(res), flush=True)
 
 
-def run_peer_leg(args, timeout_s=420.0):
-    """Rank 0 of an N > 1 run starts the peer leg as a child process and reads its JSON object; never raises."""
+def run_peer_leg(args, timeout_s=300.0, tick=None):
+    """Rank 0 of an N > 1 run starts the peer leg as a child process and reads its JSON object; never raises.  `tick` is called
+    every few seconds while the child runs (the caller's sign of life)."""
     import subprocess
+    import threading
 
     cmd = [sys.executable, os.path.abspath(__file__), "--peer-child", "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--config", args.config, "--ids", args.ids, "--cells-per-gpu", str(args.cells_per_gpu), "--pre-warm-ms", str(args.pre_warm_ms)]
@@ -716,9 +718,17 @@ def run_peer_leg(args, timeout_s=420.0):
     env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GFICF_SPAWNED_RANK")}
     try:
         pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        stop = threading.Event()
+        if tick is not None:
+            def beat():
+                while not stop.wait(5.0):
+                    tick()
+            threading.Thread(target=beat, daemon=True).start()
         try:
             so, se = pr.communicate(timeout=timeout_s)
+            stop.set()
         except subprocess.TimeoutExpired:
+            stop.set()
             import signal
 
             try:
@@ -939,8 +949,9 @@ class Bench:
         return json.dumps(o)
 
     def progress(self, stage=None):
+        """A sign of life (the watchdog counts the seconds since the last one) and, once `value` exists, the line as it stands."""
         self.guard["t"] = time.monotonic()
-        if self.rank == 0:
+        if self.rank == 0 and "value" in self.out:
             self.guard["line"] = self.line(stage)
 
     def emit(self):
@@ -965,11 +976,14 @@ class Bench:
                 time.sleep(2.0)
                 stuck = time.monotonic() - self.guard["t"] > limit
                 over = self.elapsed() > self.args.budget_s + 120.0
-                if not self.guard["done"] and self.guard["line"] is not None and (stuck or over):
+                if not self.guard["done"] and (stuck or over):
                     self.guard["done"] = True
-                    sys.stderr.write("bench.py: no progress in a later leg; printing the line as it stands and leaving with code 3\n")
-                    sys.stdout.write(self.guard["line"] + "\n")
-                    sys.stdout.flush()
+                    if self.guard["line"] is not None:
+                        sys.stderr.write(f"bench.py: no sign of life for {limit:.0f} s (or the budget long overrun); printing the line as it stands and leaving with code 3\n")
+                        sys.stdout.write(self.guard["line"] + "\n")
+                        sys.stdout.flush()
+                    else:
+                        sys.stderr.write(f"bench.py: no sign of life for {limit:.0f} s before `value` existed: nothing to print; leaving with code 3\n")
                     os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
@@ -1011,9 +1025,12 @@ class Bench:
         a, torch, ops = self.args, self.torch, self.ops
         N_total, k, batch, world, rank = self.N_total, self.k, self.batch, self.world, self.rank
         self.assert_same_format()
+        self.progress("value: inputs")
         self.idx_local, self.mat = self.make_inputs(a.ids, rank == 0)
+        self.progress("value: exchange form")
         self.exchange, self.named_outside = self.pick_exchange(self.idx_local[0], a.exchange)
         self.shards = self.make_shards(self.exchange, batch)
+        self.progress("value: timed region")
 
         def step():
             for d in range(batch):
@@ -1036,7 +1053,9 @@ class Bench:
             value_from_idle = self.edges_per_step * a.steps / dt_idle
         # ... then the clocks are settled, then W warm-up steps, then the K timed ones
         pre_warm_steps = self.settle(step)
+        self.progress("value: timed region")
         dt, region_ms = self.timed(step, a.steps, a.warmup)
+        self.progress("value: after the timed region")
         for sh in self.shards:
             sh.sync()                                                   # surfaces deferred validation errors
         self.value = value = self.edges_per_step * a.steps / dt
@@ -1075,7 +1094,9 @@ class Bench:
             "value_with_ingest_duplicate_scan": value_scan,
             "ms_per_data_set": dt / a.steps / batch * 1e3,
         })
+        self.guard["t"] = time.monotonic()
         self.out["roofline"] = self.roofline()
+        self.guard["t"] = time.monotonic()
         if world > 1:
             self.out["exchange"] = self.exchange_figures()
         self.oracle_check()
@@ -1268,7 +1289,7 @@ class Bench:
             ops.set_jaccard_distinct(True)
         dt_o, _ = self.timed(step_o, a.steps, a.warmup)
         sh.sync()
-        t_edges = time_kernel_ms(torch, lambda: ops.jaccard_edges(sh.table, self.N_total, self.k, 0, self.N_total, sh.out, None), max(a.steps, 20))
+        t_edges = time_kernel_ms(torch, lambda: ops.jaccard_edges(sh.table, self.N_total, self.k, 0, self.N_total, sh.out, None), max(a.steps, 100))
         import oracle
 
         mat_o = self.synth.knn_windowed(self.N_total, self.k, seed=42, perm_seed=43 if other == "permuted" else None)
@@ -1366,7 +1387,7 @@ class Bench:
         """The single-process form with direct peer copies, in a process of its own (rank 0 starts it; the ranks wait)."""
         if self.rank == 0:
             left = self.args.budget_s - self.elapsed()
-            self.out["peer"] = run_peer_leg(self.args, timeout_s=max(30.0, min(300.0, left - 10.0)))
+            self.out["peer"] = run_peer_leg(self.args, timeout_s=max(30.0, min(300.0, left - 10.0)), tick=lambda: self.progress("peer"))
         self.fence()
 
     def efficiency(self):

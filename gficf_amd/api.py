@@ -180,7 +180,11 @@ class MultiContext:
         """``gficf_multi_jaccard_halo_device``: the device-resident step for blocks whose ids have locality — nothing is exchanged,
         a device reads the few rows its block names outside where they lie, in the other devices' blocks (peer mapping).  ``idx_blocks[r]``:
         the (k, n_r) int32 tensor of block r on device slot r; ``bufs`` from :meth:`halo_buffers` (results in ``bufs["out"][r]``).
-        Enqueues only; :meth:`sync` waits and raises deferred errors (``GFICF_ERR_CAPACITY``: ids without locality)."""
+        The step is POSTED to per-device host threads and the call returns before anything is enqueued: the inputs must be complete
+        before the call (synchronise the torch streams that produced them) and :meth:`sync` is the ONLY completion point — the blocks
+        of ids and ``bufs`` must stay unchanged until it has returned (an event recorded after this call orders nothing).  ``sync``
+        also raises the deferred errors (``GFICF_ERR_CAPACITY``: ids without locality).  ``bufs["ws"]`` must be all-zero at the
+        first step (:meth:`halo_buffers` allocates it so; the library keeps it consistent afterwards)."""
         P = len(self.devices)
         if len(idx_blocks) != P:
             raise ValueError("one block per device slot")

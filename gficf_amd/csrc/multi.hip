@@ -74,6 +74,7 @@ struct gficf_multi {
   std::vector<hipEvent_t> ev_prev;                 // device d: everything enqueued before this step (the last step's edge kernel) is done
   std::vector<hipEvent_t> ev_pulled;               // device d: has pulled every other slice of this step
   bool step_valid = false;                         // ev_pulled holds a recorded step
+  bool step_resources_ok = false;                  // the copy streams and events above exist, all of them
   // ... enqueued by one PERSISTENT host thread per device (a step is ~45 runtime calls per device — launches, peer copies, event
   // records and waits: from one thread that is 8 x 45 calls in a row, several hundred microseconds per step at 8 devices against
   // ~100 us of device work; threads made per call would cost as much).  Every thread has a queue of jobs of its own: a job is POSTED
@@ -448,6 +449,8 @@ static int multi_post(gficf_multi* m, std::function<int(int)> body) {
       w->cv_job.notify_one();
     }
   } catch (...) {
+    // part of the workers may hold the job already: it refers to the caller's stack, so they are waited for before the error goes back
+    (void)multi_drain(m);
     GFICF_FAIL(GFICF_ERR_HIP, "out of host memory posting a multi-device job");
   }
   return GFICF_OK;
@@ -475,10 +478,24 @@ static int multi_run(gficf_multi* m, const std::function<int(int)>& body) {
   return multi_drain(m);
 }
 
+// destroys whatever copy streams / events exist (also after a creation that failed half-way) and empties the lists
+static void multi_step_resources_free(gficf_multi* m) {
+  for (size_t d = 0; d < m->cstream.size(); ++d) {
+    if (d < m->dev.size()) (void)hipSetDevice(m->dev[d]);
+    for (hipStream_t s_ : m->cstream[d]) if (s_) (void)hipStreamDestroy(s_);
+    if (d < m->cev.size()) for (hipEvent_t e_ : m->cev[d]) if (e_) (void)hipEventDestroy(e_);
+  }
+  for (hipEvent_t e_ : m->ev_prev) if (e_) (void)hipEventDestroy(e_);
+  for (hipEvent_t e_ : m->ev_pulled) if (e_) (void)hipEventDestroy(e_);
+  m->cstream.clear(); m->cev.clear(); m->ev_prev.clear(); m->ev_pulled.clear();
+  m->step_resources_ok = false;
+}
+
 // lazily: the copy streams and events of gficf_multi_jaccard_device
 static int multi_step_resources(gficf_multi* m) {
   const int P = m->ndev;
-  if ((int)m->cstream.size() == P) return GFICF_OK;
+  if (m->step_resources_ok) return GFICF_OK;
+  multi_step_resources_free(m);                                // (what a failed attempt left behind)
   m->cstream.assign((size_t)P, {});
   m->cev.assign((size_t)P, {});
   m->ev_prev.assign((size_t)P, nullptr);
@@ -495,8 +512,12 @@ static int multi_step_resources(gficf_multi* m) {
       m->cstream[d].push_back(cs);
       m->cev[d].push_back(ce);
     }
-    if (e != hipSuccess) return hip_fail("copy streams of the device-resident step", e);
+    if (e != hipSuccess) {
+      multi_step_resources_free(m);                            // nothing half-made stays behind: the next call starts over
+      return hip_fail("copy streams of the device-resident step", e);
+    }
   }
+  m->step_resources_ok = true;
   return GFICF_OK;
 }
 

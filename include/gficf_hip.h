@@ -475,8 +475,13 @@ int gficf_multi_jaccard_device(gficf_multi* m, const void* const* d_idx, int idx
  * devices.  Per device r: d_ws[r] gficf_jaccard_halo_workspace_bytes(N, P) bytes ZEROED ONCE by the caller, d_req[r] P * cap
  * int32, d_table[r] (n_r + P * cap) x gficf_jaccard_row_words(n_r + P * cap, k) int32, d_l2g[r] n_r + P * cap int32, d_out[r] as
  * in gficf_multi_jaccard_device.  A block that names more than cap rows of one owner raises GFICF_ERR_CAPACITY from
- * gficf_multi_sync (ids without locality: use gficf_multi_jaccard_device).  The blocks of ids must stay unchanged until the step has
- * run (gficf_multi_sync, or an event of the caller's on every device's stream).  Same rows of rmat as the other forms, bit for bit. */
+ * gficf_multi_sync (ids without locality: use gficf_multi_jaccard_device).  The step is POSTED to the context's per-device host
+ * threads and this call returns before anything is enqueued, so the ONLY completion point is gficf_multi_sync: the blocks of ids (which
+ * the other devices read through the peer mapping) and every buffer of the step must stay unchanged until it has returned — an event
+ * the caller records after this call may still precede the step's launches and orders nothing.  The caller's inputs must be complete
+ * (their producing streams synchronised) before the call.  d_ws is trusted to be all-zero at the first step (the plan hands it back
+ * zero after every step); a workspace with stale bits gives wrong request slots without an error.  Same rows of rmat as the other
+ * forms, bit for bit. */
 int gficf_multi_jaccard_halo_device(gficf_multi* m, const int32_t* const* d_idx, const int64_t* ld, int64_t N, int k, int cap,
                                     void* const* d_ws, int32_t* const* d_req, int32_t* const* d_table, int32_t* const* d_l2g, double* const* d_out);
 int gficf_multi_sync(gficf_multi* m);

@@ -1,9 +1,10 @@
 #!/bin/bash
 # One GPU-box round in two calls (a gpurun call is limited to 20 minutes).  Usage (through gpurun): bash tools/gpu_round.sh <tag> <part>
-#   part 1: GPU tests, smoke, bench (+ rocprofv3 kernel trace of the same command), config 4 / 5 lines with their kernel traces,
-#           stage times of the sharded step, the config-4 kernel A/B
-#   part 2: N > 1 rehearsals on the one GPU (plain `python bench.py --gpus N`: the script starts its own ranks), PMC passes, fuzz
-TAG=${1:-r04}; PART=${2:-1}
+#   part 1: GPU tests, smoke, the bench line AND the rocprofv3 kernel trace of the same command in this same call (tools/make_results.py
+#           checks one against the other), the lines + traces of configs 1-5, stage times of the sharded step + the projection
+#   part 2: N > 1 rehearsals on the one GPU (plain `python bench.py --gpus N`: the script starts its own ranks; 3 ranks at full size,
+#           5 ranks at 20 k cells per rank — 5 ranks + the peer child are the 6 processes a box allows on its card), PMC passes, fuzz
+TAG=${1:-r05}; PART=${2:-1}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -11,16 +12,17 @@ if [ "$PART" = "1" ]; then
 timeout -k 10 500 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log
 timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench.json
-(cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-live-traffic > $GRAFT_REPO_ROOT/$OUT/trace.log 2>&1); echo "trace rc=$?"
+(cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-live-traffic > $GRAFT_REPO_ROOT/$OUT/bench_traced.json 2> $GRAFT_REPO_ROOT/$OUT/trace.log); echo "trace rc=$?"
 cp $(find $OUT/trace -name "bench_kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv && head -8 $OUT/bench_kernel_stats.csv | cut -c1-200
-bash tools/trace_configs.sh $TAG > $OUT/trace_configs.txt 2>&1; echo "trace configs rc=$?"
+CONFIGS_TO_TRACE="c1 c2 c3 c4 c5" bash tools/trace_configs.sh $TAG > $OUT/trace_configs.txt 2>&1; echo "trace configs rc=$?"
 timeout -k 10 200 python tools/halo_stage_times.py 1 2 4 8 > $OUT/halo_stage_times.jsonl 2>> $OUT/bench.err; echo "stage times rc=$?"
 python tools/project_scaling.py $OUT/halo_stage_times.jsonl > $OUT/scaling_projection.md; tail -20 $OUT/scaling_projection.md
-bash tools/bits_ab.sh $TAG > $OUT/bits_ab_final.txt 2>&1; cat $OUT/bits_ab_final.txt
 else
-for A in "--gpus 2" "--gpus 3"; do
-  timeout -k 10 420 python bench.py $A --rehearse-one-gpu --steps 5 --no-gficf > "$OUT/rehearsal_$(echo $A | tr -d ' -').json" 2>> $OUT/rehearsal.err; echo "rehearsal $A rc=$?"
-done
+S=$SECONDS
+timeout -k 10 420 python bench.py --gpus 3 --rehearse-one-gpu --steps 5 --no-gficf > $OUT/rehearsal_gpus3.jsonl 2> $OUT/rehearsal_gpus3.err; echo "rehearsal 3 ranks (full size) rc=$? in $((SECONDS-S)) s"
+S=$SECONDS
+timeout -k 10 420 python bench.py --gpus 5 --rehearse-one-gpu --steps 5 --no-gficf --cells-per-gpu 20000 > $OUT/rehearsal_gpus5.jsonl 2> $OUT/rehearsal_gpus5.err; echo "rehearsal 5 ranks (20 k cells per rank) rc=$? in $((SECONDS-S)) s"
+for A in 3 5; do wc -l $OUT/rehearsal_gpus$A.jsonl; tail -1 $OUT/rehearsal_gpus$A.jsonl | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d.get(k) for k in ('legs_done','leg_seconds','skipped_legs','wall_s','checked_vs_oracle')})"; done
 bash tools/pmc_round.sh $TAG 2>&1 | tail -14
 timeout -k 10 200 python tools/fuzz_gpu.py 120 > $OUT/fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -3 $OUT/fuzz.txt
 fi

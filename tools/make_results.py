@@ -2,7 +2,14 @@
 """RESULTS.md — one page of numbers, generated from the committed records under profiles/ (nothing is typed by hand):
 bench lines (profiles/r<NN>_bench*.json), rocprofv3 kernel-trace summaries (r<NN>_*kernel_stats.csv), the PMC traffic file
 (pmc_traffic.json), the stage times of the sharded step and the projection made from them.
-Usage: python tools/make_results.py [round tag, default r04] > RESULTS.md"""
+Usage: python tools/make_results.py [round tag, default r05] > RESULTS.md
+
+Round 5: the generator CHECKS the records it prints and exits 1 (message on stderr, nothing usable on stdout) when they do not
+hold together: the bench line and the rocprofv3 trace must come from the same gpurun call and agree — the edge kernel's in-run time
+with the trace's average within 5 %, data sets x (kernel + ingest) inside ms_per_step, a GF-ICF pass's ms_per_pass within 5 % of the
+sum of its kernels' trace averages — and where several runs of the round are kept (profiles/<tag>_runs/*.json) the page quotes
+min / MEDIAN / max over them and the headline is the median, never the best box."""
+import statistics
 import csv
 import json
 import os
@@ -11,7 +18,73 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+PROBLEMS = []
+
+
+def problem(msg):
+    PROBLEMS.append(msg)
+
+
+GFICF_KERNELS = {"k_gene_count": "count", "k_nt_sum_table": "row sum + gene table", "k_cell_kept_count": "kept count", "k_scan_lookback": "scan",
+                 "k_scale_cells_lds": "scale"}
+
+
+def check_line_against_trace(label, line, stats):
+    """The consistency rules of round 5 for one (line, trace) pair of the same call."""
+    if not line or not stats:
+        return
+    r = line["roofline"]
+    rp = stats.get(r["kernel"])
+    # (kernels of a few microseconds: back-to-back launches overlap the next launch's ramp with the last one's drain, which the trace's
+    # per-dispatch durations do not — 1.5 us of slack there)
+    if rp and abs(r["kernel_ms"] * 1e3 - rp[1]) > max(0.05 * rp[1], 1.5):
+        problem(f"{label}: roofline.kernel_ms {r['kernel_ms'] * 1e3:.2f} us differs from the trace's average {rp[1]:.2f} us of {r['kernel']} by more than 5 %")
+    ds = line["config"]["data_sets_per_step"]
+    inside = ds * (r["kernel_ms"] + r.get("ingest_kernel_ms", 0.0))
+    if inside > line["ms_per_step"] * 1.02:
+        problem(f"{label}: {ds} x (kernel_ms + ingest_kernel_ms) = {inside:.4f} ms does not fit in ms_per_step {line['ms_per_step']:.4f} ms")
+    g = line.get("gficf")
+    if g and all(k in stats for k in GFICF_KERNELS):
+        ksum = sum(stats[k][1] for k in GFICF_KERNELS) / 1e3
+        if abs(g["ms_per_pass"] - ksum) / ksum > 0.05:
+            problem(f"{label}: gficf.ms_per_pass {g['ms_per_pass']:.4f} ms differs from the sum of its kernels' trace averages {ksum:.4f} ms by more than 5 % "
+                    "(a line and a trace from different calls, or a best-of selection)")
+
+
+def runs_table(w):
+    """min / median / max over the N = 1 default lines kept from the round's gpurun calls."""
+    d = os.path.join(P, f"{TAG}_runs")
+    if not os.path.isdir(d):
+        return None
+    recs = []
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".json"):
+            x = load(os.path.join(f"{TAG}_runs", f))
+            if x and x.get("n_gpus") == 1 and "north-star" in x["config"]["workload"]:
+                recs.append((f, x))
+    if len(recs) < 2:
+        return None
+    def col(fn):
+        v = [fn(x) for _, x in recs if fn(x) is not None]
+        return (min(v), statistics.median(v), max(v)) if v else None
+    rows = [("`value`, G edges/s", col(lambda x: x["value"] / 1e9), "{:.1f}"),
+            ("`value_from_idle`, G edges/s", col(lambda x: x.get("value_from_idle") and x["value_from_idle"] / 1e9), "{:.1f}"),
+            ("edge kernel, us (in-run)", col(lambda x: x["roofline"]["kernel_ms"] * 1e3), "{:.2f}"),
+            ("`roofline.frac`", col(lambda x: x["roofline"]["frac"]), "{:.4f}"),
+            ("GF-ICF canonical, ms per pass", col(lambda x: (x.get("gficf") or {}).get("ms_per_pass")), "{:.3f}"),
+            ("GF-ICF canonical, frac", col(lambda x: ((x.get("gficf") or {}).get("roofline") or {}).get("frac")), "{:.3f}"),
+            ("GF-ICF begin/end form, ms per pass", col(lambda x: ((x.get("gficf") or {}).get("begin_end_form") or {}).get("ms_per_pass")), "{:.3f}"),
+            ("GF-ICF begin/end form, frac", col(lambda x: ((x.get("gficf") or {}).get("begin_end_form") or {}).get("roofline_frac")), "{:.3f}")]
+    w(f"## The round's runs ({len(recs)} `python bench.py` lines from {len(recs)} gpurun calls, each on a fresh box: profiles/{TAG}_runs/)\n\n")
+    w("| figure | min | **median** | max |\n|---|---|---|---|\n")
+    for name, c, spec in rows:
+        if c:
+            w("| {} | {} | **{}** | {} |\n".format(name, spec.format(c[0]), spec.format(c[1]), spec.format(c[2])))
+    w("\nThe headline figures of this page are these MEDIANS; the tables below are the record of ONE call (line and rocprofv3 trace taken together: "
+      f"profiles/{TAG}_bench.json + {TAG}_bench_kernel_stats.csv), checked against its own trace by this generator.\n\n")
+    return {name: c for name, c, _ in rows}
+
 
 
 def load(name):
@@ -70,21 +143,45 @@ def main():
     c4, c5 = load(f"{TAG}_bench_c4.json"), load(f"{TAG}_bench_c5.json")
     pmc = load("pmc_traffic.json") or {}
     sb, s4, s5 = kstats(f"{TAG}_bench_kernel_stats.csv"), kstats(f"{TAG}_bench_c4_kernel_stats.csv"), kstats(f"{TAG}_bench_c5_kernel_stats.csv")
-    w = sys.stdout.write
+    chunks = []
+    w = chunks.append
+    check_line_against_trace("north star", b, sb)
+    check_line_against_trace("config 4", c4, s4)
+    check_line_against_trace("config 5", c5, s5)
     w(f"# RESULTS — round {TAG[1:]} (generated by tools/make_results.py from profiles/; do not edit)\n\n")
     w("All figures: one MI355X, device-resident inputs, synthetic data (SURVEY.md §8d), permuted ids unless said otherwise.  "
       "`frac` = algorithmic bytes (28 B/edge; 24 B/stored entry) / kernel or pass time / 8 TB/s.  Parity: every row is compared with the CPU oracle "
       "(`oracle/`: **parity unpinned** — the reference holds no fixtures and R is absent; DESIGN.md §2).\n\n")
+    runs_table(w)
     w("## Jaccard edge build (`rcpp_parallel_jaccard_coef`, src/rcpp_parallel_jaccard_coeff.cpp:24-55)\n\n")
     w("| workload | `value` (edges/s, ingest + edges per data set) | dominant kernel | kernel us (rocprofv3 avg) | kernel us (in-run HIP events) | frac (rocprofv3) | frac (line) | traffic / algorithmic | fabric rate | parity |\n")
     w("|---|---|---|---|---|---|---|---|---|---|\n")
     w(jaccard_row("north star: 100 k cells x k = 30", b, sb, "jaccard_edges_pipe_N100000_k30", pmc) + "\n")
+    small = []
     for cfg, label in (("c1", "config 1: 3 k x k = 15"), ("c2", "config 2: 10 k x k = 30"), ("c3", "config 3: 54 k x k = 30")):
         line = load(f"{TAG}_bench_{cfg}.json")
         if line:
-            w(jaccard_row(label, line, kstats(f"{TAG}_bench_{cfg}_kernel_stats.csv"), "-", pmc) + "\n")
+            st = kstats(f"{TAG}_bench_{cfg}_kernel_stats.csv")
+            check_line_against_trace(label, line, st)
+            w(jaccard_row(label, line, st, "-", pmc) + "\n")
+            small.append((label, line, st))
     w(jaccard_row("config 4: 100 k x k = 50", c4, s4, "jaccard_edges_bits_N100000_k50", pmc) + "\n")
     w(jaccard_row("config 5: 1 M x k = 30", c5, s5, "jaccard_edges_pipe_N1000000_k30", pmc) + "\n\n")
+    if small:
+        w("Configs 1-3 are ONE data set of a few microseconds per step (K = 2000 steps per line, so that the timed region is the steps and not its two fences):\n\n")
+        w("| config | step, us (wall, in order) | device: kernels per step, us (rocprofv3 averages) | form |\n|---|---|---|---|\n")
+        for label, line, st in small:
+            r = line["roofline"]
+            parts = " + ".join("{} {:.1f}".format(kn, st[kn][1]) for kn in ("k_ingest_tile", r["kernel"]) if kn in st and (kn != "k_ingest_tile" or r["kernel"] != "k_jaccard_direct"))
+            w("| {} | {:.2f} | {} | {} |\n".format(label, line["ms_per_step"] * 1e3, parts or "-",
+                                                "ONE launch, no table (`k_jaccard_direct`), one library call" if r["kernel"] == "k_jaccard_direct" else "ingest + edge kernel, one library call"))
+        w("\n(round 4, two library calls from Python per step and K = 20: 23 / 27.6 us for configs 1 / 2.)\n\n")
+    for cfg, line in (("c4", c4), ("c5", c5)):
+        sp = (line or {}).get("spatial_ids")
+        if sp:
+            w("Config {} on ids WITH locality (cells in spatial order — what the search's pivot order gives; same step, same box): edge kernel {:.1f} us (frac {:.3f}) against {:.1f} us on permuted ids; "
+              "step {:.1f} us; parity {}.\n\n".format(cfg[1], sp["kernel_ms"] * 1e3, sp["roofline_frac"], line["roofline"]["kernel_ms"] * 1e3, sp["ms_per_data_set"] * 1e3,
+                                                     "bit-exact" if sp.get("checked_vs_oracle") else "NOT CHECKED"))
     if b:
         cb = b.get("cpu_baseline") or {}
         w("North-star line: `value` {:.1f} G edges/s at settled clocks, **{} G from idle** (`value_from_idle`: the same W + K steps right after start-up), "
@@ -111,7 +208,7 @@ def main():
     if g:
         rf = g["roofline"]
         be = g.get("begin_end_form") or {}
-        names = {"k_gene_count": "count", "k_nt_sum_table": "row sum + gene table", "k_cell_kept_count": "kept count", "k_scan_lookback": "scan", "k_scale_cells_lds": "scale"}
+        names = GFICF_KERNELS
         parts = " + ".join("{} {:.0f}".format(names[k], sb[k][1]) for k in names if k in sb)
         w("| form | ms per pass | cells/s | frac | kernels (rocprofv3 average us) | parity |\n|---|---|---|---|---|---|\n")
         w("| canonical compacted CSC (`value`) | {:.3f} | {:.0f} M | {:.3f} | {} | {} |\n".format(
@@ -119,6 +216,12 @@ def main():
         if be:
             w("| pointerB / pointerE form (device-resident chain) | {:.3f} | {:.0f} M | {:.3f} | count + gene table + scale (no kept count, no scan) | entry for entry the canonical result: {} |\n".format(
                 be["ms_per_pass"], be["cells_per_sec"] / 1e6, be["roofline_frac"], be.get("equals_canonical_result")))
+        ha = g.get("host_abi") or {}
+        if ha.get("ms_per_call"):
+            w("\nThrough the host C ABI (`gficf_normalize_csc_host_plan` + `_finish`, what `.Call(\"_gficf_gficf_csc\")` binds; pageable buffers, PCIe both ways, "
+              "{:.2f} GB in / {:.2f} GB out): {:.1f} ms per call (plan {:.1f} + finish {:.1f}) = {:.1f} M cells/s; parity {}.\n".format(
+                  ha["bytes_in"] / 1e9, ha["bytes_out"] / 1e9, ha["ms_per_call"], ha["ms_plan"], ha["ms_finish"], ha["cells_per_sec"] / 1e6,
+                  "<= 1e-6 vs oracle" if ha.get("checked_vs_oracle") else "not checked"))
         w("\nstored entries {:.1f} M, kept {:.1f} M in {} genes; PMC traffic {} of the algorithmic bytes.  `t(gficf)` {} ms, cluster sums {} ms.\n\n".format(
             g["nnz"] / 1e6, g["kept_nnz"] / 1e6, g["kept_genes"], fmt(rf.get("traffic") and rf["traffic"] / rf["algorithmic_bytes_per_pass"], "{:.2f} x"),
             (g.get("transpose") or {}).get("ms", "-"), (g.get("cluster_signatures") or {}).get("ms", "-")))
@@ -155,8 +258,14 @@ def main():
     if os.path.exists(pr):
         w("Projection from those stage times + a stated exchange model (NOT a measurement; tools/project_scaling.py):\n\n")
         w(open(pr).read().strip() + "\n\n")
-    for n in (2, 3):
-        r = load(f"{TAG}_rehearsal_gpus{n}.json")
+    for n in (2, 3, 5):
+        r = load(f"{TAG}_rehearsal_gpus{n}.json") or load(f"{TAG}_rehearsal_gpus{n}.jsonl")
+        if r and "leg_seconds" in r:
+            f = os.path.join(P, f"{TAG}_rehearsal_gpus{n}.jsonl")
+            nlines = sum(1 for l in open(f) if l.lstrip().startswith("{")) if os.path.exists(f) else 1
+            w("Rehearsal, {} ranks on ONE GPU over gloo: {} cumulative lines printed (one after `value`, one after every leg; each a whole record), "
+              "wall {} s of a {:.0f} s budget, seconds per leg {}, skipped legs {}.\n\n".format(
+                  n, nlines, r.get("wall_s"), r.get("budget_s", float("nan")), r.get("leg_seconds"), r.get("skipped_legs")))
         if r:
             w("Rehearsal line, {} ranks on ONE GPU over gloo (structure and byte counts real, rates meaningless): objects present: {}; checked_vs_oracle {} / spatial {} / peer {} / chain {}.\n\n".format(
                 n, ", ".join(k for k in ("exchange", "pipelined", "spatial_ids", "single_gpu_step", "chain", "peer", "efficiency") if k in r),
@@ -172,6 +281,10 @@ def main():
         tail = [l for l in open(log).read().splitlines() if " passed" in l or " failed" in l]
         if tail:
             w("## Tests\n\n`python -m pytest tests -m gpu` on the GPU box: {}.\n".format(tail[-1].strip("= ")))
+    if PROBLEMS:
+        sys.stderr.write("tools/make_results.py: the records do not hold together:\n" + "".join("  - " + p_ + "\n" for p_ in PROBLEMS))
+        raise SystemExit(1)
+    sys.stdout.write("".join(chunks))
 
 
 if __name__ == "__main__":
