@@ -144,6 +144,7 @@ class JaccardShard:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.kpad = ops.kpad(k)
         self.row_words = ops.row_words(self.N, self.k)      # row pitch of the table (the library's choice for this N, k)
+        _format_agreed(ops, self.N, self.k, group, device)  # N > 1, once per (N, k): every rank lays the rows out alike, or every rank raises
         self.rpr = rows_per_rank(self.N, self.world)
         self.b, self.e = shard_bounds(self.N, self.world, self.rank)
         self.n_local = self.e - self.b
@@ -352,6 +353,9 @@ class JaccardHaloShard:
         nbuf = 2 if self.pipeline else 1
         i32 = dict(dtype=torch.int32, device=device)
         self.row_words = ops.row_words(self.n_ext, self.k)
+        # (a rank's sub-problem table is private — only raw index rows travel — but the request slots, the block pitch and the library
+        # build must agree: compared on the size of the largest sub-problem, which is the same number on every rank)
+        _format_agreed(ops, self.rpr + self.world * self.cap, self.k, group, device, extra=(self.cap, self.N))
         ws_bytes = ops.halo_workspace_bytes(self.N, self.world)
         self.bufs = [dict(ws=torch.zeros(ws_bytes, dtype=torch.uint8, device=device),
                           req_out=torch.zeros(self.world * self.cap, **i32), req_in=torch.zeros(self.world * self.cap, **i32),
@@ -509,6 +513,21 @@ class JaccardHaloShard:
             raise err
         status = STATUS_NAMES.get(top_num, f"status {top_num}")
         raise GficfError(top_num, f"rank {who} reported {status} in the sharded Jaccard step (this rank's own block was fine); every rank fails alike")
+
+
+_AGREED = set()
+
+
+def _format_agreed(ops, N_total, k, group, device, extra=()):
+    """assert_same_format, once per (N, k, extra) and process (every rank constructs its shards in the same order, so the
+    all-gathers match up)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    key = (int(N_total), int(k), tuple(int(v) for v in extra), id(group))
+    if key in _AGREED:
+        return
+    assert_same_format(ops, N_total, k, group=group, device=device, extra=extra)
+    _AGREED.add(key)
 
 
 def assert_same_format(ops, N_total: int, k: int, group=None, device=None, extra: tuple = ()):

@@ -125,6 +125,44 @@ def test_round4_records_are_consistent_and_results_md_is_generated_from_them():
         r = json.load(open(os.path.join(root, "profiles", f"r04_rehearsal_gpus{n}.json")))
         assert r["n_gpus"] == n and r["checked_vs_oracle"] and r["spatial_ids"]["checked_vs_oracle"] and r["peer"]["checked_vs_oracle"] and r["chain"]["checked_vs_oracle"]
         assert set(r["efficiency"]) >= {"in_order_permuted", "overlapped_permuted", "in_order_spatial", "overlapped_spatial", "peer_in_order_permuted"}
+    # round 5: the generator checks a round's records against each other — and round 4's do NOT hold together (its GF-ICF figure was the
+    # best of four boxes next to another call's trace; its per-launch event pairs overstated the kernels): the generator says so and fails
     gen = subprocess.run([sys.executable, os.path.join(root, "tools", "make_results.py"), "r04"], capture_output=True, text=True, timeout=120)
+    assert gen.returncode == 1 and gen.stdout == "" and "gficf.ms_per_pass 0.4650 ms differs from the sum of its kernels' trace averages 0.5372 ms" in gen.stderr
+    assert "does not fit in ms_per_step" in gen.stderr
+
+
+def test_round5_records_hold_together_and_results_md_is_generated_from_them():
+    """every number of RESULTS.md comes from records that agree with each other — the bench line and the rocprofv3
+    trace of the SAME gpurun call: the edge kernel's in-run time within 5 % of the trace's average, data sets x (kernel + ingest) inside
+    ms_per_step, the GF-ICF pass within 5 % of the sum of its kernels' trace averages (tools/make_results.py exits 1 otherwise) — and the
+    headline is the MEDIAN over the round's runs.  RESULTS.md is what the generator makes of profiles/."""
+    import json
+    import os
+    import statistics
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    P = os.path.join(root, "profiles")
+    d = json.load(open(os.path.join(P, "r05_bench.json")))
+    r = d["roofline"]
+    assert d["checked_vs_oracle"] is True and d["legs_done"][0] == "value" and d["skipped_legs"] == [] and set(d["leg_seconds"]) == set(d["legs_done"])
+    assert d["config"]["data_sets_per_step"] * (r["kernel_ms"] + r["ingest_kernel_ms"]) <= d["ms_per_step"] * 1.02          # (c) inside the line itself
+    assert abs(r["frac"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 2e-4
+    assert d["pipelined"]["refused_on_one_rank"] is True and d["pipelined"]["edges_per_sec"] >= d["value"]                       # item 6
+    g = d["gficf"]
+    assert g["ms_per_pass"] == statistics.median(g["ms_per_pass_batches"]) or abs(g["ms_per_pass"] - statistics.median(g["ms_per_pass_batches"])) < 1e-3
+    assert g["host_abi"]["checked_vs_oracle"] is True and g["host_abi"]["ms_per_call"] > g["ms_per_pass"]                         # the PCIe-inclusive figure is in the line
+    # the small configs: one launch / one library call per step (item 3)
+    c1 = json.load(open(os.path.join(P, "r05_bench_c1.json")))
+    c2 = json.load(open(os.path.join(P, "r05_bench_c2.json")))
+    assert c1["roofline"]["kernel"] == "k_jaccard_direct" and c1["ms_per_step"] <= 0.010 and c1["checked_vs_oracle"] is True and c1["steps"] >= 1000
+    assert c2["ms_per_step"] <= 0.014 and c2["checked_vs_oracle"] is True
+    c5 = json.load(open(os.path.join(P, "r05_bench_c5.json")))
+    assert c5["spatial_ids"]["checked_vs_oracle"] is True and c5["spatial_ids"]["kernel_ms"] < 0.75 * c5["roofline"]["kernel_ms"]   # item 7
+    runs = [f for f in os.listdir(os.path.join(P, "r05_runs")) if f.endswith(".json")]
+    assert len(runs) >= 3
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "make_results.py"), "r05"], capture_output=True, text=True, timeout=120)
     assert gen.returncode == 0, gen.stderr[-2000:]
-    assert gen.stdout == open(os.path.join(root, "RESULTS.md")).read(), "RESULTS.md is stale: python tools/make_results.py r04 > RESULTS.md"
+    assert gen.stdout == open(os.path.join(root, "RESULTS.md")).read(), "RESULTS.md is stale: python tools/make_results.py r05 > RESULTS.md"

@@ -316,3 +316,59 @@ def test_plain_multi_gpu_bench_line_carries_the_whole_scaling_answer():
     eff = out["efficiency"]
     for key in ("in_order_permuted", "overlapped_permuted", "in_order_spatial", "overlapped_spatial", "peer_in_order_permuted"):
         assert eff[key] > 0, key
+
+
+def _bench_env():
+    env = dict(os.environ)
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    return env
+
+
+def test_bench_wall_budget_skips_and_names_the_legs_it_has_no_time_for():
+    """`--budget-s`: a leg that would start with less than its reserve left is skipped on every rank alike and named in
+    `skipped_legs`; `value` always runs; the run ends with code 0 and a whole line.  `--legs` selects."""
+    import json
+    import subprocess
+
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1", "--cells-per-gpu", "20000",
+            "--no-gficf"]
+    r = subprocess.run(base + ["--budget-s", "5"], capture_output=True, text=True, timeout=280, env=_bench_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert out["legs_done"] == ["value"] and out["checked_vs_oracle"] is True and out["value"] > 0
+    assert out["skipped_legs"] == ["pipelined", "other_ids", "single_gpu_step", "chain", "peer"] and out["budget_s"] == 5.0
+    r = subprocess.run(base + ["--legs", "single_gpu_step,pipelined"], capture_output=True, text=True, timeout=280, env=_bench_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert out["legs_done"] == ["value", "pipelined", "single_gpu_step"] and out["skipped_legs"] == []
+    assert out["efficiency"]["in_order_permuted"] > 0 and "peer" not in out and "chain" not in out
+
+
+def test_bench_killed_at_any_moment_after_its_first_line_leaves_a_whole_last_line():
+    """the first real `bench.py --gpus N` must be impossible to lose — the cumulative line is printed as soon as
+    `value` exists and after every leg, so killing the whole job (SIGKILL to its process group: no handler runs) after the first print
+    leaves stdout ending in a parseable record."""
+    import json
+    import signal
+    import subprocess
+    import time
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1", "--cells-per-gpu", "20000",
+           "--no-gficf"]
+    pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=_bench_env(), start_new_session=True)
+    try:
+        first = pr.stdout.readline()                            # blocks until the line behind `value` is out
+        assert first.lstrip().startswith("{"), first[:200]
+        time.sleep(1.7)                                         # ... somewhere inside a later leg
+    finally:
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)
+        except OSError:
+            pass
+    rest = pr.stdout.read()
+    pr.wait(timeout=30)
+    lines = [l for l in (first + rest).split("\n") if l.strip()]
+    whole = [l for l in lines if l.rstrip().endswith("}")]
+    rec = json.loads(whole[-1])
+    assert rec["value"] > 0 and rec["checked_vs_oracle"] is True and "roofline" in rec and "exchange" in rec and rec["legs_done"][0] == "value"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity run of the HIP path against the oracle, longer than the test suite allows (minutes, not seconds).
 
-Jaccard: random shapes (N 1 .. 6000, now and then 131 000 .. 180 000 for the wide-row table; k 1 .. 256), five kinds of index
+Jaccard: random shapes (N 1 .. 6000, now and then 131 000 .. 180 000 for the wide-row table; k 1 .. 256, now and then 257 .. 700: the
+sorted-row path; small shapes with k <= 16 take the one-launch form through the host entries and the distinct-ids mode), five kinds of index
 matrix (windowed scrambled / windowed in order / uniform / few distinct ids = rows full of duplicates and self-references /
 a window of 2), int32 or float64 input, through every entry that returns edges: the `.Call` entry (reference matrix), the
 compact counts + host expansion, the filtered call-site form, the serial `jaccard_coeff` entry, the device-resident path
@@ -42,9 +43,13 @@ def knn_matrix(case):
     big = rng.random() < 0.04
     k = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 29, 30, 31, 32, 33, 50, 60, 61, 64, 65, 100, 120, 128, 129, 200, 255, 256])) if rng.random() < 0.6 \
         else int(rng.integers(1, 257))
+    wide = (not big) and rng.random() < 0.06                         # round 5: k > 256, the sorted-row path (csrc/jaccard_sorted.h)
     if big:
         k = min(k, 64)
         N = int(rng.integers(131_000, 180_000))
+    elif wide:
+        k = int(rng.choice([257, 258, 300, 319, 320, 321, 400, 513, 700]))
+        N = int(rng.integers(max(k // 3, 3), 1400))
     else:
         N = int(rng.integers(max(k + 2, 3), 6000)) if rng.random() < 0.9 else int(rng.integers(1, 40))
     kind = int(rng.integers(0, 5))
@@ -78,6 +83,8 @@ def jaccard_case(case):
     entry = int(rng.integers(0, 9)) if not big else int(rng.choice([0, 1, 2, 6, 7, 8]))
     if entry == 8 and k > 64:
         entry = 7
+    if entry == 5 and k > 256:                                      # (the truncating kernel for non-integer ids stops at k = 256)
+        entry = 0
     tag = f"jaccard case {case}: N={N} k={k} kind={kind} f64={as_f64} entry={entry}"
     if entry == 0:
         got = gficf_amd.rcpp_parallel_jaccard_coef(mat, False)
@@ -132,7 +139,10 @@ def jaccard_case(case):
                 raised = True
         finally:
             ops.set_jaccard_distinct(False)
-        assert raised == has_dup or (raised and not has_dup and k >= 8), tag + f" raised={raised} has_dup={has_dup}"   # (a row with 7+ overflowed ids may be reported without a repeat)
+        if k > 256:
+            assert not raised, tag + " (the sorted-row path is exact for every row: nothing to report)"
+        else:
+            assert raised == has_dup or (raised and not has_dup and k >= 8), tag + f" raised={raised} has_dup={has_dup}"   # (a row with 7+ overflowed ids may be reported without a repeat)
         if not raised:
             assert np.array_equal(rmat.cpu().numpy().T, want), tag
         bump("jaccard distinct-ids mode (error iff a row repeats an id)")

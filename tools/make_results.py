@@ -42,7 +42,7 @@ def check_line_against_trace(label, line, stats):
         problem(f"{label}: roofline.kernel_ms {r['kernel_ms'] * 1e3:.2f} us differs from the trace's average {rp[1]:.2f} us of {r['kernel']} by more than 5 %")
     ds = line["config"]["data_sets_per_step"]
     inside = ds * (r["kernel_ms"] + r.get("ingest_kernel_ms", 0.0))
-    if inside > line["ms_per_step"] * 1.02:
+    if inside > max(line["ms_per_step"] * 1.02, line["ms_per_step"] + 0.0005):      # (2 %, or half a microsecond for steps of a few microseconds)
         problem(f"{label}: {ds} x (kernel_ms + ingest_kernel_ms) = {inside:.4f} ms does not fit in ms_per_step {line['ms_per_step']:.4f} ms")
     g = line.get("gficf")
     if g and all(k in stats for k in GFICF_KERNELS):
@@ -283,6 +283,8 @@ def main():
             w("## Tests\n\n`python -m pytest tests -m gpu` on the GPU box: {}.\n".format(tail[-1].strip("= ")))
     if PROBLEMS:
         sys.stderr.write("tools/make_results.py: the records do not hold together:\n" + "".join("  - " + p_ + "\n" for p_ in PROBLEMS))
+        if os.environ.get("MAKE_RESULTS_PREVIEW"):          # a look at the page while the records are being repaired: still exit code 1
+            sys.stdout.write("**RECORDS INCONSISTENT — PREVIEW ONLY**\n\n" + "".join(chunks))
         raise SystemExit(1)
     sys.stdout.write("".join(chunks))
 
