@@ -74,6 +74,25 @@ __host__ __device__ inline uint32_t unscramble16(uint32_t half) {
   return (s * SCR_AINV) & 0xFFFFu;
 }
 
+// ---- sorted rows (csrc/jaccard_sorted.h): which k take them
+__host__ __device__ inline int sorted_kp(int k) { return (k + 63) & ~63; }
+// The smallest k that takes this path.  Beyond GFICF_JACCARD_MAX_K it is the only one; below, the general hash-set kernel
+// (k_jaccard_edges, 64 < k <= 256) competes with it, and loses from SORTED_FROM_DEFAULT on (profiles/r05_sorted_vs_general.txt).
+// GFICF_JACCARD_SORTED_FROM in the environment moves the switch (57 .. 257; every rank of a sharded build must see the same value:
+// dist.assert_same_format compares the GFICF_JACCARD_* environment).
+#ifndef GFICF_JACCARD_SORTED_FROM_DEFAULT
+#define GFICF_JACCARD_SORTED_FROM_DEFAULT 257
+#endif
+inline int sorted_from_k() {
+  static const int v = [] {
+    const char* e = getenv("GFICF_JACCARD_SORTED_FROM");
+    const int t = e ? atoi(e) : GFICF_JACCARD_SORTED_FROM_DEFAULT;
+    return t < 57 ? 57 : t > GFICF_JACCARD_MAX_K + 1 ? GFICF_JACCARD_MAX_K + 1 : t;
+  }();
+  return v;
+}
+inline bool sorted_fmt(int k) { return k >= sorted_from_k(); }
+
 struct TableFmt {
   int kpad;
   bool compact;
@@ -114,7 +133,7 @@ inline bool compact_enabled() {
 
 inline TableFmt table_fmt(int64_t N_total, int k) {
   TableFmt f;
-  f.sorted = k > GFICF_JACCARD_MAX_K;
+  f.sorted = sorted_fmt(k);
   if (f.sorted) {                                            // (a function of k alone)
     f.kpad = 2 * ((k + 63) & ~63);
     f.compact = f.dual = false;

@@ -24,8 +24,7 @@ constexpr uint32_t SORTED_PAD = 0xFFFFFFFFu;
 constexpr int SORTED_SORT_LDS_K = 16384;      // rows sorted in LDS up to this k (64 KB)
 constexpr int SORTED_EDGE_LDS_KP = 2688;      // edge kernel: A, ranks and four B rows in LDS up to this KP (6 x 4 x 2688 = 63 KB)
 
-__host__ __device__ inline int sorted_kp(int k) { return (k + 63) & ~63; }
-__host__ __device__ inline bool sorted_fmt(int k) { return k > GFICF_JACCARD_MAX_K; }
+// (sorted_kp, sorted_from_k and sorted_fmt are defined in jaccard.hip, in front of table_fmt, which needs them)
 
 // Slot-order halves: 64 rows x 64 slots per workgroup step; blockIdx.y = the tile of slots.
 template <typename T>

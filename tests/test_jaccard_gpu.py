@@ -1142,3 +1142,37 @@ def test_one_launch_form_reports_bad_and_repeated_ids(ops):
     want, wu = oracle.jaccard(dup, nthreads=4)
     assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(dup, False), want)
     assert np.array_equal(gficf_amd.jaccard_counts(dup).astype(np.int32).reshape(-1), wu)
+
+
+def test_k_beyond_256_rows_in_local_ids_with_empty_slots_and_the_mapped_neighbour_column(ops):
+    """The sorted-row path behind the sub-problem entries (gficf_jaccard_ingest_local_device: ids in [0, n_ext], 0 = no id in the slot;
+    gficf_jaccard_edges_mapped_device: column 1 = src_offset + cell + 1, column 2 through the local -> global map): an empty slot gives
+    a zero row and is no element of any set.  Expected counts from the multiset rule written out with numpy."""
+    import torch
+
+    n_ext, n_cells, k, src_off = 700, 500, 300, 12345
+    rng = np.random.default_rng(8)
+    mat = np.stack([rng.permutation(n_ext)[:k] + 1 for _ in range(n_ext)]).astype(np.int32)
+    mat[rng.random(mat.shape) < 0.1] = 0                                  # empty slots (also in the own rows)
+    mat[3, :5] = mat[3, 5] if mat[3, 5] else 7                             # ... and a row that repeats an id
+    l2g = (rng.permutation(50_000)[:n_ext] + 1).astype(np.int32)
+    idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
+    table = torch.zeros((n_ext, ops.row_words(n_ext, k)), dtype=torch.int32, device="cuda")
+    ops.jaccard_ingest_local(idx, n_ext, k, table)
+    out = torch.full((3, n_cells * k), -7.0, dtype=torch.float64, device="cuda")
+    u = torch.full((n_cells * k,), -7, dtype=torch.int32, device="cuda")
+    ops.jaccard_edges_mapped(table, n_ext, k, n_cells, src_off, torch.from_numpy(l2g).cuda(), out, u)
+    ops.sync()
+    cnt = np.stack([np.bincount(r[r > 0], minlength=n_ext + 1) for r in mat])            # multiplicity of every id (0 left out) per row
+    wu = np.zeros((n_cells, k), dtype=np.int32)
+    for i in range(n_cells):
+        nb = mat[i]
+        wu[i] = np.where(nb > 0, np.minimum(cnt[i][None, :], cnt[np.maximum(nb, 1) - 1]).sum(axis=1), 0)
+    wu = wu.reshape(-1)
+    assert np.array_equal(u.cpu().numpy(), wu)
+    pos = wu > 0
+    got = out.cpu().numpy()
+    cell = np.repeat(np.arange(n_cells), k)
+    assert np.array_equal(got[0], np.where(pos, src_off + cell + 1.0, 0.0))
+    assert np.array_equal(got[1], np.where(pos, l2g[np.maximum(mat[:n_cells].reshape(-1), 1) - 1].astype(np.float64), 0.0))
+    assert np.array_equal(got[2], np.where(pos, wu / (2.0 * k - wu), 0.0))

@@ -203,6 +203,22 @@ def main():
         w("".join(l + "\n" for l in runs[-1].splitlines()[1:] if "value" in l))          # the last run of the record (the committed tree)
         w("```\n(`bits_d<D>w<W>`: D cells in flight per wave, W waves per workgroup; the file holds the earlier runs too: the first version of the kernel, "
           "which moved ids, headers and counts through LDS, was no faster than the general kernel.)\n\n")
+    def verbatim(fname, title, keep=None):
+        f = os.path.join(P, fname)
+        if os.path.exists(f):
+            lines = [l.rstrip("\n") for l in open(f) if l.strip() and not l.startswith("/opt/amdgpu")]
+            if keep:
+                lines = [l for l in lines if keep(l)]
+            w(title + " (profiles/" + fname + "):\n\n```\n" + "\n".join(l[:230] for l in lines) + "\n```\n\n")
+
+    verbatim(f"{TAG}_direct_ab.txt", "Small problems, the step as a caller sees it (us per step wall / on the device), one box, in-process A/B (`tools/direct_ab.py`): two library calls on the "
+             "table path (what rounds 1-4 timed), one prepared call on the table path, one prepared call on the ONE-LAUNCH form (`csrc/jaccard_direct.h`; taken by default for k <= 16 and <= 65 536 edges)")
+    verbatim(f"{TAG}_bigk_time.txt", "k > 256 (the sorted-row path, `csrc/jaccard_sorted.h`; GFICF_ERR_UNSUPPORTED in round 4), device-resident ingest + edges per call (`tools/bigk_time.py`)",
+             keep=lambda l: l.startswith("N "))
+    verbatim(f"{TAG}_sorted_vs_general.txt", "56 < k <= 256: the general hash-set kernel against the sorted-row path, each in its own process (`tools/sorted_vs_general.py`)")
+    verbatim(f"{TAG}_one_buffer_ab.txt", "A caller that reuses ONE table for every data set pays ~3.7 us per data set at 100 k x 30 (`tools/one_buffer_ab.py`; the outputs do not matter)")
+    verbatim(f"{TAG}_phenograph_order_ab.txt", "`gficf_phenograph_host` at 400 k cells x 10 dimensions, k = 30, Jaccard stage on the caller's order (=0) against cells renumbered in the search's pivot "
+             "order (=1, the default from 2^17 cells on; first call: the pool grows)")
     w("## GF-ICF normalisation (`gficf()`, R/gficf.R:17-105), config 3 shape (23 k genes x 54 k cells)\n\n")
     g = (b or {}).get("gficf")
     if g:
@@ -234,7 +250,15 @@ def main():
             if m:
                 w("| {}: {} | {:.1f} M | {} | {} | {} | {} |\n".format(m.group(1), m.group(2).split("(")[0].strip(), int(m.group(3)) / 1e6, m.group(4), m.group(5), m.group(6), m.group(7)))
         w("\n(box to box this pass spreads by about 12 %: config 4 has been measured between 1.17 / 1.01 ms and 1.35 / 1.14 ms (canonical / begin-end) on the same binary; "
-          "the table is the last run.)\n\n")
+          "the table is the last run.  Round 5: one prepared library call per pass and 100-400 passes per bracket at configs 1-2 — round 4's 0.046 ms at config 1 was mostly "
+          "eighteen ctypes conversions per pass and two device syncs around five passes.)\n\n")
+        for cfg in ("c1", "c2"):
+            st = kstats(f"{TAG}_gficf_{cfg}_kernel_stats.csv")
+            if st:
+                parts = " + ".join("{} {:.1f}".format(GFICF_KERNELS[k_], st[k_][1]) for k_ in GFICF_KERNELS if k_ in st)
+                w("GF-ICF config {} kernels (rocprofv3 averages, us; canonical and begin/end passes mixed in the trace): {}.  ".format(cfg[1], parts))
+        w("At config 1 every kernel sits at the ~5 us floor of a launch with LDS and a barrier: the canonical pass is five of them; replacing a boundary "
+          "(1.5-1.9 us) by a grid barrier (4-6 us: MI355X_MICROARCH.md) would not shorten it.\n\n")
     kn = (b or {}).get("knn")
     if kn:
         gb = kn.get("graph_build") or {}
