@@ -220,367 +220,7 @@ __device__ inline void planar_rows_build4(const uint32_t* const (&ids)[4], int n
   wave_lds_fence_early();
 }
 
-// ------------------------------------------------------------------------------ ingest
-// zero_ok: 0 stands for "no id in this slot" (rows of a sharded sub-problem in local ids, halo.hip) instead of being an error
-template <typename T>
-__device__ inline uint32_t decode_id(T raw, int64_t N, bool& ok, int zero_ok = 0);
-template <>
-__device__ inline uint32_t decode_id<int32_t>(int32_t raw, int64_t N, bool& ok, int zero_ok) {
-  ok = (raw >= 1 && (int64_t)raw <= N) || (zero_ok && raw == 0);
-  return ok ? (uint32_t)raw : 0u;
-}
-template <>
-__device__ inline uint32_t decode_id<double>(double raw, int64_t N, bool& ok, int zero_ok) {
-  // reference: int k = mat(i,j) - 1  (:28) — only integer-valued ids are meaningful.
-  ok = (raw >= 1.0 && raw <= (double)N && raw == trunc(raw)) || (zero_ok && raw == 0.0);
-  return ok ? (uint32_t)raw : 0u;
-}
-
-constexpr int INGEST_ROWS = 64;
-
-// Tile transpose: 64 cells x KPAD slots per step.  Reads are coalesced along cells
-// (column-major input), writes are one contiguous run of the table (64 rows).
-template <typename T, int KPAD, bool CMP>
-__global__ __launch_bounds__(256) void k_ingest(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
-                                                int64_t N_total, uint32_t* __restrict__ table,
-                                                uint32_t* __restrict__ status, int zero_ok, int scan) {
-  __shared__ uint32_t tile[INGEST_ROWS][KPAD + 1];
-  __shared__ uint32_t dup[INGEST_ROWS];
-  constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int64_t row0 = (int64_t)blockIdx.x * INGEST_ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * INGEST_ROWS) {
-    const int64_t r = row0 + lane;
-    bool bad = false;
-    for (int j = wave; j < KPAD; j += 4) {
-      uint32_t v = 0;
-      if (j < k && r < n_rows) {
-        bool ok;
-        v = decode_id<T>(idx[(int64_t)j * ld + r], N_total, ok, zero_ok);
-        bad |= !ok;
-      }
-      tile[lane][j] = v;
-    }
-    if (tid < INGEST_ROWS) dup[tid] = 0;
-    if (bad) atomicOr(status, GFICF_ST_BAD_ID);
-    __syncthreads();
-    // duplicate ids inside a row (multiset case): thread (row = lane, part = wave)
-    bool d = false;
-    for (int j = wave; scan && j < k; j += 4) {
-      const uint32_t a = tile[lane][j];
-      if (a != 0)
-        for (int j2 = 0; j2 < j; ++j2) d |= (tile[lane][j2] == a);
-    }
-    if (d) dup[lane] = 1;
-    __syncthreads();
-    const int64_t rows_here = (n_rows - row0) < INGEST_ROWS ? (n_rows - row0) : INGEST_ROWS;
-    const int n_out = (int)rows_here * ROWW;
-    for (int e = tid; e < n_out; e += 256) {
-      const int rr = e / ROWW, j = e % ROWW;
-      uint32_t v;
-      if (!CMP) {
-        v = tile[rr][j];
-        if (j == 0 && dup[rr]) v |= ROW_DUP_FLAG;
-      } else if (j < CFmt<KPAD>::HIW) {
-        v = scramble16(tile[rr][2 * j] & 0xFFFFu) | (scramble16(tile[rr][2 * j + 1] & 0xFFFFu) << 16);
-      } else {
-        const int j0 = (j - CFmt<KPAD>::HIW) * 32;
-        v = 0;
-        for (int b = 0; b < 32 && j0 + b < CFmt<KPAD>::KC; ++b) v |= ((tile[rr][j0 + b] >> 16) & 1u) << b;
-        if (j == ROWW - 1 && dup[rr]) v |= ROW_DUP_FLAG;
-      }
-      table[row0 * ROWW + e] = v;
-    }
-    __syncthreads();
-  }
-}
-
-// Tile variant for KPAD <= 64 (the common sizes): 64 cells per workgroup of 256 threads.  Reads are coalesced along
-// cells, every (cell, slot) element is one thread's; the tile goes through LDS, then thread (cell = lane, part = wave)
-// holds the cell's row in registers and checks its quarter of the id pairs for duplicates — min over the pairs of
-// a XOR b, VALU only (a compare per pair would funnel through the scalar unit: v_cmp -> s_or, a dependent chain that
-// cost 13 us at 100 k x 30) —, then the rows are packed and leave as contiguous 16 B-per-lane runs.  (Tried instead: every id
-// inserted into a small per-row hash table in LDS with ds_cmpst, one returning atomic per element in place of a compare per
-// pair of elements — 30 us against 10 at 100 k x 30: returning LDS atomics are far slower than the 186 vector instructions
-// per thread of the all-pairs scan.  Round 3, at 64 slots where the scan is 1 225 pairs per row and holds the row in 181
-// registers: an open-addressing table of 128 words per row, every swap of a round in flight together, 94 registers — 55 us
-// against 29 at 100 k x 50; and `dup |= a == b` again, now as v_cmp_eq_u32 + s_or_b64 straight: 38 us against 29, 12.0
-// against 10.7 at 100 k x 30.  The XOR + v_min_u32 form stays.  And once the scan had left the default path (SCAN = false): the
-// rows packed in registers and stored straight from them, no LDS tile — every lane then writes its row's 16 B pieces at a 64 /
-// 128 B stride — 7.8 us against 7.0 at 100 k x 30, 54 against 39 at 1 M x 30: the tile stays for the scan-less form too.)
-template <int KPAD, int W>
-__device__ inline uint32_t dup_part(const uint32_t (&r)[KPAD], int k) {
-  uint32_t m = 0xFFFFFFFFu;                 // min over this part's pairs (j, j2 < j), j = W, W + 4, ...
-#pragma unroll
-  for (int j = W; j < KPAD; j += 4) {
-    if (KPAD < 64 || j < k) {               // wave-uniform: slots past k hold no id (k = 50 in 64 slots: 1225 of the 2016 pairs; at
-                                            // 32 slots the branches cost more than the few pairs they save: +0.9 us at k = 30)
-#pragma unroll
-      for (int j2 = 0; j2 < j; ++j2) {
-        const uint32_t x = r[j] ^ r[j2];
-        m = x < m ? x : m;
-      }
-    }
-  }
-  return m;
-}
-
-// HALO (int32 ids only): the rows of a sharded sub-problem (csrc/halo.hip) read straight from the block's global ids — own cells
-// from idx, halo slots from the reply slots — and mapped to local ids on the fly (the unfused form writes the mapped index
-// matrix first: one more kernel and 2 x 16 MB of traffic per step at 100 k cells); also writes the local -> global map.
-// SCAN = false (gficf_ctx_set_jaccard_distinct): rows are taken to hold distinct ids and no flag is written; the edge kernel
-// finds a repeated id when it inserts the row into its hash set and raises a deferred error.
-template <typename T, int KPAD, bool CMP, bool HALO = false, bool SCAN = true, bool DUAL = false>
-// (Holding the scan-less 64-slot variants to 7 waves per SIMD — so that the 1563 tiles of 100 k cells are all resident, where 79 / 93
-// vector registers give 6 / 5 workgroups per CU — spills 5 / 16 registers and is no faster: 13.1 / 26.5 us against 12.8 / 20.8; the
-// dual variant at 6 waves per SIMD, -DGFICF_INGEST_DUAL_WAVES=6: 9 spills, 24.5 us.)
-#ifndef GFICF_INGEST_DUAL_WAVES
-#define GFICF_INGEST_DUAL_WAVES 1
-#endif
-__global__ __launch_bounds__(256, HALO ? 4 : (DUAL && !SCAN) ? GFICF_INGEST_DUAL_WAVES : 1) void k_ingest_tile(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
-                                                     int64_t N_total, uint32_t* __restrict__ table,
-                                                     uint32_t* __restrict__ status, int zero_ok, const gficf_halo_map hm) {
-  constexpr int ROWS = 64;
-  constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
-  static_assert(!DUAL || (CMP && KPAD == 64), "dual rows are compact rows of 64 slots");
-  constexpr int PITCH = DUAL ? DUAL_PITCH : ROWW;            // words from one table row to the next
-  __shared__ uint32_t tile[ROWS][KPAD + 1];
-  __shared__ uint32_t dup[ROWS];
-  // dual rows: a wave's scratch for the planar part of ONE row (a whole tile of them would cost 8 KB of LDS: six workgroups per CU
-  // instead of nine, 1536 resident ones for the 1563 tiles of 100 k cells — a second round for the last 27: 26 us against 13)
-  __shared__ uint32_t prow[DUAL ? 16 : 1][DUAL ? 32 : 1];     // (four rows in flight per wave)
-  // dual rows: the planar build holds every row's "id >= 65536" mask as a ballot — the two bitmap words of the compact part, which
-  // the writers below would otherwise gather bit by bit from 60 slots (the longest chain of the kernel, on one thread in four)
-  __shared__ uint32_t bmap[DUAL ? ROWS + 3 : 1][2];
-  __shared__ const int32_t* s_peer_idx[HALO ? GFICF_HALO_MAX_PEERS : 1];
-  __shared__ int64_t s_peer_ld[HALO ? GFICF_HALO_MAX_PEERS : 1];
-  // (the wave number as a scalar: a slot index j = wave + 4 m is then uniform and the 64-bit products j * ld stay in scalar registers —
-  // as a vector value they cost two registers per load in flight, 32 of the 64-slot variants' 96, and a whole workgroup per CU)
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // HALO: the launch ingests rows [row_begin, row_end) of the sub-problem (n_rows = row_end); its LAST serve_blocks workgroups do the
-  // owner-side serve step instead (the rows other ranks asked of this one: independent of the ingest, one launch saved per step)
-  int64_t row_first = 0;
-  unsigned ingest_blocks = gridDim.x;
-  if constexpr (HALO) {
-    ingest_blocks = gridDim.x - (unsigned)hm.serve_blocks;
-    if (blockIdx.x >= ingest_blocks) {
-      gficf_halo_serve_rows(reinterpret_cast<const int32_t*>(idx), hm.n_local, k, ld, hm.b, hm.req_in, hm.n_req, hm.rows_out, status,
-                            (int64_t)(blockIdx.x - ingest_blocks) * 256 + tid, (int64_t)hm.serve_blocks * 256);
-      return;
-    }
-    row_first = hm.row_begin;
-    // peer form: the owners' blocks, indexed by a lane's own owner below (a by-value array indexed per lane would go through scratch)
-    if (hm.peer_n > 0) {
-#pragma unroll
-      for (int o = 0; o < GFICF_HALO_MAX_PEERS; ++o)
-        if (tid == o) { s_peer_idx[o] = hm.peer_idx[o]; s_peer_ld[o] = hm.peer_ld[o]; }
-      __syncthreads();
-    }
-  }
-  // (peer form: the tiles are taken from the LAST one down — the few tiles of halo slots in use read their rows through a chain of
-  // dependent loads, request -> owner's pointer -> the owner's block, possibly over xGMI: started first, that latency lies under the
-  // own cells' tiles instead of behind them)
-  const int64_t n_tiles = (n_rows - row_first + ROWS - 1) / ROWS;
-  bool from_last = false;
-  if constexpr (HALO) from_last = hm.peer_n > 0;
-  for (int64_t tile_i = blockIdx.x; tile_i < n_tiles; tile_i += ingest_blocks) {
-    const int64_t row0 = row_first + (from_last ? n_tiles - 1 - tile_i : tile_i) * ROWS;
-    const int64_t r = row0 + lane;
-    // all loads of the thread are issued before the first is looked at
-    T raw[KPAD / 4];
-    if constexpr (HALO) {
-      const int64_t q = r - hm.n_local;                      // halo slot of this row (own cells: negative)
-      const int32_t gid = (r < n_rows && q >= 0) ? hm.req_out[q] : 0;
-      // a tile of halo slots nobody asked for (most of them: the slots in use sit at the front of every owner's cap): nothing refers to
-      // its rows — skipped whole (every wave of the workgroup sees the same 64 slots: the decision is workgroup-uniform)
-      if (hm.skip_empty && row0 >= hm.n_local && __ballot(gid != 0) == 0ull) continue;
-      if (wave == 0 && r < n_rows) hm.l2g[r] = q < 0 ? (int32_t)(hm.b + r + 1) : gid;
-      if (row0 + ROWS <= hm.n_local) {                       // a tile of own cells (workgroup-uniform): the plain loads, all in flight
-#pragma unroll
-        for (int m = 0; m < KPAD / 4; ++m) {
-          const int j = wave + 4 * m;
-          raw[m] = j < k ? idx[(int64_t)j * ld + r] : (T)0;
-        }
-      } else {                                               // the seam tile and the halo slots (most of them empty)
-#pragma unroll
-        for (int m = 0; m < KPAD / 4; ++m) {
-          const int j = wave + 4 * m;
-          int32_t g = 0;
-          if (j < k && r < n_rows) {
-            if (q < 0) g = (int32_t)idx[(int64_t)j * ld + r];
-            else if (gid != 0) {
-              if (hm.peer_n > 0) {                             // the row where it lies: its owner's block (the plan asks owner o only for ids of o's block)
-                const uint32_t o = (uint32_t)q / (uint32_t)hm.cap;
-                g = s_peer_idx[o][(int64_t)j * s_peer_ld[o] + ((int64_t)gid - 1 - (int64_t)o * hm.rpr)];
-              } else g = hm.rows_in[q * k + j];
-            }
-          }
-          raw[m] = (T)g;
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < KPAD / 4; ++m) {                   // global -> local (own rows: an invalid id stays invalid; halo rows: 0)
-        const int j = wave + 4 * m;
-        if (j < k && r < n_rows) {
-          int32_t v = 0;
-          if (q < 0 || gid != 0) {
-            v = gficf_halo_local((int64_t)raw[m], hm.N_total, hm.b, hm.n_local, hm.rpr, hm.cap, hm.winfo, hm.wpo);
-            if (q >= 0 && v < 0) v = 0;
-          }
-          raw[m] = (T)v;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int m = 0; m < KPAD / 4; ++m) {
-        const int j = wave + 4 * m;
-        raw[m] = (j < k && r < n_rows) ? idx[(int64_t)j * ld + r] : (T)0;
-      }
-    }
-    if (tid < ROWS) dup[tid] = 0;
-    bool bad = false;
-#pragma unroll
-    for (int m = 0; m < KPAD / 4; ++m) {
-      const int j = wave + 4 * m;
-      uint32_t v = 0;
-      if (j < k && r < n_rows) {
-        bool ok;
-        v = decode_id<T>(raw[m], N_total, ok, zero_ok);
-        bad |= !ok;
-      }
-      tile[lane][j] = v;
-    }
-    if (bad) atomicOr(status, GFICF_ST_BAD_ID);
-    __syncthreads();
-    if constexpr (SCAN) {
-      uint32_t rr[KPAD];
-#pragma unroll
-      for (int j = 0; j < KPAD; ++j) {
-        const uint32_t v = tile[lane][j];
-        rr[j] = v != 0 ? v : (0x80000000u | (uint32_t)j);       // empty slots: values no id and no other slot has
-      }
-      uint32_t m;
-      switch (wave) {
-        case 0: m = dup_part<KPAD, 0>(rr, k); break;
-        case 1: m = dup_part<KPAD, 1>(rr, k); break;
-        case 2: m = dup_part<KPAD, 2>(rr, k); break;
-        default: m = dup_part<KPAD, 3>(rr, k); break;
-      }
-      if (m == 0) dup[lane] = 1;
-      __syncthreads();
-    }
-    const int64_t rows_here = (n_rows - row0) < ROWS ? (n_rows - row0) : ROWS;
-    if constexpr (DUAL) {                                   // a wave builds the planar parts of 16 rows of the tile, one after the other,
-      for (int r0 = wave * 16; r0 < (int)rows_here && r0 < wave * 16 + 16; r0 += 4) {   // rows 16 w .. 16 w + 15, four at a time,
-        const int n = (int)rows_here - r0 < 4 ? (int)rows_here - r0 : 4;                 // each written as one 128 B run
-        const uint32_t* const ids[4] = {&tile[r0][0], &tile[r0 + 1 < ROWS ? r0 + 1 : r0][0], &tile[r0 + 2 < ROWS ? r0 + 2 : r0][0],
-                                        &tile[r0 + 3 < ROWS ? r0 + 3 : r0][0]};
-        uint32_t dm = 0;
-        if (SCAN)
-          for (int r = 0; r < n; ++r) dm |= (dup[r0 + r] != 0u ? 1u : 0u) << r;
-        planar_rows_build4(ids, n, k, dm, &prow[wave * 4], lane, &bmap[r0]);
-        const int r = lane >> 4, w2 = (lane & 15) * 2;                                   // 16 lanes per row, 8 B each
-        if (r < n) *reinterpret_cast<uint2*>(table + (row0 + r0 + r) * PITCH + ROWW + w2) = make_uint2(prow[wave * 4 + r][w2], prow[wave * 4 + r][w2 + 1]);
-        wave_lds_fence_early();
-      }
-      __syncthreads();                                      // (the masks are read by whichever thread writes the row's last words)
-    }
-    const int n_out4 = (int)rows_here * (ROWW / 4);
-    for (int e = tid; e < n_out4; e += 256) {
-      const int rr = e / (ROWW / 4), j0 = (e % (ROWW / 4)) * 4;
-      uint4* const dst4 = reinterpret_cast<uint4*>(table + (row0 + rr) * PITCH + j0);       // (PITCH == ROWW unless the rows are dual)
-      uint32_t w4[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int j = j0 + c;
-        uint32_t x;
-        if (!CMP) {
-          x = tile[rr][j];
-          if (j == 0 && dup[rr]) x |= ROW_DUP_FLAG;
-        } else if (j < CFmt<KPAD>::HIW) {
-          x = scramble16(tile[rr][2 * j] & 0xFFFFu) | (scramble16(tile[rr][2 * j + 1] & 0xFFFFu) << 16);
-        } else if (DUAL) {
-          x = bmap[rr][j - CFmt<KPAD>::HIW];
-          if (j == ROWW - 1 && dup[rr]) x |= ROW_DUP_FLAG;
-        } else {
-          const int b0 = (j - CFmt<KPAD>::HIW) * 32;
-          x = 0;
-#pragma unroll
-          for (int b = 0; b < 32; ++b)
-            if (b0 + b < CFmt<KPAD>::KC) x |= ((tile[rr][b0 + b] >> 16) & 1u) << b;
-          if (j == ROWW - 1 && dup[rr]) x |= ROW_DUP_FLAG;
-        }
-        w4[c] = x;
-      }
-      *dst4 = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-    }
-    __syncthreads();
-  }
-}
-
-// Register variant for KPAD <= 64: one thread per cell.  The k loads of a thread are independent
-// (all in flight at once) and each is a coalesced 256 B run per wave; duplicate detection is an
-// all-pairs compare in registers; the tile goes through LDS once so that the table is written as
-// contiguous 16 B-per-lane runs.
-constexpr int INGEST2_ROWS = 64;
-
-template <typename T, int KPAD, bool CMP>
-__global__ __launch_bounds__(INGEST2_ROWS) void k_ingest_reg(const T* __restrict__ idx, int64_t n_rows, int k, int64_t ld,
-                                                             int64_t N_total, uint32_t* __restrict__ table,
-                                                             uint32_t* __restrict__ status, int zero_ok) {
-  constexpr int ROWW = CMP ? CFmt<KPAD>::ROWW : KPAD;
-  __shared__ uint32_t tile[INGEST2_ROWS][ROWW + 1];
-  const int tid = threadIdx.x;
-  for (int64_t row0 = (int64_t)blockIdx.x * INGEST2_ROWS; row0 < n_rows; row0 += (int64_t)gridDim.x * INGEST2_ROWS) {
-    const int64_t r = row0 + tid;
-    uint32_t v[KPAD];
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < KPAD; ++j) {
-      v[j] = 0;
-      if (j < k && r < n_rows) {
-        bool ok;
-        v[j] = decode_id<T>(idx[(int64_t)j * ld + r], N_total, ok, zero_ok);
-        bad |= !ok;
-      }
-    }
-    if (bad) atomicOr(status, GFICF_ST_BAD_ID);
-    bool dup = false;
-#pragma unroll
-    for (int j = 1; j < KPAD; ++j) {
-      bool dj = false;
-#pragma unroll
-      for (int j2 = 0; j2 < j; ++j2) dj |= (v[j] == v[j2]);
-      dup |= dj && v[j] != 0;
-    }
-    if (!CMP) {
-      if (dup) v[0] |= ROW_DUP_FLAG;
-#pragma unroll
-      for (int j = 0; j < KPAD; ++j) tile[tid][j] = v[j];
-    } else {
-      using F = CFmt<KPAD>;
-#pragma unroll
-      for (int w = 0; w < F::HIW; ++w) tile[tid][w] = scramble16(v[2 * w] & 0xFFFFu) | (scramble16(v[2 * w + 1] & 0xFFFFu) << 16);
-#pragma unroll
-      for (int h = 0; h < F::NW; ++h) {
-        uint32_t hw = 0;
-#pragma unroll
-        for (int b = 0; b < 32; ++b)
-          if (h * 32 + b < F::KC) hw |= ((v[h * 32 + b] >> 16) & 1u) << b;
-        if (h == F::NW - 1 && dup) hw |= ROW_DUP_FLAG;
-        tile[tid][F::HIW + h] = hw;
-      }
-    }
-    __syncthreads();
-    const int64_t rows_here = (n_rows - row0) < INGEST2_ROWS ? (n_rows - row0) : INGEST2_ROWS;
-    const int n_out4 = (int)rows_here * (ROWW / 4);
-    uint4* const out4 = reinterpret_cast<uint4*>(table + row0 * ROWW);
-    for (int e = tid; e < n_out4; e += INGEST2_ROWS) {
-      const int rr = e / (ROWW / 4), jj = (e % (ROWW / 4)) * 4;
-      out4[e] = make_uint4(tile[rr][jj], tile[rr][jj + 1], tile[rr][jj + 2], tile[rr][jj + 3]);
-    }
-    __syncthreads();
-  }
-}
+#include "jaccard_ingest.h"
 
 // ------------------------------------------------------------------------------- edges
 template <int KPAD>
@@ -858,1058 +498,11 @@ __device__ inline int group_sum(int x) {
   return x;
 }
 
-// One wave per cell, cells strided over all waves of the grid.  Per cell:
-//   * row i (one id per lane) is inserted into the wave's LDS hash set; keys that find both
-//     slots of their bucket taken go to a small per-wave overflow list;
-//   * "steps": each lane loads 16 B of a neighbour row (4 ids wide / 8 ids compact), so ROWB/16 lanes cover
-//     one row and a wave-instruction gathers RPS = 1024/ROWB rows; U steps are in flight together;
-//   * every lane probes the set with its ids (one ds_read_b64 per id), the per-row
-//     intersection count is a DPP sum over the row's lanes;
-//   * counts are permuted back to one-slot-per-lane and stored as three coalesced runs.
-// The load of the next cell's own row is issued ahead of the gathers and the stores of the
-// previous cell's edges behind them, so neither sits on the wait for the gathers.
-// MAP: the table holds the local ids of a sharded sub-problem; the neighbour column is written through o.l2g (loaded per cell
-// right after the own row is decoded, long before the edges are stored: a load at the store would put the wait for the gathers
-// in front of it).
-template <int KPAD, bool BIG, bool CMP, int OUT, bool MAP = false>
-__global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
-    const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
-  using C = JCfg<KPAD, CMP>;
-  using F = CFmt<KPAD>;
-  static_assert(!(BIG && CMP), "compact rows hold 17-bit ids");
-  using off_t = typename std::conditional<BIG, uint64_t, uint32_t>::type;
-  // LDS (dynamic, laid out here so that a wave's hash set starts at a multiple of its size and a probe
-  // address is (hash & mask) | wave_base):  hash sets | overflow list / slow-path rows | weight table
-  extern __shared__ unsigned char smem[];
-  constexpr uint32_t HBYTES = C::NB * 8;                      // bytes of one hash set
-  constexpr uint32_t SETS = 1;
-  constexpr uint32_t WBYTES = SETS * HBYTES;                  // bytes of one wave's set(s)
-  uint32_t(*const s_rows)[2][KPAD] = reinterpret_cast<uint32_t(*)[2][KPAD]>(smem + C::WAVES * WBYTES);
-  double* const s_lut = reinterpret_cast<double*>(smem + C::WAVES * WBYTES + C::WAVES * 2 * KPAD * 4);
+#include "jaccard_edges_general.h"
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  // the wave's number as a scalar: everything derived from it (the cell index, row and output addresses) then lives in
-  // scalar registers and is computed on the scalar unit instead of per lane
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned char* const hbase = smem + wave * WBYTES;          // this wave's hash set(s)
-  // W[u] = u / (2.0*k - u): same IEEE-754 double division as reference :51
-  constexpr uint32_t DUPF_OFF = edges_dupflag_off<KPAD, CMP>();
-  for (int u = tid; u <= k; u += C::WAVES * 64) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);
-  for (int b = lane; b < (int)(SETS * C::NB); b += 64) reinterpret_cast<uint2*>(hbase)[b] = make_uint2(EMPTY, EMPTY);
-  if (lane == 0) *reinterpret_cast<uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) = 0u;
-  __syncthreads();
+#include "jaccard_edges_pipe.h"
 
-  // LDS byte address of this wave's hash set (a multiple of WBYTES: dynamic LDS starts at 0 here,
-  // there is no static LDS in this kernel), OR-ed with a bucket offset per probe.  Kept in a vector register (derived
-  // from the vector thread id) so that mask-and-base is ONE v_and_or_b32 per probe (a scalar base would take the
-  // instruction's only scalar operand slot away from the mask).
-  const uint32_t wave_off = lds_address(smem) + (uint32_t)(tid >> 6) * WBYTES;
-  // compact rows: the bucket mask and bit 16 as vector registers (operands of v_bitop3_b32)
-  uint32_t bmask_v = (uint32_t)(C::NB - 1) << 3, bit16_v = 0x10000u;
-  asm volatile("" : "+v"(bmask_v), "+v"(bit16_v));
-  uint32_t* const ovlist = s_rows[wave][0];
-  const char* const tbytes = reinterpret_cast<const char*>(table);
-  const int grow = lane / C::LPR;                           // which of the RPS rows of a step this lane reads
-  const int gl = lane % C::LPR;                             // this lane's 16 B piece of that row
-  const uint32_t gcol = (uint32_t)gl * 16u;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  const int64_t nwaves = (int64_t)gridDim.x * C::WAVES;
-  constexpr uint32_t ROWB = C::ROWB;
-  constexpr int ROWW = ROWB / 4;
-  // compact rows: where this lane finds the high bits of its 8 ids — byte (gl & 3) of high word gl / 4, which
-  // sits in component hi_c of the piece held by lane hi_l of the row's lane group
-  const int hi_abs = F::HIW + (gl >> 2);
-  const int hi_l = lane - gl + (hi_abs >> 2), hi_c = hi_abs & 3;
-  const bool tail = gl >= F::KC / 8;                        // the lane(s) holding the high-bit words
-
-  // Own row of a cell: slot s -> register s / 64, lane s % 64.  The loads are issued one cell ahead and their
-  // results stay untouched in registers until the next iteration decodes them (any arithmetic on them here would
-  // put the wait for the load in front of the gathers).
-  struct OwnRaw {
-    uint32_t v[C::EPL];      // wide: the id word; compact: the 16-bit low half
-    uint32_t hw[C::EPL];     // compact: the word of high bits covering the slot
-    uint32_t last;           // compact: the row's last word (duplicate flag)
-  };
-  auto load_own = [&](int64_t row, OwnRaw& r) {
-    const uint32_t* const rw = table + row * ROWW;
-    if (CMP) r.last = rw[ROWW - 1];
-#pragma unroll
-    for (int q = 0; q < C::EPL; ++q) {
-      const int s = q * 64 + lane;
-      r.v[q] = 0;
-      r.hw[q] = 0;
-      if (s < C::NSLOT) {
-        if (!CMP) {
-          r.v[q] = rw[s];
-        } else {
-          r.v[q] = reinterpret_cast<const uint16_t*>(rw)[s];
-          r.hw[q] = (KPAD == 32) ? 0u : rw[F::HIW + (s >> 5)];      // KPAD = 32: the only high word is the last word
-        }
-      }
-    }
-  };
-  // out: id | bit 31 = the row's duplicate flag; key: the form the hash set holds (wide: the id; compact: the stored,
-  // pre-hashed half | bit 16 of the id)
-  auto decode_own = [&](const OwnRaw& r, uint32_t (&out)[C::EPL], uint32_t (&key)[C::EPL]) {
-#pragma unroll
-    for (int q = 0; q < C::EPL; ++q) {
-      if (!CMP) {
-        out[q] = r.v[q];
-        key[q] = r.v[q] & ID_MASK;
-      } else {
-        const int s = q * 64 + lane;
-        const uint32_t hw = (KPAD == 32) ? r.last : r.hw[q];
-        const uint32_t hbit = ((hw >> (s & 31)) & 1u) << 16;
-        const bool ok = s < C::NSLOT;
-        key[q] = ok ? (r.v[q] | hbit) : 0u;
-        out[q] = ok ? (unscramble16(r.v[q]) | hbit | (r.last & ROW_DUP_FLAG)) : 0u;
-      }
-    }
-  };
-
-  int64_t i = cell_begin + (int64_t)xcd_block(blockIdx.x, gridDim.x, o.xcd) * C::WAVES + wave;
-  OwnRaw raw;
-  raw.last = 0;
-#pragma unroll
-  for (int q = 0; q < C::EPL; ++q) { raw.v[q] = 0; raw.hw[q] = 0; }
-  if (i < cell_end) load_own(i, raw);
-  // edges of the previous cell, stored while the current cell's gathers are in flight
-  bool have_prev = false;
-  int64_t prev_i = 0;
-  uint32_t prev_a[C::EPL];
-  int prev_u[C::EPL];
-
-  auto store_prev = [&]() {
-    const int64_t pb = (prev_i - cell_begin) * (int64_t)k;
-#pragma unroll
-    for (int qq = 0; qq < C::EPL; ++qq) {
-      const int slot = qq * 64 + lane;
-      if (slot < C::NSLOT && slot < k) store_edge<OUT>(o, pb + slot, prev_i, prev_a[qq], prev_u[qq], s_lut);
-    }
-    have_prev = false;
-  };
-
-  // ids of a gathered piece (bv) -> id[]; returns the word that may carry the row's duplicate flag
-  auto piece_ids = [&](const uint4& bv, uint32_t (&id)[C::IPL]) -> uint32_t {
-    if (!CMP) {
-      id[0] = bv.x & ID_MASK;                // only a row's first id can carry the duplicate flag
-      id[1] = bv.y;
-      id[2] = bv.z;
-      id[3] = bv.w;
-      return bv.x;
-    }
-    // the high-bit word of this lane's ids, from the lane that holds it
-    uint32_t hw;
-    if (KPAD == 32) {
-      hw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv.w, 0xFF, 0xf, 0xf, false);   // quad_perm [3,3,3,3]
-    } else {
-      hw = 0;
-      if (F::NW >= 4) { const uint32_t v = (uint32_t)__shfl((int)bv.x, hi_l); hw = hi_c == 0 ? v : hw; }
-      if (F::NW >= 4) { const uint32_t v = (uint32_t)__shfl((int)bv.y, hi_l); hw = hi_c == 1 ? v : hw; }
-      { const uint32_t v = (uint32_t)__shfl((int)bv.z, hi_l); hw = hi_c == 2 ? v : hw; }
-      { const uint32_t v = (uint32_t)__shfl((int)bv.w, hi_l); hw = hi_c == 3 ? v : hw; }
-    }
-    uint32_t hb = (hw >> ((gl & 3) * 8)) & 0xFFu;
-    uint32_t wd[4] = {bv.x, bv.y, bv.z, bv.w};
-    if (tail) {                              // high-bit words are not ids
-      hb &= (1u << (F::KC % 8)) - 1u;
-#pragma unroll
-      for (int c = (F::KC % 8) / 2; c < 4; ++c) wd[c] = 0u;
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const uint32_t lo = (t & 1) ? (wd[t >> 1] >> 16) : (wd[t >> 1] & 0xFFFFu);
-      id[t] = lo | ((hb << (16 - t)) & 0x10000u);
-    }
-    return (gl == C::LPR - 1) ? bv.w : 0u;   // the row's last word holds the flag
-  };
-
-  // compact rows: the piece's four words with the high-bit words zeroed (wd), and the byte of high bits of this
-  // lane's 8 ids (hb); returns the word that may carry the row's duplicate flag
-  auto piece_words = [&](const uint4& bv, uint32_t (&wd)[4], uint32_t& hb) -> uint32_t {
-    uint32_t hw;
-    if (KPAD == 32) {
-      hw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv.w, 0xFF, 0xf, 0xf, false);   // quad_perm [3,3,3,3]
-    } else {
-      hw = 0;
-      if (F::NW >= 4) { const uint32_t v = (uint32_t)__shfl((int)bv.x, hi_l); hw = hi_c == 0 ? v : hw; }
-      if (F::NW >= 4) { const uint32_t v = (uint32_t)__shfl((int)bv.y, hi_l); hw = hi_c == 1 ? v : hw; }
-      { const uint32_t v = (uint32_t)__shfl((int)bv.z, hi_l); hw = hi_c == 2 ? v : hw; }
-      { const uint32_t v = (uint32_t)__shfl((int)bv.w, hi_l); hw = hi_c == 3 ? v : hw; }
-    }
-    hb = (hw >> ((gl & 3) * 8)) & 0xFFu;
-    wd[0] = bv.x; wd[1] = bv.y; wd[2] = bv.z; wd[3] = bv.w;
-    if (tail) {                              // high-bit words are not ids
-      hb &= (1u << (F::KC % 8)) - 1u;
-#pragma unroll
-      for (int c = (F::KC % 8) / 2; c < 4; ++c) wd[c] = 0u;
-    }
-    return (gl == C::LPR - 1) ? bv.w : 0u;   // the row's last word holds the flag
-  };
-
-  for (; i < cell_end; i += nwaves) {
-    uint32_t araw[C::EPL], a[C::EPL], akey[C::EPL], asafe[C::EPL];
-    decode_own(raw, araw, akey);
-    uint32_t flags = 0;
-#pragma unroll
-    for (int q = 0; q < C::EPL; ++q) {
-      flags |= araw[q];
-      a[q] = araw[q] & ID_MASK;
-      // a slot without a usable id (padding, rejected id) gathers the cell's own row instead; its
-      // count is discarded at the store
-      asafe[q] = a[q] != 0 ? a[q] : (uint32_t)(i + 1);
-    }
-    uint32_t ag[C::EPL];                         // what column 2 shows for the slot
-#pragma unroll
-    for (int q = 0; q < C::EPL; ++q) ag[q] = MAP ? (uint32_t)o.l2g[asafe[q] - 1] : a[q];
-    bool slow = __ballot((flags & ROW_DUP_FLAG) != 0) != 0ull;
-    // next cell's own row: ahead of the gathers, so that it has landed by the next iteration
-    const int64_t i_next = i + nwaves;
-    if (i_next < cell_end) load_own(i_next, raw);
-
-    int myu[C::EPL];
-#pragma unroll
-    for (int q = 0; q < C::EPL; ++q) myu[q] = 0;
-    int myslot[C::EPL];
-    int nov = 0;
-#pragma unroll
-    for (int q = 0; q < C::EPL; ++q) myslot[q] = -1;
-    bool prev_stored = false;
-
-    if (!slow) {
-      uint32_t dupflags = 0;
-      bool inserted = false, dup_here = false, own_dup = false;
-#pragma unroll
-      for (int q = 0; q < C::EPL; ++q) {        // q: which register of row i holds the slots of these steps
-        for (int t0 = 0; t0 < C::SPQ && (q * 64 + t0 * C::RPS) < k; t0 += C::U) {
-          uint4 bv[C::U];
-          // issue the gathers of U steps (U*RPS neighbour rows) before anything else
-#pragma unroll
-          for (int uu = 0; uu < C::U; ++uu) {
-            const uint32_t dst = (uint32_t)__shfl((int)asafe[q], (t0 + uu) * C::RPS + grow);
-            const off_t off = (off_t)(dst - 1) * ROWB + gcol;
-            bv[uu] = *reinterpret_cast<const uint4*>(tbytes + off);
-          }
-          if (!prev_stored) {
-            // the previous cell's edges ride behind the gathers (younger in vmcnt order, and of a count the compiler
-            // knows, so the wait for the gathers does not wait for them)
-            prev_stored = true;
-            if (have_prev) store_prev();
-          }
-          if (!inserted) {
-            // row i into the hash set, under the latency of the first gathers
-            inserted = true;
-#pragma unroll
-            for (int qi = 0; qi < C::EPL; ++qi) {
-              bool over = false;
-              if (a[qi] != 0) {
-                // wide rows: keyed by the id through the multiplicative hash; compact rows: keyed by the stored form,
-                // whose bits 3.. ARE the hash
-                const uint32_t key = akey[qi];
-                const uint32_t bo = (CMP ? (key & ((uint32_t)(C::NB - 1) << 3)) : bucket_off<KPAD, BIG>(key)) + (uint32_t)wave * WBYTES;   // byte offset of the bucket in smem
-                uint32_t old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo), EMPTY, key);
-                if (old == EMPTY) {
-                  myslot[qi] = (int)bo;
-                } else {
-                  dup_here |= old == key;        // an id twice in the row: the later one meets the earlier in one of the two slots ...
-                  old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo + 4), EMPTY, key);
-                  if (old == EMPTY) myslot[qi] = (int)bo + 4;
-                  else { dup_here |= old == key; over = true; }
-                }
-              }
-              const unsigned long long om = __ballot(over);
-              if (om) {
-                if (over) ovlist[nov + __popcll(om & lt_mask)] = akey[qi];
-                nov += __popcll(om);
-              }
-            }
-            wave_lds_fence();
-            if (nov > 1) dup_here |= ovlist_repeats(ovlist, nov);      // ... or both overflowed (rare)
-            if (dup_here) *reinterpret_cast<uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) = 1u;   // reported at the kernel's end
-            own_dup = __ballot(dup_here) != 0ull;
-          }
-          int cnt[C::U];
-#pragma unroll
-          for (int uu = 0; uu < C::U; ++uu) {
-            uint32_t miss = 0;
-            int c;
-            if (!CMP) {
-              uint32_t id[C::IPL];
-              dupflags |= piece_ids(bv[uu], id);
-              // all probes of the piece are issued before the first is compared
-              uint2 h[C::IPL];
-#pragma unroll
-              for (int t = 0; t < C::IPL; ++t) h[t] = lds_read_b64(bucket_off<KPAD, BIG>(id[t]) | wave_off);
-              // misses, counted on the vector ALU alone: min(slot0 ^ id, slot1 ^ id, 1) is 0 on a hit and 1 on a miss (a compare
-              // per slot would go v_cmp -> s_or -> v_addc through the scalar unit and its wait states for every probe)
-#pragma unroll
-              for (int t = 0; t < C::IPL; t += 2) {
-                const uint32_t m0 = min3u_one(h[t].x ^ id[t], h[t].y ^ id[t]);
-                const uint32_t m1 = min3u_one(h[t + 1].x ^ id[t + 1], h[t + 1].y ^ id[t + 1]);
-                miss += m0 + m1;                 // one v_add3_u32
-              }
-              c = C::IPL - (int)miss;
-              if (nov) {                          // wave-uniform, rare: ids that overflowed the set
-                for (int t = 0; t < nov; ++t) {
-                  const uint32_t ov = ovlist[t];
-#pragma unroll
-                  for (int tt = 0; tt < C::IPL; ++tt) c += (id[tt] == ov);
-                }
-              }
-            } else {
-              uint32_t wd[4], hb;
-              dupflags |= piece_words(bv[uu], wd, hb);
-              c = probe_compact_piece(wd, hb, bmask_v, bit16_v, wave_off);
-              if (nov) {                          // wave-uniform, rare: ids that overflowed the set (kept in their stored form)
-                for (int t = 0; t < nov; ++t) {
-                  const uint32_t ov = ovlist[t];
-#pragma unroll
-                  for (int tt = 0; tt < 8; ++tt) c += (piece_key(wd, hb, tt) == ov);
-                }
-              }
-            }
-            cnt[uu] = c;
-          }
-#pragma unroll
-          for (int uu = 0; uu < C::U; ++uu) {
-            const int rowcnt = group_sum<C::LPR>(cnt[uu]);
-            // slot s = (t0+uu)*RPS + r lives in lane s of myu[q]; its count sits in lanes r*LPR..
-            const int v = __shfl(rowcnt, (lane % C::RPS) * C::LPR);
-            myu[q] = (lane / C::RPS == t0 + uu) ? v : myu[q];
-          }
-        }
-      }
-      // a neighbour row with duplicate ids (or the own row, found at the insert): redo this cell exactly
-      slow = own_dup || __ballot((dupflags & ROW_DUP_FLAG) != 0) != 0ull;
-    }
-    if (!prev_stored && have_prev) store_prev();    // own row with duplicates (or k == 0): the gather loop was skipped
-    // ---- clear this cell's keys from the set
-#pragma unroll
-    for (int q = 0; q < C::EPL; ++q)
-      if (myslot[q] >= 0) *reinterpret_cast<uint32_t*>(smem + myslot[q]) = EMPTY;
-    wave_lds_fence();
-    if (slow) {
-      slow_cell<KPAD, CMP, OUT>(table, i, k, (i - cell_begin) * (int64_t)k, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w,
-                                o.u, o.u16, o.set_mode, s_lut, o.l2g, o.src_off);
-    } else {
-      have_prev = true;
-      prev_i = i;
-#pragma unroll
-      for (int q = 0; q < C::EPL; ++q) {
-        prev_a[q] = ag[q];
-        prev_u[q] = a[q] != 0 ? myu[q] : 0;      // rejected id: zero row
-      }
-    }
-  }
-  if (have_prev) store_prev();
-  // a row of this wave's cells named an id twice: the deferred report of the "distinct ids" mode (no flags in the table)
-  wave_lds_fence();
-  if (*reinterpret_cast<const uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) != 0u && lane == 0) {
-    uint32_t* const st = edge_kernel_dup_status();
-    if (st != nullptr) atomicOr(st, GFICF_ST_DUP_IDS);
-  }
-}
-
-// ------------------------------------------------------------------ edge kernel, software-pipelined (k <= 32)
-// The kernel above is bound by neither its arithmetic nor its LDS probes (tools/lab: taking ALL probes out leaves its time
-// unchanged, 40 fewer vector instructions per cell likewise) but by the latency of a cell's row gathers, which nothing in
-// the wave overlaps: a wave issues the gathers of cell i and waits for them before it can do anything else.  This variant,
-// for the row sizes whose gathers all fit in registers at once (k <= 32: one batch per cell), keeps TWO cells in
-// flight per wave: the gathers of cell i+1 (and the own row of cell i+2) are issued before cell i's pieces are probed, so
-// the memory system always has the wave's next requests while the wave computes.  For the wait on cell i's pieces to
-// leave the younger requests alone the compiler must know how many there are: every load and store between two
-// waits is unconditional (indices are clamped instead of branched on, the first cell is peeled instead of guarded), and
-// cells that need the exact multiset path (rows with duplicate ids) are only flagged here and redone after the loop.
-// Output: a wave takes its cells four consecutive ones at a time, parks (neighbour id, count) of each in LDS and writes
-// the quad's 4k edges of every array with ONE store of 16 B per lane (k = 30: 960 B = 15 whole 64 B segments) instead of
-// four runs of k x 8 B that straddle segments: 17 % fewer write requests, none of them partial (memory-only model,
-// tools/lab/gather_lab.hip: 39.8 -> 35.5 us at 100 k x 30).
-// B16 = false (compact rows only): N < 2^16, no id has bit 16 — the bitmap words of the rows are zero and are not looked at.
-// NOFLAG: the table was ingested without the duplicate scan (gficf_ctx_set_jaccard_distinct) and carries no row flags: the
-// kernel does not look for them (own row, every gathered piece: ~8 of its ~200 vector instructions per cell); a repeated id
-// is found at the own row's insert, as in every variant.
-template <int KPAD, bool BIG, bool CMP, int OUT, bool B16 = true, bool MAP = false, bool NOFLAG = false>
-__global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
-    const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
-  using C = JCfg<KPAD, CMP>;
-  using F = CFmt<KPAD>;
-  // (Extended to 32 < k <= 64 — eight gather steps per cell, edges leaving a pair of cells at a time — the kernel needs 177
-  // vector registers: two waves per SIMD, 164 us against 129 us of the one-cell-at-a-time kernel at 100 k x 50.  Not kept.)
-  static_assert(C::EPL == 1 && C::SPQ <= 4, "one batch of gathers per cell");
-  static_assert(!(BIG && CMP), "compact rows hold 17-bit ids");
-  using off_t = typename std::conditional<BIG, uint64_t, uint32_t>::type;
-  constexpr int NST = C::SPQ;                                 // gather steps of a cell, all in flight together
-  extern __shared__ unsigned char smem[];
-  constexpr uint32_t HBYTES = C::NB * 8;
-  constexpr uint32_t SETS = 1;
-  constexpr uint32_t WBYTES = SETS * HBYTES;
-  uint32_t(*const s_rows)[2][KPAD] = reinterpret_cast<uint32_t(*)[2][KPAD]>(smem + C::WAVES * WBYTES);
-  double* const s_lut = reinterpret_cast<double*>(smem + C::WAVES * WBYTES + C::WAVES * 2 * KPAD * 4);
-  constexpr uint32_t STAGE_OFF = C::WAVES * WBYTES + C::WAVES * 2 * KPAD * 4 + (GFICF_JACCARD_MAX_K + 1) * 8;   // behind the weight table
-  constexpr uint32_t STAGE_WAVE = 4 * 64 * 8;                 // 4 cells x 64 lanes x {id, count}
-  constexpr uint32_t DUPF_OFF = edges_dupflag_off<KPAD, CMP>();
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  unsigned char* const hbase = smem + wave * WBYTES;
-  for (int u = tid; u <= k; u += C::WAVES * 64) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);   // reference :51
-  for (int b = lane; b < (int)(SETS * C::NB); b += 64) reinterpret_cast<uint2*>(hbase)[b] = make_uint2(EMPTY, EMPTY);
-  for (int t = lane; t < 4 * 64; t += 64) reinterpret_cast<uint2*>(smem + STAGE_OFF + (uint32_t)wave * STAGE_WAVE)[t] = make_uint2(0u, 0u);
-  if (lane == 0) *reinterpret_cast<uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) = 0u;
-  __syncthreads();
-
-  const uint32_t wave_off = lds_address(smem) + (uint32_t)(tid >> 6) * WBYTES;
-  // compact rows: the bucket mask and bit 16 as vector registers (operands of v_bitop3_b32)
-  uint32_t bmask_v = (uint32_t)(C::NB - 1) << 3, bit16_v = 0x10000u;
-  asm volatile("" : "+v"(bmask_v), "+v"(bit16_v));
-  uint32_t* const ovlist = s_rows[wave][0];
-  const char* const tbytes = reinterpret_cast<const char*>(table);
-  const int grow = lane / C::LPR, gl = lane % C::LPR;
-  const uint32_t gcol = (uint32_t)gl * 16u;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  const int64_t nwaves = (int64_t)gridDim.x * C::WAVES;
-  constexpr uint32_t ROWB = C::ROWB;
-  constexpr int ROWW = ROWB / 4;
-  const int hi_abs = F::HIW + (gl >> 2);
-  const int hi_l = lane - gl + (hi_abs >> 2), hi_c = hi_abs & 3;
-  const bool tail = gl >= F::KC / 8;
-  const int slot_c = lane < C::NSLOT ? lane : C::NSLOT - 1;  // lanes beyond the row's slots load a valid slot and are masked at the decode
-  const bool slot_ok = lane < C::NSLOT;
-
-  // the wave's cells: quads of four consecutive cells, quad q0 + m * nwaves for m = 0, 1, ...
-  const int64_t first = cell_begin + 4 * ((int64_t)xcd_block(blockIdx.x, gridDim.x, o.xcd) * C::WAVES + wave);
-  if (first >= cell_end) return;                              // (after the barrier; wave-uniform)
-  const int64_t last_cell = cell_end - 1;
-  const int64_t quad_step = 4 * nwaves - 3;                   // from the last cell of a quad to the first of the wave's next
-  // quad store: lane L holds edges 2L and 2L + 1 of the quad's 4k; (cell in quad, slot) of both, as LDS addresses
-  const uint32_t stage_w = lds_address(smem) + STAGE_OFF + (uint32_t)(tid >> 6) * STAGE_WAVE;
-  int qc0, qc1;
-  uint32_t qra0, qra1;
-  {
-    const int e0 = 2 * lane, e1 = e0 + 1;
-    qc0 = (e0 >= k) + (e0 >= 2 * k) + (e0 >= 3 * k);
-    qc1 = (e1 >= k) + (e1 >= 2 * k) + (e1 >= 3 * k);
-    int j0 = e0 - qc0 * k, j1 = e1 - qc1 * k;               // lanes past the quad's edges: clamped (their stores fall outside the descriptor)
-    j0 = j0 < 63 ? j0 : 63;
-    j1 = j1 < 63 ? j1 : 63;
-    qra0 = stage_w + (uint32_t)(qc0 * 64 + j0) * 8u;
-    qra1 = stage_w + (uint32_t)(qc1 * 64 + j1) * 8u;
-  }
-
-  struct OwnRaw { uint32_t v, hw, last; };
-  // own row of a cell: loads only (unconditional), decoded one iteration later
-  auto load_own = [&](int64_t row, OwnRaw& r) {
-    const uint32_t* const rw = table + row * ROWW;
-    if (!CMP) {
-      r.v = rw[slot_c];
-      r.hw = 0; r.last = 0;
-    } else {
-      r.last = rw[ROWW - 1];
-      r.v = reinterpret_cast<const uint16_t*>(rw)[slot_c];
-      r.hw = (KPAD == 32) ? 0u : rw[F::HIW + (slot_c >> 5)];
-    }
-  };
-  // The own row in the form the hash set holds (wide: id | bit 31 = the row's duplicate flag; compact: stored, pre-hashed
-  // half | bit 16 of the id | bit 31 = the flag); 0 for lanes without a slot.  true_id() gives the id itself.
-  auto decode_own = [&](const OwnRaw& r) -> uint32_t {
-    uint32_t x;
-    if (!CMP) x = r.v;
-    else if (B16) x = r.v | ((((KPAD == 32 ? r.last : r.hw) >> (lane & 31)) & 1u) << 16) | (NOFLAG ? 0u : (r.last & ROW_DUP_FLAG));
-    else x = r.v | (NOFLAG ? 0u : (r.last & ROW_DUP_FLAG));
-    return slot_ok ? x : 0u;
-  };
-  auto true_id = [&](uint32_t keyraw) -> uint32_t {
-    const uint32_t x = keyraw & ID_MASK;
-    return CMP ? (unscramble16(x & 0xFFFFu) | (x & 0x10000u)) : x;
-  };
-  auto issue_gathers = [&](uint32_t asafe, uint4 (&bv)[NST]) {
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-      const uint32_t dst = (uint32_t)__shfl((int)asafe, st * C::RPS + grow);
-      const off_t off = (off_t)(dst - 1) * ROWB + gcol;
-      bv[st] = *reinterpret_cast<const uint4*>(tbytes + off);
-    }
-  };
-  auto piece_words = [&](const uint4& bv, uint32_t (&wd)[4], uint32_t& hb) -> uint32_t {
-    hb = 0;
-    if (B16) {
-      uint32_t hw;
-      if (KPAD == 32) hw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bv.w, 0xFF, 0xf, 0xf, false);   // quad_perm [3,3,3,3]
-      else {
-        hw = 0;
-        { const uint32_t v = (uint32_t)__shfl((int)bv.z, hi_l); hw = hi_c == 2 ? v : hw; }
-        { const uint32_t v = (uint32_t)__shfl((int)bv.w, hi_l); hw = hi_c == 3 ? v : hw; }
-      }
-      hb = (hw >> ((gl & 3) * 8)) & 0xFFu;
-    }
-    wd[0] = bv.x; wd[1] = bv.y; wd[2] = bv.z; wd[3] = bv.w;
-    if (tail) {
-      hb &= (1u << (F::KC % 8)) - 1u;
-#pragma unroll
-      for (int c = (F::KC % 8) / 2; c < 4; ++c) wd[c] = 0u;
-    }
-    return (gl == C::LPR - 1) ? bv.w : 0u;
-  };
-
-  // counts of cell `a`'s slots from its gathered pieces (fast path); returns whether the cell needs the exact path
-  auto process = [&](uint32_t araw, const uint4 (&bv)[NST], int& u_out) -> bool {
-    const uint32_t a = araw & ID_MASK;            // the hash set's form of the id (see decode_own)
-    bool slow = NOFLAG ? false : __ballot((araw & ROW_DUP_FLAG) != 0) != 0ull;
-    // row i into the hash set
-    int myslot = -1, nov = 0;
-    bool dup_here = false;
-    {
-      bool over = false;
-      if (a != 0) {
-        // wide rows: keyed by the id through the multiplicative hash; compact rows: keyed by the stored form, whose bits 3.. ARE the hash
-        const uint32_t key = a;
-        const uint32_t bo = (CMP ? (key & ((uint32_t)(C::NB - 1) << 3)) : bucket_off<KPAD, BIG>(key)) + (uint32_t)wave * WBYTES;
-        uint32_t old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo), EMPTY, key);
-        if (old == EMPTY) myslot = (int)bo;
-        else {
-          dup_here |= old == key;               // an id twice in the row (a scanned row's flag says so too)
-          old = atomicCAS(reinterpret_cast<uint32_t*>(smem + bo + 4), EMPTY, key);
-          if (old == EMPTY) myslot = (int)bo + 4;
-          else { dup_here |= old == key; over = true; }
-        }
-      }
-      // (two equal ids walk the same two slots: the later one meets the earlier in one of them, or both overflow)
-      const unsigned long long om = __ballot(over);
-      if (om) {
-        if (over) ovlist[nov + __popcll(om & lt_mask)] = a;
-        nov += __popcll(om);
-        if (nov > 1) {                           // (one cell in 300) the same id twice among the overflowed ones?
-          wave_lds_fence();
-          dup_here |= ovlist_repeats(ovlist, nov);
-        }
-      }
-    }
-    wave_lds_fence();
-    uint32_t dupflags = 0;
-    int myu = 0;
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-      int c;
-      if (!CMP) {
-        uint32_t miss = 0;
-        uint32_t id[4] = {bv[st].x & ID_MASK, bv[st].y, bv[st].z, bv[st].w};
-        if (!NOFLAG) dupflags |= bv[st].x;
-        uint2 h[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) h[t] = lds_read_b64(bucket_off<KPAD, BIG>(id[t]) | wave_off);
-#pragma unroll
-        for (int t = 0; t < 4; t += 2) {
-          const uint32_t m0 = min3u_one(h[t].x ^ id[t], h[t].y ^ id[t]);
-          const uint32_t m1 = min3u_one(h[t + 1].x ^ id[t + 1], h[t + 1].y ^ id[t + 1]);
-          miss += m0 + m1;
-        }
-        c = 4 - (int)miss;
-        if (nov) {
-          for (int t = 0; t < nov; ++t) {
-            const uint32_t ov = ovlist[t];
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) c += (id[tt] == ov);
-          }
-        }
-      } else {
-        uint32_t wd[4], hb;
-        const uint32_t fw = piece_words(bv[st], wd, hb);
-        if (!NOFLAG) dupflags |= fw;
-        c = probe_compact_piece<B16>(wd, hb, bmask_v, bit16_v, wave_off);
-        if (nov) {                                  // wave-uniform, rare: ids that overflowed the set (kept in their stored form)
-          for (int t = 0; t < nov; ++t) {
-            const uint32_t ov = ovlist[t];
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt) c += (piece_key(wd, hb, tt) == ov);
-          }
-        }
-      }
-      const int rowcnt = group_sum<C::LPR>(c);
-      const int v = __shfl(rowcnt, (lane % C::RPS) * C::LPR);
-      myu = (lane / C::RPS == st) ? v : myu;
-    }
-    if (dup_here) *reinterpret_cast<uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) = 1u;   // reported at the kernel's end
-    slow |= __ballot(dup_here || (!NOFLAG && (dupflags & ROW_DUP_FLAG) != 0)) != 0ull;      // wave-uniform
-    if (myslot >= 0) *reinterpret_cast<uint32_t*>(smem + myslot) = EMPTY;
-    wave_lds_fence();
-    u_out = a != 0 ? myu : 0;                   // rejected id: zero row
-    return slow;
-  };
-
-  // ---- prologue: own row and gathers of the first cell, own row of the second
-  OwnRaw raw;
-  load_own(first, raw);
-  uint32_t araw_cur = decode_own(raw);
-  uint4 bv_cur[NST];
-  uint32_t id_cur = true_id(araw_cur);
-  // MAP: what column 2 shows for the slot, o.l2g[id - 1] — one more unconditional load per cell, issued with the cell's
-  // gathers and first looked at when the cell's edges are parked, an iteration later
-  uint32_t gid_cur = MAP ? (uint32_t)o.l2g[(id_cur != 0 ? id_cur : (uint32_t)(first + 1)) - 1] : 0u;
-  issue_gathers(id_cur != 0 ? id_cur : (uint32_t)(first + 1), bv_cur);
-  {
-    const int64_t i1 = first + 1;
-    load_own(i1 < cell_end ? i1 : last_cell, raw);
-  }
-  bool any_slow = false;
-  int64_t prev_i = first;
-  uint32_t prev_a = 0;
-  int prev_u = 0;
-
-  // Edges leave a quad of cells at a time.  park_prev: (neighbour id, count) of the cell just counted into the wave's
-  // staging rows (all 64 lanes write: no predicate, no branch).  store_quad: 4k edges of each array through a buffer
-  // descriptor that covers exactly them — lanes past 2k fall outside its range and the hardware drops their stores, so
-  // there is no lane predicate and no branch around the stores (the compiler guards a predicated block with a branch
-  // that skips it when no lane is active, which would make the number of memory operations between two waits unknown
-  // to it).  Non-temporal (aux = 2): written once, never re-read here.
-  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-  typedef double v2d __attribute__((ext_vector_type(2)));
-#ifndef GFICF_EDGE_STORE_AUX
-#define GFICF_EDGE_STORE_AUX 2
-#endif
-  constexpr int EDGE_STORE_AUX = GFICF_EDGE_STORE_AUX;
-  auto park_prev = [&](int c) {                                       // c: the cell's place in its quad
-    reinterpret_cast<uint2*>(smem + STAGE_OFF + (uint32_t)wave * STAGE_WAVE)[c * 64 + lane] = make_uint2(prev_a, (uint32_t)prev_u);
-  };
-  // ncells < 4: the wave's last, shorter quad.  Its edges may end in the middle of a lane's pair (k odd): a raw buffer
-  // access is range-checked dword by dword, so the first half of such a lane is written and the second dropped.
-  auto store_quad = [&](int64_t qfirst, int ncells) {
-    wave_lds_fence();
-    const uint2 p0 = lds_read_b64(qra0), p1 = lds_read_b64(qra1);     // {id, count} of the lane's two edges
-    const int64_t pb = (qfirst - cell_begin) * (int64_t)k;            // scalar: first entry of the quad
-    const int nedges = ncells * k;
-    if (OUT != OUT_U16) {
-      const uint32_t c1st = (uint32_t)(qfirst + 1) + o.src_off;
-      const bool pos0 = p0.y > 0, pos1 = p1.y > 0;
-      const v2d vs = {pos0 ? (double)(c1st + (uint32_t)qc0) : 0.0, pos1 ? (double)(c1st + (uint32_t)qc1) : 0.0};   // reference :49
-      const v2d vd = {pos0 ? (double)p0.x : 0.0, pos1 ? (double)p1.x : 0.0};                                     // reference :50
-      const v2d vw = {s_lut[p0.y], s_lut[p1.y]};                                                                 // reference :51 (lut[0] = 0.0: the zero row)
-      const auto rs = __builtin_amdgcn_make_buffer_rsrc(o.src + pb, 0, nedges * 8, 0x00020000);
-      const auto rd = __builtin_amdgcn_make_buffer_rsrc(o.dst + pb, 0, nedges * 8, 0x00020000);
-      const auto rw = __builtin_amdgcn_make_buffer_rsrc(o.w + pb, 0, nedges * 8, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, vs), rs, lane * 16, 0, EDGE_STORE_AUX);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, vd), rd, lane * 16, 0, EDGE_STORE_AUX);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, vw), rw, lane * 16, 0, EDGE_STORE_AUX);
-    }
-    if (OUT == OUT_RMAT_U) {
-      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u + pb, 0, nedges * 4, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b64(v2u{p0.y, p1.y}, ru, lane * 8, 0, 2);
-    }
-    if (OUT == OUT_U16) {        // 2 B per edge: a dword holds a lane's pair, and the range is checked per dword — the odd last edge goes out on its own
-      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u16 + pb, 0, nedges * 2, 0x00020000);
-      const auto ru_even = __builtin_amdgcn_make_buffer_rsrc(o.u16 + pb, 0, (nedges & ~1) * 2, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b32(p0.y | (p1.y << 16), ru_even, lane * 4, 0, 0);
-      if (nedges & 1) __builtin_amdgcn_raw_buffer_store_b16((uint16_t)p0.y, ru, lane * 4, 0, 0);   // wave-uniform condition (rewrites the even edges with the same values)
-    }
-  };
-
-  // one cell (place CQ in its quad): prefetch the next one's requests into `nxt`, [park the previous cell's edges; behind
-  // the fourth of a quad: store the quad,] count this one's intersections from `cur`.  The two piece buffers swap roles
-  // from cell to cell (the loop is unrolled by four, an even number): copying one into the other would need the data,
-  // i.e. wait for the very gathers that are meant to stay in flight.
-  auto body = [&](int64_t i, const uint4 (&cur)[NST], uint4 (&nxt)[NST], auto cq_tag, auto park_tag) {
-    constexpr int CQ = decltype(cq_tag)::value;
-    constexpr bool PARK = decltype(park_tag)::value;
-    const int64_t i1 = i + (CQ == 3 ? quad_step : 1), i2 = i1 + (CQ == 2 ? quad_step : 1);
-    const bool valid1 = i1 < cell_end;
-    // next cell: its own row was requested an iteration ago
-    const uint32_t araw_next = valid1 ? decode_own(raw) : 0u;
-    const uint32_t a1 = true_id(araw_next);
-    // the own row of the cell after next FIRST: next iteration's wait for it then leaves the gathers issued behind it in flight
-    load_own(i2 < cell_end ? i2 : last_cell, raw);
-    __builtin_amdgcn_sched_barrier(0);                                 // (the scheduler would hoist the gathers above the own-row load)
-    const uint32_t gid_next = MAP ? (uint32_t)o.l2g[(a1 != 0 ? a1 : (uint32_t)(i + 1)) - 1] : 0u;
-    issue_gathers(a1 != 0 ? a1 : (uint32_t)(i + 1), nxt);              // no next cell: every lane reads row i (one line)
-    __builtin_amdgcn_sched_barrier(0);
-    if (PARK) park_prev((CQ + 3) & 3);
-    if (PARK && CQ == 0) store_quad(i - 4 * nwaves, 4);   // the quad before this one is complete
-    __builtin_amdgcn_sched_barrier(0);
-    int u;
-    const bool slow = process(araw_cur, cur, u);
-    any_slow |= slow;
-    prev_i = i;
-    prev_a = MAP ? gid_cur : id_cur;
-    prev_u = u;
-    araw_cur = araw_next;
-    id_cur = a1;
-    gid_cur = gid_next;
-  };
-
-  uint4 bv_b[NST];
-  using T_ = std::true_type;
-  int64_t i = first;
-  int cq_last = 0;                                                     // place in its quad of the last cell counted
-  body(i, bv_cur, bv_b, std::integral_constant<int, 0>{}, std::false_type{});
-  for (;;) {
-    if (i + 1 >= cell_end) break;
-    i += 1; cq_last = 1;
-    body(i, bv_b, bv_cur, std::integral_constant<int, 1>{}, T_{});
-    if (i + 1 >= cell_end) break;
-    i += 1; cq_last = 2;
-    body(i, bv_cur, bv_b, std::integral_constant<int, 2>{}, T_{});
-    if (i + 1 >= cell_end) break;
-    i += 1; cq_last = 3;
-    body(i, bv_b, bv_cur, std::integral_constant<int, 3>{}, T_{});
-    if (i + quad_step >= cell_end) break;
-    i += quad_step; cq_last = 0;
-    body(i, bv_cur, bv_b, std::integral_constant<int, 0>{}, T_{});
-  }
-  park_prev(cq_last);
-  store_quad(prev_i - cq_last, cq_last + 1);
-  // ---- a row of this wave's cells named an id twice: the deferred report of the "distinct ids" mode (no flags in the table)
-  if (any_slow) {
-    wave_lds_fence();
-    if (*reinterpret_cast<const uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) != 0u && lane == 0) {
-      uint32_t* const st = edge_kernel_dup_status();
-      if (st != nullptr) atomicOr(st, GFICF_ST_DUP_IDS);
-    }
-  }
-  // ---- cells with duplicate ids in their own row or in a neighbour row (never the case for real kNN output): the exact
-  // multiset path, after the loop; their fast-path rows written above are overwritten (same wave, program order)
-  if (any_slow) {
-    __builtin_amdgcn_s_waitcnt(0);
-    for (int64_t n = 0;; ++n) {                                       // the wave's cells again, in the same order
-      const int64_t c = first + (n >> 2) * 4 * nwaves + (n & 3);
-      if (c >= cell_end) break;
-      const uint32_t* const rw = table + c * ROWW;
-      const uint32_t a = lane < k ? row_slot_id(rw, lane, KPAD, CMP) : 0u;
-      bool f = row_dup_flag(rw, KPAD, CMP);
-      if (a != 0) f |= row_dup_flag(table + (int64_t)(a - 1) * ROWW, KPAD, CMP);
-      if (__ballot(f) != 0ull)
-        slow_cell<KPAD, CMP, OUT>(table, c, k, (c - cell_begin) * (int64_t)k, s_rows[wave][0], s_rows[wave][1], lane, o.src, o.dst, o.w,
-                                  o.u, o.u16, o.set_mode, s_lut, o.l2g, o.src_off);
-    }
-  }
-}
-
-// ------------------------------------------------------------------ edge kernel on dual rows: a direct-address bit set (32 < k <= 55)
-// One wave per cell, two cells in flight per wave (the pipelined kernel's scheme: cell i+1's gathers and cell i+2's own row are
-// requested before cell i's pieces are probed; every load and store between two waits is unconditional, so the wait counts stay
-// exact).  Row i goes into the wave's BIT SET — 2^17 bits = 16 KiB of LDS, plane 0 = ids below 2^16, plane 1 = the rest, the wave's
-// region 16 KiB-aligned so that a probe address is (bits of the half) | base, one v_bitop3 —: ds_or with return (an id already
-// there = the row repeats it: the deferred duplicate report).  A lane gathers 16 B = 8 halves of the PLANAR part of a neighbour
-// row; all eight lie in one plane, which the lane knows from the row's header (one ds_bpermute per piece).  Per id: word address
-// (shift, bitop3), ds_read_b32, shift by the id's low five bits (v_lshrrev takes them straight from the packed word), and 1,
-// add: 5-6 issue slots against ~7.5 of the hash-set probe, no overflow list, no set clearing beyond the k words touched, and the
-// LDS reads are 4 B wide instead of 8.  LDS bounds the residency (3 waves of 16 KiB per workgroup, 3 workgroups per CU), which a
-// kernel limited by its vector instructions tolerates; NST = gather steps of a cell (8 rows each), a template parameter so that
-// the number of requests between two waits is a constant.
-// waves per workgroup x cells in flight per wave, measured at 100 k x 50 on permuted ids (tools/bits_ab.sh, profiles/r04_bits_kernel.txt;
-// the general kernel: 121 us): 2 x 2: 99 us, 4 x 2: 99, 2 x 3: 102, 3 x 2: 113, 3 x 3: 114, 1 x 2: 118 — what matters is that the
-// waves a CU holds (LDS: 16 KiB each) divide evenly over its four SIMDs: 8 per CU (2 or 4 per workgroup), not 9.
-#ifndef GFICF_BITS_WAVES
-#define GFICF_BITS_WAVES 2
-#endif
-#ifndef GFICF_BITS_DEPTH
-#define GFICF_BITS_DEPTH 2
-#endif
-constexpr int BITS_WAVES = GFICF_BITS_WAVES;
-constexpr int BITS_DEPTH = GFICF_BITS_DEPTH;                  // cells in flight per wave (2..4)
-#ifdef GFICF_BITS_WHATIF_HALF_SET
-// LAB ONLY (tools/lab/build_bits_variants.sh): a bit set of half the size — ids alias, the counts are WRONG — to see what the kernel
-// would gain from sixteen resident waves per CU instead of eight (profiles/r05_bits_kernel.txt).  Never in the product build.
-constexpr uint32_t BITS_WB = 8192u;
-#else
-constexpr uint32_t BITS_WB = 16384u;                          // LDS bytes of one wave's bit set
-#endif
-constexpr uint32_t BITS_LUT_OFF = BITS_WAVES * BITS_WB;
-constexpr uint32_t BITS_DUPF_OFF = BITS_LUT_OFF + 64u * 8u;   // weight table: k + 1 <= 56 doubles
-constexpr size_t BITS_LDS_BYTES = BITS_DUPF_OFF + BITS_WAVES * 4u;
-
-__device__ inline uint32_t lds_read_b32(uint32_t addr) { return *(__attribute__((address_space(3))) const uint32_t*)(size_t)addr; }
-__device__ inline void lds_write_b32(uint32_t addr, uint32_t v) { *(__attribute__((address_space(3))) uint32_t*)(size_t)addr = v; }
-__device__ inline uint32_t lds_or_rtn_b32(uint32_t addr, uint32_t v) {
-  return __hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t*)(size_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-template <int NST, int OUT, bool MAP>
-__global__ __launch_bounds__(BITS_WAVES * 64) void k_jaccard_edges_bits(
-    const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
-  using F = CFmt<64>;
-  extern __shared__ unsigned char smem[];
-  double* const s_lut = reinterpret_cast<double*>(smem + BITS_LUT_OFF);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int u = tid; u <= k; u += BITS_WAVES * 64) s_lut[u] = (double)u / (2.0 * (double)k - (double)u);   // reference :51
-  {
-    uint4* const z = reinterpret_cast<uint4*>(smem + (uint32_t)wave * BITS_WB);
-    for (int t = lane; t < (int)(BITS_WB / 16); t += 64) z[t] = make_uint4(0u, 0u, 0u, 0u);
-  }
-  if (lane == 0) *reinterpret_cast<uint32_t*>(smem + BITS_DUPF_OFF + (uint32_t)wave * 4u) = 0u;
-  __syncthreads();
-
-  const uint32_t wbase = lds_address(smem) + (uint32_t)(tid >> 6) * BITS_WB;   // a multiple of 16 KiB (dynamic LDS starts at 0: no static LDS here)
-#ifdef GFICF_BITS_WHATIF_HALF_SET
-  uint32_t mask_v = 0x0FFCu;
-#else
-  uint32_t mask_v = 0x1FFCu;                                   // word offset inside a plane, as a vector register (operand of v_bitop3_b32)
-#endif
-  asm volatile("" : "+v"(mask_v));
-  const char* const tbytes = reinterpret_cast<const char*>(table);
-  const int grow = lane >> 3, gl = lane & 7;
-  const uint32_t gcol = 128u + (uint32_t)gl * 16u;            // this lane's piece of the planar part of a row
-  const int64_t nwaves = (int64_t)gridDim.x * BITS_WAVES;
-  // Lane (row group g = lane / 8, position gl = lane % 8) OWNS slot gl * 8 + g of the cell's row: gather step st serves slots
-  // st * 8 .. st * 8 + 7, row group g of the step gathers the row named by slot st * 8 + g — which is held by lane st OF THE SAME
-  // GROUP.  So the neighbour id a group needs is a broadcast inside 8 lanes (two DPP moves), the group's count for the step lands
-  // in the lane that owns the slot by a select, and the row header (in the group's eighth lane) is a DPP broadcast too: no
-  // ds_bpermute anywhere.  The kernel is bound by its LDS pipe (random ds_read_b32 probes replay on bank conflicts); with
-  // cross-lane traffic through LDS as well — id, header and count of every step — a cell cost 81 LDS instructions, now 58.
-  const int slot = gl * 8 + grow;
-  const int slot_c = slot < F::KC ? slot : F::KC - 1;
-  const bool slot_ok = slot < F::KC;
-  const int64_t first = cell_begin + (int64_t)xcd_block(blockIdx.x, gridDim.x, o.xcd) * BITS_WAVES + wave;
-  if (first >= cell_end) return;                               // (after the barrier; wave-uniform)
-  const int64_t last_cell = cell_end - 1;
-  // lane P (compile-time) of every group of 8 lanes, broadcast to the group's 8 lanes
-  auto bcast8 = [](uint32_t v, auto p_tag) -> uint32_t {
-    constexpr int P = decltype(p_tag)::value;
-    const int x = __builtin_amdgcn_update_dpp(0, (int)v, (P & 3) * 0x55, 0xf, 0xf, false);        // quad_perm [P%4 x 4]: each quad its own lane P%4
-    // the quad that holds lane P hands its value to the other quad of the group: row_shr:4 into lanes 4-7 (banks 1, 3), row_shl:4 into 0-3
-    return (uint32_t)(P < 4 ? __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xa, false) : __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false));
-  };
-
-  struct OwnRaw { uint32_t v, hw, last; };
-  auto load_own = [&](int64_t row, OwnRaw& r) {                // the compact part of the row: loads only, decoded one iteration later
-    const uint32_t* const rw = table + row * DUAL_PITCH;
-    r.last = rw[F::ROWW - 1];
-    r.v = reinterpret_cast<const uint16_t*>(rw)[slot_c];
-    r.hw = rw[F::HIW + (slot_c >> 5)];
-  };
-  // id of the lane's slot | bit 31 = the row's duplicate flag; 0 for a lane without a slot or a slot without an id
-  auto decode_own = [&](const OwnRaw& r) -> uint32_t {
-    const uint32_t half = unscramble16(r.v);
-    const uint32_t x = (half | (((r.hw >> (slot & 31)) & 1u) << 16));
-    return (slot_ok && x != 0u) ? (x | (r.last & ROW_DUP_FLAG)) : (slot_ok ? (r.last & ROW_DUP_FLAG) : 0u);
-  };
-  auto gather_step = [&](uint32_t asafe, uint4& piece, auto st_tag) {
-    const uint32_t dst = bcast8(asafe, st_tag);                // slot st * 8 + g: lane st of group g
-    piece = *reinterpret_cast<const uint4*>(tbytes + (dst - 1u) * (uint32_t)(DUAL_PITCH * 4) + gcol);
-  };
-  auto issue_gathers = [&](uint32_t asafe, uint4 (&bv)[NST]) {
-    gather_step(asafe, bv[0], std::integral_constant<int, 0>{});
-    gather_step(asafe, bv[1], std::integral_constant<int, 1>{});
-    gather_step(asafe, bv[2], std::integral_constant<int, 2>{});
-    gather_step(asafe, bv[3], std::integral_constant<int, 3>{});
-    gather_step(asafe, bv[4], std::integral_constant<int, 4>{});
-    if constexpr (NST > 5) gather_step(asafe, bv[5], std::integral_constant<int, 5>{});
-    if constexpr (NST > 6) gather_step(asafe, bv[6], std::integral_constant<int, 6>{});
-  };
-  // hits of the two halves of a packed word in the plane at `base`
-  // v_lshrrev_b32 takes its shift from the low five bits of the operand: the packed word itself serves for the low half (written
-  // in C the compiler masks the operand first and then extracts the bit with the half-rate v_bfe_u32: 6-7 issue slots per id
-  // instead of 5-6)
-  auto shr5 = [](uint32_t v, uint32_t by) -> uint32_t {
-    uint32_t r;
-    asm("v_lshrrev_b32 %0, %1, %2" : "=v"(r) : "v"(by), "v"(v));
-    return r;
-  };
-  // hits of the 8 halves of a piece (four packed words) in the plane at `base`: all eight reads are issued before the first is used
-  auto probe_piece = [&](const uint32_t (&w)[4], uint32_t base) -> int {
-    uint32_t ad[8], bw[8];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      ad[2 * c] = bitop3<0xEA>(w[c] >> 3, mask_v, base);         // ((half >> 5) << 2) | base, the low half
-      ad[2 * c + 1] = bitop3<0xEA>(w[c] >> 19, mask_v, base);    // ... the high half
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) bw[t] = lds_read_b32(ad[t]);
-    __builtin_amdgcn_sched_barrier(0);
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) cnt += (shr5(bw[2 * c], w[c]) & 1u) + (shr5(bw[2 * c + 1], w[c] >> 16) & 1u);
-    return (int)cnt;
-  };
-
-  typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-  // the edges of a cell: buffer stores through descriptors that cover exactly its k edges (lanes >= k fall outside and are
-  // dropped by the hardware: no predicate, no branch); valid == false: a range of zero (nothing is written)
-  auto store_cell = [&](int64_t cell, uint32_t dstid, int u, bool valid) {
-    const int64_t pb = (cell - cell_begin) * (int64_t)k;
-    const int n = valid ? k : 0;
-    const bool pos = u > 0;
-    if (OUT != OUT_U16) {
-      const double vs = pos ? (double)((uint32_t)(cell + 1) + o.src_off) : 0.0;     // reference :49
-      const double vd = pos ? (double)dstid : 0.0;                                    // reference :50
-      const double vw = s_lut[u];                                                      // reference :51 (lut[0] = 0.0: the zero row)
-      const auto rs = __builtin_amdgcn_make_buffer_rsrc(o.src + pb, 0, n * 8, 0x00020000);
-      const auto rd = __builtin_amdgcn_make_buffer_rsrc(o.dst + pb, 0, n * 8, 0x00020000);
-      const auto rw = __builtin_amdgcn_make_buffer_rsrc(o.w + pb, 0, n * 8, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vs), rs, slot * 8, 0, 2);      // (a lane's edge is its SLOT's)
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vd), rd, slot * 8, 0, 2);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, vw), rw, slot * 8, 0, 2);
-    }
-    if (OUT == OUT_RMAT_U) {
-      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u + pb, 0, n * 4, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b32((uint32_t)u, ru, slot * 4, 0, 2);
-    }
-    if (OUT == OUT_U16) {
-      const auto ru = __builtin_amdgcn_make_buffer_rsrc(o.u16 + pb, 0, n * 2, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b16((uint16_t)u, ru, slot * 2, 0, 0);
-    }
-  };
-
-  // counts of the cell's slots from its gathered pieces; returns whether the cell needs the exact path
-  auto process = [&](uint32_t araw, const uint4 (&bv)[NST], int& u_out) -> bool {
-    const uint32_t a = araw & 0x1FFFFu;
-    const bool has = a != 0u;
-    bool dup_here = false;
-    uint32_t my_addr = wbase;
-    if (has) {                                                  // row i into the bit set
-#ifdef GFICF_BITS_WHATIF_HALF_SET
-      my_addr = wbase + ((a >> 16) << 12) + ((((a & 0xFFFFu) >> 5) << 2) & 0x0FFCu);
-      const uint32_t m = 1u << (a & 31u);
-      (void)lds_or_rtn_b32(my_addr, m);
-#else
-      my_addr = wbase + ((a >> 16) << 13) + (((a & 0xFFFFu) >> 5) << 2);
-      const uint32_t m = 1u << (a & 31u);
-      dup_here = (lds_or_rtn_b32(my_addr, m) & m) != 0u;        // already there: the row names the id twice
-#endif
-    }
-    wave_lds_fence();
-    uint32_t hflags = araw;
-    int myu = 0;
-#ifdef GFICF_BITS_PREFETCH
-    // LAB VARIANT (profiles/r05_bits_kernel.txt): the eight set reads of step st + 1 are issued before the counts of step st are taken
-    {
-      uint32_t w4[2][4], bw[2][8];
-      auto issue = [&](int st, uint32_t (&w)[4], uint32_t (&b)[8]) {
-        const uint32_t hdr = bcast8(bv[st].w, std::integral_constant<int, 7>{});
-        hflags |= hdr;
-        const bool p1 = (uint32_t)gl >= (hdr & 15u);
-        const uint32_t base = wbase | (p1 ? (BITS_WB >> 1) : 0u);
-        w[0] = bv[st].x; w[1] = bv[st].y; w[2] = bv[st].z; w[3] = gl == 7 ? (p1 ? 0xFFFFFFFFu : 0u) : bv[st].w;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          b[2 * c] = lds_read_b32(bitop3<0xEA>(w[c] >> 3, mask_v, base));
-          b[2 * c + 1] = lds_read_b32(bitop3<0xEA>(w[c] >> 19, mask_v, base));
-        }
-      };
-      issue(0, w4[0], bw[0]);
-#pragma unroll
-      for (int st = 0; st < NST; ++st) {
-        if (st + 1 < NST) issue(st + 1, w4[(st + 1) & 1], bw[(st + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) cnt += (shr5(bw[st & 1][2 * c], w4[st & 1][c]) & 1u) + (shr5(bw[st & 1][2 * c + 1], w4[st & 1][c] >> 16) & 1u);
-        const int rowcnt = group_sum<8>((int)cnt);
-        myu = gl == st ? rowcnt : myu;
-      }
-    }
-#else
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-      const uint32_t hdr = bcast8(bv[st].w, std::integral_constant<int, 7>{});   // the row's header word sits in its eighth lane
-      hflags |= hdr;
-      const bool p1 = (uint32_t)gl >= (hdr & 15u);                               // this lane's 8 ids: first or second plane
-#ifdef GFICF_BITS_WHATIF_HALF_SET
-      const uint32_t base = wbase | (p1 ? 0x1000u : 0u);
-#else
-      const uint32_t base = wbase | (p1 ? 0x2000u : 0u);
-#endif
-      const uint32_t w4[4] = {bv[st].x, bv[st].y, bv[st].z, gl == 7 ? (p1 ? 0xFFFFFFFFu : 0u) : bv[st].w};   // (the header is not an id: the plane's pad instead)
-      const int c = probe_piece(w4, base);
-      const int rowcnt = group_sum<8>(c);                                        // every lane of the group: the row's count
-      myu = gl == st ? rowcnt : myu;                                             // ... kept by the lane that owns slot st * 8 + g
-    }
-#endif
-    if (has) lds_write_b32(my_addr, 0u);                        // the set is empty again (lanes sharing a word write the same zero)
-    if (dup_here) *reinterpret_cast<uint32_t*>(smem + BITS_DUPF_OFF + (uint32_t)wave * 4u) = 1u;   // reported at the kernel's end
-    wave_lds_fence();
-    u_out = has ? myu : 0;                                      // rejected id / no slot: zero row
-    return __ballot(dup_here || (hflags & ROW_DUP_FLAG) != 0u) != 0ull;
-  };
-
-  // ---- BITS_DEPTH cells in flight per wave: while cell m is counted, the gathers of cells m+1 .. m+DEPTH-1 and the own row of cell
-  // m+DEPTH are outstanding.  Ring slots are compile-time indices (the loop is unrolled by DEPTH).  Two — the pipelined kernel's
-  // depth — is enough: three or four changed nothing (the kernel is not waiting for its gathers; profiles/r04_bits_kernel.txt).
-  constexpr int DEPTH = BITS_DEPTH;
-  OwnRaw raw;
-  uint4 bv[DEPTH][NST];
-  uint32_t araw_r[DEPTH], gid_r[DEPTH];
-#pragma unroll
-  for (int j = 0; j < DEPTH; ++j) { araw_r[j] = 0u; gid_r[j] = 0u; }
-  load_own(first, raw);
-#pragma unroll
-  for (int j = 0; j < DEPTH - 1; ++j) {                        // cells 0 .. DEPTH-2 of the wave: own row, gathers
-    const int64_t c = first + (int64_t)j * nwaves;
-    const uint32_t ar = c < cell_end ? decode_own(raw) : 0u;
-    const uint32_t a = ar & 0x1FFFFu;
-    const int64_t cn = c + nwaves;
-    load_own(cn < cell_end ? cn : last_cell, raw);
-    const uint32_t fb = (uint32_t)((c < cell_end ? c : last_cell) + 1);
-    araw_r[j] = ar;
-    gid_r[j] = MAP ? (uint32_t)o.l2g[(a != 0u ? a : fb) - 1u] : 0u;
-    issue_gathers(a != 0u ? a : fb, bv[j]);
-  }
-  bool any_slow = false, have_prev = false;
-  int64_t prev_i = first;
-  uint32_t prev_a = 0;
-  int prev_u = 0;
-
-  auto body = [&](int64_t i, auto j_tag) {
-    constexpr int J = decltype(j_tag)::value, JN = (J + DEPTH - 1) % DEPTH;
-    const int64_t ig = i + (int64_t)(DEPTH - 1) * nwaves, io = ig + nwaves;
-    const uint32_t araw_n = ig < cell_end ? decode_own(raw) : 0u;              // its own row was requested an iteration ago
-    const uint32_t an = araw_n & 0x1FFFFu;
-    load_own(io < cell_end ? io : last_cell, raw);                            // the own row of the cell after that one FIRST
-    __builtin_amdgcn_sched_barrier(0);
-    gid_r[JN] = MAP ? (uint32_t)o.l2g[(an != 0u ? an : (uint32_t)(i + 1)) - 1u] : 0u;
-    issue_gathers(an != 0u ? an : (uint32_t)(i + 1), bv[JN]);                 // no such cell / no id: the lane reads row i (one line)
-    araw_r[JN] = araw_n;
-    __builtin_amdgcn_sched_barrier(0);
-    store_cell(prev_i, prev_a, prev_u, have_prev);                            // the cell before this one: behind the gathers
-    __builtin_amdgcn_sched_barrier(0);
-    int u;
-    any_slow |= process(araw_r[J], bv[J], u);
-    prev_i = i;
-    prev_a = MAP ? gid_r[J] : (araw_r[J] & 0x1FFFFu);
-    prev_u = u;
-    have_prev = true;
-  };
-
-  for (int64_t i = first;;) {
-    body(i, std::integral_constant<int, 0>{});
-    if (i + nwaves >= cell_end) break;
-    i += nwaves;
-    body(i, std::integral_constant<int, 1 % DEPTH>{});
-    if (i + nwaves >= cell_end) break;
-    i += nwaves;
-    if constexpr (DEPTH >= 3) {
-      body(i, std::integral_constant<int, 2 % DEPTH>{});
-      if (i + nwaves >= cell_end) break;
-      i += nwaves;
-    }
-    if constexpr (DEPTH >= 4) {
-      body(i, std::integral_constant<int, 3 % DEPTH>{});
-      if (i + nwaves >= cell_end) break;
-      i += nwaves;
-    }
-  }
-  store_cell(prev_i, prev_a, prev_u, true);
-  // ---- the deferred report of the "distinct ids" mode, and the exact path for cells whose own row or a neighbour row holds an id
-  // twice (never the case for real kNN output): after the loop; their fast-path rows written above are overwritten
-  if (any_slow) {
-    __builtin_amdgcn_s_waitcnt(0);
-    wave_lds_fence();
-    if (*reinterpret_cast<const uint32_t*>(smem + BITS_DUPF_OFF + (uint32_t)wave * 4u) != 0u && lane == 0) {
-      uint32_t* const st = edge_kernel_dup_status();
-      if (st != nullptr) atomicOr(st, GFICF_ST_DUP_IDS);
-    }
-    uint32_t* const sA = reinterpret_cast<uint32_t*>(smem + (uint32_t)wave * BITS_WB);      // (the wave's bit set is no longer needed)
-    uint32_t* const sB = sA + 64;
-    for (int64_t c = first; c < cell_end; c += nwaves) {
-      const uint32_t* const rw = table + c * DUAL_PITCH;
-      const uint32_t a = lane < k ? row_slot_id(rw, lane, 64, true) : 0u;
-      bool f = row_dup_flag(rw, 64, true);
-      if (a != 0u) f |= row_dup_flag(table + (int64_t)(a - 1u) * DUAL_PITCH, 64, true);
-      if (__ballot(f) != 0ull)
-        slow_cell<64, true, OUT>(table, c, k, (c - cell_begin) * (int64_t)k, sA, sB, lane, o.src, o.dst, o.w, o.u, o.u16, o.set_mode, s_lut, o.l2g,
-                                 o.src_off, DUAL_PITCH);
-    }
-  }
-}
+#include "jaccard_edges_bits.h"
 
 // edge_kernel_dup_status() reads the EdgeOut argument at EDGE_KERNARG_OUT: both kernels must take exactly EdgeKernArgs' list
 static_assert(std::is_same<decltype(&k_jaccard_edges<32, false, false, OUT_RMAT, false>), EdgeKernFn>::value &&
