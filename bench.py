@@ -1513,9 +1513,13 @@ class Bench:
                 return (time.perf_counter() - t1) / reps, rc
 
             th, rc = timed(lambda: L.gficf_jaccard_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(hr), 0))
-            self.out["host_abi"] = {"edges_per_sec": E1 / th, "ms_per_call": th * 1e3, "rc": rc,
-                                    "note": f"gficf_jaccard_host: pageable host buffers, device scratch from the context pool, PCIe both ways "
-                                            f"({4 * E1 / 1e6:.0f} MB in, {24 * E1 / 1e6:.0f} MB out)"}
+            # ... and into a FRESH result matrix every call, as R allocates one (its pages are first touched inside the call)
+            tf, rcf = timed(lambda: L.gficf_jaccard_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(np.empty((3, E1), dtype=np.float64)), 0))
+            self.out["host_abi"] = {"edges_per_sec": E1 / th, "ms_per_call": th * 1e3, "rc": rc, "ms_per_call_fresh_result_buffer": tf * 1e3,
+                                    "note": f"gficf_jaccard_host: pageable host buffers, device scratch from the context pool; from 2^20 edges on the "
+                                            f"result returns as uint16 counts over PCIe ({4 * E1 / 1e6:.0f} MB in, {2 * E1 / 1e6:.0f} MB out) and the host cores "
+                                            f"write the {24 * E1 / 1e6:.0f} MB matrix (round 4: the matrix itself crossed PCIe: 1.63 ms into a reused buffer, "
+                                            "4.2 ms into a fresh one)"}
             tc, rc = timed(lambda: L.gficf_jaccard_counts_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(hu)))
             tx, rc2 = timed(lambda: L.gficf_jaccard_expand_host(vp(hm), 0, N_total, k, N_total, vp(hu), vp(hr), 0))
             want_full = self.shards[0].out.cpu().numpy()

@@ -61,12 +61,17 @@ struct gficf_ctx {
   // (the one scratch a device entry draws from the pool).  No host entry allocates device memory per call.
   void* pool[GFICF_POOL_SLOTS] = {};
   size_t pool_bytes[GFICF_POOL_SLOTS] = {};
+  // grow-only PINNED host staging (the compact return of gficf_jaccard_host: uint16 counts land here before the host expands them)
+  void* h_stage = nullptr;
+  size_t h_stage_bytes = 0;
   // print hook (R glue: Rprintf); NULL = stdout
   void (*print_fn)(const char*) = nullptr;
 };
 
 // Device scratch slot of at least `bytes` bytes (reallocated only when it has to grow).
 hipError_t gficf_pool_get(gficf_ctx* ctx, int slot, size_t bytes, void** out);
+// Pinned host staging of at least `bytes` bytes (same policy; released by gficf_ctx_trim / destroy).
+hipError_t gficf_host_stage_get(gficf_ctx* ctx, size_t bytes, void** out);
 
 // Sub-allocation of one pool slot: take() the pieces (256 B aligned), then bind() once.
 struct gficf_arena {

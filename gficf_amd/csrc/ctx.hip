@@ -37,6 +37,22 @@ void gficf_print(gficf_ctx* ctx, const char* line) {
   fflush(stdout);
 }
 
+hipError_t gficf_host_stage_get(gficf_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->h_stage_bytes) {
+    if (ctx->h_stage) {
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipHostFree(ctx->h_stage);
+      ctx->h_stage = nullptr;
+      ctx->h_stage_bytes = 0;
+    }
+    hipError_t e = hipHostMalloc(&ctx->h_stage, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    ctx->h_stage_bytes = bytes;
+  }
+  *out = ctx->h_stage;
+  return hipSuccess;
+}
+
 void gficf_prefault(void* p, size_t bytes) {
   constexpr size_t PAGE = 4096, MIN_PER_THREAD = 8u << 20;
   if (!p || bytes < 2 * MIN_PER_THREAD) return;               // small buffers: not worth the threads
@@ -87,6 +103,9 @@ int gficf_ctx_trim(gficf_ctx* ctx) {
     ctx->pool[s] = nullptr;
     ctx->pool_bytes[s] = 0;
   }
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  ctx->h_stage = nullptr;
+  ctx->h_stage_bytes = 0;
   return GFICF_OK;
 }
 
@@ -149,6 +168,7 @@ void gficf_ctx_destroy(gficf_ctx* ctx) {
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   for (void* q : ctx->pool)
     if (q) (void)hipFree(q);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   delete ctx;
 }
 

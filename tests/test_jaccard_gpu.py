@@ -1176,3 +1176,29 @@ def test_k_beyond_256_rows_in_local_ids_with_empty_slots_and_the_mapped_neighbou
     assert np.array_equal(got[0], np.where(pos, src_off + cell + 1.0, 0.0))
     assert np.array_equal(got[1], np.where(pos, l2g[np.maximum(mat[:n_cells].reshape(-1), 1) - 1].astype(np.float64), 0.0))
     assert np.array_equal(got[2], np.where(pos, wu / (2.0 * k - wu), 0.0))
+
+
+@pytest.mark.parametrize("as_double", [False, True])
+def test_host_entry_compact_return_from_a_million_edges_on(as_double):
+    """gficf_jaccard_host from 2^20 edges on: uint16 counts cross PCIe and the host cores write the reference's (N*k) x 3 matrix
+    (round 5; 4.2 -> 1.8 ms per call at 100 k x 30 into a fresh R matrix).  The same matrix, bit for bit — also for a matrix with a row
+    that repeats an id (the fast sequence raises, the entry re-runs the exact one) and with counts above 255."""
+    N, k = 36_000, 30
+    mat = synth.knn_windowed(N, k, seed=77, perm_seed=78)
+    assert N * k >= (1 << 20)
+    m = mat.astype(np.float64) if as_double else mat
+    want, _ = oracle.jaccard(mat, nthreads=8)
+    got = gficf_amd.rcpp_parallel_jaccard_coef(m, False)
+    assert got.flags["F_CONTIGUOUS"] or got.flags["C_CONTIGUOUS"]
+    assert np.array_equal(got, want)
+    dup = mat.copy()
+    dup[123, 7] = dup[123, 8]
+    dup[N - 1, :] = dup[N - 1, 0]
+    wd, _ = oracle.jaccard(dup, nthreads=8)
+    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(dup.astype(np.float64) if as_double else dup, False), wd)
+    if not as_double:                                             # k = 300 (sorted rows), counts up to 300 > 255: still uint16 on the wire
+        N2, k2 = 3600, 300
+        m2 = synth.knn_windowed(N2, k2, W=300, seed=5, perm_seed=6)
+        w2, u2 = oracle.jaccard(m2, nthreads=8)
+        assert u2.max() > 255 and N2 * k2 >= (1 << 20)
+        assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(m2, False), w2)

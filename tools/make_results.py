@@ -216,6 +216,8 @@ def main():
     verbatim(f"{TAG}_bigk_time.txt", "k > 256 (the sorted-row path, `csrc/jaccard_sorted.h`; GFICF_ERR_UNSUPPORTED in round 4), device-resident ingest + edges per call (`tools/bigk_time.py`)",
              keep=lambda l: l.startswith("N "))
     verbatim(f"{TAG}_sorted_vs_general.txt", "56 < k <= 256: the general hash-set kernel against the sorted-row path, each in its own process (`tools/sorted_vs_general.py`)")
+    verbatim(f"{TAG}_host_compact_ab.txt", "`gficf_jaccard_host` (what the `.Call` binds) into a FRESH result matrix per call, as R allocates one: the 24 B/edge matrix copied back over PCIe "
+             "against the compact return (uint16 counts over PCIe + the rows written by up to 32 host threads; the default from 2^20 edges on), each in its own process (`tools/host_compact_ab.py`)")
     verbatim(f"{TAG}_one_buffer_ab.txt", "A caller that reuses ONE table for every data set pays ~3.7 us per data set at 100 k x 30 (`tools/one_buffer_ab.py`; the outputs do not matter)")
     verbatim(f"{TAG}_phenograph_order_ab.txt", "`gficf_phenograph_host` at 400 k cells x 10 dimensions, k = 30, Jaccard stage on the caller's order (=0) against cells renumbered in the search's pivot "
              "order (=1, the default from 2^17 cells on; first call: the pool grows)")
