@@ -1005,7 +1005,18 @@ class Bench:
             return
         self.progress(name)
         t0 = time.monotonic()
-        fn()
+        if self.world == 1:
+            # one GPU: a leg that fails must not cost the line (`value` is measured and checked by then); N > 1: every rank runs the same
+            # collectives, so a failure propagates (the launcher stops the job; the lines printed so far stand)
+            try:
+                fn()
+            except Exception as ex:  # noqa: BLE001
+                import traceback
+
+                self.out.setdefault("leg_errors", {})[name] = f"{type(ex).__name__}: {ex}"
+                sys.stderr.write(f"bench.py: leg {name} failed:\n{traceback.format_exc()}\n")
+        else:
+            fn()
         self.leg_seconds[name] = time.monotonic() - t0
         self.legs_done.append(name)
         self.progress()
