@@ -1198,7 +1198,7 @@ def test_host_entry_compact_return_from_a_million_edges_on(as_double):
     assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(dup.astype(np.float64) if as_double else dup, False), wd)
     if not as_double:                                             # k = 300 (sorted rows), counts up to 300 > 255: still uint16 on the wire
         N2, k2 = 3600, 300
-        m2 = synth.knn_windowed(N2, k2, W=300, seed=5, perm_seed=6)
+        m2 = synth.knn_windowed(N2, k2, W=151, seed=5, perm_seed=6)          # the tightest window: neighbouring rows are almost the same set
         w2, u2 = oracle.jaccard(m2, nthreads=8)
         assert u2.max() > 255 and N2 * k2 >= (1 << 20)
         assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(m2, False), w2)

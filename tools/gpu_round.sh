@@ -3,7 +3,8 @@
 #   part 1: GPU tests, smoke, the bench line AND the rocprofv3 kernel trace of the same command in this same call (tools/make_results.py
 #           checks one against the other), the lines + traces of configs 1-5, stage times of the sharded step + the projection
 #   part 2: N > 1 rehearsals on the one GPU (plain `python bench.py --gpus N`: the script starts its own ranks; 3 ranks at full size,
-#           5 ranks at 20 k cells per rank — 5 ranks + the peer child are the 6 processes a box allows on its card), PMC passes, fuzz
+#           5 ranks at 5 k cells per rank — 5 ranks + the peer child are the 6 processes a box allows on its card), PMC passes, fuzz,
+#           kernel trace of the k > 256 path
 TAG=${1:-r05}; PART=${2:-1}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
@@ -21,9 +22,13 @@ else
 S=$SECONDS
 timeout -k 10 420 python bench.py --gpus 3 --rehearse-one-gpu --steps 5 --no-gficf > $OUT/rehearsal_gpus3.jsonl 2> $OUT/rehearsal_gpus3.err; echo "rehearsal 3 ranks (full size) rc=$? in $((SECONDS-S)) s"
 S=$SECONDS
-timeout -k 10 420 python bench.py --gpus 5 --rehearse-one-gpu --steps 5 --no-gficf --cells-per-gpu 20000 > $OUT/rehearsal_gpus5.jsonl 2> $OUT/rehearsal_gpus5.err; echo "rehearsal 5 ranks (20 k cells per rank) rc=$? in $((SECONDS-S)) s"
+# (five processes time-slicing ONE GPU over gloo: a data set takes ~1.5 s there, so this one runs 5 k cells per rank and 2 steps — and, with a
+# budget of 200 s, shows the budget doing its work: the legs it has no time for are skipped and named)
+timeout -k 10 420 python bench.py --gpus 5 --rehearse-one-gpu --steps 2 --warmup 1 --no-gficf --cells-per-gpu 5000 --budget-s 200 > $OUT/rehearsal_gpus5.jsonl 2> $OUT/rehearsal_gpus5.err; echo "rehearsal 5 ranks (5 k cells per rank, budget 200 s) rc=$? in $((SECONDS-S)) s"
 for A in 3 5; do wc -l $OUT/rehearsal_gpus$A.jsonl; tail -1 $OUT/rehearsal_gpus$A.jsonl | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d.get(k) for k in ('legs_done','leg_seconds','skipped_legs','wall_s','checked_vs_oracle')})"; done
 bash tools/pmc_round.sh $TAG 2>&1 | tail -14
 timeout -k 10 200 python tools/fuzz_gpu.py 120 > $OUT/fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -3 $OUT/fuzz.txt
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace_bigk -o bigk -- python3 $GRAFT_REPO_ROOT/tools/bigk_time.py > $GRAFT_REPO_ROOT/$OUT/bigk_time_traced.txt 2> $GRAFT_REPO_ROOT/$OUT/trace_bigk.log); echo "bigk trace rc=$?"
+cp $(find $OUT/trace_bigk -name "bigk_kernel_stats.csv" | head -1) $OUT/bigk_kernel_stats.csv && head -6 $OUT/bigk_kernel_stats.csv | cut -c1-180
 fi
 find $OUT -name "*.db" -delete; find $OUT -size +3M -delete
