@@ -548,7 +548,9 @@ def assert_same_format(ops, N_total: int, k: int, group=None, device=None, extra
     words = [int(L.gficf_hip_abi_version()), int(ops.row_words(N_total, k)), int(ops.kpad(k)), int(ops.packed_words(N_total, k)),
              zlib.crc32(env.encode()), int(N_total), int(k)] + [int(v) for v in extra]
     gloo = dist.get_backend(group) == "gloo"
-    mine = torch.tensor(words, dtype=torch.int64, device="cpu" if gloo or device is None else device)
+    if not gloo and device is None:                               # (RCCL moves device tensors only)
+        device = torch.device("cuda", torch.cuda.current_device())
+    mine = torch.tensor(words, dtype=torch.int64, device="cpu" if gloo else device)
     got = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(got, mine, group=group)
     rows = [tuple(int(v) for v in t.tolist()) for t in got]

@@ -372,3 +372,19 @@ def test_bench_killed_at_any_moment_after_its_first_line_leaves_a_whole_last_lin
     whole = [l for l in lines if l.rstrip().endswith("}")]
     rec = json.loads(whole[-1])
     assert rec["value"] > 0 and rec["checked_vs_oracle"] is True and "roofline" in rec and "exchange" in rec and rec["legs_done"][0] == "value"
+
+
+def test_bench_under_torch_distributed_run_with_two_ranks():
+    """The driver's documented N > 1 launch — `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` — with two ranks
+    (sharing the box's one GPU over gloo): no self-spawn, the rank environment comes from the launcher; rank 0's cumulative lines are the
+    only JSON on stdout and the last one is complete."""
+    import json
+    import subprocess
+
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1",
+                        "--cells-per-gpu", "20000", "--no-gficf", "--legs", "single_gpu_step"], capture_output=True, text=True, timeout=400, env=_bench_env())
+    assert r.returncode == 0, r.stderr[-3000:]
+    recs = [json.loads(l) for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert len(recs) >= 2 and recs[-1]["legs_done"] == ["value", "single_gpu_step"] and recs[-1]["n_gpus"] == 2
+    assert recs[-1]["checked_vs_oracle"] is True and recs[-1]["efficiency"]["in_order_permuted"] > 0

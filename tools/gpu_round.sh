@@ -28,6 +28,7 @@ timeout -k 10 420 python bench.py --gpus 5 --rehearse-one-gpu --steps 2 --warmup
 for A in 3 5; do wc -l $OUT/rehearsal_gpus$A.jsonl; tail -1 $OUT/rehearsal_gpus$A.jsonl | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d.get(k) for k in ('legs_done','leg_seconds','skipped_legs','wall_s','checked_vs_oracle')})"; done
 bash tools/pmc_round.sh $TAG 2>&1 | tail -14
 timeout -k 10 200 python tools/fuzz_gpu.py 120 > $OUT/fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -3 $OUT/fuzz.txt
+timeout -k 10 300 python tools/config3_pipeline.py > $OUT/config3_pipeline.txt 2>&1; echo "config 3 pipeline rc=$?"; tail -3 $OUT/config3_pipeline.txt | cut -c1-300
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/trace_bigk -o bigk -- python3 $GRAFT_REPO_ROOT/tools/bigk_time.py > $GRAFT_REPO_ROOT/$OUT/bigk_time_traced.txt 2> $GRAFT_REPO_ROOT/$OUT/trace_bigk.log); echo "bigk trace rc=$?"
 cp $(find $OUT/trace_bigk -name "bigk_kernel_stats.csv" | head -1) $OUT/bigk_kernel_stats.csv && head -6 $OUT/bigk_kernel_stats.csv | cut -c1-180
 fi

@@ -216,6 +216,8 @@ def main():
     verbatim(f"{TAG}_bigk_time.txt", "k > 256 (the sorted-row path, `csrc/jaccard_sorted.h`; GFICF_ERR_UNSUPPORTED in round 4), device-resident ingest + edges per call (`tools/bigk_time.py`)",
              keep=lambda l: l.startswith("N "))
     verbatim(f"{TAG}_sorted_vs_general.txt", "56 < k <= 256: the general hash-set kernel against the sorted-row path, each in its own process (`tools/sorted_vs_general.py`)")
+    verbatim(f"{TAG}_config3_pipeline.txt", "BASELINE config 3 end to end through the host mirror of the R calls (`tools/config3_pipeline.py`: gficf() on 23 k genes x 54 k cells, then "
+             "clustcells(k = 30) on a 50-component stand-in for the PCA space; wall time per call, PCIe included)", keep=lambda l: l.startswith(("run", "synthetic")))
     verbatim(f"{TAG}_host_compact_ab.txt", "`gficf_jaccard_host` (what the `.Call` binds) into a FRESH result matrix per call, as R allocates one: the 24 B/edge matrix copied back over PCIe "
              "against the compact return (uint16 counts over PCIe + the rows written by up to 32 host threads; the default from 2^20 edges on), each in its own process (`tools/host_compact_ab.py`)")
     verbatim(f"{TAG}_one_buffer_ab.txt", "A caller that reuses ONE table for every data set pays ~3.7 us per data set at 100 k x 30 (`tools/one_buffer_ab.py`; the outputs do not matter)")
