@@ -1526,7 +1526,16 @@ class Bench:
             th, rc = timed(lambda: L.gficf_jaccard_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(hr), 0))
             # ... and into a FRESH result matrix every call, as R allocates one (its pages are first touched inside the call)
             tf, rcf = timed(lambda: L.gficf_jaccard_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(np.empty((3, E1), dtype=np.float64)), 0))
+            # ... and the same two with the matrix itself copied back over PCIe (round 4's form; the switch is read per call)
+            os.environ["GFICF_JACCARD_HOST_COMPACT_MIN_EDGES"] = str(1 << 62)
+            try:
+                tm, _ = timed(lambda: L.gficf_jaccard_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(hr), 0))
+                tmf, _ = timed(lambda: L.gficf_jaccard_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(np.empty((3, E1), dtype=np.float64)), 0))
+            finally:
+                del os.environ["GFICF_JACCARD_HOST_COMPACT_MIN_EDGES"]
             self.out["host_abi"] = {"edges_per_sec": E1 / th, "ms_per_call": th * 1e3, "rc": rc, "ms_per_call_fresh_result_buffer": tf * 1e3,
+                                    "matrix_over_pcie": {"ms_per_call": tm * 1e3, "ms_per_call_fresh_result_buffer": tmf * 1e3,
+                                                         "note": "GFICF_JACCARD_HOST_COMPACT_MIN_EDGES=2^62: the 24 B/edge matrix copied back (round 4's form), same process"},
                                     "note": f"gficf_jaccard_host: pageable host buffers, device scratch from the context pool; from 2^20 edges on the "
                                             f"result returns as uint16 counts over PCIe ({4 * E1 / 1e6:.0f} MB in, {2 * E1 / 1e6:.0f} MB out) and the host cores "
                                             f"write the {24 * E1 / 1e6:.0f} MB matrix (round 4: the matrix itself crossed PCIe: 1.63 ms into a reused buffer, "

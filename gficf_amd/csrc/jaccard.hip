@@ -931,12 +931,9 @@ int launch_edges_k(gficf_ctx* ctx, const uint32_t* t, int64_t N, int k, int64_t 
 
 // edges from which gficf_jaccard_host returns through uint16 counts + a host-side expansion instead of copying the 24 B/edge matrix
 // back (GFICF_JACCARD_HOST_COMPACT_MIN_EDGES in the environment; 0 = always, a huge number = never)
-int64_t host_compact_min_edges() {
-  static const int64_t v = [] {
-    const char* e = getenv("GFICF_JACCARD_HOST_COMPACT_MIN_EDGES");
-    return e ? (int64_t)atoll(e) : (int64_t)(1 << 20);       // measured crossover ~1 M edges (profiles/r05_host_compact_ab.txt)
-  }();
-  return v;
+int64_t host_compact_min_edges() {                              // (read per call: an A/B switch inside one process; a call is milliseconds)
+  const char* e = getenv("GFICF_JACCARD_HOST_COMPACT_MIN_EDGES");
+  return e ? (int64_t)atoll(e) : (int64_t)(1 << 20);          // measured crossover ~1 M edges (profiles/r05_host_compact_ab.txt)
 }
 
 int check_nk(int64_t N, int k) {

@@ -331,7 +331,7 @@ def test_bench_wall_budget_skips_and_names_the_legs_it_has_no_time_for():
     import json
     import subprocess
 
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1", "--cells-per-gpu", "20000",
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "1", "--warmup", "0", "--cells-per-gpu", "6000", "--pre-warm-ms", "0",
             "--no-gficf"]
     r = subprocess.run(base + ["--budget-s", "5"], capture_output=True, text=True, timeout=280, env=_bench_env())
     assert r.returncode == 0, r.stderr[-3000:]
@@ -354,7 +354,7 @@ def test_bench_killed_at_any_moment_after_its_first_line_leaves_a_whole_last_lin
     import subprocess
     import time
 
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1", "--cells-per-gpu", "20000",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "1", "--warmup", "0", "--cells-per-gpu", "6000", "--pre-warm-ms", "0",
            "--no-gficf"]
     pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=_bench_env(), start_new_session=True)
     try:
@@ -382,8 +382,8 @@ def test_bench_under_torch_distributed_run_with_two_ranks():
     import subprocess
 
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1",
-                        "--cells-per-gpu", "20000", "--no-gficf", "--legs", "single_gpu_step"], capture_output=True, text=True, timeout=400, env=_bench_env())
+                        "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "1", "--warmup", "0",
+                        "--cells-per-gpu", "6000", "--pre-warm-ms", "0", "--no-gficf", "--legs", "single_gpu_step"], capture_output=True, text=True, timeout=400, env=_bench_env())
     assert r.returncode == 0, r.stderr[-3000:]
     recs = [json.loads(l) for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
     assert len(recs) >= 2 and recs[-1]["legs_done"] == ["value", "single_gpu_step"] and recs[-1]["n_gpus"] == 2
