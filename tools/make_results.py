@@ -304,6 +304,11 @@ def main():
                 w("  `peer.spatial_ids` (nothing exchanged: rows named outside read in the owners' blocks): checked_vs_oracle {} in order / {} overlapped, rows named outside per device {}, "
                   "the caller's thread {:.0f} us per data set.\n\n".format(ph.get("checked_vs_oracle"), (ph.get("overlapped") or {}).get("checked_vs_oracle"),
                                                                           ph.get("rows_named_outside_per_device"), ph.get("host_enqueue_us_per_data_set", float("nan"))))
+    slow = load(f"{TAG}_rehearsal_gpus5_20k_cells_budget.jsonl")
+    if slow:
+        w("The wall budget at work (5 ranks x 20 k cells time-slicing ONE GPU over gloo: a data set takes ~1.5 s there): `value` took {:.0f} s, the line was out at {:.0f} s; "
+          "legs done {}, legs skipped for lack of budget {} (budget {:.0f} s, wall {} s), exit code 0 and a whole last line.\n\n".format(
+              slow["leg_seconds"]["value"], slow["leg_seconds"]["value"] + 2, slow["legs_done"], slow["skipped_legs"], slow["budget_s"], slow["wall_s"]))
     log = os.path.join(P, f"{TAG}_pytest_gpu.log")
     if os.path.exists(log):
         tail = [l for l in open(log).read().splitlines() if " passed" in l or " failed" in l]
