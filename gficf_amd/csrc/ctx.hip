@@ -4,6 +4,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
+
 #include "common.h"
 
 static thread_local char g_err[768] = "";
@@ -53,9 +55,21 @@ hipError_t gficf_host_stage_get(gficf_ctx* ctx, size_t bytes, void** out) {
   return hipSuccess;
 }
 
+void gficf_advise_hugepages(void* p, size_t bytes) {
+#if defined(__linux__) && defined(MADV_HUGEPAGE)
+  constexpr uintptr_t HP = (uintptr_t)2 << 20;
+  if (!p || bytes < 2 * HP || getenv("GFICF_HIP_NO_HUGEPAGE")) return;
+  const uintptr_t a = ((uintptr_t)p + HP - 1) & ~(HP - 1), e = ((uintptr_t)p + bytes) & ~(HP - 1);
+  if (e > a) (void)madvise((void*)a, (size_t)(e - a), MADV_HUGEPAGE);      // (a failure changes nothing)
+#else
+  (void)p; (void)bytes;
+#endif
+}
+
 void gficf_prefault(void* p, size_t bytes) {
   constexpr size_t PAGE = 4096, MIN_PER_THREAD = 8u << 20;
   if (!p || bytes < 2 * MIN_PER_THREAD) return;               // small buffers: not worth the threads
+  gficf_advise_hugepages(p, bytes);
   unsigned hw = std::thread::hardware_concurrency();
   size_t nt = hw ? hw : 4;
   if (nt > 16) nt = 16;

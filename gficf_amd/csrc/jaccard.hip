@@ -1307,6 +1307,7 @@ int gficf_jaccard_expand_host(const void* idx, int idx_is_f64, int64_t N, int k,
   if (E == 0) return GFICF_OK;
   if (!idx || !u || !rmat) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
   if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
+  gficf_advise_hugepages(rmat, sizeof(double) * 3 * (size_t)E);     // (a fresh R matrix: its first touch happens in the threads below)
   std::vector<double> lut((size_t)k + 1);
   for (int v = 0; v <= k; ++v) lut[v] = (double)v / (2.0 * (double)k - (double)v);     // reference :51
   unsigned hw = std::thread::hardware_concurrency();

@@ -26,12 +26,23 @@ def child(N, k):
     ctx = gficf_amd.default_context(0)
     vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     ts = []
-    for rep in range(6):
-        out = np.empty((3, N * k), dtype=np.float64)              # fresh pages every call
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes, libc.free.argtypes = ctypes.c_void_p, [ctypes.c_size_t], [ctypes.c_void_p]
+    r_like = bool(os.environ.get("AB_MALLOC"))                     # a result buffer from plain malloc, as R's allocator hands one over (numpy asks
+    for rep in range(6):                                           # for huge pages itself; R does not)
+        nbytes = 24 * N * k
+        if r_like:
+            ptr = libc.malloc(nbytes)
+            out = np.ctypeslib.as_array((ctypes.c_double * (3 * N * k)).from_address(ptr)).reshape(3, N * k)
+        else:
+            out = np.empty((3, N * k), dtype=np.float64)          # fresh pages every call
         t0 = time.perf_counter()
-        rc = L.gficf_jaccard_host(ctx.handle, vp(mat), 0, N, k, N, vp(out), 0)
+        rc = L.gficf_jaccard_host(ctx.handle, vp(mat), 0, N, k, N, ctypes.c_void_p(out.ctypes.data), 0)
         ts.append(time.perf_counter() - t0)
         assert rc == 0, _lib.last_error()
+        if r_like and rep < 5:
+            del out
+            libc.free(ptr)
     cells = min(N, 512)
     want, _ = oracle.jaccard_cells(np.ascontiguousarray(mat), 0, cells, nthreads=os.cpu_count() or 1)
     ok = bool(np.array_equal(out[:, :cells * k].T, want))
@@ -40,7 +51,8 @@ def child(N, k):
 
 def main():
     print(f"{'N':>8} {'k':>3} {'edges':>10} | {'full matrix over PCIe: best / median ms':>40} | {'compact return: best / median ms':>34} | compact / full (median)")
-    for N, k in ((3000, 15), (10000, 30), (54000, 30), (100000, 30), (100000, 50), (1000000, 30)):
+    shapes = ((3000, 15), (10000, 30), (54000, 30), (100000, 30), (100000, 50), (1000000, 30)) if not os.environ.get("AB_MALLOC") else ((54000, 30), (100000, 30), (1000000, 30))
+    for N, k in shapes:
         res = []
         for lim in (str(1 << 62), "0"):
             env = dict(os.environ, GFICF_JACCARD_HOST_COMPACT_MIN_EDGES=lim)
