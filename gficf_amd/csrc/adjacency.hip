@@ -221,6 +221,10 @@ int gficf_adjacency_host_finish(gficf_ctx* ctx, void* indptr, int indptr_is_i64,
   if (!p) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "gficf_adjacency_host_finish without a plan");
   if (!indptr || (p->nnz > 0 && (!indices || !x))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
   std::vector<int64_t> ip((size_t)p->N + 1);
+  if (p->nnz > 0 && indices && x) {               // (fresh result vectors of the caller: huge pages + parallel first touch)
+    gficf_prefault(indices, sizeof(int32_t) * (size_t)p->nnz);
+    gficf_prefault(x, sizeof(double) * (size_t)p->nnz);
+  }
   hipError_t e = hipMemcpyAsync(ip.data(), p->d_indptr, sizeof(int64_t) * ip.size(), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess && p->nnz > 0) e = hipMemcpyAsync(indices, p->d_indices, sizeof(int32_t) * (size_t)p->nnz, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess && p->nnz > 0) e = hipMemcpyAsync(x, p->d_x, sizeof(double) * (size_t)p->nnz, hipMemcpyDeviceToHost, ctx->stream);

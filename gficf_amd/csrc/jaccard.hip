@@ -1566,6 +1566,11 @@ int gficf_jaccard_filtered_host_finish(gficf_ctx* ctx, double* from, double* to,
   if (p->n_edges > 0) {
     if (!from || !to || !weight) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
     const size_t b = sizeof(double) * (size_t)p->n_edges;
+    // (freshly allocated by the caller as a rule: huge pages asked for and the pages mapped from several threads, not one fault at a
+    // time under the copies)
+    gficf_prefault(from, b);
+    gficf_prefault(to, b);
+    gficf_prefault(weight, b);
     e = hipMemcpyAsync(from, p->d_from, b, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(to, p->d_to, b, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(weight, p->d_weight, b, hipMemcpyDeviceToHost, ctx->stream);
