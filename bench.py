@@ -1167,9 +1167,7 @@ class Bench:
         if one_launch:
             t_edges_ms, t_ingest_ms, t_ingest_b2b, t_ingest_scan_ms = t_step_ds, 0.0, 0.0, 0.0
         else:
-            if not halo_form and world == 1:
-                # (the step ran the library's one-call sequence; the separate calls below need the table it left — the same table)
-                pass
+            # (one rank: the step ran the library's one-call sequence; the separate calls below read the table it left — the same table)
             t_edges_ms = time_kernel_ms(torch, one_edges, launches)
             t_ingest_b2b = time_kernel_ms(torch, one_ingest, launches)
             t_ingest_scan_ms = t_ingest_b2b

@@ -1156,6 +1156,8 @@ int gficf_jaccard_device(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int6
   return gficf_jaccard_edges_device(ctx, d_table_ws, N, k, 0, N, d_rmat, d_rmat + E, d_rmat + 2 * E, d_u);
 }
 
+static int gficf_jaccard_counts_host_body(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld, uint16_t* u);
+
 static int gficf_jaccard_host_body(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k, int64_t ld,
                        double* rmat, int print_output) {
   GFICF_CTX_ENTER(ctx);
@@ -1199,33 +1201,13 @@ static int gficf_jaccard_host_body(gficf_ctx* ctx, const void* idx, int idx_is_f
     // ---- the compact return (round 5): the 24 B row of an edge is a function of (i, idx[i,j], u), and idx is on the host already.
     // So 2 B per edge cross PCIe instead of 24 (uint16 counts into pinned staging) and the host cores write the reference's matrix
     // (gficf_jaccard_expand_host, several threads; their first touch of a freshly allocated R matrix runs in parallel too):
-    // Into a FRESH result matrix (what R hands over) 100 k x 30 takes 4.2 ms per call with the matrix copied back and 1.8 ms this way,
-    // 1 M x 30 44 ms and 8 ms; below ~1 M edges the copy wins (profiles/r05_host_compact_ab.txt).  Same bits: the weights are the
+    // Into a FRESH malloc'ed result matrix (what R hands over) 100 k x 30 takes 4.9 ms per call with the matrix copied back and 2.0 ms this
+    // way, 1 M x 30 54 ms and 8.7 ms; below ~1 M edges the copy wins (profiles/r05_host_compact_ab.txt).  Same bits: the weights are the
     // reference's own division u / (2.0 * k - u) on the host.
-    const size_t esz = idx_is_f64 ? sizeof(double) : sizeof(int32_t);
-    const int roww = table_fmt(N, k).row_words;
-    void* d_idx = nullptr;
-    int32_t* d_table = nullptr;
-    uint16_t* d_u = nullptr;
     void* h_u = nullptr;
-    hipError_t e = gficf_pool_get(ctx, 0, esz * (size_t)ld * (size_t)k, &d_idx);
-    if (e == hipSuccess) e = gficf_pool_get(ctx, 1, sizeof(int32_t) * (size_t)N * (size_t)roww, (void**)&d_table);
-    if (e == hipSuccess) e = gficf_pool_get(ctx, 2, sizeof(uint16_t) * (size_t)E, (void**)&d_u);
-    if (e == hipSuccess) e = gficf_host_stage_get(ctx, sizeof(uint16_t) * (size_t)E, &h_u);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, idx, esz * (size_t)ld * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
-    rc = GFICF_OK;
-    if (e == hipSuccess) {
-      EdgeOut o{nullptr, nullptr, nullptr, nullptr, d_u, 0};
-      if (direct_applies(ctx, N, k)) rc = launch_direct(ctx, d_idx, idx_is_f64, N, k, ld, o);
-      else {
-        rc = gficf_jaccard_ingest_device(ctx, d_idx, idx_is_f64, N, k, ld, N, d_table);
-        if (!rc) rc = launch_edges_k(ctx, (const uint32_t*)d_table, N, k, 0, N, o);
-      }
-      if (!rc) e = hipMemcpyAsync(h_u, d_u, sizeof(uint16_t) * (size_t)E, hipMemcpyDeviceToHost, ctx->stream);
-      if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
-      else (void)hipStreamSynchronize(ctx->stream);
-    }
+    const hipError_t e = gficf_host_stage_get(ctx, sizeof(uint16_t) * (size_t)E, &h_u);
     if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_jaccard_host: %s", hipGetErrorString(e));
+    rc = gficf_jaccard_counts_host_body(ctx, idx, idx_is_f64, N, k, ld, (uint16_t*)h_u);      // upload, kernels, counts into the pinned staging, sync
     if (rc) return rc;
     // threads of the expansion: one per ~250 k edges, at most 32 and at most the machine's (starting a thread costs tens of microseconds)
     const unsigned hw = std::thread::hardware_concurrency();

@@ -242,6 +242,7 @@ def main():
               "{:.2f} GB in / {:.2f} GB out): {:.1f} ms per call (plan {:.1f} + finish {:.1f}) = {:.1f} M cells/s; parity {}.\n".format(
                   ha["bytes_in"] / 1e9, ha["bytes_out"] / 1e9, ha["ms_per_call"], ha["ms_plan"], ha["ms_finish"], ha["cells_per_sec"] / 1e6,
                   "<= 1e-6 vs oracle" if ha.get("checked_vs_oracle") else "not checked"))
+        verbatim(f"{TAG}_host_gficf_malloc_ab.txt", "The same entry with the result vectors from plain `malloc`, as R allocates them (`tools/host_gficf_malloc_ab.py`)")
         w("\nstored entries {:.1f} M, kept {:.1f} M in {} genes; PMC traffic {} of the algorithmic bytes.  `t(gficf)` {} ms, cluster sums {} ms.\n\n".format(
             g["nnz"] / 1e6, g["kept_nnz"] / 1e6, g["kept_genes"], fmt(rf.get("traffic") and rf["traffic"] / rf["algorithmic_bytes_per_pass"], "{:.2f} x"),
             (g.get("transpose") or {}).get("ms", "-"), (g.get("cluster_signatures") or {}).get("ms", "-")))
