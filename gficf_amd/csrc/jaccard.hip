@@ -1233,6 +1233,7 @@ static int gficf_jaccard_host_body(gficf_ctx* ctx, const void* idx, int idx_is_f
     rc = GFICF_OK;
     if (e == hipSuccess) {
       rc = gficf_jaccard_device(ctx, d_idx, idx_is_f64, N, k, ld, d_table, d_rmat, nullptr);
+      gficf_prefault(rmat, sizeof(double) * 3 * (size_t)E);          // (>= 16 MB: huge pages + parallel first touch while the kernels run)
       if (rc == GFICF_OK) e = hipMemcpyAsync(rmat, d_rmat, sizeof(double) * 3 * (size_t)E, hipMemcpyDeviceToHost, ctx->stream);
       if (rc == GFICF_OK && e == hipSuccess) rc = gficf_ctx_sync(ctx);
       else (void)hipStreamSynchronize(ctx->stream);
@@ -1530,6 +1531,7 @@ static int gficf_jaccard_coeff_host_body(gficf_ctx* ctx, const void* idx, int id
     if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
     else (void)hipStreamSynchronize(ctx->stream);
     if (!rc && e == hipSuccess) {
+      gficf_advise_hugepages(weights, sizeof(double) * 3 * (size_t)E);                         // (a fresh R matrix, first touched by the memset)
       std::memset(weights, 0, sizeof(double) * 3 * (size_t)E);                                  // NumericMatrix weights(nrow*ncol, 3), :21
       for (int c = 0; c < 3 && e == hipSuccess && total > 0; ++c)
         e = hipMemcpyAsync(weights + (size_t)c * (size_t)E, d_from + (size_t)c * (size_t)E, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream);

@@ -1137,6 +1137,8 @@ int gficf_knn_host(gficf_ctx* ctx, const double* X, int64_t N, int d, int64_t ld
     float* d_dist = (float*)(d_idx + ob);
     rc = gficf_knn_prepare_device(ctx, d_X, 1, N, d, ld, metric, (float*)d_P);
     if (!rc) rc = gficf_knn_search_device(ctx, (const float*)d_P, N, d, k, metric, 0, N, d_ws, wsb, d_idx, dist ? d_dist : nullptr, N);
+    gficf_advise_hugepages(idx, ob * sizeof(int32_t));             // (fresh R matrices: first touched by the copies below)
+    if (dist) gficf_advise_hugepages(dist, ob * sizeof(double));
     if (!rc) e = hipMemcpyAsync(idx, d_idx, ob * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
     if (!rc && e == hipSuccess && dist) {
       hd.resize(ob);

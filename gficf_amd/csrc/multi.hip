@@ -290,6 +290,7 @@ int gficf_jaccard_host_multi(gficf_multi* m, const void* idx, int idx_is_f64, in
   if (E > 0) {
     if (!idx || !rmat) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
     if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
+    gficf_advise_hugepages(rmat, sizeof(double) * 3 * (size_t)E);      // (a fresh R matrix: first touched by the per-device downloads)
     const int P = m->ndev;
     std::vector<int64_t> bd((size_t)P + 1);
     gficf_multi_cell_blocks(N, P, bd.data());
@@ -788,6 +789,11 @@ int gficf_normalize_csc_host_multi_finish(gficf_multi* m, uint8_t* keep, int64_t
   const int64_t G = m->G, N = m->N;
   std::vector<std::vector<int64_t>> ocp((size_t)P);
   FirstError fe;
+  // (the caller's result vectors are fresh as a rule: huge pages asked for before the per-device copies first touch them)
+  if (m->nnz_kept > 0) {
+    gficf_advise_hugepages(out_rowidx, sizeof(int32_t) * (size_t)m->nnz_kept);
+    gficf_advise_hugepages(out_x, sizeof(double) * (size_t)m->nnz_kept);
+  }
   for_each_device(P, fe, [&](int r) -> int {          // a host thread per device: the downloads into the pageable results run side by side
     gficf_multi_block& B = m->blk[r];
     gficf_ctx* c = m->ctx[r];
