@@ -1233,7 +1233,8 @@ static int gficf_jaccard_host_body(gficf_ctx* ctx, const void* idx, int idx_is_f
     rc = GFICF_OK;
     if (e == hipSuccess) {
       rc = gficf_jaccard_device(ctx, d_idx, idx_is_f64, N, k, ld, d_table, d_rmat, nullptr);
-      gficf_prefault(rmat, sizeof(double) * 3 * (size_t)E);          // (>= 16 MB: huge pages + parallel first touch while the kernels run)
+      gficf_advise_hugepages(rmat, sizeof(double) * 3 * (size_t)E);  // (a fresh R matrix of 4 MB or more: huge pages for its first touch by the copy;
+      gficf_prefault(rmat, sizeof(double) * 3 * (size_t)E);          //  >= 16 MB: also touched from several threads while the kernels run)
       if (rc == GFICF_OK) e = hipMemcpyAsync(rmat, d_rmat, sizeof(double) * 3 * (size_t)E, hipMemcpyDeviceToHost, ctx->stream);
       if (rc == GFICF_OK && e == hipSuccess) rc = gficf_ctx_sync(ctx);
       else (void)hipStreamSynchronize(ctx->stream);

@@ -51,7 +51,7 @@ def child(N, k):
 
 def main():
     print(f"{'N':>8} {'k':>3} {'edges':>10} | {'full matrix over PCIe: best / median ms':>40} | {'compact return: best / median ms':>34} | compact / full (median)")
-    shapes = ((3000, 15), (10000, 30), (54000, 30), (100000, 30), (100000, 50), (1000000, 30)) if not os.environ.get("AB_MALLOC") else ((54000, 30), (100000, 30), (1000000, 30))
+    shapes = ((3000, 15), (10000, 30), (54000, 30), (100000, 30), (100000, 50), (1000000, 30)) if not os.environ.get("AB_MALLOC") else ((10000, 30), (30000, 30), (54000, 30), (100000, 30), (1000000, 30))
     for N, k in shapes:
         res = []
         for lim in (str(1 << 62), "0"):
