@@ -79,13 +79,14 @@ def _worker(rank, world, port, N, k, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("N,k", [(1001, 15), (640, 30)])
-def test_sharded_path_world2_gloo(tmp_path, N, k):
+@pytest.mark.parametrize("N,k,world", [(1001, 15, 2), (640, 30, 2), (1003, 15, 8)])
+def test_sharded_path_world2_gloo(tmp_path, N, k, world):
+    """(world 8: the rank count of the driver's largest scaling run, rehearsed on the CPU over gloo — blocks of unequal size
+    (1003 = 7 x 126 + 121), eight all-gather chunks, eight GF-ICF column blocks of a 101-cell matrix.)"""
     import oracle
     from gficf_amd import synth
     from gficf_amd.dist import shard_bounds
 
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), N, k, str(tmp_path)), nprocs=world, join=True)
     mat = synth.knn_windowed(N, k, seed=3)
     want, wu = oracle.jaccard(mat, nthreads=2)
@@ -227,7 +228,7 @@ def _local_worker(rank, world, port, N, k, perm, cap, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_local_id_halo_shard_matches_oracle_gloo(tmp_path, world):
     """JaccardHaloShard: every rank builds its block's edges on a sub-problem in local ids (own cells + the rows it names,
     fetched through fixed-capacity request slots: two all-to-alls with equal splits) — the oracle's bits on ordered ids."""
