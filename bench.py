@@ -786,11 +786,28 @@ class Bench:
                              "(one rank per GPU; --rehearse-one-gpu shares device 0 over gloo)")
         self.local_rank = local_rank
         torch.cuda.set_device(local_rank)
+        self.backend_note = None
         if world > 1:
             if args.rehearse_one_gpu:
                 dist.init_process_group("gloo")
             else:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                try:
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                except Exception as ex:  # noqa: BLE001
+                    # First contact with RCCL happens in the driver's own run: if the communicator cannot be built (every rank sees the
+                    # same failure), the run goes on over gloo — device tensors staged through the host, as the one-GPU rehearsals do —
+                    # and SAYS SO in the line (`exchange.backend`): a slow, labelled number instead of no line.  A rank that fails alone
+                    # meets nobody at the gloo rendezvous and gives up after two minutes.
+                    import datetime
+
+                    sys.stderr.write(f"bench.py: rank {rank}: RCCL process group failed ({type(ex).__name__}: {ex}); falling back to gloo\n")
+                    self.backend_note = f"RCCL init failed ({type(ex).__name__}: {str(ex)[:200]}); gloo fallback, device tensors staged through the host"
+                    try:
+                        if dist.is_initialized():
+                            dist.destroy_process_group()
+                    except Exception:  # noqa: BLE001
+                        pass
+                    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
         self.dev = torch.device("cuda", local_rank)
         self.strong = strong = args.config in CONFIGS
         if strong:
@@ -1230,6 +1247,13 @@ class Bench:
                         ("; ONE-LAUNCH form: the step is one kernel, kernel_ms is the step" if one_launch else "")}
 
     def exchange_figures(self):
+        fig = self._exchange_figures()
+        fig["backend"] = self.dist.get_backend()
+        if self.backend_note:
+            fig["backend_note"] = self.backend_note
+        return fig
+
+    def _exchange_figures(self):
         a, sh0 = self.args, self.shards[0]
         if self.exchange == "halo":
             return {"bytes_received_per_rank_per_data_set": int(sh0.bytes_received),

@@ -153,6 +153,7 @@ def test_plain_bench_command_starts_its_own_ranks():
     assert out["config"]["cells_total"] == 40000
     ex = out["exchange"]
     assert ex["rows_received_per_rank_per_data_set"] == 20000 and ex["bytes_received_per_rank_per_data_set"] > 0
+    assert ex["backend"] == "gloo" and "backend_note" not in ex           # (a rehearsal asks for gloo; a FALLBACK to it would carry the note)
 
 
 def test_bench_line_measures_the_edge_kernels_traffic_in_the_same_run():
