@@ -779,7 +779,8 @@ class Bench:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree (plain `python bench.py --gpus N` starts its own ranks)")
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (gficf_amd has no CPU fallback)")
-        if args.rehearse_one_gpu:
+        share0 = bool(os.environ.get("GFICF_BENCH_RANKS_SHARE_GPU0"))     # test hook: RCCL is ASKED for with every rank on device 0 — it refuses
+        if args.rehearse_one_gpu or share0:                               # (duplicate GPU), which is how the gloo fallback below gets exercised
             local_rank = 0
         if local_rank >= torch.cuda.device_count():
             raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) visible "
@@ -1775,7 +1776,7 @@ def main():
         from gficf_amd import launch
 
         raise SystemExit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
-                                            need_gpus=None if args.rehearse_one_gpu else args.gpus,
+                                            need_gpus=None if (args.rehearse_one_gpu or os.environ.get("GFICF_BENCH_RANKS_SHARE_GPU0")) else args.gpus,
                                             timeout_s=float(os.environ.get("GFICF_BENCH_LAUNCH_TIMEOUT", str(args.budget_s + 150.0)))))
     B = Bench(args)
     world, rank, ops = B.world, B.rank, B.ops

@@ -389,3 +389,19 @@ def test_bench_under_torch_distributed_run_with_two_ranks():
     recs = [json.loads(l) for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
     assert len(recs) >= 2 and recs[-1]["legs_done"] == ["value", "single_gpu_step"] and recs[-1]["n_gpus"] == 2
     assert recs[-1]["checked_vs_oracle"] is True and recs[-1]["efficiency"]["in_order_permuted"] > 0
+
+
+def test_bench_falls_back_to_gloo_and_says_so_when_rccl_cannot_build_its_communicator():
+    """First contact with RCCL happens in the driver's own run.  If the communicator cannot be built the run must still leave a line:
+    here RCCL is asked for with both ranks on the box's one GPU (test hook GFICF_BENCH_RANKS_SHARE_GPU0), which it refuses — the run
+    goes on over gloo and labels its line."""
+    import json
+    import subprocess
+
+    env = dict(_bench_env(), GFICF_BENCH_RANKS_SHARE_GPU0="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cells-per-gpu", "6000",
+                        "--pre-warm-ms", "0", "--no-extras"], capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.lstrip().startswith("{")][-1])
+    ex = out["exchange"]
+    assert ex["backend"] == "gloo" and "RCCL init failed" in ex["backend_note"] and out["checked_vs_oracle"] is True and out["n_gpus"] == 2
