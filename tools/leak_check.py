@@ -17,7 +17,27 @@ cp, ri, x = synth.counts_csc(G, N, seed=2)
 M = sp.csc_matrix((x, ri, cp), shape=(G, N))
 
 
+big = synth.knn_windowed(40000, 30, seed=4, perm_seed=5)            # 1.2 M edges: the compact return of gficf_jaccard_host (pinned staging, host threads)
+wide = synth.knn_windowed(1200, 300, W=200, seed=6, perm_seed=7)      # k > 256: the sorted-row path
+ops = gficf_amd.HipOps(0)
+ops.set_jaccard_distinct(True)
+d_idx = torch.from_numpy(np.ascontiguousarray(synth.knn_windowed(3000, 15, seed=8).T)).cuda()
+d_tab = torch.zeros((3000, ops.row_words(3000, 15)), dtype=torch.int32, device="cuda")
+d_out = torch.zeros((3, 3000 * 15), dtype=torch.float64, device="cuda")
+
+
+def rss_mib():
+    with open("/proc/self/statm") as f:
+        return int(f.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2**20
+
+
 def once():
+    gficf_amd.rcpp_parallel_jaccard_coef(big, False)
+    gficf_amd.rcpp_parallel_jaccard_coef(wide, False)
+    run = ops.jaccard_prepared(d_idx, 3000, 15, d_tab, d_out, None)     # a new prepared call every round (the one-launch form)
+    for _ in range(5):
+        run()
+    ops.sync()
     data = gficf_amd.gficf(M, normalize=False, verbose=False)
     nn = gficf_amd.find_nn(X, k + 1, True, "manhattan")["idx"]
     rel = gficf_amd.rcpp_parallel_jaccard_coef(nn[:, 1:], False)
@@ -32,10 +52,12 @@ def once():
 
 
 once()
+once()
 torch.cuda.synchronize()
-free0 = torch.cuda.mem_get_info()[0]
+free0, rss0 = torch.cuda.mem_get_info()[0], rss_mib()
 for i in range(40):
     once()
 torch.cuda.synchronize()
-free1 = torch.cuda.mem_get_info()[0]
-print(f"free before {free0 / 2**20:.1f} MiB, after 40 rounds {free1 / 2**20:.1f} MiB, delta {(free0 - free1) / 2**20:.2f} MiB")
+free1, rss1 = torch.cuda.mem_get_info()[0], rss_mib()
+print(f"device memory free before {free0 / 2**20:.1f} MiB, after 40 rounds {free1 / 2**20:.1f} MiB, delta {(free0 - free1) / 2**20:.2f} MiB; "
+      f"host RSS {rss0:.0f} -> {rss1:.0f} MiB")
