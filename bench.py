@@ -842,14 +842,22 @@ class Bench:
         """This rank's block of `batch` independent data sets ((k, n_local) device tensors == column-major blocks, 1-based
         global ids) and, where asked, the full matrix of data set 0 (oracle check, CPU baseline).  Only the block is generated
         (synth.knn_windowed(rows=...)): at 8 ranks a rank does an eighth of the work of the full matrix."""
-        loc, full0 = [], None
-        for d in range(self.batch):
+        import concurrent.futures as cf
+
+        def gen(d):
             perm = (43 + 7 * d) if ids_kind == "permuted" else None
             if d == 0 and need_full0:
-                full0 = self.synth.knn_windowed(self.N_total, self.k, seed=42, perm_seed=perm)
-                blk = full0[self.b:self.e]
-            else:
-                blk = self.synth.knn_windowed(self.N_total, self.k, seed=42 + 7 * d, perm_seed=perm, rows=(self.b, self.e))
+                return self.synth.knn_windowed(self.N_total, self.k, seed=42, perm_seed=perm)
+            return self.synth.knn_windowed(self.N_total, self.k, seed=42 + 7 * d, perm_seed=perm, rows=(self.b, self.e))
+
+        # (the data sets of a batch are independent: generated side by side — numpy releases the GIL in its inner loops; at 8 ranks x 100 k
+        # cells this is the longest host-side stretch in front of `value`)
+        with cf.ThreadPoolExecutor(max_workers=min(self.batch, 8)) as ex:
+            mats = list(ex.map(gen, range(self.batch)))
+        full0 = mats[0] if need_full0 else None
+        loc = []
+        for d, m in enumerate(mats):
+            blk = m[self.b:self.e] if (d == 0 and need_full0) else m
             loc.append(self.torch.from_numpy(np.ascontiguousarray(blk.T)).to(self.dev))
         return loc, full0
 
