@@ -1447,7 +1447,23 @@ struct gficf_edge_plan {
   double* d_from = nullptr;
   double* d_to = nullptr;
   double* d_weight = nullptr;
+  // compact form (round 5, from host_compact_min_edges() edges on): the uint16 counts came back instead of the kept edges; finish writes
+  // from / to / weight on the host from (cell, idx[cell, slot], u) — the caller's idx must stay valid until finish (it is the argument
+  // of the same `.Call` / Python call)
+  bool compact = false;
+  std::vector<uint16_t> u;
+  std::vector<int64_t> first;        // first[t]: output position of thread t's first kept edge; first[nthreads] = n_edges
+  const void* idx = nullptr;
+  int idx_is_f64 = 0, k = 0;
+  int64_t N = 0, ld = 0;
 };
+
+// cells [c0, c1) of thread t of nt
+static inline void cell_share(int64_t N, int64_t nt, int64_t t, int64_t& c0, int64_t& c1) {
+  const int64_t per = (N + nt - 1) / nt;
+  c0 = t * per < N ? t * per : N;
+  c1 = c0 + per < N ? c0 + per : N;
+}
 
 static void edge_plan_free(gficf_ctx* ctx) {
   delete ctx->edge_plan;
@@ -1470,6 +1486,40 @@ static int gficf_jaccard_filtered_host_plan_body(gficf_ctx* ctx, const void* idx
   if (E == 0) return GFICF_OK;
   if (!idx) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL host pointer");
   if (ld < N) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "ld = %lld < N = %lld", (long long)ld, (long long)N);
+  if (E >= host_compact_min_edges()) {
+    // the compact form: 2 B per edge over PCIe, the kept edges counted (here) and written (in finish) by the host cores
+    p->compact = true;
+    p->idx = idx; p->idx_is_f64 = idx_is_f64; p->N = N; p->k = k; p->ld = ld;
+    try {
+      p->u.resize((size_t)E);
+    } catch (...) {
+      edge_plan_free(ctx);
+      GFICF_FAIL(GFICF_ERR_HIP, "out of host memory for %lld intersection counts", (long long)E);
+    }
+    rc = gficf_jaccard_counts_host_body(ctx, idx, idx_is_f64, N, k, ld, p->u.data());
+    if (rc) { edge_plan_free(ctx); return rc; }
+    const unsigned hw = std::thread::hardware_concurrency();
+    int64_t nt = E / 250000;
+    if (nt > 32) nt = 32;
+    if (hw && nt > (int64_t)hw) nt = hw;
+    if (nt < 1) nt = 1;
+    p->first.assign((size_t)nt + 1, 0);
+    std::vector<std::thread> th;
+    const uint16_t* const u = p->u.data();
+    int64_t* const first = p->first.data();
+    for (int64_t t = 0; t < nt; ++t)
+      th.emplace_back([=] {
+        int64_t c0, c1, n = 0;
+        cell_share(N, nt, t, c0, c1);
+        for (int64_t r = c0 * k; r < c1 * k; ++r) n += u[r] != 0;
+        first[t + 1] = n;
+      });
+    for (auto& x : th) x.join();
+    for (int64_t t = 0; t < nt; ++t) first[t + 1] += first[t];
+    p->n_edges = first[nt];
+    *n_edges = p->n_edges;
+    return GFICF_OK;
+  }
   const size_t esz = idx_is_f64 ? sizeof(double) : sizeof(int32_t);
   const int roww = table_fmt(N, k).row_words;
   gficf_arena ar;
@@ -1548,6 +1598,40 @@ int gficf_jaccard_filtered_host_finish(gficf_ctx* ctx, double* from, double* to,
   gficf_edge_plan* p = ctx->edge_plan;
   if (!p) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "gficf_jaccard_filtered_host_finish without a plan");
   hipError_t e = hipSuccess;
+  if (p->compact && p->n_edges > 0) {
+    if (!from || !to || !weight) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
+    const size_t b = sizeof(double) * (size_t)p->n_edges;
+    gficf_advise_hugepages(from, b);
+    gficf_advise_hugepages(to, b);
+    gficf_advise_hugepages(weight, b);
+    const int64_t N = p->N, ld = p->ld, nt = (int64_t)p->first.size() - 1;
+    const int k = p->k, f64 = p->idx_is_f64;
+    const uint16_t* const u = p->u.data();
+    const int32_t* const ii = (const int32_t*)p->idx;
+    const double* const id = (const double*)p->idx;
+    const int64_t* const first = p->first.data();
+    const double twok = 2.0 * (double)k;
+    std::vector<std::thread> th;
+    for (int64_t t = 0; t < nt; ++t)
+      th.emplace_back([=] {
+        int64_t c0, c1;
+        cell_share(N, nt, t, c0, c1);
+        int64_t d = first[t];
+        for (int64_t i = c0; i < c1; ++i)
+          for (int j = 0; j < k; ++j) {
+            const int v = u[i * k + j];
+            if (v > 0) {                                            // reference R/clustCells.R:66 on the rows of :48-52, in order
+              from[d] = (double)(i + 1);
+              to[d] = f64 ? id[(int64_t)j * ld + i] : (double)ii[(int64_t)j * ld + i];
+              weight[d] = (double)v / (twok - (double)v);
+              ++d;
+            }
+          }
+      });
+    for (auto& x : th) x.join();
+    edge_plan_free(ctx);
+    return GFICF_OK;
+  }
   if (p->n_edges > 0) {
     if (!from || !to || !weight) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
     const size_t b = sizeof(double) * (size_t)p->n_edges;

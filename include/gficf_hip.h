@@ -291,7 +291,9 @@ int gficf_jaccard_edges_filtered_mapped_device(gficf_ctx* ctx, const int32_t* d_
                                                int64_t cell_begin, int64_t cell_end, uint16_t* d_u_ws,
                                                int64_t* d_cell_ptr, double* d_from, double* d_to,
                                                double* d_weight, const int32_t* d_order);
-/* Host form (two calls so that the caller can allocate exactly n_edges rows): R/clustCells.R:65-66. */
+/* Host form (two calls so that the caller can allocate exactly n_edges rows): R/clustCells.R:65-66.  idx must stay valid and unchanged
+ * until finish has returned: from 2^20 edges on only the uint16 counts cross PCIe and finish writes the kept rows on the host from
+ * (cell, idx[cell, slot], count) with several threads (round 5; the same rows, bit for bit). */
 int gficf_jaccard_filtered_host_plan(gficf_ctx* ctx, const void* idx, int idx_is_f64, int64_t N, int k,
                                      int64_t ld, int64_t* n_edges);
 int gficf_jaccard_filtered_host_finish(gficf_ctx* ctx, double* from, double* to, double* weight);

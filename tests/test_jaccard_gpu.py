@@ -1196,6 +1196,12 @@ def test_host_entry_compact_return_from_a_million_edges_on(as_double):
     dup[N - 1, :] = dup[N - 1, 0]
     wd, _ = oracle.jaccard(dup, nthreads=8)
     assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(dup.astype(np.float64) if as_double else dup, False), wd)
+    # the call-site mirror (gficf_jaccard_filtered_host_plan / _finish) takes the same compact form: kept rows written on the host, in order
+    for src, w_ in ((mat, want), (dup, wd)):
+        neigh = np.concatenate([np.arange(1, N + 1, dtype=np.int32)[:, None], src], axis=1)
+        rel = gficf_amd.jaccard_edges(neigh.astype(np.float64) if as_double else neigh)
+        keep = w_[:, 2] > 0
+        assert np.array_equal(rel["from"], w_[keep, 0]) and np.array_equal(rel["to"], w_[keep, 1]) and np.array_equal(rel["weight"], w_[keep, 2])
     if not as_double:                                             # k = 300 (sorted rows), counts up to 300 > 255: still uint16 on the wire
         N2, k2 = 3600, 300
         m2 = synth.knn_windowed(N2, k2, W=151, seed=5, perm_seed=6)          # the tightest window: neighbouring rows are almost the same set
