@@ -82,16 +82,20 @@ void gficf_prefault(void* p, size_t bytes) {
   volatile char* const base = (volatile char*)p;
   const size_t per = ((bytes / nt + PAGE - 1) / PAGE) * PAGE;
   std::vector<std::thread> th;
-  for (size_t t = 0; t < nt; ++t) {
-    const size_t b = t * per, e = b + per < bytes ? b + per : bytes;
-    if (b >= e) break;
-    th.emplace_back([=] {
-      // the buffer is output-only (fully overwritten afterwards): writing is allowed and is what maps the page
-      size_t q = b;
-      const size_t mis = (size_t)((uintptr_t)(base + q) & (PAGE - 1));
-      if (mis) { base[q] = 0; q += PAGE - mis; }
-      for (; q < e; q += PAGE) base[q] = 0;
-    });
+  try {                                            // (a thread that cannot be started: its pages are mapped by whoever writes them later)
+    th.reserve(nt);
+    for (size_t t = 0; t < nt; ++t) {
+      const size_t b = t * per, e = b + per < bytes ? b + per : bytes;
+      if (b >= e) break;
+      th.emplace_back([=] {
+        // the buffer is output-only (fully overwritten afterwards): writing is allowed and is what maps the page
+        size_t q = b;
+        const size_t mis = (size_t)((uintptr_t)(base + q) & (PAGE - 1));
+        if (mis) { base[q] = 0; q += PAGE - mis; }
+        for (; q < e; q += PAGE) base[q] = 0;
+      });
+    }
+  } catch (...) {
   }
   for (auto& t : th) t.join();
 }
