@@ -1570,7 +1570,9 @@ class Bench:
                                     "note": f"gficf_jaccard_host: pageable host buffers, device scratch from the context pool; from 2^20 edges on the "
                                             f"result returns as uint16 counts over PCIe ({4 * E1 / 1e6:.0f} MB in, {2 * E1 / 1e6:.0f} MB out) and the host cores "
                                             f"write the {24 * E1 / 1e6:.0f} MB matrix (round 4: the matrix itself crossed PCIe: 1.63 ms into a reused buffer, "
-                                            "4.2 ms into a fresh one)"}
+                                            "4.2 ms into a fresh one).  The `fresh_result_buffer` figures of THIS process include the first touch of a "
+                                            "72 MB matrix after the earlier legs have fragmented its memory (~5 ms either way); fresh processes — an R "
+                                            "session's situation — are measured by tools/host_compact_ab.py (profiles/r05_host_compact_ab.txt: 8.2 -> 2.0 ms)"}
             tc, rc = timed(lambda: L.gficf_jaccard_counts_host(hctx.handle, vp(hm), 0, N_total, k, N_total, vp(hu)))
             tx, rc2 = timed(lambda: L.gficf_jaccard_expand_host(vp(hm), 0, N_total, k, N_total, vp(hu), vp(hr), 0))
             want_full = self.shards[0].out.cpu().numpy()
