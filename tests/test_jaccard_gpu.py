@@ -1208,3 +1208,17 @@ def test_host_entry_compact_return_from_a_million_edges_on(as_double):
         w2, u2 = oracle.jaccard(m2, nthreads=8)
         assert u2.max() > 255 and N2 * k2 >= (1 << 20)
         assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(m2, False), w2)
+
+
+@pytest.mark.parametrize("N,k", [(3000, 15), (70_000, 15), (5000, 30), (140_000, 30), (4000, 50), (1500, 100), (900, 256), (700, 300), (1100, 513)])
+def test_every_kernel_family_against_the_closed_form_of_cyclic_windows(N, k):
+    """Row i names the next k cells of a ring: u(i, t) = k - 1 - t for every cell, by counting — no oracle involved
+    (tests/helpers/closed_form.py).  One shape per kernel: the one-launch form (3 000 x 15), the pipelined kernel on
+    wide 16-slot and compact / wide 32-slot rows, the bit-set kernel (k = 50), the general kernel (k = 100, 256), the sorted-row path
+    (k = 300, 513); through the host entry, so from 2^20 edges on through the compact return too."""
+    from tests.helpers.closed_form import cyclic_window_expected, cyclic_window_matrix
+
+    mat = cyclic_window_matrix(N, k)
+    want, wu = cyclic_window_expected(N, k)
+    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(mat, False), want)
+    assert np.array_equal(gficf_amd.jaccard_counts(mat).astype(np.int32).reshape(-1), wu)

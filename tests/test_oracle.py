@@ -385,3 +385,17 @@ def test_jaccard_noninteger_doubles_reference_truncation_hand_derived():
     for bad in (0.0, 3.0, -1.5, np.nan):
         with pytest.raises(ValueError):
             oracle.jaccard(np.array([[bad, 2.0], [1.0, 2.0]]))
+
+
+from tests.helpers.closed_form import cyclic_window_expected, cyclic_window_matrix  # noqa: E402
+
+
+@pytest.mark.parametrize("N,k", [(40, 15), (64, 30), (700, 50), (300, 100), (620, 300)])
+def test_oracle_against_the_closed_form_of_cyclic_windows(N, k):
+    """An answer that is derived, not computed: pins the oracle's restatement of :24-55 at sizes beyond the hand-worked toys
+    (and, in tests/test_jaccard_gpu.py, every kernel family of the HIP path against the same closed form)."""
+    mat = cyclic_window_matrix(N, k)
+    want, wu = cyclic_window_expected(N, k)
+    got, u = oracle.jaccard(mat, nthreads=4)
+    assert np.array_equal(u, wu) and np.array_equal(got, want)
+    assert np.array_equal(oracle.jaccard(mat.astype(np.float64), nthreads=2)[0], want)
