@@ -20,3 +20,29 @@ def cyclic_window_expected(N, k):
     dst = np.where(pos, mat.reshape(-1), 0).astype(np.float64)
     w = np.where(pos, u / (2.0 * k - u), 0.0)                      # reference src/rcpp_parallel_jaccard_coeff.cpp:51
     return np.stack([src, dst, w], axis=1), u
+
+
+def circulant_counts(G, N, s, n_rare):
+    """A genes x cells count matrix whose GF-ICF has a closed form.  Cell c holds the s genes (c + t) mod G, t = 0 .. s-1, with counts t + 1
+    (N a multiple of G: every such gene lies in exactly N s / G cells), plus — in the first n_rare cells — one RARE gene G + c with count 7
+    that no other cell has (nt = 1: dropped by any filter with min >= 1 / N).  With the rare genes dropped, every cell has
+    S_c = s (s + 1) / 2 and every kept gene the same weight w = ln((N + 1) / (N s / G + 1)), so S and w cancel in the L2 step:
+        gficf[(c + t) mod G, c] = (t + 1) / sqrt(s (s + 1) (2 s + 1) / 6)            (R/gficf.R:59, 88-89, 79, 100-103)
+    Returns (scipy CSC matrix, expected dense-equivalent as (rowidx, colptr, x) of the compacted kept matrix, kept mask, nt, w)."""
+    import scipy.sparse as sp
+
+    assert N % G == 0 and 0 < s < G and n_rare <= N
+    c = np.repeat(np.arange(N, dtype=np.int64), s)
+    t = np.tile(np.arange(s, dtype=np.int64), N)
+    rows = (c + t) % G
+    vals = (t + 1).astype(np.float64)
+    rc, rr = np.arange(n_rare, dtype=np.int64), G + np.arange(n_rare, dtype=np.int64)
+    M = sp.csc_matrix((np.concatenate([vals, np.full(n_rare, 7.0)]), (np.concatenate([rows, rr]), np.concatenate([c, rc]))), shape=(G + n_rare, N))
+    M.sort_indices()
+    keep = np.concatenate([np.ones(G, dtype=bool), np.zeros(n_rare, dtype=bool)])
+    nt = np.concatenate([np.full(G, N * s // G, dtype=np.int64), np.ones(n_rare, dtype=np.int64)])
+    w = np.log((N + 1.0) / (N * s / G + 1.0))
+    norm = np.sqrt(s * (s + 1) * (2 * s + 1) / 6.0)
+    want = sp.csc_matrix((vals / norm, (rows, c)), shape=(G, N))
+    want.sort_indices()
+    return M, want, keep, nt, w

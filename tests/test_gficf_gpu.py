@@ -756,3 +756,23 @@ def test_pointer_begin_end_form_equals_the_canonical_pass(G, N, mn, mx, seed, en
     ops.cluster_signatures_be(gk, N, cp, be["out_end"], be["out_rowidx"], be["out_x"], cl, C, s_be)
     ops.sync()
     assert torch.allclose(s_can, s_be, rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("G,N,s,n_rare", [(400, 2000, 31, 300), (2000, 60000, 300, 5000), (5000, 20000, 2500, 100)])
+def test_gficf_against_the_closed_form_of_a_circulant_matrix(G, N, s, n_rare):
+    """GF-ICF with an answer derived by algebra, no oracle in the loop (tests/helpers/closed_form.py::circulant_counts): every cell holds s
+    genes of a ring with counts 1 .. s plus, in some cells, a rare gene the 5 % filter drops; S_c and the common ICF weight cancel, so
+    gficf[(c + t) mod G, c] = (t + 1) / sqrt(s (s + 1) (2 s + 1) / 6).  Through gficf() (host entry: plan + finish) — keep mask, nt, the
+    compacted structure exact, values and w to 1e-12 — at up to 18 M stored entries and cells of 2 500 entries (the two-sweep path)."""
+    from tests.helpers.closed_form import circulant_counts
+
+    M, want, keep, nt, w = circulant_counts(G, N, s, n_rare)
+    res = gficf_amd.gficf(M, normalize=False, verbose=False)
+    assert np.array_equal(res["genes"], np.flatnonzero(keep)) and np.array_equal(res["nt"], nt[keep])
+    assert np.allclose(res["w"], w, rtol=1e-13, atol=0)
+    got = res["gficf"]
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+    assert np.allclose(got.data, want.data, rtol=1e-12, atol=0)
+    # every cell has unit L2 norm (R/gficf.R:100-103) — a property, checked on the result itself
+    sq = np.add.reduceat(got.data ** 2, got.indptr[:-1])
+    assert np.allclose(sq, 1.0, rtol=1e-12)

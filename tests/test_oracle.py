@@ -399,3 +399,21 @@ def test_oracle_against_the_closed_form_of_cyclic_windows(N, k):
     got, u = oracle.jaccard(mat, nthreads=4)
     assert np.array_equal(u, wu) and np.array_equal(got, want)
     assert np.array_equal(oracle.jaccard(mat.astype(np.float64), nthreads=2)[0], want)
+
+
+@pytest.mark.parametrize("G,N,s,n_rare", [(50, 200, 7, 20), (400, 2000, 31, 300)])
+def test_gficf_oracle_against_the_closed_form_of_a_circulant_matrix(G, N, s, n_rare):
+    """GF-ICF with an answer derived by algebra (tests/helpers/closed_form.py::circulant_counts): filter, GF, ICF, L2 and the compaction of
+    the kept genes, both restatements of R/gficf.R:40-104."""
+    from tests.helpers.closed_form import circulant_counts
+
+    M, want, keep, nt, w = circulant_counts(G, N, s, n_rare)
+    rc = oracle.gficf_csc(G + n_rare, N, M.indptr.astype(np.int64), M.indices, M.data, 0.05, 1.0)
+    rn = oracle_np.gficf_np(M, 0.05, 1.0)
+    gn = rn["gficf"].tocsc()
+    gn.sort_indices()
+    for ref, ri, cp, xv in ((rc, rc["rowidx"], rc["colptr"], rc["x"]), (rn, gn.indices, gn.indptr, gn.data)):
+        assert np.array_equal(np.asarray(ref["keep"]).astype(bool), keep) and np.array_equal(np.asarray(ref["nt"])[:G], nt[:G])
+        assert np.allclose(np.asarray(ref["w"])[:G], w, rtol=1e-14)
+        assert np.array_equal(ri, want.indices) and np.array_equal(cp, want.indptr)
+        assert np.allclose(xv, want.data, rtol=1e-13, atol=0)
