@@ -256,3 +256,21 @@ def test_phenograph_on_cells_renumbered_in_pivot_order_gives_the_same_graph_and_
         b = gficf_amd.phenograph(X, k=15, n_start=1, n_iter=2)
         assert a.n_edges == b.n_edges > 0 and a.modularity == b.modularity and a.n_clusters == b.n_clusters
         assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.parametrize("N,k,metric", [(3000, 7, "manhattan"), (150_000, 31, "manhattan"), (20_000, 16, "euclidean")])
+def test_exact_search_against_the_derived_answer_on_a_line(N, k, metric):
+    """An answer by counting, no oracle in the loop: points at the integer positions 0 .. N-1 of a line (a second, constant coordinate
+    so that d > 1).  The k nearest of point i, itself included, ties to the smaller index: i, i-1, i+1, i-2, i+2, ... — clipped at the
+    ends, where the list continues on the side that exists.  Integers below 2^24 are exact in f32, so are the distances.  150 000 points
+    take the pruned search (pivot cells, tile bounds)."""
+    X = np.stack([np.arange(N, dtype=np.float64), np.full(N, 3.0)], axis=1)
+    res = gficf_amd.find_nn(X, k, True, metric)
+    i = np.arange(N, dtype=np.int64)[:, None]
+    cand = i + np.arange(-k, k + 1, dtype=np.int64)[None, :]                    # the k nearest lie within +-k positions
+    ok = (cand >= 0) & (cand < N)
+    dist = np.where(ok, np.abs(cand - i), 10 * N)
+    order = np.lexsort((np.where(ok, cand, 10 * N), dist), axis=1)[:, :k]       # by (distance, index)
+    want = np.take_along_axis(cand, order, axis=1) + 1
+    assert np.array_equal(res["idx"], want.astype(np.int32))
+    assert np.array_equal(res["dist"], np.take_along_axis(dist, order, axis=1).astype(np.float64))
