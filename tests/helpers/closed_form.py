@@ -46,3 +46,25 @@ def circulant_counts(G, N, s, n_rare):
     want = sp.csc_matrix((vals / norm, (rows, c)), shape=(G, N))
     want.sort_indices()
     return M, want, keep, nt, w
+
+
+def cyclic_window_matrix_twice(N, k):
+    """The same ring with every id named TWICE in a row (k even): slots 2 m and 2 m + 1 of row i both hold cell i + 1 + m.  Rows are multisets
+    now: the rows of i and j = i + d share k/2 - d distinct ids, each with multiplicity two on both sides, so std::set_intersection
+    (src/rcpp_parallel_jaccard_coeff.cpp:38-46) counts 2 (k/2 - d) and Rcpp::intersect of the serial entry (src/jaccard_coeff.cpp:33)
+    k/2 - d; slot t names j = i + 1 + t // 2, i.e. d = 1 + t // 2."""
+    assert k % 2 == 0 and N >= k
+    i = np.arange(N, dtype=np.int64)[:, None]
+    t = np.arange(k, dtype=np.int64)[None, :]
+    return ((i + 1 + t // 2) % N + 1).astype(np.int32)
+
+
+def cyclic_window_twice_expected(N, k, set_semantics=False):
+    m = k // 2 - 1 - np.arange(k) // 2                                          # distinct ids shared with the neighbour of slot t
+    u = np.tile((m if set_semantics else 2 * m).astype(np.int32), N)
+    mat = cyclic_window_matrix_twice(N, k)
+    pos = u > 0
+    src = np.where(pos, np.repeat(np.arange(1, N + 1), k), 0).astype(np.float64)
+    dst = np.where(pos, mat.reshape(-1), 0).astype(np.float64)
+    w = np.where(pos, u / (2.0 * k - u), 0.0)
+    return np.stack([src, dst, w], axis=1), u

@@ -1222,3 +1222,19 @@ def test_every_kernel_family_against_the_closed_form_of_cyclic_windows(N, k):
     want, wu = cyclic_window_expected(N, k)
     assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(mat, False), want)
     assert np.array_equal(gficf_amd.jaccard_counts(mat).astype(np.int32).reshape(-1), wu)
+
+
+@pytest.mark.parametrize("N,k", [(3000, 16), (4000, 30), (2500, 50), (900, 128), (800, 300)])
+def test_multiset_and_set_semantics_against_the_closed_form(N, k):
+    """Every id named twice in a row (the exact paths: the fast sequence raises, the entry re-runs; beyond 256 the sorted rows): the parallel
+    entry counts multisets, 2 (k/2 - d), the serial entry sets, k/2 - d — derived by counting, no oracle in the loop."""
+    from tests.helpers.closed_form import cyclic_window_matrix_twice, cyclic_window_twice_expected
+
+    mat = cyclic_window_matrix_twice(N, k)
+    want, wu = cyclic_window_twice_expected(N, k)
+    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(mat, False), want)
+    assert np.array_equal(gficf_amd.jaccard_counts(mat).astype(np.int32).reshape(-1), wu)
+    ws, _ = cyclic_window_twice_expected(N, k, set_semantics=True)
+    ws = ws[ws[:, 2] > 0]
+    gs = gficf_amd.jaccard_coeff(mat, False)
+    assert np.array_equal(gs[:len(ws)], ws) and not gs[len(ws):].any()

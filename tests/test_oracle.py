@@ -417,3 +417,19 @@ def test_gficf_oracle_against_the_closed_form_of_a_circulant_matrix(G, N, s, n_r
         assert np.allclose(np.asarray(ref["w"])[:G], w, rtol=1e-14)
         assert np.array_equal(ri, want.indices) and np.array_equal(cp, want.indptr)
         assert np.allclose(xv, want.data, rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("N,k", [(50, 16), (90, 30), (700, 300)])
+def test_oracle_multiset_and_set_semantics_against_the_closed_form(N, k):
+    """Rows that name every id twice: std::set_intersection's multiset count (parallel entry) is twice Rcpp::intersect's set count (serial
+    entry), both derived by counting (tests/helpers/closed_form.py::cyclic_window_matrix_twice)."""
+    from tests.helpers.closed_form import cyclic_window_matrix_twice, cyclic_window_twice_expected
+
+    mat = cyclic_window_matrix_twice(N, k)
+    want, wu = cyclic_window_twice_expected(N, k)
+    got, u = oracle.jaccard(mat, nthreads=4)
+    assert np.array_equal(u, wu) and np.array_equal(got, want)
+    ws, _ = cyclic_window_twice_expected(N, k, set_semantics=True)
+    ws = ws[ws[:, 2] > 0]                                                        # the serial entry packs its rows from the top (:36-41)
+    gs = oracle.jaccard_coeff(mat)
+    assert np.array_equal(gs[:len(ws)], ws) and not gs[len(ws):].any()
