@@ -87,3 +87,26 @@ def test_bad_ids_are_rejected():
     with pytest.raises(gficf_amd.GficfError) as ei:
         gficf_amd.jaccard_adjacency({"from": np.array([1.0, 7.0]), "to": np.array([2.0, 1.0]), "weight": np.array([0.5, 0.5])}, 5)
     assert ei.value.status == "GFICF_ERR_BAD_ID"
+
+
+@pytest.mark.parametrize("N,k", [(500, 15), (40_000, 30)])
+def test_graph_of_a_ring_against_the_derived_adjacency_matrix(N, k):
+    """The whole hand-off on an input whose answer is derived by counting (tests/helpers/closed_form.py): row i names the next k cells of a
+    ring, so the edge i -> i + d (slot d - 1) has u = k - d and weight (k - d) / (k + d); nothing points backwards, so the symmetric
+    adjacency matrix holds A[i, i +- d] = (k - d) / (k + d) for d = 1 .. k - 1 and nothing else — 2 (k - 1) entries per column.
+    Edge filter (the u = 0 rows of slot k - 1 dropped, R/clustCells.R:66) and adjacency build (R/clustCells.R:69,80), no scipy algebra
+    and no oracle in the loop."""
+    from tests.helpers.closed_form import cyclic_window_matrix
+
+    mat = cyclic_window_matrix(N, k)
+    neigh = np.concatenate([np.arange(1, N + 1, dtype=np.int32)[:, None], mat], axis=1)
+    edges = gficf_amd.jaccard_edges(neigh)
+    assert len(edges["weight"]) == N * (k - 1)
+    A = gficf_amd.jaccard_adjacency(edges, N)
+    d = np.arange(1, k, dtype=np.int64)
+    wd = (k - d) / (k + d)                                                       # u / (2 k - u) with u = k - d
+    cols = np.repeat(np.arange(N, dtype=np.int64), 2 * (k - 1))
+    offs = np.tile(np.concatenate([-d, d]), N)
+    want = sp.csc_matrix((np.tile(np.concatenate([wd, wd]), N), ((cols + offs) % N, cols)), shape=(N, N))
+    want.sort_indices()
+    assert same(A, want)
