@@ -433,3 +433,18 @@ def test_oracle_multiset_and_set_semantics_against_the_closed_form(N, k):
     ws = ws[ws[:, 2] > 0]                                                        # the serial entry packs its rows from the top (:36-41)
     gs = oracle.jaccard_coeff(mat)
     assert np.array_equal(gs[:len(ws)], ws) and not gs[len(ws):].any()
+
+
+@pytest.mark.parametrize("N,k,metric", [(400, 7, "manhattan"), (3000, 16, "euclidean")])
+def test_knn_oracle_against_the_derived_answer_on_a_line(N, k, metric):
+    """The search oracle (oracle/knn_oracle.cpp, f32 brute force) held to an answer by counting: points at the integer positions of a line,
+    the k nearest of i (itself included, ties to the smaller index) are i, i-1, i+1, i-2, ... (tests/test_knn_gpu.py holds the HIP search to
+    the same)."""
+    X = np.stack([np.arange(N, dtype=np.float64), np.full(N, 3.0)], axis=1)
+    idx, _ = oracle.knn(X, k, metric, nthreads=4)
+    i = np.arange(N, dtype=np.int64)[:, None]
+    cand = i + np.arange(-k, k + 1, dtype=np.int64)[None, :]
+    ok = (cand >= 0) & (cand < N)
+    dist = np.where(ok, np.abs(cand - i), 10 * N)
+    order = np.lexsort((np.where(ok, cand, 10 * N), dist), axis=1)[:, :k]
+    assert np.array_equal(idx, (np.take_along_axis(cand, order, axis=1) + 1).astype(idx.dtype))
