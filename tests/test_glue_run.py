@@ -265,3 +265,26 @@ def test_dot_call_optional_entries(R):
     want_ph = gficf_amd.phenograph(X, 10, "manhattan", 0.8, 1, 1, 10, 0)
     assert np.array_equal(ph.numpy(), np.asarray(want_ph))
     assert abs(float(ph.attr("modularity").numpy()[0]) - want_ph.modularity) < 1e-12 and float(ph.attr("n.edges").numpy()[0]) == want_ph.n_edges
+
+
+@pytest.mark.gpu
+def test_dot_call_entries_against_answers_derived_by_counting(R):
+    """The two `.Call` entries of the hot path against closed forms, no oracle in the loop (tests/helpers/closed_form.py): the Jaccard
+    entry on a ring of cells (u(i, t) = k - 1 - t: one small case that takes the one-launch form, one of 1.1 M edges that returns through
+    uint16 counts + host-side expansion into the R matrix), and `_gficf_gficf_csc` on a circulant count matrix
+    (gficf = (t + 1) / sqrt(s (s + 1) (2 s + 1) / 6), rare genes dropped by the 5 % filter)."""
+    from tests.helpers.closed_form import circulant_counts, cyclic_window_expected, cyclic_window_matrix
+
+    for N, k in ((3000, 15), (36_000, 30)):
+        want, _ = cyclic_window_expected(N, k)
+        res = R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(cyclic_window_matrix(N, k)), R.vector(np.array([False])))
+        _check_call_hygiene(R)
+        assert res.dim == (N * k, 3) and np.array_equal(res.numpy(), want)
+    G, N, s, n_rare = 400, 2000, 31, 300
+    M, want, keep, nt, w = circulant_counts(G, N, s, n_rare)
+    res = _call_gficf(R, M)
+    _check_call_hygiene(R)
+    oi, op, ox, kp, ntr, wr = (res.elt(i).numpy() for i in range(6))
+    assert np.array_equal(kp.astype(bool), keep) and np.array_equal(ntr, nt.astype(np.float64))
+    assert np.array_equal(op, want.indptr) and np.array_equal(oi, want.indices)
+    assert np.allclose(ox, want.data, rtol=1e-12, atol=0) and np.allclose(wr[:G], w, rtol=1e-13) and not wr[G:].any()
