@@ -99,6 +99,8 @@ SIGNATURES = {
     "gficf_normalize_csc_host_plan": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _dbl, _dbl, _vp,
                                              ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "gficf_normalize_csc_host_finish": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gficf_normalize_csc_host_finish_raw": (_int, [_vp] * 11),
+    "gficf_csc_kept_values_host": (_int, [_i64, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gficf_csc_genes_bytes": (ctypes.c_size_t, [_i64]),
     "gficf_csc_count_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
     "gficf_csc_genes_device": (_int, [_vp, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _vp]),

@@ -399,7 +399,7 @@ ICF_TYPES = {"classic": 0, "prob": 1, "smooth": 2}      # getIdfW(type = ...), r
 NORMS = {"l2": 0, "l1": 1}                               # l.norm(norm = ...), reference R/gficf.R:100
 
 
-def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx, icf_type="classic", norm="l2", devices=None):
+def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx, icf_type="classic", norm="l2", devices=None, raw=False):
     import scipy.sparse as sp
 
     if icf_type not in ICF_TYPES or norm not in NORMS:
@@ -417,18 +417,22 @@ def _normalize_csc_host(M, prop_min, prop_max, w_in, ctx, icf_type="classic", no
         mc = None
     if mc is not None:
         return _normalize_csc_host_run(L, mc, M, colptr, rowidx, x, G, N, prop_min, prop_max, w_in,
-                                       L.gficf_normalize_csc_host_multi_plan, L.gficf_normalize_csc_host_multi_finish)
+                                       L.gficf_normalize_csc_host_multi_plan, L.gficf_normalize_csc_host_multi_finish, raw=raw)
     ctx = ctx or default_context()
     check(L.gficf_ctx_set_gficf_options(ctx.handle, ICF_TYPES[icf_type], NORMS[norm]))
     try:
-        return _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_max, w_in)
+        return _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_max, w_in, raw=raw)
     finally:
         L.gficf_ctx_set_gficf_options(ctx.handle, 0, 0)
 
 
-def _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_max, w_in, plan=None, finish=None):
+def _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_max, w_in, plan=None, finish=None, raw=False):
+    """plan + finish of the host C ABI.  ``raw``: also the filtered counts ``M[keep, ]`` (``$rawCounts``, reference R/gficf.R:40,22)
+    as a matrix of its own (own index vectors) — its values gathered by the library's host threads while the results come back
+    (``gficf_normalize_csc_host_finish_raw``; behind the multi-GPU finish call: ``gficf_csc_kept_values_host``)."""
     import scipy.sparse as sp
 
+    single = plan is None
     plan = plan or L.gficf_normalize_csc_host_plan
     finish = finish or L.gficf_normalize_csc_host_finish
     gk, nk = ctypes.c_int64(0), ctypes.c_int64(0)
@@ -445,10 +449,25 @@ def _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_m
     ocp = np.zeros(N + 1, dtype=colptr.dtype)
     ori = np.empty(nk.value, dtype=np.int32)            # fully written by the finish call
     ox = np.empty(nk.value, dtype=np.float64)
-    check(finish(ctx.handle, _np_ptr(keep), _np_ptr(nt), _np_ptr(w), _np_ptr(ocp), _np_ptr(ori), _np_ptr(ox)))
+    rri = np.empty(nk.value, dtype=np.int32) if raw else None
+    rx = np.empty(nk.value, dtype=np.float64) if raw else None
+    if raw and single:
+        check(L.gficf_normalize_csc_host_finish_raw(ctx.handle, _np_ptr(keep), _np_ptr(nt), _np_ptr(w), _np_ptr(ocp), _np_ptr(ori), _np_ptr(ox),
+                                                    _np_ptr(rowidx), _np_ptr(x), _np_ptr(rri), _np_ptr(rx)))
+    else:
+        check(finish(ctx.handle, _np_ptr(keep), _np_ptr(nt), _np_ptr(w), _np_ptr(ocp), _np_ptr(ori), _np_ptr(ox)))
+        if raw:
+            check(L.gficf_csc_kept_values_host(G, N, _np_ptr(colptr), is64, _np_ptr(rowidx), _np_ptr(x), _np_ptr(keep), _np_ptr(ocp),
+                                               _np_ptr(rri), _np_ptr(rx)))
     keep = keep.astype(bool)
     out = sp.csc_matrix((ox, ori, ocp), shape=(gk.value, N))
-    return M, keep, nt, w, out
+    if not raw:
+        return M, keep, nt, w, out
+    if M.dtype != np.float64:
+        rx = rx.astype(M.dtype)                          # the counts keep their type, as M[keep, ] does
+    rawm = sp.csc_matrix((rx, rri, ocp.copy()), shape=(gk.value, N))
+    rawm.has_sorted_indices = True
+    return M, keep, nt, w, out, rawm
 
 
 def gficf(M, cell_proportion_max: float = 1, cell_proportion_min: float = 0.05, storeRaw: bool = True,
@@ -473,10 +492,11 @@ def gficf(M, cell_proportion_max: float = 1, cell_proportion_min: float = 0.05, 
     if verbose and normalize:
         warnings.warn("normalize=True: the edgeR CPM/TMM rescale (reference R/gficf.R:43-47) is a per-cell scale "
                       "that cancels in the GF step; rawCounts holds unscaled counts", stacklevel=2)
-    M, keep, nt, w, out = _normalize_csc_host(M, cell_proportion_min, cell_proportion_max, None, ctx, icf_type, norm, devices)
+    res = _normalize_csc_host(M, cell_proportion_min, cell_proportion_max, None, ctx, icf_type, norm, devices, raw=storeRaw)
+    M, keep, nt, w, out = res[:5]
     data = {"gficf": out}
     if storeRaw:
-        data["rawCounts"] = M[np.flatnonzero(keep), :]
+        data["rawCounts"] = res[5]                        # = M[keep, ] (R/gficf.R:40,22): the result's structure, the counts as values
     data["w"] = w[keep]
     data["genes"] = np.flatnonzero(keep)
     data["nt"] = nt[keep]

@@ -6,6 +6,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <thread>
+#include <vector>
 
 #include "gficf_hip.h"
 
@@ -98,6 +100,21 @@ void gficf_advise_hugepages(void* p, size_t bytes);
 // Touch every page of a freshly allocated host buffer from several threads (first-touch page faults of a large
 // result buffer otherwise run on the one thread doing the device-to-host copy and dominate it).
 void gficf_prefault(void* p, size_t bytes);
+
+// share(t) for t in [0, nt) on nt host threads; a thread that cannot be started (std::system_error) has its share run on the calling thread
+// instead: nothing is thrown across the C ABI and the result is the same
+template <typename F>
+inline void gficf_run_shares(int64_t nt, F&& share) {
+  std::vector<std::thread> th;
+  int64_t started = 0;
+  try {
+    th.reserve((size_t)(nt > 1 ? nt - 1 : 0));
+    for (; started + 1 < nt; ++started) th.emplace_back(share, started);
+  } catch (...) {
+  }
+  for (int64_t t = started; t < nt; ++t) share(t);            // the last share (and every share no thread could be had for): on this thread
+  for (auto& x : th) x.join();
+}
 
 // releases the host-form GF-ICF plan held by the context, if any (gficf_csc.hip)
 void gficf_host_plan_free(gficf_ctx* ctx);

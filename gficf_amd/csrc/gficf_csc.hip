@@ -1278,6 +1278,68 @@ void gficf_host_plan_free(gficf_ctx* ctx) {
   ctx->plan = nullptr;
 }
 
+// ------------------------------------------------------------ the values of M[keep, ]
+// normCounts' row subsetting (reference R/gficf.R:40) is what gficf() stores as $rawCounts (:22).  The filtered matrix has the structure
+// of the GF-ICF result itself (the same kept entries in the same order: new colptr, renumbered row ids), so only its VALUES are missing:
+// the x of the kept entries.  They never leave the host — the caller's x is there already and the result must end there: host threads
+// stream them from the caller's vectors (12 B read per stored entry, 8 B written per kept one) while the device scales and the results
+// cross PCIe, instead of another 8 B per kept entry over PCIe.  (R's `M[keep, ]` on a 60 M-entry dgCMatrix, or scipy's, takes ~150 ms.)
+struct ColPtr {
+  const void* p;
+  int is64;
+  int64_t operator[](int64_t c) const { return is64 ? ((const int64_t*)p)[c] : (int64_t)((const int32_t*)p)[c]; }
+};
+
+// returns GFICF_OK or GFICF_ERR_BAD_CSC (some cell's kept entries do not fill [kept_colptr[c], kept_colptr[c+1]) exactly); sets no message:
+// it may run on a helper thread
+static int kept_values(int64_t G, int64_t N, ColPtr cp, const int32_t* rowidx, const double* x, const uint8_t* keep, ColPtr kcp,
+                       int32_t* out_rowidx, double* out_x) {
+  const int64_t nnz = N > 0 ? cp[N] : 0, nk = N > 0 ? kcp[N] : 0;
+  if (nnz <= 0) return nk == 0 ? GFICF_OK : GFICF_ERR_BAD_CSC;
+  std::vector<int32_t> remap;
+  if (out_rowidx) {
+    remap.resize((size_t)G);
+    int32_t r = 0;
+    for (int64_t g = 0; g < G; ++g) remap[(size_t)g] = keep[g] ? r++ : -1;
+  }
+  const int32_t* const rm = out_rowidx ? remap.data() : nullptr;
+  gficf_advise_hugepages(out_x, sizeof(double) * (size_t)nk);
+  if (out_rowidx) gficf_advise_hugepages(out_rowidx, sizeof(int32_t) * (size_t)nk);
+  int64_t nt = nnz / 2000000;
+  const int64_t hw = (int64_t)std::thread::hardware_concurrency();
+  if (nt > 32) nt = 32;
+  if (hw > 0 && nt > hw) nt = hw;
+  if (nt < 1) nt = 1;
+  std::atomic<int> bad{0};
+  // a share = the cells whose first entry lies in its share of the stored entries
+  auto first_cell = [&](int64_t target) {
+    int64_t lo = 0, hi = N;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (cp[mid] >= target) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+  };
+  gficf_run_shares(nt, [&](int64_t t) {
+    const int64_t c0 = t == 0 ? 0 : first_cell(nnz / nt * t), c1 = t + 1 == nt ? N : first_cell(nnz / nt * (t + 1));
+    for (int64_t c = c0; c < c1; ++c) {
+      int64_t d = kcp[c];
+      const int64_t dend = kcp[c + 1], p1 = cp[c + 1];
+      for (int64_t q = cp[c]; q < p1; ++q) {
+        const uint32_t g = (uint32_t)rowidx[q];
+        if (g < (uint64_t)G && keep[g]) {
+          if (d >= dend) { bad.store(1); return; }
+          out_x[d] = x[q];
+          if (rm) out_rowidx[d] = rm[g];
+          ++d;
+        }
+      }
+      if (d != dend) { bad.store(1); return; }
+    }
+  });
+  return bad.load() ? GFICF_ERR_BAD_CSC : GFICF_OK;
+}
+
 #define PLAN_HIP(expr)                                                                              \
   do {                                                                                              \
     hipError_t _e = (expr);                                                                         \
@@ -1348,20 +1410,45 @@ int gficf_normalize_csc_host_plan(gficf_ctx* ctx, int64_t G, int64_t N, const vo
   return GFICF_OK;
 }
 
-int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, double* w, void* out_colptr,
-                                    int32_t* out_rowidx, double* out_x) {
+// the finish call; raw_rowidx / raw_x: NULL, or the caller's @i / @x again for the values of M[keep, ] (gficf_normalize_csc_host_finish_raw)
+static int host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, double* w, void* out_colptr, int32_t* out_rowidx, double* out_x,
+                       const int32_t* raw_rowidx, const double* raw_x, int32_t* out_raw_rowidx, double* out_raw_x) {
   GFICF_CTX_ENTER(ctx);
   gficf_host_plan* p = ctx->plan;
   if (!p) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "gficf_normalize_csc_host_finish without a plan");
   if (!out_colptr || (p->nnz_kept > 0 && (!out_rowidx || !out_x))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
+  const bool want_raw = out_raw_x != nullptr && p->nnz_kept > 0;
+  if (want_raw && (!raw_rowidx || !raw_x)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "the raw values of the kept rows need the matrix's rowidx and x again");
   const size_t ksz = (size_t)(p->nnz_kept > 0 ? p->nnz_kept : 1);
   gficf_arena ar;
   const size_t o_ri = ar.take(sizeof(int32_t) * ksz), o_x = ar.take(sizeof(double) * ksz);
   PLAN_HIP(ar.bind(ctx, 7));
   int32_t* const d_ori = ar.at<int32_t>(o_ri);
   double* const d_ox = ar.at<double>(o_x);
+  std::vector<int64_t> cp((size_t)p->N + 1), cp_in;
+  std::vector<uint8_t> keep_h;
+  std::thread raw_thread;
+  int raw_rc = GFICF_OK;
+  if (want_raw) {
+    // the new column pointers and the keep flags are the plan's (the stream is idle: the plan ended in a sync); the raw values of the
+    // kept rows are then gathered by host threads from the caller's own vectors WHILE the scaling pass runs and its results come back
+    cp_in.resize((size_t)p->N + 1);
+    keep_h.resize((size_t)(p->G > 0 ? p->G : 1));
+    PLAN_HIP(hipMemcpyAsync(cp.data(), p->d_out_colptr, sizeof(int64_t) * cp.size(), hipMemcpyDeviceToHost, ctx->stream));
+    PLAN_HIP(hipMemcpyAsync(cp_in.data(), p->d_colptr, sizeof(int64_t) * cp_in.size(), hipMemcpyDeviceToHost, ctx->stream));
+    if (p->G > 0) PLAN_HIP(hipMemcpyAsync(keep_h.data(), p->d_keep, (size_t)p->G, hipMemcpyDeviceToHost, ctx->stream));
+    PLAN_HIP(hipStreamSynchronize(ctx->stream));
+  }
   int rc = gficf_csc_scale_device(ctx, p->G, p->N, p->d_colptr, p->d_rowidx, p->d_x, p->nnz, p->d_genes, p->d_gkept,
                                   p->d_out_colptr, d_ori, d_ox);
+  if (!rc && want_raw) {
+    const int64_t G = p->G, N = p->N;
+    const int64_t *ci = cp_in.data(), *co = cp.data();
+    const uint8_t* kh = keep_h.data();
+    int* const rcp = &raw_rc;
+    auto job = [=] { *rcp = kept_values(G, N, ColPtr{ci, 1}, raw_rowidx, raw_x, kh, ColPtr{co, 1}, out_raw_rowidx, out_raw_x); };
+    try { raw_thread = std::thread(job); } catch (...) { job(); }
+  }
   // the caller's result vectors are freshly allocated as a rule: map their pages from several threads instead of one
   // page fault at a time under the device-to-host copy — the row indices while the scaling pass runs, the values (twice
   // as many bytes) on a helper thread while the row indices are being copied (a pageable copy holds the calling thread)
@@ -1370,12 +1457,11 @@ int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, 
     gficf_prefault(out_rowidx, sizeof(int32_t) * (size_t)p->nnz_kept);
     double* const ox = out_x;
     const size_t xb = sizeof(double) * (size_t)p->nnz_kept;
-    fault_x = std::thread([ox, xb] { gficf_prefault(ox, xb); });
+    try { fault_x = std::thread([ox, xb] { gficf_prefault(ox, xb); }); } catch (...) { }
   }
-  std::vector<int64_t> cp((size_t)p->N + 1);
   hipError_t e = hipSuccess;
   if (!rc) {
-    e = hipMemcpyAsync(cp.data(), p->d_out_colptr, sizeof(int64_t) * cp.size(), hipMemcpyDeviceToHost, ctx->stream);
+    if (!want_raw) e = hipMemcpyAsync(cp.data(), p->d_out_colptr, sizeof(int64_t) * cp.size(), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && p->nnz_kept > 0) e = hipMemcpyAsync(out_rowidx, d_ori, sizeof(int32_t) * (size_t)p->nnz_kept, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && keep && p->G > 0) e = hipMemcpyAsync(keep, p->d_keep, (size_t)p->G, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && nt && p->G > 0) e = hipMemcpyAsync(nt, p->d_nt, sizeof(int64_t) * (size_t)p->G, hipMemcpyDeviceToHost, ctx->stream);
@@ -1385,14 +1471,45 @@ int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, 
     if (e == hipSuccess) rc = gficf_ctx_sync(ctx);
   }
   if (fault_x.joinable()) fault_x.join();
+  if (raw_thread.joinable()) raw_thread.join();
   if (e != hipSuccess || rc) (void)hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { gficf_set_error("HIP failure in gficf_normalize_csc_host_finish: %s", hipGetErrorString(e)); rc = GFICF_ERR_HIP; }
+  if (!rc && raw_rc) {
+    gficf_set_error("the rowidx / x handed to the finish call are not the matrix of the plan (the kept entries of some cell do not match its count)");
+    rc = raw_rc;
+  }
   if (!rc) {
     if (p->colptr_is_i64) std::memcpy(out_colptr, cp.data(), sizeof(int64_t) * cp.size());
     else for (size_t c = 0; c < cp.size(); ++c) ((int32_t*)out_colptr)[c] = (int32_t)cp[c];
   }
   gficf_host_plan_free(ctx);
   return rc;
+}
+
+int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, double* w, void* out_colptr,
+                                    int32_t* out_rowidx, double* out_x) {
+  return host_finish(ctx, keep, nt, w, out_colptr, out_rowidx, out_x, nullptr, nullptr, nullptr, nullptr);
+}
+
+int gficf_normalize_csc_host_finish_raw(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, double* w, void* out_colptr,
+                                        int32_t* out_rowidx, double* out_x, const int32_t* rowidx, const double* x,
+                                        int32_t* out_raw_rowidx, double* out_raw_x) {
+  return host_finish(ctx, keep, nt, w, out_colptr, out_rowidx, out_x, rowidx, x, out_raw_rowidx, out_raw_x);
+}
+
+int gficf_csc_kept_values_host(int64_t G, int64_t N, const void* colptr, int colptr_is_i64, const int32_t* rowidx, const double* x,
+                               const uint8_t* keep, const void* kept_colptr, int32_t* out_rowidx, double* out_x) {
+  if (G < 0 || N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative dimension");
+  if (N == 0) return GFICF_OK;
+  if (!colptr || !kept_colptr) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
+  const ColPtr ci{colptr, colptr_is_i64}, co{kept_colptr, colptr_is_i64};
+  if (ci[N] > 0 && (!rowidx || !x || !keep)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
+  if (co[N] > 0 && !out_x) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
+  for (int64_t c = 0; c < N; ++c)
+    if (ci[c + 1] < ci[c] || co[c + 1] < co[c]) GFICF_FAIL(GFICF_ERR_BAD_CSC, "column pointers not monotone at cell %lld", (long long)c);
+  const int rc = kept_values(G, N, ci, rowidx, x, keep, co, out_rowidx, out_x);
+  if (rc) GFICF_FAIL(rc, "kept_colptr is not the column pointer of M[keep, ] (the kept entries of some cell do not match its count)");
+  return GFICF_OK;
 }
 
 }  // extern "C"

@@ -936,21 +936,6 @@ int64_t host_compact_min_edges() {                              // (read per cal
   return e ? (int64_t)atoll(e) : (int64_t)(1 << 20);          // measured crossover ~1 M edges (profiles/r05_host_compact_ab.txt)
 }
 
-// share(t) for t in [0, nt) on nt host threads; a thread that cannot be started (std::system_error) has its share run here instead: nothing
-// is thrown across the C ABI and the result is the same
-template <typename F>
-void run_shares(int64_t nt, F&& share) {
-  std::vector<std::thread> th;
-  int64_t started = 0;
-  try {
-    th.reserve((size_t)(nt > 1 ? nt - 1 : 0));
-    for (; started + 1 < nt; ++started) th.emplace_back(share, started);
-  } catch (...) {
-  }
-  for (int64_t t = started; t < nt; ++t) share(t);            // the last share (and every share no thread could be had for): on this thread
-  for (auto& x : th) x.join();
-}
-
 int check_nk(int64_t N, int k) {
   if (N < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "N = %lld is negative", (long long)N);
   if (k < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "k = %d is negative", k);
@@ -1329,7 +1314,7 @@ int gficf_jaccard_expand_host(const void* idx, int idx_is_f64, int64_t N, int k,
   };
   if (nt <= 1) { work(0, N); return GFICF_OK; }
   const int64_t per = (N + nt - 1) / nt;
-  run_shares(nt, [&](int64_t t) {
+  gficf_run_shares(nt, [&](int64_t t) {
     const int64_t c0 = t * per, c1 = c0 + per < N ? c0 + per : N;
     if (c0 < c1) work(c0, c1);
   });
@@ -1519,7 +1504,7 @@ static int gficf_jaccard_filtered_host_plan_body(gficf_ctx* ctx, const void* idx
     p->first.assign((size_t)nt + 1, 0);
     const uint16_t* const u = p->u.data();
     int64_t* const first = p->first.data();
-    run_shares(nt, [=](int64_t t) {
+    gficf_run_shares(nt, [=](int64_t t) {
       int64_t c0, c1, n = 0;
       cell_share(N, nt, t, c0, c1);
       for (int64_t r = c0 * k; r < c1 * k; ++r) n += u[r] != 0;
@@ -1621,7 +1606,7 @@ int gficf_jaccard_filtered_host_finish(gficf_ctx* ctx, double* from, double* to,
     const double* const id = (const double*)p->idx;
     const int64_t* const first = p->first.data();
     const double twok = 2.0 * (double)k;
-    run_shares(nt, [=](int64_t t) {
+    gficf_run_shares(nt, [=](int64_t t) {
         int64_t c0, c1;
         cell_share(N, nt, t, c0, c1);
         int64_t d = first[t];

@@ -355,6 +355,23 @@ int gficf_normalize_csc_host_plan(gficf_ctx* ctx, int64_t G, int64_t N, const vo
 int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, double* w,
                                     void* out_colptr, int32_t* out_rowidx, double* out_x);
 
+/* gficf(storeRaw = TRUE) keeps the filtered counts, `$rawCounts` = normCounts' `M[keep, ]` (reference R/gficf.R:40,22).  That matrix
+ * has the structure of the GF-ICF result itself — the same kept entries in the same order: out_colptr, out_rowidx — so only its values
+ * are missing: the x of the kept entries.  They never leave the host (the caller's x is there and the result must end there):
+ *   gficf_normalize_csc_host_finish_raw = the finish call + out_raw_x[nnz_kept] (and, if out_raw_rowidx is not NULL, a copy of
+ *       the renumbered row ids of its own for a caller whose two matrices must not share a vector), gathered by host threads from
+ *       `rowidx` / `x` — the SAME vectors the plan call was given — while the device scales and the results cross PCIe;
+ *       GFICF_ERR_BAD_CSC if they are not the plan's matrix (some cell's kept entries do not match its count).  out_raw_x == NULL:
+ *       exactly gficf_normalize_csc_host_finish.
+ *   gficf_csc_kept_values_host = the same gather by itself, no device and no context involved (after the multi-GPU finish call, or
+ *       for any `M[keep, ]` whose column pointer is known): kept_colptr (same integer width as colptr) must be the column pointer of
+ *       M[keep, ]; out_rowidx may be NULL.  keep: G flags (0 / 1). */
+int gficf_normalize_csc_host_finish_raw(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, double* w, void* out_colptr,
+                                        int32_t* out_rowidx, double* out_x, const int32_t* rowidx, const double* x,
+                                        int32_t* out_raw_rowidx, double* out_raw_x);
+int gficf_csc_kept_values_host(int64_t G, int64_t N, const void* colptr, int colptr_is_i64, const int32_t* rowidx,
+                               const double* x, const uint8_t* keep, const void* kept_colptr, int32_t* out_rowidx, double* out_x);
+
 /* Device-resident pipeline (all pointers are device memory; colptr is int64 here), split
  * where a multi-GPU caller needs the seam (cells sharded by column block):
  *   1. count   : d_nt[g] += #{local cells with non-zero entry of gene g}   (d_nt zeroed by caller; a counter stays below 2^32)

@@ -4,12 +4,15 @@ gficf = function(M, cell_proportion_max = 1, cell_proportion_min = 0.05, storeRa
 {
   data = list()
   M = methods::as(M, "CsparseMatrix")
-  r = .Call(`_gficf_gficf_csc`, M@i, M@p, M@x, M@Dim, NULL, cell_proportion_min, cell_proportion_max)
+  r = if (storeRaw) .Call(`_gficf_gficf_csc_raw`, M@i, M@p, M@x, M@Dim, NULL, cell_proportion_min, cell_proportion_max)
+      else .Call(`_gficf_gficf_csc`, M@i, M@p, M@x, M@Dim, NULL, cell_proportion_min, cell_proportion_max)
   keep = as.logical(r[[4]])
-  data$gficf = Matrix::sparseMatrix(i = r[[1]], p = r[[2]], x = r[[3]], index1 = FALSE,
-                                    dims = c(sum(keep), ncol(M)), dimnames = list(rownames(M)[keep], colnames(M)))
+  dn = list(rownames(M)[keep], colnames(M))
+  data$gficf = Matrix::sparseMatrix(i = r[[1]], p = r[[2]], x = r[[3]], index1 = FALSE, dims = c(sum(keep), ncol(M)), dimnames = dn)
   if (storeRaw) {
-    raw = M[keep, ]
+    # normCounts' M[keep, ] (reference R/gficf.R:40): the structure of the result with the counts as values — r[[7]], gathered by the
+    # library while the result came back; @i and @p are the SAME vectors as $gficf's (R copies on modify), no subsetting in R
+    raw = Matrix::sparseMatrix(i = r[[1]], p = r[[2]], x = r[[7]], index1 = FALSE, dims = c(sum(keep), ncol(M)), dimnames = dn)
     # the edgeR branch (reference R/gficf.R:43-47) only rescales what is stored here: a per-cell scale
     # cancels in x/colSums(x), so $gficf is the same with or without it
     if (normalize) raw = Matrix::Matrix(edgeR::cpm(edgeR::calcNormFactors(edgeR::DGEList(counts = raw))), sparse = TRUE)

@@ -16,6 +16,7 @@
  *       (src/RcppExports.cpp:36): set intersection, rows with u > 0 packed from the top.
  *   _gficf_gficf_csc(i, p, x, dim, w, min, max)          — NEW entry for the GF-ICF chain of
  *       R/gficf.R:38-105 (the reference has no native entry on that path).
+ *   _gficf_gficf_csc_raw(i, p, x, dim, w, min, max)      — the same + the values of M[keep, ] ($rawCounts, R/gficf.R:40,22).
  *   _gficf_find_nn(X, k, metric)                         — NEW, optional: exact kNN in place of the
  *       uwot:::find_nn(..., method = "annoy") call of clustcells() (R/clustCells.R:57,60).
  *   _gficf_jaccard_adjacency(from, to, weight, n)        — NEW, optional: igraph::as_adjacency_matrix (R/clustCells.R:80,86).
@@ -129,7 +130,7 @@ SEXP _gficf_jaccard_coeff(SEXP idxSEXP, SEXP printOutputSEXP) {
 }
 
 /* list(i, p, x, keep, nt, w) for gficf() / embedNewCells(); w = NULL -> compute ICF weights */
-SEXP _gficf_gficf_csc(SEXP iS, SEXP pS, SEXP xS, SEXP dimS, SEXP wS, SEXP minS, SEXP maxS) {
+static SEXP gficf_csc_call(SEXP iS, SEXP pS, SEXP xS, SEXP dimS, SEXP wS, SEXP minS, SEXP maxS, int raw) {
   const int64_t G = INTEGER(dimS)[0], N = INTEGER(dimS)[1];
   const double* w_in = Rf_isNull(wS) ? NULL : REAL(wS);
   int64_t gk = 0, nk = 0;
@@ -138,23 +139,43 @@ SEXP _gficf_gficf_csc(SEXP iS, SEXP pS, SEXP xS, SEXP dimS, SEXP wS, SEXP minS, 
                     : gficf_normalize_csc_host_plan(ctx_get(), G, N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), Rf_asReal(minS), Rf_asReal(maxS), w_in, &gk, &nk);
   if (prc != GFICF_OK) Rf_error("gficf_hip: %s", gficf_last_error());
   if (nk > (int64_t)INT_MAX) Rf_error("gficf_hip: %.0f kept entries exceed a dgCMatrix (its @p is integer)", (double)nk);
-  SEXP out = PROTECT(Rf_allocVector(VECSXP, 6));
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, raw ? 7 : 6));
   SEXP oi = PROTECT(Rf_allocVector(INTSXP, nk)), op = PROTECT(Rf_allocVector(INTSXP, N + 1));
   SEXP ox = PROTECT(Rf_allocVector(REALSXP, nk)), keep = PROTECT(Rf_allocVector(RAWSXP, G));
   SEXP w = PROTECT(Rf_allocVector(REALSXP, G));
+  SEXP rx = PROTECT(raw ? Rf_allocVector(REALSXP, nk) : R_NilValue);      /* the values of M[keep, ]: $rawCounts shares @i and @p with $gficf */
   int64_t* nt = (int64_t*)R_alloc((size_t)G, sizeof(int64_t));
-  const int frc = m ? gficf_normalize_csc_host_multi_finish(m, RAW(keep), nt, REAL(w), INTEGER(op), INTEGER(oi), REAL(ox))
-                    : gficf_normalize_csc_host_finish(ctx_get(), RAW(keep), nt, REAL(w), INTEGER(op), INTEGER(oi), REAL(ox));
+  int frc;
+  if (m) {
+    frc = gficf_normalize_csc_host_multi_finish(m, RAW(keep), nt, REAL(w), INTEGER(op), INTEGER(oi), REAL(ox));
+    if (frc == GFICF_OK && raw)
+      frc = gficf_csc_kept_values_host(G, N, INTEGER(pS), 0, INTEGER(iS), REAL(xS), RAW(keep), INTEGER(op), NULL, REAL(rx));
+  } else if (raw) {
+    frc = gficf_normalize_csc_host_finish_raw(ctx_get(), RAW(keep), nt, REAL(w), INTEGER(op), INTEGER(oi), REAL(ox), INTEGER(iS), REAL(xS), NULL, REAL(rx));
+  } else {
+    frc = gficf_normalize_csc_host_finish(ctx_get(), RAW(keep), nt, REAL(w), INTEGER(op), INTEGER(oi), REAL(ox));
+  }
   if (frc != GFICF_OK) {
-    UNPROTECT(6);
+    UNPROTECT(7);
     Rf_error("gficf_hip: %s", gficf_last_error());
   }
   SEXP ntS = PROTECT(Rf_allocVector(REALSXP, G));
   for (int64_t g = 0; g < G; ++g) REAL(ntS)[g] = (double)nt[g];
   SET_VECTOR_ELT(out, 0, oi); SET_VECTOR_ELT(out, 1, op); SET_VECTOR_ELT(out, 2, ox);
   SET_VECTOR_ELT(out, 3, keep); SET_VECTOR_ELT(out, 4, ntS); SET_VECTOR_ELT(out, 5, w);
-  UNPROTECT(7);
+  if (raw) SET_VECTOR_ELT(out, 6, rx);
+  UNPROTECT(8);
   return out;
+}
+
+SEXP _gficf_gficf_csc(SEXP iS, SEXP pS, SEXP xS, SEXP dimS, SEXP wS, SEXP minS, SEXP maxS) {
+  return gficf_csc_call(iS, pS, xS, dimS, wS, minS, maxS, 0);
+}
+
+/* The same with a seventh list element: the x of the kept entries, i.e. the values of normCounts' `M[keep, ]` (reference R/gficf.R:40) in the
+ * structure of the result — gficf(storeRaw = TRUE) builds $rawCounts from (r[[1]], r[[2]], r[[7]]) instead of subsetting M in R. */
+SEXP _gficf_gficf_csc_raw(SEXP iS, SEXP pS, SEXP xS, SEXP dimS, SEXP wS, SEXP minS, SEXP maxS) {
+  return gficf_csc_call(iS, pS, xS, dimS, wS, minS, maxS, 1);
 }
 
 /* Optional: exact neighbour search in place of the approximate uwot:::find_nn(..., method = "annoy") call of
@@ -301,6 +322,7 @@ static const R_CallMethodDef HipCallEntries[] = {
     {"_gficf_rcpp_parallel_jaccard_coef", (DL_FUNC)&_gficf_rcpp_parallel_jaccard_coef, 2},
     {"_gficf_jaccard_coeff", (DL_FUNC)&_gficf_jaccard_coeff, 2},
     {"_gficf_gficf_csc", (DL_FUNC)&_gficf_gficf_csc, 7},
+    {"_gficf_gficf_csc_raw", (DL_FUNC)&_gficf_gficf_csc_raw, 7},
     {"_gficf_find_nn", (DL_FUNC)&_gficf_find_nn, 3},
     {"_gficf_jaccard_adjacency", (DL_FUNC)&_gficf_jaccard_adjacency, 4},
     {"_gficf_cluster_signatures", (DL_FUNC)&_gficf_cluster_signatures, 6},

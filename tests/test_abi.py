@@ -71,6 +71,43 @@ def test_null_ctx_is_rejected_not_crashing():
     assert rc == 1
 
 
+def test_kept_values_host_is_the_row_subset_of_the_counts():
+    """gficf_csc_kept_values_host (no device involved): the values — and, on request, the renumbered row ids — of `M[keep, ]` (normCounts,
+    reference R/gficf.R:40; $rawCounts :22) given its column pointer, against scipy's row subsetting: int32 and int64 pointers, empty cells,
+    explicitly stored zeros (they stay), enough entries for several host threads; a column pointer that is not M[keep, ]'s is refused."""
+    import ctypes
+
+    import scipy.sparse as sp
+
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    for G, N, dens, pt in ((50, 40, 0.3, np.int32), (3000, 9000, 0.2, np.int64), (1, 1, 1.0, np.int32), (7, 0, 0.5, np.int32)):
+        M = sp.random(G, N, density=dens, format="csc", random_state=rng, dtype=np.float64)
+        M.data = np.ceil(M.data * 9)
+        M.data[::53] = 0.0
+        if N > 10:
+            M = sp.hstack([M[:, :5], sp.csc_matrix((G, 3)), M[:, 5:]], format="csc")      # three empty cells
+        G, N = M.shape
+        keep = (rng.random(G) < 0.6).astype(np.uint8)
+        want = M[np.flatnonzero(keep), :]
+        cp, ri, x = M.indptr.astype(pt), M.indices.astype(np.int32), np.ascontiguousarray(M.data)
+        kcp = want.indptr.astype(pt)
+        for with_ids in (True, False):
+            oi = np.full(want.nnz, -7, dtype=np.int32)
+            ox = np.full(want.nnz, np.nan)
+            rc = L.gficf_csc_kept_values_host(G, N, cp.ctypes.data, int(pt is np.int64), ri.ctypes.data, x.ctypes.data, keep.ctypes.data, kcp.ctypes.data,
+                                              oi.ctypes.data if with_ids else None, ox.ctypes.data)
+            assert rc == 0, L.gficf_last_error()
+            assert np.array_equal(ox, want.data) and (not with_ids or np.array_equal(oi, want.indices))
+        if want.nnz:
+            bad = kcp.copy()
+            bad[-1] -= 1
+            ox = np.zeros(want.nnz)
+            rc = L.gficf_csc_kept_values_host(G, N, cp.ctypes.data, int(pt is np.int64), ri.ctypes.data, x.ctypes.data, keep.ctypes.data, bad.ctypes.data, None, ox.ctypes.data)
+            assert _lib.STATUS_NAMES[rc] == "GFICF_ERR_BAD_CSC"
+            assert b"kept_colptr" in L.gficf_last_error()
+
+
 def test_product_package_never_imports_oracle():
     pkg = os.path.join(ROOT, "gficf_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -61,6 +61,44 @@ def test_matches_oracle(G, N, mn, mx, seed):
     assert (res["rawCounts"] != M[res["genes"], :]).nnz == 0
 
 
+def test_raw_counts_come_back_with_the_result_and_are_the_row_subset():
+    """gficf(storeRaw=True): $rawCounts = normCounts' M[keep, ] (reference R/gficf.R:40,22) comes from the finish call itself
+    (gficf_normalize_csc_host_finish_raw: the result's structure, the counts gathered by host threads while the result crosses PCIe) — equal to
+    scipy's row subsetting entry for entry, at a size that takes several host threads, explicit zeros kept, integer counts staying integers,
+    index vectors of its own; a finish call handed another matrix than the plan's is refused."""
+    import ctypes
+
+    from gficf_amd import _lib
+    from gficf_amd.api import _np_ptr
+
+    G, N = 6000, 9000
+    cp, ri, x = synth.counts_csc(G, N, median_frac=0.2, seed=11)
+    assert len(x) > 6_000_000                                            # (three shares of host threads and more)
+    x[::101] = 0.0
+    for dt in (np.float64, np.int32):
+        M = sp.csc_matrix((x.astype(dt), ri, cp), shape=(G, N))
+        res = gficf_amd.gficf(M, normalize=False, verbose=False)
+        raw, want = res["rawCounts"], M[res["genes"], :]
+        assert raw.dtype == dt and raw.shape == want.shape
+        assert np.array_equal(raw.indptr, want.indptr) and np.array_equal(raw.indices, want.indices) and np.array_equal(raw.data, want.data)
+        assert np.array_equal(raw.indices, res["gficf"].indices) and not np.shares_memory(raw.indices, res["gficf"].indices)
+        assert not np.shares_memory(raw.indptr, res["gficf"].indptr)
+    ref = oracle.gficf_csc(G, N, cp, ri, x, 0.05, 1.0)
+    check_against_oracle(res, ref, N)
+    assert gficf_amd.gficf(M, normalize=False, verbose=False, storeRaw=False).get("rawCounts") is None
+    # another matrix at the finish call: the kept entries of some cell do not match the plan's count
+    L, ctx = _lib.load(), gficf_amd.default_context()
+    gk, nk = ctypes.c_int64(0), ctypes.c_int64(0)
+    ri32 = ri.astype(np.int32)
+    assert L.gficf_normalize_csc_host_plan(ctx.handle, G, N, _np_ptr(cp), 1, _np_ptr(ri32), _np_ptr(x), 0.05, 1.0, None, ctypes.byref(gk), ctypes.byref(nk)) == 0
+    other = ((ri32 + 1) % G).astype(np.int32)
+    ocp, ori, ox, rx = np.zeros(N + 1, dtype=np.int64), np.empty(nk.value, dtype=np.int32), np.empty(nk.value), np.empty(nk.value)
+    rc = L.gficf_normalize_csc_host_finish_raw(ctx.handle, None, None, None, _np_ptr(ocp), _np_ptr(ori), _np_ptr(ox), _np_ptr(other), _np_ptr(x), None, _np_ptr(rx))
+    assert _lib.STATUS_NAMES[rc] == "GFICF_ERR_BAD_CSC" and b"not the matrix of the plan" in L.gficf_last_error()
+    res2 = gficf_amd.gficf(M, normalize=False, verbose=False)              # the context is usable afterwards
+    assert np.array_equal(res2["rawCounts"].data, want.data)
+
+
 @pytest.mark.parametrize("shape", ["giants_first", "giants_last", "empty_blocks", "one_cell_has_it_all", "all_equal"])
 def test_skewed_cell_lengths_above_the_range_search_threshold(shape):
     """The scaling and kept-count passes cut the cells into contiguous ranges of equal stored entries (a search on colptr by

@@ -30,7 +30,7 @@ def test_glue_registers_its_routines_by_name_and_arity(R):
     tab = R.routines()
     # the two entries that REPLACE reference entries keep name and arity (src/RcppExports.cpp:87,89)
     assert tab["_gficf_rcpp_parallel_jaccard_coef"] == 2 and tab["_gficf_jaccard_coeff"] == 2
-    assert tab["_gficf_gficf_csc"] == 7 and len(tab) == 9
+    assert tab["_gficf_gficf_csc"] == 7 and tab["_gficf_gficf_csc_raw"] == 7 and len(tab) == 10
     with pytest.raises(KeyError):
         R.call("_gficf_no_such_entry")
     with pytest.raises(TypeError):                      # `.Call` with the wrong number of arguments is refused by the table
@@ -147,15 +147,15 @@ def _counts(G, N, seed=7):
     return sp.csc_matrix((x, rowidx, colptr), shape=(G, N))
 
 
-def _call_gficf(R, M, w=None, pmin=0.05, pmax=1.0):
+def _call_gficf(R, M, w=None, pmin=0.05, pmax=1.0, entry="_gficf_gficf_csc"):
     G, N = M.shape
-    return R.call("_gficf_gficf_csc", R.vector(M.indices.astype(np.int32)), R.vector(M.indptr.astype(np.int32)), R.vector(M.data),
+    return R.call(entry, R.vector(M.indices.astype(np.int32)), R.vector(M.indptr.astype(np.int32)), R.vector(M.data),
                   R.vector(np.array([G, N], dtype=np.int32)), R.null() if w is None else R.vector(np.asarray(w, dtype=np.float64)),
                   R.vector(np.array([pmin])), R.vector(np.array([pmax])))
 
 
-def _check_gficf(res, ref, G, N):
-    assert res.type == rmock.VECSXP and len(res) == 6
+def _check_gficf(res, ref, G, N, n_elts=6):
+    assert res.type == rmock.VECSXP and len(res) == n_elts
     oi, op, ox, keep, nt, w = (res.elt(i).numpy() for i in range(6))
     kb = ref["keep"].astype(bool)
     assert np.array_equal(keep.astype(bool), kb) and np.array_equal(nt[kb], ref["nt"][kb].astype(np.float64))   # (the oracle reports 0 for dropped genes)
@@ -181,6 +181,37 @@ def test_dot_call_gficf_entry_matches_the_oracle(R):
     res2 = _call_gficf(R, M, w=w_in, pmin=0.0, pmax=2.0)
     _check_call_hygiene(R)
     _check_gficf(res2, ref2, G, N)
+
+
+@pytest.mark.gpu
+def test_dot_call_gficf_raw_entry_returns_the_counts_of_the_kept_rows(R):
+    """`_gficf_gficf_csc_raw`: the six elements of `_gficf_gficf_csc` + the x of the kept entries — (r[[1]], r[[2]], r[[7]]) is normCounts'
+    `M[keep, ]` (reference R/gficf.R:40), what gficf(storeRaw = TRUE) keeps as $rawCounts (:22).  Explicitly stored zeros stay stored, as R's
+    subsetting keeps them.  Also with the device list from the environment (the gather then runs behind the multi-GPU finish call)."""
+    import oracle
+
+    G, N = 1200, 700
+    M = _counts(G, N)
+    M.data[::97] = 0.0                                                   # explicitly stored zeros
+    ref = oracle.gficf_csc(G, N, M.indptr.astype(np.int64), M.indices, M.data, 0.05, 1.0)
+
+    def check():
+        res = _call_gficf(R, M, entry="_gficf_gficf_csc_raw")
+        _check_call_hygiene(R)
+        _check_gficf(res, ref, G, N, n_elts=7)
+        keep = res.elt(3).numpy().astype(bool)
+        raw = sp.csc_matrix((res.elt(6).numpy(), res.elt(0).numpy(), res.elt(1).numpy()), shape=(int(keep.sum()), N))
+        want = M[np.flatnonzero(keep), :]
+        assert np.array_equal(raw.indptr, want.indptr) and np.array_equal(raw.indices, want.indices) and np.array_equal(raw.data, want.data)
+
+    check()
+    R.unload()
+    os.environ["GFICF_HIP_DEVICES"] = "0,0"
+    try:
+        check()
+    finally:
+        del os.environ["GFICF_HIP_DEVICES"]
+        R.unload()
 
 
 @pytest.mark.gpu
