@@ -461,6 +461,7 @@ def _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_m
                                                _np_ptr(rri), _np_ptr(rx)))
     keep = keep.astype(bool)
     out = sp.csc_matrix((ox, ori, ocp), shape=(gk.value, N))
+    out.has_sorted_indices = True                        # (M's are — _csc_parts — and the kept rows keep their order: spares later calls scipy's scan)
     if not raw:
         return M, keep, nt, w, out
     if M.dtype != np.float64:
