@@ -243,6 +243,8 @@ def gficf_case(case):
         assert np.array_equal(res["genes"], np.flatnonzero(keep)) and np.array_equal(res["nt"], ref["nt"][keep]), tag
         assert np.array_equal(g.indptr, ref["colptr"]) and np.array_equal(g.indices, ref["rowidx"]), tag
         assert np.abs(g.data - ref["x"]).max(initial=0.0) < 1e-12 and np.allclose(res["w"], ref["w"][keep], rtol=1e-12, atol=1e-12), tag
+        raw, want = res["rawCounts"], M[res["genes"], :]                  # $rawCounts = M[keep, ] (R/gficf.R:40,22), through the finish call
+        assert np.array_equal(raw.indptr, want.indptr) and np.array_equal(raw.indices, want.indices) and np.array_equal(raw.data, want.data), tag
         bump("gficf()")
     elif mode == 1:
         w_in = 0.25 + synth.rand_unit(case + 3, np.arange(G))
