@@ -459,10 +459,9 @@ static int kept_values(int64_t G, int64_t N, ColPtr cp, const int32_t* rowidx, c
     return lo;
   };
   // Per cell: count the kept entries first (the cell is a few KB, hot in L1 for the second sweep) and compare with the cell's slot — nothing
-  // is written for a matrix that is not the plan's — then a sweep WITHOUT a branch on the keep flag (it is taken 70 / 30 at the 5 % filter:
-  // mispredicted, it cost 3 x the loop): every entry is stored at the running position and the position moves on only for a kept one.  A
-  // dropped entry behind the cell's last kept one is thus stored one slot past the cell's — the first slot of the next cell, which the same
-  // thread fills afterwards; the last cell of a share (its neighbour is another thread's, or the end of the vector) takes the branching form.
+  // is written for a matrix that is not the plan's — then a sweep WITHOUT a branch on the keep flag (taken 70 / 30 at the 5 % filter): every
+  // entry is stored at the running position and the position moves on only for a kept one.  The sweep ends with the cell's last kept entry
+  // (d == dend: the entries behind it are all dropped), so every store lands inside the cell's own slot.
   gficf_run_shares(nt, [&](int64_t t) {
     const int64_t c0 = t == 0 ? 0 : first_cell(nnz / nt * t), c1 = t + 1 == nt ? N : first_cell(nnz / nt * (t + 1));
     const uint32_t Gu = (uint32_t)(G > 0xFFFFFFFFll ? 0xFFFFFFFFll : G);
@@ -475,24 +474,15 @@ static int kept_values(int64_t G, int64_t N, ColPtr cp, const int32_t* rowidx, c
         cnt += (int64_t)((g < Gu) & (keep[g < Gu ? g : 0] != 0));
       }
       if (cnt != dend - d) { bad.store(1); return; }
-      if (c + 1 == c1) {
-        for (int64_t q = q0; q < q1; ++q) {
-          const uint32_t g = (uint32_t)rowidx[q];
-          if (g < Gu && keep[g]) {
-            out_x[d] = x[q];
-            if (rm) out_rowidx[d] = rm[g];
-            ++d;
-          }
-        }
-      } else if (rm) {
-        for (int64_t q = q0; q < q1; ++q) {
+      if (rm) {
+        for (int64_t q = q0; q < q1 && d < dend; ++q) {
           const uint32_t g = (uint32_t)rowidx[q], gg = g < Gu ? g : 0;
           __builtin_nontemporal_store(x[q], out_x + d);
           __builtin_nontemporal_store(rm[gg], out_rowidx + d);
           d += (int64_t)((g < Gu) & (keep[gg] != 0));
         }
       } else {
-        for (int64_t q = q0; q < q1; ++q) {
+        for (int64_t q = q0; q < q1 && d < dend; ++q) {
           const uint32_t g = (uint32_t)rowidx[q], gg = g < Gu ? g : 0;
           __builtin_nontemporal_store(x[q], out_x + d);
           d += (int64_t)((g < Gu) & (keep[gg] != 0));

@@ -86,9 +86,15 @@ def test_kept_values_host_is_the_row_subset_of_the_counts():
         M.data = np.ceil(M.data * 9)
         M.data[::53] = 0.0
         if N > 10:
-            M = sp.hstack([M[:, :5], sp.csc_matrix((G, 3)), M[:, 5:]], format="csc")      # three empty cells
+            M = sp.hstack([M[:, :5], sp.csc_matrix((G, 3)), M[:, 5:], sp.csc_matrix((G, 2))], format="csc")      # empty cells, the last two included
         G, N = M.shape
         keep = (rng.random(G) < 0.6).astype(np.uint8)
+        if N > 10:                                        # ... and cells that hold dropped genes only: the last stored ones, one in the middle
+            M = M.tolil()
+            for c in (N - 4, N - 3, 7):
+                M[:, c] = 0
+                M[np.flatnonzero(keep == 0)[:3], c] = 2.0
+            M = M.tocsc()
         want = M[np.flatnonzero(keep), :]
         cp, ri, x = M.indptr.astype(pt), M.indices.astype(np.int32), np.ascontiguousarray(M.data)
         kcp = want.indptr.astype(pt)
@@ -99,9 +105,15 @@ def test_kept_values_host_is_the_row_subset_of_the_counts():
                                               oi.ctypes.data if with_ids else None, ox.ctypes.data)
             assert rc == 0, L.gficf_last_error()
             assert np.array_equal(ox, want.data) and (not with_ids or np.array_equal(oi, want.indices))
+        none = np.zeros(G, dtype=np.uint8)                # nothing kept: nothing is written (the output vector may be empty)
+        zcp = np.zeros(N + 1, dtype=pt)
+        guard = np.full(4, 7.0)
+        assert L.gficf_csc_kept_values_host(G, N, cp.ctypes.data, int(pt is np.int64), ri.ctypes.data, x.ctypes.data, none.ctypes.data, zcp.ctypes.data, None, guard.ctypes.data) == 0
+        assert (guard == 7.0).all()
         if want.nnz:
-            bad = kcp.copy()
-            bad[-1] -= 1
+            bad = kcp.copy()                              # still monotone, but one cell's slot is an entry short (its neighbour's one too long)
+            d = np.diff(kcp)
+            bad[1 + int(np.flatnonzero(d > 0)[0])] -= 1
             ox = np.zeros(want.nnz)
             rc = L.gficf_csc_kept_values_host(G, N, cp.ctypes.data, int(pt is np.int64), ri.ctypes.data, x.ctypes.data, keep.ctypes.data, bad.ctypes.data, None, ox.ctypes.data)
             assert _lib.STATUS_NAMES[rc] == "GFICF_ERR_BAD_CSC"

@@ -75,17 +75,23 @@ def test_raw_counts_come_back_with_the_result_and_are_the_row_subset():
     cp, ri, x = synth.counts_csc(G, N, median_frac=0.2, seed=11)
     assert len(x) > 6_000_000                                            # (three shares of host threads and more)
     x[::101] = 0.0
+    # three more cells at the end that hold nothing but a gene of their own (dropped: one cell each) — the kept rows have nothing in the LAST cells
+    # (the first version of the gather stored one slot past such a tail: tools/fuzz_gpu.py found it)
+    tail = sp.csc_matrix((np.full(3, 2.0), (np.arange(G, G + 3), np.arange(3))), shape=(G + 3, 3))
     for dt in (np.float64, np.int32):
-        M = sp.csc_matrix((x.astype(dt), ri, cp), shape=(G, N))
+        M = sp.hstack([sp.vstack([sp.csc_matrix((x.astype(dt), ri, cp), shape=(G, N)), sp.csc_matrix((3, N), dtype=dt)], format="csc"), tail.astype(dt)], format="csc")
         res = gficf_amd.gficf(M, normalize=False, verbose=False)
+        assert res["genes"].max() < G and np.diff(res["gficf"].indptr)[-3:].tolist() == [0, 0, 0]
         raw, want = res["rawCounts"], M[res["genes"], :]
         assert raw.dtype == dt and raw.shape == want.shape
         assert np.array_equal(raw.indptr, want.indptr) and np.array_equal(raw.indices, want.indices) and np.array_equal(raw.data, want.data)
         assert np.array_equal(raw.indices, res["gficf"].indices) and not np.shares_memory(raw.indices, res["gficf"].indices)
         assert not np.shares_memory(raw.indptr, res["gficf"].indptr)
-    ref = oracle.gficf_csc(G, N, cp, ri, x, 0.05, 1.0)
-    check_against_oracle(res, ref, N)
+    ref = oracle.gficf_csc(G + 3, N + 3, M.indptr.astype(np.int64), M.indices, M.data.astype(np.float64), 0.05, 1.0)
+    check_against_oracle(res, ref, N + 3)
     assert gficf_amd.gficf(M, normalize=False, verbose=False, storeRaw=False).get("rawCounts") is None
+    M = sp.csc_matrix((x, ri, cp), shape=(G, N))
+    want = M[gficf_amd.gficf(M, normalize=False, verbose=False, storeRaw=False)["genes"], :]
     # another matrix at the finish call: the kept entries of some cell do not match the plan's count
     L, ctx = _lib.load(), gficf_amd.default_context()
     gk, nk = ctypes.c_int64(0), ctypes.c_int64(0)

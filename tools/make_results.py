@@ -243,6 +243,8 @@ def main():
                   ha["bytes_in"] / 1e9, ha["bytes_out"] / 1e9, ha["ms_per_call"], ha["ms_plan"], ha["ms_finish"], ha["cells_per_sec"] / 1e6,
                   "<= 1e-6 vs oracle" if ha.get("checked_vs_oracle") else "not checked"))
         verbatim(f"{TAG}_host_gficf_malloc_ab.txt", "The same entry with the result vectors from plain `malloc`, as R allocates them (`tools/host_gficf_malloc_ab.py`)")
+        verbatim(f"{TAG}_host_gficf_raw_ab.txt", "`gficf(storeRaw = TRUE)`: `$rawCounts` = `M[keep, ]` (R/gficf.R:40,22) comes back with the result — its values gathered by host threads "
+                 "inside the finish call (`gficf_normalize_csc_host_finish_raw`, `tools/host_gficf_raw_ab.py`; 59.9 M stored entries)")
         w("\nstored entries {:.1f} M, kept {:.1f} M in {} genes; PMC traffic {} of the algorithmic bytes.  `t(gficf)` {} ms, cluster sums {} ms.\n\n".format(
             g["nnz"] / 1e6, g["kept_nnz"] / 1e6, g["kept_genes"], fmt(rf.get("traffic") and rf["traffic"] / rf["algorithmic_bytes_per_pass"], "{:.2f} x"),
             (g.get("transpose") or {}).get("ms", "-"), (g.get("cluster_signatures") or {}).get("ms", "-")))
