@@ -489,6 +489,7 @@ static int kept_values(int64_t G, int64_t N, ColPtr cp, const int32_t* rowidx, c
         }
       }
     }
+    std::atomic_thread_fence(std::memory_order_seq_cst);      // the non-temporal stores are out before the share is reported done
   });
   return bad.load() ? GFICF_ERR_BAD_CSC : GFICF_OK;
 }
