@@ -433,7 +433,7 @@ struct ColPtr {
 static int kept_values(int64_t G, int64_t N, ColPtr cp, const int32_t* rowidx, const double* x, const uint8_t* keep, ColPtr kcp,
                        int32_t* out_rowidx, double* out_x) {
   const int64_t nnz = N > 0 ? cp[N] : 0, nk = N > 0 ? kcp[N] : 0;
-  if (nnz <= 0) return nk == 0 ? GFICF_OK : GFICF_ERR_BAD_CSC;
+  if (nnz <= 0 || G <= 0) return nk == 0 ? GFICF_OK : GFICF_ERR_BAD_CSC;      // (no gene: nothing is kept, and keep[] has no element to read)
   std::vector<int32_t> remap;
   if (out_rowidx) {
     remap.resize((size_t)G);

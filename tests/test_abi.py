@@ -81,7 +81,7 @@ def test_kept_values_host_is_the_row_subset_of_the_counts():
 
     L = _lib.load()
     rng = np.random.default_rng(5)
-    for G, N, dens, pt in ((50, 40, 0.3, np.int32), (3000, 9000, 0.2, np.int64), (1, 1, 1.0, np.int32), (7, 0, 0.5, np.int32)):
+    for G, N, dens, pt in ((50, 40, 0.3, np.int32), (3000, 9000, 0.2, np.int64), (1, 1, 1.0, np.int32), (7, 0, 0.5, np.int32), (0, 5, 0.5, np.int32)):
         M = sp.random(G, N, density=dens, format="csc", random_state=rng, dtype=np.float64)
         M.data = np.ceil(M.data * 9)
         M.data[::53] = 0.0
