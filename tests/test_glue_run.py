@@ -40,6 +40,8 @@ def test_glue_registers_its_routines_by_name_and_arity(R):
 def test_torture_collector_catches_a_missing_protect(R):
     R.L.rmock_selftest_missing_protect.restype = int
     assert R.L.rmock_selftest_missing_protect() == 1
+    R.L.rmock_reset()                                    # (the self-test's dead object and its count do not stay for the tests that follow in this process)
+    assert R.L.rmock_dead_touched() == 0
 
 
 def test_argument_checks_reach_rf_error(R):
