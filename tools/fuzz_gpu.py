@@ -285,7 +285,36 @@ def gficf_case(case):
 def next_rows_case(case):
     """The rows either side of the path: exact kNN against the f32 oracle, adjacency against scipy,
     cluster signatures and the transpose against numpy / scipy restatements."""
-    which = int(rng.integers(0, 4))
+    which = int(rng.integers(0, 5))
+    if which == 4:
+        # the chain of clustcells() (R/clustCells.R:57-86) two ways: step by step through the host entries (search, Jaccard + filter, adjacency,
+        # Louvain) and fused on the device in one call (gficf_phenograph_host) — the same labels, cluster count, edge count and modularity; the
+        # modularity the optimiser reports equal to the graph's modularity of its own labels, computed here in float64
+        N = int(rng.integers(40, 4000)); d = int(rng.choice([2, 3, 10, 50])); k = int(min(N - 2, rng.choice([5, 15, 30, 33, 50])))
+        metric = str(rng.choice(["manhattan", "euclidean", "cosine"]))
+        res, algo, seed = float(rng.choice([0.5, 0.8, 1.0, 1.5])), int(rng.choice([1, 2])), int(rng.integers(0, 2**31 - 1))
+        r2 = np.random.default_rng(case)
+        C = int(rng.integers(1, 12))
+        c = r2.normal(scale=5.0, size=(C, d)); lab = r2.integers(0, C, size=N)
+        X = c[lab] + r2.normal(size=(N, d))
+        tag = f"phenograph case {case}: N={N} d={d} k={k} {metric} resolution={res} algorithm={algo} seed={seed}"
+        edges = gficf_amd.clustcells_graph(X, k, metric)
+        A = gficf_amd.jaccard_adjacency(edges, N)
+        step = gficf_amd.run_modularity_clustering(A, 1, res, algo, 3, 10, seed, False)
+        fused = gficf_amd.phenograph(X, k, metric, res, algo, 3, 10, seed)
+        assert np.array_equal(np.asarray(step), np.asarray(fused)), tag
+        assert step.n_clusters == fused.n_clusters and fused.n_edges == len(edges["weight"]) and abs(step.modularity - fused.modularity) < 1e-12, tag
+        co = A.tocoo()
+        off = co.row != co.col                                           # (the optimiser ignores the diagonal)
+        row, col, val = co.row[off], co.col[off], co.data[off]
+        m2 = val.sum()                                                   # = 2 m
+        deg = np.bincount(row, weights=val, minlength=N)
+        labs = np.asarray(fused)
+        inside = val[labs[row] == labs[col]].sum()
+        q = inside / m2 - res * float((np.bincount(labs, weights=deg) ** 2).sum()) / (m2 * m2) if m2 > 0 else 0.0
+        assert abs(q - fused.modularity) < 1e-6, (tag, q, fused.modularity)
+        bump("phenograph fused against the chain step by step (N1, N2, N4)")
+        return
     if which == 0:
         from oracle import oracle_np  # noqa: F401  (restatements live next to the oracle)
 
