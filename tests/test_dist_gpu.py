@@ -139,7 +139,7 @@ def test_plain_bench_command_starts_its_own_ranks():
     for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(v, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1",
-                        "--no-extras", "--cells-per-gpu", "20000"], capture_output=True, text=True, timeout=280, env=env)
+                        "--no-extras", "--cells-per-gpu", "8000"], capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     # N > 1 (round 5): the line is printed as soon as `value` exists and again, cumulative, after every further leg — every line a
@@ -150,9 +150,9 @@ def test_plain_bench_command_starts_its_own_ranks():
     out = recs[-1]
     assert out["skipped_legs"] == [] and out["leg_seconds"]["value"] > 0 and out["budget_s"] == 420.0
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["metric"] == "jaccard_edges_per_sec" and out["value"] > 0
-    assert out["config"]["cells_total"] == 40000
+    assert out["config"]["cells_total"] == 16000
     ex = out["exchange"]
-    assert ex["rows_received_per_rank_per_data_set"] == 20000 and ex["bytes_received_per_rank_per_data_set"] > 0
+    assert ex["rows_received_per_rank_per_data_set"] == 8000 and ex["bytes_received_per_rank_per_data_set"] > 0
     assert ex["backend"] == "gloo" and "backend_note" not in ex           # (a rehearsal asks for gloo; a FALLBACK to it would carry the note)
 
 
@@ -302,15 +302,15 @@ def test_plain_multi_gpu_bench_line_carries_the_whole_scaling_answer():
     for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(v, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1",
-                        "--cells-per-gpu", "20000", "--no-gficf", "--no-chain"], capture_output=True, text=True, timeout=580, env=env)
+                        "--cells-per-gpu", "8000", "--no-gficf", "--no-chain"], capture_output=True, text=True, timeout=580, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
-    assert out["n_gpus"] == 2 and out["checked_vs_oracle"] is True and out["config"]["cells_total"] == 40000
+    assert out["n_gpus"] == 2 and out["checked_vs_oracle"] is True and out["config"]["cells_total"] == 16000
     assert out["pipelined"]["edges_per_sec"] > 0
     sp = out["spatial_ids"]
     assert sp["exchange"] == "halo" and 0 < sp["rows_named_outside"] <= 400 and sp["checked_vs_oracle"] is True
     assert sp["in_order"]["edges_per_sec"] > 0 and sp["overlapped"]["edges_per_sec"] > 0
-    assert out["single_gpu_step"]["cells"] == 20000 and out["single_gpu_step"]["edges_per_sec"] > 0
+    assert out["single_gpu_step"]["cells"] == 8000 and out["single_gpu_step"]["edges_per_sec"] > 0
     pe = out["peer"]
     assert "error" not in pe, pe
     assert pe["checked_vs_oracle"] is True and pe["devices"] == [0, 0] and pe["edges_per_sec"] > 0

@@ -261,17 +261,16 @@ def test_full_size_properties_1M_cells(ops):
     assert np.array_equal(dst, np.where(pos, mat.reshape(-1).astype(np.float64), 0.0))
     assert np.array_equal(w, np.where(pos, u / (2.0 * k - u), 0.0))
     assert u.min() >= 0 and u.max() <= k
-    # symmetry: whenever j is in row i and i is in row j, u(i->j) == u(j->i)
-    ii = np.repeat(np.arange(N, dtype=np.int64), k)
-    jj = mat.reshape(-1).astype(np.int64) - 1
-    key_f = ii * N + jj
-    key_b = jj * N + ii
-    order = np.argsort(key_f)
-    pos_b = np.searchsorted(key_f[order], key_b)
-    pos_b = np.minimum(pos_b, E - 1)
-    mutual = key_f[order][pos_b] == key_b
+    # symmetry: whenever j is in row i and i is in row j, u(i->j) == u(j->i) — on every 10th edge (3 M of them; the first version sorted
+    # all 30 M edge keys on the host, a third of this test's 37 s)
+    e = np.arange(0, E, 10, dtype=np.int64)
+    ii, slot = e // k, e % k
+    jj = mat.reshape(-1)[e].astype(np.int64) - 1
+    back = mat[jj] == (ii + 1)[:, None]                      # where row j names i
+    mutual = back.any(axis=1)
     assert mutual.mean() > 0.1
-    assert np.array_equal(u[mutual], u[order][pos_b][mutual])
+    u2 = u.reshape(N, k)
+    assert np.array_equal(u2[ii[mutual], slot[mutual]], u2[jj[mutual], back[mutual].argmax(axis=1)])
     # a 20 k-cell sample of source cells against the oracle's counting rule (numpy restatement)
     sample = np.arange(0, N, 50)[:2000]
     rows = mat[sample]
