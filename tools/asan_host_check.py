@@ -65,6 +65,15 @@ while time.time() - t0 < budget:
                                       oi.ctypes.data if with_ids else None, ox.ctypes.data)
     assert rc == 0, L.gficf_last_error()
     assert np.array_equal(ox, want.data) and (not with_ids or np.array_equal(oi, want.indices)), (G, N)
+    if want.nnz and N > 1 and rng.random() < 0.5:           # a column pointer that is not M[keep, ]'s: refused, and nothing is stored outside the vector
+        bad = kcp.copy()
+        c = int(rng.integers(1, N + 1))
+        bad[c:] += pt(rng.choice([-1, 1]))
+        bad = np.maximum.accumulate(np.clip(bad, 0, None))
+        if not np.array_equal(bad, kcp):
+            ox2 = np.full(max(int(bad[-1]), 0), np.nan)
+            rc = L.gficf_csc_kept_values_host(G, N, cp.ctypes.data, int(pt is np.int64), ri.ctypes.data, x.ctypes.data, keep.ctypes.data, bad.ctypes.data, None, ox2.ctypes.data)
+            assert rc != 0
     n_kv += 1
     # ---- compact Jaccard return -> the (N k) x 3 matrix
     N, k = int(rng.integers(1, 3000)), int(rng.integers(1, 70))
