@@ -471,6 +471,16 @@ def _normalize_csc_host_run(L, ctx, M, colptr, rowidx, x, G, N, prop_min, prop_m
     return M, keep, nt, w, out, rawm
 
 
+def tsmessage(*parts, verbose: bool = True, time_stamp: bool = True) -> None:
+    """``tsmessage(..., verbose, time_stamp)`` of the reference (R/util.R:30-39): a line on stderr (R's ``message``) behind a
+    ``%H:%M:%S`` stamp, nothing when ``verbose`` is false."""
+    if verbose:
+        import sys
+        import time
+
+        print((time.strftime("%H:%M:%S") + " " if time_stamp else "") + "".join(str(p) for p in parts), file=sys.stderr, flush=True)
+
+
 def gficf(M, cell_proportion_max: float = 1, cell_proportion_min: float = 0.05, storeRaw: bool = True,
           normalize: bool = True, verbose: bool = True, ctx: Context | None = None, *, icf_type: str = "classic",
           norm: str = "l2", devices=None) -> dict:
@@ -493,6 +503,10 @@ def gficf(M, cell_proportion_max: float = 1, cell_proportion_min: float = 0.05, 
     if verbose and normalize:
         warnings.warn("normalize=True: the edgeR CPM/TMM rescale (reference R/gficf.R:43-47) is a per-cell scale "
                       "that cancels in the GF step; rawCounts holds unscaled counts", stacklevel=2)
+    # the reference's progress lines (tsmessage: R/gficf.R:58,87,68,99 via R/util.R:30-39; "Normalize counts.." :45 belongs to the
+    # edgeR step, which does not run here), same text, on stderr like R's message(); the four steps are ONE device call
+    for line in ("Apply GF transformation..", "Compute ICF weigth..", "Applay ICF..", f"Apply {norm}"):
+        tsmessage(line, verbose=verbose)
     res = _normalize_csc_host(M, cell_proportion_min, cell_proportion_max, None, ctx, icf_type, norm, devices, raw=storeRaw)
     M, keep, nt, w, out = res[:5]
     data = {"gficf": out}
@@ -734,8 +748,7 @@ def clustcells(data: dict, from_embedded: bool = False, k: int = 15, dist_method
         data["cell.graph"], data["cell.adjacency"] = edges, A
     if data.get("gficf") is not None:
         data["cluster.gene.rnk"], data["cluster.labels"] = cluster_signatures(data["gficf"], data["cluster"], ctx)
-    if verbose:
-        print(f"Detected Clusters: {community.n_clusters}")
+    tsmessage(f"Detected Clusters: {community.n_clusters}", verbose=verbose)       # reference R/clustCells.R:125
     return data
 
 

@@ -1,9 +1,33 @@
 # gficf_hip.R — R side of the drop-in (replaces the bodies of tf/getIdfW/idf/l.norm in gficf();
 # reference R/gficf.R:17-33).  Signature, defaults and the returned list fields are unchanged.
+
+# The R stubs of the two replaced entries.  In the reference they are generated into R/RcppExports.R:8-10,16-18 from the `// [[Rcpp::export]]`
+# tags of src/jaccard_coeff.cpp and src/rcpp_parallel_jaccard_coeff.cpp; those files are deleted, compileAttributes() stops generating
+# the stubs, and clustcells() (R/clustCells.R:65) still calls the second — so they live here, with the same names and arguments.
+rcpp_parallel_jaccard_coef <- function(mat, printOutput) .Call(`_gficf_rcpp_parallel_jaccard_coef`, mat, printOutput)
+jaccard_coeff <- function(idx, printOutput) .Call(`_gficf_jaccard_coeff`, idx, printOutput)
+
+# A dgCMatrix whatever sparse or dense class came in: `as(M, "CsparseMatrix")` alone keeps a pattern matrix (ngCMatrix: no @x slot at all)
+# or a logical / integer one (lgCMatrix, igCMatrix: @x of another type) as it is, and the entry reads @x as double.  The three-step
+# coercion is the one Matrix >= 1.5 asks for in place of the deprecated as(M, "dgCMatrix"); symmetric / triangular inputs become general.
+as_dgCMatrix_hip = function(M)
+{
+  if (!inherits(M, "dgCMatrix")) M = methods::as(methods::as(methods::as(M, "dMatrix"), "generalMatrix"), "CsparseMatrix")
+  M
+}
+
 gficf = function(M, cell_proportion_max = 1, cell_proportion_min = 0.05, storeRaw = TRUE, normalize = TRUE, verbose = TRUE)
 {
   data = list()
-  M = methods::as(M, "CsparseMatrix")
+  M = as_dgCMatrix_hip(M)
+  # The reference's five progress lines (tsmessage, R/util.R:30-39), same text: "Normalize counts.." R/gficf.R:45 (only when normalize),
+  # "Apply GF transformation.." :58, "Compute ICF weigth.." :87, "Applay ICF.." :68, "Apply l2" :99.  The four GF-ICF steps are ONE device
+  # call here, so their lines precede it together; "Normalize counts.." is printed where the edgeR call actually runs (after the call:
+  # it needs the filtered matrix, and only $rawCounts is affected) — the one line that moves relative to the reference's log.
+  tsmessage("Apply GF transformation..", verbose = verbose)
+  tsmessage("Compute ICF weigth..", verbose = verbose)
+  tsmessage("Applay ICF..", verbose = verbose)
+  tsmessage(paste("Apply", "l2"), verbose = verbose)
   r = if (storeRaw) .Call(`_gficf_gficf_csc_raw`, M@i, M@p, M@x, M@Dim, NULL, cell_proportion_min, cell_proportion_max)
       else .Call(`_gficf_gficf_csc`, M@i, M@p, M@x, M@Dim, NULL, cell_proportion_min, cell_proportion_max)
   keep = as.logical(r[[4]])
@@ -15,7 +39,10 @@ gficf = function(M, cell_proportion_max = 1, cell_proportion_min = 0.05, storeRa
     raw = Matrix::sparseMatrix(i = r[[1]], p = r[[2]], x = r[[7]], index1 = FALSE, dims = c(sum(keep), ncol(M)), dimnames = dn)
     # the edgeR branch (reference R/gficf.R:43-47) only rescales what is stored here: a per-cell scale
     # cancels in x/colSums(x), so $gficf is the same with or without it
-    if (normalize) raw = Matrix::Matrix(edgeR::cpm(edgeR::calcNormFactors(edgeR::DGEList(counts = raw))), sparse = TRUE)
+    if (normalize) {
+      tsmessage("Normalize counts..", verbose = verbose)
+      raw = Matrix::Matrix(edgeR::cpm(edgeR::calcNormFactors(edgeR::DGEList(counts = raw), normalized.lib.sizes = T)), sparse = TRUE)
+    }
     data$rawCounts = raw
   }
   data$w = stats::setNames(r[[6]][keep], rownames(M)[keep])
@@ -24,7 +51,7 @@ gficf = function(M, cell_proportion_max = 1, cell_proportion_min = 0.05, storeRa
 }
 
 # embedNewCells() keeps its name matching (reference R/gficf.R:69-78) in R and calls
-#   .Call(`_gficf_gficf_csc`, x@i, x@p, x@x, x@Dim, as.numeric(data$w[rownames(x)]), 0, 2)
+#   x = as_dgCMatrix_hip(x); .Call(`_gficf_gficf_csc`, x@i, x@p, x@x, x@Dim, as.numeric(data$w[rownames(x)]), 0, 2)
 # in place of tf() / idf() / l.norm() (reference R/cellClassifier.R:50-53).
 
 # Optional ("next" row N2): exact neighbour search for clustcells().  Replaces the two lines
@@ -60,6 +87,7 @@ jaccard_adjacency_hip = function(relations, n)
 cluster_signatures_hip = function(M, cluster.map)
 {
   u = base::unique(cluster.map)
+  M = as_dgCMatrix_hip(M)
   r = .Call(`_gficf_cluster_signatures`, M@i, M@p, M@x, M@Dim, match(cluster.map, u) - 1L, length(u))
   rownames(r) = rownames(M)
   colnames(r) = u          # sapply(u, ...) names the columns by cluster label (reference R/clustCells.R:122-123)
@@ -72,6 +100,7 @@ cluster_signatures_hip = function(M, cluster.map)
 #   data$pca$cells = transpose_hip(data$gficf)
 transpose_hip = function(M)
 {
+  M = as_dgCMatrix_hip(M)
   r = .Call(`_gficf_transpose_csc`, M@i, M@p, M@x, M@Dim)
   Matrix::sparseMatrix(i = r[[1]], p = r[[2]], x = r[[3]], index1 = FALSE, dims = rev(M@Dim), dimnames = rev(M@Dimnames))
 }
@@ -86,7 +115,7 @@ transpose_hip = function(M)
 RunModularityClusteringHip <- function(SNN = matrix(), modularity = 1, resolution = 0.8, algorithm = 1, n.start = 10, n.iter = 10,
                                        random.seed = 0, print.output = TRUE, temp.file.location = NULL, edge.file.name = "")
 {
-  SNN = methods::as(SNN, "CsparseMatrix")
+  SNN = as_dgCMatrix_hip(SNN)
   .Call(`_gficf_RunModularityClusteringHip`, SNN, as.integer(modularity), resolution, as.integer(algorithm), as.integer(n.start),
         as.integer(n.iter), as.integer(random.seed), print.output, edge.file.name)
 }

@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 MOCK = os.path.join(ROOT, "tests", "r_mock")
 SO = os.path.join(MOCK, "libgficf_glue_mock.so")
-SOURCES = [os.path.join(ROOT, "integration", "gficf_hip_glue.c"), os.path.join(MOCK, "r_runtime.c")]
+SOURCES = [os.path.join(ROOT, "integration", "gficf_hip_glue.c"), os.path.join(MOCK, "r_runtime.c"), os.path.join(MOCK, "package_rows.c")]
 HEADERS = [os.path.join(MOCK, "R.h"), os.path.join(MOCK, "Rinternals.h"), os.path.join(MOCK, "R_ext", "Rdynload.h"),
            os.path.join(ROOT, "include", "gficf_hip.h")]
 
@@ -97,6 +97,8 @@ class RMock:
             ("rmock_error_message", cs, []), ("rmock_printed", cs, []), ("rmock_driver_message", cs, []),
             ("rmock_protect_depth", ci, []), ("rmock_protect_max", ci, []), ("rmock_collected", cl, []),
             ("rmock_dead_touched", cl, []), ("rmock_allocations", cl, []),
+            ("rmock_use_dynamic_symbols", ci, []), ("rmock_n_registrations", ci, []), ("rmock_fail_allocation_after", None, [cl]),
+            ("rmock_selftest_second_registration_replaces", ci, []),
             ("rmock_call", ci, [cs, ci, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ci)]),
         ]:
             f = getattr(L, name)

@@ -12,7 +12,13 @@
  *     the glue's PROTECT discipline;
  *   * Rf_error: formats the message and longjmps back to the `.Call` trampoline (the protect stack is reset there, as R's
  *     context unwinding does); Rprintf: captured; R_alloc: released when the call ends;
- *   * R_registerRoutines: records the table; rmock_call() looks an entry up by name, checks the arity and calls it.
+ *   * R_registerRoutines: a DllInfo owns a COPY of the `.Call` table handed in, and a second call on the same DllInfo
+ *     REPLACES it (R's src/main/Rdynload.c: R_registerRoutines allocates a new CallSymbols array and overwrites numCallSymbols —
+ *     it does not append); R_useDynamicSymbols is recorded.  rmock_call() looks an entry up by name, checks the arity, calls it.
+ *   * allocation failure on request (rmock_fail_allocation_after): the n-th allocation from now raises the R error R raises when
+ *     memory runs out ("cannot allocate vector of size"), to test what a call leaves behind when it unwinds half-way.
+ * The package's init function R_init_gficf (the glue defines it) is what rmock_init() runs, with stand-ins for the three Rcpp
+ * wrappers that stay in the package (tests/r_mock/package_rows.c).
  * The Python side (tests/test_glue_run.py) builds arguments with rmock_new_* and reads results with rmock_* accessors. */
 #include <setjmp.h>
 #include <stdarg.h>
@@ -60,8 +66,10 @@ static char print_buf[8192];
 static size_t print_len = 0;
 static void* ralloc_list[256];
 static int n_ralloc = 0;
-static const R_CallMethodDef* call_table = NULL;
-static int use_dynamic_symbols = -1;
+struct _DllInfo { R_CallMethodDef* call_symbols; int n_call_symbols; int use_dynamic_symbols; int n_registrations; };
+static struct _DllInfo the_dll = {NULL, 0, -1, 0};
+#define call_table (the_dll.call_symbols)
+static long fail_alloc_in = 0;     /* > 0: the allocation that brings it to 0 fails */
 static char driver_msg[512];
 
 static size_t elt_size(int type) {
@@ -105,6 +113,7 @@ static void collect(void) {
 }
 
 static SEXP new_obj(int type, R_xlen_t len) {
+  if (in_call && fail_alloc_in > 0 && --fail_alloc_in == 0) Rf_error("cannot allocate vector of size %.1f Mb", (double)len * (double)elt_size(type) / 1048576.0);
   collect();
   SEXP s = (SEXP)calloc(1, sizeof(struct SEXPREC));
   s->type = type;
@@ -261,21 +270,57 @@ void Rf_error(const char* fmt, ...) {
 }
 int R_registerRoutines(DllInfo* dll, const R_CMethodDef* c, const R_CallMethodDef* call, const R_FortranMethodDef* f,
                        const R_ExternalMethodDef* e) {
-  (void)dll; (void)c; (void)f; (void)e;
-  call_table = call;
+  (void)c; (void)f; (void)e;
+  if (!dll) return 0;
+  int n = 0;
+  while (call && call[n].name) ++n;
+  /* a NEW array replaces whatever was registered before (what R does; the old one is simply dropped there) */
+  R_CallMethodDef* t = (R_CallMethodDef*)calloc((size_t)n + 1, sizeof(*t));
+  for (int i = 0; i < n; ++i) t[i] = call[i];
+  free(dll->call_symbols);
+  dll->call_symbols = t;
+  dll->n_call_symbols = n;
+  ++dll->n_registrations;
   return 1;
 }
-int R_useDynamicSymbols(DllInfo* dll, int v) { (void)dll; use_dynamic_symbols = v; return 1; }
+int R_useDynamicSymbols(DllInfo* dll, int v) {
+  if (!dll) return 0;
+  const int old = dll->use_dynamic_symbols;
+  dll->use_dynamic_symbols = v;
+  return old;
+}
 
 /* --------------------------------------------------------------------------------------------- the test driver's side */
-void gficf_hip_register(DllInfo* dll);        /* the glue's registration hook */
+void R_init_gficf(DllInfo* dll);              /* the package's init function: defined by the glue */
 void R_unload_gficf(DllInfo* dll);
 
+/* what dyn.load() + the package's init do: the DLL's own R_init_<pkg> runs once on a fresh DllInfo */
 void rmock_init(void) {
   if (!R_DimSymbol) { R_DimSymbol = Rf_install("dim"); R_NamesSymbol = Rf_install("names"); }
-  gficf_hip_register(NULL);
+  free(the_dll.call_symbols);
+  the_dll.call_symbols = NULL; the_dll.n_call_symbols = 0; the_dll.use_dynamic_symbols = -1; the_dll.n_registrations = 0;
+  R_init_gficf(&the_dll);
 }
-void rmock_unload(void) { R_unload_gficf(NULL); }
+void rmock_unload(void) { R_unload_gficf(&the_dll); }
+int rmock_use_dynamic_symbols(void) { return the_dll.use_dynamic_symbols; }
+int rmock_n_registrations(void) { return the_dll.n_registrations; }
+void rmock_fail_allocation_after(long n) { fail_alloc_in = n; }
+
+/* Self-test of the replace semantics: on a scratch DllInfo, registering table A (2 rows) and then table B (1 row) leaves B alone —
+ * the recipe "call R_registerRoutines once more next to Rcpp's" loses a table.  Returns the number of rows that resolve at the end
+ * (1), or -1 when a row of A still does. */
+static SEXP selftest_fn(void) { return R_NilValue; }
+int rmock_selftest_second_registration_replaces(void) {
+  struct _DllInfo d = {NULL, 0, -1, 0};
+  const R_CallMethodDef A[] = {{"a1", (DL_FUNC)&selftest_fn, 0}, {"a2", (DL_FUNC)&selftest_fn, 0}, {NULL, NULL, 0}};
+  const R_CallMethodDef B[] = {{"b1", (DL_FUNC)&selftest_fn, 0}, {NULL, NULL, 0}};
+  R_registerRoutines(&d, NULL, A, NULL, NULL);
+  R_registerRoutines(&d, NULL, B, NULL, NULL);
+  int n = 0, a_left = 0;
+  for (int i = 0; i < d.n_call_symbols; ++i) { ++n; a_left |= d.call_symbols[i].name[0] == 'a'; }
+  free(d.call_symbols);
+  return a_left ? -1 : n;
+}
 void rmock_set_torture(int on) { torture = on; }
 int rmock_n_routines(void) {
   int n = 0;

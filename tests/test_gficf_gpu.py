@@ -61,6 +61,22 @@ def test_matches_oracle(G, N, mn, mx, seed):
     assert (res["rawCounts"] != M[res["genes"], :]).nnz == 0
 
 
+def test_verbose_prints_the_reference_progress_lines(capsys):
+    """gficf(verbose = TRUE) prints the reference's tsmessage lines (R/gficf.R:58,87,68,99 through R/util.R:30-39: a %T stamp, then the text,
+    on stderr like R's message()); verbose = FALSE prints nothing."""
+    import re
+
+    cp, ri, x = synth.counts_csc(300, 200, seed=1)
+    M = sp.csc_matrix((x, ri, cp), shape=(300, 200))
+    gficf_amd.gficf(M, normalize=False, verbose=True)
+    err = capsys.readouterr().err.splitlines()
+    assert [re.sub(r"^\d\d:\d\d:\d\d ", "", ln) for ln in err] == ["Apply GF transformation..", "Compute ICF weigth..", "Applay ICF..", "Apply l2"]
+    assert all(re.match(r"^\d\d:\d\d:\d\d ", ln) for ln in err)
+    gficf_amd.gficf(M, normalize=False, verbose=False)
+    cap = capsys.readouterr()
+    assert cap.err == "" and cap.out == ""
+
+
 def test_raw_counts_come_back_with_the_result_and_are_the_row_subset():
     """gficf(storeRaw=True): $rawCounts = normCounts' M[keep, ] (reference R/gficf.R:40,22) comes from the finish call itself
     (gficf_normalize_csc_host_finish_raw: the result's structure, the counts gathered by host threads while the result crosses PCIe) — equal to

@@ -26,7 +26,17 @@ def test_registration_table_matches_the_entry_points():
     defs = {m.group(1): len([a for a in m.group(2).split(",") if a.strip()])
             for m in re.finditer(r"^SEXP (_gficf_\w+)\(([^)]*)\)\s*\{", src, re.M)}
     table = {m.group(1): int(m.group(2)) for m in re.finditer(r'\{"(_gficf_\w+)", \(DL_FUNC\)&\1, (\d+)\}', src)}
-    assert table == defs and len(table) >= 9
+    # the three Rcpp wrappers that stay in the package are rows of the ONE table too, declared extern (not defined) in the glue with
+    # the arity of the reference's own table (src/RcppExports.cpp:86,88,90)
+    package = {"_gficf_RunModularityClusteringCpp": 9, "_gficf_rcpp_WMU_test": 3, "_gficf_rcpp_parallel_WMU_test": 3}
+    for name, n in package.items():
+        assert table.pop(name) == n and name not in defs
+        ext = re.search(r"^extern SEXP " + name + r"\(([^)]*)\);", src, re.M)
+        assert ext and len(ext.group(1).split(",")) == n
+    assert table == defs and len(table) == 10
+    assert int(re.search(r"#define GFICF_HIP_N_ROWS (\d+)", src).group(1)) == len(table)
+    # exactly one R_registerRoutines call in the file, inside gficf_hip_register, followed by R_useDynamicSymbols(dll, FALSE) (:95-96)
+    assert len(re.findall(r"^\s*R_registerRoutines\(", src, re.M)) == 1 and "R_useDynamicSymbols(dll, FALSE);" in src
     # the entry that replaces the reference's keeps its name and arity (src/RcppExports.cpp:61,89)
     assert table["_gficf_rcpp_parallel_jaccard_coef"] == 2 and table["_gficf_jaccard_coeff"] == 2
     # the (N*k) x 3 allocation is range-checked, never a bare (int)(N * k)

@@ -30,11 +30,81 @@ def test_glue_registers_its_routines_by_name_and_arity(R):
     tab = R.routines()
     # the two entries that REPLACE reference entries keep name and arity (src/RcppExports.cpp:87,89)
     assert tab["_gficf_rcpp_parallel_jaccard_coef"] == 2 and tab["_gficf_jaccard_coeff"] == 2
-    assert tab["_gficf_gficf_csc"] == 7 and tab["_gficf_gficf_csc_raw"] == 7 and len(tab) == 10
+    assert tab["_gficf_gficf_csc"] == 7 and tab["_gficf_gficf_csc_raw"] == 7
     with pytest.raises(KeyError):
         R.call("_gficf_no_such_entry")
     with pytest.raises(TypeError):                      # `.Call` with the wrong number of arguments is refused by the table
         R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(np.ones((2, 1), dtype=np.int32)))
+
+
+def test_one_registration_table_survives_replace_semantics(R):
+    """R_registerRoutines REPLACES a DllInfo's `.Call` table (R src/main/Rdynload.c), it does not append: the stand-in has the same
+    semantics (self-test below).  The documented init path — the glue's own R_init_gficf, run by rmock_init() as dyn.load would — must
+    therefore register ONE table holding the ten rows of the glue AND the three Rcpp routines that stay in the package
+    (reference src/RcppExports.cpp:85-92: `_gficf_RunModularityClusteringCpp` 9, `_gficf_rcpp_WMU_test` 3, `_gficf_rcpp_parallel_WMU_test` 3),
+    then switch dynamic lookup off (:96) — so that clustcells(community.algo = "louvian 2") and findClusterMarkers() still resolve."""
+    assert R.L.rmock_selftest_second_registration_replaces() == 1        # two registrations: only the second table is left
+    assert R.L.rmock_n_registrations() == 1                              # the init path registers exactly once
+    assert R.L.rmock_use_dynamic_symbols() == 0                          # R_useDynamicSymbols(dll, FALSE)
+    want = {"_gficf_RunModularityClusteringCpp": 9, "_gficf_rcpp_WMU_test": 3, "_gficf_rcpp_parallel_WMU_test": 3,     # the package's own
+            "_gficf_rcpp_parallel_jaccard_coef": 2, "_gficf_jaccard_coeff": 2, "_gficf_gficf_csc": 7, "_gficf_gficf_csc_raw": 7,
+            "_gficf_find_nn": 3, "_gficf_jaccard_adjacency": 4, "_gficf_cluster_signatures": 6, "_gficf_transpose_csc": 4,
+            "_gficf_RunModularityClusteringHip": 9, "_gficf_phenograph": 8}
+    assert R.routines() == want and len(want) == 13
+    # the right function sits behind each of the package's names (the stand-ins return a number of their own)
+    nil = R.null()
+    for name, mark in (("_gficf_RunModularityClusteringCpp", 9009), ("_gficf_rcpp_WMU_test", 3003), ("_gficf_rcpp_parallel_WMU_test", 3103)):
+        res = R.call(name, *([nil] * want[name]))
+        assert res.type == rmock.INTSXP and int(res.numpy()[0]) == mark
+        with pytest.raises(TypeError):
+            R.call(name, nil)
+    # and a package that is loaded again (R CMD INSTALL's test load, devtools::load_all) registers the same table again
+    R.L.rmock_init()
+    assert R.routines() == want and R.L.rmock_n_registrations() == 1
+
+
+def test_gficf_entry_rejects_wrong_typed_slots_before_touching_them(R):
+    """`_gficf_gficf_csc` reads @i / @p / @x / @Dim of a dgCMatrix: a pattern or logical matrix (ngCMatrix has no @x, lgCMatrix a logical
+    one), a double @p, a short @i must reach Rf_error — not a read through the wrong type.  No device is needed to get there."""
+    i = np.array([0, 1, 0], dtype=np.int32)
+    p = np.array([0, 2, 3], dtype=np.int32)
+    x = np.array([1.0, 2.0, 3.0])
+    dim = np.array([2, 2], dtype=np.int32)
+    one = lambda v: R.vector(np.array([v]))                                     # noqa: E731
+    good = dict(i=R.vector(i), p=R.vector(p), x=R.vector(x), dim=R.vector(dim), w=R.null(), mn=one(0.0), mx=one(1.0))
+
+    def call(entry="_gficf_gficf_csc", **kw):
+        a = dict(good, **kw)
+        return R.call(entry, a["i"], a["p"], a["x"], a["dim"], a["w"], a["mn"], a["mx"])
+
+    for entry in ("_gficf_gficf_csc", "_gficf_gficf_csc_raw"):
+        with pytest.raises(rmock.RError, match="x must be a double"):
+            call(entry, x=R.vector(np.array([True, True, True])))               # lgCMatrix@x
+        with pytest.raises(rmock.RError, match="x must be a double"):
+            call(entry, x=R.null())                                             # ngCMatrix: no @x
+        with pytest.raises(rmock.RError, match="x must be a double"):
+            call(entry, x=R.vector(np.array([1, 2, 3], dtype=np.int32)))        # igCMatrix@x
+        with pytest.raises(rmock.RError, match="p must be an integer"):
+            call(entry, p=R.vector(p.astype(np.float64)))
+        with pytest.raises(rmock.RError, match="p must be an integer"):
+            call(entry, p=R.vector(p[:2]))                                      # not ncol + 1 long
+        with pytest.raises(rmock.RError, match="i must be an integer"):
+            call(entry, i=R.vector(i.astype(np.float64)))
+        with pytest.raises(rmock.RError, match="must hold"):
+            call(entry, i=R.vector(i[:2]))                                      # shorter than p[ncol + 1]
+        with pytest.raises(rmock.RError, match="must hold"):
+            call(entry, x=R.vector(x[:1]))
+        with pytest.raises(rmock.RError, match="dim must be"):
+            call(entry, dim=R.vector(dim.astype(np.float64)))
+        with pytest.raises(rmock.RError, match="dim must be"):
+            call(entry, dim=R.vector(np.array([2], dtype=np.int32)))
+        with pytest.raises(rmock.RError, match="w must be"):
+            call(entry, w=R.vector(np.array([1.0])))                            # not nrow long
+        with pytest.raises(rmock.RError, match="w must be"):
+            call(entry, w=R.vector(np.array([1, 1], dtype=np.int32)))
+        with pytest.raises(rmock.RError, match="single numbers"):
+            call(entry, mn=R.null())
+        assert R.L.rmock_protect_depth() == 0 and R.L.rmock_dead_touched() == 0
 
 
 def test_torture_collector_catches_a_missing_protect(R):
@@ -183,6 +253,44 @@ def test_dot_call_gficf_entry_matches_the_oracle(R):
     res2 = _call_gficf(R, M, w=w_in, pmin=0.0, pmax=2.0)
     _check_call_hygiene(R)
     _check_gficf(res2, ref2, G, N)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", ["_gficf_gficf_csc", "_gficf_gficf_csc_raw"])
+def test_an_r_error_between_plan_and_finish_leaves_the_next_call_correct(R, entry):
+    """The GF-ICF entry is two library calls with R allocations in between (`_plan` sizes the result, R allocates it, `_finish` fills it): an
+    R error there — memory running out in Rf_allocVector is the one R itself raises — unwinds past the glue with a plan still pending in the
+    context.  Every allocation of the call is made to fail in turn; after each failure the same entry is called again, on ANOTHER matrix, and
+    must be right (the next `_plan` drops the stale one), with the protect stack balanced and nothing dead touched."""
+    import oracle
+
+    G, N = 900, 500
+    M = _counts(G, N, seed=21)
+    M2 = _counts(700, 650, seed=22)
+    ref2 = oracle.gficf_csc(700, 650, M2.indptr.astype(np.int64), M2.indices, M2.data, 0.05, 1.0)
+    n_elts = 7 if entry.endswith("_raw") else 6
+    failed = 0
+    for nth in range(1, 12):
+        R.L.rmock_fail_allocation_after(nth)
+        try:
+            _call_gficf(R, M, entry=entry)
+            R.L.rmock_fail_allocation_after(0)
+            break                                                          # the call makes fewer than `nth` allocations: every one has been failed
+        except rmock.RError as e:
+            assert "cannot allocate" in str(e)
+            failed += 1
+        assert R.L.rmock_protect_depth() == 0
+        res = _call_gficf(R, M2, entry=entry)
+        _check_call_hygiene(R)
+        _check_gficf(res, ref2, 700, 650, n_elts=n_elts)
+    assert failed >= 6                                                     # out, i, p, x, keep, w (+ raw x, nt) — all between plan and finish
+    # and the Jaccard entry next to it is unaffected by a stale GF-ICF plan
+    mat = synth.knn_windowed(2000, 15, seed=5, perm_seed=6)
+    R.L.rmock_fail_allocation_after(1)
+    with pytest.raises(rmock.RError, match="cannot allocate"):
+        R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(mat), R.vector(np.array([False])))
+    want, _ = oracle.jaccard(mat, nthreads=4)
+    assert np.array_equal(R.call("_gficf_rcpp_parallel_jaccard_coef", R.matrix(mat), R.vector(np.array([False]))).numpy(), want)
 
 
 @pytest.mark.gpu
