@@ -116,6 +116,7 @@ SIGNATURES = {
     "gficf_csc_transpose_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, ctypes.c_size_t]),
     "gficf_csc_transpose_host": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
     "gficf_louvain_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
+    "gficf_louvain_workspace_bytes_starts": (ctypes.c_size_t, [_i64, _i64, _int]),
     "gficf_louvain_device": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _dbl, _int, _int, _int, _int, _vp, ctypes.POINTER(_i64),
                                     ctypes.POINTER(_dbl), _vp, ctypes.c_size_t]),
     "gficf_louvain_host": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _dbl, _int, _int, _int, _int, _vp, ctypes.POINTER(_i64),

@@ -1103,8 +1103,9 @@ class HipOps:
         check(self.L.gficf_cluster_signatures_device(self._bind(), G, n_cells, _tptr(colptr), _tptr(rowidx), _tptr(x),
                                                      _tptr(cluster), int(C), _tptr(out)))
 
-    def louvain_workspace_bytes(self, N: int, nnz: int) -> int:
-        return int(self.L.gficf_louvain_workspace_bytes(int(N), int(nnz)))
+    def louvain_workspace_bytes(self, N: int, nnz: int, n_start: int = 1) -> int:
+        """Device scratch of ``louvain``: with ``n_start`` given, enough for min(n_start, 16) starts to run together (one launch set)."""
+        return int(self.L.gficf_louvain_workspace_bytes_starts(int(N), int(nnz), int(n_start)))
 
     def louvain(self, N, indptr, indices, x, resolution, n_iter, labels, ws, algorithm: int = 1, n_start: int = 1, seed: int = 0):
         """Community detection on a device-resident symmetric adjacency matrix (indptr int64, indices int32, x float64).

@@ -66,6 +66,9 @@ struct gficf_ctx {
   // grow-only PINNED host staging (the compact return of gficf_jaccard_host: uint16 counts land here before the host expands them)
   void* h_stage = nullptr;
   size_t h_stage_bytes = 0;
+  // Louvain: the pinned block its control kernels report into and the two events of its one-iteration-ahead loop (louvain.hip; lazily made)
+  void* lv_host = nullptr;
+  hipEvent_t lv_ev[2] = {nullptr, nullptr};
   // print hook (R glue: Rprintf); NULL = stdout
   void (*print_fn)(const char*) = nullptr;
 };

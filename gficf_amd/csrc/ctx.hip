@@ -187,6 +187,9 @@ void gficf_ctx_destroy(gficf_ctx* ctx) {
   for (void* q : ctx->pool)
     if (q) (void)hipFree(q);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->lv_host) (void)hipHostFree(ctx->lv_host);
+  for (hipEvent_t e : ctx->lv_ev)
+    if (e) (void)hipEventDestroy(e);
   delete ctx;
 }
 

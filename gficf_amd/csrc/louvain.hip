@@ -16,27 +16,46 @@
 // modularity within a stated tolerance of the reference's own result on the same graph (tests/test_louvain_gpu.py
 // compares against a build of the reference's ModularityOptimizer.cpp, oracle/_ref/), and bit-reproducible output.
 //
-// Device algorithm (deterministic parallel Louvain):
+// Device algorithm (deterministic parallel Louvain), per start:
 //   * weights in 2^-32 fixed point (u64): every sum — a vertex's weight towards a community, the community totals —
-//     is an integer sum, so atomics commute and the result does not depend on scheduling;
+//     is an integer sum, so atomics commute and the result does not depend on scheduling or on the order of a row's entries;
 //   * local moving, synchronous within a sub-round: every vertex reads the same snapshot (labels, community totals and
 //     sizes), accumulates its edge weight per neighbouring community in an LDS hash table (one wave per vertex up to 128
-//     neighbours, one workgroup with an 8192-slot table beyond), takes the community with the best gain
+//     entries, one workgroup beyond), takes the community with the best gain
 //       gain(v -> c) = w(v, c) - k_v * K_c(without v) * resolution / 2W         (reference :540, ties: smaller id :541)
 //     if that beats staying; two singletons never swap (only the larger id moves).  The vertices are split into S
 //     hash classes that move one after the other (S grows as the graph gets small, where simultaneous moves hurt most);
 //     totals are applied between sub-rounds.  An iteration that lowers Q is undone and ends the level;
-//   * reduction: communities renumbered by a scan, every inter-community edge keyed (c_u << 32 | c_v), one rocPRIM
-//     radix sort, equal keys summed (integers again), CSR rebuilt; repeat until nothing merges;
+//   * reduction: communities renumbered by a scan; every vertex sums its entries per neighbouring community (the same LDS
+//     table) and appends one entry per community to the row of its own community in the coarse graph.  The coarse graph is
+//     a MULTIGRAPH in pointerB / pointerE form (a row may name a neighbour once per member vertex; every consumer sums
+//     per community anyway); no sort anywhere;
 //   * n_iter > 1 restarts from the finest graph with the labels found so far, as the reference's iterations do;
 //   * algorithm 2 (runLouvainAlgorithmWithMultilevelRefinement, :629-649): after the descent, back up through the levels
 //     with one more local moving on each, seeded with the labels found below it; a level's graph is rebuilt from the
-//     finest one through its saved vertex map (one sort) rather than kept.
+//     finest one through its saved vertex map rather than kept.
 //   * a vertex whose every option has a negative gain leaves for an unused cluster (:546-550): its own id, if free.
 //   * n_start "random starts": each start varies the seed of the class hash (the only arbitrary choice there is); the best
 //     modularity wins, as in the reference.  Start 0 with seed 0 is the plain run.
 //   * the alternative modularity function (2): unit node weights, the resolution as given — a context option.
 // Not reproduced: algorithm 3 (SLM).
+//
+// Round 6 — the starts in ONE launch set, the iterations without host round trips:
+//   * the n_start starts are independent problems on one graph.  They run as ONE problem on the disjoint union of B copies
+//     ("components"; B = as many starts as the workspace holds, at most 16): union vertex b * N + v, labels / totals / sizes
+//     per union vertex, every quantity that decides something (Q, moved vertices, sub-round count, seed) per component.
+//     Level 0 never materialises the copies: a wave loads a vertex's row ONCE and evaluates it for every component.  Coarse
+//     levels are one graph whose vertex ids are the scan's new ids (contiguous per component).  A component whose descent
+//     or whole run has ended idles (its kernels skip it) while the others go on; its results are those of running that start
+//     alone (tests/test_louvain_gpu.py: batched == one by one);
+//   * convergence and undo are decided on the device (k_lv_decide: one small block per iteration): the move kernel of an
+//     iteration's first sub-round also sums the internal weight of the labels it READS, i.e. the previous iteration's
+//     result, so the quality check costs no pass of its own; an iteration's kernels look at the component's action flag and
+//     do nothing once its level has ended.  The host enqueues one iteration AHEAD and waits for the previous one's event:
+//     the stream is never drained inside a level; per level there is one synchronisation (the sizes of the next level);
+//   * counters that every moving vertex used to hit with one global atomic (a single address: 150-220 us of the 158-226 us
+//     a level-0 sub-round took while most vertices still moved) are per-block partial sums in fixed slots, added up by
+//     k_lv_decide; the vertex kernels are persistent grids striding over the vertices.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -60,18 +79,79 @@ constexpr int LV_MID_DEG = 1024, LV_MID_SLOTS = 2048;   // one workgroup per ver
 constexpr int LV_BIG_SLOTS = 8192;             // beyond: 32 KB keys + 64 KB sums
 constexpr int LV_MAX_ITERS = 64;
 constexpr int LV_MAX_SAVED = 12;              // levels whose vertex map is kept for the refinement of algorithm 2
+constexpr int LV_MAX_B = 16;                  // starts run together
+constexpr int LV_GRID = 2048;                 // persistent grid of the wave-per-vertex kernels (workgroups of 4 waves)
+constexpr int LV_GRID_BIG = 1024;             // ... of the workgroup-per-vertex kernels
+constexpr int LV_SQ_BLOCKS = 64;              // slices of a component's communities in the fixed-order sum of squares
+constexpr int LV_ACC_BINS = 4096;
 
-struct LvGraph {
-  int64_t n, m;
-  const int64_t* ptr;
+enum { LV_IDLE = 0, LV_CONTINUE = 1, LV_STOP_KEEP = 2, LV_STOP_UNDO = 3 };
+
+// One level's union graph.  Level 0: `rep` copies of the caller's matrix, never materialised (union vertex b * nb + v has
+// the row of v with every neighbour shifted by b * nb); coarse levels: rep == 1.  Rows are [beg[v], end[v]).
+struct LvG {
+  int64_t n;                 // union vertices = rep * nb
+  int64_t nb;                // vertices of the stored graph
+  int32_t rep;
+  const int64_t* beg;
+  const int64_t* end;
   const int32_t* nbr;
   const u64* wt;
-  const u64* kv;
+  const u64* kv;             // [nb] vertex weights
+  const uint8_t* vcomp;      // [n] component of a union vertex; NULL at level 0: the copy number (also when there is one copy only)
+};
+
+struct LvComp {              // one start ("component" of the union)
+  int64_t v0, n;             // its vertices at the current level: union ids [v0, v0 + n)
+  int64_t seed_base;         // seeded start: community of a vertex = seed_base + its seed label
+  int64_t lab_base;          // first LDS bin of its seed labels (binned accumulation)
+  int64_t n_labels;          // the labels of the last renumbering lie in [0, n_labels)
+  int64_t newbase, n2;       // after the level's renumbering: first new id, communities in use
+  u64 self_w, in_w;          // weight folded into the level's vertices; internal weight of the accepted labels on the level's graph
+  double q_prev, q_final;
+  uint32_t seed;             // of the sub-round class hash: what a "random start" varies
+  int32_t S;                 // sub-rounds of the level
+  int32_t live;              // takes part in this level
+  int32_t cont;              // goes on to the next level (set when the level is renumbered)
+  int32_t level_done, action, iter, level_moved, any_move, finished;
+  int32_t n_saved, pad;
+  int64_t saved_n[LV_MAX_SAVED + 1];
+};
+
+struct LvCtl {               // device control block
+  LvComp c[LV_MAX_B];
+  int32_t B, pad;
+  unsigned n_mid, n_large;   // vertices of the workgroup path (list counts) of the graph the lists were built for
+  int64_t n_union2;          // union vertices after the renumbering
+};
+
+struct LvHostComp { int64_t n2; double q_prev; int32_t cont, any_move, level_moved, live; };
+struct LvHost {              // pinned host memory the control kernels write (read after an event)
+  int32_t n_cont[LV_MAX_ITERS + 2];
+  int64_t n_union2;
+  unsigned n_mid, n_large;
+  LvHostComp c[LV_MAX_B];
+  double q_iter[LV_MAX_B];   // (debug trace)
+};
+
+struct LvParts {             // per-block partial sums of the move kernels, fixed slots (no atomics, no clearing)
+  // internal weight: written by an iteration's sub-round-0 kernels, read by the same iteration's k_lv_decide.  Moved vertices: summed over
+  // ALL sub-rounds of an iteration and read by the NEXT iteration's k_lv_decide, after that iteration's sub-round 0 has started a new
+  // count — hence two sets, by iteration parity.
+  u64* in_small;  unsigned* mv_small[2];     // [LV_GRID][LV_MAX_B]
+  u64* in_mid;    unsigned* mv_mid[2];       // [LV_GRID_BIG][LV_MAX_B]
+  u64* in_large;  unsigned* mv_large[2];
+  double* sq;                              // [LV_MAX_B][LV_SQ_BLOCKS]
 };
 
 __device__ __host__ static inline uint32_t lv_hash(uint32_t v) {
   v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
   return v;
+}
+
+__device__ __host__ static inline int lv_sub_rounds_of(int64_t n, int s_env) {
+  if (s_env >= 1 && s_env <= 64) return s_env;
+  return n > 50000 ? 2 : n > 4000 ? 4 : n > 400 ? 8 : 16;
 }
 
 // ---- level 0: fixed-point weights, validation
@@ -97,16 +177,17 @@ __global__ __launch_bounds__(256) void k_lv_fix(int64_t N, int64_t nnz, const in
   }
 }
 
-__global__ __launch_bounds__(256) void k_lv_vertex_weight(LvGraph g, u64* __restrict__ kv, u64* __restrict__ two_w,
+__global__ __launch_bounds__(256) void k_lv_vertex_weight(int64_t n, int64_t m, const int64_t* __restrict__ ptr, const int32_t* __restrict__ nbr,
+                                                         const u64* __restrict__ wt, u64* __restrict__ kv, u64* __restrict__ two_w,
                                                          uint32_t* __restrict__ status) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
   u64 s = 0;
-  if (v < g.n) {
-    int64_t lo = g.ptr[v], hi = g.ptr[v + 1];
-    if (lo < 0 || hi < lo || hi > g.m) { atomicOr(status, GFICF_ST_BAD_CSC); lo = hi = 0; }
+  if (v < n) {
+    int64_t lo = ptr[v], hi = ptr[v + 1];
+    if (lo < 0 || hi < lo || hi > m) { atomicOr(status, GFICF_ST_BAD_CSC); lo = hi = 0; }
     for (int64_t e = lo; e < hi; ++e) {
-      const int32_t u = g.nbr[e];
-      if (u != v && u >= 0 && u < g.n) s += g.wt[e];
+      const int32_t u = nbr[e];
+      if (u != v && u >= 0 && u < n) s += wt[e];
     }
     kv[v] = s;
   }
@@ -123,50 +204,130 @@ __global__ __launch_bounds__(256) void k_lv_fill_u64(int64_t n, u64 v, u64* __re
   if (i < n) out[i] = v;
 }
 
-// singletons: every vertex its own community
-__global__ __launch_bounds__(256) void k_lv_init(int64_t n, const u64* __restrict__ kv, int32_t* __restrict__ comm, u64* __restrict__ K,
-                                                 int32_t* __restrict__ size) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v < n) { comm[v] = (int32_t)v; K[v] = kv[v]; size[v] = 1; }
+// ---- control kernels (one small block; thread b = component b)
+// A batch begins: the seeds of its starts, nothing found yet.
+__global__ void k_lv_ctl_batch(LvCtl* ctl, int B, int first_start, int seed) {
+  const int b = threadIdx.x;
+  if (b == 0) { ctl->B = B; ctl->n_mid = ctl->n_large = 0; ctl->n_union2 = 0; }
+  if (b >= LV_MAX_B) return;
+  LvComp& C = ctl->c[b];
+  const int start = first_start + b;
+  C.seed = start == 0 && seed == 0 ? 0u : lv_hash((uint32_t)seed * 0x9E3779B1u + (uint32_t)start + 1u);
+  C.finished = b < B ? 0 : 1;
+  C.any_move = 1;
+  C.n_labels = 0;
+  C.q_prev = C.q_final = 0.0;
+  C.self_w = C.in_w = 0;
+  C.live = C.cont = 0;
+  C.n_saved = 0;
+  C.v0 = C.n = C.n2 = C.newbase = 0;
 }
 
-// Per-label totals (K, may be NULL) and member counts of given labels in [0, C).  With few labels every vertex would
-// hit the same few addresses: up to LV_ACC_BINS labels are binned in LDS first, one global atomic per label and block.
-constexpr int LV_ACC_BINS = 4096;
-__global__ __launch_bounds__(256) void k_lv_accum(int64_t n, int64_t C, const int32_t* __restrict__ lab, const u64* __restrict__ kv,
-                                                  int32_t* __restrict__ comm, u64* __restrict__ K, int32_t* __restrict__ size) {
+// A level begins.  mode 0: level 0 of a pass (v0 = b * N, n = N; pass > 0: seeded with the labels found so far, a start whose last
+// pass moved nothing has finished).  mode 1: the level below was renumbered and reduced (v0 = newbase, n = n2 for the
+// components that go on).  mode 2: a refinement level of algorithm 2 (the participants and sizes were set by k_lv_ctl_refine).
+__global__ void k_lv_ctl_level(LvCtl* ctl, int mode, int pass, int64_t N, int s_env) {
+  __shared__ int64_t s_nl[LV_MAX_B];
+  const int b = threadIdx.x;
+  const int B = ctl->B;
+  if (b < LV_MAX_B) {
+    LvComp& C = ctl->c[b];
+    if (mode == 0) {
+      if (pass > 0 && !C.any_move) C.finished = 1;
+      C.live = b < B && !C.finished;
+      C.v0 = b < B ? (int64_t)b * N : 0;                 // (a slot beyond the batch: an empty range, never an index past the union)
+      C.n = b < B ? N : 0;
+      C.self_w = 0;
+      C.any_move = 0;
+      C.n_saved = 0;
+      C.seed_base = C.v0;
+    } else if (mode == 1) {
+      C.live = C.cont;
+      C.v0 = C.newbase; C.n = C.n2;
+      C.seed_base = C.v0;
+    }
+    C.cont = 0;
+    C.S = lv_sub_rounds_of(C.n, s_env);
+    C.level_done = C.live ? 0 : 1;
+    C.action = LV_IDLE;
+    C.iter = 0;
+    C.level_moved = 0;
+    s_nl[b] = b < B && C.live ? C.n_labels : 0;
+  }
+  __syncthreads();
+  if (b < LV_MAX_B) {
+    int64_t base = 0;
+    for (int t = 0; t < b; ++t) base += s_nl[t];
+    ctl->c[b].lab_base = base;
+  }
+}
+
+// Labels (seed == NULL: singletons), totals and sizes of the level.  A seeded start leaves totals and sizes at zero for
+// k_lv_accum.  The vertices of a component that does not take part are dead: own label, size 0 (they vanish at the next renumbering).
+__global__ __launch_bounds__(256) void k_lv_init(LvG g, const LvCtl* __restrict__ ctl, const int32_t* __restrict__ seed, int32_t* __restrict__ comm,
+                                                 u64* __restrict__ K, int32_t* __restrict__ size) {
+  for (int64_t gv = (int64_t)blockIdx.x * 256 + threadIdx.x; gv < g.n; gv += (int64_t)gridDim.x * 256) {
+    const int64_t b = g.rep > 1 ? gv / g.nb : 0;
+    const int64_t v = gv - b * g.nb;
+    const int comp = g.vcomp ? (int)g.vcomp[gv] : (int)b;
+    const LvComp& C = ctl->c[comp];
+    if (!C.live) { comm[gv] = (int32_t)gv; K[gv] = 0ull; size[gv] = 0; continue; }
+    if (seed) { comm[gv] = (int32_t)(C.seed_base + seed[gv]); K[gv] = 0ull; size[gv] = 0; }
+    else { comm[gv] = (int32_t)gv; K[gv] = g.kv[v]; size[gv] = 1; }
+  }
+}
+
+// Totals and member counts of the communities comm[] names (K, size zeroed before).  With few labels every vertex would hit the
+// same few addresses: when all components' labels fit LV_ACC_BINS bins (bin = lab_base + label - seed_base) they are summed in
+// LDS first, one global atomic per label and block.
+__global__ __launch_bounds__(256) void k_lv_accum(LvG g, const LvCtl* __restrict__ ctl, int binned, const int32_t* __restrict__ comm,
+                                                  u64* __restrict__ K, int32_t* __restrict__ size) {
   __shared__ u64 s_k[LV_ACC_BINS];
   __shared__ int32_t s_n[LV_ACC_BINS];
-  const bool binned = C <= LV_ACC_BINS;
+  __shared__ int32_t s_c[LV_ACC_BINS];
   if (binned) {
-    for (int t = threadIdx.x; t < C; t += 256) { s_k[t] = 0ull; s_n[t] = 0; }
+    for (int t = threadIdx.x; t < LV_ACC_BINS; t += 256) { s_k[t] = 0ull; s_n[t] = 0; s_c[t] = -1; }
     __syncthreads();
   }
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (int64_t)gridDim.x * 256) {
-    const int32_t c = lab[v];
-    if (comm) comm[v] = c;
+  for (int64_t gv = (int64_t)blockIdx.x * 256 + threadIdx.x; gv < g.n; gv += (int64_t)gridDim.x * 256) {
+    const int64_t b = g.rep > 1 ? gv / g.nb : 0;
+    const int comp = g.vcomp ? (int)g.vcomp[gv] : (int)b;
+    const LvComp& C = ctl->c[comp];
+    if (!C.live) continue;
+    const int32_t c = comm[gv];
+    const u64 k = g.kv[gv - b * g.nb];
     if (binned) {
-      if (K) atomicAdd(&s_k[c], kv[v]);
-      atomicAdd(&s_n[c], 1);
+      const int bin = (int)(C.lab_base + ((int64_t)c - C.seed_base));
+      s_c[bin] = c;
+      atomicAdd(&s_k[bin], k);
+      atomicAdd(&s_n[bin], 1);
     } else {
-      if (K) atomicAdd(&K[c], kv[v]);
+      atomicAdd(&K[c], k);
       atomicAdd(&size[c], 1);
     }
   }
   if (binned) {
     __syncthreads();
-    for (int t = threadIdx.x; t < C; t += 256) {
-      if (s_n[t]) atomicAdd(&size[t], s_n[t]);
-      if (K && s_k[t]) atomicAdd(&K[t], s_k[t]);
+    for (int t = threadIdx.x; t < LV_ACC_BINS; t += 256) {
+      if (s_n[t]) { atomicAdd(&size[s_c[t]], s_n[t]); if (s_k[t]) atomicAdd(&K[s_c[t]], s_k[t]); }
     }
+  }
+}
+
+// the vertices of the workgroup path: middle degrees from the front of the list, large ones from its end
+__global__ __launch_bounds__(256) void k_lv_list_big(LvG g, const int64_t* __restrict__ n_dev, int32_t* __restrict__ big, unsigned* __restrict__ n_mid_large) {
+  const int64_t nb = n_dev ? *n_dev : g.nb;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nb; v += (int64_t)gridDim.x * 256) {
+    const int64_t deg = g.end[v] - g.beg[v];
+    if (deg > LV_MID_DEG) big[nb - 1 - atomicAdd(n_mid_large + 1, 1u)] = (int32_t)v;
+    else if (deg > LV_SMALL_DEG) big[atomicAdd(n_mid_large, 1u)] = (int32_t)v;
   }
 }
 
 // ---- local moving
 struct LvMove {
   double r;            // resolution / 2W (in fixed-point units of 2W)
-  int s, S;            // this sub-round's hash class
-  uint32_t seed;       // of the class hash: what a "random start" varies
+  int s;               // this sub-round's hash class
 };
 
 __device__ static inline void lv_wave_sync() {
@@ -177,296 +338,707 @@ __device__ static inline void lv_wave_sync() {
 
 __device__ static inline bool lv_better(double g, int32_t c, double bg, int32_t bc) { return g > bg || (g == bg && c < bc); }
 
-// One wave per vertex (degree <= LV_SMALL_DEG).
-__global__ __launch_bounds__(256) void k_lv_move_small(LvGraph g, LvMove mv, const int32_t* __restrict__ comm, const u64* __restrict__ K,
-                                                       const int32_t* __restrict__ size, int32_t* __restrict__ next,
-                                                       unsigned* __restrict__ moved) {
+__device__ static inline u64 lv_wave_sum(u64 x) {
+  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+  return x;
+}
+
+// does component C take part in the sub-round kernel (s, first)?  first = the kernel of sub-round 0, which runs BEFORE the iteration's
+// decision: every component whose level has not ended
+__device__ static inline bool lv_runs(const LvComp& C, int s, bool first) {
+  return first ? !C.level_done : (C.action == LV_CONTINUE && s < C.S);
+}
+
+// the decision for vertex gv, identical in every lane (all inputs are wave-uniform)
+__device__ static inline int32_t lv_decide_vertex(int64_t gv, int32_t cv, double bg, int32_t bc, u64 stay_w, u64 kvv, double r, const u64* __restrict__ K,
+                                                  const int32_t* __restrict__ size, bool* moved) {
+  const double kvd = (double)kvv;
+  const double g_stay = (double)stay_w - kvd * (double)(K[cv] - kvv) * r;
+  bool move = bc != INT32_MAX && bg > g_stay;
+  const int32_t szc = size[cv];
+  if (move && szc == 1 && size[bc] == 1 && bc > cv) move = false;      // two singletons never swap
+  int32_t to = move ? bc : cv;
+  // every option loses: alone is better (the reference's move into an unused cluster, :546-550).  The unused cluster
+  // is the vertex's own id when nobody holds it — unique per vertex, so simultaneous escapes never meet.
+  if ((move ? bg : g_stay) < 0.0 && szc > 1 && size[gv] == 0) { to = (int32_t)gv; move = true; }
+  *moved = move;
+  return to;
+}
+
+// One wave per vertex (at most LV_SMALL_DEG entries, two per lane, loaded ONCE and evaluated for every copy of the graph).  The wave's
+// table is cleared once: the lane that claims a slot ("owner") evaluates that community and hands the slot back empty.
+// FIRST (sub-round 0): every vertex of a running component also contributes the weight of its entries inside its own community —
+// the internal weight of the labels this kernel reads, i.e. of the previous iteration's result (k_lv_decide turns it into Q).
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __restrict__ ctl, LvMove mv, const int32_t* __restrict__ comm,
+                                                       const u64* __restrict__ K, const int32_t* __restrict__ size, int32_t* __restrict__ next,
+                                                       u64* __restrict__ part_in, unsigned* __restrict__ part_mv) {
   __shared__ int32_t s_key[4][LV_SMALL_SLOTS];
   __shared__ u64 s_val[4][LV_SMALL_SLOTS];
+  __shared__ u64 s_acc[4][LV_MAX_B];
+  __shared__ unsigned s_cnt[4][LV_MAX_B];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t v = (int64_t)blockIdx.x * 4 + wave;
-  int64_t lo = 0, hi = 0;
-  bool active = v < g.n;
-  if (active) {
-    lo = g.ptr[v]; hi = g.ptr[v + 1];
-    active = hi - lo <= LV_SMALL_DEG && (mv.S == 1 || (int)(lv_hash((uint32_t)v + mv.seed) % (uint32_t)mv.S) == mv.s);
-  }
   int32_t* key = s_key[wave];
   u64* val = s_val[wave];
   // the table belongs to this wave alone and LDS serves a wave's operations in issue order: a wave-level fence (no
   // workgroup barrier) is all that separates clearing, filling and reading it
-  if (!active) return;
   for (int t = lane; t < LV_SMALL_SLOTS; t += 64) { key[t] = -1; val[t] = 0ull; }
   lv_wave_sync();
-  {
-    for (int64_t e = lo + lane; e < hi; e += 64) {
-      const int32_t u = g.nbr[e];
-      if (u == v) continue;
-      const int32_t c = comm[u];
-      uint32_t h = lv_hash((uint32_t)c) & (LV_SMALL_SLOTS - 1);
-      for (;;) {
-        const int32_t old = atomicCAS(&key[h], -1, c);
-        if (old == -1 || old == c) { atomicAdd(&val[h], g.wt[e]); break; }
-        h = (h + 1) & (LV_SMALL_SLOTS - 1);
+  u64 acc = 0;               // lane b: internal weight summed for component b
+  unsigned cnt = 0;          // lane b: vertices of component b that move
+  for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < g.nb; v += (int64_t)gridDim.x * 4) {
+    const int64_t lo = g.beg[v], hi = g.end[v];
+    if (hi - lo > LV_SMALL_DEG) continue;
+    const int64_t e0 = lo + lane, e1 = e0 + 64;
+    int32_t u0 = -1, u1 = -1;
+    u64 w0 = 0, w1 = 0;
+    if (e0 < hi) { u0 = g.nbr[e0]; w0 = g.wt[e0]; if (u0 == v) u0 = -1; }
+    if (e1 < hi) { u1 = g.nbr[e1]; w1 = g.wt[e1]; if (u1 == v) u1 = -1; }
+    const u64 kvv = g.kv[v];
+    for (int b = 0; b < g.rep; ++b) {
+      const int comp = g.vcomp ? (int)g.vcomp[v] : b;
+      const LvComp& C = ctl->c[comp];
+      if (!lv_runs(C, mv.s, FIRST)) continue;
+      const int64_t base = (int64_t)b * g.nb, gv = base + v;
+      const bool in_class = C.S == 1 || (int)(lv_hash((uint32_t)(gv - C.v0) + C.seed) % (uint32_t)C.S) == mv.s;
+      if (!FIRST && !in_class) continue;
+      const int32_t cv = comm[gv];
+      const int32_t c0 = u0 >= 0 ? comm[base + u0] : -1, c1 = u1 >= 0 ? comm[base + u1] : -1;
+      if (FIRST && !in_class) {                  // only its share of the internal weight
+        const u64 t = lv_wave_sum((c0 == cv ? w0 : 0ull) + (c1 == cv ? w1 : 0ull));
+        if (lane == comp) acc += t;
+        continue;
       }
+      int slot0 = -1, slot1 = -1;
+      bool own0 = false, own1 = false;
+      if (c0 >= 0) {
+        uint32_t h = lv_hash((uint32_t)c0) & (LV_SMALL_SLOTS - 1);
+        for (;;) {
+          const int32_t old = atomicCAS(&key[h], -1, c0);
+          if (old == -1) { own0 = true; break; }
+          if (old == c0) break;
+          h = (h + 1) & (LV_SMALL_SLOTS - 1);
+        }
+        slot0 = (int)h;
+        atomicAdd(&val[h], w0);
+      }
+      if (c1 >= 0) {
+        uint32_t h = lv_hash((uint32_t)c1) & (LV_SMALL_SLOTS - 1);
+        for (;;) {
+          const int32_t old = atomicCAS(&key[h], -1, c1);
+          if (old == -1) { own1 = true; break; }
+          if (old == c1) break;
+          h = (h + 1) & (LV_SMALL_SLOTS - 1);
+        }
+        slot1 = (int)h;
+        atomicAdd(&val[h], w1);
+      }
+      lv_wave_sync();
+      const double kvd = (double)kvv;
+      double bg = -INFINITY;
+      int32_t bc = INT32_MAX;
+      u64 stay_w = 0;
+      if (own0) {
+        const u64 w = val[slot0];
+        if (c0 == cv) stay_w = w;
+        else { const double gain = (double)w - kvd * (double)K[c0] * mv.r; if (lv_better(gain, c0, bg, bc)) { bg = gain; bc = c0; } }
+        key[slot0] = -1; val[slot0] = 0ull;
+      }
+      if (own1) {
+        const u64 w = val[slot1];
+        if (c1 == cv) stay_w = w;
+        else { const double gain = (double)w - kvd * (double)K[c1] * mv.r; if (lv_better(gain, c1, bg, bc)) { bg = gain; bc = c1; } }
+        key[slot1] = -1; val[slot1] = 0ull;
+      }
+      for (int d = 32; d > 0; d >>= 1) {
+        const double og = __shfl_xor(bg, d);
+        const int32_t oc = __shfl_xor(bc, d);
+        const u64 ow = __shfl_xor(stay_w, d);
+        if (lv_better(og, oc, bg, bc)) { bg = og; bc = oc; }
+        stay_w = ow > stay_w ? ow : stay_w;
+      }
+      lv_wave_sync();                            // the slots are empty again before the next vertex fills them
+      bool moved;
+      const int32_t to = lv_decide_vertex(gv, cv, bg, bc, stay_w, kvv, mv.r, K, size, &moved);
+      if (lane == 0) next[gv] = to;
+      if (lane == comp) { cnt += moved ? 1u : 0u; if (FIRST) acc += stay_w; }
     }
   }
-  lv_wave_sync();
-  const int32_t cv = comm[v];
-  const double kvd = (double)g.kv[v];
-  double bg = -INFINITY, stay_w = 0.0;
-  int32_t bc = INT32_MAX;
-  for (int t = lane; t < LV_SMALL_SLOTS; t += 64) {
-    const int32_t c = key[t];
-    if (c < 0) continue;
-    const double w = (double)val[t];
-    if (c == cv) { stay_w = w; continue; }
-    const double gain = w - kvd * (double)K[c] * mv.r;
-    if (lv_better(gain, c, bg, bc)) { bg = gain; bc = c; }
-  }
-  for (int d = 32; d > 0; d >>= 1) {
-    const double og = __shfl_xor(bg, d), ow = __shfl_xor(stay_w, d);
-    const int32_t oc = __shfl_xor(bc, d);
-    if (lv_better(og, oc, bg, bc)) { bg = og; bc = oc; }
-    stay_w = fmax(stay_w, ow);
-  }
-  if (lane == 0) {
-    const double g_stay = stay_w - kvd * (double)(K[cv] - g.kv[v]) * mv.r;
-    bool move = bc != INT32_MAX && bg > g_stay;
-    if (move && size[cv] == 1 && size[bc] == 1 && bc > cv) move = false;      // two singletons never swap
-    int32_t to = move ? bc : cv;
-    // every option loses: alone is better (the reference's move into an unused cluster, :546-550).  The unused cluster
-    // is the vertex's own id when nobody holds it — unique per vertex, so simultaneous escapes never meet.
-    if ((move ? bg : g_stay) < 0.0 && size[cv] > 1 && size[v] == 0) { to = (int32_t)v; move = true; }
-    next[v] = to;
-    if (move) atomicAdd(moved, 1u);
+  if (lane < LV_MAX_B) { s_acc[wave][lane] = acc; s_cnt[wave][lane] = cnt; }
+  __syncthreads();
+  if (threadIdx.x < LV_MAX_B) {
+    const int t = threadIdx.x;
+    const unsigned c = s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
+    const size_t at = (size_t)blockIdx.x * LV_MAX_B + t;
+    if (FIRST) { part_in[at] = s_acc[0][t] + s_acc[1][t] + s_acc[2][t] + s_acc[3][t]; part_mv[at] = c; }
+    else part_mv[at] += c;                      // the same grid in every sub-round of the iteration: the slot is this block's
   }
 }
 
-// One workgroup per listed vertex (degree > LV_SMALL_DEG): SLOTS = 2048 up to LV_MID_DEG neighbours, 8192 beyond.
-template <int SLOTS>
-__global__ __launch_bounds__(256) void k_lv_move_big(LvGraph g, LvMove mv, const int32_t* __restrict__ big, const int32_t* __restrict__ comm,
-                                                     const u64* __restrict__ K, const int32_t* __restrict__ size,
-                                                     int32_t* __restrict__ next, unsigned* __restrict__ moved,
+// One workgroup per listed vertex and copy (more than LV_SMALL_DEG entries): SLOTS = 2048 up to LV_MID_DEG entries, 8192 beyond.
+template <int SLOTS, bool FIRST>
+__global__ __launch_bounds__(256) void k_lv_move_big(LvG g, const LvCtl* __restrict__ ctl, LvMove mv, int large, int64_t n_list, const int32_t* __restrict__ big,
+                                                     const int32_t* __restrict__ comm, const u64* __restrict__ K, const int32_t* __restrict__ size,
+                                                     int32_t* __restrict__ next, u64* __restrict__ part_in, unsigned* __restrict__ part_mv,
                                                      uint32_t* __restrict__ status) {
   extern __shared__ unsigned char s_raw[];
   u64* val = (u64*)s_raw;
   int32_t* key = (int32_t*)(val + SLOTS);
-  __shared__ double s_g[256], s_w[4];
+  __shared__ double s_g[256];
+  __shared__ u64 s_w[4], s_in[4];
   __shared__ int32_t s_c[256];
+  __shared__ u64 s_acc[LV_MAX_B];
+  __shared__ unsigned s_cnt[LV_MAX_B];
   const int tid = threadIdx.x;
-  const int64_t v = big[blockIdx.x];
-  if (mv.S != 1 && (int)(lv_hash((uint32_t)v + mv.seed) % (uint32_t)mv.S) != mv.s) return;     // uniform per workgroup
-  const int64_t lo = g.ptr[v], hi = g.ptr[v + 1];
-  const int32_t cv = comm[v];
-  const double kvd = (double)g.kv[v];
-  double bg = -INFINITY, stay_w = 0.0;
-  int32_t bc = INT32_MAX;
-  // A vertex with more neighbours than the table comfortably holds (every neighbour can be its own community) is done in
-  // P passes over its edges, pass p taking the communities of hash class p: about deg / P <= SLOTS / 2 of them at a time.
-  const uint32_t P = (uint32_t)((hi - lo + SLOTS / 2 - 1) / (SLOTS / 2));
-  for (uint32_t p = 0; p < (P ? P : 1u); ++p) {
-    for (int t = tid; t < SLOTS; t += 256) { key[t] = -1; val[t] = 0ull; }
-    __syncthreads();
-    for (int64_t e = lo + tid; e < hi; e += 256) {
-      const int32_t u = g.nbr[e];
-      if (u == v) continue;
-      const int32_t c = comm[u];
-      const uint32_t hc = lv_hash((uint32_t)c);
-      if (P > 1 && (hc >> 13) % P != p) continue;
-      uint32_t h = hc & (SLOTS - 1);
-      int probes = 0;
-      for (;;) {
-        const int32_t old = atomicCAS(&key[h], -1, c);
-        if (old == -1 || old == c) { atomicAdd(&val[h], g.wt[e]); break; }
-        h = (h + 1) & (SLOTS - 1);
-        if (++probes >= SLOTS) { atomicOr(status, GFICF_ST_TOO_DENSE); break; }   // a hash class that overflows the table
+  if (tid < LV_MAX_B) { s_acc[tid] = 0ull; s_cnt[tid] = 0u; }
+  __syncthreads();
+  const int32_t* list = large ? big + (g.nb - n_list) : big;
+  for (int64_t item = blockIdx.x; item < n_list * g.rep; item += gridDim.x) {
+    const int b = (int)(item / n_list);
+    const int64_t v = list[item - (int64_t)b * n_list];
+    const int comp = g.vcomp ? (int)g.vcomp[v] : b;
+    const LvComp& C = ctl->c[comp];
+    if (!lv_runs(C, mv.s, FIRST)) continue;                                       // uniform per workgroup
+    const int64_t base = (int64_t)b * g.nb, gv = base + v;
+    const bool in_class = C.S == 1 || (int)(lv_hash((uint32_t)(gv - C.v0) + C.seed) % (uint32_t)C.S) == mv.s;
+    if (!FIRST && !in_class) continue;
+    const int64_t lo = g.beg[v], hi = g.end[v];
+    const int32_t cv = comm[gv];
+    const u64 kvv = g.kv[v];
+    if (FIRST && !in_class) {
+      u64 t = 0;
+      for (int64_t e = lo + tid; e < hi; e += 256) {
+        const int32_t u = g.nbr[e];
+        if (u != v && comm[base + u] == cv) t += g.wt[e];
       }
+      t = lv_wave_sum(t);
+      if ((tid & 63) == 0) s_in[tid >> 6] = t;
+      __syncthreads();
+      if (tid == 0) s_acc[comp] += s_in[0] + s_in[1] + s_in[2] + s_in[3];
+      __syncthreads();
+      continue;
     }
+    const double kvd = (double)kvv;
+    double bg = -INFINITY;
+    u64 stay_w = 0;
+    int32_t bc = INT32_MAX;
+    // A vertex with more entries than the table comfortably holds (every entry can be its own community) is done in
+    // P passes over its entries, pass p taking the communities of hash class p: about deg / P <= SLOTS / 2 of them at a time.
+    const uint32_t P = (uint32_t)((hi - lo + SLOTS / 2 - 1) / (SLOTS / 2));
+    for (uint32_t p = 0; p < (P ? P : 1u); ++p) {
+      for (int t = tid; t < SLOTS; t += 256) { key[t] = -1; val[t] = 0ull; }
+      __syncthreads();
+      for (int64_t e = lo + tid; e < hi; e += 256) {
+        const int32_t u = g.nbr[e];
+        if (u == v) continue;
+        const int32_t c = comm[base + u];
+        const uint32_t hc = lv_hash((uint32_t)c);
+        if (P > 1 && (hc >> 13) % P != p) continue;
+        uint32_t h = hc & (SLOTS - 1);
+        int probes = 0;
+        for (;;) {
+          const int32_t old = atomicCAS(&key[h], -1, c);
+          if (old == -1 || old == c) { atomicAdd(&val[h], g.wt[e]); break; }
+          h = (h + 1) & (SLOTS - 1);
+          if (++probes >= SLOTS) { atomicOr(status, GFICF_ST_TOO_DENSE); break; }   // a hash class that overflows the table
+        }
+      }
+      __syncthreads();
+      for (int t = tid; t < SLOTS; t += 256) {
+        const int32_t c = key[t];
+        if (c < 0) continue;
+        const u64 w = val[t];
+        if (c == cv) { stay_w = w; continue; }
+        const double gain = (double)w - kvd * (double)K[c] * mv.r;
+        if (lv_better(gain, c, bg, bc)) { bg = gain; bc = c; }
+      }
+      __syncthreads();
+    }
+    for (int d = 32; d > 0; d >>= 1) { const u64 o = __shfl_xor(stay_w, d); stay_w = o > stay_w ? o : stay_w; }
+    if ((tid & 63) == 0) s_w[tid >> 6] = stay_w;
+    s_g[tid] = bg; s_c[tid] = bc;
     __syncthreads();
-    for (int t = tid; t < SLOTS; t += 256) {
-      const int32_t c = key[t];
-      if (c < 0) continue;
-      const double w = (double)val[t];
-      if (c == cv) { stay_w = w; continue; }
-      const double gain = w - kvd * (double)K[c] * mv.r;
-      if (lv_better(gain, c, bg, bc)) { bg = gain; bc = c; }
+    for (int d = 128; d > 0; d >>= 1) {
+      if (tid < d && lv_better(s_g[tid + d], s_c[tid + d], s_g[tid], s_c[tid])) { s_g[tid] = s_g[tid + d]; s_c[tid] = s_c[tid + d]; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      bg = s_g[0]; bc = s_c[0];
+      stay_w = s_w[0];
+      for (int t = 1; t < 4; ++t) stay_w = s_w[t] > stay_w ? s_w[t] : stay_w;
+      bool moved;
+      next[gv] = lv_decide_vertex(gv, cv, bg, bc, stay_w, kvv, mv.r, K, size, &moved);
+      s_cnt[comp] += moved ? 1u : 0u;
+      if (FIRST) s_acc[comp] += stay_w;
     }
     __syncthreads();
   }
-  for (int d = 32; d > 0; d >>= 1) stay_w = fmax(stay_w, __shfl_xor(stay_w, d));
-  if ((tid & 63) == 0) s_w[tid >> 6] = stay_w;
-  s_g[tid] = bg; s_c[tid] = bc;
   __syncthreads();
-  for (int d = 128; d > 0; d >>= 1) {
-    if (tid < d && lv_better(s_g[tid + d], s_c[tid + d], s_g[tid], s_c[tid])) { s_g[tid] = s_g[tid + d]; s_c[tid] = s_c[tid + d]; }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    bg = s_g[0]; bc = s_c[0];
-    stay_w = fmax(fmax(s_w[0], s_w[1]), fmax(s_w[2], s_w[3]));
-    const double g_stay = stay_w - kvd * (double)(K[cv] - g.kv[v]) * mv.r;
-    bool move = bc != INT32_MAX && bg > g_stay;
-    if (move && size[cv] == 1 && size[bc] == 1 && bc > cv) move = false;
-    int32_t to = move ? bc : cv;
-    if ((move ? bg : g_stay) < 0.0 && size[cv] > 1 && size[v] == 0) { to = (int32_t)v; move = true; }     // see k_lv_move_small
-    next[v] = to;
-    if (move) atomicAdd(moved, 1u);
+  if (tid < LV_MAX_B) {
+    const size_t at = (size_t)blockIdx.x * LV_MAX_B + tid;
+    if (FIRST) { part_in[at] = s_acc[tid]; part_mv[at] = s_cnt[tid]; }
+    else part_mv[at] += s_cnt[tid];
   }
 }
 
-// the vertices of the workgroup path: middle degrees from the front of the list, large ones from its end
-__global__ __launch_bounds__(256) void k_lv_list_big(LvGraph g, int32_t* __restrict__ big, unsigned* __restrict__ n_mid_large) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v >= g.n) return;
-  const int64_t deg = g.ptr[v + 1] - g.ptr[v];
-  if (deg > LV_MID_DEG) big[g.n - 1 - atomicAdd(n_mid_large + 1, 1u)] = (int32_t)v;
-  else if (deg > LV_SMALL_DEG) big[atomicAdd(n_mid_large, 1u)] = (int32_t)v;
-}
-
-// applies the sub-round's moves to the labels, totals and sizes
-__global__ __launch_bounds__(256) void k_lv_apply(int64_t n, LvMove mv, const u64* __restrict__ kv, int32_t* __restrict__ comm,
-                                                  const int32_t* __restrict__ next, u64* __restrict__ K, int32_t* __restrict__ size) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v >= n) return;
-  if (mv.S != 1 && (int)(lv_hash((uint32_t)v + mv.seed) % (uint32_t)mv.S) != mv.s) return;
-  const int32_t a = comm[v], b = next[v];
-  if (a == b) return;
-  const u64 k = kv[v];
-  atomicAdd(&K[a], 0ull - k);
-  atomicAdd(&K[b], k);
-  atomicSub(&size[a], 1);
-  atomicAdd(&size[b], 1);
-  comm[v] = b;
-}
-
-// ---- quality: internal weight (integer) and sum of squared totals (fixed summation order)
-__global__ __launch_bounds__(256) void k_lv_internal(LvGraph g, const int32_t* __restrict__ comm, u64* __restrict__ in_w) {
-  __shared__ u64 s_sum[4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  u64 s = 0;
-  for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < g.n; v += (int64_t)gridDim.x * 4) {
-    const int32_t cv = comm[v];
-    for (int64_t e = g.ptr[v] + lane; e < g.ptr[v + 1]; e += 64) {
-      const int32_t u = g.nbr[e];
-      if (u != v && comm[u] == cv) s += g.wt[e];
-    }
-  }
-  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
-  if (lane == 0) s_sum[wave] = s;
-  __syncthreads();
-  if (threadIdx.x == 0 && (s_sum[0] | s_sum[1] | s_sum[2] | s_sum[3])) atomicAdd(in_w, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
-}
-
-// Sum of the squared community totals, in a fixed order: LV_SQ_BLOCKS slices of the communities, a fixed tree inside each,
-// the slices added up by the host in slice order.
-constexpr int LV_SQ_BLOCKS = 64;
-__global__ __launch_bounds__(256) void k_lv_sumsq(int64_t n, const u64* __restrict__ K, double* __restrict__ part) {
+// Start of an iteration: the sum of the squared community totals of every running component, in a fixed order (LV_SQ_BLOCKS slices
+// of its communities, a fixed tree inside each, the slices added up in slice order by k_lv_decide), and a copy of the totals and sizes
+// as they are now (parity = iteration & 1): what an undo of the NEXT iteration's moves goes back to.
+__global__ __launch_bounds__(256) void k_lv_pre(const LvCtl* __restrict__ ctl, int parity, const u64* __restrict__ K, const int32_t* __restrict__ size,
+                                                u64* __restrict__ snapK, int32_t* __restrict__ snapS, double* __restrict__ part_sq) {
   __shared__ double s_p[256];
-  const int64_t per = (n + LV_SQ_BLOCKS - 1) / LV_SQ_BLOCKS;
-  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  const int b = blockIdx.y;
+  const LvComp& C = ctl->c[b];
+  if (C.level_done) return;
+  (void)parity;
+  const int64_t per = (C.n + LV_SQ_BLOCKS - 1) / LV_SQ_BLOCKS;
+  const int64_t lo = C.v0 + (int64_t)blockIdx.x * per, hi = lo + per < C.v0 + C.n ? lo + per : C.v0 + C.n;
   double s = 0.0;
-  for (int64_t c = lo + threadIdx.x; c < hi; c += 256) { const double k = (double)K[c]; s += k * k; }
+  for (int64_t c = lo + threadIdx.x; c < hi; c += 256) {
+    const u64 kc = K[c];
+    snapK[c] = kc; snapS[c] = size[c];
+    const double k = (double)kc;
+    s += k * k;
+  }
   s_p[threadIdx.x] = s;
   __syncthreads();
   for (int d = 128; d > 0; d >>= 1) {
     if ((int)threadIdx.x < d) s_p[threadIdx.x] += s_p[threadIdx.x + d];
     __syncthreads();
   }
-  if (threadIdx.x == 0) part[blockIdx.x] = s_p[0];
+  if (threadIdx.x == 0) part_sq[b * LV_SQ_BLOCKS + blockIdx.x] = s_p[0];
 }
 
-// ---- reduction of the graph
+// The decision of iteration `it` for every component (one block).  The partial sums of the sub-round-0 kernels give the internal weight
+// of the labels as the iteration found them, i.e. the result of iteration it - 1, and the number of vertices that moved in it:
+//   it == 0: Q of the level's starting labels; go on.           moved == 0: the level has converged.
+//   Q < Q before: simultaneous moves made it worse -> undo iteration it - 1, the level ends.
+//   else accept; a gain below 1e-7 ends the level.              LV_MAX_ITERS iterations: the level ends.
+__global__ __launch_bounds__(1024) void k_lv_decide(LvCtl* ctl, LvParts pt, int nb_small, int nb_mid, int nb_large, int it, double two_w, double q_coef,
+                                                   LvHost* __restrict__ host) {
+  __shared__ u64 s_in[16][LV_MAX_B];
+  __shared__ unsigned s_mv[16][LV_MAX_B];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int B = ctl->B;
+  const int pv = (it & 1) ^ 1;                   // the moved counts of the iteration before this one
+  for (int b = 0; b < B; ++b) {
+    u64 a = 0;
+    unsigned m = 0;
+    for (int r = tid; r < nb_small; r += 1024) { a += pt.in_small[(size_t)r * LV_MAX_B + b]; if (it) m += pt.mv_small[pv][(size_t)r * LV_MAX_B + b]; }
+    for (int r = tid; r < nb_mid; r += 1024) { a += pt.in_mid[(size_t)r * LV_MAX_B + b]; if (it) m += pt.mv_mid[pv][(size_t)r * LV_MAX_B + b]; }
+    for (int r = tid; r < nb_large; r += 1024) { a += pt.in_large[(size_t)r * LV_MAX_B + b]; if (it) m += pt.mv_large[pv][(size_t)r * LV_MAX_B + b]; }
+    a = lv_wave_sum(a);
+    for (int d = 32; d > 0; d >>= 1) m += __shfl_xor(m, d);
+    if (lane == 0) { s_in[wave][b] = a; s_mv[wave][b] = m; }
+  }
+  __syncthreads();
+  __shared__ int s_cont[LV_MAX_B];
+  if (tid < LV_MAX_B) {
+    int cont = 0;
+    if (tid < B) {
+      LvComp& C = ctl->c[tid];
+      if (C.level_done) {
+        C.action = LV_IDLE;
+      } else {
+        u64 in_now = 0;
+        unsigned moved = 0;
+        for (int w = 0; w < 16; ++w) { in_now += s_in[w][tid]; moved += s_mv[w][tid]; }
+        double sq = 0.0;
+        for (int j = 0; j < LV_SQ_BLOCKS; ++j) sq += pt.sq[tid * LV_SQ_BLOCKS + j];
+        const double q = ((double)(in_now + C.self_w)) / two_w - q_coef * sq;          // sq = sum of squared community totals (fixed point)
+        int action;
+        if (C.iter == 0) { C.q_prev = q; C.in_w = in_now; action = LV_CONTINUE; }
+        else if (moved == 0) action = LV_STOP_KEEP;
+        else if (q < C.q_prev) action = LV_STOP_UNDO;
+        else {
+          C.level_moved = 1;
+          C.in_w = in_now;
+          const bool small_gain = q - C.q_prev < 1e-7;
+          C.q_prev = q;
+          action = small_gain ? LV_STOP_KEEP : LV_CONTINUE;
+        }
+        if (action == LV_CONTINUE && C.iter >= LV_MAX_ITERS) action = LV_STOP_KEEP;
+        if (action != LV_CONTINUE) C.level_done = 1;
+        C.action = action;
+        C.iter += 1;
+        cont = action == LV_CONTINUE;
+        host->q_iter[tid] = q;
+      }
+    }
+    s_cont[tid] = cont;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int b = 0; b < LV_MAX_B; ++b) n += s_cont[b];
+    host->n_cont[it] = n;
+    __threadfence_system();
+  }
+}
+
+// Applies the sub-round's moves to the labels, totals and sizes.  Sub-round 0 also carries out the iteration's decision: go on -> keep a
+// copy of the labels as they are (what an undo of this iteration's moves goes back to); undo -> the labels, totals and sizes of one
+// iteration ago come back.
+__global__ __launch_bounds__(256) void k_lv_apply(LvG g, const LvCtl* __restrict__ ctl, int s, int parity, int32_t* __restrict__ comm,
+                                                  const int32_t* __restrict__ next, u64* __restrict__ K, int32_t* __restrict__ size,
+                                                  int32_t* __restrict__ snapc0, int32_t* __restrict__ snapc1, const u64* __restrict__ snapK_prev,
+                                                  const int32_t* __restrict__ snapS_prev) {
+  int32_t* const snap_now = parity ? snapc1 : snapc0;
+  const int32_t* const snap_prev = parity ? snapc0 : snapc1;
+  for (int64_t gv = (int64_t)blockIdx.x * 256 + threadIdx.x; gv < g.n; gv += (int64_t)gridDim.x * 256) {
+    const int64_t b = g.rep > 1 ? gv / g.nb : 0;
+    const int comp = g.vcomp ? (int)g.vcomp[gv] : (int)b;
+    const LvComp& C = ctl->c[comp];
+    const int action = C.action;
+    if (s == 0) {
+      if (action == LV_CONTINUE) snap_now[gv] = comm[gv];
+      else if (action == LV_STOP_UNDO) { comm[gv] = snap_prev[gv]; K[gv] = snapK_prev[gv]; size[gv] = snapS_prev[gv]; }
+    }
+    if (action != LV_CONTINUE || s >= C.S) continue;
+    if (C.S != 1 && (int)(lv_hash((uint32_t)(gv - C.v0) + C.seed) % (uint32_t)C.S) != s) continue;
+    const int32_t a = comm[gv], to = next[gv];
+    if (a == to) continue;
+    const u64 k = g.kv[gv - b * g.nb];
+    atomicAdd(&K[a], 0ull - k);
+    atomicAdd(&K[to], k);
+    atomicSub(&size[a], 1);
+    atomicAdd(&size[to], 1);
+    comm[gv] = to;
+  }
+}
+
+// ---- renumbering
 __global__ __launch_bounds__(256) void k_lv_used(int64_t n, const int32_t* __restrict__ size, int64_t* __restrict__ flag) {
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (c <= n) flag[c] = c < n && size[c] > 0 ? 1 : 0;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c <= n; c += (int64_t)gridDim.x * 256) flag[c] = c < n && size[c] > 0 ? 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void k_lv_coarse_weights(int64_t n, const int32_t* __restrict__ size, const int64_t* __restrict__ newid,
-                                                           const u64* __restrict__ K, u64* __restrict__ kv2) {
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (c < n && size[c] > 0) kv2[newid[c]] = K[c];
+// After the scan: every component's first new id and number of communities; does its descent go on?
+//   (reference loop: runLouvainAlgorithm recurses while the reduced network is smaller, src/ModularityOptimizer.cpp:594-612)
+// refine: a refinement level of algorithm 2 (no descent, the labels are renumbered only).
+__global__ void k_lv_ctl_renumbered(LvCtl* ctl, const int64_t* __restrict__ newid, int64_t n_union, int seeded, int refine, int algorithm, int level,
+                                    LvHost* __restrict__ host) {
+  const int b = threadIdx.x;
+  if (b == 0) { ctl->n_union2 = newid[n_union]; host->n_union2 = newid[n_union]; }
+  if (b >= LV_MAX_B) return;
+  LvComp& C = ctl->c[b];
+  C.newbase = newid[C.v0];
+  C.n2 = C.live ? newid[C.v0 + C.n] - newid[C.v0] : 0;
+  if (C.live) {
+    C.q_final = C.q_prev;
+    C.n_labels = C.n2;
+    if (!refine) {
+      C.any_move |= C.level_moved;
+      const bool done = C.n2 == C.n || C.n2 <= 1 || (!C.level_moved && !(seeded && C.n2 < C.n));      // nothing merged: the descent is done
+      C.cont = done ? 0 : 1;
+      if (C.cont) {
+        C.self_w += C.in_w;
+        if (algorithm == 2 && C.n_saved == level && level < LV_MAX_SAVED) C.saved_n[++C.n_saved] = C.n2;
+      }
+    }
+  } else {
+    C.cont = 0;
+  }
+  host->c[b].n2 = C.n2; host->c[b].q_prev = C.q_prev; host->c[b].cont = C.cont; host->c[b].any_move = C.any_move;
+  host->c[b].level_moved = C.level_moved; host->c[b].live = C.live;
 }
 
-// lab[v] = new id of the community of the level's vertex that original vertex v maps to (src == NULL: v itself)
-__global__ __launch_bounds__(256) void k_lv_relabel(int64_t n, const int32_t* src, const int32_t* __restrict__ comm,
+// lab[b][v] = new LOCAL id (new id - the component's first) of the community of the level's vertex that original vertex v of start b
+// maps to: src == NULL -> v itself (level 0), else src[b][v] (a local vertex id of the level; may be lab itself: one read, one write per thread)
+__global__ __launch_bounds__(256) void k_lv_relabel(int64_t N, const LvCtl* __restrict__ ctl, const int32_t* src, const int32_t* __restrict__ comm,
                                                     const int64_t* __restrict__ newid, int32_t* lab) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v < n) lab[v] = (int32_t)newid[comm[src ? src[v] : v]];        // src may be lab itself: one read, one write per thread
+  const int b = blockIdx.y;
+  const LvComp& C = ctl->c[b];
+  if (!C.live) return;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < N; v += (int64_t)gridDim.x * 256) {
+    const size_t at = (size_t)b * (size_t)N + (size_t)v;
+    const int64_t x = C.v0 + (src ? (int64_t)src[at] : v);
+    lab[at] = (int32_t)(newid[comm[x]] - C.newbase);
+  }
+}
+
+// ---- reduction: the level's graph by the labels newid[comm[.]] -> the next level's (a multigraph in pointerB / pointerE form)
+// Row capacities (the entries of a community's members: no row can need more), vertex weights and components of the new vertices.
+// cap must be zero.  Few communities: the capacities are summed in LDS first (see k_lv_accum).
+__global__ __launch_bounds__(256) void k_lv_rowcap(LvG g, const LvCtl* __restrict__ ctl, const int32_t* __restrict__ comm, const int64_t* __restrict__ newid,
+                                                   const u64* __restrict__ K, const int32_t* __restrict__ size, int64_t* __restrict__ cap,
+                                                   u64* __restrict__ kv2, uint8_t* __restrict__ vcomp2) {
+  __shared__ u64 s_cap[LV_ACC_BINS];
+  const bool binned = ctl->n_union2 <= LV_ACC_BINS;
+  if (binned) {
+    for (int t = threadIdx.x; t < LV_ACC_BINS; t += 256) s_cap[t] = 0ull;
+    __syncthreads();
+  }
+  for (int64_t gv = (int64_t)blockIdx.x * 256 + threadIdx.x; gv < g.n; gv += (int64_t)gridDim.x * 256) {
+    const int64_t b = g.rep > 1 ? gv / g.nb : 0;
+    const int64_t v = gv - b * g.nb;
+    const int comp = g.vcomp ? (int)g.vcomp[gv] : (int)b;
+    const LvComp& C = ctl->c[comp];
+    const int32_t c = comm[gv];
+    if (size[c] <= 0) continue;                           // a vertex of a component that does not take part in the level: not numbered
+    // the new vertex its community becomes: weight and component written by every member alike (the members of a community belong to
+    // one component; a community id need not lie in its component's vertex range: the rebuilt levels of algorithm 2)
+    const int64_t c2 = newid[c];
+    kv2[c2] = C.cont ? K[c] : 0ull;
+    vcomp2[c2] = (uint8_t)comp;
+    if (!C.cont) continue;
+    const u64 deg = (u64)(g.end[v] - g.beg[v]);
+    if (deg == 0) continue;
+    if (binned) atomicAdd(&s_cap[c2], deg);
+    else atomicAdd((u64*)&cap[c2], deg);
+  }
+  if (binned) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < LV_ACC_BINS; t += 256)
+      if (s_cap[t]) atomicAdd((u64*)&cap[t], s_cap[t]);
+  }
+}
+
+// One wave per vertex and copy (at most LV_SMALL_DEG entries): the entries summed per neighbouring NEW community; one entry per
+// community is appended to the row of the vertex's own new community (cur: the rows' fill counts).  Entries inside the community
+// are dropped (their weight is carried as the level's internal weight).
+__global__ __launch_bounds__(256) void k_lv_emit_small(LvG g, const LvCtl* __restrict__ ctl, const int32_t* __restrict__ comm, const int64_t* __restrict__ newid,
+                                                       const int64_t* __restrict__ beg2, int32_t* __restrict__ cur, int32_t* __restrict__ nbr2,
+                                                       u64* __restrict__ wt2) {
+  __shared__ int32_t s_key[4][LV_SMALL_SLOTS];
+  __shared__ u64 s_val[4][LV_SMALL_SLOTS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int32_t* key = s_key[wave];
+  u64* val = s_val[wave];
+  for (int t = lane; t < LV_SMALL_SLOTS; t += 64) { key[t] = -1; val[t] = 0ull; }
+  lv_wave_sync();
+  const u64 lt = (1ull << lane) - 1ull;
+  for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < g.nb; v += (int64_t)gridDim.x * 4) {
+    const int64_t lo = g.beg[v], hi = g.end[v];
+    if (hi - lo > LV_SMALL_DEG || hi == lo) continue;
+    const int64_t e0 = lo + lane, e1 = e0 + 64;
+    int32_t u0 = -1, u1 = -1;
+    u64 w0 = 0, w1 = 0;
+    if (e0 < hi) { u0 = g.nbr[e0]; w0 = g.wt[e0]; if (u0 == v) u0 = -1; }
+    if (e1 < hi) { u1 = g.nbr[e1]; w1 = g.wt[e1]; if (u1 == v) u1 = -1; }
+    for (int b = 0; b < g.rep; ++b) {
+      const int comp = g.vcomp ? (int)g.vcomp[v] : b;
+      if (!ctl->c[comp].cont) continue;
+      const int64_t base = (int64_t)b * g.nb;
+      const int32_t cv = (int32_t)newid[comm[base + v]];
+      int32_t c0 = u0 >= 0 ? (int32_t)newid[comm[base + u0]] : -1, c1 = u1 >= 0 ? (int32_t)newid[comm[base + u1]] : -1;
+      if (c0 == cv) c0 = -1;
+      if (c1 == cv) c1 = -1;
+      int slot0 = -1, slot1 = -1;
+      bool own0 = false, own1 = false;
+      if (c0 >= 0) {
+        uint32_t h = lv_hash((uint32_t)c0) & (LV_SMALL_SLOTS - 1);
+        for (;;) {
+          const int32_t old = atomicCAS(&key[h], -1, c0);
+          if (old == -1) { own0 = true; break; }
+          if (old == c0) break;
+          h = (h + 1) & (LV_SMALL_SLOTS - 1);
+        }
+        slot0 = (int)h;
+        atomicAdd(&val[h], w0);
+      }
+      if (c1 >= 0) {
+        uint32_t h = lv_hash((uint32_t)c1) & (LV_SMALL_SLOTS - 1);
+        for (;;) {
+          const int32_t old = atomicCAS(&key[h], -1, c1);
+          if (old == -1) { own1 = true; break; }
+          if (old == c1) break;
+          h = (h + 1) & (LV_SMALL_SLOTS - 1);
+        }
+        slot1 = (int)h;
+        atomicAdd(&val[h], w1);
+      }
+      lv_wave_sync();
+      const u64 m0 = __ballot(own0), m1 = __ballot(own1);
+      const int n0 = __popcll(m0), total = n0 + __popcll(m1);
+      int32_t p = 0;
+      if (lane == 0 && total) p = atomicAdd(&cur[cv], total);
+      p = __shfl(p, 0);
+      const int64_t row = beg2[cv];
+      if (own0) {
+        const int64_t at = row + p + __popcll(m0 & lt);
+        nbr2[at] = c0; wt2[at] = val[slot0];
+        key[slot0] = -1; val[slot0] = 0ull;
+      }
+      if (own1) {
+        const int64_t at = row + p + n0 + __popcll(m1 & lt);
+        nbr2[at] = c1; wt2[at] = val[slot1];
+        key[slot1] = -1; val[slot1] = 0ull;
+      }
+      lv_wave_sync();
+    }
+  }
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) void k_lv_emit_big(LvG g, const LvCtl* __restrict__ ctl, int large, int64_t n_list, const int32_t* __restrict__ big,
+                                                     const int32_t* __restrict__ comm, const int64_t* __restrict__ newid, const int64_t* __restrict__ beg2,
+                                                     int32_t* __restrict__ cur, int32_t* __restrict__ nbr2, u64* __restrict__ wt2,
+                                                     uint32_t* __restrict__ status) {
+  extern __shared__ unsigned char s_raw[];
+  u64* val = (u64*)s_raw;
+  int32_t* key = (int32_t*)(val + SLOTS);
+  __shared__ int s_n;
+  __shared__ int32_t s_base;
+  const int tid = threadIdx.x;
+  const int32_t* list = large ? big + (g.nb - n_list) : big;
+  for (int64_t item = blockIdx.x; item < n_list * g.rep; item += gridDim.x) {
+    const int b = (int)(item / n_list);
+    const int64_t v = list[item - (int64_t)b * n_list];
+    const int comp = g.vcomp ? (int)g.vcomp[v] : b;
+    if (!ctl->c[comp].cont) continue;
+    const int64_t base = (int64_t)b * g.nb;
+    const int64_t lo = g.beg[v], hi = g.end[v];
+    const int32_t cv = (int32_t)newid[comm[base + v]];
+    const int64_t row = beg2[cv];
+    const uint32_t P = (uint32_t)((hi - lo + SLOTS / 2 - 1) / (SLOTS / 2));
+    for (uint32_t p = 0; p < (P ? P : 1u); ++p) {
+      for (int t = tid; t < SLOTS; t += 256) { key[t] = -1; val[t] = 0ull; }
+      if (tid == 0) s_n = 0;
+      __syncthreads();
+      for (int64_t e = lo + tid; e < hi; e += 256) {
+        const int32_t u = g.nbr[e];
+        if (u == v) continue;
+        const int32_t c = (int32_t)newid[comm[base + u]];
+        if (c == cv) continue;
+        const uint32_t hc = lv_hash((uint32_t)c);
+        if (P > 1 && (hc >> 13) % P != p) continue;
+        uint32_t h = hc & (SLOTS - 1);
+        int probes = 0;
+        for (;;) {
+          const int32_t old = atomicCAS(&key[h], -1, c);
+          if (old == -1 || old == c) { atomicAdd(&val[h], g.wt[e]); break; }
+          h = (h + 1) & (SLOTS - 1);
+          if (++probes >= SLOTS) { atomicOr(status, GFICF_ST_TOO_DENSE); break; }
+        }
+      }
+      __syncthreads();
+      int mine = 0;
+      for (int t = tid; t < SLOTS; t += 256) mine += key[t] >= 0 ? 1 : 0;
+      const int rank0 = mine ? atomicAdd(&s_n, mine) : 0;
+      __syncthreads();
+      if (tid == 0) s_base = s_n ? atomicAdd(&cur[cv], s_n) : 0;
+      __syncthreads();
+      int64_t at = row + s_base + rank0;
+      for (int t = tid; t < SLOTS; t += 256)
+        if (key[t] >= 0) { nbr2[at] = key[t]; wt2[at] = val[t]; ++at; }
+      __syncthreads();
+    }
+  }
+}
+
+// end2 = beg2 + fill count
+__global__ __launch_bounds__(256) void k_lv_finish_rows(const int64_t* __restrict__ n_dev, const int64_t* __restrict__ beg2, const int32_t* __restrict__ cur,
+                                                        int64_t* __restrict__ end2) {
+  const int64_t n = *n_dev;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n; c += (int64_t)gridDim.x * 256) end2[c] = beg2[c] + cur[c];
+}
+
+// the list counts of the next level's graph, where the host reads them after the level's one synchronisation
+__global__ void k_lv_ctl_publish(const LvCtl* __restrict__ ctl, LvHost* __restrict__ host) {
+  if (threadIdx.x == 0) { host->n_mid = ctl->n_mid; host->n_large = ctl->n_large; __threadfence_system(); }
+}
+
+// ---- algorithm 2: the levels on the way back up
+// The participants of refinement level `level` (starts that moved in this pass and saved that level), their vertex ranges (prefix of
+// the saved sizes), and — level >= 1 — the base their level vertices get as labels of the finest graph (seed_base).
+__global__ void k_lv_ctl_refine(LvCtl* ctl, int level, int64_t N) {
+  __shared__ int64_t s_n[LV_MAX_B];
+  const int b = threadIdx.x;
+  const int B = ctl->B;
+  if (b < LV_MAX_B) {
+    LvComp& C = ctl->c[b];
+    C.live = b < B && !C.finished && C.any_move && C.n_saved >= level;
+    s_n[b] = C.live ? (level ? C.saved_n[level] : N) : 0;
+  }
+  __syncthreads();
+  if (b < LV_MAX_B) {
+    LvComp& C = ctl->c[b];
+    int64_t base = 0;
+    for (int t = 0; t < b; ++t) base += s_n[t];
+    if (level == 0) { C.v0 = b < B ? (int64_t)b * N : 0; C.n = b < B ? N : 0; }
+    else { C.v0 = base; C.n = s_n[b]; }
+    C.seed_base = C.v0;
+    C.self_w = 0;                          // level 0: nothing is folded into the vertices; a rebuilt level: set by k_lv_ctl_self
+    C.newbase = C.v0; C.n2 = C.n;          // the level's vertices ARE the new ids of the rebuilding reduction
+    C.cont = C.live;                       // ... which every participant takes part in
+    if (b == LV_MAX_B - 1) ctl->n_union2 = base + s_n[b];
+  }
+}
+
+// internal weight of given labels on the level's graph, per component (per-block partial sums in the slots of the small path)
+__global__ __launch_bounds__(256) void k_lv_internal(LvG g, const LvCtl* __restrict__ ctl, const int32_t* __restrict__ comm, u64* __restrict__ part_in) {
+  __shared__ u64 s_acc[4][LV_MAX_B];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  u64 acc = 0;
+  for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < g.nb; v += (int64_t)gridDim.x * 4) {
+    for (int b = 0; b < g.rep; ++b) {
+      const int comp = g.vcomp ? (int)g.vcomp[v] : b;
+      if (!ctl->c[comp].live) continue;
+      const int64_t base = (int64_t)b * g.nb;
+      const int32_t cv = comm[base + v];
+      u64 s = 0;
+      for (int64_t e = g.beg[v] + lane; e < g.end[v]; e += 64) {
+        const int32_t u = g.nbr[e];
+        if (u != v && comm[base + u] == cv) s += g.wt[e];
+      }
+      s = lv_wave_sum(s);
+      if (lane == comp) acc += s;
+    }
+  }
+  if (lane < LV_MAX_B) s_acc[wave][lane] = acc;
+  __syncthreads();
+  if (threadIdx.x < LV_MAX_B) part_in[(size_t)blockIdx.x * LV_MAX_B + threadIdx.x] = s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x];
+}
+
+// self_w of the refinement level = the sum of those partial sums
+__global__ __launch_bounds__(256) void k_lv_ctl_self(LvCtl* ctl, const u64* __restrict__ part_in, int nb) {
+  __shared__ u64 s_in[4][LV_MAX_B];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int b = 0; b < LV_MAX_B; ++b) {
+    u64 a = 0;
+    for (int r = tid; r < nb; r += 256) a += part_in[(size_t)r * LV_MAX_B + b];
+    a = lv_wave_sum(a);
+    if (lane == 0) s_in[wave][b] = a;
+  }
+  __syncthreads();
+  if (tid < LV_MAX_B) ctl->c[tid].self_w = ctl->c[tid].live ? s_in[0][tid] + s_in[1][tid] + s_in[2][tid] + s_in[3][tid] : 0ull;
+}
+
+// seedl[x] = the label of the original vertices that make up level vertex x (they all carry the same one)
+__global__ __launch_bounds__(256) void k_lv_seed(int64_t N, const LvCtl* __restrict__ ctl, const int32_t* __restrict__ top, const int32_t* __restrict__ lab,
+                                                 int32_t* __restrict__ seedl) {
+  const int b = blockIdx.y;
+  const LvComp& C = ctl->c[b];
+  if (!C.live) return;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < N; v += (int64_t)gridDim.x * 256) {
+    const size_t at = (size_t)b * (size_t)N + (size_t)v;
+    seedl[C.v0 + top[at]] = lab[at];
+  }
 }
 
 __global__ __launch_bounds__(256) void k_lv_iota(int64_t n, int64_t* __restrict__ out) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v < n) out[v] = v;
-}
-
-// seed[x] = the label of the original vertices that make up level vertex x (they all carry the same one)
-__global__ __launch_bounds__(256) void k_lv_seed(int64_t n, const int32_t* __restrict__ top, const int32_t* __restrict__ lab,
-                                                 int32_t* __restrict__ seed) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (v < n) seed[top[v]] = lab[v];
-}
-
-// none = n2 << 32: the key of an entry that stays inside a community; it sorts behind every kept key
-__global__ __launch_bounds__(256) void k_lv_emit(LvGraph g, const int32_t* __restrict__ comm, const int64_t* __restrict__ newid, u64 none,
-                                                 u64* __restrict__ keys, u64* __restrict__ vals) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t v = (int64_t)blockIdx.x * 4 + wave;
-  if (v >= g.n) return;
-  const u64 cv = (u64)newid[comm[v]];
-  for (int64_t e = g.ptr[v] + lane; e < g.ptr[v + 1]; e += 64) {
-    const int32_t u = g.nbr[e];
-    u64 k = none;
-    if (u != v) {
-      const u64 cu = (u64)newid[comm[u]];
-      if (cu != cv) k = (cv << 32) | cu;
-    }
-    keys[e] = k;
-    vals[e] = g.wt[e];
-  }
-}
-
-// flag[e] = 1 where a new (row, col) starts; flag[m] = 0 (the scan turns it into the number of coarse entries)
-__global__ __launch_bounds__(256) void k_lv_heads(const u64* __restrict__ keys, int64_t m, u64 none, int64_t* __restrict__ flag) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e > m) return;
-  int64_t f = 0;
-  if (e < m) {
-    const u64 k = keys[e];
-    f = (k != none && (e == 0 || keys[e - 1] != k)) ? 1 : 0;
-  }
-  flag[e] = f;
-}
-
-// pos = exclusive scan of the head flags: entry e belongs to coarse entry pos[e + 1] - 1.  A workgroup takes LV_RED_CHUNK
-// consecutive sorted entries, sums them per coarse entry in LDS (their positions span less than the chunk) and adds
-// each sum once: a graph reduced to a handful of communities would otherwise put millions of atomics on a few addresses.
-constexpr int LV_RED_CHUNK = 4096;
-__global__ __launch_bounds__(256) void k_lv_reduce(const u64* __restrict__ keys, const u64* __restrict__ vals, int64_t m, u64 none,
-                                                   const int64_t* __restrict__ pos, int32_t* __restrict__ nbr2, u64* __restrict__ wt2,
-                                                   int64_t* __restrict__ row_cnt) {
-  __shared__ u64 s_w[LV_RED_CHUNK];
-  const int64_t e0 = (int64_t)blockIdx.x * LV_RED_CHUNK, e1 = e0 + LV_RED_CHUNK < m ? e0 + LV_RED_CHUNK : m;
-  if (keys[e0] == none) return;                  // the dropped entries sort last: nothing kept in this chunk
-  for (int t = threadIdx.x; t < LV_RED_CHUNK; t += 256) s_w[t] = 0ull;
-  __syncthreads();
-  const int64_t p_lo = pos[e0 + 1] - 1;
-  for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
-    const u64 k = keys[e];
-    if (k == none) break;
-    const int64_t p = pos[e + 1] - 1;
-    atomicAdd(&s_w[p - p_lo], vals[e]);
-    if (pos[e + 1] != pos[e]) {                   // a head
-      nbr2[p] = (int32_t)(k & 0xffffffffull);
-      atomicAdd((u64*)&row_cnt[k >> 32], 1ull);
-    }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < LV_RED_CHUNK; t += 256)
-    if (s_w[t]) atomicAdd(&wt2[p_lo + t], s_w[t]);
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v <= n; v += (int64_t)gridDim.x * 256) out[v] = v;
 }
 
 // ---- final numbering: clusters by decreasing size, ties by id (Clustering::orderClustersByNNodes, reference :132-158)
+__global__ __launch_bounds__(256) void k_lv_count(int64_t n, int64_t C, const int32_t* __restrict__ lab, int32_t* __restrict__ cnt) {
+  __shared__ int32_t s_n[LV_ACC_BINS];
+  const bool binned = C <= LV_ACC_BINS;
+  if (binned) {
+    for (int t = threadIdx.x; t < C; t += 256) s_n[t] = 0;
+    __syncthreads();
+  }
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n; v += (int64_t)gridDim.x * 256) {
+    if (binned) atomicAdd(&s_n[lab[v]], 1);
+    else atomicAdd(&cnt[lab[v]], 1);
+  }
+  if (binned) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < C; t += 256)
+      if (s_n[t]) atomicAdd(&cnt[t], s_n[t]);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_lv_size_keys(int64_t C, int64_t n, const int32_t* __restrict__ cnt, u64* __restrict__ keys,
                                                       u64* __restrict__ ids) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -482,6 +1054,11 @@ __global__ __launch_bounds__(256) void k_lv_final(int64_t n, const int32_t* __re
                                                   int32_t* __restrict__ out) {
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (v < n) out[v] = rank[lab[v]];
+}
+
+__global__ __launch_bounds__(256) void k_lv_iota32(int64_t n, int32_t* __restrict__ out) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v < n) out[v] = (int32_t)v;
 }
 
 // ---- host side
@@ -502,81 +1079,99 @@ static size_t lv_sort_tmp_bytes(int64_t m) {
   return tmp;
 }
 
-struct LvLevel {          // a coarse graph's arrays
-  int64_t* ptr; int32_t* nbr; u64* wt; u64* kv;
+struct LvLevel {          // a coarse graph's arrays (capacity: the union's entries)
+  int64_t* beg; int64_t* end; int32_t* nbr; u64* wt; u64* kv; uint8_t* vcomp; int32_t* big;
 };
 
 struct LvWs {
-  u64* wt0; u64* kv0;
+  u64* wt0; u64* kv0; int32_t* big0;
   LvLevel lvl[2];
-  int32_t *comm, *next, *snap_comm, *size, *snap_size, *big, *lab, *cnt, *rank, *tops, *best;
-  u64 *K, *snap_K;
-  int64_t* flag;            // max(n, m) + 1 entries: scans
-  u64 *keys_a, *vals_a, *keys_b, *vals_b;
+  int32_t *comm, *next, *snapc[2], *size, *snapS[2], *cur, *lab, *seedl, *tops, *best, *cnt, *rank;
+  u64 *K, *snapK[2];
+  int64_t* flag;            // n_union + 1 entries: the renumbering scan
+  int64_t* cap;             // n_union + 1 entries: row capacities -> row starts of the next level
+  u64 *keys_a, *vals_a, *keys_b, *vals_b;      // final numbering (N entries)
   void* sort_tmp; size_t sort_tmp_bytes;
-  double* sq_part;          // LV_SQ_BLOCKS partial sums of squared community totals
-  u64* scalars;             // [0] 2W, [1] internal weight, [2] moved (unsigned), [3] unused, [4] n_mid | n_large, [5] largest weight
+  LvParts pt;
+  LvCtl* ctl;
+  u64* scalars;             // [0] 2W, [5] largest weight
 };
 
-static size_t lv_carve(LvWs* w, void* base, int64_t N, int64_t nnz) {
+// the workspace of B starts run together
+static size_t lv_carve(LvWs* w, void* base, int64_t N, int64_t nnz, int B) {
   Bump b{(char*)base, 0, 0};
   const size_t n = (size_t)(N > 0 ? N : 1), m = (size_t)(nnz > 0 ? nnz : 1);
+  const size_t nu = n * (size_t)B, mu = m * (size_t)B;
   LvWs d;
-  d.wt0 = b.take<u64>(m); d.kv0 = b.take<u64>(n);
+  d.wt0 = b.take<u64>(m); d.kv0 = b.take<u64>(n); d.big0 = b.take<int32_t>(n);
   for (int i = 0; i < 2; ++i) {
-    d.lvl[i].ptr = b.take<int64_t>(n + 1); d.lvl[i].nbr = b.take<int32_t>(m); d.lvl[i].wt = b.take<u64>(m); d.lvl[i].kv = b.take<u64>(n);
+    d.lvl[i].beg = b.take<int64_t>(nu + 1); d.lvl[i].end = b.take<int64_t>(nu + 1); d.lvl[i].nbr = b.take<int32_t>(mu); d.lvl[i].wt = b.take<u64>(mu);
+    d.lvl[i].kv = b.take<u64>(nu); d.lvl[i].vcomp = b.take<uint8_t>(nu); d.lvl[i].big = b.take<int32_t>(nu);
   }
-  d.comm = b.take<int32_t>(n); d.next = b.take<int32_t>(n); d.snap_comm = b.take<int32_t>(n);
-  d.size = b.take<int32_t>(n); d.snap_size = b.take<int32_t>(n); d.big = b.take<int32_t>(n);
-  d.lab = b.take<int32_t>(n); d.cnt = b.take<int32_t>(n); d.rank = b.take<int32_t>(n);
-  d.tops = b.take<int32_t>(n * LV_MAX_SAVED);
-  d.best = b.take<int32_t>(n);
-  d.K = b.take<u64>(n); d.snap_K = b.take<u64>(n);
-  d.flag = b.take<int64_t>((n > m ? n : m) + 1);
-  d.keys_a = b.take<u64>(m > n ? m : n); d.vals_a = b.take<u64>(m > n ? m : n);
-  d.keys_b = b.take<u64>(m > n ? m : n); d.vals_b = b.take<u64>(m > n ? m : n);
-  d.sort_tmp_bytes = lv_sort_tmp_bytes((int64_t)(m > n ? m : n));
+  d.comm = b.take<int32_t>(nu); d.next = b.take<int32_t>(nu); d.size = b.take<int32_t>(nu); d.cur = b.take<int32_t>(nu);
+  d.lab = b.take<int32_t>(nu); d.seedl = b.take<int32_t>(nu);
+  for (int i = 0; i < 2; ++i) { d.snapc[i] = b.take<int32_t>(nu); d.snapS[i] = b.take<int32_t>(nu); d.snapK[i] = b.take<u64>(nu); }
+  d.tops = b.take<int32_t>(nu * LV_MAX_SAVED);
+  d.best = b.take<int32_t>(n); d.cnt = b.take<int32_t>(n); d.rank = b.take<int32_t>(n);
+  d.K = b.take<u64>(nu);
+  d.flag = b.take<int64_t>(nu + 1);
+  d.cap = b.take<int64_t>(nu + 1);
+  d.keys_a = b.take<u64>(n); d.vals_a = b.take<u64>(n); d.keys_b = b.take<u64>(n); d.vals_b = b.take<u64>(n);
+  d.sort_tmp_bytes = lv_sort_tmp_bytes((int64_t)n);
   d.sort_tmp = b.take<char>(d.sort_tmp_bytes);
+  d.pt.in_small = b.take<u64>((size_t)LV_GRID * LV_MAX_B); d.pt.in_mid = b.take<u64>((size_t)LV_GRID_BIG * LV_MAX_B);
+  d.pt.in_large = b.take<u64>((size_t)LV_GRID_BIG * LV_MAX_B);
+  for (int i = 0; i < 2; ++i) {
+    d.pt.mv_small[i] = b.take<unsigned>((size_t)LV_GRID * LV_MAX_B); d.pt.mv_mid[i] = b.take<unsigned>((size_t)LV_GRID_BIG * LV_MAX_B);
+    d.pt.mv_large[i] = b.take<unsigned>((size_t)LV_GRID_BIG * LV_MAX_B);
+  }
+  d.pt.sq = b.take<double>((size_t)LV_MAX_B * LV_SQ_BLOCKS);
+  d.ctl = b.take<LvCtl>(1);
   d.scalars = b.take<u64>(8);
-  d.sq_part = b.take<double>(LV_SQ_BLOCKS);
   if (w) *w = d;
   return b.off + 256;
 }
 
 static inline unsigned lv_blocks(int64_t n, int per) { return (unsigned)gficf_ceil_div(n > 0 ? n : 1, per); }
+static inline unsigned lv_grid(int64_t n, int per, unsigned cap) { const unsigned b = lv_blocks(n, per); return b < cap ? b : cap; }
 
-static int lv_sub_rounds(int64_t n) {
+static int lv_env_sub_rounds() {
   if (const char* e = getenv("GFICF_LOUVAIN_SUBROUNDS")) { const int s = atoi(e); if (s >= 1 && s <= 64) return s; }
-  return n > 50000 ? 2 : n > 4000 ? 4 : n > 400 ? 8 : 16;
+  return 0;
 }
 
-struct LvQ { double q; u64 in_w; };
-
-// Q of the current labels on graph g (self = weight already folded into the vertices), deterministic.
-static int lv_quality(gficf_ctx* ctx, const LvGraph& g, const LvWs& w, u64 self_w, double two_w, double q_coef, double* q_out, u64* in_out) {
-  GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 1, 0, sizeof(u64), ctx->stream));
-  hipLaunchKernelGGL(k_lv_internal, dim3(lv_blocks(g.n, 4) < 2048u ? lv_blocks(g.n, 4) : 2048u), dim3(256), 0, ctx->stream, g, w.comm, w.scalars + 1);
-  hipLaunchKernelGGL(k_lv_sumsq, dim3(LV_SQ_BLOCKS), dim3(256), 0, ctx->stream, g.n, w.K, w.sq_part);
-  u64 h[4];
-  double hp[LV_SQ_BLOCKS];
-  GFICF_HIP_CHECK(hipMemcpyAsync(h, w.scalars, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
-  GFICF_HIP_CHECK(hipMemcpyAsync(hp, w.sq_part, sizeof(hp), hipMemcpyDeviceToHost, ctx->stream));
-  GFICF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-  double sq = 0.0;
-  for (int i = 0; i < LV_SQ_BLOCKS; ++i) sq += hp[i];
-  *in_out = h[1];
-  *q_out = ((double)(h[1] + self_w)) / two_w - q_coef * sq;          // sq = sum of squared community totals (fixed point)
-  return GFICF_OK;
+// starts run together: as many as the workspace holds (GFICF_LOUVAIN_BATCH in the environment: at most that many — 1 = one after the other)
+static int lv_batch_limit() {
+  if (const char* e = getenv("GFICF_LOUVAIN_BATCH")) { const int b = atoi(e); if (b >= 1 && b <= LV_MAX_B) return b; }
+  return LV_MAX_B;
 }
 
 }  // namespace
 
+// the pinned block the control kernels report into, and the two events of the one-iteration-ahead loop (ctx.hip releases them)
+int gficf_lv_host_get(gficf_ctx* ctx, void** host, hipEvent_t* ev) {
+  if (!ctx->lv_host) {
+    GFICF_HIP_CHECK(hipHostMalloc(&ctx->lv_host, sizeof(LvHost), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ctx->lv_host, 0, sizeof(LvHost));
+    for (int i = 0; i < 2; ++i) GFICF_HIP_CHECK(hipEventCreateWithFlags(&ctx->lv_ev[i], hipEventDisableTiming));
+  }
+  *host = ctx->lv_host;
+  ev[0] = ctx->lv_ev[0]; ev[1] = ctx->lv_ev[1];
+  return GFICF_OK;
+}
+
 extern "C" {
 
-size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz) {
+size_t gficf_louvain_workspace_bytes_starts(int64_t N, int64_t nnz, int n_start) {
   if (N < 0 || nnz < 0) return 0;
-  return lv_carve(nullptr, nullptr, N, nnz);
+  int B = n_start < 1 ? 1 : n_start > LV_MAX_B ? LV_MAX_B : n_start;
+  const int lim = lv_batch_limit();
+  if (B > lim) B = lim;
+  while (B > 1 && (int64_t)B * N > (int64_t)INT32_MAX) --B;      // union vertex ids are int32
+  return lv_carve(nullptr, nullptr, N, nnz, B);
 }
+
+size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz) { return gficf_louvain_workspace_bytes_starts(N, nnz, 1); }
 
 int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, const int32_t* d_indices, const double* d_x, int64_t nnz,
                          double resolution, int algorithm, int n_start, int n_iter, int seed, int32_t* d_labels, int64_t* n_clusters, double* modularity, void* d_ws,
@@ -593,30 +1188,41 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   if (N > INT32_MAX) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "more than 2^31 - 1 vertices");
   if (ws_bytes < gficf_louvain_workspace_bytes(N, nnz))
     GFICF_FAIL(GFICF_ERR_INVALID_ARG, "workspace too small: %zu < %zu bytes", ws_bytes, gficf_louvain_workspace_bytes(N, nnz));
+  // as many starts together as the caller's workspace holds (gficf_louvain_workspace_bytes_starts sizes it for all of them)
+  int Bmax = n_start < LV_MAX_B ? n_start : LV_MAX_B;
+  if (Bmax > lv_batch_limit()) Bmax = lv_batch_limit();
+  while (Bmax > 1 && ((int64_t)Bmax * N > (int64_t)INT32_MAX || lv_carve(nullptr, nullptr, N, nnz, Bmax) > ws_bytes)) --Bmax;
   static std::atomic<bool> attr_set[64];                 // per device: the attribute belongs to the device's copy of the kernel
   if (!attr_set[ctx->device & 63]) {
-    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_lv_move_big<LV_BIG_SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_BIG_SLOTS * 12));
+    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_lv_move_big<LV_BIG_SLOTS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_BIG_SLOTS * 12));
+    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_lv_move_big<LV_BIG_SLOTS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_BIG_SLOTS * 12));
+    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_lv_emit_big<LV_BIG_SLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, LV_BIG_SLOTS * 12));
     attr_set[ctx->device & 63] = true;
   }
   LvWs w;
-  lv_carve(&w, d_ws, N, nnz);
+  lv_carve(&w, d_ws, N, nnz, Bmax);
   hipStream_t st = ctx->stream;
+  void* host_v = nullptr;
+  hipEvent_t ev[2];
+  int rc = gficf_lv_host_get(ctx, &host_v, ev);
+  if (rc) return rc;
+  LvHost* const host = (LvHost*)host_v;
 
-  // level 0: fixed-point weights, vertex weights, 2W
+  // level 0: fixed-point weights, vertex weights, 2W, the vertices of the workgroup path
   GFICF_HIP_CHECK(hipMemsetAsync(w.scalars, 0, 8 * sizeof(u64), st));
+  GFICF_HIP_CHECK(hipMemsetAsync(w.ctl, 0, sizeof(LvCtl), st));
   if (nnz > 0) hipLaunchKernelGGL(k_lv_fix, dim3(lv_blocks(nnz, 256) < 2048u ? lv_blocks(nnz, 256) : 2048u), dim3(256), 0, st, N, nnz, d_indices, d_x, w.wt0, w.scalars + 5, ctx->d_status);
-  LvGraph g0{N, nnz, d_indptr, d_indices, w.wt0, w.kv0};
-  hipLaunchKernelGGL(k_lv_vertex_weight, dim3(lv_blocks(N, 256)), dim3(256), 0, st, g0, w.kv0, w.scalars, ctx->d_status);
+  hipLaunchKernelGGL(k_lv_vertex_weight, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, nnz, d_indptr, d_indices, w.wt0, w.kv0, w.scalars, ctx->d_status);
   u64 h_sc[6] = {0, 0, 0, 0, 0, 0};
   GFICF_HIP_CHECK(hipMemcpyAsync(h_sc, w.scalars, sizeof(h_sc), hipMemcpyDeviceToHost, st));
-  int rc = gficf_ctx_sync(ctx);                    // also reports a malformed matrix before anything follows it
+  rc = gficf_ctx_sync(ctx);                        // also reports a malformed matrix before anything follows it
   if (rc) return rc;
   const u64 two_w_fix = h_sc[0];
   if ((double)h_sc[5] * (double)nnz >= 9.0e18)     // the u64 sums (2W, community totals) could wrap
     GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "edge weights too large for the 2^-32 fixed-point sums (largest weight x entries >= 2^31): scale the matrix");
   const double two_w = (double)two_w_fix;
   if (two_w_fix == 0) {                            // no edges: every vertex is its own cluster, Q = 0
-    hipLaunchKernelGGL(k_lv_init, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, w.kv0, d_labels, w.K, w.size);
+    hipLaunchKernelGGL(k_lv_iota32, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, d_labels);
     GFICF_HIP_CHECK(hipStreamSynchronize(st));
     *n_clusters = N;
     return GFICF_OK;
@@ -628,109 +1234,116 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   if (alt) hipLaunchKernelGGL(k_lv_fill_u64, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, (u64)LV_SCALE, w.kv0);
   const double r = alt ? resolution / LV_SCALE : resolution / two_w;
   const double q_coef = alt ? resolution / (LV_SCALE * two_w) : resolution / (two_w * two_w);
-  double q_final = 0.0;
-  bool have_labels = false;
-  int64_t n_labels = 0;                          // labels of the previous pass lie in [0, n_labels)
+  const int s_env = lv_env_sub_rounds();
+  const bool debug = getenv("GFICF_LOUVAIN_DEBUG") != nullptr;      // per-level trace on stderr
 
-  // ---- the steps of one level (host side; every one ends synchronised or enqueues on the context's stream)
-  double q_prev = 0.0;                           // Q of the labels the level holds
-  u64 in_w = 0;                                  // their internal weight on the level's graph
-  unsigned n_mid = 0, n_large = 0;
-  uint32_t start_seed = 0;                       // of the sub-round class hash (what a "random start" varies)
-  const auto grid_cap = [](unsigned b) { return b < 1024u ? b : 1024u; };
-  const bool debug = getenv("GFICF_LOUVAIN_DEBUG") != nullptr;      // per-iteration trace on stderr
-  // labels (seed == NULL: singletons), totals, sizes, the workgroup-path vertex lists, Q
-  const auto start_level = [&](const LvGraph& g, const int32_t* seed, int64_t seed_labels, u64 self_w) -> int {
-    if (seed) {
-      GFICF_HIP_CHECK(hipMemsetAsync(w.K, 0, sizeof(u64) * (size_t)g.n, st));
-      GFICF_HIP_CHECK(hipMemsetAsync(w.size, 0, sizeof(int32_t) * (size_t)g.n, st));
-      hipLaunchKernelGGL(k_lv_accum, dim3(grid_cap(lv_blocks(g.n, 256))), dim3(256), 0, st, g.n, seed_labels, seed, g.kv, w.comm, w.K, w.size);
-    } else {
-      hipLaunchKernelGGL(k_lv_init, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, g.kv, w.comm, w.K, w.size);
-    }
-    GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 4, 0, sizeof(u64), st));
-    hipLaunchKernelGGL(k_lv_list_big, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g, w.big, (unsigned*)(w.scalars + 4));
-    unsigned h_cnt[2] = {0, 0};                  // vertices of middle and of large degree
-    GFICF_HIP_CHECK(hipMemcpyAsync(h_cnt, w.scalars + 4, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
-    const int rc2 = lv_quality(ctx, g, w, self_w, two_w, q_coef, &q_prev, &in_w);
-    n_mid = h_cnt[0]; n_large = h_cnt[1];
-    return rc2;
+  // the finest graph's workgroup-path vertices: the same for every start, level-0 pass and batch
+  LvG g00{N, N, 1, d_indptr, d_indptr + 1, d_indices, w.wt0, w.kv0, nullptr};
+  hipLaunchKernelGGL(k_lv_list_big, dim3(lv_grid(N, 256, 1024)), dim3(256), 0, st, g00, (const int64_t*)nullptr, w.big0, &w.ctl->n_mid);
+  hipLaunchKernelGGL(k_lv_ctl_publish, dim3(1), dim3(64), 0, st, (const LvCtl*)w.ctl, host);
+  GFICF_HIP_CHECK(hipStreamSynchronize(st));
+  const unsigned n_mid0 = host->n_mid, n_large0 = host->n_large;
+
+  // ---- one level's steps; g = the level's union graph, big = its workgroup-path lists, (n_mid, n_large) their sizes
+  struct Lists { const int32_t* big; unsigned n_mid, n_large; };
+  // the labels as given (seed == NULL: singletons), totals, sizes
+  const auto start_level = [&](const LvG& g, const int32_t* seed, bool binned) {
+    hipLaunchKernelGGL(k_lv_init, dim3(lv_grid(g.n, 256, 2048)), dim3(256), 0, st, g, (const LvCtl*)w.ctl, seed, w.comm, w.K, w.size);
+    if (seed) hipLaunchKernelGGL(k_lv_accum, dim3(lv_grid(g.n, 256, 1024)), dim3(256), 0, st, g, (const LvCtl*)w.ctl, binned ? 1 : 0, (const int32_t*)w.comm, w.K, w.size);
   };
-  const auto local_moving = [&](const LvGraph& g, u64 self_w, bool* level_moved) -> int {
-    const int S = lv_sub_rounds(g.n);
-    *level_moved = false;
-    for (int iter = 0; iter < LV_MAX_ITERS; ++iter) {
-      GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_comm, w.comm, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-      GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_size, w.size, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-      GFICF_HIP_CHECK(hipMemcpyAsync(w.snap_K, w.K, sizeof(u64) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-      GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 2, 0, sizeof(unsigned), st));
-      for (int s = 0; s < S; ++s) {
-        const LvMove mv{r, s, S, start_seed};
-        hipLaunchKernelGGL(k_lv_move_small, dim3(lv_blocks(g.n, 4)), dim3(256), 0, st, g, mv, w.comm, w.K, w.size, w.next, (unsigned*)(w.scalars + 2));
-        if (n_mid)
-          hipLaunchKernelGGL(k_lv_move_big<LV_MID_SLOTS>, dim3(n_mid), dim3(256), LV_MID_SLOTS * 12, st, g, mv, w.big, w.comm, w.K, w.size, w.next,
-                             (unsigned*)(w.scalars + 2), ctx->d_status);
-        if (n_large)
-          hipLaunchKernelGGL(k_lv_move_big<LV_BIG_SLOTS>, dim3(n_large), dim3(256), LV_BIG_SLOTS * 12, st, g, mv, w.big + (g.n - n_large), w.comm,
-                             w.K, w.size, w.next, (unsigned*)(w.scalars + 2), ctx->d_status);
-        hipLaunchKernelGGL(k_lv_apply, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, mv, g.kv, w.comm, w.next, w.K, w.size);
+  // local moving until every component's level has ended: one iteration ahead of the device's decisions, never draining the stream
+  const auto local_moving = [&](const LvG& g, const Lists& L, int S_max) -> int {
+    const unsigned gs = lv_grid(g.nb, 4, LV_GRID), ga = lv_grid(g.n, 256, 2048);
+    const unsigned gm = L.n_mid ? (unsigned)((int64_t)L.n_mid * g.rep < LV_GRID_BIG ? (int64_t)L.n_mid * g.rep : LV_GRID_BIG) : 0u;
+    const unsigned gl = L.n_large ? (unsigned)((int64_t)L.n_large * g.rep < LV_GRID_BIG ? (int64_t)L.n_large * g.rep : LV_GRID_BIG) : 0u;
+    for (int it = 0; it <= LV_MAX_ITERS + 1; ++it) {
+      const int par = it & 1;
+      hipLaunchKernelGGL(k_lv_pre, dim3(LV_SQ_BLOCKS, (unsigned)Bmax), dim3(256), 0, st, (const LvCtl*)w.ctl, par, (const u64*)w.K, (const int32_t*)w.size,
+                         w.snapK[par], w.snapS[par], w.pt.sq);
+      for (int s = 0; s < S_max; ++s) {
+        const LvMove mv{r, s};
+        if (s == 0) {
+          hipLaunchKernelGGL(k_lv_move_small<true>, dim3(gs), dim3(256), 0, st, g, (const LvCtl*)w.ctl, mv, (const int32_t*)w.comm, (const u64*)w.K,
+                             (const int32_t*)w.size, w.next, w.pt.in_small, w.pt.mv_small[par]);
+          if (gm) hipLaunchKernelGGL((k_lv_move_big<LV_MID_SLOTS, true>), dim3(gm), dim3(256), LV_MID_SLOTS * 12, st, g, (const LvCtl*)w.ctl, mv, 0, (int64_t)L.n_mid, L.big,
+                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_mid, w.pt.mv_mid[par], ctx->d_status);
+          if (gl) hipLaunchKernelGGL((k_lv_move_big<LV_BIG_SLOTS, true>), dim3(gl), dim3(256), LV_BIG_SLOTS * 12, st, g, (const LvCtl*)w.ctl, mv, 1, (int64_t)L.n_large, L.big,
+                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_large, w.pt.mv_large[par], ctx->d_status);
+          hipLaunchKernelGGL(k_lv_decide, dim3(1), dim3(1024), 0, st, w.ctl, w.pt, (int)gs, (int)gm, (int)gl, it, two_w, q_coef, host);
+        } else {
+          hipLaunchKernelGGL(k_lv_move_small<false>, dim3(gs), dim3(256), 0, st, g, (const LvCtl*)w.ctl, mv, (const int32_t*)w.comm, (const u64*)w.K,
+                             (const int32_t*)w.size, w.next, w.pt.in_small, w.pt.mv_small[par]);
+          if (gm) hipLaunchKernelGGL((k_lv_move_big<LV_MID_SLOTS, false>), dim3(gm), dim3(256), LV_MID_SLOTS * 12, st, g, (const LvCtl*)w.ctl, mv, 0, (int64_t)L.n_mid, L.big,
+                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_mid, w.pt.mv_mid[par], ctx->d_status);
+          if (gl) hipLaunchKernelGGL((k_lv_move_big<LV_BIG_SLOTS, false>), dim3(gl), dim3(256), LV_BIG_SLOTS * 12, st, g, (const LvCtl*)w.ctl, mv, 1, (int64_t)L.n_large, L.big,
+                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_large, w.pt.mv_large[par], ctx->d_status);
+        }
+        hipLaunchKernelGGL(k_lv_apply, dim3(ga), dim3(256), 0, st, g, (const LvCtl*)w.ctl, s, par, w.comm, (const int32_t*)w.next, w.K, w.size, w.snapc[0],
+                           w.snapc[1], (const u64*)w.snapK[par ^ 1], (const int32_t*)w.snapS[par ^ 1]);
       }
-      unsigned moved = 0;
-      GFICF_HIP_CHECK(hipMemcpyAsync(&moved, w.scalars + 2, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-      double q; u64 in_now;
-      const int rc2 = lv_quality(ctx, g, w, self_w, two_w, q_coef, &q, &in_now);
-      if (rc2) return rc2;
-      if (moved == 0) break;
-      if (q < q_prev) {                          // simultaneous moves made it worse: undo the iteration, the level ends
-        GFICF_HIP_CHECK(hipMemcpyAsync(w.comm, w.snap_comm, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-        GFICF_HIP_CHECK(hipMemcpyAsync(w.size, w.snap_size, sizeof(int32_t) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-        GFICF_HIP_CHECK(hipMemcpyAsync(w.K, w.snap_K, sizeof(u64) * (size_t)g.n, hipMemcpyDeviceToDevice, st));
-        break;
+      GFICF_HIP_CHECK(hipEventRecord(ev[par], st));
+      if (it >= 1) {                                 // the decision of the iteration BEFORE the one just enqueued
+        GFICF_HIP_CHECK(hipEventSynchronize(ev[par ^ 1]));
+        if (debug) {
+          fprintf(stderr, "[louvain]   n=%lld iter %d: %d component(s) go on;", (long long)g.n, it - 1, host->n_cont[it - 1]);
+          for (int b = 0; b < Bmax; ++b) fprintf(stderr, " %.9f", host->q_iter[b]);
+          fprintf(stderr, "\n");
+        }
+        if (host->n_cont[it - 1] == 0) break;        // every level has ended: the iteration just enqueued does nothing
       }
-      *level_moved = true;
-      in_w = in_now;
-      const bool small_gain = q - q_prev < 1e-7;
-      if (debug) fprintf(stderr, "[louvain]   n=%lld iter %d: moved %u, Q %.9f -> %.9f\n", (long long)g.n, iter, moved, q_prev, q);
-      q_prev = q;
-      if (small_gain) break;
     }
     return GFICF_OK;
   };
-  // the communities in use numbered 0 .. n2-1 (w.flag = old id -> new id); lab[v] = new id of comm[src[v]] (src NULL: v)
-  const auto renumber = [&](const LvGraph& g, const int32_t* src, int64_t* n2) -> int {
-    hipLaunchKernelGGL(k_lv_used, dim3(lv_blocks(g.n + 1, 256)), dim3(256), 0, st, g.n, w.size, w.flag);
+  // the communities in use numbered 0 .. (w.flag = old id -> new id, contiguous per component); lab = new local id of comm[src] (src NULL: the vertex)
+  const auto renumber = [&](const LvG& g, const int32_t* src, bool seeded, bool refine, int level) -> int {
+    hipLaunchKernelGGL(k_lv_used, dim3(lv_grid(g.n + 1, 256, 2048)), dim3(256), 0, st, g.n, (const int32_t*)w.size, w.flag);
     const int rc2 = gficf_exclusive_scan_i64(ctx, w.flag, g.n + 1);
     if (rc2) return rc2;
-    GFICF_HIP_CHECK(hipMemcpyAsync(n2, w.flag + g.n, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(k_lv_relabel, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, src, w.comm, w.flag, w.lab);
+    hipLaunchKernelGGL(k_lv_ctl_renumbered, dim3(1), dim3(64), 0, st, w.ctl, (const int64_t*)w.flag, g.n, seeded ? 1 : 0, refine ? 1 : 0, algorithm, level, host);
+    hipLaunchKernelGGL(k_lv_relabel, dim3(lv_grid(N, 256, 512), (unsigned)Bmax), dim3(256), 0, st, N, (const LvCtl*)w.ctl, src, (const int32_t*)w.comm,
+                       (const int64_t*)w.flag, w.lab);
+    return GFICF_OK;
+  };
+  // g reduced by the labels newid[comm[.]] (the components with `cont` set) into the arrays of nl, and the workgroup-path lists of the result
+  const auto reduce = [&](const LvG& g, const Lists& L, const int64_t* newid, LvLevel& nl) -> int {
+    GFICF_HIP_CHECK(hipMemsetAsync(w.cap, 0, sizeof(int64_t) * (size_t)(g.n + 1), st));
+    GFICF_HIP_CHECK(hipMemsetAsync(w.cur, 0, sizeof(int32_t) * (size_t)g.n, st));
+    hipLaunchKernelGGL(k_lv_rowcap, dim3(lv_grid(g.n, 256, 1024)), dim3(256), 0, st, g, (const LvCtl*)w.ctl, (const int32_t*)w.comm, newid, (const u64*)w.K,
+                       (const int32_t*)w.size, w.cap, nl.kv, nl.vcomp);
+    const int rc2 = gficf_exclusive_scan_i64(ctx, w.cap, g.n + 1);
+    if (rc2) return rc2;
+    hipLaunchKernelGGL(k_lv_emit_small, dim3(lv_grid(g.nb, 4, LV_GRID)), dim3(256), 0, st, g, (const LvCtl*)w.ctl, (const int32_t*)w.comm, newid,
+                       (const int64_t*)w.cap, w.cur, nl.nbr, nl.wt);
+    if (L.n_mid) {
+      const unsigned gm = (unsigned)((int64_t)L.n_mid * g.rep < LV_GRID_BIG ? (int64_t)L.n_mid * g.rep : LV_GRID_BIG);
+      hipLaunchKernelGGL(k_lv_emit_big<LV_MID_SLOTS>, dim3(gm), dim3(256), LV_MID_SLOTS * 12, st, g, (const LvCtl*)w.ctl, 0, (int64_t)L.n_mid, L.big, (const int32_t*)w.comm, newid,
+                         (const int64_t*)w.cap, w.cur, nl.nbr, nl.wt, ctx->d_status);
+    }
+    if (L.n_large) {
+      const unsigned gl = (unsigned)((int64_t)L.n_large * g.rep < LV_GRID_BIG ? (int64_t)L.n_large * g.rep : LV_GRID_BIG);
+      hipLaunchKernelGGL(k_lv_emit_big<LV_BIG_SLOTS>, dim3(gl), dim3(256), LV_BIG_SLOTS * 12, st, g, (const LvCtl*)w.ctl, 1, (int64_t)L.n_large, L.big, (const int32_t*)w.comm, newid,
+                         (const int64_t*)w.cap, w.cur, nl.nbr, nl.wt, ctx->d_status);
+    }
+    GFICF_HIP_CHECK(hipMemcpyAsync(nl.beg, w.cap, sizeof(int64_t) * (size_t)(g.n + 1), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_lv_finish_rows, dim3(lv_grid(g.n, 256, 1024)), dim3(256), 0, st, (const int64_t*)&w.ctl->n_union2, (const int64_t*)w.cap,
+                       (const int32_t*)w.cur, nl.end);
+    // the next level's lists (its vertex count is on the device: n_union2)
+    GFICF_HIP_CHECK(hipMemsetAsync(&w.ctl->n_mid, 0, 2 * sizeof(unsigned), st));
+    LvG g2{g.n, g.n, 1, nl.beg, nl.end, nl.nbr, nl.wt, nl.kv, nl.vcomp};
+    hipLaunchKernelGGL(k_lv_list_big, dim3(lv_grid(g.n, 256, 1024)), dim3(256), 0, st, g2, (const int64_t*)&w.ctl->n_union2, nl.big, &w.ctl->n_mid);
+    hipLaunchKernelGGL(k_lv_ctl_publish, dim3(1), dim3(64), 0, st, (const LvCtl*)w.ctl, host);
+    return GFICF_OK;
+  };
+  const auto sync_level = [&]() -> int {            // the level's ONE synchronisation
+    GFICF_HIP_CHECK(hipGetLastError());
     GFICF_HIP_CHECK(hipStreamSynchronize(st));
     return GFICF_OK;
   };
-  // g reduced by the labels newid[comm[.]] (n2 of them) into the arrays of nl; kv of the result is NOT set here
-  const auto reduce = [&](const LvGraph& g, const int32_t* comm, const int64_t* newid, int64_t n2, LvLevel& nl, LvGraph* out) -> int {
-    int64_t m2 = 0;
-    if (g.m > 0) {
-      const u64 none = (u64)n2 << 32;
-      hipLaunchKernelGGL(k_lv_emit, dim3(lv_blocks(g.n, 4)), dim3(256), 0, st, g, comm, newid, none, w.keys_a, w.vals_a);
-      unsigned bits = 33;                        // the keys in use: (row < n2) << 32 | col, and none = n2 << 32
-      while (bits < 64 && ((int64_t)1 << (bits - 32)) <= n2) ++bits;
-      size_t tb = w.sort_tmp_bytes;
-      GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys_a, w.keys_b, w.vals_a, w.vals_b, (size_t)g.m, 0u, bits, st));
-      hipLaunchKernelGGL(k_lv_heads, dim3(lv_blocks(g.m + 1, 256)), dim3(256), 0, st, w.keys_b, g.m, none, w.flag);
-      int rc2 = gficf_exclusive_scan_i64(ctx, w.flag, g.m + 1);
-      if (rc2) return rc2;
-      GFICF_HIP_CHECK(hipMemcpyAsync(&m2, w.flag + g.m, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-      GFICF_HIP_CHECK(hipStreamSynchronize(st));
-      GFICF_HIP_CHECK(hipMemsetAsync(nl.wt, 0, sizeof(u64) * (size_t)(m2 > 0 ? m2 : 1), st));
-      GFICF_HIP_CHECK(hipMemsetAsync(nl.ptr, 0, sizeof(int64_t) * (size_t)(n2 + 1), st));
-      hipLaunchKernelGGL(k_lv_reduce, dim3(lv_blocks(g.m, LV_RED_CHUNK)), dim3(256), 0, st, w.keys_b, w.vals_b, g.m, none, w.flag, nl.nbr, nl.wt, nl.ptr);
-      rc2 = gficf_exclusive_scan_i64(ctx, nl.ptr, n2 + 1);
-      if (rc2) return rc2;
-    } else {
-      GFICF_HIP_CHECK(hipMemsetAsync(nl.ptr, 0, sizeof(int64_t) * (size_t)(n2 + 1), st));
-    }
-    *out = LvGraph{n2, m2, nl.ptr, nl.nbr, nl.wt, nl.kv};
-    return GFICF_OK;
+  const auto s_max_of = [&](const int64_t* n_of, const bool* live) {
+    int S = 1;
+    for (int b = 0; b < Bmax; ++b)
+      if (live[b]) { const int s = lv_sub_rounds_of(n_of[b], s_env); S = s > S ? s : S; }
+    return S;
   };
 
   // Random starts (reference src/RModularityOptimizer.cpp:108-142): every start begins from singletons, runs up to n_iter
@@ -738,107 +1351,146 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   // of the hash that splits the vertices into sub-round classes (start 0 with seed 0 is the plain deterministic run).
   double q_best = -INFINITY;
   int64_t n_best = 0;
-  for (int start = 0; start < n_start; ++start) {
-  start_seed = start == 0 && seed == 0 ? 0u : lv_hash((uint32_t)seed * 0x9E3779B1u + (uint32_t)start + 1u);
-  have_labels = false;
-  n_labels = 0;
-  for (int pass = 0; pass < n_iter; ++pass) {
-    LvGraph g = g0;
-    u64 self_w = 0;
-    bool any_move = false;
-    int n_saved = 0;                             // levels 1 .. n_saved have their vertex map in w.tops
-    int64_t saved_n[LV_MAX_SAVED + 1];
-    for (int level = 0;; ++level) {
-      const bool seeded = level == 0 && have_labels;
-      if (debug) fprintf(stderr, "[louvain] pass %d level %d: n=%lld m=%lld\n", pass, level, (long long)g.n, (long long)g.m);
-      rc = start_level(g, seeded ? w.lab : nullptr, n_labels, self_w);
-      if (rc) return rc;
-      bool level_moved = false;
-      rc = local_moving(g, self_w, &level_moved);
-      if (rc) return rc;
-      any_move |= level_moved;
-      q_final = q_prev;
-      int64_t n2 = 0;
-      rc = renumber(g, level == 0 ? nullptr : w.lab, &n2);
-      if (rc) return rc;
-      have_labels = true;
-      *n_clusters = n_labels = n2;
-      if (n2 == g.n || n2 <= 1 || (!level_moved && !(seeded && n2 < g.n))) break;      // nothing merged: the descent is done
-      // ---- the reduced graph
-      LvLevel& nl = w.lvl[level & 1];
-      hipLaunchKernelGGL(k_lv_coarse_weights, dim3(lv_blocks(g.n, 256)), dim3(256), 0, st, g.n, w.size, w.flag, w.K, nl.kv);
-      LvGraph g2;
-      rc = reduce(g, w.comm, w.flag, n2, nl, &g2);
-      if (rc) return rc;
-      self_w += in_w;
-      g = g2;
-      if (algorithm == 2 && n_saved == level && level < LV_MAX_SAVED) {               // level + 1's vertices: lab as it is now
-        GFICF_HIP_CHECK(hipMemcpyAsync(w.tops + (size_t)level * (size_t)N, w.lab, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToDevice, st));
-        saved_n[++n_saved] = n2;
+  for (int first = 0; first < n_start; first += Bmax) {
+    const int B = n_start - first < Bmax ? n_start - first : Bmax;
+    hipLaunchKernelGGL(k_lv_ctl_batch, dim3(1), dim3(64), 0, st, w.ctl, B, first, seed);
+    const LvG g0{(int64_t)B * N, N, B, d_indptr, d_indptr + 1, d_indices, w.wt0, w.kv0, nullptr};
+    const Lists L0{w.big0, n_mid0, n_large0};
+    bool finished[LV_MAX_B], any_move[LV_MAX_B], live[LV_MAX_B];
+    int64_t n_of[LV_MAX_B], n_labels[LV_MAX_B];
+    double q_final[LV_MAX_B];
+    int n_saved[LV_MAX_B];
+    int64_t saved_n[LV_MAX_B][LV_MAX_SAVED + 1];
+    for (int b = 0; b < LV_MAX_B; ++b) { finished[b] = b >= B; any_move[b] = true; n_labels[b] = 0; q_final[b] = 0.0; n_saved[b] = 0; }
+    for (int pass = 0; pass < n_iter; ++pass) {
+      int n_live = 0;
+      for (int b = 0; b < B; ++b) {
+        if (pass > 0 && !any_move[b]) finished[b] = true;
+        live[b] = !finished[b];
+        n_of[b] = N;
+        any_move[b] = false;
+        n_saved[b] = 0;
+        n_live += live[b] ? 1 : 0;
       }
-    }
-
-    // ---- algorithm 2: back up through the levels, local moving on each with the labels found below it
-    // (runLouvainAlgorithmWithMultilevelRefinement, reference :629-649).  The graph of a level is rebuilt from the finest
-    // one by its saved vertex map (one sort) instead of being kept.
-    if (algorithm == 2 && any_move) {
-      for (int level = n_saved; level >= 0; --level) {
-        const int32_t* top = level ? w.tops + (size_t)(level - 1) * (size_t)N : nullptr;
-        LvGraph gl = g0;
-        u64 self_l = 0;
-        const int32_t* seed = w.lab;
-        if (level) {
-          const int64_t nl_n = saved_n[level];
-          LvLevel& nl = w.lvl[0];
-          hipLaunchKernelGGL(k_lv_iota, dim3(lv_blocks(nl_n, 256)), dim3(256), 0, st, nl_n, w.flag);
-          GFICF_HIP_CHECK(hipMemsetAsync(nl.kv, 0, sizeof(u64) * (size_t)nl_n, st));
-          GFICF_HIP_CHECK(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * (size_t)nl_n, st));
-          hipLaunchKernelGGL(k_lv_accum, dim3(grid_cap(lv_blocks(N, 256))), dim3(256), 0, st, N, nl_n, top, w.kv0, (int32_t*)nullptr, nl.kv, w.cnt);
-          GFICF_HIP_CHECK(hipMemsetAsync(w.scalars + 1, 0, sizeof(u64), st));
-          hipLaunchKernelGGL(k_lv_internal, dim3(lv_blocks(N, 4) < 2048u ? lv_blocks(N, 4) : 2048u), dim3(256), 0, st, g0, top, w.scalars + 1);
-          GFICF_HIP_CHECK(hipMemcpyAsync(&self_l, w.scalars + 1, sizeof(u64), hipMemcpyDeviceToHost, st));
-          hipLaunchKernelGGL(k_lv_seed, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, top, w.lab, w.rank);
-          rc = reduce(g0, top, w.flag, nl_n, nl, &gl);               // synchronises: self_l is there
-          if (rc) return rc;
-          seed = w.rank;
+      if (!n_live) break;
+      LvG g = g0;
+      Lists L = L0;
+      int64_t tot_labels = 0;
+      for (int b = 0; b < B; ++b) tot_labels += live[b] ? n_labels[b] : 0;
+      for (int level = 0;; ++level) {
+        const bool seeded = level == 0 && pass > 0;
+        if (debug) fprintf(stderr, "[louvain] starts %d..%d pass %d level %d: union n=%lld\n", first, first + B - 1, pass, level, (long long)g.n);
+        hipLaunchKernelGGL(k_lv_ctl_level, dim3(1), dim3(64), 0, st, w.ctl, level == 0 ? 0 : 1, pass, N, s_env);
+        start_level(g, seeded ? w.lab : nullptr, tot_labels <= LV_ACC_BINS);
+        rc = local_moving(g, L, s_max_of(n_of, live));
+        if (rc) return rc;
+        rc = renumber(g, level == 0 ? nullptr : w.lab, seeded, false, level);
+        if (rc) return rc;
+        if (algorithm == 2 && level < LV_MAX_SAVED)       // the next level's vertices of every start that goes on: lab as it is now
+          GFICF_HIP_CHECK(hipMemcpyAsync(w.tops + (size_t)level * (size_t)Bmax * (size_t)N, w.lab, sizeof(int32_t) * (size_t)B * (size_t)N, hipMemcpyDeviceToDevice, st));
+        LvLevel& nl = w.lvl[level & 1];
+        rc = reduce(g, L, w.flag, nl);                    // (enqueued before the host knows whether anybody goes on: a small graph by then)
+        if (rc) return rc;
+        rc = sync_level();
+        if (rc) return rc;
+        int n_cont = 0;
+        for (int b = 0; b < B; ++b) {
+          if (!live[b]) continue;
+          const LvHostComp& H = host->c[b];
+          n_labels[b] = H.n2;
+          q_final[b] = H.q_prev;
+          any_move[b] = H.any_move != 0;
+          if (H.cont) {
+            if (algorithm == 2 && n_saved[b] == level && level < LV_MAX_SAVED) saved_n[b][++n_saved[b]] = H.n2;
+            n_of[b] = H.n2;
+            ++n_cont;
+          } else {
+            live[b] = false;
+          }
+          if (debug) fprintf(stderr, "[louvain]   start %d: %lld communities, Q %.9f, %s\n", first + b, (long long)H.n2, H.q_prev, H.cont ? "goes on" : "descent done");
         }
-        rc = start_level(gl, seed, n_labels, self_l);
-        if (rc) return rc;
-        bool level_moved = false;
-        rc = local_moving(gl, self_l, &level_moved);
-        if (rc) return rc;
-        q_final = q_prev;
-        int64_t n2 = 0;
-        rc = renumber(gl, top, &n2);
-        if (rc) return rc;
-        *n_clusters = n_labels = n2;
+        if (!n_cont) break;
+        const int64_t n2u = host->n_union2;
+        g = LvG{n2u, n2u, 1, nl.beg, nl.end, nl.nbr, nl.wt, nl.kv, nl.vcomp};
+        L = Lists{nl.big, host->n_mid, host->n_large};
+      }
+
+      // ---- algorithm 2: back up through the levels, local moving on each with the labels found below it
+      // (runLouvainAlgorithmWithMultilevelRefinement, reference :629-649).  The graph of a level is rebuilt from the finest
+      // one by its saved vertex map instead of being kept.
+      if (algorithm == 2) {
+        int top_level = -1;
+        for (int b = 0; b < B; ++b)
+          if (!finished[b] && any_move[b]) top_level = n_saved[b] > top_level ? n_saved[b] : top_level;
+        for (int level = top_level; level >= 0; --level) {
+          bool part[LV_MAX_B];
+          int64_t n_lv[LV_MAX_B], n_un = 0, tot_lab = 0;
+          for (int b = 0; b < LV_MAX_B; ++b) {
+            part[b] = b < B && !finished[b] && any_move[b] && n_saved[b] >= level;
+            n_lv[b] = part[b] ? (level ? saved_n[b][level] : N) : 0;
+            n_un += n_lv[b];
+            tot_lab += part[b] ? n_labels[b] : 0;
+          }
+          const int32_t* top = level ? w.tops + (size_t)(level - 1) * (size_t)Bmax * (size_t)N : nullptr;
+          hipLaunchKernelGGL(k_lv_ctl_refine, dim3(1), dim3(64), 0, st, w.ctl, level, N);
+          LvG gl = g0;
+          Lists Ll = L0;
+          const int32_t* seedp = w.lab;
+          if (level) {
+            // the level's graph: the finest one reduced by the saved vertex map (labels seed_base + top, new ids = the labels themselves)
+            LvLevel& nl = w.lvl[0];
+            hipLaunchKernelGGL(k_lv_init, dim3(lv_grid(g0.n, 256, 2048)), dim3(256), 0, st, g0, (const LvCtl*)w.ctl, top, w.comm, w.K, w.size);
+            hipLaunchKernelGGL(k_lv_accum, dim3(lv_grid(g0.n, 256, 1024)), dim3(256), 0, st, g0, (const LvCtl*)w.ctl, 0, (const int32_t*)w.comm, w.K, w.size);
+            hipLaunchKernelGGL(k_lv_internal, dim3(lv_grid(N, 4, LV_GRID)), dim3(256), 0, st, g0, (const LvCtl*)w.ctl, (const int32_t*)w.comm, w.pt.in_small);
+            hipLaunchKernelGGL(k_lv_seed, dim3(lv_grid(N, 256, 512), (unsigned)Bmax), dim3(256), 0, st, N, (const LvCtl*)w.ctl, top, (const int32_t*)w.lab, w.seedl);
+            hipLaunchKernelGGL(k_lv_iota, dim3(lv_grid(g0.n + 1, 256, 2048)), dim3(256), 0, st, g0.n, w.flag);
+            // the vertex ranges of the level are fixed by k_lv_ctl_refine: v0 of the level, not of the finest graph — seed_base carried them
+            // into the labels above; from here on v0 / n are the level's
+            rc = reduce(g0, L0, w.flag, nl);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_lv_ctl_self, dim3(1), dim3(256), 0, st, w.ctl, (const u64*)w.pt.in_small, (int)lv_grid(N, 4, LV_GRID));
+            rc = sync_level();                            // the sizes of the lists
+            if (rc) return rc;
+            gl = LvG{n_un, n_un, 1, nl.beg, nl.end, nl.nbr, nl.wt, nl.kv, nl.vcomp};
+            Ll = Lists{nl.big, host->n_mid, host->n_large};
+            seedp = w.seedl;
+          }
+          if (debug) fprintf(stderr, "[louvain] starts %d..%d pass %d refinement level %d: union n=%lld\n", first, first + B - 1, pass, level, (long long)gl.n);
+          hipLaunchKernelGGL(k_lv_ctl_level, dim3(1), dim3(64), 0, st, w.ctl, 2, pass, N, s_env);
+          start_level(gl, seedp, tot_lab <= LV_ACC_BINS);
+          rc = local_moving(gl, Ll, s_max_of(n_lv, part));
+          if (rc) return rc;
+          rc = renumber(gl, top, false, true, level);
+          if (rc) return rc;
+          rc = sync_level();
+          if (rc) return rc;
+          for (int b = 0; b < B; ++b)
+            if (part[b]) { n_labels[b] = host->c[b].n2; q_final[b] = host->c[b].q_prev; }
+        }
       }
     }
-    if (!any_move) break;
+    for (int b = 0; b < B; ++b) {
+      if (debug) fprintf(stderr, "[louvain] start %d: Q %.9f, %lld clusters\n", first + b, q_final[b], (long long)n_labels[b]);
+      if (q_final[b] > q_best) {                     // strictly better, as the reference keeps the first of equals (:128)
+        q_best = q_final[b];
+        n_best = n_labels[b];
+        GFICF_HIP_CHECK(hipMemcpyAsync(w.best, w.lab + (size_t)b * (size_t)N, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToDevice, st));
+      }
+    }
   }
-  if (debug) fprintf(stderr, "[louvain] start %d: Q %.9f, %lld clusters\n", start, q_final, (long long)n_labels);
-  if (q_final > q_best) {                        // strictly better, as the reference keeps the first of equals (:128)
-    q_best = q_final;
-    n_best = n_labels;
-    if (n_start > 1) GFICF_HIP_CHECK(hipMemcpyAsync(w.best, w.lab, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToDevice, st));
-  }
-  }
-  if (n_start > 1) GFICF_HIP_CHECK(hipMemcpyAsync(w.lab, w.best, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToDevice, st));
-  q_final = q_best;
   *n_clusters = n_best;
 
   // ---- clusters by decreasing size
-  const int64_t C = *n_clusters;
+  const int64_t C = n_best;
   GFICF_HIP_CHECK(hipMemsetAsync(w.cnt, 0, sizeof(int32_t) * (size_t)C, st));
-  hipLaunchKernelGGL(k_lv_accum, dim3(lv_blocks(N, 256) < 1024u ? lv_blocks(N, 256) : 1024u), dim3(256), 0, st, N, C, w.lab, (const u64*)nullptr,
-                     (int32_t*)nullptr, (u64*)nullptr, w.cnt);
-  hipLaunchKernelGGL(k_lv_size_keys, dim3(lv_blocks(C, 256)), dim3(256), 0, st, C, N, w.cnt, w.keys_a, w.vals_a);
+  hipLaunchKernelGGL(k_lv_count, dim3(lv_grid(N, 256, 1024)), dim3(256), 0, st, N, C, (const int32_t*)w.best, w.cnt);
+  hipLaunchKernelGGL(k_lv_size_keys, dim3(lv_blocks(C, 256)), dim3(256), 0, st, C, N, (const int32_t*)w.cnt, w.keys_a, w.vals_a);
   size_t tb = w.sort_tmp_bytes;
   GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tb, w.keys_a, w.keys_b, w.vals_a, w.vals_b, (size_t)C, 0u, 64u, st));
-  hipLaunchKernelGGL(k_lv_rank, dim3(lv_blocks(C, 256)), dim3(256), 0, st, C, w.vals_b, w.rank);
-  hipLaunchKernelGGL(k_lv_final, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, w.lab, w.rank, d_labels);
+  hipLaunchKernelGGL(k_lv_rank, dim3(lv_blocks(C, 256)), dim3(256), 0, st, C, (const u64*)w.vals_b, w.rank);
+  hipLaunchKernelGGL(k_lv_final, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, (const int32_t*)w.best, (const int32_t*)w.rank, d_labels);
   GFICF_HIP_CHECK(hipGetLastError());
-  if (modularity) *modularity = q_final;
+  if (modularity) *modularity = q_best;
   return gficf_ctx_sync(ctx);
 }
 
@@ -857,7 +1509,7 @@ int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr
   const int64_t nnz = h_ptr[(size_t)N];
   if (!mono) GFICF_FAIL(GFICF_ERR_BAD_CSC, "indptr does not start at 0 or is not monotone");
   if (nnz > 0 && (!indices || !x)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
-  const size_t nsz = (size_t)(nnz > 0 ? nnz : 1), wsb = gficf_louvain_workspace_bytes(N, nnz);
+  const size_t nsz = (size_t)(nnz > 0 ? nnz : 1), wsb = gficf_louvain_workspace_bytes_starts(N, nnz, n_start);
   gficf_arena ar;                                   // pool slot 0: no allocation per call
   const size_t o_ptr = ar.take(sizeof(int64_t) * ((size_t)N + 1)), o_idx = ar.take(sizeof(int32_t) * nsz), o_x = ar.take(sizeof(double) * nsz);
   const size_t o_lab = ar.take(sizeof(int32_t) * (size_t)N), o_ws = ar.take(wsb);

@@ -142,7 +142,7 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
   if (n_edges) *n_edges = h_cnt[0];
 
   // communities
-  const size_t lws = gficf_louvain_workspace_bytes(N, h_cnt[1]);
+  const size_t lws = gficf_louvain_workspace_bytes_starts(N, h_cnt[1], n_start);      // all the starts in one launch set
   void* d_lws = nullptr;
   e = gficf_pool_get(ctx, 1, lws, &d_lws);
   if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_phenograph_host: %s", hipGetErrorString(e));

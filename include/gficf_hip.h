@@ -557,7 +557,8 @@ int gficf_csc_transpose_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* c
  * algorithm 1 = Louvain, 2 = Louvain with multilevel refinement (one more local moving on every level on the way back
  * up, :629-649).  n_start >= 1 "random starts" (:108-142): every start begins from singletons and the best modularity is
  * kept; nothing is random here — a start varies the seed of the hash that splits the vertices into sub-round classes,
- * derived from (seed, start); start 0 with seed 0 is the plain run.  The call synchronises the stream several times (an iterative algorithm).
+ * derived from (seed, start); start 0 with seed 0 is the plain run.  The call synchronises the stream once per level of the hierarchy
+ * (the convergence of a level is decided on the device; the host enqueues one iteration ahead).
  * The matrix must be symmetric (an undirected graph's adjacency matrix is; the reference reads only its strict lower
  * triangle and mirrors it, which is the same thing then).  Edge weights must be finite and in [0, 2^20].  GFICF_ERR_UNSUPPORTED only if one hash class of a vertex's neighbouring
  * communities overflows the 8192-slot table (vertices of any degree are handled in several passes; not observed). */
@@ -567,6 +568,11 @@ int gficf_csc_transpose_host(gficf_ctx* ctx, int64_t G, int64_t N, const void* c
  * clustcells() always passes 1, which is the default of a new context. */
 int gficf_ctx_set_louvain_options(gficf_ctx* ctx, int modularity_function);
 size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz);
+/* ABI 7.  The starts are independent problems on one graph: gficf_louvain_device runs as many of them TOGETHER (one launch set over the
+ * disjoint union of the copies, at most 16) as the workspace it is given holds — with gficf_louvain_workspace_bytes() bytes one at a time, with
+ * gficf_louvain_workspace_bytes_starts(N, nnz, n_start) bytes all of min(n_start, 16) (about 24 B per matrix entry and 150 B per vertex for
+ * every start run together).  The result does not depend on how many ran together. */
+size_t gficf_louvain_workspace_bytes_starts(int64_t N, int64_t nnz, int n_start);
 int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, const int32_t* d_indices,
                          const double* d_x, int64_t nnz, double resolution, int algorithm, int n_start,
                          int n_iter, int seed, int32_t* d_labels, int64_t* n_clusters, double* modularity, void* d_ws,

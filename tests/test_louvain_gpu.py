@@ -174,6 +174,29 @@ def test_resolution_and_iterations():
         assert ref10.modularity >= oracle_np.modularity_np(A, ref_labels, 1.0) - Q_TOL
 
 
+@pytest.mark.parametrize("N,k,C,res,alg,n_start", [(5000, 15, 1, 1.0, 1, 7), (9000, 30, 8, 0.8, 1, 10), (3000, 10, 1, 1.5, 2, 5), (7000, 50, 1, 1.0, 1, 20),
+                                                      (60000, 15, 5, 0.8, 1, 3)])
+def test_starts_run_together_equal_starts_run_one_by_one(N, k, C, res, alg, n_start, monkeypatch):
+    """Round 6: the n.start starts (reference src/RModularityOptimizer.cpp:108-142) run TOGETHER, as one problem on the disjoint union of
+    the copies (one launch set; at most 16 at a time, so n_start = 20 is two batches) — a start's descent, its convergence decisions and
+    its passes must be exactly those of running it alone: labels, number of clusters and modularity are identical to the run with
+    GFICF_LOUVAIN_BATCH=1 (the starts one after the other through the same kernels), and to a batch size that does not divide n_start."""
+    A = knn_graph(N, 10, k, C, seed=3 * N + k)
+    together = gficf_amd.run_modularity_clustering(A, 1, res, alg, n_start, 10, 4242, False)
+    check_labels(A, together, res)
+    monkeypatch.setenv("GFICF_LOUVAIN_BATCH", "1")
+    one_by_one = gficf_amd.run_modularity_clustering(A, 1, res, alg, n_start, 10, 4242, False)
+    monkeypatch.setenv("GFICF_LOUVAIN_BATCH", "3")
+    by_three = gficf_amd.run_modularity_clustering(A, 1, res, alg, n_start, 10, 4242, False)
+    monkeypatch.delenv("GFICF_LOUVAIN_BATCH")
+    for other in (one_by_one, by_three):
+        assert np.array_equal(together, other) and together.modularity == other.modularity and together.n_clusters == other.n_clusters
+    # the best of the starts is at least as good as each of them alone (start s alone = n_start 1 with that start's seed is not reachable from
+    # the API; the first start is: seed and start number 0)
+    first = gficf_amd.run_modularity_clustering(A, 1, res, alg, 1, 10, 4242, False)
+    assert together.modularity >= first.modularity
+
+
 def test_device_resident_chain_and_edge_cases():
     import torch
 
