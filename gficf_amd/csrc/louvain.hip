@@ -75,8 +75,9 @@ typedef unsigned long long u64;
 constexpr double LV_SCALE = 4294967296.0;      // 2^32
 constexpr int LV_SMALL_DEG = 128;              // up to here: one wave per vertex, 256-slot table
 constexpr int LV_SMALL_SLOTS = 256;
-constexpr int LV_MID_DEG = 1024, LV_MID_SLOTS = 2048;   // one workgroup per vertex, 24 KB table
-constexpr int LV_BIG_SLOTS = 8192;             // beyond: 32 KB keys + 64 KB sums
+constexpr int LV_MID_DEG = 4096, LV_MID_SLOTS = 1024;   // up to here: still one wave per vertex, a 1024-slot table of its own, passes by hash class beyond 512 entries
+constexpr int LV_EMIT_SLOTS = 2048;            // the reduction's workgroup-per-vertex table for the same vertices
+constexpr int LV_BIG_SLOTS = 8192;             // beyond: one workgroup per vertex, 32 KB keys + 64 KB sums
 constexpr int LV_MAX_ITERS = 64;
 constexpr int LV_MAX_SAVED = 12;              // levels whose vertex map is kept for the refinement of algorithm 2
 constexpr int LV_MAX_B = 16;                  // starts run together
@@ -132,6 +133,7 @@ struct LvHost {              // pinned host memory the control kernels write (re
   unsigned n_mid, n_large;
   LvHostComp c[LV_MAX_B];
   double q_iter[LV_MAX_B];   // (debug trace)
+  unsigned mv_iter[LV_MAX_B];
 };
 
 struct LvParts {             // per-block partial sums of the move kernels, fixed slots (no atomics, no clearing)
@@ -338,9 +340,40 @@ __device__ static inline void lv_wave_sync() {
 
 __device__ static inline bool lv_better(double g, int32_t c, double bg, int32_t bc) { return g > bg || (g == bg && c < bc); }
 
+// Wave reductions on DPP row operations (no LDS traffic; the ds_bpermute butterflies they replace were ~1.2 us of the ~4.5 us a vertex took).
+// Every lane must be active.  quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror leave each row of 16 uniform; row_bcast15 (rows
+// 1, 3) and row_bcast31 (rows 2, 3) carry the rows' results down: lane 63 holds the wave's, read back with v_readlane.
+template <int CTRL, int RM>
+__device__ static inline int lv_dpp(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, RM, 0xF, false); }
+
+template <int CTRL, int RM>
+__device__ static inline void lv_sum_step(u64& x) {
+  const uint32_t lo = (uint32_t)lv_dpp<CTRL, RM>(0, (int)(uint32_t)x), hi = (uint32_t)lv_dpp<CTRL, RM>(0, (int)(uint32_t)(x >> 32));
+  x += ((u64)hi << 32) | lo;
+}
 __device__ static inline u64 lv_wave_sum(u64 x) {
-  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
-  return x;
+  lv_sum_step<0xB1, 0xF>(x); lv_sum_step<0x4E, 0xF>(x); lv_sum_step<0x141, 0xF>(x); lv_sum_step<0x140, 0xF>(x);
+  lv_sum_step<0x142, 0xA>(x); lv_sum_step<0x143, 0xC>(x);
+  return ((u64)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63);
+}
+
+struct LvBest { double g; int32_t c; };      // best gain and its community (ties: the smaller id)
+
+template <int CTRL, int RM>
+__device__ static inline double lv_dpp_f64(double x) {
+  return __hiloint2double(lv_dpp<CTRL, RM>(__double2hiint(x), __double2hiint(x)), lv_dpp<CTRL, RM>(__double2loint(x), __double2loint(x)));
+}
+// The wave's best, in every lane: the largest gain (v_max_f64 over the DPP steps), then the smallest community among the lanes that hold it —
+// the same order as lv_better, in about half the instructions of reducing the pair at once.
+__device__ static inline LvBest lv_wave_best(LvBest x) {
+  double m = x.g;
+  m = fmax(m, lv_dpp_f64<0xB1, 0xF>(m)); m = fmax(m, lv_dpp_f64<0x4E, 0xF>(m)); m = fmax(m, lv_dpp_f64<0x141, 0xF>(m));
+  m = fmax(m, lv_dpp_f64<0x140, 0xF>(m)); m = fmax(m, lv_dpp_f64<0x142, 0xA>(m)); m = fmax(m, lv_dpp_f64<0x143, 0xC>(m));
+  m = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 63), __builtin_amdgcn_readlane(__double2loint(m), 63));
+  int k = x.g == m ? x.c : INT32_MAX;
+  k = min(k, lv_dpp<0xB1, 0xF>(k, k)); k = min(k, lv_dpp<0x4E, 0xF>(k, k)); k = min(k, lv_dpp<0x141, 0xF>(k, k));
+  k = min(k, lv_dpp<0x140, 0xF>(k, k)); k = min(k, lv_dpp<0x142, 0xA>(k, k)); k = min(k, lv_dpp<0x143, 0xC>(k, k));
+  return LvBest{m, __builtin_amdgcn_readlane(k, 63)};
 }
 
 // does component C take part in the sub-round kernel (s, first)?  first = the kernel of sub-round 0, which runs BEFORE the iteration's
@@ -349,40 +382,103 @@ __device__ static inline bool lv_runs(const LvComp& C, int s, bool first) {
   return first ? !C.level_done : (C.action == LV_CONTINUE && s < C.S);
 }
 
-// the decision for vertex gv, identical in every lane (all inputs are wave-uniform)
-__device__ static inline int32_t lv_decide_vertex(int64_t gv, int32_t cv, double bg, int32_t bc, u64 stay_w, u64 kvv, double r, const u64* __restrict__ K,
-                                                  const int32_t* __restrict__ size, bool* moved) {
+// the decision for vertex gv, identical in every lane (all inputs are wave-uniform).  Kcv, szcv, szgv: total and size of its community, size of
+// the community that carries its own id — loaded by the caller before the table work, off the critical path
+__device__ static inline int32_t lv_decide_vertex(int64_t gv, int32_t cv, double bg, int32_t bc, u64 stay_w, u64 kvv, double r, u64 Kcv, int32_t szcv,
+                                                  int32_t szgv, const int32_t* __restrict__ size, bool* moved) {
   const double kvd = (double)kvv;
-  const double g_stay = (double)stay_w - kvd * (double)(K[cv] - kvv) * r;
+  const double g_stay = (double)stay_w - kvd * (double)(Kcv - kvv) * r;
   bool move = bc != INT32_MAX && bg > g_stay;
-  const int32_t szc = size[cv];
-  if (move && szc == 1 && size[bc] == 1 && bc > cv) move = false;      // two singletons never swap
+  if (move && szcv == 1 && size[bc] == 1 && bc > cv) move = false;      // two singletons never swap
   int32_t to = move ? bc : cv;
   // every option loses: alone is better (the reference's move into an unused cluster, :546-550).  The unused cluster
   // is the vertex's own id when nobody holds it — unique per vertex, so simultaneous escapes never meet.
-  if ((move ? bg : g_stay) < 0.0 && szc > 1 && size[gv] == 0) { to = (int32_t)gv; move = true; }
+  if ((move ? bg : g_stay) < 0.0 && szcv > 1 && szgv == 0) { to = (int32_t)gv; move = true; }
   *moved = move;
   return to;
 }
 
+// claims or finds community c's slot in a table of SLOTS and adds w; *own: this lane claimed it (it will evaluate the community and hand the
+// slot back empty).  Returns -1 when the table is full (reported by the caller).
+template <int SLOTS>
+__device__ static inline int lv_insert(int32_t* key, u64* val, int32_t c, u64 w, bool* own) {
+  uint32_t h = lv_hash((uint32_t)c) & (SLOTS - 1);
+  *own = false;
+  for (int probes = 0; probes < SLOTS; ++probes) {
+    const int32_t old = atomicCAS(&key[h], -1, c);
+    if (old == -1 || old == c) { *own = old == -1; atomicAdd(&val[h], w); return (int)h; }
+    h = (h + 1) & (SLOTS - 1);
+  }
+  return -1;
+}
+
+// one copy's view of a vertex in a round of k_lv_move_small
+struct LvSide {
+  int mode;                  // 0: not in this round, 1: only its share of the internal weight (sub-round 0, other class), 2: evaluate
+  int comp;
+  int64_t base, gv;
+  int32_t cv;
+  u64 Kcv; int32_t szcv, szgv;
+};
+
+template <bool FIRST>
+__device__ static inline LvSide lv_side(const LvG& g, const LvCtl* __restrict__ ctl, int s, int b, int64_t v, const int32_t* __restrict__ comm,
+                                        const u64* __restrict__ K, const int32_t* __restrict__ size) {
+  LvSide x;
+  x.mode = 0; x.comp = 0; x.base = 0; x.gv = 0; x.cv = 0; x.Kcv = 0; x.szcv = 0; x.szgv = 0;
+  if (b >= g.rep) return x;
+  x.comp = g.vcomp ? (int)g.vcomp[v] : b;
+  const LvComp& C = ctl->c[x.comp];
+  if (!lv_runs(C, s, FIRST)) return x;
+  x.base = (int64_t)b * g.nb; x.gv = x.base + v;
+  const bool in_class = C.S == 1 || (int)(lv_hash((uint32_t)(x.gv - C.v0) + C.seed) % (uint32_t)C.S) == s;
+  if (!FIRST && !in_class) return x;
+  x.mode = in_class ? 2 : 1;
+  x.cv = comm[x.gv];
+  if (in_class) { x.Kcv = K[x.cv]; x.szcv = size[x.cv]; x.szgv = size[x.gv]; }
+  return x;
+}
+
+// hash class of a vertex for S sub-rounds (S is a power of two unless GFICF_LOUVAIN_SUBROUNDS says otherwise)
+__device__ static inline int lv_class(uint32_t x, int S) {
+  const uint32_t h = lv_hash(x);
+  return (S & (S - 1)) == 0 ? (int)(h & (uint32_t)(S - 1)) : (int)(h % (uint32_t)S);
+}
+
 // One wave per vertex (at most LV_SMALL_DEG entries, two per lane, loaded ONCE and evaluated for every copy of the graph).  The wave's
 // table is cleared once: the lane that claims a slot ("owner") evaluates that community and hands the slot back empty.
-// FIRST (sub-round 0): every vertex of a running component also contributes the weight of its entries inside its own community —
-// the internal weight of the labels this kernel reads, i.e. of the previous iteration's result (k_lv_decide turns it into Q).
+// A vertex of at most 64 entries (one per lane) takes TWO copies per round: the entries go into the table once with copy b's communities and
+// once with copy b + 1's — the community ids of two copies never meet — and the two evaluations overlap their latencies.
+// The entries INSIDE the vertex's own community — in a settled partition most of the row — never go through the table: they are added up in
+// an LDS cell of their own (one instruction; the kernel is bound by VALU issue, ~130 instructions per evaluation before this form, and the
+// LDS pipe idles), which is the staying side of the decision and, FIRST (sub-round 0), the vertex's share of the internal weight of the
+// labels this kernel reads, i.e. of the previous iteration's result (k_lv_decide turns it into Q).
+// Lane l < 16 carries component l's state for the whole kernel (read with v_readlane: no control-block loads in the loop).
 template <bool FIRST>
 __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __restrict__ ctl, LvMove mv, const int32_t* __restrict__ comm,
                                                        const u64* __restrict__ K, const int32_t* __restrict__ size, int32_t* __restrict__ next,
                                                        u64* __restrict__ part_in, unsigned* __restrict__ part_mv) {
   __shared__ int32_t s_key[4][LV_SMALL_SLOTS];
   __shared__ u64 s_val[4][LV_SMALL_SLOTS];
+  __shared__ u64 s_stay[4][2];
   __shared__ u64 s_acc[4][LV_MAX_B];
   __shared__ unsigned s_cnt[4][LV_MAX_B];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int32_t* key = s_key[wave];
   u64* val = s_val[wave];
+  u64* cell = s_stay[wave];
   // the table belongs to this wave alone and LDS serves a wave's operations in issue order: a wave-level fence (no
   // workgroup barrier) is all that separates clearing, filling and reading it
   for (int t = lane; t < LV_SMALL_SLOTS; t += 64) { key[t] = -1; val[t] = 0ull; }
+  if (lane < 2) cell[lane] = 0ull;
+  int st_run = 0, st_S = 1;
+  uint32_t st_off = 0;       // seed - v0: the class of union vertex gv is that of hash(gv + st_off)
+  if (lane < LV_MAX_B) {
+    const LvComp& C = ctl->c[lane];
+    st_run = lv_runs(C, mv.s, FIRST) ? 1 : 0;
+    st_S = C.S;
+    st_off = C.seed - (uint32_t)C.v0;
+  }
   lv_wave_sync();
   u64 acc = 0;               // lane b: internal weight summed for component b
   unsigned cnt = 0;          // lane b: vertices of component b that move
@@ -395,73 +491,82 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __res
     if (e0 < hi) { u0 = g.nbr[e0]; w0 = g.wt[e0]; if (u0 == v) u0 = -1; }
     if (e1 < hi) { u1 = g.nbr[e1]; w1 = g.wt[e1]; if (u1 == v) u1 = -1; }
     const u64 kvv = g.kv[v];
-    for (int b = 0; b < g.rep; ++b) {
-      const int comp = g.vcomp ? (int)g.vcomp[v] : b;
-      const LvComp& C = ctl->c[comp];
-      if (!lv_runs(C, mv.s, FIRST)) continue;
-      const int64_t base = (int64_t)b * g.nb, gv = base + v;
-      const bool in_class = C.S == 1 || (int)(lv_hash((uint32_t)(gv - C.v0) + C.seed) % (uint32_t)C.S) == mv.s;
-      if (!FIRST && !in_class) continue;
-      const int32_t cv = comm[gv];
-      const int32_t c0 = u0 >= 0 ? comm[base + u0] : -1, c1 = u1 >= 0 ? comm[base + u1] : -1;
-      if (FIRST && !in_class) {                  // only its share of the internal weight
-        const u64 t = lv_wave_sum((c0 == cv ? w0 : 0ull) + (c1 == cv ? w1 : 0ull));
-        if (lane == comp) acc += t;
-        continue;
+    const double kvd = (double)kvv;
+    const int comp0 = g.vcomp ? (int)g.vcomp[v] : 0;
+    const bool pair = g.rep > 1 && hi - lo <= 64;
+    for (int b = 0; b < g.rep; b += pair ? 2 : 1) {
+      // side A: copy b (a coarse level: the vertex's component); side B: copy b + 1 in a pair round
+      const int compA = g.vcomp ? comp0 : b, compB = b + 1;
+      const uint32_t gvA = (uint32_t)(b * g.nb + v), gvB = gvA + (uint32_t)g.nb;
+      int modeA = 0, modeB = 0;      // 0: not in this round, 1: only its share of the internal weight (sub-round 0, other class), 2: evaluate
+      if (__builtin_amdgcn_readlane(st_run, compA)) {
+        const int S = __builtin_amdgcn_readlane(st_S, compA);
+        const bool in_class = S == 1 || lv_class(gvA + (uint32_t)__builtin_amdgcn_readlane((int)st_off, compA), S) == mv.s;
+        modeA = in_class ? 2 : FIRST ? 1 : 0;
       }
-      int slot0 = -1, slot1 = -1;
-      bool own0 = false, own1 = false;
-      if (c0 >= 0) {
-        uint32_t h = lv_hash((uint32_t)c0) & (LV_SMALL_SLOTS - 1);
-        for (;;) {
-          const int32_t old = atomicCAS(&key[h], -1, c0);
-          if (old == -1) { own0 = true; break; }
-          if (old == c0) break;
-          h = (h + 1) & (LV_SMALL_SLOTS - 1);
-        }
-        slot0 = (int)h;
-        atomicAdd(&val[h], w0);
+      if (pair && compB < g.rep && __builtin_amdgcn_readlane(st_run, compB)) {
+        const int S = __builtin_amdgcn_readlane(st_S, compB);
+        const bool in_class = S == 1 || lv_class(gvB + (uint32_t)__builtin_amdgcn_readlane((int)st_off, compB), S) == mv.s;
+        modeB = in_class ? 2 : FIRST ? 1 : 0;
       }
-      if (c1 >= 0) {
-        uint32_t h = lv_hash((uint32_t)c1) & (LV_SMALL_SLOTS - 1);
-        for (;;) {
-          const int32_t old = atomicCAS(&key[h], -1, c1);
-          if (old == -1) { own1 = true; break; }
-          if (old == c1) break;
-          h = (h + 1) & (LV_SMALL_SLOTS - 1);
-        }
-        slot1 = (int)h;
-        atomicAdd(&val[h], w1);
-      }
+      if (!modeA && !modeB) continue;
+      const uint32_t baseA = gvA - (uint32_t)v, baseB = gvB - (uint32_t)v;
+      // this lane's entries: (cx, wx) belongs to side A, (cy, wy) to side B in a pair round and to side A otherwise
+      int32_t cvA = 0, cvB = 0, cx = -1, cy = -1;
+      if (modeA) { cvA = comm[gvA]; if (u0 >= 0) cx = comm[baseA + (uint32_t)u0]; }
+      if (pair) { if (modeB) { cvB = comm[gvB]; if (u0 >= 0) cy = comm[baseB + (uint32_t)u0]; } }
+      else if (modeA && u1 >= 0) cy = comm[baseA + (uint32_t)u1];
+      const u64 wx = w0, wy = pair ? w0 : w1;
+      const int32_t cvy = pair ? cvB : cvA;
+      const bool evA = modeA == 2, evB = modeB == 2, evY = pair ? evB : evA;
+      const bool inx = cx >= 0 && cx == cvA, iny = cy >= 0 && cy == cvy;
+      // totals and sizes the decisions need, on their way while the table is filled
+      u64 Kx = 0, Ky = 0, KcvA = 0, KcvB = 0;
+      int32_t szA = 0, szgA = 0, szB = 0, szgB = 0;
+      if (evA) { KcvA = K[cvA]; szA = size[cvA]; szgA = size[gvA]; if (cx >= 0 && !inx) Kx = K[cx]; }
+      if (evB) { KcvB = K[cvB]; szB = size[cvB]; szgB = size[gvB]; }
+      if (evY && cy >= 0 && !iny) Ky = K[cy];
+      if (inx) atomicAdd(&cell[0], wx);
+      if (iny) atomicAdd(&cell[pair ? 1 : 0], wy);
+      int slotx = -1, sloty = -1;
+      bool ownx = false, owny = false;
+      if (evA && cx >= 0 && !inx) slotx = lv_insert<LV_SMALL_SLOTS>(key, val, cx, wx, &ownx);
+      if (evY && cy >= 0 && !iny) sloty = lv_insert<LV_SMALL_SLOTS>(key, val, cy, wy, &owny);
       lv_wave_sync();
-      const double kvd = (double)kvv;
-      double bg = -INFINITY;
-      int32_t bc = INT32_MAX;
-      u64 stay_w = 0;
-      if (own0) {
-        const u64 w = val[slot0];
-        if (c0 == cv) stay_w = w;
-        else { const double gain = (double)w - kvd * (double)K[c0] * mv.r; if (lv_better(gain, c0, bg, bc)) { bg = gain; bc = c0; } }
-        key[slot0] = -1; val[slot0] = 0ull;
+      const u64 stayA = cell[0], stayB = cell[1];
+      LvBest ba{-INFINITY, INT32_MAX}, bb{-INFINITY, INT32_MAX};
+      if (ownx) {
+        ba.g = (double)val[slotx] - kvd * (double)Kx * mv.r; ba.c = cx;
+        key[slotx] = -1; val[slotx] = 0ull;
       }
-      if (own1) {
-        const u64 w = val[slot1];
-        if (c1 == cv) stay_w = w;
-        else { const double gain = (double)w - kvd * (double)K[c1] * mv.r; if (lv_better(gain, c1, bg, bc)) { bg = gain; bc = c1; } }
-        key[slot1] = -1; val[slot1] = 0ull;
+      if (owny) {
+        LvBest& t = pair ? bb : ba;
+        const double gain = (double)val[sloty] - kvd * (double)Ky * mv.r;
+        if (lv_better(gain, cy, t.g, t.c)) { t.g = gain; t.c = cy; }
+        key[sloty] = -1; val[sloty] = 0ull;
       }
-      for (int d = 32; d > 0; d >>= 1) {
-        const double og = __shfl_xor(bg, d);
-        const int32_t oc = __shfl_xor(bc, d);
-        const u64 ow = __shfl_xor(stay_w, d);
-        if (lv_better(og, oc, bg, bc)) { bg = og; bc = oc; }
-        stay_w = ow > stay_w ? ow : stay_w;
+      if (evA) ba = lv_wave_best(ba);
+      if (evB) bb = lv_wave_best(bb);
+      lv_wave_sync();                            // every lane has read the cells and the slots: they are emptied before the next round fills them
+      if (lane < 2) cell[lane] = 0ull;
+      if (modeA) {
+        if (FIRST && lane == compA) acc += stayA;
+        if (evA) {
+          bool moved;
+          const int32_t to = lv_decide_vertex((int64_t)gvA, cvA, ba.g, ba.c, stayA, kvv, mv.r, KcvA, szA, szgA, size, &moved);
+          if (lane == 0) next[gvA] = to;
+          if (lane == compA) cnt += moved ? 1u : 0u;
+        }
       }
-      lv_wave_sync();                            // the slots are empty again before the next vertex fills them
-      bool moved;
-      const int32_t to = lv_decide_vertex(gv, cv, bg, bc, stay_w, kvv, mv.r, K, size, &moved);
-      if (lane == 0) next[gv] = to;
-      if (lane == comp) { cnt += moved ? 1u : 0u; if (FIRST) acc += stay_w; }
+      if (modeB) {
+        if (FIRST && lane == compB) acc += stayB;
+        if (evB) {
+          bool moved;
+          const int32_t to = lv_decide_vertex((int64_t)gvB, cvB, bb.g, bb.c, stayB, kvv, mv.r, KcvB, szB, szgB, size, &moved);
+          if (lane == 0) next[gvB] = to;
+          if (lane == compB) cnt += moved ? 1u : 0u;
+        }
+      }
     }
   }
   if (lane < LV_MAX_B) { s_acc[wave][lane] = acc; s_cnt[wave][lane] = cnt; }
@@ -475,7 +580,97 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __res
   }
 }
 
-// One workgroup per listed vertex and copy (more than LV_SMALL_DEG entries): SLOTS = 2048 up to LV_MID_DEG entries, 8192 beyond.
+// One wave per listed vertex and copy (LV_SMALL_DEG < entries <= LV_MID_DEG; workgroups of two waves, a 1024-slot table and a list of the
+// claimed slots each).  The entries stream through in chunks of 64; up to 512 of them in one pass, beyond that in P passes, pass p taking the
+// communities of hash class p.  Nothing is cleared or scanned: the claimed slots are listed, evaluated from the list and handed back empty.
+template <bool FIRST>
+__global__ __launch_bounds__(128) void k_lv_move_mid(LvG g, const LvCtl* __restrict__ ctl, LvMove mv, int64_t n_list, const int32_t* __restrict__ list,
+                                                     const int32_t* __restrict__ comm, const u64* __restrict__ K, const int32_t* __restrict__ size,
+                                                     int32_t* __restrict__ next, u64* __restrict__ part_in, unsigned* __restrict__ part_mv,
+                                                     uint32_t* __restrict__ status) {
+  __shared__ int32_t s_key[2][LV_MID_SLOTS];
+  __shared__ u64 s_val[2][LV_MID_SLOTS];
+  __shared__ uint16_t s_list[2][LV_MID_SLOTS];
+  __shared__ u64 s_acc[2][LV_MAX_B];
+  __shared__ unsigned s_cnt[2][LV_MAX_B];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int32_t* key = s_key[wave];
+  u64* val = s_val[wave];
+  uint16_t* claimed = s_list[wave];
+  for (int t = lane; t < LV_MID_SLOTS; t += 64) { key[t] = -1; val[t] = 0ull; }
+  lv_wave_sync();
+  const u64 lt = (1ull << lane) - 1ull;
+  u64 acc = 0;
+  unsigned cnt = 0;
+  for (int64_t item = (int64_t)blockIdx.x * 2 + wave; item < n_list * g.rep; item += (int64_t)gridDim.x * 2) {
+    const int b = (int)(item / n_list);
+    const int64_t v = list[item - (int64_t)b * n_list];
+    const LvSide A = lv_side<FIRST>(g, ctl, mv.s, b, v, comm, K, size);
+    if (!A.mode) continue;
+    const int64_t lo = g.beg[v], hi = g.end[v];
+    if (FIRST && A.mode == 1) {
+      u64 t = 0;
+      for (int64_t e = lo + lane; e < hi; e += 64) {
+        const int32_t u = g.nbr[e];
+        if (u != v && comm[A.base + u] == A.cv) t += g.wt[e];
+      }
+      t = lv_wave_sum(t);
+      if (lane == A.comp) acc += t;
+      continue;
+    }
+    const u64 kvv = g.kv[v];
+    const double kvd = (double)kvv;
+    LvBest best{-INFINITY, INT32_MAX};
+    u64 stay = 0;                                  // this lane's entries inside the vertex's own community (never through the table: see k_lv_move_small)
+    const uint32_t P = (uint32_t)((hi - lo + LV_MID_SLOTS / 2 - 1) / (LV_MID_SLOTS / 2));
+    for (uint32_t p = 0; p < (P ? P : 1u); ++p) {
+      int n_claimed = 0;
+      for (int64_t e = lo + lane; e - lane < hi; e += 64) {          // (every lane stays in the loop: the ballot below is the whole wave's)
+        bool own = false;
+        int slot = -1;
+        if (e < hi) {
+          const int32_t u = g.nbr[e];
+          if (u != v) {
+            const int32_t c = comm[A.base + u];
+            if (c == A.cv) { if (p == 0) stay += g.wt[e]; }
+            else if (P <= 1 || (lv_hash((uint32_t)c) >> 13) % P == p) {
+              slot = lv_insert<LV_MID_SLOTS>(key, val, c, g.wt[e], &own);
+              if (slot < 0) atomicOr(status, GFICF_ST_TOO_DENSE);     // a hash class that overflows the table
+            }
+          }
+        }
+        const u64 m = __ballot(own);
+        if (own) claimed[n_claimed + __popcll(m & lt)] = (uint16_t)slot;
+        n_claimed += __popcll(m);
+      }
+      lv_wave_sync();
+      for (int i = lane; i < n_claimed; i += 64) {
+        const int slot = claimed[i];
+        const int32_t c = key[slot];
+        const double gain = (double)val[slot] - kvd * (double)K[c] * mv.r;
+        key[slot] = -1; val[slot] = 0ull;
+        if (lv_better(gain, c, best.g, best.c)) { best.g = gain; best.c = c; }
+      }
+      lv_wave_sync();
+    }
+    best = lv_wave_best(best);
+    stay = lv_wave_sum(stay);
+    bool moved;
+    const int32_t to = lv_decide_vertex(A.gv, A.cv, best.g, best.c, stay, kvv, mv.r, A.Kcv, A.szcv, A.szgv, size, &moved);
+    if (lane == 0) next[A.gv] = to;
+    if (lane == A.comp) { cnt += moved ? 1u : 0u; if (FIRST) acc += stay; }
+  }
+  if (lane < LV_MAX_B) { s_acc[wave][lane] = acc; s_cnt[wave][lane] = cnt; }
+  __syncthreads();
+  if (threadIdx.x < LV_MAX_B) {
+    const int t = threadIdx.x;
+    const size_t at = (size_t)blockIdx.x * LV_MAX_B + t;
+    if (FIRST) { part_in[at] = s_acc[0][t] + s_acc[1][t]; part_mv[at] = s_cnt[0][t] + s_cnt[1][t]; }
+    else part_mv[at] += s_cnt[0][t] + s_cnt[1][t];
+  }
+}
+
+// One workgroup per listed vertex and copy (more than LV_MID_DEG entries): an 8192-slot table, P passes over the entries.
 template <int SLOTS, bool FIRST>
 __global__ __launch_bounds__(256) void k_lv_move_big(LvG g, const LvCtl* __restrict__ ctl, LvMove mv, int large, int64_t n_list, const int32_t* __restrict__ big,
                                                      const int32_t* __restrict__ comm, const u64* __restrict__ K, const int32_t* __restrict__ size,
@@ -567,7 +762,7 @@ __global__ __launch_bounds__(256) void k_lv_move_big(LvG g, const LvCtl* __restr
       stay_w = s_w[0];
       for (int t = 1; t < 4; ++t) stay_w = s_w[t] > stay_w ? s_w[t] : stay_w;
       bool moved;
-      next[gv] = lv_decide_vertex(gv, cv, bg, bc, stay_w, kvv, mv.r, K, size, &moved);
+      next[gv] = lv_decide_vertex(gv, cv, bg, bc, stay_w, kvv, mv.r, K[cv], size[cv], size[gv], size, &moved);
       s_cnt[comp] += moved ? 1u : 0u;
       if (FIRST) s_acc[comp] += stay_w;
     }
@@ -621,15 +816,15 @@ __global__ __launch_bounds__(1024) void k_lv_decide(LvCtl* ctl, LvParts pt, int 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int B = ctl->B;
   const int pv = (it & 1) ^ 1;                   // the moved counts of the iteration before this one
-  for (int b = 0; b < B; ++b) {
+  {
+    // element e of a slab = (row e / 16, component e % 16): thread t takes elements t, t + 1024, ... — always component t % 16, coalesced
     u64 a = 0;
     unsigned m = 0;
-    for (int r = tid; r < nb_small; r += 1024) { a += pt.in_small[(size_t)r * LV_MAX_B + b]; if (it) m += pt.mv_small[pv][(size_t)r * LV_MAX_B + b]; }
-    for (int r = tid; r < nb_mid; r += 1024) { a += pt.in_mid[(size_t)r * LV_MAX_B + b]; if (it) m += pt.mv_mid[pv][(size_t)r * LV_MAX_B + b]; }
-    for (int r = tid; r < nb_large; r += 1024) { a += pt.in_large[(size_t)r * LV_MAX_B + b]; if (it) m += pt.mv_large[pv][(size_t)r * LV_MAX_B + b]; }
-    a = lv_wave_sum(a);
-    for (int d = 32; d > 0; d >>= 1) m += __shfl_xor(m, d);
-    if (lane == 0) { s_in[wave][b] = a; s_mv[wave][b] = m; }
+    for (int e = tid; e < nb_small * LV_MAX_B; e += 1024) { a += pt.in_small[e]; if (it) m += pt.mv_small[pv][e]; }
+    for (int e = tid; e < nb_mid * LV_MAX_B; e += 1024) { a += pt.in_mid[e]; if (it) m += pt.mv_mid[pv][e]; }
+    for (int e = tid; e < nb_large * LV_MAX_B; e += 1024) { a += pt.in_large[e]; if (it) m += pt.mv_large[pv][e]; }
+    for (int d = 32; d >= LV_MAX_B; d >>= 1) { a += __shfl_xor(a, d); m += __shfl_xor(m, d); }      // lanes l, l + 16, l + 32, l + 48 hold component l % 16
+    if (lane < LV_MAX_B) { s_in[wave][lane] = a; s_mv[wave][lane] = m; }
   }
   __syncthreads();
   __shared__ int s_cont[LV_MAX_B];
@@ -663,6 +858,7 @@ __global__ __launch_bounds__(1024) void k_lv_decide(LvCtl* ctl, LvParts pt, int 
         C.iter += 1;
         cont = action == LV_CONTINUE;
         host->q_iter[tid] = q;
+        host->mv_iter[tid] = moved;
       }
     }
     s_cont[tid] = cont;
@@ -1089,7 +1285,6 @@ struct LvWs {
   int32_t *comm, *next, *snapc[2], *size, *snapS[2], *cur, *lab, *seedl, *tops, *best, *cnt, *rank;
   u64 *K, *snapK[2];
   int64_t* flag;            // n_union + 1 entries: the renumbering scan
-  int64_t* cap;             // n_union + 1 entries: row capacities -> row starts of the next level
   u64 *keys_a, *vals_a, *keys_b, *vals_b;      // final numbering (N entries)
   void* sort_tmp; size_t sort_tmp_bytes;
   LvParts pt;
@@ -1115,7 +1310,6 @@ static size_t lv_carve(LvWs* w, void* base, int64_t N, int64_t nnz, int B) {
   d.best = b.take<int32_t>(n); d.cnt = b.take<int32_t>(n); d.rank = b.take<int32_t>(n);
   d.K = b.take<u64>(nu);
   d.flag = b.take<int64_t>(nu + 1);
-  d.cap = b.take<int64_t>(nu + 1);
   d.keys_a = b.take<u64>(n); d.vals_a = b.take<u64>(n); d.keys_b = b.take<u64>(n); d.vals_b = b.take<u64>(n);
   d.sort_tmp_bytes = lv_sort_tmp_bytes((int64_t)n);
   d.sort_tmp = b.take<char>(d.sort_tmp_bytes);
@@ -1254,7 +1448,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   // local moving until every component's level has ended: one iteration ahead of the device's decisions, never draining the stream
   const auto local_moving = [&](const LvG& g, const Lists& L, int S_max) -> int {
     const unsigned gs = lv_grid(g.nb, 4, LV_GRID), ga = lv_grid(g.n, 256, 2048);
-    const unsigned gm = L.n_mid ? (unsigned)((int64_t)L.n_mid * g.rep < LV_GRID_BIG ? (int64_t)L.n_mid * g.rep : LV_GRID_BIG) : 0u;
+    const unsigned gm = L.n_mid ? (unsigned)(((int64_t)L.n_mid * g.rep + 1) / 2 < LV_GRID_BIG ? ((int64_t)L.n_mid * g.rep + 1) / 2 : LV_GRID_BIG) : 0u;      // two waves a workgroup
     const unsigned gl = L.n_large ? (unsigned)((int64_t)L.n_large * g.rep < LV_GRID_BIG ? (int64_t)L.n_large * g.rep : LV_GRID_BIG) : 0u;
     for (int it = 0; it <= LV_MAX_ITERS + 1; ++it) {
       const int par = it & 1;
@@ -1265,7 +1459,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
         if (s == 0) {
           hipLaunchKernelGGL(k_lv_move_small<true>, dim3(gs), dim3(256), 0, st, g, (const LvCtl*)w.ctl, mv, (const int32_t*)w.comm, (const u64*)w.K,
                              (const int32_t*)w.size, w.next, w.pt.in_small, w.pt.mv_small[par]);
-          if (gm) hipLaunchKernelGGL((k_lv_move_big<LV_MID_SLOTS, true>), dim3(gm), dim3(256), LV_MID_SLOTS * 12, st, g, (const LvCtl*)w.ctl, mv, 0, (int64_t)L.n_mid, L.big,
+          if (gm) hipLaunchKernelGGL(k_lv_move_mid<true>, dim3(gm), dim3(128), 0, st, g, (const LvCtl*)w.ctl, mv, (int64_t)L.n_mid, L.big,
                                      (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_mid, w.pt.mv_mid[par], ctx->d_status);
           if (gl) hipLaunchKernelGGL((k_lv_move_big<LV_BIG_SLOTS, true>), dim3(gl), dim3(256), LV_BIG_SLOTS * 12, st, g, (const LvCtl*)w.ctl, mv, 1, (int64_t)L.n_large, L.big,
                                      (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_large, w.pt.mv_large[par], ctx->d_status);
@@ -1273,7 +1467,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
         } else {
           hipLaunchKernelGGL(k_lv_move_small<false>, dim3(gs), dim3(256), 0, st, g, (const LvCtl*)w.ctl, mv, (const int32_t*)w.comm, (const u64*)w.K,
                              (const int32_t*)w.size, w.next, w.pt.in_small, w.pt.mv_small[par]);
-          if (gm) hipLaunchKernelGGL((k_lv_move_big<LV_MID_SLOTS, false>), dim3(gm), dim3(256), LV_MID_SLOTS * 12, st, g, (const LvCtl*)w.ctl, mv, 0, (int64_t)L.n_mid, L.big,
+          if (gm) hipLaunchKernelGGL(k_lv_move_mid<false>, dim3(gm), dim3(128), 0, st, g, (const LvCtl*)w.ctl, mv, (int64_t)L.n_mid, L.big,
                                      (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_mid, w.pt.mv_mid[par], ctx->d_status);
           if (gl) hipLaunchKernelGGL((k_lv_move_big<LV_BIG_SLOTS, false>), dim3(gl), dim3(256), LV_BIG_SLOTS * 12, st, g, (const LvCtl*)w.ctl, mv, 1, (int64_t)L.n_large, L.big,
                                      (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_large, w.pt.mv_large[par], ctx->d_status);
@@ -1286,7 +1480,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
         GFICF_HIP_CHECK(hipEventSynchronize(ev[par ^ 1]));
         if (debug) {
           fprintf(stderr, "[louvain]   n=%lld iter %d: %d component(s) go on;", (long long)g.n, it - 1, host->n_cont[it - 1]);
-          for (int b = 0; b < Bmax; ++b) fprintf(stderr, " %.9f", host->q_iter[b]);
+          for (int b = 0; b < Bmax; ++b) fprintf(stderr, " %.9f (%u moved)", host->q_iter[b], host->mv_iter[b]);
           fprintf(stderr, "\n");
         }
         if (host->n_cont[it - 1] == 0) break;        // every level has ended: the iteration just enqueued does nothing
@@ -1306,26 +1500,25 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   };
   // g reduced by the labels newid[comm[.]] (the components with `cont` set) into the arrays of nl, and the workgroup-path lists of the result
   const auto reduce = [&](const LvG& g, const Lists& L, const int64_t* newid, LvLevel& nl) -> int {
-    GFICF_HIP_CHECK(hipMemsetAsync(w.cap, 0, sizeof(int64_t) * (size_t)(g.n + 1), st));
+    GFICF_HIP_CHECK(hipMemsetAsync(nl.beg, 0, sizeof(int64_t) * (size_t)(g.n + 1), st));
     GFICF_HIP_CHECK(hipMemsetAsync(w.cur, 0, sizeof(int32_t) * (size_t)g.n, st));
     hipLaunchKernelGGL(k_lv_rowcap, dim3(lv_grid(g.n, 256, 1024)), dim3(256), 0, st, g, (const LvCtl*)w.ctl, (const int32_t*)w.comm, newid, (const u64*)w.K,
-                       (const int32_t*)w.size, w.cap, nl.kv, nl.vcomp);
-    const int rc2 = gficf_exclusive_scan_i64(ctx, w.cap, g.n + 1);
+                       (const int32_t*)w.size, nl.beg, nl.kv, nl.vcomp);
+    const int rc2 = gficf_exclusive_scan_i64(ctx, nl.beg, g.n + 1);
     if (rc2) return rc2;
     hipLaunchKernelGGL(k_lv_emit_small, dim3(lv_grid(g.nb, 4, LV_GRID)), dim3(256), 0, st, g, (const LvCtl*)w.ctl, (const int32_t*)w.comm, newid,
-                       (const int64_t*)w.cap, w.cur, nl.nbr, nl.wt);
+                       (const int64_t*)nl.beg, w.cur, nl.nbr, nl.wt);
     if (L.n_mid) {
       const unsigned gm = (unsigned)((int64_t)L.n_mid * g.rep < LV_GRID_BIG ? (int64_t)L.n_mid * g.rep : LV_GRID_BIG);
-      hipLaunchKernelGGL(k_lv_emit_big<LV_MID_SLOTS>, dim3(gm), dim3(256), LV_MID_SLOTS * 12, st, g, (const LvCtl*)w.ctl, 0, (int64_t)L.n_mid, L.big, (const int32_t*)w.comm, newid,
-                         (const int64_t*)w.cap, w.cur, nl.nbr, nl.wt, ctx->d_status);
+      hipLaunchKernelGGL(k_lv_emit_big<LV_EMIT_SLOTS>, dim3(gm), dim3(256), LV_EMIT_SLOTS * 12, st, g, (const LvCtl*)w.ctl, 0, (int64_t)L.n_mid, L.big, (const int32_t*)w.comm, newid,
+                         (const int64_t*)nl.beg, w.cur, nl.nbr, nl.wt, ctx->d_status);
     }
     if (L.n_large) {
       const unsigned gl = (unsigned)((int64_t)L.n_large * g.rep < LV_GRID_BIG ? (int64_t)L.n_large * g.rep : LV_GRID_BIG);
       hipLaunchKernelGGL(k_lv_emit_big<LV_BIG_SLOTS>, dim3(gl), dim3(256), LV_BIG_SLOTS * 12, st, g, (const LvCtl*)w.ctl, 1, (int64_t)L.n_large, L.big, (const int32_t*)w.comm, newid,
-                         (const int64_t*)w.cap, w.cur, nl.nbr, nl.wt, ctx->d_status);
+                         (const int64_t*)nl.beg, w.cur, nl.nbr, nl.wt, ctx->d_status);
     }
-    GFICF_HIP_CHECK(hipMemcpyAsync(nl.beg, w.cap, sizeof(int64_t) * (size_t)(g.n + 1), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_lv_finish_rows, dim3(lv_grid(g.n, 256, 1024)), dim3(256), 0, st, (const int64_t*)&w.ctl->n_union2, (const int64_t*)w.cap,
+    hipLaunchKernelGGL(k_lv_finish_rows, dim3(lv_grid(g.n, 256, 1024)), dim3(256), 0, st, (const int64_t*)&w.ctl->n_union2, (const int64_t*)nl.beg,
                        (const int32_t*)w.cur, nl.end);
     // the next level's lists (its vertex count is on the device: n_union2)
     GFICF_HIP_CHECK(hipMemsetAsync(&w.ctl->n_mid, 0, 2 * sizeof(unsigned), st));
