@@ -109,6 +109,7 @@ struct LvComp {              // one start ("component" of the union)
   int64_t n_labels;          // the labels of the last renumbering lie in [0, n_labels)
   int64_t newbase, n2;       // after the level's renumbering: first new id, communities in use
   u64 self_w, in_w;          // weight folded into the level's vertices; internal weight of the accepted labels on the level's graph
+  u64 in_run;                // internal weight of the labels as they are (kept up to date by the changes the sub-round-0 kernels report)
   double q_prev, q_final;
   uint32_t seed;             // of the sub-round class hash: what a "random start" varies
   int32_t S;                 // sub-rounds of the level
@@ -254,6 +255,7 @@ __global__ void k_lv_ctl_level(LvCtl* ctl, int mode, int pass, int64_t N, int s_
     C.action = LV_IDLE;
     C.iter = 0;
     C.level_moved = 0;
+    C.in_run = 0;
     s_nl[b] = b < B && C.live ? C.n_labels : 0;
   }
   __syncthreads();
@@ -267,8 +269,10 @@ __global__ void k_lv_ctl_level(LvCtl* ctl, int mode, int pass, int64_t N, int s_
 // Labels (seed == NULL: singletons), totals and sizes of the level.  A seeded start leaves totals and sizes at zero for
 // k_lv_accum.  The vertices of a component that does not take part are dead: own label, size 0 (they vanish at the next renumbering).
 __global__ __launch_bounds__(256) void k_lv_init(LvG g, const LvCtl* __restrict__ ctl, const int32_t* __restrict__ seed, int32_t* __restrict__ comm,
-                                                 u64* __restrict__ K, int32_t* __restrict__ size) {
+                                                 u64* __restrict__ K, int32_t* __restrict__ size, int32_t* __restrict__ mark_r, int32_t* __restrict__ mark_w,
+                                                 u64* __restrict__ iw) {
   for (int64_t gv = (int64_t)blockIdx.x * 256 + threadIdx.x; gv < g.n; gv += (int64_t)gridDim.x * 256) {
+    mark_r[gv] = 0; mark_w[gv] = 0; iw[gv] = 0ull;
     const int64_t b = g.rep > 1 ? gv / g.nb : 0;
     const int64_t v = gv - b * g.nb;
     const int comp = g.vcomp ? (int)g.vcomp[gv] : (int)b;
@@ -330,6 +334,11 @@ __global__ __launch_bounds__(256) void k_lv_list_big(LvG g, const int64_t* __res
 struct LvMove {
   double r;            // resolution / 2W (in fixed-point units of 2W)
   int s;               // this sub-round's hash class
+  // Pruning ("fast local moving"): a vertex is looked at again only when it or one of its neighbours has moved since it was last looked at.
+  // Every sub-round kernel of a level has an epoch (iteration * sub-rounds + sub-round + 1); a vertex that decides to move stamps itself and
+  // its neighbours with it (plain stores of one value: no clearing, no race); a vertex of this kernel's class was last looked at one
+  // iteration ago, so it is looked at now iff its stamp >= thr = epoch - sub-rounds (stamps start at 0: everybody in iteration 0).
+  int epoch, thr;
 };
 
 __device__ static inline void lv_wave_sync() {
@@ -457,6 +466,7 @@ __device__ static inline int lv_class(uint32_t x, int S) {
 template <bool FIRST>
 __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __restrict__ ctl, LvMove mv, const int32_t* __restrict__ comm,
                                                        const u64* __restrict__ K, const int32_t* __restrict__ size, int32_t* __restrict__ next,
+                                                       const int32_t* __restrict__ mark_r, int32_t* __restrict__ mark_w, u64* __restrict__ iw,
                                                        u64* __restrict__ part_in, unsigned* __restrict__ part_mv) {
   __shared__ int32_t s_key[4][LV_SMALL_SLOTS];
   __shared__ u64 s_val[4][LV_SMALL_SLOTS];
@@ -509,6 +519,9 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __res
         const bool in_class = S == 1 || lv_class(gvB + (uint32_t)__builtin_amdgcn_readlane((int)st_off, compB), S) == mv.s;
         modeB = in_class ? 2 : FIRST ? 1 : 0;
       }
+      // looked at only when it or a neighbour has moved since it was last looked at (the stamps this kernel reads were merged before it began)
+      if (modeA && mark_r[gvA] < mv.thr) modeA = 0;
+      if (modeB && mark_r[gvB] < mv.thr) modeB = 0;
       if (!modeA && !modeB) continue;
       const uint32_t baseA = gvA - (uint32_t)v, baseB = gvB - (uint32_t)v;
       // this lane's entries: (cx, wx) belongs to side A, (cy, wy) to side B in a pair round and to side A otherwise
@@ -550,21 +563,38 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __res
       lv_wave_sync();                            // every lane has read the cells and the slots: they are emptied before the next round fills them
       if (lane < 2) cell[lane] = 0ull;
       if (modeA) {
-        if (FIRST && lane == compA) acc += stayA;
+        if (FIRST) {                             // the change of its share of the internal weight since it was last looked at
+          const u64 was = iw[gvA];
+          if (lane == 0) iw[gvA] = stayA;
+          if (lane == compA) acc += stayA - was;
+        }
         if (evA) {
           bool moved;
           const int32_t to = lv_decide_vertex((int64_t)gvA, cvA, ba.g, ba.c, stayA, kvv, mv.r, KcvA, szA, szgA, size, &moved);
           if (lane == 0) next[gvA] = to;
           if (lane == compA) cnt += moved ? 1u : 0u;
+          if (moved) {                           // it and its neighbours are looked at again
+            if (lane == 0) mark_w[gvA] = mv.epoch;
+            if (u0 >= 0) mark_w[baseA + (uint32_t)u0] = mv.epoch;
+            if (!pair && u1 >= 0) mark_w[baseA + (uint32_t)u1] = mv.epoch;
+          }
         }
       }
       if (modeB) {
-        if (FIRST && lane == compB) acc += stayB;
+        if (FIRST) {
+          const u64 was = iw[gvB];
+          if (lane == 0) iw[gvB] = stayB;
+          if (lane == compB) acc += stayB - was;
+        }
         if (evB) {
           bool moved;
           const int32_t to = lv_decide_vertex((int64_t)gvB, cvB, bb.g, bb.c, stayB, kvv, mv.r, KcvB, szB, szgB, size, &moved);
           if (lane == 0) next[gvB] = to;
           if (lane == compB) cnt += moved ? 1u : 0u;
+          if (moved) {
+            if (lane == 0) mark_w[gvB] = mv.epoch;
+            if (u0 >= 0) mark_w[baseB + (uint32_t)u0] = mv.epoch;
+          }
         }
       }
     }
@@ -586,7 +616,8 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __res
 template <bool FIRST>
 __global__ __launch_bounds__(128) void k_lv_move_mid(LvG g, const LvCtl* __restrict__ ctl, LvMove mv, int64_t n_list, const int32_t* __restrict__ list,
                                                      const int32_t* __restrict__ comm, const u64* __restrict__ K, const int32_t* __restrict__ size,
-                                                     int32_t* __restrict__ next, u64* __restrict__ part_in, unsigned* __restrict__ part_mv,
+                                                     int32_t* __restrict__ next, const int32_t* __restrict__ mark_r, int32_t* __restrict__ mark_w,
+                                                     u64* __restrict__ iw, u64* __restrict__ part_in, unsigned* __restrict__ part_mv,
                                                      uint32_t* __restrict__ status) {
   __shared__ int32_t s_key[2][LV_MID_SLOTS];
   __shared__ u64 s_val[2][LV_MID_SLOTS];
@@ -606,7 +637,7 @@ __global__ __launch_bounds__(128) void k_lv_move_mid(LvG g, const LvCtl* __restr
     const int b = (int)(item / n_list);
     const int64_t v = list[item - (int64_t)b * n_list];
     const LvSide A = lv_side<FIRST>(g, ctl, mv.s, b, v, comm, K, size);
-    if (!A.mode) continue;
+    if (!A.mode || mark_r[A.gv] < mv.thr) continue;          // (pruning: see LvMove)
     const int64_t lo = g.beg[v], hi = g.end[v];
     if (FIRST && A.mode == 1) {
       u64 t = 0;
@@ -615,7 +646,9 @@ __global__ __launch_bounds__(128) void k_lv_move_mid(LvG g, const LvCtl* __restr
         if (u != v && comm[A.base + u] == A.cv) t += g.wt[e];
       }
       t = lv_wave_sum(t);
-      if (lane == A.comp) acc += t;
+      const u64 was = iw[A.gv];
+      if (lane == 0) iw[A.gv] = t;
+      if (lane == A.comp) acc += t - was;
       continue;
     }
     const u64 kvv = g.kv[v];
@@ -658,7 +691,16 @@ __global__ __launch_bounds__(128) void k_lv_move_mid(LvG g, const LvCtl* __restr
     bool moved;
     const int32_t to = lv_decide_vertex(A.gv, A.cv, best.g, best.c, stay, kvv, mv.r, A.Kcv, A.szcv, A.szgv, size, &moved);
     if (lane == 0) next[A.gv] = to;
-    if (lane == A.comp) { cnt += moved ? 1u : 0u; if (FIRST) acc += stay; }
+    if (FIRST) {
+      const u64 was = iw[A.gv];
+      if (lane == 0) iw[A.gv] = stay;
+      if (lane == A.comp) acc += stay - was;
+    }
+    if (lane == A.comp) cnt += moved ? 1u : 0u;
+    if (moved) {
+      if (lane == 0) mark_w[A.gv] = mv.epoch;
+      for (int64_t e = lo + lane; e < hi; e += 64) mark_w[A.base + g.nbr[e]] = mv.epoch;
+    }
   }
   if (lane < LV_MAX_B) { s_acc[wave][lane] = acc; s_cnt[wave][lane] = cnt; }
   __syncthreads();
@@ -674,11 +716,13 @@ __global__ __launch_bounds__(128) void k_lv_move_mid(LvG g, const LvCtl* __restr
 template <int SLOTS, bool FIRST>
 __global__ __launch_bounds__(256) void k_lv_move_big(LvG g, const LvCtl* __restrict__ ctl, LvMove mv, int large, int64_t n_list, const int32_t* __restrict__ big,
                                                      const int32_t* __restrict__ comm, const u64* __restrict__ K, const int32_t* __restrict__ size,
-                                                     int32_t* __restrict__ next, u64* __restrict__ part_in, unsigned* __restrict__ part_mv,
+                                                     int32_t* __restrict__ next, const int32_t* __restrict__ mark_r, int32_t* __restrict__ mark_w,
+                                                     u64* __restrict__ iw, u64* __restrict__ part_in, unsigned* __restrict__ part_mv,
                                                      uint32_t* __restrict__ status) {
   extern __shared__ unsigned char s_raw[];
   u64* val = (u64*)s_raw;
   int32_t* key = (int32_t*)(val + SLOTS);
+  __shared__ int s_moved;
   __shared__ double s_g[256];
   __shared__ u64 s_w[4], s_in[4];
   __shared__ int32_t s_c[256];
@@ -697,6 +741,7 @@ __global__ __launch_bounds__(256) void k_lv_move_big(LvG g, const LvCtl* __restr
     const int64_t base = (int64_t)b * g.nb, gv = base + v;
     const bool in_class = C.S == 1 || (int)(lv_hash((uint32_t)(gv - C.v0) + C.seed) % (uint32_t)C.S) == mv.s;
     if (!FIRST && !in_class) continue;
+    if (mark_r[gv] < mv.thr) continue;                                            // (pruning: see LvMove)
     const int64_t lo = g.beg[v], hi = g.end[v];
     const int32_t cv = comm[gv];
     const u64 kvv = g.kv[v];
@@ -709,7 +754,11 @@ __global__ __launch_bounds__(256) void k_lv_move_big(LvG g, const LvCtl* __restr
       t = lv_wave_sum(t);
       if ((tid & 63) == 0) s_in[tid >> 6] = t;
       __syncthreads();
-      if (tid == 0) s_acc[comp] += s_in[0] + s_in[1] + s_in[2] + s_in[3];
+      if (tid == 0) {
+        const u64 now = s_in[0] + s_in[1] + s_in[2] + s_in[3];
+        s_acc[comp] += now - iw[gv];
+        iw[gv] = now;
+      }
       __syncthreads();
       continue;
     }
@@ -764,8 +813,13 @@ __global__ __launch_bounds__(256) void k_lv_move_big(LvG g, const LvCtl* __restr
       bool moved;
       next[gv] = lv_decide_vertex(gv, cv, bg, bc, stay_w, kvv, mv.r, K[cv], size[cv], size[gv], size, &moved);
       s_cnt[comp] += moved ? 1u : 0u;
-      if (FIRST) s_acc[comp] += stay_w;
+      if (FIRST) { s_acc[comp] += stay_w - iw[gv]; iw[gv] = stay_w; }
+      s_moved = moved ? 1 : 0;
+      if (moved) mark_w[gv] = mv.epoch;
     }
+    __syncthreads();
+    if (s_moved)
+      for (int64_t e = lo + tid; e < hi; e += 256) mark_w[base + g.nbr[e]] = mv.epoch;
     __syncthreads();
   }
   __syncthreads();
@@ -835,9 +889,10 @@ __global__ __launch_bounds__(1024) void k_lv_decide(LvCtl* ctl, LvParts pt, int 
       if (C.level_done) {
         C.action = LV_IDLE;
       } else {
-        u64 in_now = 0;
+        u64 in_now = C.in_run;                       // + what the sub-round-0 kernels found changed (differences: the sums wrap as they should)
         unsigned moved = 0;
         for (int w = 0; w < 16; ++w) { in_now += s_in[w][tid]; moved += s_mv[w][tid]; }
+        C.in_run = in_now;
         double sq = 0.0;
         for (int j = 0; j < LV_SQ_BLOCKS; ++j) sq += pt.sq[tid * LV_SQ_BLOCKS + j];
         const double q = ((double)(in_now + C.self_w)) / two_w - q_coef * sq;          // sq = sum of squared community totals (fixed point)
@@ -878,7 +933,7 @@ __global__ __launch_bounds__(1024) void k_lv_decide(LvCtl* ctl, LvParts pt, int 
 __global__ __launch_bounds__(256) void k_lv_apply(LvG g, const LvCtl* __restrict__ ctl, int s, int parity, int32_t* __restrict__ comm,
                                                   const int32_t* __restrict__ next, u64* __restrict__ K, int32_t* __restrict__ size,
                                                   int32_t* __restrict__ snapc0, int32_t* __restrict__ snapc1, const u64* __restrict__ snapK_prev,
-                                                  const int32_t* __restrict__ snapS_prev) {
+                                                  const int32_t* __restrict__ snapS_prev, int32_t* __restrict__ mark_r, const int32_t* __restrict__ mark_w) {
   int32_t* const snap_now = parity ? snapc1 : snapc0;
   const int32_t* const snap_prev = parity ? snapc0 : snapc1;
   for (int64_t gv = (int64_t)blockIdx.x * 256 + threadIdx.x; gv < g.n; gv += (int64_t)gridDim.x * 256) {
@@ -886,6 +941,10 @@ __global__ __launch_bounds__(256) void k_lv_apply(LvG g, const LvCtl* __restrict
     const int comp = g.vcomp ? (int)g.vcomp[gv] : (int)b;
     const LvComp& C = ctl->c[comp];
     const int action = C.action;
+    if (C.level_done && action == LV_IDLE) continue;
+    // the stamps the sub-round's move kernels wrote become readable: those kernels read mark_r and write mark_w only, so what a vertex
+    // sees never depends on when a neighbour's store lands
+    { const int32_t mw = mark_w[gv]; if (mw > mark_r[gv]) mark_r[gv] = mw; }
     if (s == 0) {
       if (action == LV_CONTINUE) snap_now[gv] = comm[gv];
       else if (action == LV_STOP_UNDO) { comm[gv] = snap_prev[gv]; K[gv] = snapK_prev[gv]; size[gv] = snapS_prev[gv]; }
@@ -1282,8 +1341,8 @@ struct LvLevel {          // a coarse graph's arrays (capacity: the union's entr
 struct LvWs {
   u64* wt0; u64* kv0; int32_t* big0;
   LvLevel lvl[2];
-  int32_t *comm, *next, *snapc[2], *size, *snapS[2], *cur, *lab, *seedl, *tops, *best, *cnt, *rank;
-  u64 *K, *snapK[2];
+  int32_t *comm, *next, *snapc[2], *size, *snapS[2], *cur, *lab, *seedl, *tops, *best, *cnt, *rank, *mark_r, *mark_w;
+  u64 *K, *snapK[2], *iw;
   int64_t* flag;            // n_union + 1 entries: the renumbering scan
   u64 *keys_a, *vals_a, *keys_b, *vals_b;      // final numbering (N entries)
   void* sort_tmp; size_t sort_tmp_bytes;
@@ -1308,7 +1367,8 @@ static size_t lv_carve(LvWs* w, void* base, int64_t N, int64_t nnz, int B) {
   for (int i = 0; i < 2; ++i) { d.snapc[i] = b.take<int32_t>(nu); d.snapS[i] = b.take<int32_t>(nu); d.snapK[i] = b.take<u64>(nu); }
   d.tops = b.take<int32_t>(nu * LV_MAX_SAVED);
   d.best = b.take<int32_t>(n); d.cnt = b.take<int32_t>(n); d.rank = b.take<int32_t>(n);
-  d.K = b.take<u64>(nu);
+  d.K = b.take<u64>(nu); d.iw = b.take<u64>(nu);
+  d.mark_r = b.take<int32_t>(nu); d.mark_w = b.take<int32_t>(nu);
   d.flag = b.take<int64_t>(nu + 1);
   d.keys_a = b.take<u64>(n); d.vals_a = b.take<u64>(n); d.keys_b = b.take<u64>(n); d.vals_b = b.take<u64>(n);
   d.sort_tmp_bytes = lv_sort_tmp_bytes((int64_t)n);
@@ -1442,7 +1502,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   struct Lists { const int32_t* big; unsigned n_mid, n_large; };
   // the labels as given (seed == NULL: singletons), totals, sizes
   const auto start_level = [&](const LvG& g, const int32_t* seed, bool binned) {
-    hipLaunchKernelGGL(k_lv_init, dim3(lv_grid(g.n, 256, 2048)), dim3(256), 0, st, g, (const LvCtl*)w.ctl, seed, w.comm, w.K, w.size);
+    hipLaunchKernelGGL(k_lv_init, dim3(lv_grid(g.n, 256, 2048)), dim3(256), 0, st, g, (const LvCtl*)w.ctl, seed, w.comm, w.K, w.size, w.mark_r, w.mark_w, w.iw);
     if (seed) hipLaunchKernelGGL(k_lv_accum, dim3(lv_grid(g.n, 256, 1024)), dim3(256), 0, st, g, (const LvCtl*)w.ctl, binned ? 1 : 0, (const int32_t*)w.comm, w.K, w.size);
   };
   // local moving until every component's level has ended: one iteration ahead of the device's decisions, never draining the stream
@@ -1455,25 +1515,25 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
       hipLaunchKernelGGL(k_lv_pre, dim3(LV_SQ_BLOCKS, (unsigned)Bmax), dim3(256), 0, st, (const LvCtl*)w.ctl, par, (const u64*)w.K, (const int32_t*)w.size,
                          w.snapK[par], w.snapS[par], w.pt.sq);
       for (int s = 0; s < S_max; ++s) {
-        const LvMove mv{r, s};
+        const LvMove mv{r, s, it * S_max + s + 1, it * S_max + s + 1 - S_max};
         if (s == 0) {
           hipLaunchKernelGGL(k_lv_move_small<true>, dim3(gs), dim3(256), 0, st, g, (const LvCtl*)w.ctl, mv, (const int32_t*)w.comm, (const u64*)w.K,
-                             (const int32_t*)w.size, w.next, w.pt.in_small, w.pt.mv_small[par]);
+                             (const int32_t*)w.size, w.next, (const int32_t*)w.mark_r, w.mark_w, w.iw, w.pt.in_small, w.pt.mv_small[par]);
           if (gm) hipLaunchKernelGGL(k_lv_move_mid<true>, dim3(gm), dim3(128), 0, st, g, (const LvCtl*)w.ctl, mv, (int64_t)L.n_mid, L.big,
-                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_mid, w.pt.mv_mid[par], ctx->d_status);
+                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, (const int32_t*)w.mark_r, w.mark_w, w.iw, w.pt.in_mid, w.pt.mv_mid[par], ctx->d_status);
           if (gl) hipLaunchKernelGGL((k_lv_move_big<LV_BIG_SLOTS, true>), dim3(gl), dim3(256), LV_BIG_SLOTS * 12, st, g, (const LvCtl*)w.ctl, mv, 1, (int64_t)L.n_large, L.big,
-                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_large, w.pt.mv_large[par], ctx->d_status);
+                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, (const int32_t*)w.mark_r, w.mark_w, w.iw, w.pt.in_large, w.pt.mv_large[par], ctx->d_status);
           hipLaunchKernelGGL(k_lv_decide, dim3(1), dim3(1024), 0, st, w.ctl, w.pt, (int)gs, (int)gm, (int)gl, it, two_w, q_coef, host);
         } else {
           hipLaunchKernelGGL(k_lv_move_small<false>, dim3(gs), dim3(256), 0, st, g, (const LvCtl*)w.ctl, mv, (const int32_t*)w.comm, (const u64*)w.K,
-                             (const int32_t*)w.size, w.next, w.pt.in_small, w.pt.mv_small[par]);
+                             (const int32_t*)w.size, w.next, (const int32_t*)w.mark_r, w.mark_w, w.iw, w.pt.in_small, w.pt.mv_small[par]);
           if (gm) hipLaunchKernelGGL(k_lv_move_mid<false>, dim3(gm), dim3(128), 0, st, g, (const LvCtl*)w.ctl, mv, (int64_t)L.n_mid, L.big,
-                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_mid, w.pt.mv_mid[par], ctx->d_status);
+                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, (const int32_t*)w.mark_r, w.mark_w, w.iw, w.pt.in_mid, w.pt.mv_mid[par], ctx->d_status);
           if (gl) hipLaunchKernelGGL((k_lv_move_big<LV_BIG_SLOTS, false>), dim3(gl), dim3(256), LV_BIG_SLOTS * 12, st, g, (const LvCtl*)w.ctl, mv, 1, (int64_t)L.n_large, L.big,
-                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, w.pt.in_large, w.pt.mv_large[par], ctx->d_status);
+                                     (const int32_t*)w.comm, (const u64*)w.K, (const int32_t*)w.size, w.next, (const int32_t*)w.mark_r, w.mark_w, w.iw, w.pt.in_large, w.pt.mv_large[par], ctx->d_status);
         }
         hipLaunchKernelGGL(k_lv_apply, dim3(ga), dim3(256), 0, st, g, (const LvCtl*)w.ctl, s, par, w.comm, (const int32_t*)w.next, w.K, w.size, w.snapc[0],
-                           w.snapc[1], (const u64*)w.snapK[par ^ 1], (const int32_t*)w.snapS[par ^ 1]);
+                           w.snapc[1], (const u64*)w.snapK[par ^ 1], (const int32_t*)w.snapS[par ^ 1], w.mark_r, (const int32_t*)w.mark_w);
       }
       GFICF_HIP_CHECK(hipEventRecord(ev[par], st));
       if (it >= 1) {                                 // the decision of the iteration BEFORE the one just enqueued
@@ -1632,7 +1692,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
           if (level) {
             // the level's graph: the finest one reduced by the saved vertex map (labels seed_base + top, new ids = the labels themselves)
             LvLevel& nl = w.lvl[0];
-            hipLaunchKernelGGL(k_lv_init, dim3(lv_grid(g0.n, 256, 2048)), dim3(256), 0, st, g0, (const LvCtl*)w.ctl, top, w.comm, w.K, w.size);
+            hipLaunchKernelGGL(k_lv_init, dim3(lv_grid(g0.n, 256, 2048)), dim3(256), 0, st, g0, (const LvCtl*)w.ctl, top, w.comm, w.K, w.size, w.mark_r, w.mark_w, w.iw);
             hipLaunchKernelGGL(k_lv_accum, dim3(lv_grid(g0.n, 256, 1024)), dim3(256), 0, st, g0, (const LvCtl*)w.ctl, 0, (const int32_t*)w.comm, w.K, w.size);
             hipLaunchKernelGGL(k_lv_internal, dim3(lv_grid(N, 4, LV_GRID)), dim3(256), 0, st, g0, (const LvCtl*)w.ctl, (const int32_t*)w.comm, w.pt.in_small);
             hipLaunchKernelGGL(k_lv_seed, dim3(lv_grid(N, 256, 512), (unsigned)Bmax), dim3(256), 0, st, N, (const LvCtl*)w.ctl, top, (const int32_t*)w.lab, w.seedl);
