@@ -463,6 +463,10 @@ __device__ static inline int lv_class(uint32_t x, int S) {
 // LDS pipe idles), which is the staying side of the decision and, FIRST (sub-round 0), the vertex's share of the internal weight of the
 // labels this kernel reads, i.e. of the previous iteration's result (k_lv_decide turns it into Q).
 // Lane l < 16 carries component l's state for the whole kernel (read with v_readlane: no control-block loads in the loop).
+// Tried on one box, variants interleaved, and dropped (profiles/r06_louvain_ab.txt): the copies as the OUTER loop, two at a time over all
+// vertices, so that what is gathered for them stays in L2 (the early iterations miss L2 35 % of the time, ~1 GB of fabric traffic a sub-round)
+// — 11.1 ms against 10.4 at the config-3 shape with ten starts: re-reading the rows per pair costs more than the misses; the copies
+// INTERLEAVED in the state arrays: more misses, not fewer; both entries probing in one wave-uniform loop instead of two per-lane loops: no change.
 template <bool FIRST>
 __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __restrict__ ctl, LvMove mv, const int32_t* __restrict__ comm,
                                                        const u64* __restrict__ K, const int32_t* __restrict__ size, int32_t* __restrict__ next,
@@ -541,6 +545,9 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __res
       if (evY && cy >= 0 && !iny) Ky = K[cy];
       if (inx) atomicAdd(&cell[0], wx);
       if (iny) atomicAdd(&cell[pair ? 1 : 0], wy);
+      // Both entries go into the table together: the first probes back to back (one LDS round trip for the two), and a loop that the WAVE
+      // leaves as soon as no lane is still probing (a scalar branch on a ballot; the per-lane probe loops this replaces were unrolled
+      // into ~10 exec-mask instructions per probe and waited for every round trip twice).  At most 128 entries in 256 slots: it ends.
       int slotx = -1, sloty = -1;
       bool ownx = false, owny = false;
       if (evA && cx >= 0 && !inx) slotx = lv_insert<LV_SMALL_SLOTS>(key, val, cx, wx, &ownx);
@@ -1028,8 +1035,9 @@ __global__ __launch_bounds__(256) void k_lv_rowcap(LvG g, const LvCtl* __restric
     const int64_t v = gv - b * g.nb;
     const int comp = g.vcomp ? (int)g.vcomp[gv] : (int)b;
     const LvComp& C = ctl->c[comp];
+    if (!C.live) continue;                                // (not numbered; and its own label may coincide with a live community's id when the labels are a rebuilt level's ids)
     const int32_t c = comm[gv];
-    if (size[c] <= 0) continue;                           // a vertex of a component that does not take part in the level: not numbered
+    if (size[c] <= 0) continue;
     // the new vertex its community becomes: weight and component written by every member alike (the members of a community belong to
     // one component; a community id need not lie in its component's vertex range: the rebuilt levels of algorithm 2)
     const int64_t c2 = newid[c];
