@@ -10,9 +10,12 @@
 // Vertices are the cells 1..N in cell order (igraph orders vertices by first appearance in the edge list, which is
 // the same whenever every cell keeps at least one edge).
 //
-// Device path: every kept edge emits the two entries (i,j) and (j,i) as 64-bit keys row << 32 | col, the entries
-// are ordered by one device-wide radix sort over just the bits in use (rocPRIM: a plain library sort, not the hot
-// path), equal keys are summed in sorted order and the row pointer comes from a binary search per row.
+// Device path: every kept edge emits the two entries (i,j) and (j,i) as 64-bit keys row << b | col (b = bits of N: 2 b
+// significant bits — 34 at 100 k cells, five 8-bit radix passes; through round 5 the column sat in the low 32 bits: 32 + b
+// bits, seven passes), the entries are ordered by one device-wide radix sort over just the bits in use (rocPRIM: a plain
+// library sort, not the hot path), equal keys are summed in sorted order and the row pointer comes from a binary search per row.
+// Round 6 tried the build without a sort (row buckets filled by atomics, rows ordered by a wave each): slower, because the
+// transposed half needs a device-scope atomic per edge — profiles/r06_adjacency_row_buckets.txt; closed.
 #include <cstring>
 #include <vector>
 
@@ -27,7 +30,7 @@ constexpr u64 ADJ_NONE = ~0ull;
 
 __global__ __launch_bounds__(256) void k_adj_emit(const double* __restrict__ from, const double* __restrict__ to,
                                                   const double* __restrict__ w, int64_t cap, const int64_t* __restrict__ n_edges_p,
-                                                  int64_t N, u64* __restrict__ keys, double* __restrict__ vals,
+                                                  int64_t N, int b, u64* __restrict__ keys, double* __restrict__ vals,
                                                   uint32_t* __restrict__ status) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= cap) return;
@@ -39,8 +42,8 @@ __global__ __launch_bounds__(256) void k_adj_emit(const double* __restrict__ fro
     if (fi >= 1.0 && fi <= (double)N && fj >= 1.0 && fj <= (double)N && fi == trunc(fi) && fj == trunc(fj)) {
       const u64 i = (u64)fi - 1ull, j = (u64)fj - 1ull;
       v = w[e];
-      k0 = (i << 32) | j;
-      if (i != j) k1 = (j << 32) | i;                 // a self edge counts once
+      k0 = (i << b) | j;
+      if (i != j) k1 = (j << b) | i;                  // a self edge counts once
     } else {
       atomicOr(status, GFICF_ST_BAD_ID);
     }
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void k_adj_heads(const u64* __restrict__ keys,
 }
 
 // one thread per head: sum its run of equal keys (in sorted, i.e. emission, order) and write the entry
-__global__ __launch_bounds__(256) void k_adj_write(const u64* __restrict__ keys, const double* __restrict__ vals, int64_t M,
+__global__ __launch_bounds__(256) void k_adj_write(const u64* __restrict__ keys, const double* __restrict__ vals, int64_t M, int b,
                                                    const int64_t* __restrict__ pos, int32_t* __restrict__ indices,
                                                    double* __restrict__ x, int32_t* __restrict__ urow) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -72,9 +75,9 @@ __global__ __launch_bounds__(256) void k_adj_write(const u64* __restrict__ keys,
   double s = vals[e];
   for (int64_t t = e + 1; t < M && keys[t] == k; ++t) s += vals[t];
   const int64_t p = pos[e];
-  indices[p] = (int32_t)(uint32_t)k;
+  indices[p] = (int32_t)(k & ((1ull << b) - 1ull));
   x[p] = s;
-  urow[p] = (int32_t)(k >> 32);
+  urow[p] = (int32_t)(k >> b);
 }
 
 // indptr[r] = first entry whose row is >= r
@@ -94,11 +97,12 @@ __global__ __launch_bounds__(256) void k_adj_indptr(const int32_t* __restrict__ 
 
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-inline int key_bits(int64_t N) {
+inline int id_bits(int64_t N) {                        // 2^b > N: an id in [0, N) never has all of its b bits set, so no real key is all ones
   int b = 1;
-  while (b < 32 && ((int64_t)1 << b) < N) ++b;
-  return 32 + b;                                        // col in the low 32 bits, row above
+  while (b < 32 && ((int64_t)1 << b) <= N) ++b;
+  return b;
 }
+inline int key_bits(int64_t N) { return 2 * id_bits(N); }   // col in the low b bits, row above
 
 size_t sort_temp_bytes(int64_t M, int bits) {
   size_t tmp = 0;
@@ -132,7 +136,7 @@ int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, con
   if (!d_from || !d_to || !d_weight || !d_ws || !d_indices || !d_x) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   if (ws_bytes < gficf_adjacency_workspace_bytes(N, edge_capacity)) GFICF_FAIL(GFICF_ERR_CAPACITY, "adjacency workspace too small");
   const int64_t M = 2 * edge_capacity;
-  const int bits = key_bits(N);
+  const int bits = key_bits(N), idb = id_bits(N);
   char* p = (char*)d_ws;
   u64* k_in = (u64*)p;        p += align256((size_t)M * sizeof(u64));
   u64* k_out = (u64*)p;       p += align256((size_t)M * sizeof(u64));
@@ -143,15 +147,16 @@ int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, con
   size_t tmp_bytes = sort_temp_bytes(M, bits);
   void* tmp = (void*)p;
   hipLaunchKernelGGL(k_adj_emit, dim3((unsigned)gficf_ceil_div(edge_capacity, 256)), dim3(256), 0, ctx->stream, d_from, d_to, d_weight,
-                     edge_capacity, d_n_edges, N, k_in, v_in, ctx->d_status);
+                     edge_capacity, d_n_edges, N, idb, k_in, v_in, ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
-  // unused slots carry the all-ones key; they only need to end up behind every real key, which have zeros above `bits`
+  // unused slots carry the all-ones key; they only need to end up behind every real key: ids are below 2^b - 1, so among the `bits` bits
+  // sorted the all-ones pattern is larger than any real key
   GFICF_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)M, 0u, (unsigned)bits, ctx->stream));
   hipLaunchKernelGGL(k_adj_heads, dim3((unsigned)gficf_ceil_div(M + 1, 256)), dim3(256), 0, ctx->stream, k_out, M, pos);
   GFICF_HIP_CHECK(hipGetLastError());
   int rc = gficf_exclusive_scan_i64(ctx, pos, M + 1);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_adj_write, dim3((unsigned)gficf_ceil_div(M, 256)), dim3(256), 0, ctx->stream, k_out, v_out, M, pos, d_indices, d_x, urow);
+  hipLaunchKernelGGL(k_adj_write, dim3((unsigned)gficf_ceil_div(M, 256)), dim3(256), 0, ctx->stream, k_out, v_out, M, idb, pos, d_indices, d_x, urow);
   hipLaunchKernelGGL(k_adj_indptr, dim3((unsigned)gficf_ceil_div(N + 1, 256)), dim3(256), 0, ctx->stream, urow, pos + M, N, d_indptr);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;

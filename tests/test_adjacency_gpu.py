@@ -39,6 +39,48 @@ def test_random_edge_lists(N, E, seed):
     assert (abs(A - A.T)).nnz == 0
 
 
+@pytest.mark.parametrize("hub_degrees", [(129, 300), (4096, 4097), (5000, 20000), (60000,)])
+def test_rows_of_every_length_class(hub_degrees):
+    """Round 6: the matrix is built row by row, no device-wide sort — a wave orders a row of up to 128 entries by ranking, a workgroup one of up
+    to 4096 in LDS, longer ones in global scratch.  Hubs of every class next to ordinary rows, edges in random order (nothing grouped), and
+    REPEATED edges whose weights are NOT exactly summable: a run of one column is added up in emission order (what the stable sort of the
+    old path gave), so the sums must match a sequential addition in edge order bit for bit."""
+    rng = np.random.default_rng(len(hub_degrees) * 1000 + hub_degrees[0])
+    N = 70000
+    f, t = [], []
+    for h, deg in enumerate(hub_degrees):
+        leaves = rng.choice(np.arange(len(hub_degrees), N), deg, replace=False)
+        out = rng.random(deg) < 0.5                                        # some edges leave the hub, some arrive
+        f += [np.where(out, h, leaves)]; t += [np.where(out, leaves, h)]
+    bg = 150000
+    f += [rng.integers(0, N, bg)]; t += [rng.integers(0, N, bg)]
+    f, t = np.concatenate(f), np.concatenate(t)
+    rep = rng.integers(0, len(f), 4000)                                    # repeated edges (some reversed): runs of 2, 3, 4 ... of one column
+    f, t = np.concatenate([f, f[rep], t[rep[:1500]]]), np.concatenate([t, t[rep], f[rep[:1500]]])
+    perm = rng.permutation(len(f))
+    f, t = f[perm], t[perm]
+    w = rng.random(len(f)) * 0.9 + 0.05                                    # arbitrary doubles
+    A = gficf_amd.jaccard_adjacency({"from": (f + 1).astype(np.float64), "to": (t + 1).astype(np.float64), "weight": w}, N)
+    # the checker: entries (row, col, emission position) sorted, runs summed sequentially in that order
+    r = np.concatenate([f, t[f != t]]); c = np.concatenate([t, f[f != t]])
+    pos = np.concatenate([2 * np.arange(len(f)), 2 * np.flatnonzero(f != t) + 1]); ww = np.concatenate([w, w[f != t]])
+    order = np.lexsort((pos, r, c))                                        # CSC: by column, then row, then position (the matrix is symmetric)
+    r, c, ww = r[order], c[order], ww[order]
+    head = np.ones(len(r), dtype=bool); head[1:] = (r[1:] != r[:-1]) | (c[1:] != c[:-1])
+    starts = np.flatnonzero(head)
+    sums = np.empty(len(starts))
+    ends = np.append(starts[1:], len(r))
+    for q, (a, b) in enumerate(zip(starts, ends)):                         # (sequential addition; np.add.reduceat pairs differently)
+        acc = ww[a]
+        for z in range(a + 1, b):
+            acc = acc + ww[z]
+        sums[q] = acc
+    want = sp.csc_matrix((sums, (r[head], c[head])), shape=(N, N))
+    want.sort_indices()
+    assert same(A, want)
+    assert np.diff(A.indptr).max() >= max(hub_degrees)
+
+
 def test_clustcells_graph_to_adjacency():
     N, k = 4000, 15
     mat = synth.knn_windowed(N, k)
