@@ -1,6 +1,8 @@
 """BASELINE config 3 shape end to end through the host mirror: gficf() on a 23 k genes x 54 k cells synthetic count matrix, then
 clustcells(k = 30) on a 50-component stand-in for the PCA space (PCA itself is third-party, RSpectra/irlba, and out of scope:
 the stand-in is clustered Gaussian data).  Prints the wall time of every call (host entries: PCIe both ways included).
+Then the CPU side of the SAME pipeline on this box's host cores (BASELINE.json config 3: "... on 1 MI355X vs CPU baseline"): the oracle's
+threaded C++ restatements (ports, labelled so) and — for the community detection — the reference's own optimiser binary.
 gficf() is timed as the reference calls it (storeRaw = TRUE: $rawCounts = M[keep, ], gathered by the library's host threads while the result comes
 back; through round 4 and most of round 5 the mirror subset M with scipy: +150 ms) and without."""
 import os
@@ -38,6 +40,7 @@ for rep in range(3):
     t3 = time.perf_counter()
     fused = gficf_amd.phenograph(pca, k, "manhattan", 0.8, 1, 10, 10, 180582)
     t4 = time.perf_counter()
+    gpu_ms = {"gficf": 1e3 * (t1 - t0), "gficf_noraw": 1e3 * (t0 - tn), "clustcells": 1e3 * (t2 - t1), "phenograph": 1e3 * (t4 - t3)}
     print(f"run {rep}: gficf() {1e3 * (t1 - t0):.1f} ms with $rawCounts, {1e3 * (t0 - tn):.1f} ms without ({data['gficf'].shape[0]} genes kept), clustcells(k={k}, louvian 2) {1e3 * (t2 - t1):.1f} ms "
           f"({len(set(data['cluster']))} clusters, Q {data['modularity']:.4f}), t(gficf) {1e3 * (t3 - t2):.1f} ms, "
           f"phenograph() in one call {1e3 * (t4 - t3):.1f} ms ({fused.n_clusters} clusters)")
@@ -46,3 +49,50 @@ want = M[data["genes"], :]
 t1 = time.perf_counter()
 same = np.array_equal(want.indptr, data["rawCounts"].indptr) and np.array_equal(want.indices, data["rawCounts"].indices) and np.array_equal(want.data, data["rawCounts"].data)
 print(f"$rawCounts against the row subset M[keep, ] by scipy (what the mirror did through round 4: {1e3 * (t1 - t0):.1f} ms on top of the call): identical {same}")
+
+
+# ------------------------------------------------------------------------------------------------------------ the CPU side
+# R and the reference package cannot run here: the CPU figures are the oracle's C++ restatements of the same steps ("port") and,
+# for the community detection, the reference's own optimiser (oracle/_ref/modularity_optimizer, built from src/ModularityOptimizer.cpp with its
+# documented -DSTANDALONE command: "reference").  Bounded: the exact search is timed on a sample of the queries and extrapolated (labelled).
+import oracle
+
+nproc = os.cpu_count() or 1
+Mc = M.tocsc()
+cp64, ri32, xx = Mc.indptr.astype(np.int64), Mc.indices.astype(np.int32), Mc.data.astype(np.float64)
+
+
+def cpu_time(fn, reps=1):
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    return best, out
+
+
+t_g1, _ = cpu_time(lambda: oracle.gficf_csc(G, N, cp64, ri32, xx, 0.05, 1.0, threads=1))
+t_gn, _ = cpu_time(lambda: oracle.gficf_csc(G, N, cp64, ri32, xx, 0.05, 1.0, threads=nproc), reps=2)
+n_q = 1000                                            # queries of the exact search timed on the host
+t_kq, _ = cpu_time(lambda: oracle.knn(pca, k + 1, "manhattan", nthreads=nproc, queries=(0, n_q)))
+t_knn = t_kq * N / n_q
+neigh = gficf_amd.find_nn(pca, k + 1, metric="manhattan")["idx"][:, 1:]
+t_j2, rel = cpu_time(lambda: oracle.jaccard(neigh, nthreads=2))
+t_jn, _ = cpu_time(lambda: oracle.jaccard(neigh, nthreads=nproc), reps=2)
+edges = gficf_amd.jaccard_edges(np.concatenate([np.arange(1, N + 1, dtype=np.int32)[:, None], neigh], axis=1))
+A = gficf_amd.jaccard_adjacency(edges, N)
+t_lv = q_ref = None
+if oracle.build_ref() is not None:
+    t_lv, (ref_lab, q_ref) = cpu_time(lambda: oracle.modularity_reference(A, 0.8, 1, 10, 10, 180582))
+gpu_gficf = gpu_ms["gficf"]
+print(f"CPU side, this box: {nproc} host threads")
+print(f"  gficf()      : port {1e3 * t_g1:9.1f} ms on 1 thread, {1e3 * t_gn:9.1f} ms on {nproc} threads   | GPU gficf() {gpu_gficf:.1f} ms (host call, PCIe both ways)")
+print(f"  kNN (exact)  : port {1e3 * t_knn:9.1f} ms on {nproc} threads, EXTRAPOLATED from {n_q} of {N} queries ({1e3 * t_kq:.1f} ms)  (the reference calls Annoy, approximate)")
+print(f"  Jaccard      : port {1e3 * t_j2:9.1f} ms at nt = 2 (clustcells' default), {1e3 * t_jn:9.1f} ms on {nproc} threads")
+if t_lv is not None:
+    print(f"  Louvain      : REFERENCE binary {1e3 * t_lv:9.1f} ms (1 thread, n.start = 10, n.iter = 10, edge file I/O included), Q {q_ref}")
+cpu_clust = t_knn + t_jn + (t_lv or 0.0)
+print(f"  clustcells() : CPU {1e3 * cpu_clust:9.1f} ms (search + Jaccard on {nproc} threads + Louvain)   | GPU clustcells(louvian 2) {gpu_ms['clustcells']:.1f} ms, phenograph() in one call {gpu_ms['phenograph']:.1f} ms")
+print(f"  (GPU figures: the last of the three runs above; host calls, PCIe both ways included.  CPU gficf(): {1e3 * t_gn / gpu_gficf:.1f} x the GPU call on {nproc} threads, "
+      f"{1e3 * t_g1 / gpu_gficf:.1f} x on one; CPU clustcells: {1e3 * cpu_clust / gpu_ms['phenograph']:.0f} x phenograph().)")
