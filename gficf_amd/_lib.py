@@ -16,7 +16,7 @@ GFICF_OK = 0
 STATUS_NAMES = {
     0: "GFICF_OK", 1: "GFICF_ERR_INVALID_ARG", 2: "GFICF_ERR_BAD_ID", 3: "GFICF_ERR_BAD_CSC",
     4: "GFICF_ERR_NO_DEVICE", 5: "GFICF_ERR_HIP", 6: "GFICF_ERR_UNSUPPORTED", 7: "GFICF_ERR_CAPACITY",
-    8: "GFICF_ERR_BAD_VALUE", 9: "GFICF_ERR_EXPLICIT_ZEROS", 10: "GFICF_ERR_DUPLICATE_IDS",
+    8: "GFICF_ERR_BAD_VALUE", 9: "GFICF_ERR_EXPLICIT_ZEROS", 10: "GFICF_ERR_DUPLICATE_IDS", 11: "GFICF_ERR_SET_OVERFLOW",
 }
 JACCARD_MAX_K = 256          # the fast kernels; beyond it the exact sorted-row path, up to JACCARD_MAX_K_EXACT
 JACCARD_MAX_K_EXACT = 65535

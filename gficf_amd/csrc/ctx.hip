@@ -247,6 +247,10 @@ int gficf_ctx_sync(gficf_ctx* ctx) {
   if (st & GFICF_ST_DUP_IDS)
     GFICF_FAIL(GFICF_ERR_DUPLICATE_IDS, "a row of the kNN index matrix names an id twice and the context was told rows hold distinct ids "
                                         "(gficf_ctx_set_jaccard_distinct): discard the edges and re-run ingest + edges with the option off");
+  if (st & GFICF_ST_SET_OVERFLOW)
+    GFICF_FAIL(GFICF_ERR_SET_OVERFLOW, "a row's ids overflowed the edge kernel's hash set (more than six found their bucket full: ids spread uniformly at k near "
+                                       "256) and the context was told rows hold distinct ids: discard the edges and re-run with the option off, or with "
+                                       "GFICF_JACCARD_SORTED_FROM=57 in the environment (sorted-row path)");
   if (st & GFICF_ST_EXPLICIT_ZERO)
     GFICF_FAIL(GFICF_ERR_EXPLICIT_ZEROS, "the CSC matrix stores explicit zeros, which gficf_csc_device's count of stored entries takes for "
                                          "non-zero cells (rowSums(M != 0), reference R/gficf.R:40,88): call gficf_csc_exact_device");

@@ -91,7 +91,10 @@ inline int sorted_from_k() {
   }();
   return v;
 }
-inline bool sorted_fmt(int k) { return k >= sorted_from_k(); }
+// A host entry re-running its call after GFICF_ERR_SET_OVERFLOW takes the sorted-row path from k = 57 on, whatever the switch says
+// (thread-local: the format is otherwise a function of (N, k) and the environment alone, and stays one for every device entry).
+thread_local int g_force_sorted = 0;
+inline bool sorted_fmt(int k) { return k >= sorted_from_k() || (g_force_sorted && k >= 57); }
 
 struct TableFmt {
   int kpad;
@@ -958,11 +961,16 @@ static int distinct_first(gficf_ctx* ctx, F&& body) {
   const int saved = ctx->jaccard_assume_distinct;
   ctx->jaccard_assume_distinct = always_scan ? 0 : 1;
   int rc = body();
-  if (rc == GFICF_ERR_DUPLICATE_IDS) {
+  if (rc == GFICF_ERR_DUPLICATE_IDS || rc == GFICF_ERR_SET_OVERFLOW) {
+    // a repeated id: the exact sequence (duplicate scan, multiset counts).  A hash set that overflowed (ids spread uniformly at k near 256):
+    // the sorted-row path, exact for every input and ~13 x faster there than the exact hash-set sequence, whose cells with an overflowing set
+    // fall to all-pairs (5 000 x 256: 1.4 ms against 22 ms, profiles/r05_bigk_time.txt); below k = 57, where there is no sorted path, the exact one.
     ctx->jaccard_assume_distinct = 0;
+    g_force_sorted = rc == GFICF_ERR_SET_OVERFLOW ? 1 : 0;
     ctx->quiet_rerun = 1;                      // (the banner lines have been printed)
     rc = body();
     ctx->quiet_rerun = 0;
+    g_force_sorted = 0;
   }
   ctx->jaccard_assume_distinct = saved;
   return rc;

@@ -267,9 +267,18 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
               }
             }
             wave_lds_fence();
-            if (nov > 1) dup_here |= ovlist_repeats(ovlist, nov);      // ... or both overflowed (rare)
-            if (dup_here) *reinterpret_cast<uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) = 1u;   // reported at the kernel's end
-            own_dup = __ballot(dup_here) != 0ull;
+            // a list longer than the six entries that are compared is reported as what it is (bit 1: GFICF_ST_SET_OVERFLOW) — not as a
+            // repeated id (through round 5 it was: a spurious GFICF_ERR_DUPLICATE_IDS on uniformly spread ids at k near 256)
+            // With the duplicate scan done at the ingest (exact mode) a long list is nothing to report: a row that repeats an id carries its
+            // flag and never comes here, and the probes below walk the whole list — slower, exact.  (Through round 5 such a cell fell to the
+            // all-pairs path: 22 ms instead of ~2 at 5 000 x 256 on uniformly spread ids.)
+            const bool over_here = nov > 6 && edge_kernel_dup_status() != nullptr;
+            if (nov > 1 && nov <= 6) dup_here |= ovlist_repeats(ovlist, nov);      // ... or both overflowed (rare)
+            if (dup_here | over_here) {            // reported at the kernel's end (every lane that writes ORs its own bits into what it read)
+              uint32_t* const fw = reinterpret_cast<uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u);
+              atomicOr(fw, (dup_here ? 1u : 0u) | (over_here ? 2u : 0u));
+            }
+            own_dup = __ballot(dup_here | over_here) != 0ull;
           }
           int cnt[C::U];
 #pragma unroll
@@ -347,8 +356,9 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
   if (have_prev) store_prev();
   // a row of this wave's cells named an id twice: the deferred report of the "distinct ids" mode (no flags in the table)
   wave_lds_fence();
-  if (*reinterpret_cast<const uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u) != 0u && lane == 0) {
+  const uint32_t fbits = *reinterpret_cast<const uint32_t*>(smem + DUPF_OFF + (uint32_t)wave * 4u);
+  if (fbits != 0u && lane == 0) {
     uint32_t* const st = edge_kernel_dup_status();
-    if (st != nullptr) atomicOr(st, GFICF_ST_DUP_IDS);
+    if (st != nullptr) atomicOr(st, ((fbits & 1u) ? GFICF_ST_DUP_IDS : 0u) | ((fbits & 2u) ? GFICF_ST_SET_OVERFLOW : 0u));
   }
 }

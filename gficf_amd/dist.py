@@ -313,7 +313,7 @@ class JaccardShard:
 
 
 # deferred statuses a sharded step can end in, by severity (the collective sync raises the most severe one on every rank)
-_STATUS_SEVERITY = {"GFICF_ERR_CAPACITY": 1, "GFICF_ERR_DUPLICATE_IDS": 2, "GFICF_ERR_BAD_ID": 3, "GFICF_ERR_HIP": 4}
+_STATUS_SEVERITY = {"GFICF_ERR_CAPACITY": 1, "GFICF_ERR_SET_OVERFLOW": 2, "GFICF_ERR_DUPLICATE_IDS": 2, "GFICF_ERR_BAD_ID": 3, "GFICF_ERR_HIP": 4}
 
 
 class JaccardHaloShard:

@@ -48,9 +48,14 @@ typedef enum gficf_status {
   GFICF_ERR_DUPLICATE_IDS = 10, /* Jaccard with gficf_ctx_set_jaccard_distinct on: a row of the index matrix names an id
                                   twice (deferred); every edge computed from that table is to be discarded and the
                                   sequence re-run with the option off                                              */
-  GFICF_ERR_EXPLICIT_ZEROS = 9 /* gficf_csc_device met an explicitly stored zero: its count of
+  GFICF_ERR_EXPLICIT_ZEROS = 9, /* gficf_csc_device met an explicitly stored zero: its count of
                                   stored entries is then not rowSums(M != 0); discard the
                                   outputs and call gficf_csc_exact_device                  */
+  GFICF_ERR_SET_OVERFLOW = 11  /* ABI 7.  Jaccard with gficf_ctx_set_jaccard_distinct on, 56 < k <= 256: more than six ids of one row found
+                                  both slots of their hash-set bucket taken (ids spread uniformly over many cells at k near 256; not what a
+                                  kNN search returns).  NOT a repeated id: discard the edges and re-run with the option off, or on the
+                                  sorted-row path (GFICF_JACCARD_SORTED_FROM=57).  The host entries re-run on the sorted-row path by
+                                  themselves.  (Through ABI 6 this was reported as GFICF_ERR_DUPLICATE_IDS.)                        */
 } gficf_status;
 
 /* k <= GFICF_JACCARD_MAX_K neighbours per cell take the hash-set / bit-set edge kernels; the reference's loop has no limit

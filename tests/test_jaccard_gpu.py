@@ -881,6 +881,56 @@ def test_host_entries_take_the_fast_sequence_and_heal_themselves(monkeypatch):
     ctx.sync()                                                    # nothing deferred is left behind
 
 
+def _uniform_rows(N, k, seed):
+    """k distinct ids per row drawn uniformly from all N cells (NOT what a kNN search returns: no neighbourhood)."""
+    rng = np.random.default_rng(seed)
+    return (np.argsort(rng.random((N, N), dtype=np.float32), axis=1)[:, :k] + 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("k", [200, 230, 256])
+def test_uniformly_spread_ids_at_k_near_256_no_false_duplicate_report_and_no_cliff(ops, k):
+    """Round 6.  With ids spread uniformly over thousands of cells at k near 256 more than six ids of a row find their hash-set bucket full.
+    Through round 5 that was reported as GFICF_ERR_DUPLICATE_IDS (no id repeats) and, with the duplicate scan on, sent the cell down the
+    all-pairs path (22 ms at 5 000 x 256 against 1.7 ms at k = 257).  Now: (a) rows taken to hold distinct ids -> a deferred
+    GFICF_ERR_SET_OVERFLOW, its own status; (b) the host entry re-runs on the sorted-row path by itself: the reference's matrix, bit for bit;
+    (c) the exact device sequence walks the overflow list instead of falling to all-pairs: bit-exact and within a few milliseconds."""
+    import time
+
+    import torch
+
+    N = 5000
+    mat = _uniform_rows(N, k, seed=k)
+    want, _ = oracle.jaccard(mat, nthreads=16)
+    # (b) the `.Call` entry's mirror
+    assert np.array_equal(gficf_amd.rcpp_parallel_jaccard_coef(mat, False), want)
+    # (a) distinct mode on the device entries
+    idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
+    table = torch.zeros((N, ops.row_words(N, k)), dtype=torch.int32, device="cuda")
+    out = torch.zeros((3, N * k), dtype=torch.float64, device="cuda")
+    ops.set_jaccard_distinct(True)
+    try:
+        ops.jaccard(idx, N, k, table, out, None)
+        try:
+            ops.sync()
+            overflowed = False
+        except gficf_amd.GficfError as e:
+            overflowed = True
+            assert e.status == "GFICF_ERR_SET_OVERFLOW", e.status          # never GFICF_ERR_DUPLICATE_IDS: no id repeats
+        if not overflowed:                                                 # (no row happened to overflow: then the result must be right)
+            assert np.array_equal(out.cpu().numpy().T, want)
+    finally:
+        ops.set_jaccard_distinct(False)
+    # (c) the exact device sequence
+    ops.jaccard(idx, N, k, table, out, None)
+    ops.sync()
+    t0 = time.perf_counter()
+    ops.jaccard(idx, N, k, table, out, None)
+    ops.sync()
+    dt = time.perf_counter() - t0
+    assert np.array_equal(out.cpu().numpy().T, want)
+    assert dt < 0.008, f"{1e3 * dt:.1f} ms: the all-pairs cliff is back"
+
+
 @pytest.mark.parametrize("N,k,P", [(30_000, 30, 3), (20_000, 50, 2), (9_000, 15, 4)])
 def test_halo_form_with_rows_taken_to_hold_distinct_ids(ops, N, k, P):
     """The scan-less sequence in the sharded build on local ids (emulated ranks): clean input gives the oracle's edges with no

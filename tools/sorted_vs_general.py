@@ -28,7 +28,15 @@ def child(N, k):
     out = torch.zeros((3, N * k), dtype=torch.float64, device="cuda")
     run = ops.jaccard_prepared(idx, N, k, table, out, None)
     run()
-    ops.sync()
+    try:
+        ops.sync()
+    except gficf_amd.GficfError as e:             # a row's ids overflowed the hash set: its own status since round 6 — what a device caller does: the option off
+        if e.status != "GFICF_ERR_SET_OVERFLOW":
+            raise
+        ops.set_jaccard_distinct(False)
+        run = ops.jaccard_prepared(idx, N, k, table, out, None)
+        run()
+        ops.sync()
     cells = min(N, 256)
     want, _ = oracle.jaccard_cells(mat, 0, cells, nthreads=os.cpu_count() or 1)
     ok = bool(np.array_equal(out[:, :cells * k].cpu().numpy().T, want))
