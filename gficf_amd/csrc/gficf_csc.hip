@@ -657,6 +657,8 @@ int gficf_csc_kept_values_host(int64_t G, int64_t N, const void* colptr, int col
   if (N == 0) return GFICF_OK;
   if (!colptr || !kept_colptr) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
   const ColPtr ci{colptr, colptr_is_i64}, co{kept_colptr, colptr_is_i64};
+  // (a public entry without a context: the same checks the plan call makes — a pointer that does not start at 0 would index in front of the arrays)
+  if (ci[0] != 0 || co[0] != 0) GFICF_FAIL(GFICF_ERR_BAD_CSC, "colptr[0] = %lld, kept_colptr[0] = %lld: both must be 0", (long long)ci[0], (long long)co[0]);
   if (ci[N] > 0 && (!rowidx || !x || !keep)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
   if (co[N] > 0 && !out_x) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL output pointer");
   for (int64_t c = 0; c < N; ++c)

@@ -1040,6 +1040,9 @@ static int halo_ingest_launch(gficf_ctx* ctx, const int32_t* d_idx, int64_t n_lo
   int rc = check_nk(n_ext, k);
   if (rc) return rc;
   if (k > 64) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "halo ingest: the fused form covers k <= 64");
+  // GFICF_JACCARD_SORTED_FROM = 57 .. 64 moves k into the sorted-row format, which this launch does not write (it would fill hash-set rows
+  // into a table the edge launcher reads as sorted ones): the caller takes relabel + gficf_jaccard_ingest_local_device, as for k > 64
+  if (sorted_fmt(k)) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "halo ingest: k = %d is in the sorted-row format (GFICF_JACCARD_SORTED_FROM): the fused form does not cover it", k);
   if (n_ext == 0 || k == 0) return GFICF_OK;
   if (!d_ws || !d_req_out || (row_end > n_local && !d_rows_in && !peer_idx) || !d_table || !d_l2g || (n_local > 0 && !d_idx)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   if (peer_idx) {

@@ -118,7 +118,8 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
       hipLaunchKernelGGL(k_invert_order, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t*)d_order, (int32_t*)d_inv, N);
       hipLaunchKernelGGL(k_relabel_idx, dim3(nb), dim3(256), 0, ctx->stream, (const int32_t*)d_idx, (const int32_t*)d_order, (const int32_t*)d_inv,
                          (int32_t*)d_idx2, N, k);
-      if (hipGetLastError() != hipSuccess) rc = GFICF_ERR_HIP;
+      const hipError_t le = hipGetLastError();
+      if (le != hipSuccess) { gficf_set_error("HIP failure in gficf_phenograph_host (relabel launches): %s", hipGetErrorString(le)); rc = GFICF_ERR_HIP; }
     }
     if (!rc) rc = gficf_jaccard_ingest_device(ctx, (const int32_t*)d_idx2, 0, N, k, N, N, (int32_t*)d_table);
     if (!rc) rc = gficf_jaccard_edges_filtered_mapped_device(ctx, (const int32_t*)d_table, N, k, 0, N, (uint16_t*)d_u, (int64_t*)d_cptr, from, from + cap,

@@ -22,6 +22,8 @@ CPU with the gloo backend and a test double; there is no fallback here.
 """
 from __future__ import annotations
 
+import collections
+
 import torch
 import torch.distributed as dist
 
@@ -125,8 +127,11 @@ class JaccardShard:
     With ONE rank there is no exchange to hide, and what is left to overlap (a 6 us ingest under the tail of a 41 us edge kernel
     that already fills every CU) is worth less than the stream hops cost: measured 50.8 G edges/s against 63.4 in order at
     100 k x 30 (profiles/r04_bench.json; the pipelined step is ~10 runtime calls and host-bound).  So ``pipeline=True`` on one rank
-    RUNS IN ORDER on the caller's stream (``pipeline_in_order`` is set; wait / release are no-ops, the returned buffer is valid in
-    stream order); ``pipeline="force"`` keeps the two-stream machinery (tests of that machinery on a one-GPU box).
+    RUNS IN ORDER on the caller's stream (``pipeline_in_order`` is set); ``pipeline="force"`` keeps the two-stream machinery (tests of
+    that machinery on a one-GPU box).  The CONTRACT above still holds in that mode: the result alternates between two buffers and is
+    overwritten only by the step after next, every step records an event that :meth:`wait` makes another consumer stream wait for, and
+    the step that reuses a buffer waits for the point :meth:`release` marked — a caller written against the pipelined contract reads the
+    same data whether the steps overlap or not.
     """
 
     def __init__(self, ops, N_total: int, k: int, group=None, device=None, with_u: bool = False,
@@ -153,13 +158,22 @@ class JaccardShard:
         if self.pipeline_in_order:
             self.pipeline = False
         nbuf = 2 if self.pipeline else 1
+        nout = 2 if (self.pipeline or self.pipeline_in_order) else 1      # (in order: one table is enough — nothing reads it behind the step —, two results)
         # full table(s), padded to world*rpr rows so that every rank contributes an equal block
         self.tables = [torch.zeros((self.world * self.rpr, self.row_words), dtype=torch.int32, device=device) for _ in range(nbuf)]
-        self.outs = [torch.zeros((3, self.n_local * self.k), dtype=torch.float64, device=device) for _ in range(nbuf)]
-        self.us = [torch.zeros(self.n_local * self.k, dtype=torch.int32, device=device) if with_u else None for _ in range(nbuf)]
+        self.outs = [torch.zeros((3, self.n_local * self.k), dtype=torch.float64, device=device) for _ in range(nout)]
+        self.us = [torch.zeros(self.n_local * self.k, dtype=torch.int32, device=device) if with_u else None for _ in range(nout)]
         self.table, self.out, self.u = self.tables[0], self.outs[0], self.us[0]
         self.t = 0
-        self._prepared = {}                     # one rank: prepared single-call steps by input block (see step)
+        # one rank: prepared single-call steps of the LAST FEW input blocks (see step).  A prepared call keeps its input block alive, so the
+        # cache is small: a streaming caller that hands over a fresh block every step (KnnShard output) must not pin 64 of them (7.7 GB at
+        # 1 M x 30), nor keep the caching allocator from reusing them.
+        self._prepared = collections.OrderedDict()
+        if self.pipeline_in_order:
+            self.ev_step = [torch.cuda.Event(), torch.cuda.Event()]
+            self.ev_consumed = [None, None]
+            self.last_done = None
+            self.last_p = None
         # N > 1: rows travel bit-packed (ceil(log2(N+1)) bits per id) and are unpacked after the all-gather
         self.packed = None
         if self.world > 1 and packed_transport and exchange == "allgather":
@@ -234,26 +248,42 @@ class JaccardShard:
         (global 1-based ids).  Returns this rank's (3, n_local*k) slice of the edge matrix (valid in
         stream order on the caller's current stream)."""
         if not self.pipeline:
+            p, cur = 0, None
+            if self.pipeline_in_order:
+                # the pipelined contract, in order: two result buffers in turn; a buffer is reused only behind the point its reader marked
+                p = self.t & 1
+                cur = torch.cuda.current_stream(self.outs[p].device)
+                if self.ev_consumed[p] is not None:
+                    cur.wait_event(self.ev_consumed[p])
+                    self.ev_consumed[p] = None
+            out, u = self.outs[p], self.us[p]
             if self.world == 1 and self.exchange == "allgather" and not self.time_edges and self.n_local > 0:
                 # one rank: nothing to exchange — the library's single-device sequence in ONE call (for a small problem under
-                # set_jaccard_distinct that is one launch), its arguments converted once per input block
-                key = (idx_local_cm.data_ptr(), tuple(idx_local_cm.shape))
+                # set_jaccard_distinct that is one launch), its arguments converted once per input block and result buffer
+                key = (idx_local_cm.data_ptr(), tuple(idx_local_cm.shape), tuple(idx_local_cm.stride()), idx_local_cm.dtype, p)
                 run = self._prepared.get(key)
                 if run is None:
-                    if len(self._prepared) >= 64:
-                        self._prepared.clear()
-                    run = self._prepared[key] = self.ops.jaccard_prepared(idx_local_cm, self.N, self.k, self.table, self.out, self.u)
+                    while len(self._prepared) >= 4:
+                        self._prepared.popitem(last=False)
+                    run = self._prepared[key] = self.ops.jaccard_prepared(idx_local_cm, self.N, self.k, self.table, out, u)
+                else:
+                    self._prepared.move_to_end(key)
                 run()
-                return self.out
-            self._fill_table(self.table, idx_local_cm)
-            if self.time_edges:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            if self.n_local > 0:
-                self.ops.jaccard_edges(self.table, self.N, self.k, self.b, self.e, self.out, self.u)
-            if self.time_edges:
-                e1.record()
-                self.edge_events.append((e0, e1))
+            else:
+                self._fill_table(self.table, idx_local_cm)
+                if self.time_edges:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                if self.n_local > 0:
+                    self.ops.jaccard_edges(self.table, self.N, self.k, self.b, self.e, out, u)
+                if self.time_edges:
+                    e1.record()
+                    self.edge_events.append((e0, e1))
+            self.out, self.u = out, u
+            if self.pipeline_in_order:
+                self.ev_step[p].record(cur)
+                self.last_done, self.last_p = self.ev_step[p], p
+                self.t += 1
             return self.out
         p = self.t & 1
         table = self.tables[p]
@@ -291,14 +321,14 @@ class JaccardShard:
         return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
 
     def wait(self):
-        """Make the caller's current stream wait for the latest step (pipelined mode; no-op otherwise)."""
-        if self.pipeline and self.last_done is not None:
+        """Make the caller's current stream wait for the latest step (pipelined mode, also when it runs in order; no-op otherwise)."""
+        if (self.pipeline or self.pipeline_in_order) and self.last_done is not None:
             torch.cuda.current_stream(self.out.device).wait_event(self.last_done)
 
     def release(self):
         """Pipelined mode: the caller's current stream has read the latest returned buffer up to this point; the step
         that overwrites that buffer (the one after next) waits for it.  No-op otherwise."""
-        if self.pipeline and self.last_p is not None:
+        if (self.pipeline or self.pipeline_in_order) and self.last_p is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.out.device))
             self.ev_consumed[self.last_p] = ev
@@ -461,13 +491,13 @@ class JaccardHaloShard:
         return sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
 
     def wait(self):
-        """Make the caller's current stream wait for the latest step (pipelined mode; no-op otherwise)."""
-        if self.pipeline and self.last_done is not None:
+        """Make the caller's current stream wait for the latest step (pipelined mode, also when it runs in order; no-op otherwise)."""
+        if (self.pipeline or self.pipeline_in_order) and self.last_done is not None:
             torch.cuda.current_stream(self.out.device).wait_event(self.last_done)
 
     def release(self):
         """Pipelined mode: the caller's current stream has read the latest returned buffer up to this point."""
-        if self.pipeline and self.last_p is not None:
+        if (self.pipeline or self.pipeline_in_order) and self.last_p is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.out.device))
             self.ev_consumed[self.last_p] = ev

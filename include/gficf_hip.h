@@ -370,7 +370,9 @@ int gficf_normalize_csc_host_finish(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, 
  *       exactly gficf_normalize_csc_host_finish.
  *   gficf_csc_kept_values_host = the same gather by itself, no device and no context involved (after the multi-GPU finish call, or
  *       for any `M[keep, ]` whose column pointer is known): kept_colptr (same integer width as colptr) must be the column pointer of
- *       M[keep, ]; out_rowidx may be NULL.  keep: G flags (0 / 1). */
+ *       M[keep, ]; out_rowidx may be NULL.  keep: G flags (0 / 1).  Both pointers must start at 0 and be monotone (GFICF_ERR_BAD_CSC);
+ *       the outputs hold kept_colptr[N] entries — a cell whose kept entries do not fill its range exactly is GFICF_ERR_BAD_CSC, nothing is
+ *       written outside [0, kept_colptr[N]). */
 int gficf_normalize_csc_host_finish_raw(gficf_ctx* ctx, uint8_t* keep, int64_t* nt, double* w, void* out_colptr,
                                         int32_t* out_rowidx, double* out_x, const int32_t* rowidx, const double* x,
                                         int32_t* out_raw_rowidx, double* out_raw_x);

@@ -118,6 +118,12 @@ def test_kept_values_host_is_the_row_subset_of_the_counts():
             rc = L.gficf_csc_kept_values_host(G, N, cp.ctypes.data, int(pt is np.int64), ri.ctypes.data, x.ctypes.data, keep.ctypes.data, bad.ctypes.data, None, ox.ctypes.data)
             assert _lib.STATUS_NAMES[rc] == "GFICF_ERR_BAD_CSC"
             assert b"kept_colptr" in L.gficf_last_error()
+            # a pointer that does not start at 0 (either of the two) is refused before anything is read or written (advisor, round 5)
+            for shifted_in, shifted_out in ((cp + 1, kcp), (cp, kcp + 1), (cp, kcp - 1)):
+                ox = np.full(want.nnz, 7.0)
+                rc = L.gficf_csc_kept_values_host(G, N, shifted_in.ctypes.data, int(pt is np.int64), ri.ctypes.data, x.ctypes.data, keep.ctypes.data,
+                                                  shifted_out.ctypes.data, None, ox.ctypes.data)
+                assert _lib.STATUS_NAMES[rc] == "GFICF_ERR_BAD_CSC" and (ox == 7.0).all()
 
 
 def test_product_package_never_imports_oracle():

@@ -358,6 +358,51 @@ def test_pipelined_steps_give_the_same_bits(ops):
         assert np.array_equal(g.cpu().numpy().T, want[i])
 
 
+@pytest.mark.parametrize("mode", [True, "force"])
+def test_pipelined_contract_holds_when_one_rank_runs_in_order(ops, mode):
+    """JaccardShard(pipeline=True) on ONE rank runs in order (pipeline_in_order) — and must still honour the contract the class states for
+    the pipelined mode: the result of step s stays valid until the step after next, wait() orders ANOTHER stream behind the step, release()
+    gates the reuse of a buffer.  A caller that issues step s + 1 and only then reads step s, on a stream of its own, gets step s's result;
+    and fresh input blocks handed over every step are not kept alive by the shard (advisor, round 5)."""
+    import gc
+    import weakref
+
+    import torch
+    from gficf_amd.dist import JaccardShard
+
+    N, k = 20000, 30
+    mats = [synth.knn_windowed(N, k, seed=s) for s in (11, 12, 13, 14)]
+    want = [oracle.jaccard(m, nthreads=8)[0] for m in mats]
+    sh = JaccardShard(ops, N, k, device="cuda", with_u=False, pipeline=mode)
+    assert sh.pipeline_in_order == (mode is True)
+    reader = torch.cuda.Stream()
+    copies, refs = [], []
+    prev = None
+    for rep in range(3):
+        for i in range(4):
+            blk = torch.from_numpy(np.ascontiguousarray(mats[i].T)).cuda()       # a FRESH block every step
+            refs.append(weakref.ref(blk))
+            out = sh.step(blk)
+            with torch.cuda.stream(reader):
+                sh.wait()                                                        # the reader's stream behind this step
+                c = torch.empty_like(out)
+                c.copy_(out, non_blocking=True)
+                sh.release()
+            if prev is not None:                                                 # the result of the step BEFORE is still its own (two buffers)
+                with torch.cuda.stream(reader):
+                    copies.append((prev[0], prev[1].clone()))
+            prev = (i, out)
+            copies.append((i, c))
+            del blk
+    sh.sync()
+    torch.cuda.synchronize()
+    for i, g in copies:
+        assert np.array_equal(g.cpu().numpy().T, want[i]), i
+    gc.collect()
+    alive = sum(r() is not None for r in refs)
+    assert alive <= 4, f"{alive} of {len(refs)} input blocks are still held"
+
+
 @pytest.mark.parametrize("gen,N,k", [("win", 5000, 30), ("uni", 20000, 15), ("win", 700, 100), ("uni", 3000, 50)])
 def test_device_edge_filter_matches_reference_filter(ops, gen, N, k):
     """N1: edges with weight > 0 only, in order == relations[relations[,3] > 0, ] (R/clustCells.R:66)."""
