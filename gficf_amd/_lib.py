@@ -56,7 +56,6 @@ SIGNATURES = {
     "gficf_jaccard_expand_host": (_int, [_vp, _int, _i64, _int, _i64, _vp, _vp, _int]),
     "gficf_multi_create": (_int, [_vp, _int, ctypes.POINTER(_vp)]),
     "gficf_multi_destroy": (None, [_vp]),
-    "gficf_multi_device_count": (_int, [_vp]),
     "gficf_multi_set_print": (_int, [_vp, _vp]),
     "gficf_multi_cell_blocks": (_int, [_i64, _int, _vp]),
     "gficf_multi_cell_blocks_by_nnz": (_int, [_i64, _vp, _int, _int, _vp]),
@@ -82,14 +81,12 @@ SIGNATURES = {
     "gficf_jaccard_halo_serve_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _i64, _vp]),
     "gficf_jaccard_halo_relabel_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_ingest_local_device": (_int, [_vp, _vp, _i64, _int, _i64, _vp]),
-    "gficf_jaccard_halo_ingest_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_halo_serve_ingest_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "gficf_jaccard_halo_ingest_slots_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_halo_ingest_peer_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _i64, _int, _i64, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_edges_mapped_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_device": (_int, [_vp, _vp, _int, _i64, _int, _i64, _vp, _vp, _vp]),
     "gficf_jaccard_edges_filtered_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "gficf_jaccard_edges_filtered_mapped_device": (_int, [_vp, _vp, _i64, _int, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gficf_jaccard_filtered_host_plan": (_int, [_vp, _vp, _int, _i64, _int, _i64, ctypes.POINTER(_i64)]),
     "gficf_jaccard_filtered_host_finish": (_int, [_vp, _vp, _vp, _vp]),
     "gficf_adjacency_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
@@ -115,8 +112,7 @@ SIGNATURES = {
     "gficf_csc_transpose_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
     "gficf_csc_transpose_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, ctypes.c_size_t]),
     "gficf_csc_transpose_host": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _vp, _vp, _vp]),
-    "gficf_louvain_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
-    "gficf_louvain_workspace_bytes_starts": (ctypes.c_size_t, [_i64, _i64, _int]),
+    "gficf_louvain_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, _int]),
     "gficf_louvain_device": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _dbl, _int, _int, _int, _int, _vp, ctypes.POINTER(_i64),
                                     ctypes.POINTER(_dbl), _vp, ctypes.c_size_t]),
     "gficf_louvain_host": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _dbl, _int, _int, _int, _int, _vp, ctypes.POINTER(_i64),

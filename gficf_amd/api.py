@@ -890,16 +890,6 @@ class HipOps:
         check(self.L.gficf_jaccard_halo_relabel_device(self._bind(), _tptr(idx_cm), n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap,
                                                        _tptr(ws), _tptr(req_out), _tptr(rows_in), _tptr(idx_ext), _tptr(l2g)))
 
-    def halo_ingest(self, idx_cm, n_local, k, N_total, cell_begin, P, rows_per_rank, cap, ws, req_out, rows_in, table, l2g) -> bool:
-        """relabel + ingest in one launch (k <= 64).  Returns False when the fused form does not cover this k (nothing was
-        enqueued): the caller runs halo_relabel + jaccard_ingest_local."""
-        if k > 64:
-            return False
-        ld = idx_cm.shape[1] if idx_cm.dim() == 2 else n_local
-        check(self.L.gficf_jaccard_halo_ingest_device(self._bind(), _tptr(idx_cm), n_local, k, ld, N_total, cell_begin, P, rows_per_rank, cap,
-                                                      _tptr(ws), _tptr(req_out), _tptr(rows_in), _tptr(table), _tptr(l2g)))
-        return True
-
     def halo_serve_ingest(self, idx_cm, n_local, k, N_total, cell_begin, P, rows_per_rank, cap, ws, req_out, req_in, rows_out, table, l2g) -> bool:
         """Between the two exchanges, ONE launch (k <= 64): the rows asked of this rank (``req_in`` -> ``rows_out``) and the table
         rows of the own cells (they need the plan, not the replies).  False: k > 64, nothing enqueued (run the unfused calls)."""
@@ -1105,7 +1095,7 @@ class HipOps:
 
     def louvain_workspace_bytes(self, N: int, nnz: int, n_start: int = 1) -> int:
         """Device scratch of ``louvain``: with ``n_start`` given, enough for min(n_start, 16) starts to run together (one launch set)."""
-        return int(self.L.gficf_louvain_workspace_bytes_starts(int(N), int(nnz), int(n_start)))
+        return int(self.L.gficf_louvain_workspace_bytes(int(N), int(nnz), int(n_start)))
 
     def louvain(self, N, indptr, indices, x, resolution, n_iter, labels, ws, algorithm: int = 1, n_start: int = 1, seed: int = 0):
         """Community detection on a device-resident symmetric adjacency matrix (indptr int64, indices int32, x float64).

@@ -123,7 +123,12 @@ inline void gficf_run_shares(int64_t nt, F&& share) {
 // releases the host-form GF-ICF plan held by the context, if any (gficf_csc.hip)
 void gficf_host_plan_free(gficf_ctx* ctx);
 // same for the host-form filtered edge build (jaccard.hip)
-extern "C" void gficf_edge_plan_free(gficf_ctx* ctx);
+void gficf_edge_plan_free(gficf_ctx* ctx);
+// gficf_jaccard_edges_filtered_device on a table built from RENUMBERED cells (row p of the table = original cell d_order[p], 0-based; ids inside
+// the table in the new numbering, 1-based): both columns come out in the ORIGINAL ids, the edges in the order of the new numbering.  Internal
+// since ABI 7 (its one caller is gficf_phenograph_host, which renumbers the cells by the search's pivot order from 2^17 cells on).
+int gficf_jaccard_edges_filtered_mapped(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, uint16_t* d_u_ws,
+                                        int64_t* d_cell_ptr, double* d_from, double* d_to, double* d_weight, const int32_t* d_order);
 // same for the host-form adjacency build (adjacency.hip)
 void gficf_adj_plan_free(gficf_ctx* ctx);
 

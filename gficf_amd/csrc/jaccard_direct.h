@@ -1,4 +1,4 @@
-// jaccard_direct.h — ONE launch for small Jaccard problems (round 5).  Included by jaccard.hip inside its anonymous namespace.
+// jaccard_direct.h — ONE launch for small Jaccard problems (round 5).  Included by jaccard.hip (stands on its own: includes jaccard_shared.h).
 //
 // At the small BASELINE shapes (config 1: 3 000 x 15, config 2: 10 000 x 30) ingest + edge kernel are 3.6 + 5.7 / 8.5 us of kernels
 // and a step is bound by the two launches and the boundary between them, not by bytes.  A grid barrier between an ingest phase and
@@ -16,6 +16,18 @@
 // Rows are taken to hold DISTINCT ids (what gficf_ctx_set_jaccard_distinct promises and the host entries assume first): a row that
 // names an id twice is seen by its own cell (its self-compare counts two), which raises the deferred GFICF_ST_DUP_IDS — the
 // exact sequence is then re-run, as for the table path.  Without that promise the table path runs.
+#pragma once
+
+#include "jaccard_shared.h"
+#include "jaccard_ingest.h"      // decode_id
+
+// edges up to which gficf_jaccard_device builds a small problem in ONE launch, without a table (jaccard_direct.h; measured
+// crossover against ingest + edge kernel: profiles/r05_direct_ab.txt)
+#ifndef GFICF_JACCARD_DIRECT_DEFAULT_EDGES
+#define GFICF_JACCARD_DIRECT_DEFAULT_EDGES 65536
+#endif
+
+namespace {
 
 template <typename T, int KPAD, int OUT>
 __global__ __launch_bounds__(256) void k_jaccard_direct(const T* __restrict__ idx, int64_t N, int k, int64_t ld, EdgeOut o,
@@ -125,3 +137,5 @@ inline int launch_direct(gficf_ctx* ctx, const void* d_idx, int idx_is_f64, int6
     return k <= 16 ? launch_direct_t<double, 16>(ctx, (const double*)d_idx, N, k, ld, o) : launch_direct_t<double, 32>(ctx, (const double*)d_idx, N, k, ld, o);
   return k <= 16 ? launch_direct_t<int32_t, 16>(ctx, (const int32_t*)d_idx, N, k, ld, o) : launch_direct_t<int32_t, 32>(ctx, (const int32_t*)d_idx, N, k, ld, o);
 }
+
+}  // namespace

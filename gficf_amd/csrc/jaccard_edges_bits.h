@@ -1,5 +1,5 @@
 // jaccard_edges_bits.h — k_jaccard_edges_bits, the direct-address bit-set edge kernel on dual rows (32 < k <= 55, N <= 131 070).
-// Included by jaccard.hip inside its anonymous namespace, behind the edge kernels' shared helpers.
+// Included by jaccard.hip (stands on its own: includes jaccard_shared.h), behind the edge kernels' shared helpers.
 
 // ------------------------------------------------------------------ edge kernel on dual rows: a direct-address bit set (32 < k <= 55)
 // One wave per cell, two cells in flight per wave (the pipelined kernel's scheme: cell i+1's gathers and cell i+2's own row are
@@ -16,6 +16,12 @@
 // waves per workgroup x cells in flight per wave, measured at 100 k x 50 on permuted ids (tools/bits_ab.sh, profiles/r04_bits_kernel.txt;
 // the general kernel: 121 us): 2 x 2: 99 us, 4 x 2: 99, 2 x 3: 102, 3 x 2: 113, 3 x 3: 114, 1 x 2: 118 — what matters is that the
 // waves a CU holds (LDS: 16 KiB each) divide evenly over its four SIMDs: 8 per CU (2 or 4 per workgroup), not 9.
+#pragma once
+
+#include "jaccard_shared.h"
+
+namespace {
+
 #ifndef GFICF_BITS_WAVES
 #define GFICF_BITS_WAVES 2
 #endif
@@ -329,3 +335,5 @@ __global__ __launch_bounds__(BITS_WAVES * 64) void k_jaccard_edges_bits(
     }
   }
 }
+
+}  // namespace

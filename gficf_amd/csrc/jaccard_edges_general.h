@@ -1,5 +1,5 @@
 // jaccard_edges_general.h — k_jaccard_edges, the general hash-set edge kernel (every k <= 256 the other kernels do not take).
-// Included by jaccard.hip inside its anonymous namespace, behind the edge kernels' shared helpers (JCfg, EdgeOut, probes).
+// Included by jaccard.hip (stands on its own: includes jaccard_shared.h), behind the edge kernels' shared helpers (JCfg, EdgeOut, probes).
 
 // One wave per cell, cells strided over all waves of the grid.  Per cell:
 //   * row i (one id per lane) is inserted into the wave's LDS hash set; keys that find both
@@ -14,6 +14,12 @@
 // MAP: the table holds the local ids of a sharded sub-problem; the neighbour column is written through o.l2g (loaded per cell
 // right after the own row is decoded, long before the edges are stored: a load at the store would put the wait for the gathers
 // in front of it).
+#pragma once
+
+#include "jaccard_shared.h"
+
+namespace {
+
 template <int KPAD, bool BIG, bool CMP, int OUT, bool MAP = false>
 __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
@@ -362,3 +368,5 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges(
     if (st != nullptr) atomicOr(st, ((fbits & 1u) ? GFICF_ST_DUP_IDS : 0u) | ((fbits & 2u) ? GFICF_ST_SET_OVERFLOW : 0u));
   }
 }
+
+}  // namespace

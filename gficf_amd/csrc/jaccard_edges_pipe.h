@@ -1,5 +1,5 @@
 // jaccard_edges_pipe.h — k_jaccard_edges_pipe, the software-pipelined edge kernel for k <= 32 (the north-star shape).
-// Included by jaccard.hip inside its anonymous namespace, behind the edge kernels' shared helpers.
+// Included by jaccard.hip (stands on its own: includes jaccard_shared.h), behind the edge kernels' shared helpers.
 
 // ------------------------------------------------------------------ edge kernel, software-pipelined (k <= 32)
 // The kernel above is bound by neither its arithmetic nor its LDS probes (tools/lab: taking ALL probes out leaves its time
@@ -19,6 +19,12 @@
 // NOFLAG: the table was ingested without the duplicate scan (gficf_ctx_set_jaccard_distinct) and carries no row flags: the
 // kernel does not look for them (own row, every gathered piece: ~8 of its ~200 vector instructions per cell); a repeated id
 // is found at the own row's insert, as in every variant.
+#pragma once
+
+#include "jaccard_shared.h"
+
+namespace {
+
 template <int KPAD, bool BIG, bool CMP, int OUT, bool B16 = true, bool MAP = false, bool NOFLAG = false>
 __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     const uint32_t* __restrict__ table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, EdgeOut o) {
@@ -372,3 +378,5 @@ __global__ __launch_bounds__(jc_threads<KPAD>) void k_jaccard_edges_pipe(
     }
   }
 }
+
+}  // namespace

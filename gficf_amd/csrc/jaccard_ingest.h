@@ -3,6 +3,12 @@
 
 // ------------------------------------------------------------------------------ ingest
 // zero_ok: 0 stands for "no id in this slot" (rows of a sharded sub-problem in local ids, halo.hip) instead of being an error
+#pragma once
+
+#include "jaccard_shared.h"
+
+namespace {
+
 template <typename T>
 __device__ inline uint32_t decode_id(T raw, int64_t N, bool& ok, int zero_ok = 0);
 template <>
@@ -362,3 +368,5 @@ __global__ __launch_bounds__(INGEST2_ROWS) void k_ingest_reg(const T* __restrict
     __syncthreads();
   }
 }
+
+}  // namespace

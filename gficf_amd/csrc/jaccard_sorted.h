@@ -18,6 +18,11 @@
 //   The serial entry's set semantics (Rcpp::intersect, src/jaccard_coeff.cpp:33): only the first element of a run counts.
 // Slow next to the fast kernels (k log k per edge instead of k probes) but exact for every input and every k up to 65535 (the
 // uint16 counts of the filtered / compact returns); a data set with k > 256 neighbours per cell is not a Phenograph workload.
+#pragma once
+
+#include "jaccard_shared.h"
+
+namespace {
 
 constexpr int SORTED_MAX_K = 65535;
 constexpr uint32_t SORTED_PAD = 0xFFFFFFFFu;
@@ -247,3 +252,5 @@ inline int launch_edges_sorted(gficf_ctx* ctx, const uint32_t* table, int64_t N,
   if (o.u) return launch_edges_sorted_o<OUT_RMAT_U>(ctx, table, N, k, cb, ce, o);
   return launch_edges_sorted_o<OUT_RMAT>(ctx, table, N, k, cb, ce, o);
 }
+
+}  // namespace

@@ -1424,7 +1424,7 @@ int gficf_lv_host_get(gficf_ctx* ctx, void** host, hipEvent_t* ev) {
 
 extern "C" {
 
-size_t gficf_louvain_workspace_bytes_starts(int64_t N, int64_t nnz, int n_start) {
+size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz, int n_start) {
   if (N < 0 || nnz < 0) return 0;
   int B = n_start < 1 ? 1 : n_start > LV_MAX_B ? LV_MAX_B : n_start;
   const int lim = lv_batch_limit();
@@ -1432,8 +1432,6 @@ size_t gficf_louvain_workspace_bytes_starts(int64_t N, int64_t nnz, int n_start)
   while (B > 1 && (int64_t)B * N > (int64_t)INT32_MAX) --B;      // union vertex ids are int32
   return lv_carve(nullptr, nullptr, N, nnz, B);
 }
-
-size_t gficf_louvain_workspace_bytes(int64_t N, int64_t nnz) { return gficf_louvain_workspace_bytes_starts(N, nnz, 1); }
 
 int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, const int32_t* d_indices, const double* d_x, int64_t nnz,
                          double resolution, int algorithm, int n_start, int n_iter, int seed, int32_t* d_labels, int64_t* n_clusters, double* modularity, void* d_ws,
@@ -1448,9 +1446,9 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   if (N == 0) return GFICF_OK;
   if (!d_indptr || !d_labels || !d_ws || (nnz > 0 && (!d_indices || !d_x))) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   if (N > INT32_MAX) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "more than 2^31 - 1 vertices");
-  if (ws_bytes < gficf_louvain_workspace_bytes(N, nnz))
-    GFICF_FAIL(GFICF_ERR_INVALID_ARG, "workspace too small: %zu < %zu bytes", ws_bytes, gficf_louvain_workspace_bytes(N, nnz));
-  // as many starts together as the caller's workspace holds (gficf_louvain_workspace_bytes_starts sizes it for all of them)
+  if (ws_bytes < gficf_louvain_workspace_bytes(N, nnz, 1))
+    GFICF_FAIL(GFICF_ERR_INVALID_ARG, "workspace too small: %zu < %zu bytes", ws_bytes, gficf_louvain_workspace_bytes(N, nnz, 1));
+  // as many starts together as the caller's workspace holds (gficf_louvain_workspace_bytes(N, nnz, n_start) sizes it for all of them)
   int Bmax = n_start < LV_MAX_B ? n_start : LV_MAX_B;
   if (Bmax > lv_batch_limit()) Bmax = lv_batch_limit();
   while (Bmax > 1 && ((int64_t)Bmax * N > (int64_t)INT32_MAX || lv_carve(nullptr, nullptr, N, nnz, Bmax) > ws_bytes)) --Bmax;
@@ -1770,7 +1768,7 @@ int gficf_louvain_host(gficf_ctx* ctx, int64_t N, const void* indptr, int indptr
   const int64_t nnz = h_ptr[(size_t)N];
   if (!mono) GFICF_FAIL(GFICF_ERR_BAD_CSC, "indptr does not start at 0 or is not monotone");
   if (nnz > 0 && (!indices || !x)) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL pointer");
-  const size_t nsz = (size_t)(nnz > 0 ? nnz : 1), wsb = gficf_louvain_workspace_bytes_starts(N, nnz, n_start);
+  const size_t nsz = (size_t)(nnz > 0 ? nnz : 1), wsb = gficf_louvain_workspace_bytes(N, nnz, n_start);
   gficf_arena ar;                                   // pool slot 0: no allocation per call
   const size_t o_ptr = ar.take(sizeof(int64_t) * ((size_t)N + 1)), o_idx = ar.take(sizeof(int32_t) * nsz), o_x = ar.take(sizeof(double) * nsz);
   const size_t o_lab = ar.take(sizeof(int32_t) * (size_t)N), o_ws = ar.take(wsb);

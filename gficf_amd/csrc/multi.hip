@@ -268,7 +268,6 @@ void gficf_multi_destroy(gficf_multi* m) {
   delete m;
 }
 
-int gficf_multi_device_count(const gficf_multi* m) { return m ? m->ndev : 0; }
 
 int gficf_multi_set_print(gficf_multi* m, void (*fn)(const char*)) {
   if (!m) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "multi context is NULL");

@@ -28,7 +28,7 @@ struct Carver {
 // bytes).  The search has just computed an order in which neighbours sit next to each other — its (coarse, fine) pivot order — so
 // the index matrix is relabelled into that numbering (row p = original cell order[p], ids through the inverse), the edge kernel
 // walks cells whose rows its XCD's L2 already holds, and the kept edges come out in the ORIGINAL ids
-// (gficf_jaccard_edges_filtered_mapped_device); the adjacency build sorts them anyway.  The neighbour lists are the plain
+// (gficf_jaccard_edges_filtered_mapped); the adjacency build sorts them anyway.  The neighbour lists are the plain
 // search's own (the relabelling happens behind it): the graph, and so the labels, are those of the unordered chain for every input.
 __global__ __launch_bounds__(256) void k_invert_order(const int32_t* __restrict__ order, int32_t* __restrict__ inv, int64_t N) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -122,7 +122,7 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
       if (le != hipSuccess) { gficf_set_error("HIP failure in gficf_phenograph_host (relabel launches): %s", hipGetErrorString(le)); rc = GFICF_ERR_HIP; }
     }
     if (!rc) rc = gficf_jaccard_ingest_device(ctx, (const int32_t*)d_idx2, 0, N, k, N, N, (int32_t*)d_table);
-    if (!rc) rc = gficf_jaccard_edges_filtered_mapped_device(ctx, (const int32_t*)d_table, N, k, 0, N, (uint16_t*)d_u, (int64_t*)d_cptr, from, from + cap,
+    if (!rc) rc = gficf_jaccard_edges_filtered_mapped(ctx, (const int32_t*)d_table, N, k, 0, N, (uint16_t*)d_u, (int64_t*)d_cptr, from, from + cap,
                                                              from + 2 * cap, (const int32_t*)d_order);
   } else {
     if (!rc) rc = gficf_jaccard_ingest_device(ctx, (const int32_t*)d_idx + N, 0, N, k, N, N, (int32_t*)d_table);
@@ -143,7 +143,7 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
   if (n_edges) *n_edges = h_cnt[0];
 
   // communities
-  const size_t lws = gficf_louvain_workspace_bytes_starts(N, h_cnt[1], n_start);      // all the starts in one launch set
+  const size_t lws = gficf_louvain_workspace_bytes(N, h_cnt[1], n_start);      // all the starts in one launch set
   void* d_lws = nullptr;
   e = gficf_pool_get(ctx, 1, lws, &d_lws);
   if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_phenograph_host: %s", hipGetErrorString(e));

@@ -437,11 +437,9 @@ class JaccardHaloShard:
             _all_to_all(bf["rows_in"], bf["rows_out"], None, None, self.group)
         else:
             bf["rows_in"].copy_(bf["rows_out"])
-        fused = getattr(o, "halo_ingest", None)       # relabel + ingest in one launch where the library has it (k <= 64)
-        if fused is None or not fused(idx_local_cm, nl, k, self.N, self.b, P, self.rpr, self.cap, bf["ws"], bf["req_out"], bf["rows_in"],
-                                      bf["table"], bf["l2g"]):
-            o.halo_relabel(idx_local_cm, nl, k, self.N, self.b, P, self.rpr, self.cap, bf["ws"], bf["req_out"], bf["rows_in"], bf["idx_ext"], bf["l2g"])
-            o.jaccard_ingest_local(bf["idx_ext"], self.n_ext, k, bf["table"])
+        # k > 64 (or an ops double without the fused launches): global ids -> local ids, then the plain ingest of the sub-problem
+        o.halo_relabel(idx_local_cm, nl, k, self.N, self.b, P, self.rpr, self.cap, bf["ws"], bf["req_out"], bf["rows_in"], bf["idx_ext"], bf["l2g"])
+        o.jaccard_ingest_local(bf["idx_ext"], self.n_ext, k, bf["table"])
 
     def _edges(self, bf, stream=None):
         if self.time_edges:

@@ -31,7 +31,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_abi_version_and_kpad():
     L = _lib.load()
-    assert L.gficf_hip_abi_version() == 6
+    assert L.gficf_hip_abi_version() == 7
     assert [L.gficf_jaccard_kpad(k) for k in (0, 1, 15, 16, 17, 30, 32, 33, 50, 64, 65, 128, 129, 256)] == \
         [16, 16, 16, 16, 32, 32, 32, 64, 64, 64, 128, 128, 256, 256]
     # k > 256: "sorted" rows (slot-order ids + the same ids ascending, each half padded to 64): kpad = row pitch = 2 * ceil64(k)
@@ -46,6 +46,37 @@ def test_abi_version_and_kpad():
     assert rw(131071, 30) == 16 and rw(131072, 30) == 32 and rw(1000000, 30) == 32 and rw(1000000, 50) == 64
     assert rw(-1, 30) == -1 and rw(100, 257) == 640 and rw(10**6, 513) == 1152 and rw(100, 65536) == -1
     assert L.gficf_jaccard_packed_words(5000, 300) == 640           # sorted rows travel as they are
+
+
+def test_exported_surface_is_the_header_and_the_binder_table_is_current():
+    """ABI 7 retired five entries (an accidental export, an internal helper of gficf_phenograph_host, two superseded calls, an unused
+    query): what the library exports under the gficf_ prefix is exactly what the header declares, and the header's table of who binds
+    what (tools/abi_binders.py) is regenerated whenever a binding changes."""
+    import shutil
+    import subprocess
+    import sys
+
+    names = header_functions()
+    if shutil.which("nm"):
+        out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        exported = sorted(set(re.findall(r" T (gficf_[a-z0-9_]+)$", out, re.M)))
+        assert exported == names, set(exported) ^ set(names)
+    assert len(names) == 85
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "abi_binders.py"), "--check"])
+    assert r.returncode == 0, "include/gficf_hip.h: the BINDERS table is stale — run python tools/abi_binders.py --write"
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_every_jaccard_kernel_header_compiles_on_its_own():
+    """Round 6: the kernel headers of jaccard.hip include what they use (jaccard_shared.h) and open their own namespace; through round 5
+    they compiled only inside jaccard.hip's anonymous namespace, in one order."""
+    import subprocess
+
+    csrc = os.path.join(ROOT, "gficf_amd", "csrc")
+    for h in ("jaccard_shared", "jaccard_ingest", "jaccard_edges_general", "jaccard_edges_pipe", "jaccard_edges_bits", "jaccard_sorted", "jaccard_direct"):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", "-x", "hip",
+                            os.path.join(csrc, h + ".h")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, h + ".h:\n" + r.stderr[-2000:]
 
 
 def test_status_enum_matches_header():

@@ -614,10 +614,16 @@ def test_local_id_sub_problems_of_emulated_ranks(N, k, P, cap, perm):
         ops.halo_relabel(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in[r], idx_ext, l2g)
         table = torch.zeros((n_ext, ops.row_words(n_ext, k)), **i32)
         ops.jaccard_ingest_local(idx_ext, n_ext, k, table)
-        # relabel + ingest in one launch (k <= 64): the same table and the same map
+        # the fused pair (k <= 64: the own rows with the serve step, the halo slots behind the replies): the same table and the same map
         t2, g2 = torch.full_like(table, -1), torch.full_like(l2g, -1)
-        if ops.halo_ingest(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in[r], t2, g2):
-            assert k <= 64 and torch.equal(t2, table) and torch.equal(g2, l2g)
+        scratch = torch.zeros_like(rows_out[r])
+        if ops.halo_serve_ingest(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], req_in[r], scratch, t2, g2):
+            ops.halo_ingest_slots(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in[r], t2, g2)
+            assert k <= 64 and torch.equal(scratch, rows_out[r])
+            used = int((req_out[r] != 0).sum())                 # (slots that no request fills stay what they were: compare the rows in use)
+            ops.sync()
+            rows_used = torch.cat([torch.arange(nl, device="cuda"), nl + torch.nonzero(req_out[r] != 0).flatten()])
+            assert torch.equal(t2[rows_used], table[rows_used]) and torch.equal(g2[rows_used], l2g[rows_used]) and used == len(rows_used) - nl
         else:
             assert k > 64
         out = torch.zeros((3, nl * k), dtype=torch.float64, device="cuda")
@@ -714,10 +720,9 @@ def test_configs_4_and_5_as_eight_blocks_on_local_ids(N, k):
         rows_in = torch.cat([rows_out[p][r * cap * k:(r + 1) * cap * k] for p in range(P)])
         table = torch.zeros((n_ext, ops.row_words(n_ext, k)), **i32)
         l2g = torch.zeros(n_ext, **i32)
-        if not ops.halo_ingest(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, table, l2g):
-            idx_ext = torch.zeros((k, n_ext), **i32)
-            ops.halo_relabel(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, idx_ext, l2g)
-            ops.jaccard_ingest_local(idx_ext, n_ext, k, table)
+        idx_ext = torch.zeros((k, n_ext), **i32)
+        ops.halo_relabel(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, idx_ext, l2g)
+        ops.jaccard_ingest_local(idx_ext, n_ext, k, table)
         out = torch.zeros((3, nl * k), dtype=torch.float64, device="cuda")
         ops.jaccard_edges_mapped(table, n_ext, k, nl, b, l2g, out)
         ops.sync()
@@ -770,7 +775,7 @@ def _emulated_halo_build(ops, mat, P, cap, split=False, wss=None):
         table, l2g = tables[r], l2gs[r]
         if done[r]:
             ops.halo_ingest_slots(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, table, l2g)
-        elif not ops.halo_ingest(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, table, l2g):
+        else:
             idx_ext = torch.zeros((k, n_ext), **i32)
             ops.halo_relabel(idx[r], nl, k, N, b, P, rpr, cap, wss[r], req_out[r], rows_in, idx_ext, l2g)
             ops.jaccard_ingest_local(idx_ext, n_ext, k, table)

@@ -109,7 +109,6 @@ for P in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
             h["serve_ms"] = t_ms(lambda: ops.halo_serve(idx, nl, k, b, req_in, rows_out))
             h["relabel_unfused_us"] = 1e3 * t_ms(lambda: ops.halo_relabel(idx, nl, k, N, b, P, rpr, cap, ws, req_out, rows_in, idx_ext, l2g))
             h["ingest_unfused_us"] = 1e3 * t_ms(lambda: ops.jaccard_ingest_local(idx_ext, n_ext, k, tab2))
-            h["ingest_all_rows_one_launch_us"] = 1e3 * t_ms(lambda: ops.halo_ingest(idx, nl, k, N, b, P, rpr, cap, ws, req_out, rows_in, tab2, l2g))   # round 3's form: relabel + ingest of all rows behind both exchanges
             h["serve_alone_us"] = 1e3 * h.pop("serve_ms")
             # round 4: serve + the own cells' rows in ONE launch between the exchanges, the halo slots in use behind the second one
             h["serve_ingest_ms"] = t_ms(lambda: ops.halo_serve_ingest(idx, nl, k, N, b, P, rpr, cap, ws, req_out, req_in, rows_out, tab2, l2g))
