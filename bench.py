@@ -788,11 +788,20 @@ class Bench:
         self.local_rank = local_rank
         torch.cuda.set_device(local_rank)
         self.backend_note = None
+        self.rccl_log = None
         if world > 1:
             if args.rehearse_one_gpu:
                 dist.init_process_group("gloo")
             else:
                 try:
+                    # which algorithm / protocol RCCL picks for the exchange (a direct all-gather over the 7 links or a ring?)
+                    # goes into the line as `exchange.rccl_algo`: rank 0 asks RCCL for its INFO log in a file of its own and reads it back
+                    self.rccl_log = None
+                    if rank == 0 and "NCCL_DEBUG" not in os.environ:
+                        import tempfile
+
+                        self.rccl_log = os.path.join(tempfile.gettempdir(), f"gficf_bench_rccl_{os.getpid()}.log")
+                        os.environ["NCCL_DEBUG"], os.environ["NCCL_DEBUG_SUBSYS"], os.environ["NCCL_DEBUG_FILE"] = "INFO", "INIT,COLL,TUNING,ENV", self.rccl_log
                     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
                 except Exception as ex:  # noqa: BLE001
                     # First contact with RCCL happens in the driver's own run: if the communicator cannot be built (every rank sees the
@@ -1260,7 +1269,29 @@ class Bench:
         fig["backend"] = self.dist.get_backend()
         if self.backend_note:
             fig["backend_note"] = self.backend_note
+        fig["rccl_algo"] = self.rccl_algo()
         return fig
+
+    def rccl_algo(self):
+        """What RCCL says it runs the exchange with (its INFO log, rank 0): algorithm / protocol / channels of the collective's tuning lines.
+        Best effort — the log's wording belongs to RCCL; the lines found are quoted as they are."""
+        if self.dist.get_backend() != "nccl":
+            return {"reported": False, "why": f"backend {self.dist.get_backend()}: no RCCL collective ran"}
+        if not self.rccl_log or not os.path.exists(self.rccl_log):
+            return {"reported": False, "why": "NCCL_DEBUG was set by the caller (its log is the caller's) or RCCL wrote no log file"}
+        try:
+            with open(self.rccl_log, errors="replace") as f:
+                lines = f.read().splitlines()
+        except OSError as ex:
+            return {"reported": False, "why": f"log unreadable: {ex}"}
+        import re
+
+        pick = [ln.strip()[-220:] for ln in lines if re.search(r"(?i)(allgather|alltoall|all_gather|sendrecv).*(algo|proto)|(?i)(algo|algorithm)\s*[=:]?\s*(ring|tree|direct|collnet|nvls|pat)", ln)]
+        algo = sorted({m.group(1).lower() for ln in pick for m in re.finditer(r"(?i)\b(ring|tree|direct|collnet\w*|nvls\w*|pat)\b", ln)})
+        proto = sorted({m.group(1).upper() for ln in pick for m in re.finditer(r"(?i)\b(LL128|LL|SIMPLE)\b", ln)})
+        chan = [ln.strip()[-160:] for ln in lines if re.search(r"(?i)\bchannels?\b.*\b(coll|p2p|nChannels)", ln)][:2]
+        return {"reported": bool(pick), "algorithms_named": algo, "protocols_named": proto, "lines": pick[:4], "channel_lines": chan,
+                "log_lines": len(lines)}
 
     def _exchange_figures(self):
         a, sh0 = self.args, self.shards[0]
@@ -1454,6 +1485,55 @@ class Bench:
             if "edges_per_sec" in (out["peer"]["spatial_ids"].get("overlapped") or {}):
                 eff["peer_halo_overlapped_spatial"] = per(out["peer"]["spatial_ids"]["overlapped"]["edges_per_sec"])
         out["efficiency"] = eff
+        # ---- the model's figure beside every measured one (the constants and formulas of tools/project_scaling.py), so that ONE run on
+        # the node says whether the projections hold: per exchange form {measured, projected, residual = measured - projected}
+        LINK_GBS, LAT_US, GAP_US, PEER_LAT_US = 55.0, 20.0, 2.0, 6.0
+        t1_us = (self.n_local * self.k) / self.single * 1e6                  # one data set on one GPU, measured in this run
+        ex = out.get("exchange", {})
+        shared = bool(a.rehearse_one_gpu or os.environ.get("GFICF_BENCH_RANKS_SHARE_GPU0"))
+        how = ("time-sliced, meaningless: the ranks share ONE GPU (rehearsal) — only `projected` says anything" if shared else
+               "measured on this node in this run")
+
+        def entry(measured, ex_us, extra_launches, overlapped=False):
+            step = max(t1_us, ex_us) if overlapped else t1_us + ex_us + extra_launches * GAP_US
+            proj = round(t1_us / step, 4)
+            e = {"measured": measured, "projected": proj, "measured_is": how}
+            e["residual"] = None if measured is None else round(measured - proj, 4)
+            return e
+
+        forms = {}
+        bytes_rx = float(ex.get("bytes_received_per_rank_per_data_set", 0))
+        if self.exchange == "halo":
+            # two all-to-alls with equal splits: a peer's share over its own link, one latency each
+            ex_us = 2 * (bytes_rx / max(world - 1, 1) / 2 / (LINK_GBS * 1e3) + LAT_US)
+            extra = 3
+        else:
+            # all-gather: every rank's block over each of its links once (+ pack / unpack launches when the rows travel bit-packed)
+            ex_us = bytes_rx / max(world - 1, 1) / (LINK_GBS * 1e3) + LAT_US
+            extra = 3 if "bit-packed" in ex.get("form", "") else 1
+        forms["value"] = entry(eff.get(f"in_order_{a.ids}"), ex_us, extra)
+        forms["value"]["exchange_model_us"] = round(ex_us, 1)
+        if f"overlapped_{a.ids}" in eff:
+            forms["pipelined"] = entry(eff[f"overlapped_{a.ids}"], ex_us, extra, overlapped=True)
+        if oo and f"in_order_{other}" in eff:
+            bo = float(oo.get("bytes_received_per_rank_per_data_set", 0) or 0)
+            halo_o = oo.get("exchange") == "halo"
+            exo = 2 * (bo / max(world - 1, 1) / 2 / (LINK_GBS * 1e3) + LAT_US) if halo_o else bo / max(world - 1, 1) / (LINK_GBS * 1e3) + LAT_US
+            forms[f"{other}_ids"] = entry(eff[f"in_order_{other}"], exo, 3)
+            if f"overlapped_{other}" in eff:
+                forms[f"{other}_ids_pipelined"] = entry(eff[f"overlapped_{other}"], exo, 3, overlapped=True)
+        if f"peer_in_order_{a.ids}" in eff:
+            # peer copies: the other ranks' UNPACKED slices, one per link, all pairs at once; a copy's start-up instead of a collective's latency
+            row_b = 4 * self.ops.row_words(self.N_total, self.k)
+            exp = (self.N_total - self.n_local) / max(world - 1, 1) * row_b / (LINK_GBS * 1e3) + PEER_LAT_US
+            forms["peer"] = entry(eff[f"peer_in_order_{a.ids}"], exp, 1)
+        if "peer_halo_in_order_spatial" in eff:
+            forms["peer_spatial"] = entry(eff["peer_halo_in_order_spatial"], 3.0, 2)      # nothing exchanged: a dependent read over xGMI inside one launch
+        eff["forms"] = forms
+        eff["model"] = {"link_GB_per_s_per_direction": LINK_GBS, "collective_latency_us": LAT_US, "launch_gap_us": GAP_US, "peer_copy_startup_us": PEER_LAT_US,
+                        "single_gpu_data_set_us": round(t1_us, 1),
+                        "formulas": "in order: t1 / (t1 + exchange + gaps); pipelined: t1 / max(t1, exchange); all-gather: block bytes per link / link rate + latency; "
+                                    "halo: two equal-split all-to-alls; peer: unpacked slices per link + copy start-up (tools/project_scaling.py)"}
 
     def leg_gficf_sharded(self):
         """GF-ICF, cell-sharded: every rank owns a 54 k-cell block of a (54 k x n_gpus)-cell matrix; the only

@@ -317,6 +317,17 @@ def test_plain_multi_gpu_bench_line_carries_the_whole_scaling_answer():
     eff = out["efficiency"]
     for key in ("in_order_permuted", "overlapped_permuted", "in_order_spatial", "overlapped_spatial", "peer_in_order_permuted"):
         assert eff[key] > 0, key
+    # round 6: the model's projection beside every measured figure — ONE run on the node then says whether the projections hold; in a
+    # rehearsal (the ranks share one GPU) the measured side is labelled for what it is
+    forms = eff["forms"]
+    for name in ("value", "pipelined", "spatial_ids", "spatial_ids_pipelined", "peer"):
+        f = forms[name]
+        assert 0 < f["projected"] <= 1.0 and f["measured"] > 0 and abs(f["residual"] - (f["measured"] - f["projected"])) < 1e-3, (name, f)
+        assert f["measured_is"].startswith("time-sliced, meaningless"), f
+    assert forms["value"]["projected"] < forms["pipelined"]["projected"] <= 1.0          # hiding the exchange can only help the model
+    assert eff["model"]["link_GB_per_s_per_direction"] == 55.0 and eff["model"]["single_gpu_data_set_us"] > 0
+    ra = out["exchange"]["rccl_algo"]                                                  # gloo in a rehearsal: RCCL ran nothing, and the line says so
+    assert ra["reported"] is False and "gloo" in ra["why"]
 
 
 def _bench_env():
