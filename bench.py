@@ -279,7 +279,7 @@ def bench_knn(torch, ops, args):
         run()
         ops.jaccard_ingest(idx[1:], N, kj, N, table)
         ops.jaccard_edges_filtered(table, N, kj, 0, N, u_ws, cell_ptr, out3)
-        ops.adjacency(N, cap, cell_ptr[N:N + 1], out3, aws, indptr, indices, ax)
+        ops.adjacency(N, cap, cell_ptr[N:N + 1], out3, aws, indptr, indices, ax, grouped_by_source=True)
 
     graph()
     torch.cuda.synchronize()

@@ -90,7 +90,7 @@ SIGNATURES = {
     "gficf_jaccard_filtered_host_plan": (_int, [_vp, _vp, _int, _i64, _int, _i64, ctypes.POINTER(_i64)]),
     "gficf_jaccard_filtered_host_finish": (_int, [_vp, _vp, _vp, _vp]),
     "gficf_adjacency_workspace_bytes": (ctypes.c_size_t, [_i64, _i64]),
-    "gficf_adjacency_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp, _vp, _vp]),
+    "gficf_adjacency_device": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _vp, ctypes.c_size_t, _vp, _vp, _vp]),
     "gficf_adjacency_host_plan": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "gficf_adjacency_host_finish": (_int, [_vp, _vp, _int, _vp, _vp]),
     "gficf_normalize_csc_host_plan": (_int, [_vp, _i64, _i64, _vp, _int, _vp, _vp, _dbl, _dbl, _vp,

@@ -933,13 +933,15 @@ class HipOps:
     def adjacency_workspace_bytes(self, N: int, edge_capacity: int) -> int:
         return int(self.L.gficf_adjacency_workspace_bytes(int(N), int(edge_capacity)))
 
-    def adjacency(self, N: int, edge_capacity: int, n_edges_dev, out3, ws, indptr, indices, x):
+    def adjacency(self, N: int, edge_capacity: int, n_edges_dev, out3, ws, indptr, indices, x, grouped_by_source: bool = False):
         """out3: the (3, edge_capacity) float64 buffer of jaccard_edges_filtered (rows from / to / weight);
-        n_edges_dev: int64 device scalar (a 1-element view, e.g. cell_ptr[n:n+1]) or None = all edge_capacity rows."""
+        n_edges_dev: int64 device scalar (a 1-element view, e.g. cell_ptr[n:n+1]) or None = all edge_capacity rows.
+        grouped_by_source: the caller knows that the edges of one source cell lie together (what jaccard_edges_filtered writes):
+        no check, no stream synchronisation inside the call; False = any edge list."""
         base = out3.data_ptr()
         check(self.L.gficf_adjacency_device(self._bind(), N, edge_capacity, _tptr(n_edges_dev), ctypes.c_void_p(base),
                                             ctypes.c_void_p(base + 8 * edge_capacity), ctypes.c_void_p(base + 16 * edge_capacity),
-                                            _tptr(ws), int(ws.numel()), _tptr(indptr), _tptr(indices), _tptr(x)))
+                                            1 if grouped_by_source else 0, _tptr(ws), int(ws.numel()), _tptr(indptr), _tptr(indices), _tptr(x)))
 
     def jaccard(self, idx_cm, N: int, k: int, table_ws, rmat3, u=None):
         """Single-GPU ingest + edges.  rmat3: (3, N*k) float64 == the (N*k) x 3 R matrix."""

@@ -10,12 +10,22 @@
 // Vertices are the cells 1..N in cell order (igraph orders vertices by first appearance in the edge list, which is
 // the same whenever every cell keeps at least one edge).
 //
-// Device path: every kept edge emits the two entries (i,j) and (j,i) as 64-bit keys row << b | col (b = bits of N: 2 b
-// significant bits — 34 at 100 k cells, five 8-bit radix passes; through round 5 the column sat in the low 32 bits: 32 + b
-// bits, seven passes), the entries are ordered by one device-wide radix sort over just the bits in use (rocPRIM: a plain
-// library sort, not the hot path), equal keys are summed in sorted order and the row pointer comes from a binary search per row.
-// Round 6 tried the build without a sort (row buckets filled by atomics, rows ordered by a wave each): slower, because the
-// transposed half needs a device-scope atomic per edge — profiles/r06_adjacency_row_buckets.txt; closed.
+// Device path (round 6, second form).  Row r of A = the edges r -> * (half W) and the edges * -> r (half W^T).  The edge kernel emits
+// W grouped by source cell, so half W needs no ordering at all: the run of every source is found where it lies.  Only the transposed
+// half is ordered, and only by its row: ONE stable radix sort of E 32-bit keys (the destination, b = bits of N: 17 at 100 k cells, three
+// 8-bit passes) carrying the edge number — through round 5 the build sorted 2 E 64-bit keys row << 32 | col over seven passes, in this
+// round's first form over five.  A wave then merges the two halves of a row: ranks its <= 128 entries by (column, emission position) in
+// LDS, sums the runs of one column in that order (the order the full stable sort gave) and writes the row; longer rows take a
+// workgroup.  The sort is still rocPRIM's (a plain library sort over 1/13 of the bytes it moved before).
+//   1. k_adj_edges    validate, key = destination, value = e, (source, weight) packed for the gather of step 4, run of every source
+//   2. radix sort     E keys of b bits, stable: within one destination the edges stay in emission order
+//   3. k_adj_bounds   first sorted position of every destination (binary search), k_adj_caps + scan: room of every row
+//   4. k_adj_rows(_big)  the merge above, rows written compacted at the start of their room
+//   5. scan of the final lengths -> indptr, k_adj_compact: rows to their final place
+// An edge list that is NOT grouped by source (any caller-made list is allowed) takes one more sort of the same kind, by source.
+// Round 6's first attempt without any sort (row buckets filled by atomics) was slower: a device-scope atomic per edge for the
+// transposed half — profiles/r06_adjacency_row_buckets.txt.
+#include <atomic>
 #include <cstring>
 #include <vector>
 
@@ -26,89 +36,306 @@
 namespace {
 
 typedef unsigned long long u64;
-constexpr u64 ADJ_NONE = ~0ull;
+constexpr uint32_t ADJ_NONE = 0xFFFFFFFFu;
+constexpr int ADJ_WAVE_ROW = 128;            // entries a wave orders by ranking (two a lane)
+constexpr int ADJ_WG_ROW = 4096;             // entries a workgroup orders in LDS
 
-__global__ __launch_bounds__(256) void k_adj_emit(const double* __restrict__ from, const double* __restrict__ to,
-                                                  const double* __restrict__ w, int64_t cap, const int64_t* __restrict__ n_edges_p,
-                                                  int64_t N, int b, u64* __restrict__ keys, double* __restrict__ vals,
-                                                  uint32_t* __restrict__ status) {
+struct AdjPk { uint32_t src; uint32_t pad; double w; };      // what the transposed half gathers per entry: one 16 B read
+
+__device__ inline bool adj_edge(const double* __restrict__ from, const double* __restrict__ to, int64_t e, int64_t N, int64_t* i, int64_t* j) {
+  const double fi = from[e], fj = to[e];
+  if (!(fi >= 1.0 && fi <= (double)N && fj >= 1.0 && fj <= (double)N && fi == trunc(fi) && fj == trunc(fj))) return false;
+  *i = (int64_t)fi - 1; *j = (int64_t)fj - 1;
+  return true;
+}
+
+// One thread per edge slot.  tkey = destination (ADJ_NONE: slot unused, bad ids, or a self edge — counted once, in half W), tval = e.
+// The run of every source: its head writes rbeg, its tail rend; a source with two heads means the list is not grouped (*not_grouped).
+__global__ __launch_bounds__(256) void k_adj_edges(const double* __restrict__ from, const double* __restrict__ to, const double* __restrict__ w,
+                                                   int64_t cap, const int64_t* __restrict__ n_edges_p, int64_t N, uint32_t* __restrict__ tkey,
+                                                   uint32_t* __restrict__ tval, AdjPk* __restrict__ pk, int32_t* __restrict__ rbeg,
+                                                   int32_t* __restrict__ rend, int32_t* __restrict__ nruns, uint32_t* __restrict__ not_grouped,
+                                                   int promised, uint32_t* __restrict__ status) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= cap) return;
-  u64 k0 = ADJ_NONE, k1 = ADJ_NONE;
-  double v = 0.0;
-  const int64_t n_edges = n_edges_p ? *n_edges_p : cap;
+  const int64_t n_edges = n_edges_p ? (*n_edges_p < cap ? *n_edges_p : cap) : cap;
+  uint32_t kt = ADJ_NONE;
   if (e < n_edges) {
-    const double fi = from[e], fj = to[e];
-    if (fi >= 1.0 && fi <= (double)N && fj >= 1.0 && fj <= (double)N && fi == trunc(fi) && fj == trunc(fj)) {
-      const u64 i = (u64)fi - 1ull, j = (u64)fj - 1ull;
-      v = w[e];
-      k0 = (i << b) | j;
-      if (i != j) k1 = (j << b) | i;                  // a self edge counts once
+    int64_t i, j;
+    if (adj_edge(from, to, e, N, &i, &j)) {
+      if (i != j) kt = (uint32_t)j;
+      AdjPk q; q.src = (uint32_t)i; q.pad = 0u; q.w = w[e];
+      pk[e] = q;
     } else {
       atomicOr(status, GFICF_ST_BAD_ID);
     }
+    const double f = from[e];                               // (the runs count every edge whose source is a cell, whatever its destination)
+    if (f >= 1.0 && f <= (double)N && f == trunc(f)) {
+      const int64_t s = (int64_t)f - 1;
+      if (e == 0 || from[e - 1] != f) {
+        rbeg[s] = (int32_t)e;
+        if (atomicAdd(&nruns[s], 1) > 0) {
+          *not_grouped = 1u;
+          if (promised) atomicOr(status, GFICF_ST_NOT_GROUPED);
+        }
+      }
+      if (e == n_edges - 1 || from[e + 1] != f) rend[s] = (int32_t)(e + 1);
+    }
   }
-  keys[2 * e] = k0; vals[2 * e] = v;
-  keys[2 * e + 1] = k1; vals[2 * e + 1] = v;
+  tkey[e] = kt; tval[e] = (uint32_t)e;
 }
 
-// flags[e] = 1 where a new (row, col) starts; flags[M] = 0 (becomes the number of entries after the scan)
-__global__ __launch_bounds__(256) void k_adj_heads(const u64* __restrict__ keys, int64_t M, int64_t* __restrict__ flags) {
+// the list is not grouped: key = source for the second sort
+__global__ __launch_bounds__(256) void k_adj_source_keys(const double* __restrict__ from, const double* __restrict__ to, int64_t cap,
+                                                         const int64_t* __restrict__ n_edges_p, int64_t N, uint32_t* __restrict__ skey,
+                                                         uint32_t* __restrict__ sval) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e > M) return;
-  int64_t f = 0;
-  if (e < M) {
-    const u64 k = keys[e];
-    f = (k != ADJ_NONE && (e == 0 || keys[e - 1] != k)) ? 1 : 0;
-  }
-  flags[e] = f;
+  if (e >= cap) return;
+  const int64_t n_edges = n_edges_p ? (*n_edges_p < cap ? *n_edges_p : cap) : cap;
+  int64_t i, j;
+  skey[e] = (e < n_edges && adj_edge(from, to, e, N, &i, &j)) ? (uint32_t)i : ADJ_NONE;
+  sval[e] = (uint32_t)e;
 }
 
-// one thread per head: sum its run of equal keys (in sorted, i.e. emission, order) and write the entry
-__global__ __launch_bounds__(256) void k_adj_write(const u64* __restrict__ keys, const double* __restrict__ vals, int64_t M, int b,
-                                                   const int64_t* __restrict__ pos, int32_t* __restrict__ indices,
-                                                   double* __restrict__ x, int32_t* __restrict__ urow) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= M) return;
-  const u64 k = keys[e];
-  if (k == ADJ_NONE || (e > 0 && keys[e - 1] == k)) return;
-  double s = vals[e];
-  for (int64_t t = e + 1; t < M && keys[t] == k; ++t) s += vals[t];
-  const int64_t p = pos[e];
-  indices[p] = (int32_t)(k & ((1ull << b) - 1ull));
-  x[p] = s;
-  urow[p] = (int32_t)(k >> b);
-}
-
-// indptr[r] = first entry whose row is >= r
-__global__ __launch_bounds__(256) void k_adj_indptr(const int32_t* __restrict__ urow, const int64_t* __restrict__ nnz_p, int64_t N,
-                                                    int64_t* __restrict__ indptr) {
+// L[r] = first position of the sorted keys holding a key >= r, r = 0 .. N (unused slots sort last: L[N] = number of real keys)
+__global__ __launch_bounds__(256) void k_adj_bounds(const uint32_t* __restrict__ keys, int64_t M, int64_t N, int32_t* __restrict__ L) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r > N) return;
-  const int64_t nnz = *nnz_p;
-  int64_t lo = 0, hi = nnz;
+  int64_t lo = 0, hi = M;
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)urow[mid] < r) lo = mid + 1;
+    if ((int64_t)keys[mid] < r) lo = mid + 1;
     else hi = mid;
   }
-  indptr[r] = lo;
+  L[r] = (int32_t)lo;
+}
+
+// room of row r = its entries before equal columns are summed
+__global__ __launch_bounds__(256) void k_adj_caps(int64_t N, const int32_t* __restrict__ rbeg, const int32_t* __restrict__ rend,
+                                                  const int32_t* __restrict__ tL, const uint32_t* __restrict__ broken,
+                                                  int64_t* __restrict__ start) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r > N) return;
+  int64_t c = 0;
+  if (r < N && !(broken && *broken)) {                     // (a list promised grouped that is not: its runs mean nothing — empty rows, the status says why)
+    const int nw = rend[r] - rbeg[r];
+    c = (nw > 0 ? nw : 0) + (tL[r + 1] - tL[r]);
+  }
+  start[r] = c;
+}
+
+struct AdjIn {
+  const double* to; const double* w; const AdjPk* pk;
+  const int32_t* rbeg; const int32_t* rend;       // half W: positions [rbeg, rend) of row r — edge numbers, or positions in `se` when the list was sorted by source
+  const uint32_t* se;                             // NULL: the list is grouped by source
+  const int32_t* tL; const uint32_t* te;          // half W^T: positions [tL[r], tL[r + 1]) of the edge numbers ordered by destination
+};
+
+__device__ inline u64 adj_key(uint32_t col, uint32_t pos) { return ((u64)col << 32) | pos; }
+
+// entry t of a row whose half W holds nw entries starting at rb and whose half W^T starts at tb: key = (column, emission position), weight
+__device__ inline void adj_load(const AdjIn& I, int rb, int nw, int tb, int64_t t, u64* key, double* wv) {
+  if (t < nw) {
+    const uint32_t e = I.se ? I.se[rb + t] : (uint32_t)(rb + t);
+    *key = adj_key((uint32_t)((int64_t)I.to[e] - 1), 2u * e);
+    *wv = I.w[e];
+  } else {
+    const uint32_t e = I.te[tb + (t - nw)];
+    const AdjPk q = I.pk[e];
+    *key = adj_key(q.src, 2u * e + 1u);
+    *wv = q.w;
+  }
+}
+
+#define ADJ_WAVE_SYNC()                                                                                                                   \
+  do {                                                                                                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+// One wave per row of at most ADJ_WAVE_ROW entries.  Every lane ranks its (up to two) entries against the whole row read from LDS
+// (broadcast reads; the keys are distinct: the position is), writes them at their rank, then the heads of the runs of one column add
+// their run up in order and the row goes to the start of its room, compacted.  len2[row] = its final length.
+__global__ __launch_bounds__(256) void k_adj_rows(const AdjIn I, int64_t N, const int64_t* __restrict__ start, int32_t* __restrict__ bcol,
+                                                  double* __restrict__ bw, int64_t* __restrict__ len2, int32_t* __restrict__ big,
+                                                  unsigned* __restrict__ n_big) {
+  __shared__ u64 s_key[4][ADJ_WAVE_ROW];
+  __shared__ double s_w[4][ADJ_WAVE_ROW];
+  __shared__ u64 s_skey[4][ADJ_WAVE_ROW];
+  __shared__ double s_sw[4][ADJ_WAVE_ROW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  u64* key = s_key[wave]; double* wv = s_w[wave]; u64* skey = s_skey[wave]; double* sw = s_sw[wave];
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+    const int64_t lo = start[row];
+    const int n = (int)(start[row + 1] - lo);
+    if (n > ADJ_WAVE_ROW) {                                  // the workgroup kernel's
+      if (lane == 0) { big[atomicAdd(n_big, 1u)] = (int32_t)row; }
+      continue;
+    }
+    if (n == 0) { if (lane == 0) len2[row] = 0; continue; }
+    const int rb = I.rbeg[row], tb = I.tL[row];
+    const int nw = n - (I.tL[row + 1] - tb);
+    u64 k0 = ~0ull, k1 = ~0ull;
+    double w0 = 0.0, w1 = 0.0;
+    if (lane < n) adj_load(I, rb, nw, tb, lane, &k0, &w0);
+    if (lane + 64 < n) adj_load(I, rb, nw, tb, lane + 64, &k1, &w1);
+    key[lane] = k0; key[lane + 64] = k1;
+    ADJ_WAVE_SYNC();
+    int r0 = 0, r1 = 0;
+    for (int t = 0; t < n; ++t) { const u64 kt = key[t]; r0 += kt < k0 ? 1 : 0; r1 += kt < k1 ? 1 : 0; }
+    if (lane < n) { skey[r0] = k0; sw[r0] = w0; }
+    if (lane + 64 < n) { skey[r1] = k1; sw[r1] = w1; }
+    ADJ_WAVE_SYNC();
+    // heads of the runs of one column, their output positions (ranks among the heads), their sums
+    int out0 = -1, out1 = -1;
+    int total = 0;
+    for (int r = 0; r < 2; ++r) {
+      const int e = r * 64 + lane;
+      const bool head = e < n && (e == 0 || (skey[e] >> 32) != (skey[e - 1] >> 32));
+      const u64 m = __ballot(head);
+      const int at = total + __popcll(m & ((1ull << lane) - 1ull));
+      total += __popcll(m);
+      if (head) { if (r == 0) out0 = at; else out1 = at; }
+    }
+    for (int r = 0; r < 2; ++r) {
+      const int e = r * 64 + lane, at = r == 0 ? out0 : out1;
+      if (at < 0) continue;
+      const u64 c = skey[e] >> 32;
+      double sum = sw[e];
+      for (int t = e + 1; t < n && (skey[t] >> 32) == c; ++t) sum += sw[t];
+      key[at] = c; wv[at] = sum;                              // (the unsorted copy is no longer needed)
+    }
+    ADJ_WAVE_SYNC();
+    for (int t = lane; t < total; t += 64) { bcol[lo + t] = (int32_t)key[t]; bw[lo + t] = wv[t]; }
+    if (lane == 0) len2[row] = total;
+    ADJ_WAVE_SYNC();
+  }
+}
+
+// bitonic network over n2 (a power of two) elements held in arrays k / w
+__device__ inline void adj_bitonic(u64* k, double* w, int64_t n2, int tid, int nthreads) {
+  for (int64_t size = 2; size <= n2; size <<= 1)
+    for (int64_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int64_t t = tid; t < n2 / 2; t += nthreads) {
+        const int64_t lo = (t / stride) * 2 * stride + (t % stride), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const u64 a = k[lo], b = k[hi];
+        if ((a > b) == up) { k[lo] = b; k[hi] = a; const double x = w[lo]; w[lo] = w[hi]; w[hi] = x; }
+      }
+      __syncthreads();
+    }
+}
+
+// One workgroup per listed row (more than ADJ_WAVE_ROW entries): up to ADJ_WG_ROW entries ordered in LDS; longer rows in the scratch
+// arrays gk / gw (global memory; a row of that length is a hub of a degenerate graph: correct, not fast).
+__global__ __launch_bounds__(256) void k_adj_rows_big(const AdjIn I, const int64_t* __restrict__ start, const int32_t* __restrict__ big,
+                                                      const unsigned* __restrict__ n_big, int32_t* __restrict__ bcol, double* __restrict__ bw,
+                                                      int64_t* __restrict__ len2, u64* __restrict__ gk, double* __restrict__ gw) {
+  extern __shared__ unsigned char s_raw[];
+  u64* sk = (u64*)s_raw;
+  double* sw = (double*)(sk + ADJ_WG_ROW);
+  __shared__ int s_total;
+  __shared__ int s_cnt[256];
+  const int tid = threadIdx.x;
+  for (unsigned item = blockIdx.x; item < *n_big; item += gridDim.x) {
+    const int64_t row = big[item], lo = start[row], n = start[row + 1] - lo;
+    const int rb = I.rbeg[row], tb = I.tL[row];
+    const int nw = (int)(n - (I.tL[row + 1] - tb));
+    int64_t n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    // a row too long for LDS is ordered in global scratch: n2 < 2 n entries at twice its room's start (the scratch arrays are twice the rooms)
+    u64* k = n2 <= ADJ_WG_ROW ? sk : gk + 2 * lo;
+    double* w = n2 <= ADJ_WG_ROW ? sw : gw + 2 * lo;
+    for (int64_t t = tid; t < n2; t += 256) {
+      u64 kk = ~0ull; double ww = 0.0;
+      if (t < n) adj_load(I, rb, nw, tb, t, &kk, &ww);
+      k[t] = kk; w[t] = ww;
+    }
+    __syncthreads();
+    adj_bitonic(k, w, n2, tid, 256);
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    // the heads of the runs of one column: every thread takes a contiguous slice, the slices' bases by a serial pass over 256 counts
+    const int64_t per = (n + 255) / 256, t0 = (int64_t)tid * per, t1 = t0 + per < n ? t0 + per : n;
+    int mine = 0;
+    for (int64_t t = t0; t < t1; ++t) mine += (t == 0 || (k[t] >> 32) != (k[t - 1] >> 32)) ? 1 : 0;
+    s_cnt[tid] = mine;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int t = 0; t < 256; ++t) { const int c = s_cnt[t]; s_cnt[t] = run; run += c; } s_total = run; }
+    __syncthreads();
+    int at = s_cnt[tid];
+    for (int64_t t = t0; t < t1; ++t) {
+      if (!(t == 0 || (k[t] >> 32) != (k[t - 1] >> 32))) continue;
+      const u64 c = k[t] >> 32;
+      double sum = w[t];
+      for (int64_t q = t + 1; q < n && (k[q] >> 32) == c; ++q) sum += w[q];
+      bcol[lo + at] = (int32_t)c; bw[lo + at] = sum;
+      ++at;
+    }
+    if (tid == 0) len2[row] = s_total;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_adj_compact(int64_t N, const int64_t* __restrict__ start, const int64_t* __restrict__ indptr,
+                                                     const int32_t* __restrict__ bcol, const double* __restrict__ bw,
+                                                     int32_t* __restrict__ indices, double* __restrict__ x) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+    const int64_t src = start[row], dst = indptr[row], n = indptr[row + 1] - dst;
+    for (int64_t t = lane; t < n; t += 64) { indices[dst + t] = bcol[src + t]; x[dst + t] = bw[src + t]; }
+  }
 }
 
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-inline int id_bits(int64_t N) {                        // 2^b > N: an id in [0, N) never has all of its b bits set, so no real key is all ones
+inline int id_bits(int64_t N) {                        // 2^b > N: an id in [0, N) never has all of its b bits set, so ADJ_NONE sorts behind every real key
   int b = 1;
   while (b < 32 && ((int64_t)1 << b) <= N) ++b;
   return b;
 }
-inline int key_bits(int64_t N) { return 2 * id_bits(N); }   // col in the low b bits, row above
 
 size_t sort_temp_bytes(int64_t M, int bits) {
   size_t tmp = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp, (u64*)nullptr, (u64*)nullptr, (double*)nullptr, (double*)nullptr, (size_t)M, 0u,
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)M, 0u,
                                   (unsigned)bits, (hipStream_t) nullptr);
   return tmp;
+}
+
+struct AdjWs {
+  uint32_t *key_in, *val_in, *tkey, *te, *skey, *se;    // cap each
+  AdjPk* pk;                                            // cap
+  int32_t *rbeg, *rend, *nruns;                         // N
+  int32_t *tL, *sL;                                     // N + 2
+  uint32_t* flag;                                       // not_grouped, n_big
+  int64_t* start;                                       // N + 1: start of every row's room
+  int32_t* bcol; double* bw;                            // 2 cap each: the rooms
+  int32_t* big;                                         // N
+  u64* gk; double* gw;                                  // 4 cap each: scratch of rows too long for LDS
+  void* tmp; size_t tmp_bytes;
+};
+
+size_t adj_carve(AdjWs* w, void* base, int64_t N, int64_t cap) {
+  size_t off = 0;
+  const size_t n = (size_t)(N > 0 ? N : 1), c = (size_t)(cap > 0 ? cap : 1), m = 2 * c;
+  auto take = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return base ? (char*)base + o : (char*)nullptr; };
+  AdjWs d;
+  d.key_in = (uint32_t*)take(c * 4); d.val_in = (uint32_t*)take(c * 4);
+  d.tkey = (uint32_t*)take(c * 4); d.te = (uint32_t*)take(c * 4);
+  d.skey = (uint32_t*)take(c * 4); d.se = (uint32_t*)take(c * 4);
+  d.pk = (AdjPk*)take(c * sizeof(AdjPk));
+  d.rbeg = (int32_t*)take(3 * n * 4); d.rend = d.rbeg + n; d.nruns = d.rend + n;       // one memset
+  d.tL = (int32_t*)take((n + 2) * 4); d.sL = (int32_t*)take((n + 2) * 4);
+  d.flag = (uint32_t*)take(256);
+  d.start = (int64_t*)take((n + 1) * sizeof(int64_t));
+  d.bcol = (int32_t*)take(m * sizeof(int32_t));
+  d.bw = (double*)take(m * sizeof(double));
+  d.big = (int32_t*)take(n * sizeof(int32_t));
+  d.gk = (u64*)take(2 * m * sizeof(u64));
+  d.gw = (double*)take(2 * m * sizeof(double));
+  d.tmp_bytes = sort_temp_bytes((int64_t)c, id_bits(N));
+  d.tmp = (void*)take(d.tmp_bytes);
+  if (w) *w = d;
+  return off + 256;
 }
 
 }  // namespace
@@ -117,17 +344,16 @@ extern "C" {
 
 size_t gficf_adjacency_workspace_bytes(int64_t N, int64_t edge_capacity) {
   if (N <= 0 || edge_capacity <= 0) return 256;
-  const size_t M = 2 * (size_t)edge_capacity;
-  return 2 * align256(M * sizeof(u64)) + 2 * align256(M * sizeof(double)) + align256((M + 1) * sizeof(int64_t)) +
-         align256(M * sizeof(int32_t)) + align256(sort_temp_bytes((int64_t)M, key_bits(N))) + 256;
+  return adj_carve(nullptr, nullptr, N, edge_capacity);
 }
 
 int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, const int64_t* d_n_edges, const double* d_from,
-                           const double* d_to, const double* d_weight, void* d_ws, size_t ws_bytes, int64_t* d_indptr,
-                           int32_t* d_indices, double* d_x) {
+                           const double* d_to, const double* d_weight, int grouped_by_source, void* d_ws, size_t ws_bytes,
+                           int64_t* d_indptr, int32_t* d_indices, double* d_x) {
   GFICF_CTX_ENTER(ctx);
   if (N < 0 || edge_capacity < 0) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "negative size");
   if (N > 0x7FFFFFFFll) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "N = %lld exceeds int32 ids", (long long)N);
+  if (edge_capacity > 0x3FFFFFFFll) GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "more than 2^30 edges");
   if (!d_indptr) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   if (N == 0 || edge_capacity == 0) {
     GFICF_HIP_CHECK(hipMemsetAsync(d_indptr, 0, sizeof(int64_t) * (size_t)(N + 1), ctx->stream));
@@ -135,29 +361,53 @@ int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, con
   }
   if (!d_from || !d_to || !d_weight || !d_ws || !d_indices || !d_x) GFICF_FAIL(GFICF_ERR_INVALID_ARG, "NULL device pointer");
   if (ws_bytes < gficf_adjacency_workspace_bytes(N, edge_capacity)) GFICF_FAIL(GFICF_ERR_CAPACITY, "adjacency workspace too small");
-  const int64_t M = 2 * edge_capacity;
-  const int bits = key_bits(N), idb = id_bits(N);
-  char* p = (char*)d_ws;
-  u64* k_in = (u64*)p;        p += align256((size_t)M * sizeof(u64));
-  u64* k_out = (u64*)p;       p += align256((size_t)M * sizeof(u64));
-  double* v_in = (double*)p;  p += align256((size_t)M * sizeof(double));
-  double* v_out = (double*)p; p += align256((size_t)M * sizeof(double));
-  int64_t* pos = (int64_t*)p; p += align256((size_t)(M + 1) * sizeof(int64_t));
-  int32_t* urow = (int32_t*)p; p += align256((size_t)M * sizeof(int32_t));
-  size_t tmp_bytes = sort_temp_bytes(M, bits);
-  void* tmp = (void*)p;
-  hipLaunchKernelGGL(k_adj_emit, dim3((unsigned)gficf_ceil_div(edge_capacity, 256)), dim3(256), 0, ctx->stream, d_from, d_to, d_weight,
-                     edge_capacity, d_n_edges, N, idb, k_in, v_in, ctx->d_status);
+  static std::atomic<bool> attr_set[64];
+  if (!attr_set[ctx->device & 63]) {
+    GFICF_HIP_CHECK(hipFuncSetAttribute((const void*)k_adj_rows_big, hipFuncAttributeMaxDynamicSharedMemorySize, ADJ_WG_ROW * 16));
+    attr_set[ctx->device & 63] = true;
+  }
+  AdjWs w;
+  adj_carve(&w, d_ws, N, edge_capacity);
+  hipStream_t st = ctx->stream;
+  const int b = id_bits(N);
+  const unsigned ge = (unsigned)gficf_ceil_div(edge_capacity, 256), gn = (unsigned)gficf_ceil_div(N + 1, 256);
+  const unsigned gr = (unsigned)(gficf_ceil_div(N, 4) < 4096 ? gficf_ceil_div(N, 4) : 4096);
+  GFICF_HIP_CHECK(hipMemsetAsync(w.rbeg, 0, sizeof(int32_t) * 3 * (size_t)N, st));
+  GFICF_HIP_CHECK(hipMemsetAsync(w.flag, 0, 2 * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(k_adj_edges, dim3(ge), dim3(256), 0, st, d_from, d_to, d_weight, edge_capacity, d_n_edges, N, w.key_in, w.val_in, w.pk, w.rbeg,
+                     w.rend, w.nruns, w.flag, grouped_by_source != 0 ? 1 : 0, ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
-  // unused slots carry the all-ones key; they only need to end up behind every real key: ids are below 2^b - 1, so among the `bits` bits
-  // sorted the all-ones pattern is larger than any real key
-  GFICF_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, v_in, v_out, (size_t)M, 0u, (unsigned)bits, ctx->stream));
-  hipLaunchKernelGGL(k_adj_heads, dim3((unsigned)gficf_ceil_div(M + 1, 256)), dim3(256), 0, ctx->stream, k_out, M, pos);
+  GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.tmp, w.tmp_bytes, w.key_in, w.tkey, w.val_in, w.te, (size_t)edge_capacity, 0u, (unsigned)b, st));
+  hipLaunchKernelGGL(k_adj_bounds, dim3(gn), dim3(256), 0, st, (const uint32_t*)w.tkey, edge_capacity, N, w.tL);
+  AdjIn in;
+  in.to = d_to; in.w = d_weight; in.pk = w.pk; in.rbeg = w.rbeg; in.rend = w.rend; in.se = nullptr; in.tL = w.tL; in.te = w.te;
+  bool grouped = grouped_by_source != 0;
+  if (!grouped) {                                   // the caller does not know: ask the pass that just looked at every edge
+    uint32_t ng = 0;
+    GFICF_HIP_CHECK(hipMemcpyAsync(&ng, w.flag, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    GFICF_HIP_CHECK(hipStreamSynchronize(st));
+    grouped = ng == 0;
+  }
+  if (!grouped) {
+    hipLaunchKernelGGL(k_adj_source_keys, dim3(ge), dim3(256), 0, st, d_from, d_to, edge_capacity, d_n_edges, N, w.key_in, w.val_in);
+    GFICF_HIP_CHECK(hipGetLastError());
+    GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.tmp, w.tmp_bytes, w.key_in, w.skey, w.val_in, w.se, (size_t)edge_capacity, 0u, (unsigned)b, st));
+    hipLaunchKernelGGL(k_adj_bounds, dim3(gn), dim3(256), 0, st, (const uint32_t*)w.skey, edge_capacity, N, w.sL);
+    in.rbeg = w.sL; in.rend = w.sL + 1; in.se = w.se;
+  }
+  hipLaunchKernelGGL(k_adj_caps, dim3(gn), dim3(256), 0, st, N, in.rbeg, in.rend, (const int32_t*)w.tL, in.se ? (const uint32_t*)nullptr : (const uint32_t*)w.flag,
+                     w.start);
   GFICF_HIP_CHECK(hipGetLastError());
-  int rc = gficf_exclusive_scan_i64(ctx, pos, M + 1);
+  int rc = gficf_exclusive_scan_i64(ctx, w.start, N + 1);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_adj_write, dim3((unsigned)gficf_ceil_div(M, 256)), dim3(256), 0, ctx->stream, k_out, v_out, M, idb, pos, d_indices, d_x, urow);
-  hipLaunchKernelGGL(k_adj_indptr, dim3((unsigned)gficf_ceil_div(N + 1, 256)), dim3(256), 0, ctx->stream, urow, pos + M, N, d_indptr);
+  hipLaunchKernelGGL(k_adj_rows, dim3(gr), dim3(256), 0, st, in, N, (const int64_t*)w.start, w.bcol, w.bw, d_indptr, w.big, w.flag + 1);
+  hipLaunchKernelGGL(k_adj_rows_big, dim3(64), dim3(256), ADJ_WG_ROW * 16, st, in, (const int64_t*)w.start, (const int32_t*)w.big,
+                     (const unsigned*)(w.flag + 1), w.bcol, w.bw, d_indptr, w.gk, w.gw);
+  GFICF_HIP_CHECK(hipMemsetAsync(d_indptr + N, 0, sizeof(int64_t), st));
+  rc = gficf_exclusive_scan_i64(ctx, d_indptr, N + 1);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_adj_compact, dim3(gr), dim3(256), 0, st, N, (const int64_t*)w.start, (const int64_t*)d_indptr, (const int32_t*)w.bcol,
+                     (const double*)w.bw, d_indices, d_x);
   GFICF_HIP_CHECK(hipGetLastError());
   return GFICF_OK;
 }
@@ -208,7 +458,7 @@ int gficf_adjacency_host_plan(gficf_ctx* ctx, int64_t N, int64_t n_edges, const 
   int rc = GFICF_OK;
   int64_t total = 0;
   if (e == hipSuccess) {
-    rc = gficf_adjacency_device(ctx, N, n_edges, nullptr, d_from, d_to, d_w, d_ws, wsb, p->d_indptr, p->d_indices, p->d_x);
+    rc = gficf_adjacency_device(ctx, N, n_edges, nullptr, d_from, d_to, d_w, 0, d_ws, wsb, p->d_indptr, p->d_indices, p->d_x);
     if (!rc) e = hipMemcpyAsync(&total, p->d_indptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
     if (!rc && e == hipSuccess) rc = gficf_ctx_sync(ctx);
     else (void)hipStreamSynchronize(ctx->stream);

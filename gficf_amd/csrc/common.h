@@ -19,6 +19,7 @@ constexpr uint32_t GFICF_ST_TOO_DENSE = 8u; // Louvain: a vertex touches more co
 constexpr uint32_t GFICF_ST_EXPLICIT_ZERO = 16u; // gficf_csc_device met an explicitly stored zero (its fast count is then not exact)
 constexpr uint32_t GFICF_ST_DUP_IDS = 64u;       // Jaccard, rows taken to hold distinct ids (gficf_ctx_set_jaccard_distinct): the edge kernel met one that does not
 constexpr uint32_t GFICF_ST_SET_OVERFLOW = 128u;  // Jaccard, distinct-ids mode, general kernel: a row's ids overflowed its hash set beyond the list that is checked for repeats
+constexpr uint32_t GFICF_ST_NOT_GROUPED = 256u;  // adjacency: the edge list was promised grouped by source cell and is not
 constexpr uint32_t GFICF_ST_HALO_OVERFLOW = 32u; // sharded Jaccard, halo form: a block names more rows of one owner than the request slots hold
 
 constexpr int GFICF_POOL_SLOTS = 9;

@@ -257,6 +257,8 @@ int gficf_ctx_sync(gficf_ctx* ctx) {
   if (st & GFICF_ST_HALO_OVERFLOW)
     GFICF_FAIL(GFICF_ERR_CAPACITY, "sharded Jaccard, halo exchange: the block names more rows of one owner than the request slots hold "
                                    "(ids without locality): use the all-gather exchange for this input");
+  if (st & GFICF_ST_NOT_GROUPED)
+    GFICF_FAIL(GFICF_ERR_INVALID_ARG, "gficf_adjacency_device: the edge list was passed as grouped by source cell (grouped_by_source = 1) and is not");
   if (st & GFICF_ST_TOO_DENSE)
     GFICF_FAIL(GFICF_ERR_UNSUPPORTED, "Louvain: one hash class of a vertex's neighbouring communities overflowed the 8192-slot table");
   return GFICF_OK;

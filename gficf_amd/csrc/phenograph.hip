@@ -129,7 +129,7 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
     if (!rc) rc = gficf_jaccard_edges_filtered_device(ctx, (const int32_t*)d_table, N, k, 0, N, (uint16_t*)d_u, (int64_t*)d_cptr, from, from + cap,
                                                       from + 2 * cap);
   }
-  if (!rc) rc = gficf_adjacency_device(ctx, N, cap, (const int64_t*)d_cptr + N, from, from + cap, from + 2 * cap, d_aws, adj_ws,
+  if (!rc) rc = gficf_adjacency_device(ctx, N, cap, (const int64_t*)d_cptr + N, from, from + cap, from + 2 * cap, 1, d_aws, adj_ws,
                                        (int64_t*)d_indptr, (int32_t*)d_indices, (double*)d_ax);
   int64_t h_cnt[2] = {0, 0};                      // kept edges, adjacency entries
   if (!rc) {

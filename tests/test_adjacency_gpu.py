@@ -39,12 +39,15 @@ def test_random_edge_lists(N, E, seed):
     assert (abs(A - A.T)).nnz == 0
 
 
+@pytest.mark.parametrize("grouped", [False, True])
 @pytest.mark.parametrize("hub_degrees", [(129, 300), (4096, 4097), (5000, 20000), (60000,)])
-def test_rows_of_every_length_class(hub_degrees):
-    """Round 6: the matrix is built row by row, no device-wide sort — a wave orders a row of up to 128 entries by ranking, a workgroup one of up
-    to 4096 in LDS, longer ones in global scratch.  Hubs of every class next to ordinary rows, edges in random order (nothing grouped), and
-    REPEATED edges whose weights are NOT exactly summable: a run of one column is added up in emission order (what the stable sort of the
-    old path gave), so the sums must match a sequential addition in edge order bit for bit."""
+def test_rows_of_every_length_class(hub_degrees, grouped):
+    """Round 6: the matrix is built row by row — a wave merges the two halves of a row of up to 128 entries by ranking, a workgroup one of up
+    to 4096 in LDS, longer ones in global scratch; only the transposed half goes through a (stable, 32-bit) sort.  Hubs of every class next
+    to ordinary rows and REPEATED edges whose weights are NOT exactly summable: a run of one column is added up in emission order (what the
+    stable sort of the old path gave), so the sums must match a sequential addition in edge order bit for bit.  grouped = False: edges in
+    random order (the build finds out and orders them by source as well); True: the edges of one source lie together, the sources in random
+    order (what the edge kernel writes from renumbered cells) — the half that needs no ordering."""
     rng = np.random.default_rng(len(hub_degrees) * 1000 + hub_degrees[0])
     N = 70000
     f, t = [], []
@@ -59,6 +62,10 @@ def test_rows_of_every_length_class(hub_degrees):
     f, t = np.concatenate([f, f[rep], t[rep[:1500]]]), np.concatenate([t, t[rep], f[rep[:1500]]])
     perm = rng.permutation(len(f))
     f, t = f[perm], t[perm]
+    if grouped:
+        by_source = np.argsort(rng.permutation(N)[f], kind="stable")
+        f, t = f[by_source], t[by_source]
+        assert len(np.flatnonzero(np.diff(f))) + 1 == len(np.unique(f))   # one run per source
     w = rng.random(len(f)) * 0.9 + 0.05                                    # arbitrary doubles
     A = gficf_amd.jaccard_adjacency({"from": (f + 1).astype(np.float64), "to": (t + 1).astype(np.float64), "weight": w}, N)
     # the checker: entries (row, col, emission position) sorted, runs summed sequentially in that order
@@ -97,8 +104,10 @@ def test_clustcells_graph_to_adjacency():
     assert A[i, j] == W[i, j] * (2 if mutual else 1)
 
 
-def test_device_chain_with_device_side_edge_count():
-    """Filtered edge build -> adjacency without a host round trip: the edge count stays on the device."""
+@pytest.mark.parametrize("promise", [True, False])
+def test_device_chain_with_device_side_edge_count(promise):
+    """Filtered edge build -> adjacency without a host round trip: the edge count stays on the device (promise: the caller says that the
+    list is grouped by source, which the filtered build's is — no check, no synchronisation inside the call)."""
     import torch
 
     ops = gficf_amd.HipOps(0)
@@ -116,10 +125,36 @@ def test_device_chain_with_device_side_edge_count():
     indptr = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
     indices = torch.zeros(2 * cap, dtype=torch.int32, device="cuda")
     x = torch.zeros(2 * cap, dtype=torch.float64, device="cuda")
-    ops.adjacency(N, cap, cell_ptr[N:N + 1], out3, ws, indptr, indices, x)
+    ops.adjacency(N, cap, cell_ptr[N:N + 1], out3, ws, indptr, indices, x, grouped_by_source=promise)
     ops.sync()
     n = int(cell_ptr[N])
     f, t, w = (out3[r, :n].cpu().numpy() for r in range(3))
+    nnz = int(indptr[N])
+    A = sp.csc_matrix((x[:nnz].cpu().numpy(), indices[:nnz].cpu().numpy(), indptr.cpu().numpy()), shape=(N, N))
+    assert same(A, reference_adjacency(f, t, w, N))
+
+
+def test_a_broken_promise_is_reported_not_computed():
+    """grouped_by_source = 1 on a list that is not grouped: GFICF_ERR_INVALID_ARG at the next sync (and nothing written out of bounds: the
+    rows come out empty); the same buffers with the promise dropped give the matrix."""
+    import torch
+
+    ops = gficf_amd.HipOps(0)
+    N, E = 500, 6000
+    rng = np.random.default_rng(5)
+    f = rng.integers(1, N + 1, E).astype(np.float64); t = rng.integers(1, N + 1, E).astype(np.float64); w = rng.integers(1, 60, E) / 64.0
+    out3 = torch.from_numpy(np.stack([f, t, w])).cuda()
+    ws = torch.zeros(ops.adjacency_workspace_bytes(N, E), dtype=torch.uint8, device="cuda")
+    indptr = torch.zeros(N + 1, dtype=torch.int64, device="cuda")
+    indices = torch.zeros(2 * E, dtype=torch.int32, device="cuda")
+    x = torch.zeros(2 * E, dtype=torch.float64, device="cuda")
+    ops.adjacency(N, E, None, out3, ws, indptr, indices, x, grouped_by_source=True)
+    with pytest.raises(gficf_amd.GficfError) as ei:
+        ops.sync()
+    assert ei.value.status == "GFICF_ERR_INVALID_ARG" and "grouped" in str(ei.value)
+    assert int(indptr[N]) == 0
+    ops.adjacency(N, E, None, out3, ws, indptr, indices, x)
+    ops.sync()
     nnz = int(indptr[N])
     A = sp.csc_matrix((x[:nnz].cpu().numpy(), indices[:nnz].cpu().numpy(), indptr.cpu().numpy()), shape=(N, N))
     assert same(A, reference_adjacency(f, t, w, N))

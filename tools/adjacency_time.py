@@ -31,7 +31,7 @@ def run(N, k, reps=30):
         ops.jaccard_edges_filtered(table, N, k, 0, N, u_ws, cell_ptr, out3)
 
     def adj():
-        ops.adjacency(N, cap, cell_ptr[N:N + 1], out3, ws, indptr, indices, x)
+        ops.adjacency(N, cap, cell_ptr[N:N + 1], out3, ws, indptr, indices, x, grouped_by_source=True)
 
     def timed(fn):
         for _ in range(3):
