@@ -113,9 +113,10 @@ __global__ __launch_bounds__(256) void k_adj_bounds(const uint32_t* __restrict__
 // room of row r = its entries before equal columns are summed
 __global__ __launch_bounds__(256) void k_adj_caps(int64_t N, const int32_t* __restrict__ rbeg, const int32_t* __restrict__ rend,
                                                   const int32_t* __restrict__ tL, const uint32_t* __restrict__ broken,
-                                                  int64_t* __restrict__ start) {
+                                                  int64_t* __restrict__ start, int64_t* __restrict__ len2) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r > N) return;
+  if (r == N) len2[N] = 0;                                 // (the final lengths are scanned in place: N + 1 values)
   int64_t c = 0;
   if (r < N && !(broken && *broken)) {                     // (a list promised grouped that is not: its runs mean nothing — empty rows, the status says why)
     const int nw = rend[r] - rbeg[r];
@@ -323,9 +324,8 @@ size_t adj_carve(AdjWs* w, void* base, int64_t N, int64_t cap) {
   d.tkey = (uint32_t*)take(c * 4); d.te = (uint32_t*)take(c * 4);
   d.skey = (uint32_t*)take(c * 4); d.se = (uint32_t*)take(c * 4);
   d.pk = (AdjPk*)take(c * sizeof(AdjPk));
-  d.rbeg = (int32_t*)take(3 * n * 4); d.rend = d.rbeg + n; d.nruns = d.rend + n;       // one memset
+  d.rbeg = (int32_t*)take((3 * n + 2) * 4); d.rend = d.rbeg + n; d.nruns = d.rend + n; d.flag = (uint32_t*)(d.nruns + n);   // one memset
   d.tL = (int32_t*)take((n + 2) * 4); d.sL = (int32_t*)take((n + 2) * 4);
-  d.flag = (uint32_t*)take(256);
   d.start = (int64_t*)take((n + 1) * sizeof(int64_t));
   d.bcol = (int32_t*)take(m * sizeof(int32_t));
   d.bw = (double*)take(m * sizeof(double));
@@ -372,8 +372,7 @@ int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, con
   const int b = id_bits(N);
   const unsigned ge = (unsigned)gficf_ceil_div(edge_capacity, 256), gn = (unsigned)gficf_ceil_div(N + 1, 256);
   const unsigned gr = (unsigned)(gficf_ceil_div(N, 4) < 4096 ? gficf_ceil_div(N, 4) : 4096);
-  GFICF_HIP_CHECK(hipMemsetAsync(w.rbeg, 0, sizeof(int32_t) * 3 * (size_t)N, st));
-  GFICF_HIP_CHECK(hipMemsetAsync(w.flag, 0, 2 * sizeof(uint32_t), st));
+  GFICF_HIP_CHECK(hipMemsetAsync(w.rbeg, 0, sizeof(int32_t) * (3 * (size_t)N + 2), st));     // runs of the sources + the two flags behind them
   hipLaunchKernelGGL(k_adj_edges, dim3(ge), dim3(256), 0, st, d_from, d_to, d_weight, edge_capacity, d_n_edges, N, w.key_in, w.val_in, w.pk, w.rbeg,
                      w.rend, w.nruns, w.flag, grouped_by_source != 0 ? 1 : 0, ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
@@ -396,14 +395,13 @@ int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, con
     in.rbeg = w.sL; in.rend = w.sL + 1; in.se = w.se;
   }
   hipLaunchKernelGGL(k_adj_caps, dim3(gn), dim3(256), 0, st, N, in.rbeg, in.rend, (const int32_t*)w.tL, in.se ? (const uint32_t*)nullptr : (const uint32_t*)w.flag,
-                     w.start);
+                     w.start, d_indptr);
   GFICF_HIP_CHECK(hipGetLastError());
   int rc = gficf_exclusive_scan_i64(ctx, w.start, N + 1);
   if (rc) return rc;
   hipLaunchKernelGGL(k_adj_rows, dim3(gr), dim3(256), 0, st, in, N, (const int64_t*)w.start, w.bcol, w.bw, d_indptr, w.big, w.flag + 1);
   hipLaunchKernelGGL(k_adj_rows_big, dim3(64), dim3(256), ADJ_WG_ROW * 16, st, in, (const int64_t*)w.start, (const int32_t*)w.big,
                      (const unsigned*)(w.flag + 1), w.bcol, w.bw, d_indptr, w.gk, w.gw);
-  GFICF_HIP_CHECK(hipMemsetAsync(d_indptr + N, 0, sizeof(int64_t), st));
   rc = gficf_exclusive_scan_i64(ctx, d_indptr, N + 1);
   if (rc) return rc;
   hipLaunchKernelGGL(k_adj_compact, dim3(gr), dim3(256), 0, st, N, (const int64_t*)w.start, (const int64_t*)d_indptr, (const int32_t*)w.bcol,

@@ -13,8 +13,11 @@ rng = np.random.default_rng(1)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 54000
 X = rng.normal(size=(30, 50))[rng.integers(0, 30, N)] * 3.0 + rng.normal(size=(N, 50))
 ref = None
-for p in ("0", "1", "0", "1"):
-    os.environ["GFICF_KNN_PRUNE"] = p
+for p in (os.environ.get("PROBE_FORMS", "0,1,auto,0,1,auto").split(",")):
+    if p == "auto":
+        os.environ.pop("GFICF_KNN_PRUNE", None)
+    else:
+        os.environ["GFICF_KNN_PRUNE"] = p
     gficf_amd.find_nn(X, 31, metric="manhattan")
     t0 = time.perf_counter()
     r = gficf_amd.find_nn(X, 31, metric="manhattan")
