@@ -38,6 +38,7 @@ namespace {
 typedef unsigned long long u64;
 constexpr uint32_t ADJ_NONE = 0xFFFFFFFFu;
 constexpr int ADJ_WAVE_ROW = 128;            // entries a wave orders by ranking (two a lane)
+constexpr int ADJ_MID_ROW = 512;             // entries a wave of its own orders by ranking (eight a lane)
 constexpr int ADJ_WG_ROW = 4096;             // entries a workgroup orders in LDS
 
 struct AdjPk { uint32_t src; uint32_t pad; double w; };      // what the transposed half gathers per entry: one 16 B read
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256) void k_adj_edges(const double* __restrict__ fr
     const double f = from[e];                               // (the runs count every edge whose source is a cell, whatever its destination)
     if (f >= 1.0 && f <= (double)N && f == trunc(f)) {
       const int64_t s = (int64_t)f - 1;
+      if (e > 0 && from[e - 1] > f) not_grouped[1] = 1u;    // sources not ascending
       if (e == 0 || from[e - 1] != f) {
         rbeg[s] = (int32_t)e;
         if (atomicAdd(&nruns[s], 1) > 0) {
@@ -110,19 +112,30 @@ __global__ __launch_bounds__(256) void k_adj_bounds(const uint32_t* __restrict__
   L[r] = (int32_t)lo;
 }
 
-// room of row r = its entries before equal columns are summed
+// room of row r = its entries before equal columns are summed; rows too long for a wave of k_adj_rows are listed here (one device atomic
+// per workgroup and list: 10 % of the rows of a kNN graph of real data at k = 50 are, and an atomic per row on one address costs more than the build)
 __global__ __launch_bounds__(256) void k_adj_caps(int64_t N, const int32_t* __restrict__ rbeg, const int32_t* __restrict__ rend,
                                                   const int32_t* __restrict__ tL, const uint32_t* __restrict__ broken,
-                                                  int64_t* __restrict__ start, int64_t* __restrict__ len2) {
+                                                  int64_t* __restrict__ start, int64_t* __restrict__ len2, int32_t* __restrict__ mid,
+                                                  int32_t* __restrict__ big, unsigned* __restrict__ n_listed) {
+  __shared__ unsigned s_n[2], s_base[2];
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r > N) return;
-  if (r == N) len2[N] = 0;                                 // (the final lengths are scanned in place: N + 1 values)
+  if (threadIdx.x < 2) s_n[threadIdx.x] = 0u;
+  __syncthreads();
   int64_t c = 0;
   if (r < N && !(broken && *broken)) {                     // (a list promised grouped that is not: its runs mean nothing — empty rows, the status says why)
     const int nw = rend[r] - rbeg[r];
     c = (nw > 0 ? nw : 0) + (tL[r + 1] - tL[r]);
   }
-  start[r] = c;
+  if (r <= N) start[r] = c;
+  if (r == N) len2[N] = 0;                                 // (the final lengths are scanned in place: N + 1 values)
+  const int cls = c > ADJ_MID_ROW ? 1 : c > ADJ_WAVE_ROW ? 0 : -1;
+  unsigned my = 0;
+  if (cls >= 0) my = atomicAdd(&s_n[cls], 1u);
+  __syncthreads();
+  if (threadIdx.x < 2 && s_n[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&n_listed[threadIdx.x], s_n[threadIdx.x]);
+  __syncthreads();
+  if (cls >= 0) (cls ? big : mid)[s_base[cls] + my] = (int32_t)r;
 }
 
 struct AdjIn {
@@ -130,6 +143,7 @@ struct AdjIn {
   const int32_t* rbeg; const int32_t* rend;       // half W: positions [rbeg, rend) of row r — edge numbers, or positions in `se` when the list was sorted by source
   const uint32_t* se;                             // NULL: the list is grouped by source
   const int32_t* tL; const uint32_t* te;          // half W^T: positions [tL[r], tL[r + 1]) of the edge numbers ordered by destination
+  const uint32_t* unsorted;                       // device flag: some source is smaller than the one before it (half W^T then is not ordered by column)
 };
 
 __device__ inline u64 adj_key(uint32_t col, uint32_t pos) { return ((u64)col << 32) | pos; }
@@ -153,62 +167,120 @@ __device__ inline void adj_load(const AdjIn& I, int rb, int nw, int tb, int64_t 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 
-// One wave per row of at most ADJ_WAVE_ROW entries.  Every lane ranks its (up to two) entries against the whole row read from LDS
+// lower bound in a sorted run of distinct keys
+__device__ inline int adj_lower_bound(const u64* a, int n, u64 key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// One wave, one row of at most 64 * EPL entries (EPL a lane).  Every lane ranks its entries against the whole row read from LDS
 // (broadcast reads; the keys are distinct: the position is), writes them at their rank, then the heads of the runs of one column add
-// their run up in order and the row goes to the start of its room, compacted.  len2[row] = its final length.
+// their run up in order and the row goes to the start of its room, compacted.  Returns the row's final length.
+template <int EPL, bool MERGE>
+__device__ inline int adj_wave_row(const AdjIn& I, int64_t row, int64_t lo, int n, int lane, u64* key, u64* skey, double* sw,
+                                   int32_t* __restrict__ bcol, double* __restrict__ bw) {
+  const int rb = I.rbeg[row], tb = I.tL[row];
+  const int nw = n - (I.tL[row + 1] - tb);
+  const bool tsorted = MERGE && I.se == nullptr && *I.unsorted == 0u;
+  u64 k[EPL];
+  double w[EPL];
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    k[s] = ~0ull; w[s] = 0.0;
+    if (s * 64 + lane < n) adj_load(I, rb, nw, tb, s * 64 + lane, &k[s], &w[s]);
+    key[s * 64 + lane] = k[s];
+  }
+  ADJ_WAVE_SYNC();
+  int r[EPL];
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) r[s] = 0;
+  if (tsorted) {
+    // half W^T arrived ordered (ascending sources): an entry's rank = its rank inside its own half + the entries of the other half below it.
+    // Against half W (at most k entries, unordered): counted; against half W^T: its index there, or one binary search.
+    for (int t = 0; t < nw; ++t) {
+      const u64 kt = key[t];
+#pragma unroll
+      for (int s = 0; s < EPL; ++s) r[s] += kt < k[s] ? 1 : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+      const int t = s * 64 + lane;
+      if (t < nw) r[s] += adj_lower_bound(key + nw, n - nw, k[s]);
+      else r[s] += t - nw;
+    }
+  } else {
+    for (int t = 0; t < n; ++t) {
+      const u64 kt = key[t];
+#pragma unroll
+      for (int s = 0; s < EPL; ++s) r[s] += kt < k[s] ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < EPL; ++s)
+    if (s * 64 + lane < n) { skey[r[s]] = k[s]; sw[r[s]] = w[s]; }
+  ADJ_WAVE_SYNC();
+  // heads of the runs of one column, their output positions (ranks among the heads), their sums
+  int out[EPL];
+  int total = 0;
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    const int e = s * 64 + lane;
+    const bool head = e < n && (e == 0 || (skey[e] >> 32) != (skey[e - 1] >> 32));
+    const u64 m = __ballot(head);
+    out[s] = head ? total + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+    total += __popcll(m);
+  }
+#pragma unroll
+  for (int s = 0; s < EPL; ++s) {
+    const int e = s * 64 + lane;
+    if (out[s] < 0) continue;
+    const u64 c = skey[e] >> 32;
+    double sum = sw[e];
+    for (int t = e + 1; t < n && (skey[t] >> 32) == c; ++t) sum += sw[t];
+    bcol[lo + out[s]] = (int32_t)c; bw[lo + out[s]] = sum;
+  }
+  ADJ_WAVE_SYNC();                                            // (the next row's loads overwrite key / skey / sw)
+  return total;
+}
+
+// One wave per row of at most ADJ_WAVE_ROW entries; longer rows: up to ADJ_MID_ROW k_adj_rows_mid, beyond the workgroup kernel.
+// len2[row] = the row's final length.
 __global__ __launch_bounds__(256) void k_adj_rows(const AdjIn I, int64_t N, const int64_t* __restrict__ start, int32_t* __restrict__ bcol,
-                                                  double* __restrict__ bw, int64_t* __restrict__ len2, int32_t* __restrict__ big,
-                                                  unsigned* __restrict__ n_big) {
+                                                  double* __restrict__ bw, int64_t* __restrict__ len2) {
   __shared__ u64 s_key[4][ADJ_WAVE_ROW];
-  __shared__ double s_w[4][ADJ_WAVE_ROW];
   __shared__ u64 s_skey[4][ADJ_WAVE_ROW];
   __shared__ double s_sw[4][ADJ_WAVE_ROW];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  u64* key = s_key[wave]; double* wv = s_w[wave]; u64* skey = s_skey[wave]; double* sw = s_sw[wave];
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
     const int64_t lo = start[row];
-    const int n = (int)(start[row + 1] - lo);
-    if (n > ADJ_WAVE_ROW) {                                  // the workgroup kernel's
-      if (lane == 0) { big[atomicAdd(n_big, 1u)] = (int32_t)row; }
-      continue;
-    }
-    if (n == 0) { if (lane == 0) len2[row] = 0; continue; }
-    const int rb = I.rbeg[row], tb = I.tL[row];
-    const int nw = n - (I.tL[row + 1] - tb);
-    u64 k0 = ~0ull, k1 = ~0ull;
-    double w0 = 0.0, w1 = 0.0;
-    if (lane < n) adj_load(I, rb, nw, tb, lane, &k0, &w0);
-    if (lane + 64 < n) adj_load(I, rb, nw, tb, lane + 64, &k1, &w1);
-    key[lane] = k0; key[lane + 64] = k1;
-    ADJ_WAVE_SYNC();
-    int r0 = 0, r1 = 0;
-    for (int t = 0; t < n; ++t) { const u64 kt = key[t]; r0 += kt < k0 ? 1 : 0; r1 += kt < k1 ? 1 : 0; }
-    if (lane < n) { skey[r0] = k0; sw[r0] = w0; }
-    if (lane + 64 < n) { skey[r1] = k1; sw[r1] = w1; }
-    ADJ_WAVE_SYNC();
-    // heads of the runs of one column, their output positions (ranks among the heads), their sums
-    int out0 = -1, out1 = -1;
-    int total = 0;
-    for (int r = 0; r < 2; ++r) {
-      const int e = r * 64 + lane;
-      const bool head = e < n && (e == 0 || (skey[e] >> 32) != (skey[e - 1] >> 32));
-      const u64 m = __ballot(head);
-      const int at = total + __popcll(m & ((1ull << lane) - 1ull));
-      total += __popcll(m);
-      if (head) { if (r == 0) out0 = at; else out1 = at; }
-    }
-    for (int r = 0; r < 2; ++r) {
-      const int e = r * 64 + lane, at = r == 0 ? out0 : out1;
-      if (at < 0) continue;
-      const u64 c = skey[e] >> 32;
-      double sum = sw[e];
-      for (int t = e + 1; t < n && (skey[t] >> 32) == c; ++t) sum += sw[t];
-      key[at] = c; wv[at] = sum;                              // (the unsorted copy is no longer needed)
-    }
-    ADJ_WAVE_SYNC();
-    for (int t = lane; t < total; t += 64) { bcol[lo + t] = (int32_t)key[t]; bw[lo + t] = wv[t]; }
+    const int64_t n64 = start[row + 1] - lo;
+    if (n64 > ADJ_WAVE_ROW) continue;                        // listed by k_adj_caps for k_adj_rows_mid / k_adj_rows_big
+    const int n = (int)n64;
+    const int total = n > 0 ? adj_wave_row<ADJ_WAVE_ROW / 64, true>(I, row, lo, n, lane, s_key[wave], s_skey[wave], s_sw[wave], bcol, bw) : 0;
     if (lane == 0) len2[row] = total;
-    ADJ_WAVE_SYNC();
+  }
+}
+
+// One wave (a workgroup of its own: 12 KB of LDS) per listed row of ADJ_WAVE_ROW + 1 .. ADJ_MID_ROW entries — the tail of the in-degrees of
+// a kNN graph of real data (10 % of the rows at k = 50, 40 % at k = 100): the same ranking, eight entries a lane.
+__global__ __launch_bounds__(64) void k_adj_rows_mid(const AdjIn I, const int64_t* __restrict__ start, const int32_t* __restrict__ mid,
+                                                     const unsigned* __restrict__ n_listed, int32_t* __restrict__ bcol, double* __restrict__ bw,
+                                                     int64_t* __restrict__ len2) {
+  __shared__ u64 s_key[ADJ_MID_ROW];
+  __shared__ u64 s_skey[ADJ_MID_ROW];
+  __shared__ double s_sw[ADJ_MID_ROW];
+  const int lane = threadIdx.x;
+  for (unsigned item = blockIdx.x; item < n_listed[0]; item += gridDim.x) {
+    const int64_t row = mid[item], lo = start[row];
+    const int n = (int)(start[row + 1] - lo);
+    const int total = n <= 256 ? adj_wave_row<4, true>(I, row, lo, n, lane, s_key, s_skey, s_sw, bcol, bw)
+                               : adj_wave_row<ADJ_MID_ROW / 64, true>(I, row, lo, n, lane, s_key, s_skey, s_sw, bcol, bw);
+    if (lane == 0) len2[row] = total;
   }
 }
 
@@ -226,8 +298,12 @@ __device__ inline void adj_bitonic(u64* k, double* w, int64_t n2, int tid, int n
     }
 }
 
-// One workgroup per listed row (more than ADJ_WAVE_ROW entries): up to ADJ_WG_ROW entries ordered in LDS; longer rows in the scratch
-// arrays gk / gw (global memory; a row of that length is a hub of a degenerate graph: correct, not fast).
+// One workgroup per listed row (more than ADJ_WAVE_ROW entries; at k = 50 a kNN graph of real data has thousands: in-degrees have a tail).
+// Sources in ascending order (what the edge build writes unless the cells were renumbered): the transposed half arrives ordered by
+// column already — the stable sort kept the emission order —, so only half W (at most k entries) is ordered, by a bitonic network in LDS,
+// and the two halves are MERGED: every entry finds its place by one binary search in the other half.  Otherwise, or beyond what LDS
+// holds that way: the whole row through the bitonic network (LDS up to ADJ_WG_ROW entries, global scratch gk / gw beyond — a row of that
+// length is a hub of a degenerate graph: correct, not fast).
 __global__ __launch_bounds__(256) void k_adj_rows_big(const AdjIn I, const int64_t* __restrict__ start, const int32_t* __restrict__ big,
                                                       const unsigned* __restrict__ n_big, int32_t* __restrict__ bcol, double* __restrict__ bw,
                                                       int64_t* __restrict__ len2, u64* __restrict__ gk, double* __restrict__ gw) {
@@ -237,22 +313,44 @@ __global__ __launch_bounds__(256) void k_adj_rows_big(const AdjIn I, const int64
   __shared__ int s_total;
   __shared__ int s_cnt[256];
   const int tid = threadIdx.x;
+  const bool merge_ok = I.se == nullptr && *I.unsorted == 0u;
   for (unsigned item = blockIdx.x; item < *n_big; item += gridDim.x) {
     const int64_t row = big[item], lo = start[row], n = start[row + 1] - lo;
     const int rb = I.rbeg[row], tb = I.tL[row];
     const int nw = (int)(n - (I.tL[row + 1] - tb));
-    int64_t n2 = 1;
-    while (n2 < n) n2 <<= 1;
-    // a row too long for LDS is ordered in global scratch: n2 < 2 n entries at twice its room's start (the scratch arrays are twice the rooms)
-    u64* k = n2 <= ADJ_WG_ROW ? sk : gk + 2 * lo;
-    double* w = n2 <= ADJ_WG_ROW ? sw : gw + 2 * lo;
-    for (int64_t t = tid; t < n2; t += 256) {
-      u64 kk = ~0ull; double ww = 0.0;
-      if (t < n) adj_load(I, rb, nw, tb, t, &kk, &ww);
-      k[t] = kk; w[t] = ww;
+    u64* k;
+    double* w;
+    int64_t nw2 = 1;
+    while (nw2 < nw) nw2 <<= 1;
+    if (merge_ok && nw2 + (n - nw) + n <= ADJ_WG_ROW) {
+      const int nt = (int)(n - nw);
+      u64* const tk = sk + nw2; double* const tw = sw + nw2;       // LDS: [half W, padded to nw2][half W^T][the merged row]
+      for (int t = tid; t < (int)nw2; t += 256) {
+        u64 kk = ~0ull; double ww = 0.0;
+        if (t < nw) adj_load(I, rb, nw, tb, t, &kk, &ww);
+        sk[t] = kk; sw[t] = ww;
+      }
+      for (int t = tid; t < nt; t += 256) adj_load(I, rb, nw, tb, nw + t, &tk[t], &tw[t]);
+      __syncthreads();
+      adj_bitonic(sk, sw, nw2, tid, 256);
+      k = tk + nt; w = tw + nt;
+      for (int t = tid; t < nt; t += 256) { const int at = t + adj_lower_bound(sk, nw, tk[t]); k[at] = tk[t]; w[at] = tw[t]; }
+      for (int t = tid; t < nw; t += 256) { const int at = t + adj_lower_bound(tk, nt, sk[t]); k[at] = sk[t]; w[at] = sw[t]; }
+      __syncthreads();
+    } else {
+      int64_t n2 = 1;
+      while (n2 < n) n2 <<= 1;
+      // a row too long for LDS is ordered in global scratch: n2 < 2 n entries at twice its room's start (the scratch arrays are twice the rooms)
+      k = n2 <= ADJ_WG_ROW ? sk : gk + 2 * lo;
+      w = n2 <= ADJ_WG_ROW ? sw : gw + 2 * lo;
+      for (int64_t t = tid; t < n2; t += 256) {
+        u64 kk = ~0ull; double ww = 0.0;
+        if (t < n) adj_load(I, rb, nw, tb, t, &kk, &ww);
+        k[t] = kk; w[t] = ww;
+      }
+      __syncthreads();
+      adj_bitonic(k, w, n2, tid, 256);
     }
-    __syncthreads();
-    adj_bitonic(k, w, n2, tid, 256);
     if (tid == 0) s_total = 0;
     __syncthreads();
     // the heads of the runs of one column: every thread takes a contiguous slice, the slices' bases by a serial pass over 256 counts
@@ -307,10 +405,10 @@ struct AdjWs {
   AdjPk* pk;                                            // cap
   int32_t *rbeg, *rend, *nruns;                         // N
   int32_t *tL, *sL;                                     // N + 2
-  uint32_t* flag;                                       // not_grouped, n_big
+  uint32_t* flag;                                       // not_grouped, sources not ascending, rows listed as mid, as big
   int64_t* start;                                       // N + 1: start of every row's room
   int32_t* bcol; double* bw;                            // 2 cap each: the rooms
-  int32_t* big;                                         // N
+  int32_t *mid, *big;                                   // N each: the listed rows
   u64* gk; double* gw;                                  // 4 cap each: scratch of rows too long for LDS
   void* tmp; size_t tmp_bytes;
 };
@@ -324,11 +422,12 @@ size_t adj_carve(AdjWs* w, void* base, int64_t N, int64_t cap) {
   d.tkey = (uint32_t*)take(c * 4); d.te = (uint32_t*)take(c * 4);
   d.skey = (uint32_t*)take(c * 4); d.se = (uint32_t*)take(c * 4);
   d.pk = (AdjPk*)take(c * sizeof(AdjPk));
-  d.rbeg = (int32_t*)take((3 * n + 2) * 4); d.rend = d.rbeg + n; d.nruns = d.rend + n; d.flag = (uint32_t*)(d.nruns + n);   // one memset
+  d.rbeg = (int32_t*)take((3 * n + 4) * 4); d.rend = d.rbeg + n; d.nruns = d.rend + n; d.flag = (uint32_t*)(d.nruns + n);   // one memset
   d.tL = (int32_t*)take((n + 2) * 4); d.sL = (int32_t*)take((n + 2) * 4);
   d.start = (int64_t*)take((n + 1) * sizeof(int64_t));
   d.bcol = (int32_t*)take(m * sizeof(int32_t));
   d.bw = (double*)take(m * sizeof(double));
+  d.mid = (int32_t*)take(n * sizeof(int32_t));
   d.big = (int32_t*)take(n * sizeof(int32_t));
   d.gk = (u64*)take(2 * m * sizeof(u64));
   d.gw = (double*)take(2 * m * sizeof(double));
@@ -372,14 +471,14 @@ int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, con
   const int b = id_bits(N);
   const unsigned ge = (unsigned)gficf_ceil_div(edge_capacity, 256), gn = (unsigned)gficf_ceil_div(N + 1, 256);
   const unsigned gr = (unsigned)(gficf_ceil_div(N, 4) < 4096 ? gficf_ceil_div(N, 4) : 4096);
-  GFICF_HIP_CHECK(hipMemsetAsync(w.rbeg, 0, sizeof(int32_t) * (3 * (size_t)N + 2), st));     // runs of the sources + the two flags behind them
+  GFICF_HIP_CHECK(hipMemsetAsync(w.rbeg, 0, sizeof(int32_t) * (3 * (size_t)N + 4), st));     // runs of the sources + the three flags behind them
   hipLaunchKernelGGL(k_adj_edges, dim3(ge), dim3(256), 0, st, d_from, d_to, d_weight, edge_capacity, d_n_edges, N, w.key_in, w.val_in, w.pk, w.rbeg,
                      w.rend, w.nruns, w.flag, grouped_by_source != 0 ? 1 : 0, ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
   GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.tmp, w.tmp_bytes, w.key_in, w.tkey, w.val_in, w.te, (size_t)edge_capacity, 0u, (unsigned)b, st));
   hipLaunchKernelGGL(k_adj_bounds, dim3(gn), dim3(256), 0, st, (const uint32_t*)w.tkey, edge_capacity, N, w.tL);
   AdjIn in;
-  in.to = d_to; in.w = d_weight; in.pk = w.pk; in.rbeg = w.rbeg; in.rend = w.rend; in.se = nullptr; in.tL = w.tL; in.te = w.te;
+  in.to = d_to; in.w = d_weight; in.pk = w.pk; in.rbeg = w.rbeg; in.rend = w.rend; in.se = nullptr; in.tL = w.tL; in.te = w.te; in.unsorted = w.flag + 1;
   bool grouped = grouped_by_source != 0;
   if (!grouped) {                                   // the caller does not know: ask the pass that just looked at every edge
     uint32_t ng = 0;
@@ -395,13 +494,15 @@ int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, con
     in.rbeg = w.sL; in.rend = w.sL + 1; in.se = w.se;
   }
   hipLaunchKernelGGL(k_adj_caps, dim3(gn), dim3(256), 0, st, N, in.rbeg, in.rend, (const int32_t*)w.tL, in.se ? (const uint32_t*)nullptr : (const uint32_t*)w.flag,
-                     w.start, d_indptr);
+                     w.start, d_indptr, w.mid, w.big, w.flag + 2);
   GFICF_HIP_CHECK(hipGetLastError());
   int rc = gficf_exclusive_scan_i64(ctx, w.start, N + 1);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_adj_rows, dim3(gr), dim3(256), 0, st, in, N, (const int64_t*)w.start, w.bcol, w.bw, d_indptr, w.big, w.flag + 1);
-  hipLaunchKernelGGL(k_adj_rows_big, dim3(64), dim3(256), ADJ_WG_ROW * 16, st, in, (const int64_t*)w.start, (const int32_t*)w.big,
-                     (const unsigned*)(w.flag + 1), w.bcol, w.bw, d_indptr, w.gk, w.gw);
+  hipLaunchKernelGGL(k_adj_rows, dim3(gr), dim3(256), 0, st, in, N, (const int64_t*)w.start, w.bcol, w.bw, d_indptr);
+  hipLaunchKernelGGL(k_adj_rows_mid, dim3(4096), dim3(64), 0, st, in, (const int64_t*)w.start, (const int32_t*)w.mid, (const unsigned*)(w.flag + 2),
+                     w.bcol, w.bw, d_indptr);
+  hipLaunchKernelGGL(k_adj_rows_big, dim3(1024), dim3(256), ADJ_WG_ROW * 16, st, in, (const int64_t*)w.start, (const int32_t*)w.big,
+                     (const unsigned*)(w.flag + 3), w.bcol, w.bw, d_indptr, w.gk, w.gw);
   rc = gficf_exclusive_scan_i64(ctx, d_indptr, N + 1);
   if (rc) return rc;
   hipLaunchKernelGGL(k_adj_compact, dim3(gr), dim3(256), 0, st, N, (const int64_t*)w.start, (const int64_t*)d_indptr, (const int32_t*)w.bcol,

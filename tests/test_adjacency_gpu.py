@@ -39,15 +39,16 @@ def test_random_edge_lists(N, E, seed):
     assert (abs(A - A.T)).nnz == 0
 
 
-@pytest.mark.parametrize("grouped", [False, True])
+@pytest.mark.parametrize("grouped", [False, "any order", "ascending"])
 @pytest.mark.parametrize("hub_degrees", [(129, 300), (4096, 4097), (5000, 20000), (60000,)])
 def test_rows_of_every_length_class(hub_degrees, grouped):
     """Round 6: the matrix is built row by row — a wave merges the two halves of a row of up to 128 entries by ranking, a workgroup one of up
     to 4096 in LDS, longer ones in global scratch; only the transposed half goes through a (stable, 32-bit) sort.  Hubs of every class next
     to ordinary rows and REPEATED edges whose weights are NOT exactly summable: a run of one column is added up in emission order (what the
     stable sort of the old path gave), so the sums must match a sequential addition in edge order bit for bit.  grouped = False: edges in
-    random order (the build finds out and orders them by source as well); True: the edges of one source lie together, the sources in random
-    order (what the edge kernel writes from renumbered cells) — the half that needs no ordering."""
+    random order (the build finds out and orders them by source as well); "any order": the edges of one source lie together, the sources in
+    random order (what the edge kernel writes from renumbered cells) — half W needs no ordering; "ascending": the sources ascend as well (what
+    the edge kernel writes otherwise) — the long rows are then MERGED from their two halves instead of ordered whole."""
     rng = np.random.default_rng(len(hub_degrees) * 1000 + hub_degrees[0])
     N = 70000
     f, t = [], []
@@ -63,7 +64,7 @@ def test_rows_of_every_length_class(hub_degrees, grouped):
     perm = rng.permutation(len(f))
     f, t = f[perm], t[perm]
     if grouped:
-        by_source = np.argsort(rng.permutation(N)[f], kind="stable")
+        by_source = np.argsort(rng.permutation(N)[f] if grouped == "any order" else f, kind="stable")
         f, t = f[by_source], t[by_source]
         assert len(np.flatnonzero(np.diff(f))) + 1 == len(np.unique(f))   # one run per source
     w = rng.random(len(f)) * 0.9 + 0.05                                    # arbitrary doubles

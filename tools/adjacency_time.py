@@ -1,5 +1,6 @@
 """Device-resident time of the graph hand-off at N cells x k neighbours: Jaccard ingest + filtered edges, then the adjacency build alone.
-Usage: python tools/adjacency_time.py [N k] ..."""
+Usage: python tools/adjacency_time.py [N k] ...      ADJ_GRAPH=blobs: the kNN matrix of a real search (30 Gaussian blobs in 50 dimensions,
+manhattan — the config-3 stand-in) instead of the windowed synthetic one: in-degrees with a tail, rows of the matrix up to several hundred."""
 import os
 import sys
 import time
@@ -14,7 +15,13 @@ from gficf_amd import synth
 
 def run(N, k, reps=30):
     ops = gficf_amd.HipOps(0)
-    mat = synth.knn_windowed(N, k, seed=42, perm_seed=43)
+    kind = os.environ.get("ADJ_GRAPH", "windowed")
+    if kind == "blobs":
+        rng = np.random.default_rng(1)
+        X = rng.normal(size=(30, 50))[rng.integers(0, 30, N)] * 3.0 + rng.normal(size=(N, 50))
+        mat = gficf_amd.find_nn(X, k + 1, metric="manhattan")["idx"][:, 1:].astype(np.int32)
+    else:
+        mat = synth.knn_windowed(N, k, seed=42, perm_seed=43)
     idx = torch.from_numpy(np.ascontiguousarray(mat.T)).cuda()
     table = torch.empty((N, ops.kpad(k)), dtype=torch.int32, device="cuda")
     cap = N * k
@@ -46,7 +53,8 @@ def run(N, k, reps=30):
 
     te = timed(edges)
     ta = timed(adj)
-    print(f"N={N} k={k}: ingest + filtered edges {te:.3f} ms, adjacency {ta:.3f} ms, together {te + ta:.3f} ms ({int(cell_ptr[N])} edges kept, {int(indptr[N])} entries, "
+    deg = (indptr[1:] - indptr[:-1])
+    print(f"N={N} k={k} ({kind}; longest row {int(deg.max())}, {int((deg > 128).sum())} rows above 128 entries): ingest + filtered edges {te:.3f} ms, adjacency {ta:.3f} ms, together {te + ta:.3f} ms ({int(cell_ptr[N])} edges kept, {int(indptr[N])} entries, "
           f"workspace {ws.numel() / 1e6:.0f} MB)", flush=True)
 
 
