@@ -180,26 +180,30 @@ __global__ __launch_bounds__(256) void k_lv_fix(int64_t N, int64_t nnz, const in
   }
 }
 
+// vertex weights (the row sums without the diagonal) and 2W: a wave per vertex, the row read by consecutive lanes; one atomic per workgroup
 __global__ __launch_bounds__(256) void k_lv_vertex_weight(int64_t n, int64_t m, const int64_t* __restrict__ ptr, const int32_t* __restrict__ nbr,
                                                          const u64* __restrict__ wt, u64* __restrict__ kv, u64* __restrict__ two_w,
                                                          uint32_t* __restrict__ status) {
-  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  u64 s = 0;
-  if (v < n) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u64 total = 0;                                       // lane 0: the sum over this wave's vertices
+  for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < n; v += (int64_t)gridDim.x * 4) {
     int64_t lo = ptr[v], hi = ptr[v + 1];
-    if (lo < 0 || hi < lo || hi > m) { atomicOr(status, GFICF_ST_BAD_CSC); lo = hi = 0; }
-    for (int64_t e = lo; e < hi; ++e) {
+    if (lo < 0 || hi < lo || hi > m) { if (lane == 0) atomicOr(status, GFICF_ST_BAD_CSC); lo = hi = 0; }
+    u64 s = 0;
+    for (int64_t e = lo + lane; e < hi; e += 64) {
       const int32_t u = nbr[e];
       if (u != v && u >= 0 && u < n) s += wt[e];
     }
-    kv[v] = s;
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+    if (lane == 0) { kv[v] = s; total += s; }
   }
-  // block sum -> one atomic
   __shared__ u64 s_sum[4];
-  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
-  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = s;
+  if (lane == 0) s_sum[wave] = total;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(two_w, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+  if (threadIdx.x == 0) {
+    const u64 t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    if (t) atomicAdd(two_w, t);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_lv_fill_u64(int64_t n, u64 v, u64* __restrict__ out) {
@@ -1472,7 +1476,7 @@ int gficf_louvain_device(gficf_ctx* ctx, int64_t N, const int64_t* d_indptr, con
   GFICF_HIP_CHECK(hipMemsetAsync(w.scalars, 0, 8 * sizeof(u64), st));
   GFICF_HIP_CHECK(hipMemsetAsync(w.ctl, 0, sizeof(LvCtl), st));
   if (nnz > 0) hipLaunchKernelGGL(k_lv_fix, dim3(lv_blocks(nnz, 256) < 2048u ? lv_blocks(nnz, 256) : 2048u), dim3(256), 0, st, N, nnz, d_indices, d_x, w.wt0, w.scalars + 5, ctx->d_status);
-  hipLaunchKernelGGL(k_lv_vertex_weight, dim3(lv_blocks(N, 256)), dim3(256), 0, st, N, nnz, d_indptr, d_indices, w.wt0, w.kv0, w.scalars, ctx->d_status);
+  hipLaunchKernelGGL(k_lv_vertex_weight, dim3(lv_blocks(N, 4) < 2048u ? lv_blocks(N, 4) : 2048u), dim3(256), 0, st, N, nnz, d_indptr, d_indices, w.wt0, w.kv0, w.scalars, ctx->d_status);
   u64 h_sc[6] = {0, 0, 0, 0, 0, 0};
   GFICF_HIP_CHECK(hipMemcpyAsync(h_sc, w.scalars, sizeof(h_sc), hipMemcpyDeviceToHost, st));
   rc = gficf_ctx_sync(ctx);                        // also reports a malformed matrix before anything follows it

@@ -7,6 +7,10 @@
 // as the chain gficf_knn_* -> gficf_jaccard_ingest/edges_filtered -> gficf_adjacency -> gficf_louvain on device buffers:
 // one upload of the N x d point matrix, one download of N labels.  Every stage keeps its own contract (exact search in
 // place of Annoy, bit-exact Jaccard edges, relaxed contract of the Louvain stage: see include/gficf_hip.h).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -104,13 +108,25 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
       cv.base = (char*)blk;
     }
   }
+  // GFICF_PHENOGRAPH_DEBUG=1: the stages timed on the host, each behind a stream synchronisation of its own (lab; stderr)
+  const bool dbg = getenv("GFICF_PHENOGRAPH_DEBUG") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!dbg) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[gficf_phenograph_host] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   hipError_t e = hipMemcpyAsync(d_X, X, sizeof(double) * (size_t)ld * (size_t)d, hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) GFICF_FAIL(GFICF_ERR_HIP, "HIP failure in gficf_phenograph_host: %s", hipGetErrorString(e));
+  mark("upload of the points");
 
   // neighbours (column 0 = the cell itself is dropped by starting at column 1), edges with weight > 0, adjacency matrix
   double* from = (double*)d_e3;
   int rc = gficf_knn_prepare_device(ctx, d_X, 1, N, d, ld, metric, (float*)d_P);
   if (!rc) rc = gficf_knn_search_device(ctx, (const float*)d_P, N, d, kk, metric, 0, N, d_kws, knn_ws, (int32_t*)d_idx, nullptr, N);
+  mark("neighbour search");
   if (!rc && ordered) {
     rc = gficf_knn_pivot_order_device(ctx, (const float*)d_P, N, d, metric, d_kws, knn_ws > order_ws ? knn_ws : order_ws, (int32_t*)d_order);
     if (!rc) {
@@ -129,8 +145,10 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
     if (!rc) rc = gficf_jaccard_edges_filtered_device(ctx, (const int32_t*)d_table, N, k, 0, N, (uint16_t*)d_u, (int64_t*)d_cptr, from, from + cap,
                                                       from + 2 * cap);
   }
+  mark("Jaccard edges (filtered)");
   if (!rc) rc = gficf_adjacency_device(ctx, N, cap, (const int64_t*)d_cptr + N, from, from + cap, from + 2 * cap, 1, d_aws, adj_ws,
                                        (int64_t*)d_indptr, (int32_t*)d_indices, (double*)d_ax);
+  mark("adjacency matrix");
   int64_t h_cnt[2] = {0, 0};                      // kept edges, adjacency entries
   if (!rc) {
     GFICF_HIP_CHECK(hipMemcpyAsync(&h_cnt[0], (const int64_t*)d_cptr + N, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -150,6 +168,9 @@ extern "C" int gficf_phenograph_host(gficf_ctx* ctx, const double* X, int64_t N,
   rc = gficf_louvain_device(ctx, N, (const int64_t*)d_indptr, (const int32_t*)d_indices, (const double*)d_ax, h_cnt[1], resolution, algorithm,
                             n_start, n_iter, seed, (int32_t*)d_lab, n_clusters, modularity, d_lws, lws);
   if (rc) return rc;
+  mark("communities");
   GFICF_HIP_CHECK(hipMemcpyAsync(labels, d_lab, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
-  return gficf_ctx_sync(ctx);
+  rc = gficf_ctx_sync(ctx);
+  mark("labels to the host");
+  return rc;
 }
