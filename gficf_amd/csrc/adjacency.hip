@@ -12,15 +12,16 @@
 //
 // Device path (round 6, second form).  Row r of A = the edges r -> * (half W) and the edges * -> r (half W^T).  The edge kernel emits
 // W grouped by source cell, so half W needs no ordering at all: the run of every source is found where it lies.  Only the transposed
-// half is ordered, and only by its row: ONE stable radix sort of E 32-bit keys (the destination, b = bits of N: 17 at 100 k cells, three
-// 8-bit passes) carrying the edge number — through round 5 the build sorted 2 E 64-bit keys row << 32 | col over seven passes, in this
-// round's first form over five.  A wave then merges the two halves of a row: ranks its <= 128 entries by (column, emission position) in
-// LDS, sums the runs of one column in that order (the order the full stable sort gave) and writes the row; longer rows take a
-// workgroup.  The sort is still rocPRIM's (a plain library sort over 1/13 of the bytes it moved before).
-//   1. k_adj_edges    validate, key = destination, value = e, (source, weight) packed for the gather of step 4, run of every source
-//   2. radix sort     E keys of b bits, stable: within one destination the edges stay in emission order
-//   3. k_adj_bounds   first sorted position of every destination (binary search), k_adj_caps + scan: room of every row
-//   4. k_adj_rows(_big)  the merge above, rows written compacted at the start of their room
+// half is ordered, and only by its row: ONE stable radix sort of E 8-byte elements (destination << 32 | edge number; b = bits of N
+// significant: 17 at 100 k cells, two passes of 9 and 8 bits) — through round 5 the build sorted 2 E 64-bit keys row << 32 | col with
+// rocPRIM over seven passes, in this round's first form over five.  The passes are this file's own (k_rs_hist / k_rs_scatter: no library
+// call is left in the build).  A wave then merges the two halves of a row: ranks its <= 128 entries by (column, emission position) in
+// LDS, sums the runs of one column in that order (the order the full stable sort gave) and writes the row; longer rows take a wave of
+// their own (<= 512 entries) or a workgroup.
+//   1. k_adj_edges    validate, element = destination << 32 | e, (source, weight) packed for the gather of step 4, run of every source
+//   2. radix passes   E elements over b bits, stable: within one destination the edges stay in emission order
+//   3. k_adj_bounds   first sorted position of every destination (binary search), k_adj_caps + scan: room of every row, long rows listed
+//   4. k_adj_rows(_mid, _big)  the merge above, rows written compacted at the start of their room
 //   5. scan of the final lengths -> indptr, k_adj_compact: rows to their final place
 // An edge list that is NOT grouped by source (any caller-made list is allowed) takes one more sort of the same kind, by source.
 // Round 6's first attempt without any sort (row buckets filled by atomics) was slower: a device-scope atomic per edge for the
@@ -28,8 +29,6 @@
 #include <atomic>
 #include <cstring>
 #include <vector>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
 
@@ -53,8 +52,8 @@ __device__ inline bool adj_edge(const double* __restrict__ from, const double* _
 // One thread per edge slot.  tkey = destination (ADJ_NONE: slot unused, bad ids, or a self edge — counted once, in half W), tval = e.
 // The run of every source: its head writes rbeg, its tail rend; a source with two heads means the list is not grouped (*not_grouped).
 __global__ __launch_bounds__(256) void k_adj_edges(const double* __restrict__ from, const double* __restrict__ to, const double* __restrict__ w,
-                                                   int64_t cap, const int64_t* __restrict__ n_edges_p, int64_t N, uint32_t* __restrict__ tkey,
-                                                   uint32_t* __restrict__ tval, AdjPk* __restrict__ pk, int32_t* __restrict__ rbeg,
+                                                   int64_t cap, const int64_t* __restrict__ n_edges_p, int64_t N, u64* __restrict__ tkv,
+                                                   AdjPk* __restrict__ pk, int32_t* __restrict__ rbeg,
                                                    int32_t* __restrict__ rend, int32_t* __restrict__ nruns, uint32_t* __restrict__ not_grouped,
                                                    int promised, uint32_t* __restrict__ status) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -84,19 +83,152 @@ __global__ __launch_bounds__(256) void k_adj_edges(const double* __restrict__ fr
       if (e == n_edges - 1 || from[e + 1] != f) rend[s] = (int32_t)(e + 1);
     }
   }
-  tkey[e] = kt; tval[e] = (uint32_t)e;
+  tkv[e] = ((u64)kt << 32) | (u64)e;                       // key above, edge number below: one 8 B element through the sort
 }
 
 // the list is not grouped: key = source for the second sort
 __global__ __launch_bounds__(256) void k_adj_source_keys(const double* __restrict__ from, const double* __restrict__ to, int64_t cap,
-                                                         const int64_t* __restrict__ n_edges_p, int64_t N, uint32_t* __restrict__ skey,
-                                                         uint32_t* __restrict__ sval) {
+                                                         const int64_t* __restrict__ n_edges_p, int64_t N, u64* __restrict__ skv) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= cap) return;
   const int64_t n_edges = n_edges_p ? (*n_edges_p < cap ? *n_edges_p : cap) : cap;
   int64_t i, j;
-  skey[e] = (e < n_edges && adj_edge(from, to, e, N, &i, &j)) ? (uint32_t)i : ADJ_NONE;
-  sval[e] = (uint32_t)e;
+  skv[e] = ((u64)((e < n_edges && adj_edge(from, to, e, N, &i, &j)) ? (uint32_t)i : ADJ_NONE) << 32) | (u64)e;
+}
+
+#define ADJ_WAVE_SYNC()                                                                                                                   \
+  do {                                                                                                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+// ---- the sort: stable partition passes over (key << 32 | edge number), least significant digit first (round 6: rocPRIM's onesweep took
+// three 8-bit passes for the 17 bits of 100 k cells; digits of up to 10 bits make it two).  A pass = per-workgroup digit counts
+// (k_rs_hist) -> one scan of the [digit][workgroup] matrix -> k_rs_scatter.  Stable by construction: a workgroup owns RS_TILE consecutive
+// elements, its wave w the w-th quarter, a wave walks its quarter 64 consecutive elements at a time; an element's place = the scanned
+// count of its (digit, workgroup) + the earlier waves' elements of that digit + the wave's own earlier ones + the lower lanes' in its round.
+constexpr int RS_TILE = 4096;
+constexpr int RS_MAX_BITS = 10;
+constexpr int RS_MAX_WGS = 1024;          // workgroups of a pass (each walks ceil(tiles / RS_MAX_WGS) tiles): bounds the count matrix
+
+__device__ inline unsigned rs_digit(u64 el, int shift, unsigned mask) { return (unsigned)(el >> (32 + shift)) & mask; }
+
+__global__ __launch_bounds__(256) void k_rs_hist(const u64* __restrict__ in, int64_t M, int shift, int bits, int64_t tiles_per_wg,
+                                                 int64_t* __restrict__ hist) {
+  __shared__ unsigned cnt[1 << RS_MAX_BITS];
+  const unsigned nb = 1u << bits, mask = nb - 1u;
+  for (unsigned d = threadIdx.x; d < nb; d += 256) cnt[d] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * tiles_per_wg * RS_TILE;
+  int64_t end = base + tiles_per_wg * RS_TILE;
+  if (end > M) end = M;
+  for (int64_t i0 = base + threadIdx.x; i0 < end; i0 += 256 * 8) {      // eight loads in flight
+    u64 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int64_t i = i0 + 256 * j; v[j] = in[i < end ? i : end - 1]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (i0 + 256 * j < end) atomicAdd(&cnt[rs_digit(v[j], shift, mask)], 1u);
+  }
+  __syncthreads();
+  for (unsigned d = threadIdx.x; d < nb; d += 256) hist[(int64_t)d * gridDim.x + blockIdx.x] = (int64_t)cnt[d];
+}
+
+// LAST: the pass writes the key and the edge number apart (what the row kernels read); otherwise the element as it is.
+// A workgroup walks its tiles in order and carries every digit's next place in the output along (in the registers of the digit's
+// thread).  A tile is put in order in LDS first and written out from there: consecutive threads then write consecutive places of one
+// digit's run (a wave's store touches ~8 runs instead of ~50 scattered places).
+template <bool LAST>
+__global__ __launch_bounds__(256) void k_rs_scatter(const u64* __restrict__ in, int64_t M, int shift, int bits, int64_t tiles_per_wg,
+                                                    const int64_t* __restrict__ hist, u64* __restrict__ out, uint32_t* __restrict__ okey,
+                                                    uint32_t* __restrict__ oval) {
+  __shared__ unsigned cnt[4][1 << RS_MAX_BITS];                // counts of (wave, digit), then the wave's next place inside the tile
+  __shared__ unsigned delta[1 << RS_MAX_BITS];                 // a digit's first place inside the tile, then (its place in the output) - that
+  __shared__ u64 stage[RS_TILE];
+  const unsigned nb = 1u << bits, mask = nb - 1u;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned gpos[(1 << RS_MAX_BITS) / 256];                     // next output place of digit threadIdx.x + 256 j
+#pragma unroll
+  for (unsigned j = 0; j < (1u << RS_MAX_BITS) / 256u; ++j) {
+    const unsigned d = threadIdx.x + 256u * j;
+    gpos[j] = d < nb ? (unsigned)hist[(int64_t)d * gridDim.x + blockIdx.x] : 0u;
+  }
+  const int64_t first_tile = (int64_t)blockIdx.x * tiles_per_wg;
+  for (int64_t tile = first_tile; tile < first_tile + tiles_per_wg && tile * RS_TILE < M; ++tile) {
+    for (unsigned d = threadIdx.x; d < 4u * (1u << RS_MAX_BITS); d += 256) (&cnt[0][0])[d] = 0u;
+    __syncthreads();
+    const int64_t tbase = tile * RS_TILE, wbase = tbase + (int64_t)wave * (RS_TILE / 4);
+    u64 el[RS_TILE / 256];
+#pragma unroll
+    for (int r = 0; r < RS_TILE / 256; ++r) {                  // (all the loads first, no branch around them: sixteen in flight)
+      const int64_t idx = wbase + r * 64 + lane;
+      el[r] = in[idx < M ? idx : M - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < RS_TILE / 256; ++r)
+      if (wbase + r * 64 + lane < M) atomicAdd(&cnt[wave][rs_digit(el[r], shift, mask)], 1u);
+    __syncthreads();
+    if (wave == 0) {                                           // exclusive scan of the tile's digit counts: (nb + 63) / 64 digits a lane
+      const unsigned per = (nb + 63u) / 64u;
+      unsigned loc[(1 << RS_MAX_BITS) / 64];
+      unsigned sum = 0;
+#pragma unroll
+      for (unsigned j = 0; j < (1u << RS_MAX_BITS) / 64u; ++j) {
+        const unsigned d = lane * per + j;
+        loc[j] = sum;
+        if (j < per && d < nb) sum += cnt[0][d] + cnt[1][d] + cnt[2][d] + cnt[3][d];
+      }
+      unsigned inc = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const unsigned v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+      const unsigned base = inc - sum;
+#pragma unroll
+      for (unsigned j = 0; j < (1u << RS_MAX_BITS) / 64u; ++j) {
+        const unsigned d = lane * per + j;
+        if (j < per && d < nb) delta[d] = base + loc[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned j = 0; j < (1u << RS_MAX_BITS) / 256u; ++j) {     // counts -> first places inside the tile, wave by wave
+      const unsigned d = threadIdx.x + 256u * j;
+      if (d < nb) {
+        const unsigned first = delta[d];
+        unsigned run = first;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const unsigned c = cnt[w][d]; cnt[w][d] = run; run += c; }
+        delta[d] = gpos[j] - first;
+        gpos[j] += run - first;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_TILE / 256; ++r) {
+      const int64_t idx = wbase + r * 64 + lane;
+      const bool valid = idx < M;
+      const unsigned d = rs_digit(el[r], shift, mask);
+      u64 peers = __ballot(valid);                             // the lanes of this round holding the same digit
+      for (int b = 0; b < bits; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const u64 m = __ballot(bit);
+        peers &= bit ? m : ~m;
+      }
+      const unsigned below = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+      const unsigned at = valid ? cnt[wave][d] + below : 0u;
+      ADJ_WAVE_SYNC();
+      if (valid && below == 0u) cnt[wave][d] += (unsigned)__popcll(peers);    // the lowest lane of the group moves the wave's place on
+      if (valid) stage[at] = el[r];
+      ADJ_WAVE_SYNC();
+    }
+    __syncthreads();
+    const int tile_n = (int)(M - tbase < RS_TILE ? M - tbase : RS_TILE);
+    for (int i = threadIdx.x; i < tile_n; i += 256) {
+      const u64 e = stage[i];
+      const unsigned to = (unsigned)i + delta[rs_digit(e, shift, mask)];
+      if (LAST) { okey[to] = (uint32_t)(e >> 32); oval[to] = (uint32_t)e; }
+      else out[to] = e;
+    }
+    __syncthreads();
+  }
 }
 
 // L[r] = first position of the sorted keys holding a key >= r, r = 0 .. N (unused slots sort last: L[N] = number of real keys)
@@ -162,10 +294,6 @@ __device__ inline void adj_load(const AdjIn& I, int rb, int nw, int tb, int64_t 
   }
 }
 
-#define ADJ_WAVE_SYNC()                                                                                                                   \
-  do {                                                                                                                                    \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-  } while (0)
 
 // lower bound in a sorted run of distinct keys
 __device__ inline int adj_lower_bound(const u64* a, int n, u64 key) {
@@ -393,15 +521,13 @@ inline int id_bits(int64_t N) {                        // 2^b > N: an id in [0, 
   return b;
 }
 
-size_t sort_temp_bytes(int64_t M, int bits) {
-  size_t tmp = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)M, 0u,
-                                  (unsigned)bits, (hipStream_t) nullptr);
-  return tmp;
-}
+inline int rs_passes(int b) { return (b + RS_MAX_BITS - 1) / RS_MAX_BITS; }
+inline int rs_bits(int b) { const int p = rs_passes(b); return (b + p - 1) / p; }             // digit width: the passes share the bits evenly
 
 struct AdjWs {
-  uint32_t *key_in, *val_in, *tkey, *te, *skey, *se;    // cap each
+  u64 *kv0, *kv1;                                       // cap each: the elements of the sort, ping and pong
+  int64_t* hist;                                        // [digit][workgroup] counts of a pass
+  uint32_t *tkey, *te, *skey, *se;                      // cap each
   AdjPk* pk;                                            // cap
   int32_t *rbeg, *rend, *nruns;                         // N
   int32_t *tL, *sL;                                     // N + 2
@@ -410,7 +536,6 @@ struct AdjWs {
   int32_t* bcol; double* bw;                            // 2 cap each: the rooms
   int32_t *mid, *big;                                   // N each: the listed rows
   u64* gk; double* gw;                                  // 4 cap each: scratch of rows too long for LDS
-  void* tmp; size_t tmp_bytes;
 };
 
 size_t adj_carve(AdjWs* w, void* base, int64_t N, int64_t cap) {
@@ -418,7 +543,8 @@ size_t adj_carve(AdjWs* w, void* base, int64_t N, int64_t cap) {
   const size_t n = (size_t)(N > 0 ? N : 1), c = (size_t)(cap > 0 ? cap : 1), m = 2 * c;
   auto take = [&](size_t bytes) { const size_t o = off; off += align256(bytes); return base ? (char*)base + o : (char*)nullptr; };
   AdjWs d;
-  d.key_in = (uint32_t*)take(c * 4); d.val_in = (uint32_t*)take(c * 4);
+  d.kv0 = (u64*)take(c * 8); d.kv1 = (u64*)take(c * 8);
+  d.hist = (int64_t*)take(((size_t)1 << RS_MAX_BITS) * (size_t)RS_MAX_WGS * sizeof(int64_t));
   d.tkey = (uint32_t*)take(c * 4); d.te = (uint32_t*)take(c * 4);
   d.skey = (uint32_t*)take(c * 4); d.se = (uint32_t*)take(c * 4);
   d.pk = (AdjPk*)take(c * sizeof(AdjPk));
@@ -431,10 +557,33 @@ size_t adj_carve(AdjWs* w, void* base, int64_t N, int64_t cap) {
   d.big = (int32_t*)take(n * sizeof(int32_t));
   d.gk = (u64*)take(2 * m * sizeof(u64));
   d.gw = (double*)take(2 * m * sizeof(double));
-  d.tmp_bytes = sort_temp_bytes((int64_t)c, id_bits(N));
-  d.tmp = (void*)take(d.tmp_bytes);
   if (w) *w = d;
   return off + 256;
+}
+
+// the elements of kv0 ordered by their key's low b bits (stable) -> okey / oval; kv0 and kv1 are both overwritten
+int adj_sort(gficf_ctx* ctx, const AdjWs& w, int64_t M, int b, uint32_t* okey, uint32_t* oval) {
+  const int P = rs_passes(b), bp = rs_bits(b);
+  const int64_t ntiles = gficf_ceil_div(M, RS_TILE);
+  const int64_t tpw = gficf_ceil_div(ntiles, RS_MAX_WGS);                  // tiles a workgroup walks
+  const unsigned G = (unsigned)gficf_ceil_div(ntiles, tpw);
+  u64 *in = w.kv0, *out = w.kv1;
+  for (int p = 0; p < P; ++p) {
+    const int shift = p * bp, bits = b - shift < bp ? b - shift : bp;
+    hipLaunchKernelGGL(k_rs_hist, dim3(G), dim3(256), 0, ctx->stream, (const u64*)in, M, shift, bits, tpw, w.hist);
+    GFICF_HIP_CHECK(hipGetLastError());
+    const int rc = gficf_exclusive_scan_i64(ctx, w.hist, ((int64_t)1 << bits) * (int64_t)G);
+    if (rc) return rc;
+    if (p == P - 1)
+      hipLaunchKernelGGL(k_rs_scatter<true>, dim3(G), dim3(256), 0, ctx->stream, (const u64*)in, M, shift, bits, tpw, (const int64_t*)w.hist,
+                         (u64*)nullptr, okey, oval);
+    else
+      hipLaunchKernelGGL(k_rs_scatter<false>, dim3(G), dim3(256), 0, ctx->stream, (const u64*)in, M, shift, bits, tpw, (const int64_t*)w.hist,
+                         out, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    GFICF_HIP_CHECK(hipGetLastError());
+    u64* t = in; in = out; out = t;
+  }
+  return GFICF_OK;
 }
 
 }  // namespace
@@ -472,10 +621,11 @@ int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, con
   const unsigned ge = (unsigned)gficf_ceil_div(edge_capacity, 256), gn = (unsigned)gficf_ceil_div(N + 1, 256);
   const unsigned gr = (unsigned)(gficf_ceil_div(N, 4) < 4096 ? gficf_ceil_div(N, 4) : 4096);
   GFICF_HIP_CHECK(hipMemsetAsync(w.rbeg, 0, sizeof(int32_t) * (3 * (size_t)N + 4), st));     // runs of the sources + the three flags behind them
-  hipLaunchKernelGGL(k_adj_edges, dim3(ge), dim3(256), 0, st, d_from, d_to, d_weight, edge_capacity, d_n_edges, N, w.key_in, w.val_in, w.pk, w.rbeg,
+  hipLaunchKernelGGL(k_adj_edges, dim3(ge), dim3(256), 0, st, d_from, d_to, d_weight, edge_capacity, d_n_edges, N, w.kv0, w.pk, w.rbeg,
                      w.rend, w.nruns, w.flag, grouped_by_source != 0 ? 1 : 0, ctx->d_status);
   GFICF_HIP_CHECK(hipGetLastError());
-  GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.tmp, w.tmp_bytes, w.key_in, w.tkey, w.val_in, w.te, (size_t)edge_capacity, 0u, (unsigned)b, st));
+  int rc = adj_sort(ctx, w, edge_capacity, b, w.tkey, w.te);
+  if (rc) return rc;
   hipLaunchKernelGGL(k_adj_bounds, dim3(gn), dim3(256), 0, st, (const uint32_t*)w.tkey, edge_capacity, N, w.tL);
   AdjIn in;
   in.to = d_to; in.w = d_weight; in.pk = w.pk; in.rbeg = w.rbeg; in.rend = w.rend; in.se = nullptr; in.tL = w.tL; in.te = w.te; in.unsorted = w.flag + 1;
@@ -487,16 +637,17 @@ int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, con
     grouped = ng == 0;
   }
   if (!grouped) {
-    hipLaunchKernelGGL(k_adj_source_keys, dim3(ge), dim3(256), 0, st, d_from, d_to, edge_capacity, d_n_edges, N, w.key_in, w.val_in);
+    hipLaunchKernelGGL(k_adj_source_keys, dim3(ge), dim3(256), 0, st, d_from, d_to, edge_capacity, d_n_edges, N, w.kv0);
     GFICF_HIP_CHECK(hipGetLastError());
-    GFICF_HIP_CHECK(rocprim::radix_sort_pairs(w.tmp, w.tmp_bytes, w.key_in, w.skey, w.val_in, w.se, (size_t)edge_capacity, 0u, (unsigned)b, st));
+    rc = adj_sort(ctx, w, edge_capacity, b, w.skey, w.se);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_adj_bounds, dim3(gn), dim3(256), 0, st, (const uint32_t*)w.skey, edge_capacity, N, w.sL);
     in.rbeg = w.sL; in.rend = w.sL + 1; in.se = w.se;
   }
   hipLaunchKernelGGL(k_adj_caps, dim3(gn), dim3(256), 0, st, N, in.rbeg, in.rend, (const int32_t*)w.tL, in.se ? (const uint32_t*)nullptr : (const uint32_t*)w.flag,
                      w.start, d_indptr, w.mid, w.big, w.flag + 2);
   GFICF_HIP_CHECK(hipGetLastError());
-  int rc = gficf_exclusive_scan_i64(ctx, w.start, N + 1);
+  rc = gficf_exclusive_scan_i64(ctx, w.start, N + 1);
   if (rc) return rc;
   hipLaunchKernelGGL(k_adj_rows, dim3(gr), dim3(256), 0, st, in, N, (const int64_t*)w.start, w.bcol, w.bw, d_indptr);
   hipLaunchKernelGGL(k_adj_rows_mid, dim3(4096), dim3(64), 0, st, in, (const int64_t*)w.start, (const int32_t*)w.mid, (const unsigned*)(w.flag + 2),
