@@ -639,15 +639,14 @@ __global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, con
                                                 const float* __restrict__ centers, const float* __restrict__ radius,
                                                 const int32_t* __restrict__ tile_n, int kk, int64_t n_ct, float* __restrict__ lb,
                                                 unsigned long long* __restrict__ counters) {
-  extern __shared__ float s_q[];                     // [KNN_TQ][dpad + 1] queries (rows beyond nq: zeros, never used for the bound)
+  extern __shared__ __attribute__((aligned(16))) float s_q[];   // [dpad][KNN_TQ]: a dimension of the 64 queries is contiguous (rows beyond nq: zeros, never used)
   __shared__ float s_u[4];
   const int64_t qt = blockIdx.x, q0 = qt * KNN_TQ;
   const int nq = qtile_n[qt];
   if (nq <= 0) return;                               // padding tile: its workgroup of the search exits at once
-  const int pitch = dpad + 1;
   for (int e = threadIdx.x; e < KNN_TQ * dpad; e += 256) {
     const int row = e / dpad, dim = e % dpad;
-    s_q[row * pitch + dim] = row < nq ? Q[(q0 + row) * dpad + dim] : 0.0f;
+    s_q[dim * KNN_TQ + row] = row < nq ? Q[(q0 + row) * dpad + dim] : 0.0f;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -662,6 +661,8 @@ __global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, con
   // one thread per candidate tile: the distance of EVERY query of the tile to the candidate tile's centre c (round 6; through round 5
   // the bound went through the query tile's own centre, dist(cq, c) - rq - r: in 50 dimensions the queries all sit at nearly the same
   // distance from c, far above that — on the config-3 stand-in 97 % of the pairs are provably out of reach this way, 82 % before).
+  // (Screening the pairs with the old bound first and refining only those it leaves in reach was tried: its own upper bound of the k-th
+  // best is so loose in 50 dimensions that every pair is left in reach — slower by the screening.)
   // Every point x of the candidate tile is within r of c, so  dist(q, x) >= min_q dist(q, c) - r  and  <= max_q dist(q, c) + r.
   float u = INFINITY;                                // upper bound of the queries' k-th best (key domain)
   for (int64_t c = threadIdx.x; c < n_ct; c += 256) {
@@ -672,13 +673,18 @@ __global__ __launch_bounds__(256) void k_knn_lb(const float* __restrict__ Q, con
       float acc[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-      const float* qrow = s_q + g0 * pitch;
       for (int t = 0; t < d; ++t) {
         const float cv = centers[(int64_t)t * n_ct + c];            // [dim][tile]: consecutive threads, consecutive tiles
+        const float4* q4 = reinterpret_cast<const float4*>(s_q + t * KNN_TQ + g0);     // four 16 B broadcast reads
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float df = qrow[j * pitch + t] - cv;
-          acc[j] = METRIC == GFICF_KNN_MANHATTAN ? acc[j] + fabsf(df) : fmaf(df, df, acc[j]);
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const float4 q = q4[j4];
+          const float qa[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float df = qa[j] - cv;
+            acc[4 * j4 + j] = METRIC == GFICF_KNN_MANHATTAN ? acc[4 * j4 + j] + fabsf(df) : fmaf(df, df, acc[4 * j4 + j]);
+          }
         }
       }
 #pragma unroll
@@ -1035,7 +1041,7 @@ int gficf_knn_search_device(gficf_ctx* ctx, const float* d_points, int64_t N, in
   if (rc) return rc;
   // 3. centre and radius of every candidate tile; bound of every (query tile, candidate tile) pair
   GFICF_HIP_CHECK(hipMemsetAsync(w.counters, 0, 32, ctx->stream));
-  const size_t lds_lb = ((size_t)KNN_TQ * (dpad + 1) + dpad) * sizeof(float);
+  const size_t lds_lb = (size_t)KNN_TQ * dpad * sizeof(float);
   switch (metric) {
     case GFICF_KNN_MANHATTAN:
       hipLaunchKernelGGL(k_knn_tile_stats<GFICF_KNN_MANHATTAN>, dim3((unsigned)w.n_ct), dim3(KNN_TC), 0, ctx->stream, w.xp, w.tile_n, d, dpad, w.centers, w.radius);
