@@ -42,6 +42,10 @@ def run(N, k, n_start, reps=5):
     qn = oracle_np.modularity_np(A, labs[0], 0.8)
     print(f"louvain_device N={N} k={k} nnz={A.nnz} n_start={n_start}: {min(ts):.2f} ms min, {sorted(ts)[len(ts) // 2]:.2f} ms median of {reps} "
           f"({nc} clusters, Q {q:.6f}, numpy Q {qn:.6f}, reproducible {same}, workspace {ws.numel() / 1e6:.0f} MB)", flush=True)
+    if reps >= 50:                                   # the spread of many calls: are there stalls?
+        st = sorted(ts)
+        print("  calls sorted: " + " ".join(f"p{p}={st[min(len(st) - 1, len(st) * p // 100)]:.2f}" for p in (0, 10, 50, 90, 99)) + f" max={st[-1]:.2f} ms; "
+              f"calls above 1.5 x the median: {sum(t > 1.5 * st[len(st) // 2] for t in ts)} of {len(ts)}", flush=True)
     tp = []
     for _ in range(reps):
         t0 = time.perf_counter()

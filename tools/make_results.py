@@ -15,6 +15,7 @@ trace (tools/run_record.sh: <name>.json + <name>_kernel_stats.csv from one gpuru
 ms_per_pass lie nearest the medians — and says which."""
 import statistics
 import csv
+import glob
 import json
 import os
 import re
@@ -251,7 +252,8 @@ def main():
              keep=lambda l: l.startswith("N "))
     verbatim(f"{TAG}_sorted_vs_general.txt", "56 < k <= 256: the general hash-set kernel against the sorted-row path, each in its own process (`tools/sorted_vs_general.py`)")
     verbatim(f"{TAG}_config3_pipeline.txt", "BASELINE config 3 end to end through the host mirror of the R calls (`tools/config3_pipeline.py`: gficf() on 23 k genes x 54 k cells, then "
-             "clustcells(k = 30) on a 50-component stand-in for the PCA space; wall time per call, PCIe included)", keep=lambda l: l.startswith(("run", "synthetic")))
+             "clustcells(k = 30) on a 50-component stand-in for the PCA space; wall time per call, PCIe included; the CPU side of the same pipeline on the box's host cores below it: "
+             "ports = the oracle's restatements, REFERENCE binary = `oracle/_ref/modularity_optimizer` built from the reference's own source)")
     verbatim(f"{TAG}_host_compact_ab.txt", "`gficf_jaccard_host` (what the `.Call` binds) into a FRESH result matrix per call, as R allocates one: the 24 B/edge matrix copied back over PCIe "
              "against the compact return (uint16 counts over PCIe + the rows written by up to 32 host threads; the default from 2^20 edges on), each in its own process (`tools/host_compact_ab.py`)")
     verbatim(f"{TAG}_one_buffer_ab.txt", "A caller that reuses ONE table for every data set pays ~3.7 us per data set at 100 k x 30 (`tools/one_buffer_ab.py`; the outputs do not matter)")
@@ -304,9 +306,29 @@ def main():
     if kn:
         gb = kn.get("graph_build") or {}
         lv = kn.get("louvain") or {}
-        w("## Next rows (frozen): exact kNN {:.2f} ms pruned / {:.1f} ms unpruned (frac {:.2f} of the VALU roofline) at 100 k x 50; kNN -> Jaccard -> filter -> adjacency {:.2f} ms; "
-          "Louvain {:.1f} ms, Q = {:.4f}.\n\n".format(kn["ms_per_pass"], kn["ms_per_pass_unpruned"], kn["roofline"]["frac"], gb.get("ms_total", float("nan")),
-                                                lv.get("ms", float("nan")), lv.get("modularity", float("nan"))))
+        w("## Next rows (SURVEY.md §8f)\n\nIn the kept run's line (100 k cells x 50 components, Gaussian blobs; device-resident): exact kNN {:.2f} ms pruned / {:.1f} ms unpruned "
+          "(frac {:.2f} of the VALU roofline); kNN -> Jaccard -> filter -> adjacency {:.2f} ms, of which Jaccard + filter + adjacency {:.3f}; Louvain (one start) {:.1f} ms, Q = {:.4f}.\n\n".format(
+              kn["ms_per_pass"], kn["ms_per_pass_unpruned"], kn["roofline"]["frac"], gb.get("ms_total", float("nan")), gb.get("ms_jaccard_filter_adjacency", float("nan")),
+              lv.get("ms", float("nan")), lv.get("modularity", float("nan"))))
+    verbatim(f"{TAG}_louvain_time.txt", "Louvain and the fused call at the shapes VERDICT r05 names (`tools/louvain_time.py`: `gficf_louvain_device` on a device-resident graph; `phenograph()` = the host "
+             "mirror of `gficf_phenograph_host`, PCIe and the mirror's own conversions included; reference defaults n.start = 10, n.iter = 10; round 5: 54.2 ms / 5.45 ms / 8.3 ms for the three "
+             "Louvain lines, 70 ms for the first fused call)", keep=lambda l: l.startswith(("louvain_device", "phenograph(")))
+    verbatim(f"{TAG}_phenograph_stages.txt", "Inside one `gficf_phenograph_host` call (`GFICF_PHENOGRAPH_DEBUG=1`: a stream synchronisation behind every stage; `tools/phenograph_stages.py`; "
+             "config-3 shape with 10 starts, 100 k x 50 with one, 400 k x 30 with 10)")
+    verbatim(f"{TAG}_knn_prune_probe.txt", "The search on the config-3 stand-in, host calls (`tools/knn_prune_probe.py`; 0 = plain form, 1 = pruned form forced, auto = the device's own choice — "
+             "the plain form through round 5; tile kernel alone, rocprofv3: plain 9.71 ms, pruned with round 5's bound 4.55, with every query's own distance to the tile centre 1.03 + 0.19 for the bounds)")
+    verbatim(f"{TAG}_adjacency.txt", "Adjacency build, device-resident (`tools/adjacency_time.py`; `windowed` = the synthetic kNN matrix of the bench, `blobs` = the matrix of a real search: in-degrees "
+             "with a tail; round 5 at 100 k x 50: 1.04 ms, this round's first form 0.83)")
+    verbatim(f"{TAG}_adjacency_row_buckets.txt", "The build with NO sort (row buckets filled by atomics), written and measured first, closed", keep=lambda l: l.startswith("#"))
+    verbatim(f"{TAG}_louvain_locality.txt", "Would a locality-improving renumbering of the vertices pay in the Louvain? (`tools/louvain_locality_probe.py`)")
+    fz = sorted(glob.glob(os.path.join(P, f"{TAG}_fuzz*.txt")))
+    if fz:
+        w("Randomised parity runs on the final library (`tools/fuzz_gpu.py`, 100 s each, every case equal to the oracle or the run stops):\n\n```\n")
+        for f in fz:
+            ls = [l.rstrip() for l in open(f) if l.strip()]
+            head = [l for l in ls if "cases" in l and ("seed" in l or "bit-exact" in l or "equal" in l)]
+            w(os.path.basename(f) + ": " + (head[-1] if head else ls[0])[:240] + "\n")
+        w("```\n\n")
     w("## Sharded Jaccard step (one-GPU measurements; the driver's SCALE run is the multi-GPU measurement)\n\n")
     st = os.path.join(P, f"{TAG}_halo_stage_times.jsonl")
     if os.path.exists(st):
@@ -341,6 +363,15 @@ def main():
                 w("  `peer.spatial_ids` (nothing exchanged: rows named outside read in the owners' blocks): checked_vs_oracle {} in order / {} overlapped, rows named outside per device {}, "
                   "the caller's thread {:.0f} us per data set.\n\n".format(ph.get("checked_vs_oracle"), (ph.get("overlapped") or {}).get("checked_vs_oracle"),
                                                                           ph.get("rows_named_outside_per_device"), ph.get("host_enqueue_us_per_data_set", float("nan"))))
+            ef = (r.get("efficiency") or {}).get("forms") or {}
+            if ef:
+                w("  `efficiency.forms` of that line — per exchange form the MEASURED whole-job efficiency beside the model's PROJECTION for the same world size "
+                  "(`measured_is`: \"{}\"); on the driver's SCALE run the residual is the finding:\n\n".format(next(iter(ef.values())).get("measured_is", "measured")))
+                w("  | form | measured | projected | residual |\n  |---|---|---|---|\n")
+                for name, v in ef.items():
+                    w("  | `{}` | {} | {} | {} |\n".format(name, v.get("measured"), v.get("projected"), v.get("residual")))
+                ra = (r.get("exchange") or {}).get("rccl_algo") or {}
+                w("\n  `exchange.rccl_algo`: {}\n\n".format(json.dumps(ra)[:300]))
     slow = load(f"{TAG}_rehearsal_gpus5_20k_cells_budget.jsonl")
     if slow:
         w("The wall budget at work (5 ranks x 20 k cells time-slicing ONE GPU over gloo: a data set takes ~1.5 s there): `value` took {:.0f} s, the line was out at {:.0f} s; "
