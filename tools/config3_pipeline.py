@@ -22,7 +22,7 @@ cp, ri, x = synth.counts_csc(G, N, seed=7)
 M = sp.csc_matrix((x, ri, cp), shape=(G, N))
 rng = np.random.default_rng(1)
 C = 30
-pca = rng.normal(size=(C, 50))[rng.integers(0, C, N)] * 3.0 + rng.normal(size=(N, 50))
+pca = np.asfortranarray(rng.normal(size=(C, 50))[rng.integers(0, C, N)] * 3.0 + rng.normal(size=(N, 50)))   # column-major, as an R matrix is (the C ABI's layout: no copy in the mirror)
 print(f"synthetic input: {G} x {N}, nnz {M.nnz}, built in {time.perf_counter() - t0:.1f} s (host)")
 gficf_amd.gficf(M[:, :2000], normalize=False, verbose=False)                      # warm-up: context, library
 data = cells = noraw = None
