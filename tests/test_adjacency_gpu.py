@@ -39,6 +39,25 @@ def test_random_edge_lists(N, E, seed):
     assert (abs(A - A.T)).nnz == 0
 
 
+@pytest.mark.parametrize("N,E,grouped", [(3_000_000, 200_000, False), (3_000_000, 300_000, True), (150_000, 4_600_000, True), (150_000, 4_400_000, False),
+                                         (1023, 9_000, True), (1024, 9_000, True), (5, 40_000, False)])
+def test_every_form_of_the_sort(N, E, grouped):
+    """The build orders the transposed half with its own radix passes (digits of up to 10 bits over the bits of N, least significant first): one
+    pass up to 1023 cells, two up to 2^20 - 1, three beyond (3 M cells: 22 bits); from 4.2 M edges on a workgroup walks more than one tile and
+    carries the digits' places along.  Random lists, exactly summable weights, against scipy."""
+    rng = np.random.default_rng(N + E)
+    f = rng.integers(1, N + 1, size=E)
+    if grouped:
+        f = np.sort(f)
+    t = rng.integers(1, N + 1, size=E)
+    if N > 1_000_000:                                                     # hubs too: long rows next to the three-pass sort
+        t[: E // 50] = 7
+    f, t = f.astype(np.float64), t.astype(np.float64)
+    w = rng.integers(1, 60, size=E) / 64.0
+    A = gficf_amd.jaccard_adjacency({"from": f, "to": t, "weight": w}, N)
+    assert same(A, reference_adjacency(f, t, w, N))
+
+
 @pytest.mark.parametrize("grouped", [False, "any order", "ascending"])
 @pytest.mark.parametrize("hub_degrees", [(129, 300), (4096, 4097), (5000, 20000), (60000,)])
 def test_rows_of_every_length_class(hub_degrees, grouped):
