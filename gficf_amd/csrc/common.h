@@ -127,7 +127,7 @@ void gficf_host_plan_free(gficf_ctx* ctx);
 void gficf_edge_plan_free(gficf_ctx* ctx);
 // gficf_jaccard_edges_filtered_device on a table built from RENUMBERED cells (row p of the table = original cell d_order[p], 0-based; ids inside
 // the table in the new numbering, 1-based): both columns come out in the ORIGINAL ids, the edges in the order of the new numbering.  Internal
-// since ABI 7 (its one caller is gficf_phenograph_host, which renumbers the cells by the search's pivot order from 2^17 cells on).
+// since ABI 7 (its one caller is gficf_phenograph_host with GFICF_PHENOGRAPH_ORDER=1: cells renumbered by the search's pivot order; off by default).
 int gficf_jaccard_edges_filtered_mapped(gficf_ctx* ctx, const int32_t* d_table, int64_t N, int k, int64_t cell_begin, int64_t cell_end, uint16_t* d_u_ws,
                                         int64_t* d_cell_ptr, double* d_from, double* d_to, double* d_weight, const int32_t* d_order);
 // same for the host-form adjacency build (adjacency.hip)

@@ -27,7 +27,11 @@ struct Carver {
   }
 };
 
-// ---- the Jaccard stage on cells renumbered by locality (round 5).  From 2^17 cells on the table takes 128 B rows and, with ids in
+// ---- the Jaccard stage on cells renumbered by locality (round 5; OFF by default since round 6, GFICF_PHENOGRAPH_ORDER=1 turns it on).
+// Measured stage by stage in round 6 (profiles/r06_phenograph_order_ab.txt): the renumbering needs a pass of its own over the points
+// (every cell's nearest pivot: 10 ms at 1 M x 50) to save 0.4 ms in the edge kernel, and it hands the adjacency build sources that do
+// not ascend (its slower form) — 12.4 against 0.94 ms for the Jaccard stage at 1 M cells, 0.92 against 0.18 at 200 k.  Round 5 read a
+// first-call effect (the pool growing) as its gain.  What it does:  from 2^17 cells on the table takes 128 B rows and, with ids in
 // the order the caller's matrix happens to have, nearly every gathered row is an L2 miss (1 M x 30: 697 us, 5.5 x the algorithmic
 // bytes).  The search has just computed an order in which neighbours sit next to each other — its (coarse, fine) pivot order — so
 // the index matrix is relabelled into that numbering (row p = original cell order[p], ids through the inverse), the edge kernel
@@ -52,8 +56,9 @@ __global__ __launch_bounds__(256) void k_relabel_idx(const int32_t* __restrict__
 }
 
 bool phenograph_ordered(int64_t N) {
+  (void)N;
   if (const char* e = getenv("GFICF_PHENOGRAPH_ORDER")) return atoi(e) != 0;    // A/B switch, read per call
-  return N >= (1ll << 17);
+  return false;
 }
 
 }  // namespace

@@ -257,8 +257,9 @@ def main():
     verbatim(f"{TAG}_host_compact_ab.txt", "`gficf_jaccard_host` (what the `.Call` binds) into a FRESH result matrix per call, as R allocates one: the 24 B/edge matrix copied back over PCIe "
              "against the compact return (uint16 counts over PCIe + the rows written by up to 32 host threads; the default from 2^20 edges on), each in its own process (`tools/host_compact_ab.py`)")
     verbatim(f"{TAG}_one_buffer_ab.txt", "A caller that reuses ONE table for every data set pays ~3.7 us per data set at 100 k x 30 (`tools/one_buffer_ab.py`; the outputs do not matter)")
-    verbatim(f"{TAG}_phenograph_order_ab.txt", "`gficf_phenograph_host` at 400 k cells x 10 dimensions, k = 30, Jaccard stage on the caller's order (=0) against cells renumbered in the search's pivot "
-             "order (=1, the default from 2^17 cells on; first call: the pool grows)")
+    verbatim(f"{TAG}_phenograph_order_ab.txt", "`gficf_phenograph_host`, Jaccard stage on the caller's order (GFICF_PHENOGRAPH_ORDER=0, the default since round 6) against cells renumbered in "
+             "the search's pivot order (=1; round 5's default from 2^17 cells on): the library's own stage times at 50 dimensions (`tools/phenograph_stages.py`), then the whole call at "
+             "400 k x 10 dimensions (`tools/phenograph_order_ab.py`; its first line is a first call: the pool grows — what round 5 read as the gain)")
     w("## GF-ICF normalisation (`gficf()`, R/gficf.R:17-105), config 3 shape (23 k genes x 54 k cells)\n\n")
     g = (b or {}).get("gficf")
     if g:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gficf_phenograph_host with the Jaccard stage on the caller's cell order (GFICF_PHENOGRAPH_ORDER=0) against cells renumbered in the
-search's pivot order (=1; the default from 2^17 cells on): same labels, edges and modularity; wall time of the call and, from a
-rocprofv3 trace of this script, the edge kernel's time.  Usage: python tools/phenograph_order_ab.py [N] [d] [k]"""
+search's pivot order (=1; round 5's default from 2^17 cells on, off by default since round 6): same labels, edges and modularity; wall time of
+the call (the first of each is a first call: the pool grows) and, with GFICF_PHENOGRAPH_DEBUG=1, the library's own stage times.  Usage: python tools/phenograph_order_ab.py [N] [d] [k]"""
 import os
 import sys
 import time
