@@ -816,6 +816,11 @@ bool knn_use_prune(int64_t N) {
 inline int64_t knn_coarse(int64_t C) { return C / 16 > 2 ? C / 16 : 2; }
 
 int64_t knn_pivots(int64_t N) {
+  // points per pivot.  Round 6 swept it (one box, GFICF_KNN_PIVOT_CELL): on 30 blobs in 50 dimensions larger cells win from 400 k points on
+  // (400 k: 36.8 ms at 256, 28.0 at 1024; 1 M: 303 / 207 / 186 ms at 244 / 1024 / 4096 — cells are padded to whole tiles and the per-tile
+  // bounds grow with the number of cells), but a cell has to stay finer than the data's clusters: 1 M points in 200 clusters take 221 ms at
+  // 256 and 2 358 ms at 1 953 (nothing left to prune: the plain form).  The size that is safe for both stays; bounds per cell first and per
+  // tile inside the cells in reach would lift the cost that grows with the cells (not built).
   int64_t per = 256;
   if (const char* e = getenv("GFICF_KNN_PIVOT_CELL")) per = atoi(e) > 0 ? atoi(e) : per;    // lab knob: points per pivot
   int64_t c = gficf_ceil_div(N, per);
