@@ -47,6 +47,8 @@ def run(N, k, n_start, reps=5):
         print("  calls sorted: " + " ".join(f"p{p}={st[min(len(st) - 1, len(st) * p // 100)]:.2f}" for p in (0, 10, 50, 90, 99)) + f" max={st[-1]:.2f} ms; "
               f"calls above 1.5 x the median: {sum(t > 1.5 * st[len(st) // 2] for t in ts)} of {len(ts)}", flush=True)
     tp = []
+    if os.environ.get("LT_NO_PHENOGRAPH"):
+        return
     for _ in range(reps):
         t0 = time.perf_counter()
         ph = gficf_amd.phenograph(X, k, "manhattan", 0.8, 1, n_start, 10, 180582)
