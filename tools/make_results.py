@@ -324,7 +324,7 @@ def main():
     verbatim(f"{TAG}_louvain_locality.txt", "Would a locality-improving renumbering of the vertices pay in the Louvain? (`tools/louvain_locality_probe.py`)")
     fz = sorted(glob.glob(os.path.join(P, f"{TAG}_fuzz*.txt")))
     if fz:
-        w("Randomised parity runs on the final library (`tools/fuzz_gpu.py`, 100 s each, every case equal to the oracle or the run stops):\n\n```\n")
+        w("Randomised parity runs on the final library (`tools/fuzz_gpu.py`; every case equal to the oracle or the run stops):\n\n```\n")
         for f in fz:
             ls = [l.rstrip() for l in open(f) if l.strip()]
             head = [l for l in ls if "cases" in l and ("seed" in l or "bit-exact" in l or "equal" in l)]
