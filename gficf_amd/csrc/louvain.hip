@@ -154,7 +154,11 @@ __device__ __host__ static inline uint32_t lv_hash(uint32_t v) {
 
 __device__ __host__ static inline int lv_sub_rounds_of(int64_t n, int s_env) {
   if (s_env >= 1 && s_env <= 64) return s_env;
-  return n > 50000 ? 2 : n > 4000 ? 4 : n > 400 ? 8 : 16;
+  // sub-rounds an iteration is cut into (vertices of one hash class move together).  One is too few (modularity 0.03 - 0.06 below the reference's
+  // on weakly structured graphs: neighbours move at once), two to sixteen give the same quality within run-to-run differences of 0.003 on graphs of 300
+  // to 60 000 vertices (tools/louvain_subrounds_probe.py, profiles/r06_louvain_subrounds.txt).  Through round 6's first form small levels took 8 / 16:
+  // the coarse levels of a big problem are a few hundred vertices, and 16 sub-rounds x 3 launches an iteration were 1 ms of the 10.8 at config 3.
+  return n > 50000 ? 2 : 4;
 }
 
 // ---- level 0: fixed-point weights, validation
