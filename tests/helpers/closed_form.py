@@ -68,3 +68,29 @@ def cyclic_window_twice_expected(N, k, set_semantics=False):
     dst = np.where(pos, mat.reshape(-1), 0).astype(np.float64)
     w = np.where(pos, u / (2.0 * k - u), 0.0)
     return np.stack([src, dst, w], axis=1), u
+
+
+def ring_of_cliques(c, m, weight=1.0):
+    """c cliques of m vertices each (every pair inside joined by an edge of `weight`), clique q joined to clique q + 1 (mod c) by ONE edge, between
+    the last vertex of q and the first of q + 1.  The answer of modularity optimisation at resolution g is derived, not computed:
+    with K = m (m - 1) + 2 the total weight at a clique's vertices (in units of `weight`) and 2W = c K, merging two neighbouring cliques changes
+    Q by 2 / (2W) - 2 g K^2 / (2W)^2, negative as long as c < g K; splitting a clique only loses.  So for c < g K the optimum is one community per
+    clique and        Q = m (m - 1) / K - g / c        (reference quality function, src/ModularityOptimizer.cpp:461-482).
+    Returns (symmetric scipy CSC adjacency, clique id of every vertex)."""
+    import scipy.sparse as sp
+
+    N = c * m
+    q = np.repeat(np.arange(c, dtype=np.int64), m * m)
+    a = np.tile(np.repeat(np.arange(m, dtype=np.int64), m), c)
+    b = np.tile(np.tile(np.arange(m, dtype=np.int64), m), c)
+    keep = a != b
+    i, j = (q * m + a)[keep], (q * m + b)[keep]
+    last, first = np.arange(c, dtype=np.int64) * m + (m - 1), ((np.arange(c, dtype=np.int64) + 1) % c) * m
+    i, j = np.concatenate([i, last, first]), np.concatenate([j, first, last])
+    A = sp.csc_matrix((np.full(len(i), float(weight)), (i, j)), shape=(N, N))
+    A.sort_indices()
+    return A, np.repeat(np.arange(c, dtype=np.int32), m)
+
+
+def ring_of_cliques_modularity(c, m, resolution):
+    return m * (m - 1) / (m * (m - 1) + 2.0) - resolution / c

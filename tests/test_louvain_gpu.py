@@ -122,6 +122,22 @@ def test_alternative_modularity_function(N, k, C, res):
         gficf_amd.run_modularity_clustering(A, 2, 1.5)
 
 
+@pytest.mark.parametrize("c,m,weight,n_start", [(60, 10, 1.0, 1), (60, 10, 0.37, 10), (1000, 40, 1.0, 1), (1000, 40, 2.5, 10), (8, 5, 1.0, 10)])
+def test_ring_of_cliques_against_the_derived_partition_and_modularity(c, m, weight, n_start):
+    """An answer by counting, no oracle and no reference binary in the loop (tests/helpers/closed_form.py): c cliques of m vertices on a ring, one
+    edge between neighbours.  For c < resolution x (m (m - 1) + 2) the optimum is one community per clique and Q = m (m - 1) / (m (m - 1) + 2) -
+    resolution / c — the labels must be that partition exactly (whatever the batch of starts), the reported modularity that number."""
+    from tests.helpers import closed_form
+
+    res = 0.8
+    assert c < res * (m * (m - 1) + 2)
+    A, clique = closed_form.ring_of_cliques(c, m, weight)
+    lab = gficf_amd.run_modularity_clustering(A, 1, res, 1, n_start, 10, 7)
+    check_labels(A, lab, res)
+    assert lab.n_clusters == c and same_partition(np.asarray(lab), clique)
+    assert abs(lab.modularity - closed_form.ring_of_cliques_modularity(c, m, res)) < 1e-9
+
+
 def test_hub_vertices_beyond_the_table():
     """Hubs with 3 000 and 30 000 neighbours, each neighbour its own community at the start: more than the 2048- and the
     8192-slot table hold — the second takes several passes over its edges.  Checked against the reference binary."""

@@ -448,3 +448,20 @@ def test_knn_oracle_against_the_derived_answer_on_a_line(N, k, metric):
     dist = np.where(ok, np.abs(cand - i), 10 * N)
     order = np.lexsort((np.where(ok, cand, 10 * N), dist), axis=1)[:, :k]
     assert np.array_equal(idx, (np.take_along_axis(cand, order, axis=1) + 1).astype(idx.dtype))
+
+
+@pytest.mark.parametrize("c,m", [(8, 5), (60, 10), (200, 20)])
+def test_modularity_restatement_and_reference_binary_against_the_ring_of_cliques(c, m):
+    """The quality function's restatement, and — when oracle/_ref holds it — the REFERENCE's own optimiser, against an answer derived by counting
+    (tests/helpers/closed_form.py::ring_of_cliques): one community per clique, Q = m (m - 1) / (m (m - 1) + 2) - resolution / c.  The device
+    Louvain is held to the same answer in tests/test_louvain_gpu.py."""
+    from tests.helpers import closed_form
+
+    res = 0.8
+    A, clique = closed_form.ring_of_cliques(c, m, 0.37)
+    want = closed_form.ring_of_cliques_modularity(c, m, res)
+    assert (abs(A - A.T)).nnz == 0 and abs(oracle_np.modularity_np(A, clique, res) - want) < 1e-12
+    if oracle.build_ref() is not None:
+        labels, q = oracle.modularity_reference(A, res, 1, 10, 10, 0)
+        pairs = np.unique(np.stack([labels, clique], axis=1), axis=0)
+        assert len(pairs) == c == len(np.unique(labels)) and abs(q - want) < 6e-5        # (the binary prints four decimals)
