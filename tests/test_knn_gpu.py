@@ -238,6 +238,25 @@ def test_knn_feeds_jaccard_on_device(ops):
     assert np.array_equal(edges["weight"], want[keep, 2])
 
 
+@pytest.mark.parametrize("c,m,d", [(12, 9, 3), (300, 31, 6), (1500, 31, 50)])
+def test_phenograph_against_a_derived_answer_on_far_apart_groups(c, m, d):
+    """The whole fused call — search, Jaccard, filter, adjacency, Louvain — on an input whose answer is derived, no oracle in the loop: c groups of
+    m points, the groups 1000 apart, the points of a group a small step apart, k = m - 1.  The k nearest of a point are exactly the rest of its group
+    (whatever the ties inside), so two points of a group share m - 2 neighbours: u = m - 2, weight (m - 2) / m, every pair mutual — the graph is c
+    disjoint cliques, n_edges = c m (m - 1), the communities are the groups and Q = 1 - resolution / c (reference chain R/clustCells.R:57-86)."""
+    rng = np.random.default_rng(c)
+    g = np.repeat(np.arange(c), m)
+    X = np.zeros((c * m, d))
+    X[:, 0] = 1000.0 * g + 0.01 * np.tile(np.arange(m), c)
+    X[:, 1:] = 0.001 * rng.random((c * m, d - 1))
+    perm = rng.permutation(c * m)                       # the caller's order carries no hint
+    lab = gficf_amd.phenograph(X[perm], k=m - 1, dist_method="manhattan", resolution=0.8, n_start=3, n_iter=4, random_seed=5)
+    assert lab.n_edges == c * m * (m - 1) and lab.n_clusters == c
+    assert abs(lab.modularity - (1.0 - 0.8 / c)) < 1e-9
+    pairs = np.unique(np.stack([np.asarray(lab), g[perm]], axis=1), axis=0)
+    assert len(pairs) == c
+
+
 def test_phenograph_on_cells_renumbered_in_pivot_order_gives_the_same_graph_and_labels(monkeypatch):
     """gficf_phenograph_host with GFICF_PHENOGRAPH_ORDER=1 (round 5's default from 2^17 cells on; off by default since round 6, where the
     stage times showed it costs more than it saves): the Jaccard stage runs on cells renumbered in the search's pivot order and hands the
