@@ -504,7 +504,34 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __res
   lv_wave_sync();
   u64 acc = 0;               // lane b: internal weight summed for component b
   unsigned cnt = 0;          // lane b: vertices of component b that move
-  for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < g.nb; v += (int64_t)gridDim.x * 4) {
+  // Look-ahead (round 6, late): the lanes first look at the wave's next 64 / P vertices at once — lane (j, b) at copy b of the j-th of them, P = the
+  // copies rounded up to a power of two — and the wave then works through the vertices that have a copy to look at.  Before, a wave found out
+  // vertex by vertex (row loaded, then one stamp per pair of copies, each load behind the last): 31 us a launch at 10 x 54 k vertices with NOTHING
+  // to do, which is what the last ten iterations of a level are (a few hundred vertices still moving) — 3 - 5 us now.
+  const int P = g.rep <= 1 ? 1 : g.rep <= 2 ? 2 : g.rep <= 4 ? 4 : g.rep <= 8 ? 8 : 16;
+  const int la_j = lane / P, la_b = lane % P;
+  const int64_t v_stride = (int64_t)gridDim.x * 4;
+  for (int64_t vb = (int64_t)blockIdx.x * 4 + wave; vb < g.nb; vb += v_stride * (64 / P)) {
+   u64 la_mask;
+   {
+    const int64_t vj = vb + (int64_t)la_j * v_stride;
+    const bool there = la_b < g.rep && vj < g.nb;
+    const int comp = there ? (g.vcomp ? (int)g.vcomp[vj] : la_b) : 0;
+    const int run = __shfl(st_run, comp), S = __shfl(st_S, comp);           // (every lane takes part: the state sits in lanes 0 .. 15)
+    const uint32_t off = (uint32_t)__shfl((int)st_off, comp);
+    bool act = false;
+    if (there && run) {
+      const uint32_t gv = (uint32_t)((int64_t)la_b * g.nb + vj);
+      const bool in_class = S == 1 || lv_class(gv + off, S) == mv.s;
+      act = (in_class || FIRST) && mark_r[gv] >= mv.thr;
+    }
+    la_mask = __ballot(act);
+   }
+   while (la_mask) {                               // uniform over the wave
+    const int jj = __builtin_ctzll(la_mask) / P;
+    const unsigned look = (unsigned)((la_mask >> (jj * P)) & ((1ull << P) - 1ull));      // bit b: copy b of this vertex is looked at
+    la_mask &= ~(((1ull << P) - 1ull) << (jj * P));
+    const int64_t v = vb + (int64_t)jj * v_stride;
     const int64_t lo = g.beg[v], hi = g.end[v];
     if (hi - lo > LV_SMALL_DEG) continue;
     const int64_t e0 = lo + lane, e1 = e0 + 64;
@@ -531,9 +558,10 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __res
         const bool in_class = S == 1 || lv_class(gvB + (uint32_t)__builtin_amdgcn_readlane((int)st_off, compB), S) == mv.s;
         modeB = in_class ? 2 : FIRST ? 1 : 0;
       }
-      // looked at only when it or a neighbour has moved since it was last looked at (the stamps this kernel reads were merged before it began)
-      if (modeA && mark_r[gvA] < mv.thr) modeA = 0;
-      if (modeB && mark_r[gvB] < mv.thr) modeB = 0;
+      // looked at only when it or a neighbour has moved since it was last looked at (the stamps this kernel reads were merged before it began;
+      // read by the look-ahead above)
+      if (modeA && !((look >> b) & 1u)) modeA = 0;
+      if (modeB && !((look >> (b + 1)) & 1u)) modeB = 0;
       if (!modeA && !modeB) continue;
       const uint32_t baseA = gvA - (uint32_t)v, baseB = gvB - (uint32_t)v;
       // this lane's entries: (cx, wx) belongs to side A, (cy, wy) to side B in a pair round and to side A otherwise
@@ -613,6 +641,7 @@ __global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __res
         }
       }
     }
+   }
   }
   if (lane < LV_MAX_B) { s_acc[wave][lane] = acc; s_cnt[wave][lane] = cnt; }
   __syncthreads();
@@ -673,23 +702,34 @@ __global__ __launch_bounds__(128) void k_lv_move_mid(LvG g, const LvCtl* __restr
     const uint32_t P = (uint32_t)((hi - lo + LV_MID_SLOTS / 2 - 1) / (LV_MID_SLOTS / 2));
     for (uint32_t p = 0; p < (P ? P : 1u); ++p) {
       int n_claimed = 0;
-      for (int64_t e = lo + lane; e - lane < hi; e += 64) {          // (every lane stays in the loop: the ballot below is the whole wave's)
-        bool own = false;
-        int slot = -1;
-        if (e < hi) {
-          const int32_t u = g.nbr[e];
-          if (u != v) {
-            const int32_t c = comm[A.base + u];
-            if (c == A.cv) { if (p == 0) stay += g.wt[e]; }
+      // four chunks of 64 entries a step: their neighbour ids, then their communities, are loaded together (a chunk at a time every step waited
+      // for two dependent round trips, three to eight times a row); every lane stays in the loop: the ballots below are the whole wave's
+      for (int64_t e = lo + lane; e - lane < hi; e += 256) {
+        int32_t uu[4] = {-1, -1, -1, -1}, cc[4] = {-1, -1, -1, -1};
+        u64 ww[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          if (e + 64 * h < hi) { uu[h] = g.nbr[e + 64 * h]; ww[h] = g.wt[e + 64 * h]; }
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+          if (uu[h] >= 0 && uu[h] != v) cc[h] = comm[A.base + uu[h]];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          if (e - lane + 64 * h >= hi) break;                          // uniform: the row ended with an earlier chunk
+          bool own = false;
+          int slot = -1;
+          const int32_t c = cc[h];
+          if (c >= 0) {
+            if (c == A.cv) { if (p == 0) stay += ww[h]; }
             else if (P <= 1 || (lv_hash((uint32_t)c) >> 13) % P == p) {
-              slot = lv_insert<LV_MID_SLOTS>(key, val, c, g.wt[e], &own);
+              slot = lv_insert<LV_MID_SLOTS>(key, val, c, ww[h], &own);
               if (slot < 0) atomicOr(status, GFICF_ST_TOO_DENSE);     // a hash class that overflows the table
             }
           }
+          const u64 m = __ballot(own);
+          if (own) claimed[n_claimed + __popcll(m & lt)] = (uint16_t)slot;
+          n_claimed += __popcll(m);
         }
-        const u64 m = __ballot(own);
-        if (own) claimed[n_claimed + __popcll(m & lt)] = (uint16_t)slot;
-        n_claimed += __popcll(m);
       }
       lv_wave_sync();
       for (int i = lane; i < n_claimed; i += 64) {
@@ -889,9 +929,24 @@ __global__ __launch_bounds__(1024) void k_lv_decide(LvCtl* ctl, LvParts pt, int 
     // element e of a slab = (row e / 16, component e % 16): thread t takes elements t, t + 1024, ... — always component t % 16, coalesced
     u64 a = 0;
     unsigned m = 0;
-    for (int e = tid; e < nb_small * LV_MAX_B; e += 1024) { a += pt.in_small[e]; if (it) m += pt.mv_small[pv][e]; }
-    for (int e = tid; e < nb_mid * LV_MAX_B; e += 1024) { a += pt.in_mid[e]; if (it) m += pt.mv_mid[pv][e]; }
-    for (int e = tid; e < nb_large * LV_MAX_B; e += 1024) { a += pt.in_large[e]; if (it) m += pt.mv_large[pv][e]; }
+    // (eight loads in flight per slab and thread: one load behind the other, the 0.5 MB of partial sums took 21 us of a 29-launch critical path)
+    auto slab = [&](const u64* __restrict__ in, const unsigned* __restrict__ mvp, int n) {
+      for (int e0 = tid; e0 < n; e0 += 8 * 1024) {
+        u64 av[8];
+        unsigned mv8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int e = e0 + j * 1024;
+          av[j] = e < n ? in[e] : 0ull;
+          mv8[j] = (it && e < n) ? mvp[e] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a += av[j]; m += mv8[j]; }
+      }
+    };
+    slab(pt.in_small, pt.mv_small[pv], nb_small * LV_MAX_B);
+    slab(pt.in_mid, pt.mv_mid[pv], nb_mid * LV_MAX_B);
+    slab(pt.in_large, pt.mv_large[pv], nb_large * LV_MAX_B);
     for (int d = 32; d >= LV_MAX_B; d >>= 1) { a += __shfl_xor(a, d); m += __shfl_xor(m, d); }      // lanes l, l + 16, l + 32, l + 48 hold component l % 16
     if (lane < LV_MAX_B) { s_in[wave][lane] = a; s_mv[wave][lane] = m; }
   }
