@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void k_adj_source_keys(const double* __restric
 // count of its (digit, workgroup) + the earlier waves' elements of that digit + the wave's own earlier ones + the lower lanes' in its round.
 constexpr int RS_TILE = 4096;
 constexpr int RS_MAX_BITS = 10;
-constexpr int RS_MAX_WGS = 1024;          // workgroups of a pass (each walks ceil(tiles / RS_MAX_WGS) tiles): bounds the count matrix
+constexpr int RS_MAX_WGS = 768;           // workgroups of a pass (each walks ceil(tiles / RS_MAX_WGS) tiles): bounds the count matrix, and is what is resident at
+                                          // once (52 KB of LDS a workgroup: three a CU) — a grid beyond that runs as one and a fraction rounds
 
 __device__ inline unsigned rs_digit(u64 el, int shift, unsigned mask) { return (unsigned)(el >> (32 + shift)) & mask; }
 
@@ -650,7 +651,7 @@ int gficf_adjacency_device(gficf_ctx* ctx, int64_t N, int64_t edge_capacity, con
   rc = gficf_exclusive_scan_i64(ctx, w.start, N + 1);
   if (rc) return rc;
   hipLaunchKernelGGL(k_adj_rows, dim3(gr), dim3(256), 0, st, in, N, (const int64_t*)w.start, w.bcol, w.bw, d_indptr);
-  hipLaunchKernelGGL(k_adj_rows_mid, dim3(4096), dim3(64), 0, st, in, (const int64_t*)w.start, (const int32_t*)w.mid, (const unsigned*)(w.flag + 2),
+  hipLaunchKernelGGL(k_adj_rows_mid, dim3(3328), dim3(64), 0, st, in, (const int64_t*)w.start, (const int32_t*)w.mid, (const unsigned*)(w.flag + 2),
                      w.bcol, w.bw, d_indptr);
   hipLaunchKernelGGL(k_adj_rows_big, dim3(1024), dim3(256), ADJ_WG_ROW * 16, st, in, (const int64_t*)w.start, (const int32_t*)w.big,
                      (const unsigned*)(w.flag + 3), w.bcol, w.bw, d_indptr, w.gk, w.gw);

@@ -83,7 +83,7 @@ constexpr int LV_MAX_SAVED = 12;              // levels whose vertex map is kept
 constexpr int LV_MAX_B = 16;                  // starts run together
 constexpr int LV_GRID = 1280;                 // persistent grid of the wave-per-vertex kernels (workgroups of 4 waves): what is RESIDENT at once on 256 CUs
                                               // (83 VGPRs and 29 KB of LDS a workgroup: five a CU) — 2048 ran as 1.6 rounds (8.1 -> 7.7 ms at config 3, 10 starts)
-constexpr int LV_GRID_BIG = 1024;             // ... of the workgroup-per-vertex kernels
+constexpr int LV_GRID_BIG = 1280;             // ... of the middle-degree (two waves, 28 KB of LDS: five a CU) and workgroup-per-vertex kernels
 constexpr int LV_SQ_BLOCKS = 64;              // slices of a component's communities in the fixed-order sum of squares
 constexpr int LV_ACC_BINS = 4096;
 
