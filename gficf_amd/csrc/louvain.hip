@@ -81,8 +81,9 @@ constexpr int LV_BIG_SLOTS = 8192;             // beyond: one workgroup per vert
 constexpr int LV_MAX_ITERS = 64;
 constexpr int LV_MAX_SAVED = 12;              // levels whose vertex map is kept for the refinement of algorithm 2
 constexpr int LV_MAX_B = 16;                  // starts run together
-constexpr int LV_GRID = 1280;                 // persistent grid of the wave-per-vertex kernels (workgroups of 4 waves): what is RESIDENT at once on 256 CUs
-                                              // (83 VGPRs and 29 KB of LDS a workgroup: five a CU) — 2048 ran as 1.6 rounds (8.1 -> 7.7 ms at config 3, 10 starts)
+constexpr int LV_GRID = 1536;                 // persistent grid of the wave-per-vertex kernels (workgroups of 4 waves): what is RESIDENT at once on 256 CUs
+                                              // (k_lv_move_small is held to 80 VGPRs: six workgroups a CU) — 2048 ran as 1.6 rounds of five a CU (8.1 -> 7.7 ms at
+                                              // config 3, 10 starts; six a CU: 7.35; eight spill: 8.5)
 constexpr int LV_GRID_BIG = 1280;             // ... of the middle-degree (two waves, 28 KB of LDS: five a CU) and workgroup-per-vertex kernels
 constexpr int LV_SQ_BLOCKS = 64;              // slices of a component's communities in the fixed-order sum of squares
 constexpr int LV_ACC_BINS = 4096;
@@ -477,7 +478,7 @@ __device__ static inline int lv_class(uint32_t x, int S) {
 // — 11.1 ms against 10.4 at the config-3 shape with ten starts: re-reading the rows per pair costs more than the misses; the copies
 // INTERLEAVED in the state arrays: more misses, not fewer; both entries probing in one wave-uniform loop instead of two per-lane loops: no change.
 template <bool FIRST>
-__global__ __launch_bounds__(256) void k_lv_move_small(LvG g, const LvCtl* __restrict__ ctl, LvMove mv, const int32_t* __restrict__ comm,
+__global__ __launch_bounds__(256, 6) void k_lv_move_small(LvG g, const LvCtl* __restrict__ ctl, LvMove mv, const int32_t* __restrict__ comm,
                                                        const u64* __restrict__ K, const int32_t* __restrict__ size, int32_t* __restrict__ next,
                                                        const int32_t* __restrict__ mark_r, int32_t* __restrict__ mark_w, u64* __restrict__ iw,
                                                        u64* __restrict__ part_in, unsigned* __restrict__ part_mv) {
